@@ -1,0 +1,317 @@
+"""Generate the golden fixtures in tests/golden/ by running the UNMODIFIED reference.
+
+TEST INFRASTRUCTURE ONLY.  Runs in the build container only (needs
+/root/reference); the GPU box consumes the committed .npz files.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+The reference needs ``termcolor`` (util.py:4), which is not installed: a 2-line
+shim lives in oracle/shim/.  Importing hamiltorch reseeds the global RNGs from the
+wall clock (util.py:23), so every case seeds *after* import.
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "shim"))
+sys.path.insert(0, os.environ.get("HAMILTORCH_REFERENCE", "/root/reference"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+import hamiltorch  # noqa: E402
+from hamiltorch import samplers as S  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(1)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+class Recorder:
+    """Records the reference's own random draws: gibbs() outputs (S:969) and the
+    MH uniforms torch.rand(1) (S:1004)."""
+
+    def __enter__(self):
+        self.momenta, self.uniforms = [], []
+        self._gibbs, self._rand = S.gibbs, torch.rand
+
+        def gibbs(*a, **k):
+            m = self._gibbs(*a, **k)
+            self.momenta.append(npy(m).copy())
+            return m
+
+        def rand(*a, **k):
+            u = self._rand(*a, **k)
+            if tuple(u.shape) == (1,):
+                self.uniforms.append(npy(u).copy())
+            return u
+
+        S.gibbs = gibbs
+        torch.rand = rand
+        return self
+
+    def __exit__(self, *exc):
+        S.gibbs = self._gibbs
+        torch.rand = self._rand
+
+
+SIGMA3 = [[1.0, 0.6, 0.2], [0.6, 2.0, 0.5], [0.2, 0.5, 0.5]]
+
+
+def mvn_logp(mean, cov):
+    def f(w):
+        return torch.distributions.MultivariateNormal(mean, cov).log_prob(w).sum()
+    return f
+
+
+def quad_logp(P):
+    def f(w):
+        return -0.5 * torch.dot(w, torch.mv(P, w))
+    return f
+
+
+def gen_hmc_kat():
+    out = {}
+    # KAT1: tests/test_util.py:97-110 set-up
+    lp = mvn_logp(torch.zeros(2), torch.diag(torch.tensor([0.1, 0.1])))
+    for steps in (1, 3, 100):
+        p, m = S.leapfrog(torch.tensor([1.0, 1.0]), torch.tensor([1.0, 1.0]), lp, steps=steps,
+                          step_size=0.1, inv_mass=torch.tensor([1.0, 1.0]),
+                          sampler=hamiltorch.Sampler.HMC, integrator=hamiltorch.Integrator.EXPLICIT)
+        out[f"kat1_theta_{steps}"] = npy(p[-1]); out[f"kat1_p_{steps}"] = npy(m[-1])
+    # reversibility (bit-exact in the reference)
+    p, m = S.leapfrog(torch.tensor([1.0, 1.0]), torch.tensor([1.0, 1.0]), lp, steps=100, step_size=0.1,
+                      inv_mass=torch.tensor([1.0, 1.0]), sampler=hamiltorch.Sampler.HMC,
+                      integrator=hamiltorch.Integrator.EXPLICIT)
+    p2, m2 = S.leapfrog(p[-1], -m[-1].clone(), lp, steps=100, step_size=0.1,
+                        inv_mass=torch.tensor([1.0, 1.0]), sampler=hamiltorch.Sampler.HMC,
+                        integrator=hamiltorch.Integrator.EXPLICIT)
+    out["kat1_reversed_theta"] = npy(p2[-1])
+    # KAT2: 3-D correlated Gaussian, fp32 and fp64, three mass kinds
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        cov = torch.tensor(SIGMA3, dtype=dt)
+        lp = mvn_logp(torch.zeros(3, dtype=dt), cov)
+        th = torch.tensor([0.3, -0.2, 0.5], dtype=dt)
+        pm = torch.tensor([0.1, 0.7, -0.4], dtype=dt)
+        out[f"kat2_logp_{tag}"] = npy(lp(th))
+        full = torch.tensor([[1.0, 0.2, 0.0], [0.2, 0.5, 0.1], [0.0, 0.1, 2.0]], dtype=dt)
+        masses = {"none": None, "diag": torch.tensor([1.0, 0.5, 2.0], dtype=dt), "full": full}
+        for mk, im in masses.items():
+            H = S.hamiltonian(th, pm, lp, inv_mass=im, sampler=hamiltorch.Sampler.HMC)
+            out[f"kat2_H_{mk}_{tag}"] = npy(H).reshape(-1)
+            p, m = S.leapfrog(th, pm, lp, steps=5, step_size=0.3, inv_mass=im,
+                              sampler=hamiltorch.Sampler.HMC, integrator=hamiltorch.Integrator.EXPLICIT)
+            out[f"kat2_theta_{mk}_{tag}"] = np.stack([npy(x) for x in p])
+            out[f"kat2_p_{mk}_{tag}"] = np.stack([npy(x) for x in m])
+        out[f"kat2_inv_mass_full_{tag}"] = npy(full)
+    out["sigma3"] = np.array(SIGMA3)
+    np.savez(os.path.join(OUT, "hmc_kat.npz"), **out)
+
+
+def gen_gibbs():
+    out = {}
+    D = 4
+    mass_d = torch.tensor([0.5, 1.0, 2.0, 4.0])
+    A = torch.tensor([[2.0, 0.3, 0.0, 0.1], [0.3, 1.0, 0.2, 0.0], [0.0, 0.2, 1.5, 0.4], [0.1, 0.0, 0.4, 3.0]])
+    th = torch.zeros(D)
+    for name, mass in (("none", None), ("diag", mass_d), ("full", A)):
+        torch.manual_seed(11)
+        z = torch.normal(torch.zeros(D), torch.ones(D))  # what Normal/MVN.sample consume
+        torch.manual_seed(11)
+        p = S.gibbs(th, sampler=hamiltorch.Sampler.HMC, mass=mass)
+        out[f"z_{name}"] = npy(z); out[f"p_{name}"] = npy(p)
+        if mass is not None:
+            out[f"mass_{name}"] = npy(mass)
+    # RMHMC gibbs: p ~ N(0, G(theta))
+    P = torch.tensor(np.linalg.inv(np.array(SIGMA3)), dtype=torch.float32)
+    lp = quad_logp(P)
+    th3 = torch.tensor([0.3, -0.2, 0.5])
+    torch.manual_seed(5)
+    z = torch.normal(torch.zeros(3), torch.ones(3))
+    torch.manual_seed(5)
+    p = S.gibbs(th3, sampler=hamiltorch.Sampler.RMHMC, log_prob_func=lp, jitter=None,
+                softabs_const=1e6, metric=hamiltorch.Metric.SOFTABS)
+    out["rm_z"] = npy(z); out["rm_p"] = npy(p); out["rm_P"] = npy(P)
+    np.savez(os.path.join(OUT, "gibbs.npz"), **out)
+
+
+def gen_sample_hmc():
+    """cfg1: end-to-end sample() with the draws recorded, several burn/mass settings."""
+    out = {}
+    cov = torch.tensor(SIGMA3)
+    lp = mvn_logp(torch.zeros(3), cov)
+    full = torch.tensor([[1.0, 0.2, 0.0], [0.2, 0.5, 0.1], [0.0, 0.1, 2.0]])
+    cases = {
+        "cfg1": dict(N=400, L=5, eps=0.3, burn=0, inv_mass=None, init=torch.zeros(3), seed=123),
+        "burn10": dict(N=60, L=5, eps=0.9, burn=10, inv_mass=None, init=torch.tensor([3.0, 3.0, 3.0]), seed=7),
+        "burnm1": dict(N=40, L=4, eps=0.9, burn=-1, inv_mass=None, init=torch.tensor([1.0, -1.0, 0.5]), seed=8),
+        "diag": dict(N=50, L=6, eps=0.4, burn=0, inv_mass=torch.tensor([1.0, 0.5, 2.0]), init=torch.zeros(3), seed=9),
+        "full": dict(N=50, L=6, eps=0.4, burn=3, inv_mass=full, init=torch.zeros(3), seed=10),
+    }
+    for name, c in cases.items():
+        hamiltorch.set_random_seed(c["seed"])
+        with Recorder() as rec:
+            ret, acc = hamiltorch.sample(lp, c["init"], num_samples=c["N"], num_steps_per_sample=c["L"],
+                                         step_size=c["eps"], burn=c["burn"], inv_mass=c["inv_mass"],
+                                         debug=2, verbose=False)
+        out[f"{name}_samples"] = np.stack([npy(t) for t in ret])
+        out[f"{name}_momenta"] = np.stack(rec.momenta)
+        out[f"{name}_uniforms"] = np.concatenate(rec.uniforms)
+        out[f"{name}_acc"] = np.array(acc)
+        out[f"{name}_cfg"] = np.array([c["N"], c["L"], c["eps"], c["burn"]], dtype=np.float64)
+        out[f"{name}_init"] = npy(c["init"])
+        if c["inv_mass"] is not None:
+            out[f"{name}_inv_mass"] = npy(c["inv_mass"])
+    out["sigma3"] = np.array(SIGMA3)
+    np.savez(os.path.join(OUT, "sample_hmc.npz"), **out)
+
+
+def rand_spd(D, seed, lo=0.5, hi=2.0):
+    g = torch.Generator().manual_seed(seed)
+    Q = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))[0]
+    lam = torch.linspace(lo, hi, D, dtype=torch.float64)
+    P = (Q * lam) @ Q.T
+    return 0.5 * (P + P.T)
+
+
+def gen_rmhmc():
+    out = {}
+    # KAT3/KAT4 at D=3 (both metrics), D=10 SPD, D=6 indefinite with finite softabs_const
+    P3 = torch.tensor(np.linalg.inv(np.array(SIGMA3)))
+    cases = {
+        "d3": dict(P=P3, alpha=1e6, omega=10.0, eps=0.1, steps=2),
+        "d10": dict(P=rand_spd(10, 0), alpha=1e6, omega=10.0, eps=0.1, steps=3),
+        "d6indef": dict(P=rand_spd(6, 1, -1.0, 2.0), alpha=1.5, omega=5.0, eps=0.05, steps=2),
+    }
+    for name, c in cases.items():
+        for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+            P = c["P"].to(dt)
+            D = P.shape[0]
+            lp = quad_logp(P)
+            g = torch.Generator().manual_seed(3)
+            th = (0.5 * torch.randn(D, generator=g, dtype=torch.float64)).to(dt)
+            pm = torch.randn(D, generator=g, dtype=torch.float64).to(dt)
+            out[f"{name}_P_{tag}"] = npy(P); out[f"{name}_theta0_{tag}"] = npy(th); out[f"{name}_p0_{tag}"] = npy(pm)
+            out[f"{name}_cfg"] = np.array([c["alpha"], c["omega"], c["eps"], c["steps"]])
+            for metric, mtag in ((hamiltorch.Metric.SOFTABS, "softabs"), (hamiltorch.Metric.HESSIAN, "hessian")):
+                if mtag == "hessian" and name == "d6indef":
+                    continue  # Cholesky of an indefinite G raises in the reference
+                G, lam = S.fisher(th, lp, jitter=None, softabs_const=c["alpha"], metric=metric)
+                out[f"{name}_G_{mtag}_{tag}"] = npy(G)
+                if lam is not None:
+                    out[f"{name}_lam_{mtag}_{tag}"] = npy(lam)
+                out[f"{name}_Ginvp_{mtag}_{tag}"] = npy(S.cholesky_inverse(G.detach(), pm)).reshape(-1)
+                H = S.rm_hamiltonian(th, pm, lp, None, 1.0, softabs_const=c["alpha"], metric=metric)
+                out[f"{name}_H_{mtag}_{tag}"] = npy(H).reshape(-1)
+                lpar, lmom = S.leapfrog(th, pm, lp, steps=c["steps"], step_size=c["eps"], jitter=None,
+                                        explicit_binding_const=c["omega"], softabs_const=c["alpha"],
+                                        sampler=hamiltorch.Sampler.RMHMC,
+                                        integrator=hamiltorch.Integrator.EXPLICIT, metric=metric)
+                out[f"{name}_lf_theta_{mtag}_{tag}"] = npy(lpar[0][-1]); out[f"{name}_lf_p_{mtag}_{tag}"] = npy(lmom[0][-1])
+                out[f"{name}_lf_thetac_{mtag}_{tag}"] = npy(lpar[1]); out[f"{name}_lf_pc_{mtag}_{tag}"] = npy(lmom[1])
+    # end-to-end explicit RMHMC sample(), jitter=None, draws recorded
+    P = P3.to(torch.float32)
+    lp = quad_logp(P)
+    hamiltorch.set_random_seed(21)
+    with Recorder() as rec:
+        ret, acc = hamiltorch.sample(lp, torch.tensor([0.3, -0.2, 0.5]), num_samples=12, num_steps_per_sample=3,
+                                     step_size=0.25, burn=2, jitter=None, softabs_const=1e6,
+                                     explicit_binding_const=10.0, sampler=hamiltorch.Sampler.RMHMC,
+                                     integrator=hamiltorch.Integrator.EXPLICIT,
+                                     metric=hamiltorch.Metric.SOFTABS, debug=2, verbose=False)
+    out["e2e_samples"] = np.stack([npy(t) for t in ret])
+    out["e2e_momenta"] = np.stack(rec.momenta)
+    out["e2e_uniforms"] = np.concatenate(rec.uniforms)
+    out["e2e_acc"] = np.array(acc)
+    out["e2e_P"] = npy(P)
+    np.savez(os.path.join(OUT, "rmhmc.npz"), **out)
+
+
+def make_mlp(dims, act, seed):
+    torch.manual_seed(seed)
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(nn.Linear(dims[i], dims[i + 1]))
+        if i < len(dims) - 2:
+            layers.append({"relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid}[act]())
+    return nn.Sequential(*layers)
+
+
+def gen_mlp():
+    out = {}
+    cases = {
+        "relu2": dict(dims=[3, 5, 1], act="relu", N=12, M=3, tau_out=10.0, eps=2e-3, L=2),
+        "tanh3": dict(dims=[2, 4, 3, 1], act="tanh", N=8, M=2, tau_out=4.0, eps=5e-3, L=3),
+    }
+    for name, c in cases.items():
+        net = make_mlp(c["dims"], c["act"], 0)
+        g = torch.Generator().manual_seed(1)
+        X = torch.randn(c["N"], c["dims"][0], generator=g)
+        Y = torch.sin(X.sum(1, keepdim=True)) + 0.1 * torch.randn(c["N"], 1, generator=g)
+        theta = hamiltorch.util.flatten(net).clone().detach()
+        D = theta.numel()
+        ntens = len(list(net.parameters()))
+        tau_list = torch.tensor([1.0 + 0.5 * k for k in range(ntens)])
+        pfl = [w.nelement() for w in net.parameters()]
+        psl = [w.shape for w in net.parameters()]
+        out[f"{name}_dims"] = np.array(c["dims"]); out[f"{name}_X"] = npy(X); out[f"{name}_Y"] = npy(Y)
+        out[f"{name}_theta"] = npy(theta); out[f"{name}_tau_list"] = npy(tau_list)
+        out[f"{name}_cfg"] = np.array([c["M"], c["tau_out"], c["eps"], c["L"]])
+        # full-data log prob + gradient (define_model_log_prob, S:1093-1201)
+        f = S.define_model_log_prob(net, "regression", X, Y, pfl, psl, tau_list, c["tau_out"])
+        th = theta.clone().requires_grad_()
+        v = f(th)
+        out[f"{name}_logp"] = npy(v).reshape(-1)
+        out[f"{name}_grad"] = npy(torch.autograd.grad(v.sum(), th)[0])
+        # split closures (S:1203-1258) and one SPLITTING leapfrog (S:494-547)
+        loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(X, Y),
+                                             batch_size=c["N"] // c["M"], shuffle=False)
+        fl = S.define_split_model_log_prob(net, "regression", loader, c["M"], pfl, psl, tau_list,
+                                           c["tau_out"], verbose=False)
+        out[f"{name}_split_logp"] = np.array([float(fm(theta).sum()) for fm in fl])
+        gm = torch.Generator().manual_seed(2)
+        p0 = torch.randn(D, generator=gm)
+        inv_mass = torch.ones(D)
+        H0 = S.hamiltonian(theta, p0, fl, inv_mass=inv_mass, sampler=hamiltorch.Sampler.HMC)
+        out[f"{name}_p0"] = npy(p0); out[f"{name}_H0"] = npy(H0).reshape(-1)
+        lp_, lm_ = S.leapfrog(theta.clone(), p0.clone(), fl, steps=c["L"], step_size=c["eps"],
+                              inv_mass=inv_mass, sampler=hamiltorch.Sampler.HMC,
+                              integrator=hamiltorch.Integrator.SPLITTING)
+        out[f"{name}_lf_theta"] = npy(lp_[-1]); out[f"{name}_lf_p"] = npy(lm_[-1])
+        # end-to-end sample_split_model with recorded draws
+        hamiltorch.set_random_seed(33)
+        with Recorder() as rec:
+            ret, acc = hamiltorch.sample_split_model(net, loader, theta.clone(), c["M"], model_loss="regression",
+                                                     num_samples=10, num_steps_per_sample=c["L"],
+                                                     step_size=c["eps"], burn=0, inv_mass=inv_mass,
+                                                     tau_out=c["tau_out"], tau_list=tau_list, debug=2,
+                                                     verbose=False)
+        out[f"{name}_e2e_samples"] = np.stack([npy(t) for t in ret])
+        out[f"{name}_e2e_momenta"] = np.stack(rec.momenta)
+        out[f"{name}_e2e_uniforms"] = np.concatenate(rec.uniforms)
+        out[f"{name}_e2e_acc"] = np.array(acc)
+        # sample_model (full data, plain HMC) end-to-end
+        hamiltorch.set_random_seed(34)
+        with Recorder() as rec:
+            ret, acc = hamiltorch.sample_model(net, X, Y, theta.clone(), model_loss="regression",
+                                               num_samples=8, num_steps_per_sample=c["L"], step_size=c["eps"],
+                                               tau_out=c["tau_out"], tau_list=tau_list, debug=2, verbose=False)
+        out[f"{name}_full_samples"] = np.stack([npy(t) for t in ret])
+        out[f"{name}_full_momenta"] = np.stack(rec.momenta)
+        out[f"{name}_full_uniforms"] = np.concatenate(rec.uniforms)
+    np.savez(os.path.join(OUT, "mlp.npz"), **out)
+
+
+if __name__ == "__main__":
+    gen_hmc_kat()
+    gen_gibbs()
+    gen_sample_hmc()
+    gen_rmhmc()
+    gen_mlp()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

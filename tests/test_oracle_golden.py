@@ -1,0 +1,173 @@
+"""Pins oracle/hmc_oracle.py to fixtures produced by the unmodified reference
+(oracle/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+import hmc_oracle as O
+
+
+def gauss3(dtype):
+    g = np.load  # noqa
+    sigma = np.array([[1.0, 0.6, 0.2], [0.6, 2.0, 0.5], [0.2, 0.5, 0.5]])
+    return O.GaussianTarget.from_cov(np.zeros(3), sigma, dtype=dtype)
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors for philox4x32-10
+    assert [int(v) for v in O.philox4x32(0, 0, 0, 0, 0, 0)] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    m = 0xFFFFFFFF
+    assert [int(v) for v in O.philox4x32(m, m, m, m, m, m)] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert [int(v) for v in O.philox4x32(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822, 0x299F31D0)] == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_philox_normal_moments():
+    z = O.philox_normals(99, np.arange(256), 3, 1024, dtype=np.float64)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+    assert abs(np.mean(z ** 4) - 3) < 0.05
+    u = O.philox_uniforms(99, np.arange(256), 3, 1024, dtype=np.float32)
+    assert u.min() > 0 and u.max() < 1 and abs(u.mean() - 0.5) < 0.01
+
+
+def test_kat1_leapfrog(golden):
+    g = golden("hmc_kat")
+    tgt = O.GaussianTarget.from_cov(np.zeros(2), np.diag([0.1, 0.1]), dtype=np.float32)
+    one = np.ones((1, 2), np.float32)
+    for steps in (1, 3, 100):
+        th, p = O.hmc_leapfrog(one, one, tgt.grad, steps, 0.1, np.ones(2, np.float32))
+        np.testing.assert_allclose(th[0], g[f"kat1_theta_{steps}"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(p[0], g[f"kat1_p_{steps}"], rtol=2e-5, atol=2e-5)
+    # reversibility, ported from tests/test_util.py:97-110 (tolerance instead of bit-equality)
+    th, p = O.hmc_leapfrog(one, one, tgt.grad, 100, 0.1, np.ones(2, np.float32))
+    th2, _ = O.hmc_leapfrog(th, -p, tgt.grad, 100, 0.1, np.ones(2, np.float32))
+    np.testing.assert_allclose(th2[0], [1.0, 1.0], atol=1e-4)
+    np.testing.assert_allclose(g["kat1_reversed_theta"], [1.0, 1.0], atol=0)
+
+
+@pytest.mark.parametrize("tag,dt,tol", [("f32", np.float32, 2e-5), ("f64", np.float64, 1e-12)])
+def test_kat2_hamiltonian_and_leapfrog(golden, tag, dt, tol):
+    g = golden("hmc_kat")
+    tgt = gauss3(dt)
+    th = np.array([[0.3, -0.2, 0.5]], dt); pm = np.array([[0.1, 0.7, -0.4]], dt)
+    np.testing.assert_allclose(tgt.logp(th)[0], g[f"kat2_logp_{tag}"], rtol=tol, atol=tol)
+    masses = {"none": None, "diag": np.array([1.0, 0.5, 2.0], dt), "full": g[f"kat2_inv_mass_full_{tag}"]}
+    for mk, im in masses.items():
+        H, _ = O.hmc_hamiltonian(th, pm, tgt.logp, im)
+        np.testing.assert_allclose(H, g[f"kat2_H_{mk}_{tag}"], rtol=tol, atol=tol)
+        pt, pp = O.hmc_leapfrog(th, pm, tgt.grad, 5, 0.3, im, return_path=True)
+        np.testing.assert_allclose(np.concatenate(pt), g[f"kat2_theta_{mk}_{tag}"], rtol=tol, atol=tol)
+        np.testing.assert_allclose(np.concatenate(pp), g[f"kat2_p_{mk}_{tag}"], rtol=tol, atol=tol)
+
+
+def test_gibbs(golden):
+    g = golden("gibbs")
+    np.testing.assert_allclose(O.gibbs_momentum(g["z_none"][None]), g["p_none"][None], atol=0)
+    np.testing.assert_allclose(O.gibbs_momentum(g["z_diag"][None], g["mass_diag"])[0], g["p_diag"], rtol=1e-6)
+    np.testing.assert_allclose(O.gibbs_momentum(g["z_full"][None], g["mass_full"])[0], g["p_full"], rtol=1e-5, atol=1e-6)
+    tgt = O.GaussianTarget(np.zeros(3, np.float32), g["rm_P"])
+    p = O.rm_gibbs(np.array([[0.3, -0.2, 0.5]], np.float32), g["rm_z"][None], tgt, 1e6)
+    np.testing.assert_allclose(p[0], g["rm_p"], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["cfg1", "burn10", "burnm1", "diag", "full"])
+def test_sample_hmc_end_to_end(golden, name):
+    """The reference's own sample() output (cfg1 and burn/mass variants), its recorded
+    draws replayed through the oracle: list length, Q2 quirk, accept decisions, values."""
+    g = golden("sample_hmc")
+    N, L, eps, burn = g[f"{name}_cfg"]
+    N, L, burn = int(N), int(L), int(burn)
+    im = g[f"{name}_inv_mass"] if f"{name}_inv_mass" in g.files else None
+    tgt = gauss3(np.float32)
+    draws = O.ReplayDraws(g[f"{name}_momenta"], g[f"{name}_uniforms"])
+    ret, info = O.sample_hmc(tgt, g[f"{name}_init"][None].astype(np.float32), N, L, eps, burn, im, draws)
+    ref = g[f"{name}_samples"]
+    assert len(ret) == ref.shape[0] == N - burn
+    got = np.concatenate(ret)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+    assert abs(info["acc_rate"][0] - float(g[f"{name}_acc"])) < 1e-9
+
+
+def test_q2_quirk_present_in_reference_fixture(golden):
+    """burn10 case: first post-burn rejection resets the chain to params_init."""
+    g = golden("sample_hmc")
+    s = g["burn10_samples"]
+    assert np.all(s[0] == g["burn10_init"])
+
+
+@pytest.mark.parametrize("name", ["d3", "d10", "d6indef"])
+@pytest.mark.parametrize("tag,dt,tol", [("f32", np.float32, 3e-4), ("f64", np.float64, 1e-9)])
+def test_rmhmc_metric_hamiltonian_leapfrog(golden, name, tag, dt, tol):
+    g = golden("rmhmc")
+    alpha, omega, eps, steps = g[f"{name}_cfg"]
+    P = g[f"{name}_P_{tag}"]
+    tgt = O.GaussianTarget(np.zeros(P.shape[0], dt), P)
+    th = g[f"{name}_theta0_{tag}"][None]; pm = g[f"{name}_p0_{tag}"][None]
+    for mtag in ("softabs", "hessian"):
+        if f"{name}_G_{mtag}_{tag}" not in g.files:
+            continue
+        G, lam, _ = O.softabs_metric(tgt.neg_hessian(th), alpha, metric=mtag)
+        np.testing.assert_allclose(G[0], g[f"{name}_G_{mtag}_{tag}"], rtol=tol, atol=tol)
+        if lam is not None:
+            np.testing.assert_allclose(np.sort(lam[0]), np.sort(g[f"{name}_lam_{mtag}_{tag}"]), rtol=tol, atol=tol)
+        x, _ = O.cholesky_inverse(G, pm)
+        np.testing.assert_allclose(x[0], g[f"{name}_Ginvp_{mtag}_{tag}"], rtol=10 * tol, atol=10 * tol)
+        H, _ = O.rm_hamiltonian(th, pm, tgt, alpha, metric=mtag)
+        np.testing.assert_allclose(H, g[f"{name}_H_{mtag}_{tag}"], rtol=tol, atol=tol)
+        a, b, c, d = O.explicit_rmhmc_leapfrog(th, pm, tgt, int(steps), eps, omega, alpha, metric=mtag)
+        np.testing.assert_allclose(a[0], g[f"{name}_lf_theta_{mtag}_{tag}"], rtol=10 * tol, atol=10 * tol)
+        np.testing.assert_allclose(b[0], g[f"{name}_lf_p_{mtag}_{tag}"], rtol=10 * tol, atol=10 * tol)
+        np.testing.assert_allclose(c[0], g[f"{name}_lf_thetac_{mtag}_{tag}"], rtol=10 * tol, atol=10 * tol)
+        np.testing.assert_allclose(d[0], g[f"{name}_lf_pc_{mtag}_{tag}"], rtol=10 * tol, atol=10 * tol)
+
+
+def test_rmhmc_sample_end_to_end(golden):
+    g = golden("rmhmc")
+    tgt = O.GaussianTarget(np.zeros(3, np.float32), g["e2e_P"])
+    draws = O.ReplayDraws(g["e2e_momenta"], g["e2e_uniforms"])
+    ret, info = O.sample_rmhmc_explicit(tgt, np.array([[0.3, -0.2, 0.5]], np.float32), 12, 3, 0.25, 10.0, 1e6,
+                                        burn=2, draws=draws)
+    ref = g["e2e_samples"]
+    assert len(ret) == ref.shape[0]
+    np.testing.assert_allclose(np.concatenate(ret), ref, rtol=2e-4, atol=2e-4)
+    assert abs(info["acc_rate"][0] - float(g["e2e_acc"])) < 1e-9
+
+
+def _mlp_target(g, name, lo=None, hi=None, prior_scale=1.0):
+    M, tau_out, eps, L = g[f"{name}_cfg"]
+    act = "relu" if name.startswith("relu") else "tanh"
+    X, Y = g[f"{name}_X"], g[f"{name}_Y"]
+    if lo is not None:
+        X, Y = X[lo:hi], Y[lo:hi]
+    return O.MLPRegressionTarget(list(g[f"{name}_dims"]), X, Y, g[f"{name}_tau_list"], tau_out, prior_scale, act)
+
+
+@pytest.mark.parametrize("name", ["relu2", "tanh3"])
+def test_mlp_logp_grad_split_leapfrog(golden, name):
+    g = golden("mlp")
+    M, tau_out, eps, L = g[f"{name}_cfg"]
+    M, L = int(M), int(L)
+    theta = g[f"{name}_theta"][None].astype(np.float32)
+    full = _mlp_target(g, name)
+    lp, gr = full.logp_and_grad(theta)
+    np.testing.assert_allclose(lp, g[f"{name}_logp"], rtol=2e-5, atol=1e-4)
+    np.testing.assert_allclose(gr[0], g[f"{name}_grad"], rtol=2e-4, atol=2e-4)
+    N = g[f"{name}_X"].shape[0]; nb = N // M
+    splits = [_mlp_target(g, name, m * nb, (m + 1) * nb, prior_scale=M) for m in range(M)]
+    np.testing.assert_allclose([s.logp(theta)[0] for s in splits], g[f"{name}_split_logp"], rtol=2e-5, atol=1e-4)
+    p0 = g[f"{name}_p0"][None].astype(np.float32)
+    im = np.ones(theta.shape[1], np.float32)
+    H0, _ = O.hmc_hamiltonian(theta, p0, [s.logp for s in splits], im)
+    np.testing.assert_allclose(H0, g[f"{name}_H0"], rtol=2e-5)
+    th, pm = O.split_leapfrog(theta, p0, [s.grad for s in splits], L, eps, im)
+    np.testing.assert_allclose(th[0], g[f"{name}_lf_theta"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(pm[0], g[f"{name}_lf_p"], rtol=1e-3, atol=1e-3)
+    # end-to-end sample_split_model
+    draws = O.ReplayDraws(g[f"{name}_e2e_momenta"], g[f"{name}_e2e_uniforms"])
+    ret, info = O.sample_hmc(None, theta, 10, L, eps, 0, im, draws,
+                             grad_fns=[s.grad for s in splits], logp_fns=[s.logp for s in splits])
+    np.testing.assert_allclose(np.concatenate(ret), g[f"{name}_e2e_samples"], rtol=1e-3, atol=1e-4)
+    assert abs(info["acc_rate"][0] - float(g[f"{name}_e2e_acc"])) < 1e-9
+    # sample_model (full-data HMC, inv_mass None)
+    draws = O.ReplayDraws(g[f"{name}_full_momenta"], g[f"{name}_full_uniforms"])
+    ret, _ = O.sample_hmc(full, theta, 8, L, eps, 0, None, draws)
+    np.testing.assert_allclose(np.concatenate(ret), g[f"{name}_full_samples"], rtol=1e-3, atol=1e-4)
