@@ -1,0 +1,191 @@
+"""ctypes binding of libhamiltorch_amd.so (the C ABI declared in include/hamiltorch_amd.h).
+
+The library is the product: there is no CPU or torch fallback for the kernels it exports.
+If it is missing, or asked to run on a non-ROCm tensor, the calls below raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhamiltorch_amd.so")
+ABI_VERSION = 1
+
+MASS_NONE, MASS_DIAG, MASS_FULL = 0, 1, 2
+
+_lib = None
+_lock = threading.Lock()
+
+c_i64, c_int, c_u64, c_u32, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p
+c_f32, c_f64 = ctypes.c_float, ctypes.c_double
+
+
+class HtaDeviceInfo(ctypes.Structure):
+    _fields_ = [("abi_version", c_int), ("device", c_int), ("compute_units", c_int), ("wavefront_size", c_int),
+                ("lds_bytes_per_cu", c_int), ("clock_khz", c_int), ("hbm_bytes", c_i64), ("arch", ctypes.c_char * 64)]
+
+
+def _sig(scalar):
+    """argtypes of the dtype-suffixed entry points (scalar = c_float | c_double)."""
+    return {
+        "hta_momentum_resample": [c_vp, c_int, c_vp, c_i64, c_int, c_u64, c_u64, c_u32, c_vp],
+        "hta_kick_drift": [c_vp, c_vp, c_vp, scalar, scalar, c_int, c_vp, c_i64, c_int, c_vp],
+        "hta_hamiltonian": [c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_vp],
+        "hta_mh_select": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_u64,
+                          c_u64, c_vp],
+        "hta_hmc_gaussian_sample": [c_vp, c_vp, c_vp, c_vp, scalar, c_int, c_vp, c_vp, c_i64, c_int, c_int, scalar,
+                                    c_int, c_int, c_int, c_u64, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+        "hta_hmc_gaussian_leapfrog": [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_int, c_int, scalar, c_vp, c_vp,
+                                      c_vp],
+    }
+
+
+#: every symbol include/hamiltorch_amd.h declares (checked by tests/test_abi_symbols.py)
+PLAIN_SYMBOLS = ["hta_abi_version", "hta_last_error", "hta_device_info", "hta_set_tuning"]
+TYPED_SYMBOLS = sorted(_sig(c_f32).keys())
+
+
+def load():
+    """Load (once) and type the shared library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "hamiltorch_amd: %s is missing -- build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C hamiltorch_amd/csrc). "
+                "There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.hta_abi_version.restype = c_int
+        lib.hta_last_error.restype = ctypes.c_char_p
+        lib.hta_device_info.argtypes = [c_int, ctypes.POINTER(HtaDeviceInfo)]
+        lib.hta_set_tuning.argtypes = [ctypes.c_char_p, c_int]
+        for suf, scalar in (("f32", c_f32), ("f64", c_f64)):
+            for name, args in _sig(scalar).items():
+                fn = getattr(lib, "%s_%s" % (name, suf))
+                fn.argtypes = args
+                fn.restype = c_int
+        if lib.hta_abi_version() != ABI_VERSION:
+            raise RuntimeError("hamiltorch_amd: ABI mismatch (library %d, binding %d) -- rebuild"
+                               % (lib.hta_abi_version(), ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    return load().hta_last_error().decode("utf-8", "replace")
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("hamiltorch_amd: %s failed (%d): %s" % (what, rc, last_error()))
+
+
+def _suffix(t: torch.Tensor) -> str:
+    if t.dtype == torch.float32:
+        return "f32"
+    if t.dtype == torch.float64:
+        return "f64"
+    raise TypeError("hamiltorch_amd kernels compute in float32 or float64, got %s" % t.dtype)
+
+
+def require_device(t: torch.Tensor, what="tensor"):
+    """The kernels only exist for gfx950; anything else is an error, never a silent fallback."""
+    if not t.is_cuda:
+        raise RuntimeError(
+            "hamiltorch_amd: %s lives on '%s'; this engine runs on an AMD Instinct GPU only "
+            "(move params_init and the tensors your log_prob_func closes over to 'cuda'). "
+            "There is no CPU fallback." % (what, t.device))
+
+
+def _p(t, like=None):
+    """device pointer of a contiguous tensor (or NULL)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("hamiltorch_amd: non-contiguous tensor passed to the C ABI")
+    if like is not None and (t.dtype != like.dtype or t.device != like.device):
+        raise ValueError("hamiltorch_amd: dtype/device mismatch between kernel operands (%s/%s vs %s/%s)"
+                         % (t.dtype, t.device, like.dtype, like.device))
+    return c_vp(t.data_ptr())
+
+
+def _stream(t):
+    return c_vp(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def device_info(device=0) -> dict:
+    info = HtaDeviceInfo()
+    _check(load().hta_device_info(int(device), ctypes.byref(info)), "hta_device_info")
+    return {k: (getattr(info, k).decode() if k == "arch" else getattr(info, k)) for k, _ in HtaDeviceInfo._fields_}
+
+
+def set_tuning(key: str, value: int):
+    _check(load().hta_set_tuning(key.encode(), int(value)), "hta_set_tuning")
+
+
+# ---- thin typed wrappers ------------------------------------------------------------------------
+def momentum_resample(p, mass_kind, mass_factor, seed, chain_offset, draw):
+    require_device(p, "momentum")
+    C, D = p.shape
+    fn = getattr(load(), "hta_momentum_resample_" + _suffix(p))
+    with torch.cuda.device(p.device):
+        _check(fn(_p(p), mass_kind, _p(mass_factor, p), C, D, seed, chain_offset, draw & 0xFFFFFFFF, _stream(p)),
+               "hta_momentum_resample")
+
+
+def kick_drift(theta, p, grad, kick, drift, mass_kind, inv_mass):
+    require_device(theta, "params")
+    C, D = theta.shape
+    fn = getattr(load(), "hta_kick_drift_" + _suffix(theta))
+    with torch.cuda.device(theta.device):
+        _check(fn(_p(theta), _p(p, theta), _p(grad, theta), float(kick), float(drift), mass_kind,
+                  _p(inv_mass, theta), C, D, _stream(theta)), "hta_kick_drift")
+
+
+def hamiltonian(p, logp, mass_kind, inv_mass, out):
+    require_device(p, "momentum")
+    C, D = p.shape
+    fn = getattr(load(), "hta_hamiltonian_" + _suffix(p))
+    with torch.cuda.device(p.device):
+        _check(fn(_p(p), _p(logp, p), mass_kind, _p(inv_mass, p), _p(out, p), C, D, _stream(p)), "hta_hamiltonian")
+
+
+def mh_select(cur, prop, init, H_old, H_new, logp_new, row, reject_count, accept, n, burn, seed, chain_offset):
+    require_device(cur, "params")
+    C, D = cur.shape
+    fn = getattr(load(), "hta_mh_select_" + _suffix(cur))
+    with torch.cuda.device(cur.device):
+        _check(fn(_p(cur), _p(prop, cur), _p(init, cur), _p(H_old, cur), _p(H_new, cur), _p(logp_new, cur),
+                  _p(row, cur), _p(reject_count), _p(accept), C, D, int(n), int(burn), seed, chain_offset,
+                  _stream(cur)), "hta_mh_select")
+
+
+def hmc_gaussian_sample(theta, theta_init, P, mu, log_norm, mass_kind, inv_mass, mass_factor, L, eps, n_traj,
+                        traj_offset, burn, seed, chain_offset, samples, reject_count, H_old=None, H_new=None,
+                        accept=None):
+    require_device(theta, "params")
+    C, D = theta.shape
+    fn = getattr(load(), "hta_hmc_gaussian_sample_" + _suffix(theta))
+    with torch.cuda.device(theta.device):
+        _check(fn(_p(theta), _p(theta_init, theta), _p(P, theta), _p(mu, theta), float(log_norm), mass_kind,
+                  _p(inv_mass, theta), _p(mass_factor, theta), C, D, int(L), float(eps), int(n_traj),
+                  int(traj_offset), int(burn), seed, chain_offset, _p(samples, theta), _p(reject_count),
+                  _p(H_old, theta), _p(H_new, theta), _p(accept), _stream(theta)), "hta_hmc_gaussian_sample")
+
+
+def hmc_gaussian_leapfrog(theta, p, P, mu, mass_kind, inv_mass, steps, eps, path_theta=None, path_p=None):
+    require_device(theta, "params")
+    C, D = theta.shape
+    fn = getattr(load(), "hta_hmc_gaussian_leapfrog_" + _suffix(theta))
+    with torch.cuda.device(theta.device):
+        _check(fn(_p(theta), _p(p, theta), _p(P, theta), _p(mu, theta), mass_kind, _p(inv_mass, theta), C, D,
+                  int(steps), float(eps), _p(path_theta, theta), _p(path_p, theta), _stream(theta)),
+               "hta_hmc_gaussian_leapfrog")

@@ -1,0 +1,207 @@
+"""Bayesian-neural-network front-ends: mirror of samplers.py:1093-1562 (``define_model_log_prob``,
+``define_split_model_log_prob``, ``sample_model``, ``sample_split_model``, ``predict_model``).
+
+The closures built here are ordinary ``log_prob_func`` callables (prior S:1141-1157 +
+likelihood S:1170-1190), evaluated with ``torch.func.functional_call`` so they batch over
+chains under ``vmap``.  For an MLP with a regression likelihood they also carry a structural
+description (``_hta_spec``) that lets ``sample`` run the whole split-HMC trajectory in the
+native kernel (csrc/mlp_split.hip) instead of calling back into torch.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import util  # noqa: F401
+from .enums import Integrator, Metric, Sampler
+
+_ACTS = {nn.ReLU: "relu", nn.Tanh: "tanh", nn.Sigmoid: "sigmoid"}
+
+
+def _mlp_structure(model):
+    """[in, h1, ..., out] and the activation name if ``model`` is Sequential(Linear, act, Linear, ...)
+    with one activation kind; else None."""
+    if not isinstance(model, nn.Sequential):
+        return None
+    mods = list(model.children())
+    dims, act = [], None
+    expect_linear = True
+    for m in mods:
+        if expect_linear:
+            if not isinstance(m, nn.Linear) or m.bias is None:
+                return None
+            if dims and dims[-1] != m.in_features:
+                return None
+            if not dims:
+                dims.append(m.in_features)
+            dims.append(m.out_features)
+            expect_linear = False
+        else:
+            a = _ACTS.get(type(m))
+            if a is None or (act is not None and a != act):
+                return None
+            act = a
+            expect_linear = True
+    if expect_linear or len(dims) < 2:
+        return None
+    return dims, (act or "relu")
+
+
+def define_model_log_prob(model, model_loss, x, y, params_flattened_list, params_shape_list, tau_list, tau_out,
+                          normalizing_const=1., predict=False, prior_scale=1.0, device='cpu'):
+    """S:1093-1201.  Returns ``log_prob_func(flat_params)``."""
+    names = [n for n, _ in model.named_parameters()]
+    buffers = {n: b for n, b in model.named_buffers()}
+    taus = [torch.as_tensor(t, dtype=torch.get_default_dtype()) for t in tau_list]
+    x_dev = None if x is None else x.to(device)
+    y_dev = None if y is None else y.to(device)
+    sizes = list(params_flattened_list)
+    shapes = list(params_shape_list)
+
+    def log_prob_func(params):
+        i_prev = 0
+        l_prior = torch.zeros_like(params[0])
+        tensors = {}
+        for name, n, shape, tau in zip(names, sizes, shapes, taus):
+            w = params[i_prev:i_prev + n]
+            tau = tau.to(params)
+            # Normal(0, tau^-1/2).log_prob(w).sum()   (S:1143, S:1156)
+            l_prior = l_prior + (-0.5 * tau * (w * w) + 0.5 * torch.log(tau) - 0.9189385332046727).sum()
+            tensors[name] = w.reshape(shape)
+            i_prev += n
+        if x_dev is None:
+            return l_prior / prior_scale                                         # S:1160-1162
+        tensors.update(buffers)
+        output = torch.func.functional_call(model, tensors, (x_dev,))
+        if model_loss == 'binary_class_linear_output':
+            ll = -tau_out * nn.functional.binary_cross_entropy_with_logits(output, y_dev, reduction='sum')
+        elif model_loss == 'multi_class_linear_output':
+            ll = -tau_out * nn.functional.cross_entropy(output, y_dev.long().view(-1), reduction='sum')
+        elif model_loss == 'multi_class_log_softmax_output':
+            ll = -tau_out * nn.functional.nll_loss(output, y_dev.long().view(-1))   # S:1180 (mean reduction)
+        elif model_loss == 'regression':
+            ll = -0.5 * tau_out * ((output - y_dev) ** 2).sum(0)                  # S:1184, shape (O,)
+        elif callable(model_loss):
+            ll = -model_loss(output, y_dev).sum(0)                                # S:1188
+        else:
+            raise NotImplementedError()                                           # S:1190
+        if predict:
+            return (ll + l_prior / prior_scale), output
+        return ll + l_prior / prior_scale
+
+    st = _mlp_structure(model)
+    if st is not None and model_loss == 'regression' and x is not None and not predict \
+            and x.dim() == 2 and st[0][-1] == 1:
+        log_prob_func._hta_spec = dict(dims=st[0], act=st[1], X=x_dev, Y=y_dev.reshape(x_dev.shape[0], -1),
+                                       tau_list=[float(t) for t in taus], tau_out=float(tau_out),
+                                       prior_scale=float(prior_scale))
+    return log_prob_func
+
+
+def define_split_model_log_prob(model, model_loss, train_loader, num_splits, params_flattened_list,
+                                params_shape_list, tau_list, tau_out, normalizing_const=1., predict=False,
+                                device='cpu', verbose=True):
+    """S:1203-1258: one closure per DataLoader batch, prior divided by ``num_splits``."""
+    fns = []
+    for batch_idx, (data, target) in enumerate(train_loader):
+        if batch_idx > num_splits - 1:
+            break
+        fns.append(define_model_log_prob(model, model_loss, data.clone(), target.clone(), params_flattened_list,
+                                         params_shape_list, tau_list, tau_out, normalizing_const=normalizing_const,
+                                         prior_scale=num_splits, predict=predict, device=device))
+    if verbose:
+        print('Number of splits: ', len(fns), ' , each of batch size ', train_loader.batch_size, '\n')
+    return fns
+
+
+def _shapes_and_tau(model, tau_list):
+    shapes, sizes = [], []
+    build = tau_list is None
+    if build:
+        tau_list = []
+    for w in model.parameters():
+        shapes.append(w.shape)
+        sizes.append(w.nelement())
+        if build:
+            tau_list.append(torch.tensor(1.))                                     # S:1354-1355
+    return shapes, sizes, tau_list
+
+
+def sample_model(model, x, y, params_init, model_loss='multi_class_linear_output', num_samples=10,
+                 num_steps_per_sample=10, step_size=0.1, burn=0, inv_mass=None, jitter=None, normalizing_const=1.,
+                 softabs_const=None, explicit_binding_const=100, fixed_point_threshold=1e-5,
+                 fixed_point_max_iterations=1000, jitter_max_tries=10, sampler=Sampler.HMC, integrator=Integrator.IMPLICIT,
+                 metric=Metric.HESSIAN, debug=False, tau_out=1., tau_list=None, store_on_GPU=True, desired_accept_rate=0.8, verbose=True,
+                 **ext):
+    """S:1261-1362."""
+    from . import samplers as S
+    shapes, sizes, tau_list = _shapes_and_tau(model, tau_list)
+    f = define_model_log_prob(model, model_loss, x, y, sizes, shapes, tau_list, tau_out,
+                              normalizing_const=normalizing_const, device=params_init.device)
+    return S.sample(f, params_init, num_samples=num_samples, num_steps_per_sample=num_steps_per_sample,
+                    step_size=step_size, burn=burn, jitter=jitter, inv_mass=inv_mass,
+                    normalizing_const=normalizing_const, softabs_const=softabs_const,
+                    explicit_binding_const=explicit_binding_const, fixed_point_threshold=fixed_point_threshold,
+                    fixed_point_max_iterations=fixed_point_max_iterations, jitter_max_tries=jitter_max_tries,
+                    sampler=sampler, integrator=integrator, metric=metric, debug=debug,
+                    desired_accept_rate=desired_accept_rate, store_on_GPU=store_on_GPU, verbose=verbose, **ext)
+
+
+def sample_split_model(model, train_loader, params_init, num_splits, model_loss='multi_class_linear_output',
+                       num_samples=10, num_steps_per_sample=10, step_size=0.1, burn=0, inv_mass=None, jitter=None,
+                       normalizing_const=1., softabs_const=None, explicit_binding_const=100,
+                       fixed_point_threshold=1e-5, fixed_point_max_iterations=1000, jitter_max_tries=10,
+                       sampler=Sampler.HMC, integrator=Integrator.SPLITTING, metric=Metric.HESSIAN, debug=False,
+                       tau_out=1., tau_list=None, store_on_GPU=True, desired_accept_rate=0.8, verbose=True, **ext):
+    """S:1364-1466."""
+    from . import samplers as S
+    shapes, sizes, tau_list = _shapes_and_tau(model, tau_list)
+    fl = define_split_model_log_prob(model, model_loss, train_loader, num_splits, sizes, shapes, tau_list, tau_out,
+                                     normalizing_const=1., predict=False, device=params_init.device, verbose=verbose)
+    return S.sample(fl, params_init, num_samples=num_samples, num_steps_per_sample=num_steps_per_sample,
+                    step_size=step_size, burn=burn, jitter=jitter, inv_mass=inv_mass,
+                    normalizing_const=normalizing_const, softabs_const=softabs_const,
+                    explicit_binding_const=explicit_binding_const, fixed_point_threshold=fixed_point_threshold,
+                    fixed_point_max_iterations=fixed_point_max_iterations, jitter_max_tries=jitter_max_tries,
+                    sampler=sampler, integrator=integrator, metric=metric, debug=debug,
+                    desired_accept_rate=desired_accept_rate, store_on_GPU=store_on_GPU, verbose=verbose, **ext)
+
+
+def predict_model(model, samples, x=None, y=None, test_loader=None, model_loss='multi_class_linear_output',
+                  tau_out=1., tau_list=None, verbose=False):
+    """S:1468-1562: evaluate every sample; returns (stack(pred)[S, N, O], list of log-probs)."""
+    if x is None and test_loader is None:
+        raise RuntimeError('predict_model needs (x, y) or a test_loader')          # S:1557
+    shapes, sizes, tau_list = _shapes_and_tau(model, tau_list)
+    dev = samples[0].device
+    batches = [(x, y)] if test_loader is None else list(test_loader)
+    preds, lps = [], []
+    with torch.no_grad():
+        for s in samples:
+            outs, lp = [], 0
+            for xb, yb in batches:
+                f = define_model_log_prob(model, model_loss, xb, yb, sizes, shapes, tau_list, tau_out,
+                                          predict=True, device=dev)
+                v, o = f(s.to(dev))
+                outs.append(o)
+                lp = lp + v
+            preds.append(torch.cat(outs, 0))
+            lps.append(lp)
+    return torch.stack(preds), lps
+
+
+# ---- native engines (filled in by mlp.py once the kernel library exports them) -------------------
+def native_split_engine(log_prob_list, theta0):
+    try:
+        from . import mlp
+    except ImportError:
+        return None
+    return mlp.split_engine(log_prob_list, theta0)
+
+
+def native_hmc_engine(log_prob_func, theta0):
+    try:
+        from . import mlp
+    except ImportError:
+        return None
+    return mlp.hmc_engine(log_prob_func, theta0)

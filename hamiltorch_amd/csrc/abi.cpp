@@ -1,0 +1,47 @@
+// libhamiltorch_amd.so: ABI version, error channel, device query, tuning knobs.
+#include <stdarg.h>
+#include "common.hpp"
+
+namespace hta {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int g_small_chains_per_block = 0;  // 0 = default (64)
+int g_force_general = 0;
+}  // namespace hta
+
+extern "C" {
+
+int hta_abi_version(void) { return HTA_ABI_VERSION; }
+const char* hta_last_error(void) { return hta::g_err; }
+
+int hta_device_info(int device, HtaDeviceInfo* out) {
+  if (!out) { hta::set_error("hta_device_info: out is NULL"); return HTA_ERR_INVALID; }
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) { hta::set_error("hipGetDeviceProperties: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
+  memset(out, 0, sizeof(*out));
+  out->abi_version = HTA_ABI_VERSION;
+  out->device = device;
+  out->compute_units = prop.multiProcessorCount;
+  out->wavefront_size = prop.warpSize;
+  out->lds_bytes_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+  out->clock_khz = prop.clockRate;
+  out->hbm_bytes = (int64_t)prop.totalGlobalMem;
+  strncpy(out->arch, prop.gcnArchName, sizeof(out->arch) - 1);
+  return HTA_OK;
+}
+
+int hta_set_tuning(const char* key, int value) {
+  if (!key) return HTA_ERR_INVALID;
+  if (!strcmp(key, "small_chains_per_block")) { hta::g_small_chains_per_block = value; return HTA_OK; }
+  if (!strcmp(key, "force_general")) { hta::g_force_general = value; return HTA_OK; }
+  hta::set_error("hta_set_tuning: unknown key %s", key);
+  return HTA_ERR_INVALID;
+}
+
+}  // extern "C"

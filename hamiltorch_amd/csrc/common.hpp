@@ -1,0 +1,52 @@
+// Shared host/device helpers for libhamiltorch_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/hamiltorch_amd.h"
+
+namespace hta {
+
+void set_error(const char* fmt, ...);
+
+#define HTA_REQUIRE(cond, ...)                  \
+  do {                                          \
+    if (!(cond)) {                              \
+      ::hta::set_error(__VA_ARGS__);            \
+      return HTA_ERR_INVALID;                   \
+    }                                           \
+  } while (0)
+
+#define HTA_CHECK_LAUNCH(name)                                                        \
+  do {                                                                                \
+    hipError_t e__ = hipGetLastError();                                               \
+    if (e__ != hipSuccess) {                                                          \
+      ::hta::set_error("%s: launch failed: %s", name, hipGetErrorString(e__));        \
+      return HTA_ERR_LAUNCH;                                                          \
+    }                                                                                 \
+  } while (0)
+
+// ---- wave64 reductions (DPP via __shfl_xor butterflies) --------------------------------
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over aligned groups of G lanes (G power of two <= 64); every lane of a group gets the total
+template <int G, typename T> __device__ __forceinline__ T group_sum(T v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T> __device__ __forceinline__ bool finite_(T v) { return isfinite(v); }
+
+// accept rule of samplers.py:626 + 1000-1004: rho = min(0, H0 - H1); accept iff rho >= log(u);
+// a non-finite proposed energy or log-prob is a rejection (LogProbError path, samplers.py:1045-1057).
+template <typename T> __device__ __forceinline__ bool mh_accept(T h_old, T h_new, T logp_new, T u) {
+  const T rho = fmin((T)0, h_old - h_new);
+  return finite_(h_old) && finite_(h_new) && finite_(logp_new) && (rho >= log(u));
+}
+
+}  // namespace hta

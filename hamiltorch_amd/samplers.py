@@ -1,0 +1,461 @@
+"""Host mirror of ``hamiltorch/samplers.py`` (reference lines cited as S:n) for the sampling path.
+
+Same names, keyword arguments, return shapes and error behaviour as the reference; the
+arithmetic runs in libhamiltorch_amd.so (HIP, gfx950) for many chains at once:
+
+* ``params_init`` of shape (D,)  -> reference behaviour, one chain, list of (D,) tensors;
+* ``params_init`` of shape (C,D) -> C independent chains batched on-device, list of (C,D) tensors.
+
+Two execution paths behind ``sample``:
+  native   -- the log-prob is a recognised model family (``models.GaussianTarget`` or an MLP
+              built by ``sample_model``/``sample_split_model``): whole trajectories run inside
+              one persistent kernel;
+  generic  -- any other ``log_prob_func`` (the callback contract of S:272-274): torch evaluates
+              the callback for all chains (``torch.func.vmap``), HIP kernels do the momentum
+              draw, kick/drift, energy reduction and the Metropolis select in between.
+There is no CPU path: tensors must live on an AMD GPU.
+"""
+from __future__ import annotations
+
+import threading
+import warnings
+import torch
+import torch.nn as nn
+
+from . import _abi, util
+from .enums import Integrator, Metric, Sampler
+from .models import GaussianTarget, as_gaussian
+
+_sample_lock = threading.RLock()  # multi_chain(parallel=True) calls sample() from threads (U:396-398)
+
+
+_SPLIT_KINDS = (Integrator.SPLITTING, Integrator.SPLITTING_RAND, Integrator.SPLITTING_KMID)
+
+
+# =================================================================================================
+# helpers
+# =================================================================================================
+def _as_batch(params, what="params"):
+    """(C,D) contiguous copy of a (D,) or (C,D) tensor + whether it was 1-D."""
+    if params.dim() == 1:
+        return params.detach().clone().reshape(1, -1).contiguous(), True
+    if params.dim() == 2:
+        return params.detach().clone().contiguous(), False
+    raise RuntimeError("%s must be a 1d tensor (one chain) or a 2d [chains, D] tensor." % what)
+
+
+def _mass_operands(inv_mass, like):
+    """inv_mass None | (D,) | (D,D) | list of blocks -> (kind, inv_mass, mass_factor) on the device.
+
+    Inverts the mass matrix once, as S:942-952, and factors it for the momentum draw
+    (S:199-201): diag -> sqrt(1/inv_mass); full -> chol(inverse(inv_mass))."""
+    if inv_mass is None:
+        return _abi.MASS_NONE, None, None
+    if isinstance(inv_mass, list):  # block-diagonal list (S:287-292, S:803-809, S:944-947)
+        inv_mass = torch.block_diag(*inv_mass)
+    im = inv_mass.detach().to(device=like.device, dtype=like.dtype).contiguous()
+    D = like.shape[-1]
+    if im.dim() == 1:
+        if im.numel() != D:
+            raise RuntimeError("inv_mass has %d entries, params have %d" % (im.numel(), D))
+        return _abi.MASS_DIAG, im, torch.sqrt(1.0 / im).contiguous()
+    if im.dim() == 2:
+        if tuple(im.shape) != (D, D):
+            raise RuntimeError("inv_mass must be (D,), (D,D) or a list of blocks")
+        mass = torch.inverse(im)
+        return _abi.MASS_FULL, im, torch.linalg.cholesky(mass).contiguous()
+    raise RuntimeError("inv_mass must be (D,), (D,D) or a list of blocks")
+
+
+def _num_rows(num_samples, burn):
+    """len(ret_params): params_init plus one row per n in range(num_samples) with n > burn."""
+    return 1 + num_samples - max(0, min(num_samples, burn + 1))
+
+
+def _scalar(v):
+    return v.sum() if torch.is_tensor(v) else v
+
+
+class _BatchedCallback:
+    """Evaluates a reference-style ``log_prob_func`` (one (D,) vector in, scalar out) for all
+    chains.  ``torch.func.vmap`` when the callback allows it, otherwise a per-chain loop."""
+
+    def __init__(self, fn, pass_grad=None):
+        self.fn = fn
+        self.pass_grad = pass_grad
+        self._use_vmap = True
+        f = lambda w: _scalar(fn(w))  # noqa: E731
+        self._v_logp = torch.func.vmap(f)
+        self._v_gv = torch.func.vmap(torch.func.grad_and_value(f))
+        self._v_pg = torch.func.vmap(pass_grad) if callable(pass_grad) else None
+
+    def _loop(self, theta, want_grad):
+        lps, gs = [], []
+        for c in range(theta.shape[0]):
+            p = theta[c].detach().requires_grad_(want_grad)
+            lp = self.fn(p)
+            if want_grad:
+                p = collect_gradients(lp, p, self.pass_grad)
+                gs.append(p.grad.detach())
+                lp = lp[0] if isinstance(lp, tuple) else lp
+            lps.append(_scalar(lp).detach())
+        return (torch.stack(gs) if want_grad else None), torch.stack(lps)
+
+    def logp(self, theta):
+        if self._use_vmap:
+            try:
+                with torch.no_grad():
+                    return self._v_logp(theta).contiguous()
+            except Exception as e:  # data-dependent control flow, .item(), tuple protocol, ...
+                self._fallback(e)
+        return self._loop(theta, False)[1].contiguous()
+
+    def grad(self, theta):
+        """(grad[C,D], logp[C]) at theta."""
+        if self.pass_grad is not None and not callable(self.pass_grad):
+            g = self.pass_grad.to(theta).expand_as(theta).contiguous()
+            return g, self.logp(theta)
+        if self._use_vmap:
+            try:
+                if self._v_pg is not None:
+                    return self._v_pg(theta).contiguous(), self.logp(theta)
+                g, v = self._v_gv(theta)
+                return g.contiguous(), v.contiguous()
+            except Exception as e:
+                self._fallback(e)
+        g, v = self._loop(theta, True)
+        return g.contiguous(), v.contiguous()
+
+    def _fallback(self, e):
+        self._use_vmap = False
+        warnings.warn("hamiltorch_amd: log_prob_func is not vmap-able (%s: %s); evaluating it chain by chain"
+                      % (type(e).__name__, str(e).split("\n")[0][:120]))
+
+
+# =================================================================================================
+# reference API: small pieces
+# =================================================================================================
+def collect_gradients(log_prob, params, pass_grad=None):
+    """S:33-66: attach ``.grad`` to params via the tuple protocol, ``pass_grad`` or autograd."""
+    if isinstance(log_prob, tuple):
+        log_prob[0].backward()
+        plist = list(log_prob[1])
+        params = torch.cat([p.flatten() for p in plist])
+        params.grad = torch.cat([p.grad.flatten() for p in plist])
+    elif pass_grad is not None:
+        params.grad = pass_grad(params) if callable(pass_grad) else pass_grad
+    else:
+        params.grad = torch.autograd.grad(log_prob, params)[0]
+    return params
+
+
+def acceptance(h_old, h_new):
+    """S:609-626."""
+    return float(-h_new + h_old)
+
+
+def gibbs(params, sampler=Sampler.HMC, log_prob_func=None, jitter=None, normalizing_const=1., softabs_const=None,
+          mass=None, metric=Metric.HESSIAN, seed=None, chain_offset=0, draw=0):
+    """Momentum resampling (S:152-202) on-device.  ``mass`` is None | (D,) | (D,D) | list of blocks.
+    Draws come from the Philox stream (seed, chain, draw) instead of torch's global generator."""
+    theta, one = _as_batch(params)
+    _abi.require_device(theta, "params")
+    seed = util.next_stream_seed() if seed is None else int(seed)
+    if sampler == Sampler.RMHMC:
+        from . import rmhmc
+        p = rmhmc.gibbs(theta, log_prob_func, jitter, softabs_const, metric, seed, chain_offset, draw)
+        return p[0] if one else p
+    if isinstance(mass, list):
+        mass = torch.block_diag(*mass)
+    if mass is None:
+        kind, mf = _abi.MASS_NONE, None
+    elif mass.dim() == 1:
+        kind, mf = _abi.MASS_DIAG, torch.sqrt(mass.to(theta)).contiguous()   # S:201
+    else:
+        kind, mf = _abi.MASS_FULL, torch.linalg.cholesky(mass.to(theta)).contiguous()   # S:199
+    p = torch.empty_like(theta)
+    _abi.momentum_resample(p, kind, mf, seed, chain_offset, draw)
+    return p[0] if one else p
+
+
+def hamiltonian(params, momentum, log_prob_func, jitter=0.01, normalizing_const=1., softabs_const=1e6,
+                explicit_binding_const=100, inv_mass=None, ham_func=None, sampler=Sampler.HMC,
+                integrator=Integrator.EXPLICIT, metric=Metric.HESSIAN):
+    """S:738-846.  HMC: -log p + 0.5 p^T M^-1 p (list of callables = split sum under no_grad).
+    Returns a 0-d tensor for one chain, (C,) for a batch."""
+    if sampler == Sampler.HMC:
+        theta, one = _as_batch(params)
+        p, _ = _as_batch(momentum, "momentum")
+        _abi.require_device(theta, "params")
+        fns = log_prob_func if isinstance(log_prob_func, list) else [log_prob_func]
+        logp = None
+        for f in fns:
+            v = _BatchedCallback(f).logp(theta)
+            logp = v if logp is None else logp + v
+        kind, im, _ = _mass_operands(inv_mass, theta)
+        H = torch.empty(theta.shape[0], dtype=theta.dtype, device=theta.device)
+        _abi.hamiltonian(p, logp.to(theta.dtype).contiguous(), kind, im, H)
+        if one and util.has_nan_or_inf(logp):
+            raise util.LogProbError()   # S:783-785
+        return H[0] if one else H
+    if sampler == Sampler.RMHMC and integrator in (Integrator.IMPLICIT, Integrator.EXPLICIT):
+        h = rm_hamiltonian(params, momentum, log_prob_func, jitter, normalizing_const, softabs_const=softabs_const,
+                           sampler=sampler, integrator=integrator, metric=metric)
+        if integrator == Integrator.EXPLICIT and not isinstance(params, list):
+            return 2 * h    # S:822 (first call of the explicit sampler works with the doubled energy)
+        return h
+    raise NotImplementedError()
+
+
+def rm_hamiltonian(params, momentum, log_prob_func, jitter, normalizing_const, softabs_const=1e6,
+                   sampler=Sampler.HMC, integrator=Integrator.EXPLICIT, metric=Metric.HESSIAN):
+    """S:677-736: -log p + D/2 log 2pi + 1/2 log|G| + 1/2 p^T G^-1 p, shape (1,1) for one chain."""
+    from . import rmhmc
+    return rmhmc.rm_hamiltonian(params, momentum, log_prob_func, jitter, softabs_const, metric)
+
+
+def fisher(params, log_prob_func=None, jitter=None, normalizing_const=1., softabs_const=1e6, metric=Metric.HESSIAN):
+    """S:69-127: metric G(theta) and (for SOFTABS) the soft-absolute eigenvalues."""
+    from . import rmhmc
+    return rmhmc.fisher(params, log_prob_func, jitter, softabs_const, metric)
+
+
+def cholesky_inverse(fish, momentum):
+    """S:130-149: G^-1 p by Cholesky + two triangular solves; returns (D,1) for one system."""
+    from . import rmhmc
+    return rmhmc.cholesky_inverse(fish, momentum)
+
+
+# =================================================================================================
+# leapfrog (S:205-606)
+# =================================================================================================
+def leapfrog(params, momentum, log_prob_func, steps=10, step_size=0.1, jitter=0.01, normalizing_const=1.,
+             softabs_const=1e6, explicit_binding_const=100, fixed_point_threshold=1e-20,
+             fixed_point_max_iterations=6, jitter_max_tries=10, inv_mass=None, ham_func=None, sampler=Sampler.HMC,
+             integrator=Integrator.IMPLICIT, metric=Metric.HESSIAN, store_on_GPU=True, debug=False, pass_grad=None):
+    """Same contract as the reference: returns (ret_params, ret_momenta), lists with one entry
+    per step (explicit RMHMC: ``[list, params_copy], [list, momentum_copy]``, S:462)."""
+    theta, one = _as_batch(params)
+    p, _ = _as_batch(momentum, "momentum")
+    _abi.require_device(theta, "params")
+    unb = (lambda t: t[0]) if one else (lambda t: t)
+
+    if sampler == Sampler.HMC and integrator not in _SPLIT_KINDS:
+        kind, im, _ = _mass_operands(inv_mass, theta)
+        tgt = as_gaussian(log_prob_func, theta) if pass_grad is None else None
+        if tgt is not None:
+            pt = torch.empty((steps,) + theta.shape, dtype=theta.dtype, device=theta.device)
+            pp = torch.empty_like(pt)
+            _abi.hmc_gaussian_leapfrog(theta, p, tgt.precision, tgt.mean, kind, im, steps, step_size, pt, pp)
+            return [unb(t) for t in pt.unbind(0)], [unb(t) for t in pp.unbind(0)]
+        cb = _BatchedCallback(log_prob_func, pass_grad)
+        ret_t, ret_p = [], []
+        g, _ = cb.grad(theta)
+        _abi.kick_drift(theta, p, g, 0.5 * step_size, step_size if steps > 0 else 0.0, kind, im)   # S:281 + first S:284
+        for n in range(steps):
+            g, _ = cb.grad(theta)                                                                  # S:297
+            ret_t.append(unb(theta.clone()))
+            last = n == steps - 1
+            _abi.kick_drift(theta, p, g, step_size, 0.0, kind, im)                                 # S:298
+            ret_p.append(unb(p.clone()))
+            if last:
+                _abi.kick_drift(theta, p, g, -0.5 * step_size, 0.0, kind, im)                      # S:302
+                ret_p[-1] = unb(p.clone())
+            else:
+                _abi.kick_drift(theta, p, None, 0.0, step_size, kind, im)                          # next S:284
+        return ret_t, ret_p
+
+    if sampler == Sampler.HMC and integrator in _SPLIT_KINDS:
+        if type(log_prob_func) is not list:
+            raise RuntimeError('For splitting log_prob_func must be list of functions')      # S:466-467
+        if pass_grad is not None:
+            raise RuntimeError('Passing user-determined gradients not implemented for splitting')  # S:468-469
+        if integrator != Integrator.SPLITTING:
+            raise NotImplementedError("SPLITTING_RAND / SPLITTING_KMID are outside the accelerated path")
+        cbs = [_BatchedCallback(f) for f in log_prob_func]
+        kind, im, _ = _mass_operands(inv_mass, theta)
+        ret_t, ret_p = [], []
+        for _ in range(steps):
+            _split_step(theta, p, cbs, step_size, kind, im)
+            ret_t.append(unb(theta.clone())); ret_p.append(unb(p.clone()))
+        return ret_t, ret_p
+
+    if sampler == Sampler.RMHMC and integrator == Integrator.EXPLICIT:
+        if pass_grad is not None:
+            raise RuntimeError('Passing user-determined gradients not implemented for RMHMC')  # S:390-391
+        from . import rmhmc
+        return rmhmc.explicit_leapfrog(params, momentum, log_prob_func, steps, step_size, jitter, softabs_const,
+                                       explicit_binding_const, metric)
+    raise NotImplementedError("implicit RMHMC / S3 integrators are outside the accelerated path")
+
+
+def _split_step(theta, p, cbs, eps, kind, im):
+    """One symmetric split step (S:499-540): 2M half-kicks, 2(M-1) drifts of eps / (2(M-1))."""
+    M = len(cbs)
+    if M == 1:
+        raise RuntimeError('For symmetric splitting log_prob_func must be list of functions greater than length 1')
+    dq = eps / ((M - 1) * 2)
+    for m in range(M):
+        g, _ = cbs[m].grad(theta)
+        _abi.kick_drift(theta, p, g, 0.5 * eps, dq if m < M - 1 else 0.0, kind, im)
+    for m in reversed(range(M)):
+        g, _ = cbs[m].grad(theta)
+        _abi.kick_drift(theta, p, g, 0.5 * eps, dq if m > 0 else 0.0, kind, im)
+
+
+# =================================================================================================
+# sample (S:850-1091)
+# =================================================================================================
+def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, step_size=0.1, burn=0, jitter=None,
+           inv_mass=None, normalizing_const=1., softabs_const=None, explicit_binding_const=100,
+           fixed_point_threshold=1e-5, fixed_point_max_iterations=1000, jitter_max_tries=10, sampler=Sampler.HMC,
+           integrator=Integrator.IMPLICIT, metric=Metric.HESSIAN, debug=False, desired_accept_rate=0.8,
+           store_on_GPU=True, pass_grad=None, verbose=True, *, seed=None, chain_offset=0, native=True):
+    """Drop-in for ``hamiltorch.sample``.  Extensions (keyword-only): ``seed`` (Philox key; default
+    derives from ``set_random_seed``), ``chain_offset`` (global id of the first chain, for sharding
+    chains across GPUs), ``native=False`` forces the generic-callback path.
+
+    Returns the reference's list (length ``num_samples - burn``, element 0 = ``params_init``) of
+    (D,) tensors, or of (C,D) tensors when ``params_init`` is (C,D); with ``debug == 2`` also the
+    acceptance rate (float, or a (C,) tensor for a batch)."""
+    if params_init.dim() not in (1, 2):
+        raise RuntimeError('params_init must be a 1d tensor.')                 # S:925-926 (2-D = batch of chains)
+    if burn >= num_samples:
+        raise RuntimeError('burn must be less than num_samples.')               # S:928-929
+    nuts = False
+    if sampler == Sampler.HMC_NUTS:
+        if burn == 0:
+            raise RuntimeError('burn must be greater than 0 for NUTS.')         # S:933-934
+        raise NotImplementedError("step-size dual averaging (Sampler.HMC_NUTS) is not in the accelerated path yet")
+    _abi.require_device(params_init, "params_init")
+    _abi.load()
+    theta0, one = _as_batch(params_init, "params_init")
+    seed = util.next_stream_seed() if seed is None else int(seed)
+    burn_k = max(int(burn), -1)
+
+    with _sample_lock:
+        if sampler == Sampler.HMC:
+            if integrator in _SPLIT_KINDS:
+                if type(log_prob_func) is not list:
+                    raise RuntimeError('For splitting log_prob_func must be list of functions')
+                if pass_grad is not None:
+                    raise RuntimeError('Passing user-determined gradients not implemented for splitting')
+                if integrator != Integrator.SPLITTING:
+                    raise NotImplementedError("SPLITTING_RAND / SPLITTING_KMID are outside the accelerated path")
+                if isinstance(inv_mass, list):
+                    raise NotImplementedError("block-list inv_mass performs no drift in the reference's split "
+                                              "integrator (S:514-515); not supported")
+                eng = _resolve_split_engine(log_prob_func, theta0, native)
+            else:
+                tgt = as_gaussian(log_prob_func, theta0) if (native and pass_grad is None) else None
+                eng = _GaussianHMC(tgt) if tgt is not None else _GenericHMC(log_prob_func, pass_grad)
+            samples, rejected = eng.run(theta0, num_samples, num_steps_per_sample, step_size, burn_k, inv_mass,
+                                        seed, chain_offset, verbose, '({}; {})'.format(sampler, integrator))
+        elif sampler == Sampler.RMHMC and integrator == Integrator.EXPLICIT:
+            if pass_grad is not None:
+                raise RuntimeError('Passing user-determined gradients not implemented for RMHMC')
+            from . import rmhmc
+            samples, rejected = rmhmc.sample_explicit(log_prob_func, theta0, num_samples, num_steps_per_sample,
+                                                      step_size, burn_k, jitter, softabs_const,
+                                                      explicit_binding_const, metric, seed, chain_offset, verbose)
+        elif sampler == Sampler.RMHMC:
+            raise NotImplementedError("implicit RMHMC / S3 are outside the accelerated path (fixed-point "
+                                      "iteration counts diverge per chain)")
+        else:
+            raise NotImplementedError()
+
+    if not store_on_GPU:
+        samples = samples.cpu()                                                 # S:1012 / S:1024
+    rows = [row[0] for row in samples.unbind(0)] if one else list(samples.unbind(0))
+    acc = 1.0 - rejected.to(torch.float64) / float(num_samples)                # S:1085 / S:1089 (burn-in included)
+    if verbose:
+        print('Acceptance Rate {:.2f}'.format(float(acc.mean())))
+    if debug == 2:
+        return rows, (float(acc[0]) if one else acc)
+    return rows
+
+
+class _GaussianHMC:
+    """Native path: one persistent-kernel launch runs every trajectory (csrc/hmc_gaussian.hip)."""
+
+    def __init__(self, target: GaussianTarget):
+        self.t = target
+
+    def run(self, theta0, N, L, eps, burn, inv_mass, seed, chain_offset, verbose, label):
+        C, D = theta0.shape
+        kind, im, mf = _mass_operands(inv_mass, theta0)
+        S = _num_rows(N, burn)
+        samples = torch.empty((S, C, D), dtype=theta0.dtype, device=theta0.device)
+        samples[0].copy_(theta0)
+        cur = theta0.clone()
+        rejected = torch.zeros(C, dtype=torch.int32, device=theta0.device)
+        prog = util._Progress('Sampling ' + label, N, verbose)
+        _abi.hmc_gaussian_sample(cur, theta0, self.t.precision, self.t.mean, self.t.log_norm, kind, im, mf, L, eps,
+                                 N, 0, burn, seed, chain_offset, samples, rejected)
+        prog.end()
+        return samples, rejected
+
+
+class _GenericHMC:
+    """Generic-callback path (plain HMC, S:267-304) -- also the SPLITTING integrator when given a
+    list of callbacks (S:494-547)."""
+
+    def __init__(self, fn, pass_grad=None, split=False):
+        self.split = split
+        self.cbs = [_BatchedCallback(f) for f in fn] if split else [_BatchedCallback(fn, pass_grad)]
+
+    def _logp(self, theta):
+        out = None
+        for cb in self.cbs:           # split: sum over the subsets (S:787-796)
+            v = cb.logp(theta)
+            out = v if out is None else out + v
+        return out.to(theta.dtype).contiguous()
+
+    def run(self, theta0, N, L, eps, burn, inv_mass, seed, chain_offset, verbose, label):
+        C, D = theta0.shape
+        dev, dt = theta0.device, theta0.dtype
+        kind, im, mf = _mass_operands(inv_mass, theta0)
+        S = _num_rows(N, burn)
+        samples = torch.empty((S, C, D), dtype=dt, device=dev)
+        samples[0].copy_(theta0)
+        cur, prop, p = theta0.clone(), torch.empty_like(theta0), torch.empty_like(theta0)
+        H_old, H_new = torch.empty(C, dtype=dt, device=dev), torch.empty(C, dtype=dt, device=dev)
+        rejected = torch.zeros(C, dtype=torch.int32, device=dev)
+        prog = util._Progress('Sampling ' + label, N, verbose)
+        cb = self.cbs[0]
+        for n in range(N):
+            prog.update(n)
+            _abi.momentum_resample(p, kind, mf, seed, chain_offset, n)                     # S:969
+            _abi.hamiltonian(p, self._logp(cur), kind, im, H_old)                          # S:971
+            prop.copy_(cur)
+            if self.split:
+                for _ in range(L):
+                    _split_step(prop, p, self.cbs, eps, kind, im)                          # S:499-540
+                logp1 = self._logp(prop)
+            else:
+                g, logp1 = cb.grad(prop)
+                _abi.kick_drift(prop, p, g, 0.5 * eps, eps if L > 0 else 0.0, kind, im)    # S:281, S:284
+                for l in range(L):
+                    g, logp1 = cb.grad(prop)                                               # S:297
+                    _abi.kick_drift(prop, p, g, eps, 0.0 if l == L - 1 else eps, kind, im)  # S:298 (+ next drift)
+                _abi.kick_drift(prop, p, g, -0.5 * eps, 0.0, kind, im)                     # S:302
+                logp1 = logp1.to(dt).contiguous()   # log-prob at the end point, from the last gradient call
+            _abi.hamiltonian(p, logp1, kind, im, H_new)                                    # S:995
+            row = samples[n - burn] if n > burn else None
+            _abi.mh_select(cur, prop, theta0, H_old, H_new, logp1, row, rejected, None, n, burn, seed,
+                           chain_offset)                                                   # S:1000-1026
+        prog.end()
+        return samples, rejected
+
+
+def _resolve_split_engine(log_prob_list, theta0, native):
+    from . import bnn
+    eng = bnn.native_split_engine(log_prob_list, theta0) if native else None
+    return eng if eng is not None else _GenericHMC(log_prob_list, split=True)
+
+
+# =================================================================================================
+# BNN front-ends (S:1093-1466) live in bnn.py; re-exported here under the reference's names
+# =================================================================================================
+from .bnn import (define_model_log_prob, define_split_model_log_prob, predict_model,  # noqa: E402
+                  sample_model, sample_split_model)

@@ -1,0 +1,148 @@
+"""Host-side utilities mirroring ``hamiltorch/util.py`` (reference lines cited as U:n).
+
+Only what the sampling path needs is here: seeding (U:11-23), the NaN/Inf guard and
+``LogProbError`` (U:92-104), the flat parameter layout helpers (U:121-141) and the
+multi-chain adapters (U:385-405).  Seeding also keys the device-side Philox streams.
+"""
+from __future__ import annotations
+
+import concurrent.futures
+import random
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+_random_seed = 0
+_call_counter = 0
+_seed_lock = threading.Lock()
+
+
+def set_random_seed(seed=None):
+    """Seed python / numpy / torch (as U:11-20) and the Philox key used by the HIP kernels."""
+    global _random_seed, _call_counter
+    if seed is None:
+        seed = int((time.time() * 1e6) % 1e8)
+    with _seed_lock:
+        _random_seed = int(seed)
+        _call_counter = 0
+    random.seed(seed)
+    np.random.seed(int(seed) % (2 ** 32))
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+
+
+set_random_seed()  # the reference seeds from the clock at import time (U:23)
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
+def next_stream_seed():
+    """64-bit Philox key for the next ``sample`` call: a hash of (seed, number of calls since
+    the seed was set), the counterpart of successive calls consuming one global generator."""
+    global _call_counter
+    with _seed_lock:
+        k = _splitmix64((_random_seed & 0xFFFFFFFFFFFFFFFF) ^ _splitmix64(_call_counter))
+        _call_counter += 1
+    return k
+
+
+# ---- progress reporting (U:33-89 prints a live bar; the fused kernels have no per-sample host
+# ---- loop, so this is a start/finish line with the same closing message) ---------------------
+class _Progress:
+    def __init__(self, message, num_iters, enabled):
+        self.enabled, self.n, self.t0 = enabled, num_iters, time.time()
+        if enabled:
+            print(message)
+            sys.stdout.flush()
+
+    def update(self, i):
+        if self.enabled and self.n and (i == self.n - 1 or (i & 63) == 0):
+            dt = max(time.time() - self.t0, 1e-9)
+            print("%6d/%d | %.2f Samples/sec      " % (i + 1, self.n, (i + 1) / dt), end="\r")
+
+    def end(self, message=None):
+        if self.enabled:
+            dt = max(time.time() - self.t0, 1e-9)
+            print("%d/%d | %.2f Samples/sec" % (self.n, self.n, self.n / dt))
+            if message is not None:
+                print(message)
+
+
+def has_nan_or_inf(value):
+    """U:92-100: tensors are summed first, so inf + (-inf) also trips."""
+    if torch.is_tensor(value):
+        v = torch.sum(value)
+        return bool(torch.isnan(v)) or bool(torch.isinf(v))
+    v = float(value)
+    return v != v or v in (float("inf"), float("-inf"))
+
+
+class LogProbError(Exception):
+    pass
+
+
+def flatten(model):
+    """U:121-122: parameters() order, each flattened."""
+    return torch.cat([p.flatten() for p in model.parameters()])
+
+
+def unflatten(model, flattened_params):
+    """U:125-136."""
+    if flattened_params.dim() != 1:
+        raise ValueError("Expecting a 1d flattened_params")
+    out, i = [], 0
+    for val in model.parameters():
+        n = val.nelement()
+        out.append(flattened_params[i:i + n].view_as(val))
+        i += n
+    return out
+
+
+def update_model_params_in_place(model, params):
+    """U:139-141."""
+    for weights, new_w in zip(model.parameters(), params):
+        weights.data = new_w
+
+
+# ---- many chains (U:385-405).  The reference runs one sample() per seed, serially or in a
+# ---- thread pool; here the same adapters exist, plus the on-device batched form. -------------
+def setup_chain(sampler, prior, kwargs):
+    def chain(seed):
+        set_random_seed(seed)          # torch.manual_seed(seed) in the reference (U:387)
+        params_init = prior()
+        return sampler(params_init=params_init, **kwargs)
+    chain._hta = (sampler, prior, kwargs)
+    return chain
+
+
+def multi_chain(chain, num_workers, seeds, parallel=False, batched=False):
+    """``batched=True`` (extension): draw every chain's ``params_init`` from ``prior`` under its
+    own seed, stack them to [C, D] and run ONE on-device batched ``sample`` call; the result has
+    the reference's shape (list over chains of lists of (D,) samples)."""
+    if batched:
+        sampler, prior, kwargs = chain._hta
+        inits = []
+        for s in seeds:
+            torch.manual_seed(s)
+            inits.append(prior())
+        set_random_seed(seeds[0])
+        out = sampler(params_init=torch.stack(inits), **kwargs)
+        extra = None
+        if isinstance(out, tuple):
+            out, extra = out
+        per_chain = [[row[c] for row in out] for c in range(len(seeds))]
+        return per_chain if extra is None else (per_chain, extra)
+    if parallel:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=num_workers) as ex:
+            return list(ex.map(chain, seeds))
+    return [chain(s) for s in seeds]

@@ -1,0 +1,145 @@
+/* libhamiltorch_amd.so -- C ABI of the MI355X (gfx950) HMC / RMHMC sampling engine.
+ *
+ * This is the drop-in boundary for the per-trajectory hot path of
+ * AdamCobb/hamiltorch 0.4.1 (`hamiltorch/samplers.py`, below `S:`; `hamiltorch/util.py`, `U:`).
+ * The reference has no FFI -- its boundary is the Python function `hamiltorch.sample` (S:850) --
+ * so these are the entry points a ctypes binding of that function calls
+ * (`hamiltorch_amd/_abi.py`; INTEGRATION.md shows the reference-side stub).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (torch tensors kept alive by Python);
+ *  - chain-major dense state: theta[C, D], p[C, D], row stride D, no padding;
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t); it never synchronises, never
+ *    allocates persistent memory and never throws.  Return 0 on success, <0 on error
+ *    (`hta_last_error()` gives a thread-local message);
+ *  - `_f32` / `_f64` select the arithmetic type (the reference computes in the dtype of
+ *    `params_init`; float32 by default);
+ *  - random numbers: Philox4x32-10 keyed by (seed, chain_offset + local chain index,
+ *    trajectory index n), see csrc/philox.hpp.  `chain_offset` is the global id of this
+ *    buffer's first chain, so sharding chains over GPUs does not change any chain's stream.
+ */
+#ifndef HAMILTORCH_AMD_H
+#define HAMILTORCH_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HTA_ABI_VERSION 1
+
+#define HTA_OK 0
+#define HTA_ERR_INVALID (-1)   /* bad argument                           */
+#define HTA_ERR_LAUNCH (-2)    /* hipLaunch / runtime error              */
+#define HTA_ERR_UNSUPPORTED (-3)
+
+/* mass-matrix kinds: how `inv_mass` (S:283-296, S:800-814) and the momentum factor
+ * (S:185-201) are stored */
+#define HTA_MASS_NONE 0 /* identity; pointers ignored                                          */
+#define HTA_MASS_DIAG 1 /* inv_mass[D]; mass_factor[D]   = sqrt(1/inv_mass)   (S:201, S:952)   */
+#define HTA_MASS_FULL 2 /* inv_mass[D,D]; mass_factor[D,D] = chol(inverse(inv_mass)), lower,
+                           row-major (S:199 via MultivariateNormal.rsample, S:950)             */
+
+typedef struct HtaDeviceInfo {
+  int abi_version;
+  int device;
+  int compute_units;
+  int wavefront_size;
+  int lds_bytes_per_cu;
+  int clock_khz;
+  int64_t hbm_bytes;
+  char arch[64];
+} HtaDeviceInfo;
+
+int hta_abi_version(void);
+const char* hta_last_error(void);
+int hta_device_info(int device, HtaDeviceInfo* out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Generic-callback pieces: the state updates around a user `log_prob_func` evaluated by torch
+ * (S:270-278).  One launch each; grad / logp come from the caller.
+ * ------------------------------------------------------------------------------------------- */
+
+/* gibbs(): p ~ N(0, M)  (S:185-202).  p[C,D] out. */
+int hta_momentum_resample_f32(float* p, int mass_kind, const float* mass_factor, int64_t C, int D,
+                              uint64_t seed, uint64_t chain_offset, uint32_t draw, void* stream);
+int hta_momentum_resample_f64(double* p, int mass_kind, const double* mass_factor, int64_t C, int D,
+                              uint64_t seed, uint64_t chain_offset, uint32_t draw, void* stream);
+
+/* leapfrog pieces (S:281, S:283-298, S:302, and the split half-kicks S:505-520):
+ *   p     += kick  * grad           (skipped when grad == NULL)
+ *   theta += drift * M^-1 p         (skipped when drift == 0)
+ * in this order, fused into one pass over [C,D]. */
+int hta_kick_drift_f32(float* theta, float* p, const float* grad, float kick, float drift, int mass_kind,
+                       const float* inv_mass, int64_t C, int D, void* stream);
+int hta_kick_drift_f64(double* theta, double* p, const double* grad, double kick, double drift,
+                       int mass_kind, const double* inv_mass, int64_t C, int D, void* stream);
+
+/* hamiltonian(): H[c] = -logp[c] + 0.5 p^T M^-1 p  (S:799-815).  logp may be NULL (kinetic only). */
+int hta_hamiltonian_f32(const float* p, const float* logp, int mass_kind, const float* inv_mass,
+                        float* H, int64_t C, int D, void* stream);
+int hta_hamiltonian_f64(const double* p, const double* logp, int mass_kind, const double* inv_mass,
+                        double* H, int64_t C, int D, void* stream);
+
+/* Metropolis test + burn/accept bookkeeping of sample() (S:1000-1026, S:1045-1057), per chain:
+ *   accept iff finite(H_new), finite(logp_new) and min(0, H_old - H_new) >= log(u), u = Philox(seed, chain, n)
+ *   accept: cur <- prop;  reject: cur stays, except the reference quirk: a rejection at
+ *   n == burn + 1 resets cur to theta_init (S:1018 reads ret_params[-1] == params_init).
+ *   n > burn: the new cur is written to samples_row[C,D] (if not NULL).
+ *   reject_count[c] += !accept.   out_accept[c] (may be NULL) = accept. */
+int hta_mh_select_f32(float* theta_cur, const float* theta_prop, const float* theta_init, const float* H_old,
+                      const float* H_new, const float* logp_new, float* samples_row, int32_t* reject_count,
+                      uint8_t* out_accept, int64_t C, int D, int n, int burn, uint64_t seed,
+                      uint64_t chain_offset, void* stream);
+int hta_mh_select_f64(double* theta_cur, const double* theta_prop, const double* theta_init,
+                      const double* H_old, const double* H_new, const double* logp_new, double* samples_row,
+                      int32_t* reject_count, uint8_t* out_accept, int64_t C, int D, int n, int burn,
+                      uint64_t seed, uint64_t chain_offset, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused HMC for a dense Gaussian target  log p(x) = log_norm - 0.5 (x-mu)^T P (x-mu)
+ * (the model family of BASELINE configs 1-2).  One launch runs `n_traj` whole trajectories
+ * (gibbs S:969 -> H S:971 -> leapfrog S:281-302 -> H S:995 -> MH S:1000-1026) for all C chains,
+ * with theta / p held in registers for the whole launch.
+ *
+ *   theta       [C,D] in/out   current state of every chain
+ *   theta_init  [C,D]          params_init (only read for the Q2 reset)
+ *   P [D,D] (symmetric), mu [D]
+ *   samples     [S,C,D] or NULL; the state after trajectory n (> burn) is written to row n - burn
+ *               (row 0 = params_init is the caller's), as in S:1007-1024
+ *   reject_count[C] in/out; H_old/H_new [n_traj,C] and accept [n_traj,C] optional diagnostics
+ *   trajectory indices n = traj_offset .. traj_offset + n_traj - 1  (RNG draw index and burn test)
+ * ------------------------------------------------------------------------------------------- */
+int hta_hmc_gaussian_sample_f32(float* theta, const float* theta_init, const float* P, const float* mu,
+                                float log_norm, int mass_kind, const float* inv_mass,
+                                const float* mass_factor, int64_t C, int D, int L, float eps, int n_traj,
+                                int traj_offset, int burn, uint64_t seed, uint64_t chain_offset,
+                                float* samples, int32_t* reject_count, float* H_old, float* H_new,
+                                uint8_t* accept, void* stream);
+int hta_hmc_gaussian_sample_f64(double* theta, const double* theta_init, const double* P, const double* mu,
+                                double log_norm, int mass_kind, const double* inv_mass,
+                                const double* mass_factor, int64_t C, int D, int L, double eps, int n_traj,
+                                int traj_offset, int burn, uint64_t seed, uint64_t chain_offset,
+                                double* samples, int32_t* reject_count, double* H_old, double* H_new,
+                                uint8_t* accept, void* stream);
+
+/* leapfrog() only (S:267-304) for the same target: theta, p [C,D] in/out after `steps` steps.
+ * path_theta / path_p: optional [steps,C,D] record of every step (the lists of S:299-300, last
+ * momentum corrected as in S:302); NULL = final state only.
+ * Used by the `samplers.leapfrog` mirror and the T1 parity tests. */
+int hta_hmc_gaussian_leapfrog_f32(float* theta, float* p, const float* P, const float* mu, int mass_kind,
+                                  const float* inv_mass, int64_t C, int D, int steps, float eps,
+                                  float* path_theta, float* path_p, void* stream);
+int hta_hmc_gaussian_leapfrog_f64(double* theta, double* p, const double* P, const double* mu, int mass_kind,
+                                  const double* inv_mass, int64_t C, int D, int steps, double eps,
+                                  double* path_theta, double* path_p, void* stream);
+
+/* launch-shape knob for the fused kernels (measurement only): chains per 64-lane wave for the
+ * small-D thread-per-chain kernel.  0 = default. */
+int hta_set_tuning(const char* key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAMILTORCH_AMD_H */

@@ -1,0 +1,51 @@
+"""CPU: the C-ABI library loads and exports every symbol include/hamiltorch_amd.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "hamiltorch_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hta_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from hamiltorch_amd import _abi
+    lib = _abi.load()
+    names = declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), "missing export: " + n
+    assert lib.hta_abi_version() == _abi.ABI_VERSION
+
+
+def test_binding_covers_header():
+    from hamiltorch_amd import _abi
+    bound = set(_abi.PLAIN_SYMBOLS)
+    for n in _abi.TYPED_SYMBOLS:
+        bound |= {n + "_f32", n + "_f64"}
+    assert bound == set(declared_symbols())
+
+
+def test_error_channel_without_gpu():
+    """bad arguments are rejected before any launch (no GPU needed)."""
+    from hamiltorch_amd import _abi
+    lib = _abi.load()
+    rc = lib.hta_momentum_resample_f32(None, 0, None, 0, 0, 0, 0, 0, None)
+    assert rc == -1 and b"bad shape" in lib.hta_last_error()
+    assert lib.hta_set_tuning(b"nope", 1) == -1
+
+
+def test_product_does_not_import_oracle():
+    """the shipped package never touches oracle/ (only tests, smoke and bench's cpu_baseline may)."""
+    pkg = os.path.join(ROOT, "hamiltorch_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dp, f)).read()
+                assert "hmc_oracle" not in txt and "import oracle" not in txt, f

@@ -1,0 +1,255 @@
+"""GPU parity: the HIP path (through hamiltorch_amd -> ctypes -> libhamiltorch_amd.so) against the
+oracle on the same seeded inputs, against the golden fixtures recorded from the reference, and
+through size-independent properties at BASELINE sizes.
+
+Tolerances (calibrated on the reference fp32 vs fp64): HMC trajectories
+atol = rtol = 1e-5 (fp32), 1e-11 (fp64); a Metropolis decision within rounding of its
+threshold may flip, so end-to-end sample() comparisons allow <= 1 % of chains to differ.
+"""
+import numpy as np
+import pytest
+import torch
+
+import hmc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SIGMA3 = np.array([[1.0, 0.6, 0.2], [0.6, 2.0, 0.5], [0.2, 0.5, 0.5]])
+NP = {torch.float32: np.float32, torch.float64: np.float64}
+
+
+@pytest.fixture(scope="module")
+def ht():
+    import hamiltorch_amd
+    assert torch.cuda.is_available()
+    return hamiltorch_amd
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rand_spd(D, seed, lo=0.5, hi=2.0):
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    P = (Q * np.linspace(lo, hi, D)) @ Q.T
+    return 0.5 * (P + P.T)
+
+
+def targets(ht, P, dtype, mu=None):
+    D = P.shape[0]
+    mu = np.zeros(D) if mu is None else mu
+    t = ht.GaussianTarget(torch.tensor(mu, dtype=dtype, device=dev()), precision=torch.tensor(P, dtype=dtype, device=dev()),
+                          normalized=False)
+    o = O.GaussianTarget(mu.astype(NP[dtype]), P.astype(NP[dtype]), 0.0)
+    return t, o
+
+
+def masses(D, dtype, seed=0):
+    rng = np.random.default_rng(seed)
+    diag = rng.uniform(0.5, 2.0, D)
+    full = rand_spd(D, seed + 7, 0.5, 1.5)
+    return {"none": None, "diag": diag.astype(NP[dtype]), "full": full.astype(NP[dtype])}
+
+
+def tt(a, dtype):
+    return None if a is None else torch.tensor(a, dtype=dtype, device=dev())
+
+
+# ---------------------------------------------------------------------------------------------
+def test_device_is_gfx950(ht):
+    from hamiltorch_amd import _abi
+    info = _abi.device_info(0)
+    assert info["arch"].startswith("gfx950"), info
+    assert info["wavefront_size"] == 64 and info["compute_units"] >= 200
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-6), (torch.float64, 1e-13)])
+@pytest.mark.parametrize("D", [1, 3, 4, 7, 50, 130])
+def test_gibbs_matches_philox_oracle(ht, dtype, tol, D):
+    """K1: momentum draw == oracle Philox/Box-Muller stream (seed, chain_offset + c, draw)."""
+    C, seed, off, draw = 37, 987654321012, 1000, 5
+    z = O.philox_normals(seed, off + np.arange(C), draw, D, dtype=NP[dtype])
+    m = masses(D, dtype)
+    th = torch.zeros(C, D, dtype=dtype, device=dev())
+    for kind, mass in m.items():
+        p = ht.samplers.gibbs(th, mass=tt(mass, dtype), seed=seed, chain_offset=off, draw=draw)
+        want = O.gibbs_momentum(z, mass)
+        np.testing.assert_allclose(p.cpu().numpy(), want, rtol=10 * tol, atol=10 * tol)
+    p1 = ht.samplers.gibbs(th[0], seed=seed, chain_offset=off, draw=draw)
+    assert p1.shape == (D,)
+    np.testing.assert_allclose(p1.cpu().numpy(), z[0], rtol=tol, atol=tol)
+
+
+def test_kat1_and_reversibility(ht, golden):
+    """tests/test_util.py:97-110 through the fused leapfrog kernel + the reference's own numbers."""
+    g = golden("hmc_kat")
+    t = ht.GaussianTarget(torch.zeros(2, device=dev()), covariance=torch.diag(torch.tensor([0.1, 0.1], device=dev())))
+    one = torch.ones(2, device=dev())
+    for steps in (1, 3, 100):
+        p, m = ht.samplers.leapfrog(one, one, t, steps=steps, step_size=0.1, inv_mass=one.clone(),
+                                    sampler=ht.Sampler.HMC, integrator=ht.Integrator.EXPLICIT)
+        assert len(p) == steps and len(m) == steps and p[-1].shape == (2,)
+        np.testing.assert_allclose(p[-1].cpu().numpy(), g[f"kat1_theta_{steps}"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(m[-1].cpu().numpy(), g[f"kat1_p_{steps}"], rtol=2e-5, atol=2e-5)
+    p, m = ht.samplers.leapfrog(one, one, t, steps=100, step_size=0.1, inv_mass=one.clone(), sampler=ht.Sampler.HMC,
+                                integrator=ht.Integrator.EXPLICIT)
+    p2, _ = ht.samplers.leapfrog(p[-1], -m[-1], t, steps=100, step_size=0.1, inv_mass=one.clone(),
+                                 sampler=ht.Sampler.HMC, integrator=ht.Integrator.EXPLICIT)
+    np.testing.assert_allclose(p2[-1].cpu().numpy(), [1.0, 1.0], atol=1e-5)
+
+
+@pytest.mark.parametrize("tag,dtype,tol", [("f32", torch.float32, 2e-5), ("f64", torch.float64, 1e-12)])
+def test_kat2_hamiltonian_and_leapfrog_path(ht, golden, tag, dtype, tol):
+    g = golden("hmc_kat")
+    t = ht.GaussianTarget(torch.zeros(3, dtype=dtype, device=dev()), covariance=torch.tensor(SIGMA3, dtype=dtype, device=dev()))
+    th = torch.tensor([0.3, -0.2, 0.5], dtype=dtype, device=dev()); pm = torch.tensor([0.1, 0.7, -0.4], dtype=dtype, device=dev())
+    ims = {"none": None, "diag": tt(np.array([1.0, 0.5, 2.0]), dtype), "full": tt(g[f"kat2_inv_mass_full_{tag}"], dtype)}
+    for mk, im in ims.items():
+        H = ht.samplers.hamiltonian(th, pm, t, inv_mass=im, sampler=ht.Sampler.HMC)
+        np.testing.assert_allclose(H.cpu().numpy().reshape(-1), g[f"kat2_H_{mk}_{tag}"], rtol=tol, atol=tol)
+        for native in (t, (lambda w, t=t: t(w))):      # fused kernel and generic-callback pieces
+            p, m = ht.samplers.leapfrog(th, pm, native, steps=5, step_size=0.3, inv_mass=im, sampler=ht.Sampler.HMC,
+                                        integrator=ht.Integrator.EXPLICIT)
+            np.testing.assert_allclose(torch.stack(p).cpu().numpy(), g[f"kat2_theta_{mk}_{tag}"], rtol=tol, atol=tol)
+            np.testing.assert_allclose(torch.stack(m).cpu().numpy(), g[f"kat2_p_{mk}_{tag}"], rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float64, 1e-11)])
+@pytest.mark.parametrize("D", [1, 2, 5, 8, 9, 33, 64, 100, 257])
+def test_leapfrog_batch_vs_oracle(ht, dtype, tol, D):
+    """T1: identical (theta, p) into the kernel and the oracle; small-D (registers) and wave-per-chain layouts."""
+    C, steps, eps = 70, 7, 0.11
+    rng = np.random.default_rng(D)
+    P = rand_spd(D, D)
+    mu = rng.standard_normal(D)
+    t, o = targets(ht, P, dtype, mu)
+    th0 = rng.standard_normal((C, D)).astype(NP[dtype]); p0 = rng.standard_normal((C, D)).astype(NP[dtype])
+    for kind, im in masses(D, dtype).items():
+        if kind == "full" and D > 130:
+            continue
+        pt, pp = ht.samplers.leapfrog(tt(th0, dtype), tt(p0, dtype), t, steps=steps, step_size=eps, inv_mass=tt(im, dtype),
+                                      sampler=ht.Sampler.HMC, integrator=ht.Integrator.EXPLICIT)
+        wt, wp = O.hmc_leapfrog(th0, p0, o.grad, steps, eps, im, return_path=True)
+        scale = max(1.0, np.abs(np.stack(wt)).max(), np.abs(np.stack(wp)).max())
+        np.testing.assert_allclose(torch.stack(pt).cpu().numpy(), np.stack(wt), rtol=tol, atol=tol * scale * (1 + D / 16))
+        np.testing.assert_allclose(torch.stack(pp).cpu().numpy(), np.stack(wp), rtol=tol, atol=tol * scale * (1 + D / 16))
+        H = ht.samplers.hamiltonian(tt(th0, dtype), tt(p0, dtype), t, inv_mass=tt(im, dtype), sampler=ht.Sampler.HMC)
+        wH, _ = O.hmc_hamiltonian(th0, p0, o.logp, im)
+        np.testing.assert_allclose(H.cpu().numpy(), wH, rtol=10 * tol, atol=10 * tol * (1 + D))
+
+
+def _compare_runs(got, ref, tol, max_bad=0.01):
+    got = np.stack([g.cpu().numpy() for g in got]); ref = np.stack(ref)
+    assert got.shape == ref.shape
+    err = np.abs(got - ref).max(axis=(0, 2))
+    bad = err > tol
+    assert bad.mean() <= max_bad, "%d of %d chains differ (max err %.3g)" % (bad.sum(), bad.size, err.max())
+    return bad
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float64, 1e-10)])
+@pytest.mark.parametrize("D,mass,burn", [(3, "none", 0), (3, "diag", 4), (3, "full", -1), (6, "none", 2), (20, "diag", 0),
+                                          (70, "none", 3)])
+def test_sample_fused_vs_oracle(ht, dtype, tol, D, mass, burn):
+    """End to end: gibbs -> H -> leapfrog -> H -> MH -> burn bookkeeping (incl. the Q2 reset), same Philox draws."""
+    C, N, L, eps, seed, off = 96, 25, 5, 0.25, 4242, 17
+    P = rand_spd(D, 3) if D != 3 else np.linalg.inv(SIGMA3)
+    t, o = targets(ht, P, dtype)
+    th0 = (0.3 * O.philox_normals(seed, off + np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(NP[dtype])
+    im = masses(D, dtype)[mass]
+    out, acc = ht.sample(t, tt(th0, dtype), num_samples=N, num_steps_per_sample=L, step_size=eps, burn=burn,
+                         inv_mass=tt(im, dtype), debug=2, verbose=False, seed=seed, chain_offset=off)
+    ref, info = O.sample_hmc(o, th0, N, L, eps, burn, im, O.PhiloxDraws(seed, off + np.arange(C), NP[dtype]))
+    assert len(out) == len(ref) == N - max(burn, -1)
+    bad = _compare_runs(out, ref, tol)
+    np.testing.assert_allclose(acc.cpu().numpy()[~bad], info["acc_rate"][~bad], atol=1e-12)
+    assert 0.3 < float(acc.mean()) <= 1.0
+
+
+@pytest.mark.parametrize("mass", ["none", "diag", "full"])
+def test_sample_generic_callback_vs_fused_and_oracle(ht, mass):
+    """The same target through the generic-callback path (torch evaluates the closure, HIP does the
+    state updates) must reproduce the fused kernel and the oracle."""
+    dtype, C, N, L, eps, seed = torch.float32, 48, 12, 4, 0.3, 99
+    t, o = targets(ht, np.linalg.inv(SIGMA3), dtype)
+    th0 = (0.5 * O.philox_normals(seed, np.arange(C), 0, 3, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32)
+    im = masses(3, dtype)[mass]
+    closure = lambda w: t(w)  # noqa: E731  -- opaque to the plugin recogniser
+    out_g = ht.sample(closure, tt(th0, dtype), num_samples=N, num_steps_per_sample=L, step_size=eps, burn=1,
+                      inv_mass=tt(im, dtype), verbose=False, seed=seed)
+    out_f = ht.sample(t, tt(th0, dtype), num_samples=N, num_steps_per_sample=L, step_size=eps, burn=1,
+                      inv_mass=tt(im, dtype), verbose=False, seed=seed)
+    ref, _ = O.sample_hmc(o, th0, N, L, eps, 1, im, O.PhiloxDraws(seed, np.arange(C)))
+    _compare_runs(out_g, ref, 2e-4, 0.03)
+    _compare_runs(out_f, ref, 2e-4, 0.03)
+
+
+def test_sample_single_chain_contract(ht):
+    """(D,) in -> list of (D,) tensors of length num_samples - burn, element 0 = params_init, float acc rate."""
+    t, _ = targets(ht, np.linalg.inv(SIGMA3), torch.float32)
+    init = torch.tensor([0.5, -0.5, 0.25], device=dev())
+    out, acc = ht.sample(t, init, num_samples=30, num_steps_per_sample=5, step_size=0.3, burn=10, debug=2, verbose=False, seed=1)
+    assert isinstance(out, list) and len(out) == 20 and out[0].shape == (3,) and isinstance(acc, float)
+    assert torch.equal(out[0], init)
+    out_cpu = ht.sample(t, init, num_samples=5, verbose=False, store_on_GPU=False, seed=1)
+    assert out_cpu[0].device.type == "cpu"
+    mvn = torch.distributions.MultivariateNormal(torch.zeros(3, device=dev()), torch.tensor(SIGMA3, dtype=torch.float32, device=dev()))
+    out_mvn = ht.sample(mvn.log_prob, init, num_samples=30, num_steps_per_sample=5, step_size=0.3, burn=10, verbose=False, seed=1)
+    np.testing.assert_allclose(torch.stack(out_mvn).cpu().numpy(), torch.stack(out).cpu().numpy(), atol=1e-4)
+
+
+def test_sharding_invariance(ht):
+    """Chains are keyed by global id: two half-size calls with chain_offset reproduce one full call bit for bit."""
+    t, _ = targets(ht, np.linalg.inv(SIGMA3), torch.float32)
+    C, seed = 128, 31337
+    th0 = tt(0.1 * O.philox_normals(seed, np.arange(C), 0, 3, O.PURPOSE_INIT), torch.float32)
+    kw = dict(num_samples=15, num_steps_per_sample=6, step_size=0.3, verbose=False, seed=seed)
+    full = torch.stack(ht.sample(t, th0, **kw))
+    a = torch.stack(ht.sample(t, th0[:64], chain_offset=0, **kw))
+    b = torch.stack(ht.sample(t, th0[64:], chain_offset=64, **kw))
+    assert torch.equal(full, torch.cat([a, b], dim=1))
+
+
+def test_divergent_chain_is_rejected_not_fatal(ht):
+    """A chain whose energy overflows is a rejection for that chain only (LogProbError semantics, S:1045)."""
+    t, _ = targets(ht, np.diag([1.0, 1.0, 1e30]), torch.float32)
+    th0 = torch.ones(8, 3, device=dev())
+    out, acc = ht.sample(t, th0, num_samples=6, num_steps_per_sample=50, step_size=2.5, debug=2, verbose=False, seed=3)
+    s = torch.stack(out)
+    assert torch.isfinite(s).all() and float(acc.max()) == 0.0
+    assert torch.equal(s[-1], th0)
+
+
+def test_cfg2_statistical_parity_at_full_size(ht):
+    """BASELINE cfg2 shape (1024 chains, L=25, eps=0.3): pooled posterior mean / covariance / acceptance against the
+    exact Gaussian and the oracle's acceptance on a chain subset (T2 tolerances of SURVEY 8c)."""
+    dtype = torch.float32
+    t, o = targets(ht, np.linalg.inv(SIGMA3), dtype)
+    C, N, L, eps, seed = 1024, 300, 25, 0.3, 2024
+    th0 = tt(0.1 * O.philox_normals(seed, np.arange(C), 0, 3, O.PURPOSE_INIT), dtype)
+    out, acc = ht.sample(t, th0, num_samples=N, num_steps_per_sample=L, step_size=eps, burn=50, debug=2, verbose=False, seed=seed)
+    s = torch.stack(out[1:]).double().cpu().numpy()          # [S, C, 3]
+    pooled = s.reshape(-1, 3)
+    ess = min(O.ess_bulk(s[:, :, d]) for d in range(3))
+    sd = np.sqrt(np.diag(SIGMA3))
+    assert np.all(np.abs(pooled.mean(0)) <= 4 * sd / np.sqrt(ess))
+    np.testing.assert_allclose(np.cov(pooled.T), SIGMA3, rtol=0.05, atol=0.02)
+    sub = np.arange(64)
+    _, info = O.sample_hmc(o, th0[:64].cpu().numpy(), N, L, eps, 50, None, O.PhiloxDraws(seed, sub))
+    assert abs(float(acc[:64].mean()) - info["acc_rate"].mean()) <= 0.01
+    assert float(acc.mean()) > 0.95            # reference: 0.998 at L=25
+
+
+def test_multi_chain_adapters(ht):
+    t, _ = targets(ht, np.linalg.inv(SIGMA3), torch.float32)
+    prior = lambda: torch.randn(3, device=dev())  # noqa: E731
+    chain = ht.util.setup_chain(ht.sample, prior, dict(log_prob_func=t, num_samples=8, num_steps_per_sample=3, step_size=0.3, verbose=False))
+    res = ht.util.multi_chain(chain, 2, [1, 2, 3], parallel=False)
+    assert len(res) == 3 and len(res[0]) == 8 and res[0][0].shape == (3,)
+    res_t = ht.util.multi_chain(chain, 2, [1, 2, 3], parallel=True)
+    assert len(res_t) == 3
+    res_b = ht.util.multi_chain(chain, 2, [1, 2, 3], batched=True)
+    assert len(res_b) == 3 and len(res_b[0]) == 8 and res_b[2][0].shape == (3,)
+    # same seed -> same params_init as the serial adapter
+    assert torch.equal(res_b[1][0], res[1][0])

@@ -1,0 +1,127 @@
+"""CPU: host-side logic of the API mirror (argument checks, list lengths, closures) -- no kernels run."""
+import numpy as np
+import pytest
+import torch
+
+import hamiltorch_amd as ht
+from hamiltorch_amd import bnn, samplers, util
+
+
+def test_exports_match_reference_init():
+    # hamiltorch/__init__.py:3-4
+    for name in ("sample", "sample_model", "predict_model", "sample_split_model", "Sampler", "Integrator", "Metric",
+                 "set_random_seed"):
+        assert hasattr(ht, name)
+    assert [e.value for e in ht.Sampler] == [1, 2, 3]
+    assert [e.name for e in ht.Integrator] == ["EXPLICIT", "IMPLICIT", "S3", "SPLITTING", "SPLITTING_RAND", "SPLITTING_KMID"]
+    assert [e.name for e in ht.Metric] == ["HESSIAN", "SOFTABS", "JACOBIAN_DIAG"]
+    for name in ("leapfrog", "hamiltonian", "rm_hamiltonian", "fisher", "gibbs", "cholesky_inverse", "acceptance",
+                 "collect_gradients", "define_model_log_prob", "define_split_model_log_prob"):
+        assert hasattr(samplers, name)
+    for name in ("LogProbError", "flatten", "unflatten", "setup_chain", "multi_chain", "set_random_seed", "has_nan_or_inf"):
+        assert hasattr(util, name)
+
+
+def test_argument_errors_match_reference():
+    f = lambda w: -(w * w).sum()  # noqa: E731
+    with pytest.raises(RuntimeError, match="burn must be less than num_samples"):      # S:928-929
+        ht.sample(f, torch.zeros(3), num_samples=5, burn=5)
+    with pytest.raises(RuntimeError, match="burn must be greater than 0 for NUTS"):    # S:933-934
+        ht.sample(f, torch.zeros(3), num_samples=5, sampler=ht.Sampler.HMC_NUTS)
+    with pytest.raises(RuntimeError, match="params_init must be a 1d tensor"):         # S:925-926
+        ht.sample(f, torch.zeros(2, 2, 2), num_samples=5)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ht.sample(f, torch.zeros(3), num_samples=5)
+    with pytest.raises(ValueError):                                                    # U:126-127
+        util.unflatten(torch.nn.Linear(2, 2), torch.zeros(2, 3))
+
+
+def test_row_count_matches_reference_list_length():
+    # measured on the reference: burn=0 -> N, burn=10 -> N-10, burn=-1 -> N+1
+    assert samplers._num_rows(400, 0) == 400
+    assert samplers._num_rows(60, 10) == 50
+    assert samplers._num_rows(40, -1) == 41
+
+
+def test_has_nan_or_inf_and_flatten_roundtrip():
+    assert util.has_nan_or_inf(torch.tensor([1.0, float("inf")]))
+    assert util.has_nan_or_inf(torch.tensor([float("inf"), -float("inf")]))    # sum is NaN (U:94)
+    assert not util.has_nan_or_inf(torch.tensor([1.0, 2.0]))
+    m = torch.nn.Linear(4, 4)
+    flat = util.flatten(m)
+    parts = util.unflatten(m, flat)
+    util.update_model_params_in_place(m, parts)
+    assert torch.equal(util.flatten(m), flat)                                  # tests/test_util.py:12-24
+
+
+def test_stream_seed_is_reproducible():
+    ht.set_random_seed(5)
+    a = [util.next_stream_seed() for _ in range(3)]
+    ht.set_random_seed(5)
+    b = [util.next_stream_seed() for _ in range(3)]
+    assert a == b and len(set(a)) == 3
+
+
+def _net(dims, act):
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(torch.nn.Linear(int(dims[i]), int(dims[i + 1])))
+        if i < len(dims) - 2:
+            layers.append({"relu": torch.nn.ReLU, "tanh": torch.nn.Tanh}[act]())
+    return torch.nn.Sequential(*layers)
+
+
+@pytest.mark.parametrize("name,act", [("relu2", "relu"), ("tanh3", "tanh")])
+def test_bnn_closures_match_reference_fixture(golden, name, act):
+    """define_model_log_prob / define_split_model_log_prob (torch, CPU) vs values recorded from the reference."""
+    g = golden("mlp")
+    M, tau_out, eps, L = g[f"{name}_cfg"]
+    net = _net(g[f"{name}_dims"], act)
+    theta = torch.tensor(g[f"{name}_theta"])
+    X, Y = torch.tensor(g[f"{name}_X"]), torch.tensor(g[f"{name}_Y"])
+    tau_list = torch.tensor(g[f"{name}_tau_list"])
+    sizes = [w.nelement() for w in net.parameters()]
+    shapes = [w.shape for w in net.parameters()]
+    f = bnn.define_model_log_prob(net, "regression", X, Y, sizes, shapes, tau_list, float(tau_out))
+    th = theta.clone().requires_grad_()
+    v = f(th)
+    np.testing.assert_allclose(v.detach().numpy().reshape(-1), g[f"{name}_logp"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(torch.autograd.grad(v.sum(), th)[0].numpy(), g[f"{name}_grad"], rtol=1e-4, atol=1e-4)
+    assert f._hta_spec["dims"] == list(g[f"{name}_dims"]) and f._hta_spec["act"] == act
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(X, Y), batch_size=X.shape[0] // int(M), shuffle=False)
+    fl = bnn.define_split_model_log_prob(net, "regression", loader, int(M), sizes, shapes, tau_list, float(tau_out), verbose=False)
+    assert len(fl) == int(M)
+    np.testing.assert_allclose([float(fm(theta).sum()) for fm in fl], g[f"{name}_split_logp"], rtol=1e-5, atol=1e-4)
+    # batched evaluation used by the generic path
+    cb = samplers._BatchedCallback(f)
+    gb, lb = cb.grad(theta.repeat(3, 1))
+    np.testing.assert_allclose(gb[1].numpy(), g[f"{name}_grad"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(lb.numpy(), np.repeat(g[f"{name}_logp"], 3), rtol=1e-5, atol=1e-4)
+
+
+def test_batched_callback_loop_fallback_and_pass_grad():
+    def f(w):                      # .item() defeats vmap -> per-chain loop
+        return -(w * w).sum() * float(torch.tensor(1.0).item()) + 0 * float(w[0].item())
+    cb = samplers._BatchedCallback(f)
+    th = torch.tensor([[1.0, 2.0], [3.0, 4.0]])
+    with pytest.warns(UserWarning):
+        g, v = cb.grad(th)
+    np.testing.assert_allclose(g.numpy(), -2 * th.numpy())
+    np.testing.assert_allclose(v.numpy(), [-5.0, -25.0])
+    cb2 = samplers._BatchedCallback(lambda w: -(w * w).sum(), pass_grad=lambda w: -2 * w)
+    g2, _ = cb2.grad(th)
+    np.testing.assert_allclose(g2.numpy(), -2 * th.numpy())
+
+
+def test_gaussian_target_is_a_valid_callback():
+    sigma = torch.tensor([[1.0, 0.6, 0.2], [0.6, 2.0, 0.5], [0.2, 0.5, 0.5]])
+    t = ht.GaussianTarget(torch.zeros(3), covariance=sigma)
+    w = torch.tensor([0.3, -0.2, 0.5])
+    ref = torch.distributions.MultivariateNormal(torch.zeros(3), sigma).log_prob(w)
+    assert abs(float(t(w)) - float(ref)) < 1e-5                    # KAT2 logp = -2.97352004
+    assert abs(float(t(w)) + 2.97352004) < 1e-5
+    from hamiltorch_amd.models import as_gaussian
+    d = torch.distributions.MultivariateNormal(torch.zeros(3), sigma)
+    t2 = as_gaussian(d.log_prob)
+    assert t2 is not None and torch.allclose(t2.precision, t.precision, atol=1e-5)
+    assert as_gaussian(lambda w: w.sum()) is None
