@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""Headline benchmark: leapfrog-steps/sec at 1024 chains per GPU (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4]
+
+One "step" = one pass of the hot path over one batch: a single launch of the fused trajectory
+kernel that runs `--traj` whole trajectories (momentum draw, H, L leapfrog steps, H, Metropolis,
+sample write-out) for every chain of this rank.  Inputs are resident in HBM before the timed
+region.  For N > 1 every rank owns its own block of chains (global chain ids, no data-path
+collective): weak scaling, value = all ranks' chain-steps / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and, at N=1,
+`cpu_baseline` (the reference's per-chain torch/autograd cost structure, oracle/torch_port.py,
+timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP32_PEAK_TFLOPS = 157.3       # fp32 vector == fp32 MFMA peak
+SIGMA3 = [[1.0, 0.6, 0.2], [0.6, 2.0, 0.5], [0.2, 0.5, 0.5]]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default: the workload's)")
+    ap.add_argument("--traj", type=int, default=None, help="trajectories per launch (default: the workload's)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep", action="store_true", help="also print a chain-count sweep (stderr)")
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------
+class Cfg2:
+    """BASELINE config 2: 3-D correlated Gaussian, HMC, 1024 chains, L=25, eps=0.3, 1000 trajectories."""
+    name = "cfg2: 3-D correlated Gaussian HMC, L=25, eps=0.3, identity mass"
+    D, L, eps, chains, traj = 3, 25, 0.3, 1024, 1000
+    dtype_name = "f32"
+
+    def __init__(self, dev, chains, traj, chain_offset, seed=0):
+        import hamiltorch_amd as ht
+        from hamiltorch_amd import _abi
+        self.abi = _abi
+        self.C, self.T = chains or self.chains, traj or self.traj
+        self.off, self.seed = chain_offset, seed
+        cov = torch.tensor(SIGMA3, dtype=torch.float32, device=dev)
+        self.tgt = ht.GaussianTarget(torch.zeros(3, device=dev), covariance=cov)
+        g = torch.Generator(device="cpu").manual_seed(1234 + chain_offset)
+        self.theta0 = (0.1 * torch.randn(self.C, 3, generator=g)).to(dev)
+        self.cur = self.theta0.clone()
+        self.samples = torch.empty(self.T + 1, self.C, 3, device=dev)      # burn = -1: every trajectory stored
+        self.samples[0].copy_(self.theta0)
+        self.rej = torch.zeros(self.C, dtype=torch.int32, device=dev)
+
+    def units_per_step(self):
+        return self.C * self.T * self.L
+
+    def bytes_per_unit(self):      # theta and p, fp32, read + written once per chain-step
+        return 16 * self.D
+
+    def step(self, k):
+        self.abi.hmc_gaussian_sample(self.cur, self.theta0, self.tgt.precision, self.tgt.mean, self.tgt.log_norm,
+                                     0, None, None, self.L, self.eps, self.T, 0, -1, self.seed + k, self.off,
+                                     self.samples, self.rej)
+
+    def kernel_only(self, k):
+        self.step(k)
+
+    def check(self):
+        s = self.samples[1:]
+        assert torch.isfinite(s).all()
+        pooled = s.reshape(-1, 3).double()
+        cov = torch.cov(pooled.T).cpu()
+        want = torch.tensor(SIGMA3, dtype=torch.float64)
+        assert torch.allclose(cov, want, rtol=0.08, atol=0.04), cov
+        return 1.0 - float(self.rej.double().mean()) / (self.T * max(1, self._steps_done))
+
+    def cpu_baseline(self, seconds):
+        """The reference's CPU cost structure on this host: one chain, autograd callback, torch CPU RNG."""
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import torch_port as TP
+        torch.set_num_threads(1)
+        cov = torch.tensor(SIGMA3)
+
+        def lp(w):
+            return torch.distributions.MultivariateNormal(torch.zeros(3), cov).log_prob(w).sum()
+        init = torch.zeros(3)
+        torch.manual_seed(0)
+        t0 = time.time(); TP.port_sample(lp, init, 20, self.L, self.eps); dt = time.time() - t0
+        n = max(40, int(seconds / (dt / 20)))
+        t0 = time.time(); ret, acc = TP.port_sample(lp, init, n, self.L, self.eps, burn=-1); dt = time.time() - t0
+        from hamiltorch_amd.ess import ess_min
+        ess = ess_min(torch.stack(ret[1:]).unsqueeze(1))
+        return {"value": n * self.L / dt, "unit": "leapfrog-steps/s", "cores": 1, "kind": "port",
+                "sample": "1 chain x %d trajectories x L=%d (oracle/torch_port.py: per-step autograd on a "
+                          "MultivariateNormal.log_prob callback, as the reference), %.1f s" % (n, self.L, dt),
+                "ess_per_sec": ess / dt, "acceptance": acc}
+
+
+WORKLOADS = {"cfg2": Cfg2}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if a.workload not in WORKLOADS:
+        try:
+            import bench_extra
+            WORKLOADS.update(bench_extra.WORKLOADS)
+        except ImportError:
+            pass
+    W = WORKLOADS[a.workload]
+    w = W(dev, a.chains, a.traj, chain_offset=rank * (a.chains or W.chains))
+    w._steps_done = 0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(a.warmup):
+        w.step(k)
+    w.rej.zero_()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        ev[k][0].record()
+        w.step(a.warmup + k)
+        ev[k][1].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    w._steps_done = a.steps
+    kernel_ms = sum(s.elapsed_time(e) for s, e in ev) / max(1, a.steps)   # same stream as the launches
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    acc = w.check()
+    units = w.units_per_step() * a.steps * world
+    value = units / dt
+
+    if rank == 0:
+        alg_bytes = w.bytes_per_unit() * w.units_per_step()
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+        from hamiltorch_amd.ess import ess_min
+        ess = ess_min(w.samples[1:])
+        out = {
+            "metric": "leapfrog-steps/sec (whole node) at 1024 chains; ESS/sec vs CPU ref",
+            "value": value, "unit": "leapfrog-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": W.dtype_name, "data": "synthetic",
+            "config": {"workload": W.name, "chains_per_gpu": w.C, "chains_total": w.C * world,
+                       "trajectories_per_step": w.T, "leapfrog_steps_per_trajectory": W.L, "D": W.D,
+                       "samples_stored": True, "parallelism": "chains sharded, %d per GPU, no collective" % w.C},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "hmc_gauss_small_kernel<float,3,0>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "16*D bytes per chain-step (SURVEY 8d); state is register-resident for the whole "
+                                 "launch, so real HBM traffic is the sample rows only; at 1024 chains the launch "
+                                 "is 16 waves on 256 CUs: latency/issue bound, not bandwidth bound"},
+            "acceptance_rate": acc,
+            "ess_per_sec": ess / (kernel_ms * 1e-3),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = w.cpu_baseline(a.cpu_seconds)
+            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            out["speedup_vs_cpu_baseline_1core"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+        if a.sweep:
+            for C in (1024, 4096, 16384, 65536, 262144, 1048576):
+                ws = W(dev, C, max(10, min(w.T, (1 << 24) // C)), 0)
+                ws._steps_done = 1
+                ws.step(0); torch.cuda.synchronize()
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(); ws.step(1); e.record(); torch.cuda.synchronize()
+                ms = s.elapsed_time(e)
+                rate = ws.units_per_step() / (ms * 1e-3)
+                print("sweep C=%8d T=%5d  %.3f ms  %.3e chain-steps/s  %.1f GB/s algorithmic (%.2f%% of HBM peak)"
+                      % (C, ws.T, ms, rate, rate * ws.bytes_per_unit() / 1e9,
+                         rate * ws.bytes_per_unit() / 1e9 / HBM_PEAK_GBS * 100), file=sys.stderr, flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

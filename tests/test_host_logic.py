@@ -125,3 +125,19 @@ def test_gaussian_target_is_a_valid_callback():
     t2 = as_gaussian(d.log_prob)
     assert t2 is not None and torch.allclose(t2.precision, t.precision, atol=1e-5)
     assert as_gaussian(lambda w: w.sum()) is None
+
+
+def test_ess_matches_oracle_definition():
+    import hmc_oracle as O
+    from hamiltorch_amd.ess import ess_bulk, ess_min
+    g = torch.Generator().manual_seed(0)
+    S, C = 400, 6
+    x = torch.zeros(S, C, dtype=torch.float64)
+    e = torch.randn(S, C, generator=g, dtype=torch.float64)
+    for t in range(1, S):
+        x[t] = 0.8 * x[t - 1] + e[t]                    # AR(1): ESS ~ S*C*(1-.8)/(1+.8)
+    a, b = ess_bulk(x), O.ess_bulk(x.numpy())
+    assert abs(a - b) / b < 1e-9
+    assert 0.4 * S * C / 9 < a < 2.5 * S * C / 9
+    iid = torch.randn(S, C, 2, generator=g, dtype=torch.float64)
+    assert 0.7 * S * C < ess_min(iid) < 1.4 * S * C

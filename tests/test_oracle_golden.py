@@ -171,3 +171,24 @@ def test_mlp_logp_grad_split_leapfrog(golden, name):
     draws = O.ReplayDraws(g[f"{name}_full_momenta"], g[f"{name}_full_uniforms"])
     ret, _ = O.sample_hmc(full, theta, 8, L, eps, 0, None, draws)
     np.testing.assert_allclose(np.concatenate(ret), g[f"{name}_full_samples"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("name,seed", [("cfg1", 123), ("burn10", 7), ("burnm1", 8), ("diag", 9), ("full", 10)])
+def test_torch_port_cfg1_bit_identical(golden, name, seed):
+    """BASELINE config 1: the per-chain torch port (bench.py's cpu_baseline) reproduces the reference's
+    sample() output bit for bit from the same torch seed -- same op order, same RNG consumption."""
+    import torch
+    import torch_port as TP
+    g = golden("sample_hmc")
+    N, L, eps, burn = g[f"{name}_cfg"]
+    cov = torch.tensor(g["sigma3"], dtype=torch.float32)
+
+    def lp(w):
+        return torch.distributions.MultivariateNormal(torch.zeros(3), cov).log_prob(w).sum()
+    im = torch.tensor(g[f"{name}_inv_mass"]) if f"{name}_inv_mass" in g.files else None
+    torch.manual_seed(seed)
+    ret, acc = TP.port_sample(lp, torch.tensor(g[f"{name}_init"]), int(N), int(L), float(eps), int(burn), im)
+    got = np.stack([t.numpy() for t in ret])
+    assert got.shape == g[f"{name}_samples"].shape
+    assert np.array_equal(got, g[f"{name}_samples"])
+    assert acc == float(g[f"{name}_acc"])
