@@ -38,14 +38,15 @@ def _sig(scalar):
         "hta_mh_select": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_u64,
                           c_u64, c_vp],
         "hta_hmc_gaussian_sample": [c_vp, c_vp, c_vp, c_vp, scalar, c_int, c_vp, c_vp, c_i64, c_int, c_int, scalar,
-                                    c_int, c_int, c_int, c_u64, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+                                    c_int, c_int, c_int, c_u64, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
         "hta_hmc_gaussian_leapfrog": [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_int, c_int, scalar, c_vp, c_vp,
                                       c_vp],
     }
 
 
 #: every symbol include/hamiltorch_amd.h declares (checked by tests/test_abi_symbols.py)
-PLAIN_SYMBOLS = ["hta_abi_version", "hta_last_error", "hta_device_info", "hta_set_tuning"]
+PLAIN_SYMBOLS = ["hta_abi_version", "hta_last_error", "hta_device_info", "hta_set_tuning", "hta_profile_collect",
+                 "hta_hmc_gaussian_workspace_bytes"]
 TYPED_SYMBOLS = sorted(_sig(c_f32).keys())
 
 
@@ -67,6 +68,9 @@ def load():
         lib.hta_last_error.restype = ctypes.c_char_p
         lib.hta_device_info.argtypes = [c_int, ctypes.POINTER(HtaDeviceInfo)]
         lib.hta_set_tuning.argtypes = [ctypes.c_char_p, c_int]
+        lib.hta_profile_collect.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]
+        lib.hta_hmc_gaussian_workspace_bytes.argtypes = [c_i64, c_int, c_int, c_int]
+        lib.hta_hmc_gaussian_workspace_bytes.restype = c_i64
         for suf, scalar in (("f32", c_f32), ("f64", c_f64)):
             for name, args in _sig(scalar).items():
                 fn = getattr(lib, "%s_%s" % (name, suf))
@@ -168,9 +172,20 @@ def mh_select(cur, prop, init, H_old, H_new, logp_new, row, reject_count, accept
                   _stream(cur)), "hta_mh_select")
 
 
+def profile_collect():
+    """(summed ms, launches) of the kernels bracketed since set_tuning("profile", 1)."""
+    ms, n = ctypes.c_double(0), c_int(0)
+    _check(load().hta_profile_collect(ctypes.byref(ms), ctypes.byref(n)), "hta_profile_collect")
+    return ms.value, n.value
+
+
+def gaussian_workspace_bytes(C, D, n_traj, itemsize):
+    return int(load().hta_hmc_gaussian_workspace_bytes(int(C), int(D), int(n_traj), int(itemsize)))
+
+
 def hmc_gaussian_sample(theta, theta_init, P, mu, log_norm, mass_kind, inv_mass, mass_factor, L, eps, n_traj,
                         traj_offset, burn, seed, chain_offset, samples, reject_count, H_old=None, H_new=None,
-                        accept=None):
+                        accept=None, workspace=None):
     require_device(theta, "params")
     C, D = theta.shape
     fn = getattr(load(), "hta_hmc_gaussian_sample_" + _suffix(theta))
@@ -178,7 +193,10 @@ def hmc_gaussian_sample(theta, theta_init, P, mu, log_norm, mass_kind, inv_mass,
         _check(fn(_p(theta), _p(theta_init, theta), _p(P, theta), _p(mu, theta), float(log_norm), mass_kind,
                   _p(inv_mass, theta), _p(mass_factor, theta), C, D, int(L), float(eps), int(n_traj),
                   int(traj_offset), int(burn), seed, chain_offset, _p(samples, theta), _p(reject_count),
-                  _p(H_old, theta), _p(H_new, theta), _p(accept), _stream(theta)), "hta_hmc_gaussian_sample")
+                  _p(H_old, theta), _p(H_new, theta), _p(accept),
+                  None if workspace is None else c_vp(workspace.data_ptr()),
+                  0 if workspace is None else workspace.numel() * workspace.element_size(),
+                  _stream(theta)), "hta_hmc_gaussian_sample")
 
 
 def hmc_gaussian_leapfrog(theta, p, P, mu, mass_kind, inv_mass, steps, eps, path_theta=None, path_p=None):

@@ -12,6 +12,28 @@ void set_error(const char* fmt, ...) {
 }
 int g_small_chains_per_block = 0;  // 0 = default (64)
 int g_force_general = 0;
+
+// ---- optional HIP-event timing of the dominant kernel of each call (measurement only) -----------
+// hta_set_tuning("profile", 1) arms it; every bracketed launch then records a start/stop event pair
+// on the launch stream (no synchronisation); hta_profile_collect() waits for them and returns the sum.
+static int g_profile = 0;
+static const int kMaxPairs = 8192;
+static hipEvent_t g_ev[kMaxPairs][2];
+static int g_ev_created = 0, g_ev_used = 0;
+void profile_begin(hipStream_t s) {
+  if (!g_profile || g_ev_used >= kMaxPairs) return;
+  if (g_ev_used >= g_ev_created) {
+    (void)hipEventCreate(&g_ev[g_ev_created][0]);
+    (void)hipEventCreate(&g_ev[g_ev_created][1]);
+    ++g_ev_created;
+  }
+  (void)hipEventRecord(g_ev[g_ev_used][0], s);
+}
+void profile_end(hipStream_t s) {
+  if (!g_profile || g_ev_used >= kMaxPairs) return;
+  (void)hipEventRecord(g_ev[g_ev_used][1], s);
+  ++g_ev_used;
+}
 }  // namespace hta
 
 extern "C" {
@@ -40,8 +62,24 @@ int hta_set_tuning(const char* key, int value) {
   if (!key) return HTA_ERR_INVALID;
   if (!strcmp(key, "small_chains_per_block")) { hta::g_small_chains_per_block = value; return HTA_OK; }
   if (!strcmp(key, "force_general")) { hta::g_force_general = value; return HTA_OK; }
+  if (!strcmp(key, "profile")) { hta::g_profile = value; hta::g_ev_used = 0; return HTA_OK; }
   hta::set_error("hta_set_tuning: unknown key %s", key);
   return HTA_ERR_INVALID;
+}
+
+int hta_profile_collect(double* total_ms, int* launches) {
+  double tot = 0;
+  for (int i = 0; i < hta::g_ev_used; ++i) {
+    float ms = 0;
+    hipError_t e = hipEventSynchronize(hta::g_ev[i][1]);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, hta::g_ev[i][0], hta::g_ev[i][1]);
+    if (e != hipSuccess) { hta::set_error("hta_profile_collect: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = hta::g_ev_used;
+  hta::g_ev_used = 0;
+  return HTA_OK;
 }
 
 }  // extern "C"

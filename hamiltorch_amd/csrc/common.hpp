@@ -49,4 +49,11 @@ template <typename T> __device__ __forceinline__ bool mh_accept(T h_old, T h_new
   return finite_(h_old) && finite_(h_new) && finite_(logp_new) && (rho >= log(u));
 }
 
+// same rule with log(u) already taken (pre-drawn workspace)
+template <typename T> __device__ __forceinline__ bool mh_accept_logu(T h_old, T h_new, T logp_new, T logu) {
+  const T rho = fmin((T)0, h_old - h_new);
+  // one class test: the sum is finite iff all three are (inf - inf = NaN; realistic magnitudes cannot overflow)
+  return finite_(h_old + h_new + logp_new) && (rho >= logu);
+}
+
 }  // namespace hta

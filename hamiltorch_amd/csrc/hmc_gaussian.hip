@@ -8,48 +8,70 @@
 // sample row per stored trajectory); theta, p, the gradient and both energies live in registers.
 //
 // Two layouts:
-//   small  (D <= 8):   one chain per lane, D compile-time, P/mu in SGPRs (wave-uniform loads).
+//   small  (D <= 6):   one chain per lane, D compile-time, P/mu in SGPRs (wave-uniform loads).
 //                      This is BASELINE config 2 (3-D, 1024 chains): latency/issue bound, 16 waves.
 //   general (D <= 1024): one chain per 64-lane wave, lane l owns elements l, l+64, ...;
 //                      P streamed row-by-row (coalesced, L1/L2 resident), the offset vector
 //                      broadcast through LDS, energies by wave butterfly reduction.
 #include "common.hpp"
 #include "philox.hpp"
+#include "hmc_gaussian.hpp"
 
 namespace hta {
 
-extern int g_small_chains_per_block;
-extern int g_force_general;
 
-template <typename T> struct GaussArgs {
-  T* theta; const T* theta_init; const T* P; const T* mu; T log_norm;
-  const T* inv_mass; const T* mass_factor;
-  int64_t C; int D; int L; T eps; int n_traj; int traj_offset; int burn;
-  uint64_t seed; uint64_t chain_offset;
-  T* samples; int32_t* reject_count; T* H_old; T* H_new; uint8_t* accept;
-  T* p_io;  // leapfrog-only entry: momentum in/out
-  T* path_theta; T* path_p;  // leapfrog-only: optional per-step record [steps,C,D] (S:299-300)
-};
 
 // =============================================================================================
 // small-D: thread per chain
+//
+// What bounds it (measured, tools/scratch/issue_bench.hip -> profiles/r01_issue_bench.txt): at
+// BASELINE config 2 (1024 chains x D=3) the launch is 16 waves on a 1024-SIMD chip, and ONE wave
+// issues a dependent VALU instruction only every ~2-2.5 ns and pays ~14 ns per taken loop branch.
+// Time per leapfrog step is therefore (instructions per step per wave), not bytes and not flops.
+// So the inner loop is written for the fewest instructions per step:
+//   * d = q - mu and pre-scaled wave-uniform operands: d <- d + (eps M^-1) p ; p <- p + (-eps P) d,
+//     i.e. D + D*D fused multiply-adds, the kick accumulating straight into p (S:283-298);
+//   * fp32: two elements per instruction (v_pk_fma_f32 on explicit float2 pairs): 8 instead of 12
+//     instructions per step at D=3 (15.8 vs 22.8 ns/step);
+//   * unrolled by 5 (the reference's L values are multiples of 5): branch cost amortised;
+//   * P d is formed only at trajectory end points, and the potential at the current point is
+//     carried from the previous trajectory (accepted -> end point, rejected -> unchanged).
+// Rejected alternatives (same microbenchmark): one chain per DPP quad (4 instead of 12 FMAs per
+// step, but a DPP read of a just-written register costs ~7.6 ns: 23-28 ns/step); half-filled waves
+// (slower: 30.9 ns/step); two chains per lane (no gain).
+//
+// Random numbers.  With a workspace the momentum normals and log-uniforms of every trajectory of
+// the launch are produced first by a full-chip kernel (rng_fill_small_kernel: one thread per
+// (trajectory, chain), ~1e6 threads for config 2) as 16-byte records [z_0..z_{D-1}, log u, pad] and
+// the trajectory kernel loads one record per trajectory, one trajectory ahead: ~2.5k cycles of
+// Philox/Box-Muller per trajectory leave the 16 busy SIMDs for the 1000 idle ones.  Without a
+// workspace the draws are made inline.  Same Philox stream either way.
 // =============================================================================================
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct RecVec;
+template <> struct RecVec<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int N = 4; };
+template <> struct RecVec<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int N = 2; };
+// elements per (trajectory, chain) record: D normals + log u, padded to 16-byte vectors
+template <typename T, int D> constexpr int rec_elems() { return ((D + 1 + RecVec<T>::N - 1) / RecVec<T>::N) * RecVec<T>::N; }
+
 template <typename T, int D, int MASS> struct SmallModel {
-  T P[D][D]; T mu[D]; T im[MASS == HTA_MASS_FULL ? D * D : (MASS == HTA_MASS_DIAG ? D : 1)];
-  T mf[MASS == HTA_MASS_FULL ? D * D : (MASS == HTA_MASS_DIAG ? D : 1)];
+  static constexpr int NM = MASS == HTA_MASS_FULL ? D * D : (MASS == HTA_MASS_DIAG ? D : 1);
+  T P[D][D]; T nEP[D][D]; T mu[D]; T im[NM]; T eIM[NM]; T mf[NM]; T eps;
   __device__ __forceinline__ void load(const GaussArgs<T>& a, bool need_mf) {
+    eps = a.eps;
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       mu[i] = a.mu[i];
 #pragma unroll
-      for (int j = 0; j < D; ++j) P[i][j] = a.P[i * D + j];
+      for (int j = 0; j < D; ++j) { P[i][j] = a.P[i * D + j]; nEP[i][j] = -(a.eps * P[i][j]); }
     }
-    if (MASS == HTA_MASS_DIAG) {
+    if (MASS != HTA_MASS_NONE) {
 #pragma unroll
-      for (int i = 0; i < D; ++i) { im[i] = a.inv_mass[i]; mf[i] = need_mf ? a.mass_factor[i] : (T)0; }
-    } else if (MASS == HTA_MASS_FULL) {
-#pragma unroll
-      for (int i = 0; i < D * D; ++i) { im[i] = a.inv_mass[i]; mf[i] = need_mf ? a.mass_factor[i] : (T)0; }
+      for (int i = 0; i < NM; ++i) {
+        im[i] = a.inv_mass[i]; eIM[i] = a.eps * im[i];
+        mf[i] = need_mf ? a.mass_factor[i] : (T)0;
+      }
     }
   }
   // v = M^-1 p
@@ -64,11 +86,8 @@ template <typename T, int D, int MASS> struct SmallModel {
         v[i] = acc; }
     }
   }
-  // Pd = P (q - mu);  returns 0.5 d^T P d
-  __device__ __forceinline__ T curv(const T (&q)[D], T (&Pd)[D]) const {
-    T d[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) d[i] = q[i] - mu[i];
+  // Pd = P d;  returns 0.5 d^T P d
+  __device__ __forceinline__ T curv_d(const T (&d)[D], T (&Pd)[D]) const {
     T quad = 0;
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -87,59 +106,214 @@ template <typename T, int D, int MASS> struct SmallModel {
     for (int i = 0; i < D; ++i) k += p[i] * v[i];
     return (T)0.5 * k;
   }
-  // leapfrog (S:281-302): grad = -Pd.  On exit Pd holds P(q_L - mu), returns 0.5 d^T P d at q_L.
+  // one full step on (d, p): drift then kick (S:283-298), scalar form
+  __device__ __forceinline__ void step(T (&d)[D], T (&p)[D]) const {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      if (MASS == HTA_MASS_NONE) d[i] = fma(eps, p[i], d[i]);
+      else if (MASS == HTA_MASS_DIAG) d[i] = fma(eIM[i], p[i], d[i]);
+      else { T acc = d[i];
+#pragma unroll
+        for (int k = 0; k < D; ++k) acc = fma(eIM[i * D + k], p[k], acc);
+        d[i] = acc; }
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) p[i] = fma(nEP[i][k], d[k], p[i]);
+    }
+  }
+  // L steps.  fp32: the same FMAs as step(), two elements per v_pk_fma_f32 (bitwise identical results).
+  __device__ __forceinline__ void run_steps(T (&d)[D], T (&p)[D], int L) const {
+    if constexpr (sizeof(T) == 4 && D >= 2) {
+      constexpr int NP = D / 2;
+      constexpr bool R = (D & 1) != 0;
+      f2 dP[NP], pP[NP], AP[D][NP], EP[MASS == HTA_MASS_FULL ? D : 1][NP];
+      float dS = 0, pS = 0, AS[D], ES[MASS == HTA_MASS_FULL ? D : 1];
+#pragma unroll
+      for (int j = 0; j < NP; ++j) { dP[j] = f2{d[2 * j], d[2 * j + 1]}; pP[j] = f2{p[2 * j], p[2 * j + 1]}; }
+      if (R) { dS = d[D - 1]; pS = p[D - 1]; }
+#pragma unroll
+      for (int k = 0; k < D; ++k) {              // column k of -eps P (and of eps M^-1 for a full mass)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) AP[k][j] = f2{nEP[2 * j][k], nEP[2 * j + 1][k]};
+        AS[k] = R ? nEP[D - 1][k] : 0.f;
+        if (MASS == HTA_MASS_FULL) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) EP[k][j] = f2{eIM[(2 * j) * D + k], eIM[(2 * j + 1) * D + k]};
+          ES[k] = R ? eIM[(D - 1) * D + k] : 0.f;
+        }
+      }
+      f2 eP[NP]; float eS = eps;
+#pragma unroll
+      for (int j = 0; j < NP; ++j)
+        eP[j] = (MASS == HTA_MASS_DIAG) ? f2{eIM[2 * j], eIM[2 * j + 1]} : f2{eps, eps};
+      if (MASS == HTA_MASS_DIAG && R) eS = eIM[D - 1];
+#pragma unroll 5
+      for (int l = 0; l < L; ++l) {
+        if (MASS == HTA_MASS_FULL) {
+          f2 nd[NP]; float ndS = dS;
+#pragma unroll
+          for (int j = 0; j < NP; ++j) nd[j] = dP[j];
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            const float pk = (k < 2 * NP) ? pP[k / 2][k % 2] : pS;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) nd[j] = __builtin_elementwise_fma(EP[k][j], f2{pk, pk}, nd[j]);
+            if (R) ndS = fmaf(ES[k], pk, ndS);
+          }
+#pragma unroll
+          for (int j = 0; j < NP; ++j) dP[j] = nd[j];
+          dS = ndS;
+        } else {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) dP[j] = __builtin_elementwise_fma(eP[j], pP[j], dP[j]);
+          if (R) dS = fmaf(eS, pS, dS);
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const float dk = (k < 2 * NP) ? dP[k / 2][k % 2] : dS;
+#pragma unroll
+          for (int j = 0; j < NP; ++j) pP[j] = __builtin_elementwise_fma(AP[k][j], f2{dk, dk}, pP[j]);
+          if (R) pS = fmaf(AS[k], dk, pS);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NP; ++j) { d[2 * j] = dP[j].x; d[2 * j + 1] = dP[j].y; p[2 * j] = pP[j].x; p[2 * j + 1] = pP[j].y; }
+      if (R) { d[D - 1] = dS; p[D - 1] = pS; }
+    } else {
+#pragma unroll 5
+      for (int l = 0; l < L; ++l) step(d, p);
+    }
+  }
+  // leapfrog (S:281-302) on d = q - mu.  Pd: in = P d at the start, out = P d at the end.
+  // Returns 0.5 d^T P d at the end point.
   template <bool REC = false>
-  __device__ __forceinline__ T leapfrog(T (&q)[D], T (&p)[D], T (&Pd)[D], int L, T eps, T* rec_q = nullptr,
+  __device__ __forceinline__ T leapfrog(T (&d)[D], T (&p)[D], T (&Pd)[D], int L, T* rec_q = nullptr,
                                         T* rec_p = nullptr, int64_t rec_stride = 0) const {
     const T he = (T)0.5 * eps;
-    T quad = 0;
 #pragma unroll
     for (int i = 0; i < D; ++i) p[i] -= he * Pd[i];                 // S:281
-    for (int l = 0; l < L; ++l) {
-      T v[D]; vel(p, v);
+    if (REC) {
+      for (int l = 0; l < L; ++l) {
+        step(d, p);                                                  // S:283-298
 #pragma unroll
-      for (int i = 0; i < D; ++i) q[i] = q[i] + eps * v[i];         // S:284 / S:294 / S:296
-      quad = curv(q, Pd);                                            // S:297
-#pragma unroll
-      for (int i = 0; i < D; ++i) p[i] -= eps * Pd[i];              // S:298
-      if (REC) {                                                     // S:299-300
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-          if (rec_q) rec_q[l * rec_stride + i] = q[i];
+        for (int i = 0; i < D; ++i) {                                // S:299-300
+          if (rec_q) rec_q[l * rec_stride + i] = d[i] + mu[i];
           if (rec_p) rec_p[l * rec_stride + i] = p[i];
         }
       }
+    } else {
+      run_steps(d, p, L);
     }
+    const T quad = curv_d(d, Pd);
 #pragma unroll
     for (int i = 0; i < D; ++i) p[i] += he * Pd[i];                 // S:302
     return quad;
   }
 };
 
-template <typename T, int D, int MASS>
-__global__ void hmc_gauss_small_kernel(GaussArgs<T> a) {
+// draws of one trajectory for one chain: D normals + log(u)
+template <typename T, int D>
+__device__ __forceinline__ void draw_inline(uint64_t seed, uint64_t chain, uint32_t n, T (&z)[D], T& logu) {
+  constexpr int NQ = (D + 3) / 4;
+#pragma unroll
+  for (int b = 0; b < NQ; ++b) {
+    T zz[4];
+    normal4<T>(philox_block(seed, chain, n, PURPOSE_MOMENTUM, 0, b), zz);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (4 * b + i < D) z[4 * b + i] = zz[i];
+  }
+  logu = log(u23<T>(philox_block(seed, chain, n, PURPOSE_MH, 0, 0).x));
+}
+
+// workspace: record [t][c] of rec_elems<T,D>() values = (z_0 .. z_{D-1}, log u, padding)
+template <typename T, int D>
+__global__ void rng_fill_small_kernel(T* __restrict__ ws, int64_t C, int n_traj, int traj_offset, uint64_t seed,
+                                      uint64_t chain_offset) {
+  constexpr int W = rec_elems<T, D>();
+  typedef typename RecVec<T>::type V;
+  const int64_t total = C * n_traj;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = idx / C, c = idx - t * C;
+    T rec[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) rec[i] = 0;
+    T z[D], lu;
+    draw_inline<T, D>(seed, chain_offset + (uint64_t)c, (uint32_t)(traj_offset + (int)t), z, lu);
+#pragma unroll
+    for (int j = 0; j < D; ++j) rec[j] = z[j];
+    rec[D] = lu;
+    V* out = reinterpret_cast<V*>(ws + idx * W);
+#pragma unroll
+    for (int i = 0; i < W / RecVec<T>::N; ++i) {
+      V v;
+#pragma unroll
+      for (int e = 0; e < RecVec<T>::N; ++e) v[e] = rec[i * RecVec<T>::N + e];
+      out[i] = v;
+    }
+  }
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void load_record(const T* __restrict__ ws, size_t rec_index, T (&z)[D], T& logu) {
+  constexpr int W = rec_elems<T, D>();
+  typedef typename RecVec<T>::type V;
+  const V* in = reinterpret_cast<const V*>(ws + rec_index * W);
+  T rec[W];
+#pragma unroll
+  for (int i = 0; i < W / RecVec<T>::N; ++i) {
+    const V v = in[i];
+#pragma unroll
+    for (int e = 0; e < RecVec<T>::N; ++e) rec[i * RecVec<T>::N + e] = v[e];
+  }
+#pragma unroll
+  for (int j = 0; j < D; ++j) z[j] = rec[j];
+  logu = rec[D];
+}
+
+template <typename T, int D, int MASS, bool WS, bool DIAG>
+__global__ __launch_bounds__(256) void hmc_gauss_small_kernel(GaussArgs<T> a) {
   const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c >= a.C) return;
   SmallModel<T, D, MASS> m;
   m.load(a, true);
-  T th[D];
+  const size_t C = (size_t)a.C;
+  T th[D], dc[D], Pdc[D];
 #pragma unroll
-  for (int i = 0; i < D; ++i) th[i] = a.theta[c * D + i];
+  for (int i = 0; i < D; ++i) { th[i] = a.theta[c * D + i]; dc[i] = th[i] - m.mu[i]; }
+  T quadc = m.curv_d(dc, Pdc);        // potential state at the current point, carried across trajectories
   const uint64_t chain = a.chain_offset + (uint64_t)c;
+  const T he = (T)0.5 * m.eps;
   int32_t rejected = 0;
-  constexpr int NQ = (D + 3) / 4;
 
+  T z[D], logu = 0;
+  const T* rec = a.ws_z + (size_t)c * rec_elems<T, D>();   // this chain's record of trajectory t (+1 row of slack)
+  const size_t rec_step = C * rec_elems<T, D>();
+  if (WS) load_record<T, D>(rec, 0, z, logu);
+  // Sample rows.  CDNA's vmcnt counts stores as well as loads, and the compiler sizes the wait for the
+  // pre-fetched record by the path with the FEWEST memory operations behind it.  So every trajectory
+  // issues exactly D stores (to its sample row, or -- while n <= burn / no sample buffer -- to this
+  // chain's slot of `theta`, which is rewritten at the end anyway), and the same D stores are issued
+  // once before the loop: the wait then becomes vmcnt(D+1) on every path instead of stalling each
+  // trajectory on the previous trajectory's stores (~350 ns, profiles/r01_cfg2_*).
+  T* const scratch_row = a.theta + c * D;
+  T* srow = a.samples ? a.samples + ((size_t)(a.traj_offset > a.burn ? a.traj_offset - a.burn : 1) * C + c) * D
+                      : scratch_row;
+  const size_t srow_step = a.samples ? C * D : 0;
+#pragma unroll
+  for (int i = 0; i < D; ++i) scratch_row[i] = th[i];
   for (int t = 0; t < a.n_traj; ++t) {
     const int n = a.traj_offset + t;
-    // ---- gibbs: p ~ N(0, M)  (S:185-202)
-    T z[NQ * 4];
-#pragma unroll
-    for (int b = 0; b < NQ; ++b) {
-      T zz[4];
-      normal4<T>(philox_block(a.seed, chain, (uint32_t)n, PURPOSE_MOMENTUM, 0, b), zz);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) z[4 * b + i] = zz[i];
+    T zn[D], logun = 0;
+    if (WS) {          // next trajectory's draws: issued now, consumed after this trajectory's leapfrog
+      rec += rec_step;
+      load_record<T, D>(rec, 0, zn, logun);
+    } else {
+      draw_inline<T, D>(a.seed, chain, (uint32_t)n, z, logu);
     }
+    // ---- gibbs: p ~ N(0, M)  (S:185-202)
     T p[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -151,37 +325,50 @@ __global__ void hmc_gauss_small_kernel(GaussArgs<T> a) {
         p[i] = acc; }
     }
     // ---- H_old (S:971)
-    T q[D], Pd[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) q[i] = th[i];
-    const T quad0 = m.curv(q, Pd);
-    const T h_old = -(a.log_norm - quad0) + m.kinetic(p);
+    const T h_old = -(a.log_norm - quadc) + m.kinetic(p);
     // ---- leapfrog (S:973)
-    const T quad1 = m.leapfrog(q, p, Pd, a.L, a.eps);
+    T d[D], Pd[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) { d[i] = dc[i]; p[i] -= he * Pdc[i]; }   // S:281
+    m.run_steps(d, p, a.L);                                                // S:283-298
+    const T quad1 = m.curv_d(d, Pd);
+#pragma unroll
+    for (int i = 0; i < D; ++i) p[i] += he * Pd[i];                       // S:302
     // ---- H_new (S:995), MH (S:1000-1004)
     const T logp1 = a.log_norm - quad1;
     const T h_new = -logp1 + m.kinetic(p);
-    const T u = u23<T>(philox_block(a.seed, chain, (uint32_t)n, PURPOSE_MH, 0, 0).x);
-    const bool acc = mh_accept<T>(h_old, h_new, logp1, u);
+    const bool acc = mh_accept_logu<T>(h_old, h_new, logp1, logu);
     // ---- bookkeeping (S:1007-1026; Q2 reset at n == burn+1)
-    if (acc) {
+    rejected += acc ? 0 : 1;
 #pragma unroll
-      for (int i = 0; i < D; ++i) th[i] = q[i];
-    } else {
-      ++rejected;
-      if (n == a.burn + 1) {
-#pragma unroll
-        for (int i = 0; i < D; ++i) th[i] = a.theta_init[c * D + i];
-      }
+    for (int i = 0; i < D; ++i) {
+      th[i] = acc ? d[i] + m.mu[i] : th[i];
+      dc[i] = acc ? d[i] : dc[i];
+      Pdc[i] = acc ? Pd[i] : Pdc[i];
     }
-    if (a.samples && n > a.burn) {
-      T* row = a.samples + ((int64_t)(n - a.burn) * a.C + c) * D;
+    quadc = acc ? quad1 : quadc;
+    if (n == a.burn + 1 && !acc) {
 #pragma unroll
-      for (int i = 0; i < D; ++i) row[i] = th[i];
+      for (int i = 0; i < D; ++i) { th[i] = a.theta_init[c * D + i]; dc[i] = th[i] - m.mu[i]; }
+      quadc = m.curv_d(dc, Pdc);
     }
-    if (a.H_old) a.H_old[(int64_t)t * a.C + c] = h_old;
-    if (a.H_new) a.H_new[(int64_t)t * a.C + c] = h_new;
-    if (a.accept) a.accept[(int64_t)t * a.C + c] = acc ? 1 : 0;
+    {
+      const bool keep = n > a.burn;
+      T* dst = keep ? srow : scratch_row;
+#pragma unroll
+      for (int i = 0; i < D; ++i) dst[i] = th[i];
+      srow += keep ? srow_step : 0;
+    }
+    if (DIAG) {
+      if (a.H_old) a.H_old[(size_t)t * C + c] = h_old;
+      if (a.H_new) a.H_new[(size_t)t * C + c] = h_new;
+      if (a.accept) a.accept[(size_t)t * C + c] = acc ? 1 : 0;
+    }
+    if (WS) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) z[j] = zn[j];
+      logu = logun;
+    }
   }
 #pragma unroll
   for (int i = 0; i < D; ++i) a.theta[c * D + i] = th[i];
@@ -194,15 +381,15 @@ __global__ void leapfrog_gauss_small_kernel(GaussArgs<T> a) {
   if (c >= a.C) return;
   SmallModel<T, D, MASS> m;
   m.load(a, false);
-  T q[D], p[D], Pd[D];
+  T d[D], p[D], Pd[D];
 #pragma unroll
-  for (int i = 0; i < D; ++i) { q[i] = a.theta[c * D + i]; p[i] = a.p_io[c * D + i]; }
-  m.curv(q, Pd);
-  m.template leapfrog<true>(q, p, Pd, a.L, a.eps, a.path_theta ? a.path_theta + c * D : nullptr,
+  for (int i = 0; i < D; ++i) { d[i] = a.theta[c * D + i] - m.mu[i]; p[i] = a.p_io[c * D + i]; }
+  m.curv_d(d, Pd);
+  m.template leapfrog<true>(d, p, Pd, a.L, a.path_theta ? a.path_theta + c * D : nullptr,
                             a.path_p ? a.path_p + c * D : nullptr, a.C * D);
 #pragma unroll
   for (int i = 0; i < D; ++i) {
-    a.theta[c * D + i] = q[i]; a.p_io[c * D + i] = p[i];
+    a.theta[c * D + i] = d[i] + m.mu[i]; a.p_io[c * D + i] = p[i];
     if (a.path_p && a.L > 0) a.path_p[((int64_t)(a.L - 1) * a.C + c) * D + i] = p[i];  // S:302
   }
 }
@@ -420,8 +607,17 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void leapfrog_gauss_wave_kernel(Gau
 template <typename T, int D, int MASS> void launch_small(const GaussArgs<T>& a, bool lf_only, hipStream_t s) {
   int block = g_small_chains_per_block > 0 ? g_small_chains_per_block : 64;
   const int grid = (int)((a.C + block - 1) / block);
-  if (lf_only) leapfrog_gauss_small_kernel<T, D, MASS><<<grid, block, 0, s>>>(a);
-  else hmc_gauss_small_kernel<T, D, MASS><<<grid, block, 0, s>>>(a);
+  if (lf_only) { leapfrog_gauss_small_kernel<T, D, MASS><<<grid, block, 0, s>>>(a); return; }
+  const bool diag = a.H_old || a.H_new || a.accept;
+  profile_begin(s);
+  if (a.ws_z) {
+    if (diag) hmc_gauss_small_kernel<T, D, MASS, true, true><<<grid, block, 0, s>>>(a);
+    else hmc_gauss_small_kernel<T, D, MASS, true, false><<<grid, block, 0, s>>>(a);
+  } else {
+    if (diag) hmc_gauss_small_kernel<T, D, MASS, false, true><<<grid, block, 0, s>>>(a);
+    else hmc_gauss_small_kernel<T, D, MASS, false, false><<<grid, block, 0, s>>>(a);
+  }
+  profile_end(s);
 }
 template <typename T, int D> void launch_small_m(const GaussArgs<T>& a, int kind, bool lf, hipStream_t s) {
   if (kind == HTA_MASS_NONE) launch_small<T, D, HTA_MASS_NONE>(a, lf, s);
@@ -431,8 +627,10 @@ template <typename T, int D> void launch_small_m(const GaussArgs<T>& a, int kind
 template <typename T, int R, int MASS> void launch_wave(const GaussArgs<T>& a, bool lf_only, hipStream_t s) {
   const int grid = (int)((a.C + GEN_WAVES - 1) / GEN_WAVES);
   const size_t lds = (size_t)GEN_WAVES * 64 * R * sizeof(T);
-  if (lf_only) leapfrog_gauss_wave_kernel<T, R, MASS><<<grid, 64 * GEN_WAVES, lds, s>>>(a);
-  else hmc_gauss_wave_kernel<T, R, MASS><<<grid, 64 * GEN_WAVES, lds, s>>>(a);
+  if (lf_only) { leapfrog_gauss_wave_kernel<T, R, MASS><<<grid, 64 * GEN_WAVES, lds, s>>>(a); return; }
+  profile_begin(s);
+  hmc_gauss_wave_kernel<T, R, MASS><<<grid, 64 * GEN_WAVES, lds, s>>>(a);
+  profile_end(s);
 }
 template <typename T, int R> void launch_wave_m(const GaussArgs<T>& a, int kind, bool lf, hipStream_t s) {
   if (kind == HTA_MASS_NONE) launch_wave<T, R, HTA_MASS_NONE>(a, lf, s);
@@ -440,7 +638,26 @@ template <typename T, int R> void launch_wave_m(const GaussArgs<T>& a, int kind,
   else launch_wave<T, R, HTA_MASS_FULL>(a, lf, s);
 }
 
-template <typename T> int gaussian_dispatch(const GaussArgs<T>& a, int kind, bool lf_only, hipStream_t s) {
+// pre-draw pass: all momenta / log-uniforms of the launch, one thread per (trajectory, chain)
+template <typename T, int D> static void launch_rng_fill_d(const GaussArgs<T>& a, hipStream_t s) {
+  const int64_t total = a.C * a.n_traj;
+  int64_t g = (total + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  rng_fill_small_kernel<T, D><<<(int)g, 256, 0, s>>>(a.ws_z, a.C, a.n_traj, a.traj_offset, a.seed, a.chain_offset);
+}
+template <typename T> static void launch_rng_fill(const GaussArgs<T>& a, hipStream_t s) {
+  switch (a.D) {
+    case 1: launch_rng_fill_d<T, 1>(a, s); break;
+    case 2: launch_rng_fill_d<T, 2>(a, s); break;
+    case 3: launch_rng_fill_d<T, 3>(a, s); break;
+    case 4: launch_rng_fill_d<T, 4>(a, s); break;
+    case 5: launch_rng_fill_d<T, 5>(a, s); break;
+    default: launch_rng_fill_d<T, 6>(a, s); break;
+  }
+}
+
+template <typename T> int gaussian_dispatch(const GaussArgs<T>& a_in, int kind, bool lf_only, hipStream_t s) {
+  GaussArgs<T> a = a_in;
   const char* who = lf_only ? "hta_hmc_gaussian_leapfrog" : "hta_hmc_gaussian_sample";
   HTA_REQUIRE(a.theta && a.P && a.mu, "%s: NULL state/model pointer", who);
   HTA_REQUIRE(a.C > 0 && a.D > 0 && a.D <= 1024, "%s: need C > 0 and 1 <= D <= 1024 (C=%lld D=%d)", who,
@@ -453,17 +670,18 @@ template <typename T> int gaussian_dispatch(const GaussArgs<T>& a, int kind, boo
   if (a.n_traj == 0 && !lf_only) return HTA_OK;
   const int D = a.D;
   // f64 models past D=4 overflow the SGPR file (P alone is 2*D*D SGPRs) and would spill to scratch
-  const int small_max = sizeof(T) == 8 ? 4 : 8;
-  if (D <= small_max && !g_force_general) {
+  const int small_max = sizeof(T) == 8 ? 4 : 6;  // 2*D*D + 3*D wave-uniform operands must fit the SGPR file
+  const bool reg_resident = D <= small_max && !g_force_general;
+  if (a.ws_z && reg_resident && !lf_only) launch_rng_fill<T>(a, s);
+  else { a.ws_z = nullptr; a.ws_logu = nullptr; }
+  if (reg_resident) {
     switch (D) {
       case 1: launch_small_m<T, 1>(a, kind, lf_only, s); break;
       case 2: launch_small_m<T, 2>(a, kind, lf_only, s); break;
       case 3: launch_small_m<T, 3>(a, kind, lf_only, s); break;
       case 4: launch_small_m<T, 4>(a, kind, lf_only, s); break;
-      case 5: launch_small_m<T, 5>(a, kind, lf_only, s); break;
-      case 6: launch_small_m<T, 6>(a, kind, lf_only, s); break;
-      case 7: launch_small_m<T, 7>(a, kind, lf_only, s); break;
-      default: launch_small_m<T, 8>(a, kind, lf_only, s); break;
+      case 5: if constexpr (sizeof(T) == 4) launch_small_m<T, 5>(a, kind, lf_only, s); break;
+      default: if constexpr (sizeof(T) == 4) launch_small_m<T, 6>(a, kind, lf_only, s); break;
     }
   } else {
     const int R = (D + 63) / 64;
@@ -481,22 +699,34 @@ template <typename T> int gaussian_dispatch(const GaussArgs<T>& a, int kind, boo
 
 extern "C" {
 
+int64_t hta_hmc_gaussian_workspace_bytes(int64_t C, int D, int n_traj, int elem_size) {
+  const int per_vec = 16 / elem_size;
+  const int64_t rec = ((int64_t)(D + 1 + per_vec - 1) / per_vec) * per_vec;
+  return ((int64_t)n_traj + 1) * C * rec * elem_size;   /* + one row read ahead by the last trajectory */
+}
+
 #define HTA_DEFINE_GAUSS(SUF, T)                                                                               \
   int hta_hmc_gaussian_sample_##SUF(T* theta, const T* theta_init, const T* P, const T* mu, T log_norm,         \
                                     int mass_kind, const T* inv_mass, const T* mass_factor, int64_t C, int D,   \
                                     int L, T eps, int n_traj, int traj_offset, int burn, uint64_t seed,         \
                                     uint64_t chain_offset, T* samples, int32_t* reject_count, T* H_old,         \
-                                    T* H_new, uint8_t* accept, void* stream) {                                  \
+                                    T* H_new, uint8_t* accept, void* workspace, int64_t workspace_bytes,        \
+                                    void* stream) {                                                             \
     hta::GaussArgs<T> a{theta, theta_init, P, mu, log_norm, inv_mass, mass_factor, C, D, L, eps, n_traj,         \
                         traj_offset, burn, seed, chain_offset, samples, reject_count, H_old, H_new, accept,     \
-                        nullptr, nullptr, nullptr};                                                                               \
+                        nullptr, nullptr, nullptr, nullptr, nullptr};                                           \
+    const int64_t need = hta_hmc_gaussian_workspace_bytes(C, D, n_traj, (int)sizeof(T));                       \
+    if (workspace && workspace_bytes >= need && need > 0) {                                                     \
+      a.ws_z = (T*)workspace;                                                                                   \
+      a.ws_logu = nullptr;                                                                                      \
+    }                                                                                                           \
     return hta::gaussian_dispatch<T>(a, mass_kind, false, (hipStream_t)stream);                                 \
   }                                                                                                             \
   int hta_hmc_gaussian_leapfrog_##SUF(T* theta, T* p, const T* P, const T* mu, int mass_kind, const T* inv_mass, \
                                       int64_t C, int D, int steps, T eps, T* path_theta, T* path_p,             \
                                       void* stream) {                                                           \
     hta::GaussArgs<T> a{theta, nullptr, P, mu, (T)0, inv_mass, nullptr, C, D, steps, eps, 0, 0, 0, 0, 0,         \
-                        nullptr, nullptr, nullptr, nullptr, nullptr, p, path_theta, path_p};                                        \
+                        nullptr, nullptr, nullptr, nullptr, nullptr, p, path_theta, path_p, nullptr, nullptr};  \
     return hta::gaussian_dispatch<T>(a, mass_kind, true, (hipStream_t)stream);                                  \
   }
 

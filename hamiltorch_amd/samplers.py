@@ -378,6 +378,8 @@ def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, 
 class _GaussianHMC:
     """Native path: one persistent-kernel launch runs every trajectory (csrc/hmc_gaussian.hip)."""
 
+    WS_CAP = 128 << 20
+
     def __init__(self, target: GaussianTarget):
         self.t = target
 
@@ -390,8 +392,18 @@ class _GaussianHMC:
         cur = theta0.clone()
         rejected = torch.zeros(C, dtype=torch.int32, device=theta0.device)
         prog = util._Progress('Sampling ' + label, N, verbose)
-        _abi.hmc_gaussian_sample(cur, theta0, self.t.precision, self.t.mean, self.t.log_norm, kind, im, mf, L, eps,
-                                 N, 0, burn, seed, chain_offset, samples, rejected)
+        # scratch for the pre-drawn momenta / log-uniforms of one launch (<= WS_CAP bytes, so it stays
+        # in the 256 MB Infinity Cache); long runs are cut into several launches over `traj_offset`
+        per_traj = _abi.gaussian_workspace_bytes(C, D, 1, theta0.element_size())
+        chunk = max(1, min(N, self.WS_CAP // per_traj)) if per_traj <= self.WS_CAP else N
+        ws = None
+        if per_traj <= self.WS_CAP:
+            ws = torch.empty(chunk * per_traj, dtype=torch.uint8, device=theta0.device)
+        for start in range(0, N, chunk):
+            _abi.hmc_gaussian_sample(cur, theta0, self.t.precision, self.t.mean, self.t.log_norm, kind, im, mf, L,
+                                     eps, min(chunk, N - start), start, burn, seed, chain_offset, samples, rejected,
+                                     workspace=ws)
+            prog.update(min(N, start + chunk) - 1)
         prog.end()
         return samples, rejected
 

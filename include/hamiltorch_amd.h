@@ -110,19 +110,26 @@ int hta_mh_select_f64(double* theta_cur, const double* theta_prop, const double*
  *               (row 0 = params_init is the caller's), as in S:1007-1024
  *   reject_count[C] in/out; H_old/H_new [n_traj,C] and accept [n_traj,C] optional diagnostics
  *   trajectory indices n = traj_offset .. traj_offset + n_traj - 1  (RNG draw index and burn test)
+ *   workspace   optional scratch of >= hta_hmc_gaussian_workspace_bytes(C, D, n_traj, sizeof(T)) bytes
+ *               (one 16-byte-aligned record [z_0..z_{D-1}, log u, pad] per trajectory and chain).  When given (and D is in
+ *               the register-resident range) all random draws of the launch are produced first by a
+ *               full-chip kernel and the latency-bound trajectory kernel only loads them; results are
+ *               identical to the inline-RNG path.  NULL = draw inline.
  * ------------------------------------------------------------------------------------------- */
 int hta_hmc_gaussian_sample_f32(float* theta, const float* theta_init, const float* P, const float* mu,
                                 float log_norm, int mass_kind, const float* inv_mass,
                                 const float* mass_factor, int64_t C, int D, int L, float eps, int n_traj,
                                 int traj_offset, int burn, uint64_t seed, uint64_t chain_offset,
                                 float* samples, int32_t* reject_count, float* H_old, float* H_new,
-                                uint8_t* accept, void* stream);
+                                uint8_t* accept, void* workspace, int64_t workspace_bytes, void* stream);
 int hta_hmc_gaussian_sample_f64(double* theta, const double* theta_init, const double* P, const double* mu,
                                 double log_norm, int mass_kind, const double* inv_mass,
                                 const double* mass_factor, int64_t C, int D, int L, double eps, int n_traj,
                                 int traj_offset, int burn, uint64_t seed, uint64_t chain_offset,
                                 double* samples, int32_t* reject_count, double* H_old, double* H_new,
-                                uint8_t* accept, void* stream);
+                                uint8_t* accept, void* workspace, int64_t workspace_bytes, void* stream);
+
+int64_t hta_hmc_gaussian_workspace_bytes(int64_t C, int D, int n_traj, int elem_size);
 
 /* leapfrog() only (S:267-304) for the same target: theta, p [C,D] in/out after `steps` steps.
  * path_theta / path_p: optional [steps,C,D] record of every step (the lists of S:299-300, last
@@ -135,9 +142,12 @@ int hta_hmc_gaussian_leapfrog_f64(double* theta, double* p, const double* P, con
                                   const double* inv_mass, int64_t C, int D, int steps, double eps,
                                   double* path_theta, double* path_p, void* stream);
 
-/* launch-shape knob for the fused kernels (measurement only): chains per 64-lane wave for the
- * small-D thread-per-chain kernel.  0 = default. */
+/* measurement knobs: "small_chains_per_block" (launch shape of the thread-per-chain kernel),
+ * "force_general" (route small D through the wave-per-chain kernel), "profile" (1 = record a HIP
+ * event pair around the dominant kernel of every fused call, on the launch stream). */
 int hta_set_tuning(const char* key, int value);
+/* waits for the recorded event pairs; returns their summed elapsed time and count, then resets. */
+int hta_profile_collect(double* total_ms, int* launches);
 
 #ifdef __cplusplus
 }

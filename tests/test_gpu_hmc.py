@@ -253,3 +253,42 @@ def test_multi_chain_adapters(ht):
     assert len(res_b) == 3 and len(res_b[0]) == 8 and res_b[2][0].shape == (3,)
     # same seed -> same params_init as the serial adapter
     assert torch.equal(res_b[1][0], res[1][0])
+
+
+@pytest.mark.parametrize("D,mass", [(3, "none"), (5, "diag"), (4, "full")])
+def test_predrawn_workspace_equals_inline_rng(ht, D, mass):
+    """The full-chip RNG pre-pass + load path must reproduce the inline-draw path (same Philox stream)."""
+    from hamiltorch_amd import _abi
+    from hamiltorch_amd.samplers import _mass_operands
+    dtype = torch.float32
+    t, _ = targets(ht, rand_spd(D, 11), dtype)
+    C, N, L, eps = 200, 40, 6, 0.2
+    th0 = tt(np.random.default_rng(0).standard_normal((C, D)), dtype)
+    kind, im, mf = _mass_operands(tt(masses(D, dtype)[mass], dtype), th0)
+    outs = []
+    for use_ws in (False, True):
+        cur = th0.clone()
+        samples = torch.zeros(N + 1, C, D, device=dev())
+        rej = torch.zeros(C, dtype=torch.int32, device=dev())
+        ws = torch.empty(_abi.gaussian_workspace_bytes(C, D, N, 4), dtype=torch.uint8, device=dev()) if use_ws else None
+        _abi.hmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, kind, im, mf, L, eps, N, 0, -1, 77, 5,
+                                 samples, rej, workspace=ws)
+        outs.append((samples, rej))
+    assert torch.equal(outs[0][1], outs[1][1])
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_chunked_launches_equal_single_launch(ht):
+    """sample() cuts long runs into several launches over traj_offset: same chain either way."""
+    from hamiltorch_amd import samplers
+    t, _ = targets(ht, np.linalg.inv(SIGMA3), torch.float32)
+    th0 = tt(np.random.default_rng(1).standard_normal((64, 3)), torch.float32)
+    kw = dict(num_samples=50, num_steps_per_sample=5, step_size=0.3, burn=7, verbose=False, seed=5)
+    a = torch.stack(ht.sample(t, th0, **kw))
+    old = samplers._GaussianHMC.WS_CAP
+    try:
+        samplers._GaussianHMC.WS_CAP = 64 * 4 * 4 * 9        # room for 9 trajectories per launch
+        b = torch.stack(ht.sample(t, th0, **kw))
+    finally:
+        samplers._GaussianHMC.WS_CAP = old
+    assert torch.equal(a, b)
