@@ -29,6 +29,19 @@ class HtaDeviceInfo(ctypes.Structure):
                 ("lds_bytes_per_cu", c_int), ("clock_khz", c_int), ("hbm_bytes", c_i64), ("arch", ctypes.c_char * 64)]
 
 
+class HtaMetricArgs(ctypes.Structure):
+    """include/hamiltorch_amd.h: HtaMetricArgs."""
+    _fields_ = [("B", c_i64), ("D", ctypes.c_int32), ("metric", ctypes.c_int32), ("Hs", c_vp), ("hs_stride", c_i64),
+                ("alpha", c_f64), ("has_jitter", ctypes.c_int32), ("max_sweeps", ctypes.c_int32), ("jitter", c_f64),
+                ("seed", c_u64), ("chain_offset", c_u64), ("draw", c_u32), ("sub", c_u32), ("X", c_vp), ("Pm", c_vp),
+                ("mu", c_vp), ("log_norm", c_f64), ("m", c_vp), ("p_out", c_vp), ("x_out", c_vp), ("G_out", c_vp),
+                ("lam_out", c_vp), ("V_out", c_vp), ("L_out", c_vp), ("logdet_out", c_vp), ("quad_out", c_vp),
+                ("H_out", c_vp), ("logp_out", c_vp), ("upd_x", c_vp), ("cx", c_f64), ("upd_g", c_vp), ("cg", c_f64)]
+
+
+METRIC_HESSIAN, METRIC_SOFTABS = 0, 1
+
+
 def _sig(scalar):
     """argtypes of the dtype-suffixed entry points (scalar = c_float | c_double)."""
     return {
@@ -41,12 +54,18 @@ def _sig(scalar):
                                     c_int, c_int, c_int, c_u64, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
         "hta_hmc_gaussian_leapfrog": [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_int, c_int, scalar, c_vp, c_vp,
                                       c_vp],
+        "hta_metric_eval": [ctypes.POINTER(HtaMetricArgs), c_vp],
+        "hta_rmhmc_gaussian_leapfrog": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_f64, c_int, c_f64, c_u64, c_u64,
+                                        c_u32, c_i64, c_int, c_int, c_f64, c_f64, c_vp, c_vp, c_vp],
+        "hta_rmhmc_gaussian_sample": [c_vp, c_vp, c_vp, c_vp, c_f64, c_int, c_f64, c_int, c_f64, c_i64, c_int, c_int,
+                                      c_f64, c_f64, c_int, c_int, c_int, c_u64, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                      c_vp, c_i64, c_vp],
     }
 
 
 #: every symbol include/hamiltorch_amd.h declares (checked by tests/test_abi_symbols.py)
 PLAIN_SYMBOLS = ["hta_abi_version", "hta_last_error", "hta_device_info", "hta_set_tuning", "hta_profile_collect",
-                 "hta_hmc_gaussian_workspace_bytes"]
+                 "hta_hmc_gaussian_workspace_bytes", "hta_rmhmc_workspace_bytes"]
 TYPED_SYMBOLS = sorted(_sig(c_f32).keys())
 
 
@@ -71,6 +90,8 @@ def load():
         lib.hta_profile_collect.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]
         lib.hta_hmc_gaussian_workspace_bytes.argtypes = [c_i64, c_int, c_int, c_int]
         lib.hta_hmc_gaussian_workspace_bytes.restype = c_i64
+        lib.hta_rmhmc_workspace_bytes.argtypes = [c_i64, c_int, c_int]
+        lib.hta_rmhmc_workspace_bytes.restype = c_i64
         for suf, scalar in (("f32", c_f32), ("f64", c_f64)):
             for name, args in _sig(scalar).items():
                 fn = getattr(lib, "%s_%s" % (name, suf))
@@ -207,3 +228,58 @@ def hmc_gaussian_leapfrog(theta, p, P, mu, mass_kind, inv_mass, steps, eps, path
         _check(fn(_p(theta), _p(p, theta), _p(P, theta), _p(mu, theta), mass_kind, _p(inv_mass, theta), C, D,
                   int(steps), float(eps), _p(path_theta, theta), _p(path_p, theta), _stream(theta)),
                "hta_hmc_gaussian_leapfrog")
+
+
+# ---- RMHMC ---------------------------------------------------------------------------------------
+def metric_eval(like, B, D, metric, Hs, hs_stride, alpha, jitter=None, seed=0, chain_offset=0, draw=0, sub=0, X=None,
+                Pm=None, mu=None, log_norm=0.0, m=None, p_out=None, x_out=None, G_out=None, lam_out=None, V_out=None,
+                L_out=None, logdet_out=None, quad_out=None, H_out=None, logp_out=None, upd_x=None, cx=0.0, upd_g=None,
+                cg=0.0, max_sweeps=0):
+    """One batched metric evaluation (see HtaMetricArgs in include/hamiltorch_amd.h).  `like` fixes dtype/device."""
+    require_device(like, "params")
+    a = HtaMetricArgs()
+    a.B, a.D, a.metric, a.hs_stride, a.alpha = int(B), int(D), int(metric), int(hs_stride), float(alpha if alpha is not None else 0.0)
+    a.has_jitter, a.jitter, a.max_sweeps = (0, 0.0, int(max_sweeps)) if jitter is None else (1, float(jitter), int(max_sweeps))
+    a.seed, a.chain_offset, a.draw, a.sub = int(seed), int(chain_offset), int(draw) & 0xFFFFFFFF, int(sub)
+    a.log_norm, a.cx, a.cg = float(log_norm), float(cx), float(cg)
+    keep = []
+    for name, t in (("Hs", Hs), ("X", X), ("Pm", Pm), ("mu", mu), ("m", m), ("p_out", p_out), ("x_out", x_out),
+                    ("G_out", G_out), ("lam_out", lam_out), ("V_out", V_out), ("L_out", L_out),
+                    ("logdet_out", logdet_out), ("quad_out", quad_out), ("H_out", H_out), ("logp_out", logp_out),
+                    ("upd_x", upd_x), ("upd_g", upd_g)):
+        setattr(a, name, None if t is None else _p(t, like).value)
+        keep.append(t)
+    fn = getattr(load(), "hta_metric_eval_" + _suffix(like))
+    with torch.cuda.device(like.device):
+        _check(fn(ctypes.byref(a), _stream(like)), "hta_metric_eval")
+
+
+def rmhmc_workspace_bytes(C, D, itemsize):
+    return int(load().hta_rmhmc_workspace_bytes(int(C), int(D), int(itemsize)))
+
+
+def rmhmc_gaussian_leapfrog(theta, p, theta_c, p_c, P, mu, metric, alpha, jitter, seed, chain_offset, draw, steps, eps,
+                            omega, path_theta=None, path_p=None):
+    require_device(theta, "params")
+    C, D = theta.shape
+    fn = getattr(load(), "hta_rmhmc_gaussian_leapfrog_" + _suffix(theta))
+    with torch.cuda.device(theta.device):
+        _check(fn(_p(theta), _p(p, theta), _p(theta_c, theta), _p(p_c, theta), _p(P, theta), _p(mu, theta), int(metric),
+                  float(alpha if alpha is not None else 0.0), 0 if jitter is None else 1,
+                  0.0 if jitter is None else float(jitter), int(seed), int(chain_offset), int(draw) & 0xFFFFFFFF, C, D,
+                  int(steps), float(eps), float(omega), _p(path_theta, theta), _p(path_p, theta), _stream(theta)),
+               "hta_rmhmc_gaussian_leapfrog")
+
+
+def rmhmc_gaussian_sample(theta, theta_init, P, mu, log_norm, metric, alpha, jitter, L, eps, omega, n_traj, traj_offset,
+                          burn, seed, chain_offset, samples, reject_count, workspace, H_old=None, H_new=None, accept=None):
+    require_device(theta, "params")
+    C, D = theta.shape
+    fn = getattr(load(), "hta_rmhmc_gaussian_sample_" + _suffix(theta))
+    with torch.cuda.device(theta.device):
+        _check(fn(_p(theta), _p(theta_init, theta), _p(P, theta), _p(mu, theta), float(log_norm), int(metric),
+                  float(alpha if alpha is not None else 0.0), 0 if jitter is None else 1,
+                  0.0 if jitter is None else float(jitter), C, D, int(L), float(eps), float(omega), int(n_traj),
+                  int(traj_offset), int(burn), int(seed), int(chain_offset), _p(samples, theta), _p(reject_count),
+                  _p(H_old, theta), _p(H_new, theta), _p(accept), c_vp(workspace.data_ptr()),
+                  workspace.numel() * workspace.element_size(), _stream(theta)), "hta_rmhmc_gaussian_sample")

@@ -3,6 +3,7 @@
 // chains: theta[C,D], p[C,D] chain-major.  All are single-pass, HBM-bound, coalesced.
 #include "common.hpp"
 #include "philox.hpp"
+#include "rmhmc.hpp"
 
 namespace hta {
 
@@ -216,6 +217,11 @@ int mh_select(T* cur, const T* prop, const T* init, const T* Ho, const T* Hn, co
   HTA_CHECK_LAUNCH("hta_mh_select");
   return HTA_OK;
 }
+
+template int mh_select<float>(float*, const float*, const float*, const float*, const float*, const float*, float*,
+                              int32_t*, uint8_t*, int64_t, int, int, int, uint64_t, uint64_t, hipStream_t);
+template int mh_select<double>(double*, const double*, const double*, const double*, const double*, const double*,
+                               double*, int32_t*, uint8_t*, int64_t, int, int, int, uint64_t, uint64_t, hipStream_t);
 
 }  // namespace hta
 

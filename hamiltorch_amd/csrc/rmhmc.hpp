@@ -1,0 +1,29 @@
+// Shared declarations of the RMHMC sources (rmhmc_metric.hip, rmhmc_explicit.hip, hmc_pieces.hip).
+#pragma once
+#include "common.hpp"
+
+namespace hta {
+
+template <typename T> struct MetricArgsT {   // typed view of HtaMetricArgs (include/hamiltorch_amd.h)
+  int64_t B; int32_t D; int32_t metric;
+  const T* Hs; int64_t hs_stride;
+  double alpha;
+  int32_t has_jitter; int32_t max_sweeps; double jitter; uint64_t seed; uint64_t chain_offset; uint32_t draw; uint32_t sub;
+  const T* X; const T* Pm; const T* mu; double log_norm;
+  const T* m;
+  T* p_out;
+  T* x_out; T* G_out; T* lam_out; T* V_out; T* L_out; T* logdet_out; T* quad_out; T* H_out; T* logp_out;
+  T* upd_x; double cx; T* upd_g; double cg;
+};
+static_assert(sizeof(MetricArgsT<float>) == sizeof(HtaMetricArgs), "HtaMetricArgs layout drifted from MetricArgsT");
+
+template <typename T> int metric_eval(const MetricArgsT<T>& a, hipStream_t s);
+
+template <typename T>
+int mh_select(T* cur, const T* prop, const T* init, const T* Ho, const T* Hn, const T* lpn, T* row, int32_t* rej,
+              uint8_t* acc, int64_t C, int D, int n, int burn, uint64_t seed, uint64_t off, hipStream_t s);
+
+void profile_begin(hipStream_t s);
+void profile_end(hipStream_t s);
+
+}  // namespace hta

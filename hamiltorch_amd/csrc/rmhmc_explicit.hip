@@ -1,0 +1,162 @@
+// Explicit (Tao 2016 / Cobb et al. 2019) RMHMC integrator and sampler for constant-curvature
+// (Gaussian) targets: hamiltorch/samplers.py:389-462 (leapfrog), :969-1026 (sample, RMHMC branch).
+//
+// Host-side driver: one C call ENQUEUES the whole sequence of launches of a run (no
+// synchronisation, accept/reject stays on the device).  Per step (S:427-461) with the duplicate
+// gradient calls of each half step evaluated once:
+//   phi_A/2 : p~.. one metric_eval launch: thc += eh G(th)^-1 pmc ;  pm  -= eh P (th  - mu)
+//   phi_B/2 : one launch:                 th  += eh G(thc)^-1 pm ;  pmc -= eh P (thc - mu)
+//   phi_C   : element-wise rotation with the reference's SEQUENTIAL update order (S:447-450, Q1)
+//   phi_B/2, phi_A/2 again.
+// dH/dtheta = -grad log p exactly because dG/dtheta == 0 for this family.
+// Jitter sub-streams follow the reference's call order: 0 gibbs, 1 initial H,
+// 2 + 8 l + {1, 2, 4, 7} the metric evaluations of step l, 2 + 8 L the final H.
+#include <math.h>
+#include "common.hpp"
+#include "rmhmc.hpp"
+
+namespace hta {
+
+template <typename T>
+__global__ void phi_c_kernel(T* __restrict__ th, T* __restrict__ pm, T* __restrict__ thc, T* __restrict__ pmc, T c,
+                             T s, int64_t total) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    T a = th[t], b = pm[t], ac = thc[t], bc = pmc[t];
+    const T h = (T)0.5;
+    a = h * ((a + ac) + c * (a - ac) + s * (b - bc));       // S:447 (old values)
+    b = h * ((b + bc) - s * (a - ac) + c * (b - bc));       // S:448 (NEW theta)
+    ac = h * ((a + ac) - c * (a - ac) - s * (b - bc));      // S:449 (NEW theta, NEW p)
+    bc = h * ((b + bc) + s * (a - ac) - c * (b - bc));      // S:450 (NEW theta, p, theta~)
+    th[t] = a; pm[t] = b; thc[t] = ac; pmc[t] = bc;
+  }
+}
+
+template <typename T> struct RmModel {
+  const T* P; const T* mu; double log_norm; int metric; double alpha; int has_jitter; double jitter;
+  uint64_t seed; uint64_t chain_offset; int64_t C; int D;
+};
+
+template <typename T> static MetricArgsT<T> base_args(const RmModel<T>& m, uint32_t draw, uint32_t sub) {
+  MetricArgsT<T> a;
+  memset(&a, 0, sizeof(a));
+  a.B = m.C; a.D = m.D; a.metric = m.metric; a.Hs = m.P; a.hs_stride = 0; a.alpha = m.alpha;
+  a.has_jitter = m.has_jitter; a.jitter = m.jitter; a.seed = m.seed; a.chain_offset = m.chain_offset;
+  a.draw = draw; a.sub = sub; a.Pm = m.P; a.mu = m.mu; a.log_norm = m.log_norm;
+  return a;
+}
+
+// one half step: upd_x += eh G(X)^-1 mvec ;  upd_g -= eh P (X - mu)
+template <typename T>
+static int half_step(const RmModel<T>& m, uint32_t draw, uint32_t sub, const T* X, const T* mvec, T* upd_x, T* upd_g,
+                     double eh, hipStream_t s) {
+  MetricArgsT<T> a = base_args(m, draw, sub);
+  a.X = X; a.m = mvec; a.upd_x = upd_x; a.cx = eh; a.upd_g = upd_g; a.cg = -eh;
+  return metric_eval<T>(a, s);
+}
+
+template <typename T>
+static int explicit_steps(const RmModel<T>& m, uint32_t draw, T* th, T* pm, T* thc, T* pmc, int steps, double eps,
+                          double omega, T* path_theta, T* path_p, hipStream_t s) {
+  const int64_t total = m.C * m.D;
+  const double eh = 0.5 * eps;
+  const float ang = (float)(2.0 * omega * eps);        // S:435-436: float32 cos / sin whatever the state dtype
+  const T c = (T)cosf(ang), sn = (T)sinf(ang);
+  int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;
+  for (int l = 0; l < steps; ++l) {
+    const uint32_t k0 = 2u + 8u * (uint32_t)l;
+    int rc;
+    if ((rc = half_step<T>(m, draw, k0 + 1, th, pmc, thc, pm, eh, s))) return rc;     // phi_A/2  S:429-430
+    if ((rc = half_step<T>(m, draw, k0 + 2, thc, pm, th, pmc, eh, s))) return rc;     // phi_B/2  S:432-433
+    phi_c_kernel<T><<<grid, 256, 0, s>>>(th, pm, thc, pmc, c, sn, total);             // phi_C    S:447-450
+    if ((rc = half_step<T>(m, draw, k0 + 4, thc, pm, th, pmc, eh, s))) return rc;     // phi_B/2  S:454-455
+    if ((rc = half_step<T>(m, draw, k0 + 7, th, pmc, thc, pm, eh, s))) return rc;     // phi_A/2  S:457-458
+    if (path_theta) (void)hipMemcpyAsync(path_theta + (int64_t)l * total, th, total * sizeof(T), hipMemcpyDeviceToDevice, s);
+    if (path_p) (void)hipMemcpyAsync(path_p + (int64_t)l * total, pm, total * sizeof(T), hipMemcpyDeviceToDevice, s);
+  }
+  HTA_CHECK_LAUNCH("hta_rmhmc_gaussian_leapfrog");
+  return HTA_OK;
+}
+
+template <typename T>
+int rmhmc_leapfrog(T* th, T* pm, T* thc, T* pmc, const T* P, const T* mu, int metric, double alpha, int has_jitter,
+                   double jitter, uint64_t seed, uint64_t chain_offset, uint32_t draw, int64_t C, int D, int steps,
+                   double eps, double omega, T* path_theta, T* path_p, hipStream_t s) {
+  HTA_REQUIRE(th && pm && thc && pmc && P && mu && C > 0 && D > 0 && steps >= 0, "hta_rmhmc_gaussian_leapfrog: bad arguments");
+  RmModel<T> m{P, mu, 0.0, metric, alpha, has_jitter, jitter, seed, chain_offset, C, D};
+  return explicit_steps<T>(m, draw, th, pm, thc, pmc, steps, eps, omega, path_theta, path_p, s);
+}
+
+template <typename T>
+int rmhmc_sample(T* cur, const T* theta_init, const T* P, const T* mu, double log_norm, int metric, double alpha,
+                 int has_jitter, double jitter, int64_t C, int D, int L, double eps, double omega, int n_traj,
+                 int traj_offset, int burn, uint64_t seed, uint64_t chain_offset, T* samples, int32_t* reject_count,
+                 T* H_old_out, T* H_new_out, uint8_t* accept_out, void* workspace, int64_t workspace_bytes,
+                 hipStream_t s) {
+  const char* who = "hta_rmhmc_gaussian_sample";
+  HTA_REQUIRE(cur && theta_init && P && mu && reject_count && C > 0 && D > 0 && L >= 0 && n_traj >= 0, "%s: bad arguments", who);
+  const int64_t total = C * D;
+  const int64_t need = (4 * total + 3 * C) * (int64_t)sizeof(T);
+  HTA_REQUIRE(workspace && workspace_bytes >= need, "%s: workspace of %lld bytes required", who, (long long)need);
+  T* th = (T*)workspace; T* pm = th + total; T* thc = pm + total; T* pmc = thc + total;
+  T* H0 = pmc + total; T* H1 = H0 + C; T* lp1 = H1 + C;
+  RmModel<T> m{P, mu, log_norm, metric, alpha, has_jitter, jitter, seed, chain_offset, C, D};
+  for (int t = 0; t < n_traj; ++t) {
+    const int n = traj_offset + t;
+    int rc;
+    {   // gibbs: p ~ N(0, G(theta))  (S:183-184)
+      MetricArgsT<T> a = base_args(m, (uint32_t)n, 0);
+      a.p_out = pm;
+      if ((rc = metric_eval<T>(a, s))) return rc;
+    }
+    {   // H_old = rm_hamiltonian(theta, p)  (S:971 -> S:822, halved at S:977)
+      MetricArgsT<T> a = base_args(m, (uint32_t)n, 1);
+      a.X = cur; a.m = pm; a.H_out = H0;
+      if ((rc = metric_eval<T>(a, s))) return rc;
+    }
+    (void)hipMemcpyAsync(th, cur, total * sizeof(T), hipMemcpyDeviceToDevice, s);     // S:425-426
+    (void)hipMemcpyAsync(thc, cur, total * sizeof(T), hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(pmc, pm, total * sizeof(T), hipMemcpyDeviceToDevice, s);
+    if ((rc = explicit_steps<T>(m, (uint32_t)n, th, pm, thc, pmc, L, eps, omega, nullptr, nullptr, s))) return rc;
+    {   // H_new on the un-augmented pair (S:989, Q4)
+      MetricArgsT<T> a = base_args(m, (uint32_t)n, 2u + 8u * (uint32_t)L);
+      a.X = th; a.m = pm; a.H_out = H1; a.logp_out = lp1;
+      if ((rc = metric_eval<T>(a, s))) return rc;
+    }
+    T* row = (samples && n > burn) ? samples + (int64_t)(n - burn) * total : nullptr;
+    if ((rc = mh_select<T>(cur, th, theta_init, H0, H1, lp1, row, reject_count,
+                           accept_out ? accept_out + (int64_t)t * C : nullptr, C, D, n, burn, seed, chain_offset, s)))
+      return rc;
+    if (H_old_out) (void)hipMemcpyAsync(H_old_out + (int64_t)t * C, H0, C * sizeof(T), hipMemcpyDeviceToDevice, s);
+    if (H_new_out) (void)hipMemcpyAsync(H_new_out + (int64_t)t * C, H1, C * sizeof(T), hipMemcpyDeviceToDevice, s);
+  }
+  HTA_CHECK_LAUNCH(who);
+  return HTA_OK;
+}
+
+}  // namespace hta
+
+extern "C" {
+int64_t hta_rmhmc_workspace_bytes(int64_t C, int D, int elem_size) { return (4 * C * D + 3 * C) * (int64_t)elem_size; }
+
+#define HTA_DEFINE_RM(SUF, T)                                                                                   \
+  int hta_rmhmc_gaussian_leapfrog_##SUF(T* theta, T* p, T* theta_copy, T* p_copy, const T* P, const T* mu,       \
+                                        int metric, double alpha, int has_jitter, double jitter, uint64_t seed,  \
+                                        uint64_t chain_offset, uint32_t draw, int64_t C, int D, int steps,       \
+                                        double eps, double omega, T* path_theta, T* path_p, void* stream) {      \
+    return hta::rmhmc_leapfrog<T>(theta, p, theta_copy, p_copy, P, mu, metric, alpha, has_jitter, jitter, seed,  \
+                                  chain_offset, draw, C, D, steps, eps, omega, path_theta, path_p,               \
+                                  (hipStream_t)stream);                                                          \
+  }                                                                                                              \
+  int hta_rmhmc_gaussian_sample_##SUF(T* theta, const T* theta_init, const T* P, const T* mu, double log_norm,   \
+                                      int metric, double alpha, int has_jitter, double jitter, int64_t C, int D, \
+                                      int L, double eps, double omega, int n_traj, int traj_offset, int burn,    \
+                                      uint64_t seed, uint64_t chain_offset, T* samples, int32_t* reject_count,   \
+                                      T* H_old, T* H_new, uint8_t* accept, void* workspace,                      \
+                                      int64_t workspace_bytes, void* stream) {                                   \
+    return hta::rmhmc_sample<T>(theta, theta_init, P, mu, log_norm, metric, alpha, has_jitter, jitter, C, D, L,   \
+                                eps, omega, n_traj, traj_offset, burn, seed, chain_offset, samples, reject_count, \
+                                H_old, H_new, accept, workspace, workspace_bytes, (hipStream_t)stream);           \
+  }
+HTA_DEFINE_RM(f32, float)
+HTA_DEFINE_RM(f64, double)
+}

@@ -142,6 +142,70 @@ int hta_hmc_gaussian_leapfrog_f64(double* theta, double* p, const double* P, con
                                   const double* inv_mass, int64_t C, int D, int steps, double eps,
                                   double* path_theta, double* path_p, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Riemannian metric evaluation, batched: one workgroup per system, matrices in LDS.
+ * Covers fisher() S:108-122 (jitter, eigh, soft-abs map, Q diag Q^T), cholesky_inverse() S:146-148,
+ * rm_hamiltonian() S:710-731 and the RMHMC momentum draw S:183-184.  Every output pointer may be NULL.
+ * `Hs[b]` is the NEGATIVE Hessian of log p at system b (hs_stride 0 = one matrix shared by all
+ * systems, i.e. a Gaussian target); only its lower triangle is read (eigh UPLO='L', S:119).
+ * D <= ~140 (fp32) / ~99 (fp64): both matrices of a system live in the 160 KiB LDS of one CU.
+ * ------------------------------------------------------------------------------------------- */
+#define HTA_METRIC_HESSIAN 0 /* G = Hs (must be positive definite); log|G| and solves by Cholesky  */
+#define HTA_METRIC_SOFTABS 1 /* G = Q diag(lam / tanh(alpha lam)) Q^T                              */
+
+typedef struct HtaMetricArgs {
+  int64_t B; int32_t D; int32_t metric;
+  const void* Hs; int64_t hs_stride;        /* elements between consecutive systems (0 or D*D)      */
+  double alpha;                              /* softabs_const                                        */
+  int32_t has_jitter; int32_t max_sweeps;    /* max_sweeps 0 = default Jacobi sweep cap              */
+  double jitter; uint64_t seed; uint64_t chain_offset; uint32_t draw; uint32_t sub;
+                                             /* Hs += diag(jitter * U(0,1)), Philox(seed, chain, draw, sub) */
+  const void* X; const void* Pm; const void* mu; double log_norm;
+                                             /* optional Gaussian log p / gradient at X[B,D]:
+                                                logp = log_norm - 0.5 (X-mu)^T Pm (X-mu), Pd = Pm (X-mu)   */
+  const void* m;                             /* [B,D]: solve x = G^-1 m                              */
+  void* p_out;                               /* [B,D]: p = chol(G) z, z = Philox normals (seed, chain, draw) */
+  void* x_out; void* G_out; void* lam_out; void* V_out; void* L_out;
+  void* logdet_out; void* quad_out; void* H_out; void* logp_out;
+                                             /* H = -logp + D/2 log 2pi + 1/2 log|G| + 1/2 m^T G^-1 m (S:731) */
+  void* upd_x; double cx; void* upd_g; double cg;
+                                             /* fused half step: upd_x[b,:] += cx * x ; upd_g[b,:] += cg * Pd */
+} HtaMetricArgs;
+
+int hta_metric_eval_f32(const HtaMetricArgs* args, void* stream);
+int hta_metric_eval_f64(const HtaMetricArgs* args, void* stream);
+
+/* Explicit RMHMC integrator (S:389-462) for a Gaussian target, `steps` steps on the augmented state
+ * (theta, p, theta_copy, p_copy), all [C,D] in/out.  omega = explicit_binding_const.
+ * path_theta / path_p: optional [steps,C,D] record of (theta, p) after every step (S:460-461). */
+int hta_rmhmc_gaussian_leapfrog_f32(float* theta, float* p, float* theta_copy, float* p_copy, const float* P,
+                                    const float* mu, int metric, double alpha, int has_jitter, double jitter,
+                                    uint64_t seed, uint64_t chain_offset, uint32_t draw, int64_t C, int D,
+                                    int steps, double eps, double omega, float* path_theta, float* path_p,
+                                    void* stream);
+int hta_rmhmc_gaussian_leapfrog_f64(double* theta, double* p, double* theta_copy, double* p_copy, const double* P,
+                                    const double* mu, int metric, double alpha, int has_jitter, double jitter,
+                                    uint64_t seed, uint64_t chain_offset, uint32_t draw, int64_t C, int D,
+                                    int steps, double eps, double omega, double* path_theta, double* path_p,
+                                    void* stream);
+
+/* sample(sampler=RMHMC, integrator=EXPLICIT) (S:969-1026) for a Gaussian target: enqueues every
+ * launch of `n_traj` trajectories; arguments as hta_hmc_gaussian_sample.  workspace:
+ * hta_rmhmc_workspace_bytes(C, D, sizeof(T)) bytes (required). */
+int64_t hta_rmhmc_workspace_bytes(int64_t C, int D, int elem_size);
+int hta_rmhmc_gaussian_sample_f32(float* theta, const float* theta_init, const float* P, const float* mu,
+                                  double log_norm, int metric, double alpha, int has_jitter, double jitter,
+                                  int64_t C, int D, int L, double eps, double omega, int n_traj, int traj_offset,
+                                  int burn, uint64_t seed, uint64_t chain_offset, float* samples,
+                                  int32_t* reject_count, float* H_old, float* H_new, uint8_t* accept,
+                                  void* workspace, int64_t workspace_bytes, void* stream);
+int hta_rmhmc_gaussian_sample_f64(double* theta, const double* theta_init, const double* P, const double* mu,
+                                  double log_norm, int metric, double alpha, int has_jitter, double jitter,
+                                  int64_t C, int D, int L, double eps, double omega, int n_traj, int traj_offset,
+                                  int burn, uint64_t seed, uint64_t chain_offset, double* samples,
+                                  int32_t* reject_count, double* H_old, double* H_new, uint8_t* accept,
+                                  void* workspace, int64_t workspace_bytes, void* stream);
+
 /* measurement knobs: "small_chains_per_block" (launch shape of the thread-per-chain kernel),
  * "force_general" (route small D through the wave-per-chain kernel), "profile" (1 = record a HIP
  * event pair around the dominant kernel of every fused call, on the launch stream). */

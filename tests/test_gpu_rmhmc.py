@@ -1,0 +1,201 @@
+"""GPU parity for the Riemannian path: batched metric evaluation (Jacobi eigh, soft-abs, solves,
+log-determinant, Cholesky), Riemannian Hamiltonian, momentum draw, explicit integrator and the
+RMHMC branch of sample(), against the oracle and the fixtures recorded from the reference.
+
+Tolerances: D=100 fp32 theta/p atol 1e-4, H 1e-3; small D fp32 3e-4 relative; fp64 1e-9."""
+import numpy as np
+import pytest
+import torch
+
+import hmc_oracle as O
+
+pytestmark = pytest.mark.gpu
+NP = {torch.float32: np.float32, torch.float64: np.float64}
+
+
+@pytest.fixture(scope="module")
+def ht():
+    import hamiltorch_amd
+    assert torch.cuda.is_available()
+    return hamiltorch_amd
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def tt(a, dtype):
+    return None if a is None else torch.tensor(np.asarray(a), dtype=dtype, device=dev())
+
+
+def sym_batch(B, D, kind, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for b in range(B):
+        Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+        if kind == "spd":
+            lam = rng.uniform(0.5, 2.0, D)
+        elif kind == "indef":
+            lam = rng.uniform(0.3, 2.0, D) * rng.choice([-1.0, 1.0], D)
+        elif kind == "degenerate":
+            lam = np.repeat(rng.uniform(0.5, 2.0, (D + 2) // 3), 3)[:D]
+        else:
+            raise ValueError(kind)
+        A = (Q * lam) @ Q.T
+        out.append(0.5 * (A + A.T))
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 4e-4), (torch.float64, 2e-9)])
+@pytest.mark.parametrize("D,kind,alpha", [(1, "spd", 1e6), (2, "indef", 1.3), (3, "spd", 1e6), (5, "indef", 2.0),
+                                           (8, "degenerate", 1e6), (17, "indef", 0.7), (33, "spd", 1e6),
+                                           (64, "indef", 1e6), (100, "spd", 1e6), (101, "degenerate", 3.0)])
+def test_metric_eval_vs_oracle(ht, dtype, tol, D, kind, alpha):
+    """fisher(): G, soft-abs eigenvalues; cholesky_inverse(): G^-1 m; log|G| and m^T G^-1 m -- batched, arbitrary symmetric Hs."""
+    from hamiltorch_amd import _abi
+    if dtype == torch.float64 and D > 96:
+        pytest.skip("fp64 D > 99 exceeds the LDS of one CU")
+    B = 5
+    Hs = sym_batch(B, D, kind, D).astype(NP[dtype])
+    rng = np.random.default_rng(1)
+    m = rng.standard_normal((B, D)).astype(NP[dtype])
+    G, lam, _ = O.softabs_metric(Hs.astype(np.float64), alpha)
+    x64 = np.linalg.solve(G, m.astype(np.float64)[..., None])[..., 0]
+    t = tt(Hs, dtype)
+    Gd = torch.empty(B, D, D, dtype=dtype, device=dev()); lamd = torch.empty(B, D, dtype=dtype, device=dev())
+    xd = torch.empty(B, D, dtype=dtype, device=dev()); ld = torch.empty(B, dtype=dtype, device=dev()); qd = torch.empty(B, dtype=dtype, device=dev())
+    Vd = torch.empty(B, D, D, dtype=dtype, device=dev()); Ld = torch.empty(B, D, D, dtype=dtype, device=dev())
+    _abi.metric_eval(t, B, D, _abi.METRIC_SOFTABS, t, D * D, alpha, m=tt(m, dtype), x_out=xd, G_out=Gd, lam_out=lamd,
+                     V_out=Vd, L_out=Ld, logdet_out=ld, quad_out=qd)
+    scale = np.abs(G).max()
+    np.testing.assert_allclose(Gd.cpu().numpy(), G, rtol=tol, atol=tol * scale)
+    np.testing.assert_allclose(np.sort(lamd.cpu().numpy(), axis=1), np.sort(lam, axis=1), rtol=tol, atol=tol * scale)
+    cond = np.abs(lam).max() / np.abs(lam).min()
+    np.testing.assert_allclose(xd.cpu().numpy(), x64, rtol=tol * cond, atol=tol * cond * np.abs(x64).max())
+    np.testing.assert_allclose(ld.cpu().numpy(), np.log(lam).sum(1), rtol=tol, atol=tol * D)
+    np.testing.assert_allclose(qd.cpu().numpy(), (m * x64).sum(1), rtol=tol * cond, atol=tol * cond)
+    V = Vd.double().cpu().numpy()
+    np.testing.assert_allclose(np.einsum("bij,bik->bjk", V, V), np.broadcast_to(np.eye(D), (B, D, D)), atol=50 * tol / 4e-4 * 1e-6 if dtype == torch.float32 else 1e-12)
+    Lc = Ld.double().cpu().numpy()
+    np.testing.assert_allclose(Lc @ np.swapaxes(Lc, 1, 2), G, rtol=4 * tol, atol=4 * tol * scale)
+    # HESSIAN metric = Cholesky path, on the SPD matrix G itself (cholesky_inverse API)
+    x2 = ht.samplers.cholesky_inverse(tt(G, dtype), tt(m, dtype))
+    np.testing.assert_allclose(x2.cpu().numpy(), x64, rtol=tol * cond, atol=tol * cond * np.abs(x64).max())
+    x1 = ht.samplers.cholesky_inverse(tt(G[0], dtype), tt(m[0], dtype))
+    assert x1.shape == (D, 1)
+
+
+@pytest.mark.parametrize("name", ["d3", "d10", "d6indef"])
+@pytest.mark.parametrize("tag,dtype,tol", [("f32", torch.float32, 3e-4), ("f64", torch.float64, 1e-9)])
+def test_reference_fixtures(ht, golden, name, tag, dtype, tol):
+    """fisher / cholesky_inverse / rm_hamiltonian / explicit leapfrog against values recorded from the reference."""
+    g = golden("rmhmc")
+    alpha, omega, eps, steps = g[f"{name}_cfg"]
+    P = tt(g[f"{name}_P_{tag}"], dtype)
+    D = P.shape[0]
+    tgt = ht.GaussianTarget(torch.zeros(D, dtype=dtype, device=dev()), precision=P, normalized=False)
+    th = tt(g[f"{name}_theta0_{tag}"], dtype); pm = tt(g[f"{name}_p0_{tag}"], dtype)
+    for mtag, metric in (("softabs", ht.Metric.SOFTABS), ("hessian", ht.Metric.HESSIAN)):
+        if f"{name}_G_{mtag}_{tag}" not in g.files:
+            continue
+        for lp in (tgt, (lambda w, t=tgt: t(w))):       # plugin and opaque callback (torch.func.hessian) routes
+            G, lam = ht.samplers.fisher(th, lp, jitter=None, softabs_const=alpha, metric=metric)
+            np.testing.assert_allclose(G.cpu().numpy(), g[f"{name}_G_{mtag}_{tag}"], rtol=tol, atol=tol)
+            if mtag == "softabs":
+                np.testing.assert_allclose(np.sort(lam.cpu().numpy()), np.sort(g[f"{name}_lam_{mtag}_{tag}"]), rtol=tol, atol=tol)
+            else:
+                assert lam is None
+            H = ht.samplers.rm_hamiltonian(th, pm, lp, None, 1.0, softabs_const=alpha, metric=metric)
+            assert H.shape == (1, 1)
+            np.testing.assert_allclose(H.cpu().numpy().reshape(-1), g[f"{name}_H_{mtag}_{tag}"], rtol=tol, atol=tol)
+        x = ht.samplers.cholesky_inverse(G, pm)
+        np.testing.assert_allclose(x.cpu().numpy().reshape(-1), g[f"{name}_Ginvp_{mtag}_{tag}"], rtol=10 * tol, atol=10 * tol)
+        lpar, lmom = ht.samplers.leapfrog(th, pm, tgt, steps=int(steps), step_size=float(eps), jitter=None,
+                                          explicit_binding_const=float(omega), softabs_const=float(alpha),
+                                          sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT, metric=metric)
+        assert len(lpar[0]) == int(steps) and len(lmom[0]) == int(steps)
+        np.testing.assert_allclose(lpar[0][-1].cpu().numpy(), g[f"{name}_lf_theta_{mtag}_{tag}"], rtol=10 * tol, atol=10 * tol)
+        np.testing.assert_allclose(lmom[0][-1].cpu().numpy(), g[f"{name}_lf_p_{mtag}_{tag}"], rtol=10 * tol, atol=10 * tol)
+        np.testing.assert_allclose(lpar[1].cpu().numpy(), g[f"{name}_lf_thetac_{mtag}_{tag}"], rtol=10 * tol, atol=10 * tol)
+        np.testing.assert_allclose(lmom[1].cpu().numpy(), g[f"{name}_lf_pc_{mtag}_{tag}"], rtol=10 * tol, atol=10 * tol)
+
+
+def cfg3_target(ht, D, dtype, seed=0):
+    """P = Q diag(linspace(.5, 2, D)) Q^T, log p = -1/2 w^T P w."""
+    g = torch.Generator().manual_seed(seed)
+    Q = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))[0]
+    P = (Q * torch.linspace(0.5, 2.0, D, dtype=torch.float64)) @ Q.T
+    P = (0.5 * (P + P.T)).numpy()
+    t = ht.GaussianTarget(torch.zeros(D, dtype=dtype, device=dev()), precision=tt(P, dtype), normalized=False)
+    o = O.GaussianTarget(np.zeros(D, NP[dtype]), P.astype(NP[dtype]), 0.0)
+    return t, o
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.float64, 1e-9)])
+@pytest.mark.parametrize("D,jitter", [(4, None), (10, 1e-3), (31, None), (100, None), (100, 1e-3)])
+def test_explicit_leapfrog_and_hamiltonian_vs_oracle(ht, dtype, tol, D, jitter):
+    """T1 at cfg3's shape: same (theta, p) and the same Philox jitter stream into kernel sequence and oracle."""
+    if dtype == torch.float64 and D > 96:
+        pytest.skip("fp64 D > 99 exceeds the LDS of one CU")
+    t, o = cfg3_target(ht, D, dtype)
+    C, steps, eps, omega, alpha, seed, off, n = 6, 3, 0.1, 10.0, 1e6, 77, 40, 9
+    rng = np.random.default_rng(D)
+    th0 = (0.3 * rng.standard_normal((C, D))).astype(NP[dtype]); p0 = rng.standard_normal((C, D)).astype(NP[dtype])
+    draws = O.PhiloxDraws(seed, off + np.arange(C), NP[dtype])
+    from hamiltorch_amd import rmhmc
+    out_t, out_p = rmhmc.explicit_leapfrog(tt(th0, dtype), tt(p0, dtype), t, steps, eps, jitter, alpha, omega, ht.Metric.SOFTABS,
+                                           seed=seed, chain_offset=off, draw=n)
+    a, b, c, d = O.explicit_rmhmc_leapfrog(th0, p0, o, steps, eps, omega, alpha, jitter,
+                                           (lambda k: draws.jitter_uniforms(n, 2 + k, D)), "softabs")
+    np.testing.assert_allclose(out_t[0][-1].cpu().numpy(), a, rtol=tol, atol=tol)
+    np.testing.assert_allclose(out_p[0][-1].cpu().numpy(), b, rtol=tol, atol=tol)
+    np.testing.assert_allclose(out_t[1].cpu().numpy(), c, rtol=tol, atol=tol)
+    np.testing.assert_allclose(out_p[1].cpu().numpy(), d, rtol=tol, atol=tol)
+    H = rmhmc.rm_hamiltonian(tt(th0, dtype), tt(p0, dtype), t, jitter, alpha, ht.Metric.SOFTABS, seed=seed, chain_offset=off, draw=n, sub=1)
+    wH, _ = O.rm_hamiltonian(th0, p0, o, alpha, jitter, None if jitter is None else draws.jitter_uniforms(n, 1, D), "softabs")
+    np.testing.assert_allclose(H.cpu().numpy(), wH, rtol=10 * tol, atol=10 * tol)
+    # momentum draw p = chol(G) z with the Philox normals of (seed, chain, n)
+    pg = ht.samplers.gibbs(tt(th0, dtype), sampler=ht.Sampler.RMHMC, log_prob_func=t, jitter=jitter, softabs_const=alpha,
+                           metric=ht.Metric.SOFTABS, seed=seed, chain_offset=off, draw=n)
+    wp = O.rm_gibbs(th0, draws.normals(n, D), o, alpha, jitter, None if jitter is None else draws.jitter_uniforms(n, 0, D), "softabs")
+    np.testing.assert_allclose(pg.cpu().numpy(), wp, rtol=10 * tol, atol=10 * tol)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-4), (torch.float64, 1e-8)])
+@pytest.mark.parametrize("D,jitter,metric,burn", [(3, None, "softabs", 0), (3, 1e-3, "softabs", 2), (10, None, "hessian", -1),
+                                                  (20, 1e-3, "softabs", 0)])
+def test_sample_rmhmc_vs_oracle(ht, dtype, tol, D, jitter, metric, burn):
+    """End to end sample(sampler=RMHMC, integrator=EXPLICIT): momentum draw, both Hamiltonians, L explicit steps,
+    MH, burn bookkeeping -- same Philox streams in the kernels and the oracle."""
+    t, o = cfg3_target(ht, D, dtype, seed=5)
+    C, N, L, eps, omega, alpha, seed, off = 24, 7, 3, 0.15, 10.0, 1e6, 2025, 3
+    th0 = (0.3 * O.philox_normals(seed, off + np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(NP[dtype])
+    M = ht.Metric.SOFTABS if metric == "softabs" else ht.Metric.HESSIAN
+    out, acc = ht.sample(t, tt(th0, dtype), num_samples=N, num_steps_per_sample=L, step_size=eps, burn=burn, jitter=jitter,
+                         softabs_const=alpha, explicit_binding_const=omega, sampler=ht.Sampler.RMHMC,
+                         integrator=ht.Integrator.EXPLICIT, metric=M, debug=2, verbose=False, seed=seed, chain_offset=off)
+    ref, info = O.sample_rmhmc_explicit(o, th0, N, L, eps, omega, alpha, burn, jitter, O.PhiloxDraws(seed, off + np.arange(C), NP[dtype]), metric)
+    got = np.stack([x.cpu().numpy() for x in out]); want = np.stack(ref)
+    assert got.shape == want.shape
+    bad = np.abs(got - want).max(axis=(0, 2)) > tol
+    assert bad.mean() <= 0.05, "%d of %d chains differ" % (bad.sum(), C)
+    np.testing.assert_allclose(acc.cpu().numpy()[~bad], info["acc_rate"][~bad], atol=1e-12)
+
+
+def test_cfg3_shape_smoke_and_errors(ht):
+    """cfg3 shape (D=100, 256 chains, softabs, omega=10, eps=0.1): a short run is finite, accepts, and moves."""
+    t, _ = cfg3_target(ht, 100, torch.float32)
+    th0 = 0.1 * torch.randn(256, 100, device=dev())
+    out, acc = ht.sample(t, th0, num_samples=3, num_steps_per_sample=4, step_size=0.1, jitter=1e-3, softabs_const=1e6,
+                         explicit_binding_const=10, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT,
+                         metric=ht.Metric.SOFTABS, debug=2, verbose=False, seed=1)
+    s = torch.stack(out)
+    assert torch.isfinite(s).all() and float(acc.mean()) > 0.9 and float((s[-1] - s[0]).abs().mean()) > 1e-3
+    with pytest.raises(NotImplementedError, match="constant-curvature"):
+        ht.sample(lambda w: -(w ** 4).sum(), th0[0, :4].clone(), num_samples=2, softabs_const=1e6, sampler=ht.Sampler.RMHMC,
+                  integrator=ht.Integrator.EXPLICIT, metric=ht.Metric.SOFTABS, verbose=False)
+    with pytest.raises(NotImplementedError):
+        ht.sample(t, th0[0].clone(), num_samples=2, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.IMPLICIT, verbose=False)
+    with pytest.raises(RuntimeError, match="gradients not implemented for RMHMC"):     # S:390-391
+        ht.sample(t, th0[0].clone(), num_samples=2, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT,
+                  softabs_const=1e6, metric=ht.Metric.SOFTABS, pass_grad=lambda w: w, verbose=False)
