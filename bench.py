@@ -110,7 +110,56 @@ class Cfg2:
                 "ess_per_sec": ess / dt, "acceptance": acc}
 
 
-WORKLOADS = {"cfg2": Cfg2}
+class Cfg3:
+    """BASELINE config 3: D=100 Gaussian, explicit RMHMC, soft-abs metric, 256 chains."""
+    name = "cfg3: D=100 Gaussian explicit RMHMC, softabs alpha=1e6, omega=10, eps=0.1, L=10, jitter=1e-3"
+    D, L, eps, chains, traj = 100, 10, 0.1, 256, 2
+    omega, alpha, jitter = 10.0, 1e6, 1e-3
+    dtype_name = "f32"
+
+    def __init__(self, dev, chains, traj, chain_offset, seed=0):
+        import hamiltorch_amd as ht
+        from hamiltorch_amd import _abi
+        self.abi = _abi
+        self.C, self.T = chains or self.chains, traj or self.traj
+        self.off, self.seed = chain_offset, seed
+        g = torch.Generator().manual_seed(0)
+        Q = torch.linalg.qr(torch.randn(self.D, self.D, generator=g, dtype=torch.float64))[0]
+        P = (Q * torch.linspace(0.5, 2.0, self.D, dtype=torch.float64)) @ Q.T
+        P = 0.5 * (P + P.T)
+        self.P64 = P
+        self.tgt = ht.GaussianTarget(torch.zeros(self.D, device=dev), precision=P.float().to(dev), normalized=False)
+        g2 = torch.Generator().manual_seed(1234 + chain_offset)
+        self.theta0 = (0.1 * torch.randn(self.C, self.D, generator=g2)).to(dev)
+        self.cur = self.theta0.clone()
+        self.samples = torch.empty(self.T + 1, self.C, self.D, device=dev)
+        self.samples[0].copy_(self.theta0)
+        self.rej = torch.zeros(self.C, dtype=torch.int32, device=dev)
+        self.ws = torch.empty(_abi.rmhmc_workspace_bytes(self.C, self.D, 4), dtype=torch.uint8, device=dev)
+
+    def units_per_step(self):
+        return self.C * self.T * self.L
+
+    def flops_per_unit(self):      # SURVEY 8d: 4 distinct metric evaluations x 11.3 D^3 per explicit step
+        return 4 * 11.3 * self.D ** 3
+
+    def bytes_per_unit(self):
+        return 32 * self.D
+
+    def step(self, k):
+        self.abi.rmhmc_gaussian_sample(self.cur, self.theta0, self.tgt.precision, self.tgt.mean, self.tgt.log_norm,
+                                       self.abi.METRIC_SOFTABS, self.alpha, self.jitter, self.L, self.eps, self.omega,
+                                       self.T, 0, -1, self.seed + k, self.off, self.samples, self.rej, self.ws)
+
+    def check(self):
+        assert torch.isfinite(self.samples).all()
+        return 1.0 - float(self.rej.double().mean()) / (self.T * max(1, self._steps_done))
+
+    def cpu_baseline(self, seconds):
+        return None
+
+
+WORKLOADS = {"cfg2": Cfg2, "cfg3": Cfg3}
 
 
 def main():
@@ -173,12 +222,23 @@ def main():
     if rank == 0:
         alg_bytes = w.bytes_per_unit() * w.units_per_step()
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        if hasattr(w, "flops_per_unit"):
+            kernel_ms = prof_ms / max(1, a.steps)          # all metric-evaluation launches of one step
+            tf = w.flops_per_unit() * w.units_per_step() / (kernel_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / FP32_PEAK_TFLOPS, "traffic": None, "kernel": "metric_eval_kernel<float>",
+                    "kernel_ms_per_step": kernel_ms, "launches_per_step": prof_n / max(1, a.steps),
+                    "algorithmic_flops_per_chain_step": w.flops_per_unit(),
+                    "note": "fp32 vector == fp32 MFMA peak (157.3 TF); flop count is SURVEY 8d's 4 x 11.3 D^3 per "
+                            "explicit step (LAPACK-style eigh count); the Jacobi solver executes more"}
+        else:
+            roof = None
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)
         if os.path.exists(tf):
             traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
         from hamiltorch_amd.ess import ess_min
-        ess = ess_min(w.samples[1:])
+        ess = ess_min(w.samples[1:]) if w.T >= 8 else float("nan")
         out = {
             "metric": "leapfrog-steps/sec (whole node) at 1024 chains; ESS/sec vs CPU ref",
             "value": value, "unit": "leapfrog-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -187,7 +247,7 @@ def main():
             "config": {"workload": W.name, "chains_per_gpu": w.C, "chains_total": w.C * world,
                        "trajectories_per_step": w.T, "leapfrog_steps_per_trajectory": W.L, "D": W.D,
                        "samples_stored": True, "parallelism": "chains sharded, %d per GPU, no collective" % w.C},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": roof or {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "hmc_gauss_small_kernel<float,3,0,true>", "kernel_ms": kernel_ms,
                          "call_ms": call_ms,
@@ -199,11 +259,13 @@ def main():
             "ess_per_sec": ess / (call_ms * 1e-3),
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = w.cpu_baseline(a.cpu_seconds)
-            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
-            out["speedup_vs_cpu_baseline_1core"] = value / out["cpu_baseline"]["value"]
+            cb = w.cpu_baseline(a.cpu_seconds)
+            if cb is not None:
+                out["cpu_baseline"] = cb
+                out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+                out["speedup_vs_cpu_baseline_1core"] = value / cb["value"]
         print(json.dumps(out), flush=True)
-        if a.sweep:
+        if a.sweep and a.workload == "cfg2":
             for C in (1024, 4096, 16384, 65536, 262144, 1048576):
                 ws = W(dev, C, max(10, min(w.T, (1 << 24) // C)), 0)
                 ws._steps_done = 1

@@ -23,7 +23,7 @@
 
 namespace hta {
 
-constexpr int MT = 256;  // threads per system
+constexpr int MT = 1024;  // threads per system (16 waves: the LDS-latency-bound Jacobi rounds need >= 4 waves per SIMD)
 
 template <typename T> struct Eps;
 template <> struct Eps<float> { static constexpr float v = 1.1920929e-07f; };
@@ -95,11 +95,31 @@ __device__ __forceinline__ void rr_pair(int n, int r, int k, int& p, int& q) {
 }
 
 // Cyclic Jacobi on A[ne][lda] (symmetric, both triangles valid), V[D][ldv] <- eigenvectors (columns).
+// Work split (MT threads): the <= ceil(nblk / MT) pair-blocks a thread owns are decoded ONCE (the
+// enumeration does not depend on the round); V rows are walked with pair index = lane, so the hot
+// loops contain no integer division.
 template <typename T>
 __device__ void lds_jacobi(T* A, T* V, int D, int ne, int lda, int ldv, T* cs, int* pq, T* red, int max_sweeps) {
   const int tid = threadIdx.x;
   const int NP = ne / 2;
   const int nblk = NP * (NP + 1) / 2;
+  constexpr int MAXB = 4;                       // nblk <= 71*70/2 = 2485 < 4 * 1024
+  int blkA[MAXB], blkB[MAXB];
+#pragma unroll
+  for (int k = 0; k < MAXB; ++k) {
+    const int e = tid + k * MT;
+    blkA[k] = -1; blkB[k] = 0;
+    if (e < nblk) {
+      // row-major upper-triangular enumeration: row a holds NP - a blocks
+      int a = (int)(((float)(2 * NP + 1) - sqrtf((float)((2 * NP + 1) * (2 * NP + 1) - 8 * e))) * 0.5f);
+      if (a < 0) a = 0;
+      while (a > 0 && a * NP - a * (a - 1) / 2 > e) --a;
+      while ((a + 1) * NP - (a + 1) * a / 2 <= e) ++a;
+      blkA[k] = a; blkB[k] = a + (e - (a * NP - a * (a - 1) / 2));
+    }
+  }
+  int npw = 1; while (npw < NP) npw <<= 1;      // pairs padded to a power of two <= 128
+  const int vb = tid & (npw - 1), vi0 = tid / npw, vstep = MT / npw;
   T off_prev = (T)-1;
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     // convergence: off-diagonal vs diagonal mass
@@ -134,33 +154,32 @@ __device__ void lds_jacobi(T* A, T* V, int D, int ne, int lda, int ldv, T* cs, i
       }
       __syncthreads();
       // A <- J^T A J, one thread per pair-block (a <= b), mirrored
-      for (int e = tid; e < nblk; e += MT) {
-        // row-major upper-triangular enumeration: row a holds NP - a blocks
-        int a = (int)(((T)(2 * NP + 1) - sqrt((T)((2 * NP + 1) * (2 * NP + 1) - 8 * e))) * (T)0.5);
-        if (a < 0) a = 0;
-        while (a > 0 && a * NP - a * (a - 1) / 2 > e) --a;
-        while ((a + 1) * NP - (a + 1) * a / 2 <= e) ++a;
-        const int bb = a + (e - (a * NP - a * (a - 1) / 2));
-        const int pa = pq[2 * a], qa = pq[2 * a + 1], pb = pq[2 * bb], qb = pq[2 * bb + 1];
-        const T ca = cs[2 * a], sa = cs[2 * a + 1], cb = cs[2 * bb], sb = cs[2 * bb + 1];
-        const T m00 = A[pa * lda + pb], m01 = A[pa * lda + qb], m10 = A[qa * lda + pb], m11 = A[qa * lda + qb];
-        const T t00 = cb * m00 - sb * m01, t01 = sb * m00 + cb * m01;
-        const T t10 = cb * m10 - sb * m11, t11 = sb * m10 + cb * m11;
-        T n00 = ca * t00 - sa * t10, n01 = ca * t01 - sa * t11;
-        T n10 = sa * t00 + ca * t10, n11 = sa * t01 + ca * t11;
-        if (a == bb) { n01 = 0; n10 = 0; }
-        A[pa * lda + pb] = n00; A[pa * lda + qb] = n01; A[qa * lda + pb] = n10; A[qa * lda + qb] = n11;
-        if (a != bb) { A[pb * lda + pa] = n00; A[qb * lda + pa] = n01; A[pb * lda + qa] = n10; A[qb * lda + qa] = n11; }
+#pragma unroll
+      for (int k = 0; k < MAXB; ++k) {
+        const int a = blkA[k], bb = blkB[k];
+        if (a >= 0) {
+          const int pa = pq[2 * a], qa = pq[2 * a + 1], pb = pq[2 * bb], qb = pq[2 * bb + 1];
+          const T ca = cs[2 * a], sa = cs[2 * a + 1], cb = cs[2 * bb], sb = cs[2 * bb + 1];
+          const T m00 = A[pa * lda + pb], m01 = A[pa * lda + qb], m10 = A[qa * lda + pb], m11 = A[qa * lda + qb];
+          const T t00 = cb * m00 - sb * m01, t01 = sb * m00 + cb * m01;
+          const T t10 = cb * m10 - sb * m11, t11 = sb * m10 + cb * m11;
+          T n00 = ca * t00 - sa * t10, n01 = ca * t01 - sa * t11;
+          T n10 = sa * t00 + ca * t10, n11 = sa * t01 + ca * t11;
+          if (a == bb) { n01 = 0; n10 = 0; }
+          A[pa * lda + pb] = n00; A[pa * lda + qb] = n01; A[qa * lda + pb] = n10; A[qa * lda + qb] = n11;
+          if (a != bb) { A[pb * lda + pa] = n00; A[qb * lda + pa] = n01; A[pb * lda + qa] = n10; A[qb * lda + qa] = n11; }
+        }
       }
-      // V <- V J
-      for (int e = tid; e < D * NP; e += MT) {
-        const int i = e / NP, b = e - i * NP;
-        const int pb = pq[2 * b], qb = pq[2 * b + 1];
+      // V <- V J : pair = lane, rows strided
+      if (vb < NP) {
+        const int pb = pq[2 * vb], qb = pq[2 * vb + 1];
         if (qb < D) {     // the padding index (odd D) never rotates
-          const T c = cs[2 * b], s = cs[2 * b + 1];
-          const T vp = V[i * ldv + pb], vq = V[i * ldv + qb];
-          V[i * ldv + pb] = c * vp - s * vq;
-          V[i * ldv + qb] = s * vp + c * vq;
+          const T c = cs[2 * vb], s = cs[2 * vb + 1];
+          for (int i = vi0; i < D; i += vstep) {
+            const T vp = V[i * ldv + pb], vq = V[i * ldv + qb];
+            V[i * ldv + pb] = c * vp - s * vq;
+            V[i * ldv + qb] = s * vp + c * vq;
+          }
         }
       }
     }
