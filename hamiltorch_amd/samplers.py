@@ -348,7 +348,12 @@ def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, 
                 eng = _resolve_split_engine(log_prob_func, theta0, native)
             else:
                 tgt = as_gaussian(log_prob_func, theta0) if (native and pass_grad is None) else None
-                eng = _GaussianHMC(tgt) if tgt is not None else _GenericHMC(log_prob_func, pass_grad)
+                eng = _GaussianHMC(tgt) if tgt is not None else None
+                if eng is None and native and pass_grad is None:
+                    from . import bnn
+                    eng = bnn.native_hmc_engine(log_prob_func, theta0)
+                if eng is None:
+                    eng = _GenericHMC(log_prob_func, pass_grad)
             samples, rejected = eng.run(theta0, num_samples, num_steps_per_sample, step_size, burn_k, inv_mass,
                                         seed, chain_offset, verbose, '({}; {})'.format(sampler, integrator))
         elif sampler == Sampler.RMHMC and integrator == Integrator.EXPLICIT:

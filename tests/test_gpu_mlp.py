@@ -1,0 +1,155 @@
+"""GPU parity for the Bayesian-MLP path (BASELINE config 4): define_model_log_prob closures, the
+SPLITTING integrator and sample_model / sample_split_model, native kernel and generic-callback route,
+against the oracle (same Philox draws) and the values recorded from the reference."""
+import numpy as np
+import pytest
+import torch
+
+import hmc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ht():
+    import hamiltorch_amd
+    assert torch.cuda.is_available()
+    return hamiltorch_amd
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def make_net(dims, act, seed=0):
+    torch.manual_seed(seed)
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(torch.nn.Linear(int(dims[i]), int(dims[i + 1])))
+        if i < len(dims) - 2:
+            layers.append({"relu": torch.nn.ReLU, "tanh": torch.nn.Tanh, "sigmoid": torch.nn.Sigmoid}[act]())
+    return torch.nn.Sequential(*layers).to(dev())
+
+
+def make_data(N, n_in, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(N, n_in, generator=g)
+    Y = torch.sin(X.sum(1, keepdim=True)) + 0.1 * torch.randn(N, 1, generator=g)
+    return X, Y
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-4), (torch.float64, 1e-10)])
+@pytest.mark.parametrize("n_in,H,act,N,M", [(3, 5, "relu", 12, 3), (8, 100, "relu", 400, 4), (1, 17, "tanh", 30, 2),
+                                            (5, 64, "sigmoid", 64, 1), (16, 130, "tanh", 50, 5), (2, 300, "relu", 40, 2)])
+def test_native_logp_grad_vs_oracle(ht, dtype, tol, n_in, H, act, N, M):
+    """Value and gradient of every split closure (S:1145-1199) for a batch of chains."""
+    from hamiltorch_amd import _abi
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    X, Y = make_data(N, n_in)
+    D = H * n_in + 2 * H + 1
+    C, Nb = 7, N // M
+    rng = np.random.default_rng(H)
+    theta = (0.4 * rng.standard_normal((C, D))).astype(npdt)
+    tau = [1.0, 1.5, 2.0, 2.5]
+    tau_out, ps = 7.0, float(M)
+    th = torch.tensor(theta, dtype=dtype, device=dev())
+    Xd, Yd = X.to(dev(), dtype).contiguous(), Y.reshape(-1).to(dev(), dtype).contiguous()
+    for m in range(M):
+        g = torch.empty_like(th); lp = torch.empty(C, dtype=dtype, device=dev())
+        _abi.mlp_logp_grad(th, n_in, H, act, Xd, Yd, M, Nb, m, tau, tau_out, ps, g, lp)
+        o = O.MLPRegressionTarget([n_in, H, 1], X.numpy()[m * Nb:(m + 1) * Nb], Y.numpy()[m * Nb:(m + 1) * Nb], tau, tau_out, ps, act)
+        wl, wg = o.logp_and_grad(theta.astype(np.float64))
+        np.testing.assert_allclose(lp.cpu().numpy(), wl, rtol=tol, atol=tol * max(1.0, np.abs(wl).max()))
+        np.testing.assert_allclose(g.cpu().numpy(), wg, rtol=tol, atol=tol * max(1.0, np.abs(wg).max()))
+
+
+def test_native_matches_reference_fixture(ht, golden):
+    g = golden("mlp")
+    from hamiltorch_amd import _abi
+    M, tau_out, eps, L = g["relu2_cfg"]
+    X = torch.tensor(g["relu2_X"], device=dev()); Y = torch.tensor(g["relu2_Y"].reshape(-1), device=dev())
+    th = torch.tensor(g["relu2_theta"][None], device=dev())
+    grad = torch.empty_like(th); lp = torch.empty(1, device=dev())
+    _abi.mlp_logp_grad(th, 3, 5, "relu", X, Y, 1, 12, 0, list(g["relu2_tau_list"]), float(tau_out), 1.0, grad, lp)
+    np.testing.assert_allclose(lp.cpu().numpy(), g["relu2_logp"], rtol=2e-5, atol=1e-4)
+    np.testing.assert_allclose(grad.cpu().numpy()[0], g["relu2_grad"], rtol=2e-4, atol=2e-4)
+
+
+def _split_setup(ht, dims, act, N, M, tau_out, dtype=torch.float32):
+    net = make_net(dims, act)
+    X, Y = make_data(N, dims[0])
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(X, Y), batch_size=N // M, shuffle=False)
+    ntens = len(list(net.parameters()))
+    tau_list = torch.tensor([1.0 + 0.5 * k for k in range(ntens)])
+    nb = N // M
+    otg = [O.MLPRegressionTarget(dims, X.numpy()[m * nb:(m + 1) * nb], Y.numpy()[m * nb:(m + 1) * nb], tau_list.numpy(), tau_out, M, act)
+           for m in range(M)]
+    return net, X, Y, loader, tau_list, otg
+
+
+def _cmp(out, ref, tol, max_bad=0.07):
+    got = np.stack([o.cpu().numpy() for o in out]); want = np.stack(ref)
+    assert got.shape == want.shape
+    bad = np.abs(got - want).max(axis=(0, 2)) > tol
+    assert bad.mean() <= max_bad, "%d of %d chains differ, max err %.3g" % (bad.sum(), bad.size, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("dims,act,native_expected", [([3, 5, 1], "relu", True), ([4, 33, 1], "tanh", True), ([2, 4, 3, 1], "tanh", False)])
+@pytest.mark.parametrize("mass", ["ones", "none"])
+def test_sample_split_model_vs_oracle(ht, dims, act, native_expected, mass):
+    """sample_split_model end to end: closures per DataLoader batch, SPLITTING integrator, MH, bookkeeping."""
+    N, M, tau_out, eps, L, C, NS, seed = 24, 3, 6.0, 4e-3, 3, 20, 7, 11
+    net, X, Y, loader, tau_list, otg = _split_setup(ht, dims, act, N, M, tau_out)
+    D = sum(p.numel() for p in net.parameters())
+    th0 = (0.3 * O.philox_normals(seed, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32)
+    im = torch.ones(D, device=dev()) if mass == "ones" else None
+    kw = dict(model_loss="regression", num_samples=NS, num_steps_per_sample=L, step_size=eps, burn=1, inv_mass=im,
+              tau_out=tau_out, tau_list=tau_list, verbose=False, seed=seed)
+    out = ht.sample_split_model(net, loader, torch.tensor(th0, device=dev()), M, **kw)
+    ref, _ = O.sample_hmc(None, th0, NS, L, eps, 1, None if im is None else np.ones(D, np.float32), O.PhiloxDraws(seed, np.arange(C)),
+                          grad_fns=[t.grad for t in otg], logp_fns=[t.logp for t in otg])
+    _cmp(out, ref, 5e-4)
+    out_g = ht.sample_split_model(net, loader, torch.tensor(th0, device=dev()), M, native=False, **kw)
+    _cmp(out_g, ref, 5e-4)
+    from hamiltorch_amd import bnn, mlp
+    sizes = [w.nelement() for w in net.parameters()]; shapes = [w.shape for w in net.parameters()]
+    fl = bnn.define_split_model_log_prob(net, "regression", loader, M, sizes, shapes, tau_list, tau_out, device=dev(), verbose=False)
+    assert (mlp.split_engine(fl, torch.tensor(th0, device=dev())) is not None) == native_expected
+
+
+def test_sample_model_full_data_vs_oracle(ht):
+    """sample_model: one closure over all data, plain leapfrog (S:281-302) in the native kernel."""
+    dims, act, N, tau_out, eps, L, C, NS, seed = [3, 9, 1], "relu", 20, 5.0, 3e-3, 4, 24, 6, 5
+    net = make_net(dims, act)
+    X, Y = make_data(N, 3)
+    tau_list = torch.tensor([1.0, 1.5, 2.0, 2.5])
+    D = sum(p.numel() for p in net.parameters())
+    th0 = (0.3 * O.philox_normals(seed, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32)
+    o = O.MLPRegressionTarget(dims, X.numpy(), Y.numpy(), tau_list.numpy(), tau_out, 1.0, act)
+    out, acc = ht.sample_model(net, X, Y, torch.tensor(th0, device=dev()), model_loss="regression", num_samples=NS,
+                               num_steps_per_sample=L, step_size=eps, tau_out=tau_out, tau_list=tau_list, debug=2,
+                               verbose=False, seed=seed)
+    ref, info = O.sample_hmc(o, th0, NS, L, eps, 0, None, O.PhiloxDraws(seed, np.arange(C)))
+    _cmp(out, ref, 5e-4)
+    one = ht.sample_model(net, X, Y, torch.tensor(th0[0], device=dev()), model_loss="regression", num_samples=NS,
+                          num_steps_per_sample=L, step_size=eps, tau_out=tau_out, tau_list=tau_list, verbose=False, seed=seed)
+    assert len(one) == NS and one[0].shape == (D,)
+    np.testing.assert_allclose(torch.stack(one).cpu().numpy(), np.stack(ref)[:, 0], atol=5e-4)
+
+
+def test_cfg4_shape(ht):
+    """BASELINE config 4 shape: Linear(8,100)-ReLU-Linear(100,1), 400 points, M=4, eps=5e-4, L=10, 512 chains.
+    The reference accepts 0.86 here; a short run must be finite and accept at a similar rate."""
+    net = make_net([8, 100, 1], "relu")
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(400, 8, generator=g); w = torch.randn(8, 1, generator=g)
+    Y = torch.sin(X @ w) + 0.1 * torch.randn(400, 1, generator=g)
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(X, Y), batch_size=100, shuffle=False)
+    D = 1001
+    theta0 = ht.util.flatten(net).detach().repeat(512, 1).contiguous()
+    out, acc = ht.sample_split_model(net, loader, theta0, 4, model_loss="regression", num_samples=12, num_steps_per_sample=10,
+                                     step_size=5e-4, inv_mass=torch.ones(D, device=dev()), tau_out=100.0,
+                                     tau_list=torch.ones(4), debug=2, verbose=False, seed=3)
+    s = torch.stack(out)
+    assert s.shape == (12, 512, D) and torch.isfinite(s).all()
+    assert 0.6 < float(acc.mean()) <= 1.0
