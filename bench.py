@@ -159,7 +159,55 @@ class Cfg3:
         return None
 
 
-WORKLOADS = {"cfg2": Cfg2, "cfg3": Cfg3}
+class Cfg4:
+    """BASELINE config 4: Bayesian MLP 8-100-1 (D=1001), 400 points, symmetric split HMC M=4, 512 chains."""
+    name = "cfg4: MLP Linear(8,100)-ReLU-Linear(100,1) regression, split HMC M=4 x 100 points, eps=5e-4, L=10"
+    D, L, eps, chains, traj = 1001, 10, 5e-4, 512, 20
+    dtype_name = "f32"
+
+    def __init__(self, dev, chains, traj, chain_offset, seed=0):
+        from hamiltorch_amd import _abi
+        self.abi = _abi
+        self.C, self.T = chains or self.chains, traj or self.traj
+        self.off, self.seed = chain_offset, seed
+        g = torch.Generator().manual_seed(0)
+        X = torch.randn(400, 8, generator=g); w = torch.randn(8, 1, generator=g)
+        Y = torch.sin(X @ w) + 0.1 * torch.randn(400, 1, generator=g)
+        self.X, self.Y = X.to(dev).contiguous(), Y.reshape(-1).to(dev).contiguous()
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(8, 100), torch.nn.ReLU(), torch.nn.Linear(100, 1))
+        flat = torch.cat([p.detach().flatten() for p in net.parameters()])
+        self.theta0 = flat.repeat(self.C, 1).to(dev).contiguous()
+        self.cur = self.theta0.clone()
+        self.samples = torch.empty(self.T + 1, self.C, self.D, device=dev)
+        self.rej = torch.zeros(self.C, dtype=torch.int32, device=dev)
+        self.im = torch.ones(self.D, device=dev); self.mf = torch.ones(self.D, device=dev)
+
+    def units_per_step(self):
+        return self.C * self.T * self.L
+
+    def flops_per_unit(self):      # SURVEY 8d: 2M gradient evaluations x 6 flop per (point, weight): 8 x 6 x 100 x 900
+        return 2 * 4 * 6 * 100 * 900
+
+    def bytes_per_unit(self):
+        return 16 * self.D
+
+    roof_kernel = "mlp1_hmc_kernel<float,8,4,512>"
+
+    def step(self, k):
+        self.abi.mlp_hmc_sample(self.cur, self.theta0, 8, 100, "relu", self.X, self.Y, 4, 100, [1.0] * 4, 100.0, 4.0,
+                                self.abi.MASS_DIAG, self.im, self.mf, self.L, self.eps, self.T, 0, -1, self.seed + k,
+                                self.off, self.samples, self.rej)
+
+    def check(self):
+        assert torch.isfinite(self.samples[1:]).all()
+        return 1.0 - float(self.rej.double().mean()) / (self.T * max(1, self._steps_done))
+
+    def cpu_baseline(self, seconds):
+        return None
+
+
+WORKLOADS = {"cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4}
 
 
 def main():
@@ -226,11 +274,13 @@ def main():
             kernel_ms = prof_ms / max(1, a.steps)          # all metric-evaluation launches of one step
             tf = w.flops_per_unit() * w.units_per_step() / (kernel_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf / FP32_PEAK_TFLOPS, "traffic": None, "kernel": "metric_eval_kernel<float>",
+                    "frac": tf / FP32_PEAK_TFLOPS, "traffic": None,
+                    "kernel": getattr(w, "roof_kernel", "metric_eval_kernel<float>"),
                     "kernel_ms_per_step": kernel_ms, "launches_per_step": prof_n / max(1, a.steps),
                     "algorithmic_flops_per_chain_step": w.flops_per_unit(),
-                    "note": "fp32 vector == fp32 MFMA peak (157.3 TF); flop count is SURVEY 8d's 4 x 11.3 D^3 per "
-                            "explicit step (LAPACK-style eigh count); the Jacobi solver executes more"}
+                    "note": "fp32 vector == fp32 MFMA peak (157.3 TF); algorithmic flop count of SURVEY 8d "
+                            "(cfg3: 4 x 11.3 D^3 per explicit step, LAPACK-style eigh count -- the Jacobi solver executes "
+                            "more; cfg4: 2M x 6 flop per (point, weight) per split step)"}
         else:
             roof = None
         traffic = None

@@ -39,9 +39,9 @@ template <typename T> struct MlpArgs {
   int eval_split;
 };
 
-template <typename T> __device__ __forceinline__ T act_fn(int act, T z, T& dz) {
-  if (act == 0) { dz = z > (T)0 ? (T)1 : (T)0; return z > (T)0 ? z : (T)0; }
-  if (act == 1) { const T h = tanh(z); dz = (T)1 - h * h; return h; }
+template <int ACT, typename T> __device__ __forceinline__ T act_fn(T z, T& dz) {
+  if (ACT == 0) { dz = z > (T)0 ? (T)1 : (T)0; return z > (T)0 ? z : (T)0; }
+  if (ACT == 1) { const T h = tanh(z); dz = (T)1 - h * h; return h; }
   const T h = (T)1 / ((T)1 + exp(-z)); dz = h * ((T)1 - h); return h;
 }
 
@@ -51,7 +51,7 @@ template <int G, typename T> __device__ __forceinline__ T slice_sum(T v) {
   return v;
 }
 
-template <typename T, int INMAX, int PS, int NT>
+template <typename T, int INMAX, int PS, int NT, int ACT>
 struct MlpChain {
   // per-thread parameter record of hidden unit j
   struct Rec { T w1[INMAX]; T b1; T w2; T b2; };
@@ -76,16 +76,15 @@ struct MlpChain {
 
   // pass 1 over points [lo, lo+cnt): delta_i -> dv[i]; returns (sum r_i^2, sum delta_i)
   __device__ __forceinline__ T forward_chunk(const Rec& w, int lo, int cnt, T& sum_delta) {
-    const int n_in = a.n_in;
     __syncthreads();
     if (unit) {
       for (int i = s; i < cnt; i += PS) {
-        const T* x = Xs + (lo + i) * n_in;
+        const T* x = Xs + (lo + i) * INMAX;          // rows zero-padded to INMAX: no guards in the hot loops
         T z = w.b1;
 #pragma unroll
-        for (int k = 0; k < INMAX; ++k) if (k < n_in) z = fma(w.w1[k], x[k], z);
+        for (int k = 0; k < INMAX; ++k) z = fma(w.w1[k], x[k], z);
         T dz;
-        const T h = act_fn<T>(a.act, z, dz);
+        const T h = act_fn<ACT, T>(z, dz);
         cm[i * ldc + j] = w.w2 * h;
       }
     }
@@ -107,21 +106,23 @@ struct MlpChain {
 
   // pass 2: accumulate the likelihood gradient of points [lo, lo+cnt) into g (this thread's slice)
   __device__ __forceinline__ void backward_chunk(const Rec& w, int lo, int cnt, Rec& g) {
-    const int n_in = a.n_in;
     if (unit) {
       for (int i = s; i < cnt; i += PS) {
-        const T* x = Xs + (lo + i) * n_in;
+        const T* x = Xs + (lo + i) * INMAX;
+        T xv[INMAX];
+#pragma unroll
+        for (int k = 0; k < INMAX; ++k) xv[k] = x[k];
         T z = w.b1;
 #pragma unroll
-        for (int k = 0; k < INMAX; ++k) if (k < n_in) z = fma(w.w1[k], x[k], z);
+        for (int k = 0; k < INMAX; ++k) z = fma(w.w1[k], xv[k], z);
         T dz;
-        const T h = act_fn<T>(a.act, z, dz);
+        const T h = act_fn<ACT, T>(z, dz);
         const T d = dv[i];
         g.w2 = fma(d, h, g.w2);
         const T dh = d * w.w2 * dz;
         g.b1 += dh;
 #pragma unroll
-        for (int k = 0; k < INMAX; ++k) if (k < n_in) g.w1[k] = fma(dh, x[k], g.w1[k]);
+        for (int k = 0; k < INMAX; ++k) g.w1[k] = fma(dh, xv[k], g.w1[k]);
       }
     }
   }
@@ -155,7 +156,7 @@ struct MlpChain {
     if (unit && s == 0) {
       T sw = 0;
 #pragma unroll
-      for (int k = 0; k < INMAX; ++k) if (k < a.n_in) sw += w.w1[k] * w.w1[k];
+      for (int k = 0; k < INMAX; ++k) sw += w.w1[k] * w.w1[k];           // padding weights are exactly 0
       q = a.tau[0] * sw + a.tau[1] * w.b1 * w.b1 + a.tau[2] * w.w2 * w.w2;
     }
     if (tid == 0) q += a.tau[3] * w.b2 * w.b2;
@@ -181,7 +182,7 @@ struct MlpChain {
     T k = 0, dummy = 0;
     if (unit && s == 0) {
 #pragma unroll
-      for (int q = 0; q < INMAX; ++q) if (q < a.n_in) k += p.w1[q] * im.w1[q] * p.w1[q];
+      for (int q = 0; q < INMAX; ++q) k += p.w1[q] * im.w1[q] * p.w1[q];   // padding momenta are exactly 0
       k += p.b1 * im.b1 * p.b1 + p.w2 * im.w2 * p.w2;
     }
     if (tid == 0) k += p.b2 * im.b2 * p.b2;
@@ -200,20 +201,23 @@ struct MlpChain {
   }
 };
 
-template <typename T, int INMAX, int PS, int NT>
-__global__ __launch_bounds__(NT) void mlp1_hmc_kernel(MlpArgs<T> a, int nbch, int ldc) {
+template <typename T, int INMAX, int PS, int NT, int ACT>
+__global__ __launch_bounds__(NT, 4) void mlp1_hmc_kernel(MlpArgs<T> a, int nbch, int ldc) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  typedef MlpChain<T, INMAX, PS, NT> Ch;
+  typedef MlpChain<T, INMAX, PS, NT, ACT> Ch;
   typedef typename Ch::Rec Rec;
   Ch ch(a);
   const int tid = threadIdx.x, H = a.H, n_in = a.n_in;
   ch.tid = tid; ch.j = tid / PS; ch.s = tid % PS; ch.unit = ch.j < H; ch.nbch = nbch; ch.ldc = ldc;
   ch.Xs = reinterpret_cast<T*>(smem_raw);
-  ch.Ys = ch.Xs + a.N * n_in;
+  ch.Ys = ch.Xs + a.N * INMAX;
   ch.cm = ch.Ys + a.N;
   ch.dv = ch.cm + nbch * ldc;
   ch.red = ch.dv + nbch;
-  for (int e = tid; e < a.N * n_in; e += NT) ch.Xs[e] = a.X[e];
+  for (int e = tid; e < a.N * INMAX; e += NT) {
+    const int i = e / INMAX, k = e - i * INMAX;
+    ch.Xs[e] = (k < n_in) ? a.X[i * n_in + k] : (T)0;
+  }
   for (int e = tid; e < a.N; e += NT) ch.Ys[e] = a.Y[e];
   const int j = ch.unit ? ch.j : 0;
   const int D = H * n_in + 2 * H + 1;
@@ -334,10 +338,10 @@ __global__ __launch_bounds__(NT) void mlp1_hmc_kernel(MlpArgs<T> a, int nbch, in
   }
 }
 
-template <typename T, int INMAX, int PS, int NT> int launch_mlp(const MlpArgs<T>& a, hipStream_t s) {
+template <typename T, int INMAX, int PS, int NT, int ACT> int launch_mlp_act(const MlpArgs<T>& a, hipStream_t s) {
   // LDS: data set + chunk matrix [nbch][ldc] + delta vector + reduction scratch
   const int ldc = a.H | 1;
-  const size_t fixed = ((size_t)a.N * (a.n_in + 1) + 2 * (NT / 64) + 8) * sizeof(T);
+  const size_t fixed = ((size_t)a.N * (INMAX + 1) + 2 * (NT / 64) + 8) * sizeof(T);
   HTA_REQUIRE(fixed + (size_t)8 * (ldc + 1) * sizeof(T) <= 150 * 1024, "hta_mlp_hmc: data set (N=%d, in=%d) does not fit the LDS staging", a.N, a.n_in);
   int nbch = (int)((150 * 1024 - fixed) / ((ldc + 1) * sizeof(T)));
   const int need = a.Nb;
@@ -347,17 +351,23 @@ template <typename T, int INMAX, int PS, int NT> int launch_mlp(const MlpArgs<T>
   const size_t lds = fixed + (size_t)nbch * (ldc + 1) * sizeof(T);
   static bool done = false;
   if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp1_hmc_kernel<T, INMAX, PS, NT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp1_hmc_kernel<T, INMAX, PS, NT, ACT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { set_error("hta_mlp_hmc: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
     done = true;
   }
   const int grid = (int)(a.C < 4096 ? a.C : 4096);
   profile_begin(s);
-  mlp1_hmc_kernel<T, INMAX, PS, NT><<<grid, NT, lds, s>>>(a, nbch, ldc);
+  mlp1_hmc_kernel<T, INMAX, PS, NT, ACT><<<grid, NT, lds, s>>>(a, nbch, ldc);
   profile_end(s);
   HTA_CHECK_LAUNCH("hta_mlp_hmc");
   return HTA_OK;
+}
+
+template <typename T, int INMAX, int PS, int NT> int launch_mlp(const MlpArgs<T>& a, hipStream_t s) {
+  if (a.act == 0) return launch_mlp_act<T, INMAX, PS, NT, 0>(a, s);
+  if (a.act == 1) return launch_mlp_act<T, INMAX, PS, NT, 1>(a, s);
+  return launch_mlp_act<T, INMAX, PS, NT, 2>(a, s);
 }
 
 template <typename T, int INMAX> int dispatch_ps(const MlpArgs<T>& a, hipStream_t s) {
