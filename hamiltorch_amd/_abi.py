@@ -36,7 +36,8 @@ class HtaMetricArgs(ctypes.Structure):
                 ("seed", c_u64), ("chain_offset", c_u64), ("draw", c_u32), ("sub", c_u32), ("X", c_vp), ("Pm", c_vp),
                 ("mu", c_vp), ("log_norm", c_f64), ("m", c_vp), ("p_out", c_vp), ("x_out", c_vp), ("G_out", c_vp),
                 ("lam_out", c_vp), ("V_out", c_vp), ("L_out", c_vp), ("logdet_out", c_vp), ("quad_out", c_vp),
-                ("H_out", c_vp), ("logp_out", c_vp), ("upd_x", c_vp), ("cx", c_f64), ("upd_g", c_vp), ("cg", c_f64)]
+                ("H_out", c_vp), ("logp_out", c_vp), ("upd_x", c_vp), ("cx", c_f64), ("upd_g", c_vp), ("cg", c_f64),
+                ("V0", c_vp), ("lam0", c_vp), ("lamraw_out", c_vp)]
 
 
 METRIC_HESSIAN, METRIC_SOFTABS = 0, 1
@@ -239,7 +240,7 @@ def hmc_gaussian_leapfrog(theta, p, P, mu, mass_kind, inv_mass, steps, eps, path
 def metric_eval(like, B, D, metric, Hs, hs_stride, alpha, jitter=None, seed=0, chain_offset=0, draw=0, sub=0, X=None,
                 Pm=None, mu=None, log_norm=0.0, m=None, p_out=None, x_out=None, G_out=None, lam_out=None, V_out=None,
                 L_out=None, logdet_out=None, quad_out=None, H_out=None, logp_out=None, upd_x=None, cx=0.0, upd_g=None,
-                cg=0.0, max_sweeps=0):
+                cg=0.0, max_sweeps=0, V0=None, lam0=None, lamraw_out=None):
     """One batched metric evaluation (see HtaMetricArgs in include/hamiltorch_amd.h).  `like` fixes dtype/device."""
     require_device(like, "params")
     a = HtaMetricArgs()
@@ -251,7 +252,7 @@ def metric_eval(like, B, D, metric, Hs, hs_stride, alpha, jitter=None, seed=0, c
     for name, t in (("Hs", Hs), ("X", X), ("Pm", Pm), ("mu", mu), ("m", m), ("p_out", p_out), ("x_out", x_out),
                     ("G_out", G_out), ("lam_out", lam_out), ("V_out", V_out), ("L_out", L_out),
                     ("logdet_out", logdet_out), ("quad_out", quad_out), ("H_out", H_out), ("logp_out", logp_out),
-                    ("upd_x", upd_x), ("upd_g", upd_g)):
+                    ("upd_x", upd_x), ("upd_g", upd_g), ("V0", V0), ("lam0", lam0), ("lamraw_out", lamraw_out)):
         setattr(a, name, None if t is None else _p(t, like).value)
         keep.append(t)
     fn = getattr(load(), "hta_metric_eval_" + _suffix(like))

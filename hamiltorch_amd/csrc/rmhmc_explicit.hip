@@ -34,6 +34,7 @@ __global__ void phi_c_kernel(T* __restrict__ th, T* __restrict__ pm, T* __restri
 template <typename T> struct RmModel {
   const T* P; const T* mu; double log_norm; int metric; double alpha; int has_jitter; double jitter;
   uint64_t seed; uint64_t chain_offset; int64_t C; int D;
+  const T* V0; const T* lam0;     // eigenbasis of the jitter-free P (warm start), or NULL
 };
 
 template <typename T> static MetricArgsT<T> base_args(const RmModel<T>& m, uint32_t draw, uint32_t sub) {
@@ -42,6 +43,7 @@ template <typename T> static MetricArgsT<T> base_args(const RmModel<T>& m, uint3
   a.B = m.C; a.D = m.D; a.metric = m.metric; a.Hs = m.P; a.hs_stride = 0; a.alpha = m.alpha;
   a.has_jitter = m.has_jitter; a.jitter = m.jitter; a.seed = m.seed; a.chain_offset = m.chain_offset;
   a.draw = draw; a.sub = sub; a.Pm = m.P; a.mu = m.mu; a.log_norm = m.log_norm;
+  a.V0 = m.V0; a.lam0 = m.lam0;
   return a;
 }
 
@@ -82,7 +84,7 @@ int rmhmc_leapfrog(T* th, T* pm, T* thc, T* pmc, const T* P, const T* mu, int me
                    double jitter, uint64_t seed, uint64_t chain_offset, uint32_t draw, int64_t C, int D, int steps,
                    double eps, double omega, T* path_theta, T* path_p, hipStream_t s) {
   HTA_REQUIRE(th && pm && thc && pmc && P && mu && C > 0 && D > 0 && steps >= 0, "hta_rmhmc_gaussian_leapfrog: bad arguments");
-  RmModel<T> m{P, mu, 0.0, metric, alpha, has_jitter, jitter, seed, chain_offset, C, D};
+  RmModel<T> m{P, mu, 0.0, metric, alpha, has_jitter, jitter, seed, chain_offset, C, D, nullptr, nullptr};
   return explicit_steps<T>(m, draw, th, pm, thc, pmc, steps, eps, omega, path_theta, path_p, s);
 }
 
@@ -95,11 +97,21 @@ int rmhmc_sample(T* cur, const T* theta_init, const T* P, const T* mu, double lo
   const char* who = "hta_rmhmc_gaussian_sample";
   HTA_REQUIRE(cur && theta_init && P && mu && reject_count && C > 0 && D > 0 && L >= 0 && n_traj >= 0, "%s: bad arguments", who);
   const int64_t total = C * D;
-  const int64_t need = (4 * total + 3 * C) * (int64_t)sizeof(T);
+  const int64_t need = (4 * total + 3 * C + (int64_t)D * D + D) * (int64_t)sizeof(T);
   HTA_REQUIRE(workspace && workspace_bytes >= need, "%s: workspace of %lld bytes required", who, (long long)need);
   T* th = (T*)workspace; T* pm = th + total; T* thc = pm + total; T* pmc = thc + total;
   T* H0 = pmc + total; T* H1 = H0 + C; T* lp1 = H1 + C;
-  RmModel<T> m{P, mu, log_norm, metric, alpha, has_jitter, jitter, seed, chain_offset, C, D};
+  T* V0 = lp1 + C; T* lam0 = V0 + (int64_t)D * D;
+  RmModel<T> m{P, mu, log_norm, metric, alpha, has_jitter, jitter, seed, chain_offset, C, D, nullptr, nullptr};
+  if (metric == HTA_METRIC_SOFTABS) {
+    // the target's curvature is one matrix for all chains and all evaluation points; every evaluation only adds
+    // its own jitter to the diagonal.  Diagonalise it once and start every per-chain Jacobi from that basis.
+    MetricArgsT<T> a0 = base_args(m, 0, 0);
+    a0.B = 1; a0.has_jitter = 0; a0.V_out = V0; a0.lamraw_out = lam0;
+    int rc0 = metric_eval<T>(a0, s);
+    if (rc0) return rc0;
+    m.V0 = V0; m.lam0 = lam0;
+  }
   for (int t = 0; t < n_traj; ++t) {
     const int n = traj_offset + t;
     int rc;
@@ -136,7 +148,9 @@ int rmhmc_sample(T* cur, const T* theta_init, const T* P, const T* mu, double lo
 }  // namespace hta
 
 extern "C" {
-int64_t hta_rmhmc_workspace_bytes(int64_t C, int D, int elem_size) { return (4 * C * D + 3 * C) * (int64_t)elem_size; }
+int64_t hta_rmhmc_workspace_bytes(int64_t C, int D, int elem_size) {
+  return (4 * C * D + 3 * C + (int64_t)D * D + D) * (int64_t)elem_size;
+}
 
 #define HTA_DEFINE_RM(SUF, T)                                                                                   \
   int hta_rmhmc_gaussian_leapfrog_##SUF(T* theta, T* p, T* theta_copy, T* p_copy, const T* P, const T* mu,       \

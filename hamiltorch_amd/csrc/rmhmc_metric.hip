@@ -190,7 +190,7 @@ __device__ void lds_jacobi(T* A, T* V, int D, int ne, int lda, int ldv, T* cs, i
 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int ne, int lda, int ldv) {
+__global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int ne, int lda, int ldv, int v0_lds) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = a.D, tid = threadIdx.x;
   T* A = reinterpret_cast<T*>(smem_raw);
@@ -203,6 +203,15 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
   T* red = cs + ne;               // MT / 64
   int* pq = reinterpret_cast<int*>(red + MT / 64);
   const bool softabs = a.metric == 1;
+  // warm start: the shared eigenbasis V0 of the jitter-free Hs (LDS copy when it fits, else L2)
+  const bool warm = softabs && a.V0 && a.lam0 && a.hs_stride == 0;
+  T* V0s = reinterpret_cast<T*>(pq + ne);
+  const T* V0 = a.V0;
+  int ld0 = D;
+  if (warm && v0_lds) {
+    for (int e = tid; e < D * D; e += MT) { const int i = e / D, j = e - i * D; V0s[i * ldv + j] = a.V0[e]; }
+    V0 = V0s; ld0 = ldv;
+  }
 
   for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
     const uint64_t chain = a.chain_offset + (uint64_t)b;
@@ -224,14 +233,31 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
     }
     // ---- 1. Hs (lower triangle, as eigh(UPLO='L')) + jitter on the diagonal  (S:113-119)
     const T* Hs = a.Hs + b * a.hs_stride;
-    for (int e = tid; e < ne * ne; e += MT) {
-      const int i = e / ne, j = e - i * ne;
-      T v = 0;
-      if (i < D && j < D) {
-        v = (i >= j) ? Hs[(int64_t)i * D + j] : Hs[(int64_t)j * D + i];
-        if (i == j && a.has_jitter) v += (T)a.jitter * uniform_elem<T>(a.seed, chain, a.draw, PURPOSE_JITTER, a.sub, i);
+    if (!warm) {
+      for (int e = tid; e < ne * ne; e += MT) {
+        const int i = e / ne, j = e - i * ne;
+        T v = 0;
+        if (i < D && j < D) {
+          v = (i >= j) ? Hs[(int64_t)i * D + j] : Hs[(int64_t)j * D + i];
+          if (i == j && a.has_jitter) v += (T)a.jitter * uniform_elem<T>(a.seed, chain, a.draw, PURPOSE_JITTER, a.sub, i);
+        }
+        A[i * lda + j] = v;
       }
-      A[i * lda + j] = v;
+    } else {
+      // A = V0^T (Hs + diag(e)) V0 = diag(lam0) + sum_i e_i v0_i v0_i^T   (v0_i = row i of V0), e = jitter * u
+      __syncthreads();
+      for (int i = tid; i < D; i += MT)
+        vec1[i] = a.has_jitter ? (T)a.jitter * uniform_elem<T>(a.seed, chain, a.draw, PURPOSE_JITTER, a.sub, i) : (T)0;
+      __syncthreads();
+      for (int e = tid; e < ne * ne; e += MT) {
+        const int k = e / ne, l = e - k * ne;
+        if (k >= D || l >= D) { A[k * lda + l] = 0; continue; }
+        if (l < k) continue;
+        T acc = (k == l) ? a.lam0[k] : (T)0;
+        if (a.has_jitter)
+          for (int i = 0; i < D; ++i) acc += vec1[i] * V0[i * ld0 + k] * V0[i * ld0 + l];
+        A[k * lda + l] = acc; A[l * lda + k] = acc;
+      }
     }
     T logdet = 0, quad = 0;
     if (softabs) {
@@ -246,11 +272,36 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
         vec0[i] = lt;
         ld += log(lt);                                                  // S:726
         if (a.lam_out) a.lam_out[b * D + i] = lt;
+        if (a.lamraw_out) a.lamraw_out[b * D + i] = lam;
       }
       logdet = block_sum(ld, red);
+      if (warm && (a.V_out || a.G_out || a.p_out || a.L_out)) {
+        // eigenvectors in the original basis: V <- V0 J  (through the A region; its eigenvalues are in vec0)
+        __syncthreads();
+        for (int e = tid; e < D * D; e += MT) {
+          const int i = e / D, j = e - i * D;
+          T acc = 0;
+          for (int k = 0; k < D; ++k) acc += V0[i * ld0 + k] * V[k * ldv + j];
+          A[i * lda + j] = acc;
+        }
+        __syncthreads();
+        for (int e = tid; e < D * D; e += MT) { const int i = e / D, j = e - i * D; V[i * ldv + j] = A[i * lda + j]; }
+        __syncthreads();
+      }
+      const bool rotated = warm && !(a.V_out || a.G_out || a.p_out || a.L_out);   // V still holds J
       if (a.V_out) for (int e = tid; e < D * D; e += MT) { const int i = e / D, j = e - i * D; a.V_out[b * D * D + e] = V[i * ldv + j]; }
       if (a.m) {                       // x = Q (Q^T m / lam~)
-        for (int i = tid; i < D; i += MT) vec2[i] = a.m[b * D + i];
+        if (rotated) {                 // m' = V0^T m
+          for (int i = tid; i < D; i += MT) vec1[i] = a.m[b * D + i];
+          __syncthreads();
+          for (int k = tid; k < D; k += MT) {
+            T acc = 0;
+            for (int i = 0; i < D; ++i) acc += V0[i * ld0 + k] * vec1[i];
+            vec2[k] = acc;
+          }
+        } else {
+          for (int i = tid; i < D; i += MT) vec2[i] = a.m[b * D + i];
+        }
         __syncthreads();
         T qd = 0;
         for (int k = tid; k < D; k += MT) {
@@ -261,9 +312,18 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
           qd += acc * w;
         }
         quad = block_sum(qd, red);
+        if (rotated) {                 // x = V0 (J w)
+          for (int i = tid; i < D; i += MT) {
+            T acc = 0;
+            for (int k = 0; k < D; ++k) acc += V[i * ldv + k] * vec1[k];
+            vec3[i] = acc;
+          }
+          __syncthreads();
+        }
         for (int i = tid; i < D; i += MT) {
           T acc = 0;
-          for (int k = 0; k < D; ++k) acc += V[i * ldv + k] * vec1[k];
+          if (rotated) { for (int k = 0; k < D; ++k) acc += V0[i * ld0 + k] * vec3[k]; }
+          else { for (int k = 0; k < D; ++k) acc += V[i * ldv + k] * vec1[k]; }
           if (a.x_out) a.x_out[b * D + i] = acc;
           if (a.upd_x) a.upd_x[b * D + i] += (T)a.cx * acc;
         }
@@ -344,7 +404,10 @@ template <typename T> int metric_eval(const MetricArgsT<T>& a, hipStream_t s) {
   };
   int lda = ne + 1, ldv = (D | 1);
   if (bytes(lda, ldv) > 160 * 1024) { lda = ne; ldv = D; }
-  const size_t lds = bytes(lda, ldv);
+  size_t lds = bytes(lda, ldv);
+  const bool warm = a.metric == 1 && a.V0 && a.lam0 && a.hs_stride == 0;
+  int v0_lds = 0;
+  if (warm && lds + (size_t)D * ldv * sizeof(T) <= 160 * 1024) { v0_lds = 1; lds += (size_t)D * ldv * sizeof(T); }
   HTA_REQUIRE(lds <= 160 * 1024, "hta_metric_eval: D=%d does not fit the 160 KiB LDS of a CU for this dtype (max ~140 fp32 / ~99 fp64)", D);
   static bool attr_f = false, attr_d = false;
   bool& done = sizeof(T) == 4 ? attr_f : attr_d;
@@ -358,7 +421,7 @@ template <typename T> int metric_eval(const MetricArgsT<T>& a, hipStream_t s) {
   if (k.max_sweeps <= 0) k.max_sweeps = sizeof(T) == 4 ? 16 : 24;
   const int grid = (int)(a.B < 65536 ? a.B : 65536);
   profile_begin(s);
-  metric_eval_kernel<T><<<grid, MT, lds, s>>>(k, ne, lda, ldv);
+  metric_eval_kernel<T><<<grid, MT, lds, s>>>(k, ne, lda, ldv, v0_lds);
   profile_end(s);
   HTA_CHECK_LAUNCH("hta_metric_eval");
   return HTA_OK;

@@ -170,6 +170,11 @@ typedef struct HtaMetricArgs {
                                              /* H = -logp + D/2 log 2pi + 1/2 log|G| + 1/2 m^T G^-1 m (S:731) */
   void* upd_x; double cx; void* upd_g; double cg;
                                              /* fused half step: upd_x[b,:] += cx * x ; upd_g[b,:] += cg * Pd */
+  const void* V0; const void* lam0;          /* optional warm start (shared Hs only, hs_stride == 0): eigenvectors
+                                                [D,D] (columns) and eigenvalues [D] of the jitter-free Hs.  The
+                                                solver then diagonalises diag(lam0) + V0^T diag(jitter u) V0, which
+                                                is nearly diagonal: 2 Jacobi sweeps instead of ~10; same results    */
+  void* lamraw_out;                          /* [B,D] eigenvalues before the soft-abs map                           */
 } HtaMetricArgs;
 
 int hta_metric_eval_f32(const HtaMetricArgs* args, void* stream);
