@@ -199,3 +199,25 @@ def test_cfg3_shape_smoke_and_errors(ht):
     with pytest.raises(RuntimeError, match="gradients not implemented for RMHMC"):     # S:390-391
         ht.sample(t, th0[0].clone(), num_samples=2, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT,
                   softabs_const=1e6, metric=ht.Metric.SOFTABS, pass_grad=lambda w: w, verbose=False)
+
+
+def test_cfg3_statistical_parity_with_jitter(ht):
+    """T2 at BASELINE config 3: D=100, 256 chains, softabs alpha=1e6, omega=10, eps=0.1, L=10,
+    jitter=1e-3 (stochastic Hamiltonian: only distributional parity exists).  Pooled marginal variances must match
+    diag(P^-1) and the acceptance rate the reference's 1.0."""
+    t, o = cfg3_target(ht, 100, torch.float32)
+    C, N = 256, 60
+    g = torch.Generator().manual_seed(0)
+    cov = np.linalg.inv(o.P.astype(np.float64))
+    th0 = torch.tensor(np.random.default_rng(0).multivariate_normal(np.zeros(100), cov, size=C), dtype=torch.float32, device=dev())
+    out, acc = ht.sample(t, th0, num_samples=N, num_steps_per_sample=10, step_size=0.1, burn=-1, jitter=1e-3,
+                         softabs_const=1e6, explicit_binding_const=10, sampler=ht.Sampler.RMHMC,
+                         integrator=ht.Integrator.EXPLICIT, metric=ht.Metric.SOFTABS, debug=2, verbose=False, seed=7)
+    s = torch.stack(out[N // 2:]).double().cpu().numpy().reshape(-1, 100)
+    assert float(acc.mean()) > 0.97
+    var = s.var(axis=0)
+    np.testing.assert_allclose(var, np.diag(cov), rtol=0.12)
+    assert abs(s.mean()) < 0.02
+    # the chains actually move: lag-N/2 autocorrelation of the slowest coordinate is far from 1
+    a = torch.stack(out).double().cpu().numpy()
+    assert np.abs(a[-1] - a[0]).mean() > 0.3
