@@ -156,7 +156,24 @@ class Cfg3:
         return 1.0 - float(self.rej.double().mean()) / (self.T * max(1, self._steps_done))
 
     def cpu_baseline(self, seconds):
-        return None
+        """Reference cost structure: every dH/dtheta, dH/dp is an autograd pass through hessian + eigh (S:395-422)."""
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import torch_port as TP
+        torch.set_num_threads(1)
+        P = self.P64.float()
+
+        def lp(w):
+            return -0.5 * torch.dot(w, torch.mv(P, w))
+        init = 0.1 * torch.randn(self.D, generator=torch.Generator().manual_seed(0))
+        torch.manual_seed(0)
+        t0 = time.time(); TP.port_sample_rmhmc(lp, init, 1, 1, self.eps, self.omega, self.alpha); dt1 = time.time() - t0
+        n = max(1, int(seconds / (dt1 * self.L)))
+        t0 = time.time(); _, acc = TP.port_sample_rmhmc(lp, init, n, self.L, self.eps, self.omega, self.alpha, burn=-1)
+        dt = time.time() - t0
+        return {"value": n * self.L / dt, "unit": "leapfrog-steps/s", "cores": 1, "kind": "port",
+                "sample": "1 chain x %d trajectories x L=%d explicit steps, jitter=None (oracle/torch_port.py: autograd "
+                          "through hessian+eigh per gradient, as the reference), %.1f s" % (n, self.L, dt),
+                "acceptance": acc}
 
 
 class Cfg4:
@@ -204,7 +221,23 @@ class Cfg4:
         return 1.0 - float(self.rej.double().mean()) / (self.T * max(1, self._steps_done))
 
     def cpu_baseline(self, seconds):
-        return None
+        """Reference cost structure: per-split closure + autograd gradient for every half kick (S:499-540)."""
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import torch_port as TP
+        torch.set_num_threads(1)
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(8, 100), torch.nn.ReLU(), torch.nn.Linear(100, 1))
+        X, Y = self.X.cpu(), self.Y.cpu().reshape(-1, 1)
+        fl = [TP.port_mlp_closure(net, X[m * 100:(m + 1) * 100], Y[m * 100:(m + 1) * 100], torch.ones(4), 100.0, 4)
+              for m in range(4)]
+        init = self.theta0[0].cpu()
+        im = torch.ones(self.D)
+        t0 = time.time(); TP.port_sample_split(fl, init, 2, self.L, self.eps, -1, im); dt2 = time.time() - t0
+        n = max(2, int(seconds / (dt2 / 2)))
+        t0 = time.time(); _, acc = TP.port_sample_split(fl, init, n, self.L, self.eps, -1, im); dt = time.time() - t0
+        return {"value": n * self.L / dt, "unit": "leapfrog-steps/s", "cores": 1, "kind": "port",
+                "sample": "1 chain x %d trajectories x L=%d split steps (oracle/torch_port.py: functional model + "
+                          "autograd per half kick, as the reference), %.1f s" % (n, self.L, dt), "acceptance": acc}
 
 
 WORKLOADS = {"cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4}

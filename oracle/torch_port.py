@@ -98,3 +98,168 @@ def port_sample(log_prob_func, params_init, num_samples, num_steps_per_sample, s
             else:
                 params = burn_prev.clone()
     return ret, 1 - rejected / num_samples
+
+
+# ---------------------------------------------------------------------------------------------------
+# Explicit RMHMC (soft-abs / Hessian metric) -- same cost structure as the reference: every gradient
+# of the Riemannian Hamiltonian is an autograd pass through hessian + eigh + Cholesky (S:395-422).
+# ---------------------------------------------------------------------------------------------------
+def port_fisher(q, log_prob_func, alpha, softabs=True):
+    """S:96-122 with jitter=None."""
+    hess = torch.autograd.functional.hessian(log_prob_func, q, create_graph=True)   # S:108
+    fish = -hess
+    if not softabs:
+        return fish, None
+    lam, Q = torch.linalg.eigh(fish, UPLO='L')                                       # S:119
+    lam_t = (1. / torch.tanh(alpha * lam)) * lam                                     # S:120
+    return torch.matmul(Q, torch.matmul(lam_t.diag(), Q.t())), lam_t                 # S:121
+
+
+def port_rm_hamiltonian(q, p, log_prob_func, alpha, softabs=True):
+    """S:710-731."""
+    from numpy import pi
+    lp = log_prob_func(q)
+    pi_term = q.nelement() * torch.log(2. * torch.tensor(pi))                        # S:712 (float32)
+    fish, lam_t = port_fisher(q, log_prob_func, alpha, softabs)
+    logdet = lam_t.log().sum() if softabs else torch.slogdet(fish)[1]                # S:726 / S:728
+    low = torch.linalg.cholesky(fish)                                                # S:146-148
+    y = torch.linalg.solve_triangular(low, p.view(-1, 1), upper=False)
+    x = torch.linalg.solve_triangular(low.t(), y, upper=True)
+    return -lp + 0.5 * pi_term + 0.5 * logdet + 0.5 * torch.matmul(p.view(1, -1), x)
+
+
+def port_explicit_leapfrog(q, p, log_prob_func, steps, step_size, omega, alpha, softabs=True):
+    """S:425-461."""
+    def dH_dq(qq, pp):                                                               # S:395-398
+        qq = qq.detach().requires_grad_()
+        return torch.autograd.grad(port_rm_hamiltonian(qq, pp.detach(), log_prob_func, alpha, softabs), qq)[0]
+
+    def dH_dp(qq, pp):                                                               # S:415-422
+        pp = pp.detach().requires_grad_(); qq = qq.detach().requires_grad_()
+        return torch.autograd.grad(port_rm_hamiltonian(qq, pp, log_prob_func, alpha, softabs), pp)[0]
+    q = q.clone(); p = p.clone(); qc = q.clone(); pc = p.clone()
+    for _ in range(steps):
+        p = p - 0.5 * step_size * dH_dq(q, pc)
+        qc = qc + 0.5 * step_size * dH_dp(q, pc)
+        q = q + 0.5 * step_size * dH_dp(qc, p)
+        pc = pc - 0.5 * step_size * dH_dq(qc, p)
+        c = torch.cos(torch.FloatTensor([2 * omega * step_size])); s = torch.sin(torch.FloatTensor([2 * omega * step_size]))
+        q = 0.5 * ((q + qc) + c * (q - qc) + s * (p - pc))                           # S:447-450, sequential
+        p = 0.5 * ((p + pc) - s * (q - qc) + c * (p - pc))
+        qc = 0.5 * ((q + qc) - c * (q - qc) - s * (p - pc))
+        pc = 0.5 * ((p + pc) + s * (q - qc) - c * (p - pc))
+        q = q + 0.5 * step_size * dH_dp(qc, p)
+        pc = pc - 0.5 * step_size * dH_dq(qc, p)
+        p = p - 0.5 * step_size * dH_dq(q, pc)
+        qc = qc + 0.5 * step_size * dH_dp(q, pc)
+    return q, p
+
+
+def port_sample_rmhmc(log_prob_func, params_init, num_samples, num_steps_per_sample, step_size, omega, alpha, burn=0,
+                      softabs=True):
+    """S:969-1026, RMHMC / EXPLICIT branch, jitter=None."""
+    params = params_init.clone().requires_grad_()
+    burn_prev = params_init.clone()
+    ret = [params_init.clone()]
+    rejected = 0
+    for n in range(num_samples):
+        G, _ = port_fisher(params, log_prob_func, alpha, softabs)
+        p = torch.distributions.MultivariateNormal(torch.zeros_like(params), G).sample()   # S:183-184
+        ham = 2 * port_rm_hamiltonian(params, p, log_prob_func, alpha, softabs) / 2       # S:822, S:977
+        q_new, p_new = port_explicit_leapfrog(params, p, log_prob_func, num_steps_per_sample, step_size, omega, alpha, softabs)
+        params = q_new.detach().requires_grad_()
+        new_ham = port_rm_hamiltonian(params, p_new, log_prob_func, alpha, softabs)       # S:989
+        rho = min(0., float(-new_ham + ham))
+        if rho >= torch.log(torch.rand(1)):
+            if n > burn:
+                ret.append(q_new.detach())
+            else:
+                burn_prev = q_new.detach().clone()
+        else:
+            rejected += 1
+            if n > burn:
+                params = ret[-1]
+                ret.append(ret[-1])
+            else:
+                params = burn_prev.clone()
+    return [t.detach() for t in ret], 1 - rejected / num_samples
+
+
+# ---------------------------------------------------------------------------------------------------
+# Bayesian MLP closures + symmetric split HMC (S:1141-1258, S:494-547)
+# ---------------------------------------------------------------------------------------------------
+def port_mlp_closure(model, x, y, tau_list, tau_out, prior_scale):
+    """define_model_log_prob(model_loss='regression'), S:1145-1199."""
+    names = [n for n, _ in model.named_parameters()]
+    shapes = [w.shape for w in model.parameters()]
+    sizes = [w.nelement() for w in model.parameters()]
+    dists = [torch.distributions.Normal(torch.zeros_like(t), t ** -0.5) for t in tau_list]
+
+    def f(params):
+        i = 0
+        l_prior = torch.zeros_like(params[0], requires_grad=True)
+        tensors = {}
+        for name, n, shp, d in zip(names, sizes, shapes, dists):
+            w = params[i:i + n]
+            l_prior = d.log_prob(w).sum() + l_prior
+            tensors[name] = w.view(shp)
+            i += n
+        out = torch.func.functional_call(model, tensors, (x,))
+        ll = - 0.5 * tau_out * ((out - y) ** 2).sum(0)
+        return ll + l_prior / prior_scale
+    return f
+
+
+def port_sample_split(closures, params_init, num_samples, num_steps_per_sample, step_size, burn=0, inv_mass=None):
+    """sample(integrator=SPLITTING) over a list of closures: S:494-547 inside S:965-1026."""
+    M = len(closures)
+    mass = None if inv_mass is None else 1 / inv_mass
+    params = params_init.clone()
+    burn_prev = params_init.clone()
+    ret = [params.clone()]
+    rejected = 0
+
+    def ham(q, p):
+        lp = 0
+        with torch.no_grad():
+            for f in closures:
+                lp = lp + f(q)
+        kin = 0.5 * torch.dot(p, p) if inv_mass is None else 0.5 * torch.dot(p, inv_mass * p)
+        return -lp + kin
+
+    def grad(q, f):
+        q = q.detach().requires_grad_()
+        return torch.autograd.grad(f(q), q)[0]
+    for n in range(num_samples):
+        p = port_gibbs(params, mass)
+        h0 = ham(params, p)
+        q = params.detach().clone()
+        for _ in range(num_steps_per_sample):
+            for m in range(M):
+                g = grad(q, closures[m])
+                with torch.no_grad():
+                    p += 0.5 * step_size * g
+                    if m < M - 1:
+                        q += (step_size / ((M - 1) * 2)) * (p if inv_mass is None else inv_mass * p)
+            for m in reversed(range(M)):
+                g = grad(q, closures[m])
+                with torch.no_grad():
+                    p += 0.5 * step_size * g
+                    if m > 0:
+                        q += (step_size / ((M - 1) * 2)) * (p if inv_mass is None else inv_mass * p)
+        h1 = ham(q, p)
+        rho = min(0., float(-h1 + h0))
+        if rho >= torch.log(torch.rand(1)):
+            params = q.clone()
+            if n > burn:
+                ret.append(q.clone())
+            else:
+                burn_prev = q.clone()
+        else:
+            rejected += 1
+            if n > burn:
+                params = ret[-1]
+                ret.append(ret[-1])
+            else:
+                params = burn_prev.clone()
+    return ret, 1 - rejected / num_samples
