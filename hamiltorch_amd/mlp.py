@@ -28,36 +28,46 @@ def _common_spec(fns):
 
 
 class _MLPEngine:
-    """run() contract of samplers._GaussianHMC."""
+    """Same engine shape as samplers._GaussianHMC (begin / advance / finish / run / run_nuts)."""
 
-    def __init__(self, specs, fallback):
-        self.specs, self.fallback = specs, fallback
-        s0 = specs[0]
-        self.n_in, self.H = s0["dims"][0], s0["dims"][1]
-        self.act, self.tau, self.tau_out, self.prior_scale = s0["act"], s0["tau_list"], s0["tau_out"], s0["prior_scale"]
-        self.M, self.Nb = len(specs), s0["X"].shape[0]
+    def __new__(cls, specs, fallback):
+        from .samplers import _Engine
 
-    def _data(self, like):
-        X = torch.cat([s["X"].reshape(self.Nb, self.n_in) for s in self.specs]).to(like).contiguous()
-        Y = torch.cat([s["Y"].reshape(self.Nb) for s in self.specs]).to(like).contiguous()
-        return X, Y
+        class Impl(_Engine):
+            def __init__(self, specs, fallback):
+                self.specs, self.fallback = specs, fallback
+                s0 = specs[0]
+                self.n_in, self.H = s0["dims"][0], s0["dims"][1]
+                self.act, self.tau, self.tau_out, self.prior_scale = s0["act"], s0["tau_list"], s0["tau_out"], s0["prior_scale"]
+                self.M, self.Nb = len(specs), s0["X"].shape[0]
+                self._fb = None
 
-    def run(self, theta0, N, L, eps, burn, inv_mass, seed, chain_offset, verbose, label):
-        from .samplers import _mass_operands, _num_rows
-        kind, im, mf = _mass_operands(inv_mass, theta0)
-        if kind == _abi.MASS_FULL or theta0.shape[1] != self.H * self.n_in + 2 * self.H + 1:
-            return self.fallback().run(theta0, N, L, eps, burn, inv_mass, seed, chain_offset, verbose, label)
-        C, D = theta0.shape
-        X, Y = self._data(theta0)
-        samples = torch.empty((_num_rows(N, burn), C, D), dtype=theta0.dtype, device=theta0.device)
-        samples[0].copy_(theta0)
-        cur = theta0.clone()
-        rejected = torch.zeros(C, dtype=torch.int32, device=theta0.device)
-        prog = util._Progress('Sampling ' + label, N, verbose)
-        _abi.mlp_hmc_sample(cur, theta0, self.n_in, self.H, self.act, X, Y, self.M, self.Nb, self.tau, self.tau_out,
-                            self.prior_scale, kind, im, mf, L, eps, N, 0, burn, seed, chain_offset, samples, rejected)
-        prog.end()
-        return samples, rejected
+            def begin(self, theta0, N, burn, inv_mass, seed, chain_offset):
+                from .samplers import _mass_operands
+                kind = _mass_operands(inv_mass, theta0)[0]
+                if kind == _abi.MASS_FULL or theta0.shape[1] != self.H * self.n_in + 2 * self.H + 1:
+                    self._fb = self.fallback()          # full mass matrix / unexpected layout: generic-callback path
+                    return self._fb.begin(theta0, N, burn, inv_mass, seed, chain_offset)
+                super().begin(theta0, N, burn, inv_mass, seed, chain_offset)
+                self.X = torch.cat([s["X"].reshape(self.Nb, self.n_in) for s in self.specs]).to(theta0).contiguous()
+                self.Y = torch.cat([s["Y"].reshape(self.Nb) for s in self.specs]).to(theta0).contiguous()
+
+            def advance(self, n0, count, L, eps, H_old=None, H_new=None, progress=None):
+                if self._fb is not None:
+                    return self._fb.advance(n0, count, L, eps, H_old, H_new, progress)
+                step = 1 if H_old is not None else count
+                for start in range(n0, n0 + count, step):
+                    _abi.mlp_hmc_sample(self.cur, self.theta0, self.n_in, self.H, self.act, self.X, self.Y, self.M,
+                                        self.Nb, self.tau, self.tau_out, self.prior_scale, self.kind, self.im, self.mf,
+                                        L, eps, min(step, n0 + count - start), start, self.burn, self.seed, self.off,
+                                        self.samples, self.rejected, H_old, H_new)
+                if progress is not None:
+                    progress.update(min(self.N, n0 + count) - 1)
+
+            def finish(self):
+                return self._fb.finish() if self._fb is not None else super().finish()
+
+        return Impl(specs, fallback)
 
 
 def split_engine(log_prob_list, theta0):

@@ -326,7 +326,7 @@ def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, 
     if sampler == Sampler.HMC_NUTS:
         if burn == 0:
             raise RuntimeError('burn must be greater than 0 for NUTS.')         # S:933-934
-        raise NotImplementedError("step-size dual averaging (Sampler.HMC_NUTS) is not in the accelerated path yet")
+        sampler, nuts = Sampler.HMC, True                                       # S:935-936
     _abi.require_device(params_init, "params_init")
     _abi.load()
     theta0, one = _as_batch(params_init, "params_init")
@@ -354,8 +354,14 @@ def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, 
                     eng = bnn.native_hmc_engine(log_prob_func, theta0)
                 if eng is None:
                     eng = _GenericHMC(log_prob_func, pass_grad)
-            samples, rejected = eng.run(theta0, num_samples, num_steps_per_sample, step_size, burn_k, inv_mass,
-                                        seed, chain_offset, verbose, '({}; {})'.format(sampler, integrator))
+            label = '({}; {})'.format(sampler, integrator)
+            if nuts:
+                samples, rejected = eng.run_nuts(theta0, num_samples, num_steps_per_sample, step_size, burn_k, inv_mass,
+                                                 seed, chain_offset, verbose, label, desired_accept_rate)
+                step_size = eng.final_step_size
+            else:
+                samples, rejected = eng.run(theta0, num_samples, num_steps_per_sample, step_size, burn_k, inv_mass,
+                                            seed, chain_offset, verbose, label)
         elif sampler == Sampler.RMHMC and integrator == Integrator.EXPLICIT:
             if pass_grad is not None:
                 raise RuntimeError('Passing user-determined gradients not implemented for RMHMC')
@@ -375,12 +381,91 @@ def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, 
     acc = 1.0 - rejected.to(torch.float64) / float(num_samples)                # S:1085 / S:1089 (burn-in included)
     if verbose:
         print('Acceptance Rate {:.2f}'.format(float(acc.mean())))
+    if nuts and debug == 2:
+        return rows, step_size                                                  # S:1086-1087
     if debug == 2:
         return rows, (float(acc[0]) if one else acc)
     return rows
 
 
-class _GaussianHMC:
+class _Engine:
+    """Common shape of the HMC engines: ``begin`` allocates state, ``advance`` runs trajectories
+    [n0, n0 + count) with one step size, ``finish`` hands back (samples[S,C,D], rejected[C]).
+    ``run`` is the plain fixed-step-size sample(); ``run_nuts`` adds the burn-in dual averaging."""
+
+    def begin(self, theta0, N, burn, inv_mass, seed, chain_offset):
+        C, D = theta0.shape
+        self.theta0, self.N, self.burn, self.seed, self.off = theta0, N, burn, seed, chain_offset
+        self.kind, self.im, self.mf = _mass_operands(inv_mass, theta0)
+        self.samples = torch.empty((_num_rows(N, burn), C, D), dtype=theta0.dtype, device=theta0.device)
+        self.samples[0].copy_(theta0)
+        self.cur = theta0.clone()
+        self.rejected = torch.zeros(C, dtype=torch.int32, device=theta0.device)
+
+    def finish(self):
+        return self.samples, self.rejected
+
+    def run(self, theta0, N, L, eps, burn, inv_mass, seed, chain_offset, verbose, label):
+        self.begin(theta0, N, burn, inv_mass, seed, chain_offset)
+        prog = util._Progress('Sampling ' + label, N, verbose)
+        self.advance(0, N, L, eps, progress=prog)
+        prog.end()
+        return self.finish()
+
+    def run_nuts(self, theta0, N, L, eps0, burn, inv_mass, seed, chain_offset, verbose, label, desired):
+        """Sampler.HMC_NUTS (S:931-939, S:1030-1035): dual-averaging step size while n < burn, frozen to
+        eps_bar at n == burn.  One chain: the reference's schedule exactly.  A batch shares ONE step size,
+        adapted on the mean acceptance statistic over chains (extension; variance-reduced)."""
+        self.begin(theta0, N, burn, inv_mass, seed, chain_offset)
+        C = theta0.shape[0]
+        Ho = torch.empty(C, dtype=theta0.dtype, device=theta0.device)
+        Hn = torch.empty_like(Ho)
+        prog = util._Progress('Sampling ' + label, N, verbose)
+        eps, H_t, eps_bar = float(eps0), 0., 1.
+        for n in range(min(burn + 1, N)):
+            self.advance(n, 1, L, eps, H_old=Ho, H_new=Hn)
+            rho = torch.clamp(Ho - Hn, max=0.0)                               # S:1000
+            alpha = torch.where(torch.isfinite(rho), torch.exp(rho.float()), torch.zeros_like(rho.float()))
+            bad = bool((~torch.isfinite(rho)).any())
+            if n < burn or bad:                                               # S:1031-1032 / S:1060-1064
+                eps, eps_bar, H_t = _dual_average(float(alpha.double().mean()), n, eps0, H_t, eps_bar, desired)
+            if n == burn:
+                eps = eps_bar                                                 # S:1033-1035
+                print('Final Adapted Step Size: ', eps)
+            prog.update(n)
+        if N > burn + 1:
+            self.advance(burn + 1, N - burn - 1, L, eps, progress=prog)
+        prog.end()
+        self.final_step_size = eps
+        return self.finish()
+
+
+def _dual_average(alpha, t, step_size_init, H_t, eps_bar, desired_accept_rate=0.8):
+    """Hoffman & Gelman (2014) Algorithm 5 as the reference applies it (S:659-672); float32 log/exp like the
+    reference's torch.FloatTensor arithmetic.  `alpha` = min(1, exp(rho)) (0 for a divergent trajectory)."""
+    import numpy as np
+    f32 = np.float32
+    t = t + 1
+    mu = float(np.log(f32(10) * f32(step_size_init)))
+    gamma, t0, kappa = 0.05, 10, 0.75
+    H_t = (1 - (1 / (t + t0))) * H_t + (1 / (t + t0)) * (desired_accept_rate - alpha)
+    x_new = mu - (t ** 0.5) / gamma * H_t
+    step_size = float(np.exp(f32(x_new)))
+    x_new_bar = f32(t ** -kappa * x_new) + f32(1 - t ** -kappa) * np.log(f32(eps_bar))
+    return step_size, float(np.exp(f32(x_new_bar))), H_t
+
+
+def adaptation(rho, t, step_size_init, H_t, eps_bar, desired_accept_rate=0.8):
+    """S:629-674: (step_size, eps_bar, H_t) from the log acceptance ratio `rho` of iteration t."""
+    import numpy as np
+    if rho != rho or rho in (float('inf'), float('-inf')):
+        alpha = 0.                                                             # S:660-661
+    else:
+        alpha = min(1., float(np.exp(np.float32(rho))))                        # S:663
+    return _dual_average(alpha, t, step_size_init, H_t, eps_bar, desired_accept_rate)
+
+
+class _GaussianHMC(_Engine):
     """Native path: one persistent-kernel launch runs every trajectory (csrc/hmc_gaussian.hip)."""
 
     WS_CAP = 128 << 20
@@ -388,32 +473,30 @@ class _GaussianHMC:
     def __init__(self, target: GaussianTarget):
         self.t = target
 
-    def run(self, theta0, N, L, eps, burn, inv_mass, seed, chain_offset, verbose, label):
+    def advance(self, n0, count, L, eps, H_old=None, H_new=None, progress=None):
+        theta0 = self.theta0
         C, D = theta0.shape
-        kind, im, mf = _mass_operands(inv_mass, theta0)
-        S = _num_rows(N, burn)
-        samples = torch.empty((S, C, D), dtype=theta0.dtype, device=theta0.device)
-        samples[0].copy_(theta0)
-        cur = theta0.clone()
-        rejected = torch.zeros(C, dtype=torch.int32, device=theta0.device)
-        prog = util._Progress('Sampling ' + label, N, verbose)
         # scratch for the pre-drawn momenta / log-uniforms of one launch (<= WS_CAP bytes, so it stays
         # in the 256 MB Infinity Cache); long runs are cut into several launches over `traj_offset`
-        per_traj = _abi.gaussian_workspace_bytes(C, D, 1, theta0.element_size())
-        chunk = max(1, min(N, self.WS_CAP // per_traj)) if per_traj <= self.WS_CAP else N
+        per_traj = _abi.gaussian_workspace_bytes(C, D, 1, theta0.element_size()) // 2
+        chunk = max(1, min(count, self.WS_CAP // per_traj - 1)) if 2 * per_traj <= self.WS_CAP else count
         ws = None
-        if per_traj <= self.WS_CAP:
-            ws = torch.empty(chunk * per_traj, dtype=torch.uint8, device=theta0.device)
-        for start in range(0, N, chunk):
-            _abi.hmc_gaussian_sample(cur, theta0, self.t.precision, self.t.mean, self.t.log_norm, kind, im, mf, L,
-                                     eps, min(chunk, N - start), start, burn, seed, chain_offset, samples, rejected,
-                                     workspace=ws)
-            prog.update(min(N, start + chunk) - 1)
-        prog.end()
-        return samples, rejected
+        if 2 * per_traj <= self.WS_CAP and (H_old is None):
+            ws = getattr(self, "_ws", None)
+            need = _abi.gaussian_workspace_bytes(C, D, chunk, theta0.element_size())
+            if ws is None or ws.numel() < need:
+                ws = self._ws = torch.empty(need, dtype=torch.uint8, device=theta0.device)
+        if H_old is not None:
+            chunk = 1                      # diagnostics are [n_traj, C]: one trajectory per call (NUTS burn-in)
+        for start in range(n0, n0 + count, chunk):
+            _abi.hmc_gaussian_sample(self.cur, theta0, self.t.precision, self.t.mean, self.t.log_norm, self.kind,
+                                     self.im, self.mf, L, eps, min(chunk, n0 + count - start), start, self.burn,
+                                     self.seed, self.off, self.samples, self.rejected, H_old, H_new, workspace=ws)
+            if progress is not None:
+                progress.update(min(self.N, start + chunk) - 1)
 
 
-class _GenericHMC:
+class _GenericHMC(_Engine):
     """Generic-callback path (plain HMC, S:267-304) -- also the SPLITTING integrator when given a
     list of callbacks (S:494-547)."""
 
@@ -428,22 +511,23 @@ class _GenericHMC:
             out = v if out is None else out + v
         return out.to(theta.dtype).contiguous()
 
-    def run(self, theta0, N, L, eps, burn, inv_mass, seed, chain_offset, verbose, label):
-        C, D = theta0.shape
-        dev, dt = theta0.device, theta0.dtype
-        kind, im, mf = _mass_operands(inv_mass, theta0)
-        S = _num_rows(N, burn)
-        samples = torch.empty((S, C, D), dtype=dt, device=dev)
-        samples[0].copy_(theta0)
-        cur, prop, p = theta0.clone(), torch.empty_like(theta0), torch.empty_like(theta0)
-        H_old, H_new = torch.empty(C, dtype=dt, device=dev), torch.empty(C, dtype=dt, device=dev)
-        rejected = torch.zeros(C, dtype=torch.int32, device=dev)
-        prog = util._Progress('Sampling ' + label, N, verbose)
+    def begin(self, theta0, N, burn, inv_mass, seed, chain_offset):
+        super().begin(theta0, N, burn, inv_mass, seed, chain_offset)
+        C = theta0.shape[0]
+        self.prop, self.p = torch.empty_like(theta0), torch.empty_like(theta0)
+        self.Ho = torch.empty(C, dtype=theta0.dtype, device=theta0.device)
+        self.Hn = torch.empty_like(self.Ho)
+
+    def advance(self, n0, count, L, eps, H_old=None, H_new=None, progress=None):
+        cur, prop, p, kind, im, mf = self.cur, self.prop, self.p, self.kind, self.im, self.mf
+        Ho = self.Ho if H_old is None else H_old
+        Hn = self.Hn if H_new is None else H_new
         cb = self.cbs[0]
-        for n in range(N):
-            prog.update(n)
-            _abi.momentum_resample(p, kind, mf, seed, chain_offset, n)                     # S:969
-            _abi.hamiltonian(p, self._logp(cur), kind, im, H_old)                          # S:971
+        for n in range(n0, n0 + count):
+            if progress is not None:
+                progress.update(n)
+            _abi.momentum_resample(p, kind, mf, self.seed, self.off, n)                    # S:969
+            _abi.hamiltonian(p, self._logp(cur), kind, im, Ho)                             # S:971
             prop.copy_(cur)
             if self.split:
                 for _ in range(L):
@@ -456,13 +540,11 @@ class _GenericHMC:
                     g, logp1 = cb.grad(prop)                                               # S:297
                     _abi.kick_drift(prop, p, g, eps, 0.0 if l == L - 1 else eps, kind, im)  # S:298 (+ next drift)
                 _abi.kick_drift(prop, p, g, -0.5 * eps, 0.0, kind, im)                     # S:302
-                logp1 = logp1.to(dt).contiguous()   # log-prob at the end point, from the last gradient call
-            _abi.hamiltonian(p, logp1, kind, im, H_new)                                    # S:995
-            row = samples[n - burn] if n > burn else None
-            _abi.mh_select(cur, prop, theta0, H_old, H_new, logp1, row, rejected, None, n, burn, seed,
-                           chain_offset)                                                   # S:1000-1026
-        prog.end()
-        return samples, rejected
+                logp1 = logp1.to(cur.dtype).contiguous()   # log-prob at the end point, from the last gradient call
+            _abi.hamiltonian(p, logp1, kind, im, Hn)                                       # S:995
+            row = self.samples[n - self.burn] if n > self.burn else None
+            _abi.mh_select(cur, prop, self.theta0, Ho, Hn, logp1, row, self.rejected, None, n, self.burn, self.seed,
+                           self.off)                                                       # S:1000-1026
 
 
 def _resolve_split_engine(log_prob_list, theta0, native):

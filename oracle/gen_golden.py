@@ -171,6 +171,26 @@ def gen_sample_hmc():
     np.savez(os.path.join(OUT, "sample_hmc.npz"), **out)
 
 
+def gen_nuts():
+    """Dual-averaging step size ("HMC_NUTS", S:629-674 + S:1030-1035): the scalar recurrence and an end-to-end run."""
+    out = {}
+    rhos = [0.0, -0.5, -3.0, float("nan"), -0.01, -1.2, 0.0, -0.3]
+    ss, eb, Ht, rows = 0.3, 1.0, 0.0, []
+    for t, r in enumerate(rhos):
+        ss, eb, Ht = S.adaptation(r, t, 0.3, Ht, eb, desired_accept_rate=0.75)
+        rows.append([ss, eb, Ht])
+    out["adapt_rhos"] = np.array(rhos); out["adapt_out"] = np.array(rows)
+    lp = mvn_logp(torch.zeros(3), torch.tensor(SIGMA3))
+    hamiltorch.set_random_seed(17)
+    with Recorder() as rec:
+        ret, ss = hamiltorch.sample(lp, torch.tensor([0.5, -0.5, 0.25]), num_samples=45, num_steps_per_sample=5,
+                                    step_size=0.05, burn=20, sampler=hamiltorch.Sampler.HMC_NUTS,
+                                    desired_accept_rate=0.7, debug=2, verbose=False)
+    out["e2e_samples"] = np.stack([npy(t) for t in ret]); out["e2e_step_size"] = np.array(ss)
+    out["e2e_momenta"] = np.stack(rec.momenta); out["e2e_uniforms"] = np.concatenate(rec.uniforms)
+    np.savez(os.path.join(OUT, "nuts.npz"), **out)
+
+
 def rand_spd(D, seed, lo=0.5, hi=2.0):
     g = torch.Generator().manual_seed(seed)
     Q = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))[0]
@@ -313,5 +333,6 @@ if __name__ == "__main__":
     gen_sample_hmc()
     gen_rmhmc()
     gen_mlp()
+    gen_nuts()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -292,3 +292,28 @@ def test_chunked_launches_equal_single_launch(ht):
     finally:
         samplers._GaussianHMC.WS_CAP = old
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("route", ["fused", "generic"])
+def test_nuts_step_size_adaptation_vs_oracle(ht, route):
+    """Sampler.HMC_NUTS (dual averaging during burn-in, S:1030-1035): adapted step size and samples vs the oracle with
+    the same Philox draws -- single chain (the reference's schedule) and a batch (shared step size)."""
+    t, o = targets(ht, np.linalg.inv(SIGMA3), torch.float32)
+    lp = t if route == "fused" else (lambda w: t(w))
+    for C in (1, 16):
+        seed = 404 + C
+        th0 = (0.3 * O.philox_normals(seed, np.arange(C), 0, 3, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32)
+        init = tt(th0[0] if C == 1 else th0, torch.float32)
+        # step_size_init 0.02: the first dual-averaging jump (to ~10x) stays inside the leapfrog stability limit,
+        # so rounding differences are not amplified by unstable trajectories
+        out, ss = ht.sample(lp, init, num_samples=40, num_steps_per_sample=5, step_size=0.02, burn=15,
+                            sampler=ht.Sampler.HMC_NUTS, desired_accept_rate=0.7, debug=2, verbose=False, seed=seed)
+        ref, info = O.sample_hmc(o, th0, 40, 5, 0.02, 15, None, O.PhiloxDraws(seed, np.arange(C)), nuts_desired=0.7)
+        assert isinstance(ss, float) and abs(ss - info["step_size"]) < 5e-3 * info["step_size"]
+        got = torch.stack(out).cpu().numpy().reshape(len(ref), C, 3)
+        # after burn-in every trajectory runs with the adapted step size, so a 0.5 % step-size difference shows
+        # up as O(1e-2) differences in the samples
+        bad = np.abs(got - np.stack(ref)).max(axis=(0, 2)) > 3e-2
+        assert bad.mean() <= 0.1
+    with pytest.raises(RuntimeError, match="burn must be greater than 0 for NUTS"):
+        ht.sample(t, init, num_samples=5, sampler=ht.Sampler.HMC_NUTS, verbose=False)
