@@ -252,8 +252,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # one rank per GPU over RCCL ("nccl" on ROCm).  HTA_BENCH_BACKEND=gloo + several ranks on one GPU is only
+        # for exercising this code path on a single-GPU box.
+        backend = os.environ.get("HTA_BENCH_BACKEND", "nccl")
+        local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
