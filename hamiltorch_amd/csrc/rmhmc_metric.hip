@@ -23,7 +23,10 @@
 
 namespace hta {
 
-constexpr int MT = 1024;  // threads per system (16 waves: the LDS-latency-bound Jacobi rounds need >= 4 waves per SIMD)
+#ifndef HTA_MT
+#define HTA_MT 1024
+#endif
+constexpr int MT = HTA_MT;  // threads per system
 
 template <typename T> struct Eps;
 template <> struct Eps<float> { static constexpr float v = 1.1920929e-07f; };
@@ -88,23 +91,56 @@ template <typename T> __device__ void lds_chol_solve(const T* L, int n, int lda,
 // ------------------------------------------------------------------------------------------------
 // Round-robin pairing: n even, round r in [0, n-1), slot k in [0, n/2).
 __device__ __forceinline__ void rr_pair(int n, int r, int k, int& p, int& q) {
-  const int m = n - 1;
-  if (k == 0) { p = m; q = r; }
-  else { p = (r + k) % m; q = (r - k + m) % m; }
-  if (p > q) { const int t = p; p = q; q = t; }
+  const int m = n - 1;                     // r, k < m: one conditional subtract / add replaces the modulo
+  int x = r + k; x -= (x >= m) ? m : 0;
+  int y = r - k; y += (y < 0) ? m : 0;
+  if (k == 0) { x = m; y = r; }
+  p = min(x, y); q = max(x, y);
 }
 
-// Cyclic Jacobi on A[ne][lda] (symmetric, both triangles valid), V[D][ldv] <- eigenvectors (columns).
-// Work split (MT threads): the <= ceil(nblk / MT) pair-blocks a thread owns are decoded ONCE (the
-// enumeration does not depend on the round); V rows are walked with pair index = lane, so the hot
-// loops contain no integer division.
-template <typename T>
-__device__ void lds_jacobi(T* A, T* V, int D, int ne, int lda, int ldv, T* cs, int* pq, T* red, int max_sweeps) {
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int N = 4; };
+template <> struct Vec16<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int N = 2; };
+template <typename T> struct Vec8;      // (c, s) pair
+template <> struct Vec8<float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct Vec8<double> { typedef double type __attribute__((ext_vector_type(2))); };
+
+// Jacobi rotation annihilating a_pq.  This is the serial part of every round (NP lanes of one wave while
+// 15 waves wait at the barrier), so fp32 uses the single-instruction reciprocal / rsqrt (1 ulp): the
+// similarity transform stays orthogonal to rounding whatever the angle's accuracy, which only affects
+// how fast the off-diagonal mass decays.
+template <typename T> __device__ __forceinline__ void rotation(T app, T aqq, T apq, T& c, T& s);
+template <> __device__ __forceinline__ void rotation<float>(float app, float aqq, float apq, float& c, float& s) {
+  const float theta = 0.5f * (aqq - app) * __frcp_rn(apq);
+  const float at = fabsf(theta);
+  // t = sgn(theta) / (|theta| + sqrt(1 + theta^2)); huge |theta| -> t = 0 (inf-safe)
+  const float t = copysignf(__frcp_rn(at + __fsqrt_rn(fmaf(theta, theta, 1.0f))), theta);
+  c = __frsqrt_rn(fmaf(t, t, 1.0f));
+  s = t * c;
+}
+template <> __device__ __forceinline__ void rotation<double>(double app, double aqq, double apq, double& c, double& s) {
+  const double theta = (aqq - app) / (2.0 * apq);
+  const double t = copysign(1.0, theta) / (fabs(theta) + sqrt(1.0 + theta * theta));
+  c = 1.0 / sqrt(1.0 + t * t);
+  s = t * c;
+}
+
+// Cyclic Jacobi.  A[ne][lda]: symmetric, only the UPPER triangle (i <= j) is read and kept up to date.
+// VT[D][ldv]: row k = eigenvector k (transposed storage: a rotation mixes two contiguous rows, so it
+// moves 16 bytes per LDS instruction); ldv is a multiple of 16 bytes.
+// LDS traffic per round is what bounds this loop (16 waves share one LDS), so: (p, q) packed in one word
+// and (c, s) in one 8-byte word (2 + 2 loads per pair-block instead of 8), upper-only A (4 loads + 4 stores
+// per block, no mirror stores), vectorised VT rows, per-thread work lists decoded once.
+template <typename T, int MAXB, int MAXV>
+__device__ void lds_jacobi(T* A, T* VT, int D, int ne, int lda, int ldv, T* cs_raw, int* pq, T* red, int max_sweeps) {
+  typedef typename Vec16<T>::type V16;
+  typedef typename Vec8<T>::type CS;
+  constexpr int VN = Vec16<T>::N;
+  CS* cs = reinterpret_cast<CS*>(cs_raw);
   const int tid = threadIdx.x;
   const int NP = ne / 2;
   const int nblk = NP * (NP + 1) / 2;
-  constexpr int MAXB = 4;                       // nblk <= 71*70/2 = 2485 < 4 * 1024
-  int blkA[MAXB], blkB[MAXB];
+  int blkA[MAXB], blkB[MAXB];                   // MAXB * MT >= nblk, MAXV * MT >= NP * nv (checked at launch)
 #pragma unroll
   for (int k = 0; k < MAXB; ++k) {
     const int e = tid + k * MT;
@@ -118,16 +154,24 @@ __device__ void lds_jacobi(T* A, T* V, int D, int ne, int lda, int ldv, T* cs, i
       blkA[k] = a; blkB[k] = a + (e - (a * NP - a * (a - 1) / 2));
     }
   }
-  int npw = 1; while (npw < NP) npw <<= 1;      // pairs padded to a power of two <= 128
-  const int vb = tid & (npw - 1), vi0 = tid / npw, vstep = MT / npw;
+  const int nv = ldv / VN;                      // 16-byte vectors per VT row
+  int vtB[MAXV], vtG[MAXV];
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int e = tid + k * MT;
+    vtB[k] = (e < NP * nv) ? e / nv : -1;
+    vtG[k] = (e < NP * nv) ? e - (e / nv) * nv : 0;
+  }
   T off_prev = (T)-1;
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
-    // convergence: off-diagonal vs diagonal mass
+    // convergence: off-diagonal vs diagonal mass (upper triangle, off-diagonal counted twice)
     T off = 0, dg = 0;
     for (int e = tid; e < D * D; e += MT) {
       const int i = e / D, j = e - i * D;
-      const T a = A[i * lda + j];
-      if (i == j) dg += a * a; else off += a * a;
+      if (j >= i) {
+        const T a = A[i * lda + j];
+        if (i == j) dg += a * a; else off += (T)2 * a * a;
+      }
     }
     off = block_sum(off, red);
     dg = block_sum(dg, red);
@@ -140,45 +184,51 @@ __device__ void lds_jacobi(T* A, T* V, int D, int ne, int lda, int ldv, T* cs, i
       __syncthreads();
       if (tid < NP) {
         int p, q;
-        rr_pair(ne, r, tid, p, q);
+        rr_pair(ne, r, tid, p, q);                                     // p < q
         const T app = A[p * lda + p], aqq = A[q * lda + q], apq = A[p * lda + q];
         T c = 1, s = 0;
-        if (apq != (T)0) {
-          const T theta = (aqq - app) / ((T)2 * apq);
-          const T t = copysign((T)1, theta) / (fabs(theta) + sqrt((T)1 + theta * theta));
-          c = (T)1 / sqrt((T)1 + t * t);
-          s = t * c;
-        }
-        cs[2 * tid] = c; cs[2 * tid + 1] = s;
-        pq[2 * tid] = p; pq[2 * tid + 1] = q;
+        if (apq != (T)0) rotation<T>(app, aqq, apq, c, s);
+        CS v; v.x = c; v.y = s;
+        cs[tid] = v;
       }
       __syncthreads();
-      // A <- J^T A J, one thread per pair-block (a <= b), mirrored
+      // A <- J^T A J, one thread per pair-block (a <= b); every element lives at (min, max).  The pair table is
+      // recomputed from (r, slot) in registers instead of being read back from LDS: one dependent LDS round trip
+      // less on the critical path of every round.
 #pragma unroll
       for (int k = 0; k < MAXB; ++k) {
         const int a = blkA[k], bb = blkB[k];
         if (a >= 0) {
-          const int pa = pq[2 * a], qa = pq[2 * a + 1], pb = pq[2 * bb], qb = pq[2 * bb + 1];
-          const T ca = cs[2 * a], sa = cs[2 * a + 1], cb = cs[2 * bb], sb = cs[2 * bb + 1];
-          const T m00 = A[pa * lda + pb], m01 = A[pa * lda + qb], m10 = A[qa * lda + pb], m11 = A[qa * lda + qb];
+          int pa, qa, pb, qb;
+          rr_pair(ne, r, a, pa, qa);
+          rr_pair(ne, r, bb, pb, qb);
+          const CS ra = cs[a], rb = cs[bb];
+          const T ca = ra.x, sa = ra.y, cb = rb.x, sb = rb.y;
+          const int i00 = min(pa, pb) * lda + max(pa, pb), i01 = min(pa, qb) * lda + max(pa, qb);
+          const int i10 = min(qa, pb) * lda + max(qa, pb), i11 = min(qa, qb) * lda + max(qa, qb);
+          const T m00 = A[i00], m01 = A[i01], m10 = A[i10], m11 = A[i11];
           const T t00 = cb * m00 - sb * m01, t01 = sb * m00 + cb * m01;
           const T t10 = cb * m10 - sb * m11, t11 = sb * m10 + cb * m11;
           T n00 = ca * t00 - sa * t10, n01 = ca * t01 - sa * t11;
           T n10 = sa * t00 + ca * t10, n11 = sa * t01 + ca * t11;
-          if (a == bb) { n01 = 0; n10 = 0; }
-          A[pa * lda + pb] = n00; A[pa * lda + qb] = n01; A[qa * lda + pb] = n10; A[qa * lda + qb] = n11;
-          if (a != bb) { A[pb * lda + pa] = n00; A[qb * lda + pa] = n01; A[pb * lda + qa] = n10; A[qb * lda + qa] = n11; }
+          if (a == bb) { n01 = 0; n10 = 0; }                           // i01 == i10 here: the annihilated element
+          A[i00] = n00; A[i01] = n01; A[i10] = n10; A[i11] = n11;
         }
       }
-      // V <- V J : pair = lane, rows strided
-      if (vb < NP) {
-        const int pb = pq[2 * vb], qb = pq[2 * vb + 1];
-        if (qb < D) {     // the padding index (odd D) never rotates
-          const T c = cs[2 * vb], s = cs[2 * vb + 1];
-          for (int i = vi0; i < D; i += vstep) {
-            const T vp = V[i * ldv + pb], vq = V[i * ldv + qb];
-            V[i * ldv + pb] = c * vp - s * vq;
-            V[i * ldv + qb] = s * vp + c * vq;
+      // VT rows p, q <- rotation, 16 bytes at a time
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        const int vb = vtB[k];
+        if (vb >= 0) {
+          int pb, qb;
+          rr_pair(ne, r, vb, pb, qb);
+          if (qb < D) {     // the padding index (odd D) never rotates
+            const CS rb = cs[vb];
+            V16* rp = reinterpret_cast<V16*>(VT + pb * ldv) + vtG[k];
+            V16* rq = reinterpret_cast<V16*>(VT + qb * ldv) + vtG[k];
+            const V16 vp = *rp, vq = *rq;
+            *rp = rb.x * vp - rb.y * vq;
+            *rq = rb.y * vp + rb.x * vq;
           }
         }
       }
@@ -189,28 +239,30 @@ __device__ void lds_jacobi(T* A, T* V, int D, int ne, int lda, int ldv, T* cs, i
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int MAXB, int MAXV>
 __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int ne, int lda, int ldv, int v0_lds) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = a.D, tid = threadIdx.x;
-  T* A = reinterpret_cast<T*>(smem_raw);
-  T* V = A + ne * lda;
-  T* vec0 = V + D * ldv;          // lam~ (ne)
+  // LDS layout (16-byte aligned regions first): VT | [V0 copy] | (c,s) pairs | A | 4 vectors | reduction | pair table
+  const int cs_len = (ne + 3) & ~3;
+  T* V = reinterpret_cast<T*>(smem_raw);                 // VT[D][ldv], row k = eigenvector k
+  T* V0s = V + D * ldv;
+  T* cs = V0s + (v0_lds ? D * ldv : 0);
+  T* A = cs + cs_len;
+  T* vec0 = A + ne * lda;         // lam~ (ne)
   T* vec1 = vec0 + ne;            // y / w / solve vector (ne)
   T* vec2 = vec1 + ne;            // d = X - mu, later z (ne)
   T* vec3 = vec2 + ne;            // Pd (ne)
-  T* cs = vec3 + ne;              // 2 * NP
-  T* red = cs + ne;               // MT / 64
+  T* red = vec3 + ne;             // MT / 64
   int* pq = reinterpret_cast<int*>(red + MT / 64);
   const bool softabs = a.metric == 1;
   // warm start: the shared eigenbasis V0 of the jitter-free Hs (LDS copy when it fits, else L2)
-  const bool warm = softabs && a.V0 && a.lam0 && a.hs_stride == 0;
-  T* V0s = reinterpret_cast<T*>(pq + ne);
-  const T* V0 = a.V0;
-  int ld0 = D;
-  if (warm && v0_lds) {
-    for (int e = tid; e < D * D; e += MT) { const int i = e / D, j = e - i * D; V0s[i * ldv + j] = a.V0[e]; }
-    V0 = V0s; ld0 = ldv;
+  // (only when the LDS copy fits: the tiled formation below reads 16-byte vectors from padded rows)
+  const bool warm = softabs && a.V0 && a.lam0 && a.hs_stride == 0 && v0_lds;
+  const T* V0 = V0s;
+  const int ld0 = ldv;
+  if (warm) {
+    for (int e = tid; e < D * ldv; e += MT) { const int i = e / ldv, j = e - i * ldv; V0s[e] = (j < D) ? a.V0[i * D + j] : (T)0; }
   }
 
   for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
@@ -249,21 +301,46 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
       for (int i = tid; i < D; i += MT)
         vec1[i] = a.has_jitter ? (T)a.jitter * uniform_elem<T>(a.seed, chain, a.draw, PURPOSE_JITTER, a.sub, i) : (T)0;
       __syncthreads();
-      for (int e = tid; e < ne * ne; e += MT) {
-        const int k = e / ne, l = e - k * ne;
-        if (k >= D || l >= D) { A[k * lda + l] = 0; continue; }
-        if (l < k) continue;
-        T acc = (k == l) ? a.lam0[k] : (T)0;
-        if (a.has_jitter)
-          for (int i = 0; i < D; ++i) acc += vec1[i] * V0[i * ld0 + k] * V0[i * ld0 + l];
-        A[k * lda + l] = acc; A[l * lda + k] = acc;
+      // register-tiled: each thread owns a TB x TB tile of B and streams the rows of V0 (16-byte LDS / L2 reads)
+      constexpr int TB = 16 / (int)sizeof(T);
+      typedef typename Vec16<T>::type V16;
+      const int nt = (D + TB - 1) / TB;
+      for (int e = tid; e < ne * ne; e += MT) { const int k = e / ne, l = e - k * ne; if (k >= D || l >= D) A[k * lda + l] = 0; }
+      for (int e = tid; e < nt * nt; e += MT) {
+        const int tk = e / nt, tl = e - tk * nt;
+        if (tl < tk) continue;                                         // upper tiles only (Jacobi reads i <= j)
+        T acc[TB][TB];
+#pragma unroll
+        for (int x = 0; x < TB; ++x)
+#pragma unroll
+          for (int y = 0; y < TB; ++y) acc[x][y] = 0;
+        if (a.has_jitter) {
+          for (int i = 0; i < D; ++i) {
+            const V16 vk = *reinterpret_cast<const V16*>(V0 + i * ld0 + tk * TB);
+            const V16 vl = *reinterpret_cast<const V16*>(V0 + i * ld0 + tl * TB);
+            const T ei = vec1[i];
+#pragma unroll
+            for (int x = 0; x < TB; ++x) {
+              const T ek = ei * vk[x];
+#pragma unroll
+              for (int y = 0; y < TB; ++y) acc[x][y] = fma(ek, vl[y], acc[x][y]);
+            }
+          }
+        }
+#pragma unroll
+        for (int x = 0; x < TB; ++x)
+#pragma unroll
+          for (int y = 0; y < TB; ++y) {
+            const int k = tk * TB + x, l = tl * TB + y;
+            if (k < D && l < D && l >= k) A[k * lda + l] = acc[x][y] + ((k == l) ? a.lam0[k] : (T)0);
+          }
       }
     }
     T logdet = 0, quad = 0;
     if (softabs) {
-      for (int e = tid; e < D * D; e += MT) { const int i = e / D, j = e - i * D; V[i * ldv + j] = (i == j) ? (T)1 : (T)0; }
+      for (int e = tid; e < D * ldv; e += MT) { const int k = e / ldv, i = e - k * ldv; V[e] = (i == k) ? (T)1 : (T)0; }   // VT = I (incl. row padding)
       __syncthreads();
-      lds_jacobi<T>(A, V, D, ne, lda, ldv, cs, pq, red, a.max_sweeps);
+      lds_jacobi<T, MAXB, MAXV>(A, V, D, ne, lda, ldv, cs, pq, red, a.max_sweeps);
       // lam~ = lam / tanh(alpha lam)   (S:120)
       T ld = 0;
       for (int i = tid; i < D; i += MT) {
@@ -281,15 +358,15 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
         for (int e = tid; e < D * D; e += MT) {
           const int i = e / D, j = e - i * D;
           T acc = 0;
-          for (int k = 0; k < D; ++k) acc += V0[i * ld0 + k] * V[k * ldv + j];
+          for (int k = 0; k < D; ++k) acc += V0[i * ld0 + k] * V[j * ldv + k];     // (V0 J)[i][j], J[k][j] = VT[j][k]
           A[i * lda + j] = acc;
         }
         __syncthreads();
-        for (int e = tid; e < D * D; e += MT) { const int i = e / D, j = e - i * D; V[i * ldv + j] = A[i * lda + j]; }
+        for (int e = tid; e < D * D; e += MT) { const int i = e / D, j = e - i * D; V[j * ldv + i] = A[i * lda + j]; }
         __syncthreads();
       }
       const bool rotated = warm && !(a.V_out || a.G_out || a.p_out || a.L_out);   // V still holds J
-      if (a.V_out) for (int e = tid; e < D * D; e += MT) { const int i = e / D, j = e - i * D; a.V_out[b * D * D + e] = V[i * ldv + j]; }
+      if (a.V_out) for (int e = tid; e < D * D; e += MT) { const int i = e / D, j = e - i * D; a.V_out[b * D * D + e] = V[j * ldv + i]; }
       if (a.m) {                       // x = Q (Q^T m / lam~)
         if (rotated) {                 // m' = V0^T m
           for (int i = tid; i < D; i += MT) vec1[i] = a.m[b * D + i];
@@ -306,7 +383,7 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
         T qd = 0;
         for (int k = tid; k < D; k += MT) {
           T acc = 0;
-          for (int i = 0; i < D; ++i) acc += V[i * ldv + k] * vec2[i];
+          for (int i = 0; i < D; ++i) acc += V[k * ldv + i] * vec2[i];
           const T w = acc / vec0[k];
           vec1[k] = w;
           qd += acc * w;
@@ -315,7 +392,7 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
         if (rotated) {                 // x = V0 (J w)
           for (int i = tid; i < D; i += MT) {
             T acc = 0;
-            for (int k = 0; k < D; ++k) acc += V[i * ldv + k] * vec1[k];
+            for (int k = 0; k < D; ++k) acc += V[k * ldv + i] * vec1[k];
             vec3[i] = acc;
           }
           __syncthreads();
@@ -323,7 +400,7 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
         for (int i = tid; i < D; i += MT) {
           T acc = 0;
           if (rotated) { for (int k = 0; k < D; ++k) acc += V0[i * ld0 + k] * vec3[k]; }
-          else { for (int k = 0; k < D; ++k) acc += V[i * ldv + k] * vec1[k]; }
+          else { for (int k = 0; k < D; ++k) acc += V[k * ldv + i] * vec1[k]; }
           if (a.x_out) a.x_out[b * D + i] = acc;
           if (a.upd_x) a.upd_x[b * D + i] += (T)a.cx * acc;
         }
@@ -334,7 +411,7 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
           const int i = e / D, j = e - i * D;
           if (j <= i) {
             T acc = 0;
-            for (int k = 0; k < D; ++k) acc += V[i * ldv + k] * vec0[k] * V[j * ldv + k];
+            for (int k = 0; k < D; ++k) acc += V[k * ldv + i] * vec0[k] * V[k * ldv + j];
             A[i * lda + j] = acc; A[j * lda + i] = acc;
           }
         }
@@ -400,29 +477,38 @@ template <typename T> int metric_eval(const MetricArgsT<T>& a, hipStream_t s) {
   // LDS: A[ne][lda] + V[D][ldv] + 5 vectors + reduction scratch + pair table; pad the leading dimensions
   // to an odd stride when that still fits in the 160 KiB of one CU
   auto bytes = [&](int lda, int ldv) {
-    return (size_t)(ne * lda + D * ldv + 5 * ne + MT / 64) * sizeof(T) + (size_t)ne * sizeof(int) + 64;
+    return (size_t)(ne * lda + D * ldv + 5 * ne + 4 + MT / 64) * sizeof(T) + (size_t)ne * sizeof(int) + 64;
   };
-  int lda = ne + 1, ldv = (D | 1);
-  if (bytes(lda, ldv) > 160 * 1024) { lda = ne; ldv = D; }
+  const int vn = 16 / (int)sizeof(T);
+  int lda = ne + 1;
+  const int ldv = ((D + vn - 1) / vn) * vn;          // VT rows are moved 16 bytes at a time
+  if (bytes(lda, ldv) > 160 * 1024) lda = ne;
   size_t lds = bytes(lda, ldv);
   const bool warm = a.metric == 1 && a.V0 && a.lam0 && a.hs_stride == 0;
   int v0_lds = 0;
   if (warm && lds + (size_t)D * ldv * sizeof(T) <= 160 * 1024) { v0_lds = 1; lds += (size_t)D * ldv * sizeof(T); }
   HTA_REQUIRE(lds <= 160 * 1024, "hta_metric_eval: D=%d does not fit the 160 KiB LDS of a CU for this dtype (max ~140 fp32 / ~99 fp64)", D);
-  static bool attr_f = false, attr_d = false;
-  bool& done = sizeof(T) == 4 ? attr_f : attr_d;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&metric_eval_kernel<T>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { set_error("hta_metric_eval: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
-    done = true;
-  }
   MetricArgsT<T> k = a;
   if (k.max_sweeps <= 0) k.max_sweeps = sizeof(T) == 4 ? 16 : 24;
   const int grid = (int)(a.B < 65536 ? a.B : 65536);
-  profile_begin(s);
-  metric_eval_kernel<T><<<grid, MT, lds, s>>>(k, ne, lda, ldv, v0_lds);
-  profile_end(s);
+  // per-thread work-list lengths of the Jacobi rounds (register arrays): 2/2 up to D ~ 126, 4/3 beyond
+  const int NP = ne / 2, nv = ldv / vn;
+  const bool small = NP * (NP + 1) / 2 <= 2 * MT && NP * nv <= 2 * MT;
+  HTA_REQUIRE(NP * (NP + 1) / 2 <= 4 * MT && NP * nv <= 3 * MT, "hta_metric_eval: D=%d exceeds the per-thread work lists", D);
+  auto launch = [&](auto kern, bool& done) -> int {
+    if (!done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) { set_error("hta_metric_eval: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
+      done = true;
+    }
+    profile_begin(s);
+    kern<<<grid, MT, lds, s>>>(k, ne, lda, ldv, v0_lds);
+    profile_end(s);
+    return HTA_OK;
+  };
+  static bool done_small = false, done_big = false;   // per T instantiation
+  const int rc = small ? launch(&metric_eval_kernel<T, 2, 2>, done_small) : launch(&metric_eval_kernel<T, 4, 3>, done_big);
+  if (rc) return rc;
   HTA_CHECK_LAUNCH("hta_metric_eval");
   return HTA_OK;
 }
