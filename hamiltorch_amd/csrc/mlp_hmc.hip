@@ -90,14 +90,19 @@ struct MlpChain {
     }
     __syncthreads();
     T sse = 0, sd = 0;
-    for (int i = tid; i < cnt; i += NT) {
-      T out = w.b2;
+    constexpr int RS = 4;                      // lanes per row of the chunk matrix
+    for (int i = tid / RS; i < cnt; i += NT / RS) {
+      const int part = tid % RS;
+      T out = 0;
       const T* row = cm + i * ldc;
-      for (int jj = 0; jj < a.H; ++jj) out += row[jj];
-      const T r = out - Ys[lo + i];
-      const T d = -a.tau_out * r;
-      dv[i] = d;
-      sse += r * r; sd += d;
+      for (int jj = part; jj < a.H; jj += RS) out += row[jj];
+      out = slice_sum<RS>(out) + w.b2;
+      if (part == 0) {
+        const T r = out - Ys[lo + i];
+        const T d = -a.tau_out * r;
+        dv[i] = d;
+        sse += r * r; sd += d;
+      }
     }
     sse = block_sum2(sse, sd);
     sum_delta = sd;
@@ -274,30 +279,26 @@ __global__ __launch_bounds__(NT, 4) void mlp1_hmc_kernel(MlpArgs<T> a, int nbch,
       p.b2 = mf.b2 * normal_elem<T>(a.seed, chain, (uint32_t)n, 0, o_b2);
       const T h_old = -lp_cur + ch.kinetic(p, im);                        // S:971
       Rec q = cur, g;
-      if (M == 1) {                                                       // plain leapfrog, S:281-302
-        ch.grad_range(q, 0, a.Nb, g);
-        Ch::axpy(p, heps, g);
-        for (int l = 0; l < a.L; ++l) {
-          Ch::drift(q, eps, im, p);
-          ch.grad_range(q, 0, a.Nb, g);
-          Ch::axpy(p, eps, g);
+      // One stage loop for both integrators (a single gradient call site keeps the kernel's register budget):
+      //   plain leapfrog (M == 1, S:281-302): stage 0 kicks eps/2, stages 1..L kick eps, drifts of eps in between,
+      //     and the final half kick is taken back afterwards, in the reference's order;
+      //   symmetric split (S:499-540): per step 2M stages m = 0..M-1, M-1..0, each a half kick, with a drift of
+      //     eps / (2 (M-1)) after every stage except the two turning points.
+      const T dq = (M > 1) ? eps / (T)((M - 1) * 2) : (T)0;
+      const int nstage = (M == 1) ? a.L + 1 : a.L * 2 * M;
+      for (int st = 0; st < nstage; ++st) {
+        int lo; T kick, dr;
+        if (M == 1) { lo = 0; kick = (st == 0) ? heps : eps; dr = (st < a.L) ? eps : (T)0; }
+        else {
+          const int s2 = st % (2 * M);
+          const int m = (s2 < M) ? s2 : 2 * M - 1 - s2;
+          lo = m * a.Nb; kick = heps; dr = (s2 == M - 1 || s2 == 2 * M - 1) ? (T)0 : dq;
         }
-        Ch::axpy(p, -heps, g);
-      } else {                                                            // symmetric split, S:499-540
-        const T dq = eps / (T)((M - 1) * 2);
-        for (int l = 0; l < a.L; ++l) {
-          for (int m = 0; m < M; ++m) {
-            ch.grad_range(q, m * a.Nb, (m + 1) * a.Nb, g);
-            Ch::axpy(p, heps, g);
-            if (m < M - 1) Ch::drift(q, dq, im, p);
-          }
-          for (int m = M - 1; m >= 0; --m) {
-            ch.grad_range(q, m * a.Nb, (m + 1) * a.Nb, g);
-            Ch::axpy(p, heps, g);
-            if (m > 0) Ch::drift(q, dq, im, p);
-          }
-        }
+        ch.grad_range(q, lo, lo + a.Nb, g);
+        Ch::axpy(p, kick, g);
+        if (dr != (T)0) Ch::drift(q, dr, im, p);
       }
+      if (M == 1) Ch::axpy(p, -heps, g);                                  // S:302
       const T lp_new = ch.logp_total(q);                                  // S:995
       const T h_new = -lp_new + ch.kinetic(p, im);
       const T u = u23<T>(philox_block(a.seed, chain, (uint32_t)n, PURPOSE_MH, 0, 0).x);
