@@ -153,3 +153,21 @@ def test_cfg4_shape(ht):
     s = torch.stack(out)
     assert s.shape == (12, 512, D) and torch.isfinite(s).all()
     assert 0.6 < float(acc.mean()) <= 1.0
+
+
+def test_predict_model_on_device(ht):
+    """predict_model (S:1468-1562): predictions of every sample, stacked [S, N, O], and the per-sample log-probs."""
+    net = make_net([3, 9, 1], "relu")
+    X, Y = make_data(20, 3)
+    Xd, Yd = X.to(dev()), Y.to(dev())
+    theta0 = ht.util.flatten(net).detach().clone()
+    samples = ht.sample_model(net, Xd, Yd, theta0, model_loss="regression", num_samples=6, num_steps_per_sample=3,
+                              step_size=1e-3, tau_out=5.0, verbose=False, seed=2)
+    pred, lps = ht.predict_model(net, samples, x=Xd, y=Yd, model_loss="regression", tau_out=5.0)
+    assert pred.shape == (6, 20, 1) and len(lps) == 6
+    o = O.MLPRegressionTarget([3, 9, 1], X.numpy(), Y.numpy(), [1.0] * 4, 5.0, 1.0, "relu")
+    th = torch.stack(samples).cpu().numpy()
+    np.testing.assert_allclose(pred.cpu().numpy(), o.predict(th), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose([float(v.sum()) for v in lps], o.logp(th), rtol=1e-4, atol=1e-3)
+    with pytest.raises(RuntimeError):
+        ht.predict_model(net, samples)
