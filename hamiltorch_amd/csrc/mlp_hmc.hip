@@ -18,7 +18,7 @@
 //   2. every wave re-reads h_ij of its points and accumulates dW2_j, db1_j, dW1_j. in registers
 //      (packed FMAs, x_i from SGPRs); one LDS exchange sums the PS slice partials per gradient.
 // HBM traffic per trajectory: one [D] sample row per chain.
-#include "common.hpp"
+#include "mlp.hpp"
 #include "philox.hpp"
 
 #ifndef HTA_UNR
@@ -34,8 +34,13 @@
 #define HTA_ABL 0      // developer ablation bits (tools/scratch/mlp_ablate.sh); 0 in the product build
 #endif
 
-#ifndef HTA_TIMING
-#define HTA_TIMING 0   // developer cycle counters per phase of a gradient (wave 0 of block 0)
+#ifdef HTA_TIMING
+#undef HTA_TIMING     // the counters live in mlp_mfma.hip now; -DHTA_TIMING_VALU=1 brings these back (with mlp_valu set)
+#endif
+#ifdef HTA_TIMING_VALU
+#define HTA_TIMING 1
+#else
+#define HTA_TIMING 0
 #endif
 #if HTA_TIMING
 __device__ unsigned long long hta_dbg[16];
@@ -49,20 +54,6 @@ namespace hta {
 
 void profile_begin(hipStream_t s);
 void profile_end(hipStream_t s);
-
-template <typename T> struct MlpArgs {
-  T* theta; const T* theta_init; int64_t C;
-  int n_in; int H; int act;
-  const T* X; const T* Y; int N;
-  int M; int Nb;
-  T tau[4]; T tau_out; T prior_scale;
-  int mass_kind; const T* inv_mass; const T* mass_factor;
-  int L; T eps; int n_traj; int traj_offset; int burn;
-  uint64_t seed; uint64_t chain_offset;
-  T* samples; int32_t* reject_count; T* H_old; T* H_new; uint8_t* accept;
-  T* grad_out; T* logp_out;   // evaluation-only mode (n_traj == 0): d log p_m / d theta [C, D] and log p_m [C] of split `eval_split`
-  int eval_split;
-};
 
 // activation from the pre-activation, and its derivative from the activation value itself
 template <int ACT, typename T> __device__ __forceinline__ T act_fn(T z) {
@@ -522,6 +513,9 @@ template <typename T> int mlp_hmc(const MlpArgs<T>& a, hipStream_t s) {
   HTA_REQUIRE(a.mass_kind == HTA_MASS_NONE || (a.mass_kind == HTA_MASS_DIAG && a.inv_mass && a.mass_factor),
               "hta_mlp_hmc: only identity / diagonal inv_mass are supported natively");
   if (a.n_traj > 0) HTA_REQUIRE(a.theta_init && a.L >= 0, "hta_mlp_hmc: bad trajectory arguments");
+  if constexpr (sizeof(T) == 4) {
+    if (!g_mlp_valu && mlp_mfma_eligible(a)) return mlp_mfma(a, s);
+  }
 #ifdef HTA_MLP_SINGLE       // developer builds: one instantiation (the BASELINE config-4 shape), seconds to compile
   return launch_mlp_act<T, 8, 512, 0, true>(a, s);
 #else

@@ -38,11 +38,35 @@ def make_data(N, n_in, seed=1):
     return X, Y
 
 
+@pytest.fixture
+def valu_kernel():
+    """Keeps the fp32 sampler on the VALU kernel (mlp_hmc.hip) instead of the MFMA one (mlp_mfma.hip)."""
+    from hamiltorch_amd import _abi
+    _abi.set_tuning("mlp_valu", 1)
+    yield
+    _abi.set_tuning("mlp_valu", 0)
+
+
+SHAPES = [(3, 5, "relu", 12, 3), (8, 100, "relu", 400, 4), (1, 17, "tanh", 30, 2), (5, 64, "sigmoid", 64, 1),
+          (16, 130, "tanh", 50, 5), (2, 300, "relu", 40, 2),
+          # MFMA kernel corners: 3 input blocks + ragged 128-point chunks; 4 input blocks (no free ones-row); 17 tiles
+          (12, 40, "relu", 300, 1), (16, 100, "sigmoid", 200, 1), (9, 256, "tanh", 36, 2)]
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-4), (torch.float64, 1e-10)])
-@pytest.mark.parametrize("n_in,H,act,N,M", [(3, 5, "relu", 12, 3), (8, 100, "relu", 400, 4), (1, 17, "tanh", 30, 2),
-                                            (5, 64, "sigmoid", 64, 1), (16, 130, "tanh", 50, 5), (2, 300, "relu", 40, 2)])
+@pytest.mark.parametrize("n_in,H,act,N,M", SHAPES)
 def test_native_logp_grad_vs_oracle(ht, dtype, tol, n_in, H, act, N, M):
-    """Value and gradient of every split closure (S:1145-1199) for a batch of chains."""
+    """Value and gradient of every split closure (S:1145-1199) for a batch of chains (fp32: the MFMA kernel where it applies)."""
+    _logp_grad_case(dtype, tol, n_in, H, act, N, M)
+
+
+@pytest.mark.parametrize("n_in,H,act,N,M", SHAPES)
+def test_native_logp_grad_vs_oracle_valu_kernel(ht, valu_kernel, n_in, H, act, N, M):
+    """The same closures with the fp32 VALU kernel forced."""
+    _logp_grad_case(torch.float32, 3e-4, n_in, H, act, N, M)
+
+
+def _logp_grad_case(dtype, tol, n_in, H, act, N, M):
     from hamiltorch_amd import _abi
     npdt = np.float32 if dtype == torch.float32 else np.float64
     X, Y = make_data(N, n_in)
@@ -115,6 +139,14 @@ def test_sample_split_model_vs_oracle(ht, dims, act, native_expected, mass):
     sizes = [w.nelement() for w in net.parameters()]; shapes = [w.shape for w in net.parameters()]
     fl = bnn.define_split_model_log_prob(net, "regression", loader, M, sizes, shapes, tau_list, tau_out, device=dev(), verbose=False)
     assert (mlp.split_engine(fl, torch.tensor(th0, device=dev())) is not None) == native_expected
+
+
+def test_sample_model_full_data_vs_oracle_valu_kernel(ht, valu_kernel):
+    test_sample_model_full_data_vs_oracle(ht)
+
+
+def test_sample_split_model_vs_oracle_valu_kernel(ht, valu_kernel):
+    test_sample_split_model_vs_oracle(ht, [4, 33, 1], "tanh", True, "ones")
 
 
 def test_sample_model_full_data_vs_oracle(ht):

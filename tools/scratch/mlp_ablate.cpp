@@ -6,7 +6,7 @@
 #include <vector>
 #include <cmath>
 #include "hamiltorch_amd.h"
-#if HTA_TIMING
+#if HTA_TIMING || defined(HTA_TIMING_VALU)
 extern "C" void hta_dbg_read(unsigned long long* out);
 #endif
 
@@ -40,9 +40,9 @@ int main(int argc, char** argv) {
   long tot = 0; for (int v : r) tot += v;
   printf("%s C=%d  %.3f ms per %d trajectories (L=%d, M=%d)  -> %.3f us per gradient  rejected %ld\n", argc > 2 ? argv[2] : "", C, best, NT, L, M,
          best * 1e3 / (NT * (L * 2 * M + 2)), tot);
-#if HTA_TIMING
+#if HTA_TIMING || defined(HTA_TIMING_VALU)
   unsigned long long d[16]; hta_dbg_read(d);
-  const char* nm[8] = {"rest(axpy,drift,..)", "barrier A", "forward loop", "barrier B", "row sums", "block_sum2", "backward loop", "slice reduce"};
+  const char* nm[8] = {"rest(axpy,drift,gibbs)", "forward", "barrier 1", "residual stage", "barrier 2", "backward", "tail shuffles", "-"};
   unsigned long long tot2 = 0; for (int k = 0; k < 8; ++k) tot2 += d[k];
   for (int k = 0; k < 8; ++k) printf("   %-22s %10llu ticks  %5.1f %%\n", nm[k], d[k], 100.0 * d[k] / tot2);
 #endif

@@ -6,7 +6,7 @@ if [ "$1" = build ]; then
   mkdir -p $OUT
   for abl in ${ABLS:-0 1 2 4 8 16 5 31}; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -fno-slp-vectorize -DHTA_MLP_SINGLE -DHTA_ABL=$abl $EXTRA \
-      -Iinclude -Ihamiltorch_amd/csrc -x hip hamiltorch_amd/csrc/mlp_hmc.hip hamiltorch_amd/csrc/abi.cpp -x hip tools/scratch/mlp_ablate.cpp -o $OUT/abl_${abl}$TAG &
+      -Iinclude -Ihamiltorch_amd/csrc -x hip hamiltorch_amd/csrc/mlp_hmc.hip hamiltorch_amd/csrc/mlp_mfma.hip hamiltorch_amd/csrc/abi.cpp -x hip tools/scratch/mlp_ablate.cpp -o $OUT/abl_${abl}$TAG &
   done
   wait
 else
