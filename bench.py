@@ -209,7 +209,7 @@ class Cfg4:
     def bytes_per_unit(self):
         return 16 * self.D
 
-    roof_kernel = "mlp1_hmc_kernel<float,8,4,512>"
+    roof_kernel = "mlp_mfma_kernel<2,7,0,512>"
 
     def step(self, k):
         self.abi.mlp_hmc_sample(self.cur, self.theta0, 8, 100, "relu", self.X, self.Y, 4, 100, [1.0] * 4, 100.0, 4.0,
