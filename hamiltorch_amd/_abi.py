@@ -37,7 +37,7 @@ class HtaMetricArgs(ctypes.Structure):
                 ("mu", c_vp), ("log_norm", c_f64), ("m", c_vp), ("p_out", c_vp), ("x_out", c_vp), ("G_out", c_vp),
                 ("lam_out", c_vp), ("V_out", c_vp), ("L_out", c_vp), ("logdet_out", c_vp), ("quad_out", c_vp),
                 ("H_out", c_vp), ("logp_out", c_vp), ("upd_x", c_vp), ("cx", c_f64), ("upd_g", c_vp), ("cg", c_f64),
-                ("V0", c_vp), ("lam0", c_vp), ("lamraw_out", c_vp)]
+                ("V0", c_vp), ("lam0", c_vp), ("lamraw_out", c_vp), ("dmetric_out", c_vp)]
 
 
 METRIC_HESSIAN, METRIC_SOFTABS = 0, 1
@@ -63,6 +63,7 @@ def _sig(scalar):
                               ctypes.POINTER(scalar), scalar, scalar, c_vp, c_vp, c_vp],
         "hta_rmhmc_gaussian_leapfrog": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_f64, c_int, c_f64, c_u64, c_u64,
                                         c_u32, c_i64, c_int, c_int, c_f64, c_f64, c_vp, c_vp, c_vp],
+        "hta_rmhmc_binding_rotation": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f64, c_f64, c_vp],
         "hta_rmhmc_gaussian_sample": [c_vp, c_vp, c_vp, c_vp, c_f64, c_int, c_f64, c_int, c_f64, c_i64, c_int, c_int,
                                       c_f64, c_f64, c_int, c_int, c_int, c_u64, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                       c_vp, c_i64, c_vp],
@@ -240,7 +241,7 @@ def hmc_gaussian_leapfrog(theta, p, P, mu, mass_kind, inv_mass, steps, eps, path
 def metric_eval(like, B, D, metric, Hs, hs_stride, alpha, jitter=None, seed=0, chain_offset=0, draw=0, sub=0, X=None,
                 Pm=None, mu=None, log_norm=0.0, m=None, p_out=None, x_out=None, G_out=None, lam_out=None, V_out=None,
                 L_out=None, logdet_out=None, quad_out=None, H_out=None, logp_out=None, upd_x=None, cx=0.0, upd_g=None,
-                cg=0.0, max_sweeps=0, V0=None, lam0=None, lamraw_out=None):
+                cg=0.0, max_sweeps=0, V0=None, lam0=None, lamraw_out=None, dmetric_out=None):
     """One batched metric evaluation (see HtaMetricArgs in include/hamiltorch_amd.h).  `like` fixes dtype/device."""
     require_device(like, "params")
     a = HtaMetricArgs()
@@ -252,7 +253,8 @@ def metric_eval(like, B, D, metric, Hs, hs_stride, alpha, jitter=None, seed=0, c
     for name, t in (("Hs", Hs), ("X", X), ("Pm", Pm), ("mu", mu), ("m", m), ("p_out", p_out), ("x_out", x_out),
                     ("G_out", G_out), ("lam_out", lam_out), ("V_out", V_out), ("L_out", L_out),
                     ("logdet_out", logdet_out), ("quad_out", quad_out), ("H_out", H_out), ("logp_out", logp_out),
-                    ("upd_x", upd_x), ("upd_g", upd_g), ("V0", V0), ("lam0", lam0), ("lamraw_out", lamraw_out)):
+                    ("upd_x", upd_x), ("upd_g", upd_g), ("V0", V0), ("lam0", lam0), ("lamraw_out", lamraw_out),
+                    ("dmetric_out", dmetric_out)):
         setattr(a, name, None if t is None else _p(t, like).value)
         keep.append(t)
     fn = getattr(load(), "hta_metric_eval_" + _suffix(like))
@@ -275,6 +277,15 @@ def rmhmc_gaussian_leapfrog(theta, p, theta_c, p_c, P, mu, metric, alpha, jitter
                   0.0 if jitter is None else float(jitter), int(seed), int(chain_offset), int(draw) & 0xFFFFFFFF, C, D,
                   int(steps), float(eps), float(omega), _p(path_theta, theta), _p(path_p, theta), _stream(theta)),
                "hta_rmhmc_gaussian_leapfrog")
+
+
+def rmhmc_binding_rotation(theta, p, theta_c, p_c, eps, omega):
+    """phi_C of the explicit integrator (S:435-450), in place on the augmented state."""
+    require_device(theta, "params")
+    fn = getattr(load(), "hta_rmhmc_binding_rotation_" + _suffix(theta))
+    with torch.cuda.device(theta.device):
+        _check(fn(_p(theta), _p(p, theta), _p(theta_c, theta), _p(p_c, theta), theta.numel(), float(eps), float(omega),
+                  _stream(theta)), "hta_rmhmc_binding_rotation")
 
 
 def rmhmc_gaussian_sample(theta, theta_init, P, mu, log_norm, metric, alpha, jitter, L, eps, omega, n_traj, traj_offset,

@@ -15,6 +15,7 @@ template <typename T> struct MetricArgsT {   // typed view of HtaMetricArgs (inc
   T* x_out; T* G_out; T* lam_out; T* V_out; T* L_out; T* logdet_out; T* quad_out; T* H_out; T* logp_out;
   T* upd_x; double cx; T* upd_g; double cg;
   const T* V0; const T* lam0; T* lamraw_out;
+  T* dmetric_out;
 };
 static_assert(sizeof(MetricArgsT<float>) == sizeof(HtaMetricArgs), "HtaMetricArgs layout drifted from MetricArgsT");
 

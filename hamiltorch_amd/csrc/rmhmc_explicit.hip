@@ -152,6 +152,23 @@ int64_t hta_rmhmc_workspace_bytes(int64_t C, int D, int elem_size) {
   return (4 * C * D + 3 * C + (int64_t)D * D + D) * (int64_t)elem_size;
 }
 
+#define HTA_DEFINE_ROT(SUF, T)                                                                                  \
+  int hta_rmhmc_binding_rotation_##SUF(T* theta, T* p, T* theta_copy, T* p_copy, int64_t total, double eps,      \
+                                       double omega, void* stream) {                                             \
+    if (!theta || !p || !theta_copy || !p_copy || total <= 0) {                                                  \
+      hta::set_error("hta_rmhmc_binding_rotation: NULL pointer / empty state");                                  \
+      return HTA_ERR_INVALID;                                                                                    \
+    }                                                                                                            \
+    const float ang = (float)(2.0 * omega * eps);                                                                \
+    int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;                                         \
+    hta::phi_c_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(theta, p, theta_copy, p_copy, (T)cosf(ang),      \
+                                                                (T)sinf(ang), total);                            \
+    HTA_CHECK_LAUNCH("hta_rmhmc_binding_rotation");                                                              \
+    return HTA_OK;                                                                                               \
+  }
+HTA_DEFINE_ROT(f32, float)
+HTA_DEFINE_ROT(f64, double)
+
 #define HTA_DEFINE_RM(SUF, T)                                                                                   \
   int hta_rmhmc_gaussian_leapfrog_##SUF(T* theta, T* p, T* theta_copy, T* p_copy, const T* P, const T* mu,       \
                                         int metric, double alpha, int has_jitter, double jitter, uint64_t seed,  \

@@ -239,6 +239,19 @@ __device__ void lds_jacobi(T* A, T* VT, int D, int ne, int lda, int ldv, T* cs_r
 }
 
 // ------------------------------------------------------------------------------------------------
+// d lam~ / d lam for the soft-abs map lam~ = lam coth(alpha lam) (S:120):  coth x - x / sinh^2 x with x = alpha lam
+// (an odd function of x; series below |x| = 0.3 where the closed form cancels, exp(-2|x|) form elsewhere: no overflow)
+template <typename T> __device__ __forceinline__ T softabs_slope(T alpha, T lam) {
+  const T x = alpha * lam, ax = fabs(x);
+  if (ax < (T)0.3) {
+    const T x2 = x * x;
+    return x * ((T)(2.0 / 3.0) - x2 * ((T)(4.0 / 45.0) - x2 * ((T)(12.0 / 945.0) - x2 * (T)(8.0 / 4725.0))));
+  }
+  const T t = exp((T)-2 * ax), om = (T)1 - t;
+  const T d = ((T)1 + t) / om - ax * (T)4 * t / (om * om);
+  return x < 0 ? -d : d;
+}
+
 template <typename T, int MAXB, int MAXV>
 __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int ne, int lda, int ldv, int v0_lds) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
         if (a.lamraw_out) a.lamraw_out[b * D + i] = lam;
       }
       logdet = block_sum(ld, red);
-      if (warm && (a.V_out || a.G_out || a.p_out || a.L_out)) {
+      if (warm && (a.V_out || a.G_out || a.p_out || a.L_out || a.dmetric_out)) {
         // eigenvectors in the original basis: V <- V0 J  (through the A region; its eigenvalues are in vec0)
         __syncthreads();
         for (int e = tid; e < D * D; e += MT) {
@@ -365,7 +378,7 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
         for (int e = tid; e < D * D; e += MT) { const int i = e / D, j = e - i * D; V[j * ldv + i] = A[i * lda + j]; }
         __syncthreads();
       }
-      const bool rotated = warm && !(a.V_out || a.G_out || a.p_out || a.L_out);   // V still holds J
+      const bool rotated = warm && !(a.V_out || a.G_out || a.p_out || a.L_out || a.dmetric_out);   // V still holds J
       if (a.V_out) for (int e = tid; e < D * D; e += MT) { const int i = e / D, j = e - i * D; a.V_out[b * D * D + e] = V[j * ldv + i]; }
       if (a.m) {                       // x = Q (Q^T m / lam~)
         if (rotated) {                 // m' = V0^T m
@@ -403,6 +416,48 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
           else { for (int k = 0; k < D; ++k) acc += V[k * ldv + i] * vec1[k]; }
           if (a.x_out) a.x_out[b * D + i] = acc;
           if (a.upd_x) a.upd_x[b * D + i] += (T)a.cx * acc;
+        }
+      }
+      if (a.dmetric_out) {
+        // M = Q W Q^T with W_kl = 1/2 [k==l] lam~'_k / lam~_k - 1/2 J_kl u_k u_l  (u = Q^T m / lam~ is in vec1):
+        // the derivative of 1/2 log|G| + 1/2 m^T G^-1 m with respect to the entries of Hs (Daleckii-Krein), which the
+        // reference reaches by back-propagating S:726-731 through eigh (S:398).
+        __syncthreads();
+        for (int i = tid; i < D; i += MT) {
+          const T lam = A[i * lda + i];
+          vec3[i] = lam;
+          vec2[i] = softabs_slope<T>((T)a.alpha, lam);
+          if (!a.m) vec1[i] = 0;
+        }
+        __syncthreads();
+        const T tol = sizeof(T) == 4 ? (T)1e-3 : (T)1e-6;
+        for (int e = tid; e < D * D; e += MT) {
+          const int k = e / D, l = e - k * D;
+          const T lk = vec3[k], ll = vec3[l], dl = lk - ll;
+          T J;
+          if (k == l || fabs(dl) <= tol * (fabs(lk) + fabs(ll))) J = softabs_slope<T>((T)a.alpha, (T)0.5 * (lk + ll));
+          else J = (vec0[k] - vec0[l]) / dl;
+          T w = (T)-0.5 * J * vec1[k] * vec1[l];
+          if (k == l) w += (T)0.5 * vec2[k] / vec0[k];
+          A[k * lda + l] = w;
+        }
+        __syncthreads();
+        // T = W Q^T in place, a row-aligned batch of rows at a time
+        const int RB = MT / D;
+        for (int r0 = 0; r0 < D; r0 += RB) {
+          const int r = r0 + tid / D, j = tid % D;
+          const bool on = tid < RB * D && r < D;
+          T acc = 0;
+          if (on) for (int l = 0; l < D; ++l) acc += A[r * lda + l] * V[l * ldv + j];
+          __syncthreads();
+          if (on) A[r * lda + j] = acc;
+          __syncthreads();
+        }
+        for (int e = tid; e < D * D; e += MT) {
+          const int i = e / D, j = e - i * D;
+          T acc = 0;
+          for (int k = 0; k < D; ++k) acc += V[k * ldv + i] * A[k * lda + j];
+          a.dmetric_out[b * D * D + e] = acc;
         }
       }
       if (a.G_out || a.p_out || a.L_out) {          // G = Q diag(lam~) Q^T  (S:121), into the A region

@@ -5,9 +5,19 @@ S:677-736, the explicit integrator S:389-462 and the RMHMC branch of ``sample`` 
 The eigendecomposition / soft-abs map / solves / log-determinant run in
 ``csrc/rmhmc_metric.hip`` (one workgroup per system, matrices in LDS).  ``fisher``,
 ``cholesky_inverse``, ``rm_hamiltonian`` and the momentum draw accept any ``log_prob_func`` (its
-Hessian comes from ``torch.func.hessian``); the explicit *integrator* needs d H / d theta, which for
-a general target involves third derivatives of log p -- it is implemented for constant-curvature
-targets (``GaussianTarget``), the family of BASELINE configs 3 and 5 (SURVEY 8f N1 is the rest).
+Hessian comes from ``torch.func.hessian``).
+
+The explicit *integrator* needs d H / d theta.  For constant-curvature targets (``GaussianTarget``,
+BASELINE configs 3 and 5) that is -grad log p and a whole run is one C call.  For a general target
+(the reference differentiates S:726-731 through hessian + eigh, S:398) it is
+
+    d H / d theta_i = -d_i log p - d_i < Hess log p (theta), M >|_(M fixed),
+
+with M = Q W Q^T built from the eigen-system of the metric by ``hta_metric_eval`` (``dmetric_out``, the
+Daleckii-Krein form of the soft-abs derivative).  The contraction with the third derivatives of log p
+never forms a D^3 tensor: it is one more reverse pass through ``torch.func.hessian`` per chain, batched
+with ``vmap``.  Eight metric evaluations per step, each with its own jitter sub-stream, as the reference
+(the constant-curvature path shares them pairwise because there dH/dtheta does not depend on the metric).
 """
 from __future__ import annotations
 
@@ -42,8 +52,8 @@ def _curvature(theta, log_prob_func):
         logp = tgt.log_norm - 0.5 * ((d @ tgt.precision) * d).sum(-1)
         return tgt.precision, 0, logp.contiguous(), tgt
     f = lambda w: log_prob_func(w).sum()  # noqa: E731
-    H = torch.func.vmap(torch.func.hessian(f))(theta)                     # S:108
-    logp = torch.func.vmap(f)(theta)
+    H = torch.func.vmap(torch.func.hessian(f))(theta).to(theta.dtype)     # S:108
+    logp = torch.func.vmap(f)(theta).to(theta.dtype)
     D = theta.shape[1]
     return (-H).contiguous(), D * D, logp.contiguous(), None
 
@@ -117,14 +127,60 @@ def gibbs(theta, log_prob_func, jitter, softabs_const, metric, seed, chain_offse
     return p
 
 
-def _need_gaussian(log_prob_func, theta):
-    tgt = as_gaussian(log_prob_func, theta)
-    if tgt is None:
-        raise NotImplementedError(
-            "explicit RMHMC is accelerated for constant-curvature targets (hamiltorch_amd.GaussianTarget or a "
-            "MultivariateNormal.log_prob); a general log_prob_func needs third derivatives of log p "
-            "(samplers.py:398 differentiates through hessian + eigh) -- not in the native path yet")
-    return tgt
+class _Curvature:
+    """Batched derivatives of a user log_prob_func (one chain per row) through torch.func."""
+
+    def __init__(self, log_prob_func):
+        f = lambda w: log_prob_func(w).sum()  # noqa: E731
+        self.f = f
+        self._val = torch.func.vmap(f)
+        # gradient and Hessian in one forward-over-reverse pass: jacfwd of (grad, aux = grad)
+        g = torch.func.grad(f)
+        self._gh = torch.func.vmap(torch.func.jacfwd(lambda w: (g(w), g(w)), has_aux=True))
+        self._third = torch.func.vmap(torch.func.grad(lambda w, m: (torch.func.hessian(f)(w) * m).sum()))
+
+    # (a callback may promote: e.g. constants it builds in float64 - results are brought back to the state's dtype)
+    def value(self, theta):
+        return self._val(theta).to(theta.dtype).contiguous()
+
+    def grad_neg_hessian(self, theta):
+        H, g = self._gh(theta)
+        return g.to(theta.dtype).contiguous(), (-H).to(theta.dtype).contiguous()
+
+    def contract(self, theta, M):
+        """c_i = d_i < Hess log p (theta), M >, M held fixed: [C, D]."""
+        return self._third(theta, M).to(theta.dtype).contiguous()
+
+
+def _generic_steps(cv, kind, th, pm, thc, pmc, steps, eps, omega, alpha, jitter, seed, chain_offset, draw, path=None):
+    """S:425-461 on the augmented state, in place.  Unlike the constant-curvature path, dH/dtheta depends on the
+    metric here, so each of the reference's 8 gradient calls per step keeps its own metric evaluation and jitter
+    sub-stream (2 + 8 l + k, k = 0..7 in the reference's call order)."""
+    if kind != _abi.METRIC_SOFTABS:
+        raise NotImplementedError("explicit RMHMC on a general target is implemented for Metric.SOFTABS "
+                                  "(the Hessian metric of a non-Gaussian target is not positive definite in general)")
+    C, D = th.shape
+    eh = 0.5 * eps
+    M = torch.empty(C, D, D, dtype=th.dtype, device=th.device)
+
+    def kick(theta, mvec, upd, sub):            # upd -= eh dH/dtheta(theta, mvec),  dH/dtheta = -(g + c)   (S:395-398)
+        g, Hs = cv.grad_neg_hessian(theta)
+        _abi.metric_eval(theta, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, draw, sub, m=mvec, dmetric_out=M)
+        upd.add_(g + cv.contract(theta, M), alpha=eh)
+
+    def drift(theta, mvec, upd, sub):           # upd += eh dH/dp(theta, mvec) = eh G^-1 mvec              (S:415-422)
+        _, Hs = cv.grad_neg_hessian(theta)
+        _abi.metric_eval(theta, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, draw, sub, m=mvec, upd_x=upd, cx=eh)
+
+    for l in range(steps):
+        k0 = 2 + 8 * l
+        kick(th, pmc, pm, k0 + 0); drift(th, pmc, thc, k0 + 1)                     # phi_A(1/2)  S:429-430
+        drift(thc, pm, th, k0 + 2); kick(thc, pm, pmc, k0 + 3)                     # phi_B(1/2)  S:432-433
+        _abi.rmhmc_binding_rotation(th, pm, thc, pmc, eps, omega)                  # phi_C       S:447-450
+        drift(thc, pm, th, k0 + 4); kick(thc, pm, pmc, k0 + 5)                     # phi_B(1/2)  S:454-455
+        kick(th, pmc, pm, k0 + 6); drift(th, pmc, thc, k0 + 7)                     # phi_A(1/2)  S:457-458
+        if path is not None:
+            path[0][l].copy_(th); path[1][l].copy_(pm)
 
 
 def explicit_leapfrog(params, momentum, log_prob_func, steps, step_size, jitter, softabs_const, omega, metric,
@@ -134,13 +190,17 @@ def explicit_leapfrog(params, momentum, log_prob_func, steps, step_size, jitter,
     p, _ = _batch(momentum, "momentum")
     theta, p = theta.clone(), p.clone()
     _abi.require_device(theta, "params")
-    tgt = _need_gaussian(log_prob_func, theta)
+    tgt = as_gaussian(log_prob_func, theta)
     thc, pc = theta.clone(), p.clone()
     pt = torch.empty((steps,) + theta.shape, dtype=theta.dtype, device=theta.device)
     pp = torch.empty_like(pt)
     seed = util.next_stream_seed() if (seed is None and jitter is not None) else (seed or 0)
-    _abi.rmhmc_gaussian_leapfrog(theta, p, thc, pc, tgt.precision, tgt.mean, _metric_kind(metric), softabs_const, jitter,
-                                 seed, chain_offset, draw, steps, step_size, omega, pt, pp)
+    if tgt is not None:
+        _abi.rmhmc_gaussian_leapfrog(theta, p, thc, pc, tgt.precision, tgt.mean, _metric_kind(metric), softabs_const,
+                                     jitter, seed, chain_offset, draw, steps, step_size, omega, pt, pp)
+    else:
+        _generic_steps(_Curvature(log_prob_func), _metric_kind(metric), theta, p, thc, pc, steps, step_size, omega,
+                       softabs_const, jitter, seed, chain_offset, draw, path=(pt, pp))
     unb = (lambda t: t[0]) if one else (lambda t: t)
     return [[unb(t) for t in pt.unbind(0)], unb(thc)], [[unb(t) for t in pp.unbind(0)], unb(pc)]
 
@@ -149,10 +209,13 @@ def sample_explicit(log_prob_func, theta0, N, L, eps, burn, jitter, softabs_cons
                     verbose):
     """The RMHMC / EXPLICIT branch of sample() (S:969-1026): one C call enqueues the whole run."""
     from .samplers import _num_rows
-    tgt = _need_gaussian(log_prob_func, theta0)
+    tgt = as_gaussian(log_prob_func, theta0)
     kind = _metric_kind(metric)
     if softabs_const is None and kind == _abi.METRIC_SOFTABS:
         raise TypeError("softabs_const must be set for Metric.SOFTABS")
+    if tgt is None:
+        return _sample_explicit_generic(log_prob_func, theta0, N, L, eps, burn, jitter, softabs_const, omega, kind, seed,
+                                        chain_offset, verbose)
     C, D = theta0.shape
     S = _num_rows(N, burn)
     samples = torch.empty((S, C, D), dtype=theta0.dtype, device=theta0.device)
@@ -163,5 +226,40 @@ def sample_explicit(log_prob_func, theta0, N, L, eps, burn, jitter, softabs_cons
     prog = util._Progress('Sampling (Sampler.RMHMC; Integrator.EXPLICIT)', N, verbose)
     _abi.rmhmc_gaussian_sample(cur, theta0, tgt.precision, tgt.mean, tgt.log_norm, kind, softabs_const, jitter, L, eps,
                                omega, N, 0, burn, seed, chain_offset, samples, rejected, ws)
+    prog.end()
+    return samples, rejected
+
+
+def _sample_explicit_generic(log_prob_func, theta0, N, L, eps, burn, jitter, alpha, omega, kind, seed, chain_offset,
+                             verbose):
+    """The same trajectory loop as csrc/rmhmc_explicit.hip:rmhmc_sample with the target's derivatives coming from
+    torch.func: gibbs (sub-stream 0), H_old (1), L explicit steps (2 .. 2+8L-1), H_new on the un-augmented pair
+    (2+8L, Q4), Metropolis select + bookkeeping in `hta_mh_select`."""
+    from .samplers import _num_rows
+    C, D = theta0.shape
+    dt, dev = theta0.dtype, theta0.device
+    cv = _Curvature(log_prob_func)
+    S = _num_rows(N, burn)
+    samples = torch.empty((S, C, D), dtype=dt, device=dev)
+    samples[0].copy_(theta0)
+    cur = theta0.clone()
+    rejected = torch.zeros(C, dtype=torch.int32, device=dev)
+    H0 = torch.empty(C, dtype=dt, device=dev); H1 = torch.empty_like(H0)
+    pm = torch.empty_like(cur)
+    prog = util._Progress('Sampling (Sampler.RMHMC; Integrator.EXPLICIT)', N, verbose)
+    for n in range(N):
+        _, Hs = cv.grad_neg_hessian(cur)
+        _abi.metric_eval(cur, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, n, 0, p_out=pm)        # S:183-184
+        _abi.metric_eval(cur, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, n, 1, m=pm, H_out=H0)  # S:971
+        H0.sub_(cv.value(cur))
+        th, thc, pmc = cur.clone(), cur.clone(), pm.clone()
+        _generic_steps(cv, kind, th, pm, thc, pmc, L, eps, omega, alpha, jitter, seed, chain_offset, n)
+        _, Hs1 = cv.grad_neg_hessian(th)
+        lp1 = cv.value(th)
+        _abi.metric_eval(th, C, D, kind, Hs1, D * D, alpha, jitter, seed, chain_offset, n, 2 + 8 * L, m=pm, H_out=H1)  # S:989
+        H1.sub_(lp1)
+        row = samples[n - burn] if n > burn else None
+        _abi.mh_select(cur, th, theta0, H0, H1, lp1, row, rejected, None, n, burn, seed, chain_offset)
+        prog.update(n)
     prog.end()
     return samples, rejected

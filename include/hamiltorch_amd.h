@@ -175,6 +175,11 @@ typedef struct HtaMetricArgs {
                                                 solver then diagonalises diag(lam0) + V0^T diag(jitter u) V0, which
                                                 is nearly diagonal: 2 Jacobi sweeps instead of ~10; same results    */
   void* lamraw_out;                          /* [B,D] eigenvalues before the soft-abs map                           */
+  void* dmetric_out;                         /* [B,D,D] (SOFTABS): the symmetric matrix M with
+                                                d/dtheta_i [1/2 log|G| + 1/2 m^T G^-1 m] = <d_i Hs, M>, i.e. what the
+                                                reference gets by differentiating S:726-731 through eigh (S:398):
+                                                M = Q W Q^T, W_kl = 1/2 [k==l] lam~'_k / lam~_k - 1/2 J_kl u_k u_l,
+                                                u = Q^T m / lam~, J = divided differences of lam -> lam~ (Daleckii-Krein) */
 } HtaMetricArgs;
 
 int hta_metric_eval_f32(const HtaMetricArgs* args, void* stream);
@@ -183,6 +188,13 @@ int hta_metric_eval_f64(const HtaMetricArgs* args, void* stream);
 /* Explicit RMHMC integrator (S:389-462) for a Gaussian target, `steps` steps on the augmented state
  * (theta, p, theta_copy, p_copy), all [C,D] in/out.  omega = explicit_binding_const.
  * path_theta / path_p: optional [steps,C,D] record of (theta, p) after every step (S:460-461). */
+/* phi_C of the explicit integrator (S:435-450): the binding rotation by angle 2 omega eps on the augmented state,
+ * in the reference's sequential update order, cos / sin rounded to float32 first.  total = C * D elements. */
+int hta_rmhmc_binding_rotation_f32(float* theta, float* p, float* theta_copy, float* p_copy, int64_t total,
+                                   double eps, double omega, void* stream);
+int hta_rmhmc_binding_rotation_f64(double* theta, double* p, double* theta_copy, double* p_copy, int64_t total,
+                                   double eps, double omega, void* stream);
+
 int hta_rmhmc_gaussian_leapfrog_f32(float* theta, float* p, float* theta_copy, float* p_copy, const float* P,
                                     const float* mu, int metric, double alpha, int has_jitter, double jitter,
                                     uint64_t seed, uint64_t chain_offset, uint32_t draw, int64_t C, int D,

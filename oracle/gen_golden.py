@@ -37,7 +37,7 @@ class Recorder:
     MH uniforms torch.rand(1) (S:1004)."""
 
     def __enter__(self):
-        self.momenta, self.uniforms = [], []
+        self.momenta, self.uniforms, self.jitters = [], [], []
         self._gibbs, self._rand = S.gibbs, torch.rand
 
         def gibbs(*a, **k):
@@ -49,6 +49,8 @@ class Recorder:
             u = self._rand(*a, **k)
             if tuple(u.shape) == (1,):
                 self.uniforms.append(npy(u).copy())
+            elif u.dim() == 1:                                  # the jitter draw of fisher() (S:115): torch.rand(D), D > 1
+                self.jitters.append(npy(u).copy())
             return u
 
         S.gibbs = gibbs
@@ -327,12 +329,87 @@ def gen_mlp():
     np.savez(os.path.join(OUT, "mlp.npz"), **out)
 
 
+SCALES = [0.5, 1.0, 1.7, 2.4, 3.3]
+
+
+def funnel_ll(D, scales=None):
+    """The notebook's funnel (hamiltorch_log_prob_examples.ipynb, cell funnel_ll) for any D; `scales` s_i give
+    x_i ~ N(0, s_i exp(-v)) (distinct Hessian eigenvalues, so that eigh can be differentiated without jitter)."""
+    def f(w):
+        sc = torch.ones(D - 1, dtype=w.dtype) if scales is None else torch.tensor(scales[:D - 1], dtype=w.dtype)
+        v_dist = torch.distributions.Normal(0, 3)
+        ll = v_dist.log_prob(w[0])
+        x_dist = torch.distributions.Normal(0, (sc * torch.exp(-w[0])) ** 0.5)
+        ll = ll + x_dist.log_prob(w[1:]).sum()
+        return ll
+    return f
+
+
+def gen_funnel():
+    """Explicit RMHMC on a NON-constant-curvature target: the reference differentiates rm_hamiltonian through
+    hessian + eigh (S:398).  (a) scaled funnel, jitter=None: nothing random; (b) the notebook's funnel, whose
+    Hessian has a repeated eigenvalue, with jitter - the torch.rand(D) draws of fisher() are recorded in call order."""
+    out = {}
+    out["scales"] = np.array(SCALES)
+    for D, alpha, tag in ((4, 1e6, "a1e6"), (4, 1.3, "a1p3"), (6, 0.7, "d6")):
+        lp = funnel_ll(D, SCALES)
+        for dt, dtag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            g = torch.Generator().manual_seed(5)
+            th = (0.6 * torch.randn(D, generator=g, dtype=torch.float64)).to(dt)
+            pm = torch.randn(D, generator=g, dtype=torch.float64).to(dt)
+            key = f"{tag}_{dtag}"
+            out[f"{key}_theta0"] = npy(th); out[f"{key}_p0"] = npy(pm)
+            out[f"{tag}_cfg"] = np.array([D, alpha, 5.0, 0.05, 3])
+            G, lam = S.fisher(th, lp, jitter=None, softabs_const=alpha, metric=hamiltorch.Metric.SOFTABS)
+            out[f"{key}_G"] = npy(G); out[f"{key}_lam"] = npy(lam)
+            H = S.rm_hamiltonian(th, pm, lp, None, 1.0, softabs_const=alpha, metric=hamiltorch.Metric.SOFTABS)
+            out[f"{key}_H"] = npy(H).reshape(-1)
+            lpar, lmom = S.leapfrog(th, pm, lp, steps=3, step_size=0.05, jitter=None, explicit_binding_const=5.0,
+                                    softabs_const=alpha, sampler=hamiltorch.Sampler.RMHMC,
+                                    integrator=hamiltorch.Integrator.EXPLICIT, metric=hamiltorch.Metric.SOFTABS)
+            out[f"{key}_lf_theta"] = np.stack([npy(t) for t in lpar[0]]); out[f"{key}_lf_p"] = np.stack([npy(t) for t in lmom[0]])
+            out[f"{key}_lf_thetac"] = npy(lpar[1]); out[f"{key}_lf_pc"] = npy(lmom[1])
+    # (b) notebook funnel (s_i = 1) with jitter, one leapfrog call: 8 jitter draws per step, in call order
+    D = 5
+    lp = funnel_ll(D)
+    g = torch.Generator().manual_seed(6)
+    th = 0.5 * torch.randn(D, generator=g, dtype=torch.float64); pm = torch.randn(D, generator=g, dtype=torch.float64)
+    hamiltorch.set_random_seed(9)
+    with Recorder() as rec:
+        lpar, lmom = S.leapfrog(th, pm, lp, steps=2, step_size=0.05, jitter=0.01, explicit_binding_const=5.0,
+                                softabs_const=1e6, sampler=hamiltorch.Sampler.RMHMC,
+                                integrator=hamiltorch.Integrator.EXPLICIT, metric=hamiltorch.Metric.SOFTABS)
+    out["jit_theta0"] = npy(th); out["jit_p0"] = npy(pm); out["jit_cfg"] = np.array([D, 1e6, 5.0, 0.05, 2, 0.01])
+    out["jit_draws"] = np.stack(rec.jitters)
+    out["jit_lf_theta"] = np.stack([npy(t) for t in lpar[0]]); out["jit_lf_p"] = np.stack([npy(t) for t in lmom[0]])
+    # end-to-end sample() on the scaled funnel, jitter=None, draws recorded
+    D = 4
+    lp = funnel_ll(D, SCALES)
+    hamiltorch.set_random_seed(77)
+    with Recorder() as rec:
+        ret, acc = hamiltorch.sample(lp, torch.tensor([0.2, -0.3, 0.4, 0.1], dtype=torch.float64), num_samples=10,
+                                     num_steps_per_sample=4, step_size=0.1, burn=1, jitter=None, softabs_const=1e6,
+                                     explicit_binding_const=10.0, sampler=hamiltorch.Sampler.RMHMC,
+                                     integrator=hamiltorch.Integrator.EXPLICIT, metric=hamiltorch.Metric.SOFTABS,
+                                     debug=2, verbose=False)
+    out["e2e_samples"] = np.stack([npy(t) for t in ret])
+    out["e2e_momenta"] = np.stack(rec.momenta)
+    out["e2e_uniforms"] = np.concatenate(rec.uniforms)
+    out["e2e_acc"] = np.array(acc)
+    np.savez(os.path.join(OUT, "funnel.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                      # python oracle/gen_golden.py funnel  -> only that family
+        for name in sys.argv[1:]:
+            globals()["gen_" + name]()
+        sys.exit(0)
     gen_hmc_kat()
     gen_gibbs()
     gen_sample_hmc()
     gen_rmhmc()
     gen_mlp()
     gen_nuts()
+    gen_funnel()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -221,3 +221,89 @@ def test_cfg3_statistical_parity_with_jitter(ht):
     # the chains actually move: lag-N/2 autocorrelation of the slowest coordinate is far from 1
     a = torch.stack(out).double().cpu().numpy()
     assert np.abs(a[-1] - a[0]).mean() > 0.3
+
+
+# ---- generic (non-constant-curvature) targets: SURVEY 8f N1 ---------------------------------------------
+def funnel_logp(scales):
+    """The notebook's funnel_ll (scaled variant of oracle.FunnelTarget) as a torch callable on the device."""
+    def f(w):
+        s = torch.as_tensor(scales, dtype=w.dtype, device=w.device)
+        v, x = w[0], w[1:]
+        hl2p = 0.9189385332046727
+        lv = -v * v / 18.0 - 1.0986122886681098 - hl2p
+        return lv + (-0.5 * torch.exp(v) * (x * x / s).sum() + 0.5 * x.numel() * v - x.numel() * hl2p - 0.5 * torch.log(s).sum())
+    return f
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.float64, 1e-8)])
+@pytest.mark.parametrize("D,kind,alpha", [(2, "indef", 1.3), (5, "indef", 2.0), (8, "degenerate", 1e6), (11, "indef", 0.7),
+                                           (40, "spd", 1e6), (64, "indef", 1e6), (100, "indef", 0.05)])
+def test_softabs_dmetric_vs_oracle(ht, dtype, tol, D, kind, alpha):
+    """dmetric_out: M = Q W Q^T (the derivative of 1/2 log|G| + 1/2 m^T G^-1 m with respect to the entries of Hs),
+    including repeated eigenvalues, |alpha lam| << 1 (series branch) and >> 1."""
+    from hamiltorch_amd import _abi
+    if dtype == torch.float64 and D > 96:
+        pytest.skip("fp64 D > 99 exceeds the LDS of one CU")
+    B = 4
+    Hs = sym_batch(B, D, kind, D + 1).astype(NP[dtype])
+    m = np.random.default_rng(2).standard_normal((B, D)).astype(NP[dtype])
+    Mw, xw = O.softabs_dmetric(Hs.astype(np.float64), alpha, m)
+    Md = torch.empty(B, D, D, dtype=dtype, device=dev()); xd = torch.empty(B, D, dtype=dtype, device=dev())
+    t = tt(Hs, dtype)
+    _abi.metric_eval(t, B, D, _abi.METRIC_SOFTABS, t, D * D, alpha, m=tt(m, dtype), x_out=xd, dmetric_out=Md)
+    got = Md.double().cpu().numpy()
+    np.testing.assert_allclose(got, np.swapaxes(got, 1, 2), atol=tol * np.abs(Mw).max())
+    if kind == "degenerate":
+        # inside a repeated eigenvalue the eigenvectors are arbitrary; M is not (J is constant on the block)
+        pass
+    np.testing.assert_allclose(got, Mw, rtol=tol, atol=tol * np.abs(Mw).max())
+    # no momentum: only the log-determinant part
+    _abi.metric_eval(t, B, D, _abi.METRIC_SOFTABS, t, D * D, alpha, dmetric_out=Md)
+    M0, _ = O.softabs_dmetric(Hs.astype(np.float64), alpha, np.zeros_like(m))
+    np.testing.assert_allclose(Md.double().cpu().numpy(), M0, rtol=tol, atol=tol * np.abs(M0).max())
+
+
+@pytest.mark.parametrize("tag", ["a1e6", "a1p3", "d6"])
+@pytest.mark.parametrize("dtag,dtype,tol", [("f64", torch.float64, 5e-8), ("f32", torch.float32, 3e-3)])
+def test_generic_explicit_leapfrog_vs_reference_fixture(ht, golden, tag, dtag, dtype, tol):
+    """leapfrog(sampler=RMHMC, integrator=EXPLICIT) on the scaled funnel: the values the unmodified reference
+    produced by differentiating through hessian + eigh (S:398)."""
+    g = golden("funnel")
+    D, alpha, omega, eps, steps = g[f"{tag}_cfg"]
+    D, steps = int(D), int(steps)
+    key = f"{tag}_{dtag}"
+    lp = funnel_logp(g["scales"][:D - 1])
+    th, pm = tt(g[f"{key}_theta0"], dtype), tt(g[f"{key}_p0"], dtype)
+    H = ht.samplers.rm_hamiltonian(th, pm, lp, None, 1.0, softabs_const=alpha, metric=ht.Metric.SOFTABS)
+    np.testing.assert_allclose(H.cpu().numpy().reshape(-1), g[f"{key}_H"], rtol=tol, atol=tol)
+    lpar, lmom = ht.samplers.leapfrog(th, pm, lp, steps=steps, step_size=eps, jitter=None, explicit_binding_const=omega,
+                             softabs_const=alpha, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT,
+                             metric=ht.Metric.SOFTABS)
+    np.testing.assert_allclose(torch.stack(lpar[0]).cpu().numpy(), g[f"{key}_lf_theta"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(torch.stack(lmom[0]).cpu().numpy(), g[f"{key}_lf_p"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(lpar[1].cpu().numpy(), g[f"{key}_lf_thetac"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(lmom[1].cpu().numpy(), g[f"{key}_lf_pc"], rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-7), (torch.float32, 5e-3)])
+@pytest.mark.parametrize("D,scaled,jitter,alpha", [(5, True, None, 1e6), (5, False, 1e-2, 1e6), (11, False, 1e-3, 1.0)])
+def test_generic_sample_rmhmc_vs_oracle(ht, dtype, tol, D, scaled, jitter, alpha):
+    """End to end sample(RMHMC, EXPLICIT) on the funnel for a batch of chains: torch.func derivatives + native metric
+    / contraction matrix / rotation / select, against the oracle with the same Philox streams (8 jitter sub-streams
+    per step, as the reference draws them)."""
+    scales = np.array([0.5, 1.0, 1.7, 2.4, 3.3, 0.8, 1.2, 2.0, 2.9, 0.6])[:D - 1] if scaled else np.ones(D - 1)
+    lp = funnel_logp(scales)
+    o = O.FunnelTarget(D, scales)
+    C, N, L, eps, omega, seed, off = 12, 5, 3, 0.08, 10.0, 99, 7
+    th0 = (0.4 * O.philox_normals(seed, off + np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(NP[dtype])
+    out, acc = ht.sample(lp, tt(th0, dtype), num_samples=N, num_steps_per_sample=L, step_size=eps, burn=0, jitter=jitter,
+                         softabs_const=alpha, explicit_binding_const=omega, sampler=ht.Sampler.RMHMC,
+                         integrator=ht.Integrator.EXPLICIT, metric=ht.Metric.SOFTABS, debug=2, verbose=False, seed=seed,
+                         chain_offset=off)
+    with np.errstate(all="ignore"):
+        ref, info = O.sample_rmhmc_explicit(o, th0, N, L, eps, omega, alpha, 0, jitter,
+                                            O.PhiloxDraws(seed, off + np.arange(C), NP[dtype]))
+    got = np.stack([x.cpu().numpy() for x in out]); want = np.stack(ref)
+    assert got.shape == want.shape
+    bad = ~(np.abs(got - want).max(axis=(0, 2)) <= tol)
+    assert bad.mean() <= 0.1, "%d of %d chains differ, max err %.3g" % (bad.sum(), C, np.nanmax(np.abs(got - want)))

@@ -258,3 +258,60 @@ def test_product_adaptation_function_vs_reference(golden):
     for t, (r, want) in enumerate(zip(g["adapt_rhos"], g["adapt_out"])):
         ss, eb, Ht = samplers.adaptation(float(r), t, 0.3, Ht, eb, desired_accept_rate=0.75)
         np.testing.assert_allclose([ss, eb, Ht], want, rtol=1e-6, atol=1e-9)
+
+
+# ---- generic (non-constant-curvature) explicit RMHMC: SURVEY 8f N1 ------------------------------------
+def _funnel(g, D, scaled=True):
+    return O.FunnelTarget(D, g["scales"][:D - 1] if scaled else None)
+
+
+@pytest.mark.parametrize("tag", ["a1e6", "a1p3", "d6"])
+@pytest.mark.parametrize("dtag,dt,tol", [("f64", np.float64, 2e-8), ("f32", np.float32, 2e-3)])
+def test_funnel_metric_hamiltonian_explicit_leapfrog(golden, tag, dtag, dt, tol):
+    """fisher / rm_hamiltonian / explicit leapfrog of the reference on the scaled funnel, where dH/dtheta goes
+    through hessian + eigh (S:398): the oracle's closed form (softabs_dmetric) must reproduce it."""
+    g = golden("funnel")
+    D, alpha, omega, eps, steps = g[f"{tag}_cfg"]
+    D, steps = int(D), int(steps)
+    t = _funnel(g, D)
+    key = f"{tag}_{dtag}"
+    th, pm = g[f"{key}_theta0"][None].astype(dt), g[f"{key}_p0"][None].astype(dt)
+    G, lam_t, _ = O.softabs_metric(t.neg_hessian(th), alpha)
+    np.testing.assert_allclose(G[0], g[f"{key}_G"], rtol=tol, atol=tol * np.abs(g[f"{key}_G"]).max())
+    np.testing.assert_allclose(np.sort(lam_t[0]), np.sort(g[f"{key}_lam"]), rtol=tol, atol=tol)
+    H, _ = O.rm_hamiltonian(th, pm, t, alpha)
+    np.testing.assert_allclose(H, g[f"{key}_H"], rtol=tol, atol=tol)
+    for n in range(1, steps + 1):        # the reference's path holds the state after every step
+        a, b, ac, bc = O.explicit_rmhmc_leapfrog_generic(th, pm, t, n, eps, omega, alpha)
+        np.testing.assert_allclose(a[0], g[f"{key}_lf_theta"][n - 1], rtol=tol, atol=tol)
+        np.testing.assert_allclose(b[0], g[f"{key}_lf_p"][n - 1], rtol=tol, atol=tol)
+    np.testing.assert_allclose(ac[0], g[f"{key}_lf_thetac"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(bc[0], g[f"{key}_lf_pc"], rtol=tol, atol=tol)
+
+
+def test_funnel_explicit_leapfrog_with_recorded_jitter(golden):
+    """The notebook's funnel (repeated Hessian eigenvalue) with jitter: every one of the 8 gradient calls of a step
+    draws its own torch.rand(D) (S:115); replayed in call order."""
+    g = golden("funnel")
+    D, alpha, omega, eps, steps, jitter = g["jit_cfg"]
+    t = _funnel(g, int(D), scaled=False)
+    draws = g["jit_draws"]
+    th, pm = g["jit_theta0"][None], g["jit_p0"][None]
+    for n in range(1, int(steps) + 1):
+        a, b, _, _ = O.explicit_rmhmc_leapfrog_generic(th, pm, t, n, eps, omega, alpha, jitter, lambda k: draws[k][None])
+        np.testing.assert_allclose(a[0], g["jit_lf_theta"][n - 1], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(b[0], g["jit_lf_p"][n - 1], rtol=1e-6, atol=1e-6)
+
+
+def test_funnel_sample_end_to_end(golden):
+    """sample(RMHMC, EXPLICIT) on the scaled funnel with the reference's momenta / uniforms replayed (one of its
+    trajectories diverges to log p = -inf: the LogProbError rejection path, S:1045-1057)."""
+    g = golden("funnel")
+    t = _funnel(g, 4)
+    draws = O.ReplayDraws(g["e2e_momenta"], g["e2e_uniforms"], dtype=np.float64)
+    with np.errstate(all="ignore"):
+        ret, info = O.sample_rmhmc_explicit(t, np.array([[0.2, -0.3, 0.4, 0.1]]), 10, 4, 0.1, 10.0, 1e6, burn=1, draws=draws)
+    ref = g["e2e_samples"]
+    assert len(ret) == ref.shape[0]
+    np.testing.assert_allclose(np.concatenate(ret), ref, rtol=1e-6, atol=1e-6)
+    assert abs(info["acc_rate"][0] - float(g["e2e_acc"])) < 1e-9
