@@ -191,12 +191,12 @@ def predict_model(model, samples, x=None, y=None, test_loader=None, model_loss='
 
 
 # ---- native engines (filled in by mlp.py once the kernel library exports them) -------------------
-def native_split_engine(log_prob_list, theta0):
+def native_split_engine(log_prob_list, theta0, integrator=None):
     try:
         from . import mlp
     except ImportError:
         return None
-    return mlp.split_engine(log_prob_list, theta0)
+    return mlp.split_engine(log_prob_list, theta0, integrator)
 
 
 def native_hmc_engine(log_prob_func, theta0):

@@ -17,7 +17,26 @@ template <typename T> struct MlpArgs {
   T* samples; int32_t* reject_count; T* H_old; T* H_new; uint8_t* accept;
   T* grad_out; T* logp_out;   // evaluation-only mode (n_traj == 0): d log p_m / d theta [C, D] and log p_m [C] of split `eval_split`
   int eval_split;
+  int integ;                  // HTA_SPLIT_SYMMETRIC (plain leapfrog when M == 1) / HTA_SPLIT_RAND / HTA_SPLIT_KMID
 };
+
+// Stage st of a trajectory: which split's gradient, the kick it scales and the drift that follows it.
+//   symmetric (S:499-540): per step m = 0..M-1, M-1..0, half kicks, drift eps / (2 (M-1)) except at the two turning points;
+//     M == 1: plain leapfrog (S:281-302), stage 0 kicks eps/2, stages 1..L kick eps (the last half kick is taken back after);
+//   RAND (S:547-566): per step, for each subset in the trajectory's random order: half kick, drift eps / M, half kick;
+//   KMID (S:572-596): per step M half kicks, ONE drift of eps, M half kicks in reverse order.
+template <typename T>
+__device__ __forceinline__ void split_stage(int integ, int M, int L, int st, T eps, const int* perm, int& m, T& kick, T& dr) {
+  const T heps = (T)0.5 * eps;
+  if (integ == HTA_SPLIT_SYMMETRIC && M == 1) { m = 0; kick = (st == 0) ? heps : eps; dr = (st < L) ? eps : (T)0; return; }
+  const int s2 = st % (2 * M);
+  kick = heps;
+  if (integ == HTA_SPLIT_RAND) { m = perm[s2 >> 1]; dr = (s2 & 1) ? (T)0 : eps / (T)M; return; }
+  m = (s2 < M) ? s2 : 2 * M - 1 - s2;
+  if (integ == HTA_SPLIT_KMID) dr = (s2 == M - 1) ? eps : (T)0;
+  else dr = (s2 == M - 1 || s2 == 2 * M - 1) ? (T)0 : eps / (T)((M - 1) * 2);
+}
+__host__ __device__ inline int split_stage_count(int integ, int M, int L) { return (integ == HTA_SPLIT_SYMMETRIC && M == 1) ? L + 1 : L * 2 * M; }
 
 extern int g_mlp_valu;                                        // tuning key "mlp_valu": 1 = never take the MFMA kernel
 bool mlp_mfma_eligible(const MlpArgs<float>& a);

@@ -84,7 +84,7 @@ struct MlpChain {
   struct Rec { P2 w1[NP]; T b1; T w2; T b2; };
   const MlpArgs<T>& a;
   CPtr Xc;
-  T* Ys; T* cm; T* dv; T* red; T* w2s; T* gp; T* Xs;
+  T* Ys; T* cm; T* dv; T* red; T* w2s; T* gp; T* Xs; int* perm;
   int nbch, ldc, Hp, j, slice, PS, UGL, tid;
   bool unit;      // j < H and the wave has a slice
 #if HTA_TIMING
@@ -325,6 +325,7 @@ __global__ __launch_bounds__(NT, 4) void mlp1_hmc_kernel(MlpArgs<T> a, int nbch,
 #endif
   ch.dv = ch.Ys + a.N;
   ch.red = ch.dv + nbch;
+  ch.perm = reinterpret_cast<int*>(ch.red + 2 * (NT / 64) + 8);
   for (int e = tid; e < Hp; e += NT) ch.w2s[e] = (T)0;                    // W2 padding stays 0 for good; pass 1 rewrites the h padding
   for (int e = tid; e < a.N; e += NT) ch.Ys[e] = a.Y[e];
   const int j = (ch.j < H) ? ch.j : 0;     // lanes without a unit shadow unit 0 (their b2 replica must stay exact for the row sums)
@@ -390,26 +391,23 @@ __global__ __launch_bounds__(NT, 4) void mlp1_hmc_kernel(MlpArgs<T> a, int nbch,
       }
       const T h_old = -lp_cur + ch.kinetic(p, im);                        // S:971
       Rec q = cur, g;
-      // One stage loop for both integrators (a single gradient call site keeps the kernel's register budget):
-      //   plain leapfrog (M == 1, S:281-302): stage 0 kicks eps/2, stages 1..L kick eps, drifts of eps in between,
-      //     and the final half kick is taken back afterwards, in the reference's order;
-      //   symmetric split (S:499-540): per step 2M stages m = 0..M-1, M-1..0, each a half kick, with a drift of
-      //     eps / (2 (M-1)) after every stage except the two turning points.
-      const T dq = (M > 1) ? eps / (T)((M - 1) * 2) : (T)0;
-      const int nstage = (M == 1) ? a.L + 1 : a.L * 2 * M;
+      // One stage loop for every integrator (a single gradient call site keeps the kernel's register budget);
+      // the stage table is split_stage() in mlp.hpp.
+      const int nstage = split_stage_count(a.integ, M, a.L);
+      if (a.integ == HTA_SPLIT_RAND) {                                    // S:549: one subset order per trajectory
+        __syncthreads();
+        if (tid == 0) split_permutation(a.seed, (uint32_t)n, M, ch.perm);
+        __syncthreads();
+      }
       for (int st = 0; st < nstage; ++st) {
-        int lo; T kick, dr;
-        if (M == 1) { lo = 0; kick = (st == 0) ? heps : eps; dr = (st < a.L) ? eps : (T)0; }
-        else {
-          const int s2 = st % (2 * M);
-          const int m = (s2 < M) ? s2 : 2 * M - 1 - s2;
-          lo = m * a.Nb; kick = heps; dr = (s2 == M - 1 || s2 == 2 * M - 1) ? (T)0 : dq;
-        }
+        int m; T kick, dr;
+        split_stage<T>(a.integ, M, a.L, st, eps, ch.perm, m, kick, dr);
+        const int lo = m * a.Nb;
         ch.grad_range(q, lo, lo + a.Nb, g);
         Ch::axpy(p, kick, g);
         if (dr != (T)0) Ch::drift(q, dr, im, p);
       }
-      if (M == 1) Ch::axpy(p, -heps, g);                                  // S:302
+      if (M == 1 && a.integ == HTA_SPLIT_SYMMETRIC) Ch::axpy(p, -heps, g);                                  // S:302
       const T lp_new = ch.logp_total(q);                                  // S:995
       const T h_new = -lp_new + ch.kinetic(p, im);
       const T u = u23<T>(philox_block(a.seed, chain, (uint32_t)n, PURPOSE_MH, 0, 0).x);
@@ -462,7 +460,7 @@ template <typename T, int INMAX, int NT, int ACT, bool EXACT> int launch_mlp_act
   while (ldc % 32 != 16) ldc += 4;                     // 4 consecutive rows land on distinct bank quarters
   typedef MlpChain<T, INMAX, NT, ACT, EXACT> Ch;
   const size_t recs = (size_t)NT * Ch::GS;             // slice-exchange / momentum-draw records, aliasing the chunk matrix
-  const size_t fixed = ((size_t)Hp + a.N + (HTA_XLDS ? (size_t)a.N * INMAX : 0) + 2 * (NT / 64) + 8) * sizeof(T);
+  const size_t fixed = ((size_t)Hp + a.N + (HTA_XLDS ? (size_t)a.N * INMAX : 0) + 2 * (NT / 64) + 8 + 64) * sizeof(T);        // ... + 64 ints: subset order
   const size_t cap = 150 * 1024;
   HTA_REQUIRE(fixed + (recs + 4) * sizeof(T) <= cap && fixed + (size_t)4 * (ldc + 1) * sizeof(T) <= cap,
               "hta_mlp_hmc: data set (N=%d) / hidden layer (H=%d) do not fit the LDS staging", a.N, a.H);
@@ -513,6 +511,9 @@ template <typename T> int mlp_hmc(const MlpArgs<T>& a, hipStream_t s) {
   HTA_REQUIRE(a.mass_kind == HTA_MASS_NONE || (a.mass_kind == HTA_MASS_DIAG && a.inv_mass && a.mass_factor),
               "hta_mlp_hmc: only identity / diagonal inv_mass are supported natively");
   if (a.n_traj > 0) HTA_REQUIRE(a.theta_init && a.L >= 0, "hta_mlp_hmc: bad trajectory arguments");
+  HTA_REQUIRE(a.integ >= HTA_SPLIT_SYMMETRIC && a.integ <= HTA_SPLIT_KMID, "hta_mlp_hmc: unknown integrator %d", a.integ);
+  HTA_REQUIRE(a.integ != HTA_SPLIT_RAND || a.M <= 64, "hta_mlp_hmc: SPLITTING_RAND supports at most 64 subsets natively (M=%d)", a.M);
+  HTA_REQUIRE(a.integ != HTA_SPLIT_KMID || a.M >= 2, "hta_mlp_hmc: SPLITTING_KMID needs at least 2 subsets");
   if constexpr (sizeof(T) == 4) {
     if (!g_mlp_valu && mlp_mfma_eligible(a)) return mlp_mfma(a, s);
   }
@@ -532,13 +533,15 @@ extern "C" {
 #define HTA_DEFINE_MLP(SUF, T)                                                                                    \
   int hta_mlp_hmc_sample_##SUF(T* theta, const T* theta_init, int64_t C, int n_in, int H, int act, const T* X,     \
                                const T* Y, int N, int M, int Nb, const T* tau4, T tau_out, T prior_scale,           \
-                               int mass_kind, const T* inv_mass, const T* mass_factor, int L, T eps, int n_traj,    \
-                               int traj_offset, int burn, uint64_t seed, uint64_t chain_offset, T* samples,         \
+                               int mass_kind, const T* inv_mass, const T* mass_factor, int integrator, int L,      \
+                               T eps, int n_traj, int traj_offset, int burn, uint64_t seed, uint64_t chain_offset, \
+                               T* samples,                                                                          \
                                int32_t* reject_count, T* H_old, T* H_new, uint8_t* accept, void* stream) {          \
     if (!tau4) { hta::set_error("hta_mlp_hmc_sample: tau4 is NULL (host pointer to 4 precisions)"); return HTA_ERR_INVALID; } \
     hta::MlpArgs<T> a{theta, theta_init, C, n_in, H, act, X, Y, N, M, Nb, {tau4[0], tau4[1], tau4[2], tau4[3]},     \
                       tau_out, prior_scale, mass_kind, inv_mass, mass_factor, L, eps, n_traj, traj_offset, burn,    \
-                      seed, chain_offset, samples, reject_count, H_old, H_new, accept, nullptr, nullptr, 0};        \
+                      seed, chain_offset, samples, reject_count, H_old, H_new, accept, nullptr, nullptr, 0,         \
+                      integrator};                                                                                  \
     if (n_traj <= 0) return HTA_OK;                                                                                 \
     return hta::mlp_hmc<T>(a, (hipStream_t)stream);                                                                 \
   }                                                                                                                 \
@@ -549,7 +552,7 @@ extern "C" {
     hta::MlpArgs<T> a{const_cast<T*>(theta), nullptr, C, n_in, H, act, X, Y, N, M, Nb,                              \
                       {tau4[0], tau4[1], tau4[2], tau4[3]}, tau_out, prior_scale, HTA_MASS_NONE, nullptr, nullptr,  \
                       0, (T)0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, grad_out, logp_out,      \
-                      split};                                                                                       \
+                      split, HTA_SPLIT_SYMMETRIC};                                                                  \
     return hta::mlp_hmc<T>(a, (hipStream_t)stream);                                                                 \
   }
 HTA_DEFINE_MLP(f32, float)

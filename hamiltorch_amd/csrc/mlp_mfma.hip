@@ -272,6 +272,7 @@ __global__ __launch_bounds__(NTMAX, 4) void mlp_mfma_kernel(MlpArgs<float> a, in
   float* ones = ch.red + 16;
   ch.ones = ones;
   ch.dump = ones + (size_t)CP * INP + (size_t)ch.t * (64 + 16 * NPT);   // [NU][64 + 16 NPT] scratch behind the ones
+  int* perm = reinterpret_cast<int*>(ones + (size_t)CP * INP + (size_t)NU * (64 + 16 * NPT));   // 64 ints: subset order
   for (int e = tid; e < CP * INP; e += ch.nthr) ones[e] = 1.0f;
   for (int e = tid; e < (a.N + CP) * INP; e += ch.nthr) {
     const int i = e / INP, k = e - i * INP;
@@ -355,26 +356,22 @@ __global__ __launch_bounds__(NTMAX, 4) void mlp_mfma_kernel(MlpArgs<float> a, in
       p.b2 = mf.b2 * normal_elem<float>(a.seed, chain, (uint32_t)n, 0, o_b2);
       const float h_old = -lp_cur + ch.kinetic(p, im);                    // S:971
       Rec q = cur, gr;
-      // one stage loop for both integrators, as in mlp_hmc.hip:
-      //   plain leapfrog (M == 1, S:281-302): stage 0 kicks eps/2, stages 1..L kick eps, drifts of eps in between,
-      //     and the final half kick is taken back afterwards, in the reference's order;
-      //   symmetric split (S:499-540): per step 2M stages m = 0..M-1, M-1..0, each a half kick, with a drift of
-      //     eps / (2 (M-1)) after every stage except the two turning points.
-      const float dq = (M > 1) ? eps / (float)((M - 1) * 2) : 0.0f;
-      const int nstage = (M == 1) ? a.L + 1 : a.L * 2 * M;
+      // one stage loop for every integrator; the stage table is split_stage() in mlp.hpp
+      const int nstage = split_stage_count(a.integ, M, a.L);
+      if (a.integ == HTA_SPLIT_RAND) {                                    // S:549: one subset order per trajectory
+        __syncthreads();
+        if (tid == 0) split_permutation(a.seed, (uint32_t)n, M, perm);
+        __syncthreads();
+      }
       for (int st = 0; st < nstage; ++st) {
-        int lo; float kick, dr;
-        if (M == 1) { lo = 0; kick = (st == 0) ? heps : eps; dr = (st < a.L) ? eps : 0.0f; }
-        else {
-          const int s2 = st % (2 * M);
-          const int m = (s2 < M) ? s2 : 2 * M - 1 - s2;
-          lo = m * a.Nb; kick = heps; dr = (s2 == M - 1 || s2 == 2 * M - 1) ? 0.0f : dq;
-        }
+        int m; float kick, dr;
+        split_stage<float>(a.integ, M, a.L, st, eps, perm, m, kick, dr);
+        const int lo = m * a.Nb;
         ch.grad_range(q, lo, lo + a.Nb, gr);
         Ch::axpy(p, kick, gr);
         if (dr != 0.0f) Ch::drift(q, dr, im, p);
       }
-      if (M == 1) Ch::axpy(p, -heps, gr);                                 // S:302
+      if (M == 1 && a.integ == HTA_SPLIT_SYMMETRIC) Ch::axpy(p, -heps, gr);                                 // S:302
       const float lp_new = ch.logp_total(q);                              // S:995
       const float h_new = -lp_new + ch.kinetic(p, im);
       const float u = u23<float>(philox_block(a.seed, chain, (uint32_t)n, PURPOSE_MH, 0, 0).x);
@@ -409,7 +406,7 @@ static int mfma_npt(const MlpArgs<float>& a) { const int n = (a.Nb + 15) / 16; r
 static size_t mfma_lds_bytes(const MlpArgs<float>& a, int NK, int NU, int* npad_out) {
   const int INP = 4 * NK, CP = 16 * mfma_npt(a), Npad = (a.N + CP + 3) / 4 * 4;
   if (npad_out) *npad_out = Npad;
-  return ((size_t)(a.N + CP) * INP + Npad + (size_t)NU * CP + CP + 16 + (size_t)CP * INP + (size_t)NU * (64 + CP) + 4) * sizeof(float);
+  return ((size_t)(a.N + CP) * INP + Npad + (size_t)NU * CP + CP + 16 + (size_t)CP * INP + (size_t)NU * (64 + CP) + 64 + 4) * sizeof(float);
 }
 
 bool mlp_mfma_eligible(const MlpArgs<float>& a) {

@@ -12,7 +12,7 @@
 
 namespace hta {
 
-enum : uint32_t { PURPOSE_MOMENTUM = 0, PURPOSE_MH = 1, PURPOSE_JITTER = 2, PURPOSE_INIT = 3 };
+enum : uint32_t { PURPOSE_MOMENTUM = 0, PURPOSE_MH = 1, PURPOSE_JITTER = 2, PURPOSE_INIT = 3, PURPOSE_PERM = 4 };
 
 struct U4 { uint32_t x, y, z, w; };
 
@@ -77,6 +77,19 @@ __device__ __forceinline__ T uniform_elem(uint64_t seed, uint64_t chain, uint32_
   const U4 r = philox_block(seed, chain, draw, purpose, sub, (uint32_t)(j >> 2));
   const uint32_t v = (j & 2) ? ((j & 1) ? r.w : r.z) : ((j & 1) ? r.y : r.x);
   return u23<T>(v);
+}
+
+// The subset order of Integrator.SPLITTING_RAND (torch.randperm(M) once per trajectory, samplers.py:549): a
+// Fisher-Yates shuffle on integer draws, one order per (seed, trajectory) shared by every chain of the batch
+// (chain key 0xFFFFFFFF).  Same integers in hamiltorch_amd/util.py and oracle/hmc_oracle.py.
+__device__ inline void split_permutation(uint64_t seed, uint32_t draw, int M, int* perm) {
+  for (int i = 0; i < M; ++i) perm[i] = i;
+  for (int i = M - 1; i >= 1; --i) {
+    const U4 r = philox_block(seed, 0xFFFFFFFFull, draw, PURPOSE_PERM, 0, (uint32_t)(i >> 2));
+    const uint32_t v = (i & 2) ? ((i & 1) ? r.w : r.z) : ((i & 1) ? r.y : r.x);
+    const int j = (int)(((uint64_t)v * (uint64_t)(i + 1)) >> 32);
+    const int t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+  }
 }
 
 }  // namespace hta

@@ -30,12 +30,12 @@ def _common_spec(fns):
 class _MLPEngine:
     """Same engine shape as samplers._GaussianHMC (begin / advance / finish / run / run_nuts)."""
 
-    def __new__(cls, specs, fallback):
+    def __new__(cls, specs, fallback, integrator=0):
         from .samplers import _Engine
 
         class Impl(_Engine):
-            def __init__(self, specs, fallback):
-                self.specs, self.fallback = specs, fallback
+            def __init__(self, specs, fallback, integrator):
+                self.specs, self.fallback, self.integrator = specs, fallback, integrator
                 s0 = specs[0]
                 self.n_in, self.H = s0["dims"][0], s0["dims"][1]
                 self.act, self.tau, self.tau_out, self.prior_scale = s0["act"], s0["tau_list"], s0["tau_out"], s0["prior_scale"]
@@ -60,22 +60,27 @@ class _MLPEngine:
                     _abi.mlp_hmc_sample(self.cur, self.theta0, self.n_in, self.H, self.act, self.X, self.Y, self.M,
                                         self.Nb, self.tau, self.tau_out, self.prior_scale, self.kind, self.im, self.mf,
                                         L, eps, min(step, n0 + count - start), start, self.burn, self.seed, self.off,
-                                        self.samples, self.rejected, H_old, H_new)
+                                        self.samples, self.rejected, H_old, H_new, integrator=self.integrator)
                 if progress is not None:
                     progress.update(min(self.N, n0 + count) - 1)
 
             def finish(self):
                 return self._fb.finish() if self._fb is not None else super().finish()
 
-        return Impl(specs, fallback)
+        return Impl(specs, fallback, integrator)
 
 
-def split_engine(log_prob_list, theta0):
-    specs = _common_spec(log_prob_list)
-    if specs is None or len(specs) < 2:
-        return None
+def split_engine(log_prob_list, theta0, integrator=None):
+    """integrator: an Integrator split kind (default SPLITTING)."""
+    from .enums import Integrator
     from .samplers import _GenericHMC
-    return _MLPEngine(specs, lambda: _GenericHMC(log_prob_list, split=True))
+    integrator = Integrator.SPLITTING if integrator is None else integrator
+    kind = {Integrator.SPLITTING: _abi.SPLIT_SYMMETRIC, Integrator.SPLITTING_RAND: _abi.SPLIT_RAND,
+            Integrator.SPLITTING_KMID: _abi.SPLIT_KMID}[integrator]
+    specs = _common_spec(log_prob_list)
+    if specs is None or (len(specs) < 2 and kind != _abi.SPLIT_RAND) or len(specs) > 64:
+        return None
+    return _MLPEngine(specs, lambda: _GenericHMC(log_prob_list, split=True, integrator=integrator), kind)
 
 
 def hmc_engine(log_prob_func, theta0):

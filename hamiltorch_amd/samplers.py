@@ -270,13 +270,13 @@ def leapfrog(params, momentum, log_prob_func, steps=10, step_size=0.1, jitter=0.
             raise RuntimeError('For splitting log_prob_func must be list of functions')      # S:466-467
         if pass_grad is not None:
             raise RuntimeError('Passing user-determined gradients not implemented for splitting')  # S:468-469
-        if integrator != Integrator.SPLITTING:
-            raise NotImplementedError("SPLITTING_RAND / SPLITTING_KMID are outside the accelerated path")
         cbs = [_BatchedCallback(f) for f in log_prob_func]
         kind, im, _ = _mass_operands(inv_mass, theta)
+        # S:549: one subset order per leapfrog call
+        perm = util.split_permutation(util.next_stream_seed(), 0, len(cbs)) if integrator == Integrator.SPLITTING_RAND else None
         ret_t, ret_p = [], []
         for _ in range(steps):
-            _split_step(theta, p, cbs, step_size, kind, im)
+            _split_step(theta, p, cbs, step_size, kind, im, integrator, perm)
             ret_t.append(unb(theta.clone())); ret_p.append(unb(p.clone()))
         return ret_t, ret_p
 
@@ -289,11 +289,30 @@ def leapfrog(params, momentum, log_prob_func, steps=10, step_size=0.1, jitter=0.
     raise NotImplementedError("implicit RMHMC / S3 integrators are outside the accelerated path")
 
 
-def _split_step(theta, p, cbs, eps, kind, im):
-    """One symmetric split step (S:499-540): 2M half-kicks, 2(M-1) drifts of eps / (2(M-1))."""
+def _split_step(theta, p, cbs, eps, kind, im, integrator=Integrator.SPLITTING, perm=None):
+    """One step of a split integrator on (theta, p), in place.
+    SPLITTING (S:499-540): 2M half-kicks m = 0..M-1, M-1..0 with 2(M-1) drifts of eps / (2(M-1));
+    SPLITTING_RAND (S:547-566): for each subset in the order `perm`: half kick, drift eps / M, half kick;
+    SPLITTING_KMID (S:572-596): M half kicks, one drift of eps, M half kicks in reverse order."""
     M = len(cbs)
+    if integrator == Integrator.SPLITTING_RAND:
+        for m in range(M):
+            cb = cbs[perm[m]]
+            g, _ = cb.grad(theta)
+            _abi.kick_drift(theta, p, g, 0.5 * eps, eps / M, kind, im)
+            g, _ = cb.grad(theta)
+            _abi.kick_drift(theta, p, g, 0.5 * eps, 0.0, kind, im)
+        return
     if M == 1:
         raise RuntimeError('For symmetric splitting log_prob_func must be list of functions greater than length 1')
+    if integrator == Integrator.SPLITTING_KMID:
+        for m in range(M):
+            g, _ = cbs[m].grad(theta)
+            _abi.kick_drift(theta, p, g, 0.5 * eps, eps if m == M - 1 else 0.0, kind, im)
+        for m in reversed(range(M)):
+            g, _ = cbs[m].grad(theta)
+            _abi.kick_drift(theta, p, g, 0.5 * eps, 0.0, kind, im)
+        return
     dq = eps / ((M - 1) * 2)
     for m in range(M):
         g, _ = cbs[m].grad(theta)
@@ -340,12 +359,12 @@ def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, 
                     raise RuntimeError('For splitting log_prob_func must be list of functions')
                 if pass_grad is not None:
                     raise RuntimeError('Passing user-determined gradients not implemented for splitting')
-                if integrator != Integrator.SPLITTING:
-                    raise NotImplementedError("SPLITTING_RAND / SPLITTING_KMID are outside the accelerated path")
+                if integrator == Integrator.SPLITTING_KMID and len(log_prob_func) == 1:
+                    raise RuntimeError('For symmetric splitting log_prob_func must be list of functions greater than length 1')
                 if isinstance(inv_mass, list):
                     raise NotImplementedError("block-list inv_mass performs no drift in the reference's split "
                                               "integrator (S:514-515); not supported")
-                eng = _resolve_split_engine(log_prob_func, theta0, native)
+                eng = _resolve_split_engine(log_prob_func, theta0, native, integrator)
             else:
                 tgt = as_gaussian(log_prob_func, theta0) if (native and pass_grad is None) else None
                 eng = _GaussianHMC(tgt) if tgt is not None else None
@@ -500,8 +519,8 @@ class _GenericHMC(_Engine):
     """Generic-callback path (plain HMC, S:267-304) -- also the SPLITTING integrator when given a
     list of callbacks (S:494-547)."""
 
-    def __init__(self, fn, pass_grad=None, split=False):
-        self.split = split
+    def __init__(self, fn, pass_grad=None, split=False, integrator=Integrator.SPLITTING):
+        self.split, self.integrator = split, integrator
         self.cbs = [_BatchedCallback(f) for f in fn] if split else [_BatchedCallback(fn, pass_grad)]
 
     def _logp(self, theta):
@@ -530,8 +549,9 @@ class _GenericHMC(_Engine):
             _abi.hamiltonian(p, self._logp(cur), kind, im, Ho)                             # S:971
             prop.copy_(cur)
             if self.split:
+                perm = util.split_permutation(self.seed, n, len(self.cbs)) if self.integrator == Integrator.SPLITTING_RAND else None
                 for _ in range(L):
-                    _split_step(prop, p, self.cbs, eps, kind, im)                          # S:499-540
+                    _split_step(prop, p, self.cbs, eps, kind, im, self.integrator, perm)   # S:499-596
                 logp1 = self._logp(prop)
             else:
                 g, logp1 = cb.grad(prop)
@@ -547,10 +567,10 @@ class _GenericHMC(_Engine):
                            self.off)                                                       # S:1000-1026
 
 
-def _resolve_split_engine(log_prob_list, theta0, native):
+def _resolve_split_engine(log_prob_list, theta0, native, integrator=Integrator.SPLITTING):
     from . import bnn
-    eng = bnn.native_split_engine(log_prob_list, theta0) if native else None
-    return eng if eng is not None else _GenericHMC(log_prob_list, split=True)
+    eng = bnn.native_split_engine(log_prob_list, theta0, integrator) if native else None
+    return eng if eng is not None else _GenericHMC(log_prob_list, split=True, integrator=integrator)
 
 
 # =================================================================================================

@@ -146,3 +146,28 @@ def multi_chain(chain, num_workers, seeds, parallel=False, batched=False):
         with concurrent.futures.ThreadPoolExecutor(max_workers=num_workers) as ex:
             return list(ex.map(chain, seeds))
     return [chain(s) for s in seeds]
+
+
+# ---- subset order of Integrator.SPLITTING_RAND -----------------------------------------------------------
+def _philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 on Python ints: the same function as csrc/philox.hpp (host copy for host-side control flow)."""
+    M32 = 0xFFFFFFFF
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & M32, p1 & M32, ((p0 >> 32) ^ c3 ^ k1) & M32, p0 & M32
+        k0, k1 = (k0 + 0x9E3779B9) & M32, (k1 + 0xBB67AE85) & M32
+    return c0, c1, c2, c3
+
+
+def split_permutation(seed, draw, M):
+    """The order in which SPLITTING_RAND visits the M subsets during trajectory `draw` (the reference takes
+    torch.randperm(M) once per leapfrog call, S:549).  Fisher-Yates on integer Philox draws keyed (seed, draw),
+    purpose 4, chain key 0xFFFFFFFF: one order per trajectory for the whole batch; identical in
+    csrc/philox.hpp:split_permutation (native kernels) and oracle/hmc_oracle.py."""
+    perm = list(range(M))
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    for i in range(M - 1, 0, -1):
+        r = _philox4x32_10(i >> 2, int(draw) & 0xFFFFFFFF, 0xFFFFFFFF, 4, seed & 0xFFFFFFFF, seed >> 32)
+        j = (r[i & 3] * (i + 1)) >> 32
+        perm[i], perm[j] = perm[j], perm[i]
+    return perm

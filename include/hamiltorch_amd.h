@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HTA_ABI_VERSION 1
+#define HTA_ABI_VERSION 2
 
 #define HTA_OK 0
 #define HTA_ERR_INVALID (-1)   /* bad argument                           */
@@ -232,19 +232,25 @@ int hta_rmhmc_gaussian_sample_f64(double* theta, const double* theta_init, const
  *   tau4: HOST pointer to the 4 prior precisions (W1, b1, W2, b2); prior_scale divides the prior of
  *   every split closure (S:1199): num_splits for sample_split_model, 1 for sample_model.
  *   mass_kind: HTA_MASS_NONE or HTA_MASS_DIAG (flat [D] operands).
+ *   integrator: HTA_SPLIT_SYMMETRIC = Integrator.SPLITTING (S:499-540), HTA_SPLIT_RAND = SPLITTING_RAND
+ *   (S:547-566; the subset order is a Philox permutation per (seed, trajectory), M <= 64),
+ *   HTA_SPLIT_KMID = SPLITTING_KMID (S:572-596, M >= 2).
  * Remaining arguments as hta_hmc_gaussian_sample. */
+#define HTA_SPLIT_SYMMETRIC 0
+#define HTA_SPLIT_RAND 1
+#define HTA_SPLIT_KMID 2
 int hta_mlp_hmc_sample_f32(float* theta, const float* theta_init, int64_t C, int n_in, int H, int act,
                            const float* X, const float* Y, int N, int M, int Nb, const float* tau4, float tau_out,
                            float prior_scale, int mass_kind, const float* inv_mass, const float* mass_factor,
-                           int L, float eps, int n_traj, int traj_offset, int burn, uint64_t seed,
+                           int integrator, int L, float eps, int n_traj, int traj_offset, int burn, uint64_t seed,
                            uint64_t chain_offset, float* samples, int32_t* reject_count, float* H_old,
                            float* H_new, uint8_t* accept, void* stream);
 int hta_mlp_hmc_sample_f64(double* theta, const double* theta_init, int64_t C, int n_in, int H, int act,
                            const double* X, const double* Y, int N, int M, int Nb, const double* tau4,
                            double tau_out, double prior_scale, int mass_kind, const double* inv_mass,
-                           const double* mass_factor, int L, double eps, int n_traj, int traj_offset, int burn,
-                           uint64_t seed, uint64_t chain_offset, double* samples, int32_t* reject_count,
-                           double* H_old, double* H_new, uint8_t* accept, void* stream);
+                           const double* mass_factor, int integrator, int L, double eps, int n_traj,
+                           int traj_offset, int burn, uint64_t seed, uint64_t chain_offset, double* samples,
+                           int32_t* reject_count, double* H_old, double* H_new, uint8_t* accept, void* stream);
 /* value and gradient of ONE split closure (S:1145-1199) for every chain: grad_out[C, D], logp_out[C]. */
 int hta_mlp_logp_grad_f32(const float* theta, int64_t C, int n_in, int H, int act, const float* X, const float* Y,
                           int N, int M, int Nb, int split, const float* tau4, float tau_out, float prior_scale,

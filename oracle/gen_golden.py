@@ -37,8 +37,8 @@ class Recorder:
     MH uniforms torch.rand(1) (S:1004)."""
 
     def __enter__(self):
-        self.momenta, self.uniforms, self.jitters = [], [], []
-        self._gibbs, self._rand = S.gibbs, torch.rand
+        self.momenta, self.uniforms, self.jitters, self.perms = [], [], [], []
+        self._gibbs, self._rand, self._randperm = S.gibbs, torch.rand, torch.randperm
 
         def gibbs(*a, **k):
             m = self._gibbs(*a, **k)
@@ -53,13 +53,20 @@ class Recorder:
                 self.jitters.append(npy(u).copy())
             return u
 
+        def randperm(*a, **k):                                   # SPLITTING_RAND's subset order (S:549)
+            r = self._randperm(*a, **k)
+            self.perms.append(npy(r).copy())
+            return r
+
         S.gibbs = gibbs
         torch.rand = rand
+        torch.randperm = randperm
         return self
 
     def __exit__(self, *exc):
         S.gibbs = self._gibbs
         torch.rand = self._rand
+        torch.randperm = self._randperm
 
 
 SIGMA3 = [[1.0, 0.6, 0.2], [0.6, 2.0, 0.5], [0.2, 0.5, 0.5]]
@@ -329,6 +336,51 @@ def gen_mlp():
     np.savez(os.path.join(OUT, "mlp.npz"), **out)
 
 
+def gen_splitkinds():
+    """Integrator.SPLITTING_RAND / SPLITTING_KMID (S:547-596) on the split closures of a small MLP: one leapfrog call
+    each (RAND: its torch.randperm recorded) and an end-to-end sample_split_model run with all draws recorded."""
+    out = {}
+    c = dict(dims=[3, 5, 1], act="relu", N=12, M=3, tau_out=10.0, eps=2e-3, L=2)
+    net = make_mlp(c["dims"], c["act"], 0)
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn(c["N"], c["dims"][0], generator=g)
+    Y = torch.sin(X.sum(1, keepdim=True)) + 0.1 * torch.randn(c["N"], 1, generator=g)
+    theta = hamiltorch.util.flatten(net).clone().detach()
+    D = theta.numel()
+    tau_list = torch.tensor([1.0 + 0.5 * k for k in range(4)])
+    pfl = [w.nelement() for w in net.parameters()]
+    psl = [w.shape for w in net.parameters()]
+    out["dims"] = np.array(c["dims"]); out["X"] = npy(X); out["Y"] = npy(Y); out["theta"] = npy(theta)
+    out["tau_list"] = npy(tau_list); out["cfg"] = np.array([c["M"], c["tau_out"], c["eps"], c["L"]])
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(X, Y), batch_size=c["N"] // c["M"], shuffle=False)
+    fl = S.define_split_model_log_prob(net, "regression", loader, c["M"], pfl, psl, tau_list, c["tau_out"], verbose=False)
+    gm = torch.Generator().manual_seed(2)
+    p0 = torch.randn(D, generator=gm)
+    out["p0"] = npy(p0)
+    inv_mass = torch.ones(D)
+    for kind, tag in ((hamiltorch.Integrator.SPLITTING_RAND, "rand"), (hamiltorch.Integrator.SPLITTING_KMID, "kmid")):
+        hamiltorch.set_random_seed(41)
+        with Recorder() as rec:
+            lp_, lm_ = S.leapfrog(theta.clone(), p0.clone(), fl, steps=3, step_size=c["eps"], inv_mass=inv_mass,
+                                  sampler=hamiltorch.Sampler.HMC, integrator=kind)
+        out[f"{tag}_lf_theta"] = np.stack([npy(t) for t in lp_]); out[f"{tag}_lf_p"] = np.stack([npy(t) for t in lm_])
+        if rec.perms:
+            out[f"{tag}_lf_perm"] = np.stack(rec.perms)
+        hamiltorch.set_random_seed(42)
+        with Recorder() as rec:
+            ret, acc = hamiltorch.sample_split_model(net, loader, theta.clone(), c["M"], model_loss="regression",
+                                                     num_samples=8, num_steps_per_sample=c["L"], step_size=c["eps"],
+                                                     burn=0, inv_mass=inv_mass, tau_out=c["tau_out"], tau_list=tau_list,
+                                                     integrator=kind, debug=2, verbose=False)
+        out[f"{tag}_e2e_samples"] = np.stack([npy(t) for t in ret])
+        out[f"{tag}_e2e_momenta"] = np.stack(rec.momenta)
+        out[f"{tag}_e2e_uniforms"] = np.concatenate(rec.uniforms)
+        out[f"{tag}_e2e_acc"] = np.array(acc)
+        if rec.perms:
+            out[f"{tag}_e2e_perms"] = np.stack(rec.perms)
+    np.savez(os.path.join(OUT, "splitkinds.npz"), **out)
+
+
 SCALES = [0.5, 1.0, 1.7, 2.4, 3.3]
 
 
@@ -411,5 +463,6 @@ if __name__ == "__main__":
     gen_mlp()
     gen_nuts()
     gen_funnel()
+    gen_splitkinds()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -203,3 +203,62 @@ def test_predict_model_on_device(ht):
     np.testing.assert_allclose([float(v.sum()) for v in lps], o.logp(th), rtol=1e-4, atol=1e-3)
     with pytest.raises(RuntimeError):
         ht.predict_model(net, samples)
+
+
+# ---- SPLITTING_RAND / SPLITTING_KMID --------------------------------------------------------
+@pytest.mark.parametrize("kind", ["rand", "kmid"])
+@pytest.mark.parametrize("route", ["mfma", "valu", "generic"])
+def test_split_kinds_sample_vs_oracle(ht, kind, route):
+    """sample_split_model with Integrator.SPLITTING_RAND / SPLITTING_KMID: the MFMA kernel, the VALU kernel and the
+    generic-callback route against the oracle; the subset order of RAND is the Philox permutation of (seed, trajectory)."""
+    from hamiltorch_amd import _abi
+    dims, act, N, M, tau_out, eps, L, C, NS, seed = [4, 33, 1], "tanh", 40, 4, 6.0, 4e-3, 3, 20, 7, 17
+    net, X, Y, loader, tau_list, otg = _split_setup(ht, dims, act, N, M, tau_out)
+    D = sum(p.numel() for p in net.parameters())
+    th0 = (0.3 * O.philox_normals(seed, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32)
+    integ = ht.Integrator.SPLITTING_RAND if kind == "rand" else ht.Integrator.SPLITTING_KMID
+    kw = dict(model_loss="regression", num_samples=NS, num_steps_per_sample=L, step_size=eps, burn=1,
+              inv_mass=torch.ones(D, device=dev()), tau_out=tau_out, tau_list=tau_list, integrator=integ, verbose=False, seed=seed)
+    _abi.set_tuning("mlp_valu", 1 if route == "valu" else 0)
+    try:
+        out = ht.sample_split_model(net, loader, torch.tensor(th0, device=dev()), M, native=(route != "generic"), **kw)
+    finally:
+        _abi.set_tuning("mlp_valu", 0)
+    ref, _ = O.sample_hmc(None, th0, NS, L, eps, 1, np.ones(D, np.float32), O.PhiloxDraws(seed, np.arange(C)),
+                          grad_fns=[t.grad for t in otg], logp_fns=[t.logp for t in otg], split_kind=kind)
+    _cmp(out, ref, 5e-4)
+
+
+@pytest.mark.parametrize("kind", ["rand", "kmid"])
+def test_split_kinds_leapfrog_api_vs_reference_fixture(ht, golden, kind):
+    """samplers.leapfrog(integrator=SPLITTING_KMID) reproduces the reference's 3-step path; for SPLITTING_RAND the
+    order is our own Philox permutation, so the path is checked against the oracle run with that order."""
+    g = golden("splitkinds")
+    M, tau_out, eps, L = g["cfg"]; M = int(M)
+    net = make_net(list(g["dims"]), "relu")
+    with torch.no_grad():
+        torch.nn.utils.vector_to_parameters(torch.tensor(g["theta"], device=dev()), net.parameters())
+    X, Y = torch.tensor(g["X"]), torch.tensor(g["Y"])
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(X, Y), batch_size=X.shape[0] // M, shuffle=False)
+    from hamiltorch_amd import bnn, util
+    sizes = [w.nelement() for w in net.parameters()]; shapes = [w.shape for w in net.parameters()]
+    fl = bnn.define_split_model_log_prob(net, "regression", loader, M, sizes, shapes, torch.tensor(g["tau_list"]), float(tau_out),
+                                         device=dev(), verbose=False)
+    th, p0 = torch.tensor(g["theta"], device=dev()), torch.tensor(g["p0"], device=dev())
+    integ = ht.Integrator.SPLITTING_RAND if kind == "rand" else ht.Integrator.SPLITTING_KMID
+    util.set_random_seed(5)
+    lp_, lm_ = ht.samplers.leapfrog(th, p0, fl, steps=3, step_size=float(eps), inv_mass=torch.ones_like(th),
+                                    sampler=ht.Sampler.HMC, integrator=integ)
+    got_t, got_p = torch.stack(lp_).cpu().numpy(), torch.stack(lm_).cpu().numpy()
+    if kind == "kmid":
+        np.testing.assert_allclose(got_t, g["kmid_lf_theta"], rtol=3e-5, atol=3e-5)
+        np.testing.assert_allclose(got_p, g["kmid_lf_p"], rtol=3e-4, atol=3e-4)
+    else:
+        nb = X.shape[0] // M
+        otg = [O.MLPRegressionTarget(list(g["dims"]), g["X"][m * nb:(m + 1) * nb], g["Y"][m * nb:(m + 1) * nb], g["tau_list"],
+                                     float(tau_out), M, "relu") for m in range(M)]
+        util.set_random_seed(5)
+        perm = util.split_permutation(util.next_stream_seed(), 0, M)
+        a, b = O.split_leapfrog(g["theta"][None], g["p0"][None], [t.grad for t in otg], 3, float(eps), np.ones_like(g["theta"]), "rand", perm)
+        np.testing.assert_allclose(got_t[-1], a[0], rtol=3e-5, atol=3e-5)
+        np.testing.assert_allclose(got_p[-1], b[0], rtol=3e-4, atol=3e-4)

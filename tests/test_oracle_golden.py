@@ -315,3 +315,41 @@ def test_funnel_sample_end_to_end(golden):
     assert len(ret) == ref.shape[0]
     np.testing.assert_allclose(np.concatenate(ret), ref, rtol=1e-6, atol=1e-6)
     assert abs(info["acc_rate"][0] - float(g["e2e_acc"])) < 1e-9
+
+
+# ---- SPLITTING_RAND / SPLITTING_KMID: SURVEY 8f N3 --------------------------------------------------------
+def _split_targets(g):
+    M, tau_out, eps, L = g["cfg"]
+    M = int(M); nb = g["X"].shape[0] // M
+    return [O.MLPRegressionTarget(list(g["dims"]), g["X"][m * nb:(m + 1) * nb], g["Y"][m * nb:(m + 1) * nb], g["tau_list"],
+                                  tau_out, M, "relu") for m in range(M)], float(eps), int(L)
+
+
+@pytest.mark.parametrize("kind", ["rand", "kmid"])
+def test_split_kinds_leapfrog_and_sample(golden, kind):
+    """The two other data-split integrators of the reference (S:547-596): 3-step leapfrog paths and an end-to-end
+    sample_split_model run with the reference's own momenta, uniforms and (RAND) torch.randperm orders replayed."""
+    g = golden("splitkinds")
+    tg, eps, L = _split_targets(g)
+    grads = [t.grad for t in tg]; logps = [t.logp for t in tg]
+    th, p0 = g["theta"][None].astype(np.float32), g["p0"][None].astype(np.float32)
+    im = np.ones(th.shape[1], np.float32)
+    perm = [int(v) for v in g["rand_lf_perm"][0]] if kind == "rand" else None
+    for n in range(1, 4):
+        a, b = O.split_leapfrog(th, p0, grads, n, eps, im, kind, perm)
+        np.testing.assert_allclose(a[0], g[f"{kind}_lf_theta"][n - 1], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(b[0], g[f"{kind}_lf_p"][n - 1], rtol=2e-4, atol=2e-4)
+    draws = O.ReplayDraws(g[f"{kind}_e2e_momenta"], g[f"{kind}_e2e_uniforms"], perms=g["rand_e2e_perms"] if kind == "rand" else None)
+    ret, info = O.sample_hmc(None, th, 8, L, eps, 0, im, draws, grad_fns=grads, logp_fns=logps, split_kind=kind)
+    np.testing.assert_allclose(np.concatenate(ret), g[f"{kind}_e2e_samples"], rtol=2e-4, atol=2e-4)
+    assert abs(info["acc_rate"][0] - float(g[f"{kind}_e2e_acc"])) < 1e-9
+
+
+def test_philox_permutation_is_a_permutation_and_matches_host():
+    from hamiltorch_amd import util
+    for seed, draw, M in ((1, 0, 1), (1, 0, 2), (99, 7, 5), (2 ** 45 + 3, 11, 64)):
+        pm = O.philox_permutation(seed, draw, M)
+        assert sorted(pm) == list(range(M))
+        assert pm == util.split_permutation(seed, draw, M)
+    # not stuck on the identity
+    assert any(O.philox_permutation(5, n, 6) != list(range(6)) for n in range(4))
