@@ -163,7 +163,7 @@ def split_permutation(seed, draw, M):
     """The order in which SPLITTING_RAND visits the M subsets during trajectory `draw` (the reference takes
     torch.randperm(M) once per leapfrog call, S:549).  Fisher-Yates on integer Philox draws keyed (seed, draw),
     purpose 4, chain key 0xFFFFFFFF: one order per trajectory for the whole batch; identical in
-    csrc/philox.hpp:split_permutation (native kernels) and oracle/hmc_oracle.py."""
+    csrc/philox.hpp:split_permutation (native kernels); the CPU checker under oracle/ restates it."""
     perm = list(range(M))
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     for i in range(M - 1, 0, -1):
