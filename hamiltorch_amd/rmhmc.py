@@ -263,3 +263,107 @@ def _sample_explicit_generic(log_prob_func, theta0, N, L, eps, burn, jitter, alp
         prog.update(n)
     prog.end()
     return samples, rejected
+
+
+# ---- implicit RMHMC: the generalised leapfrog with fixed-point iterations (S:305-387) -------------------------
+def _implicit_subs(max_it):
+    """jitter sub-streams reserved per implicit step: max_it momentum iterations, 1 + max_it position
+    evaluations, 1 final kick.  A fixed layout (the reference draws from one global generator in call order):
+    a chain's draws then do not depend on how many iterations the other chains of the batch needed."""
+    return 2 * int(max_it) + 2
+
+
+def _implicit_steps(cv, kind, th, pm, steps, eps, alpha, jitter, seed, chain_offset, draw, thr, max_it, sub0=2, path=None):
+    """S:312-383 for a batch of chains, in place on (th, pm).  Chains leave a fixed-point loop individually once their
+    own max squared update is below `thr` (the reference's `break`); the loop ends when none is left or after max_it."""
+    if kind != _abi.METRIC_SOFTABS:
+        raise NotImplementedError("implicit RMHMC is implemented for Metric.SOFTABS")
+    C, D = th.shape
+    hs = 0.5 * eps
+    M = torch.empty(C, D, D, dtype=th.dtype, device=th.device)
+    x = torch.empty_like(th)
+
+    def dH_dtheta(theta, mvec, sub):                     # S:318-319 / S:368-369: -(g + c)
+        g, Hs = cv.grad_neg_hessian(theta)
+        _abi.metric_eval(theta, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, draw, sub, m=mvec, dmetric_out=M)
+        return -(g + cv.contract(theta, M))
+
+    def dH_dp(theta, mvec, sub):                         # S:346-347, S:352-353: G^-1 p
+        _, Hs = cv.grad_neg_hessian(theta)
+        _abi.metric_eval(theta, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, draw, sub, m=mvec, x_out=x)
+        return x.clone()
+
+    def fixed_point(state, update):
+        active = torch.ones(C, dtype=torch.bool, device=th.device)
+        for i in range(max_it):
+            new = update(i)
+            diff = ((state - new) ** 2).amax(dim=1)                       # S:336 / S:356
+            state.copy_(torch.where(active[:, None], new, state))
+            active &= ~(diff < thr) & torch.isfinite(diff)                # a diverged chain stops iterating: it is rejected later
+            if not bool(active.any()):
+                break
+
+    per = _implicit_subs(max_it)
+    for l in range(steps):
+        base = sub0 + l * per
+        p_old = pm.clone()
+        fixed_point(pm, lambda i: p_old - hs * dH_dtheta(th, pm, base + i))                       # S:313-340
+        th_old = th.clone()
+        g0 = dH_dp(th_old, pm, base + max_it)                                                     # S:344-348
+        fixed_point(th, lambda i: th_old + hs * dH_dp(th, pm, base + max_it + 1 + i) + hs * g0)   # S:349-361
+        pm.sub_(hs * dH_dtheta(th, pm, base + 2 * max_it + 1))                                    # S:368-383
+        if path is not None:
+            path[0][l].copy_(th); path[1][l].copy_(pm)
+
+
+def implicit_leapfrog(params, momentum, log_prob_func, steps, step_size, jitter, softabs_const, metric,
+                      fixed_point_threshold, fixed_point_max_iterations, seed=None, chain_offset=0, draw=0):
+    """leapfrog(sampler=RMHMC, integrator=IMPLICIT): (ret_params, ret_momenta), one entry per step."""
+    theta, one = _batch(params)
+    p, _ = _batch(momentum, "momentum")
+    theta, p = theta.clone(), p.clone()
+    _abi.require_device(theta, "params")
+    pt = torch.empty((steps,) + theta.shape, dtype=theta.dtype, device=theta.device)
+    pp = torch.empty_like(pt)
+    seed = util.next_stream_seed() if (seed is None and jitter is not None) else (seed or 0)
+    _implicit_steps(_Curvature(log_prob_func), _metric_kind(metric), theta, p, steps, step_size, softabs_const, jitter, seed,
+                    chain_offset, draw, fixed_point_threshold, fixed_point_max_iterations, path=(pt, pp))
+    unb = (lambda t: t[0]) if one else (lambda t: t)
+    return [unb(t) for t in pt.unbind(0)], [unb(t) for t in pp.unbind(0)]
+
+
+def sample_implicit(log_prob_func, theta0, N, L, eps, burn, jitter, alpha, metric, thr, max_it, seed, chain_offset, verbose):
+    """The RMHMC / IMPLICIT branch of sample() (S:969-1026): gibbs (sub-stream 0), H_old (1), L implicit steps
+    (2 ..), H_new (2 + L * (2 max_it + 2)), Metropolis select + bookkeeping in `hta_mh_select`."""
+    from .samplers import _num_rows
+    kind = _metric_kind(metric)
+    if alpha is None and kind == _abi.METRIC_SOFTABS:
+        raise TypeError("softabs_const must be set for Metric.SOFTABS")
+    C, D = theta0.shape
+    dt, dev = theta0.dtype, theta0.device
+    cv = _Curvature(log_prob_func)
+    S = _num_rows(N, burn)
+    samples = torch.empty((S, C, D), dtype=dt, device=dev)
+    samples[0].copy_(theta0)
+    cur = theta0.clone()
+    rejected = torch.zeros(C, dtype=torch.int32, device=dev)
+    H0 = torch.empty(C, dtype=dt, device=dev); H1 = torch.empty_like(H0)
+    pm = torch.empty_like(cur)
+    prog = util._Progress('Sampling (Sampler.RMHMC; Integrator.IMPLICIT)', N, verbose)
+    for n in range(N):
+        _, Hs = cv.grad_neg_hessian(cur)
+        _abi.metric_eval(cur, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, n, 0, p_out=pm)        # S:183-184
+        _abi.metric_eval(cur, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, n, 1, m=pm, H_out=H0)  # S:971
+        H0.sub_(cv.value(cur))
+        th = cur.clone()
+        _implicit_steps(cv, kind, th, pm, L, eps, alpha, jitter, seed, chain_offset, n, thr, max_it)
+        _, Hs1 = cv.grad_neg_hessian(th)
+        lp1 = cv.value(th)
+        _abi.metric_eval(th, C, D, kind, Hs1, D * D, alpha, jitter, seed, chain_offset, n, 2 + L * _implicit_subs(max_it),
+                         m=pm, H_out=H1)                                                                      # S:989
+        H1.sub_(lp1)
+        row = samples[n - burn] if n > burn else None
+        _abi.mh_select(cur, th, theta0, H0, H1, lp1, row, rejected, None, n, burn, seed, chain_offset)
+        prog.update(n)
+    prog.end()
+    return samples, rejected

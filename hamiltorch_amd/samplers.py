@@ -286,7 +286,13 @@ def leapfrog(params, momentum, log_prob_func, steps=10, step_size=0.1, jitter=0.
         from . import rmhmc
         return rmhmc.explicit_leapfrog(params, momentum, log_prob_func, steps, step_size, jitter, softabs_const,
                                        explicit_binding_const, metric)
-    raise NotImplementedError("implicit RMHMC / S3 integrators are outside the accelerated path")
+    if sampler == Sampler.RMHMC and integrator == Integrator.IMPLICIT:
+        if pass_grad is not None:
+            raise RuntimeError('Passing user-determined gradients not implemented for RMHMC')   # S:309-310
+        from . import rmhmc
+        return rmhmc.implicit_leapfrog(params, momentum, log_prob_func, steps, step_size, jitter, softabs_const, metric,
+                                       fixed_point_threshold, fixed_point_max_iterations)
+    raise NotImplementedError("Integrator.S3 (semi-separable Hamiltonians through a user ham_func) is outside the accelerated path")
 
 
 def _split_step(theta, p, cbs, eps, kind, im, integrator=Integrator.SPLITTING, perm=None):
@@ -388,9 +394,16 @@ def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, 
             samples, rejected = rmhmc.sample_explicit(log_prob_func, theta0, num_samples, num_steps_per_sample,
                                                       step_size, burn_k, jitter, softabs_const,
                                                       explicit_binding_const, metric, seed, chain_offset, verbose)
+        elif sampler == Sampler.RMHMC and integrator == Integrator.IMPLICIT:
+            if pass_grad is not None:
+                raise RuntimeError('Passing user-determined gradients not implemented for RMHMC')
+            from . import rmhmc
+            samples, rejected = rmhmc.sample_implicit(log_prob_func, theta0, num_samples, num_steps_per_sample, step_size,
+                                                      burn_k, jitter, softabs_const, metric, fixed_point_threshold,
+                                                      fixed_point_max_iterations, seed, chain_offset, verbose)
         elif sampler == Sampler.RMHMC:
-            raise NotImplementedError("implicit RMHMC / S3 are outside the accelerated path (fixed-point "
-                                      "iteration counts diverge per chain)")
+            raise NotImplementedError("Integrator.S3 (semi-separable Hamiltonians through a user ham_func) is outside "
+                                      "the accelerated path")
         else:
             raise NotImplementedError()
 

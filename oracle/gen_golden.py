@@ -448,6 +448,29 @@ def gen_funnel():
     out["e2e_momenta"] = np.stack(rec.momenta)
     out["e2e_uniforms"] = np.concatenate(rec.uniforms)
     out["e2e_acc"] = np.array(acc)
+    # implicit RMHMC (generalised leapfrog with fixed-point iterations, S:305-387) on the scaled funnel, jitter=None
+    for D, alpha, tag in ((4, 1e6, "imp_a1e6"), (5, 1.1, "imp_a1p1")):
+        lp = funnel_ll(D, SCALES)
+        g = torch.Generator().manual_seed(8)
+        th = 0.5 * torch.randn(D, generator=g, dtype=torch.float64); pm = torch.randn(D, generator=g, dtype=torch.float64)
+        out[f"{tag}_theta0"] = npy(th); out[f"{tag}_p0"] = npy(pm); out[f"{tag}_cfg"] = np.array([D, alpha, 0.05, 3, 1e-16, 30])
+        lpar, lmom = S.leapfrog(th, pm, lp, steps=3, step_size=0.05, jitter=None, softabs_const=alpha,
+                                fixed_point_threshold=1e-16, fixed_point_max_iterations=30, sampler=hamiltorch.Sampler.RMHMC,
+                                integrator=hamiltorch.Integrator.IMPLICIT, metric=hamiltorch.Metric.SOFTABS)
+        out[f"{tag}_lf_theta"] = np.stack([npy(t) for t in lpar]); out[f"{tag}_lf_p"] = np.stack([npy(t) for t in lmom])
+    D = 4
+    lp = funnel_ll(D, SCALES)
+    hamiltorch.set_random_seed(78)
+    with Recorder() as rec:
+        ret, acc = hamiltorch.sample(lp, torch.tensor([0.2, -0.3, 0.4, 0.1], dtype=torch.float64), num_samples=8,
+                                     num_steps_per_sample=3, step_size=0.1, burn=1, jitter=None, softabs_const=1e6,
+                                     fixed_point_threshold=1e-14, fixed_point_max_iterations=40,
+                                     sampler=hamiltorch.Sampler.RMHMC, integrator=hamiltorch.Integrator.IMPLICIT,
+                                     metric=hamiltorch.Metric.SOFTABS, debug=2, verbose=False)
+    out["imp_e2e_samples"] = np.stack([npy(t) for t in ret])
+    out["imp_e2e_momenta"] = np.stack(rec.momenta)
+    out["imp_e2e_uniforms"] = np.concatenate(rec.uniforms)
+    out["imp_e2e_acc"] = np.array(acc)
     np.savez(os.path.join(OUT, "funnel.npz"), **out)
 
 

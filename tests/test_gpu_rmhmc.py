@@ -307,3 +307,41 @@ def test_generic_sample_rmhmc_vs_oracle(ht, dtype, tol, D, scaled, jitter, alpha
     assert got.shape == want.shape
     bad = ~(np.abs(got - want).max(axis=(0, 2)) <= tol)
     assert bad.mean() <= 0.1, "%d of %d chains differ, max err %.3g" % (bad.sum(), C, np.nanmax(np.abs(got - want)))
+
+
+# ---- implicit RMHMC: generalised leapfrog with fixed-point iterations (S:305-387), SURVEY 8f N4 --------------
+@pytest.mark.parametrize("tag", ["imp_a1e6", "imp_a1p1"])
+def test_implicit_leapfrog_vs_reference_fixture(ht, golden, tag):
+    g = golden("funnel")
+    D, alpha, eps, steps, thr, max_it = g[f"{tag}_cfg"]
+    D = int(D)
+    lp = funnel_logp(g["scales"][:D - 1])
+    th, pm = tt(g[f"{tag}_theta0"], torch.float64), tt(g[f"{tag}_p0"], torch.float64)
+    lpar, lmom = ht.samplers.leapfrog(th, pm, lp, steps=int(steps), step_size=eps, jitter=None, softabs_const=alpha,
+                                      fixed_point_threshold=thr, fixed_point_max_iterations=int(max_it),
+                                      sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.IMPLICIT, metric=ht.Metric.SOFTABS)
+    np.testing.assert_allclose(torch.stack(lpar).cpu().numpy(), g[f"{tag}_lf_theta"], rtol=2e-7, atol=2e-7)
+    np.testing.assert_allclose(torch.stack(lmom).cpu().numpy(), g[f"{tag}_lf_p"], rtol=2e-7, atol=2e-7)
+
+
+@pytest.mark.parametrize("dtype,tol,thr", [(torch.float64, 1e-7, 1e-18), (torch.float32, 5e-3, 1e-9)])
+@pytest.mark.parametrize("D,scaled,jitter,alpha", [(5, True, None, 1e6), (6, False, 1e-2, 1.0)])
+def test_implicit_sample_rmhmc_vs_oracle(ht, dtype, tol, thr, D, scaled, jitter, alpha):
+    """sample(RMHMC, IMPLICIT) for a batch of chains that need different numbers of fixed-point iterations; the same
+    Philox streams (fixed sub-stream layout per step) in the product and the oracle."""
+    scales = np.array([0.5, 1.0, 1.7, 2.4, 3.3])[:D - 1] if scaled else np.ones(D - 1)
+    lp = funnel_logp(scales)
+    o = O.FunnelTarget(D, scales)
+    C, N, L, eps, seed, off, max_it = 10, 4, 2, 0.06, 321, 2, 12
+    th0 = (0.4 * O.philox_normals(seed, off + np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(NP[dtype])
+    out, acc = ht.sample(lp, tt(th0, dtype), num_samples=N, num_steps_per_sample=L, step_size=eps, burn=0, jitter=jitter,
+                         softabs_const=alpha, fixed_point_threshold=thr, fixed_point_max_iterations=max_it,
+                         sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.IMPLICIT, metric=ht.Metric.SOFTABS, debug=2,
+                         verbose=False, seed=seed, chain_offset=off)
+    with np.errstate(all="ignore"):
+        ref, info = O.sample_rmhmc_implicit(o, th0, N, L, eps, alpha, thr, max_it, 0, jitter,
+                                            O.PhiloxDraws(seed, off + np.arange(C), NP[dtype]))
+    got = np.stack([x.cpu().numpy() for x in out]); want = np.stack(ref)
+    assert got.shape == want.shape
+    bad = ~(np.abs(got - want).max(axis=(0, 2)) <= tol)
+    assert bad.mean() <= 0.1, "%d of %d chains differ, max err %.3g" % (bad.sum(), C, np.nanmax(np.abs(got - want)))

@@ -353,3 +353,28 @@ def test_philox_permutation_is_a_permutation_and_matches_host():
         assert pm == util.split_permutation(seed, draw, M)
     # not stuck on the identity
     assert any(O.philox_permutation(5, n, 6) != list(range(6)) for n in range(4))
+
+
+# ---- implicit RMHMC (generalised leapfrog, fixed-point iterations): SURVEY 8f N4 ---------------------------
+@pytest.mark.parametrize("tag", ["imp_a1e6", "imp_a1p1"])
+def test_implicit_rmhmc_leapfrog_vs_reference(golden, tag):
+    g = golden("funnel")
+    D, alpha, eps, steps, thr, max_it = g[f"{tag}_cfg"]
+    t = _funnel(g, int(D))
+    th, pm = g[f"{tag}_theta0"][None], g[f"{tag}_p0"][None]
+    for n in range(1, int(steps) + 1):
+        a, b = O.implicit_rmhmc_leapfrog(th, pm, t, n, eps, alpha, thr, int(max_it))
+        np.testing.assert_allclose(a[0], g[f"{tag}_lf_theta"][n - 1], rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(b[0], g[f"{tag}_lf_p"][n - 1], rtol=1e-7, atol=1e-7)
+
+
+def test_implicit_rmhmc_sample_end_to_end(golden):
+    g = golden("funnel")
+    t = _funnel(g, 4)
+    draws = O.ReplayDraws(g["imp_e2e_momenta"], g["imp_e2e_uniforms"], dtype=np.float64)
+    with np.errstate(all="ignore"):
+        ret, info = O.sample_rmhmc_implicit(t, np.array([[0.2, -0.3, 0.4, 0.1]]), 8, 3, 0.1, 1e6, 1e-14, 40, burn=1, draws=draws)
+    ref = g["imp_e2e_samples"]
+    assert len(ret) == ref.shape[0]
+    np.testing.assert_allclose(np.concatenate(ret), ref, rtol=1e-6, atol=1e-6)
+    assert abs(info["acc_rate"][0] - float(g["imp_e2e_acc"])) < 1e-9
