@@ -113,7 +113,7 @@ class Cfg2:
 class Cfg3:
     """BASELINE config 3: D=100 Gaussian, explicit RMHMC, soft-abs metric, 256 chains."""
     name = "cfg3: D=100 Gaussian explicit RMHMC, softabs alpha=1e6, omega=10, eps=0.1, L=10, jitter=1e-3"
-    D, L, eps, chains, traj = 100, 10, 0.1, 256, 2
+    D, L, eps, chains, traj = 100, 10, 0.1, 256, 20
     omega, alpha, jitter = 10.0, 1e6, 1e-3
     dtype_name = "f32"
 
@@ -140,8 +140,14 @@ class Cfg3:
     def units_per_step(self):
         return self.C * self.T * self.L
 
-    def flops_per_unit(self):      # 4 distinct metric evaluations x 11.3 D^3 per explicit step
-        return 4 * 11.3 * self.D ** 3
+    def flops_per_unit(self):
+        # flops the fused kernel executes per explicit step (csrc/rmhmc_fused.hip): 4 half steps x (2 + K) symmetric
+        # matrix-vector products (K = 2 refinements at jitter 1e-3) + the trajectory's Cholesky (D^3 / 3 FMAs) spread over
+        # its L steps.  (The reference's route - an eigendecomposition per metric evaluation - is 4 x 11.3 D^3 = 4.5e7
+        # per step; the soft-abs map is the identity on this spectrum, see DESIGN.md.)
+        return 4 * 4 * 2 * self.D ** 2 + (2 * self.D ** 3 / 3) / self.L
+
+    roof_kernel = "rmhmc_fused_kernel<float,56>"
 
     def bytes_per_unit(self):
         return 32 * self.D
@@ -318,9 +324,10 @@ def main():
                     "kernel": getattr(w, "roof_kernel", "metric_eval_kernel<float>"),
                     "kernel_ms_per_step": kernel_ms, "launches_per_step": prof_n / max(1, a.steps),
                     "algorithmic_flops_per_chain_step": w.flops_per_unit(),
-                    "note": "fp32 vector == fp32 MFMA peak (157.3 TF); algorithmic flop count of SURVEY 8d "
-                            "(cfg3: 4 x 11.3 D^3 per explicit step, LAPACK-style eigh count -- the Jacobi solver executes "
-                            "more; cfg4: 2M x 6 flop per (point, weight) per split step)"}
+                    "note": "fp32 vector == fp32 MFMA peak (157.3 TF).  cfg3: flops the fused kernel executes (shared-inverse "
+                            "solves + one Cholesky per trajectory; the eigh route of the reference would be 4.5e7 per step), "
+                            "one 4-wave workgroup per chain: latency bound at 256 chains; cfg4: 2M x 6 flop per (point, weight) "
+                            "per split step (SURVEY 8d)"}
         else:
             roof = None
         traffic = None

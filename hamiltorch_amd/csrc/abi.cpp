@@ -12,6 +12,7 @@ void set_error(const char* fmt, ...) {
 }
 int g_small_chains_per_block = 0;  // 0 = default (64)
 int g_force_general = 0;
+int g_rmhmc_fused = 1;           // 0 = keep the Gaussian RMHMC sampler on the per-evaluation Jacobi path (parity tests of both)
 int g_mlp_valu = 0;               // 1 = keep the Bayesian-MLP sampler on the VALU kernel (parity tests of both)
 
 // ---- optional HIP-event timing of the dominant kernel of each call (measurement only) -----------
@@ -64,6 +65,7 @@ int hta_set_tuning(const char* key, int value) {
   if (!strcmp(key, "small_chains_per_block")) { hta::g_small_chains_per_block = value; return HTA_OK; }
   if (!strcmp(key, "force_general")) { hta::g_force_general = value; return HTA_OK; }
   if (!strcmp(key, "mlp_valu")) { hta::g_mlp_valu = value; return HTA_OK; }
+  if (!strcmp(key, "rmhmc_fused")) { hta::g_rmhmc_fused = value; return HTA_OK; }
   if (!strcmp(key, "profile")) { hta::g_profile = value; hta::g_ev_used = 0; return HTA_OK; }
   hta::set_error("hta_set_tuning: unknown key %s", key);
   return HTA_ERR_INVALID;

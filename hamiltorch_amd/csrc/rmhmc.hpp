@@ -28,4 +28,15 @@ int mh_select(T* cur, const T* prop, const T* init, const T* Ho, const T* Hn, co
 void profile_begin(hipStream_t s);
 void profile_end(hipStream_t s);
 
+// rmhmc_fused.hip: the identity-soft-abs fast path of the Gaussian-target sampler
+extern int g_rmhmc_fused;                                   // tuning key "rmhmc_fused" (default 1)
+template <typename T>
+int fused_plan(const T* lam0_host, int D, int metric, double alpha, int has_jitter, double jitter, double* logdetP, int* series);
+template <typename T> int inverse_from_eigen(const T* V0, const T* lam0, T* S, int D, hipStream_t s);
+template <typename T>
+int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, const T* mu, double log_norm, double logdetP,
+                       int has_jitter, double jitter, int K, int series, int64_t C, int D, int L, double eps, double omega,
+                       int n_traj, int traj_offset, int burn, uint64_t seed, uint64_t chain_offset, T* samples,
+                       int32_t* reject_count, T* H_old, T* H_new, uint8_t* accept, hipStream_t s);
+
 }  // namespace hta

@@ -97,20 +97,39 @@ int rmhmc_sample(T* cur, const T* theta_init, const T* P, const T* mu, double lo
   const char* who = "hta_rmhmc_gaussian_sample";
   HTA_REQUIRE(cur && theta_init && P && mu && reject_count && C > 0 && D > 0 && L >= 0 && n_traj >= 0, "%s: bad arguments", who);
   const int64_t total = C * D;
-  const int64_t need = (4 * total + 3 * C + (int64_t)D * D + D) * (int64_t)sizeof(T);
+  const int64_t need = (4 * total + 3 * C + 2 * (int64_t)D * D + D) * (int64_t)sizeof(T);
   HTA_REQUIRE(workspace && workspace_bytes >= need, "%s: workspace of %lld bytes required", who, (long long)need);
   T* th = (T*)workspace; T* pm = th + total; T* thc = pm + total; T* pmc = thc + total;
   T* H0 = pmc + total; T* H1 = H0 + C; T* lp1 = H1 + C;
-  T* V0 = lp1 + C; T* lam0 = V0 + (int64_t)D * D;
+  T* V0 = lp1 + C; T* lam0 = V0 + (int64_t)D * D; T* Sinv = lam0 + D;
   RmModel<T> m{P, mu, log_norm, metric, alpha, has_jitter, jitter, seed, chain_offset, C, D, nullptr, nullptr};
-  if (metric == HTA_METRIC_SOFTABS) {
+  if (metric == HTA_METRIC_SOFTABS || g_rmhmc_fused) {
     // the target's curvature is one matrix for all chains and all evaluation points; every evaluation only adds
     // its own jitter to the diagonal.  Diagonalise it once and start every per-chain Jacobi from that basis.
     MetricArgsT<T> a0 = base_args(m, 0, 0);
-    a0.B = 1; a0.has_jitter = 0; a0.V_out = V0; a0.lamraw_out = lam0;
+    a0.metric = HTA_METRIC_SOFTABS; a0.B = 1; a0.has_jitter = 0; a0.V_out = V0; a0.lamraw_out = lam0;
     int rc0 = metric_eval<T>(a0, s);
     if (rc0) return rc0;
-    m.V0 = V0; m.lam0 = lam0;
+    if (metric == HTA_METRIC_SOFTABS) { m.V0 = V0; m.lam0 = lam0; }
+  }
+  if (g_rmhmc_fused && n_traj > 0 && D <= 1024) {
+    // When the soft-abs map is the identity on this spectrum (or the metric is the Hessian itself) the whole run is
+    // one launch of rmhmc_fused.hip; the decision needs the eigenvalues on the host: one D-element copy per run.
+    T lam_host[1024];
+    if (hipMemcpyAsync(lam_host, lam0, D * sizeof(T), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+      set_error("%s: reading the spectrum back failed: %s", who, hipGetErrorString(hipGetLastError()));
+      return HTA_ERR_LAUNCH;
+    }
+    double logdetP = 0; int series = 0;
+    const int K = fused_plan<T>(lam_host, D, metric, alpha, has_jitter, jitter, &logdetP, &series);
+    if (K >= 0) {
+      int rc = inverse_from_eigen<T>(V0, lam0, Sinv, D, s);
+      if (rc) return rc;
+      return rmhmc_fused_sample<T>(cur, theta_init, P, Sinv, mu, log_norm, logdetP, has_jitter, jitter, K, series, C, D, L, eps,
+                                   omega, n_traj, traj_offset, burn, seed, chain_offset, samples, reject_count, H_old_out,
+                                   H_new_out, accept_out, s);
+    }
   }
   for (int t = 0; t < n_traj; ++t) {
     const int n = traj_offset + t;
@@ -149,7 +168,7 @@ int rmhmc_sample(T* cur, const T* theta_init, const T* P, const T* mu, double lo
 
 extern "C" {
 int64_t hta_rmhmc_workspace_bytes(int64_t C, int D, int elem_size) {
-  return (4 * C * D + 3 * C + (int64_t)D * D + D) * (int64_t)elem_size;
+  return (4 * C * D + 3 * C + 2 * (int64_t)D * D + D) * (int64_t)elem_size;
 }
 
 #define HTA_DEFINE_ROT(SUF, T)                                                                                  \

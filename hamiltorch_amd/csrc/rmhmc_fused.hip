@@ -1,0 +1,499 @@
+// Explicit RMHMC for a Gaussian target when the soft-abs map is the identity: the whole `sample` loop
+// (hamiltorch/samplers.py:969-1026 with the integrator S:425-461) for one chain per workgroup, every
+// trajectory of a run in ONE launch.
+//
+// Why this is the same computation as csrc/rmhmc_explicit.hip + rmhmc_metric.hip.  The target's curvature is one
+// matrix P for all chains; an evaluation's metric is G = softabs(F), F = P + diag(e), e = jitter u >= 0 (S:113-121).
+// lam coth(alpha lam) = lam (1 + 2 exp(-2 alpha lam) + ...): once alpha lam_min(P) >= 20 the correction is below
+// 1e-17 relative, i.e. G == F in fp32 and fp64 (and G = F by definition for Metric.HESSIAN).  Then
+//   G^-1 m    = (P + E)^-1 m:  x_0 = S m,  x_{k+1} = x_0 - S (e . x_k)  with the shared S = P^-1; contraction factor
+//               rho <= jitter / lam_min(P), so K = O(log eps / log rho) products with ONE shared matrix (3 in fp32 at
+//               the BASELINE config-3 numbers) instead of an eigendecomposition per chain and evaluation;
+//   log |G|   = log |F| and the momentum draw p = chol(G) z (S:183-184): a Cholesky factorisation of F in LDS,
+//               three per trajectory (gibbs, H_old, H_new);
+//   dH/dtheta = P (theta - mu)  (constant curvature).
+// The host (rmhmc_explicit.hip) takes this path only when those conditions hold; everything else - finite alpha,
+// indefinite curvature, rho > 1/4, matrices beyond the LDS - keeps the Jacobi path.  Same Philox sub-streams, same
+// update order (sequential phi_C, Q1; un-augmented H_new, Q4; first post-burn rejection resets to params_init, Q2).
+//
+// Layout: P, S and the Cholesky work matrix in LDS (row stride D|1), the four state vectors and scratch vectors in
+// LDS, 256 threads: a matrix-vector product is 2 threads per row; the Cholesky trailing update a 16 x 16 thread tile.
+#include <math.h>
+#include "common.hpp"
+#include "philox.hpp"
+#include "rmhmc.hpp"
+
+#ifndef HTA_RM_TIMING
+#define HTA_RM_TIMING 0   // developer cycle counters (thread 0 of block 0): tools/scratch/rmhmc_time.py prints them
+#endif
+#if HTA_RM_TIMING
+__device__ unsigned long long hta_rm_dbg[8];
+extern "C" void hta_rm_dbg_read(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(hta_rm_dbg), sizeof(hta_rm_dbg)); }
+#define HTA_RTICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); ch.tacc[k] += now_ - ch.tlast; ch.tlast = now_; } while (0)
+#define HTA_MTICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[k] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define HTA_RTICK(k) do {} while (0)
+#define HTA_MTICK(k) do {} while (0)
+#endif
+
+namespace hta {
+
+constexpr int FNT = 256;          // 4 waves: (row block of 64) x (half of the contraction range)
+constexpr int FCB = 4;            // Cholesky panel width
+
+template <typename T> struct FusedArgs {
+  T* cur; const T* theta_init; const T* P; const T* S; const T* mu;
+  T log_norm; T logdetP; int has_jitter; T jitter; int K; int series;
+  int64_t C; int D; int L; T eps; T rot_c; T rot_s;
+  int n_traj; int traj_offset; int burn; uint64_t seed; uint64_t chain_offset;
+  T* samples; int32_t* reject_count; T* H_old; T* H_new; uint8_t* accept;
+};
+
+template <typename T> __device__ __forceinline__ T fast_rsqrt(T v) { return (T)1 / sqrt(v); }
+template <> __device__ __forceinline__ float fast_rsqrt<float>(float v) { return __builtin_amdgcn_rsqf(v); }   // v_rsq_f32, 1 ulp
+
+// KH: register-resident slice of a matrix column per thread (multiple of 8).  Thread (row, half) keeps P[k][row] and
+// S[k][row] for its KH values of k in VGPRs for the whole launch; a matrix-vector product then only streams the
+// vector (16-byte LDS broadcasts).
+template <typename T, int KH> struct FusedChain {
+  typedef T V4 __attribute__((ext_vector_type(4)));
+  const FusedArgs<T>& a;
+  int D, ld, tid, row, k0;
+  bool rowok, hi;
+  T Preg[KH], Sreg[KH];
+  T *W, *dg, *sdiag, *cur, *th, *pm, *thc, *pmc, *ev, *d, *x0, *x, *w, *q0, *q1, *r0, *r1, *s0, *s1, *red;
+  uint64_t chain;
+#if HTA_RM_TIMING
+  unsigned long long tacc[8] = {0}, tlast = 0;
+#endif
+  __device__ FusedChain(const FusedArgs<T>& a_) : a(a_) {}
+
+  // (re)load this thread's register slices: column `row`, rows k0 .. k0 + KH of the symmetric P and S (L2 hits).
+  // Called after every factorisation so that the slices are dead - and their 2 KH registers free - during it.
+  __device__ __forceinline__ void load_slices() {
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk) {
+      const int k = k0 + kk;
+      const bool ok = rowok && k < D;
+      Preg[kk] = ok ? a.P[(int64_t)k * D + row] : (T)0;
+      Sreg[kk] = ok ? a.S[(int64_t)k * D + row] : (T)0;
+    }
+  }
+
+  // four block sums at once (every thread gets all four)
+  __device__ __forceinline__ void block_sum4(T (&v)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = wave_sum(v[q]);
+    __syncthreads();
+    if ((tid & 63) == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[4 * (tid >> 6) + q] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      T s = 0;
+#pragma unroll
+      for (int i = 0; i < FNT / 64; ++i) s += red[4 * i + q];
+      v[q] = s;
+    }
+  }
+
+  // Partial products of up to three symmetric-matrix x vector products in one pass over this thread's slice:
+  //   o1 = P v1,  o2 = S v2,  o3 = (S . S) v3  (element-wise square: the second-order log-det term).
+  // The two halves of a row land in (o*0[row], o*1[row]); the consumer adds them.  No barriers inside; the vectors
+  // are zero beyond D (and so are the register slices).
+  template <bool WITH_P, int NS>
+  __device__ __forceinline__ void products(const T* v1, T* o10, T* o11, const T* v2, T* o20, T* o21, const T* v3, T* o30, T* o31) {
+    T a1[2] = {0, 0}, a2[2] = {0, 0}, a3[2] = {0, 0};
+#pragma unroll
+    for (int kk = 0; kk < KH; kk += 4) {
+      V4 u1, u2, u3;
+      if (WITH_P) u1 = *reinterpret_cast<const V4*>(v1 + k0 + kk);
+      if (NS >= 1) u2 = *reinterpret_cast<const V4*>(v2 + k0 + kk);
+      if (NS >= 2) u3 = *reinterpret_cast<const V4*>(v3 + k0 + kk);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (WITH_P) a1[e & 1] = fma(Preg[kk + e], u1[e], a1[e & 1]);
+        if (NS >= 1) a2[e & 1] = fma(Sreg[kk + e], u2[e], a2[e & 1]);
+        if (NS >= 2) a3[e & 1] = fma(Sreg[kk + e] * Sreg[kk + e], u3[e], a3[e & 1]);
+      }
+    }
+    if (!rowok) return;
+    if (WITH_P) { T* const h1 = hi ? o11 : o10; h1[row] = a1[0] + a1[1]; }
+    if (NS >= 1) { T* const h2 = hi ? o21 : o20; h2[row] = a2[0] + a2[1]; }
+    if (NS >= 2) { T* const h3 = hi ? o31 : o30; h3[row] = a3[0] + a3[1]; }
+  }
+
+  // jitter of evaluation `sub` of trajectory n  (S:113-115)
+  __device__ __forceinline__ void draw_jitter(uint32_t n, uint32_t sub) {
+    if (tid < D) ev[tid] = a.has_jitter ? a.jitter * uniform_elem<T>(a.seed, chain, n, PURPOSE_JITTER, sub, tid) : (T)0;
+  }
+
+  // W = P + diag(ev) -> its Cholesky factor (strictly-lower part in W, diagonal in dg), right-looking in panels of
+  // FCB columns: the panel rows are one thread each (the FCB x FCB diagonal block is refactored by every thread from
+  // LDS: no extra barrier), the rank-FCB trailing update a 16 x 16 thread tile with the panel rows it needs in
+  // registers.  Returns this thread's share of log |F| (sum over threads = log |F|).
+  __device__ __forceinline__ T factor() {
+    __syncthreads();
+    {
+      const float invD = 1.0f / (float)D;
+      for (int e0 = tid; e0 < D * D; e0 += 8 * FNT) {       // 8 independent L2 loads in flight per thread
+        T t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + u * FNT; t[u] = e < D * D ? a.P[e] : (T)0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * FNT;
+          int i = (int)(((float)e + 0.5f) * invD);             // e / D without the integer divide (e < 2^14)
+          const int j = e - i * D;
+          if (e < D * D && j <= i) W[i * ld + j] = t[u] + (i == j ? ev[i] : (T)0);
+        }
+      }
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    for (int kb = 0; kb < D; kb += FCB) {
+      const int nb = min(FCB, D - kb);
+      HTA_MTICK(1);
+      // --- panel: diagonal block factor (registers, every thread), then this thread's row of the panel
+      T Ld[FCB][FCB], rinv[FCB];
+#pragma unroll
+      for (int c = 0; c < FCB; ++c)
+#pragma unroll
+        for (int c2 = 0; c2 < FCB; ++c2) Ld[c][c2] = (c < nb && c2 <= c) ? W[(kb + c) * ld + kb + c2] : (T)(c == c2);
+#pragma unroll
+      for (int c = 0; c < FCB; ++c) {
+#pragma unroll
+        for (int c2 = 0; c2 < c; ++c2) {
+          T v = Ld[c][c2];
+#pragma unroll
+          for (int c3 = 0; c3 < c2; ++c3) v = fma(-Ld[c][c3], Ld[c2][c3], v);
+          Ld[c][c2] = v * rinv[c2];
+        }
+        T v = Ld[c][c];
+#pragma unroll
+        for (int c3 = 0; c3 < c; ++c3) v = fma(-Ld[c][c3], Ld[c][c3], v);
+        rinv[c] = fast_rsqrt<T>(v);
+        Ld[c][c] = v * rinv[c];
+      }
+      T lrow[FCB];
+      const int i = kb + FCB + tid;                       // rows below the diagonal block: one thread each
+      const bool below = i < D;
+      if (below) {
+#pragma unroll
+        for (int c = 0; c < FCB; ++c) {
+          T v = c < nb ? W[i * ld + kb + c] : (T)0;
+#pragma unroll
+          for (int c3 = 0; c3 < c; ++c3) v = fma(-lrow[c3], Ld[c][c3], v);
+          lrow[c] = v * rinv[c];
+        }
+      }
+      __syncthreads();                                     // every thread has read the old panel / diagonal block
+      if (below) {
+#pragma unroll
+        for (int c = 0; c < FCB; ++c) if (c < nb) W[i * ld + kb + c] = lrow[c];
+      }
+#pragma unroll
+      for (int c = 0; c < FCB; ++c) {                      // rows of the diagonal block itself (static indices: Ld stays in registers)
+        if (tid == c && c < nb) {
+          dg[kb + c] = Ld[c][c];
+#pragma unroll
+          for (int c2 = 0; c2 < c; ++c2) W[(kb + c) * ld + kb + c2] = Ld[c][c2];
+        }
+      }
+      __syncthreads();
+      HTA_MTICK(6);
+      // --- trailing update with the finished panel: rows ii = r0 + 16 a (a-th slot of ty), columns j = c0 + 16 b (tx)
+      const int rbase = kb + FCB + ty, cbase = kb + FCB + tx;
+      for (int ii = rbase; ii < D; ii += 16) {
+        T* wrow = W + ii * ld;
+        T li[FCB];
+#pragma unroll
+        for (int c = 0; c < FCB; ++c) li[c] = wrow[kb + c];
+        for (int j = cbase; j <= ii; j += 32) {            // two column slots per trip: both sets of loads in flight together
+          const int j2 = j + 16;
+          const bool two = j2 <= ii;
+          const T* p1 = W + j * ld + kb;
+          const T* p2 = W + (two ? j2 : j) * ld + kb;
+          T l1[FCB], l2[FCB];
+#pragma unroll
+          for (int c = 0; c < FCB; ++c) { l1[c] = p1[c]; l2[c] = p2[c]; }
+          T v1 = wrow[j], v2 = wrow[two ? j2 : j];
+#pragma unroll
+          for (int c = 0; c < FCB; ++c) { v1 = fma(-li[c], l1[c], v1); v2 = fma(-li[c], l2[c], v2); }
+          wrow[j] = v1;
+          if (two) wrow[j2] = v2;
+        }
+      }
+      __syncthreads();
+      HTA_MTICK(7);
+    }
+    return tid < D ? (T)2 * log(dg[tid]) : (T)0;
+  }
+
+  // refinement of x = (P + diag(ev))^-1 m from x0 = S m (already in x0 / x / w = ev . x): K products with S
+  __device__ __forceinline__ void refine() {
+    for (int it = 0; it < a.K; ++it) {
+      __syncthreads();
+      products<false, 1>(nullptr, nullptr, nullptr, w, r0, r1, nullptr, nullptr, nullptr);
+      __syncthreads();
+      if (tid < D) { const T xn = x0[tid] - (r0[tid] + r1[tid]); x[tid] = xn; w[tid] = ev[tid] * xn; }
+    }
+  }
+
+  // one half step (csrc/rmhmc_explicit.hip:half_step): upd_x += eh G(X)^-1 m ; upd_g -= eh P (X - mu)
+  __device__ __forceinline__ void half_step(uint32_t n, uint32_t sub, const T* X, const T* m, T* upd_x, T* upd_g, T eh) {
+    __syncthreads();
+    draw_jitter(n, sub);
+    if (tid < D) d[tid] = X[tid] - a.mu[tid];
+    __syncthreads();
+    products<true, 1>(d, q0, q1, m, r0, r1, nullptr, nullptr, nullptr);
+    __syncthreads();
+    if (tid < D) {
+      upd_g[tid] -= eh * (q0[tid] + q1[tid]);
+      const T xs = r0[tid] + r1[tid];
+      x0[tid] = xs; x[tid] = xs; w[tid] = ev[tid] * xs;
+    }
+    refine();
+    if (tid < D) upd_x[tid] += eh * x[tid];
+  }
+
+  // H = -log p + D/2 log 2 pi + 1/2 log|G| + 1/2 m^T G^-1 m  (S:731) at (X, m), jitter sub-stream `sub`
+  __device__ __forceinline__ T hamiltonian(uint32_t n, uint32_t sub, const T* X, const T* m, T& logp_out) {
+    __syncthreads();
+    draw_jitter(n, sub);
+    if (tid < D) d[tid] = X[tid] - a.mu[tid];
+    T ld_part = 0;
+    const bool series = a.series || !a.has_jitter;
+    if (!series) { ld_part = factor(); load_slices(); }     // exact: Cholesky of P + E
+    __syncthreads();
+    if (series && a.has_jitter) products<true, 2>(d, q0, q1, m, r0, r1, ev, s0, s1);
+    else products<true, 1>(d, q0, q1, m, r0, r1, nullptr, nullptr, nullptr);
+    __syncthreads();
+    T dPd = 0;
+    if (tid < D) {
+      dPd = d[tid] * (q0[tid] + q1[tid]);
+      const T xs = r0[tid] + r1[tid];
+      x0[tid] = xs; x[tid] = xs; w[tid] = ev[tid] * xs;
+      if (series && a.has_jitter)       // log|P + E| = log|P| + tr(SE) - 1/2 tr((SE)^2) + O(D rho^3 / 3)
+        ld_part = ev[tid] * (sdiag[tid] - (T)0.5 * (s0[tid] + s1[tid]));
+    }
+    refine();
+    T v[4] = {dPd, tid < D ? m[tid] * x[tid] : (T)0, ld_part, (T)0};
+    block_sum4(v);
+    const T lp = a.log_norm - (T)0.5 * v[0];
+    const T logdet = series ? a.logdetP + v[2] : v[2];
+    logp_out = lp;
+    const float pi_term = (float)D * 1.8378770351409912f;     // S:712: float32 whatever the state dtype
+    return -lp + (T)0.5 * (T)pi_term + (T)0.5 * logdet + (T)0.5 * v[1];
+  }
+};
+
+constexpr int FVEC = 18;          // LDS vectors of a chain (each padded to 128 entries, zero beyond D)
+
+template <typename T, int KH>
+__global__ __launch_bounds__(FNT) void rmhmc_fused_kernel(FusedArgs<T> a, int ld) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  FusedChain<T, KH> ch(a);
+  const int D = a.D, tid = threadIdx.x;
+  constexpr int Dp = 128;
+  ch.D = D; ch.ld = ld; ch.tid = tid;
+  {
+    const int wave = tid >> 6;
+    ch.row = (wave & 1) * 64 + (tid & 63);
+    ch.rowok = ch.row < D;
+    ch.hi = wave >> 1;
+    ch.k0 = ch.hi ? KH : 0;
+  }
+  T* v = reinterpret_cast<T*>(smem_raw);
+  T** slots[FVEC] = {&ch.dg, &ch.sdiag, &ch.cur, &ch.th, &ch.pm, &ch.thc, &ch.pmc, &ch.ev, &ch.d, &ch.x0, &ch.x, &ch.w,
+                     &ch.q0, &ch.q1, &ch.r0, &ch.r1, &ch.s0, &ch.s1};
+  for (int i = 0; i < FVEC; ++i) *slots[i] = v + i * Dp;
+  ch.red = v + FVEC * Dp;
+  ch.W = ch.red + 16;
+  for (int e = tid; e < FVEC * Dp; e += FNT) v[e] = (T)0;
+  __syncthreads();
+  if (tid < D) ch.sdiag[tid] = a.S[(int64_t)tid * D + tid];
+  const T eh = (T)0.5 * a.eps;
+#if HTA_RM_TIMING
+  __syncthreads();
+  ch.tlast = __builtin_readcyclecounter();
+#endif
+  bool have_factor = false;                                 // without jitter chol(P) serves every chain and trajectory
+  for (int64_t c = blockIdx.x; c < a.C; c += gridDim.x) {
+    ch.chain = a.chain_offset + (uint64_t)c;
+    __syncthreads();
+    if (tid < D) ch.cur[tid] = a.cur[c * D + tid];
+    int32_t rejected = 0;
+    for (int t = 0; t < a.n_traj; ++t) {
+      const uint32_t n = (uint32_t)(a.traj_offset + t);
+      // ---- gibbs: p = chol(G(theta)) z  (S:183-184), jitter sub-stream 0
+      __syncthreads();
+      HTA_RTICK(0);
+      ch.draw_jitter(n, 0);
+      if (a.has_jitter || !have_factor) { ch.factor(); have_factor = true; ch.load_slices(); }
+      HTA_RTICK(1);
+      if (tid < D) ch.d[tid] = normal_elem<T>(a.seed, ch.chain, n, 0, tid);
+      __syncthreads();
+      if (tid < D) {
+        T acc0 = ch.dg[tid] * ch.d[tid], acc1 = 0;
+        const T* rowp = ch.W + tid * ld;
+        int k = 0;
+        for (; k + 1 < tid; k += 2) { acc0 = fma(rowp[k], ch.d[k], acc0); acc1 = fma(rowp[k + 1], ch.d[k + 1], acc1); }
+        if (k < tid) acc0 = fma(rowp[k], ch.d[k], acc0);
+        ch.pm[tid] = acc0 + acc1;
+      }
+      __syncthreads();
+      // ---- H_old (S:971 -> S:822), sub-stream 1
+      HTA_RTICK(2);
+      T lp0;
+      const T H0 = ch.hamiltonian(n, 1, ch.cur, ch.pm, lp0);
+      HTA_RTICK(3);
+      if (tid < D) { ch.th[tid] = ch.cur[tid]; ch.thc[tid] = ch.cur[tid]; ch.pmc[tid] = ch.pm[tid]; }   // S:425-426
+      // ---- L explicit steps (S:427-461)
+      for (int l = 0; l < a.L; ++l) {
+        const uint32_t k0 = 2u + 8u * (uint32_t)l;
+        ch.half_step(n, k0 + 1, ch.th, ch.pmc, ch.thc, ch.pm, eh);          // phi_A/2  S:429-430
+        ch.half_step(n, k0 + 2, ch.thc, ch.pm, ch.th, ch.pmc, eh);          // phi_B/2  S:432-433
+        if (tid < D) {                                                        // phi_C    S:447-450, sequential (Q1)
+          T xx = ch.th[tid], b = ch.pm[tid], xc = ch.thc[tid], bc = ch.pmc[tid];
+          const T h = (T)0.5, cc = a.rot_c, ss = a.rot_s;
+          xx = h * ((xx + xc) + cc * (xx - xc) + ss * (b - bc));
+          b = h * ((b + bc) - ss * (xx - xc) + cc * (b - bc));
+          xc = h * ((xx + xc) - cc * (xx - xc) - ss * (b - bc));
+          bc = h * ((b + bc) + ss * (xx - xc) - cc * (b - bc));
+          ch.th[tid] = xx; ch.pm[tid] = b; ch.thc[tid] = xc; ch.pmc[tid] = bc;
+        }
+        ch.half_step(n, k0 + 4, ch.thc, ch.pm, ch.th, ch.pmc, eh);          // phi_B/2  S:454-455
+        ch.half_step(n, k0 + 7, ch.th, ch.pmc, ch.thc, ch.pm, eh);          // phi_A/2  S:457-458
+      }
+      // ---- H_new on the un-augmented pair (S:989, Q4), sub-stream 2 + 8L
+      HTA_RTICK(4);
+      T lp1;
+      const T H1 = ch.hamiltonian(n, 2u + 8u * (uint32_t)a.L, ch.th, ch.pm, lp1);
+      HTA_RTICK(5);
+      // ---- Metropolis test + bookkeeping (S:1000-1026, S:1045-1057), as hmc_pieces.hip:mh_select_kernel
+      const T u = u23<T>(philox_block(a.seed, ch.chain, n, PURPOSE_MH, 0, 0).x);
+      const bool acc = mh_accept<T>(H0, H1, lp1, u);
+      const bool reset = (!acc) && ((int)n == a.burn + 1);                    // Q2
+      __syncthreads();
+      if (tid < D) {
+        const T vnew = acc ? ch.th[tid] : (reset ? a.theta_init[c * D + tid] : ch.cur[tid]);
+        ch.cur[tid] = vnew;
+        if (a.samples && (int)n > a.burn) a.samples[((int64_t)((int)n - a.burn) * a.C + c) * D + tid] = vnew;
+      }
+      if (!acc) ++rejected;
+      if (tid == 0) {
+        if (a.H_old) a.H_old[(int64_t)t * a.C + c] = H0;
+        if (a.H_new) a.H_new[(int64_t)t * a.C + c] = H1;
+        if (a.accept) a.accept[(int64_t)t * a.C + c] = acc ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    if (tid < D) a.cur[c * D + tid] = ch.cur[tid];
+    if (tid == 0) a.reject_count[c] += rejected;
+#if HTA_RM_TIMING
+    if (tid == 0 && blockIdx.x == 0) for (int k = 0; k < 8; ++k) hta_rm_dbg[k] = ch.tacc[k];
+#endif
+  }
+}
+
+// S = V0 diag(1 / lam0) V0^T from the eigen-system of the jitter-free P (one workgroup; once per run)
+template <typename T>
+__global__ void inverse_from_eigen_kernel(const T* __restrict__ V0, const T* __restrict__ lam0, T* __restrict__ S, int D) {
+  for (int e = threadIdx.x; e < D * D; e += blockDim.x) {
+    const int i = e / D, j = e - i * D;
+    T acc = 0;
+    for (int k = 0; k < D; ++k) acc = fma(V0[i * D + k] / lam0[k], V0[j * D + k], acc);
+    S[e] = acc;
+  }
+}
+
+template <typename T> size_t fused_lds_bytes(int D, int* ld_out) {
+  const int ld = D | 1;
+  if (ld_out) *ld_out = ld;
+  return ((size_t)FVEC * 128 + 16 + (size_t)D * ld) * sizeof(T);
+}
+
+// Decides whether the identity-soft-abs path applies (lam0: host copy of the jitter-free eigenvalues) and, if so,
+// how many refinement products a solve needs (return value K >= 0; -1: the Jacobi path must be used), log |P|, and
+// whether the two log-determinants of a trajectory may use log|P + E| = log|P| + tr(SE) - tr((SE)^2)/2, whose
+// truncation error is below D rho^3 / 3 (accepted when that is under a quarter ulp of the Hamiltonian's D/2 log 2 pi).
+template <typename T>
+int fused_plan(const T* lam0_host, int D, int metric, double alpha, int has_jitter, double jitter, double* logdetP, int* series) {
+  if (D > 128 || fused_lds_bytes<T>(D, nullptr) > 150 * 1024) return -1;     // 2 row blocks of 64 lanes, slices of <= 64
+  double lmin = lam0_host[0], ld = 0;
+  for (int i = 0; i < D; ++i) { lmin = lam0_host[i] < lmin ? (double)lam0_host[i] : lmin; ld += log((double)lam0_host[i]); }
+  if (!(lmin > 0.0)) return -1;                                     // not positive definite: soft-abs flips signs
+  if (metric == HTA_METRIC_SOFTABS && !(alpha * lmin >= 20.0)) return -1;   // coth(alpha lam) != 1 at working precision
+  *logdetP = ld; *series = 1;
+  if (!has_jitter) return 0;
+  if (!(jitter >= 0.0)) return -1;
+  const double rho = jitter / lmin;
+  if (rho > 0.25) return -1;
+  if (rho == 0.0) return 0;
+  const double eps = sizeof(T) == 4 ? 6e-8 : 1.1e-16;
+  *series = (D * rho * rho * rho / 3.0) <= 0.25 * eps * (0.5 * D);
+  int K = (int)ceil(log(eps * 0.25) / log(rho)) - 1;                // relative error after K refinements: rho^(K+1)
+  if (K < 1) K = 1;
+  return K > 40 ? -1 : K;
+}
+
+template <typename T>
+int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, const T* mu, double log_norm, double logdetP,
+                       int has_jitter, double jitter, int K, int series, int64_t C, int D, int L, double eps, double omega,
+                       int n_traj, int traj_offset, int burn, uint64_t seed, uint64_t chain_offset, T* samples,
+                       int32_t* reject_count, T* H_old, T* H_new, uint8_t* accept, hipStream_t s) {
+  int ld;
+  const size_t lds = fused_lds_bytes<T>(D, &ld);
+  const float ang = (float)(2.0 * omega * eps);                      // S:435-436: float32 cos / sin whatever the state dtype
+  FusedArgs<T> a{cur, theta_init, P, Sinv, mu, (T)log_norm, (T)logdetP, has_jitter, (T)jitter, K, series, C, D, L, (T)eps,
+                 (T)cosf(ang), (T)sinf(ang), n_traj, traj_offset, burn, seed, chain_offset, samples, reject_count, H_old,
+                 H_new, accept};
+  const int grid = (int)(C < 8192 ? C : 8192);
+  const int KH = (((D + 1) / 2) + 7) / 8 * 8;                        // register slice: half the contraction range, in eights
+  auto launch = [&](auto kern, bool& done) -> int {
+    if (!done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) { set_error("hta_rmhmc_gaussian_sample: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
+      done = true;
+    }
+    profile_begin(s);
+    kern<<<grid, FNT, lds, s>>>(a, ld);
+    profile_end(s);
+    return HTA_OK;
+  };
+  static bool done[8] = {false, false, false, false, false, false, false, false};     // per T instantiation
+  int rc;
+  switch (KH) {
+    case 8: rc = launch(&rmhmc_fused_kernel<T, 8>, done[0]); break;
+    case 16: rc = launch(&rmhmc_fused_kernel<T, 16>, done[1]); break;
+    case 24: rc = launch(&rmhmc_fused_kernel<T, 24>, done[2]); break;
+    case 32: rc = launch(&rmhmc_fused_kernel<T, 32>, done[3]); break;
+    case 40: rc = launch(&rmhmc_fused_kernel<T, 40>, done[4]); break;
+    case 48: rc = launch(&rmhmc_fused_kernel<T, 48>, done[5]); break;
+    case 56: rc = launch(&rmhmc_fused_kernel<T, 56>, done[6]); break;
+    default: rc = launch(&rmhmc_fused_kernel<T, 64>, done[7]); break;
+  }
+  if (rc) return rc;
+  HTA_CHECK_LAUNCH("hta_rmhmc_gaussian_sample (fused)");
+  return HTA_OK;
+}
+
+template <typename T> int inverse_from_eigen(const T* V0, const T* lam0, T* S, int D, hipStream_t s) {
+  inverse_from_eigen_kernel<T><<<1, 1024, 0, s>>>(V0, lam0, S, D);
+  HTA_CHECK_LAUNCH("hta_rmhmc_gaussian_sample (inverse)");
+  return HTA_OK;
+}
+
+#define HTA_INST(T)                                                                                                   \
+  template int fused_plan<T>(const T*, int, int, double, int, double, double*, int*);                                 \
+  template int inverse_from_eigen<T>(const T*, const T*, T*, int, hipStream_t);                                       \
+  template int rmhmc_fused_sample<T>(T*, const T*, const T*, const T*, const T*, double, double, int, double, int,   \
+                                     int, int64_t, int, int, double, double, int, int, int, uint64_t, uint64_t, T*,   \
+                                     int32_t*, T*, T*, uint8_t*, hipStream_t);
+HTA_INST(float)
+HTA_INST(double)
+
+}  // namespace hta

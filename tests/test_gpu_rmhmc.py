@@ -191,11 +191,9 @@ def test_cfg3_shape_smoke_and_errors(ht):
                          metric=ht.Metric.SOFTABS, debug=2, verbose=False, seed=1)
     s = torch.stack(out)
     assert torch.isfinite(s).all() and float(acc.mean()) > 0.9 and float((s[-1] - s[0]).abs().mean()) > 1e-3
-    with pytest.raises(NotImplementedError, match="constant-curvature"):
-        ht.sample(lambda w: -(w ** 4).sum(), th0[0, :4].clone(), num_samples=2, softabs_const=1e6, sampler=ht.Sampler.RMHMC,
-                  integrator=ht.Integrator.EXPLICIT, metric=ht.Metric.SOFTABS, verbose=False)
-    with pytest.raises(NotImplementedError):
-        ht.sample(t, th0[0].clone(), num_samples=2, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.IMPLICIT, verbose=False)
+    with pytest.raises(NotImplementedError, match="S3"):
+        ht.sample(t, th0[0].clone(), num_samples=2, softabs_const=1e6, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.S3,
+                  metric=ht.Metric.SOFTABS, verbose=False)
     with pytest.raises(RuntimeError, match="gradients not implemented for RMHMC"):     # S:390-391
         ht.sample(t, th0[0].clone(), num_samples=2, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT,
                   softabs_const=1e6, metric=ht.Metric.SOFTABS, pass_grad=lambda w: w, verbose=False)
@@ -345,3 +343,36 @@ def test_implicit_sample_rmhmc_vs_oracle(ht, dtype, tol, thr, D, scaled, jitter,
     assert got.shape == want.shape
     bad = ~(np.abs(got - want).max(axis=(0, 2)) <= tol)
     assert bad.mean() <= 0.1, "%d of %d chains differ, max err %.3g" % (bad.sum(), C, np.nanmax(np.abs(got - want)))
+
+
+# ---- identity-soft-abs fast path (csrc/rmhmc_fused.hip) vs the per-evaluation Jacobi path ----------------------
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-4), (torch.float64, 1e-9)])
+@pytest.mark.parametrize("D,jitter,metric", [(100, 1e-3, "softabs"), (100, None, "softabs"), (37, 5e-2, "softabs"), (20, 1e-3, "hessian")])
+def test_fused_path_equals_jacobi_path(ht, dtype, tol, D, jitter, metric):
+    """The same run through the fused whole-trajectory kernel and through the eigendecomposition per evaluation:
+    G = softabs(P + jitter) equals P + jitter on this spectrum, so both must agree chain by chain."""
+    from hamiltorch_amd import _abi
+    if dtype == torch.float64 and D > 64:
+        pytest.skip("fp64: three D x D matrices exceed the LDS of one CU (the driver then keeps the Jacobi path)")
+    t, o = cfg3_target(ht, D, dtype, seed=7)
+    C, N, L, eps, omega, alpha, seed = 16, 4, 3, 0.1, 10.0, 1e6, 11
+    th0 = (0.3 * O.philox_normals(seed, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(NP[dtype])
+    M = ht.Metric.SOFTABS if metric == "softabs" else ht.Metric.HESSIAN
+    kw = dict(num_samples=N, num_steps_per_sample=L, step_size=eps, burn=0, jitter=jitter, softabs_const=alpha,
+              explicit_binding_const=omega, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT, metric=M, debug=2,
+              verbose=False, seed=seed)
+    outs = []
+    for fused in (1, 0):
+        _abi.set_tuning("rmhmc_fused", fused)
+        try:
+            _abi.set_tuning("profile", 1)
+            out, acc = ht.sample(t, tt(th0, dtype), **kw)
+            ms, launches = _abi.profile_collect()
+            _abi.set_tuning("profile", 0)
+        finally:
+            _abi.set_tuning("rmhmc_fused", 1)
+        outs.append((np.stack([x.cpu().numpy() for x in out]), acc.cpu().numpy(), launches))
+    assert outs[0][2] < outs[1][2], "the fused path was not taken (%d vs %d launches)" % (outs[0][2], outs[1][2])
+    bad = np.abs(outs[0][0] - outs[1][0]).max(axis=(0, 2)) > tol
+    assert bad.mean() <= 0.07, "%d of %d chains differ, max %.3g" % (bad.sum(), C, np.abs(outs[0][0] - outs[1][0]).max())
+    np.testing.assert_allclose(outs[0][1][~bad], outs[1][1][~bad], atol=1e-12)
