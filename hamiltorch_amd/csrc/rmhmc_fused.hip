@@ -60,6 +60,7 @@ template <typename T, int KH> struct FusedChain {
   const FusedArgs<T>& a;
   int D, ld, tid, row, k0;
   bool rowok, hi;
+  T mu_r;                       // mu[tid]
   T Preg[KH], Sreg[KH];
   T *W, *dg, *sdiag, *cur, *th, *pm, *thc, *pmc, *ev, *d, *x0, *x, *w, *q0, *q1, *r0, *r1, *s0, *s1, *red;
   uint64_t chain;
@@ -68,8 +69,8 @@ template <typename T, int KH> struct FusedChain {
 #endif
   __device__ FusedChain(const FusedArgs<T>& a_) : a(a_) {}
 
-  // (re)load this thread's register slices: column `row`, rows k0 .. k0 + KH of the symmetric P and S (L2 hits).
-  // Called after every factorisation so that the slices are dead - and their 2 KH registers free - during it.
+  // load this thread's register slices once per launch: column `row`, rows k0 .. k0 + KH of the symmetric P and S.
+  // (Reloading them per trajectory makes the compiler hoist 2 KH 64-bit addresses out of the loops: 4 KH registers.)
   __device__ __forceinline__ void load_slices() {
 #pragma unroll
     for (int kk = 0; kk < KH; ++kk) {
@@ -125,6 +126,10 @@ template <typename T, int KH> struct FusedChain {
     if (NS >= 2) { T* const h3 = hi ? o31 : o30; h3[row] = a3[0] + a3[1]; }
   }
 
+  T ev_next;                    // this thread's element of the next evaluation's jitter
+  __device__ __forceinline__ T jitter_elem(uint32_t n, uint32_t sub) {
+    return (a.has_jitter && tid < D) ? a.jitter * uniform_elem<T>(a.seed, chain, n, PURPOSE_JITTER, sub, tid) : (T)0;
+  }
   // jitter of evaluation `sub` of trajectory n  (S:113-115)
   __device__ __forceinline__ void draw_jitter(uint32_t n, uint32_t sub) {
     if (tid < D) ev[tid] = a.has_jitter ? a.jitter * uniform_elem<T>(a.seed, chain, n, PURPOSE_JITTER, sub, tid) : (T)0;
@@ -242,13 +247,15 @@ template <typename T, int KH> struct FusedChain {
     }
   }
 
-  // one half step (csrc/rmhmc_explicit.hip:half_step): upd_x += eh G(X)^-1 m ; upd_g -= eh P (X - mu)
-  __device__ __forceinline__ void half_step(uint32_t n, uint32_t sub, const T* X, const T* m, T* upd_x, T* upd_g, T eh) {
+  // one half step (csrc/rmhmc_explicit.hip:half_step): upd_x += eh G(X)^-1 m ; upd_g -= eh P (X - mu).
+  // The jitter of this evaluation was drawn during the previous one (ev_next: the Philox rounds run under that
+  // evaluation's LDS traffic); `next_sub` is the sub-stream of the evaluation that follows.
+  __device__ __forceinline__ void half_step(uint32_t n, uint32_t next_sub, const T* X, const T* m, T* upd_x, T* upd_g, T eh) {
     __syncthreads();
-    draw_jitter(n, sub);
-    if (tid < D) d[tid] = X[tid] - a.mu[tid];
+    if (tid < D) { ev[tid] = ev_next; d[tid] = X[tid] - mu_r; }
     __syncthreads();
     products<true, 1>(d, q0, q1, m, r0, r1, nullptr, nullptr, nullptr);
+    ev_next = jitter_elem(n, next_sub);
     __syncthreads();
     if (tid < D) {
       upd_g[tid] -= eh * (q0[tid] + q1[tid]);
@@ -263,10 +270,10 @@ template <typename T, int KH> struct FusedChain {
   __device__ __forceinline__ T hamiltonian(uint32_t n, uint32_t sub, const T* X, const T* m, T& logp_out) {
     __syncthreads();
     draw_jitter(n, sub);
-    if (tid < D) d[tid] = X[tid] - a.mu[tid];
+    if (tid < D) d[tid] = X[tid] - mu_r;
     T ld_part = 0;
     const bool series = a.series || !a.has_jitter;
-    if (!series) { ld_part = factor(); load_slices(); }     // exact: Cholesky of P + E
+    if (!series) ld_part = factor();                        // exact: Cholesky of P + E
     __syncthreads();
     if (series && a.has_jitter) products<true, 2>(d, q0, q1, m, r0, r1, ev, s0, s1);
     else products<true, 1>(d, q0, q1, m, r0, r1, nullptr, nullptr, nullptr);
@@ -293,7 +300,7 @@ template <typename T, int KH> struct FusedChain {
 constexpr int FVEC = 18;          // LDS vectors of a chain (each padded to 128 entries, zero beyond D)
 
 template <typename T, int KH>
-__global__ __launch_bounds__(FNT) void rmhmc_fused_kernel(FusedArgs<T> a, int ld) {
+__global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int ld) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   FusedChain<T, KH> ch(a);
   const int D = a.D, tid = threadIdx.x;
@@ -315,11 +322,13 @@ __global__ __launch_bounds__(FNT) void rmhmc_fused_kernel(FusedArgs<T> a, int ld
   for (int e = tid; e < FVEC * Dp; e += FNT) v[e] = (T)0;
   __syncthreads();
   if (tid < D) ch.sdiag[tid] = a.S[(int64_t)tid * D + tid];
+  ch.mu_r = tid < D ? a.mu[tid] : (T)0;
   const T eh = (T)0.5 * a.eps;
 #if HTA_RM_TIMING
   __syncthreads();
   ch.tlast = __builtin_readcyclecounter();
 #endif
+  ch.load_slices();
   bool have_factor = false;                                 // without jitter chol(P) serves every chain and trajectory
   for (int64_t c = blockIdx.x; c < a.C; c += gridDim.x) {
     ch.chain = a.chain_offset + (uint64_t)c;
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(FNT) void rmhmc_fused_kernel(FusedArgs<T> a, int ld
       __syncthreads();
       HTA_RTICK(0);
       ch.draw_jitter(n, 0);
-      if (a.has_jitter || !have_factor) { ch.factor(); have_factor = true; ch.load_slices(); }
+      if (a.has_jitter || !have_factor) { ch.factor(); have_factor = true; }
       HTA_RTICK(1);
       if (tid < D) ch.d[tid] = normal_elem<T>(a.seed, ch.chain, n, 0, tid);
       __syncthreads();
@@ -354,8 +363,9 @@ __global__ __launch_bounds__(FNT) void rmhmc_fused_kernel(FusedArgs<T> a, int ld
       // ---- L explicit steps (S:427-461)
       for (int l = 0; l < a.L; ++l) {
         const uint32_t k0 = 2u + 8u * (uint32_t)l;
-        ch.half_step(n, k0 + 1, ch.th, ch.pmc, ch.thc, ch.pm, eh);          // phi_A/2  S:429-430
-        ch.half_step(n, k0 + 2, ch.thc, ch.pm, ch.th, ch.pmc, eh);          // phi_B/2  S:432-433
+        if (l == 0) ch.ev_next = ch.jitter_elem(n, k0 + 1);
+        ch.half_step(n, k0 + 2, ch.th, ch.pmc, ch.thc, ch.pm, eh);          // phi_A/2  S:429-430 (sub-stream k0 + 1)
+        ch.half_step(n, k0 + 4, ch.thc, ch.pm, ch.th, ch.pmc, eh);          // phi_B/2  S:432-433 (k0 + 2)
         if (tid < D) {                                                        // phi_C    S:447-450, sequential (Q1)
           T xx = ch.th[tid], b = ch.pm[tid], xc = ch.thc[tid], bc = ch.pmc[tid];
           const T h = (T)0.5, cc = a.rot_c, ss = a.rot_s;
@@ -365,8 +375,8 @@ __global__ __launch_bounds__(FNT) void rmhmc_fused_kernel(FusedArgs<T> a, int ld
           bc = h * ((b + bc) + ss * (xx - xc) - cc * (b - bc));
           ch.th[tid] = xx; ch.pm[tid] = b; ch.thc[tid] = xc; ch.pmc[tid] = bc;
         }
-        ch.half_step(n, k0 + 4, ch.thc, ch.pm, ch.th, ch.pmc, eh);          // phi_B/2  S:454-455
-        ch.half_step(n, k0 + 7, ch.th, ch.pmc, ch.thc, ch.pm, eh);          // phi_A/2  S:457-458
+        ch.half_step(n, k0 + 7, ch.thc, ch.pm, ch.th, ch.pmc, eh);          // phi_B/2  S:454-455 (k0 + 4)
+        ch.half_step(n, k0 + 8 + 1, ch.th, ch.pmc, ch.thc, ch.pm, eh);      // phi_A/2  S:457-458 (k0 + 7); next: step l + 1
       }
       // ---- H_new on the un-augmented pair (S:989, Q4), sub-stream 2 + 8L
       HTA_RTICK(4);
