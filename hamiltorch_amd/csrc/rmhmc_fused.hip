@@ -29,7 +29,7 @@
 #if HTA_RM_TIMING
 __device__ unsigned long long hta_rm_dbg[8];
 extern "C" void hta_rm_dbg_read(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(hta_rm_dbg), sizeof(hta_rm_dbg)); }
-#define HTA_RTICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); ch.tacc[k] += now_ - ch.tlast; ch.tlast = now_; } while (0)
+#define HTA_RTICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); ch.tacc[0] += now_ - ch.tlast; ch.tlast = now_; } while (0)
 #define HTA_MTICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[k] += now_ - tlast; tlast = now_; } while (0)
 #else
 #define HTA_RTICK(k) do {} while (0)
@@ -194,6 +194,7 @@ template <typename T, int KH> struct FusedChain {
           lrow[c] = v * rinv[c];
         }
       }
+      HTA_MTICK(2);
       __syncthreads();                                     // every thread has read the old panel / diagonal block
       if (below) {
 #pragma unroll
@@ -231,6 +232,7 @@ template <typename T, int KH> struct FusedChain {
           if (two) wrow[j2] = v2;
         }
       }
+      HTA_MTICK(3);
       __syncthreads();
       HTA_MTICK(7);
     }

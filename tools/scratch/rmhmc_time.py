@@ -29,7 +29,7 @@ lib = ctypes.CDLL(_abi.LIB_PATH)
 if hasattr(lib, "hta_rm_dbg_read"):
     buf = (ctypes.c_ulonglong * 8)()
     lib.hta_rm_dbg_read(buf)
-    names = ["other (MH, copies)", "gibbs: factor fill/rest", "gibbs: L z", "H_old", "steps", "H_new", "factor: panel", "factor: trailing"]
+    names = ["other + steps + H", "factor: fill / top", "factor: panel compute", "factor: trailing compute", "-", "-", "factor: panel barriers+writes", "factor: trailing barrier wait"]
     tot = sum(buf)
     for k in range(8):
         print("   %-20s %12d cycles  %5.1f %%" % (names[k], buf[k], 100.0 * buf[k] / max(1, tot)))
