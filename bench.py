@@ -135,7 +135,7 @@ class Cfg3:
         self.samples = torch.empty(self.T + 1, self.C, self.D, device=dev)
         self.samples[0].copy_(self.theta0)
         self.rej = torch.zeros(self.C, dtype=torch.int32, device=dev)
-        self.ws = torch.empty(_abi.rmhmc_workspace_bytes(self.C, self.D, 4), dtype=torch.uint8, device=dev)
+        self.ws = torch.empty(_abi.rmhmc_workspace_bytes(self.C, self.D, 4, self.T), dtype=torch.uint8, device=dev)
 
     def units_per_step(self):
         return self.C * self.T * self.L

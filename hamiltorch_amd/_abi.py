@@ -263,8 +263,12 @@ def metric_eval(like, B, D, metric, Hs, hs_stride, alpha, jitter=None, seed=0, c
         _check(fn(ctypes.byref(a), _stream(like)), "hta_metric_eval")
 
 
-def rmhmc_workspace_bytes(C, D, itemsize):
-    return int(load().hta_rmhmc_workspace_bytes(int(C), int(D), int(itemsize)))
+def rmhmc_workspace_bytes(C, D, itemsize, n_traj=0, cap_bytes=256 << 20):
+    """Base layout plus room for the pre-drawn momenta of up to `n_traj` trajectories (capped at `cap_bytes`)."""
+    base = int(load().hta_rmhmc_workspace_bytes(int(C), int(D), int(itemsize)))
+    per = int(C) * int(D) * int(itemsize)
+    extra = min(int(n_traj), max(0, cap_bytes // max(per, 1))) * per
+    return base + extra
 
 
 def rmhmc_gaussian_leapfrog(theta, p, theta_c, p_c, P, mu, metric, alpha, jitter, seed, chain_offset, draw, steps, eps,

@@ -37,6 +37,6 @@ template <typename T>
 int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, const T* mu, double log_norm, double logdetP,
                        int has_jitter, double jitter, int K, int series, int64_t C, int D, int L, double eps, double omega,
                        int n_traj, int traj_offset, int burn, uint64_t seed, uint64_t chain_offset, T* samples,
-                       int32_t* reject_count, T* H_old, T* H_new, uint8_t* accept, hipStream_t s);
+                       int32_t* reject_count, T* H_old, T* H_new, uint8_t* accept, T* p_ws, int64_t p_ws_elems, hipStream_t s);
 
 }  // namespace hta

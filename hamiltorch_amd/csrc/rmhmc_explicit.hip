@@ -126,9 +126,14 @@ int rmhmc_sample(T* cur, const T* theta_init, const T* P, const T* mu, double lo
     if (K >= 0) {
       int rc = inverse_from_eigen<T>(V0, lam0, Sinv, D, s);
       if (rc) return rc;
+      // room for pre-drawn momenta: whatever the caller's workspace holds beyond the base layout, else the (unused on
+      // this path) augmented-state area at its head: 4 trajectories per pass
+      T* p_ws = Sinv + (int64_t)D * D;
+      int64_t p_elems = workspace_bytes / (int64_t)sizeof(T) - (p_ws - (T*)workspace);
+      if (p_elems < total) { p_ws = th; p_elems = 4 * total; }
       return rmhmc_fused_sample<T>(cur, theta_init, P, Sinv, mu, log_norm, logdetP, has_jitter, jitter, K, series, C, D, L, eps,
                                    omega, n_traj, traj_offset, burn, seed, chain_offset, samples, reject_count, H_old_out,
-                                   H_new_out, accept_out, s);
+                                   H_new_out, accept_out, p_ws, p_elems, s);
     }
   }
   for (int t = 0; t < n_traj; ++t) {

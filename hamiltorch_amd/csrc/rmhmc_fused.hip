@@ -47,10 +47,112 @@ template <typename T> struct FusedArgs {
   int64_t C; int D; int L; T eps; T rot_c; T rot_s;
   int n_traj; int traj_offset; int burn; uint64_t seed; uint64_t chain_offset;
   T* samples; int32_t* reject_count; T* H_old; T* H_new; uint8_t* accept;
+  const T* p_ws;                // pre-drawn momenta [n_traj, C, D] (rmhmc_momentum_kernel) or NULL: factor in the kernel
 };
 
 template <typename T> __device__ __forceinline__ T fast_rsqrt(T v) { return (T)1 / sqrt(v); }
 template <> __device__ __forceinline__ float fast_rsqrt<float>(float v) { return __builtin_amdgcn_rsqf(v); }   // v_rsq_f32, 1 ulp
+
+// W = P + diag(ev) -> its Cholesky factor (strictly-lower part in W, diagonal in dg), right-looking in panels of
+// FCB columns: the panel rows are one thread each (the FCB x FCB diagonal block is refactored by every thread from
+// LDS: no extra barrier), the rank-FCB trailing update a 16 x 16 thread tile with the panel rows it needs in
+// registers.  Returns this thread's share of log |F| (sum over threads = log |F|).
+template <typename T>
+__device__ __forceinline__ T chol_in_lds(const T* __restrict__ P, const T* ev, T* W, T* dg, int D, int ld, int tid) {
+  __syncthreads();
+  {
+    const float invD = 1.0f / (float)D;
+    for (int e0 = tid; e0 < D * D; e0 += 8 * FNT) {       // 8 independent L2 loads in flight per thread
+      T t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int e = e0 + u * FNT; t[u] = e < D * D ? P[e] : (T)0; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * FNT;
+        int i = (int)(((float)e + 0.5f) * invD);             // e / D without the integer divide (e < 2^14)
+        const int j = e - i * D;
+        if (e < D * D && j <= i) W[i * ld + j] = t[u] + (i == j ? ev[i] : (T)0);
+      }
+    }
+  }
+  __syncthreads();
+  const int tx = tid & 15, ty = tid >> 4;
+  for (int kb = 0; kb < D; kb += FCB) {
+    const int nb = min(FCB, D - kb);
+    // --- panel: diagonal block factor (registers, every thread), then this thread's row of the panel
+    T Ld[FCB][FCB], rinv[FCB];
+#pragma unroll
+    for (int c = 0; c < FCB; ++c)
+#pragma unroll
+      for (int c2 = 0; c2 < FCB; ++c2) Ld[c][c2] = (c < nb && c2 <= c) ? W[(kb + c) * ld + kb + c2] : (T)(c == c2);
+#pragma unroll
+    for (int c = 0; c < FCB; ++c) {
+#pragma unroll
+      for (int c2 = 0; c2 < c; ++c2) {
+        T v = Ld[c][c2];
+#pragma unroll
+        for (int c3 = 0; c3 < c2; ++c3) v = fma(-Ld[c][c3], Ld[c2][c3], v);
+        Ld[c][c2] = v * rinv[c2];
+      }
+      T v = Ld[c][c];
+#pragma unroll
+      for (int c3 = 0; c3 < c; ++c3) v = fma(-Ld[c][c3], Ld[c][c3], v);
+      rinv[c] = fast_rsqrt<T>(v);
+      Ld[c][c] = v * rinv[c];
+    }
+    T lrow[FCB];
+    const int i = kb + FCB + tid;                       // rows below the diagonal block: one thread each
+    const bool below = i < D;
+    if (below) {
+#pragma unroll
+      for (int c = 0; c < FCB; ++c) {
+        T v = c < nb ? W[i * ld + kb + c] : (T)0;
+#pragma unroll
+        for (int c3 = 0; c3 < c; ++c3) v = fma(-lrow[c3], Ld[c][c3], v);
+        lrow[c] = v * rinv[c];
+      }
+    }
+    __syncthreads();                                     // every thread has read the old panel / diagonal block
+    if (below) {
+#pragma unroll
+      for (int c = 0; c < FCB; ++c) if (c < nb) W[i * ld + kb + c] = lrow[c];
+    }
+#pragma unroll
+    for (int c = 0; c < FCB; ++c) {                      // rows of the diagonal block itself (static indices: Ld stays in registers)
+      if (tid == c && c < nb) {
+        dg[kb + c] = Ld[c][c];
+#pragma unroll
+        for (int c2 = 0; c2 < c; ++c2) W[(kb + c) * ld + kb + c2] = Ld[c][c2];
+      }
+    }
+    __syncthreads();
+    // --- trailing update with the finished panel: rows ii = r0 + 16 a (a-th slot of ty), columns j = c0 + 16 b (tx)
+    const int rbase = kb + FCB + ty, cbase = kb + FCB + tx;
+    for (int ii = rbase; ii < D; ii += 16) {
+      T* wrow = W + ii * ld;
+      T li[FCB];
+#pragma unroll
+      for (int c = 0; c < FCB; ++c) li[c] = wrow[kb + c];
+      for (int j = cbase; j <= ii; j += 32) {            // two column slots per trip: both sets of loads in flight together
+        const int j2 = j + 16;
+        const bool two = j2 <= ii;
+        const T* p1 = W + j * ld + kb;
+        const T* p2 = W + (two ? j2 : j) * ld + kb;
+        T l1[FCB], l2[FCB];
+#pragma unroll
+        for (int c = 0; c < FCB; ++c) { l1[c] = p1[c]; l2[c] = p2[c]; }
+        T v1 = wrow[j], v2 = wrow[two ? j2 : j];
+#pragma unroll
+        for (int c = 0; c < FCB; ++c) { v1 = fma(-li[c], l1[c], v1); v2 = fma(-li[c], l2[c], v2); }
+        wrow[j] = v1;
+        if (two) wrow[j2] = v2;
+      }
+    }
+    __syncthreads();
+  }
+  return tid < D ? (T)2 * log(dg[tid]) : (T)0;
+}
+
 
 // KH: register-resident slice of a matrix column per thread (multiple of 8).  Thread (row, half) keeps P[k][row] and
 // S[k][row] for its KH values of k in VGPRs for the whole launch; a matrix-vector product then only streams the
@@ -135,109 +237,7 @@ template <typename T, int KH> struct FusedChain {
     if (tid < D) ev[tid] = a.has_jitter ? a.jitter * uniform_elem<T>(a.seed, chain, n, PURPOSE_JITTER, sub, tid) : (T)0;
   }
 
-  // W = P + diag(ev) -> its Cholesky factor (strictly-lower part in W, diagonal in dg), right-looking in panels of
-  // FCB columns: the panel rows are one thread each (the FCB x FCB diagonal block is refactored by every thread from
-  // LDS: no extra barrier), the rank-FCB trailing update a 16 x 16 thread tile with the panel rows it needs in
-  // registers.  Returns this thread's share of log |F| (sum over threads = log |F|).
-  __device__ __forceinline__ T factor() {
-    __syncthreads();
-    {
-      const float invD = 1.0f / (float)D;
-      for (int e0 = tid; e0 < D * D; e0 += 8 * FNT) {       // 8 independent L2 loads in flight per thread
-        T t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int e = e0 + u * FNT; t[u] = e < D * D ? a.P[e] : (T)0; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int e = e0 + u * FNT;
-          int i = (int)(((float)e + 0.5f) * invD);             // e / D without the integer divide (e < 2^14)
-          const int j = e - i * D;
-          if (e < D * D && j <= i) W[i * ld + j] = t[u] + (i == j ? ev[i] : (T)0);
-        }
-      }
-    }
-    __syncthreads();
-    const int tx = tid & 15, ty = tid >> 4;
-    for (int kb = 0; kb < D; kb += FCB) {
-      const int nb = min(FCB, D - kb);
-      HTA_MTICK(1);
-      // --- panel: diagonal block factor (registers, every thread), then this thread's row of the panel
-      T Ld[FCB][FCB], rinv[FCB];
-#pragma unroll
-      for (int c = 0; c < FCB; ++c)
-#pragma unroll
-        for (int c2 = 0; c2 < FCB; ++c2) Ld[c][c2] = (c < nb && c2 <= c) ? W[(kb + c) * ld + kb + c2] : (T)(c == c2);
-#pragma unroll
-      for (int c = 0; c < FCB; ++c) {
-#pragma unroll
-        for (int c2 = 0; c2 < c; ++c2) {
-          T v = Ld[c][c2];
-#pragma unroll
-          for (int c3 = 0; c3 < c2; ++c3) v = fma(-Ld[c][c3], Ld[c2][c3], v);
-          Ld[c][c2] = v * rinv[c2];
-        }
-        T v = Ld[c][c];
-#pragma unroll
-        for (int c3 = 0; c3 < c; ++c3) v = fma(-Ld[c][c3], Ld[c][c3], v);
-        rinv[c] = fast_rsqrt<T>(v);
-        Ld[c][c] = v * rinv[c];
-      }
-      T lrow[FCB];
-      const int i = kb + FCB + tid;                       // rows below the diagonal block: one thread each
-      const bool below = i < D;
-      if (below) {
-#pragma unroll
-        for (int c = 0; c < FCB; ++c) {
-          T v = c < nb ? W[i * ld + kb + c] : (T)0;
-#pragma unroll
-          for (int c3 = 0; c3 < c; ++c3) v = fma(-lrow[c3], Ld[c][c3], v);
-          lrow[c] = v * rinv[c];
-        }
-      }
-      HTA_MTICK(2);
-      __syncthreads();                                     // every thread has read the old panel / diagonal block
-      if (below) {
-#pragma unroll
-        for (int c = 0; c < FCB; ++c) if (c < nb) W[i * ld + kb + c] = lrow[c];
-      }
-#pragma unroll
-      for (int c = 0; c < FCB; ++c) {                      // rows of the diagonal block itself (static indices: Ld stays in registers)
-        if (tid == c && c < nb) {
-          dg[kb + c] = Ld[c][c];
-#pragma unroll
-          for (int c2 = 0; c2 < c; ++c2) W[(kb + c) * ld + kb + c2] = Ld[c][c2];
-        }
-      }
-      __syncthreads();
-      HTA_MTICK(6);
-      // --- trailing update with the finished panel: rows ii = r0 + 16 a (a-th slot of ty), columns j = c0 + 16 b (tx)
-      const int rbase = kb + FCB + ty, cbase = kb + FCB + tx;
-      for (int ii = rbase; ii < D; ii += 16) {
-        T* wrow = W + ii * ld;
-        T li[FCB];
-#pragma unroll
-        for (int c = 0; c < FCB; ++c) li[c] = wrow[kb + c];
-        for (int j = cbase; j <= ii; j += 32) {            // two column slots per trip: both sets of loads in flight together
-          const int j2 = j + 16;
-          const bool two = j2 <= ii;
-          const T* p1 = W + j * ld + kb;
-          const T* p2 = W + (two ? j2 : j) * ld + kb;
-          T l1[FCB], l2[FCB];
-#pragma unroll
-          for (int c = 0; c < FCB; ++c) { l1[c] = p1[c]; l2[c] = p2[c]; }
-          T v1 = wrow[j], v2 = wrow[two ? j2 : j];
-#pragma unroll
-          for (int c = 0; c < FCB; ++c) { v1 = fma(-li[c], l1[c], v1); v2 = fma(-li[c], l2[c], v2); }
-          wrow[j] = v1;
-          if (two) wrow[j2] = v2;
-        }
-      }
-      HTA_MTICK(3);
-      __syncthreads();
-      HTA_MTICK(7);
-    }
-    return tid < D ? (T)2 * log(dg[tid]) : (T)0;
-  }
+  __device__ __forceinline__ T factor() { return chol_in_lds<T>(a.P, ev, W, dg, D, ld, tid); }
 
   // refinement of x = (P + diag(ev))^-1 m from x0 = S m (already in x0 / x / w = ev . x): K products with S
   __device__ __forceinline__ void refine() {
@@ -342,18 +342,22 @@ __global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int
       // ---- gibbs: p = chol(G(theta)) z  (S:183-184), jitter sub-stream 0
       __syncthreads();
       HTA_RTICK(0);
-      ch.draw_jitter(n, 0);
-      if (a.has_jitter || !have_factor) { ch.factor(); have_factor = true; }
-      HTA_RTICK(1);
-      if (tid < D) ch.d[tid] = normal_elem<T>(a.seed, ch.chain, n, 0, tid);
-      __syncthreads();
-      if (tid < D) {
-        T acc0 = ch.dg[tid] * ch.d[tid], acc1 = 0;
-        const T* rowp = ch.W + tid * ld;
-        int k = 0;
-        for (; k + 1 < tid; k += 2) { acc0 = fma(rowp[k], ch.d[k], acc0); acc1 = fma(rowp[k + 1], ch.d[k + 1], acc1); }
-        if (k < tid) acc0 = fma(rowp[k], ch.d[k], acc0);
-        ch.pm[tid] = acc0 + acc1;
+      if (a.p_ws) {
+        if (tid < D) ch.pm[tid] = a.p_ws[((int64_t)t * a.C + c) * D + tid];
+      } else {
+        ch.draw_jitter(n, 0);
+        if (a.has_jitter || !have_factor) { ch.factor(); have_factor = true; }
+        HTA_RTICK(1);
+        if (tid < D) ch.d[tid] = normal_elem<T>(a.seed, ch.chain, n, 0, tid);
+        __syncthreads();
+        if (tid < D) {
+          T acc0 = ch.dg[tid] * ch.d[tid], acc1 = 0;
+          const T* rowp = ch.W + tid * ld;
+          int k = 0;
+          for (; k + 1 < tid; k += 2) { acc0 = fma(rowp[k], ch.d[k], acc0); acc1 = fma(rowp[k + 1], ch.d[k + 1], acc1); }
+          if (k < tid) acc0 = fma(rowp[k], ch.d[k], acc0);
+          ch.pm[tid] = acc0 + acc1;
+        }
       }
       __syncthreads();
       // ---- H_old (S:971 -> S:822), sub-stream 1
@@ -411,6 +415,43 @@ __global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int
   }
 }
 
+// The momentum draws of a block of trajectories, off the chains' critical path: task (t, c) -> p = chol(P + diag(e)) z
+// with the jitter sub-stream 0 and the normals of (chain c, trajectory traj_offset + t)  (S:183-184).  One workgroup per
+// task at a time, 3 per CU: the factorisations of different tasks overlap each other's LDS latency, which the chain-
+// serial kernel cannot do.  Without jitter the factor is the same for every task and is computed once per workgroup.
+template <typename T>
+__global__ __launch_bounds__(FNT) void rmhmc_momentum_kernel(const T* __restrict__ P, int has_jitter, T jitter, int64_t C, int D,
+                                                             int ld, int n_traj, int traj_offset, uint64_t seed,
+                                                             uint64_t chain_offset, T* __restrict__ p_ws) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* W = reinterpret_cast<T*>(smem_raw);
+  T* dg = W + D * ld; T* ev = dg + 128; T* z = ev + 128;
+  const int tid = threadIdx.x;
+  const int64_t ntask = (int64_t)n_traj * C;
+  bool have = false;
+  for (int64_t task = blockIdx.x; task < ntask; task += gridDim.x) {
+    const int t = (int)(task / C);
+    const int64_t c = task - (int64_t)t * C;
+    const uint64_t chain = chain_offset + (uint64_t)c;
+    const uint32_t n = (uint32_t)(traj_offset + t);
+    __syncthreads();
+    if (tid < D) {
+      ev[tid] = has_jitter ? jitter * uniform_elem<T>(seed, chain, n, PURPOSE_JITTER, 0, tid) : (T)0;
+      z[tid] = normal_elem<T>(seed, chain, n, 0, tid);
+    }
+    if (has_jitter || !have) { chol_in_lds<T>(P, ev, W, dg, D, ld, tid); have = true; }
+    __syncthreads();
+    if (tid < D) {
+      T acc0 = dg[tid] * z[tid], acc1 = 0;
+      const T* rowp = W + tid * ld;
+      int k = 0;
+      for (; k + 1 < tid; k += 2) { acc0 = fma(rowp[k], z[k], acc0); acc1 = fma(rowp[k + 1], z[k + 1], acc1); }
+      if (k < tid) acc0 = fma(rowp[k], z[k], acc0);
+      p_ws[task * D + tid] = acc0 + acc1;
+    }
+  }
+}
+
 // S = V0 diag(1 / lam0) V0^T from the eigen-system of the jitter-free P (one workgroup; once per run)
 template <typename T>
 __global__ void inverse_from_eigen_kernel(const T* __restrict__ V0, const T* __restrict__ lam0, T* __restrict__ S, int D) {
@@ -456,39 +497,61 @@ template <typename T>
 int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, const T* mu, double log_norm, double logdetP,
                        int has_jitter, double jitter, int K, int series, int64_t C, int D, int L, double eps, double omega,
                        int n_traj, int traj_offset, int burn, uint64_t seed, uint64_t chain_offset, T* samples,
-                       int32_t* reject_count, T* H_old, T* H_new, uint8_t* accept, hipStream_t s) {
+                       int32_t* reject_count, T* H_old, T* H_new, uint8_t* accept, T* p_ws, int64_t p_ws_elems, hipStream_t s) {
   int ld;
   const size_t lds = fused_lds_bytes<T>(D, &ld);
   const float ang = (float)(2.0 * omega * eps);                      // S:435-436: float32 cos / sin whatever the state dtype
-  FusedArgs<T> a{cur, theta_init, P, Sinv, mu, (T)log_norm, (T)logdetP, has_jitter, (T)jitter, K, series, C, D, L, (T)eps,
-                 (T)cosf(ang), (T)sinf(ang), n_traj, traj_offset, burn, seed, chain_offset, samples, reject_count, H_old,
-                 H_new, accept};
   const int grid = (int)(C < 8192 ? C : 8192);
   const int KH = (((D + 1) / 2) + 7) / 8 * 8;                        // register slice: half the contraction range, in eights
-  auto launch = [&](auto kern, bool& done) -> int {
-    if (!done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) { set_error("hta_rmhmc_gaussian_sample: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
-      done = true;
-    }
-    profile_begin(s);
-    kern<<<grid, FNT, lds, s>>>(a, ld);
-    profile_end(s);
-    return HTA_OK;
-  };
+  // momenta of a block of trajectories are drawn ahead by rmhmc_momentum_kernel when the workspace has room for them
+  const int64_t per_traj = C * (int64_t)D;
+  int block = (p_ws && p_ws_elems >= per_traj) ? (int)(p_ws_elems / per_traj < n_traj ? p_ws_elems / per_traj : n_traj) : 0;
   static bool done[8] = {false, false, false, false, false, false, false, false};     // per T instantiation
-  int rc;
-  switch (KH) {
-    case 8: rc = launch(&rmhmc_fused_kernel<T, 8>, done[0]); break;
-    case 16: rc = launch(&rmhmc_fused_kernel<T, 16>, done[1]); break;
-    case 24: rc = launch(&rmhmc_fused_kernel<T, 24>, done[2]); break;
-    case 32: rc = launch(&rmhmc_fused_kernel<T, 32>, done[3]); break;
-    case 40: rc = launch(&rmhmc_fused_kernel<T, 40>, done[4]); break;
-    case 48: rc = launch(&rmhmc_fused_kernel<T, 48>, done[5]); break;
-    case 56: rc = launch(&rmhmc_fused_kernel<T, 56>, done[6]); break;
-    default: rc = launch(&rmhmc_fused_kernel<T, 64>, done[7]); break;
+  static bool done_mom = false;
+  for (int t0 = 0; t0 < n_traj; t0 += (block > 0 ? block : n_traj)) {
+    const int nt = block > 0 ? (n_traj - t0 < block ? n_traj - t0 : block) : n_traj;
+    if (block > 0) {
+      const size_t mlds = ((size_t)D * ld + 3 * 128) * sizeof(T);
+      if (!done_mom) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rmhmc_momentum_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_error("hta_rmhmc_gaussian_sample: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
+        done_mom = true;
+      }
+      const int64_t ntask = (int64_t)nt * C;
+      const int mgrid = (int)(ntask < 256 * 12 ? ntask : 256 * 12);
+      profile_begin(s);
+      rmhmc_momentum_kernel<T><<<mgrid, FNT, mlds, s>>>(P, has_jitter, (T)jitter, C, D, ld, nt, traj_offset + t0, seed, chain_offset, p_ws);
+      profile_end(s);
+    }
+    FusedArgs<T> a{cur, theta_init, P, Sinv, mu, (T)log_norm, (T)logdetP, has_jitter, (T)jitter, K, series, C, D, L, (T)eps,
+                   (T)cosf(ang), (T)sinf(ang), nt, traj_offset + t0, burn, seed, chain_offset, samples, reject_count,
+                   H_old ? H_old + (int64_t)t0 * C : nullptr, H_new ? H_new + (int64_t)t0 * C : nullptr,
+                   accept ? accept + (int64_t)t0 * C : nullptr, block > 0 ? p_ws : nullptr};
+    auto launch = [&](auto kern, bool& dn) -> int {
+      if (!dn) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_error("hta_rmhmc_gaussian_sample: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
+        dn = true;
+      }
+      profile_begin(s);
+      kern<<<grid, FNT, lds, s>>>(a, ld);
+      profile_end(s);
+      return HTA_OK;
+    };
+    int rc;
+    switch (KH) {
+      case 8: rc = launch(&rmhmc_fused_kernel<T, 8>, done[0]); break;
+      case 16: rc = launch(&rmhmc_fused_kernel<T, 16>, done[1]); break;
+      case 24: rc = launch(&rmhmc_fused_kernel<T, 24>, done[2]); break;
+      case 32: rc = launch(&rmhmc_fused_kernel<T, 32>, done[3]); break;
+      case 40: rc = launch(&rmhmc_fused_kernel<T, 40>, done[4]); break;
+      case 48: rc = launch(&rmhmc_fused_kernel<T, 48>, done[5]); break;
+      case 56: rc = launch(&rmhmc_fused_kernel<T, 56>, done[6]); break;
+      default: rc = launch(&rmhmc_fused_kernel<T, 64>, done[7]); break;
+    }
+    if (rc) return rc;
   }
-  if (rc) return rc;
   HTA_CHECK_LAUNCH("hta_rmhmc_gaussian_sample (fused)");
   return HTA_OK;
 }
@@ -504,7 +567,7 @@ template <typename T> int inverse_from_eigen(const T* V0, const T* lam0, T* S, i
   template int inverse_from_eigen<T>(const T*, const T*, T*, int, hipStream_t);                                       \
   template int rmhmc_fused_sample<T>(T*, const T*, const T*, const T*, const T*, double, double, int, double, int,   \
                                      int, int64_t, int, int, double, double, int, int, int, uint64_t, uint64_t, T*,   \
-                                     int32_t*, T*, T*, uint8_t*, hipStream_t);
+                                     int32_t*, T*, T*, uint8_t*, T*, int64_t, hipStream_t);
 HTA_INST(float)
 HTA_INST(double)
 

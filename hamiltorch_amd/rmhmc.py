@@ -222,7 +222,7 @@ def sample_explicit(log_prob_func, theta0, N, L, eps, burn, jitter, softabs_cons
     samples[0].copy_(theta0)
     cur = theta0.clone()
     rejected = torch.zeros(C, dtype=torch.int32, device=theta0.device)
-    ws = torch.empty(_abi.rmhmc_workspace_bytes(C, D, theta0.element_size()), dtype=torch.uint8, device=theta0.device)
+    ws = torch.empty(_abi.rmhmc_workspace_bytes(C, D, theta0.element_size(), N), dtype=torch.uint8, device=theta0.device)
     prog = util._Progress('Sampling (Sampler.RMHMC; Integrator.EXPLICIT)', N, verbose)
     _abi.rmhmc_gaussian_sample(cur, theta0, tgt.precision, tgt.mean, tgt.log_norm, kind, softabs_const, jitter, L, eps,
                                omega, N, 0, burn, seed, chain_offset, samples, rejected, ws)

@@ -208,7 +208,9 @@ int hta_rmhmc_gaussian_leapfrog_f64(double* theta, double* p, double* theta_copy
 
 /* sample(sampler=RMHMC, integrator=EXPLICIT) (S:969-1026) for a Gaussian target: enqueues every
  * launch of `n_traj` trajectories; arguments as hta_hmc_gaussian_sample.  workspace:
- * hta_rmhmc_workspace_bytes(C, D, sizeof(T)) bytes (required). */
+ * hta_rmhmc_workspace_bytes(C, D, sizeof(T)) bytes at least (required).  Every further C*D*sizeof(T) bytes let the
+ * fused path (soft-abs map == identity on the target's spectrum, csrc/rmhmc_fused.hip) draw the momenta of one more
+ * trajectory per pass ahead of the chains (full-chip Cholesky batch); with the minimum it works in passes of 4. */
 int64_t hta_rmhmc_workspace_bytes(int64_t C, int D, int elem_size);
 int hta_rmhmc_gaussian_sample_f32(float* theta, const float* theta_init, const float* P, const float* mu,
                                   double log_norm, int metric, double alpha, int has_jitter, double jitter,

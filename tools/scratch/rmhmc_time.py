@@ -11,7 +11,7 @@ P = (Q * torch.linspace(0.5, 2.0, D, dtype=torch.float64)) @ Q.T
 P = 0.5 * (P + P.T)
 tgt = ht.GaussianTarget(torch.zeros(D, device=dev), precision=P.float().to(dev), normalized=False)
 th0 = (0.1 * torch.randn(C, D, generator=g)).to(dev)
-ws = torch.empty(_abi.rmhmc_workspace_bytes(C, D, 4), dtype=torch.uint8, device=dev)
+ws = torch.empty(_abi.rmhmc_workspace_bytes(C, D, 4, T), dtype=torch.uint8, device=dev)
 for L, jit in ((0, 1e-3), (10, 1e-3), (10, None), (20, 1e-3)):
     cur = th0.clone(); rej = torch.zeros(C, dtype=torch.int32, device=dev)
     best = 1e9
