@@ -136,6 +136,11 @@ class Cfg3:
         self.samples[0].copy_(self.theta0)
         self.rej = torch.zeros(self.C, dtype=torch.int32, device=dev)
         self.ws = torch.empty(_abi.rmhmc_workspace_bytes(self.C, self.D, 4, self.T), dtype=torch.uint8, device=dev)
+        if os.environ.get("HTA_RMHMC_FUSED", "1") == "0":      # reproduce the general (eigendecomposition per evaluation) path
+            _abi.set_tuning("rmhmc_fused", 0)
+            self.name += " [Jacobi path forced]"
+            self.roof_kernel = "metric_eval_kernel<float,2,2>"
+            self.flops_per_unit = lambda: 4 * 11.3 * self.D ** 3
 
     def units_per_step(self):
         return self.C * self.T * self.L
