@@ -415,6 +415,213 @@ __global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int
   }
 }
 
+// ---- two chains per workgroup -------------------------------------------------------------------------------------
+// From ~1000 chains per GPU on, several chains share a CU.  The register-resident slices of P and S do not depend on the
+// chain, so one workgroup can carry TWO chains through every product pass: twice the FMAs per slice element read, the
+// same number of barriers and LDS round trips.  Element-wise work is split by thread half: threads 0..127 own chain 0 of
+// the pair, threads 128..255 chain 1.  Needs the pre-drawn momenta (p_ws) and the log-det series (or no jitter): no
+// Cholesky, hence no work matrix, in this kernel.
+constexpr int F2V = 16;           // per-chain LDS vectors of the pair kernel
+
+template <typename T, int KH> struct FusedPair {
+  typedef T V4 __attribute__((ext_vector_type(4)));
+  static constexpr int CHS = F2V * 128;      // stride between the two chains' vector sets
+  const FusedArgs<T>& a;
+  int D, tid, row, k0, ei;
+  bool rowok, hi, eok;
+  T Preg[KH], Sreg[KH];
+  T mu_r, sd_r, ev_next;
+  // vector sets (chain 0 at the pointer, chain 1 at + CHS); `my` = the set of this thread's own chain
+  T *cur, *th, *pm, *thc, *pmc, *ev, *d, *x0, *x, *w, *q0, *q1, *r0, *r1, *s0, *s1, *red;
+  int my;
+  uint64_t chain;
+  __device__ FusedPair(const FusedArgs<T>& a_) : a(a_) {}
+
+  __device__ __forceinline__ void block_sum4(T (&v)[4]) {          // sums over the two waves of this thread's chain
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = wave_sum(v[q]);
+    __syncthreads();
+    if ((tid & 63) == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[4 * (tid >> 6) + q] = v[q];
+    }
+    __syncthreads();
+    const int w0 = (tid >> 7) * 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = red[4 * w0 + q] + red[4 * (w0 + 1) + q];
+  }
+
+  template <bool WITH_P, int NS>
+  __device__ __forceinline__ void products(const T* v1, T* o10, T* o11, const T* v2, T* o20, T* o21, const T* v3, T* o30, T* o31) {
+    T a1[2] = {0, 0}, a2[2] = {0, 0}, a3[2] = {0, 0};
+#pragma unroll
+    for (int kk = 0; kk < KH; kk += 4) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        V4 u1, u2, u3;
+        if (WITH_P) u1 = *reinterpret_cast<const V4*>(v1 + q * CHS + k0 + kk);
+        if (NS >= 1) u2 = *reinterpret_cast<const V4*>(v2 + q * CHS + k0 + kk);
+        if (NS >= 2) u3 = *reinterpret_cast<const V4*>(v3 + q * CHS + k0 + kk);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (WITH_P) a1[q] = fma(Preg[kk + e], u1[e], a1[q]);
+          if (NS >= 1) a2[q] = fma(Sreg[kk + e], u2[e], a2[q]);
+          if (NS >= 2) a3[q] = fma(Sreg[kk + e] * Sreg[kk + e], u3[e], a3[q]);
+        }
+      }
+    }
+    if (!rowok) return;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (WITH_P) { T* const h1 = (hi ? o11 : o10) + q * CHS; h1[row] = a1[q]; }
+      if (NS >= 1) { T* const h2 = (hi ? o21 : o20) + q * CHS; h2[row] = a2[q]; }
+      if (NS >= 2) { T* const h3 = (hi ? o31 : o30) + q * CHS; h3[row] = a3[q]; }
+    }
+  }
+
+  __device__ __forceinline__ T jitter_elem(uint32_t n, uint32_t sub) {
+    return (a.has_jitter && eok) ? a.jitter * uniform_elem<T>(a.seed, chain, n, PURPOSE_JITTER, sub, ei) : (T)0;
+  }
+
+  __device__ __forceinline__ void refine() {
+    for (int it = 0; it < a.K; ++it) {
+      __syncthreads();
+      products<false, 1>(nullptr, nullptr, nullptr, w, r0, r1, nullptr, nullptr, nullptr);
+      __syncthreads();
+      if (eok) { const T xn = x0[my + ei] - (r0[my + ei] + r1[my + ei]); x[my + ei] = xn; w[my + ei] = ev[my + ei] * xn; }
+    }
+  }
+
+  __device__ __forceinline__ void half_step(uint32_t n, uint32_t next_sub, const T* X, const T* m, T* upd_x, T* upd_g, T eh) {
+    __syncthreads();
+    if (eok) { ev[my + ei] = ev_next; d[my + ei] = X[my + ei] - mu_r; }
+    __syncthreads();
+    products<true, 1>(d, q0, q1, m, r0, r1, nullptr, nullptr, nullptr);
+    ev_next = jitter_elem(n, next_sub);
+    __syncthreads();
+    if (eok) {
+      upd_g[my + ei] -= eh * (q0[my + ei] + q1[my + ei]);
+      const T xs = r0[my + ei] + r1[my + ei];
+      x0[my + ei] = xs; x[my + ei] = xs; w[my + ei] = ev[my + ei] * xs;
+    }
+    refine();
+    if (eok) upd_x[my + ei] += eh * x[my + ei];
+  }
+
+  __device__ __forceinline__ T hamiltonian(uint32_t n, uint32_t sub, const T* X, const T* m, T& logp_out) {
+    __syncthreads();
+    if (eok) { ev[my + ei] = jitter_elem(n, sub); d[my + ei] = X[my + ei] - mu_r; }
+    __syncthreads();
+    if (a.has_jitter) products<true, 2>(d, q0, q1, m, r0, r1, ev, s0, s1);
+    else products<true, 1>(d, q0, q1, m, r0, r1, nullptr, nullptr, nullptr);
+    __syncthreads();
+    T dPd = 0, ld_part = 0;
+    if (eok) {
+      dPd = d[my + ei] * (q0[my + ei] + q1[my + ei]);
+      const T xs = r0[my + ei] + r1[my + ei];
+      x0[my + ei] = xs; x[my + ei] = xs; w[my + ei] = ev[my + ei] * xs;
+      if (a.has_jitter) ld_part = ev[my + ei] * (sd_r - (T)0.5 * (s0[my + ei] + s1[my + ei]));
+    }
+    refine();
+    T v[4] = {dPd, eok ? m[my + ei] * x[my + ei] : (T)0, ld_part, (T)0};
+    block_sum4(v);
+    const T lp = a.log_norm - (T)0.5 * v[0];
+    logp_out = lp;
+    const float pi_term = (float)D * 1.8378770351409912f;     // S:712
+    return -lp + (T)0.5 * (T)pi_term + (T)0.5 * (a.logdetP + v[2]) + (T)0.5 * v[1];
+  }
+};
+
+template <typename T, int KH>
+__global__ __launch_bounds__(FNT, 2) void rmhmc_fused_pair_kernel(FusedArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  FusedPair<T, KH> ch(a);
+  const int D = a.D, tid = threadIdx.x;
+  ch.D = D; ch.tid = tid;
+  {
+    const int wave = tid >> 6;
+    ch.row = (wave & 1) * 64 + (tid & 63);
+    ch.rowok = ch.row < D;
+    ch.hi = wave >> 1;
+    ch.k0 = ch.hi ? KH : 0;
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk) {
+      const int k = ch.k0 + kk;
+      const bool ok = ch.rowok && k < D;
+      ch.Preg[kk] = ok ? a.P[(int64_t)k * D + ch.row] : (T)0;
+      ch.Sreg[kk] = ok ? a.S[(int64_t)k * D + ch.row] : (T)0;
+    }
+  }
+  T* v = reinterpret_cast<T*>(smem_raw);
+  T** slots[F2V] = {&ch.cur, &ch.th, &ch.pm, &ch.thc, &ch.pmc, &ch.ev, &ch.d, &ch.x0, &ch.x, &ch.w,
+                    &ch.q0, &ch.q1, &ch.r0, &ch.r1, &ch.s0, &ch.s1};
+  for (int i = 0; i < F2V; ++i) *slots[i] = v + i * 128;
+  ch.red = v + 2 * F2V * 128;
+  for (int e = tid; e < 2 * F2V * 128; e += FNT) v[e] = (T)0;
+  const int eq = tid >> 7;
+  ch.ei = tid & 127;
+  ch.my = eq * FusedPair<T, KH>::CHS;
+  ch.mu_r = ch.ei < D ? a.mu[ch.ei] : (T)0;
+  ch.sd_r = ch.ei < D ? a.S[(int64_t)ch.ei * D + ch.ei] : (T)0;
+  const T eh = (T)0.5 * a.eps;
+  const int64_t npair = (a.C + 1) / 2;
+  for (int64_t cp = blockIdx.x; cp < npair; cp += gridDim.x) {
+    const int64_t c = 2 * cp + eq;
+    const bool live = c < a.C;                               // an odd chain count leaves the last pair half empty
+    ch.eok = live && ch.ei < D;
+    ch.chain = a.chain_offset + (uint64_t)(live ? c : 0);
+    const int ei = ch.ei, my = ch.my;
+    __syncthreads();
+    if (ch.eok) ch.cur[my + ei] = a.cur[c * D + ei];
+    int32_t rejected = 0;
+    for (int t = 0; t < a.n_traj; ++t) {
+      const uint32_t n = (uint32_t)(a.traj_offset + t);
+      __syncthreads();
+      if (ch.eok) ch.pm[my + ei] = a.p_ws[((int64_t)t * a.C + c) * D + ei];       // S:183-184, drawn by rmhmc_momentum_kernel
+      T lp0;
+      const T H0 = ch.hamiltonian(n, 1, ch.cur, ch.pm, lp0);                     // S:971
+      if (ch.eok) { ch.th[my + ei] = ch.cur[my + ei]; ch.thc[my + ei] = ch.cur[my + ei]; ch.pmc[my + ei] = ch.pm[my + ei]; }
+      for (int l = 0; l < a.L; ++l) {
+        const uint32_t k0 = 2u + 8u * (uint32_t)l;
+        if (l == 0) ch.ev_next = ch.jitter_elem(n, k0 + 1);
+        ch.half_step(n, k0 + 2, ch.th, ch.pmc, ch.thc, ch.pm, eh);          // phi_A/2  S:429-430
+        ch.half_step(n, k0 + 4, ch.thc, ch.pm, ch.th, ch.pmc, eh);          // phi_B/2  S:432-433
+        if (ch.eok) {                                                         // phi_C    S:447-450, sequential (Q1)
+          T xx = ch.th[my + ei], b = ch.pm[my + ei], xc = ch.thc[my + ei], bc = ch.pmc[my + ei];
+          const T h = (T)0.5, cc = a.rot_c, ss = a.rot_s;
+          xx = h * ((xx + xc) + cc * (xx - xc) + ss * (b - bc));
+          b = h * ((b + bc) - ss * (xx - xc) + cc * (b - bc));
+          xc = h * ((xx + xc) - cc * (xx - xc) - ss * (b - bc));
+          bc = h * ((b + bc) + ss * (xx - xc) - cc * (b - bc));
+          ch.th[my + ei] = xx; ch.pm[my + ei] = b; ch.thc[my + ei] = xc; ch.pmc[my + ei] = bc;
+        }
+        ch.half_step(n, k0 + 7, ch.thc, ch.pm, ch.th, ch.pmc, eh);          // phi_B/2  S:454-455
+        ch.half_step(n, k0 + 8 + 1, ch.th, ch.pmc, ch.thc, ch.pm, eh);      // phi_A/2  S:457-458
+      }
+      T lp1;
+      const T H1 = ch.hamiltonian(n, 2u + 8u * (uint32_t)a.L, ch.th, ch.pm, lp1);   // S:989 (Q4)
+      const T u = u23<T>(philox_block(a.seed, ch.chain, n, PURPOSE_MH, 0, 0).x);
+      const bool acc = mh_accept<T>(H0, H1, lp1, u);                        // S:1000-1004, per chain of the pair
+      const bool reset = (!acc) && ((int)n == a.burn + 1);                    // Q2
+      __syncthreads();
+      if (ch.eok) {
+        const T vnew = acc ? ch.th[my + ei] : (reset ? a.theta_init[c * D + ei] : ch.cur[my + ei]);
+        ch.cur[my + ei] = vnew;
+        if (a.samples && (int)n > a.burn) a.samples[((int64_t)((int)n - a.burn) * a.C + c) * D + ei] = vnew;
+      }
+      if (!acc) ++rejected;
+      if (ei == 0 && live) {
+        if (a.H_old) a.H_old[(int64_t)t * a.C + c] = H0;
+        if (a.H_new) a.H_new[(int64_t)t * a.C + c] = H1;
+        if (a.accept) a.accept[(int64_t)t * a.C + c] = acc ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    if (ch.eok) a.cur[c * D + ei] = ch.cur[my + ei];
+    if (ei == 0 && live) a.reject_count[c] += rejected;
+  }
+}
+
 // The momentum draws of a block of trajectories, off the chains' critical path: task (t, c) -> p = chol(P + diag(e)) z
 // with the jitter sub-stream 0 and the normals of (chain c, trajectory traj_offset + t)  (S:183-184).  One workgroup per
 // task at a time, 3 per CU: the factorisations of different tasks overlap each other's LDS latency, which the chain-
@@ -507,6 +714,7 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
   const int64_t per_traj = C * (int64_t)D;
   int block = (p_ws && p_ws_elems >= per_traj) ? (int)(p_ws_elems / per_traj < n_traj ? p_ws_elems / per_traj : n_traj) : 0;
   static bool done[8] = {false, false, false, false, false, false, false, false};     // per T instantiation
+  static bool done2[8] = {false, false, false, false, false, false, false, false};
   static bool done_mom = false;
   for (int t0 = 0; t0 < n_traj; t0 += (block > 0 ? block : n_traj)) {
     const int nt = block > 0 ? (n_traj - t0 < block ? n_traj - t0 : block) : n_traj;
@@ -528,7 +736,21 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
                    (T)cosf(ang), (T)sinf(ang), nt, traj_offset + t0, burn, seed, chain_offset, samples, reject_count,
                    H_old ? H_old + (int64_t)t0 * C : nullptr, H_new ? H_new + (int64_t)t0 * C : nullptr,
                    accept ? accept + (int64_t)t0 * C : nullptr, block > 0 ? p_ws : nullptr};
-    auto launch = [&](auto kern, bool& dn) -> int {
+    // >= 4 chains per CU: two chains per workgroup (needs pre-drawn momenta and the log-det series)
+    const bool pair = g_rmhmc_fused != 2 && block > 0 && (series || !has_jitter) && C >= 1024;
+    auto launch = [&](auto kern, auto kern2, bool& dn, bool& dn2) -> int {
+      if (pair) {
+        if (!dn2) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          if (e != hipSuccess) { set_error("hta_rmhmc_gaussian_sample: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
+          dn2 = true;
+        }
+        const int64_t npair = (C + 1) / 2;
+        profile_begin(s);
+        kern2<<<(int)(npair < 8192 ? npair : 8192), FNT, (2 * F2V * 128 + 32) * sizeof(T), s>>>(a);
+        profile_end(s);
+        return HTA_OK;
+      }
       if (!dn) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { set_error("hta_rmhmc_gaussian_sample: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
@@ -541,14 +763,14 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
     };
     int rc;
     switch (KH) {
-      case 8: rc = launch(&rmhmc_fused_kernel<T, 8>, done[0]); break;
-      case 16: rc = launch(&rmhmc_fused_kernel<T, 16>, done[1]); break;
-      case 24: rc = launch(&rmhmc_fused_kernel<T, 24>, done[2]); break;
-      case 32: rc = launch(&rmhmc_fused_kernel<T, 32>, done[3]); break;
-      case 40: rc = launch(&rmhmc_fused_kernel<T, 40>, done[4]); break;
-      case 48: rc = launch(&rmhmc_fused_kernel<T, 48>, done[5]); break;
-      case 56: rc = launch(&rmhmc_fused_kernel<T, 56>, done[6]); break;
-      default: rc = launch(&rmhmc_fused_kernel<T, 64>, done[7]); break;
+      case 8: rc = launch(&rmhmc_fused_kernel<T, 8>, &rmhmc_fused_pair_kernel<T, 8>, done[0], done2[0]); break;
+      case 16: rc = launch(&rmhmc_fused_kernel<T, 16>, &rmhmc_fused_pair_kernel<T, 16>, done[1], done2[1]); break;
+      case 24: rc = launch(&rmhmc_fused_kernel<T, 24>, &rmhmc_fused_pair_kernel<T, 24>, done[2], done2[2]); break;
+      case 32: rc = launch(&rmhmc_fused_kernel<T, 32>, &rmhmc_fused_pair_kernel<T, 32>, done[3], done2[3]); break;
+      case 40: rc = launch(&rmhmc_fused_kernel<T, 40>, &rmhmc_fused_pair_kernel<T, 40>, done[4], done2[4]); break;
+      case 48: rc = launch(&rmhmc_fused_kernel<T, 48>, &rmhmc_fused_pair_kernel<T, 48>, done[5], done2[5]); break;
+      case 56: rc = launch(&rmhmc_fused_kernel<T, 56>, &rmhmc_fused_pair_kernel<T, 56>, done[6], done2[6]); break;
+      default: rc = launch(&rmhmc_fused_kernel<T, 64>, &rmhmc_fused_pair_kernel<T, 64>, done[7], done2[7]); break;
     }
     if (rc) return rc;
   }

@@ -376,3 +376,28 @@ def test_fused_path_equals_jacobi_path(ht, dtype, tol, D, jitter, metric):
     bad = np.abs(outs[0][0] - outs[1][0]).max(axis=(0, 2)) > tol
     assert bad.mean() <= 0.07, "%d of %d chains differ, max %.3g" % (bad.sum(), C, np.abs(outs[0][0] - outs[1][0]).max())
     np.testing.assert_allclose(outs[0][1][~bad], outs[1][1][~bad], atol=1e-12)
+
+
+@pytest.mark.parametrize("D,jitter", [(100, 1e-3), (20, None), (37, 2e-3)])
+def test_fused_pair_kernel_equals_single_chain_kernel(ht, D, jitter):
+    """From 1024 chains on the fused path carries two chains per workgroup; an odd chain count leaves the last pair half
+    empty.  Same run with the pair kernel disabled (tuning value 2) must agree chain by chain."""
+    from hamiltorch_amd import _abi
+    t, _ = cfg3_target(ht, D, torch.float32, seed=3)
+    C, N, L, eps, seed = 1025, 3, 2, 0.1, 5
+    th0 = (0.3 * O.philox_normals(seed, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32)
+    kw = dict(num_samples=N, num_steps_per_sample=L, step_size=eps, burn=0, jitter=jitter, softabs_const=1e6,
+              explicit_binding_const=10.0, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT,
+              metric=ht.Metric.SOFTABS, debug=2, verbose=False, seed=seed)
+    outs = []
+    for mode in (1, 2):
+        _abi.set_tuning("rmhmc_fused", mode)
+        try:
+            out, acc = ht.sample(t, tt(th0, torch.float32), **kw)
+        finally:
+            _abi.set_tuning("rmhmc_fused", 1)
+        outs.append((np.stack([x.cpu().numpy() for x in out]), acc.cpu().numpy()))
+    assert np.isfinite(outs[0][0]).all()
+    bad = np.abs(outs[0][0] - outs[1][0]).max(axis=(0, 2)) > 2e-4
+    assert bad.mean() <= 0.02, "%d of %d chains differ, max %.3g" % (bad.sum(), C, np.abs(outs[0][0] - outs[1][0]).max())
+    np.testing.assert_allclose(outs[0][1][~bad], outs[1][1][~bad], atol=1e-12)
