@@ -497,6 +497,29 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
           }
           quad = block_sum(qd, red);
         }
+        if (a.dmetric_out) {
+          // Hessian metric: d/dHs [1/2 log|G| + 1/2 m^T G^-1 m] = 1/2 G^-1 - 1/2 v v^T, v = G^-1 m (in vec1, 0 without m).
+          // L^-1 column by column (one thread per column, plain forward substitution, no barriers) into the V region,
+          // then G^-1 = L^-T L^-1.
+          __syncthreads();
+          if (!a.m) for (int i = tid; i < D; i += MT) vec1[i] = 0;
+          for (int j = tid; j < D; j += MT) {
+            for (int i = 0; i < j; ++i) V[i * ldv + j] = 0;
+            V[j * ldv + j] = (T)1 / A[j * lda + j];
+            for (int i = j + 1; i < D; ++i) {
+              T acc = 0;
+              for (int k = j; k < i; ++k) acc = fma(A[i * lda + k], V[k * ldv + j], acc);
+              V[i * ldv + j] = -acc / A[i * lda + i];
+            }
+          }
+          __syncthreads();
+          for (int e = tid; e < D * D; e += MT) {
+            const int i = e / D, j = e - i * D;
+            T acc = 0;
+            for (int k = (i > j ? i : j); k < D; ++k) acc = fma(V[k * ldv + i], V[k * ldv + j], acc);
+            a.dmetric_out[b * D * D + e] = (T)0.5 * acc - (T)0.5 * vec1[i] * vec1[j];
+          }
+        }
       }
       if (a.p_out) {                   // p = L z  (S:184 via MultivariateNormal.rsample)
         __syncthreads();

@@ -156,10 +156,7 @@ def _generic_steps(cv, kind, th, pm, thc, pmc, steps, eps, omega, alpha, jitter,
     """S:425-461 on the augmented state, in place.  Unlike the constant-curvature path, dH/dtheta depends on the
     metric here, so each of the reference's 8 gradient calls per step keeps its own metric evaluation and jitter
     sub-stream (2 + 8 l + k, k = 0..7 in the reference's call order)."""
-    if kind != _abi.METRIC_SOFTABS:
-        raise NotImplementedError("explicit RMHMC on a general target is implemented for Metric.SOFTABS "
-                                  "(the Hessian metric of a non-Gaussian target is not positive definite in general)")
-    C, D = th.shape
+    C, D = th.shape                 # Metric.HESSIAN needs a log-concave target (G = -Hessian positive definite), as in the reference
     eh = 0.5 * eps
     M = torch.empty(C, D, D, dtype=th.dtype, device=th.device)
 
@@ -276,8 +273,6 @@ def _implicit_subs(max_it):
 def _implicit_steps(cv, kind, th, pm, steps, eps, alpha, jitter, seed, chain_offset, draw, thr, max_it, sub0=2, path=None):
     """S:312-383 for a batch of chains, in place on (th, pm).  Chains leave a fixed-point loop individually once their
     own max squared update is below `thr` (the reference's `break`); the loop ends when none is left or after max_it."""
-    if kind != _abi.METRIC_SOFTABS:
-        raise NotImplementedError("implicit RMHMC is implemented for Metric.SOFTABS")
     C, D = th.shape
     hs = 0.5 * eps
     M = torch.empty(C, D, D, dtype=th.dtype, device=th.device)

@@ -175,11 +175,12 @@ typedef struct HtaMetricArgs {
                                                 solver then diagonalises diag(lam0) + V0^T diag(jitter u) V0, which
                                                 is nearly diagonal: 2 Jacobi sweeps instead of ~10; same results    */
   void* lamraw_out;                          /* [B,D] eigenvalues before the soft-abs map                           */
-  void* dmetric_out;                         /* [B,D,D] (SOFTABS): the symmetric matrix M with
+  void* dmetric_out;                         /* [B,D,D]: the symmetric matrix M with
                                                 d/dtheta_i [1/2 log|G| + 1/2 m^T G^-1 m] = <d_i Hs, M>, i.e. what the
                                                 reference gets by differentiating S:726-731 through eigh (S:398):
                                                 M = Q W Q^T, W_kl = 1/2 [k==l] lam~'_k / lam~_k - 1/2 J_kl u_k u_l,
-                                                u = Q^T m / lam~, J = divided differences of lam -> lam~ (Daleckii-Krein) */
+                                                u = Q^T m / lam~, J = divided differences of lam -> lam~ (Daleckii-Krein);
+                                                HESSIAN metric: M = 1/2 G^-1 - 1/2 v v^T, v = G^-1 m                */
 } HtaMetricArgs;
 
 int hta_metric_eval_f32(const HtaMetricArgs* args, void* stream);

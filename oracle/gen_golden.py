@@ -474,6 +474,38 @@ def gen_funnel():
     np.savez(os.path.join(OUT, "funnel.npz"), **out)
 
 
+def gen_logcosh():
+    """Metric.HESSIAN on a general (log-concave, non-Gaussian) target: log p = -1/2 w^T P w - sum log cosh(A w).
+    Explicit and implicit RMHMC leapfrog paths of the reference, jitter=None."""
+    out = {}
+    D = 5
+    rng = np.random.default_rng(1)
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    P = (Q * np.linspace(0.5, 2.0, D)) @ Q.T
+    P = 0.5 * (P + P.T)
+    A = 0.7 * rng.standard_normal((7, D))
+    out["P"] = P; out["A"] = A
+    Pt, At = torch.tensor(P), torch.tensor(A)
+
+    def lp(w):
+        return -0.5 * torch.dot(w, torch.mv(Pt.to(w.dtype), w)) - torch.log(torch.cosh(torch.mv(At.to(w.dtype), w))).sum()
+    g = torch.Generator().manual_seed(4)
+    th = 0.6 * torch.randn(D, generator=g, dtype=torch.float64); pm = torch.randn(D, generator=g, dtype=torch.float64)
+    out["theta0"] = npy(th); out["p0"] = npy(pm); out["cfg"] = np.array([5.0, 0.08, 3, 1e-16, 30])
+    G, _ = S.fisher(th, lp, jitter=None, metric=hamiltorch.Metric.HESSIAN)
+    out["G"] = npy(G)
+    out["H"] = npy(S.rm_hamiltonian(th, pm, lp, None, 1.0, metric=hamiltorch.Metric.HESSIAN)).reshape(-1)
+    lpar, lmom = S.leapfrog(th, pm, lp, steps=3, step_size=0.08, jitter=None, explicit_binding_const=5.0,
+                            sampler=hamiltorch.Sampler.RMHMC, integrator=hamiltorch.Integrator.EXPLICIT,
+                            metric=hamiltorch.Metric.HESSIAN)
+    out["exp_theta"] = np.stack([npy(t) for t in lpar[0]]); out["exp_p"] = np.stack([npy(t) for t in lmom[0]])
+    lpar, lmom = S.leapfrog(th, pm, lp, steps=3, step_size=0.08, jitter=None, fixed_point_threshold=1e-16,
+                            fixed_point_max_iterations=30, sampler=hamiltorch.Sampler.RMHMC,
+                            integrator=hamiltorch.Integrator.IMPLICIT, metric=hamiltorch.Metric.HESSIAN)
+    out["imp_theta"] = np.stack([npy(t) for t in lpar]); out["imp_p"] = np.stack([npy(t) for t in lmom])
+    np.savez(os.path.join(OUT, "logcosh.npz"), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                      # python oracle/gen_golden.py funnel  -> only that family
         for name in sys.argv[1:]:
@@ -487,5 +519,6 @@ if __name__ == "__main__":
     gen_nuts()
     gen_funnel()
     gen_splitkinds()
+    gen_logcosh()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

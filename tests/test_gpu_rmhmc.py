@@ -401,3 +401,64 @@ def test_fused_pair_kernel_equals_single_chain_kernel(ht, D, jitter):
     bad = np.abs(outs[0][0] - outs[1][0]).max(axis=(0, 2)) > 2e-4
     assert bad.mean() <= 0.02, "%d of %d chains differ, max %.3g" % (bad.sum(), C, np.abs(outs[0][0] - outs[1][0]).max())
     np.testing.assert_allclose(outs[0][1][~bad], outs[1][1][~bad], atol=1e-12)
+
+
+# ---- Metric.HESSIAN on a general log-concave target ---------------------------------------------------------------
+def logcosh_logp(P, A):
+    def f(w):
+        Pt = torch.as_tensor(P, dtype=w.dtype, device=w.device); At = torch.as_tensor(A, dtype=w.dtype, device=w.device)
+        return -0.5 * torch.dot(w, torch.mv(Pt, w)) - torch.log(torch.cosh(torch.mv(At, w))).sum()
+    return f
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.float64, 1e-8)])
+@pytest.mark.parametrize("D", [3, 16, 60])
+def test_hessian_dmetric_vs_oracle(ht, dtype, tol, D):
+    """dmetric_out for Metric.HESSIAN: M = 1/2 G^-1 - 1/2 v v^T from the in-LDS Cholesky factor."""
+    from hamiltorch_amd import _abi
+    B = 4
+    Hs = sym_batch(B, D, "spd", D + 3).astype(NP[dtype])
+    m = np.random.default_rng(3).standard_normal((B, D)).astype(NP[dtype])
+    Mw, vw = O.hessian_dmetric(Hs.astype(np.float64), m)
+    Md = torch.empty(B, D, D, dtype=dtype, device=dev()); xd = torch.empty(B, D, dtype=dtype, device=dev())
+    t = tt(Hs, dtype)
+    _abi.metric_eval(t, B, D, _abi.METRIC_HESSIAN, t, D * D, 0.0, m=tt(m, dtype), x_out=xd, dmetric_out=Md)
+    np.testing.assert_allclose(Md.double().cpu().numpy(), Mw, rtol=tol, atol=tol * np.abs(Mw).max())
+    np.testing.assert_allclose(xd.double().cpu().numpy(), vw, rtol=tol, atol=tol * np.abs(vw).max())
+
+
+def test_hessian_metric_general_target_vs_reference_fixture(ht, golden):
+    g = golden("logcosh")
+    omega, eps, steps, thr, max_it = g["cfg"]
+    lp = logcosh_logp(g["P"], g["A"])
+    th, pm = tt(g["theta0"], torch.float64), tt(g["p0"], torch.float64)
+    H = ht.samplers.rm_hamiltonian(th, pm, lp, None, 1.0, metric=ht.Metric.HESSIAN)
+    np.testing.assert_allclose(H.cpu().numpy().reshape(-1), g["H"], rtol=1e-9, atol=1e-9)
+    lpar, lmom = ht.samplers.leapfrog(th, pm, lp, steps=int(steps), step_size=eps, jitter=None, explicit_binding_const=omega,
+                                      sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT, metric=ht.Metric.HESSIAN)
+    np.testing.assert_allclose(torch.stack(lpar[0]).cpu().numpy(), g["exp_theta"], rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(torch.stack(lmom[0]).cpu().numpy(), g["exp_p"], rtol=1e-7, atol=1e-7)
+    lpar, lmom = ht.samplers.leapfrog(th, pm, lp, steps=int(steps), step_size=eps, jitter=None, fixed_point_threshold=thr,
+                                      fixed_point_max_iterations=int(max_it), sampler=ht.Sampler.RMHMC,
+                                      integrator=ht.Integrator.IMPLICIT, metric=ht.Metric.HESSIAN)
+    np.testing.assert_allclose(torch.stack(lpar).cpu().numpy(), g["imp_theta"], rtol=2e-7, atol=2e-7)
+    np.testing.assert_allclose(torch.stack(lmom).cpu().numpy(), g["imp_p"], rtol=2e-7, atol=2e-7)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-7), (torch.float32, 5e-3)])
+def test_hessian_metric_general_target_sample_vs_oracle(ht, dtype, tol):
+    """sample(RMHMC, EXPLICIT, Metric.HESSIAN) with jitter on the log-cosh target, batch of chains, same Philox streams."""
+    rng = np.random.default_rng(2); D = 8
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D))); P = (Q * np.linspace(0.5, 2.0, D)) @ Q.T; P = 0.5 * (P + P.T)
+    A = 0.6 * rng.standard_normal((10, D))
+    lp, o = logcosh_logp(P, A), O.LogCoshTarget(P, A)
+    C, N, L, eps, omega, seed, off, jitter = 12, 4, 3, 0.1, 10.0, 77, 1, 1e-3
+    th0 = (0.4 * O.philox_normals(seed, off + np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(NP[dtype])
+    out, acc = ht.sample(lp, tt(th0, dtype), num_samples=N, num_steps_per_sample=L, step_size=eps, burn=0, jitter=jitter,
+                         explicit_binding_const=omega, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT,
+                         metric=ht.Metric.HESSIAN, debug=2, verbose=False, seed=seed, chain_offset=off)
+    ref, info = O.sample_rmhmc_explicit(o, th0, N, L, eps, omega, 1.0, 0, jitter, O.PhiloxDraws(seed, off + np.arange(C), NP[dtype]),
+                                        "hessian")
+    got = np.stack([x.cpu().numpy() for x in out]); want = np.stack(ref)
+    bad = ~(np.abs(got - want).max(axis=(0, 2)) <= tol)
+    assert bad.mean() <= 0.1, "%d of %d chains differ, max err %.3g" % (bad.sum(), C, np.nanmax(np.abs(got - want)))

@@ -378,3 +378,22 @@ def test_implicit_rmhmc_sample_end_to_end(golden):
     assert len(ret) == ref.shape[0]
     np.testing.assert_allclose(np.concatenate(ret), ref, rtol=1e-6, atol=1e-6)
     assert abs(info["acc_rate"][0] - float(g["imp_e2e_acc"])) < 1e-9
+
+
+def test_hessian_metric_general_target_vs_reference(golden):
+    """Metric.HESSIAN on the log-cosh target (log-concave, not Gaussian): explicit and implicit RMHMC paths of the
+    reference against the oracle's closed form M = 1/2 G^-1 - 1/2 v v^T."""
+    g = golden("logcosh")
+    omega, eps, steps, thr, max_it = g["cfg"]
+    t = O.LogCoshTarget(g["P"], g["A"])
+    th, pm = g["theta0"][None], g["p0"][None]
+    np.testing.assert_allclose(t.neg_hessian(th)[0], g["G"], rtol=1e-10, atol=1e-10)
+    H, _ = O.rm_hamiltonian(th, pm, t, 1.0, metric="hessian")
+    np.testing.assert_allclose(H, g["H"], rtol=1e-9, atol=1e-9)
+    for n in range(1, int(steps) + 1):
+        a, b, _, _ = O.explicit_rmhmc_leapfrog_generic(th, pm, t, n, eps, omega, 1.0, metric="hessian")
+        np.testing.assert_allclose(a[0], g["exp_theta"][n - 1], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(b[0], g["exp_p"][n - 1], rtol=1e-8, atol=1e-8)
+        a, b = O.implicit_rmhmc_leapfrog(th, pm, t, n, eps, 1.0, thr, int(max_it), metric="hessian")
+        np.testing.assert_allclose(a[0], g["imp_theta"][n - 1], rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(b[0], g["imp_p"][n - 1], rtol=1e-7, atol=1e-7)
