@@ -1,5 +1,6 @@
-// Fused (split-)HMC for a one-hidden-layer Bayesian MLP with a Gaussian (regression) likelihood:
-// BASELINE config 4.  One workgroup per chain; the whole trajectory loop of sample()
+// Fused (split-)HMC for a one-hidden-layer Bayesian MLP with a Gaussian (regression) likelihood, any dtype and shape
+// (n_in <= 32, H <= 1024): the fp64 / wide-layer route, and the fp32 parity partner (tuning key "mlp_valu") of
+// mlp_mfma.hip, which runs BASELINE config 4.  One workgroup per chain; the whole trajectory loop of sample()
 // (hamiltorch/samplers.py:965-1026) runs on-chip with
 //   log p_m(theta) = -1/2 tau_out sum_{i in split m} (f(x_i) - y_i)^2
 //                    + (1/prior_scale) sum_layers Normal(0, tau_l^-1/2).log_prob(w).sum()
@@ -27,9 +28,6 @@
 #define HTA_STR_(x) #x
 #define HTA_UNROLL_(n) _Pragma(HTA_STR_(unroll n))
 #define HTA_UNROLL(n) HTA_UNROLL_(n)
-#ifndef HTA_XLDS
-#define HTA_XLDS 0
-#endif
 #ifndef HTA_ABL
 #define HTA_ABL 0      // developer ablation bits (tools/scratch/mlp_ablate.sh); 0 in the product build
 #endif
@@ -84,7 +82,7 @@ struct MlpChain {
   struct Rec { P2 w1[NP]; T b1; T w2; T b2; };
   const MlpArgs<T>& a;
   CPtr Xc;
-  T* Ys; T* cm; T* dv; T* red; T* w2s; T* gp; T* Xs; int* perm;
+  T* Ys; T* cm; T* dv; T* red; T* w2s; T* gp; int* perm;
   int nbch, ldc, Hp, j, slice, PS, UGL, tid;
   bool unit;      // j < H and the wave has a slice
 #if HTA_TIMING
@@ -96,14 +94,6 @@ struct MlpChain {
 
   // x_i (wave-uniform) as NP pairs, zero-padded to INMAX; EXACT (n_in == INMAX): the whole row in one scalar load
   __device__ __forceinline__ void load_x(int i, P2 (&x)[NP]) const {
-#if HTA_XLDS
-    {
-      const V4* r = reinterpret_cast<const V4*>(Xs + (size_t)i * INMAX);
-#pragma unroll
-      for (int k = 0; k < NP / 2; ++k) { const V4 v = r[k]; x[2 * k] = P2{v.x, v.y}; x[2 * k + 1] = P2{v.z, v.w}; }
-      return;
-    }
-#endif
     if (EXACT) {
       typedef T VX __attribute__((ext_vector_type(INMAX)));
       const VX v = *reinterpret_cast<const __attribute__((address_space(4))) VX*>(Xc + (int64_t)i * INMAX);
@@ -318,11 +308,7 @@ __global__ __launch_bounds__(NT, 4) void mlp1_hmc_kernel(MlpArgs<T> a, int nbch,
   ch.cm = reinterpret_cast<T*>(smem_raw);
   ch.gp = ch.cm;                                // per-thread records, live only between the two passes' use of the chunk matrix
   ch.w2s = ch.cm + cmsz;
-  ch.Xs = ch.w2s + Hp;
-  ch.Ys = ch.Xs + (HTA_XLDS ? (size_t)a.N * INMAX : 0);
-#if HTA_XLDS
-  for (int e = tid; e < a.N * INMAX; e += NT) { const int i = e / INMAX, k = e - i * INMAX; ch.Xs[e] = (k < n_in) ? a.X[i * n_in + k] : (T)0; }
-#endif
+  ch.Ys = ch.w2s + Hp;
   ch.dv = ch.Ys + a.N;
   ch.red = ch.dv + nbch;
   ch.perm = reinterpret_cast<int*>(ch.red + 2 * (NT / 64) + 8);
@@ -460,7 +446,7 @@ template <typename T, int INMAX, int NT, int ACT, bool EXACT> int launch_mlp_act
   while (ldc % 32 != 16) ldc += 4;                     // 4 consecutive rows land on distinct bank quarters
   typedef MlpChain<T, INMAX, NT, ACT, EXACT> Ch;
   const size_t recs = (size_t)NT * Ch::GS;             // slice-exchange / momentum-draw records, aliasing the chunk matrix
-  const size_t fixed = ((size_t)Hp + a.N + (HTA_XLDS ? (size_t)a.N * INMAX : 0) + 2 * (NT / 64) + 8 + 64) * sizeof(T);        // ... + 64 ints: subset order
+  const size_t fixed = ((size_t)Hp + a.N + 2 * (NT / 64) + 8 + 64) * sizeof(T);        // ... + 64 ints: subset order
   const size_t cap = 150 * 1024;
   HTA_REQUIRE(fixed + (recs + 4) * sizeof(T) <= cap && fixed + (size_t)4 * (ldc + 1) * sizeof(T) <= cap,
               "hta_mlp_hmc: data set (N=%d) / hidden layer (H=%d) do not fit the LDS staging", a.N, a.H);
