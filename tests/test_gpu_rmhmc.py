@@ -462,3 +462,22 @@ def test_hessian_metric_general_target_sample_vs_oracle(ht, dtype, tol):
     got = np.stack([x.cpu().numpy() for x in out]); want = np.stack(ref)
     bad = ~(np.abs(got - want).max(axis=(0, 2)) <= tol)
     assert bad.mean() <= 0.1, "%d of %d chains differ, max err %.3g" % (bad.sum(), C, np.nanmax(np.abs(got - want)))
+
+
+def test_fused_workspace_passes_are_equivalent(ht):
+    """The fused path pre-draws the momenta of as many trajectories as the workspace holds; with the minimum workspace it
+    works in passes of 4.  Same samples either way (bit for bit: the same kernels on the same streams)."""
+    from hamiltorch_amd import _abi
+    D, C, T, L = 24, 40, 11, 2
+    t, _ = cfg3_target(ht, D, torch.float32, seed=9)
+    th0 = tt((0.3 * O.philox_normals(3, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32), torch.float32)
+    outs = []
+    for nbytes in (_abi.rmhmc_workspace_bytes(C, D, 4, 0), _abi.rmhmc_workspace_bytes(C, D, 4, T)):
+        cur = th0.clone(); rej = torch.zeros(C, dtype=torch.int32, device=dev())
+        samples = torch.zeros(T + 1, C, D, device=dev())
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+        _abi.rmhmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, _abi.METRIC_SOFTABS, 1e6, 1e-3, L, 0.1, 10.0,
+                                   T, 0, -1, 21, 0, samples, rej, ws)
+        outs.append((samples.cpu().numpy(), rej.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.abs(outs[0][0][-1] - outs[0][0][0]).max() > 1e-3
