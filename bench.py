@@ -113,7 +113,7 @@ class Cfg2:
 class Cfg3:
     """BASELINE config 3: D=100 Gaussian, explicit RMHMC, soft-abs metric, 256 chains."""
     name = "cfg3: D=100 Gaussian explicit RMHMC, softabs alpha=1e6, omega=10, eps=0.1, L=10, jitter=1e-3"
-    D, L, eps, chains, traj = 100, 10, 0.1, 256, 100
+    D, L, eps, chains, traj = 100, 10, 0.1, 256, 400
     omega, alpha, jitter = 10.0, 1e6, 1e-3
     dtype_name = "f32"
 
