@@ -12,7 +12,7 @@ void set_error(const char* fmt, ...) {
 }
 int g_small_chains_per_block = 0;  // 0 = default (64)
 int g_force_general = 0;
-int g_rmhmc_fused = 1;           // 0 = per-evaluation Jacobi path, 2 = fused but never two chains per workgroup (parity tests)
+int g_rmhmc_fused = 1;           // 0 = per-evaluation Jacobi path, 3 = fused with two chains per workgroup (parity tests)
 int g_mlp_valu = 0;               // 1 = keep the Bayesian-MLP sampler on the VALU kernel (parity tests of both)
 
 // ---- optional HIP-event timing of the dominant kernel of each call (measurement only) -----------

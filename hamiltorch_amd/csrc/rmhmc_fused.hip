@@ -154,26 +154,44 @@ __device__ __forceinline__ T chol_in_lds(const T* __restrict__ P, const T* ev, T
 }
 
 
-// KH: register-resident slice of a matrix column per thread (multiple of 8).  Thread (row, half) keeps P[k][row] and
+// Sum of the two half-row partials of a row: lanes l (lower k half) and l + 32 (upper half) of one wave.  The total is
+// valid in the UPPER lane (the row's owner).  v_permlane32_swap_b32 (gfx950) puts the lower half of `h` under the upper
+// lanes in one VALU op - an LDS bpermute round trip here costs more than the barrier it saves.
+__device__ __forceinline__ float row_total(float h) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, h), false, false);
+  return h + __builtin_bit_cast(float, r[0]);
+}
+__device__ __forceinline__ double row_total(double h) { return h + __shfl_xor(h, 32, 64); }
+
+// KH: register-resident slice of a matrix column per thread (multiple of 8).  Lane (row, half) keeps P[k][row] and
 // S[k][row] for its KH values of k in VGPRs for the whole launch; a matrix-vector product then only streams the
-// vector (16-byte LDS broadcasts).
-template <typename T, int KH> struct FusedChain {
+// vector (16-byte LDS reads).  The two halves of a row sit in the SAME wave (lanes l and l + 32): their partial sums
+// meet through one lane swap, the upper lane ("owner" of the row) finishes the element-wise work of its element in
+// registers - no partial-sum vectors, no combine phases: one barrier per product pass.
+// NC chains can share a workgroup (NC = 2): the slices do not depend on the chain, so a pass carries both chains for the
+// same register reads and barriers - but not for the same LDS traffic, which is what bounds a pass (see the dispatch).
+constexpr int FVC = 10;           // LDS vectors per chain: cur th pm thc pmc ev d0 d1 w0 w1 (128 entries each, zero beyond D)
+
+template <typename T, int KH, int NC> struct Fused {
   typedef T V4 __attribute__((ext_vector_type(4)));
+  static constexpr int CHS = FVC * 128;
   const FusedArgs<T>& a;
-  int D, ld, tid, row, k0;
-  bool rowok, hi;
-  T mu_r;                       // mu[tid]
+  int D, ld, tid, row, k0, dpar;
+  bool own;
   T Preg[KH], Sreg[KH];
-  T *W, *dg, *sdiag, *cur, *th, *pm, *thc, *pmc, *ev, *d, *x0, *x, *w, *q0, *q1, *r0, *r1, *s0, *s1, *red;
-  uint64_t chain;
+  T mu_r, sd_r;                       // mu[row], S[row][row]
+  T ev_r[NC];                         // this owner's elements of the current evaluation's jitter
+  int jslot;                          // next unread evaluation slot of the jitter buffer
+  T *cur, *th, *pm, *thc, *pmc, *ev, *d0, *d1, *w0, *w1, *dg, *red, *W, *jb;
+  uint64_t chain[NC];
+  bool live[NC];
 #if HTA_RM_TIMING
   unsigned long long tacc[8] = {0}, tlast = 0;
 #endif
-  __device__ FusedChain(const FusedArgs<T>& a_) : a(a_) {}
+  __device__ Fused(const FusedArgs<T>& a_) : a(a_) {}
 
-  // load this thread's register slices once per launch: column `row`, rows k0 .. k0 + KH of the symmetric P and S.
-  // (Reloading them per trajectory makes the compiler hoist 2 KH 64-bit addresses out of the loops: 4 KH registers.)
-  __device__ __forceinline__ void load_slices() {
+  __device__ __forceinline__ void load_slices() {           // once per launch (symmetric matrices: column `row`)
+    const bool rowok = row < D;
 #pragma unroll
     for (int kk = 0; kk < KH; ++kk) {
       const int k = k0 + kk;
@@ -183,442 +201,349 @@ template <typename T, int KH> struct FusedChain {
     }
   }
 
-  // four block sums at once (every thread gets all four)
-  __device__ __forceinline__ void block_sum4(T (&v)[4]) {
+  // NC x 4 block sums at once (every thread gets all of them)
+  __device__ __forceinline__ void block_sums(T (&v)[NC][4]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = wave_sum(v[q]);
+    for (int q = 0; q < NC; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[q][e] = wave_sum(v[q][e]);
     __syncthreads();
     if ((tid & 63) == 0) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) red[4 * (tid >> 6) + q] = v[q];
+      for (int q = 0; q < NC; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[(tid >> 6) * 8 + q * 4 + e] = v[q][e];
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      T s = 0;
-#pragma unroll
-      for (int i = 0; i < FNT / 64; ++i) s += red[4 * i + q];
-      v[q] = s;
-    }
-  }
-
-  // Partial products of up to three symmetric-matrix x vector products in one pass over this thread's slice:
-  //   o1 = P v1,  o2 = S v2,  o3 = (S . S) v3  (element-wise square: the second-order log-det term).
-  // The two halves of a row land in (o*0[row], o*1[row]); the consumer adds them.  No barriers inside; the vectors
-  // are zero beyond D (and so are the register slices).
-  template <bool WITH_P, int NS>
-  __device__ __forceinline__ void products(const T* v1, T* o10, T* o11, const T* v2, T* o20, T* o21, const T* v3, T* o30, T* o31) {
-    T a1[2] = {0, 0}, a2[2] = {0, 0}, a3[2] = {0, 0};
-#pragma unroll
-    for (int kk = 0; kk < KH; kk += 4) {
-      V4 u1, u2, u3;
-      if (WITH_P) u1 = *reinterpret_cast<const V4*>(v1 + k0 + kk);
-      if (NS >= 1) u2 = *reinterpret_cast<const V4*>(v2 + k0 + kk);
-      if (NS >= 2) u3 = *reinterpret_cast<const V4*>(v3 + k0 + kk);
+    for (int q = 0; q < NC; ++q)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (WITH_P) a1[e & 1] = fma(Preg[kk + e], u1[e], a1[e & 1]);
-        if (NS >= 1) a2[e & 1] = fma(Sreg[kk + e], u2[e], a2[e & 1]);
-        if (NS >= 2) a3[e & 1] = fma(Sreg[kk + e] * Sreg[kk + e], u3[e], a3[e & 1]);
+        T s = 0;
+#pragma unroll
+        for (int i = 0; i < FNT / 64; ++i) s += red[i * 8 + q * 4 + e];
+        v[q][e] = s;
       }
-    }
-    if (!rowok) return;
-    if (WITH_P) { T* const h1 = hi ? o11 : o10; h1[row] = a1[0] + a1[1]; }
-    if (NS >= 1) { T* const h2 = hi ? o21 : o20; h2[row] = a2[0] + a2[1]; }
-    if (NS >= 2) { T* const h3 = hi ? o31 : o30; h3[row] = a3[0] + a3[1]; }
   }
 
-  T ev_next;                    // this thread's element of the next evaluation's jitter
-  __device__ __forceinline__ T jitter_elem(uint32_t n, uint32_t sub) {
-    return (a.has_jitter && tid < D) ? a.jitter * uniform_elem<T>(a.seed, chain, n, PURPOSE_JITTER, sub, tid) : (T)0;
+  // Row `row` of up to three symmetric-matrix x vector products per chain, complete in both lanes of the row:
+  //   o1 = P v1,  o2 = S v2,  o3 = (S . S) v3  (element-wise square: the second-order log-det term).
+  // No barriers inside; vectors and slices are zero beyond D.
+  template <bool WITH_P, int NS>
+  __device__ __forceinline__ void products(const T* v1, const T* v2, const T* v3, T (&o1)[NC], T (&o2)[NC], T (&o3)[NC]) {
+    T a1[NC][2], a2[NC][2], a3[NC][2];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) { a1[q][0] = a1[q][1] = a2[q][0] = a2[q][1] = a3[q][0] = a3[q][1] = 0; }
+    constexpr int NCH = KH / 4;
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      if (NS <= 1) {
+        // every 16-byte vector load of this chain first, then the FMAs: left to itself the compiler issues three loads
+        // and waits for them, 14 exposed LDS round trips per pass
+        V4 u1[NCH], u2[NCH];
+#pragma unroll
+        for (int cb = 0; cb < NCH; ++cb) {
+          if (WITH_P) u1[cb] = *reinterpret_cast<const V4*>(v1 + q * CHS + k0 + 4 * cb);
+          if (NS >= 1) u2[cb] = *reinterpret_cast<const V4*>(v2 + q * CHS + k0 + 4 * cb);
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCH; ++cb) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (WITH_P) a1[q][e & 1] = fma(Preg[4 * cb + e], u1[cb][e], a1[q][e & 1]);
+            if (NS >= 1) a2[q][e & 1] = fma(Sreg[4 * cb + e], u2[cb][e], a2[q][e & 1]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < KH; kk += 4) {
+          V4 u1, u2, u3;
+          if (WITH_P) u1 = *reinterpret_cast<const V4*>(v1 + q * CHS + k0 + kk);
+          u2 = *reinterpret_cast<const V4*>(v2 + q * CHS + k0 + kk);
+          u3 = *reinterpret_cast<const V4*>(v3 + q * CHS + k0 + kk);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (WITH_P) a1[q][e & 1] = fma(Preg[kk + e], u1[e], a1[q][e & 1]);
+            a2[q][e & 1] = fma(Sreg[kk + e], u2[e], a2[q][e & 1]);
+            a3[q][e & 1] = fma(Sreg[kk + e] * Sreg[kk + e], u3[e], a3[q][e & 1]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      if (WITH_P) o1[q] = row_total(a1[q][0] + a1[q][1]);
+      if (NS >= 1) o2[q] = row_total(a2[q][0] + a2[q][1]);
+      if (NS >= 2) o3[q] = row_total(a3[q][0] + a3[q][1]);
+    }
   }
-  // jitter of evaluation `sub` of trajectory n  (S:113-115)
-  __device__ __forceinline__ void draw_jitter(uint32_t n, uint32_t sub) {
-    if (tid < D) ev[tid] = a.has_jitter ? a.jitter * uniform_elem<T>(a.seed, chain, n, PURPOSE_JITTER, sub, tid) : (T)0;
+
+  __device__ __forceinline__ T jitter_elem(int q, uint32_t n, uint32_t sub) {
+    return (a.has_jitter && own && live[q]) ? a.jitter * uniform_elem<T>(a.seed, chain[q], n, PURPOSE_JITTER, sub, row) : (T)0;
+  }
+
+  // Jitter of the next NSLOT evaluations of the integrator in ONE Philox pass per wave: lane (slot, blk) draws the block
+  // of 4 uniforms of rows 32 wave + 4 blk .. + 3 for evaluation `slot` (NC == 1: 8 evaluations = 2 steps; NC == 2: 4
+  // evaluations x 2 chains = 1 step).  A wave only ever reads the rows it wrote: no barrier.  (Drawing per evaluation
+  // costs ~100 VALU instructions per wave and half step however few lanes need it - a fifth of the half step.)
+  static constexpr int NSLOT = 8 / NC;
+  __device__ __forceinline__ void refill_jitter(uint32_t n, int l) {
+    jslot = 0;
+    if (!a.has_jitter) return;
+    const int lane = tid & 63, slot = lane >> 3, blk = lane & 7;
+    const int q = NC == 1 ? 0 : (slot & 1), e = NC == 1 ? slot : (slot >> 1);
+    const int which = e & 3;
+    const uint32_t sub = 2u + 8u * (uint32_t)(l + (e >> 2)) + (which == 0 ? 1u : which == 1 ? 2u : which == 2 ? 4u : 7u);
+    const int r0 = 32 * (tid >> 6) + 4 * blk;
+    const U4 r = philox_block(a.seed, chain[q], n, PURPOSE_JITTER, sub, (uint32_t)(r0 >> 2));
+    const V4 val = {a.jitter * u23<T>(r.x), a.jitter * u23<T>(r.y), a.jitter * u23<T>(r.z), a.jitter * u23<T>(r.w)};
+    *reinterpret_cast<V4*>(jb + (e * NC + q) * 128 + r0) = val;
+  }
+
+  // x = (P + diag(e))^-1 m continued from x0 = S m: xr <- x0 - S (e . x), K times; w buffers alternate (a fast wave's
+  // store of the next e . x must not overtake a slow wave's reads of the current one)
+  __device__ __forceinline__ void refine(const T (&x0)[NC], T (&xr)[NC]) {
+    for (int it = 0; it < a.K; ++it) {
+      const T* wr = (it & 1) ? w1 : w0;
+      T* ww = (it & 1) ? w0 : w1;
+      __syncthreads();
+      T sx[NC], u1[NC], u3[NC];
+      products<false, 1>(nullptr, wr, nullptr, u1, sx, u3);
+      if (own) {
+#pragma unroll
+        for (int q = 0; q < NC; ++q) { xr[q] = x0[q] - sx[q]; ww[q * CHS + row] = ev_r[q] * xr[q]; }
+      }
+    }
+  }
+
+  // one half step (csrc/rmhmc_explicit.hip:half_step): upd_x += eh G(X)^-1 m ; upd_g -= eh P (X - mu); its jitter is
+  // the next slot of the buffer refill_jitter() filled.  1 + K barriers.
+  __device__ __forceinline__ void half_step(const T* X, const T* m, T* upd_x, T* upd_g, T eh) {
+    T* d = dpar ? d1 : d0;                                 // alternate: with K == 0 nothing else separates two evaluations
+    dpar ^= 1;
+    if (own) {
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        ev_r[q] = a.has_jitter ? jb[(jslot * NC + q) * 128 + row] : (T)0;
+        d[q * CHS + row] = X[q * CHS + row] - mu_r;
+      }
+    }
+    ++jslot;
+    HTA_MTICK(4);
+    __syncthreads();
+    HTA_MTICK(5);
+    T Pd[NC], x0[NC], u3[NC], xr[NC];
+    products<true, 1>(d, m, nullptr, Pd, x0, u3);
+    HTA_MTICK(6);
+    if (own) {
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        upd_g[q * CHS + row] -= eh * Pd[q];
+        xr[q] = x0[q];
+        w0[q * CHS + row] = ev_r[q] * x0[q];
+      }
+    }
+    HTA_MTICK(7);
+    refine(x0, xr);
+    if (own) {
+#pragma unroll
+      for (int q = 0; q < NC; ++q) upd_x[q * CHS + row] += eh * xr[q];
+    }
+    HTA_MTICK(3);
   }
 
   __device__ __forceinline__ T factor() { return chol_in_lds<T>(a.P, ev, W, dg, D, ld, tid); }
 
-  // refinement of x = (P + diag(ev))^-1 m from x0 = S m (already in x0 / x / w = ev . x): K products with S
-  __device__ __forceinline__ void refine() {
-    for (int it = 0; it < a.K; ++it) {
-      __syncthreads();
-      products<false, 1>(nullptr, nullptr, nullptr, w, r0, r1, nullptr, nullptr, nullptr);
-      __syncthreads();
-      if (tid < D) { const T xn = x0[tid] - (r0[tid] + r1[tid]); x[tid] = xn; w[tid] = ev[tid] * xn; }
+  // H = -log p + D/2 log 2 pi + 1/2 log|G| + 1/2 m^T G^-1 m  (S:731) at (X, m) per chain, jitter sub-stream `sub`
+  __device__ __forceinline__ void hamiltonian(uint32_t n, uint32_t sub, const T* X, const T* m, T (&H)[NC], T (&logp)[NC]) {
+    T* d = dpar ? d1 : d0;
+    dpar ^= 1;
+    T dr[NC];
+    if (own) {
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        const T e = jitter_elem(q, n, sub);
+        ev_r[q] = e; ev[q * CHS + row] = e;
+        dr[q] = X[q * CHS + row] - mu_r; d[q * CHS + row] = dr[q];
+      }
     }
-  }
-
-  // one half step (csrc/rmhmc_explicit.hip:half_step): upd_x += eh G(X)^-1 m ; upd_g -= eh P (X - mu).
-  // The jitter of this evaluation was drawn during the previous one (ev_next: the Philox rounds run under that
-  // evaluation's LDS traffic); `next_sub` is the sub-stream of the evaluation that follows.
-  __device__ __forceinline__ void half_step(uint32_t n, uint32_t next_sub, const T* X, const T* m, T* upd_x, T* upd_g, T eh) {
-    __syncthreads();
-    if (tid < D) { ev[tid] = ev_next; d[tid] = X[tid] - mu_r; }
-    __syncthreads();
-    products<true, 1>(d, q0, q1, m, r0, r1, nullptr, nullptr, nullptr);
-    ev_next = jitter_elem(n, next_sub);
-    __syncthreads();
-    if (tid < D) {
-      upd_g[tid] -= eh * (q0[tid] + q1[tid]);
-      const T xs = r0[tid] + r1[tid];
-      x0[tid] = xs; x[tid] = xs; w[tid] = ev[tid] * xs;
-    }
-    refine();
-    if (tid < D) upd_x[tid] += eh * x[tid];
-  }
-
-  // H = -log p + D/2 log 2 pi + 1/2 log|G| + 1/2 m^T G^-1 m  (S:731) at (X, m), jitter sub-stream `sub`
-  __device__ __forceinline__ T hamiltonian(uint32_t n, uint32_t sub, const T* X, const T* m, T& logp_out) {
-    __syncthreads();
-    draw_jitter(n, sub);
-    if (tid < D) d[tid] = X[tid] - mu_r;
-    T ld_part = 0;
     const bool series = a.series || !a.has_jitter;
-    if (!series) ld_part = factor();                        // exact: Cholesky of P + E
+    T ld_exact = 0;
+    if (NC == 1 && !series) ld_exact = factor();              // exact log|P + E| (its own barriers; reads ev from LDS)
     __syncthreads();
-    if (series && a.has_jitter) products<true, 2>(d, q0, q1, m, r0, r1, ev, s0, s1);
-    else products<true, 1>(d, q0, q1, m, r0, r1, nullptr, nullptr, nullptr);
-    __syncthreads();
-    T dPd = 0;
-    if (tid < D) {
-      dPd = d[tid] * (q0[tid] + q1[tid]);
-      const T xs = r0[tid] + r1[tid];
-      x0[tid] = xs; x[tid] = xs; w[tid] = ev[tid] * xs;
-      if (series && a.has_jitter)       // log|P + E| = log|P| + tr(SE) - 1/2 tr((SE)^2) + O(D rho^3 / 3)
-        ld_part = ev[tid] * (sdiag[tid] - (T)0.5 * (s0[tid] + s1[tid]));
+    T Pd[NC], x0[NC], s2[NC], xr[NC];
+    if (series && a.has_jitter) products<true, 2>(d, m, ev, Pd, x0, s2);
+    else products<true, 1>(d, m, nullptr, Pd, x0, s2);
+    T v[NC][4];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) { v[q][0] = v[q][1] = v[q][2] = v[q][3] = 0; xr[q] = x0[q]; }
+    if (own) {
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        v[q][0] = dr[q] * Pd[q];
+        w0[q * CHS + row] = ev_r[q] * x0[q];
+        // log|P + E| = log|P| + tr(SE) - 1/2 tr((SE)^2) + O(D rho^3 / 3)
+        if (series && a.has_jitter) v[q][2] = ev_r[q] * (sd_r - (T)0.5 * s2[q]);
+      }
     }
-    refine();
-    T v[4] = {dPd, tid < D ? m[tid] * x[tid] : (T)0, ld_part, (T)0};
-    block_sum4(v);
-    const T lp = a.log_norm - (T)0.5 * v[0];
-    const T logdet = series ? a.logdetP + v[2] : v[2];
-    logp_out = lp;
+    if (NC == 1 && !series) v[0][2] = ld_exact;
+    refine(x0, xr);
+    if (own) {
+#pragma unroll
+      for (int q = 0; q < NC; ++q) v[q][1] = m[q * CHS + row] * xr[q];
+    }
+    block_sums(v);
     const float pi_term = (float)D * 1.8378770351409912f;     // S:712: float32 whatever the state dtype
-    return -lp + (T)0.5 * (T)pi_term + (T)0.5 * logdet + (T)0.5 * v[1];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      const T lp = a.log_norm - (T)0.5 * v[q][0];
+      const T logdet = series ? a.logdetP + v[q][2] : v[q][2];
+      logp[q] = lp;
+      H[q] = -lp + (T)0.5 * (T)pi_term + (T)0.5 * logdet + (T)0.5 * v[q][1];
+    }
   }
 };
 
-constexpr int FVEC = 18;          // LDS vectors of a chain (each padded to 128 entries, zero beyond D)
-
-template <typename T, int KH>
-__global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int ld) {
+template <typename T, int KH, int NC>
+__global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int ld, int need_w) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  FusedChain<T, KH> ch(a);
+  typedef Fused<T, KH, NC> F;
+  F ch(a);
   const int D = a.D, tid = threadIdx.x;
-  constexpr int Dp = 128;
-  ch.D = D; ch.ld = ld; ch.tid = tid;
+  ch.D = D; ch.ld = ld; ch.tid = tid; ch.dpar = 0;
   {
-    const int wave = tid >> 6;
-    ch.row = (wave & 1) * 64 + (tid & 63);
-    ch.rowok = ch.row < D;
-    ch.hi = wave >> 1;
-    ch.k0 = ch.hi ? KH : 0;
+    const int wave = tid >> 6, lane = tid & 63;
+    ch.row = 32 * wave + (lane & 31);
+    ch.k0 = (lane >> 5) ? KH : 0;
+    ch.own = (lane >= 32) && ch.row < D;                    // the upper lane of a row holds the complete sums
   }
   T* v = reinterpret_cast<T*>(smem_raw);
-  T** slots[FVEC] = {&ch.dg, &ch.sdiag, &ch.cur, &ch.th, &ch.pm, &ch.thc, &ch.pmc, &ch.ev, &ch.d, &ch.x0, &ch.x, &ch.w,
-                     &ch.q0, &ch.q1, &ch.r0, &ch.r1, &ch.s0, &ch.s1};
-  for (int i = 0; i < FVEC; ++i) *slots[i] = v + i * Dp;
-  ch.red = v + FVEC * Dp;
-  ch.W = ch.red + 16;
-  for (int e = tid; e < FVEC * Dp; e += FNT) v[e] = (T)0;
-  __syncthreads();
-  if (tid < D) ch.sdiag[tid] = a.S[(int64_t)tid * D + tid];
-  ch.mu_r = tid < D ? a.mu[tid] : (T)0;
+  T** slots[FVC] = {&ch.cur, &ch.th, &ch.pm, &ch.thc, &ch.pmc, &ch.ev, &ch.d0, &ch.d1, &ch.w0, &ch.w1};
+  for (int i = 0; i < FVC; ++i) *slots[i] = v + i * 128;
+  ch.dg = v + NC * F::CHS;
+  ch.red = ch.dg + 128;
+  ch.jb = ch.red + 32;                                      // [8 evaluation slots][128]
+  ch.W = ch.jb + 8 * 128;                                   // only with need_w
+  for (int e = tid; e < NC * F::CHS + 128; e += FNT) v[e] = (T)0;
+  const int row = ch.row;
+  ch.mu_r = row < D ? a.mu[row] : (T)0;
+  ch.sd_r = row < D ? a.S[(int64_t)row * D + row] : (T)0;
   const T eh = (T)0.5 * a.eps;
+  ch.load_slices();
 #if HTA_RM_TIMING
   __syncthreads();
   ch.tlast = __builtin_readcyclecounter();
 #endif
-  ch.load_slices();
   bool have_factor = false;                                 // without jitter chol(P) serves every chain and trajectory
-  for (int64_t c = blockIdx.x; c < a.C; c += gridDim.x) {
-    ch.chain = a.chain_offset + (uint64_t)c;
-    __syncthreads();
-    if (tid < D) ch.cur[tid] = a.cur[c * D + tid];
-    int32_t rejected = 0;
-    for (int t = 0; t < a.n_traj; ++t) {
-      const uint32_t n = (uint32_t)(a.traj_offset + t);
-      // ---- gibbs: p = chol(G(theta)) z  (S:183-184), jitter sub-stream 0
-      __syncthreads();
-      HTA_RTICK(0);
-      if (a.p_ws) {
-        if (tid < D) ch.pm[tid] = a.p_ws[((int64_t)t * a.C + c) * D + tid];
-      } else {
-        ch.draw_jitter(n, 0);
-        if (a.has_jitter || !have_factor) { ch.factor(); have_factor = true; }
-        HTA_RTICK(1);
-        if (tid < D) ch.d[tid] = normal_elem<T>(a.seed, ch.chain, n, 0, tid);
-        __syncthreads();
-        if (tid < D) {
-          T acc0 = ch.dg[tid] * ch.d[tid], acc1 = 0;
-          const T* rowp = ch.W + tid * ld;
-          int k = 0;
-          for (; k + 1 < tid; k += 2) { acc0 = fma(rowp[k], ch.d[k], acc0); acc1 = fma(rowp[k + 1], ch.d[k + 1], acc1); }
-          if (k < tid) acc0 = fma(rowp[k], ch.d[k], acc0);
-          ch.pm[tid] = acc0 + acc1;
-        }
-      }
-      __syncthreads();
-      // ---- H_old (S:971 -> S:822), sub-stream 1
-      HTA_RTICK(2);
-      T lp0;
-      const T H0 = ch.hamiltonian(n, 1, ch.cur, ch.pm, lp0);
-      HTA_RTICK(3);
-      if (tid < D) { ch.th[tid] = ch.cur[tid]; ch.thc[tid] = ch.cur[tid]; ch.pmc[tid] = ch.pm[tid]; }   // S:425-426
-      // ---- L explicit steps (S:427-461)
-      for (int l = 0; l < a.L; ++l) {
-        const uint32_t k0 = 2u + 8u * (uint32_t)l;
-        if (l == 0) ch.ev_next = ch.jitter_elem(n, k0 + 1);
-        ch.half_step(n, k0 + 2, ch.th, ch.pmc, ch.thc, ch.pm, eh);          // phi_A/2  S:429-430 (sub-stream k0 + 1)
-        ch.half_step(n, k0 + 4, ch.thc, ch.pm, ch.th, ch.pmc, eh);          // phi_B/2  S:432-433 (k0 + 2)
-        if (tid < D) {                                                        // phi_C    S:447-450, sequential (Q1)
-          T xx = ch.th[tid], b = ch.pm[tid], xc = ch.thc[tid], bc = ch.pmc[tid];
-          const T h = (T)0.5, cc = a.rot_c, ss = a.rot_s;
-          xx = h * ((xx + xc) + cc * (xx - xc) + ss * (b - bc));
-          b = h * ((b + bc) - ss * (xx - xc) + cc * (b - bc));
-          xc = h * ((xx + xc) - cc * (xx - xc) - ss * (b - bc));
-          bc = h * ((b + bc) + ss * (xx - xc) - cc * (b - bc));
-          ch.th[tid] = xx; ch.pm[tid] = b; ch.thc[tid] = xc; ch.pmc[tid] = bc;
-        }
-        ch.half_step(n, k0 + 7, ch.thc, ch.pm, ch.th, ch.pmc, eh);          // phi_B/2  S:454-455 (k0 + 4)
-        ch.half_step(n, k0 + 8 + 1, ch.th, ch.pmc, ch.thc, ch.pm, eh);      // phi_A/2  S:457-458 (k0 + 7); next: step l + 1
-      }
-      // ---- H_new on the un-augmented pair (S:989, Q4), sub-stream 2 + 8L
-      HTA_RTICK(4);
-      T lp1;
-      const T H1 = ch.hamiltonian(n, 2u + 8u * (uint32_t)a.L, ch.th, ch.pm, lp1);
-      HTA_RTICK(5);
-      // ---- Metropolis test + bookkeeping (S:1000-1026, S:1045-1057), as hmc_pieces.hip:mh_select_kernel
-      const T u = u23<T>(philox_block(a.seed, ch.chain, n, PURPOSE_MH, 0, 0).x);
-      const bool acc = mh_accept<T>(H0, H1, lp1, u);
-      const bool reset = (!acc) && ((int)n == a.burn + 1);                    // Q2
-      __syncthreads();
-      if (tid < D) {
-        const T vnew = acc ? ch.th[tid] : (reset ? a.theta_init[c * D + tid] : ch.cur[tid]);
-        ch.cur[tid] = vnew;
-        if (a.samples && (int)n > a.burn) a.samples[((int64_t)((int)n - a.burn) * a.C + c) * D + tid] = vnew;
-      }
-      if (!acc) ++rejected;
-      if (tid == 0) {
-        if (a.H_old) a.H_old[(int64_t)t * a.C + c] = H0;
-        if (a.H_new) a.H_new[(int64_t)t * a.C + c] = H1;
-        if (a.accept) a.accept[(int64_t)t * a.C + c] = acc ? 1 : 0;
-      }
+  const int64_t ngroup = (a.C + NC - 1) / NC;
+  for (int64_t cg = blockIdx.x; cg < ngroup; cg += gridDim.x) {
+    int64_t c[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      c[q] = NC * cg + q;
+      ch.live[q] = c[q] < a.C;                               // an odd chain count leaves the last pair half empty
+      ch.chain[q] = a.chain_offset + (uint64_t)(ch.live[q] ? c[q] : 0);
     }
     __syncthreads();
-    if (tid < D) a.cur[c * D + tid] = ch.cur[tid];
-    if (tid == 0) a.reject_count[c] += rejected;
+    if (ch.own) {
+#pragma unroll
+      for (int q = 0; q < NC; ++q) ch.cur[q * F::CHS + row] = ch.live[q] ? a.cur[c[q] * D + row] : (T)0;
+    }
+    int32_t rejected[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) rejected[q] = 0;
+    for (int t = 0; t < a.n_traj; ++t) {
+      const uint32_t n = (uint32_t)(a.traj_offset + t);
+      HTA_RTICK(0);
+      // ---- gibbs: p = chol(G(theta)) z  (S:183-184), jitter sub-stream 0
+      if (a.p_ws) {
+        if (ch.own) {
+#pragma unroll
+          for (int q = 0; q < NC; ++q) ch.pm[q * F::CHS + row] = ch.live[q] ? a.p_ws[((int64_t)t * a.C + c[q]) * D + row] : (T)0;
+        }
+      } else if (NC == 1) {                                   // no pre-drawn momenta: factor here (tid-indexed helper phases)
+        __syncthreads();
+        if (tid < D) ch.ev[tid] = a.has_jitter ? a.jitter * uniform_elem<T>(a.seed, ch.chain[0], n, PURPOSE_JITTER, 0, tid) : (T)0;
+        if (a.has_jitter || !have_factor) { ch.factor(); have_factor = true; }
+        if (tid < D) ch.w1[tid] = normal_elem<T>(a.seed, ch.chain[0], n, 0, tid);
+        __syncthreads();
+        if (tid < D) {
+          T acc0 = ch.dg[tid] * ch.w1[tid], acc1 = 0;
+          const T* rowp = ch.W + tid * ld;
+          int k = 0;
+          for (; k + 1 < tid; k += 2) { acc0 = fma(rowp[k], ch.w1[k], acc0); acc1 = fma(rowp[k + 1], ch.w1[k + 1], acc1); }
+          if (k < tid) acc0 = fma(rowp[k], ch.w1[k], acc0);
+          ch.pm[tid] = acc0 + acc1;
+        }
+        __syncthreads();
+      }
+      // ---- H_old (S:971 -> S:822), sub-stream 1
+      T H0[NC], H1[NC], lp0[NC], lp1[NC];
+      ch.hamiltonian(n, 1, ch.cur, ch.pm, H0, lp0);
+      if (ch.own) {                                                           // S:425-426
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+          const int o = q * F::CHS + row;
+          ch.th[o] = ch.cur[o]; ch.thc[o] = ch.cur[o]; ch.pmc[o] = ch.pm[o];
+        }
+      }
+      HTA_RTICK(1);
+      // ---- L explicit steps (S:427-461)
+      for (int l = 0; l < a.L; ++l) {
+        if (l == 0 || ch.jslot == F::NSLOT) ch.refill_jitter(n, l);         // sub-streams 2 + 8 l + {1, 2, 4, 7}, ...
+        ch.half_step(ch.th, ch.pmc, ch.thc, ch.pm, eh);                       // phi_A/2  S:429-430
+        ch.half_step(ch.thc, ch.pm, ch.th, ch.pmc, eh);                       // phi_B/2  S:432-433
+        if (ch.own) {                                                         // phi_C    S:447-450, sequential (Q1)
+#pragma unroll
+          for (int q = 0; q < NC; ++q) {
+            const int o = q * F::CHS + row;
+            T xx = ch.th[o], b = ch.pm[o], xc = ch.thc[o], bc = ch.pmc[o];
+            const T h = (T)0.5, cc = a.rot_c, ss = a.rot_s;
+            xx = h * ((xx + xc) + cc * (xx - xc) + ss * (b - bc));
+            b = h * ((b + bc) - ss * (xx - xc) + cc * (b - bc));
+            xc = h * ((xx + xc) - cc * (xx - xc) - ss * (b - bc));
+            bc = h * ((b + bc) + ss * (xx - xc) - cc * (b - bc));
+            ch.th[o] = xx; ch.pm[o] = b; ch.thc[o] = xc; ch.pmc[o] = bc;
+          }
+        }
+        ch.half_step(ch.thc, ch.pm, ch.th, ch.pmc, eh);                       // phi_B/2  S:454-455
+        ch.half_step(ch.th, ch.pmc, ch.thc, ch.pm, eh);                       // phi_A/2  S:457-458
+      }
+      HTA_RTICK(2);
+      // ---- H_new on the un-augmented pair (S:989, Q4), sub-stream 2 + 8L
+      ch.hamiltonian(n, 2u + 8u * (uint32_t)a.L, ch.th, ch.pm, H1, lp1);
+      HTA_RTICK(3);
+      // ---- Metropolis test + bookkeeping (S:1000-1026, S:1045-1057), as hmc_pieces.hip:mh_select_kernel
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        const T u = u23<T>(philox_block(a.seed, ch.chain[q], n, PURPOSE_MH, 0, 0).x);
+        const bool acc = mh_accept<T>(H0[q], H1[q], lp1[q], u);
+        const bool reset = (!acc) && ((int)n == a.burn + 1);                  // Q2
+        if (ch.own && ch.live[q]) {
+          const int o = q * F::CHS + row;
+          const T vnew = acc ? ch.th[o] : (reset ? a.theta_init[c[q] * D + row] : ch.cur[o]);
+          ch.cur[o] = vnew;
+          if (a.samples && (int)n > a.burn) a.samples[((int64_t)((int)n - a.burn) * a.C + c[q]) * D + row] = vnew;
+        }
+        if (!acc) ++rejected[q];
+        if (tid == 0 && ch.live[q]) {
+          if (a.H_old) a.H_old[(int64_t)t * a.C + c[q]] = H0[q];
+          if (a.H_new) a.H_new[(int64_t)t * a.C + c[q]] = H1[q];
+          if (a.accept) a.accept[(int64_t)t * a.C + c[q]] = acc ? 1 : 0;
+        }
+      }
+    }
+    if (ch.own) {
+#pragma unroll
+      for (int q = 0; q < NC; ++q) if (ch.live[q]) a.cur[c[q] * D + row] = ch.cur[q * F::CHS + row];
+    }
+    if (tid == 0) {
+#pragma unroll
+      for (int q = 0; q < NC; ++q) if (ch.live[q]) a.reject_count[c[q]] += rejected[q];
+    }
 #if HTA_RM_TIMING
     if (tid == 0 && blockIdx.x == 0) for (int k = 0; k < 8; ++k) hta_rm_dbg[k] = ch.tacc[k];
 #endif
-  }
-}
-
-// ---- two chains per workgroup -------------------------------------------------------------------------------------
-// From ~1000 chains per GPU on, several chains share a CU.  The register-resident slices of P and S do not depend on the
-// chain, so one workgroup can carry TWO chains through every product pass: twice the FMAs per slice element read, the
-// same number of barriers and LDS round trips.  Element-wise work is split by thread half: threads 0..127 own chain 0 of
-// the pair, threads 128..255 chain 1.  Needs the pre-drawn momenta (p_ws) and the log-det series (or no jitter): no
-// Cholesky, hence no work matrix, in this kernel.
-constexpr int F2V = 16;           // per-chain LDS vectors of the pair kernel
-
-template <typename T, int KH> struct FusedPair {
-  typedef T V4 __attribute__((ext_vector_type(4)));
-  static constexpr int CHS = F2V * 128;      // stride between the two chains' vector sets
-  const FusedArgs<T>& a;
-  int D, tid, row, k0, ei;
-  bool rowok, hi, eok;
-  T Preg[KH], Sreg[KH];
-  T mu_r, sd_r, ev_next;
-  // vector sets (chain 0 at the pointer, chain 1 at + CHS); `my` = the set of this thread's own chain
-  T *cur, *th, *pm, *thc, *pmc, *ev, *d, *x0, *x, *w, *q0, *q1, *r0, *r1, *s0, *s1, *red;
-  int my;
-  uint64_t chain;
-  __device__ FusedPair(const FusedArgs<T>& a_) : a(a_) {}
-
-  __device__ __forceinline__ void block_sum4(T (&v)[4]) {          // sums over the two waves of this thread's chain
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = wave_sum(v[q]);
-    __syncthreads();
-    if ((tid & 63) == 0) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) red[4 * (tid >> 6) + q] = v[q];
-    }
-    __syncthreads();
-    const int w0 = (tid >> 7) * 2;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = red[4 * w0 + q] + red[4 * (w0 + 1) + q];
-  }
-
-  template <bool WITH_P, int NS>
-  __device__ __forceinline__ void products(const T* v1, T* o10, T* o11, const T* v2, T* o20, T* o21, const T* v3, T* o30, T* o31) {
-    T a1[2] = {0, 0}, a2[2] = {0, 0}, a3[2] = {0, 0};
-#pragma unroll
-    for (int kk = 0; kk < KH; kk += 4) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        V4 u1, u2, u3;
-        if (WITH_P) u1 = *reinterpret_cast<const V4*>(v1 + q * CHS + k0 + kk);
-        if (NS >= 1) u2 = *reinterpret_cast<const V4*>(v2 + q * CHS + k0 + kk);
-        if (NS >= 2) u3 = *reinterpret_cast<const V4*>(v3 + q * CHS + k0 + kk);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (WITH_P) a1[q] = fma(Preg[kk + e], u1[e], a1[q]);
-          if (NS >= 1) a2[q] = fma(Sreg[kk + e], u2[e], a2[q]);
-          if (NS >= 2) a3[q] = fma(Sreg[kk + e] * Sreg[kk + e], u3[e], a3[q]);
-        }
-      }
-    }
-    if (!rowok) return;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (WITH_P) { T* const h1 = (hi ? o11 : o10) + q * CHS; h1[row] = a1[q]; }
-      if (NS >= 1) { T* const h2 = (hi ? o21 : o20) + q * CHS; h2[row] = a2[q]; }
-      if (NS >= 2) { T* const h3 = (hi ? o31 : o30) + q * CHS; h3[row] = a3[q]; }
-    }
-  }
-
-  __device__ __forceinline__ T jitter_elem(uint32_t n, uint32_t sub) {
-    return (a.has_jitter && eok) ? a.jitter * uniform_elem<T>(a.seed, chain, n, PURPOSE_JITTER, sub, ei) : (T)0;
-  }
-
-  __device__ __forceinline__ void refine() {
-    for (int it = 0; it < a.K; ++it) {
-      __syncthreads();
-      products<false, 1>(nullptr, nullptr, nullptr, w, r0, r1, nullptr, nullptr, nullptr);
-      __syncthreads();
-      if (eok) { const T xn = x0[my + ei] - (r0[my + ei] + r1[my + ei]); x[my + ei] = xn; w[my + ei] = ev[my + ei] * xn; }
-    }
-  }
-
-  __device__ __forceinline__ void half_step(uint32_t n, uint32_t next_sub, const T* X, const T* m, T* upd_x, T* upd_g, T eh) {
-    __syncthreads();
-    if (eok) { ev[my + ei] = ev_next; d[my + ei] = X[my + ei] - mu_r; }
-    __syncthreads();
-    products<true, 1>(d, q0, q1, m, r0, r1, nullptr, nullptr, nullptr);
-    ev_next = jitter_elem(n, next_sub);
-    __syncthreads();
-    if (eok) {
-      upd_g[my + ei] -= eh * (q0[my + ei] + q1[my + ei]);
-      const T xs = r0[my + ei] + r1[my + ei];
-      x0[my + ei] = xs; x[my + ei] = xs; w[my + ei] = ev[my + ei] * xs;
-    }
-    refine();
-    if (eok) upd_x[my + ei] += eh * x[my + ei];
-  }
-
-  __device__ __forceinline__ T hamiltonian(uint32_t n, uint32_t sub, const T* X, const T* m, T& logp_out) {
-    __syncthreads();
-    if (eok) { ev[my + ei] = jitter_elem(n, sub); d[my + ei] = X[my + ei] - mu_r; }
-    __syncthreads();
-    if (a.has_jitter) products<true, 2>(d, q0, q1, m, r0, r1, ev, s0, s1);
-    else products<true, 1>(d, q0, q1, m, r0, r1, nullptr, nullptr, nullptr);
-    __syncthreads();
-    T dPd = 0, ld_part = 0;
-    if (eok) {
-      dPd = d[my + ei] * (q0[my + ei] + q1[my + ei]);
-      const T xs = r0[my + ei] + r1[my + ei];
-      x0[my + ei] = xs; x[my + ei] = xs; w[my + ei] = ev[my + ei] * xs;
-      if (a.has_jitter) ld_part = ev[my + ei] * (sd_r - (T)0.5 * (s0[my + ei] + s1[my + ei]));
-    }
-    refine();
-    T v[4] = {dPd, eok ? m[my + ei] * x[my + ei] : (T)0, ld_part, (T)0};
-    block_sum4(v);
-    const T lp = a.log_norm - (T)0.5 * v[0];
-    logp_out = lp;
-    const float pi_term = (float)D * 1.8378770351409912f;     // S:712
-    return -lp + (T)0.5 * (T)pi_term + (T)0.5 * (a.logdetP + v[2]) + (T)0.5 * v[1];
-  }
-};
-
-template <typename T, int KH>
-__global__ __launch_bounds__(FNT, 2) void rmhmc_fused_pair_kernel(FusedArgs<T> a) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  FusedPair<T, KH> ch(a);
-  const int D = a.D, tid = threadIdx.x;
-  ch.D = D; ch.tid = tid;
-  {
-    const int wave = tid >> 6;
-    ch.row = (wave & 1) * 64 + (tid & 63);
-    ch.rowok = ch.row < D;
-    ch.hi = wave >> 1;
-    ch.k0 = ch.hi ? KH : 0;
-#pragma unroll
-    for (int kk = 0; kk < KH; ++kk) {
-      const int k = ch.k0 + kk;
-      const bool ok = ch.rowok && k < D;
-      ch.Preg[kk] = ok ? a.P[(int64_t)k * D + ch.row] : (T)0;
-      ch.Sreg[kk] = ok ? a.S[(int64_t)k * D + ch.row] : (T)0;
-    }
-  }
-  T* v = reinterpret_cast<T*>(smem_raw);
-  T** slots[F2V] = {&ch.cur, &ch.th, &ch.pm, &ch.thc, &ch.pmc, &ch.ev, &ch.d, &ch.x0, &ch.x, &ch.w,
-                    &ch.q0, &ch.q1, &ch.r0, &ch.r1, &ch.s0, &ch.s1};
-  for (int i = 0; i < F2V; ++i) *slots[i] = v + i * 128;
-  ch.red = v + 2 * F2V * 128;
-  for (int e = tid; e < 2 * F2V * 128; e += FNT) v[e] = (T)0;
-  const int eq = tid >> 7;
-  ch.ei = tid & 127;
-  ch.my = eq * FusedPair<T, KH>::CHS;
-  ch.mu_r = ch.ei < D ? a.mu[ch.ei] : (T)0;
-  ch.sd_r = ch.ei < D ? a.S[(int64_t)ch.ei * D + ch.ei] : (T)0;
-  const T eh = (T)0.5 * a.eps;
-  const int64_t npair = (a.C + 1) / 2;
-  for (int64_t cp = blockIdx.x; cp < npair; cp += gridDim.x) {
-    const int64_t c = 2 * cp + eq;
-    const bool live = c < a.C;                               // an odd chain count leaves the last pair half empty
-    ch.eok = live && ch.ei < D;
-    ch.chain = a.chain_offset + (uint64_t)(live ? c : 0);
-    const int ei = ch.ei, my = ch.my;
-    __syncthreads();
-    if (ch.eok) ch.cur[my + ei] = a.cur[c * D + ei];
-    int32_t rejected = 0;
-    for (int t = 0; t < a.n_traj; ++t) {
-      const uint32_t n = (uint32_t)(a.traj_offset + t);
-      __syncthreads();
-      if (ch.eok) ch.pm[my + ei] = a.p_ws[((int64_t)t * a.C + c) * D + ei];       // S:183-184, drawn by rmhmc_momentum_kernel
-      T lp0;
-      const T H0 = ch.hamiltonian(n, 1, ch.cur, ch.pm, lp0);                     // S:971
-      if (ch.eok) { ch.th[my + ei] = ch.cur[my + ei]; ch.thc[my + ei] = ch.cur[my + ei]; ch.pmc[my + ei] = ch.pm[my + ei]; }
-      for (int l = 0; l < a.L; ++l) {
-        const uint32_t k0 = 2u + 8u * (uint32_t)l;
-        if (l == 0) ch.ev_next = ch.jitter_elem(n, k0 + 1);
-        ch.half_step(n, k0 + 2, ch.th, ch.pmc, ch.thc, ch.pm, eh);          // phi_A/2  S:429-430
-        ch.half_step(n, k0 + 4, ch.thc, ch.pm, ch.th, ch.pmc, eh);          // phi_B/2  S:432-433
-        if (ch.eok) {                                                         // phi_C    S:447-450, sequential (Q1)
-          T xx = ch.th[my + ei], b = ch.pm[my + ei], xc = ch.thc[my + ei], bc = ch.pmc[my + ei];
-          const T h = (T)0.5, cc = a.rot_c, ss = a.rot_s;
-          xx = h * ((xx + xc) + cc * (xx - xc) + ss * (b - bc));
-          b = h * ((b + bc) - ss * (xx - xc) + cc * (b - bc));
-          xc = h * ((xx + xc) - cc * (xx - xc) - ss * (b - bc));
-          bc = h * ((b + bc) + ss * (xx - xc) - cc * (b - bc));
-          ch.th[my + ei] = xx; ch.pm[my + ei] = b; ch.thc[my + ei] = xc; ch.pmc[my + ei] = bc;
-        }
-        ch.half_step(n, k0 + 7, ch.thc, ch.pm, ch.th, ch.pmc, eh);          // phi_B/2  S:454-455
-        ch.half_step(n, k0 + 8 + 1, ch.th, ch.pmc, ch.thc, ch.pm, eh);      // phi_A/2  S:457-458
-      }
-      T lp1;
-      const T H1 = ch.hamiltonian(n, 2u + 8u * (uint32_t)a.L, ch.th, ch.pm, lp1);   // S:989 (Q4)
-      const T u = u23<T>(philox_block(a.seed, ch.chain, n, PURPOSE_MH, 0, 0).x);
-      const bool acc = mh_accept<T>(H0, H1, lp1, u);                        // S:1000-1004, per chain of the pair
-      const bool reset = (!acc) && ((int)n == a.burn + 1);                    // Q2
-      __syncthreads();
-      if (ch.eok) {
-        const T vnew = acc ? ch.th[my + ei] : (reset ? a.theta_init[c * D + ei] : ch.cur[my + ei]);
-        ch.cur[my + ei] = vnew;
-        if (a.samples && (int)n > a.burn) a.samples[((int64_t)((int)n - a.burn) * a.C + c) * D + ei] = vnew;
-      }
-      if (!acc) ++rejected;
-      if (ei == 0 && live) {
-        if (a.H_old) a.H_old[(int64_t)t * a.C + c] = H0;
-        if (a.H_new) a.H_new[(int64_t)t * a.C + c] = H1;
-        if (a.accept) a.accept[(int64_t)t * a.C + c] = acc ? 1 : 0;
-      }
-    }
-    __syncthreads();
-    if (ch.eok) a.cur[c * D + ei] = ch.cur[my + ei];
-    if (ei == 0 && live) a.reject_count[c] += rejected;
   }
 }
 
@@ -670,10 +595,10 @@ __global__ void inverse_from_eigen_kernel(const T* __restrict__ V0, const T* __r
   }
 }
 
-template <typename T> size_t fused_lds_bytes(int D, int* ld_out) {
+template <typename T> size_t fused_lds_bytes(int D, int* ld_out, int NC = 1, bool need_w = true) {
   const int ld = D | 1;
   if (ld_out) *ld_out = ld;
-  return ((size_t)FVEC * 128 + 16 + (size_t)D * ld) * sizeof(T);
+  return ((size_t)NC * FVC * 128 + 128 + 32 + 8 * 128 + (need_w ? (size_t)D * ld : 0)) * sizeof(T);
 }
 
 // Decides whether the identity-soft-abs path applies (lam0: host copy of the jitter-free eigenvalues) and, if so,
@@ -706,7 +631,7 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
                        int n_traj, int traj_offset, int burn, uint64_t seed, uint64_t chain_offset, T* samples,
                        int32_t* reject_count, T* H_old, T* H_new, uint8_t* accept, T* p_ws, int64_t p_ws_elems, hipStream_t s) {
   int ld;
-  const size_t lds = fused_lds_bytes<T>(D, &ld);
+  (void)fused_lds_bytes<T>(D, &ld);
   const float ang = (float)(2.0 * omega * eps);                      // S:435-436: float32 cos / sin whatever the state dtype
   const int grid = (int)(C < 8192 ? C : 8192);
   const int KH = (((D + 1) / 2) + 7) / 8 * 8;                        // register slice: half the contraction range, in eights
@@ -736,8 +661,11 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
                    (T)cosf(ang), (T)sinf(ang), nt, traj_offset + t0, burn, seed, chain_offset, samples, reject_count,
                    H_old ? H_old + (int64_t)t0 * C : nullptr, H_new ? H_new + (int64_t)t0 * C : nullptr,
                    accept ? accept + (int64_t)t0 * C : nullptr, block > 0 ? p_ws : nullptr};
-    // >= 4 chains per CU: two chains per workgroup (needs pre-drawn momenta and the log-det series)
-    const bool pair = g_rmhmc_fused != 2 && block > 0 && (series || !has_jitter) && C >= 1024;
+    // two chains per workgroup (NC = 2; needs pre-drawn momenta and the log-det series): measured 5 % SLOWER than one
+    // chain per workgroup at 1024 and 4096 chains (the pass is LDS-bandwidth bound: every wave streams every vector), so it
+    // is only taken on request (tuning value 3: parity tests keep the variant alive)
+    const bool pair = g_rmhmc_fused == 3 && block > 0 && (series || !has_jitter);
+    const bool need_w = !(block > 0 && (series || !has_jitter));      // a Cholesky inside the kernel: work matrix in LDS
     auto launch = [&](auto kern, auto kern2, bool& dn, bool& dn2) -> int {
       if (pair) {
         if (!dn2) {
@@ -747,7 +675,7 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
         }
         const int64_t npair = (C + 1) / 2;
         profile_begin(s);
-        kern2<<<(int)(npair < 8192 ? npair : 8192), FNT, (2 * F2V * 128 + 32) * sizeof(T), s>>>(a);
+        kern2<<<(int)(npair < 8192 ? npair : 8192), FNT, fused_lds_bytes<T>(D, nullptr, 2, false), s>>>(a, ld, 0);
         profile_end(s);
         return HTA_OK;
       }
@@ -757,20 +685,20 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
         dn = true;
       }
       profile_begin(s);
-      kern<<<grid, FNT, lds, s>>>(a, ld);
+      kern<<<grid, FNT, fused_lds_bytes<T>(D, nullptr, 1, need_w), s>>>(a, ld, need_w ? 1 : 0);
       profile_end(s);
       return HTA_OK;
     };
     int rc;
     switch (KH) {
-      case 8: rc = launch(&rmhmc_fused_kernel<T, 8>, &rmhmc_fused_pair_kernel<T, 8>, done[0], done2[0]); break;
-      case 16: rc = launch(&rmhmc_fused_kernel<T, 16>, &rmhmc_fused_pair_kernel<T, 16>, done[1], done2[1]); break;
-      case 24: rc = launch(&rmhmc_fused_kernel<T, 24>, &rmhmc_fused_pair_kernel<T, 24>, done[2], done2[2]); break;
-      case 32: rc = launch(&rmhmc_fused_kernel<T, 32>, &rmhmc_fused_pair_kernel<T, 32>, done[3], done2[3]); break;
-      case 40: rc = launch(&rmhmc_fused_kernel<T, 40>, &rmhmc_fused_pair_kernel<T, 40>, done[4], done2[4]); break;
-      case 48: rc = launch(&rmhmc_fused_kernel<T, 48>, &rmhmc_fused_pair_kernel<T, 48>, done[5], done2[5]); break;
-      case 56: rc = launch(&rmhmc_fused_kernel<T, 56>, &rmhmc_fused_pair_kernel<T, 56>, done[6], done2[6]); break;
-      default: rc = launch(&rmhmc_fused_kernel<T, 64>, &rmhmc_fused_pair_kernel<T, 64>, done[7], done2[7]); break;
+      case 8: rc = launch(&rmhmc_fused_kernel<T, 8, 1>, &rmhmc_fused_kernel<T, 8, 2>, done[0], done2[0]); break;
+      case 16: rc = launch(&rmhmc_fused_kernel<T, 16, 1>, &rmhmc_fused_kernel<T, 16, 2>, done[1], done2[1]); break;
+      case 24: rc = launch(&rmhmc_fused_kernel<T, 24, 1>, &rmhmc_fused_kernel<T, 24, 2>, done[2], done2[2]); break;
+      case 32: rc = launch(&rmhmc_fused_kernel<T, 32, 1>, &rmhmc_fused_kernel<T, 32, 2>, done[3], done2[3]); break;
+      case 40: rc = launch(&rmhmc_fused_kernel<T, 40, 1>, &rmhmc_fused_kernel<T, 40, 2>, done[4], done2[4]); break;
+      case 48: rc = launch(&rmhmc_fused_kernel<T, 48, 1>, &rmhmc_fused_kernel<T, 48, 2>, done[5], done2[5]); break;
+      case 56: rc = launch(&rmhmc_fused_kernel<T, 56, 1>, &rmhmc_fused_kernel<T, 56, 2>, done[6], done2[6]); break;
+      default: rc = launch(&rmhmc_fused_kernel<T, 64, 1>, &rmhmc_fused_kernel<T, 64, 2>, done[7], done2[7]); break;
     }
     if (rc) return rc;
   }

@@ -380,8 +380,8 @@ def test_fused_path_equals_jacobi_path(ht, dtype, tol, D, jitter, metric):
 
 @pytest.mark.parametrize("D,jitter", [(100, 1e-3), (20, None), (37, 2e-3)])
 def test_fused_pair_kernel_equals_single_chain_kernel(ht, D, jitter):
-    """From 1024 chains on the fused path carries two chains per workgroup; an odd chain count leaves the last pair half
-    empty.  Same run with the pair kernel disabled (tuning value 2) must agree chain by chain."""
+    """The fused kernel can carry two chains per workgroup (tuning value 3; an odd chain count leaves the last pair half
+    empty).  Same run with one chain per workgroup (the default) must agree chain by chain."""
     from hamiltorch_amd import _abi
     t, _ = cfg3_target(ht, D, torch.float32, seed=3)
     C, N, L, eps, seed = 1025, 3, 2, 0.1, 5
@@ -390,7 +390,7 @@ def test_fused_pair_kernel_equals_single_chain_kernel(ht, D, jitter):
               explicit_binding_const=10.0, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT,
               metric=ht.Metric.SOFTABS, debug=2, verbose=False, seed=seed)
     outs = []
-    for mode in (1, 2):
+    for mode in (3, 1):
         _abi.set_tuning("rmhmc_fused", mode)
         try:
             out, acc = ht.sample(t, tt(th0, torch.float32), **kw)

@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import hamiltorch_amd as ht
 from hamiltorch_amd import _abi
 dev = torch.device("cuda:0")
+_abi.set_tuning("rmhmc_fused", int(os.environ.get("FUSED", "1")))
 D, C, T = 100, int(sys.argv[1]) if len(sys.argv) > 1 else 256, int(sys.argv[2]) if len(sys.argv) > 2 else 4
 g = torch.Generator().manual_seed(0)
 Q = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))[0]
@@ -29,7 +30,7 @@ lib = ctypes.CDLL(_abi.LIB_PATH)
 if hasattr(lib, "hta_rm_dbg_read"):
     buf = (ctypes.c_ulonglong * 8)()
     lib.hta_rm_dbg_read(buf)
-    names = ["other + steps + H", "factor: fill / top", "factor: panel compute", "factor: trailing compute", "-", "-", "factor: panel barriers+writes", "factor: trailing barrier wait"]
+    names = ["everything else", "-", "-", "half step: refinements + tail", "half step: prologue (ev, d)", "half step: barrier", "half step: products(P d, S m)", "half step: element-wise after products"]
     tot = sum(buf)
     for k in range(8):
         print("   %-20s %12d cycles  %5.1f %%" % (names[k], buf[k], 100.0 * buf[k] / max(1, tot)))
