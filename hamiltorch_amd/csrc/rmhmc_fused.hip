@@ -19,6 +19,7 @@
 // Layout: P, S and the Cholesky work matrix in LDS (row stride D|1), the four state vectors and scratch vectors in
 // LDS, 256 threads: a matrix-vector product is 2 threads per row; the Cholesky trailing update a 16 x 16 thread tile.
 #include <math.h>
+#include <utility>
 #include "common.hpp"
 #include "philox.hpp"
 #include "rmhmc.hpp"
@@ -163,6 +164,17 @@ __device__ __forceinline__ float row_total(float h) {
 }
 __device__ __forceinline__ double row_total(double h) { return h + __shfl_xor(h, 32, 64); }
 
+// acc += s * (lane J of this lane's 16-lane row of u): v_fmac_f32 with the DPP row_newbcast control (gfx90a+).  A chunk of
+// 16 vector elements then costs ONE 4-byte LDS load per lane (lane l fetches element l & 15) and 16 FMAs, instead of four
+// 16-byte loads that every lane repeats: the product passes were LDS-bandwidth bound (8 clocks per 16-byte wave load).
+template <int J> __device__ __forceinline__ void fmac_bcast(float& acc, float u, float s) {
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(s), "n"(J));
+}
+template <int... J>
+__device__ __forceinline__ void chunk_fma(const float* reg, float u, float (&acc)[2], std::integer_sequence<int, J...>) {
+  (fmac_bcast<J>(acc[J & 1], u, reg[J]), ...);
+}
+
 // KH: register-resident slice of a matrix column per thread (multiple of 8).  Lane (row, half) keeps P[k][row] and
 // S[k][row] for its KH values of k in VGPRs for the whole launch; a matrix-vector product then only streams the
 // vector (16-byte LDS reads).  The two halves of a row sit in the SAME wave (lanes l and l + 32): their partial sums
@@ -170,7 +182,7 @@ __device__ __forceinline__ double row_total(double h) { return h + __shfl_xor(h,
 // registers - no partial-sum vectors, no combine phases: one barrier per product pass.
 // NC chains can share a workgroup (NC = 2): the slices do not depend on the chain, so a pass carries both chains for the
 // same register reads and barriers - but not for the same LDS traffic, which is what bounds a pass (see the dispatch).
-constexpr int FVC = 10;           // LDS vectors per chain: cur th pm thc pmc ev d0 d1 w0 w1 (128 entries each, zero beyond D)
+constexpr int FVC = 7;            // LDS vectors per chain: pm pmc ev d0 d1 w0 w1 (128 entries each, zero beyond D)
 
 template <typename T, int KH, int NC> struct Fused {
   typedef T V4 __attribute__((ext_vector_type(4)));
@@ -181,8 +193,10 @@ template <typename T, int KH, int NC> struct Fused {
   T Preg[KH], Sreg[KH];
   T mu_r, sd_r;                       // mu[row], S[row][row]
   T ev_r[NC];                         // this owner's elements of the current evaluation's jitter
+  T scur[NC], sth[NC], spm[NC], sthc[NC], spmc[NC];   // the owner's element of the chain state (theta, p and their copies):
+                                      // registers; only the momenta are mirrored in LDS (they are product operands)
   int jslot;                          // next unread evaluation slot of the jitter buffer
-  T *cur, *th, *pm, *thc, *pmc, *ev, *d0, *d1, *w0, *w1, *dg, *red, *W, *jb;
+  T *pm, *pmc, *ev, *d0, *d1, *w0, *w1, *dg, *red, *W, *jb;
   uint64_t chain[NC];
   bool live[NC];
 #if HTA_RM_TIMING
@@ -237,7 +251,28 @@ template <typename T, int KH, int NC> struct Fused {
     constexpr int NCH = KH / 4;
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
-      if (NS <= 1) {
+      if (NS <= 1 && sizeof(T) == 4) {
+        // fp32: one 4-byte load per lane and chunk of 16 elements, broadcast inside the FMA (see fmac_bcast)
+        constexpr int NB = (KH + 15) / 16;
+        float u1[NB], u2[NB];
+        const int l15 = tid & 15;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+          const int off = q * CHS + k0 + 16 * cb + ((16 * cb + 8 < KH) ? l15 : (l15 & 7));    // a trailing half chunk has 8 elements
+          if (WITH_P) u1[cb] = v1[off];
+          if (NS >= 1) u2[cb] = v2[off];
+        }
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+          if (16 * cb + 8 < KH) {
+            if (WITH_P) chunk_fma(reinterpret_cast<const float*>(Preg) + 16 * cb, u1[cb], reinterpret_cast<float(&)[2]>(a1[q]), std::make_integer_sequence<int, 16>{});
+            if (NS >= 1) chunk_fma(reinterpret_cast<const float*>(Sreg) + 16 * cb, u2[cb], reinterpret_cast<float(&)[2]>(a2[q]), std::make_integer_sequence<int, 16>{});
+          } else {
+            if (WITH_P) chunk_fma(reinterpret_cast<const float*>(Preg) + 16 * cb, u1[cb], reinterpret_cast<float(&)[2]>(a1[q]), std::make_integer_sequence<int, 8>{});
+            if (NS >= 1) chunk_fma(reinterpret_cast<const float*>(Sreg) + 16 * cb, u2[cb], reinterpret_cast<float(&)[2]>(a2[q]), std::make_integer_sequence<int, 8>{});
+          }
+        }
+      } else if (NS <= 1) {
         // every 16-byte vector load of this chain first, then the FMAs: left to itself the compiler issues three loads
         // and waits for them, 14 exposed LDS round trips per pass
         V4 u1[NCH], u2[NCH];
@@ -317,15 +352,16 @@ template <typename T, int KH, int NC> struct Fused {
   }
 
   // one half step (csrc/rmhmc_explicit.hip:half_step): upd_x += eh G(X)^-1 m ; upd_g -= eh P (X - mu); its jitter is
-  // the next slot of the buffer refill_jitter() filled.  1 + K barriers.
-  __device__ __forceinline__ void half_step(const T* X, const T* m, T* upd_x, T* upd_g, T eh) {
+  // the next slot of the buffer refill_jitter() filled.  X, upd_x: owner registers; m: LDS vector; upd_g: owner register
+  // mirrored to its LDS vector.  1 + K barriers.
+  __device__ __forceinline__ void half_step(const T (&X)[NC], const T* m, T (&upd_x)[NC], T (&upd_g)[NC], T* upd_g_lds, T eh) {
     T* d = dpar ? d1 : d0;                                 // alternate: with K == 0 nothing else separates two evaluations
     dpar ^= 1;
     if (own) {
 #pragma unroll
       for (int q = 0; q < NC; ++q) {
         ev_r[q] = a.has_jitter ? jb[(jslot * NC + q) * 128 + row] : (T)0;
-        d[q * CHS + row] = X[q * CHS + row] - mu_r;
+        d[q * CHS + row] = X[q] - mu_r;
       }
     }
     ++jslot;
@@ -338,7 +374,8 @@ template <typename T, int KH, int NC> struct Fused {
     if (own) {
 #pragma unroll
       for (int q = 0; q < NC; ++q) {
-        upd_g[q * CHS + row] -= eh * Pd[q];
+        upd_g[q] -= eh * Pd[q];
+        upd_g_lds[q * CHS + row] = upd_g[q];
         xr[q] = x0[q];
         w0[q * CHS + row] = ev_r[q] * x0[q];
       }
@@ -347,7 +384,7 @@ template <typename T, int KH, int NC> struct Fused {
     refine(x0, xr);
     if (own) {
 #pragma unroll
-      for (int q = 0; q < NC; ++q) upd_x[q * CHS + row] += eh * xr[q];
+      for (int q = 0; q < NC; ++q) upd_x[q] += eh * xr[q];
     }
     HTA_MTICK(3);
   }
@@ -355,7 +392,8 @@ template <typename T, int KH, int NC> struct Fused {
   __device__ __forceinline__ T factor() { return chol_in_lds<T>(a.P, ev, W, dg, D, ld, tid); }
 
   // H = -log p + D/2 log 2 pi + 1/2 log|G| + 1/2 m^T G^-1 m  (S:731) at (X, m) per chain, jitter sub-stream `sub`
-  __device__ __forceinline__ void hamiltonian(uint32_t n, uint32_t sub, const T* X, const T* m, T (&H)[NC], T (&logp)[NC]) {
+  __device__ __forceinline__ void hamiltonian(uint32_t n, uint32_t sub, const T (&X)[NC], const T* m, const T (&mr)[NC], T (&H)[NC],
+                                              T (&logp)[NC]) {
     T* d = dpar ? d1 : d0;
     dpar ^= 1;
     T dr[NC];
@@ -364,7 +402,7 @@ template <typename T, int KH, int NC> struct Fused {
       for (int q = 0; q < NC; ++q) {
         const T e = jitter_elem(q, n, sub);
         ev_r[q] = e; ev[q * CHS + row] = e;
-        dr[q] = X[q * CHS + row] - mu_r; d[q * CHS + row] = dr[q];
+        dr[q] = X[q] - mu_r; d[q * CHS + row] = dr[q];
       }
     }
     const bool series = a.series || !a.has_jitter;
@@ -390,7 +428,7 @@ template <typename T, int KH, int NC> struct Fused {
     refine(x0, xr);
     if (own) {
 #pragma unroll
-      for (int q = 0; q < NC; ++q) v[q][1] = m[q * CHS + row] * xr[q];
+      for (int q = 0; q < NC; ++q) v[q][1] = mr[q] * xr[q];
     }
     block_sums(v);
     const float pi_term = (float)D * 1.8378770351409912f;     // S:712: float32 whatever the state dtype
@@ -418,7 +456,7 @@ __global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int
     ch.own = (lane >= 32) && ch.row < D;                    // the upper lane of a row holds the complete sums
   }
   T* v = reinterpret_cast<T*>(smem_raw);
-  T** slots[FVC] = {&ch.cur, &ch.th, &ch.pm, &ch.thc, &ch.pmc, &ch.ev, &ch.d0, &ch.d1, &ch.w0, &ch.w1};
+  T** slots[FVC] = {&ch.pm, &ch.pmc, &ch.ev, &ch.d0, &ch.d1, &ch.w0, &ch.w1};
   for (int i = 0; i < FVC; ++i) *slots[i] = v + i * 128;
   ch.dg = v + NC * F::CHS;
   ch.red = ch.dg + 128;
@@ -444,11 +482,8 @@ __global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int
       ch.live[q] = c[q] < a.C;                               // an odd chain count leaves the last pair half empty
       ch.chain[q] = a.chain_offset + (uint64_t)(ch.live[q] ? c[q] : 0);
     }
-    __syncthreads();
-    if (ch.own) {
 #pragma unroll
-      for (int q = 0; q < NC; ++q) ch.cur[q * F::CHS + row] = ch.live[q] ? a.cur[c[q] * D + row] : (T)0;
-    }
+    for (int q = 0; q < NC; ++q) ch.scur[q] = (ch.own && ch.live[q]) ? a.cur[c[q] * D + row] : (T)0;
     int32_t rejected[NC];
 #pragma unroll
     for (int q = 0; q < NC; ++q) rejected[q] = 0;
@@ -459,7 +494,10 @@ __global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int
       if (a.p_ws) {
         if (ch.own) {
 #pragma unroll
-          for (int q = 0; q < NC; ++q) ch.pm[q * F::CHS + row] = ch.live[q] ? a.p_ws[((int64_t)t * a.C + c[q]) * D + row] : (T)0;
+          for (int q = 0; q < NC; ++q) {
+            ch.spm[q] = ch.live[q] ? a.p_ws[((int64_t)t * a.C + c[q]) * D + row] : (T)0;
+            ch.pm[q * F::CHS + row] = ch.spm[q];
+          }
         }
       } else if (NC == 1) {                                   // no pre-drawn momenta: factor here (tid-indexed helper phases)
         __syncthreads();
@@ -476,42 +514,40 @@ __global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int
           ch.pm[tid] = acc0 + acc1;
         }
         __syncthreads();
+        if (ch.own) ch.spm[0] = ch.pm[row];
       }
       // ---- H_old (S:971 -> S:822), sub-stream 1
       T H0[NC], H1[NC], lp0[NC], lp1[NC];
-      ch.hamiltonian(n, 1, ch.cur, ch.pm, H0, lp0);
-      if (ch.own) {                                                           // S:425-426
+      ch.hamiltonian(n, 1, ch.scur, ch.pm, ch.spm, H0, lp0);
 #pragma unroll
-        for (int q = 0; q < NC; ++q) {
-          const int o = q * F::CHS + row;
-          ch.th[o] = ch.cur[o]; ch.thc[o] = ch.cur[o]; ch.pmc[o] = ch.pm[o];
-        }
+      for (int q = 0; q < NC; ++q) {                                          // S:425-426
+        ch.sth[q] = ch.scur[q]; ch.sthc[q] = ch.scur[q]; ch.spmc[q] = ch.spm[q];
+        if (ch.own) ch.pmc[q * F::CHS + row] = ch.spm[q];
       }
       HTA_RTICK(1);
       // ---- L explicit steps (S:427-461)
       for (int l = 0; l < a.L; ++l) {
         if (l == 0 || ch.jslot == F::NSLOT) ch.refill_jitter(n, l);         // sub-streams 2 + 8 l + {1, 2, 4, 7}, ...
-        ch.half_step(ch.th, ch.pmc, ch.thc, ch.pm, eh);                       // phi_A/2  S:429-430
-        ch.half_step(ch.thc, ch.pm, ch.th, ch.pmc, eh);                       // phi_B/2  S:432-433
-        if (ch.own) {                                                         // phi_C    S:447-450, sequential (Q1)
+        ch.half_step(ch.sth, ch.pmc, ch.sthc, ch.spm, ch.pm, eh);             // phi_A/2  S:429-430
+        ch.half_step(ch.sthc, ch.pm, ch.sth, ch.spmc, ch.pmc, eh);            // phi_B/2  S:432-433
+        if (a.K == 0) __syncthreads();                                        // slower waves may still stream pm (no refinement barrier)
 #pragma unroll
-          for (int q = 0; q < NC; ++q) {
-            const int o = q * F::CHS + row;
-            T xx = ch.th[o], b = ch.pm[o], xc = ch.thc[o], bc = ch.pmc[o];
-            const T h = (T)0.5, cc = a.rot_c, ss = a.rot_s;
-            xx = h * ((xx + xc) + cc * (xx - xc) + ss * (b - bc));
-            b = h * ((b + bc) - ss * (xx - xc) + cc * (b - bc));
-            xc = h * ((xx + xc) - cc * (xx - xc) - ss * (b - bc));
-            bc = h * ((b + bc) + ss * (xx - xc) - cc * (b - bc));
-            ch.th[o] = xx; ch.pm[o] = b; ch.thc[o] = xc; ch.pmc[o] = bc;
-          }
+        for (int q = 0; q < NC; ++q) {                                        // phi_C    S:447-450, sequential (Q1)
+          T xx = ch.sth[q], b = ch.spm[q], xc = ch.sthc[q], bc = ch.spmc[q];
+          const T h = (T)0.5, cc = a.rot_c, ss = a.rot_s;
+          xx = h * ((xx + xc) + cc * (xx - xc) + ss * (b - bc));
+          b = h * ((b + bc) - ss * (xx - xc) + cc * (b - bc));
+          xc = h * ((xx + xc) - cc * (xx - xc) - ss * (b - bc));
+          bc = h * ((b + bc) + ss * (xx - xc) - cc * (b - bc));
+          ch.sth[q] = xx; ch.spm[q] = b; ch.sthc[q] = xc; ch.spmc[q] = bc;
+          if (ch.own) { ch.pm[q * F::CHS + row] = b; ch.pmc[q * F::CHS + row] = bc; }
         }
-        ch.half_step(ch.thc, ch.pm, ch.th, ch.pmc, eh);                       // phi_B/2  S:454-455
-        ch.half_step(ch.th, ch.pmc, ch.thc, ch.pm, eh);                       // phi_A/2  S:457-458
+        ch.half_step(ch.sthc, ch.pm, ch.sth, ch.spmc, ch.pmc, eh);            // phi_B/2  S:454-455
+        ch.half_step(ch.sth, ch.pmc, ch.sthc, ch.spm, ch.pm, eh);             // phi_A/2  S:457-458
       }
       HTA_RTICK(2);
       // ---- H_new on the un-augmented pair (S:989, Q4), sub-stream 2 + 8L
-      ch.hamiltonian(n, 2u + 8u * (uint32_t)a.L, ch.th, ch.pm, H1, lp1);
+      ch.hamiltonian(n, 2u + 8u * (uint32_t)a.L, ch.sth, ch.pm, ch.spm, H1, lp1);
       HTA_RTICK(3);
       // ---- Metropolis test + bookkeeping (S:1000-1026, S:1045-1057), as hmc_pieces.hip:mh_select_kernel
 #pragma unroll
@@ -520,9 +556,8 @@ __global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int
         const bool acc = mh_accept<T>(H0[q], H1[q], lp1[q], u);
         const bool reset = (!acc) && ((int)n == a.burn + 1);                  // Q2
         if (ch.own && ch.live[q]) {
-          const int o = q * F::CHS + row;
-          const T vnew = acc ? ch.th[o] : (reset ? a.theta_init[c[q] * D + row] : ch.cur[o]);
-          ch.cur[o] = vnew;
+          const T vnew = acc ? ch.sth[q] : (reset ? a.theta_init[c[q] * D + row] : ch.scur[q]);
+          ch.scur[q] = vnew;
           if (a.samples && (int)n > a.burn) a.samples[((int64_t)((int)n - a.burn) * a.C + c[q]) * D + row] = vnew;
         }
         if (!acc) ++rejected[q];
@@ -535,7 +570,7 @@ __global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int
     }
     if (ch.own) {
 #pragma unroll
-      for (int q = 0; q < NC; ++q) if (ch.live[q]) a.cur[c[q] * D + row] = ch.cur[q * F::CHS + row];
+      for (int q = 0; q < NC; ++q) if (ch.live[q]) a.cur[c[q] * D + row] = ch.scur[q];
     }
     if (tid == 0) {
 #pragma unroll
