@@ -133,23 +133,25 @@ class _Curvature:
     def __init__(self, log_prob_func):
         f = lambda w: log_prob_func(w).sum()  # noqa: E731
         self.f = f
-        self._val = torch.func.vmap(f)
+        # each of these is replayed as a HIP graph (util.GraphedCallable): eager torch.func is hundreds of tiny launches
+        self._val = util.GraphedCallable(torch.func.vmap(f))
         # gradient and Hessian in one forward-over-reverse pass: jacfwd of (grad, aux = grad)
         g = torch.func.grad(f)
-        self._gh = torch.func.vmap(torch.func.jacfwd(lambda w: (g(w), g(w)), has_aux=True))
-        self._third = torch.func.vmap(torch.func.grad(lambda w, m: (torch.func.hessian(f)(w) * m).sum()))
+        self._gh = util.GraphedCallable(torch.func.vmap(torch.func.jacfwd(lambda w: (g(w), g(w)), has_aux=True)))
+        self._third = util.GraphedCallable(torch.func.vmap(torch.func.grad(lambda w, m: (torch.func.hessian(f)(w) * m).sum())))
 
     # (a callback may promote: e.g. constants it builds in float64 - results are brought back to the state's dtype)
+    # (the graph outputs are static buffers: every result is copied / converted into a fresh tensor here)
     def value(self, theta):
-        return self._val(theta).to(theta.dtype).contiguous()
+        return self._val(theta).to(theta.dtype, copy=True).contiguous()
 
     def grad_neg_hessian(self, theta):
         H, g = self._gh(theta)
-        return g.to(theta.dtype).contiguous(), (-H).to(theta.dtype).contiguous()
+        return g.to(theta.dtype, copy=True).contiguous(), (-H).to(theta.dtype).contiguous()
 
     def contract(self, theta, M):
         """c_i = d_i < Hess log p (theta), M >, M held fixed: [C, D]."""
-        return self._third(theta, M).to(theta.dtype).contiguous()
+        return self._third(theta, M).to(theta.dtype, copy=True).contiguous()
 
 
 def _generic_steps(cv, kind, th, pm, thc, pmc, steps, eps, omega, alpha, jitter, seed, chain_offset, draw, path=None):

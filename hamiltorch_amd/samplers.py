@@ -76,6 +76,11 @@ def _scalar(v):
     return v.sum() if torch.is_tensor(v) else v
 
 
+def _own(t):
+    """A contiguous private copy (graph outputs are static buffers, vmap outputs may be strided)."""
+    return torch.empty(t.shape, dtype=t.dtype, device=t.device).copy_(t)
+
+
 class _BatchedCallback:
     """Evaluates a reference-style ``log_prob_func`` (one (D,) vector in, scalar out) for all
     chains.  ``torch.func.vmap`` when the callback allows it, otherwise a per-chain loop."""
@@ -85,9 +90,10 @@ class _BatchedCallback:
         self.pass_grad = pass_grad
         self._use_vmap = True
         f = lambda w: _scalar(fn(w))  # noqa: E731
-        self._v_logp = torch.func.vmap(f)
-        self._v_gv = torch.func.vmap(torch.func.grad_and_value(f))
-        self._v_pg = torch.func.vmap(pass_grad) if callable(pass_grad) else None
+        # replayed as HIP graphs on the device (util.GraphedCallable): a trajectory calls these hundreds of times
+        self._v_logp = util.GraphedCallable(torch.func.vmap(f))
+        self._v_gv = util.GraphedCallable(torch.func.vmap(torch.func.grad_and_value(f)))
+        self._v_pg = util.GraphedCallable(torch.func.vmap(pass_grad)) if callable(pass_grad) else None
 
     def _loop(self, theta, want_grad):
         lps, gs = [], []
@@ -105,7 +111,7 @@ class _BatchedCallback:
         if self._use_vmap:
             try:
                 with torch.no_grad():
-                    return self._v_logp(theta).contiguous()
+                    return _own(self._v_logp(theta))
             except Exception as e:  # data-dependent control flow, .item(), tuple protocol, ...
                 self._fallback(e)
         return self._loop(theta, False)[1].contiguous()
@@ -118,9 +124,9 @@ class _BatchedCallback:
         if self._use_vmap:
             try:
                 if self._v_pg is not None:
-                    return self._v_pg(theta).contiguous(), self.logp(theta)
+                    return _own(self._v_pg(theta)), self.logp(theta)
                 g, v = self._v_gv(theta)
-                return g.contiguous(), v.contiguous()
+                return _own(g), _own(v)
             except Exception as e:
                 self._fallback(e)
         g, v = self._loop(theta, True)

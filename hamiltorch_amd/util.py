@@ -7,6 +7,7 @@ multi-chain adapters (U:385-405).  Seeding also keys the device-side Philox stre
 from __future__ import annotations
 
 import concurrent.futures
+import os
 import random
 import sys
 import threading
@@ -171,3 +172,56 @@ def split_permutation(seed, draw, M):
         j = (r[i & 3] * (i + 1)) >> 32
         perm[i], perm[j] = perm[j], perm[i]
     return perm
+
+
+# ---- HIP-graph replay of torch-side callbacks ----------------------------------------------------------------
+class GraphedCallable:
+    """Replays a pure tensor function (a user's log_prob_func under vmap / grad / hessian) as a captured HIP graph.
+
+    A generic-callback trajectory calls the user's function hundreds of times on tensors of one fixed shape; in eager
+    mode every call is dozens to hundreds of tiny launches and the run is bound by launch overhead, not by the GPU.
+    The function is captured once per input signature (``torch.cuda.CUDAGraph``) into static buffers and replayed on
+    the current stream, between the native kernels.  Anything that cannot be captured (data-dependent control flow,
+    ``.item()``, host tensors) falls back to eager evaluation for good.  The outputs are static buffers: they are
+    valid until the next call with the same signature, which is how the samplers use them.
+    ``HAMILTORCH_AMD_GRAPHS=0`` disables it."""
+
+    def __init__(self, fn):
+        self.fn = fn
+        self.cache = {}
+        self.enabled = os.environ.get("HAMILTORCH_AMD_GRAPHS", "1") != "0"
+
+    def __call__(self, *args):
+        if not self.enabled or not args[0].is_cuda:
+            return self.fn(*args)
+        key = tuple((tuple(a.shape), a.dtype, a.device) for a in args)
+        ent = self.cache.get(key)
+        if ent is None:
+            ent = self.cache[key] = self._capture(args)
+        if ent is False:
+            return self.fn(*args)
+        static_in, graph, static_out = ent
+        for s_, a in zip(static_in, args):
+            s_.copy_(a)
+        graph.replay()
+        return static_out
+
+    def _capture(self, args):
+        static_in = [a.detach().clone() for a in args]
+        side = torch.cuda.Stream(device=args[0].device)
+        side.wait_stream(torch.cuda.current_stream(args[0].device))
+        with torch.cuda.stream(side):
+            for _ in range(2):                      # warm-up (lazy initialisation, allocator) - errors propagate to the caller
+                self.fn(*static_in)
+        torch.cuda.current_stream(args[0].device).wait_stream(side)
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.fn(*static_in)
+            return static_in, graph, out
+        except Exception as e:  # not capturable: stay eager
+            import warnings
+            warnings.warn("hamiltorch_amd: callback not capturable as a HIP graph (%s: %s); evaluating it eagerly"
+                          % (type(e).__name__, str(e).split("\n")[0][:120]))
+            self.enabled = False
+            return False

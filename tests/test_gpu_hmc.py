@@ -317,3 +317,37 @@ def test_nuts_step_size_adaptation_vs_oracle(ht, route):
         assert bad.mean() <= 0.1
     with pytest.raises(RuntimeError, match="burn must be greater than 0 for NUTS"):
         ht.sample(t, init, num_samples=5, sampler=ht.Sampler.HMC_NUTS, verbose=False)
+
+
+def test_graph_replay_of_callbacks_matches_eager(ht):
+    """util.GraphedCallable: a capturable log_prob_func is replayed as a HIP graph between the native kernels; a callback
+    that cannot be captured (host scalars mixed in, as torch.distributions.Normal(0, 3) does) silently stays eager.
+    Same samples as the eager evaluation either way."""
+    import os
+    from hamiltorch_amd import util
+    dev_ = torch.device("cuda:0")
+    D, C = 6, 32
+
+    def capturable(w):
+        return -0.5 * (w * w).sum() - 0.05 * (w ** 4).sum()
+
+    def host_scalars(w):
+        return torch.distributions.Normal(0, 3, validate_args=False).log_prob(w).sum()
+    th0 = 0.3 * torch.randn(C, D, generator=torch.Generator().manual_seed(0)).to(dev_)
+    for fn in (capturable, host_scalars):
+        outs = []
+        for graphs in ("1", "0"):
+            os.environ["HAMILTORCH_AMD_GRAPHS"] = graphs
+            try:
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    out = ht.sample(fn, th0, num_samples=6, num_steps_per_sample=4, step_size=0.1, verbose=False, seed=4)
+            finally:
+                os.environ.pop("HAMILTORCH_AMD_GRAPHS", None)
+            outs.append(torch.stack(out).cpu().numpy())
+        np.testing.assert_allclose(outs[0], outs[1], rtol=1e-6, atol=1e-6)
+    g = util.GraphedCallable(torch.func.vmap(torch.func.grad(capturable)))
+    a = g(th0).clone(); b = torch.func.vmap(torch.func.grad(capturable))(th0)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    assert g.cache and next(iter(g.cache.values())) is not False
