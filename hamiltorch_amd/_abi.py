@@ -52,6 +52,9 @@ def _sig(scalar):
         "hta_hamiltonian": [c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_vp],
         "hta_mh_select": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_u64,
                           c_u64, c_vp],
+        "hta_momentum_resample_at": [c_vp, c_int, c_vp, c_i64, c_int, c_u64, c_u64, c_vp, c_vp],
+        "hta_mh_select_at": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_u64, c_u64,
+                             c_vp],
         "hta_hmc_gaussian_sample": [c_vp, c_vp, c_vp, c_vp, scalar, c_int, c_vp, c_vp, c_i64, c_int, c_int, scalar,
                                     c_int, c_int, c_int, c_u64, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
         "hta_hmc_gaussian_leapfrog": [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_int, c_int, scalar, c_vp, c_vp,
@@ -72,7 +75,7 @@ def _sig(scalar):
 
 
 #: every symbol include/hamiltorch_amd.h declares (checked by tests/test_abi_symbols.py)
-PLAIN_SYMBOLS = ["hta_abi_version", "hta_last_error", "hta_device_info", "hta_set_tuning", "hta_profile_collect",
+PLAIN_SYMBOLS = ["hta_abi_version", "hta_last_error", "hta_device_info", "hta_set_tuning", "hta_profile_collect", "hta_counter_add",
                  "hta_hmc_gaussian_workspace_bytes", "hta_rmhmc_workspace_bytes"]
 TYPED_SYMBOLS = sorted(_sig(c_f32).keys())
 
@@ -98,6 +101,8 @@ def load():
         lib.hta_profile_collect.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]
         lib.hta_hmc_gaussian_workspace_bytes.argtypes = [c_i64, c_int, c_int, c_int]
         lib.hta_hmc_gaussian_workspace_bytes.restype = c_i64
+        lib.hta_counter_add.argtypes = [c_vp, c_int, c_vp]
+        lib.hta_counter_add.restype = c_int
         lib.hta_rmhmc_workspace_bytes.argtypes = [c_i64, c_int, c_int]
         lib.hta_rmhmc_workspace_bytes.restype = c_i64
         for suf, scalar in (("f32", c_f32), ("f64", c_f64)):
@@ -189,6 +194,31 @@ def hamiltonian(p, logp, mass_kind, inv_mass, out):
     fn = getattr(load(), "hta_hamiltonian_" + _suffix(p))
     with torch.cuda.device(p.device):
         _check(fn(_p(p), _p(logp, p), mass_kind, _p(inv_mass, p), _p(out, p), C, D, _stream(p)), "hta_hamiltonian")
+
+
+def momentum_resample_at(p, mass_kind, mass_factor, seed, chain_offset, n_dev):
+    """gibbs() with the trajectory index in device memory (int32 tensor): capturable in a HIP graph."""
+    require_device(p, "momentum")
+    C, D = p.shape
+    fn = getattr(load(), "hta_momentum_resample_at_" + _suffix(p))
+    with torch.cuda.device(p.device):
+        _check(fn(_p(p), mass_kind, _p(mass_factor, p), C, D, seed, chain_offset, c_vp(n_dev.data_ptr()), _stream(p)),
+               "hta_momentum_resample_at")
+
+
+def mh_select_at(cur, prop, init, H_old, H_new, logp_new, samples_base, reject_count, accept, n_dev, burn, seed, chain_offset):
+    require_device(cur, "params")
+    C, D = cur.shape
+    fn = getattr(load(), "hta_mh_select_at_" + _suffix(cur))
+    with torch.cuda.device(cur.device):
+        _check(fn(_p(cur), _p(prop, cur), _p(init, cur), _p(H_old, cur), _p(H_new, cur), _p(logp_new, cur),
+                  _p(samples_base, cur), _p(reject_count), _p(accept), C, D, c_vp(n_dev.data_ptr()), int(burn), seed,
+                  chain_offset, _stream(cur)), "hta_mh_select_at")
+
+
+def counter_add(n_dev, delta=1):
+    with torch.cuda.device(n_dev.device):
+        _check(load().hta_counter_add(c_vp(n_dev.data_ptr()), int(delta), _stream(n_dev)), "hta_counter_add")
 
 
 def mh_select(cur, prop, init, H_old, H_new, logp_new, row, reject_count, accept, n, burn, seed, chain_offset):

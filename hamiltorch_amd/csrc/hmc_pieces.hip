@@ -11,7 +11,8 @@ namespace hta {
 // NONE/DIAG: one thread per Philox block of 4 elements.
 template <typename T, int MASS>
 __global__ void resample_kernel(T* __restrict__ p, const T* __restrict__ mf, int64_t C, int D, int nq,
-                                uint64_t seed, uint64_t chain_offset, uint32_t draw) {
+                                uint64_t seed, uint64_t chain_offset, uint32_t draw, const int32_t* __restrict__ n_dev) {
+  if (n_dev) draw = (uint32_t)*n_dev;      // trajectory index kept on the device: the launch can sit in a replayed HIP graph
   const int64_t total = C * nq;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
@@ -30,7 +31,8 @@ __global__ void resample_kernel(T* __restrict__ p, const T* __restrict__ mf, int
 // FULL: p = Lm z, one block per chain, z staged in LDS (Lm lower-triangular, row-major).
 template <typename T>
 __global__ void resample_full_kernel(T* __restrict__ p, const T* __restrict__ Lm, int64_t C, int D,
-                                     uint64_t seed, uint64_t chain_offset, uint32_t draw) {
+                                     uint64_t seed, uint64_t chain_offset, uint32_t draw, const int32_t* __restrict__ n_dev) {
+  if (n_dev) draw = (uint32_t)*n_dev;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* z = reinterpret_cast<T*>(smem_raw);
   for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
@@ -110,7 +112,12 @@ __global__ void mh_select_kernel(T* __restrict__ cur, const T* __restrict__ prop
                                  const T* __restrict__ H_old, const T* __restrict__ H_new,
                                  const T* __restrict__ logp_new, T* __restrict__ row,
                                  int32_t* __restrict__ reject_count, uint8_t* __restrict__ out_accept, int64_t C,
-                                 int D, int n, int burn, uint64_t seed, uint64_t chain_offset) {
+                                 int D, int n, int burn, uint64_t seed, uint64_t chain_offset,
+                                 const int32_t* __restrict__ n_dev) {
+  if (n_dev) {                 // device-side trajectory index: `row` is then the BASE of the [S, C, D] sample buffer
+    n = *n_dev;
+    if (row && n > burn) row += (int64_t)(n - burn) * C * D;
+  }
   const int64_t c = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
   const int lane = threadIdx.x % G;
   if (c >= C) return;
@@ -136,21 +143,23 @@ static inline int grid_for(int64_t total, int block) {
 }
 static inline int pow2_group(int D) { int g = 1; while (g < D && g < 64) g <<= 1; return g; }
 
+__global__ void counter_add_kernel(int32_t* counter, int delta) { *counter += delta; }
+
 template <typename T>
 int momentum_resample(T* p, int kind, const T* mf, int64_t C, int D, uint64_t seed, uint64_t off, uint32_t draw,
-                      hipStream_t s) {
+                      hipStream_t s, const int32_t* n_dev = nullptr) {
   HTA_REQUIRE(p && C > 0 && D > 0, "hta_momentum_resample: bad shape C=%lld D=%d", (long long)C, D);
   HTA_REQUIRE(kind == HTA_MASS_NONE || mf, "hta_momentum_resample: mass_factor is NULL");
   const int nq = (D + 3) / 4;
   if (kind == HTA_MASS_NONE)
-    resample_kernel<T, HTA_MASS_NONE><<<grid_for(C * nq, 256), 256, 0, s>>>(p, mf, C, D, nq, seed, off, draw);
+    resample_kernel<T, HTA_MASS_NONE><<<grid_for(C * nq, 256), 256, 0, s>>>(p, mf, C, D, nq, seed, off, draw, n_dev);
   else if (kind == HTA_MASS_DIAG)
-    resample_kernel<T, HTA_MASS_DIAG><<<grid_for(C * nq, 256), 256, 0, s>>>(p, mf, C, D, nq, seed, off, draw);
+    resample_kernel<T, HTA_MASS_DIAG><<<grid_for(C * nq, 256), 256, 0, s>>>(p, mf, C, D, nq, seed, off, draw, n_dev);
   else if (kind == HTA_MASS_FULL) {
     const int block = D <= 64 ? 64 : (D <= 128 ? 128 : 256);
     const size_t lds = (size_t)nq * 4 * sizeof(T);
     HTA_REQUIRE(lds <= 64 * 1024, "hta_momentum_resample: D=%d too large for the full-mass path", D);
-    resample_full_kernel<T><<<(int)(C < 4096 ? C : 4096), block, lds, s>>>(p, mf, C, D, seed, off, draw);
+    resample_full_kernel<T><<<(int)(C < 4096 ? C : 4096), block, lds, s>>>(p, mf, C, D, seed, off, draw, n_dev);
   } else HTA_REQUIRE(false, "hta_momentum_resample: unknown mass kind %d", kind);
   HTA_CHECK_LAUNCH("hta_momentum_resample");
   return HTA_OK;
@@ -202,13 +211,14 @@ int hamiltonian(const T* p, const T* logp, int kind, const T* im, T* H, int64_t 
 }
 
 template <typename T>
-int mh_select(T* cur, const T* prop, const T* init, const T* Ho, const T* Hn, const T* lpn, T* row, int32_t* rej,
-              uint8_t* acc, int64_t C, int D, int n, int burn, uint64_t seed, uint64_t off, hipStream_t s) {
+int mh_select_impl(T* cur, const T* prop, const T* init, const T* Ho, const T* Hn, const T* lpn, T* row, int32_t* rej,
+                   uint8_t* acc, int64_t C, int D, int n, int burn, uint64_t seed, uint64_t off, hipStream_t s,
+                   const int32_t* n_dev) {
   HTA_REQUIRE(cur && prop && init && Ho && Hn && rej && C > 0 && D > 0, "hta_mh_select: bad arguments");
   const int G = pow2_group(D);
   const int block = 256;
   const int grid = (int)((C * G + block - 1) / block);
-#define HTA_MH(GG) mh_select_kernel<T, GG><<<grid, block, 0, s>>>(cur, prop, init, Ho, Hn, lpn, row, rej, acc, C, D, n, burn, seed, off)
+#define HTA_MH(GG) mh_select_kernel<T, GG><<<grid, block, 0, s>>>(cur, prop, init, Ho, Hn, lpn, row, rej, acc, C, D, n, burn, seed, off, n_dev)
   switch (G) {
     case 1: HTA_MH(1); break; case 2: HTA_MH(2); break; case 4: HTA_MH(4); break; case 8: HTA_MH(8); break;
     case 16: HTA_MH(16); break; case 32: HTA_MH(32); break; default: HTA_MH(64); break;
@@ -216,6 +226,12 @@ int mh_select(T* cur, const T* prop, const T* init, const T* Ho, const T* Hn, co
 #undef HTA_MH
   HTA_CHECK_LAUNCH("hta_mh_select");
   return HTA_OK;
+}
+
+template <typename T>
+int mh_select(T* cur, const T* prop, const T* init, const T* Ho, const T* Hn, const T* lpn, T* row, int32_t* rej,
+              uint8_t* acc, int64_t C, int D, int n, int burn, uint64_t seed, uint64_t off, hipStream_t s) {
+  return mh_select_impl<T>(cur, prop, init, Ho, Hn, lpn, row, rej, acc, C, D, n, burn, seed, off, s, nullptr);
 }
 
 template int mh_select<float>(float*, const float*, const float*, const float*, const float*, const float*, float*,
@@ -259,5 +275,36 @@ int hta_mh_select_f64(double* cur, const double* prop, const double* init, const
                       const double* lpn, double* row, int32_t* rej, uint8_t* acc, int64_t C, int D, int n, int burn,
                       uint64_t seed, uint64_t off, void* s) {
   return hta::mh_select<double>(cur, prop, init, Ho, Hn, lpn, row, rej, acc, C, D, n, burn, seed, off, (hipStream_t)s);
+}
+
+/* trajectory index on the device: the same two operations for launches captured in a HIP graph and replayed once per
+ * trajectory (the generic-callback engine); hta_counter_add advances the index inside the graph. */
+int hta_momentum_resample_at_f32(float* p, int k, const float* mf, int64_t C, int D, uint64_t seed, uint64_t off,
+                                 const int32_t* n_dev, void* s) {
+  if (!n_dev) { hta::set_error("hta_momentum_resample_at: n_dev is NULL"); return HTA_ERR_INVALID; }
+  return hta::momentum_resample<float>(p, k, mf, C, D, seed, off, 0, (hipStream_t)s, n_dev);
+}
+int hta_momentum_resample_at_f64(double* p, int k, const double* mf, int64_t C, int D, uint64_t seed, uint64_t off,
+                                 const int32_t* n_dev, void* s) {
+  if (!n_dev) { hta::set_error("hta_momentum_resample_at: n_dev is NULL"); return HTA_ERR_INVALID; }
+  return hta::momentum_resample<double>(p, k, mf, C, D, seed, off, 0, (hipStream_t)s, n_dev);
+}
+int hta_mh_select_at_f32(float* cur, const float* prop, const float* init, const float* Ho, const float* Hn,
+                         const float* lpn, float* samples_base, int32_t* rej, uint8_t* acc, int64_t C, int D,
+                         const int32_t* n_dev, int burn, uint64_t seed, uint64_t off, void* s) {
+  if (!n_dev) { hta::set_error("hta_mh_select_at: n_dev is NULL"); return HTA_ERR_INVALID; }
+  return hta::mh_select_impl<float>(cur, prop, init, Ho, Hn, lpn, samples_base, rej, acc, C, D, 0, burn, seed, off, (hipStream_t)s, n_dev);
+}
+int hta_mh_select_at_f64(double* cur, const double* prop, const double* init, const double* Ho, const double* Hn,
+                         const double* lpn, double* samples_base, int32_t* rej, uint8_t* acc, int64_t C, int D,
+                         const int32_t* n_dev, int burn, uint64_t seed, uint64_t off, void* s) {
+  if (!n_dev) { hta::set_error("hta_mh_select_at: n_dev is NULL"); return HTA_ERR_INVALID; }
+  return hta::mh_select_impl<double>(cur, prop, init, Ho, Hn, lpn, samples_base, rej, acc, C, D, 0, burn, seed, off, (hipStream_t)s, n_dev);
+}
+int hta_counter_add(int32_t* counter, int delta, void* s) {
+  if (!counter) { hta::set_error("hta_counter_add: NULL counter"); return HTA_ERR_INVALID; }
+  hta::counter_add_kernel<<<1, 1, 0, (hipStream_t)s>>>(counter, delta);
+  HTA_CHECK_LAUNCH("hta_counter_add");
+  return HTA_OK;
 }
 }

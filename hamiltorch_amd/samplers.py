@@ -18,6 +18,7 @@ There is no CPU path: tensors must live on an AMD GPU.
 from __future__ import annotations
 
 import threading
+import os
 import warnings
 import torch
 import torch.nn as nn
@@ -131,6 +132,10 @@ class _BatchedCallback:
                 self._fallback(e)
         g, v = self._loop(theta, True)
         return g.contiguous(), v.contiguous()
+
+    def capturable(self):
+        """True while every piece of this callback replays as a HIP graph (so a whole trajectory can be captured)."""
+        return self._use_vmap and all(g is None or g.capturable() for g in (self._v_logp, self._v_gv, self._v_pg))
 
     def _fallback(self, e):
         self._use_vmap = False
@@ -556,34 +561,89 @@ class _GenericHMC(_Engine):
         self.Ho = torch.empty(C, dtype=theta0.dtype, device=theta0.device)
         self.Hn = torch.empty_like(self.Ho)
 
-    def advance(self, n0, count, L, eps, H_old=None, H_new=None, progress=None):
+    def _trajectory(self, n, L, eps, Ho, Hn, n_dev=None):
+        """One trajectory (S:969-1026).  n_dev: the trajectory index lives in device memory - the form a HIP graph replays."""
         cur, prop, p, kind, im, mf = self.cur, self.prop, self.p, self.kind, self.im, self.mf
-        Ho = self.Ho if H_old is None else H_old
-        Hn = self.Hn if H_new is None else H_new
         cb = self.cbs[0]
-        for n in range(n0, n0 + count):
-            if progress is not None:
-                progress.update(n)
+        if n_dev is None:
             _abi.momentum_resample(p, kind, mf, self.seed, self.off, n)                    # S:969
-            _abi.hamiltonian(p, self._logp(cur), kind, im, Ho)                             # S:971
-            prop.copy_(cur)
-            if self.split:
-                perm = util.split_permutation(self.seed, n, len(self.cbs)) if self.integrator == Integrator.SPLITTING_RAND else None
-                for _ in range(L):
-                    _split_step(prop, p, self.cbs, eps, kind, im, self.integrator, perm)   # S:499-596
-                logp1 = self._logp(prop)
-            else:
-                g, logp1 = cb.grad(prop)
-                _abi.kick_drift(prop, p, g, 0.5 * eps, eps if L > 0 else 0.0, kind, im)    # S:281, S:284
-                for l in range(L):
-                    g, logp1 = cb.grad(prop)                                               # S:297
-                    _abi.kick_drift(prop, p, g, eps, 0.0 if l == L - 1 else eps, kind, im)  # S:298 (+ next drift)
-                _abi.kick_drift(prop, p, g, -0.5 * eps, 0.0, kind, im)                     # S:302
-                logp1 = logp1.to(cur.dtype).contiguous()   # log-prob at the end point, from the last gradient call
-            _abi.hamiltonian(p, logp1, kind, im, Hn)                                       # S:995
+        else:
+            _abi.momentum_resample_at(p, kind, mf, self.seed, self.off, n_dev)
+        _abi.hamiltonian(p, self._logp(cur), kind, im, Ho)                                 # S:971
+        prop.copy_(cur)
+        if self.split:
+            perm = util.split_permutation(self.seed, n, len(self.cbs)) if self.integrator == Integrator.SPLITTING_RAND else None
+            for _ in range(L):
+                _split_step(prop, p, self.cbs, eps, kind, im, self.integrator, perm)       # S:499-596
+            logp1 = self._logp(prop)
+        else:
+            g, logp1 = cb.grad(prop)
+            _abi.kick_drift(prop, p, g, 0.5 * eps, eps if L > 0 else 0.0, kind, im)        # S:281, S:284
+            for l in range(L):
+                g, logp1 = cb.grad(prop)                                                   # S:297
+                _abi.kick_drift(prop, p, g, eps, 0.0 if l == L - 1 else eps, kind, im)     # S:298 (+ next drift)
+            _abi.kick_drift(prop, p, g, -0.5 * eps, 0.0, kind, im)                         # S:302
+            logp1 = logp1.to(cur.dtype).contiguous()   # log-prob at the end point, from the last gradient call
+        _abi.hamiltonian(p, logp1, kind, im, Hn)                                           # S:995
+        if n_dev is None:
             row = self.samples[n - self.burn] if n > self.burn else None
             _abi.mh_select(cur, prop, self.theta0, Ho, Hn, logp1, row, self.rejected, None, n, self.burn, self.seed,
                            self.off)                                                       # S:1000-1026
+        else:
+            _abi.mh_select_at(cur, prop, self.theta0, Ho, Hn, logp1, self.samples, self.rejected, None, n_dev, self.burn,
+                              self.seed, self.off)
+            _abi.counter_add(n_dev, 1)
+
+    def _graph_eligible(self, count, H_old):
+        return (H_old is None and count >= 4 and not getattr(self, "_no_graph", False)
+                and os.environ.get("HAMILTORCH_AMD_GRAPHS", "1") != "0"
+                and not (self.split and self.integrator == Integrator.SPLITTING_RAND)      # its subset order is drawn on the host
+                and all(cb.capturable() for cb in self.cbs))
+
+    def advance(self, n0, count, L, eps, H_old=None, H_new=None, progress=None):
+        Ho = self.Ho if H_old is None else H_old
+        Hn = self.Hn if H_new is None else H_new
+        n, end = n0, n0 + count
+        if self._graph_eligible(count, H_old):
+            # The whole trajectory - native kernels and the torch callback - is captured ONCE as a HIP graph and replayed
+            # with the trajectory index in device memory: no per-launch host work between the ~3 L launches of a trajectory.
+            if progress is not None:
+                progress.update(n)
+            self._trajectory(n, L, eps, Ho, Hn)                                            # eager: settles vmap / capture fallbacks
+            n += 1
+            graph = self._capture_trajectory(n, L, eps, Ho, Hn) if self._graph_eligible(end - n, H_old) else None
+            if graph is not None:
+                n += 1                                                                     # the capture warm-up ran trajectory n
+                while n < end:
+                    if progress is not None:
+                        progress.update(n)
+                    graph.replay()
+                    n += 1
+        while n < end:
+            if progress is not None:
+                progress.update(n)
+            self._trajectory(n, L, eps, Ho, Hn)
+            n += 1
+
+    def _capture_trajectory(self, n, L, eps, Ho, Hn):
+        dev = self.cur.device
+        n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self._trajectory(n, L, eps, Ho, Hn, n_dev)                                     # warm-up = trajectory n itself
+        torch.cuda.current_stream(dev).wait_stream(side)
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._trajectory(n, L, eps, Ho, Hn, n_dev)
+        except Exception as e:      # e.g. a callback that is not capturable: stay eager (nothing ran during the capture)
+            warnings.warn("hamiltorch_amd: trajectory not capturable as a HIP graph (%s: %s); running it launch by launch"
+                          % (type(e).__name__, str(e).split("\n")[0][:120]))
+            self._no_graph = True
+            return None
+        self._graph_keep = (graph, n_dev)          # keep the index tensor alive as long as the graph
+        return graph
 
 
 def _resolve_split_engine(log_prob_list, theta0, native, integrator=Integrator.SPLITTING):

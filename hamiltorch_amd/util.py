@@ -191,9 +191,13 @@ class GraphedCallable:
         self.cache = {}
         self.enabled = os.environ.get("HAMILTORCH_AMD_GRAPHS", "1") != "0"
 
+    def capturable(self):
+        """False once a capture of this function has failed (or graphs are disabled)."""
+        return self.enabled and all(v is not False for v in self.cache.values())
+
     def __call__(self, *args):
-        if not self.enabled or not args[0].is_cuda:
-            return self.fn(*args)
+        if not self.enabled or not args[0].is_cuda or torch.cuda.is_current_stream_capturing():
+            return self.fn(*args)          # (inside an enclosing capture the ops are recorded inline)
         key = tuple((tuple(a.shape), a.dtype, a.device) for a in args)
         ent = self.cache.get(key)
         if ent is None:

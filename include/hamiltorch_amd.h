@@ -67,6 +67,14 @@ int hta_momentum_resample_f32(float* p, int mass_kind, const float* mass_factor,
 int hta_momentum_resample_f64(double* p, int mass_kind, const double* mass_factor, int64_t C, int D,
                               uint64_t seed, uint64_t chain_offset, uint32_t draw, void* stream);
 
+/* The same draw with the trajectory index read from device memory (`*n_dev`): such a launch can be captured in a HIP
+ * graph and replayed once per trajectory (hta_counter_add advances the index inside the graph). */
+int hta_momentum_resample_at_f32(float* p, int mass_kind, const float* mass_factor, int64_t C, int D, uint64_t seed,
+                                 uint64_t chain_offset, const int32_t* n_dev, void* stream);
+int hta_momentum_resample_at_f64(double* p, int mass_kind, const double* mass_factor, int64_t C, int D, uint64_t seed,
+                                 uint64_t chain_offset, const int32_t* n_dev, void* stream);
+int hta_counter_add(int32_t* counter, int delta, void* stream);
+
 /* leapfrog pieces (S:281, S:283-298, S:302, and the split half-kicks S:505-520):
  *   p     += kick  * grad           (skipped when grad == NULL)
  *   theta += drift * M^-1 p         (skipped when drift == 0)
@@ -96,6 +104,16 @@ int hta_mh_select_f64(double* theta_cur, const double* theta_prop, const double*
                       const double* H_old, const double* H_new, const double* logp_new, double* samples_row,
                       int32_t* reject_count, uint8_t* out_accept, int64_t C, int D, int n, int burn,
                       uint64_t seed, uint64_t chain_offset, void* stream);
+/* n = *n_dev (device memory); samples_base is the START of the [S, C, D] sample buffer (row n - burn is addressed by
+ * the kernel when n > burn).  For launches replayed from a HIP graph. */
+int hta_mh_select_at_f32(float* theta_cur, const float* theta_prop, const float* theta_init, const float* H_old,
+                         const float* H_new, const float* logp_new, float* samples_base, int32_t* reject_count,
+                         uint8_t* out_accept, int64_t C, int D, const int32_t* n_dev, int burn, uint64_t seed,
+                         uint64_t chain_offset, void* stream);
+int hta_mh_select_at_f64(double* theta_cur, const double* theta_prop, const double* theta_init, const double* H_old,
+                         const double* H_new, const double* logp_new, double* samples_base, int32_t* reject_count,
+                         uint8_t* out_accept, int64_t C, int D, const int32_t* n_dev, int burn, uint64_t seed,
+                         uint64_t chain_offset, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused HMC for a dense Gaussian target  log p(x) = log_norm - 0.5 (x-mu)^T P (x-mu)

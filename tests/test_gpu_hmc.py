@@ -351,3 +351,68 @@ def test_graph_replay_of_callbacks_matches_eager(ht):
     a = g(th0).clone(); b = torch.func.vmap(torch.func.grad(capturable))(th0)
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-6, atol=1e-7)
     assert g.cache and next(iter(g.cache.values())) is not False
+
+
+def test_whole_trajectory_graph_matches_eager(ht):
+    """_GenericHMC.advance captures one whole trajectory (native kernels + callback, trajectory index in device memory:
+    hta_momentum_resample_at / hta_mh_select_at / hta_counter_add) and replays it; samples, burn-in handling and the
+    split integrators are the same as launch-by-launch execution."""
+    import os
+    import warnings
+    dev_ = torch.device("cuda:0")
+    D, C = 5, 48
+
+    def lp(w):
+        return -0.5 * (w * w).sum() - 0.05 * (w ** 4).sum()
+
+    def lp_b(w):
+        return -0.25 * ((w - 0.5) ** 2).sum()
+    th0 = 0.3 * torch.randn(C, D, generator=torch.Generator().manual_seed(1)).to(dev_)
+    cases = [dict(log_prob_func=lp, num_samples=24, burn=5, num_steps_per_sample=6, step_size=0.15),
+             dict(log_prob_func=lp, num_samples=12, num_steps_per_sample=3, step_size=0.1, inv_mass=torch.full((D,), 2.0)),
+             dict(log_prob_func=[lp, lp_b], num_samples=12, num_steps_per_sample=3, step_size=0.1,
+                  integrator=ht.Integrator.SPLITTING)]
+    for kw in cases:
+        outs = []
+        for graphs in ("1", "0"):
+            os.environ["HAMILTORCH_AMD_GRAPHS"] = graphs
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("error")          # no fallback warning: the capture must succeed
+                    out = ht.sample(params_init=th0, verbose=False, seed=9, **kw)
+            finally:
+                os.environ.pop("HAMILTORCH_AMD_GRAPHS", None)
+            outs.append(torch.stack(out).cpu().numpy())
+        assert outs[0].shape == outs[1].shape
+        np.testing.assert_allclose(outs[0], outs[1], rtol=1e-6, atol=1e-6)
+
+
+def test_device_counter_entry_points(ht):
+    """The *_at entry points read the trajectory index from device memory and draw the same streams as the host-index ones."""
+    from hamiltorch_amd import _abi
+    dev_ = torch.device("cuda:0")
+    C, D = 33, 7
+    n_dev = torch.tensor([6], dtype=torch.int32, device=dev_)
+    mf = torch.ones(1, device=dev_)
+    p_a = torch.empty(C, D, device=dev_); p_b = torch.empty(C, D, device=dev_)
+    _abi.momentum_resample(p_a, 0, mf, 123, 2, 6)
+    _abi.momentum_resample_at(p_b, 0, mf, 123, 2, n_dev)
+    assert torch.equal(p_a, p_b)
+    _abi.counter_add(n_dev, 1)
+    assert int(n_dev.item()) == 7
+    g = torch.Generator().manual_seed(3)
+    cur = torch.randn(C, D, generator=g).to(dev_); prop = torch.randn(C, D, generator=g).to(dev_)
+    Ho = torch.randn(C, generator=g).to(dev_); Hn = Ho + 0.5 * torch.randn(C, generator=g).to(dev_)
+    lpn = torch.randn(C, generator=g).to(dev_)
+    res = []
+    for at in (False, True):
+        c, samples = cur.clone(), torch.zeros(4, C, D, device=dev_)
+        rej = torch.zeros(C, dtype=torch.int32, device=dev_)
+        if at:
+            _abi.mh_select_at(c, prop, cur, Ho, Hn, lpn, samples, rej, None, n_dev, 5, 123, 2)
+        else:
+            _abi.mh_select(c, prop, cur, Ho, Hn, lpn, samples[7 - 5], rej, None, 7, 5, 123, 2)
+        res.append((c.cpu(), samples.cpu(), rej.cpu()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert 0 < int(res[0][2].sum()) < C
