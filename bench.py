@@ -351,12 +351,15 @@ def main():
                        "samples_stored": True, "parallelism": "chains sharded, %d per GPU, no collective" % w.C},
             "roofline": roof or {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "hmc_gauss_small_kernel<float,3,0,true>", "kernel_ms": kernel_ms,
+                         "kernel": "hmc_gauss_quad_kernel<3,false>" if w.C <= 65536 else "hmc_gauss_eig_kernel<float,3,false>",
+                         "kernel_ms": kernel_ms,
                          "call_ms": call_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "16*D bytes per chain-step (SURVEY 8d); state is register-resident for the whole "
-                                 "launch, so real HBM traffic is the sample rows only; at 1024 chains the launch "
-                                 "is 16 waves on 256 CUs: latency/issue bound, not bandwidth bound"},
+                                 "launch, so real HBM traffic is the draw records and the sample rows only; trajectories "
+                                 "are integrated in the eigenbasis of P (identity mass), one eigen-coordinate per lane of "
+                                 "a DPP quad: 2 dependent FMAs per step; at 1024 chains the launch is 64 waves on 256 "
+                                 "CUs: latency/issue bound, not bandwidth bound"},
             "acceptance_rate": acc,
             "ess_per_sec": ess / (call_ms * 1e-3),
         }

@@ -33,7 +33,8 @@ namespace hta {
 //     i.e. D + D*D fused multiply-adds, the kick accumulating straight into p (S:283-298);
 //   * fp32: two elements per instruction (v_pk_fma_f32 on explicit float2 pairs): 8 instead of 12
 //     instructions per step at D=3 (15.8 vs 22.8 ns/step);
-//   * unrolled by 5 (the reference's L values are multiples of 5): branch cost amortised;
+//   * steps in straight-line blocks of 10 and 5 (repeat_steps; the reference's L values are multiples of 5): L = 25 is
+//     two back-edges per trajectory;
 //   * P d is formed only at trajectory end points, and the potential at the current point is
 //     carried from the previous trajectory (accepted -> end point, rejected -> unchanged).
 // Rejected alternatives (same microbenchmark): one chain per DPP quad (4 instead of 12 FMAs per
@@ -54,6 +55,31 @@ template <> struct RecVec<float> { typedef float type __attribute__((ext_vector_
 template <> struct RecVec<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int N = 2; };
 // elements per (trajectory, chain) record: D normals + log u, padded to 16-byte vectors
 template <typename T, int D> constexpr int rec_elems() { return ((D + 1 + RecVec<T>::N - 1) / RecVec<T>::N) * RecVec<T>::N; }
+
+// L leapfrog steps for a lone wave: a taken branch costs ~14 ns (six dependent FMAs), so the steps come in straight-line
+// blocks of 25; what is left over (blocks of 10, one of 5, single steps) sits off the hot path.  L = 25, 50, ... take no
+// branch inside a trajectory at all.
+template <typename F> __device__ __forceinline__ void repeat_steps(int L, F&& step) {
+  int l = L;
+  while (l >= 25) {
+#pragma unroll
+    for (int u = 0; u < 25; ++u) step();
+    l -= 25;
+  }
+  if (__builtin_expect(l > 0, 0)) {
+    while (l >= 10) {
+#pragma unroll
+      for (int u = 0; u < 10; ++u) step();
+      l -= 10;
+    }
+    if (l >= 5) {
+#pragma unroll
+      for (int u = 0; u < 5; ++u) step();
+      l -= 5;
+    }
+    while (l > 0) { step(); --l; }
+  }
+}
 
 template <typename T, int D, int MASS> struct SmallModel {
   static constexpr int NM = MASS == HTA_MASS_FULL ? D * D : (MASS == HTA_MASS_DIAG ? D : 1);
@@ -149,8 +175,7 @@ template <typename T, int D, int MASS> struct SmallModel {
       for (int j = 0; j < NP; ++j)
         eP[j] = (MASS == HTA_MASS_DIAG) ? f2{eIM[2 * j], eIM[2 * j + 1]} : f2{eps, eps};
       if (MASS == HTA_MASS_DIAG && R) eS = eIM[D - 1];
-#pragma unroll 5
-      for (int l = 0; l < L; ++l) {
+      repeat_steps(L, [&]() {
         if (MASS == HTA_MASS_FULL) {
           f2 nd[NP]; float ndS = dS;
 #pragma unroll
@@ -177,13 +202,12 @@ template <typename T, int D, int MASS> struct SmallModel {
           for (int j = 0; j < NP; ++j) pP[j] = __builtin_elementwise_fma(AP[k][j], f2{dk, dk}, pP[j]);
           if (R) pS = fmaf(AS[k], dk, pS);
         }
-      }
+      });
 #pragma unroll
       for (int j = 0; j < NP; ++j) { d[2 * j] = dP[j].x; d[2 * j + 1] = dP[j].y; p[2 * j] = pP[j].x; p[2 * j + 1] = pP[j].y; }
       if (R) { d[D - 1] = dS; p[D - 1] = pS; }
     } else {
-#pragma unroll 5
-      for (int l = 0; l < L; ++l) step(d, p);
+      repeat_steps(L, [&]() { step(d, p); });
     }
   }
   // leapfrog (S:281-302) on d = q - mu.  Pd: in = P d at the start, out = P d at the end.
@@ -230,8 +254,15 @@ __device__ __forceinline__ void draw_inline(uint64_t seed, uint64_t chain, uint3
 // workspace: record [t][c] of rec_elems<T,D>() values = (z_0 .. z_{D-1}, log u, padding)
 template <typename T, int D>
 __global__ void rng_fill_small_kernel(T* __restrict__ ws, int64_t C, int n_traj, int traj_offset, uint64_t seed,
-                                      uint64_t chain_offset) {
+                                      uint64_t chain_offset, const T* __restrict__ eig) {
   constexpr int W = rec_elems<T, D>();
+  T Q[D][D];            // eigenbasis route: records hold Q^T z (wave-uniform operands)
+  if (eig) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int k = 0; k < D; ++k) Q[i][k] = eig[D + i * D + k];
+  }
   typedef typename RecVec<T>::type V;
   const int64_t total = C * n_traj;
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
@@ -242,8 +273,18 @@ __global__ void rng_fill_small_kernel(T* __restrict__ ws, int64_t C, int n_traj,
     for (int i = 0; i < W; ++i) rec[i] = 0;
     T z[D], lu;
     draw_inline<T, D>(seed, chain_offset + (uint64_t)c, (uint32_t)(traj_offset + (int)t), z, lu);
+    if (eig) {
 #pragma unroll
-    for (int j = 0; j < D; ++j) rec[j] = z[j];
+      for (int k = 0; k < D; ++k) {
+        T acc = Q[0][k] * z[0];
+#pragma unroll
+        for (int i = 1; i < D; ++i) acc = fma(Q[i][k], z[i], acc);
+        rec[k] = acc;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < D; ++j) rec[j] = z[j];
+    }
     rec[D] = lu;
     V* out = reinterpret_cast<V*>(ws + idx * W);
 #pragma unroll
@@ -373,6 +414,366 @@ __global__ __launch_bounds__(256) void hmc_gauss_small_kernel(GaussArgs<T> a) {
 #pragma unroll
   for (int i = 0; i < D; ++i) a.theta[c * D + i] = th[i];
   if (a.reject_count) a.reject_count[c] += rejected;
+}
+
+
+// =============================================================================================
+// small-D, identity mass: the same trajectories integrated in the eigenbasis of P
+//
+// With M = I the Hamiltonian is invariant under y = Q^T (q - mu), r = Q^T p for the orthogonal Q of
+// P = Q diag(lam) Q^T, and in (y, r) the leapfrog map (S:281-302) decouples by coordinate:
+//     r_i -= eps lam_i y_i ;  y_i += eps r_i          -> 2 D fused multiply-adds per step instead of D + D*D.
+// At config 2 (D = 3, one 64-chain wave per CU, issue bound) that is 4 instead of 8 VALU instructions per step.
+// eig_small_kernel diagonalises P once per launch (one thread, cyclic Jacobi in fp64, registers only), the
+// pre-draw pass rotates the momentum normals (r = Q^T z: the records still come from the same Philox draws),
+// energies are 0.5 sum lam_i y_i^2 + 0.5 |r|^2, and a sample row is q = mu + Q y.  Same map, same draws, same
+// accept rule as the direct kernel above; results differ from it by rounding only (tests compare both routes).
+// Layout of the eig block (T): lam[D], Q[D][D] (Q[i][k] = component i of eigenvector k).
+// =============================================================================================
+template <typename T, int D>
+__global__ void eig_small_kernel(const T* __restrict__ P, T* __restrict__ eig) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double A[D][D], V[D][D];
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      A[i][j] = 0.5 * ((double)P[i * D + j] + (double)P[j * D + i]);   // the precision matrix is symmetric
+      V[i][j] = i == j ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    double off = 0, dia = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) { if (i < j) off += A[i][j] * A[i][j]; if (i == j) dia += A[i][i] * A[i][i]; }
+    if (!(off > 1e-34 * dia)) break;
+#pragma unroll
+    for (int p = 0; p < D - 1; ++p) {
+#pragma unroll
+      for (int q = p + 1; q < D; ++q) {
+        const double apq = A[p][q];
+        if (fabs(apq) > 1e-300) {
+          const double tau = (A[q][q] - A[p][p]) / (2.0 * apq);
+          const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+          const double c = 1.0 / sqrt(1.0 + t * t), sn = t * c;
+#pragma unroll
+          for (int k = 0; k < D; ++k) {       // A <- A J (columns p, q)
+            const double akp = A[k][p], akq = A[k][q];
+            A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq;
+          }
+#pragma unroll
+          for (int k = 0; k < D; ++k) {       // A <- J^T A (rows p, q)
+            const double apk = A[p][k], aqk = A[q][k];
+            A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk;
+          }
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            const double vkp = V[k][p], vkq = V[k][q];
+            V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    eig[i] = (T)A[i][i];
+#pragma unroll
+    for (int k = 0; k < D; ++k) eig[D + i * D + k] = (T)V[i][k];
+  }
+}
+
+template <typename T, int D, bool DIAG>
+__global__ __launch_bounds__(256) void hmc_gauss_eig_kernel(GaussArgs<T> a, const T* __restrict__ eig) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= a.C) return;
+  constexpr int NP = D / 2;
+  constexpr bool R = (D & 1) != 0;
+  T lam[D], Q[D][D], mu[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    lam[i] = eig[i]; mu[i] = a.mu[i];
+#pragma unroll
+    for (int k = 0; k < D; ++k) Q[i][k] = eig[D + i * D + k];
+  }
+  const T eps = a.eps, he = (T)0.5 * a.eps;
+  T nel[D], hl[D], hlam[D];                      // -eps lam, eps/2 lam, lam/2
+#pragma unroll
+  for (int i = 0; i < D; ++i) { nel[i] = -(eps * lam[i]); hl[i] = he * lam[i]; hlam[i] = (T)0.5 * lam[i]; }
+  const size_t C = (size_t)a.C;
+  auto to_y = [&](const T* __restrict__ q, T (&y)[D]) {
+    T d[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) d[i] = q[i] - mu[i];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      T acc = Q[0][k] * d[0];
+#pragma unroll
+      for (int i = 1; i < D; ++i) acc = fma(Q[i][k], d[i], acc);
+      y[k] = acc;
+    }
+  };
+  auto potential = [&](const T (&y)[D]) {          // 0.5 y^T diag(lam) y
+    T q = hlam[0] * y[0] * y[0];
+#pragma unroll
+    for (int i = 1; i < D; ++i) q = fma(hlam[i] * y[i], y[i], q);
+    return q;
+  };
+  T yc[D];
+  to_y(a.theta + c * D, yc);
+  T quadc = potential(yc);
+  int32_t rejected = 0;
+
+  T z[D], logu = 0;
+  const T* rec = a.ws_z + (size_t)c * rec_elems<T, D>();
+  const size_t rec_step = C * rec_elems<T, D>();
+  load_record<T, D>(rec, 0, z, logu);
+  // unconditional sample stores, primed once before the loop: see hmc_gauss_small_kernel
+  T* const scratch_row = a.theta + c * D;
+  T* srow = a.samples ? a.samples + ((size_t)(a.traj_offset > a.burn ? a.traj_offset - a.burn : 1) * C + c) * D
+                      : scratch_row;
+  const size_t srow_step = a.samples ? C * D : 0;
+  auto store_q = [&](T* __restrict__ dst) {     // q = mu + Q y of the current point
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      T acc_ = mu[i];
+#pragma unroll
+      for (int k = 0; k < D; ++k) acc_ = fma(Q[i][k], yc[k], acc_);
+      dst[i] = acc_;
+    }
+  };
+  store_q(scratch_row);      // the same store a trajectory issues (to rounding the value it overwrites): keeps vmcnt uniform
+  for (int t = 0; t < a.n_traj; ++t) {
+    const int n = a.traj_offset + t;
+    T zn[D], logun = 0;
+    rec += rec_step;
+    load_record<T, D>(rec, 0, zn, logun);
+    // ---- gibbs (S:185-186): r = Q^T z, rotated by the pre-draw pass
+    T r[D], y[D];
+    T kin = z[0] * z[0];
+#pragma unroll
+    for (int i = 1; i < D; ++i) kin = fma(z[i], z[i], kin);
+    const T h_old = -(a.log_norm - quadc) + (T)0.5 * kin;          // S:971
+    // ---- leapfrog (S:973 -> S:281-302)
+#pragma unroll
+    for (int i = 0; i < D; ++i) { y[i] = yc[i]; r[i] = fma(-hl[i], yc[i], z[i]); }   // S:281
+    if constexpr (sizeof(T) == 4 && D >= 2) {
+      f2 yP[NP], rP[NP], eP[NP], nP[NP];
+      float yS = 0, rS = 0;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        yP[j] = f2{y[2 * j], y[2 * j + 1]}; rP[j] = f2{r[2 * j], r[2 * j + 1]};
+        eP[j] = f2{eps, eps}; nP[j] = f2{nel[2 * j], nel[2 * j + 1]};
+      }
+      if (R) { yS = y[D - 1]; rS = r[D - 1]; }
+      repeat_steps(a.L, [&]() {                                     // S:283-298 (drift, then the merged kick)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) yP[j] = __builtin_elementwise_fma(eP[j], rP[j], yP[j]);
+        if (R) yS = fmaf(eps, rS, yS);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) rP[j] = __builtin_elementwise_fma(nP[j], yP[j], rP[j]);
+        if (R) rS = fmaf(nel[D - 1], yS, rS);
+      });
+#pragma unroll
+      for (int j = 0; j < NP; ++j) { y[2 * j] = yP[j].x; y[2 * j + 1] = yP[j].y; r[2 * j] = rP[j].x; r[2 * j + 1] = rP[j].y; }
+      if (R) { y[D - 1] = yS; r[D - 1] = rS; }
+    } else {
+      repeat_steps(a.L, [&]() {
+#pragma unroll
+        for (int i = 0; i < D; ++i) y[i] = fma(eps, r[i], y[i]);
+#pragma unroll
+        for (int i = 0; i < D; ++i) r[i] = fma(nel[i], y[i], r[i]);
+      });
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) r[i] = fma(hl[i], y[i], r[i]);      // S:302
+    const T quad1 = potential(y);
+    // ---- H_new (S:995), MH (S:1000-1004)
+    const T logp1 = a.log_norm - quad1;
+    T kin1 = r[0] * r[0];
+#pragma unroll
+    for (int i = 1; i < D; ++i) kin1 = fma(r[i], r[i], kin1);
+    const T h_new = -logp1 + (T)0.5 * kin1;
+    const bool acc = mh_accept_logu<T>(h_old, h_new, logp1, logu);
+    // ---- bookkeeping (S:1007-1026; Q2 reset at n == burn+1)
+    rejected += acc ? 0 : 1;
+#pragma unroll
+    for (int i = 0; i < D; ++i) yc[i] = acc ? y[i] : yc[i];
+    quadc = acc ? quad1 : quadc;
+    if (__builtin_expect(n == a.burn + 1, 0)) {                      // wave-uniform, once per run: kept off the hot path
+      if (!acc) {
+        to_y(a.theta_init + c * D, yc);
+        quadc = potential(yc);
+      }
+    }
+    {
+      const bool keep = n > a.burn;
+      store_q(keep ? srow : scratch_row);
+      srow += keep ? srow_step : 0;
+    }
+    if (DIAG) {
+      if (a.H_old) a.H_old[(size_t)t * C + c] = h_old;
+      if (a.H_new) a.H_new[(size_t)t * C + c] = h_new;
+      if (a.accept) a.accept[(size_t)t * C + c] = acc ? 1 : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) z[j] = zn[j];
+    logu = logun;
+  }
+  store_q(scratch_row);
+  if (a.reject_count) a.reject_count[c] += rejected;
+}
+
+
+// =============================================================================================
+// D <= 4, fp32, identity mass, latency regime: one chain per DPP quad, one eigen-coordinate per lane
+//
+// In the eigenbasis the coordinates of a chain do not interact DURING a trajectory, so lane k of a quad integrates
+// coordinate k alone: a step is the two dependent FMAs  y += eps r ; r -= eps lam_k y  and nothing else (the chain-per-lane
+// kernel above issues four instructions per step at D = 3).  Lanes meet only at trajectory boundaries:
+//   * accept test: h_old - h_new = sum_k (0.5 z_k^2 + 0.5 lam_k yc_k^2) - (0.5 r_k^2 + 0.5 lam_k y_k^2)  (log_norm cancels),
+//     one two-stage quad butterfly (DPP quad_perm) of the per-lane difference; every lane gets the same decision;
+//   * sample row: q_i = mu_i + sum_k Q[i][k] yc_k, lane i broadcasting yc_k from lane k (DPP quad_perm:[k,k,k,k]);
+//   * the draw record [Q^T z, log u, pad] is read one element per lane; log u is lane D's element (D < 4).
+// A lane >= D of the quad is a dummy coordinate (lam = 0, momentum 0).  1024 chains are 64 waves instead of 16; the
+// dispatcher takes this kernel while the chip has idle SIMDs for the extra waves (C <= g_quad_max_chains) and the
+// chain-per-lane kernel beyond, where instruction count per chain decides.
+// =============================================================================================
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int K> __device__ __forceinline__ float quad_bcast(float v) { return dpp_f<K * 0x55>(v); }
+__device__ __forceinline__ float quad_sum(float v) {
+  v += dpp_f<0xB1>(v);          // quad_perm:[1,0,3,2]
+  v += dpp_f<0x4E>(v);          // quad_perm:[2,3,0,1]
+  return v;
+}
+
+template <int D, bool DIAG>
+__global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, const float* __restrict__ eig) {
+  typedef float T;
+  const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t c = gt >> 2;
+  const int k = (int)(gt & 3);
+  if (c >= a.C) return;                         // whole quads leave together
+  const bool live = k < D;
+  const int kk = live ? k : 0;
+  const T lam = live ? eig[kk] : 0.f;
+  const T mu = live ? a.mu[kk] : 0.f;
+  T Qrow[D], Qcol[D];                           // Q[k][j] and Q[j][k]
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    Qrow[j] = live ? eig[D + kk * D + j] : 0.f;
+    Qcol[j] = live ? eig[D + j * D + kk] : 0.f;
+  }
+  // a dummy lane (k >= D) integrates nothing: eps = lam = 0, so its y stays 0, its r stays whatever its record slot held
+  // (log u or padding) and its energy difference is exactly 0
+  const T eps = live ? a.eps : 0.f, nel = -(eps * lam), hl = 0.5f * eps * lam, hlam = 0.5f * lam;
+  const size_t C = (size_t)a.C;
+  auto bc = [&](T v, int j) {                   // lane j of the quad (j compile-time after unrolling)
+    return j == 0 ? quad_bcast<0>(v) : j == 1 ? quad_bcast<1>(v) : j == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v);
+  };
+  auto to_y = [&](const T* __restrict__ q) {    // y_k = sum_i Q[i][k] (q_i - mu_i)
+    const T d = live ? q[c * D + kk] - mu : 0.f;
+    T y = Qcol[0] * bc(d, 0);
+#pragma unroll
+    for (int i = 1; i < D; ++i) y = fmaf(Qcol[i], bc(d, i), y);
+    return y;
+  };
+  auto to_q = [&](T y) {                         // q_k = mu_k + sum_j Q[k][j] y_j: v_fmac_f32 with a DPP-broadcast operand
+    T q = mu;
+    asm volatile("s_nop 1");                     // VALU write of y -> DPP read: 2 wait states (inline asm is not tracked)
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+      asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[%3,%3,%3,%3] row_mask:0xf bank_mask:0xf"
+                   : "+v"(q) : "v"(y), "v"(Qrow[j]), "n"(j));
+    return q;
+  };
+  T yc = to_y(a.theta);
+  T potc = hlam * yc * yc;                       // this coordinate's share of the potential at the current point
+  int32_t rejected = 0;
+
+  constexpr int W = rec_elems<T, D>();
+  typedef const __attribute__((address_space(1))) T* grec_t;   // stays a global pointer through the ordering asm below
+  grec_t rec = (grec_t)(a.ws_z + (size_t)c * W + k);            // element k of this chain's record (W >= 4 floats)
+  const T* recu = a.ws_z + (size_t)c * W + D;    // D == 4: log u sits in the second vector
+  const size_t rec_step = C * W;
+  // records are read two trajectories ahead (a trajectory is shorter than one HBM round trip): two rows of slack
+  T z0 = *rec, lu0 = D == 4 ? *recu : 0.f;
+  rec += rec_step; recu += rec_step;
+  T z1 = *rec, lu1 = D == 4 ? *recu : 0.f;
+  (void)recu;
+  // Every lane stores once per trajectory, unconditionally (uniform vmcnt, see hmc_gauss_small_kernel): a dummy lane
+  // writes a dump word at the end of the eig block.
+  T* const dump = const_cast<T*>(eig) + 48 + k;
+  T* const scratch = live ? a.theta + c * D + kk : dump;
+  *scratch = to_q(yc);
+  // Two phases, one loop body: trajectories with n <= burn rewrite the scratch slot (pointer step 0), the others walk the
+  // sample rows.
+  const int n_burn = a.samples ? min(max(a.burn - a.traj_offset + 1, 0), a.n_traj) : a.n_traj;
+  int t = 0;
+  for (int phase = 0; phase < 2; ++phase) {
+    const int t_end = phase == 0 ? n_burn : a.n_traj;
+    T* dst = scratch;
+    size_t dst_step = 0;
+    if (phase == 1 && live) {
+      dst = a.samples + ((size_t)max(a.traj_offset + t - a.burn, 1) * C + c) * D + kk;
+      dst_step = C * D;
+    }
+    // one trajectory; `slot` holds its record element and is refilled with the one two trajectories ahead (the loop is
+    // unrolled by two over the slots, so the newest load is never touched by a register rotation)
+    auto trajectory = [&](T& slot, T& slot_u) {
+      const int n = a.traj_offset + t;
+      rec += rec_step;
+      // everything that reads the record first, so that its register is free for the refill
+      // ---- gibbs S:185-186 (rotated draws), H_old S:971, half kick S:281
+      T y = yc, r, eo, logu;
+      {
+        const T z = slot;
+        logu = D == 4 ? slot_u : bc(z, D < 4 ? D : 0);
+        eo = fmaf(0.5f * z, z, potc);
+        r = fmaf(-hl, yc, z);
+      }
+      // (the empty asm orders the refill after the record's last use, so the load can target the record's own register;
+      //  otherwise the scheduler hoists the load and the back-edge copy of its result waits for it)
+      asm volatile("" : "+v"(rec) : "v"(r), "v"(eo), "v"(logu));
+      slot = *rec;
+      if (D == 4) slot_u = *(rec + (D - k));
+      repeat_steps(a.L, [&]() { y = fmaf(eps, r, y); r = fmaf(nel, y, r); });      // S:283-298
+      r = fmaf(hl, y, r);                                                           // S:302
+      // ---- H_new S:995 and the MH test S:1000-1004
+      const T pot1 = hlam * y * y;
+      const T en = fmaf(0.5f * r, r, pot1);
+      const T dH = quad_sum(eo - en);                                               // h_old - h_new
+      const bool acc = finite_(dH) && (fminf(0.f, dH) >= logu);
+      rejected += acc ? 0 : 1;
+      yc = acc ? y : yc;
+      potc = acc ? pot1 : potc;
+      if (__builtin_expect(n == a.burn + 1, 0)) {                                   // Q2 reset (S:1016-1018)
+        if (!acc) { yc = to_y(a.theta_init); potc = hlam * yc * yc; }
+      }
+      *dst = to_q(yc);
+      dst += dst_step;
+      if (DIAG) {
+        const T ho = quad_sum(eo) - a.log_norm, hn = quad_sum(en) - a.log_norm;
+        if (k == 0) {
+          if (a.H_old) a.H_old[(size_t)t * C + c] = ho;
+          if (a.H_new) a.H_new[(size_t)t * C + c] = hn;
+          if (a.accept) a.accept[(size_t)t * C + c] = acc ? 1 : 0;
+        }
+      }
+      ++t;
+    };
+    while (t + 1 < t_end) { trajectory(z0, lu0); trajectory(z1, lu1); }
+    if (t < t_end) {
+      trajectory(z0, lu0);
+      T tmp = z0; z0 = z1; z1 = tmp;
+      tmp = lu0; lu0 = lu1; lu1 = tmp;
+    }
+  }
+  *scratch = to_q(yc);
+  if (a.reject_count && k == 0) a.reject_count[c] += rejected;
 }
 
 template <typename T, int D, int MASS>
@@ -609,6 +1010,23 @@ template <typename T, int D, int MASS> void launch_small(const GaussArgs<T>& a, 
   const int grid = (int)((a.C + block - 1) / block);
   if (lf_only) { leapfrog_gauss_small_kernel<T, D, MASS><<<grid, block, 0, s>>>(a); return; }
   const bool diag = a.H_old || a.H_new || a.accept;
+  if (MASS == HTA_MASS_NONE && a.ws_z && a.ws_logu) {      // eigenbasis route (a.ws_logu = the eig block)
+    if constexpr (sizeof(T) == 4 && D <= 4) {
+      if (g_gauss_eig >= 1 && g_gauss_eig != 2 && a.C <= g_quad_max_chains) {   // latency regime: a quad per chain
+        const int qgrid = (int)((a.C * 4 + 63) / 64);
+        profile_begin(s);
+        if (diag) hmc_gauss_quad_kernel<D, true><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
+        else hmc_gauss_quad_kernel<D, false><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
+        profile_end(s);
+        return;
+      }
+    }
+    profile_begin(s);
+    if (diag) hmc_gauss_eig_kernel<T, D, true><<<grid, block, 0, s>>>(a, a.ws_logu);
+    else hmc_gauss_eig_kernel<T, D, false><<<grid, block, 0, s>>>(a, a.ws_logu);
+    profile_end(s);
+    return;
+  }
   profile_begin(s);
   if (a.ws_z) {
     if (diag) hmc_gauss_small_kernel<T, D, MASS, true, true><<<grid, block, 0, s>>>(a);
@@ -643,7 +1061,9 @@ template <typename T, int D> static void launch_rng_fill_d(const GaussArgs<T>& a
   const int64_t total = a.C * a.n_traj;
   int64_t g = (total + 255) / 256;
   if (g > 256 * 16) g = 256 * 16;
-  rng_fill_small_kernel<T, D><<<(int)g, 256, 0, s>>>(a.ws_z, a.C, a.n_traj, a.traj_offset, a.seed, a.chain_offset);
+  if (a.ws_logu) eig_small_kernel<T, D><<<1, 64, 0, s>>>(a.P, a.ws_logu);
+  rng_fill_small_kernel<T, D><<<(int)g, 256, 0, s>>>(a.ws_z, a.C, a.n_traj, a.traj_offset, a.seed, a.chain_offset,
+                                                     a.ws_logu);
 }
 template <typename T> static void launch_rng_fill(const GaussArgs<T>& a, hipStream_t s) {
   switch (a.D) {
@@ -672,6 +1092,7 @@ template <typename T> int gaussian_dispatch(const GaussArgs<T>& a_in, int kind, 
   // f64 models past D=4 overflow the SGPR file (P alone is 2*D*D SGPRs) and would spill to scratch
   const int small_max = sizeof(T) == 8 ? 4 : 6;  // 2*D*D + 3*D wave-uniform operands must fit the SGPR file
   const bool reg_resident = D <= small_max && !g_force_general;
+  if (!(kind == HTA_MASS_NONE && g_gauss_eig)) a.ws_logu = nullptr;   // eigenbasis route: identity mass only
   if (a.ws_z && reg_resident && !lf_only) launch_rng_fill<T>(a, s);
   else { a.ws_z = nullptr; a.ws_logu = nullptr; }
   if (reg_resident) {
@@ -702,7 +1123,8 @@ extern "C" {
 int64_t hta_hmc_gaussian_workspace_bytes(int64_t C, int D, int n_traj, int elem_size) {
   const int per_vec = 16 / elem_size;
   const int64_t rec = ((int64_t)(D + 1 + per_vec - 1) / per_vec) * per_vec;
-  return ((int64_t)n_traj + 1) * C * rec * elem_size;   /* + one row read ahead by the last trajectory */
+  /* + two rows read ahead by the last trajectories, + the eigen block (lam[D], Q[D][D]; D <= 6) of the eigenbasis route */
+  return ((int64_t)n_traj + 2) * C * rec * elem_size + (D <= 6 ? 64 * elem_size : 0);
 }
 
 #define HTA_DEFINE_GAUSS(SUF, T)                                                                               \
@@ -718,7 +1140,7 @@ int64_t hta_hmc_gaussian_workspace_bytes(int64_t C, int D, int n_traj, int elem_
     const int64_t need = hta_hmc_gaussian_workspace_bytes(C, D, n_traj, (int)sizeof(T));                       \
     if (workspace && workspace_bytes >= need && need > 0) {                                                     \
       a.ws_z = (T*)workspace;                                                                                   \
-      a.ws_logu = nullptr;                                                                                      \
+      a.ws_logu = D <= 6 ? (T*)((char*)workspace + need) - 64 : nullptr;   /* eig block */                      \
     }                                                                                                           \
     return hta::gaussian_dispatch<T>(a, mass_kind, false, (hipStream_t)stream);                                 \
   }                                                                                                             \

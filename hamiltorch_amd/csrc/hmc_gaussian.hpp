@@ -12,11 +12,13 @@ template <typename T> struct GaussArgs {
   T* samples; int32_t* reject_count; T* H_old; T* H_new; uint8_t* accept;
   T* p_io;  // leapfrog-only entry: momentum in/out
   T* path_theta; T* path_p;  // leapfrog-only: optional per-step record [steps,C,D] (S:299-300)
-  T* ws_z; T* ws_logu;       // optional pre-drawn records [n_traj,C,(z_0..z_{D-1}, log u, pad)] (ws_logu unused)
+  T* ws_z; T* ws_logu;       // optional pre-drawn records [n_traj,C,(z_0..z_{D-1}, log u, pad)]; ws_logu: eig block (lam, Q) or NULL
 };
 
 extern int g_small_chains_per_block;
 extern int g_force_general;
+extern int g_gauss_eig;
+extern int g_quad_max_chains;
 void profile_begin(hipStream_t s);
 void profile_end(hipStream_t s);
 

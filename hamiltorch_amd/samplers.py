@@ -521,10 +521,12 @@ class _GaussianHMC(_Engine):
         C, D = theta0.shape
         # scratch for the pre-drawn momenta / log-uniforms of one launch (<= WS_CAP bytes, so it stays
         # in the 256 MB Infinity Cache); long runs are cut into several launches over `traj_offset`
-        per_traj = _abi.gaussian_workspace_bytes(C, D, 1, theta0.element_size()) // 2
-        chunk = max(1, min(count, self.WS_CAP // per_traj - 1)) if 2 * per_traj <= self.WS_CAP else count
+        fixed = _abi.gaussian_workspace_bytes(C, D, 0, theta0.element_size())       # look-ahead rows + eigen block
+        per_traj = _abi.gaussian_workspace_bytes(C, D, 1, theta0.element_size()) - fixed
+        fits = fixed + per_traj <= self.WS_CAP
+        chunk = max(1, min(count, (self.WS_CAP - fixed) // per_traj)) if fits else count
         ws = None
-        if 2 * per_traj <= self.WS_CAP and (H_old is None):
+        if fits and (H_old is None):
             ws = getattr(self, "_ws", None)
             need = _abi.gaussian_workspace_bytes(C, D, chunk, theta0.element_size())
             if ws is None or ws.numel() < need:

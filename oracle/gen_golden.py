@@ -180,6 +180,40 @@ def gen_sample_hmc():
     np.savez(os.path.join(OUT, "sample_hmc.npz"), **out)
 
 
+def gen_blockmass():
+    """Block-diagonal inv_mass given as a list of blocks (S:188-197, S:287-292, S:803-809, S:944-947)."""
+    out = {}
+    b0 = torch.tensor([[1.5, 0.4], [0.4, 0.8]])
+    b1 = torch.tensor([[2.0, 0.3, 0.0], [0.3, 1.0, -0.2], [0.0, -0.2, 0.6]])
+    out["b0"], out["b1"] = npy(b0), npy(b1)
+    th = torch.zeros(5)
+    torch.manual_seed(21)
+    z = torch.cat([torch.normal(torch.zeros(2), torch.ones(2)), torch.normal(torch.zeros(3), torch.ones(3))])
+    torch.manual_seed(21)
+    p = S.gibbs(th, sampler=hamiltorch.Sampler.HMC, mass=[b0, b1])
+    out["gibbs_z"], out["gibbs_p"] = npy(z), npy(p)
+    A = np.array([[1.0, 0.3, 0.0, 0.2, 0.0], [0.3, 2.0, 0.4, 0.0, 0.1], [0.0, 0.4, 1.5, 0.3, 0.0],
+                  [0.2, 0.0, 0.3, 0.8, 0.2], [0.0, 0.1, 0.0, 0.2, 1.2]], dtype=np.float32)
+    P = torch.tensor(A)
+    lp = quad_logp(P)
+    out["P"] = A
+    pm = torch.tensor([0.5, -1.0, 0.25, 2.0, -0.3]); th1 = torch.tensor([0.1, 0.2, -0.3, 0.4, -0.5])
+    out["kat_theta"], out["kat_p"] = npy(th1), npy(pm)
+    out["kat_H"] = npy(S.hamiltonian(th1, pm, lp, inv_mass=[b0, b1], sampler=hamiltorch.Sampler.HMC))
+    pl, ml = S.leapfrog(th1, pm, lp, steps=4, step_size=0.2, inv_mass=[b0, b1], sampler=hamiltorch.Sampler.HMC,
+                        integrator=hamiltorch.Integrator.IMPLICIT)
+    out["kat_theta_L"], out["kat_p_L"] = npy(pl[-1]), npy(ml[-1])
+    init = torch.tensor([0.5, -0.5, 0.2, 0.0, 1.0])
+    hamiltorch.set_random_seed(31)
+    with Recorder() as rec:
+        ret, acc = hamiltorch.sample(lp, init, num_samples=60, num_steps_per_sample=5, step_size=0.8, burn=4,
+                                     inv_mass=[b0, b1], debug=2, verbose=False)
+    out["samples"] = np.stack([npy(t) for t in ret]); out["momenta"] = np.stack(rec.momenta)
+    out["uniforms"] = np.concatenate(rec.uniforms); out["acc"] = np.array(acc); out["init"] = npy(init)
+    out["cfg"] = np.array([60, 5, 0.8, 4], dtype=np.float64)
+    np.savez(os.path.join(OUT, "blockmass.npz"), **out)
+
+
 def gen_nuts():
     """Dual-averaging step size ("HMC_NUTS", S:629-674 + S:1030-1035): the scalar recurrence and an end-to-end run."""
     out = {}
@@ -520,5 +554,6 @@ if __name__ == "__main__":
     gen_funnel()
     gen_splitkinds()
     gen_logcosh()
+    gen_blockmass()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

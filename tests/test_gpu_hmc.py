@@ -6,6 +6,8 @@ Tolerances (calibrated on the reference fp32 vs fp64): HMC trajectori
 atol = rtol = 1e-5 (fp32), 1e-11 (fp64); a Metropolis decision within rounding of its
 threshold may flip, so end-to-end sample() comparisons allow <= 1 % of chains to differ.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -266,32 +268,44 @@ def test_predrawn_workspace_equals_inline_rng(ht, D, mass):
     th0 = tt(np.random.default_rng(0).standard_normal((C, D)), dtype)
     kind, im, mf = _mass_operands(tt(masses(D, dtype)[mass], dtype), th0)
     outs = []
-    for use_ws in (False, True):
-        cur = th0.clone()
-        samples = torch.zeros(N + 1, C, D, device=dev())
-        rej = torch.zeros(C, dtype=torch.int32, device=dev())
-        ws = torch.empty(_abi.gaussian_workspace_bytes(C, D, N, 4), dtype=torch.uint8, device=dev()) if use_ws else None
-        _abi.hmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, kind, im, mf, L, eps, N, 0, -1, 77, 5,
-                                 samples, rej, workspace=ws)
-        outs.append((samples, rej))
+    _abi.set_tuning("gauss_eig", 0)     # same arithmetic on both sides (the eigenbasis route needs the pre-pass; it has its own test)
+    try:
+        for use_ws in (False, True):
+            cur = th0.clone()
+            samples = torch.zeros(N + 1, C, D, device=dev())
+            rej = torch.zeros(C, dtype=torch.int32, device=dev())
+            ws = torch.empty(_abi.gaussian_workspace_bytes(C, D, N, 4), dtype=torch.uint8, device=dev()) if use_ws else None
+            _abi.hmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, kind, im, mf, L, eps, N, 0, -1, 77, 5,
+                                     samples, rej, workspace=ws)
+            outs.append((samples, rej))
+    finally:
+        _abi.set_tuning("gauss_eig", 1)
     assert torch.equal(outs[0][1], outs[1][1])
     np.testing.assert_allclose(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy(), rtol=0, atol=1e-6)
 
 
 def test_chunked_launches_equal_single_launch(ht):
-    """sample() cuts long runs into several launches over traj_offset: same chain either way."""
-    from hamiltorch_amd import samplers
+    """sample() cuts long runs into several launches over traj_offset: same chain either way (bit for bit on the direct
+    kernels; to rounding on the eigenbasis route, whose state crosses a launch boundary as q = mu + Q y)."""
+    from hamiltorch_amd import samplers, _abi
     t, _ = targets(ht, np.linalg.inv(SIGMA3), torch.float32)
     th0 = tt(np.random.default_rng(1).standard_normal((64, 3)), torch.float32)
     kw = dict(num_samples=50, num_steps_per_sample=5, step_size=0.3, burn=7, verbose=False, seed=5)
     a = torch.stack(ht.sample(t, th0, **kw))
     old = samplers._GaussianHMC.WS_CAP
     try:
-        samplers._GaussianHMC.WS_CAP = 64 * 4 * 4 * 9        # room for 9 trajectories per launch
+        samplers._GaussianHMC.WS_CAP = 64 * 4 * 4 * 9        # room for a few trajectories per launch
         b = torch.stack(ht.sample(t, th0, **kw))
+        err = (a - b).abs().amax(dim=(0, 2))
+        assert (err > 2e-5).float().mean() <= 0.02, float(err.max())
+        _abi.set_tuning("gauss_eig", 0)
+        a0 = torch.stack(ht.sample(t, th0, **kw))
+        samplers._GaussianHMC.WS_CAP = old
+        b0 = torch.stack(ht.sample(t, th0, **kw))
+        assert torch.equal(a0, b0)
     finally:
         samplers._GaussianHMC.WS_CAP = old
-    assert torch.equal(a, b)
+        _abi.set_tuning("gauss_eig", 1)
 
 
 @pytest.mark.parametrize("route", ["fused", "generic"])
@@ -416,3 +430,61 @@ def test_device_counter_entry_points(ht):
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert 0 < int(res[0][2].sum()) < C
+
+
+@pytest.mark.parametrize("route", ["fused", "generic"])
+def test_block_list_inv_mass_vs_oracle_and_reference_fixture(ht, route):
+    """inv_mass as a list of diagonal blocks (S:188-197, S:287-292, S:803-809, S:944-947): pieces against the reference
+    fixture, batched sample() against the oracle on the same Philox draws, on the fused and the generic-callback route."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "blockmass.npz"))
+    dtype = torch.float32
+    blocks_np = [g["b0"], g["b1"]]
+    blocks = [tt(b, dtype) for b in blocks_np]
+    t, o = targets(ht, g["P"], dtype)
+    fn = t if route == "fused" else (lambda w: t(w))
+    H = ht.samplers.hamiltonian(tt(g["kat_theta"], dtype), tt(g["kat_p"], dtype), fn, inv_mass=blocks, sampler=ht.Sampler.HMC)
+    np.testing.assert_allclose(H.cpu().numpy().reshape(-1), g["kat_H"], rtol=1e-5)
+    pl, ml = ht.samplers.leapfrog(tt(g["kat_theta"], dtype), tt(g["kat_p"], dtype), fn, steps=4, step_size=0.2,
+                                  inv_mass=blocks, sampler=ht.Sampler.HMC)
+    np.testing.assert_allclose(pl[-1].cpu().numpy(), g["kat_theta_L"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ml[-1].cpu().numpy(), g["kat_p_L"], rtol=1e-4, atol=1e-5)
+    C, N, L, eps, burn, seed = 64, 20, 5, 0.8, 3, 77
+    th0 = (0.3 * O.philox_normals(seed, np.arange(C), 0, 5, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32)
+    out = ht.sample(fn, tt(th0, dtype), num_samples=N, num_steps_per_sample=L, step_size=eps, burn=burn, inv_mass=blocks,
+                    verbose=False, seed=seed)
+    ref, info = O.sample_hmc(o, th0, N, L, eps, burn, blocks_np, O.PhiloxDraws(seed, np.arange(C)))
+    _compare_runs(out, ref, 2e-4, 0.03)
+    assert 0.3 < info["acc_rate"].mean() < 1.0
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.float64, 1e-11)])
+@pytest.mark.parametrize("D", [1, 2, 3, 4, 5, 6])
+def test_eigenbasis_route_equals_direct_route(ht, dtype, tol, D):
+    """Identity-mass small-D Gaussian HMC integrates in the eigenbasis of P (2 D FMAs per step); hta_set_tuning('gauss_eig', 0)
+    selects the direct kernel (D + D^2 FMAs per step).  Same draws, same map: samples agree to rounding, chain by chain, also
+    with a mean offset, burn-in (Q2 reset) and nearly degenerate / widely spread spectra."""
+    from hamiltorch_amd import _abi
+    if dtype == torch.float64 and D > 4:
+        pytest.skip("fp64 register-resident kernels stop at D=4")
+    C, N, L, eps, seed = 128, 30, 7, 0.2, 5 + D
+    rng = np.random.default_rng(D)
+    Qm, _ = np.linalg.qr(rng.normal(size=(D, D)))
+    lam = np.concatenate([[4.0, 4.0 + 1e-7], rng.uniform(0.05, 6.0, size=D)])[:D]
+    P = (Qm * lam) @ Qm.T
+    mu = rng.normal(size=D)
+    t, _ = targets(ht, P, dtype, mu=mu)
+    th0 = tt(mu + rng.normal(size=(C, D)), dtype)
+    outs = []
+    for mode in (1, 0):
+        _abi.set_tuning("gauss_eig", mode)
+        try:
+            out, acc = ht.sample(t, th0, num_samples=N, num_steps_per_sample=L, step_size=eps, burn=3, debug=2, verbose=False,
+                                 seed=seed)
+        finally:
+            _abi.set_tuning("gauss_eig", 1)
+        outs.append((torch.stack(out).cpu().numpy(), acc.cpu().numpy()))
+    err = np.abs(outs[0][0] - outs[1][0]).max(axis=(0, 2))
+    assert (err > tol * 10).mean() <= 0.02, "max err %.3g" % err.max()      # a rounding-level accept flip moves a whole chain
+    good = err <= tol * 10
+    np.testing.assert_allclose(outs[0][1][good], outs[1][1][good], atol=1e-12)
+    assert 0.2 < outs[0][1].mean() <= 1.0
