@@ -658,17 +658,17 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
   const int k = (int)(gt & 3);
   if (c >= a.C) return;                         // whole quads leave together
   const bool live = k < D;
-  const int kk = live ? k : 0;
+  const int kk = live ? k : 0;                  // a dummy lane (k >= D) mirrors lane 0 on the output side (same address, same value)
   const T lam = live ? eig[kk] : 0.f;
-  const T mu = live ? a.mu[kk] : 0.f;
+  const T mu = a.mu[kk];
   T Qrow[D], Qcol[D];                           // Q[k][j] and Q[j][k]
 #pragma unroll
   for (int j = 0; j < D; ++j) {
-    Qrow[j] = live ? eig[D + kk * D + j] : 0.f;
+    Qrow[j] = eig[D + kk * D + j];
     Qcol[j] = live ? eig[D + j * D + kk] : 0.f;
   }
-  // a dummy lane (k >= D) integrates nothing: eps = lam = 0, so its y stays 0, its r stays whatever its record slot held
-  // (log u or padding) and its energy difference is exactly 0
+  // a dummy lane integrates nothing: eps = lam = 0, so its y stays 0, its r stays whatever its record slot held (log u or
+  // padding) and its energy difference is exactly 0
   const T eps = live ? a.eps : 0.f, nel = -(eps * lam), hl = 0.5f * eps * lam, hlam = 0.5f * lam;
   const size_t C = (size_t)a.C;
   auto bc = [&](T v, int j) {                   // lane j of the quad (j compile-time after unrolling)
@@ -692,69 +692,79 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
   };
   T yc = to_y(a.theta);
   T potc = hlam * yc * yc;                       // this coordinate's share of the potential at the current point
-  int32_t rejected = 0;
+  int32_t accepted = 0;
 
+  // Addresses are (wave-uniform base) + (32-bit lane offset): the bases advance on the scalar unit.
   constexpr int W = rec_elems<T, D>();
-  typedef const __attribute__((address_space(1))) T* grec_t;   // stays a global pointer through the ordering asm below
-  grec_t rec = (grec_t)(a.ws_z + (size_t)c * W + k);            // element k of this chain's record (W >= 4 floats)
-  const T* recu = a.ws_z + (size_t)c * W + D;    // D == 4: log u sits in the second vector
-  const size_t rec_step = C * W;
+  typedef const __attribute__((address_space(1))) char* gbytes_t;
+  gbytes_t recb = (gbytes_t)a.ws_z;                                // row of the record stream
+  uint32_t roff = (uint32_t)(((size_t)c * W + k) * sizeof(T));     // element k of this chain's record (W >= 4 floats)
+  const uint32_t uoff = (uint32_t)(((size_t)c * W + D) * sizeof(T));   // D == 4: log u sits in the second vector
+  const size_t rec_step = C * W * sizeof(T);
+  auto rec_at = [&](uint32_t off) { return *(const __attribute__((address_space(1))) T*)(recb + off); };
   // records are read two trajectories ahead (a trajectory is shorter than one HBM round trip): two rows of slack
-  T z0 = *rec, lu0 = D == 4 ? *recu : 0.f;
-  rec += rec_step; recu += rec_step;
-  T z1 = *rec, lu1 = D == 4 ? *recu : 0.f;
-  (void)recu;
-  // Every lane stores once per trajectory, unconditionally (uniform vmcnt, see hmc_gauss_small_kernel): a dummy lane
-  // writes a dump word at the end of the eig block.
-  T* const dump = const_cast<T*>(eig) + 48 + k;
-  T* const scratch = live ? a.theta + c * D + kk : dump;
-  *scratch = to_q(yc);
-  // Two phases, one loop body: trajectories with n <= burn rewrite the scratch slot (pointer step 0), the others walk the
-  // sample rows.
+  T z0 = rec_at(roff), lu0 = D == 4 ? rec_at(uoff) : 0.f;
+  recb += rec_step;
+  T z1 = rec_at(roff), lu1 = D == 4 ? rec_at(uoff) : 0.f;
+  // Every lane stores once per trajectory, unconditionally (uniform vmcnt, see hmc_gauss_small_kernel).
+  const uint32_t qoff = (uint32_t)(((size_t)c * D + kk) * sizeof(T));
+  typedef __attribute__((address_space(1))) char* gwbytes_t;
+  auto put = [&](gwbytes_t row, T v) { *(__attribute__((address_space(1))) T*)(row + qoff) = v; };
+  put((gwbytes_t)a.theta, to_q(yc));
+  // Two phases, one loop body: trajectories with n <= burn rewrite the chain's slot of `theta` (row step 0), the others
+  // walk the sample rows.
   const int n_burn = a.samples ? min(max(a.burn - a.traj_offset + 1, 0), a.n_traj) : a.n_traj;
   int t = 0;
   for (int phase = 0; phase < 2; ++phase) {
     const int t_end = phase == 0 ? n_burn : a.n_traj;
-    T* dst = scratch;
-    size_t dst_step = 0;
-    if (phase == 1 && live) {
-      dst = a.samples + ((size_t)max(a.traj_offset + t - a.burn, 1) * C + c) * D + kk;
-      dst_step = C * D;
+    gwbytes_t row = (gwbytes_t)a.theta;
+    size_t row_step = 0;
+    if (phase == 1) {
+      row = (gwbytes_t)(a.samples + (size_t)max(a.traj_offset + t - a.burn, 1) * C * D);
+      row_step = C * D * sizeof(T);
     }
     // one trajectory; `slot` holds its record element and is refilled with the one two trajectories ahead (the loop is
     // unrolled by two over the slots, so the newest load is never touched by a register rotation)
     auto trajectory = [&](T& slot, T& slot_u) {
       const int n = a.traj_offset + t;
-      rec += rec_step;
+      recb += rec_step;
       // everything that reads the record first, so that its register is free for the refill
       // ---- gibbs S:185-186 (rotated draws), H_old S:971, half kick S:281
       T y = yc, r, eo, logu;
       {
         const T z = slot;
-        logu = D == 4 ? slot_u : bc(z, D < 4 ? D : 0);
+        logu = D == 4 ? slot_u
+                      : __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, z), (D < 4 ? D : 0) * 0x55,
+                                                                            0xF, 0xF, true));
         eo = fmaf(0.5f * z, z, potc);
         r = fmaf(-hl, yc, z);
       }
       // (the empty asm orders the refill after the record's last use, so the load can target the record's own register;
       //  otherwise the scheduler hoists the load and the back-edge copy of its result waits for it)
-      asm volatile("" : "+v"(rec) : "v"(r), "v"(eo), "v"(logu));
-      slot = *rec;
-      if (D == 4) slot_u = *(rec + (D - k));
+      asm volatile("" : "+v"(roff) : "v"(r), "v"(eo), "v"(logu));
+      slot = rec_at(roff);
+      if (D == 4) slot_u = rec_at(uoff);
       repeat_steps(a.L, [&]() { y = fmaf(eps, r, y); r = fmaf(nel, y, r); });      // S:283-298
       r = fmaf(hl, y, r);                                                           // S:302
       // ---- H_new S:995 and the MH test S:1000-1004
       const T pot1 = hlam * y * y;
       const T en = fmaf(0.5f * r, r, pot1);
       const T dH = quad_sum(eo - en);                                               // h_old - h_new
-      const bool acc = finite_(dH) && (fminf(0.f, dH) >= logu);
-      rejected += acc ? 0 : 1;
-      yc = acc ? y : yc;
-      potc = acc ? pot1 : potc;
+      // the decision as a lane mask (v_cmp into an SGPR pair), consumed by a carry-in add and two selects
+      const uint64_t accmask = __builtin_amdgcn_fcmpf(fminf(0.f, dH), logu, 3 /* oge */) &
+                               __builtin_amdgcn_fcmpf(fabsf(dH), __builtin_inff(), 4 /* olt: finite */);
+      {
+        uint64_t carry_out;
+        asm("v_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(accepted), "=s"(carry_out) : "s"(accmask));
+        asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(yc) : "v"(y), "s"(accmask));
+        asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(potc) : "v"(pot1), "s"(accmask));
+      }
+      const bool acc = (accmask >> (threadIdx.x & 63)) & 1;                         // per-lane form: rare paths only
       if (__builtin_expect(n == a.burn + 1, 0)) {                                   // Q2 reset (S:1016-1018)
         if (!acc) { yc = to_y(a.theta_init); potc = hlam * yc * yc; }
       }
-      *dst = to_q(yc);
-      dst += dst_step;
+      put(row, to_q(yc));
+      row += row_step;
       if (DIAG) {
         const T ho = quad_sum(eo) - a.log_norm, hn = quad_sum(en) - a.log_norm;
         if (k == 0) {
@@ -772,8 +782,8 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
       tmp = lu0; lu0 = lu1; lu1 = tmp;
     }
   }
-  *scratch = to_q(yc);
-  if (a.reject_count && k == 0) a.reject_count[c] += rejected;
+  put((gwbytes_t)a.theta, to_q(yc));
+  if (a.reject_count && k == 0) a.reject_count[c] += a.n_traj - accepted;
 }
 
 template <typename T, int D, int MASS>
@@ -1012,7 +1022,7 @@ template <typename T, int D, int MASS> void launch_small(const GaussArgs<T>& a, 
   const bool diag = a.H_old || a.H_new || a.accept;
   if (MASS == HTA_MASS_NONE && a.ws_z && a.ws_logu) {      // eigenbasis route (a.ws_logu = the eig block)
     if constexpr (sizeof(T) == 4 && D <= 4) {
-      if (g_gauss_eig >= 1 && g_gauss_eig != 2 && a.C <= g_quad_max_chains) {   // latency regime: a quad per chain
+      if (g_gauss_eig >= 1 && g_gauss_eig != 2 && a.C <= g_quad_max_chains && a.C <= (1 << 24)) {   // latency regime: a quad per chain (32-bit lane offsets)
         const int qgrid = (int)((a.C * 4 + 63) / 64);
         profile_begin(s);
         if (diag) hmc_gauss_quad_kernel<D, true><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
