@@ -786,6 +786,7 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
   if (a.reject_count && k == 0) a.reject_count[c] += a.n_traj - accepted;
 }
 
+
 template <typename T, int D, int MASS>
 __global__ void leapfrog_gauss_small_kernel(GaussArgs<T> a) {
   const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1015,6 +1016,11 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void leapfrog_gauss_wave_kernel(Gau
 // =============================================================================================
 // dispatch
 // =============================================================================================
+// the quad kernel's eligibility
+template <typename T> static bool quad_route(const GaussArgs<T>& a) {
+  return sizeof(T) == 4 && a.D <= 4 && a.ws_z && a.ws_logu && g_gauss_eig >= 1 && g_gauss_eig != 2 &&
+         a.C <= g_quad_max_chains && a.C <= (1 << 24);
+}
 template <typename T, int D, int MASS> void launch_small(const GaussArgs<T>& a, bool lf_only, hipStream_t s) {
   int block = g_small_chains_per_block > 0 ? g_small_chains_per_block : 64;
   const int grid = (int)((a.C + block - 1) / block);
@@ -1022,7 +1028,7 @@ template <typename T, int D, int MASS> void launch_small(const GaussArgs<T>& a, 
   const bool diag = a.H_old || a.H_new || a.accept;
   if (MASS == HTA_MASS_NONE && a.ws_z && a.ws_logu) {      // eigenbasis route (a.ws_logu = the eig block)
     if constexpr (sizeof(T) == 4 && D <= 4) {
-      if (g_gauss_eig >= 1 && g_gauss_eig != 2 && a.C <= g_quad_max_chains && a.C <= (1 << 24)) {   // latency regime: a quad per chain (32-bit lane offsets)
+      if (quad_route(a)) {   // latency regime: a quad per chain (32-bit lane offsets)
         const int qgrid = (int)((a.C * 4 + 63) / 64);
         profile_begin(s);
         if (diag) hmc_gauss_quad_kernel<D, true><<<qgrid, 64, 0, s>>>(a, a.ws_logu);

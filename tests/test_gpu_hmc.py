@@ -488,3 +488,4 @@ def test_eigenbasis_route_equals_direct_route(ht, dtype, tol, D):
     good = err <= tol * 10
     np.testing.assert_allclose(outs[0][1][good], outs[1][1][good], atol=1e-12)
     assert 0.2 < outs[0][1].mean() <= 1.0
+
