@@ -13,6 +13,7 @@
 //   general (D <= 1024): one chain per 64-lane wave, lane l owns elements l, l+64, ...;
 //                      P streamed row-by-row (coalesced, L1/L2 resident), the offset vector
 //                      broadcast through LDS, energies by wave butterfly reduction.
+#include <type_traits>
 #include "common.hpp"
 #include "philox.hpp"
 #include "hmc_gaussian.hpp"
@@ -650,7 +651,9 @@ __device__ __forceinline__ float quad_sum(float v) {
   return v;
 }
 
-template <int D, bool DIAG>
+// LB > 0: a.L == LB is known at compile time (straight-line steps, no loop bookkeeping: at this size every scalar
+// instruction on the hot path costs what a vector one does); LB == 0: any L.
+template <int D, bool DIAG, int LB>
 __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, const float* __restrict__ eig) {
   typedef float T;
   const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -725,8 +728,9 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
     }
     // one trajectory; `slot` holds its record element and is refilled with the one two trajectories ahead (the loop is
     // unrolled by two over the slots, so the newest load is never touched by a register rotation)
-    auto trajectory = [&](T& slot, T& slot_u) {
-      const int n = a.traj_offset + t;
+    // `q2`: this is trajectory burn+1, the one the reference resets to params_init when it is rejected (S:1016-1018);
+    // a separate instance, so that the others carry no check for it.
+    auto trajectory = [&](T& slot, T& slot_u, auto q2) {
       recb += rec_step;
       // everything that reads the record first, so that its register is free for the refill
       // ---- gibbs S:185-186 (rotated draws), H_old S:971, half kick S:281
@@ -744,7 +748,12 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
       asm volatile("" : "+v"(roff) : "v"(r), "v"(eo), "v"(logu));
       slot = rec_at(roff);
       if (D == 4) slot_u = rec_at(uoff);
-      repeat_steps(a.L, [&]() { y = fmaf(eps, r, y); r = fmaf(nel, y, r); });      // S:283-298
+      if constexpr (LB > 0) {                                                       // S:283-298
+#pragma unroll
+        for (int l = 0; l < LB; ++l) { y = fmaf(eps, r, y); r = fmaf(nel, y, r); }
+      } else {
+        repeat_steps(a.L, [&]() { y = fmaf(eps, r, y); r = fmaf(nel, y, r); });
+      }
       r = fmaf(hl, y, r);                                                           // S:302
       // ---- H_new S:995 and the MH test S:1000-1004
       const T pot1 = hlam * y * y;
@@ -753,19 +762,51 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
       // the decision as a lane mask (v_cmp into an SGPR pair), consumed by a carry-in add and two selects
       const uint64_t accmask = __builtin_amdgcn_fcmpf(fminf(0.f, dH), logu, 3 /* oge */) &
                                __builtin_amdgcn_fcmpf(fabsf(dH), __builtin_inff(), 4 /* olt: finite */);
-      {
+      T q = mu;
+      if constexpr (!decltype(q2)::value) {
+        // accepted += acc; yc, potc <- accepted point; q_k = mu_k + sum_j Q[k][j] yc_j.  One block: the two instructions
+        // between the write of yc and its first DPP read are the wait states that read needs.
+        uint64_t carry_out;
+        static_assert(D >= 1 && D <= 4, "quad kernel");
+        if constexpr (D == 1)
+          asm volatile("v_addc_co_u32_e64 %0, %4, 0, %0, %5\n\tv_cndmask_b32_e64 %1, %1, %6, %5\n\tv_cndmask_b32_e64 %2, %2, %7, %5\n\t"
+                       "s_nop 0\n\tv_fmac_f32_dpp %3, %1, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf"
+                       : "+v"(accepted), "+v"(yc), "+v"(potc), "+v"(q), "=&s"(carry_out)
+                       : "s"(accmask), "v"(y), "v"(pot1), "v"(Qrow[0]));
+        else if constexpr (D == 2)
+          asm volatile("v_addc_co_u32_e64 %0, %4, 0, %0, %5\n\tv_cndmask_b32_e64 %1, %1, %6, %5\n\tv_cndmask_b32_e64 %2, %2, %7, %5\n\t"
+                       "s_nop 0\n\tv_fmac_f32_dpp %3, %1, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                       "v_fmac_f32_dpp %3, %1, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf"
+                       : "+v"(accepted), "+v"(yc), "+v"(potc), "+v"(q), "=&s"(carry_out)
+                       : "s"(accmask), "v"(y), "v"(pot1), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]));
+        else if constexpr (D == 3)
+          asm volatile("v_addc_co_u32_e64 %0, %4, 0, %0, %5\n\tv_cndmask_b32_e64 %1, %1, %6, %5\n\tv_cndmask_b32_e64 %2, %2, %7, %5\n\t"
+                       "s_nop 0\n\tv_fmac_f32_dpp %3, %1, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                       "v_fmac_f32_dpp %3, %1, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                       "v_fmac_f32_dpp %3, %1, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf"
+                       : "+v"(accepted), "+v"(yc), "+v"(potc), "+v"(q), "=&s"(carry_out)
+                       : "s"(accmask), "v"(y), "v"(pot1), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]), "v"(Qrow[D > 2 ? 2 : 0]));
+        else
+          asm volatile("v_addc_co_u32_e64 %0, %4, 0, %0, %5\n\tv_cndmask_b32_e64 %1, %1, %6, %5\n\tv_cndmask_b32_e64 %2, %2, %7, %5\n\t"
+                       "s_nop 0\n\tv_fmac_f32_dpp %3, %1, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                       "v_fmac_f32_dpp %3, %1, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                       "v_fmac_f32_dpp %3, %1, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                       "v_fmac_f32_dpp %3, %1, %11 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+                       : "+v"(accepted), "+v"(yc), "+v"(potc), "+v"(q), "=&s"(carry_out)
+                       : "s"(accmask), "v"(y), "v"(pot1), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]), "v"(Qrow[D > 2 ? 2 : 0]),
+                         "v"(Qrow[D > 3 ? 3 : 0]));
+      } else {
         uint64_t carry_out;
         asm("v_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(accepted), "=s"(carry_out) : "s"(accmask));
         asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(yc) : "v"(y), "s"(accmask));
         asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(potc) : "v"(pot1), "s"(accmask));
+        if (!((accmask >> (threadIdx.x & 63)) & 1)) { yc = to_y(a.theta_init); potc = hlam * yc * yc; }
+        q = to_q(yc);
       }
-      const bool acc = (accmask >> (threadIdx.x & 63)) & 1;                         // per-lane form: rare paths only
-      if (__builtin_expect(n == a.burn + 1, 0)) {                                   // Q2 reset (S:1016-1018)
-        if (!acc) { yc = to_y(a.theta_init); potc = hlam * yc * yc; }
-      }
-      put(row, to_q(yc));
+      put(row, q);
       row += row_step;
       if (DIAG) {
+        const bool acc = (accmask >> (threadIdx.x & 63)) & 1;
         const T ho = quad_sum(eo) - a.log_norm, hn = quad_sum(en) - a.log_norm;
         if (k == 0) {
           if (a.H_old) a.H_old[(size_t)t * C + c] = ho;
@@ -775,9 +816,15 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
       }
       ++t;
     };
-    while (t + 1 < t_end) { trajectory(z0, lu0); trajectory(z1, lu1); }
+    std::false_type plain;
+    if (phase == 1 && t < t_end && a.traj_offset + t == a.burn + 1) {              // the Q2 trajectory opens the stored phase
+      trajectory(z0, lu0, std::true_type{});
+      T tmp = z0; z0 = z1; z1 = tmp;
+      tmp = lu0; lu0 = lu1; lu1 = tmp;
+    }
+    while (t + 1 < t_end) { trajectory(z0, lu0, plain); trajectory(z1, lu1, plain); }
     if (t < t_end) {
-      trajectory(z0, lu0);
+      trajectory(z0, lu0, plain);
       T tmp = z0; z0 = z1; z1 = tmp;
       tmp = lu0; lu0 = lu1; lu1 = tmp;
     }
@@ -1031,8 +1078,12 @@ template <typename T, int D, int MASS> void launch_small(const GaussArgs<T>& a, 
       if (quad_route(a)) {   // latency regime: a quad per chain (32-bit lane offsets)
         const int qgrid = (int)((a.C * 4 + 63) / 64);
         profile_begin(s);
-        if (diag) hmc_gauss_quad_kernel<D, true><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
-        else hmc_gauss_quad_kernel<D, false><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
+        const int lb = g_gauss_eig == 3 ? 0 : a.L;       // gauss_eig = 3: the any-L instance (tests compare the two)
+        if (diag) hmc_gauss_quad_kernel<D, true, 0><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
+        else if (lb == 25) hmc_gauss_quad_kernel<D, false, 25><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
+        else if (lb == 10) hmc_gauss_quad_kernel<D, false, 10><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
+        else if (lb == 5) hmc_gauss_quad_kernel<D, false, 5><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
+        else hmc_gauss_quad_kernel<D, false, 0><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
         profile_end(s);
         return;
       }

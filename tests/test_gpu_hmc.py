@@ -489,3 +489,38 @@ def test_eigenbasis_route_equals_direct_route(ht, dtype, tol, D):
     np.testing.assert_allclose(outs[0][1][good], outs[1][1][good], atol=1e-12)
     assert 0.2 < outs[0][1].mean() <= 1.0
 
+
+
+@pytest.mark.parametrize("D,C,L", [(3, 1024, 25), (1, 17, 5), (2, 100, 10), (4, 333, 25), (3, 5, 10)])
+def test_quad_kernel_step_count_instances_agree(ht, D, C, L):
+    """hmc_gauss_quad_kernel has instances with the step count compiled in (L = 5, 10, 25: no loop bookkeeping on the hot
+    path) and a separate instance of the burn+1 trajectory (Q2 reset); hta_set_tuning('gauss_eig', 3) selects the any-L
+    instance.  Same arithmetic: bit-identical samples, reject counts and final state, with the Q2 reset exercised."""
+    from hamiltorch_amd import _abi
+    rng = np.random.default_rng(D * 100 + C)
+    P = rand_spd(D, 5 + D)
+    mu = rng.normal(size=D)
+    t, _ = targets(ht, P, torch.float32, mu=mu)
+    th0 = tt(mu + rng.normal(size=(C, D)), torch.float32)
+    N, burn, eps = 37, 3, 0.9 / np.sqrt(np.linalg.eigvalsh(P).max()) * (25.0 / L) ** 0.25
+    outs = []
+    for mode in (1, 3):
+        _abi.set_tuning("gauss_eig", mode)
+        try:
+            cur = th0.clone()
+            samples = torch.zeros(N - burn + 1, C, D, device=dev())
+            rej = torch.zeros(C, dtype=torch.int32, device=dev())
+            ws = torch.zeros(_abi.gaussian_workspace_bytes(C, D, N, 4), dtype=torch.uint8, device=dev())
+            for start, cnt in ((0, 2), (2, N - 2)):          # the Q2 trajectory (n = burn+1 = 4) inside the second launch
+                _abi.hmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, 0, None, None, L, float(eps), cnt, start, burn,
+                                         31, 7, samples, rej, workspace=ws)
+            torch.cuda.synchronize()
+        finally:
+            _abi.set_tuning("gauss_eig", 1)
+        outs.append((samples.cpu(), rej.cpu(), cur.cpu()))
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
+    if C >= 100:
+        assert 0 < int(outs[0][1].sum()) < C * N
+        # Q2: a chain rejected at n = burn+1 restarts from params_init -> its first stored row after the seed row equals th0
+        assert bool((outs[0][0][1] == th0.cpu()).all(dim=1).any())
