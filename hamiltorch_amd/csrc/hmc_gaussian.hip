@@ -255,7 +255,7 @@ __device__ __forceinline__ void draw_inline(uint64_t seed, uint64_t chain, uint3
 // workspace: record [t][c] of rec_elems<T,D>() values = (z_0 .. z_{D-1}, log u, padding)
 template <typename T, int D>
 __global__ void rng_fill_small_kernel(T* __restrict__ ws, int64_t C, int n_traj, int traj_offset, uint64_t seed,
-                                      uint64_t chain_offset, const T* __restrict__ eig) {
+                                      uint64_t chain_offset, const T* __restrict__ eig, T lu_scale) {
   constexpr int W = rec_elems<T, D>();
   T Q[D][D];            // eigenbasis route: records hold Q^T z (wave-uniform operands)
   if (eig) {
@@ -286,7 +286,7 @@ __global__ void rng_fill_small_kernel(T* __restrict__ ws, int64_t C, int n_traj,
 #pragma unroll
       for (int j = 0; j < D; ++j) rec[j] = z[j];
     }
-    rec[D] = lu;
+    rec[D] = lu_scale * lu;          // the quad kernel compares doubled energies: it gets 2 log u
     V* out = reinterpret_cast<V*>(ws + idx * W);
 #pragma unroll
     for (int i = 0; i < W / RecVec<T>::N; ++i) {
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
   }
   // a dummy lane integrates nothing: eps = lam = 0, so its y stays 0, its r stays whatever its record slot held (log u or
   // padding) and its energy difference is exactly 0
-  const T eps = live ? a.eps : 0.f, nel = -(eps * lam), hl = 0.5f * eps * lam, hlam = 0.5f * lam;
+  const T eps = live ? a.eps : 0.f, nel = -(eps * lam), hl = 0.5f * eps * lam;
   const size_t C = (size_t)a.C;
   auto bc = [&](T v, int j) {                   // lane j of the quad (j compile-time after unrolling)
     return j == 0 ? quad_bcast<0>(v) : j == 1 ? quad_bcast<1>(v) : j == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v);
@@ -694,7 +694,9 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
     return q;
   };
   T yc = to_y(a.theta);
-  T potc = hlam * yc * yc;                       // this coordinate's share of the potential at the current point
+  // Energies are carried DOUBLED (2 x potential share = lam y^2, 2 x kinetic share = r^2; the record holds 2 log u): one
+  // multiply less per energy, and scaling by two commutes with rounding, so the decisions are those of the plain form.
+  T potc = lam * yc * yc;                        // twice this coordinate's share of the potential at the current point
   int32_t accepted = 0;
 
   // Addresses are (wave-uniform base) + (32-bit lane offset): the bases advance on the scalar unit.
@@ -740,7 +742,7 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
         logu = D == 4 ? slot_u
                       : __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, z), (D < 4 ? D : 0) * 0x55,
                                                                             0xF, 0xF, true));
-        eo = fmaf(0.5f * z, z, potc);
+        eo = fmaf(z, z, potc);
         r = fmaf(-hl, yc, z);
       }
       // (the empty asm orders the refill after the record's last use, so the load can target the record's own register;
@@ -756,9 +758,9 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
       }
       r = fmaf(hl, y, r);                                                           // S:302
       // ---- H_new S:995 and the MH test S:1000-1004
-      const T pot1 = hlam * y * y;
-      const T en = fmaf(0.5f * r, r, pot1);
-      const T dH = quad_sum(eo - en);                                               // h_old - h_new
+      const T pot1 = lam * y * y;
+      const T en = fmaf(r, r, pot1);
+      const T dH = quad_sum(eo - en);                                               // 2 (h_old - h_new)
       // the decision as a lane mask (v_cmp into an SGPR pair), consumed by a carry-in add and two selects
       const uint64_t accmask = __builtin_amdgcn_fcmpf(fminf(0.f, dH), logu, 3 /* oge */) &
                                __builtin_amdgcn_fcmpf(fabsf(dH), __builtin_inff(), 4 /* olt: finite */);
@@ -800,14 +802,14 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
         asm("v_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(accepted), "=s"(carry_out) : "s"(accmask));
         asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(yc) : "v"(y), "s"(accmask));
         asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(potc) : "v"(pot1), "s"(accmask));
-        if (!((accmask >> (threadIdx.x & 63)) & 1)) { yc = to_y(a.theta_init); potc = hlam * yc * yc; }
+        if (!((accmask >> (threadIdx.x & 63)) & 1)) { yc = to_y(a.theta_init); potc = lam * yc * yc; }
         q = to_q(yc);
       }
       put(row, q);
       row += row_step;
       if (DIAG) {
         const bool acc = (accmask >> (threadIdx.x & 63)) & 1;
-        const T ho = quad_sum(eo) - a.log_norm, hn = quad_sum(en) - a.log_norm;
+        const T ho = 0.5f * quad_sum(eo) - a.log_norm, hn = 0.5f * quad_sum(en) - a.log_norm;
         if (k == 0) {
           if (a.H_old) a.H_old[(size_t)t * C + c] = ho;
           if (a.H_new) a.H_new[(size_t)t * C + c] = hn;
@@ -1130,7 +1132,7 @@ template <typename T, int D> static void launch_rng_fill_d(const GaussArgs<T>& a
   if (g > 256 * 16) g = 256 * 16;
   if (a.ws_logu) eig_small_kernel<T, D><<<1, 64, 0, s>>>(a.P, a.ws_logu);
   rng_fill_small_kernel<T, D><<<(int)g, 256, 0, s>>>(a.ws_z, a.C, a.n_traj, a.traj_offset, a.seed, a.chain_offset,
-                                                     a.ws_logu);
+                                                     a.ws_logu, quad_route(a) ? (T)2 : (T)1);
 }
 template <typename T> static void launch_rng_fill(const GaussArgs<T>& a, hipStream_t s) {
   switch (a.D) {
