@@ -351,7 +351,7 @@ def main():
                        "samples_stored": True, "parallelism": "chains sharded, %d per GPU, no collective" % w.C},
             "roofline": roof or {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "hmc_gauss_quad_kernel<3,false>" if w.C <= 65536 else "hmc_gauss_eig_kernel<float,3,false>",
+                         "kernel": "hmc_gauss_quad_kernel<3,false,25>" if w.C <= 65536 else "hmc_gauss_eig_kernel<float,3,false>",
                          "kernel_ms": kernel_ms,
                          "call_ms": call_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
