@@ -12,6 +12,7 @@ void set_error(const char* fmt, ...) {
 }
 int g_small_chains_per_block = 0;  // 0 = default (64)
 int g_force_general = 0;
+int g_rmhmc_overlap = 1;   // fused RMHMC: momentum draws of the next block of trajectories on a side stream
 int g_gauss_eig = 1;       // small-D identity-mass Gaussian HMC integrates in the eigenbasis of P (0: direct kernel, 2: chain per lane only)
 int g_quad_max_chains = 65536;   // up to here a chain takes a DPP quad (one eigen-coordinate per lane), beyond a lane
 int g_rmhmc_fused = 1;           // 0 = per-evaluation Jacobi path, 3 = fused with two chains per workgroup (parity tests)
@@ -67,6 +68,7 @@ int hta_set_tuning(const char* key, int value) {
   if (!strcmp(key, "small_chains_per_block")) { hta::g_small_chains_per_block = value; return HTA_OK; }
   if (!strcmp(key, "force_general")) { hta::g_force_general = value; return HTA_OK; }
   if (!strcmp(key, "gauss_eig")) { hta::g_gauss_eig = value; return HTA_OK; }
+  if (!strcmp(key, "rmhmc_overlap")) { hta::g_rmhmc_overlap = value; return HTA_OK; }
   if (!strcmp(key, "quad_max_chains")) { hta::g_quad_max_chains = value; return HTA_OK; }
   if (!strcmp(key, "mlp_valu")) { hta::g_mlp_valu = value; return HTA_OK; }
   if (!strcmp(key, "rmhmc_fused")) { hta::g_rmhmc_fused = value; return HTA_OK; }

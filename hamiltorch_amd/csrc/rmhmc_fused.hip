@@ -660,6 +660,26 @@ int fused_plan(const T* lam0_host, int D, int metric, double alpha, int has_jitt
   return K > 40 ? -1 : K;
 }
 
+// side stream + events of the momentum / trajectory overlap, one set per device, created on first use
+struct Overlap { hipStream_t side; hipEvent_t start, ready[2], freed[2]; };
+static Overlap* overlap_for_current_device() {
+  static Overlap pool[16];
+  static bool made[16] = {false};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!made[dev]) {
+    Overlap& o = pool[dev];
+    if (hipStreamCreateWithFlags(&o.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    bool ok = hipEventCreateWithFlags(&o.start, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i)
+      ok = hipEventCreateWithFlags(&o.ready[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&o.freed[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) return nullptr;
+    made[dev] = true;
+  }
+  return &pool[dev];
+}
+
 template <typename T>
 int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, const T* mu, double log_norm, double logdetP,
                        int has_jitter, double jitter, int K, int series, int64_t C, int D, int L, double eps, double omega,
@@ -673,11 +693,28 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
   // momenta of a block of trajectories are drawn ahead by rmhmc_momentum_kernel when the workspace has room for them
   const int64_t per_traj = C * (int64_t)D;
   int block = (p_ws && p_ws_elems >= per_traj) ? (int)(p_ws_elems / per_traj < n_traj ? p_ws_elems / per_traj : n_traj) : 0;
+  // With room for two blocks the draws of block b+1 (side stream) overlap the trajectories of block b: the momentum kernel
+  // is a quarter of the serial time at config 3, and both kernels are latency bound, so they share the CUs well.
+  // p_ws is used as two halves; events order "half drawn" -> trajectories and "half consumed" -> next draw.
+  Overlap* ov = nullptr;
+  if (g_rmhmc_overlap && block >= 16 && n_traj >= 32) {
+    ov = overlap_for_current_device();
+    if (ov) {
+      int sub = (n_traj + 7) / 8;                      // ~8 blocks: only the first draw is exposed
+      if (sub < 8) sub = 8;
+      if (sub > block / 2) sub = block / 2;
+      block = sub;
+      (void)hipEventRecord(ov->start, s);
+      (void)hipStreamWaitEvent(ov->side, ov->start, 0);
+    }
+  }
   static bool done[8] = {false, false, false, false, false, false, false, false};     // per T instantiation
   static bool done2[8] = {false, false, false, false, false, false, false, false};
   static bool done_mom = false;
-  for (int t0 = 0; t0 < n_traj; t0 += (block > 0 ? block : n_traj)) {
+  int bidx = 0;
+  for (int t0 = 0; t0 < n_traj; t0 += (block > 0 ? block : n_traj), ++bidx) {
     const int nt = block > 0 ? (n_traj - t0 < block ? n_traj - t0 : block) : n_traj;
+    T* const p_blk = (ov && (bidx & 1)) ? p_ws + (int64_t)block * per_traj : p_ws;
     if (block > 0) {
       const size_t mlds = ((size_t)D * ld + 3 * 128) * sizeof(T);
       if (!done_mom) {
@@ -688,14 +725,22 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
       }
       const int64_t ntask = (int64_t)nt * C;
       const int mgrid = (int)(ntask < 256 * 12 ? ntask : 256 * 12);
-      profile_begin(s);
-      rmhmc_momentum_kernel<T><<<mgrid, FNT, mlds, s>>>(P, has_jitter, (T)jitter, C, D, ld, nt, traj_offset + t0, seed, chain_offset, p_ws);
-      profile_end(s);
+      if (ov) {
+        if (bidx >= 2) (void)hipStreamWaitEvent(ov->side, ov->freed[bidx & 1], 0);     // trajectories of block b-2 are done with it
+        rmhmc_momentum_kernel<T><<<mgrid, FNT, mlds, ov->side>>>(P, has_jitter, (T)jitter, C, D, ld, nt, traj_offset + t0, seed,
+                                                                 chain_offset, p_blk);
+        (void)hipEventRecord(ov->ready[bidx & 1], ov->side);
+        (void)hipStreamWaitEvent(s, ov->ready[bidx & 1], 0);
+      } else {
+        profile_begin(s);
+        rmhmc_momentum_kernel<T><<<mgrid, FNT, mlds, s>>>(P, has_jitter, (T)jitter, C, D, ld, nt, traj_offset + t0, seed, chain_offset, p_blk);
+        profile_end(s);
+      }
     }
     FusedArgs<T> a{cur, theta_init, P, Sinv, mu, (T)log_norm, (T)logdetP, has_jitter, (T)jitter, K, series, C, D, L, (T)eps,
                    (T)cosf(ang), (T)sinf(ang), nt, traj_offset + t0, burn, seed, chain_offset, samples, reject_count,
                    H_old ? H_old + (int64_t)t0 * C : nullptr, H_new ? H_new + (int64_t)t0 * C : nullptr,
-                   accept ? accept + (int64_t)t0 * C : nullptr, block > 0 ? p_ws : nullptr};
+                   accept ? accept + (int64_t)t0 * C : nullptr, block > 0 ? p_blk : nullptr};
     // two chains per workgroup (NC = 2; needs pre-drawn momenta and the log-det series): measured 5 % SLOWER than one
     // chain per workgroup at 1024 and 4096 chains (the pass is LDS-bandwidth bound: every wave streams every vector), so it
     // is only taken on request (tuning value 3: parity tests keep the variant alive)
@@ -736,6 +781,7 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
       default: rc = launch(&rmhmc_fused_kernel<T, 64, 1>, &rmhmc_fused_kernel<T, 64, 2>, done[7], done2[7]); break;
     }
     if (rc) return rc;
+    if (ov) (void)hipEventRecord(ov->freed[bidx & 1], s);
   }
   HTA_CHECK_LAUNCH("hta_rmhmc_gaussian_sample (fused)");
   return HTA_OK;

@@ -481,3 +481,34 @@ def test_fused_workspace_passes_are_equivalent(ht):
         outs.append((samples.cpu().numpy(), rej.cpu().numpy()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert np.abs(outs[0][0][-1] - outs[0][0][0]).max() > 1e-3
+
+
+@pytest.mark.parametrize("T", [32, 75, 200])
+def test_fused_momentum_overlap_equals_serial(ht, T):
+    """With room for two blocks the momentum draws of block b+1 run on a side stream under the trajectories of block b
+    (hta_set_tuning('rmhmc_overlap', 0) keeps everything on the caller's stream).  Same kernels, same draws: bit-identical
+    samples / reject counts, also when the call is repeated back to back (event reuse) and followed by work on the
+    caller's stream that reads the results."""
+    from hamiltorch_amd import _abi
+    D, C, L = 24, 40, 2
+    t, _ = cfg3_target(ht, D, torch.float32, seed=9)
+    th0 = tt((0.3 * O.philox_normals(3, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32), torch.float32)
+    outs = []
+    for mode in (1, 0):
+        _abi.set_tuning("rmhmc_overlap", mode)
+        try:
+            res = []
+            for rep in range(2):
+                cur = th0.clone(); rej = torch.zeros(C, dtype=torch.int32, device=dev())
+                samples = torch.zeros(T + 1, C, D, device=dev())
+                ws = torch.empty(_abi.rmhmc_workspace_bytes(C, D, 4, T), dtype=torch.uint8, device=dev())
+                _abi.rmhmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, _abi.METRIC_SOFTABS, 1e6, 1e-3, L, 0.1, 10.0,
+                                           T, 0, -1, 21 + rep, 0, samples, rej, ws)
+                res.append((samples.sum(dim=0).cpu().numpy(), samples.cpu().numpy(), rej.cpu().numpy()))   # no explicit sync
+        finally:
+            _abi.set_tuning("rmhmc_overlap", 1)
+        outs.append(res)
+    for a_, b_ in zip(outs[0], outs[1]):
+        for x, y in zip(a_, b_):
+            assert np.array_equal(x, y)
+    assert not np.array_equal(outs[0][0][1], outs[0][1][1])
