@@ -133,6 +133,10 @@ int hta_mh_select_at_f64(double* theta_cur, const double* theta_prop, const doub
  *               the register-resident range) all random draws of the launch are produced first by a
  *               full-chip kernel and the latency-bound trajectory kernel only loads them; results are
  *               identical to the inline-RNG path.  NULL = draw inline.
+ *               With a workspace, identity mass and D <= 6 (fp64: 4) the trajectories are integrated in the eigenbasis
+ *               of P (2 D instead of D + D*D multiply-adds per step; fp32, D <= 4 and C <= 65536: one chain per DPP
+ *               quad); the workspace then also holds the eigen block.  Same map and draws; results differ from the
+ *               direct form by rounding only (hta_set_tuning("gauss_eig", 0) selects the direct form).
  * ------------------------------------------------------------------------------------------- */
 int hta_hmc_gaussian_sample_f32(float* theta, const float* theta_init, const float* P, const float* mu,
                                 float log_norm, int mass_kind, const float* inv_mass,
@@ -229,7 +233,9 @@ int hta_rmhmc_gaussian_leapfrog_f64(double* theta, double* p, double* theta_copy
  * launch of `n_traj` trajectories; arguments as hta_hmc_gaussian_sample.  workspace:
  * hta_rmhmc_workspace_bytes(C, D, sizeof(T)) bytes at least (required).  Every further C*D*sizeof(T) bytes let the
  * fused path (soft-abs map == identity on the target's spectrum, csrc/rmhmc_fused.hip) draw the momenta of one more
- * trajectory per pass ahead of the chains (full-chip Cholesky batch); with the minimum it works in passes of 4. */
+ * trajectory per pass ahead of the chains (full-chip Cholesky batch); with the minimum it works in passes of 4.  With
+ * room for >= 16 trajectories the draws of the next block run on an internal side stream (forked from and joined back into
+ * `stream` inside the call) under the trajectories of the current one. */
 int64_t hta_rmhmc_workspace_bytes(int64_t C, int D, int elem_size);
 int hta_rmhmc_gaussian_sample_f32(float* theta, const float* theta_init, const float* P, const float* mu,
                                   double log_norm, int metric, double alpha, int has_jitter, double jitter,
@@ -282,7 +288,11 @@ int hta_mlp_logp_grad_f64(const double* theta, int64_t C, int n_in, int H, int a
 
 /* measurement knobs: "small_chains_per_block" (launch shape of the thread-per-chain kernel),
  * "force_general" (route small D through the wave-per-chain kernel), "profile" (1 = record a HIP
- * event pair around the dominant kernel of every fused call, on the launch stream). */
+ * event pair around the dominant kernel of every fused call, on the launch stream);
+ * route selectors kept for the parity tests: "gauss_eig" (1 default; 0 = direct small-D Gaussian kernel, 2 = eigenbasis with
+ * one chain per lane only, 3 = quad kernel without the compiled-in step counts), "quad_max_chains" (65536), "rmhmc_fused"
+ * (1 default; 0 = per-evaluation Jacobi path, 3 = two chains per workgroup), "rmhmc_overlap" (1 default; 0 = momentum draws
+ * on the caller's stream), "mlp_valu" (1 = VALU MLP kernel instead of the MFMA one). */
 int hta_set_tuning(const char* key, int value);
 /* waits for the recorded event pairs; returns their summed elapsed time and count, then resets. */
 int hta_profile_collect(double* total_ms, int* launches);
