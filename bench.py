@@ -46,6 +46,25 @@ def parse():
 # ---------------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------------
+def _usable_cores():
+    """(logical CPUs visible, CPUs this process may actually keep busy: affinity mask and cgroup CPU quota)."""
+    avail = os.cpu_count() or 1
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else avail
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())          # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return avail, n
+
+
 class Cfg2:
     """BASELINE config 2: 3-D correlated Gaussian, HMC, 1024 chains, L=25, eps=0.3, 1000 trajectories."""
     name = "cfg2: 3-D correlated Gaussian HMC, L=25, eps=0.3, identity mass"
@@ -89,25 +108,33 @@ class Cfg2:
         return 1.0 - float(self.rej.double().mean()) / (self.T * max(1, self._steps_done))
 
     def cpu_baseline(self, seconds):
-        """The reference's CPU cost structure on this host: one chain, autograd callback, torch CPU RNG."""
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import torch_port as TP
-        torch.set_num_threads(1)
-        cov = torch.tensor(SIGMA3)
-
-        def lp(w):
-            return torch.distributions.MultivariateNormal(torch.zeros(3), cov).log_prob(w).sum()
-        init = torch.zeros(3)
-        torch.manual_seed(0)
-        t0 = time.time(); TP.port_sample(lp, init, 20, self.L, self.eps); dt = time.time() - t0
-        n = max(40, int(seconds / (dt / 20)))
-        t0 = time.time(); ret, acc = TP.port_sample(lp, init, n, self.L, self.eps, burn=-1); dt = time.time() - t0
+        """The reference's CPU cost structure on this host: one single-threaded chain per process (autograd
+        callback, torch CPU RNG), one process per usable host core (affinity mask / cgroup CPU quota; HTA_BENCH_CPU_PROCS
+        caps it); rate = all leapfrog steps / the slowest process's sampling time."""
+        import subprocess
+        avail, procs = _usable_cores()
+        procs = max(1, min(procs, int(os.environ.get("HTA_BENCH_CPU_PROCS", "64"))))
+        env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        t0 = time.time()
+        ps = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "torch_port.py"), "cfg2", str(1000 + i),
+                                str(self.L), repr(self.eps), repr(float(seconds))], stdout=subprocess.PIPE,
+                               stderr=subprocess.DEVNULL, env=env, text=True) for i in range(procs)]
+        res = []
+        for p_ in ps:
+            out_, _ = p_.communicate(timeout=60 + 20 * seconds)
+            r = json.loads(out_.strip().splitlines()[-1])
+            res.append((r["n"], r["L"], r["dt"], r["acc"], r["samples"]))
+        wall = time.time() - t0
+        steps = sum(n * L for n, L, _, _, _ in res)
+        dt = max(r[2] for r in res)
         from hamiltorch_amd.ess import ess_min
-        ess = ess_min(torch.stack(ret[1:]).unsqueeze(1))
-        return {"value": n * self.L / dt, "unit": "leapfrog-steps/s", "cores": 1, "kind": "port",
-                "sample": "1 chain x %d trajectories x L=%d (oracle/torch_port.py: per-step autograd on a "
-                          "MultivariateNormal.log_prob callback, as the reference), %.1f s" % (n, self.L, dt),
-                "ess_per_sec": ess / dt, "acceptance": acc}
+        ess = sum(ess_min(torch.tensor(r[4]).unsqueeze(1)) for r in res)
+        return {"value": steps / dt, "unit": "leapfrog-steps/s", "cores": procs, "kind": "port",
+                "sample": "%d processes x 1 chain x ~%d trajectories x L=%d, one thread each (oracle/torch_port.py: per-step "
+                          "autograd on a MultivariateNormal.log_prob callback, as the reference), %.1f s sampling, %.1f s with "
+                          "process start-up" % (procs, res[0][0], self.L, dt, wall),
+                "per_core": steps / dt / procs, "ess_per_sec": ess / dt,
+                "acceptance": sum(r[3] for r in res) / procs, "host_cores_available": avail, "host_cores_usable": procs}
 
 
 class Cfg3:
@@ -367,8 +394,9 @@ def main():
             cb = w.cpu_baseline(a.cpu_seconds)
             if cb is not None:
                 out["cpu_baseline"] = cb
-                out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
-                out["speedup_vs_cpu_baseline_1core"] = value / cb["value"]
+                out["cpu_baseline"].setdefault("host_cores_available", os.cpu_count())
+                out["speedup_vs_cpu_baseline"] = value / cb["value"]          # against the `cores` the baseline used
+                out["speedup_vs_cpu_baseline_1core"] = value / (cb["value"] / max(1, cb.get("cores", 1)))
         print(json.dumps(out), flush=True)
         if a.sweep and a.workload == "cfg2":
             for C in (1024, 4096, 16384, 65536, 262144, 1048576):

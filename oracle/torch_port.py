@@ -263,3 +263,31 @@ def port_sample_split(closures, params_init, num_samples, num_steps_per_sample, 
             else:
                 params = burn_prev.clone()
     return ret, 1 - rejected / num_samples
+
+
+# ---- bench.py cpu_baseline, config 2: one chain per process on the host cores ------------------------------
+def cfg2_worker(args):
+    """One single-threaded chain of the config-2 target for about `seconds` of wall clock.
+    Returns (trajectories, L, sampling seconds, acceptance, samples[n,3] as a nested list)."""
+    import time
+    seed, L, eps, seconds, sigma = args
+    torch.set_num_threads(1)
+    cov = torch.tensor(sigma)
+
+    def lp(w):
+        return torch.distributions.MultivariateNormal(torch.zeros(3), cov).log_prob(w).sum()
+    init = torch.zeros(3)
+    torch.manual_seed(seed)
+    t0 = time.time(); port_sample(lp, init, 20, L, eps); dt = time.time() - t0
+    n = max(40, int(seconds / (dt / 20)))
+    t0 = time.time(); ret, acc = port_sample(lp, init, n, L, eps, burn=-1); dt = time.time() - t0
+    return n, L, dt, acc, torch.stack(ret[1:]).tolist()
+
+
+if __name__ == "__main__":          # python oracle/torch_port.py cfg2 <seed> <L> <eps> <seconds>  -> one JSON line
+    import json
+    import sys
+    assert sys.argv[1] == "cfg2"
+    sigma = [[1.0, 0.6, 0.2], [0.6, 2.0, 0.5], [0.2, 0.5, 0.5]]
+    n, L, dt, acc, samples = cfg2_worker((int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), float(sys.argv[5]), sigma))
+    print(json.dumps({"n": n, "L": L, "dt": dt, "acc": acc, "samples": samples}))
