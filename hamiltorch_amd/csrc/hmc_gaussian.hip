@@ -641,6 +641,7 @@ __global__ __launch_bounds__(256) void hmc_gauss_eig_kernel(GaussArgs<T> a, cons
 // dispatcher takes this kernel while the chip has idle SIMDs for the extra waves (C <= g_quad_max_chains) and the
 // chain-per-lane kernel beyond, where instruction count per chain decides.
 // =============================================================================================
+constexpr int QUAD_SLOTS_MAX = 4;     // record look-ahead of the quad kernel = rows of slack in the workspace
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
@@ -707,10 +708,17 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
   const uint32_t uoff = (uint32_t)(((size_t)c * W + D) * sizeof(T));   // D == 4: log u sits in the second vector
   const size_t rec_step = C * W * sizeof(T);
   auto rec_at = [&](uint32_t off) { return *(const __attribute__((address_space(1))) T*)(recb + off); };
-  // records are read two trajectories ahead (a trajectory is shorter than one HBM round trip): two rows of slack
-  T z0 = rec_at(roff), lu0 = D == 4 ? rec_at(uoff) : 0.f;
-  recb += rec_step;
-  T z1 = rec_at(roff), lu1 = D == 4 ? rec_at(uoff) : 0.f;
+  // Records are read NS trajectories ahead: a trajectory (~90 ns at L = 5, ~180 ns at L = 25) is shorter than the ~250 ns
+  // an HBM load takes to return, and the look-ahead has to cover it.  The workspace carries QUAD_SLOTS_MAX rows of slack.
+  constexpr int NS = LB == 5 ? 4 : (LB == 10 ? 3 : 2);
+  static_assert(NS <= QUAD_SLOTS_MAX, "workspace slack");
+  T zs[NS], lus[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    if (i) recb += rec_step;
+    zs[i] = rec_at(roff);
+    lus[i] = D == 4 ? rec_at(uoff) : 0.f;
+  }
   // Every lane stores once per trajectory, unconditionally (uniform vmcnt, see hmc_gauss_small_kernel).
   const uint32_t qoff = (uint32_t)(((size_t)c * D + kk) * sizeof(T));
   typedef __attribute__((address_space(1))) char* gwbytes_t;
@@ -819,17 +827,21 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
       ++t;
     };
     std::false_type plain;
+    auto rotate = [&]() {                       // slot 0 was consumed and refilled with the newest row: it becomes the last
+      const T z = zs[0], u = lus[0];
+#pragma unroll
+      for (int i = 0; i + 1 < NS; ++i) { zs[i] = zs[i + 1]; lus[i] = lus[i + 1]; }
+      zs[NS - 1] = z; lus[NS - 1] = u;
+    };
     if (phase == 1 && t < t_end && a.traj_offset + t == a.burn + 1) {              // the Q2 trajectory opens the stored phase
-      trajectory(z0, lu0, std::true_type{});
-      T tmp = z0; z0 = z1; z1 = tmp;
-      tmp = lu0; lu0 = lu1; lu1 = tmp;
+      trajectory(zs[0], lus[0], std::true_type{});
+      rotate();
     }
-    while (t + 1 < t_end) { trajectory(z0, lu0, plain); trajectory(z1, lu1, plain); }
-    if (t < t_end) {
-      trajectory(z0, lu0, plain);
-      T tmp = z0; z0 = z1; z1 = tmp;
-      tmp = lu0; lu0 = lu1; lu1 = tmp;
+    while (t + NS - 1 < t_end) {                // unrolled over the slots: no register rotation on the hot path
+#pragma unroll
+      for (int i = 0; i < NS; ++i) trajectory(zs[i], lus[i], plain);
     }
+    while (t < t_end) { trajectory(zs[0], lus[0], plain); rotate(); }
   }
   put((gwbytes_t)a.theta, to_q(yc));
   if (a.reject_count && k == 0) a.reject_count[c] += a.n_traj - accepted;
@@ -1192,8 +1204,8 @@ extern "C" {
 int64_t hta_hmc_gaussian_workspace_bytes(int64_t C, int D, int n_traj, int elem_size) {
   const int per_vec = 16 / elem_size;
   const int64_t rec = ((int64_t)(D + 1 + per_vec - 1) / per_vec) * per_vec;
-  /* + two rows read ahead by the last trajectories, + the eigen block (lam[D], Q[D][D]; D <= 6) of the eigenbasis route */
-  return ((int64_t)n_traj + 2) * C * rec * elem_size + (D <= 6 ? 64 * elem_size : 0);
+  /* + four rows read ahead by the last trajectories, + the eigen block (lam[D], Q[D][D]; D <= 6) of the eigenbasis route */
+  return ((int64_t)n_traj + 4) * C * rec * elem_size + (D <= 6 ? 64 * elem_size : 0);
 }
 
 #define HTA_DEFINE_GAUSS(SUF, T)                                                                               \
