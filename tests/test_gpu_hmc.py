@@ -524,3 +524,37 @@ def test_quad_kernel_step_count_instances_agree(ht, D, C, L):
         assert 0 < int(outs[0][1].sum()) < C * N
         # Q2: a chain rejected at n = burn+1 restarts from params_init -> its first stored row after the seed row equals th0
         assert bool((outs[0][0][1] == th0.cpu()).all(dim=1).any())
+
+
+def test_edge_sizes_against_oracle(ht):
+    """Edges of the Gaussian path: the maximum dimension (D = 1024, wave-per-chain kernel), a single chain, an empty launch
+    (n_traj = 0 leaves everything untouched) and a chain count beyond the quad kernel's range (one chain per lane,
+    eigenbasis) -- each against the oracle on the same Philox draws."""
+    from hamiltorch_amd import _abi
+    dtype = torch.float32
+    # D = 1024, 3 chains
+    D, C, N, L, eps, seed = 1024, 3, 4, 3, 0.02, 11
+    P = rand_spd(D, 2)
+    t, o = targets(ht, P, dtype)
+    th0 = (0.1 * O.philox_normals(seed, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32)
+    out = ht.sample(t, tt(th0, dtype), num_samples=N, num_steps_per_sample=L, step_size=eps, verbose=False, seed=seed)
+    ref, _ = O.sample_hmc(o, th0, N, L, eps, 0, None, O.PhiloxDraws(seed, np.arange(C)))
+    _compare_runs(out, ref, 5e-4, 0.0)
+    # one chain, 3-D (a single quad of one wave)
+    t3, o3 = targets(ht, np.linalg.inv(SIGMA3), dtype)
+    th1 = np.array([[0.3, -0.2, 0.5]], np.float32)
+    out = ht.sample(t3, tt(th1, dtype), num_samples=40, num_steps_per_sample=25, step_size=0.3, verbose=False, seed=5)
+    ref, _ = O.sample_hmc(o3, th1, 40, 25, 0.3, 0, None, O.PhiloxDraws(5, np.arange(1)))
+    _compare_runs(out, ref, 2e-4, 0.0)
+    # empty launch through the C ABI
+    cur = tt(th1, dtype).clone(); rej = torch.zeros(1, dtype=torch.int32, device=dev())
+    ws = torch.zeros(_abi.gaussian_workspace_bytes(1, 3, 0, 4), dtype=torch.uint8, device=dev())
+    _abi.hmc_gaussian_sample(cur, cur.clone(), t3.precision, t3.mean, t3.log_norm, 0, None, None, 25, 0.3, 0, 0, 0, 1, 0, None, rej,
+                             workspace=ws)
+    assert torch.equal(cur.cpu(), torch.tensor(th1)) and int(rej.item()) == 0
+    # 70000 chains: past quad_max_chains -> one chain per lane
+    C = 70000
+    th0 = (0.3 * O.philox_normals(3, np.arange(C), 0, 3, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32)
+    out = ht.sample(t3, tt(th0, dtype), num_samples=6, num_steps_per_sample=10, step_size=0.3, verbose=False, seed=3)
+    ref, _ = O.sample_hmc(o3, th0, 6, 10, 0.3, 0, None, O.PhiloxDraws(3, np.arange(C)))
+    _compare_runs(out, ref, 2e-4, 0.002)
