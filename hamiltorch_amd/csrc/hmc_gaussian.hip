@@ -49,6 +49,12 @@ namespace hta {
 // Philox/Box-Muller per trajectory leave the 16 busy SIMDs for the 1000 idle ones.  Without a
 // workspace the draws are made inline.  Same Philox stream either way.
 // =============================================================================================
+// eig block of the eigenbasis route (see eig_small_kernel): offsets of Qt, Tin, Tout behind lam[D]
+constexpr int EIG_ELEMS = 128;
+#define EIG_QT(D) (D)
+#define EIG_TIN(D) ((D) + (D) * (D))
+#define EIG_TOUT(D) ((D) + 2 * (D) * (D))
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <typename T> struct RecVec;
@@ -257,12 +263,12 @@ template <typename T, int D>
 __global__ void rng_fill_small_kernel(T* __restrict__ ws, int64_t C, int n_traj, int traj_offset, uint64_t seed,
                                       uint64_t chain_offset, const T* __restrict__ eig, T lu_scale) {
   constexpr int W = rec_elems<T, D>();
-  T Q[D][D];            // eigenbasis route: records hold Q^T z (wave-uniform operands)
+  T Q[D][D];            // eigenbasis route: records hold Q^T z (wave-uniform operands); eig block: Qt[k][i] = Q[i][k]
   if (eig) {
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
-      for (int k = 0; k < D; ++k) Q[i][k] = eig[D + i * D + k];
+      for (int k = 0; k < D; ++k) Q[i][k] = eig[EIG_QT(D) + k * D + i];
   }
   typedef typename RecVec<T>::type V;
   const int64_t total = C * n_traj;
@@ -429,19 +435,72 @@ __global__ __launch_bounds__(256) void hmc_gauss_small_kernel(GaussArgs<T> a) {
 // pre-draw pass rotates the momentum normals (r = Q^T z: the records still come from the same Philox draws),
 // energies are 0.5 sum lam_i y_i^2 + 0.5 |r|^2, and a sample row is q = mu + Q y.  Same map, same draws, same
 // accept rule as the direct kernel above; results differ from it by rounding only (tests compare both routes).
-// Layout of the eig block (T): lam[D], Q[D][D] (Q[i][k] = component i of eigenvector k).
 // =============================================================================================
+// Layout of the eig block (T, EIG_ELEMS elements): lam[D] | Qt[D][D] (rotation of the draws, r = Qt z) | Tin[D][D]
+// (y = Tin (q - mu)) | Tout[D][D] (q = mu + Tout y).
+// A mass matrix M = L L^T (diag or full; `mass_factor` is L, S:199-201) is whitened away first: with d~ = L^T d,
+// p~ = L^-1 p the leapfrog map with mass M is the identity-mass map for P~ = L^-1 P L^-T, the momentum draw p = L z
+// (S:198-201) is p~ = z and the kinetic energy is 0.5 |p~|^2.  So: P~ = Q diag(lam) Q^T, Qt = Q^T, Tin = Q^T L^T,
+// Tout = L^-T Q.  Identity mass: L = I.
+
 template <typename T, int D>
-__global__ void eig_small_kernel(const T* __restrict__ P, T* __restrict__ eig) {
+__global__ void eig_small_kernel(const T* __restrict__ P, int mass_kind, const T* __restrict__ mass_factor,
+                                 T* __restrict__ eig) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double A[D][D], V[D][D];
+  double A[D][D], V[D][D], Lm[D][D], Li[D][D];
 #pragma unroll
   for (int i = 0; i < D; ++i)
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       A[i][j] = 0.5 * ((double)P[i * D + j] + (double)P[j * D + i]);   // the precision matrix is symmetric
       V[i][j] = i == j ? 1.0 : 0.0;
+      Lm[i][j] = mass_kind == HTA_MASS_NONE ? (i == j ? 1.0 : 0.0)
+                 : mass_kind == HTA_MASS_DIAG ? (i == j ? (double)mass_factor[i] : 0.0)
+                                              : (j <= i ? (double)mass_factor[i * D + j] : 0.0);
+      Li[i][j] = 0.0;
     }
+  if (mass_kind != HTA_MASS_NONE) {
+    // Li = L^-1 (lower triangular, forward substitution), then A <- Li A Li^T
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      Li[j][j] = 1.0 / Lm[j][j];
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        if (i > j) {
+          double acc = 0;
+#pragma unroll
+          for (int k = 0; k < D; ++k) if (k >= j && k < i) acc += Lm[i][k] * Li[k][j];
+          Li[i][j] = -acc / Lm[i][i];
+        }
+      }
+    }
+    double B[D][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) acc += Li[i][k] * A[k][j];
+        B[i][j] = acc;
+      }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) acc += B[i][k] * Li[j][k];
+        A[i][j] = acc;
+      }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) if (i < j) { const double m = 0.5 * (A[i][j] + A[j][i]); A[i][j] = A[j][i] = m; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < D; ++i) Li[i][i] = 1.0;
+  }
   for (int sweep = 0; sweep < 12; ++sweep) {
     double off = 0, dia = 0;
 #pragma unroll
@@ -478,10 +537,17 @@ __global__ void eig_small_kernel(const T* __restrict__ P, T* __restrict__ eig) {
     }
   }
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
-    eig[i] = (T)A[i][i];
+  for (int k = 0; k < D; ++k) {
+    eig[k] = (T)A[k][k];
 #pragma unroll
-    for (int k = 0; k < D; ++k) eig[D + i * D + k] = (T)V[i][k];
+    for (int i = 0; i < D; ++i) {
+      eig[EIG_QT(D) + k * D + i] = (T)V[i][k];
+      double tin = 0, tout = 0;                 // Tin[k][i] = sum_j Q[j][k] L[i][j];  Tout[k][i] = sum_j Li[j][k] Q[j][i]
+#pragma unroll
+      for (int j = 0; j < D; ++j) { tin += V[j][k] * Lm[i][j]; tout += Li[j][k] * V[j][i]; }
+      eig[EIG_TIN(D) + k * D + i] = (T)tin;
+      eig[EIG_TOUT(D) + k * D + i] = (T)tout;
+    }
   }
 }
 
@@ -491,12 +557,12 @@ __global__ __launch_bounds__(256) void hmc_gauss_eig_kernel(GaussArgs<T> a, cons
   if (c >= a.C) return;
   constexpr int NP = D / 2;
   constexpr bool R = (D & 1) != 0;
-  T lam[D], Q[D][D], mu[D];
+  T lam[D], Tin[D][D], Tout[D][D], mu[D];
 #pragma unroll
   for (int i = 0; i < D; ++i) {
     lam[i] = eig[i]; mu[i] = a.mu[i];
 #pragma unroll
-    for (int k = 0; k < D; ++k) Q[i][k] = eig[D + i * D + k];
+    for (int k = 0; k < D; ++k) { Tin[i][k] = eig[EIG_TIN(D) + i * D + k]; Tout[i][k] = eig[EIG_TOUT(D) + i * D + k]; }
   }
   const T eps = a.eps, he = (T)0.5 * a.eps;
   T nel[D], hl[D], hlam[D];                      // -eps lam, eps/2 lam, lam/2
@@ -509,9 +575,9 @@ __global__ __launch_bounds__(256) void hmc_gauss_eig_kernel(GaussArgs<T> a, cons
     for (int i = 0; i < D; ++i) d[i] = q[i] - mu[i];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-      T acc = Q[0][k] * d[0];
+      T acc = Tin[k][0] * d[0];
 #pragma unroll
-      for (int i = 1; i < D; ++i) acc = fma(Q[i][k], d[i], acc);
+      for (int i = 1; i < D; ++i) acc = fma(Tin[k][i], d[i], acc);
       y[k] = acc;
     }
   };
@@ -540,7 +606,7 @@ __global__ __launch_bounds__(256) void hmc_gauss_eig_kernel(GaussArgs<T> a, cons
     for (int i = 0; i < D; ++i) {
       T acc_ = mu[i];
 #pragma unroll
-      for (int k = 0; k < D; ++k) acc_ = fma(Q[i][k], yc[k], acc_);
+      for (int k = 0; k < D; ++k) acc_ = fma(Tout[i][k], yc[k], acc_);
       dst[i] = acc_;
     }
   };
@@ -668,8 +734,8 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
   T Qrow[D], Qcol[D];                           // Q[k][j] and Q[j][k]
 #pragma unroll
   for (int j = 0; j < D; ++j) {
-    Qrow[j] = eig[D + kk * D + j];
-    Qcol[j] = live ? eig[D + j * D + kk] : 0.f;
+    Qrow[j] = eig[EIG_TOUT(D) + kk * D + j];                  // q_k = mu_k + sum_j Tout[k][j] y_j
+    Qcol[j] = live ? eig[EIG_TIN(D) + kk * D + j] : 0.f;     // y_k = sum_i Tin[k][i] (q_i - mu_i)
   }
   // a dummy lane integrates nothing: eps = lam = 0, so its y stays 0, its r stays whatever its record slot held (log u or
   // padding) and its energy difference is exactly 0
@@ -1087,7 +1153,7 @@ template <typename T, int D, int MASS> void launch_small(const GaussArgs<T>& a, 
   const int grid = (int)((a.C + block - 1) / block);
   if (lf_only) { leapfrog_gauss_small_kernel<T, D, MASS><<<grid, block, 0, s>>>(a); return; }
   const bool diag = a.H_old || a.H_new || a.accept;
-  if (MASS == HTA_MASS_NONE && a.ws_z && a.ws_logu) {      // eigenbasis route (a.ws_logu = the eig block)
+  if (a.ws_z && a.ws_logu) {      // eigenbasis route, any mass kind (whitened; a.ws_logu = the eig block)
     if constexpr (sizeof(T) == 4 && D <= 4) {
       if (quad_route(a)) {   // latency regime: a quad per chain (32-bit lane offsets)
         const int qgrid = (int)((a.C * 4 + 63) / 64);
@@ -1138,22 +1204,22 @@ template <typename T, int R> void launch_wave_m(const GaussArgs<T>& a, int kind,
 }
 
 // pre-draw pass: all momenta / log-uniforms of the launch, one thread per (trajectory, chain)
-template <typename T, int D> static void launch_rng_fill_d(const GaussArgs<T>& a, hipStream_t s) {
+template <typename T, int D> static void launch_rng_fill_d(const GaussArgs<T>& a, int mass_kind, hipStream_t s) {
   const int64_t total = a.C * a.n_traj;
   int64_t g = (total + 255) / 256;
   if (g > 256 * 16) g = 256 * 16;
-  if (a.ws_logu) eig_small_kernel<T, D><<<1, 64, 0, s>>>(a.P, a.ws_logu);
+  if (a.ws_logu) eig_small_kernel<T, D><<<1, 64, 0, s>>>(a.P, mass_kind, a.mass_factor, a.ws_logu);
   rng_fill_small_kernel<T, D><<<(int)g, 256, 0, s>>>(a.ws_z, a.C, a.n_traj, a.traj_offset, a.seed, a.chain_offset,
                                                      a.ws_logu, quad_route(a) ? (T)2 : (T)1);
 }
-template <typename T> static void launch_rng_fill(const GaussArgs<T>& a, hipStream_t s) {
+template <typename T> static void launch_rng_fill(const GaussArgs<T>& a, int mass_kind, hipStream_t s) {
   switch (a.D) {
-    case 1: launch_rng_fill_d<T, 1>(a, s); break;
-    case 2: launch_rng_fill_d<T, 2>(a, s); break;
-    case 3: launch_rng_fill_d<T, 3>(a, s); break;
-    case 4: launch_rng_fill_d<T, 4>(a, s); break;
-    case 5: launch_rng_fill_d<T, 5>(a, s); break;
-    default: launch_rng_fill_d<T, 6>(a, s); break;
+    case 1: launch_rng_fill_d<T, 1>(a, mass_kind, s); break;
+    case 2: launch_rng_fill_d<T, 2>(a, mass_kind, s); break;
+    case 3: launch_rng_fill_d<T, 3>(a, mass_kind, s); break;
+    case 4: launch_rng_fill_d<T, 4>(a, mass_kind, s); break;
+    case 5: launch_rng_fill_d<T, 5>(a, mass_kind, s); break;
+    default: launch_rng_fill_d<T, 6>(a, mass_kind, s); break;
   }
 }
 
@@ -1173,8 +1239,8 @@ template <typename T> int gaussian_dispatch(const GaussArgs<T>& a_in, int kind, 
   // f64 models past D=4 overflow the SGPR file (P alone is 2*D*D SGPRs) and would spill to scratch
   const int small_max = sizeof(T) == 8 ? 4 : 6;  // 2*D*D + 3*D wave-uniform operands must fit the SGPR file
   const bool reg_resident = D <= small_max && !g_force_general;
-  if (!(kind == HTA_MASS_NONE && g_gauss_eig)) a.ws_logu = nullptr;   // eigenbasis route: identity mass only
-  if (a.ws_z && reg_resident && !lf_only) launch_rng_fill<T>(a, s);
+  if (!g_gauss_eig) a.ws_logu = nullptr;       // direct kernels on request
+  if (a.ws_z && reg_resident && !lf_only) launch_rng_fill<T>(a, kind, s);
   else { a.ws_z = nullptr; a.ws_logu = nullptr; }
   if (reg_resident) {
     switch (D) {
@@ -1204,8 +1270,8 @@ extern "C" {
 int64_t hta_hmc_gaussian_workspace_bytes(int64_t C, int D, int n_traj, int elem_size) {
   const int per_vec = 16 / elem_size;
   const int64_t rec = ((int64_t)(D + 1 + per_vec - 1) / per_vec) * per_vec;
-  /* + four rows read ahead by the last trajectories, + the eigen block (lam[D], Q[D][D]; D <= 6) of the eigenbasis route */
-  return ((int64_t)n_traj + 4) * C * rec * elem_size + (D <= 6 ? 64 * elem_size : 0);
+  /* + four rows read ahead by the last trajectories, + the eigen block (lam, Qt, Tin, Tout; D <= 6) of the eigenbasis route */
+  return ((int64_t)n_traj + 4) * C * rec * elem_size + (D <= 6 ? 128 * elem_size : 0);
 }
 
 #define HTA_DEFINE_GAUSS(SUF, T)                                                                               \
@@ -1221,7 +1287,7 @@ int64_t hta_hmc_gaussian_workspace_bytes(int64_t C, int D, int n_traj, int elem_
     const int64_t need = hta_hmc_gaussian_workspace_bytes(C, D, n_traj, (int)sizeof(T));                       \
     if (workspace && workspace_bytes >= need && need > 0) {                                                     \
       a.ws_z = (T*)workspace;                                                                                   \
-      a.ws_logu = D <= 6 ? (T*)((char*)workspace + need) - 64 : nullptr;   /* eig block */                      \
+      a.ws_logu = D <= 6 ? (T*)((char*)workspace + need) - 128 : nullptr;  /* eig block */                      \
     }                                                                                                           \
     return hta::gaussian_dispatch<T>(a, mass_kind, false, (hipStream_t)stream);                                 \
   }                                                                                                             \

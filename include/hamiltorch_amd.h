@@ -133,10 +133,11 @@ int hta_mh_select_at_f64(double* theta_cur, const double* theta_prop, const doub
  *               the register-resident range) all random draws of the launch are produced first by a
  *               full-chip kernel and the latency-bound trajectory kernel only loads them; results are
  *               identical to the inline-RNG path.  NULL = draw inline.
- *               With a workspace, identity mass and D <= 6 (fp64: 4) the trajectories are integrated in the eigenbasis
- *               of P (2 D instead of D + D*D multiply-adds per step; fp32, D <= 4 and C <= 65536: one chain per DPP
- *               quad); the workspace then also holds the eigen block.  Same map and draws; results differ from the
- *               direct form by rounding only (hta_set_tuning("gauss_eig", 0) selects the direct form).
+ *               With a workspace and D <= 6 (fp64: 4) the trajectories are integrated in the eigenbasis of the
+ *               mass-whitened precision matrix L^-1 P L^-T, M = L L^T (2 D instead of D + D*D multiply-adds per step;
+ *               fp32, D <= 4 and C <= 65536: one chain per DPP quad); the workspace then also holds the eigen block.
+ *               Same map and draws; results differ from the direct form by rounding only
+ *               (hta_set_tuning("gauss_eig", 0) selects the direct form).
  * ------------------------------------------------------------------------------------------- */
 int hta_hmc_gaussian_sample_f32(float* theta, const float* theta_init, const float* P, const float* mu,
                                 float log_norm, int mass_kind, const float* inv_mass,

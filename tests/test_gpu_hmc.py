@@ -458,11 +458,13 @@ def test_block_list_inv_mass_vs_oracle_and_reference_fixture(ht, route):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.float64, 1e-11)])
+@pytest.mark.parametrize("mass", ["none", "diag", "full"])
 @pytest.mark.parametrize("D", [1, 2, 3, 4, 5, 6])
-def test_eigenbasis_route_equals_direct_route(ht, dtype, tol, D):
-    """Identity-mass small-D Gaussian HMC integrates in the eigenbasis of P (2 D FMAs per step); hta_set_tuning('gauss_eig', 0)
-    selects the direct kernel (D + D^2 FMAs per step).  Same draws, same map: samples agree to rounding, chain by chain, also
-    with a mean offset, burn-in (Q2 reset) and nearly degenerate / widely spread spectra."""
+def test_eigenbasis_route_equals_direct_route(ht, dtype, tol, D, mass):
+    """Small-D Gaussian HMC integrates in the eigenbasis of the (mass-whitened) precision matrix (2 D FMAs per step);
+    hta_set_tuning('gauss_eig', 0) selects the direct kernel (D + D^2 FMAs per step, more with a mass matrix).  Same draws,
+    same map: samples agree to rounding, chain by chain, for identity / diagonal / full mass, with a mean offset, burn-in
+    (Q2 reset) and nearly degenerate / widely spread spectra."""
     from hamiltorch_amd import _abi
     if dtype == torch.float64 and D > 4:
         pytest.skip("fp64 register-resident kernels stop at D=4")
@@ -479,7 +481,7 @@ def test_eigenbasis_route_equals_direct_route(ht, dtype, tol, D):
         _abi.set_tuning("gauss_eig", mode)
         try:
             out, acc = ht.sample(t, th0, num_samples=N, num_steps_per_sample=L, step_size=eps, burn=3, debug=2, verbose=False,
-                                 seed=seed)
+                                 seed=seed, inv_mass=tt(masses(D, dtype)[mass], dtype))
         finally:
             _abi.set_tuning("gauss_eig", 1)
         outs.append((torch.stack(out).cpu().numpy(), acc.cpu().numpy()))
