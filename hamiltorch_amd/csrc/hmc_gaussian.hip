@@ -13,10 +13,12 @@
 //   general (D <= 1024): one chain per 64-lane wave, lane l owns elements l, l+64, ...;
 //                      P streamed row-by-row (coalesced, L1/L2 resident), the offset vector
 //                      broadcast through LDS, energies by wave butterfly reduction.
+#include <cstring>
 #include <type_traits>
 #include "common.hpp"
 #include "philox.hpp"
 #include "hmc_gaussian.hpp"
+#include "rmhmc.hpp"
 
 namespace hta {
 
@@ -1107,6 +1109,137 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void hmc_gauss_wave_kernel(GaussArg
   }
 }
 
+
+// =============================================================================================
+// general D, identity mass: the wave-per-chain kernel in the eigenbasis of P
+//
+// Same change of variables as the small-D route: y = Q^T (q - mu), r = Q^T p decouple the leapfrog map by coordinate, so a
+// step is two multiply-adds per element and no matrix-vector product at all (the direct kernel streams P once per step).
+// What is left per trajectory are two products with the D x D eigenvector matrix: the rotation of the momentum draw
+// (r = Q^T z: the same Philox normals as the direct kernel) and the sample row q = mu + Q y.  P is diagonalised once per
+// launch by the Jacobi kernel of the RMHMC path (csrc/rmhmc_metric.hip: one workgroup, A and V in LDS; D <= ~140 fp32 /
+// ~99 fp64), then transposed once.  Eig area (workspace): V[D][D] (V[i][k] = component i of eigenvector k) | Vt[D][D] | lam[D].
+// =============================================================================================
+template <typename T>
+__global__ void transpose_kernel(const T* __restrict__ V, T* __restrict__ Vt, int D) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < D * D; e += gridDim.x * blockDim.x) {
+    const int i = e / D, k = e - i * D;
+    Vt[k * D + i] = V[e];
+  }
+}
+
+template <typename T, int R>
+__global__ __launch_bounds__(64 * GEN_WAVES) void hmc_gauss_wave_eig_kernel(GaussArgs<T> a, const T* __restrict__ eig) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* lds = reinterpret_cast<T*>(smem_raw) + wave * 64 * R;
+  const int64_t cc = (int64_t)blockIdx.x * GEN_WAVES + wave;
+  const bool live = cc < a.C;
+  const int64_t c = live ? cc : a.C - 1;  // dead waves shadow the last chain (barriers stay matched), no stores
+  WaveModel<T, R, HTA_MASS_NONE> m;
+  m.init(a, lds, lane);
+  const int D = a.D;
+  const T* V = eig;                       // matvec(V, x) = V^T x  (it reads A[k][j])
+  const T* Vt = eig + (int64_t)D * D;     // matvec(Vt, x) = V x
+  const T* lamp = Vt + (int64_t)D * D;
+  const T eps = a.eps, he = (T)0.5 * a.eps;
+  T lam[R], nel[R], hl[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int j = lane + 64 * r;
+    lam[r] = j < D ? lamp[j] : (T)0;
+    nel[r] = -(eps * lam[r]); hl[r] = he * lam[r];
+  }
+  auto to_y = [&](const T* __restrict__ q, T (&y)[R]) {        // every wave of the workgroup must call this together
+    T d[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) d[r] = (lane + 64 * r < D) ? q[c * D + lane + 64 * r] - m.muv[r] : (T)0;
+    m.matvec(V, d, y, lane, false);
+  };
+  auto to_q = [&](const T (&y)[R], T (&q)[R]) {                // likewise
+    m.matvec(Vt, y, q, lane, false);
+#pragma unroll
+    for (int r = 0; r < R; ++r) q[r] += m.muv[r];
+  };
+  auto potential = [&](const T (&y)[R]) {
+    T s = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) s = fma(lam[r] * y[r], y[r], s);
+    return (T)0.5 * wave_sum(s);
+  };
+  auto kinetic = [&](const T (&p)[R]) {
+    T s = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) s = fma(p[r], p[r], s);
+    return (T)0.5 * wave_sum(s);
+  };
+  T yc[R];
+  to_y(a.theta, yc);
+  T quadc = potential(yc);
+  const uint64_t chain = a.chain_offset + (uint64_t)c;
+  int32_t rejected = 0;
+
+  for (int t = 0; t < a.n_traj; ++t) {
+    const int n = a.traj_offset + t;
+    T z[R], p[R], y[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int j = lane + 64 * r;
+      z[r] = j < D ? normal_elem<T>(a.seed, chain, (uint32_t)n, 0, j) : (T)0;      // S:185-186
+    }
+    m.matvec(V, z, p, lane, false);                                                  // r = Q^T z
+    const T h_old = -(a.log_norm - quadc) + kinetic(p);                              // S:971
+#pragma unroll
+    for (int r = 0; r < R; ++r) { y[r] = yc[r]; p[r] = fma(-hl[r], yc[r], p[r]); }  // S:281
+    for (int l = 0; l < a.L; ++l) {                                                  // S:283-298
+#pragma unroll
+      for (int r = 0; r < R; ++r) { y[r] = fma(eps, p[r], y[r]); p[r] = fma(nel[r], y[r], p[r]); }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) p[r] = fma(hl[r], y[r], p[r]);                      // S:302
+    const T quad1 = potential(y);
+    const T logp1 = a.log_norm - quad1;
+    const T h_new = -logp1 + kinetic(p);                                             // S:995
+    const T u = u23<T>(philox_block(a.seed, chain, (uint32_t)n, PURPOSE_MH, 0, 0).x);
+    const bool acc = mh_accept<T>(h_old, h_new, logp1, u);                           // S:1000-1004
+    T yinit[R];
+    if (n == a.burn + 1) to_y(a.theta_init, yinit);          // workgroup-uniform: the Q2 candidate of every chain
+    if (acc) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) yc[r] = y[r];
+      quadc = quad1;
+    } else {
+      ++rejected;
+      if (n == a.burn + 1) {                                  // Q2 reset (S:1016-1018)
+#pragma unroll
+        for (int r = 0; r < R; ++r) yc[r] = yinit[r];
+        quadc = potential(yc);
+      }
+    }
+    if (a.samples && n > a.burn) {                            // workgroup-uniform
+      T q[R];
+      to_q(yc, q);
+      if (live) {
+        T* row = a.samples + ((int64_t)(n - a.burn) * a.C + c) * D;
+#pragma unroll
+        for (int r = 0; r < R; ++r) if (lane + 64 * r < D) row[lane + 64 * r] = q[r];
+      }
+    }
+    if (live && lane == 0) {
+      if (a.H_old) a.H_old[(int64_t)t * a.C + c] = h_old;
+      if (a.H_new) a.H_new[(int64_t)t * a.C + c] = h_new;
+      if (a.accept) a.accept[(int64_t)t * a.C + c] = acc ? 1 : 0;
+    }
+  }
+  T q[R];
+  to_q(yc, q);
+  if (live) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) if (lane + 64 * r < D) a.theta[c * D + lane + 64 * r] = q[r];
+    if (lane == 0 && a.reject_count) a.reject_count[c] += rejected;
+  }
+}
+
 template <typename T, int R, int MASS>
 __global__ __launch_bounds__(64 * GEN_WAVES) void leapfrog_gauss_wave_kernel(GaussArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1197,6 +1330,27 @@ template <typename T, int R, int MASS> void launch_wave(const GaussArgs<T>& a, b
   hmc_gauss_wave_kernel<T, R, MASS><<<grid, 64 * GEN_WAVES, lds, s>>>(a);
   profile_end(s);
 }
+// eigenbasis route of the wave kernel: identity mass, an eig area in the workspace, D within the Jacobi kernel's reach
+template <typename T> static bool wave_eig_route(const GaussArgs<T>& a, int kind, bool lf_only) {
+  return !lf_only && kind == HTA_MASS_NONE && g_gauss_eig && a.ws_logu && a.D <= (sizeof(T) == 4 ? 128 : 96);
+}
+template <typename T, int R> int launch_wave_eig(const GaussArgs<T>& a, hipStream_t s) {
+  const int D = a.D;
+  T* V = a.ws_logu; T* Vt = V + (int64_t)D * D; T* lam = Vt + (int64_t)D * D;
+  MetricArgsT<T> m0;
+  memset(&m0, 0, sizeof(m0));
+  m0.B = 1; m0.D = D; m0.metric = HTA_METRIC_SOFTABS; m0.Hs = a.P; m0.hs_stride = 0; m0.alpha = 1.0;
+  m0.V_out = V; m0.lamraw_out = lam;
+  const int rc = metric_eval<T>(m0, s);
+  if (rc) return rc;
+  transpose_kernel<T><<<(D * D + 255) / 256, 256, 0, s>>>(V, Vt, D);
+  const int grid = (int)((a.C + GEN_WAVES - 1) / GEN_WAVES);
+  const size_t lds = (size_t)GEN_WAVES * 64 * R * sizeof(T);
+  profile_begin(s);
+  hmc_gauss_wave_eig_kernel<T, R><<<grid, 64 * GEN_WAVES, lds, s>>>(a, V);
+  profile_end(s);
+  return HTA_OK;
+}
 template <typename T, int R> void launch_wave_m(const GaussArgs<T>& a, int kind, bool lf, hipStream_t s) {
   if (kind == HTA_MASS_NONE) launch_wave<T, R, HTA_MASS_NONE>(a, lf, s);
   else if (kind == HTA_MASS_DIAG) launch_wave<T, R, HTA_MASS_DIAG>(a, lf, s);
@@ -1241,7 +1395,7 @@ template <typename T> int gaussian_dispatch(const GaussArgs<T>& a_in, int kind, 
   const bool reg_resident = D <= small_max && !g_force_general;
   if (!g_gauss_eig) a.ws_logu = nullptr;       // direct kernels on request
   if (a.ws_z && reg_resident && !lf_only) launch_rng_fill<T>(a, kind, s);
-  else { a.ws_z = nullptr; a.ws_logu = nullptr; }
+  else { a.ws_z = nullptr; if (reg_resident || lf_only) a.ws_logu = nullptr; }
   if (reg_resident) {
     switch (D) {
       case 1: launch_small_m<T, 1>(a, kind, lf_only, s); break;
@@ -1253,7 +1407,11 @@ template <typename T> int gaussian_dispatch(const GaussArgs<T>& a_in, int kind, 
     }
   } else {
     const int R = (D + 63) / 64;
-    if (R <= 1) launch_wave_m<T, 1>(a, kind, lf_only, s);
+    if (wave_eig_route(a, kind, lf_only)) {
+      const int rc = R <= 1 ? launch_wave_eig<T, 1>(a, s) : launch_wave_eig<T, 2>(a, s);
+      if (rc) return rc;
+    }
+    else if (R <= 1) launch_wave_m<T, 1>(a, kind, lf_only, s);
     else if (R <= 2) launch_wave_m<T, 2>(a, kind, lf_only, s);
     else if (R <= 4) launch_wave_m<T, 4>(a, kind, lf_only, s);
     else if (R <= 8) launch_wave_m<T, 8>(a, kind, lf_only, s);
@@ -1268,6 +1426,8 @@ template <typename T> int gaussian_dispatch(const GaussArgs<T>& a_in, int kind, 
 extern "C" {
 
 int64_t hta_hmc_gaussian_workspace_bytes(int64_t C, int D, int n_traj, int elem_size) {
+  if (D > 6)      /* wave-per-chain kernels draw inline: only the eig area V | Vt | lam of the eigenbasis route */
+    return ((int64_t)2 * D * D + D + 64) * elem_size;
   const int per_vec = 16 / elem_size;
   const int64_t rec = ((int64_t)(D + 1 + per_vec - 1) / per_vec) * per_vec;
   /* + four rows read ahead by the last trajectories, + the eigen block (lam, Qt, Tin, Tout; D <= 6) of the eigenbasis route */
@@ -1286,8 +1446,8 @@ int64_t hta_hmc_gaussian_workspace_bytes(int64_t C, int D, int n_traj, int elem_
                         nullptr, nullptr, nullptr, nullptr, nullptr};                                           \
     const int64_t need = hta_hmc_gaussian_workspace_bytes(C, D, n_traj, (int)sizeof(T));                       \
     if (workspace && workspace_bytes >= need && need > 0) {                                                     \
-      a.ws_z = (T*)workspace;                                                                                   \
-      a.ws_logu = D <= 6 ? (T*)((char*)workspace + need) - 128 : nullptr;  /* eig block */                      \
+      a.ws_z = D <= 6 ? (T*)workspace : nullptr;                                                                \
+      a.ws_logu = D <= 6 ? (T*)((char*)workspace + need) - 128 : (T*)workspace;  /* eig block / eig area */     \
     }                                                                                                           \
     return hta::gaussian_dispatch<T>(a, mass_kind, false, (hipStream_t)stream);                                 \
   }                                                                                                             \

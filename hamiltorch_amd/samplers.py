@@ -521,10 +521,11 @@ class _GaussianHMC(_Engine):
         C, D = theta0.shape
         # scratch for the pre-drawn momenta / log-uniforms of one launch (<= WS_CAP bytes, so it stays
         # in the 256 MB Infinity Cache); long runs are cut into several launches over `traj_offset`
-        fixed = _abi.gaussian_workspace_bytes(C, D, 0, theta0.element_size())       # look-ahead rows + eigen block
+        fixed = _abi.gaussian_workspace_bytes(C, D, 0, theta0.element_size())       # look-ahead rows + eigen block / area
         per_traj = _abi.gaussian_workspace_bytes(C, D, 1, theta0.element_size()) - fixed
         fits = fixed + per_traj <= self.WS_CAP
-        chunk = max(1, min(count, (self.WS_CAP - fixed) // per_traj)) if fits else count
+        # (D > 6: the kernels draw inline, the workspace is only the eigen area and does not grow with the trajectories)
+        chunk = max(1, min(count, (self.WS_CAP - fixed) // per_traj)) if (fits and per_traj > 0) else count
         ws = None
         if fits and (H_old is None):
             ws = getattr(self, "_ws", None)

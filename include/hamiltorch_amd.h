@@ -137,7 +137,9 @@ int hta_mh_select_at_f64(double* theta_cur, const double* theta_prop, const doub
  *               mass-whitened precision matrix L^-1 P L^-T, M = L L^T (2 D instead of D + D*D multiply-adds per step;
  *               fp32, D <= 4 and C <= 65536: one chain per DPP quad); the workspace then also holds the eigen block.
  *               Same map and draws; results differ from the direct form by rounding only
- *               (hta_set_tuning("gauss_eig", 0) selects the direct form).
+ *               (hta_set_tuning("gauss_eig", 0) selects the direct form).  6 < D <= 128 (fp64: 96) with identity mass:
+ *               the workspace is the eigen area only (the kernels draw inline) and the wave-per-chain kernel
+ *               integrates in the eigenbasis of P likewise.
  * ------------------------------------------------------------------------------------------- */
 int hta_hmc_gaussian_sample_f32(float* theta, const float* theta_init, const float* P, const float* mu,
                                 float log_norm, int mass_kind, const float* inv_mass,

@@ -560,3 +560,35 @@ def test_edge_sizes_against_oracle(ht):
     out = ht.sample(t3, tt(th0, dtype), num_samples=6, num_steps_per_sample=10, step_size=0.3, verbose=False, seed=3)
     ref, _ = O.sample_hmc(o3, th0, 6, 10, 0.3, 0, None, O.PhiloxDraws(3, np.arange(C)))
     _compare_runs(out, ref, 2e-4, 0.002)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-4), (torch.float64, 1e-9)])
+@pytest.mark.parametrize("D", [7, 20, 64, 70, 100, 128])
+def test_wave_eigenbasis_route_vs_direct_and_oracle(ht, dtype, tol, D):
+    """D > 6, identity mass: the wave-per-chain kernel integrates in the eigenbasis of P (diagonalised once per launch by
+    the Jacobi kernel; two D x D products per trajectory instead of one per step).  Against the direct wave kernel
+    (hta_set_tuning('gauss_eig', 0)) and the oracle on the same Philox draws, with burn-in (Q2 reset) and a mean offset."""
+    from hamiltorch_amd import _abi
+    if dtype == torch.float64 and D > 96:
+        pytest.skip("fp64 Jacobi kernel stops at D ~ 99")
+    C, N, L, eps, seed, burn = 37, 12, 6, 0.15, 40 + D, 2
+    rng = np.random.default_rng(D)
+    P = rand_spd(D, 3)
+    mu = rng.normal(size=D)
+    t, o = targets(ht, P, dtype, mu=mu)
+    th0 = (mu + 0.5 * O.philox_normals(seed, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(NP[dtype])
+    outs = []
+    for mode in (1, 0):
+        _abi.set_tuning("gauss_eig", mode)
+        try:
+            out, acc = ht.sample(t, tt(th0, dtype), num_samples=N, num_steps_per_sample=L, step_size=eps, burn=burn, debug=2,
+                                 verbose=False, seed=seed)
+        finally:
+            _abi.set_tuning("gauss_eig", 1)
+        outs.append((out, acc.cpu().numpy()))
+    ref, info = O.sample_hmc(o, th0, N, L, eps, burn, None, O.PhiloxDraws(seed, np.arange(C), NP[dtype]))
+    bad_e = _compare_runs(outs[0][0], ref, tol, 0.06)
+    bad_d = _compare_runs(outs[1][0], ref, tol, 0.06)
+    good = ~(bad_e | bad_d)
+    np.testing.assert_allclose(outs[0][1][good], outs[1][1][good], atol=1e-12)
+    assert 0.3 < outs[0][1].mean() <= 1.0
