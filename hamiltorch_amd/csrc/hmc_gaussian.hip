@@ -1431,7 +1431,7 @@ int64_t hta_hmc_gaussian_workspace_bytes(int64_t C, int D, int n_traj, int elem_
   const int per_vec = 16 / elem_size;
   const int64_t rec = ((int64_t)(D + 1 + per_vec - 1) / per_vec) * per_vec;
   /* + four rows read ahead by the last trajectories, + the eigen block (lam, Qt, Tin, Tout; D <= 6) of the eigenbasis route */
-  return ((int64_t)n_traj + 4) * C * rec * elem_size + (D <= 6 ? 128 * elem_size : 0);
+  return ((int64_t)n_traj + 4) * C * rec * elem_size + (D <= 6 ? hta::EIG_ELEMS * elem_size : 0);
 }
 
 #define HTA_DEFINE_GAUSS(SUF, T)                                                                               \
@@ -1447,7 +1447,7 @@ int64_t hta_hmc_gaussian_workspace_bytes(int64_t C, int D, int n_traj, int elem_
     const int64_t need = hta_hmc_gaussian_workspace_bytes(C, D, n_traj, (int)sizeof(T));                       \
     if (workspace && workspace_bytes >= need && need > 0) {                                                     \
       a.ws_z = D <= 6 ? (T*)workspace : nullptr;                                                                \
-      a.ws_logu = D <= 6 ? (T*)((char*)workspace + need) - 128 : (T*)workspace;  /* eig block / eig area */     \
+      a.ws_logu = D <= 6 ? (T*)((char*)workspace + need) - hta::EIG_ELEMS : (T*)workspace;  /* eig block / eig area */     \
     }                                                                                                           \
     return hta::gaussian_dispatch<T>(a, mass_kind, false, (hipStream_t)stream);                                 \
   }                                                                                                             \
