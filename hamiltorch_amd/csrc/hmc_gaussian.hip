@@ -768,14 +768,13 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
   T potc = lam * yc * yc;                        // twice this coordinate's share of the potential at the current point
   int32_t accepted = 0;
 
-  // Addresses are (wave-uniform base) + (32-bit lane offset): the bases advance on the scalar unit.
+  // The record pointer is per lane and advances with one 64-bit vector add per trajectory (a scalar base would take an
+  // s_add / s_addc pair: at this size a scalar instruction costs what a vector one does).
   constexpr int W = rec_elems<T, D>();
-  typedef const __attribute__((address_space(1))) char* gbytes_t;
-  gbytes_t recb = (gbytes_t)a.ws_z;                                // row of the record stream
-  uint32_t roff = (uint32_t)(((size_t)c * W + k) * sizeof(T));     // element k of this chain's record (W >= 4 floats)
-  const uint32_t uoff = (uint32_t)(((size_t)c * W + D) * sizeof(T));   // D == 4: log u sits in the second vector
-  const size_t rec_step = C * W * sizeof(T);
-  auto rec_at = [&](uint32_t off) { return *(const __attribute__((address_space(1))) T*)(recb + off); };
+  typedef const __attribute__((address_space(1))) T* grec_t;       // stays a global pointer through the ordering asm below
+  grec_t rec = (grec_t)(a.ws_z + (size_t)c * W + k);               // element k of this chain's record (W >= 4 floats)
+  const int ushift = D - k;                                        // D == 4: log u sits in the second vector
+  const size_t rec_step = C * W;
   // Records are read NS trajectories ahead: a trajectory (~90 ns at L = 5, ~180 ns at L = 25) is shorter than the ~250 ns
   // an HBM load takes to return, and the look-ahead has to cover it.  The workspace carries QUAD_SLOTS_MAX rows of slack.
   constexpr int NS = LB == 5 ? 4 : (LB == 10 ? 3 : 2);
@@ -783,9 +782,9 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
   T zs[NS], lus[NS];
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
-    if (i) recb += rec_step;
-    zs[i] = rec_at(roff);
-    lus[i] = D == 4 ? rec_at(uoff) : 0.f;
+    if (i) rec += rec_step;
+    zs[i] = *rec;
+    lus[i] = D == 4 ? *(rec + ushift) : 0.f;
   }
   // Every lane stores once per trajectory, unconditionally (uniform vmcnt, see hmc_gauss_small_kernel).
   const uint32_t qoff = (uint32_t)(((size_t)c * D + kk) * sizeof(T));
@@ -809,7 +808,7 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
     // `q2`: this is trajectory burn+1, the one the reference resets to params_init when it is rejected (S:1016-1018);
     // a separate instance, so that the others carry no check for it.
     auto trajectory = [&](T& slot, T& slot_u, auto q2) {
-      recb += rec_step;
+      rec += rec_step;
       // everything that reads the record first, so that its register is free for the refill
       // ---- gibbs S:185-186 (rotated draws), H_old S:971, half kick S:281
       T y = yc, r, eo, logu;
@@ -823,9 +822,9 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
       }
       // (the empty asm orders the refill after the record's last use, so the load can target the record's own register;
       //  otherwise the scheduler hoists the load and the back-edge copy of its result waits for it)
-      asm volatile("" : "+v"(roff) : "v"(r), "v"(eo), "v"(logu));
-      slot = rec_at(roff);
-      if (D == 4) slot_u = rec_at(uoff);
+      asm volatile("" : "+v"(rec) : "v"(r), "v"(eo), "v"(logu));
+      slot = *rec;
+      if (D == 4) slot_u = *(rec + ushift);
       if constexpr (LB > 0) {                                                       // S:283-298
 #pragma unroll
         for (int l = 0; l < LB; ++l) { y = fmaf(eps, r, y); r = fmaf(nel, y, r); }
@@ -838,41 +837,37 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
       const T en = fmaf(r, r, pot1);
       const T dH = quad_sum(eo - en);                                               // 2 (h_old - h_new)
       // the decision as a lane mask (v_cmp into an SGPR pair), consumed by a carry-in add and two selects
-      const uint64_t accmask = __builtin_amdgcn_fcmpf(fminf(0.f, dH), logu, 3 /* oge */) &
-                               __builtin_amdgcn_fcmpf(fabsf(dH), __builtin_inff(), 4 /* olt: finite */);
-      T q = mu;
+      // rho = min(0, dH) >= log u  <=>  dH >= log u, because log u <= 0 (S:1000-1004).  A non-finite dH must reject:
+      // fma(dH, 0, dH) is dH when dH is finite and NaN otherwise (inf * 0), and NaN >= x is false - one compare in all.
+      const uint64_t accmask = __builtin_amdgcn_fcmpf(__builtin_fmaf(dH, 0.0f, dH), logu, 3 /* oge */);
+      T q;
       if constexpr (!decltype(q2)::value) {
-        // accepted += acc; yc, potc <- accepted point; q_k = mu_k + sum_j Q[k][j] yc_j.  One block: the two instructions
-        // between the write of yc and its first DPP read are the wait states that read needs.
+        // accepted += acc; yc, potc <- accepted point; q_k = mu_k + sum_j Tout[k][j] yc_j.  One block: the two instructions
+        // between the write of yc and its first DPP read (the select of potc, the move of mu) are the wait states it needs.
         uint64_t carry_out;
         static_assert(D >= 1 && D <= 4, "quad kernel");
+#define HTA_QHEAD "v_addc_co_u32_e64 %0, %4, 0, %0, %5\n\tv_cndmask_b32_e64 %1, %1, %6, %5\n\tv_cndmask_b32_e64 %2, %2, %7, %5\n\t" \
+                  "v_mov_b32 %3, %8\n\t"
+#define HTA_QF(J, OP) "v_fmac_f32_dpp %3, %1, %" #OP " quad_perm:[" #J "," #J "," #J "," #J "] row_mask:0xf bank_mask:0xf"
         if constexpr (D == 1)
-          asm volatile("v_addc_co_u32_e64 %0, %4, 0, %0, %5\n\tv_cndmask_b32_e64 %1, %1, %6, %5\n\tv_cndmask_b32_e64 %2, %2, %7, %5\n\t"
-                       "s_nop 0\n\tv_fmac_f32_dpp %3, %1, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf"
-                       : "+v"(accepted), "+v"(yc), "+v"(potc), "+v"(q), "=&s"(carry_out)
-                       : "s"(accmask), "v"(y), "v"(pot1), "v"(Qrow[0]));
+          asm volatile(HTA_QHEAD HTA_QF(0, 9)
+                       : "+v"(accepted), "+v"(yc), "+v"(potc), "=&v"(q), "=&s"(carry_out)
+                       : "s"(accmask), "v"(y), "v"(pot1), "v"(mu), "v"(Qrow[0]));
         else if constexpr (D == 2)
-          asm volatile("v_addc_co_u32_e64 %0, %4, 0, %0, %5\n\tv_cndmask_b32_e64 %1, %1, %6, %5\n\tv_cndmask_b32_e64 %2, %2, %7, %5\n\t"
-                       "s_nop 0\n\tv_fmac_f32_dpp %3, %1, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-                       "v_fmac_f32_dpp %3, %1, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf"
-                       : "+v"(accepted), "+v"(yc), "+v"(potc), "+v"(q), "=&s"(carry_out)
-                       : "s"(accmask), "v"(y), "v"(pot1), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]));
+          asm volatile(HTA_QHEAD HTA_QF(0, 9) "\n\t" HTA_QF(1, 10)
+                       : "+v"(accepted), "+v"(yc), "+v"(potc), "=&v"(q), "=&s"(carry_out)
+                       : "s"(accmask), "v"(y), "v"(pot1), "v"(mu), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]));
         else if constexpr (D == 3)
-          asm volatile("v_addc_co_u32_e64 %0, %4, 0, %0, %5\n\tv_cndmask_b32_e64 %1, %1, %6, %5\n\tv_cndmask_b32_e64 %2, %2, %7, %5\n\t"
-                       "s_nop 0\n\tv_fmac_f32_dpp %3, %1, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-                       "v_fmac_f32_dpp %3, %1, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
-                       "v_fmac_f32_dpp %3, %1, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf"
-                       : "+v"(accepted), "+v"(yc), "+v"(potc), "+v"(q), "=&s"(carry_out)
-                       : "s"(accmask), "v"(y), "v"(pot1), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]), "v"(Qrow[D > 2 ? 2 : 0]));
+          asm volatile(HTA_QHEAD HTA_QF(0, 9) "\n\t" HTA_QF(1, 10) "\n\t" HTA_QF(2, 11)
+                       : "+v"(accepted), "+v"(yc), "+v"(potc), "=&v"(q), "=&s"(carry_out)
+                       : "s"(accmask), "v"(y), "v"(pot1), "v"(mu), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]), "v"(Qrow[D > 2 ? 2 : 0]));
         else
-          asm volatile("v_addc_co_u32_e64 %0, %4, 0, %0, %5\n\tv_cndmask_b32_e64 %1, %1, %6, %5\n\tv_cndmask_b32_e64 %2, %2, %7, %5\n\t"
-                       "s_nop 0\n\tv_fmac_f32_dpp %3, %1, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-                       "v_fmac_f32_dpp %3, %1, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
-                       "v_fmac_f32_dpp %3, %1, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
-                       "v_fmac_f32_dpp %3, %1, %11 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
-                       : "+v"(accepted), "+v"(yc), "+v"(potc), "+v"(q), "=&s"(carry_out)
-                       : "s"(accmask), "v"(y), "v"(pot1), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]), "v"(Qrow[D > 2 ? 2 : 0]),
+          asm volatile(HTA_QHEAD HTA_QF(0, 9) "\n\t" HTA_QF(1, 10) "\n\t" HTA_QF(2, 11) "\n\t" HTA_QF(3, 12)
+                       : "+v"(accepted), "+v"(yc), "+v"(potc), "=&v"(q), "=&s"(carry_out)
+                       : "s"(accmask), "v"(y), "v"(pot1), "v"(mu), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]), "v"(Qrow[D > 2 ? 2 : 0]),
                          "v"(Qrow[D > 3 ? 3 : 0]));
+#undef HTA_QHEAD
+#undef HTA_QF
       } else {
         uint64_t carry_out;
         asm("v_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(accepted), "=s"(carry_out) : "s"(accmask));
@@ -905,7 +900,11 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
       trajectory(zs[0], lus[0], std::true_type{});
       rotate();
     }
-    while (t + NS - 1 < t_end) {                // unrolled over the slots: no register rotation on the hot path
+    while (t + 2 * NS - 1 < t_end) {            // unrolled over the slots (twice): no register rotation on the hot path
+#pragma unroll
+      for (int i = 0; i < 2 * NS; ++i) trajectory(zs[i % NS], lus[i % NS], plain);
+    }
+    if (t + NS - 1 < t_end) {
 #pragma unroll
       for (int i = 0; i < NS; ++i) trajectory(zs[i], lus[i], plain);
     }
