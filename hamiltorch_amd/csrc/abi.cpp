@@ -14,19 +14,24 @@ int g_small_chains_per_block = 0;  // 0 = default (64)
 int g_force_general = 0;
 int g_rmhmc_overlap = 1;   // fused RMHMC: momentum draws of the next block of trajectories on a side stream
 int g_gauss_eig = 1;       // small-D identity-mass Gaussian HMC integrates in the eigenbasis of P (0: direct kernel, 2: chain per lane only)
+int g_fill_blocks = 4096;        // grid cap of the pre-draw pass (256-thread blocks, grid-stride)
 int g_quad_max_chains = 65536;   // up to here a chain takes a DPP quad (one eigen-coordinate per lane), beyond a lane
 int g_rmhmc_fused = 1;           // 0 = per-evaluation Jacobi path, 3 = fused with two chains per workgroup (parity tests)
 int g_mlp_valu = 0;               // 1 = keep the Bayesian-MLP sampler on the VALU kernel (parity tests of both)
 
 // ---- optional HIP-event timing of the dominant kernel of each call (measurement only) -----------
-// hta_set_tuning("profile", 1) arms it; every bracketed launch then records a start/stop event pair
-// on the launch stream (no synchronisation); hta_profile_collect() waits for them and returns the sum.
+// hta_set_tuning("profile", N) arms it; every N-th bracketed launch then records a start/stop event pair
+// on the launch stream (no synchronisation); hta_profile_collect() waits for them and returns the sum and the
+// number of pairs.  (An event record is a barrier packet: ~3 us of bubble each, which is why N > 1 exists.)
 static int g_profile = 0;
+static int g_prof_seen = 0;
+static bool g_prof_armed = false;
 static const int kMaxPairs = 8192;
 static hipEvent_t g_ev[kMaxPairs][2];
 static int g_ev_created = 0, g_ev_used = 0;
 void profile_begin(hipStream_t s) {
-  if (!g_profile || g_ev_used >= kMaxPairs) return;
+  g_prof_armed = g_profile > 0 && g_ev_used < kMaxPairs && (g_prof_seen++ % g_profile) == 0;
+  if (!g_prof_armed) return;
   if (g_ev_used >= g_ev_created) {
     (void)hipEventCreate(&g_ev[g_ev_created][0]);
     (void)hipEventCreate(&g_ev[g_ev_created][1]);
@@ -35,7 +40,8 @@ void profile_begin(hipStream_t s) {
   (void)hipEventRecord(g_ev[g_ev_used][0], s);
 }
 void profile_end(hipStream_t s) {
-  if (!g_profile || g_ev_used >= kMaxPairs) return;
+  if (!g_prof_armed) return;
+  g_prof_armed = false;
   (void)hipEventRecord(g_ev[g_ev_used][1], s);
   ++g_ev_used;
 }
@@ -70,9 +76,10 @@ int hta_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gauss_eig")) { hta::g_gauss_eig = value; return HTA_OK; }
   if (!strcmp(key, "rmhmc_overlap")) { hta::g_rmhmc_overlap = value; return HTA_OK; }
   if (!strcmp(key, "quad_max_chains")) { hta::g_quad_max_chains = value; return HTA_OK; }
+  if (!strcmp(key, "fill_blocks")) { hta::g_fill_blocks = value > 0 ? value : 4096; return HTA_OK; }
   if (!strcmp(key, "mlp_valu")) { hta::g_mlp_valu = value; return HTA_OK; }
   if (!strcmp(key, "rmhmc_fused")) { hta::g_rmhmc_fused = value; return HTA_OK; }
-  if (!strcmp(key, "profile")) { hta::g_profile = value; hta::g_ev_used = 0; return HTA_OK; }
+  if (!strcmp(key, "profile")) { hta::g_profile = value; hta::g_ev_used = 0; hta::g_prof_seen = 0; return HTA_OK; }
   hta::set_error("hta_set_tuning: unknown key %s", key);
   return HTA_ERR_INVALID;
 }

@@ -1360,7 +1360,7 @@ template <typename T, int R> void launch_wave_m(const GaussArgs<T>& a, int kind,
 template <typename T, int D> static void launch_rng_fill_d(const GaussArgs<T>& a, int mass_kind, hipStream_t s) {
   const int64_t total = a.C * a.n_traj;
   int64_t g = (total + 255) / 256;
-  if (g > 256 * 16) g = 256 * 16;
+  if (g > g_fill_blocks) g = g_fill_blocks;
   if (a.ws_logu) eig_small_kernel<T, D><<<1, 64, 0, s>>>(a.P, mass_kind, a.mass_factor, a.ws_logu);
   rng_fill_small_kernel<T, D><<<(int)g, 256, 0, s>>>(a.ws_z, a.C, a.n_traj, a.traj_offset, a.seed, a.chain_offset,
                                                      a.ws_logu, quad_route(a) ? (T)2 : (T)1);

@@ -290,8 +290,8 @@ int hta_mlp_logp_grad_f64(const double* theta, int64_t C, int n_in, int H, int a
                           double prior_scale, double* grad_out, double* logp_out, void* stream);
 
 /* measurement knobs: "small_chains_per_block" (launch shape of the thread-per-chain kernel),
- * "force_general" (route small D through the wave-per-chain kernel), "profile" (1 = record a HIP
- * event pair around the dominant kernel of every fused call, on the launch stream);
+ * "force_general" (route small D through the wave-per-chain kernel), "profile" (N > 0 = record a HIP
+ * event pair around the dominant kernel of every N-th fused call, on the launch stream);
  * route selectors kept for the parity tests: "gauss_eig" (1 default; 0 = direct small-D Gaussian kernel, 2 = eigenbasis with
  * one chain per lane only, 3 = quad kernel without the compiled-in step counts), "quad_max_chains" (65536), "rmhmc_fused"
  * (1 default; 0 = per-evaluation Jacobi path, 3 = two chains per workgroup), "rmhmc_overlap" (1 default; 0 = momentum draws
