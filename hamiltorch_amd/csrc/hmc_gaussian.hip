@@ -755,7 +755,8 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
   };
   auto to_q = [&](T y) {                         // q_k = mu_k + sum_j Q[k][j] y_j: v_fmac_f32 with a DPP-broadcast operand
     T q = mu;
-    asm volatile("s_nop 1");                     // VALU write of y -> DPP read: 2 wait states (inline asm is not tracked)
+    // VALU write of y -> DPP read: 2 wait states (inline asm is not tracked); tied to y so it cannot move ahead of y's producer
+    asm volatile("s_nop 1" : "+v"(y));
 #pragma unroll
     for (int j = 0; j < D; ++j)
       asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[%3,%3,%3,%3] row_mask:0xf bank_mask:0xf"
