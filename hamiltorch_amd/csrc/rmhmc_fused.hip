@@ -582,6 +582,262 @@ __global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int
   }
 }
 
+
+// =============================================================================================
+// The same run, 16 chains per workgroup, products on the matrix cores (fp32, D <= 112, pre-drawn momenta, log-det series)
+//
+// S and P are the same for every chain, so a product pass over 16 chains is S X with X a D x 16 matrix:
+// v_mfma_f32_16x16x4_f32 tiles (exact fp32 products, fp32 accumulation; 2048 flop per instruction where the one-chain
+// kernel issues one v_fmac_f32_dpp per 128).  Wave w owns the row tile 16w..16w+15: its A fragments (S and P, 28 VGPRs
+// each: lane (i, g) holds A[16w+i][28g+j], j < 28 - the K index is permuted so that a lane's share of an operand vector is
+// contiguous in LDS) stay in registers for the launch; the B operand of chain column n is X[n][28g+j], seven 16-byte
+// LDS reads per vector and pass; the accumulator is C[4g+reg][n]: lane (n, g) OWNS elements 16w+4g .. +3 of chain n's vectors
+// and does their element-wise work in registers (four consecutive rows = one Philox block of jitter per evaluation).
+// Same streams, same update order, same barriers per pass as rmhmc_fused_kernel; sums run in a different order.
+// What it buys is bounded by the fp32 matrix rate (64 flop/clk/SIMD, twice the VALU FMA rate, minus 25 % tile padding at
+// D = 100) and by its pass latency (7 row tiles on 4 SIMDs: 2 x 56 MFMAs x 32 clk per first pass): measured against one chain
+// per workgroup 0.6x / 0.96x / 1.19x / 1.37x at 512 / 1024 / 2048 / 4096 chains (tools/scratch/pair_check.py), so it is taken
+// from 2048 chains per GPU on (hta_set_tuning("rmhmc_batch", 0) off, 2 always); there the per-trajectory Cholesky of the
+// momentum draw is the next limit.
+// =============================================================================================
+constexpr int BNC = 16, BLD = 116, BWV = 7, BNT = 64 * BWV, BKJ = 28;
+typedef float bf4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(BNT) void rmhmc_batch_kernel(FusedArgs<float> a) {
+  typedef float T;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* lds = reinterpret_cast<T*>(smem_raw);
+  constexpr int MSZ = BNC * BLD;
+  T* PM = lds; T* PMC = PM + MSZ; T* D0 = PMC + MSZ; T* D1 = D0 + MSZ; T* W0 = D1 + MSZ; T* W1 = W0 + MSZ; T* EV = W1 + MSZ;
+  T* red = EV + MSZ;                                      // [BWV][BNC][4]
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cl = l & 15, g = l >> 4;
+  const int D = a.D;
+  const int row0 = 16 * w + 4 * g, arow = 16 * w + cl;
+  T Sa[BKJ], Pa[BKJ];
+#pragma unroll
+  for (int j = 0; j < BKJ; ++j) {
+    const int k = BKJ * g + j;
+    const bool ok = arow < D && k < D;
+    Sa[j] = ok ? a.S[(int64_t)k * D + arow] : 0.f;        // symmetric: column arow, coalesced over the lanes of a tile
+    Pa[j] = ok ? a.P[(int64_t)k * D + arow] : 0.f;
+  }
+  T mu_r[4], sd_r[4];
+  bool rok[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int r = row0 + e;
+    rok[e] = r < D;
+    mu_r[e] = rok[e] ? a.mu[r] : 0.f;
+    sd_r[e] = rok[e] ? a.S[(int64_t)r * D + r] : 0.f;
+  }
+  for (int e = tid; e < 7 * MSZ + BWV * BNC * 4; e += BNT) lds[e] = 0.f;
+  const T eh = 0.5f * a.eps;
+  const int own_off = cl * BLD + row0, b_off = cl * BLD + BKJ * g;
+  int dpar = 0;
+  T ev_r[4] = {0.f, 0.f, 0.f, 0.f};
+  uint64_t chain = 0;
+  bool live = false;
+
+  auto put4 = [&](T* X, const T (&v)[4]) { *reinterpret_cast<bf4*>(X + own_off) = bf4{v[0], v[1], v[2], v[3]}; };
+  auto load_b = [&](const T* X, T (&b)[BKJ]) {
+#pragma unroll
+    for (int q = 0; q < BKJ / 4; ++q) {
+      const bf4 v = *reinterpret_cast<const bf4*>(X + b_off + 4 * q);
+      b[4 * q] = v[0]; b[4 * q + 1] = v[1]; b[4 * q + 2] = v[2]; b[4 * q + 3] = v[3];
+    }
+  };
+  auto jitter4 = [&](uint32_t n, uint32_t sub) {            // this lane's four rows are one Philox block (uniform_elem layout)
+    if (!a.has_jitter) return;
+    const U4 r = philox_block(a.seed, chain, n, PURPOSE_JITTER, sub, (uint32_t)(row0 >> 2));
+    const T u[4] = {u23<T>(r.x), u23<T>(r.y), u23<T>(r.z), u23<T>(r.w)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ev_r[e] = (live && rok[e]) ? a.jitter * u[e] : 0.f;
+  };
+  // x = (P + diag(e))^-1 m continued from x0 = S m (rmhmc_fused_kernel: refine)
+  auto refine = [&](const T (&x0)[4], T (&xr)[4]) {
+    for (int it = 0; it < a.K; ++it) {
+      const T* wr = (it & 1) ? W1 : W0;
+      T* ww = (it & 1) ? W0 : W1;
+      __syncthreads();
+      T bw[BKJ];
+      load_b(wr, bw);
+      bf4 sx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < BKJ; ++j) sx = __builtin_amdgcn_mfma_f32_16x16x4f32(Sa[j], bw[j], sx, 0, 0, 0);
+      T wv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { xr[e] = x0[e] - sx[e]; wv[e] = ev_r[e] * xr[e]; }
+      put4(ww, wv);
+    }
+  };
+  // one half step: upd_x += eh G(X)^-1 m ; upd_g -= eh P (X - mu)   (rmhmc_fused_kernel: half_step)
+  auto half_step = [&](uint32_t n, uint32_t sub, const T (&X)[4], const T* m, T (&upd_x)[4], T (&upd_g)[4], T* upd_g_lds) {
+    T* d = dpar ? D1 : D0;
+    dpar ^= 1;
+    jitter4(n, sub);
+    T dv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dv[e] = rok[e] ? X[e] - mu_r[e] : 0.f;
+    put4(d, dv);
+    __syncthreads();
+    T bd[BKJ], bm[BKJ];
+    load_b(d, bd);
+    load_b(m, bm);
+    bf4 Pd = {0.f, 0.f, 0.f, 0.f}, x0v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < BKJ; ++j) {
+      Pd = __builtin_amdgcn_mfma_f32_16x16x4f32(Pa[j], bd[j], Pd, 0, 0, 0);
+      x0v = __builtin_amdgcn_mfma_f32_16x16x4f32(Sa[j], bm[j], x0v, 0, 0, 0);
+    }
+    T x0[4], xr[4], wv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      upd_g[e] -= eh * Pd[e];
+      x0[e] = x0v[e]; xr[e] = x0v[e];
+      wv[e] = ev_r[e] * x0v[e];
+    }
+    put4(upd_g_lds, upd_g);
+    put4(W0, wv);
+    refine(x0, xr);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) upd_x[e] += eh * xr[e];
+  };
+  // three sums per chain over the rows, complete in every lane of the chain's column
+  auto block_sums = [&](T (&v)[3]) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      v[e] += __shfl_xor(v[e], 16, 64);
+      v[e] += __shfl_xor(v[e], 32, 64);
+    }
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) red[(w * BNC + cl) * 4 + e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      T s = 0.f;
+#pragma unroll
+      for (int i = 0; i < BWV; ++i) s += red[(i * BNC + cl) * 4 + e];
+      v[e] = s;
+    }
+  };
+  // H = -log p + D/2 log 2 pi + 1/2 log|G| + 1/2 m^T G^-1 m  (S:731)   (rmhmc_fused_kernel: hamiltonian, series branch)
+  auto hamiltonian = [&](uint32_t n, uint32_t sub, const T (&X)[4], const T* m, const T (&mr)[4], T& H, T& logp) {
+    T* d = dpar ? D1 : D0;
+    dpar ^= 1;
+    jitter4(n, sub);
+    T dr[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dr[e] = rok[e] ? X[e] - mu_r[e] : 0.f;
+    put4(EV, ev_r);
+    put4(d, dr);
+    __syncthreads();
+    T bd[BKJ], bm[BKJ];
+    load_b(d, bd);
+    load_b(m, bm);
+    bf4 Pd = {0.f, 0.f, 0.f, 0.f}, x0v = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < BKJ; ++j) {
+      Pd = __builtin_amdgcn_mfma_f32_16x16x4f32(Pa[j], bd[j], Pd, 0, 0, 0);
+      x0v = __builtin_amdgcn_mfma_f32_16x16x4f32(Sa[j], bm[j], x0v, 0, 0, 0);
+    }
+    if (a.has_jitter) {                                     // second-order log-det term: (S . S) e
+      T be[BKJ];
+      load_b(EV, be);
+#pragma unroll
+      for (int j = 0; j < BKJ; ++j) s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Sa[j] * Sa[j], be[j], s2, 0, 0, 0);
+    }
+    T v[3] = {0.f, 0.f, 0.f}, x0[4], xr[4], wv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      x0[e] = x0v[e]; xr[e] = x0v[e];
+      v[0] += dr[e] * Pd[e];
+      wv[e] = ev_r[e] * x0v[e];
+      if (a.has_jitter) v[2] += ev_r[e] * (sd_r[e] - 0.5f * s2[e]);      // log|P + E| = log|P| + tr(SE) - 1/2 tr((SE)^2) + ...
+    }
+    put4(W0, wv);
+    refine(x0, xr);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[1] += mr[e] * xr[e];
+    block_sums(v);
+    const float pi_term = (float)D * 1.8378770351409912f;   // S:712
+    logp = a.log_norm - 0.5f * v[0];
+    H = -logp + 0.5f * pi_term + 0.5f * (a.logdetP + v[2]) + 0.5f * v[1];
+  };
+
+  const int64_t ngroup = (a.C + BNC - 1) / BNC;
+  for (int64_t cg = blockIdx.x; cg < ngroup; cg += gridDim.x) {
+    const int64_t c = BNC * cg + cl;
+    live = c < a.C;
+    chain = a.chain_offset + (uint64_t)(live ? c : 0);
+    T scur[4], sth[4], spm[4], sthc[4], spmc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) scur[e] = (live && rok[e]) ? a.cur[c * D + row0 + e] : 0.f;
+    int32_t rejected = 0;
+    __syncthreads();                                        // the previous group's last reads of the vector matrices
+    for (int t = 0; t < a.n_traj; ++t) {
+      const uint32_t n = (uint32_t)(a.traj_offset + t);
+      // ---- gibbs: p = chol(G(theta)) z, drawn ahead by rmhmc_momentum_kernel (S:183-184)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) spm[e] = (live && rok[e]) ? a.p_ws[((int64_t)t * a.C + c) * D + row0 + e] : 0.f;
+      put4(PM, spm);
+      T H0, H1, lp0, lp1;
+      hamiltonian(n, 1, scur, PM, spm, H0, lp0);            // S:971 -> S:822
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { sth[e] = scur[e]; sthc[e] = scur[e]; spmc[e] = spm[e]; }   // S:425-426
+      put4(PMC, spm);
+      for (int lstep = 0; lstep < a.L; ++lstep) {           // S:427-461
+        const uint32_t k0 = 2u + 8u * (uint32_t)lstep;
+        half_step(n, k0 + 1, sth, PMC, sthc, spm, PM);      // phi_A/2  S:429-430
+        half_step(n, k0 + 2, sthc, PM, sth, spmc, PMC);     // phi_B/2  S:432-433
+        if (a.K == 0) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                       // phi_C    S:447-450, sequential (Q1)
+          T xx = sth[e], b = spm[e], xc = sthc[e], bc = spmc[e];
+          const T h = 0.5f, cc = a.rot_c, ss = a.rot_s;
+          xx = h * ((xx + xc) + cc * (xx - xc) + ss * (b - bc));
+          b = h * ((b + bc) - ss * (xx - xc) + cc * (b - bc));
+          xc = h * ((xx + xc) - cc * (xx - xc) - ss * (b - bc));
+          bc = h * ((b + bc) + ss * (xx - xc) - cc * (b - bc));
+          sth[e] = xx; spm[e] = b; sthc[e] = xc; spmc[e] = bc;
+        }
+        put4(PM, spm);
+        put4(PMC, spmc);
+        half_step(n, k0 + 4, sthc, PM, sth, spmc, PMC);     // phi_B/2  S:454-455
+        half_step(n, k0 + 7, sth, PMC, sthc, spm, PM);      // phi_A/2  S:457-458
+      }
+      hamiltonian(n, 2u + 8u * (uint32_t)a.L, sth, PM, spm, H1, lp1);   // S:989 (Q4)
+      // ---- Metropolis test + bookkeeping (S:1000-1026, S:1045-1057)
+      const T u = u23<T>(philox_block(a.seed, chain, n, PURPOSE_MH, 0, 0).x);
+      const bool acc = mh_accept<T>(H0, H1, lp1, u);
+      const bool reset = (!acc) && ((int)n == a.burn + 1);  // Q2
+      if (live) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (rok[e]) {
+            const T vnew = acc ? sth[e] : (reset ? a.theta_init[c * D + row0 + e] : scur[e]);
+            scur[e] = vnew;
+            if (a.samples && (int)n > a.burn) a.samples[((int64_t)((int)n - a.burn) * a.C + c) * D + row0 + e] = vnew;
+          }
+        }
+        if (w == 0 && g == 0) {
+          if (a.H_old) a.H_old[(int64_t)t * a.C + c] = H0;
+          if (a.H_new) a.H_new[(int64_t)t * a.C + c] = H1;
+          if (a.accept) a.accept[(int64_t)t * a.C + c] = acc ? 1 : 0;
+        }
+      }
+      if (!acc) ++rejected;
+    }
+    if (live) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (rok[e]) a.cur[c * D + row0 + e] = scur[e];
+      if (w == 0 && g == 0) a.reject_count[c] += rejected;
+    }
+  }
+}
+
 // The momentum draws of a block of trajectories, off the chains' critical path: task (t, c) -> p = chol(P + diag(e)) z
 // with the jitter sub-stream 0 and the normals of (chain c, trajectory traj_offset + t)  (S:183-184).  One workgroup per
 // task at a time, 3 per CU: the factorisations of different tasks overlap each other's LDS latency, which the chain-
@@ -747,6 +1003,25 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
     const bool pair = g_rmhmc_fused == 3 && block > 0 && (series || !has_jitter);
     const bool need_w = !(block > 0 && (series || !has_jitter));      // a Cholesky inside the kernel: work matrix in LDS
     auto launch = [&](auto kern, auto kern2, bool& dn, bool& dn2) -> int {
+      if constexpr (sizeof(T) == 4) {
+        const bool batch = g_rmhmc_batch && !pair && block > 0 && (series || !has_jitter) && D <= 16 * BWV &&
+                           (C >= 2048 || g_rmhmc_batch == 2);
+        if (batch) {
+          static bool dn_b = false;
+          if (!dn_b) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rmhmc_batch_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { set_error("hta_rmhmc_gaussian_sample: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
+            dn_b = true;
+          }
+          const int64_t ngroup = (C + BNC - 1) / BNC;
+          const size_t blds = (size_t)(7 * BNC * BLD + BWV * BNC * 4) * sizeof(float);
+          profile_begin(s);
+          rmhmc_batch_kernel<<<(int)(ngroup < 4096 ? ngroup : 4096), BNT, blds, s>>>(a);
+          profile_end(s);
+          return HTA_OK;
+        }
+      }
       if (pair) {
         if (!dn2) {
           hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

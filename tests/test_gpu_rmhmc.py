@@ -512,3 +512,33 @@ def test_fused_momentum_overlap_equals_serial(ht, T):
         for x, y in zip(a_, b_):
             assert np.array_equal(x, y)
     assert not np.array_equal(outs[0][0][1], outs[0][1][1])
+
+
+@pytest.mark.parametrize("D,C,jit", [(24, 40, 1e-3), (100, 50, 1e-3), (100, 33, None), (112, 17, 1e-3), (7, 16, 1e-3)])
+def test_batched_mfma_kernel_equals_fused_kernel(ht, D, C, jit):
+    """rmhmc_batch_kernel (16 chains per workgroup, S X and P X as v_mfma_f32_16x16x4_f32 tiles) against rmhmc_fused_kernel
+    (one chain per workgroup, the parity reference of this path): same streams and update order, sums in a different order ->
+    chain by chain to rounding, with ragged groups, burn-in (Q2 reset) and without jitter."""
+    from hamiltorch_amd import _abi
+    T, L, burn = 9, 3, 2
+    t, _ = cfg3_target(ht, D, torch.float32, seed=9)
+    th0 = tt((0.3 * O.philox_normals(3, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32), torch.float32)
+    outs = []
+    for mode in (2, 0):
+        _abi.set_tuning("rmhmc_batch", mode)
+        try:
+            cur = th0.clone(); rej = torch.zeros(C, dtype=torch.int32, device=dev())
+            samples = torch.zeros(T - burn + 1, C, D, device=dev())
+            ws = torch.empty(_abi.rmhmc_workspace_bytes(C, D, 4, T), dtype=torch.uint8, device=dev())
+            _abi.rmhmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, _abi.METRIC_SOFTABS, 1e6, jit, L, 0.1, 10.0,
+                                       T, 0, burn, 21, 0, samples, rej, ws)
+            torch.cuda.synchronize()
+        finally:
+            _abi.set_tuning("rmhmc_batch", 1)
+        outs.append((samples.cpu().numpy(), rej.cpu().numpy(), cur.cpu().numpy()))
+    err = np.abs(outs[0][0] - outs[1][0]).max(axis=(0, 2))
+    assert (err > 2e-4).mean() <= 0.05, "max err %.3g (%d chains differ)" % (err.max(), (err > 2e-4).sum())
+    good = err <= 2e-4
+    assert np.array_equal(outs[0][1][good], outs[1][1][good])
+    np.testing.assert_allclose(outs[0][2][good], outs[1][2][good], atol=2e-4)
+    assert np.abs(outs[0][0][T - 1 - burn] - outs[0][0][1]).max() > 1e-3          # rows 1 .. T-1-burn are written
