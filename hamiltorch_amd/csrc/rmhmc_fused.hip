@@ -674,7 +674,6 @@ __global__ __launch_bounds__(BNT) void rmhmc_batch_kernel(FusedArgs<float> a) {
   auto half_step = [&](uint32_t n, uint32_t sub, const T (&X)[4], const T* m, T (&upd_x)[4], T (&upd_g)[4], T* upd_g_lds) {
     T* d = dpar ? D1 : D0;
     dpar ^= 1;
-    jitter4(n, sub);
     T dv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) dv[e] = rok[e] ? X[e] - mu_r[e] : 0.f;
@@ -689,6 +688,7 @@ __global__ __launch_bounds__(BNT) void rmhmc_batch_kernel(FusedArgs<float> a) {
       Pd = __builtin_amdgcn_mfma_f32_16x16x4f32(Pa[j], bd[j], Pd, 0, 0, 0);
       x0v = __builtin_amdgcn_mfma_f32_16x16x4f32(Sa[j], bm[j], x0v, 0, 0, 0);
     }
+    jitter4(n, sub);            // first needed after the products: its Philox rounds issue under the MFMAs
     T x0[4], xr[4], wv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -953,7 +953,9 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
   // is a quarter of the serial time at config 3, and both kernels are latency bound, so they share the CUs well.
   // p_ws is used as two halves; events order "half drawn" -> trajectories and "half consumed" -> next draw.
   Overlap* ov = nullptr;
-  if (g_rmhmc_overlap && block >= 16 && n_traj >= 32) {
+  // (from 4096 chains on both kernels fill the chip by themselves and the overlap only makes them contend: 4096 chains
+  //  50.5 ms overlapped, 46.6 ms serial; 2048 chains 30.7 ms overlapped, 32.3 ms serial)
+  if (g_rmhmc_overlap && block >= 16 && n_traj >= 32 && (C < 4096 || g_rmhmc_overlap == 2)) {
     ov = overlap_for_current_device();
     if (ov) {
       int sub = (n_traj + 7) / 8;                      // ~8 blocks: only the first draw is exposed
