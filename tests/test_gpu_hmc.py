@@ -592,3 +592,38 @@ def test_wave_eigenbasis_route_vs_direct_and_oracle(ht, dtype, tol, D):
     good = ~(bad_e | bad_d)
     np.testing.assert_allclose(outs[0][1][good], outs[1][1][good], atol=1e-12)
     assert 0.3 < outs[0][1].mean() <= 1.0
+
+
+@pytest.mark.parametrize("D", [3, 6, 40])
+def test_eigenbasis_routes_with_indefinite_curvature_and_divergence(ht, D):
+    """The eigenbasis kernels do not need a positive definite P: with negative eigenvalues the map is the same leapfrog map
+    (hyperbolic in those coordinates) and agrees with the direct kernels; with a step size that makes trajectories overflow
+    every non-finite proposal is rejected and the states stay finite (S:1045-1057)."""
+    from hamiltorch_amd import _abi
+    dtype = torch.float32
+    rng = np.random.default_rng(D)
+    Qm, _ = np.linalg.qr(rng.normal(size=(D, D)))
+    lam = np.concatenate([[-0.5, 1.0, 2.0], rng.uniform(0.3, 2.0, size=D)])[:D]
+    P = (Qm * lam) @ Qm.T
+    t, _ = targets(ht, 0.5 * (P + P.T), dtype)
+    C = 64
+    th0 = tt(0.1 * rng.normal(size=(C, D)), dtype)
+    outs = []
+    for mode in (1, 0):
+        _abi.set_tuning("gauss_eig", mode)
+        try:
+            out, acc = ht.sample(t, th0, num_samples=8, num_steps_per_sample=10, step_size=0.1, debug=2, verbose=False, seed=3)
+        finally:
+            _abi.set_tuning("gauss_eig", 1)
+        outs.append((torch.stack(out).cpu().numpy(), acc.cpu().numpy()))
+    err = np.abs(outs[0][0] - outs[1][0]).max(axis=(0, 2))
+    assert (err > 2e-3).mean() <= 0.05, err.max()
+    assert np.isfinite(outs[0][0]).all()
+    # overflow: |lambda_min| eps^2 L^2 large -> exp growth past fp32 along the negative direction
+    big = ht.sample(t, th0, num_samples=6, num_steps_per_sample=400, step_size=2.0, verbose=False, seed=4)
+    s = torch.stack(big)
+    assert torch.isfinite(s).all()
+    # every proposal diverged and was rejected: the rows repeat bit for bit; against params_init they differ by the rounding of
+    # the eigenbasis round trip q = mu + Q (Q^T (q - mu))
+    assert torch.equal(s[-1], s[1])
+    np.testing.assert_allclose(s[-1].cpu().numpy(), s[0].cpu().numpy(), atol=1e-6)
