@@ -603,16 +603,30 @@ __global__ __launch_bounds__(256) void hmc_gauss_eig_kernel(GaussArgs<T> a, cons
   T* srow = a.samples ? a.samples + ((size_t)(a.traj_offset > a.burn ? a.traj_offset - a.burn : 1) * C + c) * D
                       : scratch_row;
   const size_t srow_step = a.samples ? C * D : 0;
-  auto store_q = [&](T* __restrict__ dst) {     // q = mu + Q y of the current point
+  // the stored row is kept as it was written: a rejected trajectory repeats the previous row bit for bit (the first rows
+  // params_init itself, S:1018); only an accepted proposal is mapped back, q = mu + Tout y
+  T qc[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) qc[i] = scratch_row[i];
+  auto to_q = [&](const T (&y_)[D], T (&q_)[D]) {
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       T acc_ = mu[i];
 #pragma unroll
-      for (int k = 0; k < D; ++k) acc_ = fma(Tout[i][k], yc[k], acc_);
-      dst[i] = acc_;
+      for (int k = 0; k < D; ++k) acc_ = fma(Tout[i][k], y_[k], acc_);
+      q_[i] = acc_;
     }
   };
-  store_q(scratch_row);      // the same store a trajectory issues (to rounding the value it overwrites): keeps vmcnt uniform
+  auto store_q = [&](T* __restrict__ dst) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) dst[i] = qc[i];
+  };
+  {                          // the same store a trajectory issues (to rounding the value it overwrites): keeps vmcnt uniform
+    T q0[D];
+    to_q(yc, q0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) scratch_row[i] = q0[i];
+  }
   for (int t = 0; t < a.n_traj; ++t) {
     const int n = a.traj_offset + t;
     T zn[D], logun = 0;
@@ -667,13 +681,17 @@ __global__ __launch_bounds__(256) void hmc_gauss_eig_kernel(GaussArgs<T> a, cons
     const bool acc = mh_accept_logu<T>(h_old, h_new, logp1, logu);
     // ---- bookkeeping (S:1007-1026; Q2 reset at n == burn+1)
     rejected += acc ? 0 : 1;
+    T qp[D];
+    to_q(y, qp);
 #pragma unroll
-    for (int i = 0; i < D; ++i) yc[i] = acc ? y[i] : yc[i];
+    for (int i = 0; i < D; ++i) { yc[i] = acc ? y[i] : yc[i]; qc[i] = acc ? qp[i] : qc[i]; }
     quadc = acc ? quad1 : quadc;
     if (__builtin_expect(n == a.burn + 1, 0)) {                      // wave-uniform, once per run: kept off the hot path
       if (!acc) {
         to_y(a.theta_init + c * D, yc);
         quadc = potential(yc);
+#pragma unroll
+        for (int i = 0; i < D; ++i) qc[i] = a.theta_init[c * D + i];
       }
     }
     {
@@ -764,6 +782,9 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
     return q;
   };
   T yc = to_y(a.theta);
+  // the row element this lane stores: kept as it was written (a rejected trajectory repeats the previous row bit for bit,
+  // the first rows repeat params_init exactly, S:1018) - only an accepted proposal is mapped back, q = mu + Tout y
+  T qc = a.theta[c * D + kk];
   // Energies are carried DOUBLED (2 x potential share = lam y^2, 2 x kinetic share = r^2; the record holds 2 log u): one
   // multiply less per energy, and scaling by two commutes with rounding, so the decisions are those of the plain form.
   T potc = lam * yc * yc;                        // twice this coordinate's share of the potential at the current point
@@ -836,48 +857,47 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
       // ---- H_new S:995 and the MH test S:1000-1004
       const T pot1 = lam * y * y;
       const T en = fmaf(r, r, pot1);
+      // the proposal's row element q_k = mu_k + sum_j Tout[k][j] y_j: v_fmac_f32 with a DPP-broadcast operand.  Ordered after
+      // `en` (dummy operand): the instructions since the last write of y are the wait states its DPP read needs.
+      T qp;
+      static_assert(D >= 1 && D <= 4, "quad kernel");
+#define HTA_QF(J, OP) "\n\tv_fmac_f32_dpp %0, %1, %" #OP " quad_perm:[" #J "," #J "," #J "," #J "] row_mask:0xf bank_mask:0xf"
+      if constexpr (D == 1)
+        asm volatile("v_mov_b32 %0, %2" HTA_QF(0, 4) : "=&v"(qp) : "v"(y), "v"(mu), "v"(en), "v"(Qrow[0]));
+      else if constexpr (D == 2)
+        asm volatile("v_mov_b32 %0, %2" HTA_QF(0, 4) HTA_QF(1, 5)
+                     : "=&v"(qp) : "v"(y), "v"(mu), "v"(en), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]));
+      else if constexpr (D == 3)
+        asm volatile("v_mov_b32 %0, %2" HTA_QF(0, 4) HTA_QF(1, 5) HTA_QF(2, 6)
+                     : "=&v"(qp) : "v"(y), "v"(mu), "v"(en), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]), "v"(Qrow[D > 2 ? 2 : 0]));
+      else
+        asm volatile("v_mov_b32 %0, %2" HTA_QF(0, 4) HTA_QF(1, 5) HTA_QF(2, 6) HTA_QF(3, 7)
+                     : "=&v"(qp) : "v"(y), "v"(mu), "v"(en), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]), "v"(Qrow[D > 2 ? 2 : 0]),
+                       "v"(Qrow[D > 3 ? 3 : 0]));
+#undef HTA_QF
       const T dH = quad_sum(eo - en);                                               // 2 (h_old - h_new)
       // the decision as a lane mask (v_cmp into an SGPR pair), consumed by a carry-in add and two selects
       // rho = min(0, dH) >= log u  <=>  dH >= log u, because log u <= 0 (S:1000-1004).  A non-finite dH must reject:
       // fma(dH, 0, dH) is dH when dH is finite and NaN otherwise (inf * 0), and NaN >= x is false - one compare in all.
       const uint64_t accmask = __builtin_amdgcn_fcmpf(__builtin_fmaf(dH, 0.0f, dH), logu, 3 /* oge */);
-      T q;
       if constexpr (!decltype(q2)::value) {
-        // accepted += acc; yc, potc <- accepted point; q_k = mu_k + sum_j Tout[k][j] yc_j.  One block: the two instructions
-        // between the write of yc and its first DPP read (the select of potc, the move of mu) are the wait states it needs.
+        // accepted += acc; yc, potc, qc <- accepted point: a carry-in add and three selects on the accept mask
         uint64_t carry_out;
-        static_assert(D >= 1 && D <= 4, "quad kernel");
-#define HTA_QHEAD "v_addc_co_u32_e64 %0, %4, 0, %0, %5\n\tv_cndmask_b32_e64 %1, %1, %6, %5\n\tv_cndmask_b32_e64 %2, %2, %7, %5\n\t" \
-                  "v_mov_b32 %3, %8\n\t"
-#define HTA_QF(J, OP) "v_fmac_f32_dpp %3, %1, %" #OP " quad_perm:[" #J "," #J "," #J "," #J "] row_mask:0xf bank_mask:0xf"
-        if constexpr (D == 1)
-          asm volatile(HTA_QHEAD HTA_QF(0, 9)
-                       : "+v"(accepted), "+v"(yc), "+v"(potc), "=&v"(q), "=&s"(carry_out)
-                       : "s"(accmask), "v"(y), "v"(pot1), "v"(mu), "v"(Qrow[0]));
-        else if constexpr (D == 2)
-          asm volatile(HTA_QHEAD HTA_QF(0, 9) "\n\t" HTA_QF(1, 10)
-                       : "+v"(accepted), "+v"(yc), "+v"(potc), "=&v"(q), "=&s"(carry_out)
-                       : "s"(accmask), "v"(y), "v"(pot1), "v"(mu), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]));
-        else if constexpr (D == 3)
-          asm volatile(HTA_QHEAD HTA_QF(0, 9) "\n\t" HTA_QF(1, 10) "\n\t" HTA_QF(2, 11)
-                       : "+v"(accepted), "+v"(yc), "+v"(potc), "=&v"(q), "=&s"(carry_out)
-                       : "s"(accmask), "v"(y), "v"(pot1), "v"(mu), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]), "v"(Qrow[D > 2 ? 2 : 0]));
-        else
-          asm volatile(HTA_QHEAD HTA_QF(0, 9) "\n\t" HTA_QF(1, 10) "\n\t" HTA_QF(2, 11) "\n\t" HTA_QF(3, 12)
-                       : "+v"(accepted), "+v"(yc), "+v"(potc), "=&v"(q), "=&s"(carry_out)
-                       : "s"(accmask), "v"(y), "v"(pot1), "v"(mu), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]), "v"(Qrow[D > 2 ? 2 : 0]),
-                         "v"(Qrow[D > 3 ? 3 : 0]));
-#undef HTA_QHEAD
-#undef HTA_QF
+        asm volatile("v_addc_co_u32_e64 %0, %4, 0, %0, %5\n\tv_cndmask_b32_e64 %1, %1, %6, %5\n\tv_cndmask_b32_e64 %2, %2, %7, %5\n\t"
+                     "v_cndmask_b32_e64 %3, %3, %8, %5"
+                     : "+v"(accepted), "+v"(yc), "+v"(potc), "+v"(qc), "=&s"(carry_out)
+                     : "s"(accmask), "v"(y), "v"(pot1), "v"(qp));
       } else {
         uint64_t carry_out;
         asm("v_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(accepted), "=s"(carry_out) : "s"(accmask));
         asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(yc) : "v"(y), "s"(accmask));
         asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(potc) : "v"(pot1), "s"(accmask));
-        if (!((accmask >> (threadIdx.x & 63)) & 1)) { yc = to_y(a.theta_init); potc = lam * yc * yc; }
-        q = to_q(yc);
+        asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(qc) : "v"(qp), "s"(accmask));
+        if (!((accmask >> (threadIdx.x & 63)) & 1)) {        // Q2: back to params_init itself
+          yc = to_y(a.theta_init); potc = lam * yc * yc; qc = a.theta_init[c * D + kk];
+        }
       }
-      put(row, q);
+      put(row, qc);
       row += row_step;
       if (DIAG) {
         const bool acc = (accmask >> (threadIdx.x & 63)) & 1;
@@ -911,7 +931,7 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
     }
     while (t < t_end) { trajectory(zs[0], lus[0], plain); rotate(); }
   }
-  put((gwbytes_t)a.theta, to_q(yc));
+  put((gwbytes_t)a.theta, qc);
   if (a.reject_count && k == 0) a.reject_count[c] += a.n_traj - accepted;
 }
 
@@ -1173,7 +1193,9 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void hmc_gauss_wave_eig_kernel(Gaus
     for (int r = 0; r < R; ++r) s = fma(p[r], p[r], s);
     return (T)0.5 * wave_sum(s);
   };
-  T yc[R];
+  T yc[R], qc[R];                // qc: the current point as it is stored (a rejection repeats it bit for bit, S:1018)
+#pragma unroll
+  for (int r = 0; r < R; ++r) qc[r] = (lane + 64 * r < D) ? a.theta[c * D + lane + 64 * r] : (T)0;
   to_y(a.theta, yc);
   T quadc = potential(yc);
   const uint64_t chain = a.chain_offset + (uint64_t)c;
@@ -1202,28 +1224,28 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void hmc_gauss_wave_eig_kernel(Gaus
     const T h_new = -logp1 + kinetic(p);                                             // S:995
     const T u = u23<T>(philox_block(a.seed, chain, (uint32_t)n, PURPOSE_MH, 0, 0).x);
     const bool acc = mh_accept<T>(h_old, h_new, logp1, u);                           // S:1000-1004
-    T yinit[R];
+    T yinit[R], qp[R];
     if (n == a.burn + 1) to_y(a.theta_init, yinit);          // workgroup-uniform: the Q2 candidate of every chain
+    to_q(y, qp);                                              // workgroup-uniform: the proposal mapped back
     if (acc) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) yc[r] = y[r];
+      for (int r = 0; r < R; ++r) { yc[r] = y[r]; qc[r] = qp[r]; }
       quadc = quad1;
     } else {
       ++rejected;
-      if (n == a.burn + 1) {                                  // Q2 reset (S:1016-1018)
+      if (n == a.burn + 1) {                                  // Q2 reset (S:1016-1018): params_init itself
 #pragma unroll
-        for (int r = 0; r < R; ++r) yc[r] = yinit[r];
+        for (int r = 0; r < R; ++r) {
+          yc[r] = yinit[r];
+          qc[r] = (lane + 64 * r < D) ? a.theta_init[c * D + lane + 64 * r] : (T)0;
+        }
         quadc = potential(yc);
       }
     }
-    if (a.samples && n > a.burn) {                            // workgroup-uniform
-      T q[R];
-      to_q(yc, q);
-      if (live) {
-        T* row = a.samples + ((int64_t)(n - a.burn) * a.C + c) * D;
+    if (a.samples && n > a.burn && live) {
+      T* row = a.samples + ((int64_t)(n - a.burn) * a.C + c) * D;
 #pragma unroll
-        for (int r = 0; r < R; ++r) if (lane + 64 * r < D) row[lane + 64 * r] = q[r];
-      }
+      for (int r = 0; r < R; ++r) if (lane + 64 * r < D) row[lane + 64 * r] = qc[r];
     }
     if (live && lane == 0) {
       if (a.H_old) a.H_old[(int64_t)t * a.C + c] = h_old;
@@ -1231,11 +1253,9 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void hmc_gauss_wave_eig_kernel(Gaus
       if (a.accept) a.accept[(int64_t)t * a.C + c] = acc ? 1 : 0;
     }
   }
-  T q[R];
-  to_q(yc, q);
   if (live) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) if (lane + 64 * r < D) a.theta[c * D + lane + 64 * r] = q[r];
+    for (int r = 0; r < R; ++r) if (lane + 64 * r < D) a.theta[c * D + lane + 64 * r] = qc[r];
     if (lane == 0 && a.reject_count) a.reject_count[c] += rejected;
   }
 }

@@ -623,7 +623,5 @@ def test_eigenbasis_routes_with_indefinite_curvature_and_divergence(ht, D):
     big = ht.sample(t, th0, num_samples=6, num_steps_per_sample=400, step_size=2.0, verbose=False, seed=4)
     s = torch.stack(big)
     assert torch.isfinite(s).all()
-    # every proposal diverged and was rejected: the rows repeat bit for bit; against params_init they differ by the rounding of
-    # the eigenbasis round trip q = mu + Q (Q^T (q - mu))
-    assert torch.equal(s[-1], s[1])
-    np.testing.assert_allclose(s[-1].cpu().numpy(), s[0].cpu().numpy(), atol=1e-6)
+    # every proposal diverged and was rejected: the rows repeat params_init bit for bit (S:1018), as in the reference
+    assert torch.equal(s[-1], s[0])
