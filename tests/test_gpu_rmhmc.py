@@ -514,7 +514,8 @@ def test_fused_momentum_overlap_equals_serial(ht, T):
     assert not np.array_equal(outs[0][0][1], outs[0][1][1])
 
 
-@pytest.mark.parametrize("D,C,jit", [(24, 40, 1e-3), (100, 50, 1e-3), (100, 33, None), (112, 17, 1e-3), (7, 16, 1e-3)])
+@pytest.mark.parametrize("D,C,jit", [(24, 40, 1e-3), (100, 50, 1e-3), (100, 33, None), (112, 17, 1e-3), (7, 16, 1e-3),
+                                     (100, 2050, 1e-3)])
 def test_batched_mfma_kernel_equals_fused_kernel(ht, D, C, jit):
     """rmhmc_batch_kernel (16 chains per workgroup, S X and P X as v_mfma_f32_16x16x4_f32 tiles) against rmhmc_fused_kernel
     (one chain per workgroup, the parity reference of this path): same streams and update order, sums in a different order ->
@@ -524,7 +525,7 @@ def test_batched_mfma_kernel_equals_fused_kernel(ht, D, C, jit):
     t, _ = cfg3_target(ht, D, torch.float32, seed=9)
     th0 = tt((0.3 * O.philox_normals(3, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32), torch.float32)
     outs = []
-    for mode in (2, 0):
+    for mode in (2 if C < 2048 else 1, 0):          # from 2048 chains on the default route is the batched kernel
         _abi.set_tuning("rmhmc_batch", mode)
         try:
             cur = th0.clone(); rej = torch.zeros(C, dtype=torch.int32, device=dev())
