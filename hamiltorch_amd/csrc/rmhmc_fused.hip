@@ -600,9 +600,12 @@ __global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int
 // from 2048 chains per GPU on (hta_set_tuning("rmhmc_batch", 0) off, 2 always); there the per-trajectory Cholesky of the
 // momentum draw is the next limit.
 // =============================================================================================
-constexpr int BNC = 16, BLD = 116, BWV = 7, BNT = 64 * BWV, BKJ = 28;
+constexpr int BNC = 16, BLD = 116, BWV = 7, BNT = 64 * BWV, BSEG = 28;
 typedef float bf4 __attribute__((ext_vector_type(4)));
 
+// BKJ: MFMAs per product and row tile = K / 4 (25 for D <= 100, 28 up to 112).  A vector is stored in four segments of BSEG
+// floats (16-byte aligned); element `row` sits in segment row / BKJ at offset row % BKJ.
+template <int BKJ>
 __global__ __launch_bounds__(BNT) void rmhmc_batch_kernel(FusedArgs<float> a) {
   typedef float T;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -632,19 +635,30 @@ __global__ __launch_bounds__(BNT) void rmhmc_batch_kernel(FusedArgs<float> a) {
   }
   for (int e = tid; e < 7 * MSZ + BWV * BNC * 4; e += BNT) lds[e] = 0.f;
   const T eh = 0.5f * a.eps;
-  const int own_off = cl * BLD + row0, b_off = cl * BLD + BKJ * g;
+  int own_pos[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) own_pos[e] = cl * BLD + ((row0 + e) / BKJ) * BSEG + (row0 + e) % BKJ;
+  const int b_off = cl * BLD + BSEG * g;
   int dpar = 0;
   T ev_r[4] = {0.f, 0.f, 0.f, 0.f};
   uint64_t chain = 0;
   bool live = false;
 
-  auto put4 = [&](T* X, const T (&v)[4]) { *reinterpret_cast<bf4*>(X + own_off) = bf4{v[0], v[1], v[2], v[3]}; };
+  auto put4 = [&](T* X, const T (&v)[4]) {
+    if constexpr (BKJ == BSEG) *reinterpret_cast<bf4*>(X + own_pos[0]) = bf4{v[0], v[1], v[2], v[3]};
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (rok[e]) X[own_pos[e]] = v[e];     // rows >= D have no slot in this layout (and stay 0)
+    }
+  };
   auto load_b = [&](const T* X, T (&b)[BKJ]) {
 #pragma unroll
     for (int q = 0; q < BKJ / 4; ++q) {
       const bf4 v = *reinterpret_cast<const bf4*>(X + b_off + 4 * q);
       b[4 * q] = v[0]; b[4 * q + 1] = v[1]; b[4 * q + 2] = v[2]; b[4 * q + 3] = v[3];
     }
+#pragma unroll
+    for (int j = (BKJ / 4) * 4; j < BKJ; ++j) b[j] = X[b_off + j];
   };
   auto jitter4 = [&](uint32_t n, uint32_t sub) {            // this lane's four rows are one Philox block (uniform_elem layout)
     if (!a.has_jitter) return;
@@ -1011,15 +1025,19 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
         if (batch) {
           static bool dn_b = false;
           if (!dn_b) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rmhmc_batch_kernel),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rmhmc_batch_kernel<25>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+              e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rmhmc_batch_kernel<28>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) { set_error("hta_rmhmc_gaussian_sample: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
             dn_b = true;
           }
           const int64_t ngroup = (C + BNC - 1) / BNC;
           const size_t blds = (size_t)(7 * BNC * BLD + BWV * BNC * 4) * sizeof(float);
           profile_begin(s);
-          rmhmc_batch_kernel<<<(int)(ngroup < 4096 ? ngroup : 4096), BNT, blds, s>>>(a);
+          if (D <= 100) rmhmc_batch_kernel<25><<<(int)(ngroup < 4096 ? ngroup : 4096), BNT, blds, s>>>(a);
+          else rmhmc_batch_kernel<28><<<(int)(ngroup < 4096 ? ngroup : 4096), BNT, blds, s>>>(a);
           profile_end(s);
           return HTA_OK;
         }
