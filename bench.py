@@ -319,6 +319,9 @@ def main():
             torch.cuda.synchronize()
 
     from hamiltorch_amd import _abi
+    for kv in filter(None, os.environ.get("HTA_TUNING", "").split(",")):      # e.g. HTA_TUNING=rmhmc_momwave=0 (A/B runs)
+        key, val = kv.split("=")
+        _abi.set_tuning(key, int(val))
     for k in range(a.warmup):
         w.step(k)
     w.rej.zero_()

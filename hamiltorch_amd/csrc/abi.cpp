@@ -13,6 +13,7 @@ void set_error(const char* fmt, ...) {
 int g_small_chains_per_block = 0;  // 0 = default (64)
 int g_force_general = 0;
 int g_rmhmc_batch = 1;     // fused RMHMC: 16 chains per workgroup on the matrix cores from 2048 chains on (0 off, 2 always)
+int g_rmhmc_momwave = 1;   // fused RMHMC: momentum draws by the wave-per-task kernel (fp32, jitter, D <= 104); 0: workgroup-per-task kernel
 int g_rmhmc_overlap = 1;   // fused RMHMC: momentum draws of the next block of trajectories on a side stream
 int g_gauss_eig = 1;       // small-D identity-mass Gaussian HMC integrates in the eigenbasis of P (0: direct kernel, 2: chain per lane only)
 int g_fill_blocks = 4096;        // grid cap of the pre-draw pass (256-thread blocks, grid-stride)
@@ -75,6 +76,7 @@ int hta_set_tuning(const char* key, int value) {
   if (!strcmp(key, "small_chains_per_block")) { hta::g_small_chains_per_block = value; return HTA_OK; }
   if (!strcmp(key, "force_general")) { hta::g_force_general = value; return HTA_OK; }
   if (!strcmp(key, "gauss_eig")) { hta::g_gauss_eig = value; return HTA_OK; }
+  if (!strcmp(key, "rmhmc_momwave")) { hta::g_rmhmc_momwave = value; return HTA_OK; }
   if (!strcmp(key, "rmhmc_overlap")) { hta::g_rmhmc_overlap = value; return HTA_OK; }
   if (!strcmp(key, "rmhmc_batch")) { hta::g_rmhmc_batch = value; return HTA_OK; }
   if (!strcmp(key, "quad_max_chains")) { hta::g_quad_max_chains = value; return HTA_OK; }

@@ -889,6 +889,173 @@ __global__ __launch_bounds__(FNT) void rmhmc_momentum_kernel(const T* __restrict
   }
 }
 
+// The same draws, one WAVE per task, the work matrix in registers (fp32, jitter on, D <= 8 NB).  The workgroup kernel above
+// is bound by its LDS round trips: every trailing-update FMA reads its operands from LDS and writes its result back (1.5
+// LDS operations per FMA, 2 workgroup barriers per panel, 3 tasks per CU: 53 us per task at D = 100).  Here lane
+// (ty, tx) = (l >> 3, l & 7) owns the elements (ty + 8a, tx + 8b), b <= a, of the lower triangle (NB(NB+1)/2 VGPRs); only
+// the current panel of 4 columns passes through LDS (one 16-byte row per lane in, one out), the rank-4 update reads 4
+// panel values per block row / block column (16-byte loads) for 4 FMAs per owned element, there are no workgroup
+// barriers, and the factor is never stored: p = L z is accumulated row by row as the panels finish (row r belongs to
+// lane r & 63).  12+ tasks per CU.  Same streams and the same factor as rmhmc_momentum_kernel; the sums of p run in
+// panel order.
+template <int NB>
+__global__ __launch_bounds__(64) void rmhmc_momentum_wave_kernel(const float* __restrict__ P, float jitter, int64_t C, int D,
+                                                                 int n_traj, int traj_offset, uint64_t seed, uint64_t chain_offset,
+                                                                 float* __restrict__ p_ws) {
+  constexpr int NR = 8 * NB;                             // padded rows
+  constexpr int NROW = (NR + 63) / 64;                   // rows per lane in the panel step
+  __shared__ __attribute__((aligned(16))) float pan[NR * 4], pan2[NR * 4], zv[NR], evv[NR];
+  const int l = threadIdx.x, ty = l >> 3, tx = l & 7;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  for (int e = l; e < NR * 4; e += 64) { pan[e] = 0.f; pan2[e] = 0.f; }
+  const int64_t ntask = (int64_t)n_traj * C;
+  for (int64_t task = blockIdx.x; task < ntask; task += gridDim.x) {
+    const int t = (int)(task / C);
+    const int64_t c = task - (int64_t)t * C;
+    const uint64_t chain = chain_offset + (uint64_t)c;
+    const uint32_t n = (uint32_t)(traj_offset + t);
+    // ---- this task's matrix: W = P + diag(jitter u)  (S:113-116), lower blocks, straight from L2
+    // (rows / columns >= D are clamped copies: a factor's leading D x D part does not depend on what lies beyond it, and
+    //  nothing of the padding is stored.  P does not depend on the task: the compiler keeps these loads out of the task
+    //  loop, i.e. P's share of a lane stays in VGPRs for the launch - 2 waves per SIMD at NB = 13)
+    float W[NB][NB];
+#pragma unroll
+    for (int a = 0; a < NB; ++a) {
+      const float* rowp = P + min(ty + 8 * a, D - 1) * D;
+#pragma unroll
+      for (int b = 0; b <= a; ++b) W[a][b] = rowp[min(tx + 8 * b, D - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < NROW; ++q) {
+      const int r = l + 64 * q;
+      if (r < NR) {
+        evv[r] = r < D ? jitter * uniform_elem<float>(seed, chain, n, PURPOSE_JITTER, 0, r) : 0.f;
+        zv[r] = r < D ? normal_elem<float>(seed, chain, n, 0, r) : 0.f;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (ty == tx) {
+#pragma unroll
+      for (int a = 0; a < NB; ++a) W[a][a] += evv[ty + 8 * a];
+    }
+    float pacc[NROW];
+#pragma unroll
+    for (int q = 0; q < NROW; ++q) pacc[q] = 0.f;
+
+    for (int bp = 0; bp < NB; ++bp) {
+      if (8 * bp >= D) break;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int kb = 8 * bp + 4 * half;
+        if (kb < D) {
+          // ---- the panel's columns kb .. kb+3 (block column bp) leave their owners' registers
+          if ((tx >> 2) == half) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              if (b == bp) {                               // uniform: one of the NB bodies runs, register indices stay static
+#pragma unroll
+                for (int a = b; a < NB; ++a) pan[(ty + 8 * a) * 4 + (tx & 3)] = W[a][b];
+              }
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          // ---- diagonal block factor (every lane, registers), then the panel rows this lane handles
+          float Ld[4][4], rinv[4];
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const f4 rowv = *reinterpret_cast<const f4*>(pan + (kb + cc) * 4);
+            const bool in = kb + cc < D;
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2) Ld[cc][c2] = (in && c2 <= cc) ? rowv[c2] : (cc == c2 ? 1.f : 0.f);
+          }
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+            for (int c2 = 0; c2 < cc; ++c2) {
+              float v = Ld[cc][c2];
+#pragma unroll
+              for (int c3 = 0; c3 < c2; ++c3) v = fmaf(-Ld[cc][c3], Ld[c2][c3], v);
+              Ld[cc][c2] = v * rinv[c2];
+            }
+            float v = Ld[cc][cc];
+#pragma unroll
+            for (int c3 = 0; c3 < cc; ++c3) v = fmaf(-Ld[cc][c3], Ld[cc][c3], v);
+            rinv[cc] = fast_rsqrt<float>(v);
+            Ld[cc][cc] = v * rinv[cc];
+          }
+          const f4 zk = *reinterpret_cast<const f4*>(zv + kb);
+#pragma unroll
+          for (int q = 0; q < NROW; ++q) {
+            const int r = l + 64 * q;
+            if (r < NR) {
+              f4 out = {0.f, 0.f, 0.f, 0.f};
+              if (r >= kb + 4) {
+                const f4 wv = *reinterpret_cast<const f4*>(pan + r * 4);
+                float lrow[4];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                  float v = wv[cc];
+#pragma unroll
+                  for (int c3 = 0; c3 < cc; ++c3) v = fmaf(-lrow[c3], Ld[cc][c3], v);
+                  lrow[cc] = v * rinv[cc];
+                  pacc[q] = fmaf(lrow[cc], zk[cc], pacc[q]);
+                }
+                out = f4{lrow[0], lrow[1], lrow[2], lrow[3]};
+              } else if (r >= kb) {                        // a row of the diagonal block: its finished entries times z
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+                  if (r == kb + cc) {
+#pragma unroll
+                    for (int c2 = 0; c2 <= cc; ++c2) pacc[q] = fmaf(Ld[cc][c2], zk[c2], pacc[q]);
+                  }
+              }
+              if (r >= kb) *reinterpret_cast<f4*>(pan2 + r * 4) = out;      // rows of finished panels hold zeros: no-op updates
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          // ---- rank-4 update of the owned blocks right of / below the panel
+          // (block columns in chunks of CH: CH column vectors live at a time instead of NB)
+          constexpr int CH = 4;
+#pragma unroll
+          for (int b0 = 0; b0 < NB; b0 += CH) {
+            if (b0 + CH > bp) {
+              f4 lj[CH];
+#pragma unroll
+              for (int u = 0; u < CH; ++u) if (b0 + u < NB) lj[u] = *reinterpret_cast<const f4*>(pan2 + (tx + 8 * (b0 + u)) * 4);
+#pragma unroll
+              for (int a = b0; a < NB; ++a) {
+                if (a >= bp) {
+                  const f4 li = *reinterpret_cast<const f4*>(pan2 + (ty + 8 * a) * 4);
+#pragma unroll
+                  for (int u = 0; u < CH; ++u) {
+                    if (b0 + u <= a) {                     // columns left of the panel see zeros in pan2: no-op updates
+                      float v = W[a][b0 + u];
+#pragma unroll
+                      for (int cc = 0; cc < 4; ++cc) v = fmaf(-li[cc], lj[u][cc], v);
+                      W[a][b0 + u] = v;
+                    }
+                  }
+                }
+              }
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NROW; ++q) {
+      const int r = l + 64 * q;
+      if (r < D) p_ws[task * D + r] = pacc[q];
+    }
+    // pan2 holds zeros again except the last panel's diagonal rows (written as zeros above): nothing to clear
+  }
+}
+
 // S = V0 diag(1 / lam0) V0^T from the eigen-system of the jitter-free P (one workgroup; once per run)
 template <typename T>
 __global__ void inverse_from_eigen_kernel(const T* __restrict__ V0, const T* __restrict__ lam0, T* __restrict__ S, int D) {
@@ -997,7 +1164,30 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
       }
       const int64_t ntask = (int64_t)nt * C;
       const int mgrid = (int)(ntask < 256 * 12 ? ntask : 256 * 12);
-      if (ov) {
+      bool wave_done = false;
+      if constexpr (sizeof(T) == 4) {
+        // fp32 with jitter (a factorisation per task), D <= 104: one wave per task, work matrix in registers
+        if (g_rmhmc_momwave && has_jitter && D <= 104) {
+          hipStream_t ms = ov ? ov->side : s;
+          const int wgrid = (int)(ntask < 256 * 16 ? ntask : 256 * 16);
+          if (ov) { if (bidx >= 2) (void)hipStreamWaitEvent(ov->side, ov->freed[bidx & 1], 0); }
+          else profile_begin(s);
+          const int nb = (D + 7) / 8;
+#define HTA_MOMWAVE(NB) rmhmc_momentum_wave_kernel<NB><<<wgrid, 64, 0, ms>>>(P, (float)jitter, C, D, nt, traj_offset + t0, seed, chain_offset, p_blk)
+          if (nb <= 4) HTA_MOMWAVE(4);
+          else if (nb <= 7) HTA_MOMWAVE(7);
+          else if (nb <= 10) HTA_MOMWAVE(10);
+          else HTA_MOMWAVE(13);
+#undef HTA_MOMWAVE
+          if (ov) {
+            (void)hipEventRecord(ov->ready[bidx & 1], ov->side);
+            (void)hipStreamWaitEvent(s, ov->ready[bidx & 1], 0);
+          } else profile_end(s);
+          wave_done = true;
+        }
+      }
+      if (wave_done) {
+      } else if (ov) {
         if (bidx >= 2) (void)hipStreamWaitEvent(ov->side, ov->freed[bidx & 1], 0);     // trajectories of block b-2 are done with it
         rmhmc_momentum_kernel<T><<<mgrid, FNT, mlds, ov->side>>>(P, has_jitter, (T)jitter, C, D, ld, nt, traj_offset + t0, seed,
                                                                  chain_offset, p_blk);

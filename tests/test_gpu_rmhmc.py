@@ -543,3 +543,37 @@ def test_batched_mfma_kernel_equals_fused_kernel(ht, D, C, jit):
     assert np.array_equal(outs[0][1][good], outs[1][1][good])
     np.testing.assert_allclose(outs[0][2][good], outs[1][2][good], atol=2e-4)
     assert np.abs(outs[0][0][T - 1 - burn] - outs[0][0][1]).max() > 1e-3          # rows 1 .. T-1-burn are written
+
+
+@pytest.mark.parametrize("D,C,jit,batch", [(7, 19, 1e-3, 0), (24, 40, 1e-2, 0), (50, 33, 1e-3, 0), (77, 21, 1e-3, 0),
+                                           (100, 50, 1e-3, 0), (104, 9, 1e-3, 0), (100, 40, 1e-3, 2)])
+def test_wave_momentum_kernel_equals_workgroup_kernel(ht, D, C, jit, batch):
+    """rmhmc_momentum_wave_kernel (one wave per draw, the work matrix in registers, p = L z accumulated panel by panel) against
+    rmhmc_momentum_kernel (Cholesky in LDS, then the triangular product): same jitter / normal streams and the same factor;
+    the sums of p run in a different order -> whole runs agree chain by chain to rounding, every NB instance, ragged D."""
+    from hamiltorch_amd import _abi
+    T, L, burn = 9, 3, 2
+    t, _ = cfg3_target(ht, D, torch.float32, seed=11)
+    th0 = tt((0.3 * O.philox_normals(5, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32), torch.float32)
+    outs = []
+    _abi.set_tuning("rmhmc_batch", batch)
+    try:
+        for mode in (1, 0):
+            _abi.set_tuning("rmhmc_momwave", mode)
+            cur = th0.clone(); rej = torch.zeros(C, dtype=torch.int32, device=dev())
+            samples = torch.zeros(T - burn + 1, C, D, device=dev())
+            ws = torch.empty(_abi.rmhmc_workspace_bytes(C, D, 4, T), dtype=torch.uint8, device=dev())
+            _abi.rmhmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, _abi.METRIC_SOFTABS, 1e6, jit, L, 0.1, 10.0,
+                                       T, 0, burn, 23, 0, samples, rej, ws)
+            torch.cuda.synchronize()
+            outs.append((samples.cpu().numpy(), rej.cpu().numpy(), cur.cpu().numpy()))
+    finally:
+        _abi.set_tuning("rmhmc_momwave", 1)
+        _abi.set_tuning("rmhmc_batch", 1)
+    assert np.isfinite(outs[0][0]).all()
+    err = np.abs(outs[0][0] - outs[1][0]).max(axis=(0, 2))
+    assert (err > 2e-4).mean() <= 0.05, "max err %.3g (%d chains differ)" % (err.max(), (err > 2e-4).sum())
+    good = err <= 2e-4
+    assert np.array_equal(outs[0][1][good], outs[1][1][good])
+    np.testing.assert_allclose(outs[0][2][good], outs[1][2][good], atol=2e-4)
+    assert np.abs(outs[0][0][T - 1 - burn] - outs[0][0][1]).max() > 1e-3
