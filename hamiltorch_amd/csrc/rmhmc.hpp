@@ -32,6 +32,7 @@ void profile_end(hipStream_t s);
 extern int g_rmhmc_fused;                                   // tuning key "rmhmc_fused" (default 1)
 extern int g_rmhmc_batch;                                   // tuning key "rmhmc_batch" (default 1)
 extern int g_rmhmc_momwave;                                 // tuning key "rmhmc_momwave" (default 1)
+extern int g_rmhmc_mfma4, g_rmhmc_mfma4_lo, g_rmhmc_mfma4_hi;    // tuning keys "rmhmc_mfma4" (default 1), "rmhmc_mfma4_lo", "rmhmc_mfma4_hi"
 extern int g_rmhmc_overlap;                                 // tuning key "rmhmc_overlap" (default 1)
 template <typename T>
 int fused_plan(const T* lam0_host, int D, int metric, double alpha, int has_jitter, double jitter, double* logdetP, int* series);

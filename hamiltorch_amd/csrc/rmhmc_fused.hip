@@ -852,6 +852,276 @@ __global__ __launch_bounds__(BNT) void rmhmc_batch_kernel(FusedArgs<float> a) {
   }
 }
 
+// =============================================================================================
+// The same run, FOUR chains per workgroup: v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4 x 4, K = 1; fp32, D <= 100)
+//
+// rmhmc_batch_kernel needs 16 chains per workgroup (the N of its 16 x 16 tile), i.e. C / 16 workgroups: at 1024 chains it
+// keeps 64 of the 256 CUs busy.  The 16-block form has N = 4: block b multiplies rows 4b .. 4b+3 of A with the SAME 4
+// columns, so one wave covers 64 rows x 4 chains per instruction and two waves a whole product - C / 4 workgroups of two
+// waves, one wave per SIMD, the matrix pipes of every CU in use from 512 chains on.  Same flop rate per instruction
+// (64 flop / clk / SIMD), same ownership: lane (b, n) = (l >> 2, l & 3) supplies A[64w + l][k] (S and P: 2 x 100 VGPRs for
+// the launch) and X[n][k] (LDS, 16-byte reads, the same address for the 16 lanes of a chain) and receives
+// C[64w + 4b + r][n], r < 4: four consecutive rows of chain n = one Philox block of jitter, element-wise work in registers.
+// Same streams, same update order and barriers as rmhmc_batch_kernel; a product's sum runs over k = 0 .. D-1 in order.
+// =============================================================================================
+constexpr int QNC = 4, QLD = 116, QWV = 2, QNT = 64 * QWV, QK = 100;
+
+__global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
+  typedef float T;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* lds = reinterpret_cast<T*>(smem_raw);
+  constexpr int MSZ = QNC * QLD;
+  T* PM = lds; T* PMC = PM + MSZ; T* D0 = PMC + MSZ; T* D1 = D0 + MSZ; T* W0 = D1 + MSZ; T* W1 = W0 + MSZ; T* EV = W1 + MSZ;
+  T* red = EV + MSZ;                                      // [QWV][QNC][4]
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cl = l & 3, blk = l >> 2;
+  const int D = a.D;
+  const int row0 = 64 * w + 4 * blk, arow = 64 * w + l;
+  T Sa[QK], Pa[QK];
+#pragma unroll
+  for (int k = 0; k < QK; ++k) {
+    const bool ok = arow < D && k < D;
+    Sa[k] = ok ? a.S[(int64_t)k * D + arow] : 0.f;        // symmetric: column arow, coalesced over the lanes
+    Pa[k] = ok ? a.P[(int64_t)k * D + arow] : 0.f;
+  }
+  T mu_r[4], sd_r[4];
+  bool rok[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int r = row0 + e;
+    rok[e] = r < D;
+    mu_r[e] = rok[e] ? a.mu[r] : 0.f;
+    sd_r[e] = rok[e] ? a.S[(int64_t)r * D + r] : 0.f;
+  }
+  for (int e = tid; e < 7 * MSZ + QWV * QNC * 4; e += QNT) lds[e] = 0.f;
+  const T eh = 0.5f * a.eps;
+  const bool rany = row0 < QLD;                           // rows 116 .. 127 have no slot (and are >= D)
+  const int own_off = cl * QLD + row0, b_off = cl * QLD;
+  int dpar = 0;
+  T ev_r[4] = {0.f, 0.f, 0.f, 0.f};
+  uint64_t chain = 0;
+  bool live = false;
+
+  auto put4 = [&](T* X, const T (&v)[4]) { if (rany) *reinterpret_cast<bf4*>(X + own_off) = bf4{v[0], v[1], v[2], v[3]}; };
+  auto jitter4 = [&](uint32_t n, uint32_t sub) {            // this lane's four rows are one Philox block (uniform_elem layout)
+    if (!a.has_jitter) return;
+    const U4 r = philox_block(a.seed, chain, n, PURPOSE_JITTER, sub, (uint32_t)(row0 >> 2));
+    const T u[4] = {u23<T>(r.x), u23<T>(r.y), u23<T>(r.z), u23<T>(r.w)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ev_r[e] = (live && rok[e]) ? a.jitter * u[e] : 0.f;
+  };
+  // One wave per SIMD: nothing else hides an LDS round trip, so the operand chunks (4 values of k per 16-byte read) are
+  // fetched two chunks (16 MFMAs = 128 clocks) ahead of their use.
+  auto chunk = [&](const T* X, int q) { return *reinterpret_cast<const bf4*>(X + b_off + 4 * q); };
+  // two products with one pass over k: acc1 = A1 X1, acc2 = A2 X2 (two independent accumulator chains)
+  auto prod2 = [&](const T (&A1)[QK], const T* X1, const T (&A2)[QK], const T* X2, bf4& acc1, bf4& acc2) {
+    bf4 c1 = chunk(X1, 0), c2 = chunk(X2, 0), n1 = chunk(X1, 1), n2 = chunk(X2, 1);
+#pragma unroll
+    for (int q = 0; q < QK / 4; ++q) {
+      bf4 f1 = n1, f2 = n2;
+      if (q + 2 < QK / 4) { f1 = chunk(X1, q + 2); f2 = chunk(X2, q + 2); }
+      __builtin_amdgcn_sched_barrier(0);                    // (the scheduler otherwise sinks the reads next to their use)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1[4 * q + u], c1[u], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(A2[4 * q + u], c2[u], acc2, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      c1 = n1; c2 = n2; n1 = f1; n2 = f2;
+    }
+  };
+  // x = (P + diag(e))^-1 m continued from x0 = S m (rmhmc_fused_kernel: refine)
+  auto refine = [&](const T (&x0)[4], T (&xr)[4]) {
+    for (int it = 0; it < a.K; ++it) {
+      const T* wr = (it & 1) ? W1 : W0;
+      T* ww = (it & 1) ? W0 : W1;
+      __syncthreads();
+      bf4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};      // even / odd k: two chains keep the pipe issuing
+      bf4 c = chunk(wr, 0), n1 = chunk(wr, 1), n2 = chunk(wr, 2);
+#pragma unroll
+      for (int q = 0; q < QK / 4; ++q) {
+        bf4 f = n2;
+        if (q + 3 < QK / 4) f = chunk(wr, q + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        sa = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q], c[0], sa, 0, 0, 0);
+        sb = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q + 1], c[1], sb, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q + 2], c[2], sa, 0, 0, 0);
+        sb = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q + 3], c[3], sb, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        c = n1; n1 = n2; n2 = f;
+      }
+      T wv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { xr[e] = x0[e] - (sa[e] + sb[e]); wv[e] = ev_r[e] * xr[e]; }
+      put4(ww, wv);
+    }
+  };
+  // one half step: upd_x += eh G(X)^-1 m ; upd_g -= eh P (X - mu)   (rmhmc_fused_kernel: half_step)
+  auto half_step = [&](uint32_t n, uint32_t sub, const T (&X)[4], const T* m, T (&upd_x)[4], T (&upd_g)[4], T* upd_g_lds) {
+    T* d = dpar ? D1 : D0;
+    dpar ^= 1;
+    T dv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dv[e] = rok[e] ? X[e] - mu_r[e] : 0.f;
+    put4(d, dv);
+    __syncthreads();
+    bf4 Pd = {0.f, 0.f, 0.f, 0.f}, x0v = {0.f, 0.f, 0.f, 0.f};
+    prod2(Pa, d, Sa, m, Pd, x0v);
+    jitter4(n, sub);            // first needed after the products: its Philox rounds issue under the MFMAs
+    T x0[4], xr[4], wv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      upd_g[e] -= eh * Pd[e];
+      x0[e] = x0v[e]; xr[e] = x0v[e];
+      wv[e] = ev_r[e] * x0v[e];
+    }
+    put4(upd_g_lds, upd_g);
+    put4(W0, wv);
+    refine(x0, xr);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) upd_x[e] += eh * xr[e];
+  };
+  // three sums per chain over the rows, complete in every lane of the chain's column
+  auto block_sums = [&](T (&v)[3]) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      v[e] += __shfl_xor(v[e], 4, 64);
+      v[e] += __shfl_xor(v[e], 8, 64);
+      v[e] += __shfl_xor(v[e], 16, 64);
+      v[e] += __shfl_xor(v[e], 32, 64);
+    }
+    __syncthreads();
+    if (blk == 0) {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) red[(w * QNC + cl) * 4 + e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      T s = 0.f;
+#pragma unroll
+      for (int i = 0; i < QWV; ++i) s += red[(i * QNC + cl) * 4 + e];
+      v[e] = s;
+    }
+  };
+  // H = -log p + D/2 log 2 pi + 1/2 log|G| + 1/2 m^T G^-1 m  (S:731)   (rmhmc_fused_kernel: hamiltonian, series branch)
+  auto hamiltonian = [&](uint32_t n, uint32_t sub, const T (&X)[4], const T* m, const T (&mr)[4], T& H, T& logp) {
+    T* d = dpar ? D1 : D0;
+    dpar ^= 1;
+    jitter4(n, sub);
+    T dr[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dr[e] = rok[e] ? X[e] - mu_r[e] : 0.f;
+    put4(EV, ev_r);
+    put4(d, dr);
+    __syncthreads();
+    bf4 Pd = {0.f, 0.f, 0.f, 0.f}, x0v = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    prod2(Pa, d, Sa, m, Pd, x0v);
+    if (a.has_jitter) {                                     // second-order log-det term: (S . S) e
+      bf4 c = chunk(EV, 0), n1 = chunk(EV, 1), n2 = chunk(EV, 2), s2b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < QK / 4; ++q) {
+        bf4 f = n2;
+        if (q + 3 < QK / 4) f = chunk(EV, q + 3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u += 2) {
+          s2 = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q + u] * Sa[4 * q + u], c[u], s2, 0, 0, 0);
+          s2b = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q + u + 1] * Sa[4 * q + u + 1], c[u + 1], s2b, 0, 0, 0);
+        }
+        c = n1; n1 = n2; n2 = f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s2[e] += s2b[e];
+    }
+    T v[3] = {0.f, 0.f, 0.f}, x0[4], xr[4], wv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      x0[e] = x0v[e]; xr[e] = x0v[e];
+      v[0] += dr[e] * Pd[e];
+      wv[e] = ev_r[e] * x0v[e];
+      if (a.has_jitter) v[2] += ev_r[e] * (sd_r[e] - 0.5f * s2[e]);      // log|P + E| = log|P| + tr(SE) - 1/2 tr((SE)^2) + ...
+    }
+    put4(W0, wv);
+    refine(x0, xr);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[1] += mr[e] * xr[e];
+    block_sums(v);
+    const float pi_term = (float)D * 1.8378770351409912f;   // S:712
+    logp = a.log_norm - 0.5f * v[0];
+    H = -logp + 0.5f * pi_term + 0.5f * (a.logdetP + v[2]) + 0.5f * v[1];
+  };
+
+  const int64_t ngroup = (a.C + QNC - 1) / QNC;
+  for (int64_t cg = blockIdx.x; cg < ngroup; cg += gridDim.x) {
+    const int64_t c = QNC * cg + cl;
+    live = c < a.C;
+    chain = a.chain_offset + (uint64_t)(live ? c : 0);
+    T scur[4], sth[4], spm[4], sthc[4], spmc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) scur[e] = (live && rok[e]) ? a.cur[c * D + row0 + e] : 0.f;
+    int32_t rejected = 0;
+    __syncthreads();                                        // the previous group's last reads of the vector matrices
+    for (int t = 0; t < a.n_traj; ++t) {
+      const uint32_t n = (uint32_t)(a.traj_offset + t);
+      // ---- gibbs: p = chol(G(theta)) z, drawn ahead by the momentum kernel (S:183-184)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) spm[e] = (live && rok[e]) ? a.p_ws[((int64_t)t * a.C + c) * D + row0 + e] : 0.f;
+      put4(PM, spm);
+      T H0, H1, lp0, lp1;
+      hamiltonian(n, 1, scur, PM, spm, H0, lp0);            // S:971 -> S:822
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { sth[e] = scur[e]; sthc[e] = scur[e]; spmc[e] = spm[e]; }   // S:425-426
+      put4(PMC, spm);
+      for (int lstep = 0; lstep < a.L; ++lstep) {           // S:427-461
+        const uint32_t k0 = 2u + 8u * (uint32_t)lstep;
+        half_step(n, k0 + 1, sth, PMC, sthc, spm, PM);      // phi_A/2  S:429-430
+        half_step(n, k0 + 2, sthc, PM, sth, spmc, PMC);     // phi_B/2  S:432-433
+        if (a.K == 0) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                       // phi_C    S:447-450, sequential (Q1)
+          T xx = sth[e], b = spm[e], xc = sthc[e], bc = spmc[e];
+          const T h = 0.5f, cc = a.rot_c, ss = a.rot_s;
+          xx = h * ((xx + xc) + cc * (xx - xc) + ss * (b - bc));
+          b = h * ((b + bc) - ss * (xx - xc) + cc * (b - bc));
+          xc = h * ((xx + xc) - cc * (xx - xc) - ss * (b - bc));
+          bc = h * ((b + bc) + ss * (xx - xc) - cc * (b - bc));
+          sth[e] = xx; spm[e] = b; sthc[e] = xc; spmc[e] = bc;
+        }
+        put4(PM, spm);
+        put4(PMC, spmc);
+        half_step(n, k0 + 4, sthc, PM, sth, spmc, PMC);     // phi_B/2  S:454-455
+        half_step(n, k0 + 7, sth, PMC, sthc, spm, PM);      // phi_A/2  S:457-458
+      }
+      hamiltonian(n, 2u + 8u * (uint32_t)a.L, sth, PM, spm, H1, lp1);   // S:989 (Q4)
+      // ---- Metropolis test + bookkeeping (S:1000-1026, S:1045-1057)
+      const T u = u23<T>(philox_block(a.seed, chain, n, PURPOSE_MH, 0, 0).x);
+      const bool acc = mh_accept<T>(H0, H1, lp1, u);
+      const bool reset = (!acc) && ((int)n == a.burn + 1);  // Q2
+      if (live) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (rok[e]) {
+            const T vnew = acc ? sth[e] : (reset ? a.theta_init[c * D + row0 + e] : scur[e]);
+            scur[e] = vnew;
+            if (a.samples && (int)n > a.burn) a.samples[((int64_t)((int)n - a.burn) * a.C + c) * D + row0 + e] = vnew;
+          }
+        }
+        if (w == 0 && blk == 0) {
+          if (a.H_old) a.H_old[(int64_t)t * a.C + c] = H0;
+          if (a.H_new) a.H_new[(int64_t)t * a.C + c] = H1;
+          if (a.accept) a.accept[(int64_t)t * a.C + c] = acc ? 1 : 0;
+        }
+      }
+      if (!acc) ++rejected;
+    }
+    if (live) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (rok[e]) a.cur[c * D + row0 + e] = scur[e];
+      if (w == 0 && blk == 0) a.reject_count[c] += rejected;
+    }
+  }
+}
+
 // The momentum draws of a block of trajectories, off the chains' critical path: task (t, c) -> p = chol(P + diag(e)) z
 // with the jitter sub-stream 0 and the normals of (chain c, trajectory traj_offset + t)  (S:183-184).  One workgroup per
 // task at a time, 3 per CU: the factorisations of different tasks overlap each other's LDS latency, which the chain-
@@ -907,6 +1177,7 @@ __global__ __launch_bounds__(64) void rmhmc_momentum_wave_kernel(const float* __
   __shared__ __attribute__((aligned(16))) float pan[NR * 4], pan2[NR * 4], zv[NR], evv[NR];
   const int l = threadIdx.x, ty = l >> 3, tx = l & 7;
   typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
   for (int e = l; e < NR * 4; e += 64) { pan[e] = 0.f; pan2[e] = 0.f; }
   const int64_t ntask = (int64_t)n_traj * C;
   for (int64_t task = blockIdx.x; task < ntask; task += gridDim.x) {
@@ -1024,14 +1295,24 @@ __global__ __launch_bounds__(64) void rmhmc_momentum_wave_kernel(const float* __
             if (b0 + CH > bp) {
               f4 lj[CH];
 #pragma unroll
-              for (int u = 0; u < CH; ++u) if (b0 + u < NB) lj[u] = *reinterpret_cast<const f4*>(pan2 + (tx + 8 * (b0 + u)) * 4);
+              for (int u = 0; u < CH; ++u) lj[u] = (b0 + u < NB) ? *reinterpret_cast<const f4*>(pan2 + (tx + 8 * (b0 + u)) * 4) : f4{0.f, 0.f, 0.f, 0.f};
+              f2 ljp[CH / 2][4];
+#pragma unroll
+              for (int u = 0; u < CH; u += 2)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) ljp[u >> 1][cc] = f2{lj[u][cc], lj[u + 1][cc]};
 #pragma unroll
               for (int a = b0; a < NB; ++a) {
                 if (a >= bp) {
                   const f4 li = *reinterpret_cast<const f4*>(pan2 + (ty + 8 * a) * 4);
 #pragma unroll
-                  for (int u = 0; u < CH; ++u) {
-                    if (b0 + u <= a) {                     // columns left of the panel see zeros in pan2: no-op updates
+                  for (int u = 0; u < CH; u += 2) {        // two columns per v_pk_fma_f32 (columns left of the panel see zeros
+                    if (b0 + u + 1 <= a) {                 //  in pan2: no-op updates)
+                      f2 v = {W[a][b0 + u], W[a][b0 + u + 1]};
+#pragma unroll
+                      for (int cc = 0; cc < 4; ++cc) v = __builtin_elementwise_fma(f2{-li[cc], -li[cc]}, ljp[u >> 1][cc], v);
+                      W[a][b0 + u] = v[0]; W[a][b0 + u + 1] = v[1];
+                    } else if (b0 + u <= a) {
                       float v = W[a][b0 + u];
 #pragma unroll
                       for (int cc = 0; cc < 4; ++cc) v = fmaf(-li[cc], lj[u][cc], v);
@@ -1209,6 +1490,19 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
     const bool pair = g_rmhmc_fused == 3 && block > 0 && (series || !has_jitter);
     const bool need_w = !(block > 0 && (series || !has_jitter));      // a Cholesky inside the kernel: work matrix in LDS
     auto launch = [&](auto kern, auto kern2, bool& dn, bool& dn2) -> int {
+      if constexpr (sizeof(T) == 4) {
+        // four chains per workgroup on the 16-block matrix instruction: C / 4 two-wave workgroups (tuning key "rmhmc_mfma4")
+        const bool quad4 = g_rmhmc_mfma4 && !pair && block > 0 && (series || !has_jitter) && D <= QK &&
+                           ((C >= g_rmhmc_mfma4_lo && C < g_rmhmc_mfma4_hi) || g_rmhmc_mfma4 == 2);
+        if (quad4) {
+          const int64_t ngroup = (C + QNC - 1) / QNC;
+          const size_t qlds = (size_t)(7 * QNC * QLD + QWV * QNC * 4) * sizeof(float);
+          profile_begin(s);
+          rmhmc_mfma4_kernel<<<(int)(ngroup < 8192 ? ngroup : 8192), QNT, qlds, s>>>(a);
+          profile_end(s);
+          return HTA_OK;
+        }
+      }
       if constexpr (sizeof(T) == 4) {
         const bool batch = g_rmhmc_batch && !pair && block > 0 && (series || !has_jitter) && D <= 16 * BWV &&
                            (C >= 2048 || g_rmhmc_batch == 2);

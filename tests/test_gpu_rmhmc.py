@@ -525,8 +525,9 @@ def test_batched_mfma_kernel_equals_fused_kernel(ht, D, C, jit):
     t, _ = cfg3_target(ht, D, torch.float32, seed=9)
     th0 = tt((0.3 * O.philox_normals(3, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32), torch.float32)
     outs = []
-    for mode in (2 if C < 2048 else 1, 0):          # from 2048 chains on the default route is the batched kernel
+    for mode in (2, 0):
         _abi.set_tuning("rmhmc_batch", mode)
+        _abi.set_tuning("rmhmc_mfma4", 0)           # (from 704 to 2048 chains the default route is rmhmc_mfma4_kernel)
         try:
             cur = th0.clone(); rej = torch.zeros(C, dtype=torch.int32, device=dev())
             samples = torch.zeros(T - burn + 1, C, D, device=dev())
@@ -536,6 +537,7 @@ def test_batched_mfma_kernel_equals_fused_kernel(ht, D, C, jit):
             torch.cuda.synchronize()
         finally:
             _abi.set_tuning("rmhmc_batch", 1)
+            _abi.set_tuning("rmhmc_mfma4", 1)
         outs.append((samples.cpu().numpy(), rej.cpu().numpy(), cur.cpu().numpy()))
     err = np.abs(outs[0][0] - outs[1][0]).max(axis=(0, 2))
     assert (err > 2e-4).mean() <= 0.05, "max err %.3g (%d chains differ)" % (err.max(), (err > 2e-4).sum())
@@ -577,3 +579,61 @@ def test_wave_momentum_kernel_equals_workgroup_kernel(ht, D, C, jit, batch):
     assert np.array_equal(outs[0][1][good], outs[1][1][good])
     np.testing.assert_allclose(outs[0][2][good], outs[1][2][good], atol=2e-4)
     assert np.abs(outs[0][0][T - 1 - burn] - outs[0][0][1]).max() > 1e-3
+
+
+@pytest.mark.parametrize("D,C,jit", [(7, 9, 1e-3), (24, 33, 1e-3), (64, 18, 1e-3), (65, 7, 1e-3), (100, 50, 1e-3), (100, 33, None),
+                                     (100, 1030, 1e-3)])
+def test_mfma4_kernel_equals_fused_kernel(ht, D, C, jit):
+    """rmhmc_mfma4_kernel (4 chains per two-wave workgroup, S X and P X on v_mfma_f32_4x4x1_16b_f32) against rmhmc_fused_kernel
+    (one chain per workgroup): same streams and update order, sums in a different order -> chain by chain to rounding, with
+    ragged groups, burn-in (Q2 reset), D on both sides of a wave's 64 rows, and without jitter."""
+    from hamiltorch_amd import _abi
+    T, L, burn = 9, 3, 2
+    t, _ = cfg3_target(ht, D, torch.float32, seed=9)
+    th0 = tt((0.3 * O.philox_normals(3, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32), torch.float32)
+    outs = []
+    try:
+        for mode in (2 if C < 704 else 1, 0):      # from 704 to 2048 chains it is the default route
+            _abi.set_tuning("rmhmc_mfma4", mode)
+            _abi.set_tuning("rmhmc_batch", 0)
+            cur = th0.clone(); rej = torch.zeros(C, dtype=torch.int32, device=dev())
+            samples = torch.zeros(T - burn + 1, C, D, device=dev())
+            ws = torch.empty(_abi.rmhmc_workspace_bytes(C, D, 4, T), dtype=torch.uint8, device=dev())
+            _abi.rmhmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, _abi.METRIC_SOFTABS, 1e6, jit, L, 0.1, 10.0,
+                                       T, 0, burn, 21, 0, samples, rej, ws)
+            torch.cuda.synchronize()
+            outs.append((samples.cpu().numpy(), rej.cpu().numpy(), cur.cpu().numpy()))
+    finally:
+        _abi.set_tuning("rmhmc_mfma4", MFMA4_DEFAULT)
+        _abi.set_tuning("rmhmc_batch", 1)
+    assert np.isfinite(outs[0][0]).all()
+    err = np.abs(outs[0][0] - outs[1][0]).max(axis=(0, 2))
+    assert (err > 2e-4).mean() <= 0.05, "max err %.3g (%d chains differ)" % (err.max(), (err > 2e-4).sum())
+    good = err <= 2e-4
+    assert np.array_equal(outs[0][1][good], outs[1][1][good])
+    np.testing.assert_allclose(outs[0][2][good], outs[1][2][good], atol=2e-4)
+    assert np.abs(outs[0][0][T - 1 - burn] - outs[0][0][1]).max() > 1e-3
+
+
+MFMA4_DEFAULT = 1      # the library's default for the "rmhmc_mfma4" tuning key (csrc/abi.cpp)
+
+
+@pytest.mark.parametrize("C", [1024, 2050, 4100])
+def test_sample_rmhmc_cfg5_shapes_vs_oracle(ht, C):
+    """sample(RMHMC, EXPLICIT, SOFTABS) at D=100 on the default routes of large batches (1024 chains:
+    rmhmc_mfma4_kernel; 2050 and 4100: rmhmc_batch_kernel; momenta from rmhmc_momentum_wave_kernel) against the oracle on the
+    first and last chains of the batch (same Philox streams; SURVEY 8c tolerance 1e-4 on theta)."""
+    D, N, L, eps, omega, alpha, seed, off, jitter = 100, 4, 2, 0.1, 10.0, 1e6, 77, 5, 1e-3
+    t, o = cfg3_target(ht, D, torch.float32, seed=0)
+    th0 = (0.1 * O.philox_normals(seed, off + np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32)
+    out = ht.sample(t, tt(th0, torch.float32), num_samples=N, num_steps_per_sample=L, step_size=eps, jitter=jitter,
+                    softabs_const=alpha, explicit_binding_const=omega, sampler=ht.Sampler.RMHMC,
+                    integrator=ht.Integrator.EXPLICIT, metric=ht.Metric.SOFTABS, verbose=False, seed=seed, chain_offset=off)
+    got = np.stack([x.cpu().numpy() for x in out])
+    sel = np.r_[0:3, C - 3:C]
+    ref, _ = O.sample_rmhmc_explicit(o, th0[sel], N, L, eps, omega, alpha, 0, jitter, O.PhiloxDraws(seed, off + sel, np.float32), "softabs")
+    want = np.stack(ref)
+    assert np.isfinite(got).all() and got.shape == (N, C, D)
+    err = np.abs(got[:, sel] - want).max(axis=(0, 2))
+    assert (err < 3e-4).sum() >= len(sel) - 1, err
+    assert np.abs(got[-1] - got[0]).mean() > 1e-3
