@@ -179,7 +179,19 @@ class Cfg3:
         # per step; the soft-abs map is the identity on this spectrum, see DESIGN.md.)
         return 4 * 4 * 2 * self.D ** 2 + (2 * self.D ** 3 / 3) / self.L
 
-    roof_kernel = "rmhmc_fused_kernel<float,56>"
+    @property
+    def roof_kernel(self):      # the trajectory kernel the library picks at this chain count (csrc/rmhmc_fused.hip dispatch)
+        if "roof_kernel" in self.__dict__:
+            return self.__dict__["roof_kernel"]
+        if self.C < 704:
+            return "rmhmc_fused_kernel<float,56,1> (one chain per workgroup)"
+        if self.C <= 2048:
+            return "rmhmc_mfma4_kernel (4 chains per workgroup, v_mfma_f32_4x4x1_16b)"
+        return "rmhmc_batch_kernel<25> (16 chains per workgroup, v_mfma_f32_16x16x4) + rmhmc_momentum_wave_kernel<13>"
+
+    @roof_kernel.setter
+    def roof_kernel(self, v):
+        self.__dict__["roof_kernel"] = v
 
     def bytes_per_unit(self):
         return 32 * self.D
@@ -361,10 +373,11 @@ def main():
                     "kernel": getattr(w, "roof_kernel", "metric_eval_kernel<float>"),
                     "kernel_ms_per_step": kernel_ms, "launches_per_step": prof_n / max(1, a.steps),
                     "algorithmic_flops_per_chain_step": w.flops_per_unit(),
-                    "note": "fp32 vector == fp32 MFMA peak (157.3 TF).  cfg3: flops the fused kernel executes (shared-inverse "
-                            "solves + one Cholesky per trajectory; the eigh route of the reference would be 4.5e7 per step), "
-                            "one 4-wave workgroup per chain: latency bound at 256 chains; cfg4: 2M x 6 flop per (point, weight) "
-                            "per split step (SURVEY 8d)"}
+                    "note": "fp32 vector == fp32 MFMA peak (157.3 TF).  cfg3: flops the fused route executes (shared-inverse "
+                            "solves + one Cholesky per trajectory; the eigh route of the reference would be 4.5e7 per step); "
+                            "kernel time = every profiled launch of a step (trajectory kernels, and the momentum kernel when it "
+                            "runs on the same stream); below 704 chains one 4-wave workgroup per chain: latency bound; cfg4: "
+                            "2M x 6 flop per (point, weight) per split step (SURVEY 8d)"}
         else:
             roof = None
         traffic = None
