@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: leapfrog-steps/sec at 1024 chains per GPU (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5]
 
 One "step" = one pass of the hot path over one batch: a single launch of the fused trajectory
 kernel that runs `--traj` whole trajectories (momentum draw, H, L leapfrog steps, H, Metropolis,
@@ -226,6 +226,18 @@ class Cfg3:
                 "acceptance": acc}
 
 
+class Cfg5(Cfg3):
+    """BASELINE config 5: cfg3 sharded over the node, 1024 chains per GPU (8192 on 8 GPUs), 100 trajectories per step; the one
+    collective of the path - the gather of samples[S, C/G, D] over RCCL - runs after the timed region and is reported as
+    `gather_ms` (excluded from the rate, 8e)."""
+    name = "cfg5: cfg3 (D=100 explicit RMHMC, softabs, jitter=1e-3, L=10) sharded, 1024 chains per GPU"
+    chains, traj = 1024, 100
+
+    def gather(self, world):
+        from hamiltorch_amd.dist import gather_samples
+        return gather_samples(self.samples, self.C * world)
+
+
 class Cfg4:
     """BASELINE config 4: Bayesian MLP 8-100-1 (D=1001), 400 points, symmetric split HMC M=4, 512 chains."""
     name = "cfg4: MLP Linear(8,100)-ReLU-Linear(100,1) regression, split HMC M=4 x 100 points, eps=5e-4, L=10"
@@ -290,7 +302,7 @@ class Cfg4:
                           "autograd per half kick, as the reference), %.1f s" % (n, self.L, dt), "acceptance": acc}
 
 
-WORKLOADS = {"cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4}
+WORKLOADS = {"cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4, "cfg5": Cfg5}
 
 
 def main():
@@ -361,6 +373,15 @@ def main():
     acc = w.check()
     units = w.units_per_step() * a.steps * world
     value = units / dt
+    gather_ms = None
+    if hasattr(w, "gather"):            # the path's only collective, outside the timed region
+        barrier()
+        tg = time.perf_counter()
+        gathered = w.gather(world)
+        barrier()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        assert gathered.shape[1] == w.C * world
+        del gathered
 
     if rank == 0:
         alg_bytes = w.bytes_per_unit() * w.units_per_step()
@@ -408,6 +429,10 @@ def main():
             "acceptance_rate": acc,
             "ess_per_sec": ess / (call_ms * 1e-3),
         }
+        if gather_ms is not None:
+            out["gather_ms"] = gather_ms
+            out["config"]["parallelism"] += "; one all_gather of samples[%d, %d, %d] per rank after the timed region" % (
+                w.T + 1, w.C, W.D)
         if world == 1 and not a.no_cpu_baseline:
             cb = w.cpu_baseline(a.cpu_seconds)
             if cb is not None:

@@ -10,6 +10,7 @@ import torch
 import hmc_oracle as O
 
 pytestmark = pytest.mark.gpu
+MFMA4_DEFAULT = 1      # the library's default for the "rmhmc_mfma4" tuning key (csrc/abi.cpp)
 NP = {torch.float32: np.float32, torch.float64: np.float64}
 
 
@@ -614,8 +615,6 @@ def test_mfma4_kernel_equals_fused_kernel(ht, D, C, jit):
     np.testing.assert_allclose(outs[0][2][good], outs[1][2][good], atol=2e-4)
     assert np.abs(outs[0][0][T - 1 - burn] - outs[0][0][1]).max() > 1e-3
 
-
-MFMA4_DEFAULT = 1      # the library's default for the "rmhmc_mfma4" tuning key (csrc/abi.cpp)
 
 
 @pytest.mark.parametrize("C", [1024, 2050, 4100])
