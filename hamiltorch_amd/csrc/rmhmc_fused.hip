@@ -1468,6 +1468,7 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
         }
       }
       if (wave_done) {
+        // drawn by the wave-per-draw kernel above
       } else if (ov) {
         if (bidx >= 2) (void)hipStreamWaitEvent(ov->side, ov->freed[bidx & 1], 0);     // trajectories of block b-2 are done with it
         rmhmc_momentum_kernel<T><<<mgrid, FNT, mlds, ov->side>>>(P, has_jitter, (T)jitter, C, D, ld, nt, traj_offset + t0, seed,

@@ -289,7 +289,8 @@ int hta_mlp_logp_grad_f64(const double* theta, int64_t C, int n_in, int H, int a
                           const double* Y, int N, int M, int Nb, int split, const double* tau4, double tau_out,
                           double prior_scale, double* grad_out, double* logp_out, void* stream);
 
-/* measurement knobs: "small_chains_per_block" (launch shape of the thread-per-chain kernel),
+/* measurement knobs: "small_chains_per_block" (launch shape of the thread-per-chain kernel), "fill_blocks" (grid cap of the
+ * pre-draw pass of the Gaussian path: 256-thread blocks, grid-stride; 4096),
  * "force_general" (route small D through the wave-per-chain kernel), "profile" (N > 0 = record a HIP
  * event pair around the dominant kernel of every N-th fused call, on the launch stream);
  * route selectors kept for the parity tests: "gauss_eig" (1 default; 0 = direct small-D Gaussian kernel, 2 = eigenbasis with

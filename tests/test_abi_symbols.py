@@ -49,3 +49,20 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dp, f)).read()
                 assert "hmc_oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_every_tuning_key_is_documented_and_accepted():
+    """every key hta_set_tuning accepts (csrc/abi.cpp) is described in the header, and setting it back to its default works
+    without a GPU (the keys only select routes / launch shapes)."""
+    from hamiltorch_amd import _abi
+    src = open(os.path.join(ROOT, "hamiltorch_amd", "csrc", "abi.cpp")).read()
+    keys = re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', src)
+    assert len(keys) >= 10 and len(set(keys)) == len(keys)
+    header = open(os.path.join(ROOT, "include", "hamiltorch_amd.h")).read()
+    for k in keys:
+        assert '"%s"' % k in header, "tuning key %s is not documented in include/hamiltorch_amd.h" % k
+    defaults = dict(re.findall(r"int g_([a-z0-9_]+) = (\d+)", src))
+    lib = _abi.load()
+    for k in keys:
+        if k in defaults:
+            assert lib.hta_set_tuning(k.encode(), int(defaults[k])) == 0
