@@ -540,6 +540,56 @@ def gen_logcosh():
     np.savez(os.path.join(OUT, "logcosh.npz"), **out)
 
 
+def gen_cfg3():
+    """BASELINE config 3 at full size: D=100, P = Q diag(linspace(.5, 2, 100)) Q^T (generator seed 0), soft-abs
+    metric alpha=1e6, omega=10, eps=0.1 - metric pieces, Hamiltonian, a 3-step explicit leapfrog path without jitter
+    (fp32 + fp64), a 2-step path with jitter=1e-3 and the reference's torch.rand(D) draws recorded in call order, and an
+    end-to-end sample() with every draw recorded."""
+    out = {}
+    D, alpha, omega, eps, jitter = 100, 1e6, 10.0, 0.1, 1e-3
+    P64 = rand_spd(D, 0)
+    out["cfg"] = np.array([D, alpha, omega, eps, jitter])
+    g = torch.Generator().manual_seed(3)
+    th64 = 0.1 * torch.randn(D, generator=g, dtype=torch.float64)
+    pm64 = torch.randn(D, generator=g, dtype=torch.float64)
+    kw = dict(explicit_binding_const=omega, softabs_const=alpha, sampler=hamiltorch.Sampler.RMHMC,
+              integrator=hamiltorch.Integrator.EXPLICIT, metric=hamiltorch.Metric.SOFTABS)
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        P, th, pm = P64.to(dt), th64.to(dt), pm64.to(dt)
+        lp = quad_logp(P)
+        out[f"P_{tag}"] = npy(P); out[f"theta0_{tag}"] = npy(th); out[f"p0_{tag}"] = npy(pm)
+        G, lam = S.fisher(th, lp, jitter=None, softabs_const=alpha, metric=hamiltorch.Metric.SOFTABS)
+        out[f"lam_{tag}"] = npy(lam); out[f"Gdiag_{tag}"] = npy(torch.diagonal(G))
+        out[f"Ginvp_{tag}"] = npy(S.cholesky_inverse(G.detach(), pm)).reshape(-1)
+        out[f"H_{tag}"] = npy(S.rm_hamiltonian(th, pm, lp, None, 1.0, softabs_const=alpha, metric=hamiltorch.Metric.SOFTABS)).reshape(-1)
+        lpar, lmom = S.leapfrog(th, pm, lp, steps=3, step_size=eps, jitter=None, **kw)
+        out[f"lf_theta_{tag}"] = np.stack([npy(t) for t in lpar[0]]); out[f"lf_p_{tag}"] = np.stack([npy(t) for t in lmom[0]])
+        out[f"lf_thetac_{tag}"] = npy(lpar[1]); out[f"lf_pc_{tag}"] = npy(lmom[1])
+    # with jitter: 8 fisher() calls per step, each with its own torch.rand(D) (S:115)
+    P, th, pm = P64.float(), th64.float(), pm64.float()
+    lp = quad_logp(P)
+    hamiltorch.set_random_seed(5)
+    with Recorder() as rec:
+        lpar, lmom = S.leapfrog(th, pm, lp, steps=2, step_size=eps, jitter=jitter, **kw)
+    assert len(rec.jitters) == 16, len(rec.jitters)
+    out["jit_draws"] = np.stack(rec.jitters)
+    out["jit_lf_theta"] = np.stack([npy(t) for t in lpar[0]]); out["jit_lf_p"] = np.stack([npy(t) for t in lmom[0]])
+    # end to end, jitter on: per trajectory 1 (gibbs) + 1 (H) + 8 L (leapfrog) + 1 (H) metric evaluations
+    N, L = 4, 2
+    hamiltorch.set_random_seed(9)
+    with Recorder() as rec:
+        ret, acc = hamiltorch.sample(lp, th.clone(), num_samples=N, num_steps_per_sample=L, step_size=eps, burn=0, jitter=jitter,
+                                     debug=2, verbose=False, **kw)
+    assert len(rec.momenta) == N and len(rec.jitters) == N * (8 * L + 3), (len(rec.momenta), len(rec.jitters))
+    out["e2e_cfg"] = np.array([N, L])
+    out["e2e_samples"] = np.stack([npy(t) for t in ret])
+    out["e2e_momenta"] = np.stack(rec.momenta)
+    out["e2e_uniforms"] = np.concatenate(rec.uniforms)
+    out["e2e_jitters"] = np.stack(rec.jitters)
+    out["e2e_acc"] = np.array(acc)
+    np.savez_compressed(os.path.join(OUT, "cfg3.npz"), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                      # python oracle/gen_golden.py funnel  -> only that family
         for name in sys.argv[1:]:
@@ -555,5 +605,6 @@ if __name__ == "__main__":
     gen_splitkinds()
     gen_logcosh()
     gen_blockmass()
+    gen_cfg3()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

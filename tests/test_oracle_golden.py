@@ -423,3 +423,59 @@ def test_block_list_inv_mass(golden):
     # the block list is the block-diagonal full matrix
     full = np.zeros((5, 5), np.float32); full[:2, :2] = g["b0"]; full[2:, 2:] = g["b1"]
     np.testing.assert_allclose(O.kinetic(pm, blocks), O.kinetic(pm, full), rtol=1e-6)
+
+
+@pytest.mark.parametrize("tag,dt,tol,htol", [("f32", np.float32, 1e-4, 1e-3), ("f64", np.float64, 1e-9, 1e-9)])
+def test_cfg3_full_size_metric_hamiltonian_leapfrog(golden, tag, dt, tol, htol):
+    """BASELINE config 3 at D=100 against the unmodified reference (tests/golden/cfg3.npz): soft-abs eigenvalues, G^-1 p,
+    the Riemannian Hamiltonian and every step of a 3-step explicit leapfrog path.  SURVEY 8c tolerances: 1e-4 on theta / p,
+    1e-3 on H in fp32 (the reference's own fp32-vs-fp64 distance is 1e-6)."""
+    g = golden("cfg3")
+    D, alpha, omega, eps, _ = g["cfg"]
+    P = g[f"P_{tag}"]
+    tgt = O.GaussianTarget(np.zeros(int(D), dt), P)
+    th, pm = g[f"theta0_{tag}"][None], g[f"p0_{tag}"][None]
+    G, lam, _ = O.softabs_metric(tgt.neg_hessian(th), alpha, metric="softabs")
+    np.testing.assert_allclose(np.sort(lam[0]), np.sort(g[f"lam_{tag}"]), rtol=tol, atol=tol)
+    np.testing.assert_allclose(np.diagonal(G[0]), g[f"Gdiag_{tag}"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(O.cholesky_inverse(G, pm)[0][0], g[f"Ginvp_{tag}"], rtol=tol, atol=tol)
+    H, _ = O.rm_hamiltonian(th, pm, tgt, alpha, metric="softabs")
+    np.testing.assert_allclose(H, g[f"H_{tag}"], rtol=0, atol=htol)
+    for n in (1, 2, 3):
+        a, b, c, d = O.explicit_rmhmc_leapfrog(th, pm, tgt, n, eps, omega, alpha, metric="softabs")
+        np.testing.assert_allclose(a[0], g[f"lf_theta_{tag}"][n - 1], rtol=0, atol=tol)
+        np.testing.assert_allclose(b[0], g[f"lf_p_{tag}"][n - 1], rtol=0, atol=tol)
+    np.testing.assert_allclose(c[0], g[f"lf_thetac_{tag}"], rtol=0, atol=tol)
+    np.testing.assert_allclose(d[0], g[f"lf_pc_{tag}"], rtol=0, atol=tol)
+
+
+def test_cfg3_full_size_leapfrog_with_recorded_jitter(golden):
+    """cfg3 with jitter=1e-3: the reference draws torch.rand(D) in each of the 8 metric evaluations of a step (S:115); the
+    recorded draws replayed in call order through the oracle give the reference's path."""
+    g = golden("cfg3")
+    D, alpha, omega, eps, jitter = g["cfg"]
+    tgt = O.GaussianTarget(np.zeros(int(D), np.float32), g["P_f32"])
+    th, pm = g["theta0_f32"][None], g["p0_f32"][None]
+    draws = g["jit_draws"]
+    for n in (1, 2):
+        a, b, _, _ = O.explicit_rmhmc_leapfrog(th, pm, tgt, n, eps, omega, alpha, jitter, lambda k: draws[k][None])
+        np.testing.assert_allclose(a[0], g["jit_lf_theta"][n - 1], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(b[0], g["jit_lf_p"][n - 1], rtol=0, atol=1e-4)
+    # the jitter matters at this tolerance: without it the path is measurably different
+    a0, _, _, _ = O.explicit_rmhmc_leapfrog(th, pm, tgt, 2, eps, omega, alpha)
+    assert np.abs(a0[0] - g["jit_lf_theta"][1]).max() > 1e-6
+
+
+def test_cfg3_full_size_sample_end_to_end(golden):
+    """hamiltorch.sample(RMHMC, EXPLICIT, SOFTABS, jitter=1e-3) at D=100 with every draw of the reference recorded
+    (momenta, Metropolis uniforms, the 8 L + 3 jitter vectors per trajectory)."""
+    g = golden("cfg3")
+    D, alpha, omega, eps, jitter = g["cfg"]
+    N, L = (int(v) for v in g["e2e_cfg"])
+    tgt = O.GaussianTarget(np.zeros(int(D), np.float32), g["P_f32"])
+    draws = O.ReplayDraws(g["e2e_momenta"], g["e2e_uniforms"], jitters=g["e2e_jitters"], jitters_per_traj=8 * L + 3)
+    ret, info = O.sample_rmhmc_explicit(tgt, g["theta0_f32"][None], N, L, eps, omega, alpha, burn=0, jitter=jitter, draws=draws)
+    ref = g["e2e_samples"]
+    assert len(ret) == ref.shape[0]
+    np.testing.assert_allclose(np.concatenate(ret), ref, rtol=0, atol=2e-4)
+    assert abs(info["acc_rate"][0] - float(g["e2e_acc"])) < 1e-9
