@@ -540,6 +540,88 @@ def gen_logcosh():
     np.savez(os.path.join(OUT, "logcosh.npz"), **out)
 
 
+def gen_cfg2():
+    """BASELINE config 2's per-chain computation: KAT2 target, identity mass, L=25, eps=0.3 - 25-step leapfrog
+    paths from four starts (fp32 + fp64) and an end-to-end sample() of 40 trajectories with the draws recorded."""
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    th0 = 0.1 * torch.randn(4, 3, generator=g, dtype=torch.float64)
+    pm0 = torch.randn(4, 3, generator=g, dtype=torch.float64)
+    out["theta0"] = npy(th0); out["p0"] = npy(pm0)
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        lp = mvn_logp(torch.zeros(3, dtype=dt), torch.tensor(SIGMA3, dtype=dt))
+        ths, pms = [], []
+        for k in range(4):
+            p, m = S.leapfrog(th0[k].to(dt), pm0[k].to(dt), lp, steps=25, step_size=0.3,
+                              sampler=hamiltorch.Sampler.HMC, integrator=hamiltorch.Integrator.EXPLICIT)
+            ths.append(np.stack([npy(x) for x in p])); pms.append(np.stack([npy(x) for x in m]))
+        out[f"lf_theta_{tag}"] = np.stack(ths); out[f"lf_p_{tag}"] = np.stack(pms)        # [start, step, 3]
+    lp = mvn_logp(torch.zeros(3), torch.tensor(SIGMA3))
+    hamiltorch.set_random_seed(77)
+    with Recorder() as rec:
+        ret, acc = hamiltorch.sample(lp, th0[0].float(), num_samples=40, num_steps_per_sample=25, step_size=0.3, burn=0,
+                                     debug=2, verbose=False)
+    out["e2e_samples"] = np.stack([npy(t) for t in ret])
+    out["e2e_momenta"] = np.stack(rec.momenta)
+    out["e2e_uniforms"] = np.concatenate(rec.uniforms)
+    out["e2e_acc"] = np.array(acc)
+    np.savez(os.path.join(OUT, "cfg2.npz"), **out)
+
+
+def gen_cfg4():
+    """BASELINE config 4 at full size: Linear(8,100)-ReLU-Linear(100,1) (D=1001), X = randn(400, 8), w = randn(8, 1),
+    Y = sin(X w) + 0.1 randn (generator seed 0), 4 splits of 100 points, tau_out=100, tau_list=ones(4), inv_mass=ones(D),
+    eps=5e-4, L=10: full-data log-prob + gradient, the split closures, one SPLITTING leapfrog path of L steps and
+    end-to-end sample_split_model / sample_model runs with the reference's draws recorded.  Same key layout as mlp.npz."""
+    out = {}
+    name, dims, N, M, tau_out, eps, L = "relu_cfg4", [8, 100, 1], 400, 4, 100.0, 5e-4, 10
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(N, 8, generator=g); w = torch.randn(8, 1, generator=g)
+    Y = torch.sin(X @ w) + 0.1 * torch.randn(N, 1, generator=g)
+    net = make_mlp(dims, "relu", 0)
+    theta = hamiltorch.util.flatten(net).clone().detach()
+    D = theta.numel()
+    tau_list = torch.ones(4)
+    pfl = [t.nelement() for t in net.parameters()]
+    psl = [t.shape for t in net.parameters()]
+    out[f"{name}_dims"] = np.array(dims); out[f"{name}_X"] = npy(X); out[f"{name}_Y"] = npy(Y)
+    out[f"{name}_theta"] = npy(theta); out[f"{name}_tau_list"] = npy(tau_list)
+    out[f"{name}_cfg"] = np.array([M, tau_out, eps, L])
+    f = S.define_model_log_prob(net, "regression", X, Y, pfl, psl, tau_list, tau_out)
+    th = theta.clone().requires_grad_()
+    v = f(th)
+    out[f"{name}_logp"] = npy(v).reshape(-1)
+    out[f"{name}_grad"] = npy(torch.autograd.grad(v.sum(), th)[0])
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(X, Y), batch_size=N // M, shuffle=False)
+    fl = S.define_split_model_log_prob(net, "regression", loader, M, pfl, psl, tau_list, tau_out, verbose=False)
+    out[f"{name}_split_logp"] = np.array([float(fm(theta).sum()) for fm in fl])
+    p0 = torch.randn(D, generator=torch.Generator().manual_seed(2))
+    inv_mass = torch.ones(D)
+    out[f"{name}_p0"] = npy(p0)
+    out[f"{name}_H0"] = npy(S.hamiltonian(theta, p0, fl, inv_mass=inv_mass, sampler=hamiltorch.Sampler.HMC)).reshape(-1)
+    lp_, lm_ = S.leapfrog(theta.clone(), p0.clone(), fl, steps=L, step_size=eps, inv_mass=inv_mass,
+                          sampler=hamiltorch.Sampler.HMC, integrator=hamiltorch.Integrator.SPLITTING)
+    out[f"{name}_lf_theta"] = npy(lp_[-1]); out[f"{name}_lf_p"] = npy(lm_[-1])
+    hamiltorch.set_random_seed(33)
+    with Recorder() as rec:
+        ret, acc = hamiltorch.sample_split_model(net, loader, theta.clone(), M, model_loss="regression", num_samples=5,
+                                                 num_steps_per_sample=L, step_size=eps, burn=0, inv_mass=inv_mass,
+                                                 tau_out=tau_out, tau_list=tau_list, debug=2, verbose=False)
+    out[f"{name}_e2e_samples"] = np.stack([npy(t) for t in ret])
+    out[f"{name}_e2e_momenta"] = np.stack(rec.momenta)
+    out[f"{name}_e2e_uniforms"] = np.concatenate(rec.uniforms)
+    out[f"{name}_e2e_acc"] = np.array(acc)
+    hamiltorch.set_random_seed(34)
+    with Recorder() as rec:
+        ret, acc = hamiltorch.sample_model(net, X, Y, theta.clone(), model_loss="regression", num_samples=4,
+                                           num_steps_per_sample=L, step_size=eps, tau_out=tau_out, tau_list=tau_list,
+                                           debug=2, verbose=False)
+    out[f"{name}_full_samples"] = np.stack([npy(t) for t in ret])
+    out[f"{name}_full_momenta"] = np.stack(rec.momenta)
+    out[f"{name}_full_uniforms"] = np.concatenate(rec.uniforms)
+    np.savez_compressed(os.path.join(OUT, "cfg4.npz"), **out)
+
+
 def gen_cfg3():
     """BASELINE config 3 at full size: D=100, P = Q diag(linspace(.5, 2, 100)) Q^T (generator seed 0), soft-abs
     metric alpha=1e6, omega=10, eps=0.1 - metric pieces, Hamiltonian, a 3-step explicit leapfrog path without jitter
@@ -605,6 +687,8 @@ if __name__ == "__main__":
     gen_splitkinds()
     gen_logcosh()
     gen_blockmass()
+    gen_cfg2()
     gen_cfg3()
+    gen_cfg4()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -141,9 +141,12 @@ def _mlp_target(g, name, lo=None, hi=None, prior_scale=1.0):
     return O.MLPRegressionTarget(list(g[f"{name}_dims"]), X, Y, g[f"{name}_tau_list"], tau_out, prior_scale, act)
 
 
-@pytest.mark.parametrize("name", ["relu2", "tanh3"])
+@pytest.mark.parametrize("name", ["relu2", "tanh3", "relu_cfg4"])
 def test_mlp_logp_grad_split_leapfrog(golden, name):
-    g = golden("mlp")
+    """relu2 / tanh3: small networks; relu_cfg4: BASELINE config 4 at full size (8-100-1, D=1001, 400 points, M=4, tau_out=100,
+    eps=5e-4, L=10; tests/golden/cfg4.npz) - all recorded from the unmodified reference."""
+    g = golden("cfg4" if name == "relu_cfg4" else "mlp")
+    n_e2e, n_full = g[f"{name}_e2e_samples"].shape[0], g[f"{name}_full_samples"].shape[0]
     M, tau_out, eps, L = g[f"{name}_cfg"]
     M, L = int(M), int(L)
     theta = g[f"{name}_theta"][None].astype(np.float32)
@@ -163,13 +166,13 @@ def test_mlp_logp_grad_split_leapfrog(golden, name):
     np.testing.assert_allclose(pm[0], g[f"{name}_lf_p"], rtol=1e-3, atol=1e-3)
     # end-to-end sample_split_model
     draws = O.ReplayDraws(g[f"{name}_e2e_momenta"], g[f"{name}_e2e_uniforms"])
-    ret, info = O.sample_hmc(None, theta, 10, L, eps, 0, im, draws,
+    ret, info = O.sample_hmc(None, theta, n_e2e, L, eps, 0, im, draws,
                              grad_fns=[s.grad for s in splits], logp_fns=[s.logp for s in splits])
     np.testing.assert_allclose(np.concatenate(ret), g[f"{name}_e2e_samples"], rtol=1e-3, atol=1e-4)
     assert abs(info["acc_rate"][0] - float(g[f"{name}_e2e_acc"])) < 1e-9
     # sample_model (full-data HMC, inv_mass None)
     draws = O.ReplayDraws(g[f"{name}_full_momenta"], g[f"{name}_full_uniforms"])
-    ret, _ = O.sample_hmc(full, theta, 8, L, eps, 0, None, draws)
+    ret, _ = O.sample_hmc(full, theta, n_full, L, eps, 0, None, draws)
     np.testing.assert_allclose(np.concatenate(ret), g[f"{name}_full_samples"], rtol=1e-3, atol=1e-4)
 
 
@@ -479,3 +482,30 @@ def test_cfg3_full_size_sample_end_to_end(golden):
     assert len(ret) == ref.shape[0]
     np.testing.assert_allclose(np.concatenate(ret), ref, rtol=0, atol=2e-4)
     assert abs(info["acc_rate"][0] - float(g["e2e_acc"])) < 1e-9
+
+
+@pytest.mark.parametrize("tag,dt,tol", [("f32", np.float32, 1e-5), ("f64", np.float64, 1e-12)])
+def test_cfg2_leapfrog_paths_L25(golden, tag, dt, tol):
+    """BASELINE config 2's per-chain computation against the unmodified reference (tests/golden/cfg2.npz): every step of
+    four 25-step leapfrog paths, identity mass, eps=0.3.  SURVEY 8c tolerance for HMC: atol = rtol = 1e-5 (the reference's
+    own fp32-vs-fp64 distance at L=25 is 1e-7)."""
+    g = golden("cfg2")
+    tgt = gauss3(dt)
+    for k in range(4):
+        th, pm = g["theta0"][k][None].astype(dt), g["p0"][k][None].astype(dt)
+        pt, pp = O.hmc_leapfrog(th, pm, tgt.grad, 25, 0.3, None, return_path=True)
+        np.testing.assert_allclose(np.concatenate(pt), g[f"lf_theta_{tag}"][k], rtol=tol, atol=tol)
+        np.testing.assert_allclose(np.concatenate(pp), g[f"lf_p_{tag}"][k], rtol=tol, atol=tol)
+
+
+def test_cfg2_sample_end_to_end_L25(golden):
+    """hamiltorch.sample(HMC, L=25, eps=0.3) on the KAT2 target, 40 trajectories, the reference's draws replayed."""
+    g = golden("cfg2")
+    tgt = gauss3(np.float32)
+    draws = O.ReplayDraws(g["e2e_momenta"], g["e2e_uniforms"])
+    ret, info = O.sample_hmc(tgt, g["theta0"][0][None].astype(np.float32), 40, 25, 0.3, 0, None, draws)
+    ref = g["e2e_samples"]
+    assert len(ret) == ref.shape[0] == 40
+    np.testing.assert_allclose(np.concatenate(ret), ref, rtol=1e-4, atol=1e-4)
+    assert abs(info["acc_rate"][0] - float(g["e2e_acc"])) < 1e-9
+    assert 0.5 < float(g["e2e_acc"]) <= 1.0
