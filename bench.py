@@ -390,7 +390,7 @@ def main():
             kernel_ms = prof_ms / max(1, a.steps)          # all metric-evaluation launches of one step
             tf = w.flops_per_unit() * w.units_per_step() / (kernel_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf / FP32_PEAK_TFLOPS, "traffic": None,
+                    "frac": tf / FP32_PEAK_TFLOPS, "traffic": None,      # filled below from profiles/traffic_<workload>.json
                     "kernel": getattr(w, "roof_kernel", "metric_eval_kernel<float>"),
                     "kernel_ms_per_step": kernel_ms, "launches_per_step": prof_n / max(1, a.steps),
                     "algorithmic_flops_per_chain_step": w.flops_per_unit(),
@@ -403,8 +403,10 @@ def main():
             roof = None
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)
-        if os.path.exists(tf):
+        if os.path.exists(tf) and w.C == W.chains and w.T == W.traj:       # measured at the workload's own shape only
             traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+        if roof is not None:
+            roof["traffic"] = traffic                      # per step (all launches), like `achieved` for these workloads
         from hamiltorch_amd.ess import ess_min
         ess = ess_min(w.samples[1:]) if w.T >= 8 else float("nan")
         out = {
