@@ -170,23 +170,40 @@ def sample_split_model(model, train_loader, params_init, num_splits, model_loss=
 def predict_model(model, samples, x=None, y=None, test_loader=None, model_loss='multi_class_linear_output',
                   tau_out=1., tau_list=None, verbose=False):
     """S:1468-1562: evaluate every sample; returns (stack(pred)[S, N, O], list of log-probs)."""
-    if x is None and test_loader is None:
-        raise RuntimeError('predict_model needs (x, y) or a test_loader')          # S:1557
     shapes, sizes, tau_list = _shapes_and_tau(model, tau_list)
     dev = samples[0].device
-    batches = [(x, y)] if test_loader is None else list(test_loader)
     preds, lps = [], []
     with torch.no_grad():
-        for s in samples:
-            outs, lp = [], 0
-            for xb, yb in batches:
-                f = define_model_log_prob(model, model_loss, xb, yb, sizes, shapes, tau_list, tau_out,
-                                          predict=True, device=dev)
-                v, o = f(s.to(dev))
-                outs.append(o)
-                lp = lp + v
-            preds.append(torch.cat(outs, 0))
-            lps.append(lp)
+        if test_loader is not None and (x is None or isinstance(test_loader, torch.utils.data.DataLoader)):
+            # S:1520-1541: one closure per batch through define_split_model_log_prob, i.e. the prior divided by the number of
+            # batches in every closure (counted once over the loader); the batch count is the reference's own formula
+            # (S:1522-1525: a float when the batch size divides the data set, round() + 1 otherwise), kept as is.
+            if isinstance(test_loader, torch.utils.data.DataLoader):
+                n_data, bs = len(test_loader.dataset), test_loader.batch_size
+                num_batches = n_data / bs if n_data % bs == 0 else int(round(n_data / bs) + 1)
+            else:                                                                  # any other iterable of (x, y) batches
+                test_loader = list(test_loader)
+                num_batches = len(test_loader)
+            fns = define_split_model_log_prob(model, model_loss, test_loader, num_batches, sizes, shapes, tau_list, tau_out,
+                                              predict=True, device=dev, verbose=verbose)
+            for s in samples:
+                outs, lp = [], 0.
+                for f in fns:
+                    v, o = f(s.to(dev))
+                    lp = lp + v.cpu()                                              # S:1536
+                    outs.append(o)
+                preds.append(torch.cat(outs, 0))
+                lps.append(lp)
+        elif x is not None and y is not None:
+            if x.device != dev:                                                    # S:1544-1545
+                raise RuntimeError('x on device: {} and samples on device: {}'.format(x.device, dev))
+            f = define_model_log_prob(model, model_loss, x, y, sizes, shapes, tau_list, tau_out, predict=True, device=dev)
+            for s in samples:
+                v, o = f(s)
+                preds.append(o)
+                lps.append(v)
+        else:
+            raise RuntimeError('Val data not defined (i.e. arguments x, y, val_loader are all not defined)')   # S:1557
     return torch.stack(preds), lps
 
 

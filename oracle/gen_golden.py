@@ -540,6 +540,61 @@ def gen_logcosh():
     np.savez(os.path.join(OUT, "logcosh.npz"), **out)
 
 
+def custom_loss(out, y):                    # a user log-likelihood (S:1186-1188): summed over the batch by the reference
+    return 1.5 * ((out - y) ** 2).sum(1)
+
+
+LOSS_CASES = {
+    "binary": dict(loss="binary_class_linear_output", dims=[4, 6, 1], log_softmax=False, classes=2),
+    "multi": dict(loss="multi_class_linear_output", dims=[4, 6, 3], log_softmax=False, classes=3),
+    "logsoftmax": dict(loss="multi_class_log_softmax_output", dims=[4, 6, 3], log_softmax=True, classes=3),
+    "custom": dict(loss=custom_loss, dims=[4, 6, 2], log_softmax=False, classes=0),
+}
+
+
+def make_loss_net(c):
+    net = make_mlp(c["dims"], "tanh", 0)
+    if c["log_softmax"]:
+        net = nn.Sequential(*list(net.children()), nn.LogSoftmax(dim=1))
+    return net
+
+
+def gen_losses():
+    """define_model_log_prob for every model_loss kind besides 'regression' (S:1170-1190), the prior-only closure (S:1160-1162)
+    and predict_model (S:1468-1562, tensors and DataLoader form), recorded from the reference on small networks."""
+    out = {}
+    for name, c in LOSS_CASES.items():
+        net = make_loss_net(c)
+        g = torch.Generator().manual_seed(4)
+        N = 10
+        X = torch.randn(N, 4, generator=g)
+        if c["classes"]:
+            Y = torch.randint(0, c["classes"], (N, 1), generator=g).float()
+        else:
+            Y = torch.randn(N, c["dims"][-1], generator=g)
+        theta = (hamiltorch.util.flatten(net).clone().detach() + 0.1 * torch.randn(hamiltorch.util.flatten(net).numel(), generator=g))
+        tau_list = torch.tensor([1.0 + 0.5 * k for k in range(len(list(net.parameters())))])
+        pfl = [t.nelement() for t in net.parameters()]
+        psl = [t.shape for t in net.parameters()]
+        tau_out = 2.0
+        out[f"{name}_X"] = npy(X); out[f"{name}_Y"] = npy(Y); out[f"{name}_theta"] = npy(theta); out[f"{name}_tau_list"] = npy(tau_list)
+        f = S.define_model_log_prob(net, c["loss"], X, Y, pfl, psl, tau_list, tau_out)
+        th = theta.clone().requires_grad_()
+        v = f(th)
+        out[f"{name}_logp"] = npy(v).reshape(-1)
+        out[f"{name}_grad"] = npy(torch.autograd.grad(v.sum(), th)[0])
+        f0 = S.define_model_log_prob(net, c["loss"], None, None, pfl, psl, tau_list, tau_out, prior_scale=3.0)
+        out[f"{name}_prior_only"] = npy(f0(theta)).reshape(-1)
+        samples = [theta + 0.05 * torch.randn(theta.numel(), generator=g) for _ in range(3)]
+        out[f"{name}_samples"] = np.stack([npy(t) for t in samples])
+        pred, lps = hamiltorch.predict_model(net, samples, x=X, y=Y, model_loss=c["loss"], tau_out=tau_out, tau_list=tau_list)
+        out[f"{name}_pred"] = npy(pred); out[f"{name}_pred_lp"] = np.stack([npy(t).reshape(-1) for t in lps])
+        loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(X, Y), batch_size=5, shuffle=False)
+        pred, lps = hamiltorch.predict_model(net, samples, test_loader=loader, model_loss=c["loss"], tau_out=tau_out, tau_list=tau_list)
+        out[f"{name}_pred_loader"] = npy(pred); out[f"{name}_pred_loader_lp"] = np.stack([npy(t).reshape(-1) for t in lps])
+    np.savez(os.path.join(OUT, "losses.npz"), **out)
+
+
 def gen_cfg2():
     """BASELINE config 2's per-chain computation: KAT2 target, identity mass, L=25, eps=0.3 - 25-step leapfrog
     paths from four starts (fp32 + fp64) and an end-to-end sample() of 40 trajectories with the draws recorded."""
@@ -687,6 +742,7 @@ if __name__ == "__main__":
     gen_splitkinds()
     gen_logcosh()
     gen_blockmass()
+    gen_losses()
     gen_cfg2()
     gen_cfg3()
     gen_cfg4()

@@ -141,3 +141,46 @@ def test_ess_matches_oracle_definition():
     assert 0.4 * S * C / 9 < a < 2.5 * S * C / 9
     iid = torch.randn(S, C, 2, generator=g, dtype=torch.float64)
     assert 0.7 * S * C < ess_min(iid) < 1.4 * S * C
+
+
+def _custom_loss(out, y):                    # the user log-likelihood of oracle/gen_golden.py:custom_loss
+    return 1.5 * ((out - y) ** 2).sum(1)
+
+
+LOSS_CASES = {"binary": ("binary_class_linear_output", [4, 6, 1], False), "multi": ("multi_class_linear_output", [4, 6, 3], False),
+              "logsoftmax": ("multi_class_log_softmax_output", [4, 6, 3], True), "custom": (_custom_loss, [4, 6, 2], False)}
+
+
+@pytest.mark.parametrize("name", sorted(LOSS_CASES))
+def test_model_loss_kinds_and_predict_model_match_reference_fixture(golden, name):
+    """Every model_loss kind besides 'regression' (S:1170-1190), the prior-only closure (S:1160-1162) and predict_model in its
+    tensor and DataLoader forms (S:1468-1562; the loader form adds the prior once per batch, as the reference does) against
+    values recorded from the unmodified reference (tests/golden/losses.npz)."""
+    g = golden("losses")
+    loss, dims, log_softmax = LOSS_CASES[name]
+    net = _net(dims, "tanh")
+    if log_softmax:
+        net = torch.nn.Sequential(*list(net.children()), torch.nn.LogSoftmax(dim=1))
+    X, Y, theta = torch.tensor(g[f"{name}_X"]), torch.tensor(g[f"{name}_Y"]), torch.tensor(g[f"{name}_theta"])
+    tau_list = torch.tensor(g[f"{name}_tau_list"])
+    sizes = [w.nelement() for w in net.parameters()]
+    shapes = [w.shape for w in net.parameters()]
+    f = bnn.define_model_log_prob(net, loss, X, Y, sizes, shapes, tau_list, 2.0)
+    th = theta.clone().requires_grad_()
+    v = f(th)
+    np.testing.assert_allclose(v.detach().numpy().reshape(-1), g[f"{name}_logp"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(torch.autograd.grad(v.sum(), th)[0].numpy(), g[f"{name}_grad"], rtol=1e-4, atol=1e-4)
+    f0 = bnn.define_model_log_prob(net, loss, None, None, sizes, shapes, tau_list, 2.0, prior_scale=3.0)
+    np.testing.assert_allclose(f0(theta).detach().numpy().reshape(-1), g[f"{name}_prior_only"], rtol=1e-5, atol=1e-5)
+    samples = [torch.tensor(s) for s in g[f"{name}_samples"]]
+    pred, lps = ht.predict_model(net, samples, x=X, y=Y, model_loss=loss, tau_out=2.0, tau_list=tau_list)
+    np.testing.assert_allclose(pred.numpy(), g[f"{name}_pred"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(np.stack([t.numpy().reshape(-1) for t in lps]), g[f"{name}_pred_lp"], rtol=1e-5, atol=1e-4)
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(X, Y), batch_size=5, shuffle=False)
+    pred, lps = ht.predict_model(net, samples, test_loader=loader, model_loss=loss, tau_out=2.0, tau_list=tau_list)
+    np.testing.assert_allclose(pred.numpy(), g[f"{name}_pred_loader"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(np.stack([t.numpy().reshape(-1) for t in lps]), g[f"{name}_pred_loader_lp"], rtol=1e-5, atol=1e-4)
+    with pytest.raises(RuntimeError):                                            # S:1557: no data at all
+        ht.predict_model(net, samples)
+    with pytest.raises(NotImplementedError):                                     # S:1190: unknown loss
+        bnn.define_model_log_prob(net, "no_such_loss", X, Y, sizes, shapes, tau_list, 2.0)(theta)
