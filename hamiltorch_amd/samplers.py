@@ -90,7 +90,11 @@ class _BatchedCallback:
         self.fn = fn
         self.pass_grad = pass_grad
         self._use_vmap = True
-        f = lambda w: _scalar(fn(w))  # noqa: E731
+        def f(w):
+            r = fn(w)
+            if isinstance(r, tuple):      # (log_prob, params) protocol (S:54-58): its gradients come from .backward()
+                raise TypeError("tuple protocol (log_prob, params)")
+            return _scalar(r)
         # replayed as HIP graphs on the device (util.GraphedCallable): a trajectory calls these hundreds of times
         self._v_logp = util.GraphedCallable(torch.func.vmap(f))
         self._v_gv = util.GraphedCallable(torch.func.vmap(torch.func.grad_and_value(f)))
@@ -104,7 +108,7 @@ class _BatchedCallback:
             if want_grad:
                 p = collect_gradients(lp, p, self.pass_grad)
                 gs.append(p.grad.detach())
-                lp = lp[0] if isinstance(lp, tuple) else lp
+            lp = lp[0] if isinstance(lp, tuple) else lp
             lps.append(_scalar(lp).detach())
         return (torch.stack(gs) if want_grad else None), torch.stack(lps)
 

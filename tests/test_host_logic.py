@@ -184,3 +184,25 @@ def test_model_loss_kinds_and_predict_model_match_reference_fixture(golden, name
         ht.predict_model(net, samples)
     with pytest.raises(NotImplementedError):                                     # S:1190: unknown loss
         bnn.define_model_log_prob(net, "no_such_loss", X, Y, sizes, shapes, tau_list, 2.0)(theta)
+
+
+def test_tuple_protocol_callback():
+    """log_prob_func may return (log_prob, iterable_of_params) whose .grad's are concatenated (S:54-58): the batched
+    evaluator falls back to the per-chain loop and collect_gradients follows the reference."""
+    def f(w):
+        a = w[:2].detach().requires_grad_()
+        b = w[2:].detach().requires_grad_()
+        return -(a * a).sum() - 2.0 * (b * b).sum(), [a, b]
+    th = torch.tensor([[1.0, 2.0, 3.0], [-1.0, 0.5, 0.25]])
+    cb = samplers._BatchedCallback(f)
+    with pytest.warns(UserWarning):
+        g, v = cb.grad(th)
+    np.testing.assert_allclose(g.numpy(), np.concatenate([-2 * th[:, :2].numpy(), -4 * th[:, 2:].numpy()], axis=1))
+    np.testing.assert_allclose(v.numpy(), [-(1 + 4) - 2 * 9, -(1 + 0.25) - 2 * 0.0625])
+    np.testing.assert_allclose(cb.logp(th).numpy(), v.numpy())
+    p = torch.tensor([1.0, 2.0, 3.0], requires_grad=True)
+    out = samplers.collect_gradients(f(p), p)
+    np.testing.assert_allclose(out.grad.numpy(), [-2.0, -4.0, -12.0])
+    # a fixed gradient tensor and a callable (S:59-63)
+    assert torch.equal(samplers.collect_gradients(None, p.detach(), torch.ones(3)).grad, torch.ones(3))
+    assert torch.equal(samplers.collect_gradients(None, p.detach(), lambda w: 2 * w).grad, 2 * p.detach())
