@@ -540,6 +540,26 @@ def gen_logcosh():
     np.savez(os.path.join(OUT, "logcosh.npz"), **out)
 
 
+def gen_signatures():
+    """Parameter names, order and defaults of the reference's public functions on the path, as JSON."""
+    import inspect
+    import json
+    from hamiltorch import util as U
+
+    def sig(f):
+        return [[k, None if v.default is inspect._empty else repr(v.default)] for k, v in inspect.signature(f).parameters.items()]
+    out = {}
+    for n in ("sample", "sample_model", "sample_split_model", "predict_model"):
+        out[n] = sig(getattr(hamiltorch, n))
+    for n in ("leapfrog", "hamiltonian", "rm_hamiltonian", "fisher", "gibbs", "cholesky_inverse", "acceptance", "collect_gradients",
+              "define_model_log_prob", "define_split_model_log_prob", "adaptation"):
+        out["samplers." + n] = sig(getattr(S, n))
+    for n in ("flatten", "unflatten", "setup_chain", "multi_chain", "set_random_seed", "has_nan_or_inf", "update_model_params_in_place"):
+        out["util." + n] = sig(getattr(U, n))
+    out["enums"] = {e.__name__: {m.name: m.value for m in e} for e in (hamiltorch.Sampler, hamiltorch.Integrator, hamiltorch.Metric)}
+    json.dump(out, open(os.path.join(OUT, "signatures.json"), "w"), indent=1, sort_keys=True)
+
+
 def custom_loss(out, y):                    # a user log-likelihood (S:1186-1188): summed over the batch by the reference
     return 1.5 * ((out - y) ** 2).sum(1)
 
@@ -743,6 +763,7 @@ if __name__ == "__main__":
     gen_logcosh()
     gen_blockmass()
     gen_losses()
+    gen_signatures()
     gen_cfg2()
     gen_cfg3()
     gen_cfg4()

@@ -206,3 +206,27 @@ def test_tuple_protocol_callback():
     # a fixed gradient tensor and a callable (S:59-63)
     assert torch.equal(samplers.collect_gradients(None, p.detach(), torch.ones(3)).grad, torch.ones(3))
     assert torch.equal(samplers.collect_gradients(None, p.detach(), lambda w: 2 * w).grad, 2 * p.detach())
+
+
+def test_public_signatures_match_reference():
+    """Every public function of the path keeps the reference's parameter names, order and defaults (extra keyword
+    parameters - seed, chain_offset, ... - may follow), and the enums keep their members and values
+    (tests/golden/signatures.json, recorded from the unmodified reference by oracle/gen_golden.py)."""
+    import inspect
+    import json
+    import os
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "signatures.json")))
+    enums = ref.pop("enums")
+    for ename, members in enums.items():
+        mine = {m.name: m.value for m in getattr(ht, ename)}
+        assert mine == members, ename
+    for name, params in ref.items():
+        obj = ht
+        for part in name.split("."):
+            obj = getattr(obj, part)
+        mine = inspect.signature(obj).parameters
+        order = [k for k in mine if k in {p[0] for p in params}]
+        assert order == [p[0] for p in params], name
+        for k, default in params:
+            got = mine[k].default
+            assert (default is None and got is inspect._empty) or repr(got) == default, (name, k, default, got)
