@@ -1,9 +1,6 @@
 """CPU: the C-ABI library loads and exports every symbol include/hamiltorch_amd.h declares."""
-import ctypes
 import os
 import re
-
-import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
