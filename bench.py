@@ -216,13 +216,14 @@ class Cfg3:
             return -0.5 * torch.dot(w, torch.mv(P, w))
         init = 0.1 * torch.randn(self.D, generator=torch.Generator().manual_seed(0))
         torch.manual_seed(0)
-        t0 = time.time(); TP.port_sample_rmhmc(lp, init, 1, 1, self.eps, self.omega, self.alpha); dt1 = time.time() - t0
+        t0 = time.time(); TP.port_sample_rmhmc(lp, init, 1, 1, self.eps, self.omega, self.alpha, jitter=self.jitter); dt1 = time.time() - t0
         n = max(1, int(seconds / (dt1 * self.L)))
-        t0 = time.time(); _, acc = TP.port_sample_rmhmc(lp, init, n, self.L, self.eps, self.omega, self.alpha, burn=-1)
+        t0 = time.time()
+        _, acc = TP.port_sample_rmhmc(lp, init, n, self.L, self.eps, self.omega, self.alpha, burn=-1, jitter=self.jitter)
         dt = time.time() - t0
         return {"value": n * self.L / dt, "unit": "leapfrog-steps/s", "cores": 1, "kind": "port",
-                "sample": "1 chain x %d trajectories x L=%d explicit steps, jitter=None (oracle/torch_port.py: autograd "
-                          "through hessian+eigh per gradient, as the reference), %.1f s" % (n, self.L, dt),
+                "sample": "1 chain x %d trajectories x L=%d explicit steps, jitter=%g (oracle/torch_port.py: autograd "
+                          "through hessian+eigh per gradient, as the reference), %.1f s" % (n, self.L, self.jitter, dt),
                 "acceptance": acc}
 
 

@@ -104,10 +104,13 @@ def port_sample(log_prob_func, params_init, num_samples, num_steps_per_sample, s
 # Explicit RMHMC (soft-abs / Hessian metric) -- same cost structure as the reference: every gradient
 # of the Riemannian Hamiltonian is an autograd pass through hessian + eigh + Cholesky (S:395-422).
 # ---------------------------------------------------------------------------------------------------
-def port_fisher(q, log_prob_func, alpha, softabs=True):
-    """S:96-122 with jitter=None."""
+def port_fisher(q, log_prob_func, alpha, softabs=True, jitter=None):
+    """S:96-122; jitter draws torch.rand(D) from the global generator exactly where the reference does (S:113-115)."""
     hess = torch.autograd.functional.hessian(log_prob_func, q, create_graph=True)   # S:108
     fish = -hess
+    if jitter is not None:
+        n = fish.shape[0]
+        fish = fish + torch.eye(n) * torch.rand(n) * jitter                         # S:115
     if not softabs:
         return fish, None
     lam, Q = torch.linalg.eigh(fish, UPLO='L')                                       # S:119
@@ -115,12 +118,12 @@ def port_fisher(q, log_prob_func, alpha, softabs=True):
     return torch.matmul(Q, torch.matmul(lam_t.diag(), Q.t())), lam_t                 # S:121
 
 
-def port_rm_hamiltonian(q, p, log_prob_func, alpha, softabs=True):
+def port_rm_hamiltonian(q, p, log_prob_func, alpha, softabs=True, jitter=None):
     """S:710-731."""
     from numpy import pi
     lp = log_prob_func(q)
     pi_term = q.nelement() * torch.log(2. * torch.tensor(pi))                        # S:712 (float32)
-    fish, lam_t = port_fisher(q, log_prob_func, alpha, softabs)
+    fish, lam_t = port_fisher(q, log_prob_func, alpha, softabs, jitter)
     logdet = lam_t.log().sum() if softabs else torch.slogdet(fish)[1]                # S:726 / S:728
     low = torch.linalg.cholesky(fish)                                                # S:146-148
     y = torch.linalg.solve_triangular(low, p.view(-1, 1), upper=False)
@@ -128,15 +131,15 @@ def port_rm_hamiltonian(q, p, log_prob_func, alpha, softabs=True):
     return -lp + 0.5 * pi_term + 0.5 * logdet + 0.5 * torch.matmul(p.view(1, -1), x)
 
 
-def port_explicit_leapfrog(q, p, log_prob_func, steps, step_size, omega, alpha, softabs=True):
+def port_explicit_leapfrog(q, p, log_prob_func, steps, step_size, omega, alpha, softabs=True, jitter=None):
     """S:425-461."""
     def dH_dq(qq, pp):                                                               # S:395-398
         qq = qq.detach().requires_grad_()
-        return torch.autograd.grad(port_rm_hamiltonian(qq, pp.detach(), log_prob_func, alpha, softabs), qq)[0]
+        return torch.autograd.grad(port_rm_hamiltonian(qq, pp.detach(), log_prob_func, alpha, softabs, jitter), qq)[0]
 
     def dH_dp(qq, pp):                                                               # S:415-422
         pp = pp.detach().requires_grad_(); qq = qq.detach().requires_grad_()
-        return torch.autograd.grad(port_rm_hamiltonian(qq, pp, log_prob_func, alpha, softabs), pp)[0]
+        return torch.autograd.grad(port_rm_hamiltonian(qq, pp, log_prob_func, alpha, softabs, jitter), pp)[0]
     q = q.clone(); p = p.clone(); qc = q.clone(); pc = p.clone()
     for _ in range(steps):
         p = p - 0.5 * step_size * dH_dq(q, pc)
@@ -156,19 +159,19 @@ def port_explicit_leapfrog(q, p, log_prob_func, steps, step_size, omega, alpha, 
 
 
 def port_sample_rmhmc(log_prob_func, params_init, num_samples, num_steps_per_sample, step_size, omega, alpha, burn=0,
-                      softabs=True):
-    """S:969-1026, RMHMC / EXPLICIT branch, jitter=None."""
+                      softabs=True, jitter=None):
+    """S:969-1026, RMHMC / EXPLICIT branch."""
     params = params_init.clone().requires_grad_()
     burn_prev = params_init.clone()
     ret = [params_init.clone()]
     rejected = 0
     for n in range(num_samples):
-        G, _ = port_fisher(params, log_prob_func, alpha, softabs)
+        G, _ = port_fisher(params, log_prob_func, alpha, softabs, jitter)
         p = torch.distributions.MultivariateNormal(torch.zeros_like(params), G).sample()   # S:183-184
-        ham = 2 * port_rm_hamiltonian(params, p, log_prob_func, alpha, softabs) / 2       # S:822, S:977
-        q_new, p_new = port_explicit_leapfrog(params, p, log_prob_func, num_steps_per_sample, step_size, omega, alpha, softabs)
+        ham = 2 * port_rm_hamiltonian(params, p, log_prob_func, alpha, softabs, jitter) / 2       # S:822, S:977
+        q_new, p_new = port_explicit_leapfrog(params, p, log_prob_func, num_steps_per_sample, step_size, omega, alpha, softabs, jitter)
         params = q_new.detach().requires_grad_()
-        new_ham = port_rm_hamiltonian(params, p_new, log_prob_func, alpha, softabs)       # S:989
+        new_ham = port_rm_hamiltonian(params, p_new, log_prob_func, alpha, softabs, jitter)       # S:989
         rho = min(0., float(-new_ham + ham))
         if rho >= torch.log(torch.rand(1)):
             if n > burn:

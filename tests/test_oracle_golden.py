@@ -509,3 +509,24 @@ def test_cfg2_sample_end_to_end_L25(golden):
     np.testing.assert_allclose(np.concatenate(ret), ref, rtol=1e-4, atol=1e-4)
     assert abs(info["acc_rate"][0] - float(g["e2e_acc"])) < 1e-9
     assert 0.5 < float(g["e2e_acc"]) <= 1.0
+
+
+def test_torch_port_cfg3_with_jitter_matches_reference_run(golden):
+    """The RMHMC port at BASELINE config 3's size WITH jitter (bench.py's cfg3 cpu_baseline): same torch seed -> the same
+    torch.rand(D) / MultivariateNormal / torch.rand(1) consumption as the reference, hence its sample() output."""
+    import torch
+    import torch_port as TP
+    g = golden("cfg3")
+    D, alpha, omega, eps, jitter = g["cfg"]
+    N, L = (int(v) for v in g["e2e_cfg"])
+    P = torch.tensor(g["P_f32"])
+
+    def lp(w):
+        return -0.5 * torch.dot(w, torch.mv(P, w))
+    torch.manual_seed(9)
+    ret, acc = TP.port_sample_rmhmc(lp, torch.tensor(g["theta0_f32"]), N, L, float(eps), float(omega), float(alpha), burn=0,
+                                    jitter=float(jitter))
+    got = np.stack([t.numpy() for t in ret])
+    assert got.shape == g["e2e_samples"].shape
+    np.testing.assert_allclose(got, g["e2e_samples"], rtol=0, atol=2e-5)
+    assert acc == float(g["e2e_acc"])
