@@ -530,3 +530,45 @@ def test_torch_port_cfg3_with_jitter_matches_reference_run(golden):
     assert got.shape == g["e2e_samples"].shape
     np.testing.assert_allclose(got, g["e2e_samples"], rtol=0, atol=2e-5)
     assert acc == float(g["e2e_acc"])
+
+
+def test_torch_port_cfg4_full_size_matches_reference_run(golden):
+    """bench.py's cfg4 cpu_baseline (split-HMC port over MLP closures) at BASELINE config 4's size: Linear(8,100)-ReLU-
+    Linear(100,1), 4 splits of 100 points, tau_out=100, eps=5e-4, L=10 - the reference's sample_split_model from the same seed."""
+    import torch
+    import torch_port as TP
+    g = golden("cfg4")
+    name = "relu_cfg4"
+    M, tau_out, eps, L = g[f"{name}_cfg"]
+    M, L = int(M), int(L)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 100), torch.nn.ReLU(), torch.nn.Linear(100, 1))
+    X, Y = torch.tensor(g[f"{name}_X"]), torch.tensor(g[f"{name}_Y"])
+    tau_list = torch.tensor(g[f"{name}_tau_list"])
+    nb = X.shape[0] // M
+    fl = [TP.port_mlp_closure(net, X[m * nb:(m + 1) * nb], Y[m * nb:(m + 1) * nb], tau_list, float(tau_out), M) for m in range(M)]
+    torch.manual_seed(33)
+    for _ in torch.utils.data.DataLoader(torch.utils.data.TensorDataset(X, Y), batch_size=nb, shuffle=False):
+        pass                                       # the loader's base-seed draw (see test_torch_port_split_matches_reference_run)
+    n = g[f"{name}_e2e_samples"].shape[0]
+    ret, acc = TP.port_sample_split(fl, torch.tensor(g[f"{name}_theta"]), n, L, float(eps), 0, torch.ones(1001))
+    got = np.stack([t.numpy() for t in ret])
+    np.testing.assert_allclose(got, g[f"{name}_e2e_samples"], rtol=1e-5, atol=1e-6)
+    assert acc == float(g[f"{name}_e2e_acc"])
+
+
+def test_torch_port_cfg2_bit_identical(golden):
+    """bench.py's cfg2 cpu_baseline (one chain of BASELINE config 2: L=25, eps=0.3) reproduces the reference's sample()
+    bit for bit from the same torch seed."""
+    import torch
+    import torch_port as TP
+    g = golden("cfg2")
+    cov = torch.tensor([[1.0, 0.6, 0.2], [0.6, 2.0, 0.5], [0.2, 0.5, 0.5]])
+
+    def lp(w):
+        return torch.distributions.MultivariateNormal(torch.zeros(3), cov).log_prob(w).sum()
+    torch.manual_seed(77)
+    ret, acc = TP.port_sample(lp, torch.tensor(g["theta0"][0], dtype=torch.float32), 40, 25, 0.3, 0, None)
+    got = np.stack([t.numpy() for t in ret])
+    assert got.shape == g["e2e_samples"].shape
+    assert np.array_equal(got, g["e2e_samples"])
+    assert acc == float(g["e2e_acc"])
