@@ -63,3 +63,15 @@ def test_every_tuning_key_is_documented_and_accepted():
     for k in keys:
         if k in defaults:
             assert lib.hta_set_tuning(k.encode(), int(defaults[k])) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """without the built HIP extension the package raises (no CPU path, no silent fallback)."""
+    import pytest
+    from hamiltorch_amd import _abi
+    monkeypatch.setattr(_abi, "_lib", None)
+    monkeypatch.setattr(_abi, "LIB_PATH", str(tmp_path / "libhamiltorch_amd.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _abi.load()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _abi.set_tuning("rmhmc_batch", 1)
