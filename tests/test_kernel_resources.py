@@ -46,7 +46,7 @@ def _find(kernels, *parts):
 def test_spill_budget_of_the_hot_kernels(kernels):
     """No scratch at all in the cfg2 kernels and in the many-chain RMHMC kernels; the one-chain RMHMC kernel (256-register cap
     from __launch_bounds__(256, 2)) and the MLP MFMA kernel (128-register cap from its 512-thread workgroup) spill a few
-    registers outside their inner loops - bounded here so that a change which pushes the inner loops into scratch shows up."""
+    registers - bounded here so that a change which pushes more of the inner loops into scratch shows up."""
     clean = ["hmc_gauss_quad_kernel", "hmc_gauss_eig_kernel", "hmc_gauss_wave_eig_kernel", "rmhmc_batch_kernel", "rmhmc_mfma4_kernel",
              "rmhmc_momentum_wave_kernel", "rmhmc_momentum_kernel"]
     for h in clean:
@@ -70,5 +70,9 @@ def test_register_budgets_behind_the_occupancy_claims(kernels):
         assert waves(k) >= 1 and kernels[k]["lds"] == 0, (k, kernels[k])   # one wave per SIMD, dynamic LDS only
     for k in _find(kernels, "rmhmc_fused_kernelIfLi56ELi1E"):
         assert waves(k) >= 2, (k, kernels[k])                      # __launch_bounds__(256, 2)
+    # the momentum draws of the next block run UNDER the one-chain trajectory kernel (side stream): both fit one SIMD
+    fused = max(kernels[k]["vgpr"] for k in _find(kernels, "rmhmc_fused_kernelIfLi56ELi1E"))
+    mom = max(kernels[k]["vgpr"] for k in _find(kernels, "rmhmc_momentum_wave_kernel", "Li13E"))
+    assert fused + mom <= 512, (fused, mom)
     for k in _find(kernels, "hmc_gauss_quad_kernelILi3ELb0ELi25E"):
         assert kernels[k]["vgpr"] <= 64, (k, kernels[k])           # cfg2: the whole state of a chain in registers
