@@ -3,19 +3,23 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5]
 
-One "step" = one pass of the hot path over one batch: a single launch of the fused trajectory
-kernel that runs `--traj` whole trajectories (momentum draw, H, L leapfrog steps, H, Metropolis,
-sample write-out) for every chain of this rank.  Inputs are resident in HBM before the timed
-region.  For N > 1 every rank owns its own block of chains (global chain ids, no data-path
+One "step" = one pass of the hot path over one batch: one C-ABI call that runs `--traj` whole trajectories
+(momentum draw, H, L leapfrog steps, H, Metropolis, sample write-out) for every chain of this rank.  Inputs are
+resident in HBM before the timed region.  `--gpus N` with N > 1 launches N ranks itself (one per GPU, RCCL) unless it
+already runs under torch.distributed.run; every rank owns its own block of chains (global chain ids, no data-path
 collective): weak scaling, value = all ranks' chain-steps / max-over-ranks time.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and, at N=1,
-`cpu_baseline` (the reference's per-chain torch/autograd cost structure, oracle/torch_port.py,
-timed on this box's host cores on a bounded sample).
+Rank 0 prints ONE JSON line (contract in the task description).  `value` is the primary workload (cfg2: BASELINE
+config 2, the 1024-chain headline).  At N = 1 the default run adds `"secondary"`: BASELINE.json's second north-star
+target (D=100 explicit RMHMC at 1024 chains) and configs 3 / 4, each with its own `roofline` and `cpu_baseline`.
+Every `roofline` carries the SURVEY 8(d) model fraction AND `physical` (counter HBM GB/s, SIMDs occupied, matrix-pipe
+busy share: from the committed rocprofv3 PMC passes in profiles/physical.json, collected with tools/physical.sh).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
 import sys
 import time
 
@@ -26,7 +30,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3       # fp32 vector == fp32 MFMA peak
+N_SIMDS = 1024                 # 256 CUs x 4
 SIGMA3 = [[1.0, 0.6, 0.2], [0.6, 2.0, 0.5], [0.2, 0.5, 0.5]]
+METRIC = "leapfrog-steps/sec (whole node) at 1024 chains; ESS/sec vs CPU ref"
 
 
 def parse():
@@ -37,14 +43,15 @@ def parse():
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default: the workload's)")
     ap.add_argument("--traj", type=int, default=None, help="trajectories per launch (default: the workload's)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock budget of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=9.0, help="wall-clock budget of ONE workload's CPU baseline (3 repeats)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="primary workload only")
     ap.add_argument("--sweep", action="store_true", help="also print a chain-count sweep (stderr)")
     return ap.parse_args()
 
 
 # ---------------------------------------------------------------------------------------------------
-# workloads
+# helpers
 # ---------------------------------------------------------------------------------------------------
 def _usable_cores():
     """(logical CPUs visible, CPUs this process may actually keep busy: affinity mask and cgroup CPU quota)."""
@@ -65,22 +72,68 @@ def _usable_cores():
     return avail, n
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _philox_init(abi, C, D, dev, chain_offset, scale=0.1):
+    """params_init[c] = scale * N(0, I) from Philox(seed 0, subsequence = global chain id), drawn by the
+    library's own generator (hta_momentum_resample with identity mass, draw 0)."""
+    z = torch.empty(C, D, device=dev)
+    abi.momentum_resample(z, abi.MASS_NONE, None, 0, chain_offset, 0)
+    return (scale * z).contiguous()
+
+
+def _median3(fn):
+    """Median-by-value of three runs of fn() -> dict with "value" (repeat >= 3x, report the median)."""
+    runs = [fn() for _ in range(3)]
+    runs.sort(key=lambda r: r["value"])
+    out = runs[1]
+    out["repeats"] = [r["value"] for r in runs]
+    return out
+
+
+_PHYSICAL = None
+
+
+def _physical(key):
+    """Counter-derived utilisation of the workload's dominant kernel from the committed PMC passes (profiles/physical.json;
+    tools/physical.sh collects FETCH_SIZE / WRITE_SIZE / SQ_BUSY_CYCLES / SQ_VALU_MFMA_BUSY_CYCLES / SQ_WAVES in separate
+    rocprofv3 --pmc runs of this file's own command line).  None when the profile was taken at another shape."""
+    global _PHYSICAL
+    if _PHYSICAL is None:
+        try:
+            _PHYSICAL = json.load(open(os.path.join(ROOT, "profiles", "physical.json")))
+        except (OSError, ValueError):
+            _PHYSICAL = {}
+    return _PHYSICAL.get(key)
+
+
+# ---------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------
 class Cfg2:
     """BASELINE config 2: 3-D correlated Gaussian, HMC, 1024 chains, L=25, eps=0.3, 1000 trajectories."""
+    key = "cfg2"
     name = "cfg2: 3-D correlated Gaussian HMC, L=25, eps=0.3, identity mass"
     D, L, eps, chains, traj = 3, 25, 0.3, 1024, 1000
     dtype_name = "f32"
 
-    def __init__(self, dev, chains, traj, chain_offset, seed=0):
+    def __init__(self, dev, chains, traj, chain_offset, seed=1):
         import hamiltorch_amd as ht
         from hamiltorch_amd import _abi
-        self.abi = _abi
+        self.abi, self.ht = _abi, ht
         self.C, self.T = chains or self.chains, traj or self.traj
         self.off, self.seed = chain_offset, seed
         cov = torch.tensor(SIGMA3, dtype=torch.float32, device=dev)
         self.tgt = ht.GaussianTarget(torch.zeros(3, device=dev), covariance=cov)
-        g = torch.Generator(device="cpu").manual_seed(1234 + chain_offset)
-        self.theta0 = (0.1 * torch.randn(self.C, 3, generator=g)).to(dev)
+        self.theta0 = _philox_init(_abi, self.C, 3, dev, chain_offset)
         self.cur = self.theta0.clone()
         self.samples = torch.empty(self.T + 1, self.C, 3, device=dev)      # burn = -1: every trajectory stored
         self.samples[0].copy_(self.theta0)
@@ -98,6 +151,12 @@ class Cfg2:
                                      0, None, None, self.L, self.eps, self.T, 0, -1, self.seed + k, self.off,
                                      self.samples, self.rej, workspace=self.ws)
 
+    def api_call(self, k):
+        """The same work through the public API (hamiltorch_amd.sample: route selection, allocation of the sample tensor,
+        the list of per-trajectory views)."""
+        return self.ht.sample(self.tgt, self.theta0, num_samples=self.T, num_steps_per_sample=self.L, step_size=self.eps,
+                              burn=-1, verbose=False, seed=self.seed + k, chain_offset=self.off)
+
     def check(self):
         s = self.samples[1:]
         assert torch.isfinite(s).all()
@@ -107,44 +166,77 @@ class Cfg2:
         assert torch.allclose(cov, want, rtol=0.08, atol=0.04), cov
         return 1.0 - float(self.rej.double().mean()) / (self.T * max(1, self._steps_done))
 
+    def roofline(self, kernel_ms, call_ms, prof_n, steps):
+        alg_bytes = self.bytes_per_unit() * self.units_per_step()
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        quad = self.C <= 65536
+        waves = (self.C * 4 + 63) // 64 if quad else (self.C + 63) // 64
+        # the bound that physically applies at 1024 chains: one dependent FMA chain per wave.  2 L dependent v_fma_f32 per
+        # trajectory at the 4-cycle dependent-issue latency (MI355X_MICROARCH.md) against the measured cycles per trajectory
+        clk_ghz = self.abi.device_info(0)["clock_khz"] / 1e6
+        cyc_per_traj = kernel_ms * 1e-3 * clk_ghz * 1e9 / self.T
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "kernel": "hmc_gauss_quad_kernel<3,false,25>" if quad else "hmc_gauss_eig_kernel<float,3,false>",
+                "kernel_ms": kernel_ms, "call_ms": call_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                "latency_model": {"dependent_fma_per_trajectory": 2 * self.L, "floor_cycles_per_trajectory": 8 * self.L,
+                                  "measured_cycles_per_trajectory": cyc_per_traj, "frac_of_latency_floor": 8 * self.L / cyc_per_traj,
+                                  "clock_ghz": clk_ghz},
+                "waves_per_launch": waves, "simds_occupied_frac": min(1.0, waves / N_SIMDS),
+                "note": "frac = SURVEY 8(d)'s streaming MODEL (16*D bytes per chain-step), not a utilisation: the state is "
+                        "register-resident for the whole launch, real HBM traffic (`traffic`, PMC) is the draw records and the "
+                        "sample rows only.  At 1024 chains the launch is 64 waves on 1024 SIMDs; what bounds it is the serial "
+                        "chain of 2 L dependent FMAs per trajectory (eigenbasis of P, one eigen-coordinate per lane of a DPP "
+                        "quad): see latency_model and physical"}
+
     def cpu_baseline(self, seconds):
         """The reference's CPU cost structure on this host: one single-threaded chain per process (autograd
         callback, torch CPU RNG), one process per usable host core (affinity mask / cgroup CPU quota; HTA_BENCH_CPU_PROCS
-        caps it); rate = all leapfrog steps / the slowest process's sampling time."""
+        caps it); rate = all leapfrog steps / the slowest process's sampling time.  Median of three rounds."""
         import subprocess
         avail, procs = _usable_cores()
         procs = max(1, min(procs, int(os.environ.get("HTA_BENCH_CPU_PROCS", "64"))))
         env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
-        t0 = time.time()
-        ps = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "torch_port.py"), "cfg2", str(1000 + i),
-                                str(self.L), repr(self.eps), repr(float(seconds))], stdout=subprocess.PIPE,
-                               stderr=subprocess.DEVNULL, env=env, text=True) for i in range(procs)]
-        res = []
-        for p_ in ps:
-            out_, _ = p_.communicate(timeout=60 + 20 * seconds)
-            r = json.loads(out_.strip().splitlines()[-1])
-            res.append((r["n"], r["L"], r["dt"], r["acc"], r["samples"]))
-        wall = time.time() - t0
-        steps = sum(n * L for n, L, _, _, _ in res)
-        dt = max(r[2] for r in res)
         from hamiltorch_amd.ess import ess_min
-        ess = sum(ess_min(torch.tensor(r[4]).unsqueeze(1)) for r in res)
-        return {"value": steps / dt, "unit": "leapfrog-steps/s", "cores": procs, "kind": "port",
-                "sample": "%d processes x 1 chain x ~%d trajectories x L=%d, one thread each (oracle/torch_port.py: per-step "
-                          "autograd on a MultivariateNormal.log_prob callback, as the reference), %.1f s sampling, %.1f s with "
-                          "process start-up" % (procs, res[0][0], self.L, dt, wall),
-                "per_core": steps / dt / procs, "ess_per_sec": ess / dt,
-                "acceptance": sum(r[3] for r in res) / procs, "host_cores_available": avail, "host_cores_usable": procs}
+
+        def once(rep):
+            t0 = time.time()
+            ps = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "torch_port.py"), "cfg2", str(1000 + 97 * rep + i),
+                                    str(self.L), repr(self.eps), repr(float(seconds) / 3)], stdout=subprocess.PIPE,
+                                   stderr=subprocess.DEVNULL, env=env, text=True) for i in range(procs)]
+            res = []
+            for p_ in ps:
+                out_, _ = p_.communicate(timeout=120 + 20 * seconds)
+                r = json.loads(out_.strip().splitlines()[-1])
+                res.append((r["n"], r["L"], r["dt"], r["acc"], r["samples"]))
+            wall = time.time() - t0
+            steps = sum(n * L for n, L, _, _, _ in res)
+            dt = max(r[2] for r in res)
+            ess = sum(ess_min(torch.tensor(r[4]).unsqueeze(1)) for r in res)
+            return {"value": steps / dt, "unit": "leapfrog-steps/s", "cores": procs, "kind": "port",
+                    "sample": "%d processes x 1 chain x ~%d trajectories x L=%d, one thread each (oracle/torch_port.py: per-step "
+                              "autograd on a MultivariateNormal.log_prob callback, as the reference), %.1f s sampling, %.1f s with "
+                              "process start-up; median of 3 such rounds" % (procs, res[0][0], self.L, dt, wall),
+                    "per_core": steps / dt / procs, "ess_per_sec": ess / dt,
+                    "acceptance": sum(r[3] for r in res) / procs, "host_cores_available": avail, "host_cores_usable": procs}
+        reps = [once(r) for r in range(3)]
+        reps.sort(key=lambda r: r["value"])
+        out = reps[1]
+        out["repeats"] = [r["value"] for r in reps]
+        out["pinned_to"] = "tests/golden/cfg2.npz (tests/test_oracle_golden.py::test_torch_port_cfg2_bit_identical: the port " \
+                           "reproduces the unmodified reference's sample() bit for bit from the same torch seed)"
+        return out
 
 
 class Cfg3:
     """BASELINE config 3: D=100 Gaussian, explicit RMHMC, soft-abs metric, 256 chains."""
+    key = "cfg3"
     name = "cfg3: D=100 Gaussian explicit RMHMC, softabs alpha=1e6, omega=10, eps=0.1, L=10, jitter=1e-3"
     D, L, eps, chains, traj = 100, 10, 0.1, 256, 400
     omega, alpha, jitter = 10.0, 1e6, 1e-3
     dtype_name = "f32"
+    SURVEY_FLOPS = 4 * 11.3 * 100 ** 3          # 4 metric evaluations x (eigh 9 D^3 + assembly 2 D^3 + Cholesky D^3/3): 4.5e7
 
-    def __init__(self, dev, chains, traj, chain_offset, seed=0):
+    def __init__(self, dev, chains, traj, chain_offset, seed=1, jacobi=False):
         import hamiltorch_amd as ht
         from hamiltorch_amd import _abi
         self.abi = _abi
@@ -156,54 +248,71 @@ class Cfg3:
         P = 0.5 * (P + P.T)
         self.P64 = P
         self.tgt = ht.GaussianTarget(torch.zeros(self.D, device=dev), precision=P.float().to(dev), normalized=False)
-        g2 = torch.Generator().manual_seed(1234 + chain_offset)
-        self.theta0 = (0.1 * torch.randn(self.C, self.D, generator=g2)).to(dev)
+        self.theta0 = _philox_init(_abi, self.C, self.D, dev, chain_offset)
         self.cur = self.theta0.clone()
         self.samples = torch.empty(self.T + 1, self.C, self.D, device=dev)
         self.samples[0].copy_(self.theta0)
         self.rej = torch.zeros(self.C, dtype=torch.int32, device=dev)
         self.ws = torch.empty(_abi.rmhmc_workspace_bytes(self.C, self.D, 4, self.T), dtype=torch.uint8, device=dev)
-        if os.environ.get("HTA_RMHMC_FUSED", "1") == "0":      # reproduce the general (eigendecomposition per evaluation) path
-            _abi.set_tuning("rmhmc_fused", 0)
-            self.name += " [Jacobi path forced]"
-            self.roof_kernel = "metric_eval_kernel<float,2,2>"
-            self.flops_per_unit = lambda: 4 * 11.3 * self.D ** 3
+        self.jacobi = jacobi or os.environ.get("HTA_RMHMC_FUSED", "1") == "0"
+        if self.jacobi:      # the general route: an eigendecomposition per metric evaluation (what SURVEY 8d's flop count describes)
+            self.name = self.name + " [eigendecomposition route forced: hta_set_tuning('rmhmc_fused', 0)]"
 
     def units_per_step(self):
         return self.C * self.T * self.L
 
-    def flops_per_unit(self):
+    def executed_flops_per_unit(self):
         # flops the fused kernel executes per explicit step (csrc/rmhmc_fused.hip): 4 half steps x (2 + K) symmetric
         # matrix-vector products (K = 2 refinements at jitter 1e-3) + the trajectory's Cholesky (D^3 / 3 FMAs) spread over
-        # its L steps.  (The reference's route - an eigendecomposition per metric evaluation - is 4 x 11.3 D^3 = 4.5e7
-        # per step; the soft-abs map is the identity on this spectrum, see DESIGN.md.)
+        # its L steps.
         return 4 * 4 * 2 * self.D ** 2 + (2 * self.D ** 3 / 3) / self.L
 
     @property
     def roof_kernel(self):      # the trajectory kernel the library picks at this chain count (csrc/rmhmc_fused.hip dispatch)
-        if "roof_kernel" in self.__dict__:
-            return self.__dict__["roof_kernel"]
+        if self.jacobi:
+            return "metric_eval_kernel<float> (+ phi_c_kernel, mh_select)"
         if self.C < 704:
             return "rmhmc_fused_kernel<float,56,1> (one chain per workgroup)"
         if self.C <= 2048:
             return "rmhmc_mfma4_kernel (4 chains per workgroup, v_mfma_f32_4x4x1_16b)"
         return "rmhmc_batch_kernel<25> (16 chains per workgroup, v_mfma_f32_16x16x4) + rmhmc_momentum_wave_kernel<13>"
 
-    @roof_kernel.setter
-    def roof_kernel(self, v):
-        self.__dict__["roof_kernel"] = v
-
     def bytes_per_unit(self):
         return 32 * self.D
 
     def step(self, k):
-        self.abi.rmhmc_gaussian_sample(self.cur, self.theta0, self.tgt.precision, self.tgt.mean, self.tgt.log_norm,
-                                       self.abi.METRIC_SOFTABS, self.alpha, self.jitter, self.L, self.eps, self.omega,
-                                       self.T, 0, -1, self.seed + k, self.off, self.samples, self.rej, self.ws)
+        if self.jacobi:
+            self.abi.set_tuning("rmhmc_fused", 0)
+        try:
+            self.abi.rmhmc_gaussian_sample(self.cur, self.theta0, self.tgt.precision, self.tgt.mean, self.tgt.log_norm,
+                                           self.abi.METRIC_SOFTABS, self.alpha, self.jitter, self.L, self.eps, self.omega,
+                                           self.T, 0, -1, self.seed + k, self.off, self.samples, self.rej, self.ws)
+        finally:
+            if self.jacobi:
+                self.abi.set_tuning("rmhmc_fused", 1)
 
     def check(self):
         assert torch.isfinite(self.samples).all()
         return 1.0 - float(self.rej.double().mean()) / (self.T * max(1, self._steps_done))
+
+    def roofline(self, kernel_ms, call_ms, prof_n, steps):
+        """Two fractions, both against the 157.3 TFLOP/s fp32 peak (vector == matrix): `frac` in SURVEY 8(d)'s terms (4.5e7 flop
+        per chain-step: the reference's eigendecomposition per metric evaluation) -- meaningful for the eigendecomposition
+        route, and a >1 'model speed-up' for the closed-form routes, which do not do that work; `executed` = the flops the
+        timed kernels really execute."""
+        units = self.units_per_step()
+        tf_survey = self.SURVEY_FLOPS * units / (kernel_ms * 1e-3) / 1e12
+        tf_exec = (self.SURVEY_FLOPS if self.jacobi else self.executed_flops_per_unit()) * units / (kernel_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": tf_exec, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_exec / FP32_PEAK_TFLOPS,
+                "traffic": None, "kernel": self.roof_kernel, "kernel_ms_per_step": kernel_ms, "call_ms": call_ms,
+                "launches_per_step": prof_n / max(1, steps),
+                "executed_flops_per_chain_step": self.SURVEY_FLOPS if self.jacobi else self.executed_flops_per_unit(),
+                "survey_8d": {"flops_per_chain_step": self.SURVEY_FLOPS, "achieved": tf_survey, "frac": tf_survey / FP32_PEAK_TFLOPS,
+                              "note": "SURVEY 8(d) counts an eigendecomposition per metric evaluation; a frac > 1 here means the "
+                                      "timed route does not do that work (closed form for constant curvature, DESIGN.md section 4)"},
+                "note": "achieved/frac = flops the timed kernels execute (%s) / fp32 peak 157.3 TF; kernel time = every profiled "
+                        "launch of a step" % ("eigendecomposition route: 4 x 11.3 D^3 per step" if self.jacobi else
+                                               "shared-inverse solves + one Cholesky per trajectory")}
 
     def cpu_baseline(self, seconds):
         """Reference cost structure: every dH/dtheta, dH/dp is an autograd pass through hessian + eigh (S:395-422)."""
@@ -217,35 +326,49 @@ class Cfg3:
         init = 0.1 * torch.randn(self.D, generator=torch.Generator().manual_seed(0))
         torch.manual_seed(0)
         t0 = time.time(); TP.port_sample_rmhmc(lp, init, 1, 1, self.eps, self.omega, self.alpha, jitter=self.jitter); dt1 = time.time() - t0
-        n = max(1, int(seconds / (dt1 * self.L)))
-        t0 = time.time()
-        _, acc = TP.port_sample_rmhmc(lp, init, n, self.L, self.eps, self.omega, self.alpha, burn=-1, jitter=self.jitter)
-        dt = time.time() - t0
-        return {"value": n * self.L / dt, "unit": "leapfrog-steps/s", "cores": 1, "kind": "port",
-                "sample": "1 chain x %d trajectories x L=%d explicit steps, jitter=%g (oracle/torch_port.py: autograd "
-                          "through hessian+eigh per gradient, as the reference), %.1f s" % (n, self.L, self.jitter, dt),
-                "acceptance": acc}
+        n = max(1, int(seconds / 3 / (dt1 * self.L)))
+
+        def once():
+            t0 = time.time()
+            _, acc = TP.port_sample_rmhmc(lp, init, n, self.L, self.eps, self.omega, self.alpha, burn=-1, jitter=self.jitter)
+            dt = time.time() - t0
+            return {"value": n * self.L / dt, "unit": "leapfrog-steps/s", "cores": 1, "kind": "port",
+                    "sample": "1 chain x %d trajectories x L=%d explicit steps, jitter=%g (oracle/torch_port.py: autograd "
+                              "through hessian+eigh per gradient, as the reference), %.1f s; median of 3" % (n, self.L, self.jitter, dt),
+                    "acceptance": acc}
+        out = _median3(once)
+        out["pinned_to"] = "tests/golden/cfg3.npz (test_torch_port_cfg3_with_jitter_matches_reference_run)"
+        return out
 
 
 class Cfg5(Cfg3):
     """BASELINE config 5: cfg3 sharded over the node, 1024 chains per GPU (8192 on 8 GPUs), 100 trajectories per step; the one
-    collective of the path - the gather of samples[S, C/G, D] over RCCL - runs after the timed region and is reported as
-    `gather_ms` (excluded from the rate, 8e)."""
+    collective of the path - the gather of samples[S, C/G, D] to rank 0 over RCCL - runs after the timed region and is
+    reported as `gather_ms` (excluded from the rate, 8e)."""
+    key = "cfg5"
     name = "cfg5: cfg3 (D=100 explicit RMHMC, softabs, jitter=1e-3, L=10) sharded, 1024 chains per GPU"
     chains, traj = 1024, 100
 
     def gather(self, world):
         from hamiltorch_amd.dist import gather_samples
-        return gather_samples(self.samples, self.C * world)
+        return gather_samples(self.samples, self.C * world, dst=0)
+
+
+class Cfg3N(Cfg3):
+    """BASELINE.json's second north-star target: the D=100 explicit-RMHMC problem at 1024 chains on one GPU."""
+    key = "cfg3@1024"
+    name = "north-star RMHMC target: " + Cfg3.name + ", 1024 chains"
+    chains, traj = 1024, 100
 
 
 class Cfg4:
     """BASELINE config 4: Bayesian MLP 8-100-1 (D=1001), 400 points, symmetric split HMC M=4, 512 chains."""
+    key = "cfg4"
     name = "cfg4: MLP Linear(8,100)-ReLU-Linear(100,1) regression, split HMC M=4 x 100 points, eps=5e-4, L=10"
     D, L, eps, chains, traj = 1001, 10, 5e-4, 512, 20
     dtype_name = "f32"
 
-    def __init__(self, dev, chains, traj, chain_offset, seed=0):
+    def __init__(self, dev, chains, traj, chain_offset, seed=1):
         from hamiltorch_amd import _abi
         self.abi = _abi
         self.C, self.T = chains or self.chains, traj or self.traj
@@ -272,7 +395,7 @@ class Cfg4:
     def bytes_per_unit(self):
         return 16 * self.D
 
-    roof_kernel = "mlp_mfma_kernel<2,7,0,512>"
+    roof_kernel = "mlp_mfma_kernel"
 
     def step(self, k):
         self.abi.mlp_hmc_sample(self.cur, self.theta0, 8, 100, "relu", self.X, self.Y, 4, 100, [1.0] * 4, 100.0, 4.0,
@@ -282,6 +405,13 @@ class Cfg4:
     def check(self):
         assert torch.isfinite(self.samples[1:]).all()
         return 1.0 - float(self.rej.double().mean()) / (self.T * max(1, self._steps_done))
+
+    def roofline(self, kernel_ms, call_ms, prof_n, steps):
+        tf = self.flops_per_unit() * self.units_per_step() / (kernel_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
+                "traffic": None, "kernel": self.roof_kernel, "kernel_ms_per_step": kernel_ms, "call_ms": call_ms,
+                "launches_per_step": prof_n / max(1, steps), "algorithmic_flops_per_chain_step": self.flops_per_unit(),
+                "note": "2M x 6 flop per (point, weight) per split step (SURVEY 8d) against the fp32 matrix peak"}
 
     def cpu_baseline(self, seconds):
         """Reference cost structure: per-split closure + autograd gradient for every half kick (S:499-540)."""
@@ -296,46 +426,29 @@ class Cfg4:
         init = self.theta0[0].cpu()
         im = torch.ones(self.D)
         t0 = time.time(); TP.port_sample_split(fl, init, 2, self.L, self.eps, -1, im); dt2 = time.time() - t0
-        n = max(2, int(seconds / (dt2 / 2)))
-        t0 = time.time(); _, acc = TP.port_sample_split(fl, init, n, self.L, self.eps, -1, im); dt = time.time() - t0
-        return {"value": n * self.L / dt, "unit": "leapfrog-steps/s", "cores": 1, "kind": "port",
-                "sample": "1 chain x %d trajectories x L=%d split steps (oracle/torch_port.py: functional model + "
-                          "autograd per half kick, as the reference), %.1f s" % (n, self.L, dt), "acceptance": acc}
+        n = max(2, int(seconds / 3 / (dt2 / 2)))
+
+        def once():
+            t0 = time.time(); _, acc = TP.port_sample_split(fl, init, n, self.L, self.eps, -1, im); dt = time.time() - t0
+            return {"value": n * self.L / dt, "unit": "leapfrog-steps/s", "cores": 1, "kind": "port",
+                    "sample": "1 chain x %d trajectories x L=%d split steps (oracle/torch_port.py: functional model + "
+                              "autograd per half kick, as the reference), %.1f s; median of 3" % (n, self.L, dt), "acceptance": acc}
+        out = _median3(once)
+        out["pinned_to"] = "tests/golden/cfg4.npz (test_torch_port_cfg4_full_size_matches_reference_run)"
+        return out
 
 
-WORKLOADS = {"cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4, "cfg5": Cfg5}
+WORKLOADS = {"cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4, "cfg5": Cfg5, "cfg3@1024": Cfg3N}
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # one rank per GPU over RCCL ("nccl" on ROCm).  HTA_BENCH_BACKEND=gloo + several ranks on one GPU is only
-        # for exercising this code path on a single-GPU box.
-        backend = os.environ.get("HTA_BENCH_BACKEND", "nccl")
-        local = local % torch.cuda.device_count()
-        torch.cuda.set_device(local)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-    if a.workload not in WORKLOADS:
-        try:
-            import bench_extra
-            WORKLOADS.update(bench_extra.WORKLOADS)
-        except ImportError:
-            pass
-    W = WORKLOADS[a.workload]
-    w = W(dev, a.chains, a.traj, chain_offset=rank * (a.chains or W.chains))
-    w._steps_done = 0
+# ---------------------------------------------------------------------------------------------------
+# one measurement
+# ---------------------------------------------------------------------------------------------------
+def measure(w, steps, warmup, world, dist, dev, profile_every=1):
+    """W untimed warm-up steps, then exactly `steps` timed steps bracketed by barrier + synchronize on both sides; the
+    MAX over ranks of the wall time.  Also: device time per call (one event pair around the region) and the dominant
+    kernels' time from HIP events recorded inside the library on the launch stream (hta_set_tuning('profile', n))."""
+    abi = w.abi
 
     def barrier():
         torch.cuda.synchronize()
@@ -343,110 +456,192 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    from hamiltorch_amd import _abi
-    for kv in filter(None, os.environ.get("HTA_TUNING", "").split(",")):      # e.g. HTA_TUNING=rmhmc_momwave=0 (A/B runs)
-        key, val = kv.split("=")
-        _abi.set_tuning(key, int(val))
-    for k in range(a.warmup):
+    w._steps_done = 0
+    for k in range(warmup):
         w.step(k)
     w.rej.zero_()
     barrier()
-    # HIP event pair around the dominant kernel, on its stream, live in the timed region: every launch for the workloads with
-    # several launches per step; every 4th for cfg2, where a pair (two barrier packets) is 3 % of a 0.19 ms step
-    _abi.set_tuning("profile", 4 if a.workload == "cfg2" else 1)
+    abi.set_tuning("profile", profile_every)
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     t0 = time.perf_counter()
     ev[0].record()          # one event pair around the whole timed region (per-step pairs put bubbles between the launches)
-    for k in range(a.steps):
-        w.step(a.warmup + k)
+    for k in range(steps):
+        w.step(warmup + k)
     ev[1].record()
     barrier()
     dt = time.perf_counter() - t0
-    w._steps_done = a.steps
-    call_ms = ev[0].elapsed_time(ev[1]) / max(1, a.steps)                 # device time per C-ABI call (all its kernels)
-    prof_ms, prof_n = _abi.profile_collect()
-    _abi.set_tuning("profile", 0)
-    kernel_ms = prof_ms / max(1, prof_n)                                  # the trajectory kernel alone
+    w._steps_done = steps
+    call_ms = ev[0].elapsed_time(ev[1]) / max(1, steps)                   # device time per C-ABI call (all its kernels)
+    prof_ms, prof_n = abi.profile_collect()
+    abi.set_tuning("profile", 0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    acc = w.check()
-    units = w.units_per_step() * a.steps * world
-    value = units / dt
-    gather_ms = None
-    if hasattr(w, "gather"):            # the path's only collective, outside the timed region
-        barrier()
-        tg = time.perf_counter()
-        gathered = w.gather(world)
-        barrier()
-        gather_ms = (time.perf_counter() - tg) * 1e3
-        assert gathered.shape[1] == w.C * world
-        del gathered
+    return dt, call_ms, prof_ms, prof_n
 
-    if rank == 0:
-        alg_bytes = w.bytes_per_unit() * w.units_per_step()
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        if hasattr(w, "flops_per_unit"):
-            kernel_ms = prof_ms / max(1, a.steps)          # all metric-evaluation launches of one step
-            tf = w.flops_per_unit() * w.units_per_step() / (kernel_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf / FP32_PEAK_TFLOPS, "traffic": None,      # filled below from profiles/traffic_<workload>.json
-                    "kernel": getattr(w, "roof_kernel", "metric_eval_kernel<float>"),
-                    "kernel_ms_per_step": kernel_ms, "launches_per_step": prof_n / max(1, a.steps),
-                    "algorithmic_flops_per_chain_step": w.flops_per_unit(),
-                    "note": "fp32 vector == fp32 MFMA peak (157.3 TF).  cfg3: flops the fused route executes (shared-inverse "
-                            "solves + one Cholesky per trajectory; the eigh route of the reference would be 4.5e7 per step); "
-                            "kernel time = every profiled launch of a step (trajectory kernels, and the momentum kernel when it "
-                            "runs on the same stream); below 704 chains one 4-wave workgroup per chain: latency bound; cfg4: "
-                            "2M x 6 flop per (point, weight) per split step (SURVEY 8d)"}
-        else:
-            roof = None
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)
-        if os.path.exists(tf) and w.C == W.chains and w.T == W.traj:       # measured at the workload's own shape only
-            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
-        if roof is not None:
-            roof["traffic"] = traffic                      # per step (all launches), like `achieved` for these workloads
-        from hamiltorch_amd.ess import ess_min
-        ess = ess_min(w.samples[1:]) if w.T >= 8 else float("nan")
-        out = {
-            "metric": "leapfrog-steps/sec (whole node) at 1024 chains; ESS/sec vs CPU ref",
-            "value": value, "unit": "leapfrog-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": W.dtype_name, "data": "synthetic",
+
+def result_of(w, W, dt, call_ms, prof_ms, prof_n, steps, warmup, world):
+    """The per-workload record: value, roofline (+ physical), acceptance, ESS/s."""
+    acc = w.check()
+    units = w.units_per_step() * steps * world
+    if isinstance(w, Cfg2):
+        kernel_ms = prof_ms / max(1, prof_n)                              # the trajectory kernel alone (sampled launches)
+    else:
+        kernel_ms = prof_ms / max(1, steps)                               # every profiled launch of one step
+    roof = w.roofline(kernel_ms, call_ms, prof_n, steps)
+    pkey = "%s%s@%d" % (W.key.split("@")[0], "jacobi" if getattr(w, "jacobi", False) else "", w.C)
+    phys = _physical(pkey)
+    roof["physical"] = phys
+    if phys is not None and phys.get("trajectories_per_step") == w.T:      # bytes per step only at the shape they were counted at
+        roof["traffic"] = phys.get("hbm_bytes_per_step")
+    from hamiltorch_amd.ess import ess_min
+    ess = ess_min(w.samples[1:]) if w.T >= 8 else float("nan")
+    return {"workload": W.name, "value": units / dt, "unit": "leapfrog-steps/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "dtype": W.dtype_name,
             "config": {"workload": W.name, "chains_per_gpu": w.C, "chains_total": w.C * world,
                        "trajectories_per_step": w.T, "leapfrog_steps_per_trajectory": W.L, "D": W.D,
                        "samples_stored": True, "parallelism": "chains sharded, %d per GPU, no collective" % w.C},
-            "roofline": roof or {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "hmc_gauss_quad_kernel<3,false,25>" if w.C <= 65536 else "hmc_gauss_eig_kernel<float,3,false>",
-                         "kernel_ms": kernel_ms,
-                         "call_ms": call_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "16*D bytes per chain-step (SURVEY 8d); state is register-resident for the whole "
-                                 "launch, so real HBM traffic is the draw records and the sample rows only; trajectories "
-                                 "are integrated in the eigenbasis of P (identity mass), one eigen-coordinate per lane of "
-                                 "a DPP quad: 2 dependent FMAs per step; at 1024 chains the launch is 64 waves on 256 "
-                                 "CUs: latency/issue bound, not bandwidth bound"},
-            "acceptance_rate": acc,
-            "ess_per_sec": ess / (call_ms * 1e-3),
-        }
+            "roofline": roof, "acceptance_rate": acc, "ess_per_sec": ess / (call_ms * 1e-3)}
+
+
+def api_timing(w, reps=5):
+    """Wall time of the same work through hamiltorch_amd.sample() (synchronised): median of `reps` calls after one warm-up."""
+    w.api_call(0)
+    torch.cuda.synchronize()
+    ts = []
+    for k in range(reps):
+        t0 = time.perf_counter()
+        out = w.api_call(1 + k)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+        del out
+    return statistics.median(ts)
+
+
+# ---------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _self_launch(n):
+    """`python bench.py --gpus N` outside torch.distributed.run: re-exec as N ranks on this node, one per GPU."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def main():
+    a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        _self_launch(a.gpus)                                              # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or let bench.py launch the "
+                         "ranks itself)" % (a.gpus, world, a.gpus))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dist = None
+    backend = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # one rank per GPU over RCCL ("nccl" on ROCm).  HTA_BENCH_BACKEND=gloo + several ranks on one GPU is only
+        # for exercising this code path on a single-GPU box.
+        backend = os.environ.get("HTA_BENCH_BACKEND", "nccl")
+        ndev = torch.cuda.device_count()
+        if backend == "nccl" and ndev < world:
+            raise SystemExit("bench.py: %d ranks over RCCL need %d GPUs, this node shows %d" % (world, world, ndev))
+        local = local % ndev
+        torch.cuda.set_device(local)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    ranks_seen, devices = 1, [[0, local]]
+    if world > 1:
+        one = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(one)                                              # over RCCL: every rank is really there
+        ranks_seen = int(one.item())
+        ids = [None] * world
+        dist.all_gather_object(ids, [rank, local])
+        devices = ids
+        assert ranks_seen == dist.get_world_size() == a.gpus, (ranks_seen, dist.get_world_size(), a.gpus)
+    if a.workload not in WORKLOADS:
+        try:
+            import bench_extra
+            WORKLOADS.update(bench_extra.WORKLOADS)
+        except ImportError:
+            pass
+    from hamiltorch_amd import _abi
+    for kv in filter(None, os.environ.get("HTA_TUNING", "").split(",")):      # e.g. HTA_TUNING=rmhmc_momwave=0 (A/B runs)
+        key, val = kv.split("=")
+        _abi.set_tuning(key, int(val))
+
+    W = WORKLOADS[a.workload]
+    w = W(dev, a.chains, a.traj, chain_offset=rank * (a.chains or W.chains))
+    # HIP event pair around the dominant kernel, on its stream, live in the timed region: every launch for the workloads with
+    # several launches per step; every 4th for cfg2, where a pair (two barrier packets) is 3 % of a 0.19 ms step
+    dt, call_ms, prof_ms, prof_n = measure(w, a.steps, a.warmup, world, dist, dev, 4 if a.workload == "cfg2" else 1)
+    res = result_of(w, W, dt, call_ms, prof_ms, prof_n, a.steps, a.warmup, world)
+    gather_ms = None
+    if hasattr(w, "gather"):            # the path's only collective, outside the timed region
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        tg = time.perf_counter()
+        gathered = w.gather(world)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        if rank == 0:
+            assert gathered.shape[1] == w.C * world
+        del gathered
+
+    if rank == 0:
+        out = {"metric": METRIC, "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": W.dtype_name, "data": "synthetic", "config": res["config"], "roofline": res["roofline"],
+               "acceptance_rate": res["acceptance_rate"], "ess_per_sec": res["ess_per_sec"],
+               "ranks_seen": ranks_seen, "rank_devices": devices,
+               "launcher": "torch.distributed.run" if world > 1 else "single process",
+               "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None}
         if gather_ms is not None:
             out["gather_ms"] = gather_ms
-            out["config"]["parallelism"] += "; one all_gather of samples[%d, %d, %d] per rank after the timed region" % (
+            out["config"]["parallelism"] += "; one gather of samples[%d, %d, %d] per rank to rank 0 after the timed region" % (
                 w.T + 1, w.C, W.D)
+        if hasattr(w, "api_call") and world == 1:
+            api_ms = api_timing(w)
+            out["api_ms_per_step"] = api_ms
+            out["api_value"] = w.units_per_step() / (api_ms * 1e-3)
+            out["api_note"] = "the same step through hamiltorch_amd.sample() (route selection, sample-tensor allocation, list of " \
+                              "views), host wall time incl. synchronize, median of 5"
         if world == 1 and not a.no_cpu_baseline:
             cb = w.cpu_baseline(a.cpu_seconds)
             if cb is not None:
+                cb.setdefault("host_cores_available", os.cpu_count())
+                cb["host_cpu"] = _cpu_model()
                 out["cpu_baseline"] = cb
-                out["cpu_baseline"].setdefault("host_cores_available", os.cpu_count())
-                out["speedup_vs_cpu_baseline"] = value / cb["value"]          # against the `cores` the baseline used
-                out["speedup_vs_cpu_baseline_1core"] = value / (cb["value"] / max(1, cb.get("cores", 1)))
+                out["speedup_vs_cpu_baseline"] = res["value"] / cb["value"]          # against the `cores` the baseline used
+                out["speedup_vs_cpu_baseline_1core"] = res["value"] / (cb["value"] / max(1, cb.get("cores", 1)))
+        if world == 1 and a.workload == "cfg2" and not a.no_secondary and a.chains is None and a.traj is None:
+            del w
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary(dev, a)
         print(json.dumps(out), flush=True)
         if a.sweep and a.workload == "cfg2":
             for C in (1024, 4096, 16384, 65536, 262144, 1048576):
-                ws = W(dev, C, max(10, min(w.T, (1 << 24) // C)), 0)
+                ws = W(dev, C, max(10, min(1000, (1 << 24) // C)), 0)
                 ws._steps_done = 1
                 ws.step(0); torch.cuda.synchronize()
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -459,6 +654,37 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def secondary(dev, a):
+    """BASELINE.json's other targets on the same GPU, each a complete record: the D=100 explicit-RMHMC north-star size
+    (1024 chains), config 3 (256 chains) on the default route and on the eigendecomposition route SURVEY 8(d)'s flop
+    count describes, config 4 (512 chains)."""
+    out = []
+    plan = [(Cfg3N, {}, 4, 1, True), (Cfg3, {}, 3, 1, True), (Cfg3, {"jacobi": True, "traj": 20}, 2, 1, False), (Cfg4, {}, 10, 2, True)]
+    cpu_cache = {}
+    for W, kw, steps, warmup, want_cpu in plan:
+        try:
+            w = W(dev, None, kw.get("traj"), 0, **{k: v for k, v in kw.items() if k != "traj"})
+            dt, call_ms, prof_ms, prof_n = measure(w, steps, warmup, 1, None, dev, 1)
+            r = result_of(w, W, dt, call_ms, prof_ms, prof_n, steps, warmup, 1)
+            if getattr(w, "jacobi", False):
+                r["workload"] = w.name
+                r["config"]["workload"] = w.name
+            if not a.no_cpu_baseline:
+                ck = "cfg3" if isinstance(w, Cfg3) else W.key
+                if ck not in cpu_cache and want_cpu:
+                    cpu_cache[ck] = w.cpu_baseline(a.cpu_seconds)
+                    cpu_cache[ck]["host_cpu"] = _cpu_model()
+                if ck in cpu_cache:
+                    r["cpu_baseline"] = cpu_cache[ck]
+                    r["speedup_vs_cpu_baseline_1core"] = r["value"] / (cpu_cache[ck]["value"] / max(1, cpu_cache[ck].get("cores", 1)))
+            out.append(r)
+            del w
+            torch.cuda.empty_cache()
+        except Exception as e:          # a secondary line must never take the headline down with it
+            out.append({"workload": W.name, "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
+    return out
 
 
 if __name__ == "__main__":

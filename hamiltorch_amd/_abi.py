@@ -121,9 +121,13 @@ def last_error() -> str:
     return load().hta_last_error().decode("utf-8", "replace")
 
 
+class InvalidArguments(RuntimeError):
+    """HTA_ERR_INVALID (-1): the library refused the arguments before launching anything."""
+
+
 def _check(rc, what):
     if rc != 0:
-        raise RuntimeError("hamiltorch_amd: %s failed (%d): %s" % (what, rc, last_error()))
+        raise (InvalidArguments if rc == -1 else RuntimeError)("hamiltorch_amd: %s failed (%d): %s" % (what, rc, last_error()))
 
 
 def _suffix(t: torch.Tensor) -> str:

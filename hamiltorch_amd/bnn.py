@@ -9,6 +9,8 @@ native kernel (csrc/mlp_split.hip) instead of calling back into torch.
 """
 from __future__ import annotations
 
+import math
+
 import torch
 import torch.nn as nn
 
@@ -52,7 +54,8 @@ def define_model_log_prob(model, model_loss, x, y, params_flattened_list, params
     """S:1093-1201.  Returns ``log_prob_func(flat_params)``."""
     names = [n for n, _ in model.named_parameters()]
     buffers = {n: b for n, b in model.named_buffers()}
-    taus = [torch.as_tensor(t, dtype=torch.get_default_dtype()) for t in tau_list]
+    taus = [float(t) for t in tau_list]                  # host scalars: the closure stays capturable as a HIP graph
+    half_log_taus = [0.5 * math.log(t) for t in taus]
     x_dev = None if x is None else x.to(device)
     y_dev = None if y is None else y.to(device)
     sizes = list(params_flattened_list)
@@ -62,11 +65,10 @@ def define_model_log_prob(model, model_loss, x, y, params_flattened_list, params
         i_prev = 0
         l_prior = torch.zeros_like(params[0])
         tensors = {}
-        for name, n, shape, tau in zip(names, sizes, shapes, taus):
+        for name, n, shape, tau, hlt in zip(names, sizes, shapes, taus, half_log_taus):
             w = params[i_prev:i_prev + n]
-            tau = tau.to(params)
             # Normal(0, tau^-1/2).log_prob(w).sum()   (S:1143, S:1156)
-            l_prior = l_prior + (-0.5 * tau * (w * w) + 0.5 * torch.log(tau) - 0.9189385332046727).sum()
+            l_prior = l_prior + (-0.5 * tau * (w * w) + (hlt - 0.9189385332046727)).sum()
             tensors[name] = w.reshape(shape)
             i_prev += n
         if x_dev is None:
@@ -93,7 +95,7 @@ def define_model_log_prob(model, model_loss, x, y, params_flattened_list, params
     if st is not None and model_loss == 'regression' and x is not None and not predict \
             and x.dim() == 2 and st[0][-1] == 1:
         log_prob_func._hta_spec = dict(dims=st[0], act=st[1], X=x_dev, Y=y_dev.reshape(x_dev.shape[0], -1),
-                                       tau_list=[float(t) for t in taus], tau_out=float(tau_out),
+                                       tau_list=list(taus), tau_out=float(tau_out),
                                        prior_scale=float(prior_scale))
     return log_prob_func
 

@@ -27,6 +27,18 @@ void set_error(const char* fmt, ...);
     }                                                                                 \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): a process that samples on a second GPU
+// must opt the kernel in there as well.  A DevOnce is a "done" flag per device of the calling thread's current device.
+struct DevOnce {
+  bool f[64] = {};
+  static int dev() {
+    int d = 0;
+    return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) ? d : 63;
+  }
+  bool operator!() const { return !f[dev()]; }
+  DevOnce& operator=(bool v) { f[dev()] = v; return *this; }
+};
+
 // ---- wave64 reductions (DPP via __shfl_xor butterflies) --------------------------------
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

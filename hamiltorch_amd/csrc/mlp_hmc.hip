@@ -457,7 +457,7 @@ template <typename T, int INMAX, int NT, int ACT, bool EXACT> int launch_mlp_act
   size_t cmsz = (size_t)nbch * ldc;
   if (cmsz < recs) cmsz = recs;
   const size_t lds = fixed + (cmsz + nbch) * sizeof(T);
-  static bool done = false;
+  static DevOnce done;
   if (!done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp1_hmc_kernel<T, INMAX, NT, ACT, EXACT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -420,7 +420,7 @@ template <int NK, int NPT, int ACT, int NTMAX> static int launch_mfma(const MlpA
   const int NU = (a.H + 15) / 16;
   int Npad;
   const size_t lds = mfma_lds_bytes(a, NK, NU, &Npad);
-  static bool done = false;
+  static DevOnce done;
   if (!done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_mfma_kernel<NK, NPT, ACT, NTMAX>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

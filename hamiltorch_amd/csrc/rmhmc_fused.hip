@@ -1428,9 +1428,9 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
       (void)hipStreamWaitEvent(ov->side, ov->start, 0);
     }
   }
-  static bool done[8] = {false, false, false, false, false, false, false, false};     // per T instantiation
-  static bool done2[8] = {false, false, false, false, false, false, false, false};
-  static bool done_mom = false;
+  static DevOnce done[8];     // per T instantiation
+  static DevOnce done2[8];
+  static DevOnce done_mom;
   int bidx = 0;
   for (int t0 = 0; t0 < n_traj; t0 += (block > 0 ? block : n_traj), ++bidx) {
     const int nt = block > 0 ? (n_traj - t0 < block ? n_traj - t0 : block) : n_traj;
@@ -1490,7 +1490,7 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
     // is only taken on request (tuning value 3: parity tests keep the variant alive)
     const bool pair = g_rmhmc_fused == 3 && block > 0 && (series || !has_jitter);
     const bool need_w = !(block > 0 && (series || !has_jitter));      // a Cholesky inside the kernel: work matrix in LDS
-    auto launch = [&](auto kern, auto kern2, bool& dn, bool& dn2) -> int {
+    auto launch = [&](auto kern, auto kern2, DevOnce& dn, DevOnce& dn2) -> int {
       if constexpr (sizeof(T) == 4) {
         // four chains per workgroup on the 16-block matrix instruction: C / 4 two-wave workgroups (tuning key "rmhmc_mfma4")
         const bool quad4 = g_rmhmc_mfma4 && !pair && block > 0 && (series || !has_jitter) && D <= QK &&
@@ -1508,7 +1508,7 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
         const bool batch = g_rmhmc_batch && !pair && block > 0 && (series || !has_jitter) && D <= 16 * BWV &&
                            (C >= 2048 || g_rmhmc_batch == 2);
         if (batch) {
-          static bool dn_b = false;
+          static DevOnce dn_b;
           if (!dn_b) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rmhmc_batch_kernel<25>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

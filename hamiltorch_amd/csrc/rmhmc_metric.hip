@@ -573,7 +573,7 @@ template <typename T> int metric_eval(const MetricArgsT<T>& a, hipStream_t s) {
   const int NP = ne / 2, nv = ldv / vn;
   const bool small = NP * (NP + 1) / 2 <= 2 * MT && NP * nv <= 2 * MT;
   HTA_REQUIRE(NP * (NP + 1) / 2 <= 4 * MT && NP * nv <= 3 * MT, "hta_metric_eval: D=%d exceeds the per-thread work lists", D);
-  auto launch = [&](auto kern, bool& done) -> int {
+  auto launch = [&](auto kern, DevOnce& done) -> int {
     if (!done) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) { set_error("hta_metric_eval: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
@@ -584,7 +584,7 @@ template <typename T> int metric_eval(const MetricArgsT<T>& a, hipStream_t s) {
     profile_end(s);
     return HTA_OK;
   };
-  static bool done_small = false, done_big = false;   // per T instantiation
+  static DevOnce done_small, done_big;   // per T instantiation
   const int rc = small ? launch(&metric_eval_kernel<T, 2, 2>, done_small) : launch(&metric_eval_kernel<T, 4, 3>, done_big);
   if (rc) return rc;
   HTA_CHECK_LAUNCH("hta_metric_eval");

@@ -3,7 +3,9 @@
 One process per GPU (``torchrun``; backend ``nccl`` = RCCL over xGMI on ROCm, ``gloo`` in the CPU
 tests).  Rank r owns the contiguous block of chains ``shard_chains(C, r, world)``; the device RNG is
 keyed by GLOBAL chain id (``chain_offset``), so the union of all ranks' samples is identical --
-bit for bit -- to a single-GPU run over all C chains.  No collective runs during sampling; the
+bit for bit -- to a single-GPU run over all C chains (``Sampler.HMC_NUTS``: the shared step size is adapted on
+the acceptance statistic of all ranks' chains -- one tiny all-reduce per burn-in trajectory -- so it is the
+single-GPU step size up to the summation order of that mean).  No collective runs during sampling; the
 only communication is one optional gather of the sample tensor at the end (41 MB per rank for
 BASELINE config 5, well under a millisecond on the 7-link xGMI mesh).
 """
@@ -37,17 +39,20 @@ def gather_samples(local: torch.Tensor, total_chains: int, group=None, dst=None)
         pad = torch.zeros(S, cmax, D, dtype=local.dtype, device=local.device)
         pad[:, :local.shape[1]] = local
     pad = pad.contiguous()
+    home = pad.device
+    if pad.is_cuda and dist.get_backend(group) == "gloo":      # gloo moves host memory only (CPU tests, several ranks on one GPU)
+        pad = pad.cpu()
     if dst is None:
-        out = torch.empty(world * S, cmax, D, dtype=local.dtype, device=local.device)
+        out = torch.empty(world * S, cmax, D, dtype=local.dtype, device=pad.device)
         dist.all_gather_into_tensor(out, pad, group=group)      # rank r's block lands in rows [r*S, (r+1)*S)
         out = out.view(world, S, cmax, D)
         parts = [out[r, :, :counts[r]] for r in range(world)]
-        return torch.cat(parts, dim=1)
+        return torch.cat(parts, dim=1).to(home)
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
     dist.gather(pad, bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    return torch.cat([bufs[r][:, :counts[r]] for r in range(world)], dim=1)
+    return torch.cat([bufs[r][:, :counts[r]] for r in range(world)], dim=1).to(home)
 
 
 def sample_sharded(sample_fn, params_init_all: torch.Tensor, *args, gather=True, group=None, **kwargs):
@@ -63,7 +68,19 @@ def sample_sharded(sample_fn, params_init_all: torch.Tensor, *args, gather=True,
     C = params_init_all.shape[0]
     off, cnt = shard_chains(C, rank, world)
     local_init = params_init_all[off:off + cnt].contiguous()
-    out = sample_fn(*args, params_init=local_init, chain_offset=off, **kwargs)
+    from . import samplers
+    prev = samplers._nuts_reduce
+    if world > 1:
+        def reduce_(a_sum, a_cnt, bad):          # Sampler.HMC_NUTS: one step size adapted on the chains of ALL ranks
+            t = torch.tensor([a_sum, a_cnt, float(bad)], dtype=torch.float64,
+                             device=local_init.device if dist.get_backend(group) != "gloo" else "cpu")
+            dist.all_reduce(t, group=group)
+            return float(t[0]), float(t[1]), bool(t[2] > 0)
+        samplers._nuts_reduce = reduce_
+    try:
+        out = sample_fn(*args, params_init=local_init, chain_offset=off, **kwargs)
+    finally:
+        samplers._nuts_reduce = prev
     extra = None
     if isinstance(out, tuple):
         out, extra = out

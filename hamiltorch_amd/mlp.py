@@ -48,6 +48,7 @@ class _MLPEngine:
                 if kind == _abi.MASS_FULL or theta0.shape[1] != self.H * self.n_in + 2 * self.H + 1:
                     self._fb = self.fallback()          # full mass matrix / unexpected layout: generic-callback path
                     return self._fb.begin(theta0, N, burn, inv_mass, seed, chain_offset)
+                self._begin_args = (theta0, N, burn, inv_mass, seed, chain_offset)
                 super().begin(theta0, N, burn, inv_mass, seed, chain_offset)
                 self.X = torch.cat([s["X"].reshape(self.Nb, self.n_in) for s in self.specs]).to(theta0).contiguous()
                 self.Y = torch.cat([s["Y"].reshape(self.Nb) for s in self.specs]).to(theta0).contiguous()
@@ -57,10 +58,20 @@ class _MLPEngine:
                     return self._fb.advance(n0, count, L, eps, H_old, H_new, progress)
                 step = 1 if H_old is not None else count
                 for start in range(n0, n0 + count, step):
-                    _abi.mlp_hmc_sample(self.cur, self.theta0, self.n_in, self.H, self.act, self.X, self.Y, self.M,
-                                        self.Nb, self.tau, self.tau_out, self.prior_scale, self.kind, self.im, self.mf,
-                                        L, eps, min(step, n0 + count - start), start, self.burn, self.seed, self.off,
-                                        self.samples, self.rejected, H_old, H_new, integrator=self.integrator)
+                    try:
+                        _abi.mlp_hmc_sample(self.cur, self.theta0, self.n_in, self.H, self.act, self.X, self.Y, self.M,
+                                            self.Nb, self.tau, self.tau_out, self.prior_scale, self.kind, self.im, self.mf,
+                                            L, eps, min(step, n0 + count - start), start, self.burn, self.seed, self.off,
+                                            self.samples, self.rejected, H_old, H_new, integrator=self.integrator)
+                    except _abi.InvalidArguments:
+                        # the kernels stage the whole data set in LDS (csrc/mlp_hmc.hip: "do not fit the LDS staging"); the
+                        # reference works for any N.  Arguments are validated before anything is launched, so nothing ran:
+                        # a refusal on the very first launch moves the run to the generic-callback path.
+                        if start != 0 or n0 != 0:
+                            raise
+                        self._fb = self.fallback()
+                        self._fb.begin(*self._begin_args)
+                        return self._fb.advance(n0, count, L, eps, H_old, H_new, progress)
                 if progress is not None:
                     progress.update(min(self.N, n0 + count) - 1)
 

@@ -4,6 +4,13 @@ contract, samplers.py:272-274) AND carry the closed form the HIP kernels need, s
 
 An unrecognised callable still works: it is evaluated by torch (``torch.func.vmap`` over
 chains) with the HIP kernels doing the state updates in between (samplers._GenericHMC).
+
+The reference's own idiom is neither of the recognised objects but a closure,
+``lambda w: MultivariateNormal(mean, cov).log_prob(w).sum()`` (tests/test_util.py:98-101 and every
+notebook).  ``probe_gaussian`` recognises such closures by what they compute: constant curvature and a
+gradient affine in the input at widely spread probe points; ``verify_gaussian`` re-checks the recovered
+closed form against the closure on the samples a run produced (``sample`` falls back to the
+generic-callback path on any mismatch).
 """
 from __future__ import annotations
 
@@ -82,3 +89,123 @@ def as_gaussian(log_prob_func, like=None):
     if like is not None and (tgt.mean.device != like.device or tgt.mean.dtype != like.dtype):
         tgt = tgt.to(device=like.device, dtype=like.dtype)
     return tgt
+
+
+MAX_NATIVE_DIM = 1024      # hta_hmc_gaussian_sample's limit (csrc/hmc_gaussian.hip: wave-per-chain kernel)
+
+
+def _tol(dtype):
+    return 2e-4 if dtype == torch.float32 else 1e-9
+
+
+def probe_gaussian(log_prob_func, theta0, max_dim=MAX_NATIVE_DIM):
+    """GaussianTarget equal to ``log_prob_func`` if that callable is a quadratic form, else None.
+
+    Evaluates value, gradient and Hessian (``torch.func``) at five probe points spread over three orders of
+    magnitude around ``theta0[0]`` (+-1, +-30, +1000 along random directions) and accepts only if
+      * every Hessian is finite, symmetric and equal to the first to rounding (constant curvature),
+      * the gradients are the affine map ``-P (x - mu)`` of ONE ``mu`` (solved from the first point),
+      * the values are ``log_norm - 1/2 (x - mu)^T P (x - mu)`` with ONE ``log_norm``.
+    A function that is only piecewise quadratic can pass when every probe lands in one piece; ``sample``
+    therefore verifies the closed form on the run's own samples afterwards (``verify_gaussian``).
+    Anything torch.func cannot differentiate twice / batch returns None (the generic path handles it)."""
+    if not callable(log_prob_func) or isinstance(log_prob_func, (list, tuple)):
+        return None
+    x0 = theta0.detach().reshape(-1, theta0.shape[-1])[0]
+    D = x0.numel()
+    if D > max_dim:
+        return None
+    dt, dev = x0.dtype, x0.device
+    if dt not in (torch.float32, torch.float64):
+        return None
+    g = torch.Generator(device="cpu").manual_seed(0x6A55)
+    dirs = torch.randn(5, D, generator=g, dtype=torch.float64)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True).clamp_min(1e-30) * (D ** 0.5)
+    scale = torch.tensor([1.0, -1.0, 30.0, -30.0, 1000.0], dtype=torch.float64)[:, None]
+    pts = (x0.double().cpu()[None] + scale * dirs).to(device=dev, dtype=dt)
+
+    def f(w):
+        r = log_prob_func(w)
+        if isinstance(r, tuple):
+            raise TypeError("tuple protocol")
+        return r.sum()
+    tol = _tol(dt)
+    try:
+        with torch.enable_grad():
+            # cheap screen first (4 gradients): along one line the gradient of a quadratic is affine in the step
+            line = (x0.double().cpu()[None] + torch.tensor([0.0, 1.0, -1.0, 30.0], dtype=torch.float64)[:, None] * dirs[0]).to(device=dev, dtype=dt)
+            gl = torch.func.vmap(torch.func.grad(f))(line).double()
+            if gl.shape != (4, D) or not torch.isfinite(gl).all():
+                return None
+            d1, d2, d3 = gl[1] - gl[0], gl[2] - gl[0], gl[3] - gl[0]
+            gs = float(gl.abs().max()) + 1e-30
+            if float((d1 + d2).abs().max()) > 50 * tol * gs or float((d3 - 30.0 * d1).abs().max()) > 50 * tol * gs * 30:
+                return None
+            H = torch.func.vmap(torch.func.hessian(f))(pts)
+            gr = torch.func.vmap(torch.func.grad(f))(pts)
+            v = torch.func.vmap(f)(pts)
+    except (RuntimeError, TypeError, ValueError, NotImplementedError, AttributeError, IndexError) as e:
+        if isinstance(e, (torch.OutOfMemoryError, torch.AcceleratorError)):
+            raise
+        return None
+    if H.shape != (5, D, D) or gr.shape != (5, D) or v.shape != (5,):
+        return None
+    H, gr, v, X = H.double(), gr.double(), v.double(), pts.double()
+    if not (torch.isfinite(H).all() and torch.isfinite(gr).all() and torch.isfinite(v).all()):
+        return None
+    hs = float(H[0].abs().max())
+    if hs == 0.0:
+        return None                                             # flat / linear: not a Gaussian
+    if float((H - H[0]).abs().max()) > tol * hs or float((H[0] - H[0].T).abs().max()) > tol * hs:
+        return None
+    P = -0.5 * (H[0] + H[0].T)
+    try:
+        mu = X[0] + torch.linalg.solve(P, gr[0])               # grad = -P (x - mu)
+    except RuntimeError:
+        return None
+    if not torch.isfinite(mu).all():
+        return None
+    d = X - mu
+    want_g = -(d @ P)
+    gs = float(want_g.abs().max()) + float(gr.abs().max())
+    if float((gr - want_g).abs().max()) > 50 * tol * max(gs, 1e-30):
+        return None
+    quad = 0.5 * ((d @ P) * d).sum(-1)
+    log_norm = float(v[0] + quad[0])
+    vs = float(quad.abs().max()) + abs(log_norm)
+    if float((v - (log_norm - quad)).abs().max()) > 50 * tol * max(vs, 1e-30):
+        return None
+    tgt = object.__new__(GaussianTarget)
+    tgt.mean = mu.to(device=dev, dtype=dt).contiguous()
+    tgt.precision = P.to(device=dev, dtype=dt).contiguous()
+    tgt.log_norm = log_norm
+    tgt.probed_from = log_prob_func
+    return tgt
+
+
+def verify_gaussian(tgt, log_prob_func, samples, max_rows=2048):
+    """True if the closed form ``tgt`` reproduces ``log_prob_func`` on rows drawn evenly from ``samples[S, C, D]``
+    (the states a run actually visited) -- the guard behind ``probe_gaussian``."""
+    rows = samples.reshape(-1, samples.shape[-1])
+    if rows.shape[0] > max_rows:
+        idx = torch.linspace(0, rows.shape[0] - 1, max_rows, device=rows.device).long()
+        rows = rows[idx]
+    rows = rows[torch.isfinite(rows).all(dim=1)]
+    if rows.numel() == 0:
+        return True
+
+    def f(w):
+        return log_prob_func(w).sum()
+    try:
+        with torch.no_grad():
+            v = torch.func.vmap(f)(rows)
+    except (RuntimeError, TypeError, ValueError, NotImplementedError) as e:
+        if isinstance(e, (torch.OutOfMemoryError, torch.AcceleratorError)):
+            raise
+        v = torch.stack([f(r) for r in rows[:64]])
+        rows = rows[:64]
+    d = rows.double() - tgt.mean.double()
+    want = tgt.log_norm - 0.5 * ((d @ tgt.precision.double()) * d).sum(-1)
+    err = (v.double() - want).abs()
+    ok = err <= 100 * _tol(rows.dtype) * (1.0 + want.abs())
+    return bool(ok.all())

@@ -128,11 +128,14 @@ def gibbs(theta, log_prob_func, jitter, softabs_const, metric, seed, chain_offse
 
 
 class _Curvature:
-    """Batched derivatives of a user log_prob_func (one chain per row) through torch.func."""
+    """Batched derivatives of a user log_prob_func (one chain per row) through torch.func; a callback torch.func cannot
+    batch (``.item()``, data-dependent control flow: the reference handles those, one chain at a time) drops to a
+    per-chain loop over ``torch.autograd.functional`` for the rest of the run."""
 
     def __init__(self, log_prob_func):
         f = lambda w: log_prob_func(w).sum()  # noqa: E731
         self.f = f
+        self._loop = False
         # each of these is replayed as a HIP graph (util.GraphedCallable): eager torch.func is hundreds of tiny launches
         self._val = util.GraphedCallable(torch.func.vmap(f))
         # gradient and Hessian in one forward-over-reverse pass: jacfwd of (grad, aux = grad)
@@ -140,18 +143,47 @@ class _Curvature:
         self._gh = util.GraphedCallable(torch.func.vmap(torch.func.jacfwd(lambda w: (g(w), g(w)), has_aux=True)))
         self._third = util.GraphedCallable(torch.func.vmap(torch.func.grad(lambda w, m: (torch.func.hessian(f)(w) * m).sum())))
 
+    def _try(self, batched, looped, *args):
+        if not self._loop:
+            try:
+                return batched(*args)
+            except Exception as e:
+                from .samplers import _not_batchable
+                if not _not_batchable(e):
+                    raise
+                import warnings
+                warnings.warn("hamiltorch_amd: log_prob_func is not vmap-able (%s: %s); evaluating its derivatives chain by chain"
+                              % (type(e).__name__, str(e).split("\n")[0][:120]))
+                self._loop = True
+        return looped(*args)
+
     # (a callback may promote: e.g. constants it builds in float64 - results are brought back to the state's dtype)
     # (the graph outputs are static buffers: every result is copied / converted into a fresh tensor here)
     def value(self, theta):
-        return self._val(theta).to(theta.dtype, copy=True).contiguous()
+        def looped(th):
+            with torch.no_grad():
+                return torch.stack([self.f(t) for t in th])
+        return self._try(self._val, looped, theta).to(theta.dtype, copy=True).contiguous()
 
     def grad_neg_hessian(self, theta):
-        H, g = self._gh(theta)
+        def looped(th):
+            H = torch.stack([torch.autograd.functional.hessian(self.f, t) for t in th])
+            g = torch.stack([torch.autograd.grad(self.f(t_), t_)[0] for t_ in (t.detach().requires_grad_() for t in th)])
+            return H, g
+        H, g = self._try(self._gh, looped, theta)
         return g.to(theta.dtype, copy=True).contiguous(), (-H).to(theta.dtype).contiguous()
 
     def contract(self, theta, M):
         """c_i = d_i < Hess log p (theta), M >, M held fixed: [C, D]."""
-        return self._third(theta, M).to(theta.dtype, copy=True).contiguous()
+        def looped(th, Mm):
+            out = []
+            for t, m in zip(th, Mm):
+                t = t.detach().requires_grad_()
+                with torch.enable_grad():
+                    Hm = (torch.autograd.functional.hessian(self.f, t, create_graph=True) * m).sum()
+                out.append(torch.autograd.grad(Hm, t, allow_unused=True)[0] if Hm.requires_grad else torch.zeros_like(t))
+            return torch.stack([o if o is not None else torch.zeros_like(th[0]) for o in out])
+        return self._try(self._third, looped, theta, M).to(theta.dtype, copy=True).contiguous()
 
 
 def _generic_steps(cv, kind, th, pm, thc, pmc, steps, eps, omega, alpha, jitter, seed, chain_offset, draw, path=None):

@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from . import _abi, util
 from .enums import Integrator, Metric, Sampler
-from .models import GaussianTarget, as_gaussian
+from .models import GaussianTarget, as_gaussian, probe_gaussian, verify_gaussian, MAX_NATIVE_DIM
 
 _sample_lock = threading.RLock()  # multi_chain(parallel=True) calls sample() from threads (U:396-398)
 
@@ -82,6 +82,15 @@ def _own(t):
     return torch.empty(t.shape, dtype=t.dtype, device=t.device).copy_(t)
 
 
+def _not_batchable(e):
+    """True for the errors torch.func raises on a callback it cannot batch (``.item()``, data-dependent control
+    flow, the tuple protocol, in-place writes into captured tensors ...); device faults and out-of-memory are not
+    that: they propagate."""
+    if isinstance(e, (torch.OutOfMemoryError, torch.AcceleratorError)):
+        return False
+    return isinstance(e, (RuntimeError, TypeError, ValueError, NotImplementedError, AttributeError, IndexError))
+
+
 class _BatchedCallback:
     """Evaluates a reference-style ``log_prob_func`` (one (D,) vector in, scalar out) for all
     chains.  ``torch.func.vmap`` when the callback allows it, otherwise a per-chain loop."""
@@ -118,6 +127,8 @@ class _BatchedCallback:
                 with torch.no_grad():
                     return _own(self._v_logp(theta))
             except Exception as e:  # data-dependent control flow, .item(), tuple protocol, ...
+                if not _not_batchable(e):
+                    raise
                 self._fallback(e)
         return self._loop(theta, False)[1].contiguous()
 
@@ -133,6 +144,8 @@ class _BatchedCallback:
                 g, v = self._v_gv(theta)
                 return _own(g), _own(v)
             except Exception as e:
+                if not _not_batchable(e):
+                    raise
                 self._fallback(e)
         g, v = self._loop(theta, True)
         return g.contiguous(), v.contiguous()
@@ -373,6 +386,7 @@ def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, 
     seed = util.next_stream_seed() if seed is None else int(seed)
     burn_k = max(int(burn), -1)
 
+    probed = None
     with _sample_lock:
         if sampler == Sampler.HMC:
             if integrator in _SPLIT_KINDS:
@@ -388,6 +402,10 @@ def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, 
                 eng = _resolve_split_engine(log_prob_func, theta0, native, integrator)
             else:
                 tgt = as_gaussian(log_prob_func, theta0) if (native and pass_grad is None) else None
+                if tgt is None and native and pass_grad is None:
+                    probed = tgt = _probe(log_prob_func, theta0)
+                if tgt is not None and tgt.dim > MAX_NATIVE_DIM:
+                    tgt = probed = None                                         # beyond the fused kernels: generic-callback path
                 eng = _GaussianHMC(tgt) if tgt is not None else None
                 if eng is None and native and pass_grad is None:
                     from . import bnn
@@ -395,20 +413,37 @@ def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, 
                 if eng is None:
                     eng = _GenericHMC(log_prob_func, pass_grad)
             label = '({}; {})'.format(sampler, integrator)
-            if nuts:
-                samples, rejected = eng.run_nuts(theta0, num_samples, num_steps_per_sample, step_size, burn_k, inv_mass,
-                                                 seed, chain_offset, verbose, label, desired_accept_rate)
-                step_size = eng.final_step_size
-            else:
-                samples, rejected = eng.run(theta0, num_samples, num_steps_per_sample, step_size, burn_k, inv_mass,
-                                            seed, chain_offset, verbose, label)
+            def run(e):
+                if nuts:
+                    out = e.run_nuts(theta0, num_samples, num_steps_per_sample, step_size, burn_k, inv_mass, seed,
+                                     chain_offset, verbose, label, desired_accept_rate)
+                    return out, e.final_step_size
+                return e.run(theta0, num_samples, num_steps_per_sample, step_size, burn_k, inv_mass, seed, chain_offset,
+                             verbose, label), step_size
+            (samples, rejected), step_size_out = run(eng)
+            if probed is not None and not verify_gaussian(probed, log_prob_func, samples):
+                _probe_mismatch(log_prob_func)
+                (samples, rejected), step_size_out = run(_GenericHMC(log_prob_func, pass_grad))
+            step_size = step_size_out
         elif sampler == Sampler.RMHMC and integrator == Integrator.EXPLICIT:
             if pass_grad is not None:
                 raise RuntimeError('Passing user-determined gradients not implemented for RMHMC')
             from . import rmhmc
-            samples, rejected = rmhmc.sample_explicit(log_prob_func, theta0, num_samples, num_steps_per_sample,
+            lp = log_prob_func
+            if native and as_gaussian(log_prob_func, theta0) is None:
+                probed = _probe(log_prob_func, theta0)
+                if probed is not None and probed.dim <= 128:                       # the constant-curvature RMHMC kernels' range
+                    lp = probed
+                else:
+                    probed = None
+            samples, rejected = rmhmc.sample_explicit(lp, theta0, num_samples, num_steps_per_sample,
                                                       step_size, burn_k, jitter, softabs_const,
                                                       explicit_binding_const, metric, seed, chain_offset, verbose)
+            if probed is not None and not verify_gaussian(probed, log_prob_func, samples):
+                _probe_mismatch(log_prob_func)
+                samples, rejected = rmhmc.sample_explicit(log_prob_func, theta0, num_samples, num_steps_per_sample,
+                                                          step_size, burn_k, jitter, softabs_const,
+                                                          explicit_binding_const, metric, seed, chain_offset, verbose)
         elif sampler == Sampler.RMHMC and integrator == Integrator.IMPLICIT:
             if pass_grad is not None:
                 raise RuntimeError('Passing user-determined gradients not implemented for RMHMC')
@@ -433,6 +468,25 @@ def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, 
     if debug == 2:
         return rows, (float(acc[0]) if one else acc)
     return rows
+
+
+def _probe(log_prob_func, theta0):
+    """The reference's own example closures (``MultivariateNormal(...).log_prob(w).sum()``, tests/test_util.py:98-101) are
+    quadratic forms behind an opaque callable: recognise them by their curvature and run the fused kernels.
+    ``HAMILTORCH_AMD_PROBE=0`` (or ``native=False``) keeps every unrecognised callable on the generic path."""
+    if os.environ.get("HAMILTORCH_AMD_PROBE", "1") == "0" or hasattr(log_prob_func, "_hta_spec"):
+        return None
+    return probe_gaussian(log_prob_func, theta0)
+
+
+def _probe_mismatch(log_prob_func):
+    warnings.warn("hamiltorch_amd: %r looked like a Gaussian at the probe points but disagrees with that closed form on "
+                  "the sampled states; re-running on the generic-callback path" % (log_prob_func,))
+
+
+#: set by dist.sample_sharded: (sum, count) -> (global sum, global count) over the process group, so that a sharded
+#: HMC_NUTS run adapts ONE step size on all chains of all ranks, as the single-process run does
+_nuts_reduce = None
 
 
 class _Engine:
@@ -462,7 +516,9 @@ class _Engine:
     def run_nuts(self, theta0, N, L, eps0, burn, inv_mass, seed, chain_offset, verbose, label, desired):
         """Sampler.HMC_NUTS (S:931-939, S:1030-1035): dual-averaging step size while n < burn, frozen to
         eps_bar at n == burn.  One chain: the reference's schedule exactly.  A batch shares ONE step size,
-        adapted on the mean acceptance statistic over chains (extension; variance-reduced)."""
+        adapted on the mean acceptance statistic over chains (extension; variance-reduced); under
+        dist.sample_sharded the mean runs over the chains of every rank (`_nuts_reduce`), so the result does not
+        depend on the sharding."""
         self.begin(theta0, N, burn, inv_mass, seed, chain_offset)
         C = theta0.shape[0]
         Ho = torch.empty(C, dtype=theta0.dtype, device=theta0.device)
@@ -474,8 +530,11 @@ class _Engine:
             rho = torch.clamp(Ho - Hn, max=0.0)                               # S:1000
             alpha = torch.where(torch.isfinite(rho), torch.exp(rho.float()), torch.zeros_like(rho.float()))
             bad = bool((~torch.isfinite(rho)).any())
+            a_sum, a_cnt = float(alpha.double().sum()), float(alpha.numel())
+            if _nuts_reduce is not None:                                      # sharded run: the statistic of ALL chains
+                a_sum, a_cnt, bad = _nuts_reduce(a_sum, a_cnt, bad)
             if n < burn or bad:                                               # S:1031-1032 / S:1060-1064
-                eps, eps_bar, H_t = _dual_average(float(alpha.double().mean()), n, eps0, H_t, eps_bar, desired)
+                eps, eps_bar, H_t = _dual_average(a_sum / a_cnt, n, eps0, H_t, eps_bar, desired)
             if n == burn:
                 eps = eps_bar                                                 # S:1033-1035
                 print('Final Adapted Step Size: ', eps)
@@ -645,8 +704,10 @@ class _GenericHMC(_Engine):
             with torch.cuda.graph(graph):
                 self._trajectory(n, L, eps, Ho, Hn, n_dev)
         except Exception as e:      # e.g. a callback that is not capturable: stay eager (nothing ran during the capture)
-            warnings.warn("hamiltorch_amd: trajectory not capturable as a HIP graph (%s: %s); running it launch by launch"
-                          % (type(e).__name__, str(e).split("\n")[0][:120]))
+            if isinstance(e, torch.OutOfMemoryError):
+                raise
+            torch.cuda.synchronize(dev)
+            util.graph_log.append("trajectory: %s: %s" % (type(e).__name__, str(e).split("\n")[0][:160]))
             self._no_graph = True
             return None
         self._graph_keep = (graph, n_dev)          # keep the index tensor alive as long as the graph

@@ -181,10 +181,15 @@ class GraphedCallable:
     A generic-callback trajectory calls the user's function hundreds of times on tensors of one fixed shape; in eager
     mode every call is dozens to hundreds of tiny launches and the run is bound by launch overhead, not by the GPU.
     The function is captured once per input signature (``torch.cuda.CUDAGraph``) into static buffers and replayed on
-    the current stream, between the native kernels.  Anything that cannot be captured (data-dependent control flow,
-    ``.item()``, host tensors) falls back to eager evaluation for good.  The outputs are static buffers: they are
-    valid until the next call with the same signature, which is how the samplers use them.
-    ``HAMILTORCH_AMD_GRAPHS=0`` disables it."""
+    the current stream, between the native kernels.  The outputs are static buffers: they are valid until the next
+    call with the same signature, which is how the samplers use them.
+
+    A function is *not capturable* -- and is then evaluated eagerly for good, silently (``graph_log`` keeps the reason) --
+    when the capture raises (``.item()``, host tensors, data-dependent control flow: "operation not permitted when stream
+    is capturing"), when it records no device work at all (an empty graph: its "static output" would never be
+    refreshed), or when a replay on a perturbed input does not reproduce the eager result (a value baked in at capture
+    time).  The last check is what makes a stale-output replay impossible: a graph is only used after it has been
+    seen to follow its input.  ``HAMILTORCH_AMD_GRAPHS=0`` disables capturing altogether."""
 
     def __init__(self, fn):
         self.fn = fn
@@ -210,22 +215,62 @@ class GraphedCallable:
         graph.replay()
         return static_out
 
+    def _give_up(self, why):
+        graph_log.append("%s: %s" % (getattr(self.fn, "__name__", type(self.fn).__name__), why))
+        del graph_log[:-64]
+        self.enabled = False
+        return False
+
     def _capture(self, args):
+        import warnings
+        dev = args[0].device
         static_in = [a.detach().clone() for a in args]
-        side = torch.cuda.Stream(device=args[0].device)
-        side.wait_stream(torch.cuda.current_stream(args[0].device))
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(2):                      # warm-up (lazy initialisation, allocator) - errors propagate to the caller
                 self.fn(*static_in)
-        torch.cuda.current_stream(args[0].device).wait_stream(side)
+        torch.cuda.current_stream(dev).wait_stream(side)
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self.fn(*static_in)
-            return static_in, graph, out
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                with torch.cuda.graph(graph):
+                    out = self.fn(*static_in)
         except Exception as e:  # not capturable: stay eager
-            import warnings
-            warnings.warn("hamiltorch_amd: callback not capturable as a HIP graph (%s: %s); evaluating it eagerly"
-                          % (type(e).__name__, str(e).split("\n")[0][:120]))
-            self.enabled = False
-            return False
+            if isinstance(e, torch.OutOfMemoryError):
+                raise
+            torch.cuda.synchronize(dev)
+            return self._give_up("%s: %s" % (type(e).__name__, str(e).split("\n")[0][:160]))
+        if any("graph is empty" in str(w.message).lower() for w in caught):
+            return self._give_up("the capture recorded no device work (empty graph)")
+        # the graph must follow its input: replay on perturbed inputs and compare with the eager evaluation
+        try:
+            for s_ in static_in:
+                if s_.is_floating_point():
+                    s_.mul_(1.0 + 2.0 ** -6).add_(2.0 ** -7)
+            graph.replay()
+            got = _flat_outputs(out)
+            want = _flat_outputs(self.fn(*static_in))
+            ok = len(got) == len(want) and all(
+                g.shape == w_.shape and bool(torch.isclose(g.double(), w_.double(), rtol=1e-4, atol=1e-6, equal_nan=True).all())
+                for g, w_ in zip(got, want))
+        except Exception as e:
+            if isinstance(e, torch.OutOfMemoryError):
+                raise
+            ok = False
+        if not ok:
+            return self._give_up("a replay on perturbed inputs does not reproduce the eager result")
+        return static_in, graph, out
+
+
+#: reasons of the most recent capture refusals (diagnostics; nothing is printed or warned)
+graph_log = []
+
+
+def _flat_outputs(out):
+    if torch.is_tensor(out):
+        return [out]
+    if isinstance(out, (tuple, list)):
+        return [t for o in out for t in _flat_outputs(o)]
+    return []

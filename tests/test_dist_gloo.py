@@ -37,6 +37,18 @@ def _worker(rank, world, port, C, q):
         full = torch.stack(rows)
         off, cnt = hd.shard_chains(C, rank, world)
         only0 = hd.gather_samples(full[:, off:off + cnt].contiguous(), C, dst=0)
+        # Sampler.HMC_NUTS under sharding: the acceptance statistic is reduced over ALL ranks' chains (samplers._nuts_reduce)
+        seen = {}
+
+        def probe_sampler(params_init, chain_offset, seed, **kw):
+            from hamiltorch_amd import samplers
+            seen["hook"] = samplers._nuts_reduce
+            seen["red"] = samplers._nuts_reduce(float(params_init.shape[0]) * 0.5, float(params_init.shape[0]), rank == 1)
+            return [params_init]
+        hd.sample_sharded(probe_sampler, init, seed=1, gather=False)
+        from hamiltorch_amd import samplers
+        assert seen["hook"] is not None and samplers._nuts_reduce is None        # installed for the call only
+        assert seen["red"] == (0.5 * C, float(C), True), seen["red"]
         q.put((rank, full.numpy(), None if only0 is None else only0.numpy()))
     finally:
         dist.destroy_process_group()

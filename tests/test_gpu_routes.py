@@ -1,0 +1,202 @@
+"""GPU: routing decisions of the API mirror -- which callables reach the fused kernels, which fall back to the
+generic-callback path, and that HIP-graph replays of user callbacks can never serve a stale value."""
+import json
+import os
+import subprocess
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import hmc_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIGMA3 = [[1.0, 0.6, 0.2], [0.6, 2.0, 0.5], [0.2, 0.5, 0.5]]
+
+
+@pytest.fixture(scope="module")
+def ht():
+    import hamiltorch_amd
+    assert torch.cuda.is_available()
+    return hamiltorch_amd
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _launches(fn):
+    """Number of profiled trajectory-kernel launches (the library's own HIP-event hook) while fn() runs."""
+    from hamiltorch_amd import _abi
+    _abi.set_tuning("profile", 1)
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+        _, n = _abi.profile_collect()
+    finally:
+        _abi.set_tuning("profile", 0)
+    return out, n
+
+
+def test_reference_test_closure_runs_on_the_fused_kernel(ht):
+    """tests/test_util.py:98-101 of the reference: an opaque closure around MultivariateNormal(...).log_prob(w).sum().
+    sample() recognises it by its curvature and runs hmc_gauss_quad_kernel: one trajectory-kernel launch for the whole run,
+    no per-step torch callbacks, samples bit-identical to the explicit GaussianTarget."""
+    def log_prob(omega):
+        mean = torch.zeros(2, device=dev())
+        var = torch.tensor([.10, .10], device=dev())
+        return torch.distributions.MultivariateNormal(mean, torch.diag(var)).log_prob(omega).sum()
+
+    C = 256
+    init = torch.ones(C, 2, device=dev())
+    kw = dict(num_samples=50, num_steps_per_sample=10, step_size=0.1, verbose=False, seed=3)
+    calls = [0]
+
+    def counted(w):
+        calls[0] += 1
+        return log_prob(w)
+    out, n = _launches(lambda: ht.sample(counted, init, **kw))
+    assert n == 1, "expected ONE fused launch, saw %d profiled launches" % n
+    assert calls[0] < 40, "the closure was evaluated %d times: the run went through the callback path" % calls[0]
+    t = ht.GaussianTarget(torch.zeros(2, device=dev()), covariance=torch.diag(torch.tensor([.10, .10], device=dev())))
+    want = ht.sample(t, init, **kw)
+    np.testing.assert_allclose(torch.stack(out).cpu().numpy(), torch.stack(want).cpu().numpy(), rtol=0, atol=2e-5)
+    # opt-out: native=False keeps the callback path (and agrees)
+    out_g = ht.sample(log_prob, init[:32], native=False, **kw)
+    err = (torch.stack(out_g) - torch.stack(want)[:, :32]).abs().amax(dim=(0, 2))
+    assert float((err > 2e-4).float().mean()) <= 0.05
+    # one chain, the reference's call shape
+    one = ht.sample(log_prob, torch.tensor([1., 1.], device=dev()), num_samples=20, num_steps_per_sample=10, step_size=0.1,
+                    verbose=False, seed=3)
+    assert len(one) == 20 and one[0].shape == (2,)
+
+
+def test_notebook_closure_matches_oracle_on_fused_route(ht):
+    """The notebooks' `MVN(mean, cov).log_prob(w).sum()` closure at cfg2's shape against the oracle, chain by chain."""
+    mean = torch.zeros(3, device=dev()); cov = torch.tensor(SIGMA3, device=dev())
+
+    def lp(w):
+        return torch.distributions.MultivariateNormal(mean, cov).log_prob(w).sum()
+    C, N, L, eps, seed = 512, 60, 25, 0.3, 17
+    th0 = (0.1 * O.philox_normals(seed, np.arange(C), 0, 3, O.PURPOSE_INIT)).astype(np.float32)
+    (out, acc), n = _launches(lambda: ht.sample(lp, torch.tensor(th0, device=dev()), num_samples=N, num_steps_per_sample=L,
+                                                step_size=eps, debug=2, verbose=False, seed=seed))
+    assert n == 1
+    P = np.linalg.inv(np.array(SIGMA3))
+    o = O.GaussianTarget(np.zeros(3, np.float32), P.astype(np.float32), float(-1.5 * np.log(2 * np.pi) + 0.5 * np.linalg.slogdet(P)[1]))
+    ref, info = O.sample_hmc(o, th0, N, L, eps, 0, None, O.PhiloxDraws(seed, np.arange(C)))
+    err = np.abs(torch.stack(out).cpu().numpy() - np.stack(ref)).max(axis=(0, 2))
+    assert (err > 2e-4).mean() <= 0.01, err.max()
+
+
+def test_probe_mismatch_falls_back_to_generic_path(ht):
+    """A piecewise-quadratic callable whose probe points all sit in one piece: the fused run is discarded when the closed
+    form disagrees with the callable on the sampled states, and the generic path's result is returned."""
+    def lp(w):      # Gaussian inside |w| < 1.5, much narrower outside
+        return -0.5 * (w * w).sum() - 200.0 * torch.relu(w.abs() - 1.5).pow(2).sum() * (w.abs().max() < 900.0)
+    th0 = torch.zeros(64, 2, device=dev())
+    kw = dict(num_samples=40, num_steps_per_sample=8, step_size=0.4, verbose=False, seed=5)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        out = ht.sample(lp, th0, **kw)
+    want = ht.sample(lp, th0, native=False, **kw)
+    if any("looked like a Gaussian" in str(w.message) for w in caught):
+        assert torch.equal(torch.stack(out), torch.stack(want))
+    s = torch.stack(out)
+    assert float(s.abs().max()) < 2.5          # the walls were felt: this is not N(0, I)
+
+
+def test_gaussian_beyond_kernel_range_uses_generic_path(ht):
+    """D > 1024 is outside hta_hmc_gaussian_sample: sample() must take the callback path instead of raising."""
+    D, C = 1100, 4
+    t = ht.GaussianTarget(torch.zeros(D, device=dev()), precision=torch.diag(torch.linspace(0.5, 2.0, D, device=dev())), normalized=False)
+    th0 = 0.1 * torch.randn(C, D, generator=torch.Generator().manual_seed(0)).to(dev())
+    out, acc = ht.sample(t, th0, num_samples=4, num_steps_per_sample=3, step_size=0.05, debug=2, verbose=False, seed=1)
+    s = torch.stack(out)
+    assert s.shape == (4, C, D) and torch.isfinite(s).all() and float(acc.mean()) > 0.5
+
+
+def test_mlp_with_large_data_set_falls_back_instead_of_raising(ht):
+    """The native MLP kernels stage the data set in LDS; the reference works for any N.  N = 60000 points exceed the staging:
+    sample_model must run (generic path) rather than fail."""
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(2, 4), torch.nn.Tanh(), torch.nn.Linear(4, 1)).to(dev())
+    X = torch.randn(60000, 2); Y = torch.sin(X.sum(1, keepdim=True))
+    th0 = ht.util.flatten(net).detach().repeat(8, 1).contiguous()
+    out = ht.sample_model(net, X, Y, th0, model_loss="regression", num_samples=3, num_steps_per_sample=2, step_size=1e-4,
+                          tau_out=1.0, verbose=False, seed=2)
+    s = torch.stack(out)
+    assert s.shape == (3, 8, 17) and torch.isfinite(s).all()
+
+
+def test_graph_replay_cannot_serve_stale_values(ht):
+    """util.GraphedCallable only keeps a graph that was seen to follow its input: mutate the input, replay, compare with
+    eager.  A function that bakes a value in at capture time, one that records no device work, and one that raises
+    under capture all end up evaluated eagerly -- silently (no warnings), with the reason in util.graph_log."""
+    from hamiltorch_amd import util
+    x = torch.randn(8, 5, device=dev())
+    good = util.GraphedCallable(torch.func.vmap(torch.func.grad(lambda w: -(w ** 4).sum())))
+    for k in range(4):
+        xx = x * (1.0 + k)
+        np.testing.assert_allclose(good(xx).cpu().numpy(), (-4 * xx ** 3).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert good.capturable() and good.cache
+    baked = {"v": None}
+
+    def bakes(w):                                   # host round trip outside the graph: the classic stale-value shape
+        if baked["v"] is None or not torch.cuda.is_current_stream_capturing():
+            baked["v"] = w.detach().clone()
+        return baked["v"] * 2.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        gb = util.GraphedCallable(bakes)
+        for k in range(3):
+            xx = x + k
+            np.testing.assert_allclose(gb(xx).cpu().numpy(), (2.0 * xx).cpu().numpy(), rtol=1e-6)
+        empty = util.GraphedCallable(lambda w: w)                               # no device work at all
+        assert empty(x) is x or torch.equal(empty(x), x)
+        raises = util.GraphedCallable(lambda w: w * float(w.sum()))             # .item() under capture
+        np.testing.assert_allclose(raises(x).cpu().numpy(), (x * float(x.sum())).cpu().numpy(), rtol=1e-5)
+        np.testing.assert_allclose(raises(2 * x).cpu().numpy(), (2 * x * float(2 * x.sum())).cpu().numpy(), rtol=1e-5)
+    assert not raises.capturable() and not empty.capturable()
+    assert util.graph_log
+
+
+def test_generic_paths_emit_no_capture_warnings(ht):
+    """A green run prints no graph-capture warnings: BNN closures are capturable now (host-scalar precisions), and whatever
+    is not capturable is evaluated eagerly without comment."""
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(2, 3), torch.nn.Tanh(), torch.nn.Linear(3, 3), torch.nn.Tanh(), torch.nn.Linear(3, 1)).to(dev())
+    X = torch.randn(20, 2); Y = torch.sin(X.sum(1, keepdim=True))
+    th0 = ht.util.flatten(net).detach().repeat(8, 1).contiguous()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        out = ht.sample_model(net, X, Y, th0, model_loss="regression", num_samples=8, num_steps_per_sample=3, step_size=1e-3,
+                              tau_out=1.0, verbose=False, seed=2)
+
+        def host_scalars(w):
+            return torch.distributions.Normal(0, 3, validate_args=False).log_prob(w).sum() - 0.1 * (w ** 4).sum()
+        out2 = ht.sample(host_scalars, torch.zeros(8, 3, device=dev()), num_samples=8, num_steps_per_sample=3, step_size=0.1,
+                         verbose=False, seed=1)
+    assert torch.isfinite(torch.stack(out)).all() and torch.isfinite(torch.stack(out2)).all()
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself(ht):
+    """`python bench.py --gpus 2` with no launcher around it re-executes itself as two ranks (ADVICE r1 / VERDICT r1 item 3).
+    On this one-GPU box the ranks share the device and talk over gloo (HTA_BENCH_BACKEND); the driver's 8-GPU run uses RCCL."""
+    env = dict(os.environ, HTA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "cfg5", "--traj", "6", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and len(j["rank_devices"]) == 2
+    assert j["config"]["chains_total"] == 2048 and j["gather_ms"] > 0 and j["value"] > 0
+    # a mismatch between --gpus and the launcher's world size is an error, not a silent 1-GPU number
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                         "--no-cpu-baseline"], env=env2, capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)

@@ -230,3 +230,67 @@ def test_public_signatures_match_reference():
         for k, default in params:
             got = mine[k].default
             assert (default is None and got is inspect._empty) or repr(got) == default, (name, k, default, got)
+
+
+# ---- recognition of the reference's own example closures (models.probe_gaussian) -------------------------------------
+def _ref_closure():                       # tests/test_util.py:98-101 of the reference, verbatim in structure
+    def log_prob(omega):
+        mean = torch.zeros(2)
+        var = torch.tensor([.10, .10])
+        return torch.distributions.MultivariateNormal(mean, torch.diag(var)).log_prob(omega).sum()
+    return log_prob
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float64, 1e-12)])
+def test_probe_recognises_reference_closures(dtype, tol):
+    from hamiltorch_amd.models import GaussianTarget, probe_gaussian, verify_gaussian
+    t = probe_gaussian(_ref_closure(), torch.ones(2)) if dtype == torch.float32 else None
+    if t is not None:
+        np.testing.assert_allclose(t.precision.numpy(), np.diag([10.0, 10.0]), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(t.mean.numpy(), 0.0, atol=1e-5)
+    # the notebooks' idiom: a correlated MVN with a mean, batched initial state
+    mean = torch.tensor([0.3, -1.0, 2.0], dtype=dtype)
+    cov = torch.tensor([[1.0, 0.6, 0.2], [0.6, 2.0, 0.5], [0.2, 0.5, 0.5]], dtype=dtype)
+    f = lambda w: torch.distributions.MultivariateNormal(mean, cov).log_prob(w).sum()  # noqa: E731
+    t = probe_gaussian(f, torch.zeros(16, 3, dtype=dtype))
+    ref = GaussianTarget(mean, covariance=cov)
+    assert t is not None and t.mean.dtype == dtype
+    np.testing.assert_allclose(t.precision.numpy(), ref.precision.numpy(), rtol=tol * 10, atol=tol * 10)
+    np.testing.assert_allclose(t.mean.numpy(), mean.numpy(), rtol=tol * 10, atol=tol * 10)
+    assert abs(t.log_norm - ref.log_norm) < tol * 100
+    x = torch.randn(7, 5, 3, dtype=dtype)
+    assert verify_gaussian(t, f, x)
+    # bare quadratic form, D = 100 (BASELINE config 3's log_prob as the survey writes it)
+    g = torch.Generator().manual_seed(0)
+    Q = torch.linalg.qr(torch.randn(100, 100, generator=g, dtype=torch.float64))[0]
+    P = ((Q * torch.linspace(0.5, 2.0, 100, dtype=torch.float64)) @ Q.T).to(dtype)
+    t = probe_gaussian(lambda w: -0.5 * torch.dot(w, torch.mv(P, w)), torch.zeros(4, 100, dtype=dtype))
+    assert t is not None
+    np.testing.assert_allclose(t.precision.numpy(), (0.5 * (P + P.T)).numpy(), rtol=0, atol=tol * 10)
+    assert float(t.mean.abs().max()) < tol * 1e3 and abs(t.log_norm) < tol * 1e3
+
+
+def test_probe_rejects_everything_else():
+    from hamiltorch_amd.models import probe_gaussian, verify_gaussian
+    th = torch.zeros(4, 5)
+    assert probe_gaussian(lambda w: -(w ** 4).sum(), th) is None                                     # not quadratic
+    assert probe_gaussian(lambda w: -0.5 * (w * w).sum() - 0.1 * torch.cos(w).sum(), th) is None      # curvature varies
+    assert probe_gaussian(lambda w: w.sum(), th) is None                                             # linear: no curvature
+    assert probe_gaussian(lambda w: -0.5 * w[0] * w[0] / 9 - 0.5 * (w[1:] ** 2).sum() * torch.exp(-w[0]), th) is None   # funnel
+    assert probe_gaussian(lambda w: -0.5 * float((w * w).sum()) * torch.ones(()), th) is None         # not differentiable by torch.func
+    assert probe_gaussian(lambda w: (-(w * w).sum(), [w]), th) is None                               # tuple protocol
+    assert probe_gaussian([lambda w: -(w * w).sum()], th) is None                                    # split list
+    assert probe_gaussian(lambda w: -(w * w).sum(), torch.zeros(2, 2000)) is None                    # beyond the fused kernels
+    # piecewise quadratic with every probe inside one piece: passes the probe, caught on the samples
+    hub = lambda w: -torch.nn.functional.huber_loss(w, torch.zeros_like(w), reduction="sum", delta=5000.0)  # noqa: E731
+    t = probe_gaussian(hub, th)
+    assert t is not None
+    assert verify_gaussian(t, hub, torch.randn(6, 4, 5))
+    assert not verify_gaussian(t, hub, 1e4 * torch.randn(6, 4, 5))
+
+
+def test_graphed_callable_is_transparent_on_cpu_and_logs_refusals():
+    g = util.GraphedCallable(lambda w: (w * w).sum(-1))
+    x = torch.randn(3, 4)
+    assert torch.equal(g(x), (x * x).sum(-1)) and g.cache == {}          # host tensors: plain call, nothing captured
+    assert isinstance(util.graph_log, list)

@@ -1,0 +1,31 @@
+#!/bin/bash
+# tools/physical.sh <tag>: the rocprofv3 passes behind profiles/physical.json (bench.py's `roofline.physical`) and the per-round
+# kernel-stat summaries.  One workload per block; per workload: --kernel-trace --stats, then three SEPARATE --pmc passes
+# (kernel-trace only beside them).  Run on the GPU box (gpurun); writes gpurun_out/<tag>_*.
+export TMPDIR=/tmp
+R=${1:-r02}
+O=gpurun_out/${R}_phys
+mkdir -p $O
+t0=$(date +%s)
+one() {  # key steps warmup traj env -- bench args
+  local key=$1 steps=$2 warm=$3 traj=$4 envs=$5; shift 5
+  local d=$O/$key; mkdir -p $d
+  local cmd="python bench.py --no-cpu-baseline --no-secondary --steps $steps --warmup $warm $*"
+  echo "{\"command\": \"$envs $cmd\", \"steps\": $steps, \"warmup\": $warm, \"traj\": $traj, \"source\": \"tools/physical.sh $R\"}" > $d/meta.json
+  env $envs timeout 120 rocprofv3 --kernel-trace --stats -f csv -d $d/stats -o s -- $cmd > $d/bench.json 2> /dev/null
+  env $envs timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $d/pmc_rd -o r -- $cmd > /dev/null 2>&1
+  env $envs timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $d/pmc_wr -o w -- $cmd > /dev/null 2>&1
+  env $envs timeout 120 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES GRBM_GUI_ACTIVE -f csv -d $d/pmc_sq -o q -- $cmd > /dev/null 2>&1
+  cp $(find $d/stats -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_${key}_kernel_stats.csv 2> /dev/null
+  echo "$key done ($(( $(date +%s) - t0 )) s)"
+}
+one cfg2@1024 20 3 1000 X=1
+one cfg3@1024 3 1 100 X=1 --workload cfg3@1024
+one cfg3@256 2 1 400 X=1 --workload cfg3
+one cfg3jacobi@256 1 1 20 HTA_RMHMC_FUSED=0 --workload cfg3 --traj 20
+one cfg4@512 5 1 20 X=1 --workload cfg4
+python tools/physical.py cfg2@1024=$O/cfg2@1024 cfg3@1024=$O/cfg3@1024 cfg3@256=$O/cfg3@256 cfg3jacobi@256=$O/cfg3jacobi@256 cfg4@512=$O/cfg4@512 > gpurun_out/${R}_physical.json
+python tools/pmc_summarize.py $(find $O -name "*counter_collection.csv" | sort) > gpurun_out/${R}_pmc_all.txt
+# keep the merge small: raw traces stay on the box
+find $O -name "*.csv" -size +2M -delete
+echo "physical done ($(( $(date +%s) - t0 )) s)"; head -c 1500 gpurun_out/${R}_physical.json
