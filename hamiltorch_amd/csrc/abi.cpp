@@ -21,6 +21,7 @@ int g_gauss_eig = 1;       // small-D identity-mass Gaussian HMC integrates in t
 int g_fill_blocks = 4096;        // grid cap of the pre-draw pass (256-thread blocks, grid-stride)
 int g_quad_max_chains = 65536;   // up to here a chain takes a DPP quad (one eigen-coordinate per lane), beyond a lane
 int g_rmhmc_fused = 1;           // 0 = per-evaluation Jacobi path, 3 = fused with two chains per workgroup (parity tests)
+extern int g_metric_mfma;         // rmhmc_metric_mfma.hip
 int g_mlp_valu = 0;               // 1 = keep the Bayesian-MLP sampler on the VALU kernel (parity tests of both)
 
 // ---- optional HIP-event timing of the dominant kernel of each call (measurement only) -----------
@@ -87,6 +88,7 @@ int hta_set_tuning(const char* key, int value) {
   if (!strcmp(key, "quad_max_chains")) { hta::g_quad_max_chains = value; return HTA_OK; }
   if (!strcmp(key, "fill_blocks")) { hta::g_fill_blocks = value > 0 ? value : 4096; return HTA_OK; }
   if (!strcmp(key, "mlp_valu")) { hta::g_mlp_valu = value; return HTA_OK; }
+  if (!strcmp(key, "metric_mfma")) { hta::g_metric_mfma = value; return HTA_OK; }
   if (!strcmp(key, "rmhmc_fused")) { hta::g_rmhmc_fused = value; return HTA_OK; }
   if (!strcmp(key, "profile")) { hta::g_profile = value; hta::g_ev_used = 0; hta::g_prof_seen = 0; return HTA_OK; }
   hta::set_error("hta_set_tuning: unknown key %s", key);

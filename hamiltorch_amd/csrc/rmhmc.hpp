@@ -20,6 +20,9 @@ template <typename T> struct MetricArgsT {   // typed view of HtaMetricArgs (inc
 static_assert(sizeof(MetricArgsT<float>) == sizeof(HtaMetricArgs), "HtaMetricArgs layout drifted from MetricArgsT");
 
 template <typename T> int metric_eval(const MetricArgsT<T>& a, hipStream_t s);
+extern int g_metric_mfma;                                   // tuning key "metric_mfma" (default 1)
+bool metric_warm_mfma_eligible(const MetricArgsT<float>& a);
+int metric_warm_mfma(const MetricArgsT<float>& a, hipStream_t s);     // rmhmc_metric_mfma.hip
 
 template <typename T>
 int mh_select(T* cur, const T* prop, const T* init, const T* Ho, const T* Hn, const T* lpn, T* row, int32_t* rej,

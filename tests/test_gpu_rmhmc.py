@@ -636,3 +636,103 @@ def test_sample_rmhmc_cfg5_shapes_vs_oracle(ht, C):
     err = np.abs(got[:, sel] - want).max(axis=(0, 2))
     assert (err < 3e-4).sum() >= len(sel) - 1, err
     assert np.abs(got[-1] - got[0]).mean() > 1e-3
+
+
+# ---- the matrix-core evaluation kernel (csrc/rmhmc_metric_mfma.hip) against the Jacobi kernel and the oracle ---------------
+def _warm_eval(ht, P, X, m, alpha, jitter, seed, mode, want_g=True):
+    """One batched warm-start evaluation through hta_metric_eval with hta_set_tuning('metric_mfma', mode)."""
+    from hamiltorch_amd import _abi
+    dt = torch.float32
+    B, D = m.shape
+    Pd = tt(P, dt)
+    V0 = torch.empty(D, D, device=dev()); lam0 = torch.empty(D, device=dev())
+    _abi.set_tuning("metric_mfma", 0)                      # the shared basis always comes from the Jacobi kernel (as in the driver)
+    _abi.metric_eval(Pd, 1, D, _abi.METRIC_SOFTABS, Pd, 0, alpha, V_out=V0, lamraw_out=lam0)
+    out = dict(x=torch.zeros(B, D, device=dev()), H=torch.empty(B, device=dev()), ld=torch.empty(B, device=dev()),
+               q=torch.empty(B, device=dev()), lam=torch.empty(B, D, device=dev()), p=torch.empty(B, D, device=dev()),
+               G=torch.empty(B, D, D, device=dev()), lp=torch.empty(B, device=dev()), ug=torch.zeros(B, D, device=dev()))
+    mu = torch.zeros(D, device=dev())
+    try:
+        _abi.set_tuning("metric_mfma", mode)
+        _abi.metric_eval(Pd, B, D, _abi.METRIC_SOFTABS, Pd, 0, alpha, jitter, seed, 3, 7, 2, X=tt(X, dt), Pm=Pd, mu=mu, log_norm=0.25,
+                         m=tt(m, dt), upd_x=out["x"], cx=0.5, upd_g=out["ug"], cg=-0.5, lam_out=out["lam"], logdet_out=out["ld"],
+                         quad_out=out["q"], H_out=out["H"], logp_out=out["lp"], V0=V0, lam0=lam0)
+        if want_g:
+            _abi.metric_eval(Pd, B, D, _abi.METRIC_SOFTABS, Pd, 0, alpha, jitter, seed, 3, 7, 0, p_out=out["p"], G_out=out["G"],
+                             V0=V0, lam0=lam0)
+        torch.cuda.synchronize()
+    finally:
+        _abi.set_tuning("metric_mfma", 1)
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("D,kind,alpha,jitter", [(3, "spd", 1e6, 1e-3), (10, "spd", 1e6, None), (16, "indef", 1.3, 1e-3), (31, "spd", 1e6, 1e-3),
+                                                 (64, "indef", 2.0, 1e-2), (100, "spd", 1e6, 1e-3), (100, "spd", 1e6, 0.3),
+                                                 (101, "degenerate", 3.0, 1e-3), (112, "spd", 1e6, 1e-3), (9, "identity", 1e6, 1e-3)])
+def test_metric_mfma_kernel_equals_jacobi_kernel(ht, D, kind, alpha, jitter):
+    """csrc/rmhmc_metric_mfma.hip (eigenvectors refined from the shared basis with MFMA GEMMs; MFMA Cholesky) against the
+    Jacobi kernel on the same systems and jitter streams, and both against the oracle's eigh: G^-1 m, log|G|, m^T G^-1 m,
+    H, log p, P (X - mu), the soft-abs spectrum, the assembled G and the momentum draw p = chol(G) z.  Cases: well separated
+    spectra (refinement converges), an indefinite curvature with finite alpha, a large jitter and (nearly) degenerate /
+    identity spectra (the in-kernel fallback to Jacobi)."""
+    rng = np.random.default_rng(D)
+    if kind == "identity":
+        P = 1.5 * np.eye(D)
+    elif kind == "spd" and D == 100:
+        P = cfg3_target(ht, 100, torch.float32)[1].P.astype(np.float64)
+    else:
+        P = sym_batch(1, D, kind, D + 1)[0]
+    B, seed = 37, 99
+    X = (0.3 * rng.standard_normal((B, D))).astype(np.float32)
+    m = rng.standard_normal((B, D)).astype(np.float32)
+    a = _warm_eval(ht, P, X, m, alpha, jitter, seed, 1)
+    j = _warm_eval(ht, P, X, m, alpha, jitter, seed, 0)
+    # the oracle on the same jitter stream (chain_offset 3, draw 7, sub 2 / 0)
+    Hs = np.broadcast_to(P, (B, D, D)).astype(np.float64).copy()
+    ju = None if jitter is None else O.philox_uniforms(seed, 3 + np.arange(B), 7, D, O.PURPOSE_JITTER, 2, dtype=np.float64)
+    G, lam, _ = O.softabs_metric(Hs, alpha, jitter, ju)
+    x64 = np.linalg.solve(G, m.astype(np.float64)[..., None])[..., 0]
+    cond = np.abs(lam).max() / np.abs(lam).min()
+    tol = 4e-4
+    for got in (a, j):
+        np.testing.assert_allclose(got["x"], 0.5 * x64, rtol=tol * cond, atol=tol * cond * np.abs(x64).max())
+        np.testing.assert_allclose(got["ld"], np.log(lam).sum(1), rtol=tol, atol=tol * D)
+        np.testing.assert_allclose(got["q"], (m * x64).sum(1), rtol=tol * cond, atol=tol * cond)
+        np.testing.assert_allclose(np.sort(got["lam"], axis=1), np.sort(lam, axis=1), rtol=tol, atol=tol * np.abs(lam).max())
+        want_lp = 0.25 - 0.5 * np.einsum("bi,ij,bj->b", X.astype(np.float64), P, X.astype(np.float64))
+        np.testing.assert_allclose(got["lp"], want_lp, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(got["ug"], -0.5 * (X.astype(np.float64) @ P), rtol=1e-4, atol=1e-4)
+        wantH = -want_lp + 0.5 * D * np.log(2 * np.pi) + 0.5 * np.log(lam).sum(1) + 0.5 * (m * x64).sum(1)
+        np.testing.assert_allclose(got["H"], wantH, rtol=tol * cond, atol=tol * cond * 10)
+    # kernel against kernel: tighter than either against float64
+    np.testing.assert_allclose(a["x"], j["x"], rtol=2e-4 * cond, atol=2e-5 * cond * np.abs(x64).max())
+    np.testing.assert_allclose(a["H"], j["H"], rtol=1e-5 * cond, atol=1e-4 * cond)
+    # G (sub-stream 0) and the momentum draw
+    ju0 = None if jitter is None else O.philox_uniforms(seed, 3 + np.arange(B), 7, D, O.PURPOSE_JITTER, 0, dtype=np.float64)
+    G0, _, _ = O.softabs_metric(Hs, alpha, jitter, ju0)
+    z = O.philox_normals(seed, 3 + np.arange(B), 7, D, dtype=np.float64)
+    p64 = np.einsum("bij,bj->bi", np.linalg.cholesky(G0), z)
+    for got in (a, j):
+        np.testing.assert_allclose(got["G"], G0, rtol=tol, atol=tol * np.abs(G0).max())
+        np.testing.assert_allclose(got["p"], p64, rtol=tol * cond, atol=tol * cond * np.abs(p64).max())
+
+
+def test_metric_mfma_kernel_issues_matrix_instructions_on_cfg3(ht):
+    """The eigendecomposition route of BASELINE config 3 (hta_set_tuning('rmhmc_fused', 0)) runs its metric evaluations on
+    rmhmc_metric_mfma.hip and agrees with the Jacobi kernel chain by chain over a short run."""
+    from hamiltorch_amd import _abi
+    t, _ = cfg3_target(ht, 100, torch.float32)
+    C, N, L = 64, 3, 4
+    th0 = tt((0.1 * O.philox_normals(5, np.arange(C), 0, 100, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32), torch.float32)
+    kw = dict(num_samples=N, num_steps_per_sample=L, step_size=0.1, jitter=1e-3, softabs_const=1e6, explicit_binding_const=10.0,
+              sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT, metric=ht.Metric.SOFTABS, verbose=False, seed=5)
+    outs = []
+    try:
+        _abi.set_tuning("rmhmc_fused", 0)
+        for mode in (1, 0):
+            _abi.set_tuning("metric_mfma", mode)
+            outs.append(torch.stack(ht.sample(t, th0, **kw)).cpu().numpy())
+    finally:
+        _abi.set_tuning("rmhmc_fused", 1); _abi.set_tuning("metric_mfma", 1)
+    err = np.abs(outs[0] - outs[1]).max(axis=(0, 2))
+    assert (err > 3e-4).sum() <= 1, err.max()

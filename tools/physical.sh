@@ -10,7 +10,7 @@ t0=$(date +%s)
 one() {  # key steps warmup traj env -- bench args
   local key=$1 steps=$2 warm=$3 traj=$4 envs=$5; shift 5
   local d=$O/$key; mkdir -p $d
-  local cmd="python bench.py --no-cpu-baseline --no-secondary --steps $steps --warmup $warm $*"
+  local cmd="python bench.py --no-cpu-baseline --no-secondary --no-api --steps $steps --warmup $warm $*"
   echo "{\"command\": \"$envs $cmd\", \"steps\": $steps, \"warmup\": $warm, \"traj\": $traj, \"source\": \"tools/physical.sh $R\"}" > $d/meta.json
   env $envs timeout 120 rocprofv3 --kernel-trace --stats -f csv -d $d/stats -o s -- $cmd > $d/bench.json 2> /dev/null
   env $envs timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $d/pmc_rd -o r -- $cmd > /dev/null 2>&1
