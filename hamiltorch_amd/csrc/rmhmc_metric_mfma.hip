@@ -33,6 +33,16 @@ int g_metric_mfma = 1;   // tuning key "metric_mfma": 1 = warm fp32 evaluations 
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+#ifndef HTA_TIMING
+#define HTA_TIMING 0
+#endif
+#if HTA_TIMING      // developer builds (tools/scratch/metric_phase.cpp): s_memtime stamps of workgroup 0 at the phase boundaries
+__device__ long long hta_metric_dbg[32];
+#define HTA_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) hta_metric_dbg[k] = clock64(); } while (0)
+#else
+#define HTA_STAMP(k) do { } while (0)
+#endif
+
 constexpr float kFallbackE = 0.03f;   // max |E_ij| beyond which the refinement is not trusted
 constexpr float kConvE = 3e-4f;       // an update with max |E_ij| below this leaves an error of order 1e-7
 
@@ -44,55 +54,138 @@ __device__ __forceinline__ void upper_tile(int t, int nt, int& I, int& J) {
 }
 
 // C = Cinit + op(A) op(B) on zero-padded [DP][LD] buffers.  op(A)[m][k] = TA ? A[k][m] : A[m][k]; op(B)[k][n] = TB ? B[n][k]
-// : B[k][n], times kscale[k] when given.  SYM: the product is symmetric - upper tiles only, mirrored on store.
+// : B[k][n], times kscale[k] when SCALE.  SYM: the product is symmetric - upper macro tiles only, mirrored on store.
 // Lane l of a wave feeds A[m = l & 15][k = l >> 4], B[k = l >> 4][n = l & 15] and owns C[4 (l >> 4) + r][l & 15].
-template <bool TA, bool TB, bool SYM>
-__device__ __forceinline__ void lds_gemm(const float* A, const float* B, float* C, const float* Cinit, const float* kscale,
-                                         int nt, int LD) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 15, lk = lane >> 4;
-  const int ntile = SYM ? nt * (nt + 1) / 2 : nt * nt;
-  for (int t = wave; t < ntile; t += MT / 64) {
-    int I, J;
-    if (SYM) upper_tile(t, nt, I, J);
-    else { I = t / nt; J = t - I * nt; }
-    f4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (Cinit) {
+//
+// A wave owns one MACRO tile of 2 x 2 instruction tiles: an operand fetched from LDS feeds two instructions (LDS traffic is
+// what bounds a one-tile-per-wave loop: 2 x 256 bytes per 32-cycle instruction and SIMD) and the four accumulators are
+// independent chains (40 cycles of dependent latency against 32 of issue).  nt <= 7 gives at most 16 macro tiles, one per
+// wave; they are dealt out by size (full 2 x 2 tiles, then the 1 x 2 / 2 x 1 edges of an odd nt, then the corner) in
+// boustrophedon order over the four SIMDs - wave w runs on SIMD w & 3 - so that the matrix pipes get equal shares.
+// The contraction covers k4 steps of four indices (k4 = ceil(D / 4)): chunks of four steps, the operands of the next chunk
+// in flight while the current one is on the pipe.
+// the k loop of one macro tile; R2 / C2: the macro tile has a second tile row / column
+template <bool TA, bool TB, bool SCALE, bool R2, bool C2>
+__device__ __forceinline__ void gemm_macro(const float* pa0, const float* pb0, const float* kscale, int k4, int LD, int lk, f4 (&acc)[2][2]) {
+  const int as = TA ? 4 * LD : 4, bs = TB ? 4 : 4 * LD;
+  const float* pa1 = pa0 + (TA ? 16 : 16 * LD);
+  const float* pb1 = pb0 + (TB ? 16 * LD : 16);
+  float av[2][2][4], bv[2][2][4];                               // [buffer][tile row / column][step]
+#define HTA_LOAD_STEP(buf, u, ks)                                                        \
+  do {                                                                                   \
+    av[buf][0][u] = pa0[(ks) * as];                                                      \
+    if (R2) av[buf][1][u] = pa1[(ks) * as];                                              \
+    const float sc__ = SCALE ? kscale[4 * (ks) + lk] : 1.f;                              \
+    bv[buf][0][u] = SCALE ? pb0[(ks) * bs] * sc__ : pb0[(ks) * bs];                      \
+    if (C2) bv[buf][1][u] = SCALE ? pb1[(ks) * bs] * sc__ : pb1[(ks) * bs];              \
+  } while (0)
+#define HTA_MMA_STEP(buf, u)                                                                                              \
+  do {                                                                                                                    \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][0][u], bv[buf][0][u], acc[0][0], 0, 0, 0);                   \
+    if (C2) acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][0][u], bv[buf][1][u], acc[0][1], 0, 0, 0);           \
+    if (R2) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][1][u], bv[buf][0][u], acc[1][0], 0, 0, 0);           \
+    if (R2 && C2) acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][1][u], bv[buf][1][u], acc[1][1], 0, 0, 0);     \
+  } while (0)
+  const int nchunk = k4 >> 2;
+  if (nchunk > 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = Cinit[(16 * I + 4 * lk + r) * LD + 16 * J + li];
+    for (int u = 0; u < 4; ++u) HTA_LOAD_STEP(0, u, u);
+    int ch = 0;
+    for (; ch + 2 < nchunk; ch += 2) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) HTA_LOAD_STEP(1, u, 4 * (ch + 1) + u);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) HTA_MMA_STEP(0, u);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) HTA_LOAD_STEP(0, u, 4 * (ch + 2) + u);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) HTA_MMA_STEP(1, u);
     }
-    const float* ap = TA ? A + lk * LD + 16 * I + li : A + (16 * I + li) * LD + lk;
-    const float* bp = TB ? B + (16 * J + li) * LD + lk : B + lk * LD + 16 * J + li;
-    const int as = TA ? 4 * LD : 4, bs = TB ? 4 : 4 * LD;
-    // the contraction runs over all DP = 16 nt (zero padded) indices in chunks of four instructions; the operands of the
-    // next chunk are fetched from LDS while the current one is on the matrix pipe
-    float a0[4], b0[4];
+    if (ch + 1 < nchunk) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      a0[u] = ap[u * as];
-      b0[u] = bp[u * bs];
-      if (kscale) b0[u] *= kscale[4 * u + lk];
-    }
-    for (int c = 0; c < nt; ++c) {
-      float a1[4], b1[4];
-      const int cn = (c + 1 < nt) ? c + 1 : c;                 // (the last chunk re-reads itself: no branch in the loop body)
+      for (int u = 0; u < 4; ++u) HTA_LOAD_STEP(1, u, 4 * (ch + 1) + u);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        a1[u] = ap[(4 * cn + u) * as];
-        b1[u] = bp[(4 * cn + u) * bs];
-        if (kscale) b1[u] *= kscale[16 * cn + 4 * u + lk];
-      }
+      for (int u = 0; u < 4; ++u) HTA_MMA_STEP(0, u);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], b0[u], acc, 0, 0, 0);
+      for (int u = 0; u < 4; ++u) HTA_MMA_STEP(1, u);
+    } else {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { a0[u] = a1[u]; b0[u] = b1[u]; }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      C[(16 * I + 4 * lk + r) * LD + 16 * J + li] = acc[r];
-      if (SYM && I != J) C[(16 * J + li) * LD + 16 * I + 4 * lk + r] = acc[r];
+      for (int u = 0; u < 4; ++u) HTA_MMA_STEP(0, u);
     }
   }
+  for (int ks = 4 * nchunk; ks < k4; ++ks) {
+    HTA_LOAD_STEP(0, 0, ks);
+    HTA_MMA_STEP(0, 0);
+  }
+#undef HTA_LOAD_STEP
+#undef HTA_MMA_STEP
+}
+
+// (Operands are OFFSETS, in floats, into the kernel's dynamic LDS block: an out-of-line function only sees generic pointers
+// in its arguments - flat loads, every wait a full one; and its integer arguments arrive in vector registers: readfirstlane
+// makes them scalars again so that the tile bookkeeping compiles to scalar branches.)
+template <bool TA, bool TB, bool SYM, bool SCALE>
+__device__ __attribute__((noinline)) void lds_gemm(int offA, int offB, int offC, int offCinit, int offScale, int nt, int k4, int LD) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* const lds = reinterpret_cast<float*>(smem_raw);
+  nt = __builtin_amdgcn_readfirstlane(nt); k4 = __builtin_amdgcn_readfirstlane(k4); LD = __builtin_amdgcn_readfirstlane(LD);
+  const float* A = lds + __builtin_amdgcn_readfirstlane(offA);
+  const float* B = lds + __builtin_amdgcn_readfirstlane(offB);
+  float* C = lds + __builtin_amdgcn_readfirstlane(offC);
+  offCinit = __builtin_amdgcn_readfirstlane(offCinit);
+  const float* Cinit = offCinit >= 0 ? lds + offCinit : nullptr;
+  const float* kscale = SCALE ? lds + __builtin_amdgcn_readfirstlane(offScale) : nullptr;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform: scalar branches below
+  const int li = lane & 15, lk = lane >> 4;
+  const int nf = nt >> 1, odd = nt & 1;
+  const int s = wave & 3, q = wave >> 2;
+  int k = (q & 1) ? 4 * q + 3 - s : 4 * q + s;                  // position in the size-sorted macro list
+  int r, c;
+  if (SYM) {
+    const int nfull = nf * (nf + 1) / 2;
+    if (k < nfull) upper_tile(k, nf, r, c);
+    else { k -= nfull; if (!odd || k > nf) return; if (k < nf) { r = k; c = nf; } else { r = nf; c = nf; } }
+  } else {
+    const int nfull = nf * nf;
+    if (k < nfull) { r = k / nf; c = k - r * nf; }
+    else {
+      k -= nfull;
+      if (!odd || k > 2 * nf) return;
+      if (k < nf) { r = k; c = nf; } else if (k < 2 * nf) { r = nf; c = k - nf; } else { r = nf; c = nf; }
+    }
+  }
+  const int I0 = 2 * r, J0 = 2 * c;
+  const bool r2 = I0 + 1 < nt, c2 = J0 + 1 < nt;
+  const float* pa0 = TA ? A + lk * LD + 16 * I0 + li : A + (16 * I0 + li) * LD + lk;
+  const float* pb0 = TB ? B + (16 * J0 + li) * LD + lk : B + lk * LD + 16 * J0 + li;
+  f4 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      acc[x][y] = f4{0.f, 0.f, 0.f, 0.f};
+      if (Cinit && (x == 0 || r2) && (y == 0 || c2)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[x][y][t] = Cinit[(16 * (I0 + x) + 4 * lk + t) * LD + 16 * (J0 + y) + li];
+      }
+    }
+  if (r2 && c2) gemm_macro<TA, TB, SCALE, true, true>(pa0, pb0, kscale, k4, LD, lk, acc);
+  else if (r2) gemm_macro<TA, TB, SCALE, true, false>(pa0, pb0, kscale, k4, LD, lk, acc);
+  else if (c2) gemm_macro<TA, TB, SCALE, false, true>(pa0, pb0, kscale, k4, LD, lk, acc);
+  else gemm_macro<TA, TB, SCALE, false, false>(pa0, pb0, kscale, k4, LD, lk, acc);
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      if ((x == 1 && !r2) || (y == 1 && !c2)) continue;
+      const int I = I0 + x, J = J0 + y;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        C[(16 * I + 4 * lk + t) * LD + 16 * J + li] = acc[x][y][t];
+        if (SYM && r != c) C[(16 * J + li) * LD + 16 * I + 4 * lk + t] = acc[x][y][t];
+      }
+    }
 }
 
 __device__ __forceinline__ float block_max(float v, float* red) {
@@ -112,13 +205,60 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // TRANS ? M[k * ld + row] : M[row * ld + k]; n = vector length (rows and columns).  Every lane of a row's group returns the sum.
 template <bool TRANS> __device__ __forceinline__ float mv8(const float* M, int ld, const float* v, int n) {
   const int row = threadIdx.x >> 3, seg = threadIdx.x & 7;
-  float acc = 0.f;
-  if (row < n)
-    for (int k = seg; k < n; k += 8) acc = fmaf(TRANS ? M[k * ld + row] : M[row * ld + k], v[k], acc);
+  float acc0 = 0.f, acc1 = 0.f;
+  if (row < n) {
+    // n <= 112: 14 steps of 8, seven operand pairs in flight at a time
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float mv[7], vv[7];
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        const int k = seg + 8 * (7 * h + u);
+        const bool on = k < n;
+        mv[u] = on ? (TRANS ? M[k * ld + row] : M[row * ld + k]) : 0.f;
+        vv[u] = on ? v[k] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 7; ++u) { if (u & 1) acc1 = fmaf(mv[u], vv[u], acc1); else acc0 = fmaf(mv[u], vv[u], acc0); }
+    }
+  }
+  float acc = acc0 + acc1;
   acc += __shfl_xor(acc, 1, 64);
   acc += __shfl_xor(acc, 2, 64);
   acc += __shfl_xor(acc, 4, 64);
   return acc;
+}
+
+// y = M v for a SYMMETRIC dense row-major [n][n] matrix in global memory (P; L2 resident): thread (column c = tid & 127,
+// slice q = tid >> 7) sums M[k][c] v[k] over k = q, q + 8, ... - consecutive lanes read consecutive addresses, all 14 loads
+// of a thread are in flight together, no cross-lane reduction.  The 8 slice partials meet in `part` ([8][128] floats of
+// LDS); after the barrier inside, y[c] = sum_q part[q][c] is returned to the threads tid < 128 (0 elsewhere).
+__device__ __forceinline__ float gmv_sym(const __attribute__((address_space(1))) float* M, const float* v, int n, float* part) {
+  const int c = threadIdx.x & 127, q = threadIdx.x >> 7;
+  float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float mv[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int k = q + 8 * (7 * h + u);
+      mv[u] = (c < n && k < n) ? M[k * n + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int k = q + 8 * (7 * h + u);
+      const float vk = k < n ? v[k] : 0.f;
+      if (u & 1) acc1 = fmaf(mv[u], vk, acc1); else acc0 = fmaf(mv[u], vk, acc0);
+    }
+  }
+  part[q * 128 + c] = acc0 + acc1;
+  __syncthreads();
+  float y = 0.f;
+  if (threadIdx.x < 128) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) y += part[t * 128 + threadIdx.x];
+  }
+  return y;
 }
 
 // the same for a lower-triangular M: out[row] = sum_{k <= row} M[row][k] v[k]  (p = L z)
@@ -134,10 +274,16 @@ __device__ __forceinline__ float mv8_lower(const float* M, int ld, const float* 
 }
 
 // a zero-padded [DP][LD] copy of a dense row-major [D][D] matrix in global memory
-__device__ __forceinline__ void stage_dense(const float* __restrict__ src, float* dst, int D, int DP, int LD) {
-  for (int e = threadIdx.x; e < DP * LD; e += MT) {
-    const int i = e / LD, j = e - i * LD;
-    dst[e] = (i < D && j < D) ? src[i * D + j] : 0.f;
+__device__ __forceinline__ void stage_dense(const __attribute__((address_space(1))) float* src, float* dst, int D, int DP, int LD) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {                              // DP <= 112, LD <= 116: seven loads of a thread in flight at a time
+    float v[7];
+    const int j = lane + 64 * h;
+#pragma unroll
+    for (int t = 0; t < 7; ++t) { const int i = wave + 16 * t; v[t] = (i < D && j < D) ? src[i * D + j] : 0.f; }
+#pragma unroll
+    for (int t = 0; t < 7; ++t) { const int i = wave + 16 * t; if (i < DP && j < LD) dst[i * LD + j] = v[t]; }
   }
 }
 
@@ -146,10 +292,18 @@ __device__ __forceinline__ void stage_dense(const float* __restrict__ src, float
 // broadcast of the pivot row through LDS), the panel below it is L21 = A21 inv(L11)^T and the trailing matrix loses
 // L21 L21^T, both as MFMA tiles (K = 16: four instructions per tile).  The factor replaces the lower triangle; W is a
 // [16][20] scratch block.  A non-positive pivot yields NaN, as the reference's cholesky raises.
-__device__ __attribute__((noinline)) void mfma_cholesky(float* G, int D, int DP, int LD, float* W) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ float lane_bcast(float x, int lane) {       // v_readlane_b32: `lane` is uniform (a compile-time constant here)
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
+}
+
+__device__ __attribute__((noinline)) void mfma_cholesky(int offG, int D, int DP, int LD, int offW) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* const G = reinterpret_cast<float*>(smem_raw) + __builtin_amdgcn_readfirstlane(offG);
+  float* const W = reinterpret_cast<float*>(smem_raw) + __builtin_amdgcn_readfirstlane(offW);
+  D = __builtin_amdgcn_readfirstlane(D); DP = __builtin_amdgcn_readfirstlane(DP); LD = __builtin_amdgcn_readfirstlane(LD);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
-  const int nt = DP / 16;
+  const int nt = DP / 16, k4 = (D + 3) / 4;
   for (int pb = 0; pb < nt; ++pb) {
     const int c0 = 16 * pb;
     __syncthreads();
@@ -162,7 +316,7 @@ __device__ __attribute__((noinline)) void mfma_cholesky(float* G, int D, int DP,
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const bool cj = c0 + j < D;
-        float d = __shfl(row[j], j, 64);                       // pivot
+        float d = lane_bcast(row[j], j);                       // pivot
         d = cj ? sqrtf(d) : 1.f;
         const float inv = 1.f / d;
         float lij = (lane == j) ? d : row[j] * inv;            // column j of L (rows >= j)
@@ -171,7 +325,7 @@ __device__ __attribute__((noinline)) void mfma_cholesky(float* G, int D, int DP,
         row[j] = lij;
 #pragma unroll
         for (int k = j + 1; k < 16; ++k) {
-          const float lkj = __shfl(lij, k, 64);                // L[k][j]
+          const float lkj = lane_bcast(lij, k);                // L[k][j]
           if (lane >= k) row[k] -= lij * lkj;
         }
       }
@@ -186,8 +340,8 @@ __device__ __attribute__((noinline)) void mfma_cholesky(float* G, int D, int DP,
       for (int i = 0; i < 16; ++i) {
         float acc = (lane == i) ? 1.f : 0.f;
 #pragma unroll
-        for (int k = 0; k < i; ++k) acc -= __shfl(row[k], i, 64) * invc[k];
-        invc[i] = acc / __shfl(row[i], i, 64);
+        for (int k = 0; k < i; ++k) acc -= lane_bcast(row[k], i) * invc[k];
+        invc[i] = acc / lane_bcast(row[i], i);
       }
       if (lane < 16) {
 #pragma unroll
@@ -227,148 +381,215 @@ __device__ __attribute__((noinline)) void mfma_cholesky(float* G, int D, int DP,
   __syncthreads();
 }
 
-// the rare path, kept out of line so that its registers do not weigh on the refinement loop
-__device__ __attribute__((noinline)) void jacobi_fallback(float* A, float* VT, int D, int ne, int LD, float* cs, float* red, int max_sweeps) {
-  lds_jacobi<float, 2, 2>(A, VT, D, ne, LD, LD, cs, nullptr, red, max_sweeps);
+// ---- the phases of an evaluation, each OUT OF LINE ---------------------------------------------------------------------
+// Inlined into one kernel body, the compiler hoists every phase's per-thread address arithmetic over the whole kernel and
+// keeps it alive across the others: > 128 live registers at 1024 threads, i.e. scratch traffic inside the loops.  As
+// functions nothing is live across a phase but a few scalars.  LDS operands are offsets (see lds_gemm); global operands
+// are cast back to the global address space (a generic pointer argument would become flat loads).
+typedef const __attribute__((address_space(1))) float* gcf;
+#define HTA_LDS_BASE() extern __shared__ __attribute__((aligned(16))) char smem_raw[]; float* const lds = reinterpret_cast<float*>(smem_raw)
+#define HTA_U(x) __builtin_amdgcn_readfirstlane(x)
+
+__device__ __attribute__((noinline)) void jacobi_fallback(int offA, int offVT, int D, int ne, int LD, int offCs, int offRed, int max_sweeps) {
+  HTA_LDS_BASE();
+  D = HTA_U(D); ne = HTA_U(ne); LD = HTA_U(LD); max_sweeps = HTA_U(max_sweeps);
+  lds_jacobi<float, 2, 2>(lds + HTA_U(offA), lds + HTA_U(offVT), D, ne, LD, LD, lds + HTA_U(offCs), nullptr, lds + HTA_U(offRed), max_sweeps);
+}
+
+__device__ __attribute__((noinline)) void ph_stage(const float* src, int offDst, int D, int DP, int LD) {
+  HTA_LDS_BASE();
+  stage_dense((gcf)src, lds + HTA_U(offDst), HTA_U(D), HTA_U(DP), HTA_U(LD));
+}
+
+// sum_i d_i (P d)_i over the block, upd_g += cg P d  (d in LDS at offVd; P symmetric, global)
+__device__ __attribute__((noinline)) float ph_logp(const float* P, int offVd, int D, int offPart, int offRed, float* upd_g, float cg) {
+  HTA_LDS_BASE();
+  D = HTA_U(D);
+  const float* vd = lds + HTA_U(offVd);
+  const float pd = gmv_sym((gcf)P, vd, D, lds + HTA_U(offPart));
+  float part = 0.f;
+  if ((int)threadIdx.x < D) {
+    part = vd[threadIdx.x] * pd;
+    if (upd_g) { __attribute__((address_space(1))) float* g = (__attribute__((address_space(1))) float*)upd_g; g[threadIdx.x] += cg * pd; }
+  }
+  return block_sum(part, lds + HTA_U(offRed));
+}
+
+// M (or M^T) v with M [n][ld] and v in LDS; every lane of row (tid >> 3)'s group of 8 returns the row's sum
+__device__ __attribute__((noinline)) float ph_mv8(int trans, int offM, int ld, int offV, int n) {
+  HTA_LDS_BASE();
+  ld = HTA_U(ld); n = HTA_U(n);
+  const float* M = lds + HTA_U(offM); const float* v = lds + HTA_U(offV);
+  return HTA_U(trans) ? mv8<true>(M, ld, v, n) : mv8<false>(M, ld, v, n);
+}
+
+// One pass of the refinement's element-wise step: lam_i = S_ii / Gm_ii, then E from S (at offS) and Gm (at offG; the
+// identity when have_x == 0) into offDst (which may be offS).  Returns max |E_ij|, i != j (1 for NaN / inf / > kFallbackE).
+__device__ __attribute__((noinline)) float ph_refine_E(int offS, int offG, int offDst, int offLam, int offRed, int have_x, int D, int LD) {
+  HTA_LDS_BASE();
+  D = HTA_U(D); LD = HTA_U(LD); have_x = HTA_U(have_x);
+  const float* by = lds + HTA_U(offS); const float* bz = lds + HTA_U(offG);
+  float* edst = lds + HTA_U(offDst); float* vlam = lds + HTA_U(offLam); float* red = lds + HTA_U(offRed);
+  const int tid = threadIdx.x;
+  float scale = 0.f;
+  if (tid < D) {
+    const float l = have_x ? by[tid * LD + tid] / bz[tid * LD + tid] : by[tid * LD + tid];
+    vlam[tid] = l;
+    scale = fabsf(l);
+  }
+  scale = block_max(scale, red);                                   // (its barriers also publish vlam)
+  const float tiny = 8.f * Eps<float>::v * scale;
+  float emax = 0.f;
+  const int j = tid & 127;                                         // 8 rows of up to 128 columns per pass: no index division
+  const float lj = j < D ? vlam[j] : 0.f;
+#pragma unroll 7
+  for (int p8 = 0; p8 < 14; ++p8) {
+    const int i = (tid >> 7) + 8 * p8;
+    if (i >= D || j >= D) continue;
+    const float gm = have_x ? bz[i * LD + j] : (i == j ? 1.f : 0.f);
+    float E;
+    if (i == j) E = 0.5f * (1.f - gm) + (have_x ? 0.f : 1.f);
+    else {
+      const float num = by[i * LD + j] - lj * gm;
+      E = (fabsf(num) <= tiny) ? -0.5f * gm : __fdividef(num, lj - vlam[i]);
+      emax = fmaxf(emax, fabsf(E));
+      if (!(fabsf(E) <= kFallbackE)) emax = 1.f;                   // NaN / inf / too large
+    }
+    edst[i * LD + j] = E;
+  }
+  return block_max(emax, red);
+}
+
+__device__ __attribute__((noinline)) void ph_chol_solve(int offG, int D, int LD, int offV) {
+  HTA_LDS_BASE();
+  lds_chol_solve<float>(lds + HTA_U(offG), HTA_U(D), HTA_U(LD), lds + HTA_U(offV));
+}
+
+__device__ __attribute__((noinline)) float ph_mv8_lower(int offM, int ld, int offV, int n) {
+  HTA_LDS_BASE();
+  return mv8_lower(lds + HTA_U(offM), HTA_U(ld), lds + HTA_U(offV), HTA_U(n));
 }
 
 __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float> a, int DP, int LD) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = a.D, tid = threadIdx.x;
-  const int nt = DP / 16;
+  const int nt = DP / 16, k4 = (D + 3) / 4;
   const int ne = D + (D & 1);
-  float* buf0 = reinterpret_cast<float*>(smem_raw);
-  float* buf1 = buf0 + DP * LD;
-  float* buf2 = buf1 + DP * LD;
-  float* vjit = buf2 + DP * LD;      // e = jitter * u                          (later: Jacobi (c, s) pairs)
-  float* vlam = vjit + DP;           // eigenvalues of Hs
-  float* vlt = vlam + DP;            // soft-abs eigenvalues
-  float* vm = vlt + DP;              // m, then m' = V0^T m
-  float* vy = vm + DP;               // y = X^T m', then w = y / lam~
-  float* vx = vy + DP;               // x' = X w
-  float* vd = vx + DP;               // d = X - mu / z
-  float* vpd = vd + DP;              // P d / x
-  float* red = vpd + DP;             // MT / 64
-  float* W = red + MT / 64;          // [16][20] panel scratch
+  float* const lds0 = reinterpret_cast<float*>(smem_raw);
+  const int BS = DP * LD > 1024 ? DP * LD : 1024;             // (gmv_sym parks 8 x 128 slice partials in a matrix buffer)
+  const int oB0 = 0, oB1 = BS, oB2 = 2 * BS;
+  const int oJit = 3 * BS;           // e = jitter * u                          (later: Jacobi (c, s) pairs)
+  const int oLam = oJit + DP;        // eigenvalues of Hs
+  const int oLt = oLam + DP;         // soft-abs eigenvalues
+  const int oM = oLt + DP;           // m, then m' = V0^T m
+  const int oY = oM + DP;            // w = (X^T m') / lam~
+  const int oX = oY + DP;            // x' = X w
+  const int oD = oX + DP;            // d = X - mu / z
+  const int oRed = oD + 2 * DP;      // MT / 64
+  const int oW = oRed + MT / 64;     // [16][20] panel scratch
+  float* vjit = lds0 + oJit; float* vlam = lds0 + oLam; float* vlt = lds0 + oLt; float* vm = lds0 + oM; float* vy = lds0 + oY;
+  float* vx = lds0 + oX; float* vd = lds0 + oD; float* red = lds0 + oRed;
   const bool softabs = a.metric == 1;
 
   for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
     const uint64_t chain = a.chain_offset + (uint64_t)b;
     __syncthreads();
+    HTA_STAMP(0);
     // ---- 0. operands: jitter, the solve vector, d = X - mu; V0 into LDS
-    for (int i = tid; i < DP; i += MT) {
+    if (tid < DP) {
+      const int i = tid;
       vjit[i] = (i < D && a.has_jitter) ? (float)a.jitter * uniform_elem<float>(a.seed, chain, a.draw, PURPOSE_JITTER, a.sub, i) : 0.f;
       vm[i] = (i < D && a.m) ? a.m[b * D + i] : 0.f;
       vd[i] = (i < D && a.X) ? a.X[b * D + i] - a.mu[i] : 0.f;
     }
-    if (softabs) stage_dense(a.V0, buf1, D, DP, LD);
+    if (softabs) ph_stage(a.V0, oB1, D, DP, LD);
     __syncthreads();
+    HTA_STAMP(1);
     // ---- Gaussian log-prob and P (X - mu)
     float logp = 0.f;
-    if (a.X) {
-      const float pd = mv8<false>(a.Pm, D, vd, D);
-      const int row = tid >> 3;
-      float part = 0.f;
-      if ((tid & 7) == 0 && row < D) {
-        vpd[row] = pd;
-        part = vd[row] * pd;
-        if (a.upd_g) a.upd_g[b * D + row] += (float)a.cg * pd;
-      }
-      logp = (float)a.log_norm - 0.5f * block_sum(part, red);
-    }
+    if (a.X) logp = (float)a.log_norm - 0.5f * ph_logp(a.Pm, oD, D, oB2, oRed, a.upd_g ? a.upd_g + b * D : nullptr, (float)a.cg);
     // ---- m' = V0^T m
     if (a.m && softabs) {
-      const float v = mv8<true>(buf1, LD, vm, D);
+      const float v = ph_mv8(1, oB1, LD, oM, D);
       __syncthreads();
       if ((tid & 7) == 0 && (tid >> 3) < DP) vm[tid >> 3] = ((tid >> 3) < D) ? v : 0.f;
     }
-    // ---- 1. A = diag(lam0) + V0^T diag(e) V0 into buf0 (symmetric, zero padded)
+    HTA_STAMP(2);
+    // ---- 1. A = diag(lam0) + V0^T diag(e) V0 into buffer 0 (symmetric, zero padded)
     if (softabs) {
-      lds_gemm<true, false, true>(buf1, buf1, buf0, nullptr, vjit, nt, LD);
+      lds_gemm<true, false, true, true>(oB1, oB1, oB0, -1, oJit, nt, k4, LD);
       __syncthreads();
-      for (int i = tid; i < D; i += MT) buf0[i * LD + i] += a.lam0[i];
+      if (tid < D) lds0[oB0 + tid * LD + tid] += a.lam0[tid];
     }
     __syncthreads();
+    HTA_STAMP(3);
     // ---- 2. eigenvectors X of A by iterative refinement from X = I; bx: X, by: A / S / E, bz: scratch
-    float* bx = buf1; float* by = buf0; float* bz = buf2;
+    int bx = oB1, by = oB0, bz = oB2;
     bool have_x = false, converged = false, fallback = !softabs;     // Metric.HESSIAN: G = A, no decomposition needed
     if (softabs) {
       for (int it = 0; it < 4 && !converged && !fallback; ++it) {
         if (it >= 2) {                                               // rare: A was consumed by the previous pass, form it again
-          stage_dense(a.V0, bz, D, DP, LD);
+          ph_stage(a.V0, bz, D, DP, LD);
           __syncthreads();
-          lds_gemm<true, false, true>(bz, bz, by, nullptr, vjit, nt, LD);
+          lds_gemm<true, false, true, true>(bz, bz, by, -1, oJit, nt, k4, LD);
           __syncthreads();
-          for (int i = tid; i < D; i += MT) by[i * LD + i] += a.lam0[i];
+          if (tid < D) lds0[by + tid * LD + tid] += a.lam0[tid];
           __syncthreads();
         }
+        HTA_STAMP(4 + 4 * it);
         if (have_x) {
-          lds_gemm<false, false, false>(by, bx, bz, nullptr, nullptr, nt, LD);       // T = A X
+          lds_gemm<false, false, false, false>(by, bx, bz, -1, -1, nt, k4, LD);       // T = A X
           __syncthreads();
-          lds_gemm<true, false, true>(bx, bz, by, nullptr, nullptr, nt, LD);         // S = X^T T
+          lds_gemm<true, false, true, false>(bx, bz, by, -1, -1, nt, k4, LD);         // S = X^T T
           __syncthreads();
-          lds_gemm<true, false, true>(bx, bx, bz, nullptr, nullptr, nt, LD);         // Gm = X^T X
+          lds_gemm<true, false, true, false>(bx, bx, bz, -1, -1, nt, k4, LD);         // Gm = X^T X
           __syncthreads();
         }
-        for (int i = tid; i < D; i += MT) vlam[i] = have_x ? by[i * LD + i] / bz[i * LD + i] : by[i * LD + i];
-        __syncthreads();
-        float emax = 0.f, scale = 0.f;
-        for (int i = tid; i < D; i += MT) scale = fmaxf(scale, fabsf(vlam[i]));
-        scale = block_max(scale, red);
-        const float tiny = 8.f * Eps<float>::v * scale;
-        float* const edst = have_x ? by : bx;                         // first pass: X = I + E next to A (still needed for A X)
-        for (int e = tid; e < D * D; e += MT) {
-          const int i = e / D, j = e - i * D;
-          const float gm = have_x ? bz[i * LD + j] : (i == j ? 1.f : 0.f);
-          float E;
-          if (i == j) E = 0.5f * (1.f - gm) + (have_x ? 0.f : 1.f);
-          else {
-            const float num = by[i * LD + j] - vlam[j] * gm;
-            E = (fabsf(num) <= tiny) ? -0.5f * gm : num / (vlam[j] - vlam[i]);
-            emax = fmaxf(emax, fabsf(E));
-            if (!(fabsf(E) <= kFallbackE)) emax = 1.f;               // NaN / inf / too large
-          }
-          edst[i * LD + j] = E;
-        }
-        emax = block_max(emax, red);
+        HTA_STAMP(5 + 4 * it);
+        // first pass: X = I + E goes next to A (still needed for A X); later passes: E in place of S
+        const float emax = ph_refine_E(by, bz, have_x ? by : bx, oLam, oRed, have_x ? 1 : 0, D, LD);
+        HTA_STAMP(6 + 4 * it);
         if (emax > kFallbackE) { fallback = true; break; }
         __syncthreads();
         if (have_x) {
-          lds_gemm<false, false, false>(bx, by, bz, bx, nullptr, nt, LD);            // X <- X + X E
+          lds_gemm<false, false, false, false>(bx, by, bz, bx, -1, nt, k4, LD);       // X <- X + X E
           __syncthreads();
-          float* t = bx; bx = bz; bz = t;
+          const int t = bx; bx = bz; bz = t;
         } else {
-          have_x = true;                                                                 // bx = I + E, by = A still
+          have_x = true;                                                              // bx = I + E, by = A still
         }
         converged = emax <= kConvE;
+        HTA_STAMP(7 + 4 * it);
       }
       if (!converged) fallback = true;
       if (fallback) {
         // cyclic Jacobi on A (rmhmc_metric_dev.hpp): no assumption on gaps or perturbation size
         __syncthreads();
-        stage_dense(a.V0, bz, D, DP, LD);
+        ph_stage(a.V0, bz, D, DP, LD);
         __syncthreads();
-        lds_gemm<true, false, true>(bz, bz, by, nullptr, vjit, nt, LD);
+        lds_gemm<true, false, true, true>(bz, bz, by, -1, oJit, nt, k4, LD);
         __syncthreads();
-        for (int i = tid; i < D; i += MT) by[i * LD + i] += a.lam0[i];
-        for (int e = tid; e < DP * LD; e += MT) { const int i = e / LD, j = e - i * LD; bz[e] = (i == j && i < D) ? 1.f : 0.f; }
+        if (tid < D) lds0[by + tid * LD + tid] += a.lam0[tid];
+        for (int e = tid; e < DP * LD; e += MT) { const int i = e / LD, j = e - i * LD; lds0[bz + e] = (i == j && i < D) ? 1.f : 0.f; }
         __syncthreads();
-        jacobi_fallback(by, bz, D, ne, LD, vjit, red, a.max_sweeps);
-        for (int i = tid; i < D; i += MT) vlam[i] = by[i * LD + i];
-        for (int e = tid; e < DP * LD; e += MT) { const int i = e / LD, j = e - i * LD; bx[e] = (i < D && j < D) ? bz[j * LD + i] : 0.f; }   // X[i][k] = VT[k][i]
+        jacobi_fallback(by, bz, D, ne, LD, oJit, oRed, a.max_sweeps);
+        if (tid < D) vlam[tid] = lds0[by + tid * LD + tid];
+        for (int e = tid; e < DP * LD; e += MT) { const int i = e / LD, j = e - i * LD; lds0[bx + e] = (i < D && j < D) ? lds0[bz + j * LD + i] : 0.f; }   // X[i][k] = VT[k][i]
         __syncthreads();
       }
     }
+    HTA_STAMP(20);
     // ---- 3. soft-abs map, log-determinant  (S:120, S:726)
     float logdet = 0.f, quad = 0.f;
     if (softabs) {
       float ld = 0.f;
-      for (int i = tid; i < DP; i += MT) {
+      if (tid < DP) {
+        const int i = tid;
         float lt = 1.f;
         if (i < D) {
           const float lam = vlam[i];
           lt = (1.f / tanhf((float)a.alpha * lam)) * lam;
-          ld += logf(lt);
+          ld = logf(lt);
           if (a.lam_out) a.lam_out[b * D + i] = lt;
           if (a.lamraw_out) a.lamraw_out[b * D + i] = lam;
         }
@@ -377,7 +598,7 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
       logdet = block_sum(ld, red);
       // ---- 4. x = V0 X (X^T m' / lam~)
       if (a.m) {
-        const float y = mv8<true>(bx, LD, vm, D);
+        const float y = ph_mv8(1, bx, LD, oM, D);
         const int row = tid >> 3;
         float qd = 0.f;
         if ((tid & 7) == 0 && row < DP) {
@@ -386,64 +607,71 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
           qd = (row < D) ? y * w : 0.f;
         }
         quad = block_sum(qd, red);
-        const float xp = mv8<false>(bx, LD, vy, D);
+        const float xp = ph_mv8(0, bx, LD, oY, D);
         if ((tid & 7) == 0 && row < DP) vx[row] = (row < D) ? xp : 0.f;
         __syncthreads();
-        const float x = mv8<false>(a.V0, D, vx, D);
+        ph_stage(a.V0, by, D, DP, LD);                          // (the E buffer is dead)
+        __syncthreads();
+        const float x = ph_mv8(0, by, LD, oX, D);
         if ((tid & 7) == 0 && row < D) {
           if (a.x_out) a.x_out[b * D + row] = x;
           if (a.upd_x) a.upd_x[b * D + row] += (float)a.cx * x;
         }
       }
     }
+    HTA_STAMP(21);
     // ---- 5. G = Q diag(lam~) Q^T, Q = V0 X  (S:121) for fisher() / the momentum draw; Metric.HESSIAN: G = Hs itself
     if (a.G_out || a.p_out || !softabs) {
       __syncthreads();
-      float* g = bz;
+      int g = bz;
       if (softabs) {
-        stage_dense(a.V0, by, D, DP, LD);
+        ph_stage(a.V0, by, D, DP, LD);
         __syncthreads();
-        lds_gemm<false, false, false>(by, bx, bz, nullptr, nullptr, nt, LD);         // Q = V0 X
+        lds_gemm<false, false, false, false>(by, bx, bz, -1, -1, nt, k4, LD);         // Q = V0 X
         __syncthreads();
-        lds_gemm<false, true, true>(bz, bz, by, nullptr, vlt, nt, LD);               // G = Q (diag(lam~) Q^T)
+        lds_gemm<false, true, true, true>(bz, bz, by, -1, oLt, nt, k4, LD);           // G = Q (diag(lam~) Q^T)
         g = by;
       } else {
+        const float* Hs = a.Hs + b * a.hs_stride;
         for (int e = tid; e < DP * LD; e += MT) {
           const int i = e / LD, j = e - i * LD;
           float v = 0.f;
-          if (i < D && j < D) { const float* Hs = a.Hs + b * a.hs_stride; v = (i >= j) ? Hs[i * D + j] : Hs[j * D + i]; if (i == j) v += vjit[i]; }
-          g[e] = v;
+          if (i < D && j < D) { v = (i >= j) ? Hs[i * D + j] : Hs[j * D + i]; if (i == j) v += vjit[i]; }
+          lds0[g + e] = v;
         }
       }
       __syncthreads();
-      if (a.G_out) for (int e = tid; e < D * D; e += MT) { const int i = e / D, j = e - i * D; a.G_out[b * D * D + e] = g[i * LD + j]; }
+      if (a.G_out) for (int e = tid; e < D * D; e += MT) { const int i = e / D, j = e - i * D; a.G_out[b * D * D + e] = lds0[g + i * LD + j]; }
+      HTA_STAMP(22);
       if (a.p_out || !softabs) {
-        mfma_cholesky(g, D, DP, LD, W);
+        mfma_cholesky(g, D, DP, LD, oW);
+        HTA_STAMP(23);
         if (!softabs) {
           float ld = 0.f;
-          for (int i = tid; i < D; i += MT) ld += 2.f * logf(g[i * LD + i]);             // slogdet (S:728) for a PD metric
+          if (tid < D) ld = 2.f * logf(lds0[g + tid * LD + tid]);                     // slogdet (S:728) for a PD metric
           logdet = block_sum(ld, red);
           if (a.m) {
-            for (int i = tid; i < D; i += MT) { vy[i] = a.m[b * D + i]; vx[i] = vy[i]; }
-            lds_chol_solve<float>(g, D, LD, vy);
+            if (tid < D) { vy[tid] = a.m[b * D + tid]; vx[tid] = vy[tid]; }
+            ph_chol_solve(g, D, LD, oY);
             float qd = 0.f;
-            for (int i = tid; i < D; i += MT) {
-              qd += vx[i] * vy[i];
-              if (a.x_out) a.x_out[b * D + i] = vy[i];
-              if (a.upd_x) a.upd_x[b * D + i] += (float)a.cx * vy[i];
+            if (tid < D) {
+              qd = vx[tid] * vy[tid];
+              if (a.x_out) a.x_out[b * D + tid] = vy[tid];
+              if (a.upd_x) a.upd_x[b * D + tid] += (float)a.cx * vy[tid];
             }
             quad = block_sum(qd, red);
           }
         }
         if (a.p_out) {                   // p = L z  (S:184 via MultivariateNormal.rsample)
           __syncthreads();
-          for (int i = tid; i < DP; i += MT) vd[i] = (i < D) ? normal_elem<float>(a.seed, chain, a.draw, 0, i) : 0.f;
+          if (tid < DP) vd[tid] = (tid < D) ? normal_elem<float>(a.seed, chain, a.draw, 0, tid) : 0.f;
           __syncthreads();
-          const float p = mv8_lower(g, LD, vd, D);
+          const float p = ph_mv8_lower(g, LD, oD, D);
           if ((tid & 7) == 0 && (tid >> 3) < D) a.p_out[b * D + (tid >> 3)] = p;
         }
       }
     }
+    HTA_STAMP(24);
     if (tid == 0) {
       if (a.logdet_out) a.logdet_out[b] = logdet;
       if (a.quad_out) a.quad_out[b] = quad;
@@ -465,7 +693,7 @@ bool metric_warm_mfma_eligible(const MetricArgsT<float>& a) {
 int metric_warm_mfma(const MetricArgsT<float>& a, hipStream_t s) {
   const int D = a.D;
   const int DP = (D + 15) / 16 * 16, LD = DP + 4;
-  const size_t lds = ((size_t)3 * DP * LD + 8 * DP + MT / 64 + 16 * 20) * sizeof(float);
+  const size_t lds = ((size_t)3 * (DP * LD > 1024 ? DP * LD : 1024) + 8 * DP + MT / 64 + 16 * 20) * sizeof(float);   // = oW + 320 floats
   HTA_REQUIRE(lds <= 160 * 1024, "hta_metric_eval (mfma): D=%d does not fit the LDS", D);
   MetricArgsT<float> k = a;
   if (k.max_sweeps <= 0) k.max_sweeps = 16;

@@ -1,0 +1,54 @@
+// Phase timer of metric_warm_mfma_kernel (developer tool): s_memtime stamps of workgroup 0 at the phase boundaries.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DHTA_TIMING=1 -ffp-contract=on -fno-slp-vectorize -x hip tools/scratch/metric_phase.cpp -o tools/scratch/metric_phase.bin
+#include "../../hamiltorch_amd/csrc/abi.cpp"
+#include "../../hamiltorch_amd/csrc/rmhmc_metric_mfma.hip"
+#include <vector>
+#include <cmath>
+#include <cstdlib>
+namespace hta {   // the symbols the two sources expect from the rest of the library
+
+template <typename T> int metric_eval(const MetricArgsT<T>&, hipStream_t) { return 0; }
+}
+int main(int argc, char** argv) {
+  const int D = argc > 1 ? atoi(argv[1]) : 100, B = argc > 2 ? atoi(argv[2]) : 256, gibbs = argc > 3 ? atoi(argv[3]) : 0;
+  const double jitter = argc > 4 ? atof(argv[4]) : 1e-3;
+  std::vector<double> Q(D * D);
+  srand(1);
+  for (auto& v : Q) v = rand() / (double)RAND_MAX - 0.5;
+  for (int k = 0; k < D; ++k) {                       // Gram-Schmidt on the columns
+    for (int j = 0; j < k; ++j) { double d = 0; for (int i = 0; i < D; ++i) d += Q[i * D + k] * Q[i * D + j]; for (int i = 0; i < D; ++i) Q[i * D + k] -= d * Q[i * D + j]; }
+    double n = 0; for (int i = 0; i < D; ++i) n += Q[i * D + k] * Q[i * D + k]; n = sqrt(n); for (int i = 0; i < D; ++i) Q[i * D + k] /= n;
+  }
+  std::vector<float> V0(D * D), lam0(D), P(D * D), X(B * D), m(B * D);
+  for (int k = 0; k < D; ++k) lam0[k] = 0.5f + 1.5f * k / (D > 1 ? D - 1 : 1);
+  for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) { double a = 0; for (int k = 0; k < D; ++k) a += Q[i * D + k] * lam0[k] * Q[j * D + k]; P[i * D + j] = (float)a; V0[i * D + j] = (float)Q[i * D + j]; }
+  for (auto& v : X) v = 0.1f * (rand() / (float)RAND_MAX - 0.5f);
+  for (auto& v : m) v = rand() / (float)RAND_MAX - 0.5f;
+  float *dV0, *dl, *dP, *dX, *dm, *dx, *dg, *dp, *dH, *dmu;
+  hipMalloc(&dV0, D * D * 4); hipMalloc(&dl, D * 4); hipMalloc(&dP, D * D * 4); hipMalloc(&dX, B * D * 4); hipMalloc(&dm, B * D * 4);
+  hipMalloc(&dx, B * D * 4); hipMalloc(&dg, B * D * 4); hipMalloc(&dp, B * D * 4); hipMalloc(&dH, B * 4); hipMalloc(&dmu, D * 4);
+  hipMemcpy(dV0, V0.data(), D * D * 4, hipMemcpyHostToDevice); hipMemcpy(dl, lam0.data(), D * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dP, P.data(), D * D * 4, hipMemcpyHostToDevice); hipMemcpy(dX, X.data(), B * D * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dm, m.data(), B * D * 4, hipMemcpyHostToDevice); hipMemset(dx, 0, B * D * 4); hipMemset(dg, 0, B * D * 4); hipMemset(dmu, 0, D * 4);
+  hta::MetricArgsT<float> a; memset(&a, 0, sizeof(a));
+  a.B = B; a.D = D; a.metric = 1; a.Hs = dP; a.hs_stride = 0; a.alpha = 1e6; a.has_jitter = jitter > 0; a.jitter = jitter; a.seed = 5; a.draw = 1; a.sub = 2;
+  a.Pm = dP; a.mu = dmu; a.V0 = dV0; a.lam0 = dl;
+  if (gibbs) a.p_out = dp; else { a.X = dX; a.m = dm; a.upd_x = dx; a.cx = 0.05; a.upd_g = dg; a.cg = -0.05; a.H_out = dH; }
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0, 0);
+    for (int k = 0; k < 10; ++k) { int rc = hta::metric_warm_mfma(a, 0); if (rc) { printf("error %s\n", hta_last_error()); return 1; } }
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("D=%d B=%d gibbs=%d jitter=%g: %.1f us per launch\n", D, B, gibbs, jitter, ms * 100);
+  }
+  long long t[32]; hipMemcpyFromSymbol(t, HIP_SYMBOL(hta::hta_metric_dbg), sizeof(t));
+  const char* names[32] = {"start", "operands+V0 stage", "logp + V0^T m", "formation", "it0 begin", "it0 gemms", "it0 E", "it0 X", "it1 begin", "it1 gemms(T,S,Gm)", "it1 E", "it1 X update",
+                           "it2 begin", "it2 gemms", "it2 E", "it2 X", "it3 begin", "it3 gemms", "it3 E", "it3 X", "refine end", "softabs+solve", "G assembly", "cholesky", "end"};
+  long long prev = t[0];
+  for (int k = 1; k <= 24; ++k) { if (t[k] > prev) { printf("  %-22s %8lld cycles\n", names[k], t[k] - prev); prev = t[k]; } }
+  printf("  total %lld cycles\n", prev - t[0]);
+  printf("  fine stamps (cycles since start): Pd gmv %lld | logp sum %lld | (m' at %lld) ... lt/logdet %lld | y %lld | x' %lld | V0 x' gmv %lld | end %lld\n",
+         t[25] - t[0], t[26] - t[0], t[2] - t[0], t[27] - t[0], t[28] - t[0], t[29] - t[0], t[30] - t[0], t[24] - t[0]);
+  return 0;
+}
