@@ -1122,6 +1122,333 @@ __global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
   }
 }
 
+// =============================================================================================
+// The four-chain kernel on ALL FOUR SIMDs of a CU (the default from 704 to 2048 chains; "rmhmc_mfma4_waves" = 2 keeps the
+// two-wave kernel above, its parity reference).
+//
+// At 1024 chains there are 256 groups of four chains - one workgroup per CU - and the two-wave kernel leaves two of the four
+// matrix pipes of every CU idle.  Splitting the 128 (padded) rows over four waves alone would not help: the 16-block
+// instruction covers 64 rows at a time.  But its 16 blocks are INDEPENDENT 4 x 4 outer products, so here blocks 0..7 take a
+// wave's 32 rows at the even contraction indices and blocks 8..15 the SAME rows at the odd ones: one instruction advances k
+// by two, a product is 50 (+2 padding) instructions per wave instead of 100, and the two partial sums of a row sit in lanes
+// l and l ^ 32 of one wave - combined by v_permlane32_swap, no LDS, no barrier.  Per lane: 2 x 52 matrix operands instead of
+// 2 x 100.  The vectors live in LDS with even and odd rows apart (16-byte operand reads per parity).  Both lane halves run
+// the element-wise code (duplicate state, one writer), which frees a trick for the jitter: a half step's Philox block is the
+// most expensive scalar piece (quarter-rate integer multiplies), and the two halves draw the blocks of TWO half steps at
+// once and swap them - two Philox passes per step instead of four.  Same streams, same update order, same barriers as the
+// two-wave kernel; the sums run over even k then odd k (results agree to rounding).
+// =============================================================================================
+// (XHL = 68, XLD = 140: the 8 operand segments a wave reads at once - 4 chains x 2 parities, 16 bytes each - start at banks
+//  0, 12, 24, 36 and 4, 16, 28, 40: no two share a bank; 64 / 128 would put all eight on the same four banks)
+constexpr int XNC = 4, XHL = 68, XLD = 2 * XHL + 4, XWV = 4, XNT = 64 * XWV, XKJ = 52, XQ = XKJ / 4;
+
+__device__ __forceinline__ float other_half(float h, bool upper) {    // the value lane l ^ 32 holds
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, h), false, false);
+  return __builtin_bit_cast(float, upper ? r[0] : r[1]);
+}
+
+__global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) {
+  typedef float T;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* lds = reinterpret_cast<T*>(smem_raw);
+  constexpr int MSZ = XNC * XLD;
+  T* PM = lds; T* PMC = PM + MSZ; T* D0 = PMC + MSZ; T* D1 = D0 + MSZ; T* W0 = D1 + MSZ; T* W1 = W0 + MSZ; T* EV = W1 + MSZ;
+  T* red = EV + MSZ;                                      // [XWV][XNC][4]
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cl = l & 3, blk = l >> 2;
+  const int kpar = blk >> 3, rb = blk & 7;
+  const bool upper = kpar != 0;
+  const int D = a.D;
+  const int row0 = 32 * w + 4 * rb, arow = row0 + cl;     // this lane OWNS rows row0..row0+3 of chain cl and SUPPLIES matrix row arow
+  T Sa[XKJ], Pa[XKJ];
+#pragma unroll
+  for (int j = 0; j < XKJ; ++j) {
+    const int k = 2 * j + kpar;
+    const bool ok = arow < D && k < D;
+    Sa[j] = ok ? a.S[(int64_t)k * D + arow] : 0.f;        // symmetric: column arow, coalesced over the lanes
+    Pa[j] = ok ? a.P[(int64_t)k * D + arow] : 0.f;
+  }
+  T mu_r[4], sd_r[4];
+  bool rok[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int r = row0 + e;
+    rok[e] = r < D;
+    mu_r[e] = rok[e] ? a.mu[r] : 0.f;
+    sd_r[e] = rok[e] ? a.S[(int64_t)r * D + r] : 0.f;
+  }
+  for (int e = tid; e < 7 * MSZ + XWV * XNC * 4; e += XNT) lds[e] = 0.f;
+  const T eh = 0.5f * a.eps;
+  const int own_off = cl * XLD + (row0 >> 1);             // rows row0, row0+2 -> even half; row0+1, row0+3 -> odd half
+  const int b_off = cl * XLD + kpar * XHL;
+  int dpar = 0;
+  T ev_r[4] = {0.f, 0.f, 0.f, 0.f};
+  uint64_t chain = 0;
+  bool live = false;
+
+  typedef float bf2 __attribute__((ext_vector_type(2)));
+  auto put4 = [&](T* X, const T (&v)[4]) {
+    if (!upper) {
+      *reinterpret_cast<bf2*>(X + own_off) = bf2{v[0], v[2]};
+      *reinterpret_cast<bf2*>(X + own_off + XHL) = bf2{v[1], v[3]};
+    }
+  };
+  // the jitter of this lane's four rows for ONE sub-stream (uniform_elem layout: rows 4b..4b+3 are Philox block b)
+  auto jitter_raw = [&](uint32_t n, uint32_t sub, T (&out)[4]) {
+    const U4 r = philox_block(a.seed, chain, n, PURPOSE_JITTER, sub, (uint32_t)(row0 >> 2));
+    const T u[4] = {u23<T>(r.x), u23<T>(r.y), u23<T>(r.z), u23<T>(r.w)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[e] = (live && rok[e]) ? a.jitter * u[e] : 0.f;
+  };
+  // two sub-streams with one Philox pass: the lower lane half draws subA, the upper half subB, then they swap
+  auto jitter_pair = [&](uint32_t n, uint32_t subA, uint32_t subB, T (&eA)[4], T (&eB)[4]) {
+    if (!a.has_jitter) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { eA[e] = 0.f; eB[e] = 0.f; }
+      return;
+    }
+    T mine[4];
+    jitter_raw(n, upper ? subB : subA, mine);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const T oth = other_half(mine[e], upper);
+      eA[e] = upper ? oth : mine[e];
+      eB[e] = upper ? mine[e] : oth;
+    }
+  };
+  auto chunk = [&](const T* X, int q) { return *reinterpret_cast<const bf4*>(X + b_off + 4 * q); };
+  auto both = [&](bf4& acc) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += other_half(acc[e], upper);
+  };
+  // two products with one pass over k: acc1 = A1 X1, acc2 = A2 X2 (two independent accumulator chains)
+  // One wave per SIMD: nothing else hides an LDS round trip, so the operand chunks (4 values of k per 16-byte read) are
+  // fetched two chunks ahead of their use.  (Requesting all 13 chunks of a vector up front was measured 9 % slower:
+  // profiles/r02e_mfma4_waves_ab.txt.)
+  auto prod2 = [&](const T (&A1)[XKJ], const T* X1, const T (&A2)[XKJ], const T* X2, bf4& acc1, bf4& acc2) {
+    bf4 c1 = chunk(X1, 0), c2 = chunk(X2, 0), n1 = chunk(X1, 1), n2 = chunk(X2, 1);
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+      bf4 f1 = n1, f2 = n2;
+      if (q + 2 < XQ) { f1 = chunk(X1, q + 2); f2 = chunk(X2, q + 2); }
+      __builtin_amdgcn_sched_barrier(0);                    // (the scheduler otherwise sinks the reads next to their use)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1[4 * q + u], c1[u], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(A2[4 * q + u], c2[u], acc2, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      c1 = n1; c2 = n2; n1 = f1; n2 = f2;
+    }
+    both(acc1); both(acc2);
+  };
+  // x = (P + diag(e))^-1 m continued from x0 = S m (rmhmc_fused_kernel: refine)
+  auto refine = [&](const T (&x0)[4], T (&xr)[4]) {
+    for (int it = 0; it < a.K; ++it) {
+      const T* wr = (it & 1) ? W1 : W0;
+      T* ww = (it & 1) ? W0 : W1;
+      __syncthreads();
+      bf4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};      // two chains keep the pipe issuing
+      bf4 c = chunk(wr, 0), n1 = chunk(wr, 1), n2 = chunk(wr, 2);
+#pragma unroll
+      for (int q = 0; q < XQ; ++q) {
+        bf4 f = n2;
+        if (q + 3 < XQ) f = chunk(wr, q + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        sa = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q], c[0], sa, 0, 0, 0);
+        sb = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q + 1], c[1], sb, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q + 2], c[2], sa, 0, 0, 0);
+        sb = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q + 3], c[3], sb, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        c = n1; n1 = n2; n2 = f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sa[e] += sb[e];
+      both(sa);
+      T wv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { xr[e] = x0[e] - sa[e]; wv[e] = ev_r[e] * xr[e]; }
+      put4(ww, wv);
+    }
+  };
+  // one half step with the jitter in ev_r: upd_x += eh G(X)^-1 m ; upd_g -= eh P (X - mu)   (rmhmc_fused_kernel: half_step)
+  auto half_step = [&](const T (&X)[4], const T* m, T (&upd_x)[4], T (&upd_g)[4], T* upd_g_lds) {
+    T* d = dpar ? D1 : D0;
+    dpar ^= 1;
+    T dv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dv[e] = rok[e] ? X[e] - mu_r[e] : 0.f;
+    put4(d, dv);
+    __syncthreads();
+    bf4 Pd = {0.f, 0.f, 0.f, 0.f}, x0v = {0.f, 0.f, 0.f, 0.f};
+    prod2(Pa, d, Sa, m, Pd, x0v);
+    T x0[4], xr[4], wv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      upd_g[e] -= eh * Pd[e];
+      x0[e] = x0v[e]; xr[e] = x0v[e];
+      wv[e] = ev_r[e] * x0v[e];
+    }
+    put4(upd_g_lds, upd_g);
+    put4(W0, wv);
+    refine(x0, xr);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) upd_x[e] += eh * xr[e];
+  };
+  // three sums per chain over the rows, complete in every lane of the chain's column (the upper lane half holds duplicates
+  // of the lower one: it contributes nothing)
+  auto block_sums = [&](T (&v)[3]) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      if (upper) v[e] = 0.f;
+      v[e] += __shfl_xor(v[e], 4, 64);
+      v[e] += __shfl_xor(v[e], 8, 64);
+      v[e] += __shfl_xor(v[e], 16, 64);
+    }
+    __syncthreads();
+    if (blk == 0) {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) red[(w * XNC + cl) * 4 + e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      T s = 0.f;
+#pragma unroll
+      for (int i = 0; i < XWV; ++i) s += red[(i * XNC + cl) * 4 + e];
+      v[e] = s;
+    }
+  };
+  // H = -log p + D/2 log 2 pi + 1/2 log|G| + 1/2 m^T G^-1 m  (S:731)   (rmhmc_fused_kernel: hamiltonian, series branch)
+  auto hamiltonian = [&](uint32_t n, uint32_t sub, const T (&X)[4], const T* m, const T (&mr)[4], T& H, T& logp) {
+    T* d = dpar ? D1 : D0;
+    dpar ^= 1;
+    if (a.has_jitter) jitter_raw(n, sub, ev_r);
+    T dr[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dr[e] = rok[e] ? X[e] - mu_r[e] : 0.f;
+    put4(EV, ev_r);
+    put4(d, dr);
+    __syncthreads();
+    bf4 Pd = {0.f, 0.f, 0.f, 0.f}, x0v = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    prod2(Pa, d, Sa, m, Pd, x0v);
+    if (a.has_jitter) {                                     // second-order log-det term: (S . S) e
+      bf4 c = chunk(EV, 0), n1 = chunk(EV, 1), n2 = chunk(EV, 2), s2b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < XQ; ++q) {
+        bf4 f = n2;
+        if (q + 3 < XQ) f = chunk(EV, q + 3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u += 2) {
+          s2 = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q + u] * Sa[4 * q + u], c[u], s2, 0, 0, 0);
+          s2b = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q + u + 1] * Sa[4 * q + u + 1], c[u + 1], s2b, 0, 0, 0);
+        }
+        c = n1; n1 = n2; n2 = f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s2[e] += s2b[e];
+      both(s2);
+    }
+    T v[3] = {0.f, 0.f, 0.f}, x0[4], xr[4], wv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      x0[e] = x0v[e]; xr[e] = x0v[e];
+      v[0] += dr[e] * Pd[e];
+      wv[e] = ev_r[e] * x0v[e];
+      if (a.has_jitter) v[2] += ev_r[e] * (sd_r[e] - 0.5f * s2[e]);      // log|P + E| = log|P| + tr(SE) - 1/2 tr((SE)^2) + ...
+    }
+    put4(W0, wv);
+    refine(x0, xr);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[1] += mr[e] * xr[e];
+    block_sums(v);
+    const float pi_term = (float)D * 1.8378770351409912f;   // S:712
+    logp = a.log_norm - 0.5f * v[0];
+    H = -logp + 0.5f * pi_term + 0.5f * (a.logdetP + v[2]) + 0.5f * v[1];
+  };
+
+  const int64_t ngroup = (a.C + XNC - 1) / XNC;
+  for (int64_t cg = blockIdx.x; cg < ngroup; cg += gridDim.x) {
+    const int64_t c = XNC * cg + cl;
+    live = c < a.C;
+    chain = a.chain_offset + (uint64_t)(live ? c : 0);
+    T scur[4], sth[4], spm[4], sthc[4], spmc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) scur[e] = (live && rok[e]) ? a.cur[c * D + row0 + e] : 0.f;
+    int32_t rejected = 0;
+    __syncthreads();                                        // the previous group's last reads of the vector matrices
+    for (int t = 0; t < a.n_traj; ++t) {
+      const uint32_t n = (uint32_t)(a.traj_offset + t);
+      // ---- gibbs: p = chol(G(theta)) z, drawn ahead by the momentum kernel (S:183-184)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) spm[e] = (live && rok[e]) ? a.p_ws[((int64_t)t * a.C + c) * D + row0 + e] : 0.f;
+      put4(PM, spm);
+      T H0, H1, lp0, lp1;
+      hamiltonian(n, 1, scur, PM, spm, H0, lp0);            // S:971 -> S:822
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { sth[e] = scur[e]; sthc[e] = scur[e]; spmc[e] = spm[e]; }   // S:425-426
+      put4(PMC, spm);
+      for (int lstep = 0; lstep < a.L; ++lstep) {           // S:427-461
+        const uint32_t k0 = 2u + 8u * (uint32_t)lstep;
+        T e1[4], e2[4];
+        jitter_pair(n, k0 + 1, k0 + 2, e1, e2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ev_r[e] = e1[e];
+        half_step(sth, PMC, sthc, spm, PM);                 // phi_A/2  S:429-430
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ev_r[e] = e2[e];
+        half_step(sthc, PM, sth, spmc, PMC);                // phi_B/2  S:432-433
+        if (a.K == 0) __syncthreads();
+        jitter_pair(n, k0 + 4, k0 + 7, e1, e2);             // (issued before the rotation: independent work for the scheduler)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                       // phi_C    S:447-450, sequential (Q1)
+          T xx = sth[e], b = spm[e], xc = sthc[e], bc = spmc[e];
+          const T h = 0.5f, cc = a.rot_c, ss = a.rot_s;
+          xx = h * ((xx + xc) + cc * (xx - xc) + ss * (b - bc));
+          b = h * ((b + bc) - ss * (xx - xc) + cc * (b - bc));
+          xc = h * ((xx + xc) - cc * (xx - xc) - ss * (b - bc));
+          bc = h * ((b + bc) + ss * (xx - xc) - cc * (b - bc));
+          sth[e] = xx; spm[e] = b; sthc[e] = xc; spmc[e] = bc;
+        }
+        put4(PM, spm);
+        put4(PMC, spmc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ev_r[e] = e1[e];
+        half_step(sthc, PM, sth, spmc, PMC);                // phi_B/2  S:454-455
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ev_r[e] = e2[e];
+        half_step(sth, PMC, sthc, spm, PM);                 // phi_A/2  S:457-458
+      }
+      hamiltonian(n, 2u + 8u * (uint32_t)a.L, sth, PM, spm, H1, lp1);   // S:989 (Q4)
+      // ---- Metropolis test + bookkeeping (S:1000-1026, S:1045-1057)
+      const T u = u23<T>(philox_block(a.seed, chain, n, PURPOSE_MH, 0, 0).x);
+      const bool acc = mh_accept<T>(H0, H1, lp1, u);
+      const bool reset = (!acc) && ((int)n == a.burn + 1);  // Q2
+      if (live) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (rok[e]) {
+            const T vnew = acc ? sth[e] : (reset ? a.theta_init[c * D + row0 + e] : scur[e]);
+            scur[e] = vnew;
+            if (!upper && a.samples && (int)n > a.burn) a.samples[((int64_t)((int)n - a.burn) * a.C + c) * D + row0 + e] = vnew;
+          }
+        }
+        if (w == 0 && blk == 0) {
+          if (a.H_old) a.H_old[(int64_t)t * a.C + c] = H0;
+          if (a.H_new) a.H_new[(int64_t)t * a.C + c] = H1;
+          if (a.accept) a.accept[(int64_t)t * a.C + c] = acc ? 1 : 0;
+        }
+      }
+      if (!acc) ++rejected;
+    }
+    if (live) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (rok[e] && !upper) a.cur[c * D + row0 + e] = scur[e];
+      if (w == 0 && blk == 0) a.reject_count[c] += rejected;
+    }
+  }
+}
+
 // The momentum draws of a block of trajectories, off the chains' critical path: task (t, c) -> p = chol(P + diag(e)) z
 // with the jitter sub-stream 0 and the normals of (chain c, trajectory traj_offset + t)  (S:183-184).  One workgroup per
 // task at a time, 3 per CU: the factorisations of different tasks overlap each other's LDS latency, which the chain-
@@ -1497,9 +1824,16 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
                            ((C >= g_rmhmc_mfma4_lo && C < g_rmhmc_mfma4_hi) || g_rmhmc_mfma4 == 2);
         if (quad4) {
           const int64_t ngroup = (C + QNC - 1) / QNC;
-          const size_t qlds = (size_t)(7 * QNC * QLD + QWV * QNC * 4) * sizeof(float);
           profile_begin(s);
-          rmhmc_mfma4_kernel<<<(int)(ngroup < 8192 ? ngroup : 8192), QNT, qlds, s>>>(a);
+          // four waves per group while the groups fit one per CU (<= 1024 chains on 256 CUs): beyond that two groups share a CU
+          // and the two-wave kernel already fills its four SIMDs
+          if (g_rmhmc_mfma4_waves == 2 || (g_rmhmc_mfma4_waves != 5 && ngroup > 256)) {
+            const size_t qlds = (size_t)(7 * QNC * QLD + QWV * QNC * 4) * sizeof(float);
+            rmhmc_mfma4_kernel<<<(int)(ngroup < 8192 ? ngroup : 8192), QNT, qlds, s>>>(a);
+          } else {
+            const size_t xlds = (size_t)(7 * XNC * XLD + XWV * XNC * 4) * sizeof(float);
+            rmhmc_mfma4x4_kernel<<<(int)(ngroup < 8192 ? ngroup : 8192), XNT, xlds, s>>>(a);
+          }
           profile_end(s);
           return HTA_OK;
         }
