@@ -22,7 +22,7 @@ int g_gauss_eig = 1;       // small-D identity-mass Gaussian HMC integrates in t
 int g_fill_blocks = 4096;        // grid cap of the pre-draw pass (256-thread blocks, grid-stride)
 int g_quad_max_chains = 65536;   // up to here a chain takes a DPP quad (one eigen-coordinate per lane), beyond a lane
 int g_rmhmc_fused = 1;           // 0 = per-evaluation Jacobi path, 3 = fused with two chains per workgroup (parity tests)
-extern int g_metric_mfma;         // rmhmc_metric_mfma.hip
+extern int g_metric_mfma, g_rmhmc_wide;         // rmhmc_metric_mfma.hip
 int g_mlp_valu = 0;               // 1 = keep the Bayesian-MLP sampler on the VALU kernel (parity tests of both)
 
 // ---- optional HIP-event timing of the dominant kernel of each call (measurement only) -----------
@@ -85,6 +85,7 @@ int hta_set_tuning(const char* key, int value) {
   if (!strcmp(key, "rmhmc_mfma4_lo")) { hta::g_rmhmc_mfma4_lo = value; return HTA_OK; }
   if (!strcmp(key, "rmhmc_mfma4_hi")) { hta::g_rmhmc_mfma4_hi = value; return HTA_OK; }
   if (!strcmp(key, "rmhmc_mfma4_waves")) { hta::g_rmhmc_mfma4_waves = value; return HTA_OK; }
+  if (!strcmp(key, "rmhmc_wide")) { hta::g_rmhmc_wide = value; return HTA_OK; }
   if (!strcmp(key, "rmhmc_overlap")) { hta::g_rmhmc_overlap = value; return HTA_OK; }
   if (!strcmp(key, "rmhmc_batch")) { hta::g_rmhmc_batch = value; return HTA_OK; }
   if (!strcmp(key, "quad_max_chains")) { hta::g_quad_max_chains = value; return HTA_OK; }

@@ -443,7 +443,7 @@ template <typename T, int KH, int NC> struct Fused {
 };
 
 template <typename T, int KH, int NC>
-__global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int ld, int need_w) {
+__device__ __forceinline__ void fused_body(const FusedArgs<T>& a, int ld, int need_w) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   typedef Fused<T, KH, NC> F;
   F ch(a);
@@ -580,6 +580,22 @@ __global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int
     if (tid == 0 && blockIdx.x == 0) for (int k = 0; k < 8; ++k) hta_rm_dbg[k] = ch.tacc[k];
 #endif
   }
+}
+
+template <typename T, int KH, int NC>
+__global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int ld, int need_w) {
+  fused_body<T, KH, NC>(a, ld, need_w);
+}
+
+// The same kernel for launches of at most one workgroup per CU (chains <= compute units: BASELINE config 3's 256 chains):
+// two workgroups per CU cannot be resident then, so the two-workgroup register cap of 256 - under which the KH = 56 / 64
+// instances keep 26 / 35 registers in scratch - buys nothing.  HTA_FUSED_WIDE_VGPRS registers instead: together with the
+// overlapped momentum waves (rmhmc_momentum_wave_kernel, capped at 512 - HTA_FUSED_WIDE_VGPRS) a SIMD's 512 are exactly used.
+#define HTA_FUSED_WIDE_VGPRS 288
+template <int KH>
+__global__ __launch_bounds__(FNT) __attribute__((amdgpu_num_vgpr(HTA_FUSED_WIDE_VGPRS))) void rmhmc_fused_kernel_wide(FusedArgs<float> a, int ld, int need_w) {
+  fused_body<float, KH, 1>(a, ld, need_w);
+
 }
 
 
@@ -1496,7 +1512,7 @@ __global__ __launch_bounds__(FNT) void rmhmc_momentum_kernel(const T* __restrict
 // lane r & 63).  12+ tasks per CU.  Same streams and the same factor as rmhmc_momentum_kernel; the sums of p run in
 // panel order.
 template <int NB>
-__global__ __launch_bounds__(64) void rmhmc_momentum_wave_kernel(const float* __restrict__ P, float jitter, int64_t C, int D,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(512 - HTA_FUSED_WIDE_VGPRS))) void rmhmc_momentum_wave_kernel(const float* __restrict__ P, float jitter, int64_t C, int D,
                                                                  int n_traj, int traj_offset, uint64_t seed, uint64_t chain_offset,
                                                                  float* __restrict__ p_ws) {
   constexpr int NR = 8 * NB;                             // padded rows
@@ -1725,6 +1741,18 @@ static Overlap* overlap_for_current_device() {
   return &pool[dev];
 }
 
+int g_rmhmc_wide = 1;      // tuning key "rmhmc_wide": spill-free one-workgroup-per-CU instances of the one-chain kernel
+static int fused_cu_count() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!cus[dev]) {
+    hipDeviceProp_t prop;
+    cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
+  return cus[dev];
+}
+
 template <typename T>
 int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, const T* mu, double log_norm, double logdetP,
                        int has_jitter, double jitter, int K, int series, int64_t C, int D, int L, double eps, double omega,
@@ -1877,6 +1905,21 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { set_error("hta_rmhmc_gaussian_sample: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
         dn = true;
+      }
+      if constexpr (sizeof(T) == 4) {
+        if (g_rmhmc_wide && (KH == 56 || KH == 64) && C <= fused_cu_count()) {       // one workgroup per CU at most: the spill-free instances
+          static DevOnce dw[2];
+          auto wide = KH == 56 ? &rmhmc_fused_kernel_wide<56> : &rmhmc_fused_kernel_wide<64>;
+          if (!dw[KH == 64]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wide), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { set_error("hta_rmhmc_gaussian_sample: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
+            dw[KH == 64] = true;
+          }
+          profile_begin(s);
+          wide<<<grid, FNT, fused_lds_bytes<T>(D, nullptr, 1, need_w), s>>>(a, ld, need_w ? 1 : 0);
+          profile_end(s);
+          return HTA_OK;
+        }
       }
       profile_begin(s);
       kern<<<grid, FNT, fused_lds_bytes<T>(D, nullptr, 1, need_w), s>>>(a, ld, need_w ? 1 : 0);
