@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhamiltorch_amd.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 MASS_NONE, MASS_DIAG, MASS_FULL = 0, 1, 2
 
@@ -60,10 +60,10 @@ def _sig(scalar):
         "hta_hmc_gaussian_leapfrog": [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_int, c_int, scalar, c_vp, c_vp,
                                       c_vp],
         "hta_metric_eval": [ctypes.POINTER(HtaMetricArgs), c_vp],
-        "hta_mlp_hmc_sample": [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int,
+        "hta_mlp_hmc_sample": [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int,
                                ctypes.POINTER(scalar), scalar, scalar, c_int, c_vp, c_vp, c_int, c_int, scalar, c_int,
                                c_int, c_int, c_u64, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
-        "hta_mlp_logp_grad": [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
+        "hta_mlp_logp_grad": [c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
                               ctypes.POINTER(scalar), scalar, scalar, c_vp, c_vp, c_vp],
         "hta_rmhmc_gaussian_leapfrog": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_f64, c_int, c_f64, c_u64, c_u64,
                                         c_u32, c_i64, c_int, c_int, c_f64, c_f64, c_vp, c_vp, c_vp],
@@ -343,6 +343,7 @@ def rmhmc_gaussian_sample(theta, theta_init, P, mu, log_norm, metric, alpha, jit
 
 # ---- Bayesian MLP (regression) -----------------------------------------------------------------------
 ACTS = {"relu": 0, "tanh": 1, "sigmoid": 2}
+LOSSES = {"regression": 0, "binary_class_linear_output": 1}       # HTA_LOSS_REGRESSION / HTA_LOSS_BINARY_LOGITS
 
 
 def _tau4(like, tau):
@@ -352,23 +353,23 @@ def _tau4(like, tau):
 
 def mlp_hmc_sample(theta, theta_init, n_in, H, act, X, Y, M, Nb, tau, tau_out, prior_scale, mass_kind, inv_mass,
                    mass_factor, L, eps, n_traj, traj_offset, burn, seed, chain_offset, samples, reject_count,
-                   H_old=None, H_new=None, accept=None, integrator=0):
+                   H_old=None, H_new=None, accept=None, integrator=0, loss="regression"):
     require_device(theta, "params")
     C = theta.shape[0]
     fn = getattr(load(), "hta_mlp_hmc_sample_" + _suffix(theta))
     with torch.cuda.device(theta.device):
-        _check(fn(_p(theta), _p(theta_init, theta), C, int(n_in), int(H), ACTS[act], _p(X, theta), _p(Y, theta),
+        _check(fn(_p(theta), _p(theta_init, theta), C, int(n_in), int(H), ACTS[act], LOSSES[loss], _p(X, theta), _p(Y, theta),
                   X.shape[0], int(M), int(Nb), _tau4(theta, tau), float(tau_out), float(prior_scale), mass_kind,
                   _p(inv_mass, theta), _p(mass_factor, theta), int(integrator), int(L), float(eps), int(n_traj), int(traj_offset),
                   int(burn), int(seed), int(chain_offset), _p(samples, theta), _p(reject_count), _p(H_old, theta),
                   _p(H_new, theta), _p(accept), _stream(theta)), "hta_mlp_hmc_sample")
 
 
-def mlp_logp_grad(theta, n_in, H, act, X, Y, M, Nb, split, tau, tau_out, prior_scale, grad_out, logp_out):
+def mlp_logp_grad(theta, n_in, H, act, X, Y, M, Nb, split, tau, tau_out, prior_scale, grad_out, logp_out, loss="regression"):
     require_device(theta, "params")
     C = theta.shape[0]
     fn = getattr(load(), "hta_mlp_logp_grad_" + _suffix(theta))
     with torch.cuda.device(theta.device):
-        _check(fn(_p(theta), C, int(n_in), int(H), ACTS[act], _p(X, theta), _p(Y, theta), X.shape[0], int(M), int(Nb),
+        _check(fn(_p(theta), C, int(n_in), int(H), ACTS[act], LOSSES[loss], _p(X, theta), _p(Y, theta), X.shape[0], int(M), int(Nb),
                   int(split), _tau4(theta, tau), float(tau_out), float(prior_scale), _p(grad_out, theta),
                   _p(logp_out, theta), _stream(theta)), "hta_mlp_logp_grad")

@@ -92,11 +92,11 @@ def define_model_log_prob(model, model_loss, x, y, params_flattened_list, params
         return ll + l_prior / prior_scale
 
     st = _mlp_structure(model)
-    if st is not None and model_loss == 'regression' and x is not None and not predict \
-            and x.dim() == 2 and st[0][-1] == 1:
+    if st is not None and model_loss in ('regression', 'binary_class_linear_output') and x is not None and not predict \
+            and x.dim() == 2 and st[0][-1] == 1 and y_dev.numel() == x_dev.shape[0]:
         log_prob_func._hta_spec = dict(dims=st[0], act=st[1], X=x_dev, Y=y_dev.reshape(x_dev.shape[0], -1),
                                        tau_list=list(taus), tau_out=float(tau_out),
-                                       prior_scale=float(prior_scale))
+                                       prior_scale=float(prior_scale), loss=model_loss)
     return log_prob_func
 
 

@@ -18,6 +18,7 @@ template <typename T> struct MlpArgs {
   T* grad_out; T* logp_out;   // evaluation-only mode (n_traj == 0): d log p_m / d theta [C, D] and log p_m [C] of split `eval_split`
   int eval_split;
   int integ;                  // HTA_SPLIT_SYMMETRIC (plain leapfrog when M == 1) / HTA_SPLIT_RAND / HTA_SPLIT_KMID
+  int loss;                   // HTA_LOSS_REGRESSION / HTA_LOSS_BINARY_LOGITS
 };
 
 // Stage st of a trajectory: which split's gradient, the kick it scales and the drift that follows it.
@@ -37,6 +38,23 @@ __device__ __forceinline__ void split_stage(int integ, int M, int L, int st, T e
   else dr = (s2 == M - 1 || s2 == 2 * M - 1) ? (T)0 : eps / (T)((M - 1) * 2);
 }
 __host__ __device__ inline int split_stage_count(int integ, int M, int L) { return (integ == HTA_SPLIT_SYMMETRIC && M == 1) ? L + 1 : L * 2 * M; }
+
+// The likelihood of one point (S:1170-1184) as (delta, e): delta = d log-lik / d f and e with log-lik = -1/2 tau_out e, so that both
+// kernels keep ONE accumulation (sum of e) and ONE scaling whatever the likelihood.
+//   regression:        r = f - y; delta = -tau_out r;               e = r^2
+//   Bernoulli, logits: delta = -tau_out (sigmoid(f) - y);           e = 2 (softplus(f) - y f)
+template <typename T> __device__ __forceinline__ void mlp_point_loss(int loss, T f, T y, T tau_out, T& delta, T& e) {
+  if (loss == HTA_LOSS_BINARY_LOGITS) {
+    const T ex = exp(-fabs(f));                              // in (0, 1]: no overflow
+    const T sg = f >= (T)0 ? (T)1 / ((T)1 + ex) : ex / ((T)1 + ex);
+    delta = -tau_out * (sg - y);
+    e = (T)2 * (fmax(f, (T)0) - y * f + log1p(ex));
+  } else {
+    const T r = f - y;
+    delta = -tau_out * r;
+    e = r * r;
+  }
+}
 
 extern int g_mlp_valu;                                        // tuning key "mlp_valu": 1 = never take the MFMA kernel
 bool mlp_mfma_eligible(const MlpArgs<float>& a);

@@ -156,10 +156,10 @@ HTA_UNROLL(HTA_UNR)
       }
       const T out = slice_sum<RS>(acc.x + acc.y) + w.b2;
       if (part == 0) {
-        const T r = out - Ys[lo + i];
-        const T d = -a.tau_out * r;
+        T d, e;
+        mlp_point_loss<T>(a.loss, out, Ys[lo + i], a.tau_out, d, e);
         dv[i] = d;
-        sse += r * r; sd += d;
+        sse += e; sd += d;
       }
     }
     HTA_TICK(4);
@@ -493,6 +493,7 @@ template <typename T> int mlp_hmc(const MlpArgs<T>& a, hipStream_t s) {
   HTA_REQUIRE(a.n_in >= 1 && a.n_in <= 32, "hta_mlp_hmc: input width %d not in [1, 32]", a.n_in);
   HTA_REQUIRE(a.H >= 1 && a.H <= 1024, "hta_mlp_hmc: hidden width %d not in [1, 1024]", a.H);
   HTA_REQUIRE(a.act >= 0 && a.act <= 2, "hta_mlp_hmc: unknown activation %d", a.act);
+  HTA_REQUIRE(a.loss == HTA_LOSS_REGRESSION || a.loss == HTA_LOSS_BINARY_LOGITS, "hta_mlp_hmc: unknown loss kind %d", a.loss);
   HTA_REQUIRE(a.M >= 1 && a.Nb >= 1 && (int64_t)a.M * a.Nb <= a.N, "hta_mlp_hmc: M=%d splits of Nb=%d points exceed N=%d", a.M, a.Nb, a.N);
   HTA_REQUIRE(a.mass_kind == HTA_MASS_NONE || (a.mass_kind == HTA_MASS_DIAG && a.inv_mass && a.mass_factor),
               "hta_mlp_hmc: only identity / diagonal inv_mass are supported natively");
@@ -517,7 +518,7 @@ template <typename T> int mlp_hmc(const MlpArgs<T>& a, hipStream_t s) {
 
 extern "C" {
 #define HTA_DEFINE_MLP(SUF, T)                                                                                    \
-  int hta_mlp_hmc_sample_##SUF(T* theta, const T* theta_init, int64_t C, int n_in, int H, int act, const T* X,     \
+  int hta_mlp_hmc_sample_##SUF(T* theta, const T* theta_init, int64_t C, int n_in, int H, int act, int loss_kind, const T* X, \
                                const T* Y, int N, int M, int Nb, const T* tau4, T tau_out, T prior_scale,           \
                                int mass_kind, const T* inv_mass, const T* mass_factor, int integrator, int L,      \
                                T eps, int n_traj, int traj_offset, int burn, uint64_t seed, uint64_t chain_offset, \
@@ -527,18 +528,18 @@ extern "C" {
     hta::MlpArgs<T> a{theta, theta_init, C, n_in, H, act, X, Y, N, M, Nb, {tau4[0], tau4[1], tau4[2], tau4[3]},     \
                       tau_out, prior_scale, mass_kind, inv_mass, mass_factor, L, eps, n_traj, traj_offset, burn,    \
                       seed, chain_offset, samples, reject_count, H_old, H_new, accept, nullptr, nullptr, 0,         \
-                      integrator};                                                                                  \
+                      integrator, loss_kind};                                                                       \
     if (n_traj <= 0) return HTA_OK;                                                                                 \
     return hta::mlp_hmc<T>(a, (hipStream_t)stream);                                                                 \
   }                                                                                                                 \
-  int hta_mlp_logp_grad_##SUF(const T* theta, int64_t C, int n_in, int H, int act, const T* X, const T* Y, int N,   \
+  int hta_mlp_logp_grad_##SUF(const T* theta, int64_t C, int n_in, int H, int act, int loss_kind, const T* X, const T* Y, int N, \
                               int M, int Nb, int split, const T* tau4, T tau_out, T prior_scale, T* grad_out,       \
                               T* logp_out, void* stream) {                                                          \
     if (!tau4) { hta::set_error("hta_mlp_logp_grad: tau4 is NULL"); return HTA_ERR_INVALID; }                       \
     hta::MlpArgs<T> a{const_cast<T*>(theta), nullptr, C, n_in, H, act, X, Y, N, M, Nb,                              \
                       {tau4[0], tau4[1], tau4[2], tau4[3]}, tau_out, prior_scale, HTA_MASS_NONE, nullptr, nullptr,  \
                       0, (T)0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, grad_out, logp_out,      \
-                      split, HTA_SPLIT_SYMMETRIC};                                                                  \
+                      split, HTA_SPLIT_SYMMETRIC, loss_kind};                                                       \
     return hta::mlp_hmc<T>(a, (hipStream_t)stream);                                                                 \
   }
 HTA_DEFINE_MLP(f32, float)

@@ -142,8 +142,9 @@ struct MfmaChain {
           f += (tt + 2 < NU) ? v2 : 0.0f;
           f += (tt + 3 < NU) ? v3 : 0.0f;
         }
-        const float r = f - Ys[c0 + i];
-        rbuf[i] = (i < cnt) ? (GRAD ? -a.tau_out * r : r) : 0.0f;
+        float dl_, e_;
+        mlp_point_loss<float>(a.loss, f, Ys[c0 + i], a.tau_out, dl_, e_);
+        rbuf[i] = (i < cnt) ? (GRAD ? dl_ : e_) : 0.0f;                  // GRAD: delta_p; else the point's e (log-lik = -1/2 tau_out sum e)
       }
       HTA_TICK(3);
       __syncthreads();
@@ -169,7 +170,7 @@ struct MfmaChain {
           gacc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[(16 * pt + 3) * INP], bop[3], gacc1, 0, 0, 0);
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) ssev[e] = fmaf(dl[e], dl[e], ssev[e]);
+          for (int e = 0; e < 4; ++e) ssev[e] += dl[e];
         }
       }
     }

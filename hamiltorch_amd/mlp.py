@@ -1,7 +1,8 @@
 """Native engines for the Bayesian-MLP closures built by ``bnn.define_model_log_prob`` (S:1093-1258).
 
 A closure carries ``_hta_spec`` (dims, activation, data, precisions) when the model is
-``Sequential(Linear, act, Linear)`` with a scalar regression output; ``sample`` then runs the
+``Sequential(Linear, act, Linear)`` with one output and a Gaussian ('regression') or Bernoulli-with-logits
+('binary_class_linear_output') likelihood; ``sample`` then runs the
 whole (split-)HMC trajectory loop in ``csrc/mlp_hmc.hip`` instead of calling back into torch.
 Anything else falls back to the generic-callback path.
 """
@@ -21,8 +22,8 @@ def _common_spec(fns):
         return None
     nb = s0["X"].shape[0]
     for s in specs[1:]:
-        if (s["dims"], s["act"], s["tau_list"], s["tau_out"], s["prior_scale"]) != \
-                (s0["dims"], s0["act"], s0["tau_list"], s0["tau_out"], s0["prior_scale"]) or s["X"].shape[0] != nb:
+        if (s["dims"], s["act"], s["tau_list"], s["tau_out"], s["prior_scale"], s["loss"]) != \
+                (s0["dims"], s0["act"], s0["tau_list"], s0["tau_out"], s0["prior_scale"], s0["loss"]) or s["X"].shape[0] != nb:
             return None
     return specs
 
@@ -39,6 +40,7 @@ class _MLPEngine:
                 s0 = specs[0]
                 self.n_in, self.H = s0["dims"][0], s0["dims"][1]
                 self.act, self.tau, self.tau_out, self.prior_scale = s0["act"], s0["tau_list"], s0["tau_out"], s0["prior_scale"]
+                self.loss = s0["loss"]
                 self.M, self.Nb = len(specs), s0["X"].shape[0]
                 self._fb = None
 
@@ -62,7 +64,7 @@ class _MLPEngine:
                         _abi.mlp_hmc_sample(self.cur, self.theta0, self.n_in, self.H, self.act, self.X, self.Y, self.M,
                                             self.Nb, self.tau, self.tau_out, self.prior_scale, self.kind, self.im, self.mf,
                                             L, eps, min(step, n0 + count - start), start, self.burn, self.seed, self.off,
-                                            self.samples, self.rejected, H_old, H_new, integrator=self.integrator)
+                                            self.samples, self.rejected, H_old, H_new, integrator=self.integrator, loss=self.loss)
                     except _abi.InvalidArguments:
                         # the kernels stage the whole data set in LDS (csrc/mlp_hmc.hip: "do not fit the LDS staging"); the
                         # reference works for any N.  Arguments are validated before anything is launched, so nothing ran:

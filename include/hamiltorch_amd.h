@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HTA_ABI_VERSION 2
+#define HTA_ABI_VERSION 3
 
 #define HTA_OK 0
 #define HTA_ERR_INVALID (-1)   /* bad argument                           */
@@ -254,11 +254,14 @@ int hta_rmhmc_gaussian_sample_f64(double* theta, const double* theta_init, const
                                   void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Fused (split-)HMC for a one-hidden-layer Bayesian MLP, regression likelihood (BASELINE config 4):
+ * Fused (split-)HMC for a one-hidden-layer Bayesian MLP with one output (BASELINE config 4):
  * the closures of define_model_log_prob / define_split_model_log_prob (S:1093-1258) and the
  * SPLITTING integrator (S:499-540; M == 1: plain leapfrog S:281-302) for C chains, one workgroup
  * per chain.  theta[C, D], D = H*n_in + 2H + 1 in nn.Module.parameters() order (W1, b1, W2, b2).
  *   X[N, n_in], Y[N]: the M splits are rows [m*Nb, (m+1)*Nb).  act: 0 relu, 1 tanh, 2 sigmoid.
+ *   loss_kind: HTA_LOSS_REGRESSION  -1/2 tau_out sum (f - y)^2                         (model_loss 'regression', S:1184)
+ *              HTA_LOSS_BINARY_LOGITS -tau_out sum [softplus(f) - y f], y in [0, 1]      ('binary_class_linear_output':
+ *                                    binary_cross_entropy_with_logits, reduction 'sum', S:1172)
  *   tau4: HOST pointer to the 4 prior precisions (W1, b1, W2, b2); prior_scale divides the prior of
  *   every split closure (S:1199): num_splits for sample_split_model, 1 for sample_model.
  *   mass_kind: HTA_MASS_NONE or HTA_MASS_DIAG (flat [D] operands).
@@ -266,26 +269,28 @@ int hta_rmhmc_gaussian_sample_f64(double* theta, const double* theta_init, const
  *   (S:547-566; the subset order is a Philox permutation per (seed, trajectory), M <= 64),
  *   HTA_SPLIT_KMID = SPLITTING_KMID (S:572-596, M >= 2).
  * Remaining arguments as hta_hmc_gaussian_sample. */
+#define HTA_LOSS_REGRESSION 0
+#define HTA_LOSS_BINARY_LOGITS 1
 #define HTA_SPLIT_SYMMETRIC 0
 #define HTA_SPLIT_RAND 1
 #define HTA_SPLIT_KMID 2
-int hta_mlp_hmc_sample_f32(float* theta, const float* theta_init, int64_t C, int n_in, int H, int act,
+int hta_mlp_hmc_sample_f32(float* theta, const float* theta_init, int64_t C, int n_in, int H, int act, int loss_kind,
                            const float* X, const float* Y, int N, int M, int Nb, const float* tau4, float tau_out,
                            float prior_scale, int mass_kind, const float* inv_mass, const float* mass_factor,
                            int integrator, int L, float eps, int n_traj, int traj_offset, int burn, uint64_t seed,
                            uint64_t chain_offset, float* samples, int32_t* reject_count, float* H_old,
                            float* H_new, uint8_t* accept, void* stream);
-int hta_mlp_hmc_sample_f64(double* theta, const double* theta_init, int64_t C, int n_in, int H, int act,
+int hta_mlp_hmc_sample_f64(double* theta, const double* theta_init, int64_t C, int n_in, int H, int act, int loss_kind,
                            const double* X, const double* Y, int N, int M, int Nb, const double* tau4,
                            double tau_out, double prior_scale, int mass_kind, const double* inv_mass,
                            const double* mass_factor, int integrator, int L, double eps, int n_traj,
                            int traj_offset, int burn, uint64_t seed, uint64_t chain_offset, double* samples,
                            int32_t* reject_count, double* H_old, double* H_new, uint8_t* accept, void* stream);
 /* value and gradient of ONE split closure (S:1145-1199) for every chain: grad_out[C, D], logp_out[C]. */
-int hta_mlp_logp_grad_f32(const float* theta, int64_t C, int n_in, int H, int act, const float* X, const float* Y,
+int hta_mlp_logp_grad_f32(const float* theta, int64_t C, int n_in, int H, int act, int loss_kind, const float* X, const float* Y,
                           int N, int M, int Nb, int split, const float* tau4, float tau_out, float prior_scale,
                           float* grad_out, float* logp_out, void* stream);
-int hta_mlp_logp_grad_f64(const double* theta, int64_t C, int n_in, int H, int act, const double* X,
+int hta_mlp_logp_grad_f64(const double* theta, int64_t C, int n_in, int H, int act, int loss_kind, const double* X,
                           const double* Y, int N, int M, int Nb, int split, const double* tau4, double tau_out,
                           double prior_scale, double* grad_out, double* logp_out, void* stream);
 

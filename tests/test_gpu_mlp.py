@@ -262,3 +262,69 @@ def test_split_kinds_leapfrog_api_vs_reference_fixture(ht, golden, kind):
         a, b = O.split_leapfrog(g["theta"][None], g["p0"][None], [t.grad for t in otg], 3, float(eps), np.ones_like(g["theta"]), "rand", perm)
         np.testing.assert_allclose(got_t[-1], a[0], rtol=3e-5, atol=3e-5)
         np.testing.assert_allclose(got_p[-1], b[0], rtol=3e-4, atol=3e-4)
+
+
+# ---- Bernoulli-with-logits likelihood in the native kernels (model_loss='binary_class_linear_output', S:1172) -------------
+@pytest.mark.parametrize("route", ["mfma", "valu", "f64"])
+def test_native_binary_logits_likelihood(ht, golden, route):
+    """hta_mlp_logp_grad with HTA_LOSS_BINARY_LOGITS: the reference's fixture (Linear(4,6)-Tanh-Linear(6,1), tau_out = 2) and
+    the oracle on random batches (several shapes, splits, large logits), on the MFMA kernel, the VALU kernel and in fp64."""
+    from hamiltorch_amd import _abi
+    dtype = torch.float64 if route == "f64" else torch.float32
+    npdt = np.float64 if route == "f64" else np.float32
+    tol = 1e-10 if route == "f64" else 3e-4
+    _abi.set_tuning("mlp_valu", 1 if route == "valu" else 0)
+    try:
+        g = golden("losses")
+        X = torch.tensor(g["binary_X"], dtype=dtype, device=dev()); Y = torch.tensor(g["binary_Y"].reshape(-1), dtype=dtype, device=dev())
+        th = torch.tensor(g["binary_theta"][None], dtype=dtype, device=dev())
+        grad = torch.empty_like(th); lp = torch.empty(1, dtype=dtype, device=dev())
+        _abi.mlp_logp_grad(th, 4, 6, "tanh", X, Y, 1, 10, 0, list(g["binary_tau_list"]), 2.0, 1.0, grad, lp, loss="binary_class_linear_output")
+        np.testing.assert_allclose(lp.cpu().numpy(), g["binary_logp"], rtol=2e-5)
+        np.testing.assert_allclose(grad[0].cpu().numpy(), g["binary_grad"], rtol=3e-4, atol=3e-5)
+        for n_in, H, act, N, M, scale in [(3, 5, "relu", 12, 3, 0.4), (8, 100, "relu", 400, 4, 0.4), (5, 64, "sigmoid", 64, 1, 0.4), (2, 17, "tanh", 30, 2, 30.0)]:
+            rng = np.random.default_rng(H)
+            Xn = rng.standard_normal((N, n_in)).astype(npdt); Yn = (rng.uniform(size=(N, 1)) < 0.5).astype(npdt)
+            D = H * n_in + 2 * H + 1
+            C, Nb = 6, N // M
+            theta = (scale * rng.standard_normal((C, D))).astype(npdt)          # scale 30: logits of order +-100 (no overflow)
+            tau = [1.0, 1.5, 2.0, 2.5]
+            thd = torch.tensor(theta, device=dev()); Xd = torch.tensor(Xn, device=dev()); Yd = torch.tensor(Yn.reshape(-1), device=dev())
+            for m in range(M):
+                gd = torch.empty_like(thd); lpd = torch.empty(C, dtype=dtype, device=dev())
+                _abi.mlp_logp_grad(thd, n_in, H, act, Xd, Yd, M, Nb, m, tau, 3.0, float(M), gd, lpd, loss="binary_class_linear_output")
+                o = O.MLPRegressionTarget([n_in, H, 1], Xn[m * Nb:(m + 1) * Nb], Yn[m * Nb:(m + 1) * Nb], tau, 3.0, float(M), act,
+                                          loss="binary_class_linear_output")
+                wl, wg = o.logp_and_grad(theta.astype(np.float64))
+                np.testing.assert_allclose(lpd.cpu().numpy(), wl, rtol=tol, atol=tol * max(1.0, np.abs(wl).max()))
+                np.testing.assert_allclose(gd.cpu().numpy(), wg, rtol=tol, atol=tol * max(1.0, np.abs(wg).max()))
+    finally:
+        _abi.set_tuning("mlp_valu", 0)
+
+
+def test_sample_model_binary_classifier_native_vs_oracle_and_generic(ht):
+    """sample_model(model_loss='binary_class_linear_output') on a one-hidden-layer classifier runs in the native kernel
+    (one launch, no callbacks) and reproduces the oracle chain by chain; native=False (torch callbacks) agrees."""
+    from hamiltorch_amd import _abi
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(3, 9), torch.nn.Tanh(), torch.nn.Linear(9, 1)).to(dev())
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn(40, 3, generator=g); Y = (X.sum(1, keepdim=True) + 0.3 * torch.randn(40, 1, generator=g) > 0).float()
+    tau_list = torch.tensor([1.0, 1.5, 2.0, 2.5])
+    D = sum(p.numel() for p in net.parameters())
+    C, NS, L, eps, seed = 32, 8, 5, 2e-2, 21
+    th0 = (0.3 * O.philox_normals(seed, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32)
+    kw = dict(model_loss="binary_class_linear_output", num_samples=NS, num_steps_per_sample=L, step_size=eps, tau_out=1.0,
+              tau_list=tau_list, verbose=False, seed=seed)
+    _abi.set_tuning("profile", 1)
+    out = ht.sample_model(net, X, Y, torch.tensor(th0, device=dev()), **kw)
+    torch.cuda.synchronize()
+    _, launches = _abi.profile_collect()
+    _abi.set_tuning("profile", 0)
+    assert launches == 1, launches
+    o = O.MLPRegressionTarget([3, 9, 1], X.numpy(), Y.numpy(), tau_list.numpy(), 1.0, 1.0, "tanh", loss="binary_class_linear_output")
+    ref, info = O.sample_hmc(o, th0, NS, L, eps, 0, None, O.PhiloxDraws(seed, np.arange(C)))
+    _cmp(out, ref, 5e-4)
+    out_g = ht.sample_model(net, X, Y, torch.tensor(th0, device=dev()), native=False, **kw)
+    _cmp(out_g, ref, 5e-4)
+    assert 0.3 < info["acc_rate"].mean() <= 1.0

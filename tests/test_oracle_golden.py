@@ -572,3 +572,14 @@ def test_torch_port_cfg2_bit_identical(golden):
     assert got.shape == g["e2e_samples"].shape
     assert np.array_equal(got, g["e2e_samples"])
     assert acc == float(g["e2e_acc"])
+
+
+def test_mlp_binary_logits_likelihood_vs_reference_fixture(golden):
+    """define_model_log_prob(model_loss='binary_class_linear_output') (S:1172) on Linear(4,6)-Tanh-Linear(6,1), tau_out = 2:
+    value and gradient of the oracle's Bernoulli-with-logits likelihood against the unmodified reference (tests/golden/losses.npz)."""
+    g = golden("losses")
+    o = O.MLPRegressionTarget([4, 6, 1], g["binary_X"], g["binary_Y"], g["binary_tau_list"], 2.0, 1.0, "tanh",
+                              loss="binary_class_linear_output")
+    lp, gr = o.logp_and_grad(g["binary_theta"][None].astype(np.float64))
+    np.testing.assert_allclose(lp, g["binary_logp"], rtol=2e-6)
+    np.testing.assert_allclose(gr[0], g["binary_grad"], rtol=2e-5, atol=2e-6)
