@@ -200,3 +200,50 @@ def test_bench_gpus_flag_launches_the_ranks_itself(ht):
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                          "--no-cpu-baseline"], env=env2, capture_output=True, text=True, timeout=300)
     assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)
+
+
+_SHARD_WORKER = r'''
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import hamiltorch_amd as ht
+from hamiltorch_amd import dist as hd
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+dev = torch.device("cuda:0")
+cov = torch.tensor([[1.0, 0.6, 0.2], [0.6, 2.0, 0.5], [0.2, 0.5, 0.5]], device=dev)
+t = ht.GaussianTarget(torch.zeros(3, device=dev), covariance=cov)
+C = 37                                                  # uneven blocks: 19 + 18
+init = (0.1 * torch.randn(C, 3, generator=torch.Generator().manual_seed(5))).to(dev)
+kw = dict(num_samples=30, num_steps_per_sample=7, step_size=0.3, burn=4, verbose=False, seed=99)
+rows = hd.sample_sharded(ht.sample, init, t, **kw)
+nuts, eps = hd.sample_sharded(ht.sample, init, t, sampler=ht.Sampler.HMC_NUTS, debug=2, desired_accept_rate=0.7,
+                              **dict(kw, step_size=0.02, burn=10))
+if rank == 0:
+    full = torch.stack(ht.sample(t, init, **kw))
+    nfull, neps = ht.sample(t, init, sampler=ht.Sampler.HMC_NUTS, debug=2, desired_accept_rate=0.7, **dict(kw, step_size=0.02, burn=10))
+    print(json.dumps({"equal": bool(torch.equal(torch.stack(rows), full)), "shape": list(torch.stack(rows).shape),
+                      "eps": eps, "eps_single": neps,
+                      "nuts_err": float((torch.stack(nuts) - torch.stack(nfull)).abs().max())}))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_sample_sharded_on_the_device_equals_single_process(ht, tmp_path):
+    """dist.sample_sharded with the real kernels: two ranks (gloo, sharing this box's one GPU) over 37 chains - uneven blocks -
+    reproduce the single-process sample() bit for bit (global chain ids key the RNG), and Sampler.HMC_NUTS adapts the same
+    step size on the all-reduced acceptance statistic (sum order aside)."""
+    script = tmp_path / "shard_worker.py"
+    script.write_text(_SHARD_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29600 + os.getpid() % 300), str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["equal"] and j["shape"] == [26, 37, 3], j
+    assert abs(j["eps"] - j["eps_single"]) <= 1e-6 * j["eps_single"], j
+    assert j["nuts_err"] < 1e-3, j
