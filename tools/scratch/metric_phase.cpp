@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 namespace hta {   // the symbols the two sources expect from the rest of the library
+int g_rmhmc_wide = 1;
 
 template <typename T> int metric_eval(const MetricArgsT<T>&, hipStream_t) { return 0; }
 }
