@@ -117,11 +117,33 @@ def update_model_params_in_place(model, params):
 
 # ---- many chains (U:385-405).  The reference runs one sample() per seed, serially or in a
 # ---- thread pool; here the same adapters exist, plus the on-device batched form. -------------
+_chain_lock = threading.Lock()
+
+
+def _accepts_seed(fn):
+    import inspect
+    try:
+        ps = inspect.signature(fn).parameters
+    except (TypeError, ValueError):
+        return False
+    return "seed" in ps or any(p.kind == p.VAR_KEYWORD for p in ps.values())
+
+
 def setup_chain(sampler, prior, kwargs):
+    """U:385-390.  The reference's chain seeds the GLOBAL generator and then samples from it, which is racy under
+    multi_chain(parallel=True) (threads interleave seeding and drawing).  Here seeding, the draw of params_init and the
+    derivation of the chain's Philox key happen under one lock and the key is handed to the sampler explicitly, so a chain's
+    result depends on its seed alone - serial, threaded or batched."""
+    takes_seed = _accepts_seed(sampler)
+
     def chain(seed):
-        set_random_seed(seed)          # torch.manual_seed(seed) in the reference (U:387)
-        params_init = prior()
-        return sampler(params_init=params_init, **kwargs)
+        kw = dict(kwargs)
+        with _chain_lock:
+            set_random_seed(seed)          # torch.manual_seed(seed) in the reference (U:387)
+            params_init = prior()
+            if takes_seed and kw.get("seed") is None:
+                kw["seed"] = next_stream_seed()
+        return sampler(params_init=params_init, **kw)
     chain._hta = (sampler, prior, kwargs)
     return chain
 

@@ -255,6 +255,28 @@ def test_multi_chain_adapters(ht):
     assert len(res_b) == 3 and len(res_b[0]) == 8 and res_b[2][0].shape == (3,)
     # same seed -> same params_init as the serial adapter
     assert torch.equal(res_b[1][0], res[1][0])
+    # values, not only shapes: the serial adapter IS sample() under set_random_seed(seed) with params_init = prior() ...
+    for k, seed in enumerate([1, 2, 3]):
+        ht.set_random_seed(seed)
+        init = prior()
+        want = ht.sample(log_prob_func=t, params_init=init, num_samples=8, num_steps_per_sample=3, step_size=0.3, verbose=False)
+        assert torch.equal(torch.stack(res[k]), torch.stack(want))
+        assert torch.equal(torch.stack(res_t[k]), torch.stack(want))       # the thread pool serialises on the sampling lock: same chains
+    # ... and the batched adapter is ONE sample() call over the stacked initial states under the first seed
+    inits = []
+    for seed in [1, 2, 3]:
+        torch.manual_seed(seed)
+        inits.append(prior())
+    ht.set_random_seed(1)
+    want_b = ht.sample(log_prob_func=t, params_init=torch.stack(inits), num_samples=8, num_steps_per_sample=3, step_size=0.3, verbose=False)
+    for c in range(3):
+        assert torch.equal(torch.stack(res_b[c]), torch.stack([row[c] for row in want_b]))
+    # every chain of the batch is a valid draw sequence of the target: pooled over a longer batched run the covariance is right
+    chain_l = ht.util.setup_chain(ht.sample, prior, dict(log_prob_func=t, num_samples=300, num_steps_per_sample=10, step_size=0.3, burn=50,
+                                                         verbose=False))
+    big = ht.util.multi_chain(chain_l, 2, list(range(64)), batched=True)
+    pooled = torch.stack([torch.stack(ch) for ch in big]).reshape(-1, 3).double().cpu().numpy()
+    np.testing.assert_allclose(np.cov(pooled.T), SIGMA3, rtol=0.15, atol=0.08)
 
 
 @pytest.mark.parametrize("D,mass", [(3, "none"), (5, "diag"), (4, "full")])
