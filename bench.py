@@ -636,6 +636,8 @@ def main():
                 out["cpu_baseline"] = cb
                 out["speedup_vs_cpu_baseline"] = res["value"] / cb["value"]          # against the `cores` the baseline used
                 out["speedup_vs_cpu_baseline_1core"] = res["value"] / (cb["value"] / max(1, cb.get("cores", 1)))
+                if cb.get("ess_per_sec"):                                              # the metric's second half: ESS/sec vs the CPU reference
+                    out["ess_per_sec_vs_cpu_baseline"] = res["ess_per_sec"] / cb["ess_per_sec"]
         if world == 1 and a.workload == "cfg2" and not a.no_secondary and a.chains is None and a.traj is None:
             del w
             torch.cuda.empty_cache()

@@ -169,12 +169,48 @@ def sample_split_model(model, train_loader, params_init, num_splits, model_loss=
                     desired_accept_rate=desired_accept_rate, store_on_GPU=store_on_GPU, verbose=verbose, **ext)
 
 
+#: how predict_model evaluated its closures so far (tests / diagnostics)
+predict_stats = {"batched": 0, "looped": 0}
+
+
+def _eval_all(f, samples, dev):
+    """(log_prob, output) of the predict-closure `f` for every sample: ONE batched evaluation over the stacked samples
+    (`torch.func.vmap`, in chunks that keep the activations under ~256 MB) instead of the reference's Python loop over samples
+    (S:1530-1552); a closure vmap cannot batch falls back to that loop.  Returns (list of log-probs, list of outputs)."""
+    S = len(samples)
+    if S == 0:
+        return [], []
+    flat = [t.to(dev) for t in samples]
+    if all(t.dim() == 1 and t.shape == flat[0].shape for t in flat):
+        try:
+            with torch.no_grad():
+                v0, o0 = f(flat[0])
+                per = max(1, int(o0.numel()) * 64)                       # rough activation footprint of one sample
+                chunk = max(1, min(S, (64 << 20) // per))
+                vs, os_ = [], []
+                for c0 in range(0, S, chunk):
+                    v, o = torch.func.vmap(f)(torch.stack(flat[c0:c0 + chunk]))
+                    vs.append(v); os_.append(o)
+                v = torch.cat(vs); o = torch.cat(os_)
+            predict_stats["batched"] += 1
+            return [v[k].reshape(v0.shape) for k in range(S)], [o[k] for k in range(S)]
+        except (RuntimeError, TypeError, ValueError, NotImplementedError) as e:
+            if isinstance(e, (torch.OutOfMemoryError, torch.AcceleratorError)):
+                raise
+    predict_stats["looped"] += 1
+    vs, os_ = [], []
+    for t in flat:
+        v, o = f(t)
+        vs.append(v); os_.append(o)
+    return vs, os_
+
+
 def predict_model(model, samples, x=None, y=None, test_loader=None, model_loss='multi_class_linear_output',
                   tau_out=1., tau_list=None, verbose=False):
-    """S:1468-1562: evaluate every sample; returns (stack(pred)[S, N, O], list of log-probs)."""
+    """S:1468-1562: evaluate every sample; returns (stack(pred)[S, N, O], list of log-probs).  All samples are evaluated in
+    one batched pass on the device (`_eval_all`)."""
     shapes, sizes, tau_list = _shapes_and_tau(model, tau_list)
     dev = samples[0].device
-    preds, lps = [], []
     with torch.no_grad():
         if test_loader is not None and (x is None or isinstance(test_loader, torch.utils.data.DataLoader)):
             # S:1520-1541: one closure per batch through define_split_model_log_prob, i.e. the prior divided by the number of
@@ -188,22 +224,19 @@ def predict_model(model, samples, x=None, y=None, test_loader=None, model_loss='
                 num_batches = len(test_loader)
             fns = define_split_model_log_prob(model, model_loss, test_loader, num_batches, sizes, shapes, tau_list, tau_out,
                                               predict=True, device=dev, verbose=verbose)
-            for s in samples:
-                outs, lp = [], 0.
-                for f in fns:
-                    v, o = f(s.to(dev))
-                    lp = lp + v.cpu()                                              # S:1536
-                    outs.append(o)
-                preds.append(torch.cat(outs, 0))
+            per_batch = [_eval_all(f, samples, dev) for f in fns]
+            preds, lps = [], []
+            for k in range(len(samples)):
+                lp = 0.
+                for vs, _ in per_batch:
+                    lp = lp + vs[k].cpu()                                          # S:1536
+                preds.append(torch.cat([os_[k] for _, os_ in per_batch], 0))
                 lps.append(lp)
         elif x is not None and y is not None:
             if x.device != dev:                                                    # S:1544-1545
                 raise RuntimeError('x on device: {} and samples on device: {}'.format(x.device, dev))
             f = define_model_log_prob(model, model_loss, x, y, sizes, shapes, tau_list, tau_out, predict=True, device=dev)
-            for s in samples:
-                v, o = f(s)
-                preds.append(o)
-                lps.append(v)
+            lps, preds = _eval_all(f, samples, dev)
         else:
             raise RuntimeError('Val data not defined (i.e. arguments x, y, val_loader are all not defined)')   # S:1557
     return torch.stack(preds), lps

@@ -670,7 +670,7 @@ def _warm_eval(ht, P, X, m, alpha, jitter, seed, mode, want_g=True):
     return {k: v.cpu().numpy() for k, v in out.items()}
 
 
-@pytest.mark.parametrize("D,kind,alpha,jitter", [(3, "spd", 1e6, 1e-3), (10, "spd", 1e6, None), (16, "indef", 1.3, 1e-3), (31, "spd", 1e6, 1e-3),
+@pytest.mark.parametrize("D,kind,alpha,jitter", [(1, "spd", 1e6, 1e-3), (2, "indef", 1.3, 1e-2), (3, "spd", 1e6, 1e-3), (10, "spd", 1e6, None), (16, "indef", 1.3, 1e-3), (31, "spd", 1e6, 1e-3),
                                                  (64, "indef", 2.0, 1e-2), (100, "spd", 1e6, 1e-3), (100, "spd", 1e6, 0.3),
                                                  (101, "degenerate", 3.0, 1e-3), (112, "spd", 1e6, 1e-3), (9, "identity", 1e6, 1e-3)])
 def test_metric_mfma_kernel_equals_jacobi_kernel(ht, D, kind, alpha, jitter):

@@ -180,6 +180,10 @@ def test_model_loss_kinds_and_predict_model_match_reference_fixture(golden, name
     pred, lps = ht.predict_model(net, samples, test_loader=loader, model_loss=loss, tau_out=2.0, tau_list=tau_list)
     np.testing.assert_allclose(pred.numpy(), g[f"{name}_pred_loader"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(np.stack([t.numpy().reshape(-1) for t in lps]), g[f"{name}_pred_loader_lp"], rtol=1e-5, atol=1e-4)
+    before = dict(bnn.predict_stats)
+    ht.predict_model(net, samples, x=X, y=Y, model_loss=loss, tau_out=2.0, tau_list=tau_list)
+    assert bnn.predict_stats["batched"] == before["batched"] + 1 and bnn.predict_stats["looped"] == before["looped"], \
+        "predict_model fell back to the per-sample loop for model_loss=%r" % (loss,)
     with pytest.raises(RuntimeError):                                            # S:1557: no data at all
         ht.predict_model(net, samples)
     with pytest.raises(NotImplementedError):                                     # S:1190: unknown loss
