@@ -43,12 +43,17 @@ __host__ __device__ inline int split_stage_count(int integ, int M, int L) { retu
 // kernels keep ONE accumulation (sum of e) and ONE scaling whatever the likelihood.
 //   regression:        r = f - y; delta = -tau_out r;               e = r^2
 //   Bernoulli, logits: delta = -tau_out (sigmoid(f) - y);           e = 2 (softplus(f) - y f)
+// (the Bernoulli branch is OUT OF LINE: inlined, its exp / log1p sequences raise the register pressure of the sampler kernels,
+//  which run at a 128-register cap, for every likelihood - 4 % on BASELINE config 4)
+template <typename T> __device__ __attribute__((noinline)) void mlp_point_loss_binary(T f, T y, T tau_out, T& delta, T& e) {
+  const T ex = exp(-fabs(f));                              // in (0, 1]: no overflow
+  const T sg = f >= (T)0 ? (T)1 / ((T)1 + ex) : ex / ((T)1 + ex);
+  delta = -tau_out * (sg - y);
+  e = (T)2 * (fmax(f, (T)0) - y * f + log1p(ex));
+}
 template <typename T> __device__ __forceinline__ void mlp_point_loss(int loss, T f, T y, T tau_out, T& delta, T& e) {
   if (loss == HTA_LOSS_BINARY_LOGITS) {
-    const T ex = exp(-fabs(f));                              // in (0, 1]: no overflow
-    const T sg = f >= (T)0 ? (T)1 / ((T)1 + ex) : ex / ((T)1 + ex);
-    delta = -tau_out * (sg - y);
-    e = (T)2 * (fmax(f, (T)0) - y * f + log1p(ex));
+    mlp_point_loss_binary<T>(f, y, tau_out, delta, e);
   } else {
     const T r = f - y;
     delta = -tau_out * r;

@@ -142,9 +142,8 @@ struct MfmaChain {
           f += (tt + 2 < NU) ? v2 : 0.0f;
           f += (tt + 3 < NU) ? v3 : 0.0f;
         }
-        float dl_, e_;
-        mlp_point_loss<float>(a.loss, f, Ys[c0 + i], a.tau_out, dl_, e_);
-        rbuf[i] = (i < cnt) ? (GRAD ? dl_ : e_) : 0.0f;                  // GRAD: delta_p; else the point's e (log-lik = -1/2 tau_out sum e)
+        const float r = f - Ys[c0 + i];
+        rbuf[i] = (i < cnt) ? (GRAD ? -a.tau_out * r : r) : 0.0f;
       }
       HTA_TICK(3);
       __syncthreads();
@@ -170,7 +169,7 @@ struct MfmaChain {
           gacc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[(16 * pt + 3) * INP], bop[3], gacc1, 0, 0, 0);
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) ssev[e] += dl[e];
+          for (int e = 0; e < 4; ++e) ssev[e] = fmaf(dl[e], dl[e], ssev[e]);
         }
       }
     }
@@ -411,6 +410,9 @@ static size_t mfma_lds_bytes(const MlpArgs<float>& a, int NK, int NU, int* npad_
 }
 
 bool mlp_mfma_eligible(const MlpArgs<float>& a) {
+  // Gaussian likelihood only: the other likelihoods run on the VALU kernel (mlp_hmc.hip).  Their exp / log1p sequences - even
+  // out of line, even behind a call never taken - cost this kernel 2-4 % on BASELINE config 4 at its 128-register cap (measured).
+  if (a.loss != HTA_LOSS_REGRESSION) return false;
   if (a.n_in < 1 || a.n_in > 16 || a.H < 1 || a.H > 256) return false;
   if (!(a.mass_kind == HTA_MASS_NONE || a.mass_kind == HTA_MASS_DIAG)) return false;
   const int NK = (a.n_in + 3) / 4, NU = (a.H + 15) / 16;

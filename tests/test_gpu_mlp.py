@@ -268,7 +268,8 @@ def test_split_kinds_leapfrog_api_vs_reference_fixture(ht, golden, kind):
 @pytest.mark.parametrize("route", ["mfma", "valu", "f64"])
 def test_native_binary_logits_likelihood(ht, golden, route):
     """hta_mlp_logp_grad with HTA_LOSS_BINARY_LOGITS: the reference's fixture (Linear(4,6)-Tanh-Linear(6,1), tau_out = 2) and
-    the oracle on random batches (several shapes, splits, large logits), on the MFMA kernel, the VALU kernel and in fp64."""
+    the oracle on random batches (several shapes, splits, large logits) - the VALU kernel in fp32 (default route and forced:
+    the MFMA kernel serves the Gaussian likelihood only) and fp64."""
     from hamiltorch_amd import _abi
     dtype = torch.float64 if route == "f64" else torch.float32
     npdt = np.float64 if route == "f64" else np.float32
