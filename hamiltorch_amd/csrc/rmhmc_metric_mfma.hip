@@ -303,7 +303,7 @@ __device__ __attribute__((noinline)) void mfma_cholesky(int offG, int D, int DP,
   D = __builtin_amdgcn_readfirstlane(D); DP = __builtin_amdgcn_readfirstlane(DP); LD = __builtin_amdgcn_readfirstlane(LD);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
-  const int nt = DP / 16, k4 = (D + 3) / 4;
+  const int nt = DP / 16;
   for (int pb = 0; pb < nt; ++pb) {
     const int c0 = 16 * pb;
     __syncthreads();
