@@ -28,13 +28,15 @@
 #define HTA_RM_TIMING 0   // developer cycle counters (thread 0 of block 0): tools/scratch/rmhmc_time.py prints them
 #endif
 #if HTA_RM_TIMING
-__device__ unsigned long long hta_rm_dbg[8];
+__device__ unsigned long long hta_rm_dbg[16];
 extern "C" void hta_rm_dbg_read(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(hta_rm_dbg), sizeof(hta_rm_dbg)); }
+#define HTA_XTICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); xacc[k] += now_ - xlast; xlast = now_; } while (0)
 #define HTA_RTICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); ch.tacc[0] += now_ - ch.tlast; ch.tlast = now_; } while (0)
 #define HTA_MTICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[k] += now_ - tlast; tlast = now_; } while (0)
 #else
 #define HTA_RTICK(k) do {} while (0)
 #define HTA_MTICK(k) do {} while (0)
+#define HTA_XTICK(k) do {} while (0)
 #endif
 
 namespace hta {
@@ -882,13 +884,15 @@ __global__ __launch_bounds__(BNT) void rmhmc_batch_kernel(FusedArgs<float> a) {
 // =============================================================================================
 constexpr int QNC = 4, QLD = 116, QWV = 2, QNT = 64 * QWV, QK = 100;
 
+template <bool PAIRED>
 __global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
   typedef float T;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
   constexpr int MSZ = QNC * QLD;
   T* PM = lds; T* PMC = PM + MSZ; T* D0 = PMC + MSZ; T* D1 = D0 + MSZ; T* W0 = D1 + MSZ; T* W1 = W0 + MSZ; T* EV = W1 + MSZ;
-  T* red = EV + MSZ;                                      // [QWV][QNC][4]
+  T* V0 = EV + MSZ; T* V1 = V0 + MSZ;                     // the second half step's refinement vectors (half_pair)
+  T* red = V1 + MSZ;                                      // [QWV][QNC][4]
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cl = l & 3, blk = l >> 2;
   const int D = a.D;
   const int row0 = 64 * w + 4 * blk, arow = 64 * w + l;
@@ -908,8 +912,9 @@ __global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
     mu_r[e] = rok[e] ? a.mu[r] : 0.f;
     sd_r[e] = rok[e] ? a.S[(int64_t)r * D + r] : 0.f;
   }
-  for (int e = tid; e < 7 * MSZ + QWV * QNC * 4; e += QNT) lds[e] = 0.f;
+  for (int e = tid; e < 9 * MSZ + QWV * QNC * 4; e += QNT) lds[e] = 0.f;
   const T eh = 0.5f * a.eps;
+  const bool paired = PAIRED && a.K >= 1;
   const bool rany = row0 < QLD;                           // rows 116 .. 127 have no slot (and are >= D)
   const int own_off = cl * QLD + row0, b_off = cl * QLD;
   int dpar = 0;
@@ -996,6 +1001,88 @@ __global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) upd_x[e] += eh * xr[e];
   };
+  // TWO consecutive half steps, a then b, as K + 2 product phases instead of 2 (K + 1): the schedule of
+  // rmhmc_mfma4x4_kernel's half_pair (see there: same products, operands and summation order as two half_step calls).
+  //   a:  g1 -= eh P (X1 - mu)   X2 += eh (P + E_a)^-1 G2        b:  g2 -= eh P (X2 - mu)   X1 += eh (P + E_b)^-1 G1
+  auto half_pair = [&](uint32_t n, uint32_t suba, uint32_t subb, T (&X1)[4], T (&X2)[4], T (&g1)[4], T* G1, T (&g2)[4], T* G2, bool publish) {
+    T dv[4], wv[4], x0a[4], xra[4], x0b[4], xrb[4], ea[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dv[e] = rok[e] ? X1[e] - mu_r[e] : 0.f;
+    put4(D0, dv);
+    __syncthreads();
+    {                                                      // phase 1
+      bf4 Pd = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
+      prod2(Pa, D0, Sa, G2, Pd, xv);
+      jitter4(n, suba);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ea[e] = ev_r[e];
+        g1[e] -= eh * Pd[e];
+        x0a[e] = xv[e]; xra[e] = xv[e];
+        wv[e] = ea[e] * xv[e];
+      }
+      put4(G1, g1);
+      put4(W0, wv);
+    }
+    auto finish_a = [&]() {                                // a's solve is complete: its position update, and b's P operand
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        X2[e] += eh * xra[e];
+        dv[e] = rok[e] ? X2[e] - mu_r[e] : 0.f;
+      }
+      put4(D1, dv);
+    };
+    __syncthreads();
+    {                                                      // phase 2: a's refinement 0, b's S G1
+      bf4 ra = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
+      prod2(Sa, W0, Sa, G1, ra, xv);
+      jitter4(n, subb);                                     // ev_r: b's jitter from here on
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xra[e] = x0a[e] - ra[e];
+        x0b[e] = xv[e]; xrb[e] = xv[e];
+      }
+      if (a.K > 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wv[e] = ea[e] * xra[e];
+        put4(W1, wv);
+      } else finish_a();
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wv[e] = ev_r[e] * xrb[e];
+      put4(V0, wv);
+    }
+    for (int it = 1; it < a.K; ++it) {                     // phases 3 .. K+1: a's refinement it, b's refinement it - 1
+      const T* wa = (it & 1) ? W1 : W0;
+      T* wan = (it & 1) ? W0 : W1;
+      const T* wb = (it & 1) ? V0 : V1;
+      T* wbn = (it & 1) ? V1 : V0;
+      __syncthreads();
+      bf4 ra = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
+      prod2(Sa, wa, Sa, wb, ra, rb);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { xra[e] = x0a[e] - ra[e]; xrb[e] = x0b[e] - rb[e]; }
+      if (it + 1 < a.K) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wv[e] = ea[e] * xra[e];
+        put4(wan, wv);
+      } else finish_a();
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wv[e] = ev_r[e] * xrb[e];
+      put4(wbn, wv);
+    }
+    __syncthreads();
+    {                                                      // phase K+2: b's P d_b and its last refinement
+      const T* wb = ((a.K - 1) & 1) ? V1 : V0;
+      bf4 Pd = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
+      prod2(Pa, D1, Sa, wb, Pd, rb);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        g2[e] -= eh * Pd[e];
+        X1[e] += eh * (x0b[e] - rb[e]);
+      }
+      if (publish) put4(G2, g2);
+    }
+  };
   // three sums per chain over the rows, complete in every lane of the chain's column
   auto block_sums = [&](T (&v)[3]) {
 #pragma unroll
@@ -1021,7 +1108,7 @@ __global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
   };
   // H = -log p + D/2 log 2 pi + 1/2 log|G| + 1/2 m^T G^-1 m  (S:731)   (rmhmc_fused_kernel: hamiltonian, series branch)
   auto hamiltonian = [&](uint32_t n, uint32_t sub, const T (&X)[4], const T* m, const T (&mr)[4], T& H, T& logp) {
-    T* d = dpar ? D1 : D0;
+    T* d = (dpar && !paired) ? D1 : D0;                     // (paired: D1's last readers may still be in half_pair's last phase)
     dpar ^= 1;
     jitter4(n, sub);
     T dr[4];
@@ -1090,8 +1177,11 @@ __global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
       put4(PMC, spm);
       for (int lstep = 0; lstep < a.L; ++lstep) {           // S:427-461
         const uint32_t k0 = 2u + 8u * (uint32_t)lstep;
-        half_step(n, k0 + 1, sth, PMC, sthc, spm, PM);      // phi_A/2  S:429-430
-        half_step(n, k0 + 2, sthc, PM, sth, spmc, PMC);     // phi_B/2  S:432-433
+        if (paired) half_pair(n, k0 + 1, k0 + 2, sth, sthc, spm, PM, spmc, PMC, false);   // phi_A/2, phi_B/2  S:429-433 (the rotation publishes PMC)
+        else {
+          half_step(n, k0 + 1, sth, PMC, sthc, spm, PM);    // phi_A/2  S:429-430
+          half_step(n, k0 + 2, sthc, PM, sth, spmc, PMC);   // phi_B/2  S:432-433
+        }
         if (a.K == 0) __syncthreads();
 #pragma unroll
         for (int e = 0; e < 4; ++e) {                       // phi_C    S:447-450, sequential (Q1)
@@ -1105,8 +1195,11 @@ __global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
         }
         put4(PM, spm);
         put4(PMC, spmc);
-        half_step(n, k0 + 4, sthc, PM, sth, spmc, PMC);     // phi_B/2  S:454-455
-        half_step(n, k0 + 7, sth, PMC, sthc, spm, PM);      // phi_A/2  S:457-458
+        if (paired) half_pair(n, k0 + 4, k0 + 7, sthc, sth, spmc, PMC, spm, PM, true);    // phi_B/2, phi_A/2  S:454-458
+        else {
+          half_step(n, k0 + 4, sthc, PM, sth, spmc, PMC);   // phi_B/2  S:454-455
+          half_step(n, k0 + 7, sth, PMC, sthc, spm, PM);    // phi_A/2  S:457-458
+        }
       }
       hamiltonian(n, 2u + 8u * (uint32_t)a.L, sth, PM, spm, H1, lp1);   // S:989 (Q4)
       // ---- Metropolis test + bookkeeping (S:1000-1026, S:1045-1057)
@@ -1139,40 +1232,65 @@ __global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
 }
 
 // =============================================================================================
-// The four-chain kernel on ALL FOUR SIMDs of a CU (the default from 704 to 2048 chains; "rmhmc_mfma4_waves" = 2 keeps the
+// The four-chain kernel on ALL FOUR SIMDs of a CU (the default from 704 to 1024 chains; "rmhmc_mfma4_waves" = 2 keeps the
 // two-wave kernel above, its parity reference).
 //
 // At 1024 chains there are 256 groups of four chains - one workgroup per CU - and the two-wave kernel leaves two of the four
 // matrix pipes of every CU idle.  Splitting the 128 (padded) rows over four waves alone would not help: the 16-block
-// instruction covers 64 rows at a time.  But its 16 blocks are INDEPENDENT 4 x 4 outer products, so here blocks 0..7 take a
-// wave's 32 rows at the even contraction indices and blocks 8..15 the SAME rows at the odd ones: one instruction advances k
-// by two, a product is 50 (+2 padding) instructions per wave instead of 100, and the two partial sums of a row sit in lanes
-// l and l ^ 32 of one wave - combined by v_permlane32_swap, no LDS, no barrier.  Per lane: 2 x 52 matrix operands instead of
-// 2 x 100.  The vectors live in LDS with even and odd rows apart (16-byte operand reads per parity).  Both lane halves run
-// the element-wise code (duplicate state, one writer), which frees a trick for the jitter: a half step's Philox block is the
-// most expensive scalar piece (quarter-rate integer multiplies), and the two halves draw the blocks of TWO half steps at
-// once and swap them - two Philox passes per step instead of four.  Same streams, same update order, same barriers as the
-// two-wave kernel; the sums run over even k then odd k (results agree to rounding).
+// instruction covers 64 rows at a time.  But its 16 blocks are INDEPENDENT 4 x 4 outer products, so here eight blocks take a
+// wave's 32 rows at the even contraction indices and the other eight the SAME rows at the odd ones: one instruction advances
+// k by two, a product is 50 (+2 padding) instructions per wave instead of 100, and the two partial sums of a row sit in lanes
+// l and l ^ 8 of one wave - combined by a DPP row rotation, no LDS, no barrier.  Per lane: 2 x 52 matrix operands instead of
+// 2 x 100.  The vectors live in LDS with even and odd rows apart (16-byte operand reads per parity).  Both parities run the
+// element-wise code (duplicate state, one writer), which frees a trick for the jitter: a half step's Philox block is the
+// most expensive scalar piece (quarter-rate integer multiplies), and the two parities draw the blocks of TWO half steps at
+// once and exchange them - two Philox passes per step instead of four.
+//
+// Round 2 added three things (measured steps: profiles/README.md, r02j-r02n):
+//  * TRACK ("rmhmc_pair" = 1, default): y = P (theta - mu), S p and their copies' twins are carried along element-wise, so a
+//    half step keeps only its K refinement products and the two half steps of a pair solve side by side (see the comment at
+//    `T y[4], ...` below): 5 product phases and 12 products per step at K = 2 instead of 8 and 16.
+//  * the operand fetch through the B-broadcast modifier of the instruction (blgp 4..7, see mfma_from_group): parity and chain
+//    of a lane depend only on its position inside its 16-lane group, so each group fetches a different 16-byte chunk and one
+//    LDS read feeds 16 instructions instead of 4.
+//  * the non-TRACK path ("rmhmc_pair" = 0) is the schedule of the two-wave kernel: same streams, same update order, same
+//    barriers; the sums run over even k then odd k (results agree to rounding).
 // =============================================================================================
-// (XHL = 68, XLD = 140: the 8 operand segments a wave reads at once - 4 chains x 2 parities, 16 bytes each - start at banks
-//  0, 12, 24, 36 and 4, 16, 28, 40: no two share a bank; 64 / 128 would put all eight on the same four banks)
-constexpr int XNC = 4, XHL = 68, XLD = 2 * XHL + 4, XWV = 4, XNT = 64 * XWV, XKJ = 52, XQ = XKJ / 4;
+// (XHL = 68, XLD = 140: the 8 operand segments a group of 8 lanes reads at once - 4 chains x 16 bytes, two such groups per
+//  parity - start at banks 0, 12, 24, 36 (+4 for the odd parity): no two share a bank; 64 / 128 would put them on the same four)
+constexpr int XNC = 4, XHL = 68, XLD = 2 * XHL + 4, XWV = 4, XNT = 64 * XWV, XKJ = 52, XQ = XKJ / 4, XSQ = (XQ + 3) / 4, XBUF = 16;
 
-__device__ __forceinline__ float other_half(float h, bool upper) {    // the value lane l ^ 32 holds
-  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, h), false, false);
-  return __builtin_bit_cast(float, upper ? r[0] : r[1]);
+// lane l ^ 8's value (the same rows at the other contraction parity): a DPP rotation inside the 16-lane row
+__device__ __forceinline__ float other_parity(float h) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, h), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+}
+// the 16-block product with the B operand of ALL four 16-lane groups taken from group S (blgp 4 + S; semantics probed on
+// gfx950 by tools/scratch/blgp_probe.cpp)
+template <int S> __device__ __forceinline__ bf4 mfma_from_group(float av, float bv, bf4 c) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, c, 0, 0, 4 + S);
+}
+template <int... I, typename F> __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
 }
 
+template <bool TRACK>
 __global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) {
   typedef float T;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
   constexpr int MSZ = XNC * XLD;
   T* PM = lds; T* PMC = PM + MSZ; T* D0 = PMC + MSZ; T* D1 = D0 + MSZ; T* W0 = D1 + MSZ; T* W1 = W0 + MSZ; T* EV = W1 + MSZ;
-  T* red = EV + MSZ;                                      // [XWV][XNC][4]
-  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cl = l & 3, blk = l >> 2;
-  const int kpar = blk >> 3, rb = blk & 7;
-  const bool upper = kpar != 0;
+  T* DC = EV + MSZ;                                       // tracked products: theta_c - mu (D1: theta - mu)
+  T* WS = DC + MSZ;                                       // tracked products: 2 pairs x 2 solves x 2 refinement vectors
+  T* red = WS + 8 * MSZ;                                  // [XWV][XNC][4]
+  // lane bits: [1:0] chain, [2] low bit of the row block, [3] contraction parity, [5:4] 16-lane group = high bits of the row
+  // block.  The parity and the chain are functions of the lane's position INSIDE its 16-lane group, so a group's B operand
+  // serves all four groups (mfma_from_group): each group fetches a different 16-byte chunk of the vectors and one LDS read
+  // feeds 16 matrix instructions instead of 4 - with every lane fetching its own copy of every chunk the four waves' reads
+  // (1 KB per instruction) kept the LDS port busy 64 of every 67 clocks of matrix work.
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cl = l & 3, grp = l >> 4;
+  const int kpar = (l >> 3) & 1, rb = 2 * grp + ((l >> 2) & 1);
+  const bool upper = kpar != 0, lead = (l >> 2) == 0;
   const int D = a.D;
   const int row0 = 32 * w + 4 * rb, arow = row0 + cl;     // this lane OWNS rows row0..row0+3 of chain cl and SUPPLIES matrix row arow
   T Sa[XKJ], Pa[XKJ];
@@ -1192,10 +1310,13 @@ __global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) 
     mu_r[e] = rok[e] ? a.mu[r] : 0.f;
     sd_r[e] = rok[e] ? a.S[(int64_t)r * D + r] : 0.f;
   }
-  for (int e = tid; e < 7 * MSZ + XWV * XNC * 4; e += XNT) lds[e] = 0.f;
+  for (int e = tid; e < XBUF * MSZ + XWV * XNC * 4; e += XNT) lds[e] = 0.f;
   const T eh = 0.5f * a.eps;
+#if HTA_RM_TIMING
+  unsigned long long xacc[16] = {0}, xlast = 0;
+#endif
   const int own_off = cl * XLD + (row0 >> 1);             // rows row0, row0+2 -> even half; row0+1, row0+3 -> odd half
-  const int b_off = cl * XLD + kpar * XHL;
+  const int b_off = cl * XLD + kpar * XHL + 4 * grp;      // this group's chunk of a super-chunk of four
   int dpar = 0;
   T ev_r[4] = {0.f, 0.f, 0.f, 0.f};
   uint64_t chain = 0;
@@ -1226,36 +1347,54 @@ __global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) 
     jitter_raw(n, upper ? subB : subA, mine);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const T oth = other_half(mine[e], upper);
+      const T oth = other_parity(mine[e]);
       eA[e] = upper ? oth : mine[e];
       eB[e] = upper ? mine[e] : oth;
     }
   };
-  auto chunk = [&](const T* X, int q) { return *reinterpret_cast<const bf4*>(X + b_off + 4 * q); };
-  auto both = [&](bf4& acc) {
+  // super-chunk Q of a vector: 16 contraction indices of this lane's parity, 4 per 16-lane group
+  auto fetch = [&](const T* X, bf4 (&c)[XSQ]) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] += other_half(acc[e], upper);
+    for (int Q = 0; Q < XSQ; ++Q) c[Q] = *reinterpret_cast<const bf4*>(X + b_off + 16 * Q);
   };
-  // two products with one pass over k: acc1 = A1 X1, acc2 = A2 X2 (two independent accumulator chains)
-  // One wave per SIMD: nothing else hides an LDS round trip, so the operand chunks (4 values of k per 16-byte read) are
-  // fetched two chunks ahead of their use.  (Requesting all 13 chunks of a vector up front was measured 9 % slower:
-  // profiles/r02e_mfma4_waves_ab.txt.)
-  auto prod2 = [&](const T (&A1)[XKJ], const T* X1, const T (&A2)[XKJ], const T* X2, bf4& acc1, bf4& acc2) {
-    bf4 c1 = chunk(X1, 0), c2 = chunk(X2, 0), n1 = chunk(X1, 1), n2 = chunk(X2, 1);
+  auto both = [&](bf4& acc) {                                // lanes l and l ^ 8 both end with (even k) + (odd k)
 #pragma unroll
-    for (int q = 0; q < XQ; ++q) {
-      bf4 f1 = n1, f2 = n2;
-      if (q + 2 < XQ) { f1 = chunk(X1, q + 2); f2 = chunk(X2, q + 2); }
-      __builtin_amdgcn_sched_barrier(0);                    // (the scheduler otherwise sinks the reads next to their use)
+    for (int e = 0; e < 4; ++e) acc[e] += other_parity(acc[e]);
+  };
+  // two products with one pass over k: acc1 = A1 X1, acc2 = A2 X2 (two independent accumulator chains); the four reads of
+  // each vector are issued up front (one wave per SIMD: nothing else hides an LDS round trip)
+  auto prod2 = [&](const T (&A1)[XKJ], const T* X1, const T (&A2)[XKJ], const T* X2, bf4& acc1, bf4& acc2) {
+    bf4 c1[XSQ], c2[XSQ];
+    fetch(X1, c1);
+    fetch(X2, c2);
+    __builtin_amdgcn_sched_barrier(0);                      // (the scheduler otherwise sinks the reads next to their use)
+    static_for(std::make_integer_sequence<int, XQ>{}, [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1[4 * q + u], c1[u], acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(A2[4 * q + u], c2[u], acc2, 0, 0, 0);
+        acc1 = mfma_from_group<q % 4>(A1[4 * q + u], c1[q / 4][u], acc1);
+        acc2 = mfma_from_group<q % 4>(A2[4 * q + u], c2[q / 4][u], acc2);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      c1 = n1; c2 = n2; n1 = f1; n2 = f2;
-    }
+    });
     both(acc1); both(acc2);
+  };
+  // one product on two accumulator chains (k in the order 0 2 | 1 3 of every chunk, as the two-wave kernel sums it)
+  auto prod1 = [&](const T (&A1)[XKJ], const T* X1, bool squared, bf4& acc) {
+    bf4 c1[XSQ], sb = {0.f, 0.f, 0.f, 0.f};
+    fetch(X1, c1);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for(std::make_integer_sequence<int, XQ>{}, [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+#pragma unroll
+      for (int u = 0; u < 4; u += 2) {
+        const T a0 = A1[4 * q + u], a1 = A1[4 * q + u + 1];
+        acc = mfma_from_group<q % 4>(squared ? a0 * a0 : a0, c1[q / 4][u], acc);
+        sb = mfma_from_group<q % 4>(squared ? a1 * a1 : a1, c1[q / 4][u + 1], sb);
+      }
+    });
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += sb[e];
+    both(acc);
   };
   // x = (P + diag(e))^-1 m continued from x0 = S m (rmhmc_fused_kernel: refine)
   auto refine = [&](const T (&x0)[4], T (&xr)[4]) {
@@ -1263,23 +1402,8 @@ __global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) 
       const T* wr = (it & 1) ? W1 : W0;
       T* ww = (it & 1) ? W0 : W1;
       __syncthreads();
-      bf4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};      // two chains keep the pipe issuing
-      bf4 c = chunk(wr, 0), n1 = chunk(wr, 1), n2 = chunk(wr, 2);
-#pragma unroll
-      for (int q = 0; q < XQ; ++q) {
-        bf4 f = n2;
-        if (q + 3 < XQ) f = chunk(wr, q + 3);
-        __builtin_amdgcn_sched_barrier(0);
-        sa = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q], c[0], sa, 0, 0, 0);
-        sb = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q + 1], c[1], sb, 0, 0, 0);
-        sa = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q + 2], c[2], sa, 0, 0, 0);
-        sb = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q + 3], c[3], sb, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        c = n1; n1 = n2; n2 = f;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) sa[e] += sb[e];
-      both(sa);
+      bf4 sa = {0.f, 0.f, 0.f, 0.f};
+      prod1(Sa, wr, false, sa);
       T wv[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { xr[e] = x0[e] - sa[e]; wv[e] = ev_r[e] * xr[e]; }
@@ -1310,6 +1434,79 @@ __global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) 
 #pragma unroll
     for (int e = 0; e < 4; ++e) upd_x[e] += eh * xr[e];
   };
+  // ---- TRACK: the half steps without their P d and S m products ------------------------------------------------------
+  // S = P^-1 is what makes this path possible in the first place, and it also makes two of a half step's K + 2 products
+  // redundant.  Keep y = P (theta - mu), y_c = P (theta_c - mu), z = S p, z_c = S p_c next to the four state vectors:
+  //   p -= eh P (theta - mu) = eh y           =>  z -= eh (theta - mu)                          (S P = I)
+  //   theta_c += eh x,  x = (P + E)^-1 p_c    =>  y_c += eh P x = eh (p_c - e . x_(K-1))         (x_K = S p_c - S (e . x_(K-1)))
+  // element-wise, exact for the iteration as implemented.  The solve starts from x_0 = S p_c = z_c: only its K refinement
+  // products remain, and the second half step of a pair (position theta_c, momentum the p just updated) no longer depends on
+  // the first one's solve: the two solves run side by side, one accumulator chain each - K product phases per PAIR of half
+  // steps instead of 2 (K + 1).  The rotation phi_C mixes all four vectors; right after it the four tracked products are
+  // evaluated afresh in one phase (so a tracked vector carries at most four element-wise updates of rounding).  Per step at
+  // K = 2: 5 barrier-separated phases and 12 products instead of 8 and 16.
+  T y[4], yc[4], z[4], zc[4];
+  auto prod4 = [&](const T* X1, const T* X2, const T* X3, const T* X4, bf4& p1, bf4& p2, bf4& s3, bf4& s4) {   // P X1, P X2, S X3, S X4
+    bf4 c1[XSQ], c2[XSQ], c3[XSQ], c4[XSQ];
+    fetch(X1, c1); fetch(X2, c2); fetch(X3, c3); fetch(X4, c4);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for(std::make_integer_sequence<int, XQ>{}, [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        p1 = mfma_from_group<q % 4>(Pa[4 * q + u], c1[q / 4][u], p1);
+        p2 = mfma_from_group<q % 4>(Pa[4 * q + u], c2[q / 4][u], p2);
+        s3 = mfma_from_group<q % 4>(Sa[4 * q + u], c3[q / 4][u], s3);
+        s4 = mfma_from_group<q % 4>(Sa[4 * q + u], c4[q / 4][u], s4);
+      }
+    });
+    both(p1); both(p2); both(s3); both(s4);
+  };
+  // two independent solves x = (P + E)^-1 m from x_0 = S m, K phases; wa / wb return e . x_(K-1) (zero without jitter)
+  auto solve2 = [&](T* WB, const T (&ea)[4], const T (&eb)[4], const T (&x0a)[4], const T (&x0b)[4], T (&xa)[4], T (&xb)[4],
+                    T (&wa)[4], T (&wb)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { xa[e] = x0a[e]; xb[e] = x0b[e]; wa[e] = 0.f; wb[e] = 0.f; }
+    for (int it = 0; it < a.K; ++it) {
+      T* A = WB + (it & 1) * MSZ;                           // read in this phase only; rewritten two phases later
+      T* B = A + 2 * MSZ;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { wa[e] = ea[e] * xa[e]; wb[e] = eb[e] * xb[e]; }
+      put4(A, wa);
+      put4(B, wb);
+      HTA_XTICK(3);
+      __syncthreads();
+      HTA_XTICK(1);
+      bf4 ra = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
+      prod2(Sa, A, Sa, B, ra, rb);
+      HTA_XTICK(2);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { xa[e] = x0a[e] - ra[e]; xb[e] = x0b[e] - rb[e]; }
+    }
+  };
+  // a pair of half steps (S:429-433 and, with the roles of the copies swapped, S:454-458):
+  //   a:  g1 -= eh P (X1 - mu)   X2 += eh (P + E_a)^-1 g2        b:  g2 -= eh P (X2 - mu)   X1 += eh (P + E_b)^-1 g1
+  // with y1 = P (X1 - mu), y2 = P (X2 - mu), z1 = S g1, z2 = S g2 kept current
+  auto pair_tracked = [&](T* WB, const T (&ea)[4], const T (&eb)[4], T (&X1)[4], T (&X2)[4], T (&g1)[4], T (&g2)[4],
+                          T (&y1)[4], T (&y2)[4], T (&z1)[4], T (&z2)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      g1[e] -= eh * y1[e];                                  // a's momentum update ...
+      z1[e] -= eh * (rok[e] ? X1[e] - mu_r[e] : 0.f);       // ... and S g1 with it
+    }
+    T xa[4], xb[4], wa[4], wb[4];
+    solve2(WB, ea, eb, z2, z1, xa, xb, wa, wb);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      X2[e] += eh * xa[e];                                  // a's position update; P x_a = g2 - e_a . x_a(K-1)
+      y2[e] += eh * (g2[e] - wa[e]);
+      g2[e] -= eh * y2[e];                                  // b's momentum update
+      z2[e] -= eh * (rok[e] ? X2[e] - mu_r[e] : 0.f);
+      X1[e] += eh * xb[e];                                  // b's position update
+      y1[e] += eh * (g1[e] - wb[e]);
+    }
+    HTA_XTICK(3);
+  };
   // three sums per chain over the rows, complete in every lane of the chain's column (the upper lane half holds duplicates
   // of the lower one: it contributes nothing)
   auto block_sums = [&](T (&v)[3]) {
@@ -1317,11 +1514,11 @@ __global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) 
     for (int e = 0; e < 3; ++e) {
       if (upper) v[e] = 0.f;
       v[e] += __shfl_xor(v[e], 4, 64);
-      v[e] += __shfl_xor(v[e], 8, 64);
       v[e] += __shfl_xor(v[e], 16, 64);
+      v[e] += __shfl_xor(v[e], 32, 64);
     }
     __syncthreads();
-    if (blk == 0) {
+    if (lead) {
 #pragma unroll
       for (int e = 0; e < 3; ++e) red[(w * XNC + cl) * 4 + e] = v[e];
     }
@@ -1335,8 +1532,9 @@ __global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) 
     }
   };
   // H = -log p + D/2 log 2 pi + 1/2 log|G| + 1/2 m^T G^-1 m  (S:731)   (rmhmc_fused_kernel: hamiltonian, series branch)
-  auto hamiltonian = [&](uint32_t n, uint32_t sub, const T (&X)[4], const T* m, const T (&mr)[4], T& H, T& logp) {
-    T* d = dpar ? D1 : D0;
+  auto hamiltonian = [&](uint32_t n, uint32_t sub, const T (&X)[4], const T* m, const T (&mr)[4], T& H, T& logp, T (&Pd_out)[4],
+                         T (&Sm_out)[4]) {
+    T* d = (dpar && !TRACK) ? D1 : D0;                      // (TRACK: D1 belongs to the refresh phase)
     dpar ^= 1;
     if (a.has_jitter) jitter_raw(n, sub, ev_r);
     T dr[4];
@@ -1347,28 +1545,12 @@ __global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) 
     __syncthreads();
     bf4 Pd = {0.f, 0.f, 0.f, 0.f}, x0v = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     prod2(Pa, d, Sa, m, Pd, x0v);
-    if (a.has_jitter) {                                     // second-order log-det term: (S . S) e
-      bf4 c = chunk(EV, 0), n1 = chunk(EV, 1), n2 = chunk(EV, 2), s2b = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int q = 0; q < XQ; ++q) {
-        bf4 f = n2;
-        if (q + 3 < XQ) f = chunk(EV, q + 3);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 4; u += 2) {
-          s2 = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q + u] * Sa[4 * q + u], c[u], s2, 0, 0, 0);
-          s2b = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q + u + 1] * Sa[4 * q + u + 1], c[u + 1], s2b, 0, 0, 0);
-        }
-        c = n1; n1 = n2; n2 = f;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) s2[e] += s2b[e];
-      both(s2);
-    }
+    if (a.has_jitter) prod1(Sa, EV, true, s2);              // second-order log-det term: (S . S) e
     T v[3] = {0.f, 0.f, 0.f}, x0[4], xr[4], wv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       x0[e] = x0v[e]; xr[e] = x0v[e];
+      Pd_out[e] = Pd[e]; Sm_out[e] = x0v[e];
       v[0] += dr[e] * Pd[e];
       wv[e] = ev_r[e] * x0v[e];
       if (a.has_jitter) v[2] += ev_r[e] * (sd_r[e] - 0.5f * s2[e]);      // log|P + E| = log|P| + tr(SE) - 1/2 tr((SE)^2) + ...
@@ -1393,29 +1575,39 @@ __global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) 
     for (int e = 0; e < 4; ++e) scur[e] = (live && rok[e]) ? a.cur[c * D + row0 + e] : 0.f;
     int32_t rejected = 0;
     __syncthreads();                                        // the previous group's last reads of the vector matrices
+#if HTA_RM_TIMING
+    xlast = __builtin_readcyclecounter();
+#endif
     for (int t = 0; t < a.n_traj; ++t) {
       const uint32_t n = (uint32_t)(a.traj_offset + t);
       // ---- gibbs: p = chol(G(theta)) z, drawn ahead by the momentum kernel (S:183-184)
 #pragma unroll
       for (int e = 0; e < 4; ++e) spm[e] = (live && rok[e]) ? a.p_ws[((int64_t)t * a.C + c) * D + row0 + e] : 0.f;
       put4(PM, spm);
+      HTA_XTICK(7);
       T H0, H1, lp0, lp1;
-      hamiltonian(n, 1, scur, PM, spm, H0, lp0);            // S:971 -> S:822
+      hamiltonian(n, 1, scur, PM, spm, H0, lp0, y, z);      // S:971 -> S:822
+      HTA_XTICK(5);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { sth[e] = scur[e]; sthc[e] = scur[e]; spmc[e] = spm[e]; }   // S:425-426
-      put4(PMC, spm);
+      for (int e = 0; e < 4; ++e) { sth[e] = scur[e]; sthc[e] = scur[e]; spmc[e] = spm[e]; yc[e] = y[e]; zc[e] = z[e]; }   // S:425-426
+      if (!TRACK) put4(PMC, spm);
       for (int lstep = 0; lstep < a.L; ++lstep) {           // S:427-461
         const uint32_t k0 = 2u + 8u * (uint32_t)lstep;
         T e1[4], e2[4];
         jitter_pair(n, k0 + 1, k0 + 2, e1, e2);
+        HTA_XTICK(0);
+        if (TRACK) pair_tracked(WS, e1, e2, sth, sthc, spm, spmc, y, yc, z, zc);     // phi_A/2, phi_B/2  S:429-433
+        else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ev_r[e] = e1[e];
-        half_step(sth, PMC, sthc, spm, PM);                 // phi_A/2  S:429-430
+          for (int e = 0; e < 4; ++e) ev_r[e] = e1[e];
+          half_step(sth, PMC, sthc, spm, PM);               // phi_A/2  S:429-430
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ev_r[e] = e2[e];
-        half_step(sthc, PM, sth, spmc, PMC);                // phi_B/2  S:432-433
+          for (int e = 0; e < 4; ++e) ev_r[e] = e2[e];
+          half_step(sthc, PM, sth, spmc, PMC);              // phi_B/2  S:432-433
+        }
         if (a.K == 0) __syncthreads();
         jitter_pair(n, k0 + 4, k0 + 7, e1, e2);             // (issued before the rotation: independent work for the scheduler)
+        HTA_XTICK(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {                       // phi_C    S:447-450, sequential (Q1)
           T xx = sth[e], b = spm[e], xc = sthc[e], bc = spmc[e];
@@ -1428,14 +1620,38 @@ __global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) 
         }
         put4(PM, spm);
         put4(PMC, spmc);
+        if (TRACK) {                                        // the four tracked products of the rotated state, afresh
+          T dt[4], dc[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ev_r[e] = e1[e];
-        half_step(sthc, PM, sth, spmc, PMC);                // phi_B/2  S:454-455
+          for (int e = 0; e < 4; ++e) { dt[e] = rok[e] ? sth[e] - mu_r[e] : 0.f; dc[e] = rok[e] ? sthc[e] - mu_r[e] : 0.f; }
+          put4(D1, dt);
+          put4(DC, dc);
+          HTA_XTICK(4);
+          __syncthreads();
+          HTA_XTICK(1);
+          bf4 p1 = {0.f, 0.f, 0.f, 0.f}, p2 = {0.f, 0.f, 0.f, 0.f}, s3 = {0.f, 0.f, 0.f, 0.f}, s4 = {0.f, 0.f, 0.f, 0.f};
+          prod4(D1, DC, PM, PMC, p1, p2, s3, s4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ev_r[e] = e2[e];
-        half_step(sth, PMC, sthc, spm, PM);                 // phi_A/2  S:457-458
+          for (int e = 0; e < 4; ++e) { y[e] = p1[e]; yc[e] = p2[e]; z[e] = s3[e]; zc[e] = s4[e]; }
+          HTA_XTICK(2);
+          pair_tracked(WS + 4 * MSZ, e1, e2, sthc, sth, spmc, spm, yc, y, zc, z);    // phi_B/2, phi_A/2  S:454-458
+        } else {
+          HTA_XTICK(4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ev_r[e] = e1[e];
+          half_step(sthc, PM, sth, spmc, PMC);              // phi_B/2  S:454-455
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ev_r[e] = e2[e];
+          half_step(sth, PMC, sthc, spm, PM);               // phi_A/2  S:457-458
+        }
       }
-      hamiltonian(n, 2u + 8u * (uint32_t)a.L, sth, PM, spm, H1, lp1);   // S:989 (Q4)
+      if (TRACK) {                                          // (the tracked half steps keep the momenta in registers)
+        if (a.K == 0) __syncthreads();                      // no solve phase since the refresh phase read PM
+        put4(PM, spm);
+      }
+      T unused1[4], unused2[4];
+      hamiltonian(n, 2u + 8u * (uint32_t)a.L, sth, PM, spm, H1, lp1, unused1, unused2);   // S:989 (Q4)
+      HTA_XTICK(5);
       // ---- Metropolis test + bookkeeping (S:1000-1026, S:1045-1057)
       const T u = u23<T>(philox_block(a.seed, chain, n, PURPOSE_MH, 0, 0).x);
       const bool acc = mh_accept<T>(H0, H1, lp1, u);
@@ -1449,20 +1665,24 @@ __global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) 
             if (!upper && a.samples && (int)n > a.burn) a.samples[((int64_t)((int)n - a.burn) * a.C + c) * D + row0 + e] = vnew;
           }
         }
-        if (w == 0 && blk == 0) {
+        if (w == 0 && lead) {
           if (a.H_old) a.H_old[(int64_t)t * a.C + c] = H0;
           if (a.H_new) a.H_new[(int64_t)t * a.C + c] = H1;
           if (a.accept) a.accept[(int64_t)t * a.C + c] = acc ? 1 : 0;
         }
       }
       if (!acc) ++rejected;
+      HTA_XTICK(6);
     }
     if (live) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (rok[e] && !upper) a.cur[c * D + row0 + e] = scur[e];
-      if (w == 0 && blk == 0) a.reject_count[c] += rejected;
+      if (w == 0 && lead) a.reject_count[c] += rejected;
     }
   }
+#if HTA_RM_TIMING
+  if (tid == 0 && blockIdx.x == 0) for (int k = 0; k < 16; ++k) hta_rm_dbg[k] = xacc[k];
+#endif
 }
 
 // The momentum draws of a block of trajectories, off the chains' critical path: task (t, c) -> p = chol(P + diag(e)) z
@@ -1856,11 +2076,13 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
           // four waves per group while the groups fit one per CU (<= 1024 chains on 256 CUs): beyond that two groups share a CU
           // and the two-wave kernel already fills its four SIMDs
           if (g_rmhmc_mfma4_waves == 2 || (g_rmhmc_mfma4_waves != 5 && ngroup > 256)) {
-            const size_t qlds = (size_t)(7 * QNC * QLD + QWV * QNC * 4) * sizeof(float);
-            rmhmc_mfma4_kernel<<<(int)(ngroup < 8192 ? ngroup : 8192), QNT, qlds, s>>>(a);
+            const size_t qlds = (size_t)(9 * QNC * QLD + QWV * QNC * 4) * sizeof(float);
+            if (g_rmhmc_pair) rmhmc_mfma4_kernel<true><<<(int)(ngroup < 8192 ? ngroup : 8192), QNT, qlds, s>>>(a);
+            else rmhmc_mfma4_kernel<false><<<(int)(ngroup < 8192 ? ngroup : 8192), QNT, qlds, s>>>(a);
           } else {
-            const size_t xlds = (size_t)(7 * XNC * XLD + XWV * XNC * 4) * sizeof(float);
-            rmhmc_mfma4x4_kernel<<<(int)(ngroup < 8192 ? ngroup : 8192), XNT, xlds, s>>>(a);
+            const size_t xlds = (size_t)(XBUF * XNC * XLD + XWV * XNC * 4) * sizeof(float);
+            if (g_rmhmc_pair) rmhmc_mfma4x4_kernel<true><<<(int)(ngroup < 8192 ? ngroup : 8192), XNT, xlds, s>>>(a);
+            else rmhmc_mfma4x4_kernel<false><<<(int)(ngroup < 8192 ? ngroup : 8192), XNT, xlds, s>>>(a);
           }
           profile_end(s);
           return HTA_OK;

@@ -594,9 +594,11 @@ def test_mfma4_kernel_equals_fused_kernel(ht, D, C, jit):
     th0 = tt((0.3 * O.philox_normals(3, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32), torch.float32)
     outs = []
     try:
-        for mode, waves in ((2 if C < 704 else 1, 4), (0, 4), (2 if C < 704 else 1, 2)):      # from 704 to 2048 chains it is the default route
+        on = 2 if C < 704 else 1                                 # from 704 to 2048 chains it is the default route
+        for mode, waves, pair in ((on, 4, 1), (0, 4, 1), (on, 2, 1), (on, 4, 0)):
             _abi.set_tuning("rmhmc_mfma4", mode)
             _abi.set_tuning("rmhmc_mfma4_waves", waves)          # 4: rmhmc_mfma4x4_kernel (default), 2: rmhmc_mfma4_kernel
+            _abi.set_tuning("rmhmc_pair", pair)                  # 1: two half steps in K + 2 product phases (default), 0: one at a time
             _abi.set_tuning("rmhmc_batch", 0)
             cur = th0.clone(); rej = torch.zeros(C, dtype=torch.int32, device=dev())
             samples = torch.zeros(T - burn + 1, C, D, device=dev())
@@ -608,10 +610,13 @@ def test_mfma4_kernel_equals_fused_kernel(ht, D, C, jit):
     finally:
         _abi.set_tuning("rmhmc_mfma4", MFMA4_DEFAULT)
         _abi.set_tuning("rmhmc_mfma4_waves", 4)
+        _abi.set_tuning("rmhmc_pair", 1)
         _abi.set_tuning("rmhmc_batch", 1)
     assert np.isfinite(outs[0][0]).all()
     err2 = np.abs(outs[0][0] - outs[2][0]).max(axis=(0, 2))          # four-wave kernel against the two-wave kernel
     assert (err2 > 2e-4).mean() <= 0.05, "four- vs two-wave kernel: max err %.3g (%d chains differ)" % (err2.max(), (err2 > 2e-4).sum())
+    err3 = np.abs(outs[0][0] - outs[3][0]).max(axis=(0, 2))          # paired half steps against one half step at a time
+    assert (err3 > 2e-4).mean() <= 0.05, "paired vs single half steps: max err %.3g (%d chains differ)" % (err3.max(), (err3 > 2e-4).sum())
     err = np.abs(outs[0][0] - outs[1][0]).max(axis=(0, 2))
     assert (err > 2e-4).mean() <= 0.05, "max err %.3g (%d chains differ)" % (err.max(), (err > 2e-4).sum())
     good = err <= 2e-4
