@@ -184,9 +184,10 @@ __device__ __forceinline__ void chunk_fma(const float* reg, float u, float (&acc
 // registers - no partial-sum vectors, no combine phases: one barrier per product pass.
 // NC chains can share a workgroup (NC = 2): the slices do not depend on the chain, so a pass carries both chains for the
 // same register reads and barriers - but not for the same LDS traffic, which is what bounds a pass (see the dispatch).
-constexpr int FVC = 7;            // LDS vectors per chain: pm pmc ev d0 d1 w0 w1 (128 entries each, zero beyond D)
+constexpr int FVC = 16;           // LDS vectors per chain: pm pmc ev d0 d1 w0 w1 | dc + 8 solve vectors of the tracked schedule
+                                  // (128 entries each, zero beyond D)
 
-template <typename T, int KH, int NC> struct Fused {
+template <typename T, int KH, int NC, bool TRACK = false> struct Fused {
   typedef T V4 __attribute__((ext_vector_type(4)));
   static constexpr int CHS = FVC * 128;
   const FusedArgs<T>& a;
@@ -198,7 +199,8 @@ template <typename T, int KH, int NC> struct Fused {
   T scur[NC], sth[NC], spm[NC], sthc[NC], spmc[NC];   // the owner's element of the chain state (theta, p and their copies):
                                       // registers; only the momenta are mirrored in LDS (they are product operands)
   int jslot;                          // next unread evaluation slot of the jitter buffer
-  T *pm, *pmc, *ev, *d0, *d1, *w0, *w1, *dg, *red, *W, *jb;
+  T y[NC], yc[NC], z[NC], zc[NC];     // TRACK: the owner's element of P (theta - mu), P (theta_c - mu), S p, S p_c
+  T *pm, *pmc, *ev, *d0, *d1, *w0, *w1, *dc, *ws, *dg, *red, *W, *jb;
   uint64_t chain[NC];
   bool live[NC];
 #if HTA_RM_TIMING
@@ -391,12 +393,148 @@ template <typename T, int KH, int NC> struct Fused {
     HTA_MTICK(3);
   }
 
+  // ---- TRACK: the half steps without their P d and S m products (the schedule and its derivation: rmhmc_mfma4x4_kernel) ----
+  // Up to two P products and two S products with ONE pass over the slices: op_i = P vp_i, os_i = S vs_i, complete in both
+  // lanes of the row.  Per product the chunks and the order of the sum are those of products().
+  template <int NPV, int NSV>
+  __device__ __forceinline__ void products_multi(const T* vp0, const T* vp1, const T* vs0, const T* vs1, T (&op0)[NC], T (&op1)[NC],
+                                                 T (&os0)[NC], T (&os1)[NC]) {
+    constexpr int NV = NPV + NSV;
+    const T* vec[4] = {vp0, vp1, vs0, vs1};
+    T acc[NC][4][2];
+#pragma unroll
+    for (int q = 0; q < NC; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[q][i][0] = acc[q][i][1] = 0;
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      if constexpr (sizeof(T) == 4) {
+        constexpr int NB = (KH + 15) / 16;
+        float u[4][NB];
+        const int l15 = tid & 15;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+          const int off = q * CHS + k0 + 16 * cb + ((16 * cb + 8 < KH) ? l15 : (l15 & 7));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool used = i < 2 ? i < NPV : i - 2 < NSV;
+            if (used) u[i][cb] = vec[i][off];
+          }
+        }
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool used = i < 2 ? i < NPV : i - 2 < NSV;
+            if (!used) continue;
+            const float* reg = reinterpret_cast<const float*>(i < 2 ? Preg : Sreg) + 16 * cb;
+            if (16 * cb + 8 < KH) chunk_fma(reg, u[i][cb], reinterpret_cast<float(&)[2]>(acc[q][i]), std::make_integer_sequence<int, 16>{});
+            else chunk_fma(reg, u[i][cb], reinterpret_cast<float(&)[2]>(acc[q][i]), std::make_integer_sequence<int, 8>{});
+          }
+        }
+      } else {
+        constexpr int NCH = KH / 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool used = i < 2 ? i < NPV : i - 2 < NSV;
+          if (!used) continue;
+          V4 uu[NCH];
+#pragma unroll
+          for (int cb = 0; cb < NCH; ++cb) uu[cb] = *reinterpret_cast<const V4*>(vec[i] + q * CHS + k0 + 4 * cb);
+#pragma unroll
+          for (int cb = 0; cb < NCH; ++cb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[q][i][e & 1] = fma((i < 2 ? Preg : Sreg)[4 * cb + e], uu[cb][e], acc[q][i][e & 1]);
+        }
+      }
+    }
+    (void)NV;
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      if (NPV >= 1) op0[q] = row_total(acc[q][0][0] + acc[q][0][1]);
+      if (NPV >= 2) op1[q] = row_total(acc[q][1][0] + acc[q][1][1]);
+      if (NSV >= 1) os0[q] = row_total(acc[q][2][0] + acc[q][2][1]);
+      if (NSV >= 2) os1[q] = row_total(acc[q][3][0] + acc[q][3][1]);
+    }
+  }
+
+  // two independent solves x = (P + E)^-1 m from x_0 = S m, K phases (one barrier and one pass over S each); wa / wb return
+  // e . x_(K-1) (zero without jitter).  wb4: this pair's four vectors a0 a1 b0 b1.
+  __device__ __forceinline__ void solve2(T* wb4, const T (&ea)[NC], const T (&eb)[NC], const T (&x0a)[NC], const T (&x0b)[NC],
+                                         T (&xa)[NC], T (&xb)[NC], T (&wa)[NC], T (&wb)[NC]) {
+#pragma unroll
+    for (int q = 0; q < NC; ++q) { xa[q] = x0a[q]; xb[q] = x0b[q]; wa[q] = 0; wb[q] = 0; }
+    for (int it = 0; it < a.K; ++it) {
+      T* A = wb4 + (it & 1) * 128;                         // read in this phase only; rewritten two phases later
+      T* B = A + 2 * 128;
+      if (own) {
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+          wa[q] = ea[q] * xa[q]; wb[q] = eb[q] * xb[q];
+          A[q * CHS + row] = wa[q]; B[q * CHS + row] = wb[q];
+        }
+      }
+      HTA_MTICK(4);
+      __syncthreads();
+      HTA_MTICK(5);
+      T ra[NC], rb[NC], u0[NC], u1[NC];
+      products_multi<0, 2>(nullptr, nullptr, A, B, u0, u1, ra, rb);
+      HTA_MTICK(6);
+#pragma unroll
+      for (int q = 0; q < NC; ++q) { xa[q] = x0a[q] - ra[q]; xb[q] = x0b[q] - rb[q]; }
+    }
+  }
+
+  // a pair of half steps (S:429-433 and, with the roles of the copies swapped, S:454-458):
+  //   a:  g1 -= eh P (X1 - mu)   X2 += eh (P + E_a)^-1 g2        b:  g2 -= eh P (X2 - mu)   X1 += eh (P + E_b)^-1 g1
+  // with y1 = P (X1 - mu), y2 = P (X2 - mu), z1 = S g1, z2 = S g2 kept current; the jitter of a and b: the next two slots
+  __device__ __forceinline__ void pair_tracked(T* wb4, T (&X1)[NC], T (&X2)[NC], T (&g1)[NC], T (&g2)[NC], T (&y1)[NC], T (&y2)[NC],
+                                               T (&z1)[NC], T (&z2)[NC], T eh) {
+    T ea[NC], eb[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      ea[q] = (a.has_jitter && own) ? jb[(jslot * NC + q) * 128 + row] : (T)0;
+      eb[q] = (a.has_jitter && own) ? jb[((jslot + 1) * NC + q) * 128 + row] : (T)0;
+      g1[q] -= eh * y1[q];                                  // a's momentum update ...
+      z1[q] -= eh * (X1[q] - mu_r);                         // ... and S g1 with it (S P = I)
+    }
+    jslot += 2;
+    T xa[NC], xb[NC], wa[NC], wb[NC];
+    solve2(wb4, ea, eb, z2, z1, xa, xb, wa, wb);
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      X2[q] += eh * xa[q];                                  // a's position update; P x_a = g2 - e_a . x_a(K-1)
+      y2[q] += eh * (g2[q] - wa[q]);
+      g2[q] -= eh * y2[q];                                  // b's momentum update
+      z2[q] -= eh * (X2[q] - mu_r);
+      X1[q] += eh * xb[q];                                  // b's position update
+      y1[q] += eh * (g1[q] - wb[q]);
+    }
+    HTA_MTICK(7);
+  }
+
+  // the four tracked products of the current state, afresh (after the rotation phi_C): one barrier, one pass over P and S
+  __device__ __forceinline__ void refresh_tracked() {
+    if (own) {
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        d1[q * CHS + row] = sth[q] - mu_r; dc[q * CHS + row] = sthc[q] - mu_r;
+        pm[q * CHS + row] = spm[q]; pmc[q * CHS + row] = spmc[q];
+      }
+    }
+    HTA_MTICK(4);
+    __syncthreads();
+    HTA_MTICK(5);
+    products_multi<2, 2>(d1, dc, pm, pmc, y, yc, z, zc);
+    HTA_MTICK(3);
+  }
+
   __device__ __forceinline__ T factor() { return chol_in_lds<T>(a.P, ev, W, dg, D, ld, tid); }
 
   // H = -log p + D/2 log 2 pi + 1/2 log|G| + 1/2 m^T G^-1 m  (S:731) at (X, m) per chain, jitter sub-stream `sub`
   __device__ __forceinline__ void hamiltonian(uint32_t n, uint32_t sub, const T (&X)[NC], const T* m, const T (&mr)[NC], T (&H)[NC],
-                                              T (&logp)[NC]) {
-    T* d = dpar ? d1 : d0;
+                                              T (&logp)[NC], T (&Pd_out)[NC], T (&Sm_out)[NC]) {
+    T* d = (dpar && !TRACK) ? d1 : d0;                      // (TRACK: d1 belongs to the refresh phase)
     dpar ^= 1;
     T dr[NC];
     if (own) {
@@ -416,7 +554,7 @@ template <typename T, int KH, int NC> struct Fused {
     else products<true, 1>(d, m, nullptr, Pd, x0, s2);
     T v[NC][4];
 #pragma unroll
-    for (int q = 0; q < NC; ++q) { v[q][0] = v[q][1] = v[q][2] = v[q][3] = 0; xr[q] = x0[q]; }
+    for (int q = 0; q < NC; ++q) { v[q][0] = v[q][1] = v[q][2] = v[q][3] = 0; xr[q] = x0[q]; Pd_out[q] = Pd[q]; Sm_out[q] = x0[q]; }
     if (own) {
 #pragma unroll
       for (int q = 0; q < NC; ++q) {
@@ -444,10 +582,10 @@ template <typename T, int KH, int NC> struct Fused {
   }
 };
 
-template <typename T, int KH, int NC>
+template <typename T, int KH, int NC, bool TRACK = false>
 __device__ __forceinline__ void fused_body(const FusedArgs<T>& a, int ld, int need_w) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  typedef Fused<T, KH, NC> F;
+  typedef Fused<T, KH, NC, TRACK> F;
   F ch(a);
   const int D = a.D, tid = threadIdx.x;
   ch.D = D; ch.ld = ld; ch.tid = tid; ch.dpar = 0;
@@ -458,8 +596,8 @@ __device__ __forceinline__ void fused_body(const FusedArgs<T>& a, int ld, int ne
     ch.own = (lane >= 32) && ch.row < D;                    // the upper lane of a row holds the complete sums
   }
   T* v = reinterpret_cast<T*>(smem_raw);
-  T** slots[FVC] = {&ch.pm, &ch.pmc, &ch.ev, &ch.d0, &ch.d1, &ch.w0, &ch.w1};
-  for (int i = 0; i < FVC; ++i) *slots[i] = v + i * 128;
+  T** slots[9] = {&ch.pm, &ch.pmc, &ch.ev, &ch.d0, &ch.d1, &ch.w0, &ch.w1, &ch.dc, &ch.ws};    // ws: 8 vectors
+  for (int i = 0; i < 9; ++i) *slots[i] = v + i * 128;
   ch.dg = v + NC * F::CHS;
   ch.red = ch.dg + 128;
   ch.jb = ch.red + 32;                                      // [8 evaluation slots][128]
@@ -520,18 +658,22 @@ __device__ __forceinline__ void fused_body(const FusedArgs<T>& a, int ld, int ne
       }
       // ---- H_old (S:971 -> S:822), sub-stream 1
       T H0[NC], H1[NC], lp0[NC], lp1[NC];
-      ch.hamiltonian(n, 1, ch.scur, ch.pm, ch.spm, H0, lp0);
+      ch.hamiltonian(n, 1, ch.scur, ch.pm, ch.spm, H0, lp0, ch.y, ch.z);
 #pragma unroll
       for (int q = 0; q < NC; ++q) {                                          // S:425-426
         ch.sth[q] = ch.scur[q]; ch.sthc[q] = ch.scur[q]; ch.spmc[q] = ch.spm[q];
-        if (ch.own) ch.pmc[q * F::CHS + row] = ch.spm[q];
+        ch.yc[q] = ch.y[q]; ch.zc[q] = ch.z[q];
+        if (!TRACK && ch.own) ch.pmc[q * F::CHS + row] = ch.spm[q];
       }
       HTA_RTICK(1);
       // ---- L explicit steps (S:427-461)
       for (int l = 0; l < a.L; ++l) {
         if (l == 0 || ch.jslot == F::NSLOT) ch.refill_jitter(n, l);         // sub-streams 2 + 8 l + {1, 2, 4, 7}, ...
-        ch.half_step(ch.sth, ch.pmc, ch.sthc, ch.spm, ch.pm, eh);             // phi_A/2  S:429-430
-        ch.half_step(ch.sthc, ch.pm, ch.sth, ch.spmc, ch.pmc, eh);            // phi_B/2  S:432-433
+        if (TRACK) ch.pair_tracked(ch.ws, ch.sth, ch.sthc, ch.spm, ch.spmc, ch.y, ch.yc, ch.z, ch.zc, eh);   // phi_A/2, phi_B/2  S:429-433
+        else {
+          ch.half_step(ch.sth, ch.pmc, ch.sthc, ch.spm, ch.pm, eh);           // phi_A/2  S:429-430
+          ch.half_step(ch.sthc, ch.pm, ch.sth, ch.spmc, ch.pmc, eh);          // phi_B/2  S:432-433
+        }
         if (a.K == 0) __syncthreads();                                        // slower waves may still stream pm (no refinement barrier)
 #pragma unroll
         for (int q = 0; q < NC; ++q) {                                        // phi_C    S:447-450, sequential (Q1)
@@ -542,14 +684,27 @@ __device__ __forceinline__ void fused_body(const FusedArgs<T>& a, int ld, int ne
           xc = h * ((xx + xc) - cc * (xx - xc) - ss * (b - bc));
           bc = h * ((b + bc) + ss * (xx - xc) - cc * (b - bc));
           ch.sth[q] = xx; ch.spm[q] = b; ch.sthc[q] = xc; ch.spmc[q] = bc;
-          if (ch.own) { ch.pm[q * F::CHS + row] = b; ch.pmc[q * F::CHS + row] = bc; }
+          if (!TRACK && ch.own) { ch.pm[q * F::CHS + row] = b; ch.pmc[q * F::CHS + row] = bc; }
         }
-        ch.half_step(ch.sthc, ch.pm, ch.sth, ch.spmc, ch.pmc, eh);            // phi_B/2  S:454-455
-        ch.half_step(ch.sth, ch.pmc, ch.sthc, ch.spm, ch.pm, eh);             // phi_A/2  S:457-458
+        if (TRACK) {
+          ch.refresh_tracked();
+          ch.pair_tracked(ch.ws + 4 * 128, ch.sthc, ch.sth, ch.spmc, ch.spm, ch.yc, ch.y, ch.zc, ch.z, eh);   // phi_B/2, phi_A/2  S:454-458
+        } else {
+          ch.half_step(ch.sthc, ch.pm, ch.sth, ch.spmc, ch.pmc, eh);          // phi_B/2  S:454-455
+          ch.half_step(ch.sth, ch.pmc, ch.sthc, ch.spm, ch.pm, eh);           // phi_A/2  S:457-458
+        }
       }
       HTA_RTICK(2);
+      if (TRACK) {                                                            // (the tracked half steps keep the momenta in registers)
+        if (a.K == 0) __syncthreads();                                        // no solve phase since the refresh phase read pm
+        if (ch.own) {
+#pragma unroll
+          for (int q = 0; q < NC; ++q) ch.pm[q * F::CHS + row] = ch.spm[q];
+        }
+      }
       // ---- H_new on the un-augmented pair (S:989, Q4), sub-stream 2 + 8L
-      ch.hamiltonian(n, 2u + 8u * (uint32_t)a.L, ch.sth, ch.pm, ch.spm, H1, lp1);
+      T unused1[NC], unused2[NC];
+      ch.hamiltonian(n, 2u + 8u * (uint32_t)a.L, ch.sth, ch.pm, ch.spm, H1, lp1, unused1, unused2);
       HTA_RTICK(3);
       // ---- Metropolis test + bookkeeping (S:1000-1026, S:1045-1057), as hmc_pieces.hip:mh_select_kernel
 #pragma unroll
@@ -584,9 +739,9 @@ __device__ __forceinline__ void fused_body(const FusedArgs<T>& a, int ld, int ne
   }
 }
 
-template <typename T, int KH, int NC>
+template <typename T, int KH, int NC, bool TRACK = false>
 __global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int ld, int need_w) {
-  fused_body<T, KH, NC>(a, ld, need_w);
+  fused_body<T, KH, NC, TRACK>(a, ld, need_w);
 }
 
 // The same kernel for launches of at most one workgroup per CU (chains <= compute units: BASELINE config 3's 256 chains):
@@ -594,10 +749,9 @@ __global__ __launch_bounds__(FNT, 2) void rmhmc_fused_kernel(FusedArgs<T> a, int
 // instances keep 26 / 35 registers in scratch - buys nothing.  HTA_FUSED_WIDE_VGPRS registers instead: together with the
 // overlapped momentum waves (rmhmc_momentum_wave_kernel, capped at 512 - HTA_FUSED_WIDE_VGPRS) a SIMD's 512 are exactly used.
 #define HTA_FUSED_WIDE_VGPRS 288
-template <int KH>
+template <int KH, bool TRACK = false>
 __global__ __launch_bounds__(FNT) __attribute__((amdgpu_num_vgpr(HTA_FUSED_WIDE_VGPRS))) void rmhmc_fused_kernel_wide(FusedArgs<float> a, int ld, int need_w) {
-  fused_body<float, KH, 1>(a, ld, need_w);
-
+  fused_body<float, KH, 1, TRACK>(a, ld, need_w);
 }
 
 
@@ -2005,6 +2159,7 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
   }
   static DevOnce done[8];     // per T instantiation
   static DevOnce done2[8];
+  static DevOnce done_t[8];   // the tracked-products instances
   static DevOnce done_mom;
   int bidx = 0;
   for (int t0 = 0; t0 < n_traj; t0 += (block > 0 ? block : n_traj), ++bidx) {
@@ -2130,12 +2285,14 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
       }
       if constexpr (sizeof(T) == 4) {
         if (g_rmhmc_wide && (KH == 56 || KH == 64) && C <= fused_cu_count()) {       // one workgroup per CU at most: the spill-free instances
-          static DevOnce dw[2];
-          auto wide = KH == 56 ? &rmhmc_fused_kernel_wide<56> : &rmhmc_fused_kernel_wide<64>;
-          if (!dw[KH == 64]) {
+          static DevOnce dw4[4];
+          DevOnce& dwf = dw4[(KH == 64) + 2 * (g_rmhmc_pair != 0)];
+          auto wide = g_rmhmc_pair ? (KH == 56 ? &rmhmc_fused_kernel_wide<56, true> : &rmhmc_fused_kernel_wide<64, true>)
+                                   : (KH == 56 ? &rmhmc_fused_kernel_wide<56, false> : &rmhmc_fused_kernel_wide<64, false>);
+          if (!dwf) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wide), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) { set_error("hta_rmhmc_gaussian_sample: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
-            dw[KH == 64] = true;
+            dwf = true;
           }
           profile_begin(s);
           wide<<<grid, FNT, fused_lds_bytes<T>(D, nullptr, 1, need_w), s>>>(a, ld, need_w ? 1 : 0);
@@ -2149,16 +2306,23 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
       return HTA_OK;
     };
     int rc;
+    // the tracked-products instances: fp32 only (the fp64 ones would spill twice as much under the 256-register cap)
+#define HTA_KH_CASE(KHV, IDX)                                                                                              \
+    if constexpr (sizeof(T) == 4) {                                                                                       \
+      if (g_rmhmc_pair) { rc = launch(&rmhmc_fused_kernel<T, KHV, 1, true>, &rmhmc_fused_kernel<T, KHV, 2>, done_t[IDX], done2[IDX]); break; } \
+    }                                                                                                                     \
+    rc = launch(&rmhmc_fused_kernel<T, KHV, 1>, &rmhmc_fused_kernel<T, KHV, 2>, done[IDX], done2[IDX]); break;
     switch (KH) {
-      case 8: rc = launch(&rmhmc_fused_kernel<T, 8, 1>, &rmhmc_fused_kernel<T, 8, 2>, done[0], done2[0]); break;
-      case 16: rc = launch(&rmhmc_fused_kernel<T, 16, 1>, &rmhmc_fused_kernel<T, 16, 2>, done[1], done2[1]); break;
-      case 24: rc = launch(&rmhmc_fused_kernel<T, 24, 1>, &rmhmc_fused_kernel<T, 24, 2>, done[2], done2[2]); break;
-      case 32: rc = launch(&rmhmc_fused_kernel<T, 32, 1>, &rmhmc_fused_kernel<T, 32, 2>, done[3], done2[3]); break;
-      case 40: rc = launch(&rmhmc_fused_kernel<T, 40, 1>, &rmhmc_fused_kernel<T, 40, 2>, done[4], done2[4]); break;
-      case 48: rc = launch(&rmhmc_fused_kernel<T, 48, 1>, &rmhmc_fused_kernel<T, 48, 2>, done[5], done2[5]); break;
-      case 56: rc = launch(&rmhmc_fused_kernel<T, 56, 1>, &rmhmc_fused_kernel<T, 56, 2>, done[6], done2[6]); break;
-      default: rc = launch(&rmhmc_fused_kernel<T, 64, 1>, &rmhmc_fused_kernel<T, 64, 2>, done[7], done2[7]); break;
+      case 8: HTA_KH_CASE(8, 0)
+      case 16: HTA_KH_CASE(16, 1)
+      case 24: HTA_KH_CASE(24, 2)
+      case 32: HTA_KH_CASE(32, 3)
+      case 40: HTA_KH_CASE(40, 4)
+      case 48: HTA_KH_CASE(48, 5)
+      case 56: HTA_KH_CASE(56, 6)
+      default: HTA_KH_CASE(64, 7)
     }
+#undef HTA_KH_CASE
     if (rc) return rc;
     if (ov) (void)hipEventRecord(ov->freed[bidx & 1], s);
   }

@@ -582,6 +582,43 @@ def test_wave_momentum_kernel_equals_workgroup_kernel(ht, D, C, jit, batch):
     assert np.abs(outs[0][0][T - 1 - burn] - outs[0][0][1]).max() > 1e-3
 
 
+@pytest.mark.parametrize("D,C,jit", [(100, 40, 1e-3), (100, 300, 1e-3), (100, 24, None), (37, 30, 5e-2), (20, 12, 1e-3), (64, 20, 2e-3),
+                                     (3, 5, 1e-3)])
+def test_tracked_products_equal_explicit_products(ht, D, C, jit):
+    """"rmhmc_pair" = 1 (default): the one-chain kernel carries P (theta - mu) and S p along element-wise and evaluates only the
+    refinement products of a half step, two half steps side by side (csrc/rmhmc_fused.hip: pair_tracked).  "rmhmc_pair" = 0
+    evaluates every product of every half step.  Same streams, same update order: chain by chain to rounding - one workgroup per
+    CU and two (C = 300), without jitter (K = 0: no solve phases at all), many refinements (jitter 5e-2), burn-in (Q2 reset)."""
+    from hamiltorch_amd import _abi
+    T, L, burn = 9, 4, 2
+    t, _ = cfg3_target(ht, D, torch.float32, seed=5)
+    th0 = tt((0.3 * O.philox_normals(3, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32), torch.float32)
+    outs = []
+    try:
+        for pair in (1, 0):
+            _abi.set_tuning("rmhmc_pair", pair)
+            _abi.set_tuning("rmhmc_mfma4", 0); _abi.set_tuning("rmhmc_batch", 0)
+            cur = th0.clone(); rej = torch.zeros(C, dtype=torch.int32, device=dev())
+            samples = torch.zeros(T - burn + 1, C, D, device=dev())
+            Ho = torch.zeros(T, C, device=dev()); Hn = torch.zeros(T, C, device=dev())
+            ws = torch.empty(_abi.rmhmc_workspace_bytes(C, D, 4, T), dtype=torch.uint8, device=dev())
+            _abi.rmhmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, _abi.METRIC_SOFTABS, 1e6, jit, L, 0.1, 10.0,
+                                       T, 0, burn, 21, 0, samples, rej, ws, H_old=Ho, H_new=Hn)
+            torch.cuda.synchronize()
+            outs.append((samples.cpu().numpy(), rej.cpu().numpy(), cur.cpu().numpy(), Ho.cpu().numpy(), Hn.cpu().numpy()))
+    finally:
+        _abi.set_tuning("rmhmc_pair", 1)
+        _abi.set_tuning("rmhmc_mfma4", MFMA4_DEFAULT); _abi.set_tuning("rmhmc_batch", 1)
+    assert np.isfinite(outs[0][0]).all()
+    np.testing.assert_allclose(outs[0][4][0], outs[1][4][0], rtol=2e-5, atol=2e-4)      # H_new of the first trajectory: before any accept decision
+    err = np.abs(outs[0][0] - outs[1][0]).max(axis=(0, 2))
+    assert (err > 2e-4).mean() <= 0.05, "max err %.3g (%d chains differ)" % (err.max(), (err > 2e-4).sum())
+    good = err <= 2e-4
+    assert np.array_equal(outs[0][1][good], outs[1][1][good])
+    np.testing.assert_allclose(outs[0][2][good], outs[1][2][good], atol=2e-4)
+    assert np.abs(outs[0][0][T - 1 - burn] - outs[0][0][1]).max() > 1e-3
+
+
 @pytest.mark.parametrize("D,C,jit", [(7, 9, 1e-3), (24, 33, 1e-3), (64, 18, 1e-3), (65, 7, 1e-3), (100, 50, 1e-3), (100, 33, None),
                                      (100, 1030, 1e-3)])
 def test_mfma4_kernel_equals_fused_kernel(ht, D, C, jit):

@@ -3,6 +3,10 @@ import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import hamiltorch_amd as ht
 from hamiltorch_amd import _abi
+if os.environ.get("TIMING_LIB"):
+    _abi.LIB_PATH = os.environ["TIMING_LIB"]
+for kv in filter(None, os.environ.get("HTA_TUNING", "").split(",")):
+    k_, v_ = kv.split("="); _abi.set_tuning(k_, int(v_))
 dev = torch.device("cuda:0")
 _abi.set_tuning("rmhmc_fused", int(os.environ.get("FUSED", "1")))
 D, C, T = 100, int(sys.argv[1]) if len(sys.argv) > 1 else 256, int(sys.argv[2]) if len(sys.argv) > 2 else 4
@@ -13,7 +17,7 @@ P = 0.5 * (P + P.T)
 tgt = ht.GaussianTarget(torch.zeros(D, device=dev), precision=P.float().to(dev), normalized=False)
 th0 = (0.1 * torch.randn(C, D, generator=g)).to(dev)
 ws = torch.empty(_abi.rmhmc_workspace_bytes(C, D, 4, T), dtype=torch.uint8, device=dev)
-for L, jit in ((0, 1e-3), (10, 1e-3), (10, None), (20, 1e-3)):
+for L, jit in ((10, 1e-3),):
     cur = th0.clone(); rej = torch.zeros(C, dtype=torch.int32, device=dev)
     best = 1e9
     for rep in range(3):
@@ -28,9 +32,9 @@ for L, jit in ((0, 1e-3), (10, 1e-3), (10, None), (20, 1e-3)):
 import ctypes
 lib = ctypes.CDLL(_abi.LIB_PATH)
 if hasattr(lib, "hta_rm_dbg_read"):
-    buf = (ctypes.c_ulonglong * 8)()
+    buf = (ctypes.c_ulonglong * 16)()
     lib.hta_rm_dbg_read(buf)
-    names = ["everything else", "-", "-", "half step: refinements + tail", "half step: prologue (ev, d)", "half step: barrier", "half step: products(P d, S m)", "half step: element-wise after products"]
+    names = ["everything else", "-", "-", "refinements + tail | tracked: refresh products", "prologue (publish)", "barrier", "products", "element-wise after products"]
     tot = sum(buf)
     for k in range(8):
         print("   %-20s %12d cycles  %5.1f %%" % (names[k], buf[k], 100.0 * buf[k] / max(1, tot)))
