@@ -36,6 +36,7 @@ extern int g_rmhmc_fused;                                   // tuning key "rmhmc
 extern int g_rmhmc_batch;                                   // tuning key "rmhmc_batch" (default 1)
 extern int g_rmhmc_momwave;                                 // tuning key "rmhmc_momwave" (default 1)
 extern int g_rmhmc_mfma4_waves;                             // tuning key "rmhmc_mfma4_waves" (default 4; 2 = the two-wave kernel)
+extern int g_rmhmc_uv;                                      // tuning key "rmhmc_uv" (default 1: rmhmc_uv.hip up to 2 x CUs chains; 0 off; 2 always)
 extern int g_rmhmc_pair;                                    // tuning key "rmhmc_pair" (default 1: two half steps per K + 2 product phases)
 extern int g_rmhmc_mfma4, g_rmhmc_mfma4_lo, g_rmhmc_mfma4_hi;    // tuning keys "rmhmc_mfma4" (default 1), "rmhmc_mfma4_lo", "rmhmc_mfma4_hi"
 extern int g_rmhmc_overlap;                                 // tuning key "rmhmc_overlap" (default 1)

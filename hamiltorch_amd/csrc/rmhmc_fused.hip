@@ -23,6 +23,7 @@
 #include "common.hpp"
 #include "philox.hpp"
 #include "rmhmc.hpp"
+#include "rmhmc_fused_dev.hpp"
 
 #ifndef HTA_RM_TIMING
 #define HTA_RM_TIMING 0   // developer cycle counters (thread 0 of block 0): tools/scratch/rmhmc_time.py prints them
@@ -43,15 +44,6 @@ namespace hta {
 
 constexpr int FNT = 256;          // 4 waves: (row block of 64) x (half of the contraction range)
 constexpr int FCB = 4;            // Cholesky panel width
-
-template <typename T> struct FusedArgs {
-  T* cur; const T* theta_init; const T* P; const T* S; const T* mu;
-  T log_norm; T logdetP; int has_jitter; T jitter; int K; int series;
-  int64_t C; int D; int L; T eps; T rot_c; T rot_s;
-  int n_traj; int traj_offset; int burn; uint64_t seed; uint64_t chain_offset;
-  T* samples; int32_t* reject_count; T* H_old; T* H_new; uint8_t* accept;
-  const T* p_ws;                // pre-drawn momenta [n_traj, C, D] (rmhmc_momentum_kernel) or NULL: factor in the kernel
-};
 
 template <typename T> __device__ __forceinline__ T fast_rsqrt(T v) { return (T)1 / sqrt(v); }
 template <> __device__ __forceinline__ float fast_rsqrt<float>(float v) { return __builtin_amdgcn_rsqf(v); }   // v_rsq_f32, 1 ulp
@@ -773,7 +765,6 @@ __global__ __launch_bounds__(FNT) __attribute__((amdgpu_num_vgpr(HTA_FUSED_WIDE_
 // momentum draw is the next limit.
 // =============================================================================================
 constexpr int BNC = 16, BLD = 116, BWV = 7, BNT = 64 * BWV, BSEG = 28;
-typedef float bf4 __attribute__((ext_vector_type(4)));
 
 // BKJ: MFMAs per product and row tile = K / 4 (25 for D <= 100, 28 up to 112).  A vector is stored in four segments of BSEG
 // floats (16-byte aligned); element `row` sits in segment row / BKJ at offset row % BKJ.
@@ -1410,23 +1401,7 @@ __global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
 //  * the non-TRACK path ("rmhmc_pair" = 0) is the schedule of the two-wave kernel: same streams, same update order, same
 //    barriers; the sums run over even k then odd k (results agree to rounding).
 // =============================================================================================
-// (XHL = 68, XLD = 140: the 8 operand segments a group of 8 lanes reads at once - 4 chains x 16 bytes, two such groups per
-//  parity - start at banks 0, 12, 24, 36 (+4 for the odd parity): no two share a bank; 64 / 128 would put them on the same four)
-constexpr int XNC = 4, XHL = 68, XLD = 2 * XHL + 4, XWV = 4, XNT = 64 * XWV, XKJ = 52, XQ = XKJ / 4, XSQ = (XQ + 3) / 4, XBUF = 16;
-
-// lane l ^ 8's value (the same rows at the other contraction parity): a DPP rotation inside the 16-lane row
-__device__ __forceinline__ float other_parity(float h) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, h), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
-}
-// the 16-block product with the B operand of ALL four 16-lane groups taken from group S (blgp 4 + S; semantics probed on
-// gfx950 by tools/scratch/blgp_probe.cpp)
-template <int S> __device__ __forceinline__ bf4 mfma_from_group(float av, float bv, bf4 c) {
-  return __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, c, 0, 0, 4 + S);
-}
-template <int... I, typename F> __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-
+// (layout constants and the operand helpers: rmhmc_fused_dev.hpp)
 template <bool TRACK>
 __global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) {
   typedef float T;
@@ -2222,6 +2197,16 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
     const bool need_w = !(block > 0 && (series || !has_jitter));      // a Cholesky inside the kernel: work matrix in LDS
     auto launch = [&](auto kern, auto kern2, DevOnce& dn, DevOnce& dn2) -> int {
       if constexpr (sizeof(T) == 4) {
+        // one or two chains per workgroup, their state sets as columns of the 16-block matrix instruction (rmhmc_uv.hip): up to
+        // 2 x (compute units) chains (tuning key "rmhmc_uv": 0 off, 2 at any chain count)
+        const bool uv = g_rmhmc_uv && g_rmhmc_mfma4 != 2 && g_rmhmc_batch != 2 && !pair && block > 0 && (series || !has_jitter) && D <= QK &&
+                        (C <= 2 * (int64_t)fused_cu_count() || g_rmhmc_uv == 2);
+        if (uv) {
+          profile_begin(s);
+          const int rc_uv = rmhmc_uv_launch(a, fused_cu_count(), s);
+          profile_end(s);
+          return rc_uv;
+        }
         // four chains per workgroup on the 16-block matrix instruction: C / 4 two-wave workgroups (tuning key "rmhmc_mfma4")
         const bool quad4 = g_rmhmc_mfma4 && !pair && block > 0 && (series || !has_jitter) && D <= QK &&
                            ((C >= g_rmhmc_mfma4_lo && C < g_rmhmc_mfma4_hi) || g_rmhmc_mfma4 == 2);

@@ -304,6 +304,8 @@ int hta_mlp_logp_grad_f64(const double* theta, int64_t C, int n_in, int H, int a
  * on the caller's stream), "rmhmc_batch" (1 default: 16 chains per workgroup on the matrix cores from 2048 chains on; 0 off, 2 always),
  * "rmhmc_mfma4" (1 default: 4 chains per workgroup on v_mfma_f32_4x4x1_16b for "rmhmc_mfma4_lo" = 704 <= chains < "rmhmc_mfma4_hi" = 2049;
  * 0 off, 2 always; "rmhmc_mfma4_waves" 4 default: four waves per group - rows x contraction parity inside a wave; 2 = two waves;
+ * "rmhmc_uv" 1 default: up to 2 x (compute units) chains run one or two per workgroup with their state sets as columns of the
+ * matrix instruction - csrc/rmhmc_uv.hip; 0 off, 2 at any chain count;
  * "rmhmc_pair" 1 default: two consecutive half steps share K + 2 product phases, 0 = one half step at a time), "rmhmc_wide" (1 default: the spill-free one-workgroup-per-CU
  * instances of the one-chain kernel when chains <= compute units; 0 = always the two-workgroups-per-CU instances), "rmhmc_momwave" (1 default: one wave per momentum draw, fp32 with jitter, D <= 104; 0 = one workgroup per draw), "mlp_valu" (1 = VALU MLP kernel instead of the MFMA one),
  * "metric_mfma" (1 default: fp32 metric evaluations that share an eigenbasis, and Metric.HESSIAN ones, run on the matrix cores -

@@ -528,7 +528,8 @@ def test_batched_mfma_kernel_equals_fused_kernel(ht, D, C, jit):
     outs = []
     for mode in (2, 0):
         _abi.set_tuning("rmhmc_batch", mode)
-        _abi.set_tuning("rmhmc_mfma4", 0)           # (from 704 to 2048 chains the default route is rmhmc_mfma4_kernel)
+        _abi.set_tuning("rmhmc_mfma4", 0)           # (from 513 to 2048 chains the default route is a four-chain kernel,
+        _abi.set_tuning("rmhmc_uv", 0)              #  up to 512 chains rmhmc_uv_kernel)
         try:
             cur = th0.clone(); rej = torch.zeros(C, dtype=torch.int32, device=dev())
             samples = torch.zeros(T - burn + 1, C, D, device=dev())
@@ -539,6 +540,7 @@ def test_batched_mfma_kernel_equals_fused_kernel(ht, D, C, jit):
         finally:
             _abi.set_tuning("rmhmc_batch", 1)
             _abi.set_tuning("rmhmc_mfma4", 1)
+            _abi.set_tuning("rmhmc_uv", 1)
         outs.append((samples.cpu().numpy(), rej.cpu().numpy(), cur.cpu().numpy()))
     err = np.abs(outs[0][0] - outs[1][0]).max(axis=(0, 2))
     assert (err > 2e-4).mean() <= 0.05, "max err %.3g (%d chains differ)" % (err.max(), (err > 2e-4).sum())
@@ -582,6 +584,46 @@ def test_wave_momentum_kernel_equals_workgroup_kernel(ht, D, C, jit, batch):
     assert np.abs(outs[0][0][T - 1 - burn] - outs[0][0][1]).max() > 1e-3
 
 
+@pytest.mark.parametrize("D,C,jit", [(100, 40, 1e-3), (100, 301, 1e-3), (100, 24, None), (37, 30, 5e-2), (7, 9, 1e-3), (64, 18, 2e-3),
+                                     (65, 7, 1e-3), (3, 5, 1e-3), (100, 700, 1e-3)])
+def test_uv_kernel_equals_one_chain_kernel(ht, D, C, jit):
+    """rmhmc_uv_kernel (csrc/rmhmc_uv.hip: one chain per workgroup up to 256 chains, two beyond; a chain's state set and its
+    copy are two columns of v_mfma_f32_4x4x1_16b_f32, tracked products) against rmhmc_fused_kernel with every product evaluated
+    ("rmhmc_pair" = 0, one chain per workgroup on the vector ALUs): same streams and update order, sums in a different order ->
+    chain by chain to rounding; an odd chain count (half-empty last workgroup), no jitter (no solve phases), many refinements,
+    D on both sides of a wave's 32 rows, burn-in (Q2 reset), and beyond the default range ("rmhmc_uv" = 2 at 700 chains)."""
+    from hamiltorch_amd import _abi
+    T, L, burn = 9, 4, 2
+    t, _ = cfg3_target(ht, D, torch.float32, seed=5)
+    th0 = tt((0.3 * O.philox_normals(3, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32), torch.float32)
+    outs = []
+    try:
+        for uv in (2, 0):
+            _abi.set_tuning("rmhmc_uv", uv); _abi.set_tuning("rmhmc_pair", 1 if uv else 0)
+            _abi.set_tuning("rmhmc_mfma4", 0); _abi.set_tuning("rmhmc_batch", 0)
+            cur = th0.clone(); rej = torch.zeros(C, dtype=torch.int32, device=dev())
+            samples = torch.zeros(T - burn + 1, C, D, device=dev())
+            Ho = torch.zeros(T, C, device=dev()); Hn = torch.zeros(T, C, device=dev()); ac = torch.zeros(T, C, dtype=torch.uint8, device=dev())
+            ws = torch.empty(_abi.rmhmc_workspace_bytes(C, D, 4, T), dtype=torch.uint8, device=dev())
+            _abi.rmhmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, _abi.METRIC_SOFTABS, 1e6, jit, L, 0.1, 10.0,
+                                       T, 0, burn, 21, 0, samples, rej, ws, H_old=Ho, H_new=Hn, accept=ac)
+            torch.cuda.synchronize()
+            outs.append((samples.cpu().numpy(), rej.cpu().numpy(), cur.cpu().numpy(), Ho.cpu().numpy(), Hn.cpu().numpy(), ac.cpu().numpy()))
+    finally:
+        _abi.set_tuning("rmhmc_uv", 1); _abi.set_tuning("rmhmc_pair", 1)
+        _abi.set_tuning("rmhmc_mfma4", MFMA4_DEFAULT); _abi.set_tuning("rmhmc_batch", 1)
+    assert np.isfinite(outs[0][0]).all()
+    np.testing.assert_allclose(outs[0][3][0], outs[1][3][0], rtol=2e-5, atol=2e-4)      # H_old / H_new of the first trajectory:
+    np.testing.assert_allclose(outs[0][4][0], outs[1][4][0], rtol=2e-5, atol=2e-4)      # before any accept decision
+    err = np.abs(outs[0][0] - outs[1][0]).max(axis=(0, 2))
+    assert (err > 2e-4).mean() <= 0.05, "max err %.3g (%d chains differ)" % (err.max(), (err > 2e-4).sum())
+    good = err <= 2e-4
+    assert np.array_equal(outs[0][1][good], outs[1][1][good])
+    assert np.array_equal(outs[0][5][:, good], outs[1][5][:, good])
+    np.testing.assert_allclose(outs[0][2][good], outs[1][2][good], atol=2e-4)
+    assert np.abs(outs[0][0][T - 1 - burn] - outs[0][0][1]).max() > 1e-3
+
+
 @pytest.mark.parametrize("D,C,jit", [(100, 40, 1e-3), (100, 300, 1e-3), (100, 24, None), (37, 30, 5e-2), (20, 12, 1e-3), (64, 20, 2e-3),
                                      (3, 5, 1e-3)])
 def test_tracked_products_equal_explicit_products(ht, D, C, jit):
@@ -597,7 +639,7 @@ def test_tracked_products_equal_explicit_products(ht, D, C, jit):
     try:
         for pair in (1, 0):
             _abi.set_tuning("rmhmc_pair", pair)
-            _abi.set_tuning("rmhmc_mfma4", 0); _abi.set_tuning("rmhmc_batch", 0)
+            _abi.set_tuning("rmhmc_mfma4", 0); _abi.set_tuning("rmhmc_batch", 0); _abi.set_tuning("rmhmc_uv", 0)
             cur = th0.clone(); rej = torch.zeros(C, dtype=torch.int32, device=dev())
             samples = torch.zeros(T - burn + 1, C, D, device=dev())
             Ho = torch.zeros(T, C, device=dev()); Hn = torch.zeros(T, C, device=dev())
@@ -608,7 +650,7 @@ def test_tracked_products_equal_explicit_products(ht, D, C, jit):
             outs.append((samples.cpu().numpy(), rej.cpu().numpy(), cur.cpu().numpy(), Ho.cpu().numpy(), Hn.cpu().numpy()))
     finally:
         _abi.set_tuning("rmhmc_pair", 1)
-        _abi.set_tuning("rmhmc_mfma4", MFMA4_DEFAULT); _abi.set_tuning("rmhmc_batch", 1)
+        _abi.set_tuning("rmhmc_mfma4", MFMA4_DEFAULT); _abi.set_tuning("rmhmc_batch", 1); _abi.set_tuning("rmhmc_uv", 1)
     assert np.isfinite(outs[0][0]).all()
     np.testing.assert_allclose(outs[0][4][0], outs[1][4][0], rtol=2e-5, atol=2e-4)      # H_new of the first trajectory: before any accept decision
     err = np.abs(outs[0][0] - outs[1][0]).max(axis=(0, 2))
@@ -635,8 +677,9 @@ def test_mfma4_kernel_equals_fused_kernel(ht, D, C, jit):
         for mode, waves, pair in ((on, 4, 1), (0, 4, 1), (on, 2, 1), (on, 4, 0)):
             _abi.set_tuning("rmhmc_mfma4", mode)
             _abi.set_tuning("rmhmc_mfma4_waves", waves)          # 4: rmhmc_mfma4x4_kernel (default), 2: rmhmc_mfma4_kernel
-            _abi.set_tuning("rmhmc_pair", pair)                  # 1: two half steps in K + 2 product phases (default), 0: one at a time
+            _abi.set_tuning("rmhmc_pair", pair)                  # 1: tracked products (default), 0: every product of every half step
             _abi.set_tuning("rmhmc_batch", 0)
+            _abi.set_tuning("rmhmc_uv", 0)                       # (mode 0: the one-chain kernel, the reference)
             cur = th0.clone(); rej = torch.zeros(C, dtype=torch.int32, device=dev())
             samples = torch.zeros(T - burn + 1, C, D, device=dev())
             ws = torch.empty(_abi.rmhmc_workspace_bytes(C, D, 4, T), dtype=torch.uint8, device=dev())
@@ -649,6 +692,7 @@ def test_mfma4_kernel_equals_fused_kernel(ht, D, C, jit):
         _abi.set_tuning("rmhmc_mfma4_waves", 4)
         _abi.set_tuning("rmhmc_pair", 1)
         _abi.set_tuning("rmhmc_batch", 1)
+        _abi.set_tuning("rmhmc_uv", 1)
     assert np.isfinite(outs[0][0]).all()
     err2 = np.abs(outs[0][0] - outs[2][0]).max(axis=(0, 2))          # four-wave kernel against the two-wave kernel
     assert (err2 > 2e-4).mean() <= 0.05, "four- vs two-wave kernel: max err %.3g (%d chains differ)" % (err2.max(), (err2 > 2e-4).sum())

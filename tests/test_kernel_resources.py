@@ -49,7 +49,7 @@ def test_spill_budget_of_the_hot_kernels(kernels):
     no register lives there).  Still bounded, not zero: the two-workgroups-per-CU instance of the one-chain kernel (256-register
     cap, used from 257 to 703 chains) and the MLP MFMA kernel (128-register cap from two 448-thread workgroups per CU)."""
     clean = ["hmc_gauss_quad_kernel", "hmc_gauss_eig_kernel", "hmc_gauss_wave_eig_kernel", "rmhmc_batch_kernel", "rmhmc_mfma4_kernel",
-             "rmhmc_mfma4x4_kernel", "rmhmc_momentum_wave_kernel", "rmhmc_momentum_kernel"]
+             "rmhmc_mfma4x4_kernel", "rmhmc_uv_kernel", "rmhmc_momentum_wave_kernel", "rmhmc_momentum_kernel"]
     for h in clean:
         for k in _find(kernels, h):
             assert kernels[k]["scratch"] == 0 and kernels[k]["spill"] == 0, (k, kernels[k])
