@@ -263,19 +263,24 @@ class Cfg3:
         return self.C * self.T * self.L
 
     def executed_flops_per_unit(self):
-        # flops the fused kernel executes per explicit step (csrc/rmhmc_fused.hip): 4 half steps x (2 + K) symmetric
-        # matrix-vector products (K = 2 refinements at jitter 1e-3) + the trajectory's Cholesky (D^3 / 3 FMAs) spread over
-        # its L steps.
-        return 4 * 4 * 2 * self.D ** 2 + (2 * self.D ** 3 / 3) / self.L
+        # flops the trajectory kernels execute per explicit step (csrc/rmhmc_fused.hip, csrc/rmhmc_uv.hip, tracked schedule):
+        # 4 half steps x K refinement products (K = 2 at jitter 1e-3) + the 4 products after the rotation = 12 symmetric
+        # matrix-vector products (round 1: 4 x (2 + K) = 16) + the trajectory's Cholesky (D^3 / 3 FMAs) spread over its L steps.
+        return (4 * 2 + 4) * 2 * self.D ** 2 + (2 * self.D ** 3 / 3) / self.L
 
     @property
     def roof_kernel(self):      # the trajectory kernel the library picks at this chain count (csrc/rmhmc_fused.hip dispatch)
         if self.jacobi:
             return "metric_eval_kernel<float> (+ phi_c_kernel, mh_select)"
+        if self.C <= 512:
+            return "rmhmc_uv_kernel<%d> (%s per workgroup: state set and copy as columns of v_mfma_f32_4x4x1_16b)" % (
+                (1, "one chain") if self.C <= 256 else (2, "two chains"))
         if self.C < 704:
-            return "rmhmc_fused_kernel<float,56,1> (one chain per workgroup)"
+            return "rmhmc_fused_kernel<float,56,1,true> (one chain per workgroup, vector ALUs)"
+        if self.C <= 1024:
+            return "rmhmc_mfma4x4_kernel<true> (4 chains per four-wave workgroup, v_mfma_f32_4x4x1_16b)"
         if self.C <= 2048:
-            return "rmhmc_mfma4_kernel (4 chains per workgroup, v_mfma_f32_4x4x1_16b)"
+            return "rmhmc_mfma4_kernel (4 chains per two-wave workgroup, v_mfma_f32_4x4x1_16b)"
         return "rmhmc_batch_kernel<25> (16 chains per workgroup, v_mfma_f32_16x16x4) + rmhmc_momentum_wave_kernel<13>"
 
     def bytes_per_unit(self):

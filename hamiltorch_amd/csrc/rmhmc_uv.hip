@@ -250,7 +250,14 @@ __global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
         const uint32_t k0 = 2u + 8u * (uint32_t)lstep;
         // jitter: in S:429-433 the set that moves first (U) solves with sub-stream k0 + 2 and V with k0 + 1; in S:454-458 V moves
         // first (k0 + 7) and U second (k0 + 4).  The even parity draws this column's block of the first pair, the odd parity
-        // that of the second pair, then they exchange: one Philox pass per step and lane.
+        // that of the second pair, then they exchange: one Philox pass per step and lane (about 1000 clocks of a 9000-clock
+        // step).  Measured and rejected (profiles/README.md, r02r - r02t): the pass's rounds issued one per chunk of eight matrix
+        // instructions of the refresh phase - 1.5x SLOWER (3.08e7 against 4.71e7 steps/s at 256 chains: a wave issues in order,
+        // a quarter-rate multiply holds back the matrix instructions behind it); one round in each window where a phase waits for
+        // LDS (after the operand fetch, between the stores and the barrier) - 5 % slower; the kernel under a 256-register cap so
+        // that two workgroups share a CU's SIMDs (17 registers in scratch) - 1024 chains as 512 two-chain workgroups then reach
+        // 1.18e8, the four-chain kernel 1.15e8 in the same run, while 512 chains lose 15 %: a second resident wave does not hide
+        // the phases' fixed costs, they are issue time, not idle time.
         T e1[4] = {0.f, 0.f, 0.f, 0.f}, e2[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.has_jitter) {
           const uint32_t sub1 = setV ? k0 + 1u : k0 + 2u, sub2 = setV ? k0 + 7u : k0 + 4u;
