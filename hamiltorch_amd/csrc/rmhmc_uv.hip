@@ -255,9 +255,9 @@ __global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
         // instructions of the refresh phase - 1.5x SLOWER (3.08e7 against 4.71e7 steps/s at 256 chains: a wave issues in order,
         // a quarter-rate multiply holds back the matrix instructions behind it); one round in each window where a phase waits for
         // LDS (after the operand fetch, between the stores and the barrier) - 5 % slower; the kernel under a 256-register cap so
-        // that two workgroups share a CU's SIMDs (17 registers in scratch) - 1024 chains as 512 two-chain workgroups then reach
-        // 1.18e8, the four-chain kernel 1.15e8 in the same run, while 512 chains lose 15 %: a second resident wave does not hide
-        // the phases' fixed costs, they are issue time, not idle time.
+        // that two workgroups share a CU's SIMDs - with P's operands in LDS instead of registers (nothing in scratch inside the
+        // step loop) 1024 chains as 512 two-chain workgroups reach 9.2e7 where the four-chain kernel does 1.15e8 in the same
+        // run, and 512 chains lose 15 %: a second resident workgroup bought no overlap at all.
         T e1[4] = {0.f, 0.f, 0.f, 0.f}, e2[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.has_jitter) {
           const uint32_t sub1 = setV ? k0 + 1u : k0 + 2u, sub2 = setV ? k0 + 7u : k0 + 4u;
