@@ -275,8 +275,6 @@ class Cfg3:
         if self.C <= 512:
             return "rmhmc_uv_kernel<%d> (%s per workgroup: state set and copy as columns of v_mfma_f32_4x4x1_16b)" % (
                 (1, "one chain") if self.C <= 256 else (2, "two chains"))
-        if self.C < 704:
-            return "rmhmc_fused_kernel<float,56,1,true> (one chain per workgroup, vector ALUs)"
         if self.C <= 1024:
             return "rmhmc_mfma4x4_kernel<true> (4 chains per four-wave workgroup, v_mfma_f32_4x4x1_16b)"
         if self.C <= 2048:

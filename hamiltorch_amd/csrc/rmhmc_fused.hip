@@ -1026,18 +1026,22 @@ __global__ __launch_bounds__(BNT) void rmhmc_batch_kernel(FusedArgs<float> a) {
 // the launch) and X[n][k] (LDS, 16-byte reads, the same address for the 16 lanes of a chain) and receives
 // C[64w + 4b + r][n], r < 4: four consecutive rows of chain n = one Philox block of jitter, element-wise work in registers.
 // Same streams, same update order and barriers as rmhmc_batch_kernel; a product's sum runs over k = 0 .. D-1 in order.
+// TRACK ("rmhmc_pair" = 1, the default): the tracked-products schedule derived at rmhmc_mfma4x4_kernel - 12 products in 5 phases
+// per step at K = 2 instead of 16 in 8 (2048 chains: 1.36e8 -> 1.59e8 steps/s, 1536: 1.10e8 -> 1.29e8).  This kernel serves
+// 1025 .. 2048 chains per GPU, where two of its workgroups fill a CU's four SIMDs.
 // =============================================================================================
-constexpr int QNC = 4, QLD = 116, QWV = 2, QNT = 64 * QWV, QK = 100;
+constexpr int QNC = 4, QLD = 116, QWV = 2, QNT = 64 * QWV, QK = 100, QBUF = 16;
 
-template <bool PAIRED>
+template <bool TRACK>
 __global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
   typedef float T;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
   constexpr int MSZ = QNC * QLD;
   T* PM = lds; T* PMC = PM + MSZ; T* D0 = PMC + MSZ; T* D1 = D0 + MSZ; T* W0 = D1 + MSZ; T* W1 = W0 + MSZ; T* EV = W1 + MSZ;
-  T* V0 = EV + MSZ; T* V1 = V0 + MSZ;                     // the second half step's refinement vectors (half_pair)
-  T* red = V1 + MSZ;                                      // [QWV][QNC][4]
+  T* DC = EV + MSZ;                                       // tracked products: theta_c - mu (D1: theta - mu)
+  T* WS = DC + MSZ;                                       // tracked products: 2 pairs x 2 solves x 2 refinement vectors
+  T* red = WS + 8 * MSZ;                                  // [QWV][QNC][4]
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cl = l & 3, blk = l >> 2;
   const int D = a.D;
   const int row0 = 64 * w + 4 * blk, arow = 64 * w + l;
@@ -1057,9 +1061,8 @@ __global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
     mu_r[e] = rok[e] ? a.mu[r] : 0.f;
     sd_r[e] = rok[e] ? a.S[(int64_t)r * D + r] : 0.f;
   }
-  for (int e = tid; e < 9 * MSZ + QWV * QNC * 4; e += QNT) lds[e] = 0.f;
+  for (int e = tid; e < QBUF * MSZ + QWV * QNC * 4; e += QNT) lds[e] = 0.f;
   const T eh = 0.5f * a.eps;
-  const bool paired = PAIRED && a.K >= 1;
   const bool rany = row0 < QLD;                           // rows 116 .. 127 have no slot (and are >= D)
   const int own_off = cl * QLD + row0, b_off = cl * QLD;
   int dpar = 0;
@@ -1146,86 +1149,71 @@ __global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) upd_x[e] += eh * xr[e];
   };
-  // TWO consecutive half steps, a then b, as K + 2 product phases instead of 2 (K + 1): the schedule of
-  // rmhmc_mfma4x4_kernel's half_pair (see there: same products, operands and summation order as two half_step calls).
-  //   a:  g1 -= eh P (X1 - mu)   X2 += eh (P + E_a)^-1 G2        b:  g2 -= eh P (X2 - mu)   X1 += eh (P + E_b)^-1 G1
-  auto half_pair = [&](uint32_t n, uint32_t suba, uint32_t subb, T (&X1)[4], T (&X2)[4], T (&g1)[4], T* G1, T (&g2)[4], T* G2, bool publish) {
-    T dv[4], wv[4], x0a[4], xra[4], x0b[4], xrb[4], ea[4];
+  // ---- TRACK: the tracked-products schedule of rmhmc_mfma4x4_kernel (derivation there) in this kernel's layout ----------
+  T y[4], yc[4], z[4], zc[4];
+  auto prod4 = [&](const T* X1, const T* X2, const T* X3, const T* X4, bf4& p1, bf4& p2, bf4& s3, bf4& s4) {   // P X1, P X2, S X3, S X4
+    bf4 c1 = chunk(X1, 0), c2 = chunk(X2, 0), c3 = chunk(X3, 0), c4 = chunk(X4, 0);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) dv[e] = rok[e] ? X1[e] - mu_r[e] : 0.f;
-    put4(D0, dv);
-    __syncthreads();
-    {                                                      // phase 1
-      bf4 Pd = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
-      prod2(Pa, D0, Sa, G2, Pd, xv);
-      jitter4(n, suba);
+    for (int q = 0; q < QK / 4; ++q) {
+      bf4 n1 = c1, n2 = c2, n3 = c3, n4 = c4;
+      if (q + 1 < QK / 4) { n1 = chunk(X1, q + 1); n2 = chunk(X2, q + 1); n3 = chunk(X3, q + 1); n4 = chunk(X4, q + 1); }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        ea[e] = ev_r[e];
-        g1[e] -= eh * Pd[e];
-        x0a[e] = xv[e]; xra[e] = xv[e];
-        wv[e] = ea[e] * xv[e];
+      for (int u = 0; u < 4; ++u) {
+        p1 = __builtin_amdgcn_mfma_f32_4x4x1f32(Pa[4 * q + u], c1[u], p1, 0, 0, 0);
+        p2 = __builtin_amdgcn_mfma_f32_4x4x1f32(Pa[4 * q + u], c2[u], p2, 0, 0, 0);
+        s3 = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q + u], c3[u], s3, 0, 0, 0);
+        s4 = __builtin_amdgcn_mfma_f32_4x4x1f32(Sa[4 * q + u], c4[u], s4, 0, 0, 0);
       }
-      put4(G1, g1);
-      put4(W0, wv);
+      __builtin_amdgcn_sched_barrier(0);
+      c1 = n1; c2 = n2; c3 = n3; c4 = n4;
     }
-    auto finish_a = [&]() {                                // a's solve is complete: its position update, and b's P operand
+  };
+  // two independent solves x = (P + E)^-1 m from x_0 = S m, K phases; wa / wb return e . x_(K-1) (zero without jitter)
+  auto solve2 = [&](T* WB, const T (&ea)[4], const T (&eb)[4], const T (&x0a)[4], const T (&x0b)[4], T (&xa)[4], T (&xb)[4],
+                    T (&wa)[4], T (&wb)[4]) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        X2[e] += eh * xra[e];
-        dv[e] = rok[e] ? X2[e] - mu_r[e] : 0.f;
-      }
-      put4(D1, dv);
-    };
-    __syncthreads();
-    {                                                      // phase 2: a's refinement 0, b's S G1
-      bf4 ra = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
-      prod2(Sa, W0, Sa, G1, ra, xv);
-      jitter4(n, subb);                                     // ev_r: b's jitter from here on
+    for (int e = 0; e < 4; ++e) { xa[e] = x0a[e]; xb[e] = x0b[e]; wa[e] = 0.f; wb[e] = 0.f; }
+    for (int it = 0; it < a.K; ++it) {
+      T* A = WB + (it & 1) * MSZ;                           // read in this phase only; rewritten two phases later
+      T* B = A + 2 * MSZ;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        xra[e] = x0a[e] - ra[e];
-        x0b[e] = xv[e]; xrb[e] = xv[e];
-      }
-      if (a.K > 1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) wv[e] = ea[e] * xra[e];
-        put4(W1, wv);
-      } else finish_a();
-#pragma unroll
-      for (int e = 0; e < 4; ++e) wv[e] = ev_r[e] * xrb[e];
-      put4(V0, wv);
-    }
-    for (int it = 1; it < a.K; ++it) {                     // phases 3 .. K+1: a's refinement it, b's refinement it - 1
-      const T* wa = (it & 1) ? W1 : W0;
-      T* wan = (it & 1) ? W0 : W1;
-      const T* wb = (it & 1) ? V0 : V1;
-      T* wbn = (it & 1) ? V1 : V0;
+      for (int e = 0; e < 4; ++e) { wa[e] = ea[e] * xa[e]; wb[e] = eb[e] * xb[e]; }
+      put4(A, wa);
+      put4(B, wb);
       __syncthreads();
       bf4 ra = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
-      prod2(Sa, wa, Sa, wb, ra, rb);
+      prod2(Sa, A, Sa, B, ra, rb);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { xra[e] = x0a[e] - ra[e]; xrb[e] = x0b[e] - rb[e]; }
-      if (it + 1 < a.K) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) wv[e] = ea[e] * xra[e];
-        put4(wan, wv);
-      } else finish_a();
-#pragma unroll
-      for (int e = 0; e < 4; ++e) wv[e] = ev_r[e] * xrb[e];
-      put4(wbn, wv);
+      for (int e = 0; e < 4; ++e) { xa[e] = x0a[e] - ra[e]; xb[e] = x0b[e] - rb[e]; }
     }
-    __syncthreads();
-    {                                                      // phase K+2: b's P d_b and its last refinement
-      const T* wb = ((a.K - 1) & 1) ? V1 : V0;
-      bf4 Pd = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
-      prod2(Pa, D1, Sa, wb, Pd, rb);
+  };
+  // a pair of half steps (S:429-433 and, with the roles of the copies swapped, S:454-458):
+  //   a:  g1 -= eh P (X1 - mu)   X2 += eh (P + E_a)^-1 g2        b:  g2 -= eh P (X2 - mu)   X1 += eh (P + E_b)^-1 g1
+  // with y1 = P (X1 - mu), y2 = P (X2 - mu), z1 = S g1, z2 = S g2 kept current
+  auto pair_tracked = [&](T* WB, uint32_t n, uint32_t suba, uint32_t subb, T (&X1)[4], T (&X2)[4], T (&g1)[4], T (&g2)[4],
+                          T (&y1)[4], T (&y2)[4], T (&z1)[4], T (&z2)[4]) {
+    T ea[4], eb[4];
+    jitter4(n, suba);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        g2[e] -= eh * Pd[e];
-        X1[e] += eh * (x0b[e] - rb[e]);
-      }
-      if (publish) put4(G2, g2);
+    for (int e = 0; e < 4; ++e) ea[e] = ev_r[e];
+    jitter4(n, subb);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      eb[e] = ev_r[e];
+      g1[e] -= eh * y1[e];                                  // a's momentum update ...
+      z1[e] -= eh * (rok[e] ? X1[e] - mu_r[e] : 0.f);       // ... and S g1 with it
+    }
+    T xa[4], xb[4], wa[4], wb[4];
+    solve2(WB, ea, eb, z2, z1, xa, xb, wa, wb);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      X2[e] += eh * xa[e];                                  // a's position update; P x_a = g2 - e_a . x_a(K-1)
+      y2[e] += eh * (g2[e] - wa[e]);
+      g2[e] -= eh * y2[e];                                  // b's momentum update
+      z2[e] -= eh * (rok[e] ? X2[e] - mu_r[e] : 0.f);
+      X1[e] += eh * xb[e];                                  // b's position update
+      y1[e] += eh * (g1[e] - wb[e]);
     }
   };
   // three sums per chain over the rows, complete in every lane of the chain's column
@@ -1252,8 +1240,9 @@ __global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
     }
   };
   // H = -log p + D/2 log 2 pi + 1/2 log|G| + 1/2 m^T G^-1 m  (S:731)   (rmhmc_fused_kernel: hamiltonian, series branch)
-  auto hamiltonian = [&](uint32_t n, uint32_t sub, const T (&X)[4], const T* m, const T (&mr)[4], T& H, T& logp) {
-    T* d = (dpar && !paired) ? D1 : D0;                     // (paired: D1's last readers may still be in half_pair's last phase)
+  auto hamiltonian = [&](uint32_t n, uint32_t sub, const T (&X)[4], const T* m, const T (&mr)[4], T& H, T& logp, T (&Pd_out)[4],
+                         T (&Sm_out)[4]) {
+    T* d = (dpar && !TRACK) ? D1 : D0;                      // (TRACK: D1 belongs to the refresh phase)
     dpar ^= 1;
     jitter4(n, sub);
     T dr[4];
@@ -1285,6 +1274,7 @@ __global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       x0[e] = x0v[e]; xr[e] = x0v[e];
+      Pd_out[e] = Pd[e]; Sm_out[e] = x0v[e];
       v[0] += dr[e] * Pd[e];
       wv[e] = ev_r[e] * x0v[e];
       if (a.has_jitter) v[2] += ev_r[e] * (sd_r[e] - 0.5f * s2[e]);      // log|P + E| = log|P| + tr(SE) - 1/2 tr((SE)^2) + ...
@@ -1316,13 +1306,13 @@ __global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
       for (int e = 0; e < 4; ++e) spm[e] = (live && rok[e]) ? a.p_ws[((int64_t)t * a.C + c) * D + row0 + e] : 0.f;
       put4(PM, spm);
       T H0, H1, lp0, lp1;
-      hamiltonian(n, 1, scur, PM, spm, H0, lp0);            // S:971 -> S:822
+      hamiltonian(n, 1, scur, PM, spm, H0, lp0, y, z);      // S:971 -> S:822
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { sth[e] = scur[e]; sthc[e] = scur[e]; spmc[e] = spm[e]; }   // S:425-426
-      put4(PMC, spm);
+      for (int e = 0; e < 4; ++e) { sth[e] = scur[e]; sthc[e] = scur[e]; spmc[e] = spm[e]; yc[e] = y[e]; zc[e] = z[e]; }   // S:425-426
+      if (!TRACK) put4(PMC, spm);
       for (int lstep = 0; lstep < a.L; ++lstep) {           // S:427-461
         const uint32_t k0 = 2u + 8u * (uint32_t)lstep;
-        if (paired) half_pair(n, k0 + 1, k0 + 2, sth, sthc, spm, PM, spmc, PMC, false);   // phi_A/2, phi_B/2  S:429-433 (the rotation publishes PMC)
+        if (TRACK) pair_tracked(WS, n, k0 + 1, k0 + 2, sth, sthc, spm, spmc, y, yc, z, zc);    // phi_A/2, phi_B/2  S:429-433
         else {
           half_step(n, k0 + 1, sth, PMC, sthc, spm, PM);    // phi_A/2  S:429-430
           half_step(n, k0 + 2, sthc, PM, sth, spmc, PMC);   // phi_B/2  S:432-433
@@ -1340,13 +1330,29 @@ __global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
         }
         put4(PM, spm);
         put4(PMC, spmc);
-        if (paired) half_pair(n, k0 + 4, k0 + 7, sthc, sth, spmc, PMC, spm, PM, true);    // phi_B/2, phi_A/2  S:454-458
-        else {
+        if (TRACK) {                                        // the four tracked products of the rotated state, afresh
+          T dt[4], dc[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { dt[e] = rok[e] ? sth[e] - mu_r[e] : 0.f; dc[e] = rok[e] ? sthc[e] - mu_r[e] : 0.f; }
+          put4(D1, dt);
+          put4(DC, dc);
+          __syncthreads();
+          bf4 p1 = {0.f, 0.f, 0.f, 0.f}, p2 = {0.f, 0.f, 0.f, 0.f}, s3 = {0.f, 0.f, 0.f, 0.f}, s4 = {0.f, 0.f, 0.f, 0.f};
+          prod4(D1, DC, PM, PMC, p1, p2, s3, s4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { y[e] = p1[e]; yc[e] = p2[e]; z[e] = s3[e]; zc[e] = s4[e]; }
+          pair_tracked(WS + 4 * MSZ, n, k0 + 4, k0 + 7, sthc, sth, spmc, spm, yc, y, zc, z);   // phi_B/2, phi_A/2  S:454-458
+        } else {
           half_step(n, k0 + 4, sthc, PM, sth, spmc, PMC);   // phi_B/2  S:454-455
           half_step(n, k0 + 7, sth, PMC, sthc, spm, PM);    // phi_A/2  S:457-458
         }
       }
-      hamiltonian(n, 2u + 8u * (uint32_t)a.L, sth, PM, spm, H1, lp1);   // S:989 (Q4)
+      if (TRACK) {                                          // (the tracked half steps keep the momenta in registers)
+        if (a.K == 0) __syncthreads();                      // no solve phase since the refresh phase read PM
+        put4(PM, spm);
+      }
+      T unused1[4], unused2[4];
+      hamiltonian(n, 2u + 8u * (uint32_t)a.L, sth, PM, spm, H1, lp1, unused1, unused2);   // S:989 (Q4)
       // ---- Metropolis test + bookkeeping (S:1000-1026, S:1045-1057)
       const T u = u23<T>(philox_block(a.seed, chain, n, PURPOSE_MH, 0, 0).x);
       const bool acc = mh_accept<T>(H0, H1, lp1, u);
@@ -1377,7 +1383,7 @@ __global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
 }
 
 // =============================================================================================
-// The four-chain kernel on ALL FOUR SIMDs of a CU (the default from 704 to 1024 chains; "rmhmc_mfma4_waves" = 2 keeps the
+// The four-chain kernel on ALL FOUR SIMDs of a CU (the default from 513 to 1024 chains; "rmhmc_mfma4_waves" = 2 keeps the
 // two-wave kernel above, its parity reference).
 //
 // At 1024 chains there are 256 groups of four chains - one workgroup per CU - and the two-wave kernel leaves two of the four
@@ -2216,7 +2222,7 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
           // four waves per group while the groups fit one per CU (<= 1024 chains on 256 CUs): beyond that two groups share a CU
           // and the two-wave kernel already fills its four SIMDs
           if (g_rmhmc_mfma4_waves == 2 || (g_rmhmc_mfma4_waves != 5 && ngroup > 256)) {
-            const size_t qlds = (size_t)(9 * QNC * QLD + QWV * QNC * 4) * sizeof(float);
+            const size_t qlds = (size_t)(QBUF * QNC * QLD + QWV * QNC * 4) * sizeof(float);
             if (g_rmhmc_pair) rmhmc_mfma4_kernel<true><<<(int)(ngroup < 8192 ? ngroup : 8192), QNT, qlds, s>>>(a);
             else rmhmc_mfma4_kernel<false><<<(int)(ngroup < 8192 ? ngroup : 8192), QNT, qlds, s>>>(a);
           } else {

@@ -302,7 +302,7 @@ int hta_mlp_logp_grad_f64(const double* theta, int64_t C, int n_in, int H, int a
  * one chain per lane only, 3 = quad kernel without the compiled-in step counts), "quad_max_chains" (65536), "rmhmc_fused"
  * (1 default; 0 = per-evaluation Jacobi path, 3 = two chains per workgroup), "rmhmc_overlap" (1 default; 0 = momentum draws
  * on the caller's stream), "rmhmc_batch" (1 default: 16 chains per workgroup on the matrix cores from 2048 chains on; 0 off, 2 always),
- * "rmhmc_mfma4" (1 default: 4 chains per workgroup on v_mfma_f32_4x4x1_16b for "rmhmc_mfma4_lo" = 704 <= chains < "rmhmc_mfma4_hi" = 2049;
+ * "rmhmc_mfma4" (1 default: 4 chains per workgroup on v_mfma_f32_4x4x1_16b for "rmhmc_mfma4_lo" = 513 <= chains < "rmhmc_mfma4_hi" = 2049;
  * 0 off, 2 always; "rmhmc_mfma4_waves" 4 default: four waves per group - rows x contraction parity inside a wave; 2 = two waves;
  * "rmhmc_uv" 1 default: up to 2 x (compute units) chains run one or two per workgroup with their state sets as columns of the
  * matrix instruction - csrc/rmhmc_uv.hip; 0 off, 2 at any chain count;

@@ -673,7 +673,7 @@ def test_mfma4_kernel_equals_fused_kernel(ht, D, C, jit):
     th0 = tt((0.3 * O.philox_normals(3, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32), torch.float32)
     outs = []
     try:
-        on = 2 if C < 704 else 1                                 # from 704 to 2048 chains it is the default route
+        on = 2 if C < 513 else 1                                 # from 513 to 2048 chains it is the default route
         for mode, waves, pair in ((on, 4, 1), (0, 4, 1), (on, 2, 1), (on, 4, 0)):
             _abi.set_tuning("rmhmc_mfma4", mode)
             _abi.set_tuning("rmhmc_mfma4_waves", waves)          # 4: rmhmc_mfma4x4_kernel (default), 2: rmhmc_mfma4_kernel
