@@ -762,20 +762,27 @@ __global__ __launch_bounds__(FNT) __attribute__((amdgpu_num_vgpr(HTA_FUSED_WIDE_
 // D = 100) and by its pass latency (7 row tiles on 4 SIMDs: 2 x 56 MFMAs x 32 clk per first pass): measured against one chain
 // per workgroup 0.6x / 0.96x / 1.19x / 1.37x at 512 / 1024 / 2048 / 4096 chains (tools/scratch/pair_check.py), so it is taken
 // from 2048 chains per GPU on (hta_set_tuning("rmhmc_batch", 0) off, 2 always); there the per-trajectory Cholesky of the
-// momentum draw is the next limit.
+// momentum draw is the next limit.  TRACK ("rmhmc_pair" = 1, the default): the tracked-products schedule derived at
+// rmhmc_mfma4x4_kernel (4096 chains: 1.56e8 -> 1.84e8 steps/s, 3072: 1.24e8 -> 1.47e8).
 // =============================================================================================
-constexpr int BNC = 16, BLD = 116, BWV = 7, BNT = 64 * BWV, BSEG = 28;
+constexpr int BNC = 16, BLD = 116, BWV = 7, BNT = 64 * BWV, BSEG = 28, BBUF = 12;
 
 // BKJ: MFMAs per product and row tile = K / 4 (25 for D <= 100, 28 up to 112).  A vector is stored in four segments of BSEG
 // floats (16-byte aligned); element `row` sits in segment row / BKJ at offset row % BKJ.
-template <int BKJ>
+template <int BKJ, bool TRACK>
 __global__ __launch_bounds__(BNT) void rmhmc_batch_kernel(FusedArgs<float> a) {
   typedef float T;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
   constexpr int MSZ = BNC * BLD;
-  T* PM = lds; T* PMC = PM + MSZ; T* D0 = PMC + MSZ; T* D1 = D0 + MSZ; T* W0 = D1 + MSZ; T* W1 = W0 + MSZ; T* EV = W1 + MSZ;
-  T* red = EV + MSZ;                                      // [BWV][BNC][4]
+  T* PM = lds; T* PMC = PM + MSZ; T* D1 = PMC + MSZ;
+  T* DC = D1 + MSZ;                                       // tracked products: theta_c - mu (D1: theta - mu)
+  T* D0 = DC + MSZ; T* W0 = D0 + MSZ; T* W1 = W0 + MSZ; T* EV = W1 + MSZ;
+  // tracked products: 2 pairs x 2 solves x 2 refinement vectors.  The first pair's four ARE the Hamiltonians' D0 W0 W1 EV
+  // (contiguous): a Hamiltonian and the first pair of a step are always separated by barriers (block_sums / the solve phases of
+  // the second pair), and the whole set stays at 12 matrices = 88 KB
+  T* WS2 = EV + MSZ;
+  T* red = WS2 + 4 * MSZ;                                 // [BWV][BNC][4]
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cl = l & 15, g = l >> 4;
   const int D = a.D;
   const int row0 = 16 * w + 4 * g, arow = 16 * w + cl;
@@ -796,7 +803,7 @@ __global__ __launch_bounds__(BNT) void rmhmc_batch_kernel(FusedArgs<float> a) {
     mu_r[e] = rok[e] ? a.mu[r] : 0.f;
     sd_r[e] = rok[e] ? a.S[(int64_t)r * D + r] : 0.f;
   }
-  for (int e = tid; e < 7 * MSZ + BWV * BNC * 4; e += BNT) lds[e] = 0.f;
+  for (int e = tid; e < BBUF * MSZ + BWV * BNC * 4; e += BNT) lds[e] = 0.f;
   const T eh = 0.5f * a.eps;
   int own_pos[4];
 #pragma unroll
@@ -879,6 +886,99 @@ __global__ __launch_bounds__(BNT) void rmhmc_batch_kernel(FusedArgs<float> a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) upd_x[e] += eh * xr[e];
   };
+  // ---- TRACK: the tracked-products schedule of rmhmc_mfma4x4_kernel (derivation there) in this kernel's layout ----------
+  T y[4], yc[4], z[4], zc[4];
+  // two independent solves x = (P + E)^-1 m from x_0 = S m, K phases; wa / wb return e . x_(K-1) (zero without jitter)
+  auto solve2 = [&](T* WB, const T (&ea)[4], const T (&eb)[4], const T (&x0a)[4], const T (&x0b)[4], T (&xa)[4], T (&xb)[4],
+                    T (&wa)[4], T (&wb)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { xa[e] = x0a[e]; xb[e] = x0b[e]; wa[e] = 0.f; wb[e] = 0.f; }
+    for (int it = 0; it < a.K; ++it) {
+      T* A = WB + (it & 1) * MSZ;                           // read in this phase only; rewritten two phases later
+      T* B = A + 2 * MSZ;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { wa[e] = ea[e] * xa[e]; wb[e] = eb[e] * xb[e]; }
+      put4(A, wa);
+      put4(B, wb);
+      __syncthreads();
+      T ba[BKJ], bb[BKJ];
+      load_b(A, ba);
+      load_b(B, bb);
+      bf4 ra = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < BKJ; ++j) {
+        ra = __builtin_amdgcn_mfma_f32_16x16x4f32(Sa[j], ba[j], ra, 0, 0, 0);
+        rb = __builtin_amdgcn_mfma_f32_16x16x4f32(Sa[j], bb[j], rb, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { xa[e] = x0a[e] - ra[e]; xb[e] = x0b[e] - rb[e]; }
+    }
+  };
+  // a pair of half steps (S:429-433 and, with the roles of the copies swapped, S:454-458):
+  //   a:  g1 -= eh P (X1 - mu)   X2 += eh (P + E_a)^-1 g2        b:  g2 -= eh P (X2 - mu)   X1 += eh (P + E_b)^-1 g1
+  // with y1 = P (X1 - mu), y2 = P (X2 - mu), z1 = S g1, z2 = S g2 kept current
+  auto pair_tracked = [&](T* WB, uint32_t n, uint32_t suba, uint32_t subb, T (&X1)[4], T (&X2)[4], T (&g1)[4], T (&g2)[4],
+                          T (&y1)[4], T (&y2)[4], T (&z1)[4], T (&z2)[4]) {
+    T ea[4], eb[4];
+    jitter4(n, suba);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ea[e] = ev_r[e];
+    jitter4(n, subb);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      eb[e] = ev_r[e];
+      g1[e] -= eh * y1[e];                                  // a's momentum update ...
+      z1[e] -= eh * (rok[e] ? X1[e] - mu_r[e] : 0.f);       // ... and S g1 with it
+    }
+    T xa[4], xb[4], wa[4], wb[4];
+    solve2(WB, ea, eb, z2, z1, xa, xb, wa, wb);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      X2[e] += eh * xa[e];                                  // a's position update; P x_a = g2 - e_a . x_a(K-1)
+      y2[e] += eh * (g2[e] - wa[e]);
+      g2[e] -= eh * y2[e];                                  // b's momentum update
+      z2[e] -= eh * (rok[e] ? X2[e] - mu_r[e] : 0.f);
+      X1[e] += eh * xb[e];                                  // b's position update
+      y1[e] += eh * (g1[e] - wb[e]);
+    }
+  };
+  // y, y_c, z, z_c of the current state, afresh: two passes of two products (four operand vectors at once do not fit the registers)
+  auto refresh_tracked = [&](const T (&th)[4], const T (&thc)[4], const T (&pm_)[4], const T (&pmc_)[4]) {
+    T dt[4], dc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dt[e] = rok[e] ? th[e] - mu_r[e] : 0.f; dc[e] = rok[e] ? thc[e] - mu_r[e] : 0.f; }
+    put4(D1, dt);
+    put4(DC, dc);
+    put4(PM, pm_);
+    put4(PMC, pmc_);
+    __syncthreads();
+    {
+      T b1[BKJ], b2[BKJ];
+      load_b(D1, b1);
+      load_b(DC, b2);
+      bf4 p1 = {0.f, 0.f, 0.f, 0.f}, p2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < BKJ; ++j) {
+        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Pa[j], b1[j], p1, 0, 0, 0);
+        p2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Pa[j], b2[j], p2, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { y[e] = p1[e]; yc[e] = p2[e]; }
+    }
+    {
+      T b1[BKJ], b2[BKJ];
+      load_b(PM, b1);
+      load_b(PMC, b2);
+      bf4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < BKJ; ++j) {
+        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Sa[j], b1[j], s1, 0, 0, 0);
+        s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Sa[j], b2[j], s2, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { z[e] = s1[e]; zc[e] = s2[e]; }
+    }
+  };
   // three sums per chain over the rows, complete in every lane of the chain's column
   auto block_sums = [&](T (&v)[3]) {
 #pragma unroll
@@ -901,8 +1001,9 @@ __global__ __launch_bounds__(BNT) void rmhmc_batch_kernel(FusedArgs<float> a) {
     }
   };
   // H = -log p + D/2 log 2 pi + 1/2 log|G| + 1/2 m^T G^-1 m  (S:731)   (rmhmc_fused_kernel: hamiltonian, series branch)
-  auto hamiltonian = [&](uint32_t n, uint32_t sub, const T (&X)[4], const T* m, const T (&mr)[4], T& H, T& logp) {
-    T* d = dpar ? D1 : D0;
+  auto hamiltonian = [&](uint32_t n, uint32_t sub, const T (&X)[4], const T* m, const T (&mr)[4], T& H, T& logp, T (&Pd_out)[4],
+                         T (&Sm_out)[4]) {
+    T* d = (dpar && !TRACK) ? D1 : D0;                      // (TRACK: D1 belongs to the refresh phase)
     dpar ^= 1;
     jitter4(n, sub);
     T dr[4];
@@ -930,6 +1031,7 @@ __global__ __launch_bounds__(BNT) void rmhmc_batch_kernel(FusedArgs<float> a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       x0[e] = x0v[e]; xr[e] = x0v[e];
+      Pd_out[e] = Pd[e]; Sm_out[e] = x0v[e];
       v[0] += dr[e] * Pd[e];
       wv[e] = ev_r[e] * x0v[e];
       if (a.has_jitter) v[2] += ev_r[e] * (sd_r[e] - 0.5f * s2[e]);      // log|P + E| = log|P| + tr(SE) - 1/2 tr((SE)^2) + ...
@@ -961,14 +1063,17 @@ __global__ __launch_bounds__(BNT) void rmhmc_batch_kernel(FusedArgs<float> a) {
       for (int e = 0; e < 4; ++e) spm[e] = (live && rok[e]) ? a.p_ws[((int64_t)t * a.C + c) * D + row0 + e] : 0.f;
       put4(PM, spm);
       T H0, H1, lp0, lp1;
-      hamiltonian(n, 1, scur, PM, spm, H0, lp0);            // S:971 -> S:822
+      hamiltonian(n, 1, scur, PM, spm, H0, lp0, y, z);      // S:971 -> S:822
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { sth[e] = scur[e]; sthc[e] = scur[e]; spmc[e] = spm[e]; }   // S:425-426
-      put4(PMC, spm);
+      for (int e = 0; e < 4; ++e) { sth[e] = scur[e]; sthc[e] = scur[e]; spmc[e] = spm[e]; yc[e] = y[e]; zc[e] = z[e]; }   // S:425-426
+      if (!TRACK) put4(PMC, spm);
       for (int lstep = 0; lstep < a.L; ++lstep) {           // S:427-461
         const uint32_t k0 = 2u + 8u * (uint32_t)lstep;
-        half_step(n, k0 + 1, sth, PMC, sthc, spm, PM);      // phi_A/2  S:429-430
-        half_step(n, k0 + 2, sthc, PM, sth, spmc, PMC);     // phi_B/2  S:432-433
+        if (TRACK) pair_tracked(D0, n, k0 + 1, k0 + 2, sth, sthc, spm, spmc, y, yc, z, zc);    // phi_A/2, phi_B/2  S:429-433
+        else {
+          half_step(n, k0 + 1, sth, PMC, sthc, spm, PM);    // phi_A/2  S:429-430
+          half_step(n, k0 + 2, sthc, PM, sth, spmc, PMC);   // phi_B/2  S:432-433
+        }
         if (a.K == 0) __syncthreads();
 #pragma unroll
         for (int e = 0; e < 4; ++e) {                       // phi_C    S:447-450, sequential (Q1)
@@ -980,12 +1085,22 @@ __global__ __launch_bounds__(BNT) void rmhmc_batch_kernel(FusedArgs<float> a) {
           bc = h * ((b + bc) + ss * (xx - xc) - cc * (b - bc));
           sth[e] = xx; spm[e] = b; sthc[e] = xc; spmc[e] = bc;
         }
-        put4(PM, spm);
-        put4(PMC, spmc);
-        half_step(n, k0 + 4, sthc, PM, sth, spmc, PMC);     // phi_B/2  S:454-455
-        half_step(n, k0 + 7, sth, PMC, sthc, spm, PM);      // phi_A/2  S:457-458
+        if (TRACK) {
+          refresh_tracked(sth, sthc, spm, spmc);
+          pair_tracked(WS2, n, k0 + 4, k0 + 7, sthc, sth, spmc, spm, yc, y, zc, z);   // phi_B/2, phi_A/2  S:454-458
+        } else {
+          put4(PM, spm);
+          put4(PMC, spmc);
+          half_step(n, k0 + 4, sthc, PM, sth, spmc, PMC);   // phi_B/2  S:454-455
+          half_step(n, k0 + 7, sth, PMC, sthc, spm, PM);    // phi_A/2  S:457-458
+        }
       }
-      hamiltonian(n, 2u + 8u * (uint32_t)a.L, sth, PM, spm, H1, lp1);   // S:989 (Q4)
+      if (TRACK) {                                          // (the tracked half steps keep the momenta in registers)
+        if (a.K == 0) __syncthreads();                      // no solve phase since the refresh phase read PM
+        put4(PM, spm);
+      }
+      T unused1[4], unused2[4];
+      hamiltonian(n, 2u + 8u * (uint32_t)a.L, sth, PM, spm, H1, lp1, unused1, unused2);   // S:989 (Q4)
       // ---- Metropolis test + bookkeeping (S:1000-1026, S:1045-1057)
       const T u = u23<T>(philox_block(a.seed, chain, n, PURPOSE_MH, 0, 0).x);
       const bool acc = mh_accept<T>(H0, H1, lp1, u);
@@ -2240,19 +2355,24 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
         if (batch) {
           static DevOnce dn_b;
           if (!dn_b) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rmhmc_batch_kernel<25>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess)
-              e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rmhmc_batch_kernel<28>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipSuccess;
+            const void* kerns[4] = {reinterpret_cast<const void*>(&rmhmc_batch_kernel<25, true>), reinterpret_cast<const void*>(&rmhmc_batch_kernel<28, true>),
+                                    reinterpret_cast<const void*>(&rmhmc_batch_kernel<25, false>), reinterpret_cast<const void*>(&rmhmc_batch_kernel<28, false>)};
+            for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) { set_error("hta_rmhmc_gaussian_sample: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
             dn_b = true;
           }
           const int64_t ngroup = (C + BNC - 1) / BNC;
-          const size_t blds = (size_t)(7 * BNC * BLD + BWV * BNC * 4) * sizeof(float);
+          const size_t blds = (size_t)(BBUF * BNC * BLD + BWV * BNC * 4) * sizeof(float);      // 88 KB: one workgroup per CU
+          const int bgrid = (int)(ngroup < 4096 ? ngroup : 4096);
           profile_begin(s);
-          if (D <= 100) rmhmc_batch_kernel<25><<<(int)(ngroup < 4096 ? ngroup : 4096), BNT, blds, s>>>(a);
-          else rmhmc_batch_kernel<28><<<(int)(ngroup < 4096 ? ngroup : 4096), BNT, blds, s>>>(a);
+          if (g_rmhmc_pair) {
+            if (D <= 100) rmhmc_batch_kernel<25, true><<<bgrid, BNT, blds, s>>>(a);
+            else rmhmc_batch_kernel<28, true><<<bgrid, BNT, blds, s>>>(a);
+          } else {
+            if (D <= 100) rmhmc_batch_kernel<25, false><<<bgrid, BNT, blds, s>>>(a);
+            else rmhmc_batch_kernel<28, false><<<bgrid, BNT, blds, s>>>(a);
+          }
           profile_end(s);
           return HTA_OK;
         }
