@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhamiltorch_amd.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 MASS_NONE, MASS_DIAG, MASS_FULL = 0, 1, 2
 
@@ -65,6 +65,11 @@ def _sig(scalar):
                                c_int, c_int, c_u64, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
         "hta_mlp_logp_grad": [c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
                               ctypes.POINTER(scalar), scalar, scalar, c_vp, c_vp, c_vp],
+        "hta_netn_hmc_sample": [c_vp, c_vp, c_i64, c_int, ctypes.POINTER(c_int), c_int, c_int, c_vp, c_vp, c_int, c_int, c_int,
+                                ctypes.POINTER(scalar), scalar, scalar, c_int, c_vp, c_vp, c_int, c_int, scalar, c_int,
+                                c_int, c_int, c_u64, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+        "hta_netn_logp_grad": [c_vp, c_i64, c_int, ctypes.POINTER(c_int), c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                               ctypes.POINTER(scalar), scalar, scalar, c_vp, c_vp, c_vp],
         "hta_rmhmc_gaussian_leapfrog": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_f64, c_int, c_f64, c_u64, c_u64,
                                         c_u32, c_i64, c_int, c_int, c_f64, c_f64, c_vp, c_vp, c_vp],
         "hta_rmhmc_binding_rotation": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f64, c_f64, c_vp],
@@ -344,6 +349,8 @@ def rmhmc_gaussian_sample(theta, theta_init, P, mu, log_norm, metric, alpha, jit
 # ---- Bayesian MLP (regression) -----------------------------------------------------------------------
 ACTS = {"relu": 0, "tanh": 1, "sigmoid": 2}
 LOSSES = {"regression": 0, "binary_class_linear_output": 1}       # HTA_LOSS_REGRESSION / HTA_LOSS_BINARY_LOGITS
+NET_LOSSES = dict(LOSSES, multi_class_linear_output=2)             # + HTA_LOSS_SOFTMAX_CE (hta_netn_* only)
+NETN_MAX_LAYERS, NETN_MAX_WIDTH, NETN_MAX_PARAMS = 4, 64, 512     # csrc/netn_hmc.hip
 
 
 def _tau4(like, tau):
@@ -373,3 +380,39 @@ def mlp_logp_grad(theta, n_in, H, act, X, Y, M, Nb, split, tau, tau_out, prior_s
         _check(fn(_p(theta), C, int(n_in), int(H), ACTS[act], LOSSES[loss], _p(X, theta), _p(Y, theta), X.shape[0], int(M), int(Nb),
                   int(split), _tau4(theta, tau), float(tau_out), float(prior_scale), _p(grad_out, theta),
                   _p(logp_out, theta), _stream(theta)), "hta_mlp_logp_grad")
+
+
+# ---- Bayesian networks of any small shape (csrc/netn_hmc.hip) ----------------------------------------
+def _net_operands(like, dims, taus):
+    ct = c_f32 if like.dtype == torch.float32 else c_f64
+    dims = [int(d) for d in dims]
+    taus = [float(t) for t in taus]
+    if len(taus) != 2 * (len(dims) - 1):
+        raise InvalidArguments("hta_netn: %d precisions for %d Linear layers (one per weight and per bias)" % (len(taus), len(dims) - 1))
+    return len(dims) - 1, (c_int * len(dims))(*dims), (ct * len(taus))(*taus)
+
+
+def netn_hmc_sample(theta, theta_init, dims, act, X, Y, M, Nb, taus, tau_out, prior_scale, mass_kind, inv_mass, mass_factor,
+                    L, eps, n_traj, traj_offset, burn, seed, chain_offset, samples, reject_count, H_old=None, H_new=None,
+                    accept=None, integrator=0, loss="regression"):
+    require_device(theta, "params")
+    C = theta.shape[0]
+    nl, cd, ct = _net_operands(theta, dims, taus)
+    fn = getattr(load(), "hta_netn_hmc_sample_" + _suffix(theta))
+    with torch.cuda.device(theta.device):
+        _check(fn(_p(theta), _p(theta_init, theta), C, nl, cd, ACTS[act], NET_LOSSES[loss], _p(X, theta), _p(Y, theta),
+                  X.shape[0], int(M), int(Nb), ct, float(tau_out), float(prior_scale), mass_kind, _p(inv_mass, theta),
+                  _p(mass_factor, theta), int(integrator), int(L), float(eps), int(n_traj), int(traj_offset), int(burn),
+                  int(seed), int(chain_offset), _p(samples, theta), _p(reject_count), _p(H_old, theta), _p(H_new, theta),
+                  _p(accept), _stream(theta)), "hta_netn_hmc_sample")
+
+
+def netn_logp_grad(theta, dims, act, X, Y, M, Nb, split, taus, tau_out, prior_scale, grad_out, logp_out, loss="regression"):
+    require_device(theta, "params")
+    C = theta.shape[0]
+    nl, cd, ct = _net_operands(theta, dims, taus)
+    fn = getattr(load(), "hta_netn_logp_grad_" + _suffix(theta))
+    with torch.cuda.device(theta.device):
+        _check(fn(_p(theta), C, nl, cd, ACTS[act], NET_LOSSES[loss], _p(X, theta), _p(Y, theta), X.shape[0], int(M), int(Nb),
+                  int(split), ct, float(tau_out), float(prior_scale), _p(grad_out, theta), _p(logp_out, theta),
+                  _stream(theta)), "hta_netn_logp_grad")

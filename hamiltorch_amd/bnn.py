@@ -21,8 +21,74 @@ _ACTS = {nn.ReLU: "relu", nn.Tanh: "tanh", nn.Sigmoid: "sigmoid"}
 
 
 def _mlp_structure(model):
-    """[in, h1, ..., out] and the activation name if ``model`` is Sequential(Linear, act, Linear, ...)
-    with one activation kind; else None."""
+    """[in, h1, ..., out] and the activation name if ``model`` computes Linear, act, Linear, ... with one activation kind and
+    its parameters are flattened in that order (U:121-122): an ``nn.Sequential`` of those modules, or any module whose
+    ``forward`` traces (``torch.fx``) to such a chain - the reference notebooks' ``Net`` classes (``self.l1 .. self.l3`` and
+    ``torch.relu`` calls in ``forward``); else None."""
+    st = _sequential_structure(model)
+    return st if st is not None else _traced_structure(model)
+
+
+_ACT_FUNCS = {"relu": "relu", "tanh": "tanh", "sigmoid": "sigmoid"}
+
+
+def _traced_structure(model):
+    if isinstance(model, nn.Sequential) or not isinstance(model, nn.Module):
+        return None
+    try:
+        import torch.fx
+        gm = torch.fx.symbolic_trace(model)
+    except Exception:                     # data-dependent control flow etc.: not a plain chain
+        return None
+    mods = dict(gm.named_modules())
+    dims, act, linears = [], None, []
+    prev, expect_linear, seen_input = None, True, False
+    for node in gm.graph.nodes:
+        if node.op == "placeholder":
+            if seen_input:
+                return None
+            seen_input, prev = True, node
+            continue
+        if node.op == "output":
+            out = node.args[0]
+            if out is not prev or expect_linear or len(dims) < 2:
+                return None
+            continue
+        tensor_args = [a for a in node.args if isinstance(a, torch.fx.Node)]
+        if tensor_args != [prev] or any(isinstance(v, torch.fx.Node) for v in node.kwargs.values()):
+            return None
+        if node.op == "call_module" and isinstance(mods.get(node.target), nn.Linear):
+            m = mods[node.target]
+            if not expect_linear or m.bias is None or (dims and dims[-1] != m.in_features):
+                return None
+            if not dims:
+                dims.append(m.in_features)
+            dims.append(m.out_features)
+            linears.append(m)
+            expect_linear = False
+        else:
+            if node.op == "call_module":
+                a = _ACTS.get(type(mods.get(node.target)))
+            elif node.op == "call_function":
+                a = _ACT_FUNCS.get(getattr(node.target, "__name__", ""))
+            elif node.op == "call_method":
+                a = _ACT_FUNCS.get(node.target)
+            else:
+                a = None
+            if a is None or expect_linear or (act is not None and a != act) or len(node.args) != 1 \
+                    or any(v not in (False, None) for v in node.kwargs.values()):       # (F.relu records inplace=False)
+                return None
+            act = a
+            expect_linear = True
+        prev = node
+    params = list(model.parameters())
+    want = [t for m in linears for t in (m.weight, m.bias)]
+    if len(params) != len(want) or any(a is not b for a, b in zip(params, want)) or list(model.buffers()):
+        return None                       # other parameters, shared layers, or a flattening order that is not the order of use
+    return dims, (act or "relu")
+
+
+def _sequential_structure(model):
     if not isinstance(model, nn.Sequential):
         return None
     mods = list(model.children())
@@ -91,12 +157,23 @@ def define_model_log_prob(model, model_loss, x, y, params_flattened_list, params
             return (ll + l_prior / prior_scale), output
         return ll + l_prior / prior_scale
 
-    st = _mlp_structure(model)
-    if st is not None and model_loss in ('regression', 'binary_class_linear_output') and x is not None and not predict \
-            and x.dim() == 2 and st[0][-1] == 1 and y_dev.numel() == x_dev.shape[0]:
-        log_prob_func._hta_spec = dict(dims=st[0], act=st[1], X=x_dev, Y=y_dev.reshape(x_dev.shape[0], -1),
-                                       tau_list=list(taus), tau_out=float(tau_out),
-                                       prior_scale=float(prior_scale), loss=model_loss)
+    st = _mlp_structure(model) if (x is not None and not predict and x.dim() == 2) else None
+    if st is not None:
+        n_pts, n_out = x_dev.shape[0], st[0][-1]
+        # the likelihoods with a native kernel: Gaussian on one output, Bernoulli with logits (any number of outputs, summed),
+        # softmax cross-entropy on integer labels; the other kinds (and multi-output regression, whose closure returns one
+        # value per output, S:1184) stay on the callback path
+        if model_loss == 'regression' and n_out == 1 and y_dev.numel() == n_pts:
+            y_spec = y_dev.reshape(n_pts, 1)
+        elif model_loss == 'binary_class_linear_output' and y_dev.numel() == n_pts * n_out:
+            y_spec = y_dev.reshape(n_pts, n_out)
+        elif model_loss == 'multi_class_linear_output' and n_out >= 2 and y_dev.numel() == n_pts:
+            y_spec = y_dev.reshape(n_pts)
+        else:
+            y_spec = None
+        if y_spec is not None:
+            log_prob_func._hta_spec = dict(dims=st[0], act=st[1], X=x_dev, Y=y_spec, tau_list=list(taus), tau_out=float(tau_out),
+                                           prior_scale=float(prior_scale), loss=model_loss)
     return log_prob_func
 
 

@@ -1,0 +1,430 @@
+// Fused (split-)HMC for SMALL fully connected Bayesian networks of any depth: 1 .. 4 Linear layers (none to three hidden ones),
+// one activation kind between them, Gaussian / Bernoulli-with-logits / softmax-cross-entropy likelihood.
+// Same contract as mlp_hmc.hip (hamiltorch/samplers.py:965-1026 trajectory loop, S:1141-1199 closures, S:499-596 split
+// integrators, S:281-302 leapfrog); what it adds are the shapes the reference's notebooks actually sample: the two-hidden-layer
+// regression net of the split-HMC notebook (1-10-10-1), the softmax regression of the BNN notebook (Linear(4, 3),
+// `multi_class_linear_output`, the default `model_loss` of sample_model) and small classifiers with several outputs.
+//
+// Work layout.  These nets have tens to a few hundred parameters and layers 1 .. 32 wide: nothing for a matrix core to hold on
+// to, but a data set of hundreds of points.  ONE WAVE PER CHAIN, lanes = points: a lane carries its point through the layers
+// (activations and deltas of the point in this lane's column of two small LDS matrices, [unit][lane]: conflict-free), the
+// parameters of the chain are a broadcast operand (one LDS copy per wave, every lane reads the same address), and a weight's
+// gradient sum_p delta[p][o] a[p][i] is a reduction over the lanes - six DPP steps (fp32) whose total lane 0 adds into the
+// wave's gradient vector with one LDS atomic.  Leapfrog state (q, p, gradient, masses) lives in registers, parameter
+// 64 k + lane in register k of lane `lane`.  One wave per workgroup: barriers cost nothing, 1024 chains put a wave on every SIMD.
+// Layer shapes are run-time values (uniform loops); limits: D <= 512 parameters, widths <= 64, N <= what L2 holds (X is read
+// from global memory, coalesced over the lanes).
+#include "mlp.hpp"
+#include "philox.hpp"
+
+namespace hta {
+
+void profile_begin(hipStream_t s);
+void profile_end(hipStream_t s);
+
+constexpr int NETN_MAX_LAYERS = 4;      // Linear layers
+constexpr int NETN_KMAX = 8;            // parameters per lane: D <= 512
+constexpr int NETN_MAX_WIDTH = 64;
+
+template <typename T> struct NetArgs {
+  T* theta; const T* theta_init; int64_t C;
+  int n_layers; int dims[NETN_MAX_LAYERS + 1]; int act; int loss;
+  const T* X; const T* Y; int N; int M; int Nb;
+  T tau[2 * NETN_MAX_LAYERS]; T tau_out; T prior_scale;
+  int mass_kind; const T* inv_mass; const T* mass_factor;
+  int L; T eps; int n_traj; int traj_offset; int burn;
+  uint64_t seed; uint64_t chain_offset;
+  T* samples; int32_t* reject_count; T* H_old; T* H_new; uint8_t* accept;
+  T* grad_out; T* logp_out; int eval_split;
+  int integ;
+};
+
+template <int CTRL, int ROWMASK> __device__ __forceinline__ float dpp_add(float v) {
+  const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false);
+  return v + __builtin_bit_cast(float, o);
+}
+// sum over the 64 lanes, uniform result (SGPR): quad butterflies, two row rotations, then the row totals hop to lane 63
+__device__ __forceinline__ float wave_total(float v) {
+  v = dpp_add<0xB1, 0xF>(v);           // quad_perm:[1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);           // quad_perm:[2,3,0,1]
+  v = dpp_add<0x124, 0xF>(v);          // row_ror:4
+  v = dpp_add<0x128, 0xF>(v);          // row_ror:8   -> every lane holds its row's total
+  v = dpp_add<0x142, 0xA>(v);          // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);          // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ double wave_total(double v) { return wave_sum(v); }
+
+template <typename T> __device__ __forceinline__ T netn_act(int act, T z) {
+  if (act == 0) return z > (T)0 ? z : (T)0;
+  if (act == 1) return tanh(z);
+  return (T)1 / ((T)1 + exp(-z));
+}
+template <typename T> __device__ __forceinline__ T netn_act_deriv(int act, T h) {      // in terms of the activation's value
+  if (act == 0) return h > (T)0 ? (T)1 : (T)0;
+  if (act == 1) return (T)1 - h * h;
+  return h * ((T)1 - h);
+}
+
+template <typename T>
+struct NetChain {
+  struct Rec { T v[NETN_KMAX]; };
+  const NetArgs<T>& a;
+  int lane, D, nl, n_out, out_row;
+  int woff[NETN_MAX_LAYERS], boff[NETN_MAX_LAYERS], aoff[NETN_MAX_LAYERS + 1];
+  T *th, *gacc, *act, *dl0, *dl1;
+  int* perm;
+  Rec tauv;                              // prior precision of every parameter this lane owns (0 beyond D)
+  T prior_const;                         // sum_t n_t (1/2 log tau_t - 1/2 log 2 pi)
+  __device__ NetChain(const NetArgs<T>& a_) : a(a_) {}
+
+  __device__ __forceinline__ T& A(int row) { return act[row * 64 + lane]; }
+
+  __device__ __forceinline__ void publish(const Rec& q) {     // the wave's copy of the parameters; gradient vector cleared
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NETN_KMAX; ++k) {
+      const int pid = 64 * k + lane;
+      if (pid < D) { th[pid] = q.v[k]; gacc[pid] = (T)0; }
+    }
+    __syncthreads();
+  }
+
+  // this lane's point through the layers; returns nothing, the outputs sit in rows aoff[nl] .. of `act`
+  __device__ __forceinline__ void forward(int p, bool valid) {
+    const int n_in = a.dims[0];
+    for (int i = 0; i < n_in; ++i) A(i) = valid ? a.X[(int64_t)p * n_in + i] : (T)0;
+#pragma unroll
+    for (int l = 0; l < NETN_MAX_LAYERS; ++l) {             // (unrolled with a guard: the per-layer tables stay in scalar registers)
+      if (l >= nl) break;
+      const int I = a.dims[l], O = a.dims[l + 1];
+      const T* W = th + woff[l];
+      for (int o = 0; o < O; ++o) {
+        T acc = th[boff[l] + o];
+        for (int i = 0; i < I; ++i) acc = fma(W[o * I + i], A(aoff[l] + i), acc);
+        A(aoff[l + 1] + o) = (l + 1 < nl) ? netn_act<T>(a.act, acc) : acc;
+      }
+    }
+  }
+
+  // likelihood of this lane's point (S:1170-1184): e with log-lik = -1/2 tau_out e, and d log-lik / d output into dl (rows 0 .. n_out)
+  __device__ __forceinline__ T point_loss(int p, bool valid, T* dl, bool want_delta) {
+    const int O = n_out, orow = out_row;
+    T e = 0;
+    if (a.loss == HTA_LOSS_SOFTMAX_CE) {                     // S:1173-1178: CrossEntropyLoss(reduction='sum') on logits, integer labels
+      const int y = valid ? (int)a.Y[p] : 0;
+      T m = A(orow);
+      for (int o = 1; o < O; ++o) m = fmax(m, A(orow + o));
+      T s = 0;
+      for (int o = 0; o < O; ++o) s += exp(A(orow + o) - m);
+      const T lse = m + log(s);
+      e = (T)2 * (lse - A(orow + (y >= 0 && y < O ? y : 0)));
+      if (want_delta)
+        for (int o = 0; o < O; ++o) dl[o * 64 + lane] = valid ? -a.tau_out * (exp(A(orow + o) - lse) - (o == y ? (T)1 : (T)0)) : (T)0;
+    } else {
+      for (int o = 0; o < O; ++o) {
+        const T f = A(orow + o), y = valid ? a.Y[(int64_t)p * O + o] : (T)0;
+        T d, ee;
+        mlp_point_loss<T>(a.loss, f, y, a.tau_out, d, ee);
+        e += ee;
+        if (want_delta) dl[o * 64 + lane] = valid ? d : (T)0;
+      }
+    }
+    return valid ? e : (T)0;
+  }
+
+  // d log-lik / d theta of split points [lo, hi) summed into gacc (through publish()'s zero), returns sum of e over the points
+  __device__ __forceinline__ T pass(const Rec& q, int lo, int hi, bool grad) {
+    publish(q);
+    T esum = 0;
+    for (int p0 = lo; p0 < hi; p0 += 64) {
+      const int p = p0 + lane;
+      const bool valid = p < hi;
+      forward(p, valid);
+      T* dcur = dl0; T* dprev = dl1;
+      esum += point_loss(p, valid, dcur, grad);
+      if (!grad) continue;
+#pragma unroll
+      for (int l = NETN_MAX_LAYERS - 1; l >= 0; --l) {
+        if (l >= nl) continue;
+        const int I = a.dims[l], O = a.dims[l + 1];
+        const T* W = th + woff[l];
+        for (int o = 0; o < O; ++o) {
+          const T d = dcur[o * 64 + lane];
+          const T gb = wave_total(d);
+          if (lane == 0) atomicAdd(&gacc[boff[l] + o], gb);
+          for (int i = 0; i < I; ++i) {
+            const T gw = wave_total(d * A(aoff[l] + i));
+            if (lane == 0) atomicAdd(&gacc[woff[l] + o * I + i], gw);
+          }
+        }
+        if (l > 0) {
+          for (int i = 0; i < I; ++i) {
+            T s = 0;
+            for (int o = 0; o < O; ++o) s = fma(dcur[o * 64 + lane], W[o * I + i], s);
+            dprev[i * 64 + lane] = s * netn_act_deriv<T>(a.act, A(aoff[l] + i));
+          }
+          T* t = dcur; dcur = dprev; dprev = t;
+        }
+      }
+    }
+    return wave_total(esum);
+  }
+
+  // d log p_m / d theta over points [lo, hi) + prior / prior_scale  (S:1156); returns the log-likelihood part
+  __device__ __forceinline__ T grad_range(const Rec& q, int lo, int hi, Rec& g) {
+    const T esum = pass(q, lo, hi, true);
+    __syncthreads();                                        // lane 0's atomics
+    const T ips = (T)1 / a.prior_scale;
+#pragma unroll
+    for (int k = 0; k < NETN_KMAX; ++k) {
+      const int pid = 64 * k + lane;
+      g.v[k] = pid < D ? gacc[pid] - ips * tauv.v[k] * q.v[k] : (T)0;
+    }
+    return (T)-0.5 * a.tau_out * esum;
+  }
+  __device__ __forceinline__ T loglik_range(const Rec& q, int lo, int hi) { return (T)-0.5 * a.tau_out * pass(q, lo, hi, false); }
+
+  // prior log-density (whole, not divided): sum_t [ -1/2 tau_t sum w^2 + n_t (1/2 log tau_t - 1/2 log 2 pi) ]
+  __device__ __forceinline__ T log_prior(const Rec& w) {
+    T qq = 0;
+#pragma unroll
+    for (int k = 0; k < NETN_KMAX; ++k) qq = fma(tauv.v[k] * w.v[k], w.v[k], qq);       // entries beyond D are exactly 0
+    return (T)-0.5 * wave_total(qq) + prior_const;
+  }
+  // sum_m log p_m(theta) = full-data log-likelihood + (M / prior_scale) * prior   (S:787-796)
+  __device__ __forceinline__ T logp_total(const Rec& w) {
+    return loglik_range(w, 0, a.M * a.Nb) + ((T)a.M / a.prior_scale) * log_prior(w);
+  }
+  __device__ __forceinline__ T kinetic(const Rec& p, const Rec& im) {
+    T k = 0;
+#pragma unroll
+    for (int q = 0; q < NETN_KMAX; ++q) k = fma(p.v[q] * im.v[q], p.v[q], k);
+    return (T)0.5 * wave_total(k);
+  }
+  static __device__ __forceinline__ void axpy(Rec& y, T c, const Rec& x) {
+#pragma unroll
+    for (int k = 0; k < NETN_KMAX; ++k) y.v[k] = fma(c, x.v[k], y.v[k]);
+  }
+  static __device__ __forceinline__ void drift(Rec& q, T c, const Rec& im, const Rec& p) {   // q += c M^-1 p
+#pragma unroll
+    for (int k = 0; k < NETN_KMAX; ++k) q.v[k] = fma(c * im.v[k], p.v[k], q.v[k]);
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(64) void netn_hmc_kernel(NetArgs<T> a, int D, int SW, int WM) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  typedef NetChain<T> Ch;
+  typedef typename Ch::Rec Rec;
+  Ch ch(a);
+  const int lane = threadIdx.x;
+  ch.lane = lane; ch.D = D; ch.nl = a.n_layers;
+  const int Dp = (D + 63) & ~63;
+  ch.th = reinterpret_cast<T*>(smem_raw);
+  ch.gacc = ch.th + Dp;
+  ch.act = ch.gacc + Dp;
+  ch.dl0 = ch.act + (size_t)SW * 64;
+  ch.dl1 = ch.dl0 + (size_t)WM * 64;
+  ch.perm = reinterpret_cast<int*>(ch.dl1 + (size_t)WM * 64);
+  {
+    int off = 0, ao = 0;
+    T pc = 0;
+    const T hl2p = (T)0.9189385332046727;
+    ch.aoff[0] = 0;
+#pragma unroll
+    for (int l = 0; l < NETN_MAX_LAYERS; ++l) {
+      if (l >= a.n_layers) { ch.woff[l] = ch.boff[l] = 0; ch.aoff[l + 1] = ao; continue; }
+      const int I = a.dims[l], O = a.dims[l + 1];
+      ch.woff[l] = off; off += I * O;
+      ch.boff[l] = off; off += O;
+      ao += I; ch.aoff[l + 1] = ao;
+      pc += (T)(I * O) * ((T)0.5 * log(a.tau[2 * l]) - hl2p) + (T)O * ((T)0.5 * log(a.tau[2 * l + 1]) - hl2p);
+    }
+    ch.prior_const = pc;
+    ch.out_row = ao;
+    int no = a.dims[1];
+#pragma unroll
+    for (int l = 1; l < NETN_MAX_LAYERS; ++l) if (l < a.n_layers) no = a.dims[l + 1];
+    ch.n_out = no;
+  }
+  Rec im, mf;
+  const bool dg = a.mass_kind == HTA_MASS_DIAG;
+#pragma unroll
+  for (int k = 0; k < NETN_KMAX; ++k) {
+    const int pid = 64 * k + lane;
+    const bool ok = pid < D;
+    T tv = 0;
+    if (ok) {
+#pragma unroll
+      for (int l = 0; l < NETN_MAX_LAYERS; ++l) {
+        if (l >= a.n_layers) break;
+        if (pid >= ch.woff[l] && pid < ch.boff[l]) tv = a.tau[2 * l];
+        if (pid >= ch.boff[l] && pid < ch.boff[l] + a.dims[l + 1]) tv = a.tau[2 * l + 1];
+      }
+    }
+    ch.tauv.v[k] = tv;
+    im.v[k] = (ok && dg) ? a.inv_mass[pid] : (T)1;
+    mf.v[k] = (ok && dg) ? a.mass_factor[pid] : (T)1;
+  }
+  auto load_rec = [&](const T* src, Rec& w) {
+#pragma unroll
+    for (int k = 0; k < NETN_KMAX; ++k) { const int pid = 64 * k + lane; w.v[k] = pid < D ? src[pid] : (T)0; }
+  };
+  auto store_rec = [&](T* dst, const Rec& w) {
+#pragma unroll
+    for (int k = 0; k < NETN_KMAX; ++k) { const int pid = 64 * k + lane; if (pid < D) dst[pid] = w.v[k]; }
+  };
+
+  for (int64_t c = blockIdx.x; c < a.C; c += gridDim.x) {
+    const uint64_t chain = a.chain_offset + (uint64_t)c;
+    Rec cur;
+    load_rec(a.theta + c * D, cur);
+
+    if (a.n_traj == 0) {          // evaluation-only: gradient and value of one split closure (parity tests)
+      Rec g;
+      const int lo = a.eval_split * a.Nb;
+      const T ll = ch.grad_range(cur, lo, lo + a.Nb, g);
+      const T lp = ll + ch.log_prior(cur) / a.prior_scale;
+      if (a.grad_out) store_rec(a.grad_out + c * D, g);
+      if (a.logp_out && lane == 0) a.logp_out[c] = lp;
+      continue;
+    }
+
+    T lp_cur = ch.logp_total(cur);
+    int32_t rejected = 0;
+    const T eps = a.eps, heps = (T)0.5 * a.eps;
+    const int M = a.M;
+    for (int t = 0; t < a.n_traj; ++t) {
+      const int n = a.traj_offset + t;
+      // ---- gibbs (S:185-186 / S:200-201)
+      Rec p;
+#pragma unroll
+      for (int k = 0; k < NETN_KMAX; ++k) {
+        const int pid = 64 * k + lane;
+        p.v[k] = pid < D ? mf.v[k] * normal_elem<T>(a.seed, chain, (uint32_t)n, 0, pid) : (T)0;
+      }
+      const T h_old = -lp_cur + ch.kinetic(p, im);                        // S:971
+      Rec q = cur, g;
+      const int nstage = split_stage_count(a.integ, M, a.L);
+      if (a.integ == HTA_SPLIT_RAND) {                                    // S:549: one subset order per trajectory
+        __syncthreads();
+        if (lane == 0) split_permutation(a.seed, (uint32_t)n, M, ch.perm);
+        __syncthreads();
+      }
+      for (int st = 0; st < nstage; ++st) {
+        int m; T kick, dr;
+        split_stage<T>(a.integ, M, a.L, st, eps, ch.perm, m, kick, dr);
+        const int lo = m * a.Nb;
+        ch.grad_range(q, lo, lo + a.Nb, g);
+        Ch::axpy(p, kick, g);
+        if (dr != (T)0) Ch::drift(q, dr, im, p);
+      }
+      if (M == 1 && a.integ == HTA_SPLIT_SYMMETRIC) Ch::axpy(p, -heps, g);                                  // S:302
+      const T lp_new = ch.logp_total(q);                                  // S:995
+      const T h_new = -lp_new + ch.kinetic(p, im);
+      const T u = u23<T>(philox_block(a.seed, chain, (uint32_t)n, PURPOSE_MH, 0, 0).x);
+      const bool acc = mh_accept<T>(h_old, h_new, lp_new, u);             // S:1000-1004
+      if (acc) { cur = q; lp_cur = lp_new; }
+      else {
+        ++rejected;
+        if (n == a.burn + 1) {                                            // Q2 reset to params_init (S:1018)
+          load_rec(a.theta_init + c * D, cur);
+          lp_cur = ch.logp_total(cur);
+        }
+      }
+      if (a.samples && n > a.burn) store_rec(a.samples + ((int64_t)(n - a.burn) * a.C + c) * D, cur);
+      if (lane == 0) {
+        if (a.H_old) a.H_old[(int64_t)t * a.C + c] = h_old;
+        if (a.H_new) a.H_new[(int64_t)t * a.C + c] = h_new;
+        if (a.accept) a.accept[(int64_t)t * a.C + c] = acc ? 1 : 0;
+      }
+    }
+    store_rec(a.theta + c * D, cur);
+    if (lane == 0 && a.reject_count) a.reject_count[c] += rejected;
+  }
+}
+
+template <typename T> int netn_hmc(const NetArgs<T>& a, hipStream_t s) {
+  HTA_REQUIRE(a.theta && a.X && a.Y && a.C > 0, "hta_netn_hmc: NULL pointer / empty batch");
+  HTA_REQUIRE(a.n_layers >= 1 && a.n_layers <= NETN_MAX_LAYERS, "hta_netn_hmc: %d Linear layers not in [1, %d]", a.n_layers, NETN_MAX_LAYERS);
+  int D = 0, SW = a.dims[0], WM = 1;
+  for (int l = 0; l <= a.n_layers; ++l)
+    HTA_REQUIRE(a.dims[l] >= 1 && a.dims[l] <= NETN_MAX_WIDTH, "hta_netn_hmc: layer width %d not in [1, %d]", a.dims[l], NETN_MAX_WIDTH);
+  for (int l = 0; l < a.n_layers; ++l) {
+    D += a.dims[l] * a.dims[l + 1] + a.dims[l + 1];
+    SW += a.dims[l + 1];
+    if (a.dims[l + 1] > WM) WM = a.dims[l + 1];
+    if (a.dims[l] > WM) WM = a.dims[l];
+  }
+  HTA_REQUIRE(D <= 64 * NETN_KMAX, "hta_netn_hmc: %d parameters exceed the native limit of %d", D, 64 * NETN_KMAX);
+  HTA_REQUIRE(a.act >= 0 && a.act <= 2, "hta_netn_hmc: unknown activation %d", a.act);
+  HTA_REQUIRE(a.loss == HTA_LOSS_REGRESSION || a.loss == HTA_LOSS_BINARY_LOGITS || a.loss == HTA_LOSS_SOFTMAX_CE,
+              "hta_netn_hmc: unknown loss kind %d", a.loss);
+  HTA_REQUIRE(a.M >= 1 && a.Nb >= 1 && (int64_t)a.M * a.Nb <= a.N, "hta_netn_hmc: M=%d splits of Nb=%d points exceed N=%d", a.M, a.Nb, a.N);
+  HTA_REQUIRE(a.mass_kind == HTA_MASS_NONE || (a.mass_kind == HTA_MASS_DIAG && a.inv_mass && a.mass_factor),
+              "hta_netn_hmc: only identity / diagonal inv_mass are supported natively");
+  if (a.n_traj > 0) HTA_REQUIRE(a.theta_init && a.L >= 0, "hta_netn_hmc: bad trajectory arguments");
+  HTA_REQUIRE(a.integ >= HTA_SPLIT_SYMMETRIC && a.integ <= HTA_SPLIT_KMID, "hta_netn_hmc: unknown integrator %d", a.integ);
+  HTA_REQUIRE(a.integ != HTA_SPLIT_RAND || a.M <= 64, "hta_netn_hmc: SPLITTING_RAND supports at most 64 subsets natively (M=%d)", a.M);
+  HTA_REQUIRE(a.integ != HTA_SPLIT_KMID || a.M >= 2, "hta_netn_hmc: SPLITTING_KMID needs at least 2 subsets");
+  const int Dp = (D + 63) & ~63;
+  const size_t lds = ((size_t)2 * Dp + (size_t)(SW + 2 * WM) * 64) * sizeof(T) + 64 * sizeof(int);
+  HTA_REQUIRE(lds <= 150 * 1024, "hta_netn_hmc: the layer widths need %zu bytes of LDS", lds);
+  static DevOnce done;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&netn_hmc_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { set_error("hta_netn_hmc: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
+    done = true;
+  }
+  const int grid = (int)(a.C < 65536 ? a.C : 65536);
+  profile_begin(s);
+  netn_hmc_kernel<T><<<grid, 64, lds, s>>>(a, D, SW, WM);
+  profile_end(s);
+  HTA_CHECK_LAUNCH("hta_netn_hmc");
+  return HTA_OK;
+}
+
+template <typename T>
+static int netn_fill(NetArgs<T>& a, int n_layers, const int* dims, const T* taus) {
+  if (!dims || !taus) { set_error("hta_netn: dims / taus is NULL (host pointers)"); return HTA_ERR_INVALID; }
+  if (n_layers < 1 || n_layers > NETN_MAX_LAYERS) { set_error("hta_netn: %d Linear layers not in [1, %d]", n_layers, NETN_MAX_LAYERS); return HTA_ERR_INVALID; }
+  a.n_layers = n_layers;
+  for (int l = 0; l <= NETN_MAX_LAYERS; ++l) a.dims[l] = l <= n_layers ? dims[l] : 0;
+  for (int l = 0; l < 2 * NETN_MAX_LAYERS; ++l) a.tau[l] = l < 2 * n_layers ? taus[l] : (T)1;
+  return HTA_OK;
+}
+
+}  // namespace hta
+
+extern "C" {
+#define HTA_DEFINE_NETN(SUF, T)                                                                                          \
+  int hta_netn_hmc_sample_##SUF(T* theta, const T* theta_init, int64_t C, int n_layers, const int* dims, int act,        \
+                                int loss_kind, const T* X, const T* Y, int N, int M, int Nb, const T* taus, T tau_out,   \
+                                T prior_scale, int mass_kind, const T* inv_mass, const T* mass_factor, int integrator,   \
+                                int L, T eps, int n_traj, int traj_offset, int burn, uint64_t seed, uint64_t chain_offset, \
+                                T* samples, int32_t* reject_count, T* H_old, T* H_new, uint8_t* accept, void* stream) {  \
+    hta::NetArgs<T> a{};                                                                                                 \
+    if (int rc = hta::netn_fill<T>(a, n_layers, dims, taus)) return rc;                                                  \
+    a.theta = theta; a.theta_init = theta_init; a.C = C; a.act = act; a.loss = loss_kind; a.X = X; a.Y = Y; a.N = N;      \
+    a.M = M; a.Nb = Nb; a.tau_out = tau_out; a.prior_scale = prior_scale; a.mass_kind = mass_kind; a.inv_mass = inv_mass; \
+    a.mass_factor = mass_factor; a.L = L; a.eps = eps; a.n_traj = n_traj; a.traj_offset = traj_offset; a.burn = burn;    \
+    a.seed = seed; a.chain_offset = chain_offset; a.samples = samples; a.reject_count = reject_count; a.H_old = H_old;   \
+    a.H_new = H_new; a.accept = accept; a.integ = integrator;                                                            \
+    if (n_traj <= 0) return HTA_OK;                                                                                      \
+    return hta::netn_hmc<T>(a, (hipStream_t)stream);                                                                     \
+  }                                                                                                                      \
+  int hta_netn_logp_grad_##SUF(const T* theta, int64_t C, int n_layers, const int* dims, int act, int loss_kind, const T* X, \
+                               const T* Y, int N, int M, int Nb, int split, const T* taus, T tau_out, T prior_scale,     \
+                               T* grad_out, T* logp_out, void* stream) {                                                 \
+    hta::NetArgs<T> a{};                                                                                                 \
+    if (int rc = hta::netn_fill<T>(a, n_layers, dims, taus)) return rc;                                                  \
+    a.theta = const_cast<T*>(theta); a.C = C; a.act = act; a.loss = loss_kind; a.X = X; a.Y = Y; a.N = N; a.M = M;        \
+    a.Nb = Nb; a.tau_out = tau_out; a.prior_scale = prior_scale; a.mass_kind = HTA_MASS_NONE; a.grad_out = grad_out;     \
+    a.logp_out = logp_out; a.eval_split = split; a.integ = HTA_SPLIT_SYMMETRIC;                                          \
+    return hta::netn_hmc<T>(a, (hipStream_t)stream);                                                                     \
+  }
+HTA_DEFINE_NETN(f32, float)
+HTA_DEFINE_NETN(f64, double)
+#undef HTA_DEFINE_NETN
+}

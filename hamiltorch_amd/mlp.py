@@ -1,10 +1,11 @@
 """Native engines for the Bayesian-MLP closures built by ``bnn.define_model_log_prob`` (S:1093-1258).
 
-A closure carries ``_hta_spec`` (dims, activation, data, precisions) when the model is
-``Sequential(Linear, act, Linear)`` with one output and a Gaussian ('regression') or Bernoulli-with-logits
-('binary_class_linear_output') likelihood; ``sample`` then runs the
-whole (split-)HMC trajectory loop in ``csrc/mlp_hmc.hip`` instead of calling back into torch.
-Anything else falls back to the generic-callback path.
+A closure carries ``_hta_spec`` (dims, activation, data, precisions) when the model is a chain Linear, act, Linear, ...
+(``bnn._mlp_structure``) with a Gaussian ('regression'), Bernoulli-with-logits ('binary_class_linear_output') or softmax
+('multi_class_linear_output') likelihood; ``sample`` then runs the whole (split-)HMC trajectory loop natively instead of
+calling back into torch: one hidden layer and one output in ``csrc/mlp_hmc.hip`` / ``mlp_mfma.hip``, other small shapes
+(no or several hidden layers, several outputs, softmax) in ``csrc/netn_hmc.hip``.  Anything else falls back to the
+generic-callback path.
 """
 from __future__ import annotations
 
@@ -18,7 +19,7 @@ def _common_spec(fns):
     if any(s is None for s in specs):
         return None
     s0 = specs[0]
-    if len(s0["dims"]) != 3 or s0["dims"][-1] != 1 or s0["dims"][0] > 32 or s0["dims"][1] > 1024:
+    if _kernel_for(s0) is None:
         return None
     nb = s0["X"].shape[0]
     for s in specs[1:]:
@@ -26,6 +27,23 @@ def _common_spec(fns):
                 (s0["dims"], s0["act"], s0["tau_list"], s0["tau_out"], s0["prior_scale"], s0["loss"]) or s["X"].shape[0] != nb:
             return None
     return specs
+
+
+def _n_params(dims):
+    return sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(len(dims) - 1))
+
+
+def _kernel_for(spec):
+    """'mlp1': csrc/mlp_hmc.hip / mlp_mfma.hip (one hidden layer, one output, Gaussian or Bernoulli likelihood, any width up to
+    1024); 'netn': csrc/netn_hmc.hip (1 .. 4 Linear layers, widths <= 64, <= 512 parameters, also softmax cross-entropy);
+    None: the callback path."""
+    dims, loss = spec["dims"], spec["loss"]
+    if len(dims) == 3 and dims[-1] == 1 and dims[0] <= 32 and dims[1] <= 1024 and loss in _abi.LOSSES:
+        return "mlp1"
+    if 2 <= len(dims) <= _abi.NETN_MAX_LAYERS + 1 and max(dims) <= _abi.NETN_MAX_WIDTH and _n_params(dims) <= _abi.NETN_MAX_PARAMS \
+            and loss in _abi.NET_LOSSES:
+        return "netn"
+    return None
 
 
 class _MLPEngine:
@@ -38,6 +56,7 @@ class _MLPEngine:
             def __init__(self, specs, fallback, integrator):
                 self.specs, self.fallback, self.integrator = specs, fallback, integrator
                 s0 = specs[0]
+                self.dims, self.kernel = list(s0["dims"]), _kernel_for(s0)
                 self.n_in, self.H = s0["dims"][0], s0["dims"][1]
                 self.act, self.tau, self.tau_out, self.prior_scale = s0["act"], s0["tau_list"], s0["tau_out"], s0["prior_scale"]
                 self.loss = s0["loss"]
@@ -47,13 +66,13 @@ class _MLPEngine:
             def begin(self, theta0, N, burn, inv_mass, seed, chain_offset):
                 from .samplers import _mass_operands
                 kind = _mass_operands(inv_mass, theta0)[0]
-                if kind == _abi.MASS_FULL or theta0.shape[1] != self.H * self.n_in + 2 * self.H + 1:
+                if kind == _abi.MASS_FULL or theta0.shape[1] != _n_params(self.dims):
                     self._fb = self.fallback()          # full mass matrix / unexpected layout: generic-callback path
                     return self._fb.begin(theta0, N, burn, inv_mass, seed, chain_offset)
                 self._begin_args = (theta0, N, burn, inv_mass, seed, chain_offset)
                 super().begin(theta0, N, burn, inv_mass, seed, chain_offset)
                 self.X = torch.cat([s["X"].reshape(self.Nb, self.n_in) for s in self.specs]).to(theta0).contiguous()
-                self.Y = torch.cat([s["Y"].reshape(self.Nb) for s in self.specs]).to(theta0).contiguous()
+                self.Y = torch.cat([s["Y"].reshape(self.Nb, -1) for s in self.specs]).to(theta0).contiguous()
 
             def advance(self, n0, count, L, eps, H_old=None, H_new=None, progress=None):
                 if self._fb is not None:
@@ -61,6 +80,13 @@ class _MLPEngine:
                 step = 1 if H_old is not None else count
                 for start in range(n0, n0 + count, step):
                     try:
+                        if self.kernel == "netn":
+                            _abi.netn_hmc_sample(self.cur, self.theta0, self.dims, self.act, self.X, self.Y, self.M, self.Nb,
+                                                 self.tau, self.tau_out, self.prior_scale, self.kind, self.im, self.mf, L, eps,
+                                                 min(step, n0 + count - start), start, self.burn, self.seed, self.off,
+                                                 self.samples, self.rejected, H_old, H_new, integrator=self.integrator,
+                                                 loss=self.loss)
+                            continue
                         _abi.mlp_hmc_sample(self.cur, self.theta0, self.n_in, self.H, self.act, self.X, self.Y, self.M,
                                             self.Nb, self.tau, self.tau_out, self.prior_scale, self.kind, self.im, self.mf,
                                             L, eps, min(step, n0 + count - start), start, self.burn, self.seed, self.off,

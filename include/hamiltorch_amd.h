@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HTA_ABI_VERSION 3
+#define HTA_ABI_VERSION 4
 
 #define HTA_OK 0
 #define HTA_ERR_INVALID (-1)   /* bad argument                           */
@@ -271,6 +271,8 @@ int hta_rmhmc_gaussian_sample_f64(double* theta, const double* theta_init, const
  * Remaining arguments as hta_hmc_gaussian_sample. */
 #define HTA_LOSS_REGRESSION 0
 #define HTA_LOSS_BINARY_LOGITS 1
+#define HTA_LOSS_SOFTMAX_CE 2     /* hta_netn_* only: -tau_out sum_p [logsumexp(f_p) - f_p[y_p]], y_p a class index stored as a float
+                                   * ('multi_class_linear_output': CrossEntropyLoss(reduction='sum') on logits, samplers.py:1173-1178) */
 #define HTA_SPLIT_SYMMETRIC 0
 #define HTA_SPLIT_RAND 1
 #define HTA_SPLIT_KMID 2
@@ -293,6 +295,36 @@ int hta_mlp_logp_grad_f32(const float* theta, int64_t C, int n_in, int H, int ac
 int hta_mlp_logp_grad_f64(const double* theta, int64_t C, int n_in, int H, int act, int loss_kind, const double* X,
                           const double* Y, int N, int M, int Nb, int split, const double* tau4, double tau_out,
                           double prior_scale, double* grad_out, double* logp_out, void* stream);
+
+/* ---- Bayesian networks of any small shape (csrc/netn_hmc.hip; ABI 4) ---------------------------------------------------------
+ * The same two entry points for fully connected nets of 1 .. 4 Linear layers (none to three hidden layers, one activation kind
+ * between them, every width <= 64, at most 512 parameters), one wave per chain: the models of the reference's notebooks that the
+ * one-hidden-layer kernels above do not cover - Net([1, 10, 10, 1]) of the split-HMC notebook, the softmax regression
+ * Linear(4, 3) with `multi_class_linear_output` (sample_model's default model_loss) of the BNN notebook.  Replaces, like
+ * hta_mlp_*, `define_model_log_prob` / `define_split_model_log_prob` + the trajectory loop of `sample`
+ * (hamiltorch/samplers.py:1093-1258, :965-1026, :499-596, :281-302).
+ *   dims   HOST pointer to n_layers + 1 ints: input width, the layers' output widths
+ *   taus   HOST pointer to 2 n_layers prior precisions (weight, bias per layer: the reference's tau_list, util.py:121-122 order)
+ *   theta  [C, D], D = sum_l dims[l] dims[l+1] + dims[l+1]: per layer weight[out, in] row-major, then bias[out]
+ *   Y      [N, dims[n_layers]] for HTA_LOSS_REGRESSION / HTA_LOSS_BINARY_LOGITS (summed over the outputs),
+ *          [N] class indices stored as floats for HTA_LOSS_SOFTMAX_CE
+ * everything else as in hta_mlp_hmc_sample / hta_mlp_logp_grad. */
+int hta_netn_hmc_sample_f32(float* theta, const float* theta_init, int64_t C, int n_layers, const int* dims, int act, int loss_kind,
+                            const float* X, const float* Y, int N, int M, int Nb, const float* taus, float tau_out,
+                            float prior_scale, int mass_kind, const float* inv_mass, const float* mass_factor, int integrator,
+                            int L, float eps, int n_traj, int traj_offset, int burn, uint64_t seed, uint64_t chain_offset,
+                            float* samples, int32_t* reject_count, float* H_old, float* H_new, uint8_t* accept, void* stream);
+int hta_netn_hmc_sample_f64(double* theta, const double* theta_init, int64_t C, int n_layers, const int* dims, int act, int loss_kind,
+                            const double* X, const double* Y, int N, int M, int Nb, const double* taus, double tau_out,
+                            double prior_scale, int mass_kind, const double* inv_mass, const double* mass_factor, int integrator,
+                            int L, double eps, int n_traj, int traj_offset, int burn, uint64_t seed, uint64_t chain_offset,
+                            double* samples, int32_t* reject_count, double* H_old, double* H_new, uint8_t* accept, void* stream);
+int hta_netn_logp_grad_f32(const float* theta, int64_t C, int n_layers, const int* dims, int act, int loss_kind, const float* X,
+                           const float* Y, int N, int M, int Nb, int split, const float* taus, float tau_out, float prior_scale,
+                           float* grad_out, float* logp_out, void* stream);
+int hta_netn_logp_grad_f64(const double* theta, int64_t C, int n_layers, const int* dims, int act, int loss_kind, const double* X,
+                           const double* Y, int N, int M, int Nb, int split, const double* taus, double tau_out, double prior_scale,
+                           double* grad_out, double* logp_out, void* stream);
 
 /* measurement knobs: "small_chains_per_block" (launch shape of the thread-per-chain kernel), "fill_blocks" (grid cap of the
  * pre-draw pass of the Gaussian path: 256-thread blocks, grid-stride; 4096),

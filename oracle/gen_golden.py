@@ -615,6 +615,62 @@ def gen_losses():
     np.savez(os.path.join(OUT, "losses.npz"), **out)
 
 
+def gen_deepnet():
+    """The shapes of the reference's notebooks that need more than one hidden layer / one output: log-probability and gradient
+    of every closure of define_split_model_log_prob (prior divided by the number of splits), recorded from the reference."""
+    class Net(nn.Module):                                   # hamiltorch_split_HMC_BNN_example / hamiltorch_Bayesian_NN_example
+        def __init__(self, layer_sizes, act):
+            super().__init__()
+            self.act, self.n = act, len(layer_sizes) - 1
+            self.l1 = nn.Linear(layer_sizes[0], layer_sizes[1])          # attributes l1, l2, ... as in the notebooks
+            if self.n > 1:
+                self.l2 = nn.Linear(layer_sizes[1], layer_sizes[2])
+            if self.n > 2:
+                self.l3 = nn.Linear(layer_sizes[2], layer_sizes[3])
+
+        def forward(self, x):
+            f = torch.relu if self.act == "relu" else torch.tanh
+            x = self.l1(x)
+            if self.n > 1:
+                x = self.l2(f(x))
+            if self.n > 2:
+                x = self.l3(f(x))
+            return x
+
+    cases = {"deepreg": dict(dims=[1, 10, 10, 1], act="relu", loss="regression", N=24, M=2, classes=0, tau_out=7.0),
+             "softmaxlin": dict(dims=[4, 3], act="relu", loss="multi_class_linear_output", N=30, M=3, classes=3, tau_out=1.0),
+             "bin2": dict(dims=[3, 5, 4, 2], act="tanh", loss="binary_class_linear_output", N=20, M=2, classes=-1, tau_out=1.5)}
+    out = {}
+    for name, c in cases.items():
+        torch.manual_seed(11)
+        net = Net(c["dims"], c["act"])
+        g = torch.Generator().manual_seed(5)
+        X = torch.randn(c["N"], c["dims"][0], generator=g)
+        if c["classes"] > 0:
+            Y = torch.randint(0, c["classes"], (c["N"], 1), generator=g).float()
+        elif c["classes"] < 0:
+            Y = torch.randint(0, 2, (c["N"], c["dims"][-1]), generator=g).float()
+        else:
+            Y = torch.randn(c["N"], c["dims"][-1], generator=g)
+        theta = hamiltorch.util.flatten(net).clone().detach() + 0.1 * torch.randn(hamiltorch.util.flatten(net).numel(), generator=g)
+        tau_list = torch.tensor([1.0 + 0.25 * k for k in range(len(list(net.parameters())))])
+        pfl = [t.nelement() for t in net.parameters()]
+        psl = [t.shape for t in net.parameters()]
+        loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(X, Y), batch_size=c["N"] // c["M"], shuffle=False)
+        fns = S.define_split_model_log_prob(net, c["loss"], loader, c["M"], pfl, psl, tau_list, c["tau_out"], verbose=False)
+        lps, grads = [], []
+        for f in fns:
+            th = theta.clone().requires_grad_()
+            v = f(th)
+            lps.append(npy(v).reshape(-1)[0] if v.numel() == 1 else npy(v.sum()))
+            grads.append(npy(torch.autograd.grad(v.sum(), th)[0]))
+        out.update({name + "_dims": np.array(c["dims"]), name + "_act": np.array(c["act"]), name + "_loss": np.array(c["loss"]),
+                    name + "_M": np.array(c["M"]), name + "_X": npy(X), name + "_Y": npy(Y), name + "_theta": npy(theta),
+                    name + "_tau_list": npy(tau_list), name + "_tau_out": np.array(c["tau_out"]), name + "_logp": np.array(lps, dtype=np.float64),
+                    name + "_grad": np.stack(grads)})
+    np.savez(os.path.join(OUT, "deepnet.npz"), **out)
+
+
 def gen_cfg2():
     """BASELINE config 2's per-chain computation: KAT2 target, identity mass, L=25, eps=0.3 - 25-step leapfrog
     paths from four starts (fp32 + fp64) and an end-to-end sample() of 40 trajectories with the draws recorded."""
@@ -763,6 +819,7 @@ if __name__ == "__main__":
     gen_logcosh()
     gen_blockmass()
     gen_losses()
+    gen_deepnet()
     gen_signatures()
     gen_cfg2()
     gen_cfg3()

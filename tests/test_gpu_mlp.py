@@ -118,7 +118,7 @@ def _cmp(out, ref, tol, max_bad=0.07):
     assert bad.mean() <= max_bad, "%d of %d chains differ, max err %.3g" % (bad.sum(), bad.size, np.abs(got - want).max())
 
 
-@pytest.mark.parametrize("dims,act,native_expected", [([3, 5, 1], "relu", True), ([4, 33, 1], "tanh", True), ([2, 4, 3, 1], "tanh", False)])
+@pytest.mark.parametrize("dims,act,native_expected", [([3, 5, 1], "relu", True), ([4, 33, 1], "tanh", True), ([2, 4, 3, 1], "tanh", True)])       # (two hidden layers: csrc/netn_hmc.hip)
 @pytest.mark.parametrize("mass", ["ones", "none"])
 def test_sample_split_model_vs_oracle(ht, dims, act, native_expected, mass):
     """sample_split_model end to end: closures per DataLoader batch, SPLITTING integrator, MH, bookkeeping."""

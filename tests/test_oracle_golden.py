@@ -583,3 +583,32 @@ def test_mlp_binary_logits_likelihood_vs_reference_fixture(golden):
     lp, gr = o.logp_and_grad(g["binary_theta"][None].astype(np.float64))
     np.testing.assert_allclose(lp, g["binary_logp"], rtol=2e-6)
     np.testing.assert_allclose(gr[0], g["binary_grad"], rtol=2e-5, atol=2e-6)
+
+
+def test_mlp_softmax_likelihood_vs_reference_fixture(golden):
+    """define_model_log_prob(model_loss='multi_class_linear_output') (S:1173-1178) on Linear(4,6)-Tanh-Linear(6,3), tau_out = 2:
+    value and gradient of the oracle's softmax cross-entropy likelihood against the unmodified reference (tests/golden/losses.npz)."""
+    g = golden("losses")
+    o = O.MLPRegressionTarget([4, 6, 3], g["multi_X"], g["multi_Y"], g["multi_tau_list"], 2.0, 1.0, "tanh",
+                              loss="multi_class_linear_output")
+    lp, gr = o.logp_and_grad(g["multi_theta"][None].astype(np.float64))
+    np.testing.assert_allclose(lp, g["multi_logp"], rtol=2e-6)
+    np.testing.assert_allclose(gr[0], g["multi_grad"], rtol=2e-5, atol=2e-6)
+
+
+def test_deep_and_linear_nets_vs_reference_fixture(golden):
+    """The shapes of the reference's notebooks (tests/golden/deepnet.npz, recorded from the unmodified reference by
+    oracle/gen_golden.py: gen_deepnet): Net([1, 10, 10, 1]) with torch.relu in forward() and model_loss 'regression'
+    (hamiltorch_split_HMC_BNN_example), Linear(4, 3) with 'multi_class_linear_output' (hamiltorch_Bayesian_NN_example),
+    and a [3, 5, 4, 2] tanh net with 'binary_class_linear_output' on two outputs: log-probability and gradient of every
+    split closure."""
+    g = golden("deepnet")
+    for name in ("deepreg", "softmaxlin", "bin2"):
+        dims, act, loss = [int(d) for d in g[name + "_dims"]], str(g[name + "_act"]), str(g[name + "_loss"])
+        M = int(g[name + "_M"]); X, Y = g[name + "_X"], g[name + "_Y"]; Nb = X.shape[0] // M
+        for m in range(M):
+            o = O.MLPRegressionTarget(dims, X[m * Nb:(m + 1) * Nb], Y[m * Nb:(m + 1) * Nb], g[name + "_tau_list"], float(g[name + "_tau_out"]),
+                                      float(M), act, loss=loss)
+            lp, gr = o.logp_and_grad(g[name + "_theta"][None].astype(np.float64))
+            np.testing.assert_allclose(lp, g[name + "_logp"][m], rtol=3e-6)
+            np.testing.assert_allclose(gr[0], g[name + "_grad"][m], rtol=3e-5, atol=3e-6)
