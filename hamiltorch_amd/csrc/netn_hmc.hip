@@ -54,6 +54,37 @@ __device__ __forceinline__ float wave_total(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ double wave_total(double v) { return wave_sum(v); }
+// four sums at once, step by step: the four chains of dependent DPP adds fill each other's wait states
+__device__ __forceinline__ void wave_total4(float (&v)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = dpp_add<0xB1, 0xF>(v[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = dpp_add<0x4E, 0xF>(v[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = dpp_add<0x124, 0xF>(v[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = dpp_add<0x128, 0xF>(v[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = dpp_add<0x142, 0xA>(v[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = dpp_add<0x143, 0xC>(v[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[k]), 63));
+}
+__device__ __forceinline__ void wave_total4(double (&v)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
+}
+// *p += v by the calling lane(s), p in LDS: the plain LDS add (atomicAdd on a wave-uniform value makes the compiler count the
+// active lanes and scale the value first - a dozen instructions where one is meant)
+__device__ __forceinline__ void lds_add(float* p, float v) {
+  const uint32_t off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)p;
+  asm volatile("ds_add_f32 %0, %1" : : "v"(off), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_add(double* p, double v) {
+  const uint32_t off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)p;
+  asm volatile("ds_add_f64 %0, %1" : : "v"(off), "v"(v) : "memory");
+}
 
 template <typename T> __device__ __forceinline__ T netn_act(int act, T z) {
   if (act == 0) return z > (T)0 ? z : (T)0;
@@ -99,9 +130,19 @@ struct NetChain {
       if (l >= nl) break;
       const int I = a.dims[l], O = a.dims[l + 1];
       const T* W = th + woff[l];
+      // one wave per SIMD and a chain of dependent FMAs: every LDS round trip would be exposed - four operand pairs are
+      // requested before the first of their FMAs (the sum keeps its order i = 0, 1, 2, ...)
       for (int o = 0; o < O; ++o) {
         T acc = th[boff[l] + o];
-        for (int i = 0; i < I; ++i) acc = fma(W[o * I + i], A(aoff[l] + i), acc);
+        const T* Wr = W + o * I;
+        const T* Ar = act + aoff[l] * 64 + lane;
+        int i = 0;
+        for (; i + 4 <= I; i += 4) {
+          const T w0 = Wr[i], w1 = Wr[i + 1], w2 = Wr[i + 2], w3 = Wr[i + 3];
+          const T a0 = Ar[i * 64], a1 = Ar[(i + 1) * 64], a2 = Ar[(i + 2) * 64], a3 = Ar[(i + 3) * 64];
+          acc = fma(w0, a0, acc); acc = fma(w1, a1, acc); acc = fma(w2, a2, acc); acc = fma(w3, a3, acc);
+        }
+        for (; i < I; ++i) acc = fma(Wr[i], Ar[i * 64], acc);
         A(aoff[l + 1] + o) = (l + 1 < nl) ? netn_act<T>(a.act, acc) : acc;
       }
     }
@@ -149,20 +190,34 @@ struct NetChain {
         if (l >= nl) continue;
         const int I = a.dims[l], O = a.dims[l + 1];
         const T* W = th + woff[l];
+        const T* Ar = act + aoff[l] * 64 + lane;
         for (int o = 0; o < O; ++o) {
           const T d = dcur[o * 64 + lane];
           const T gb = wave_total(d);
-          if (lane == 0) atomicAdd(&gacc[boff[l] + o], gb);
-          for (int i = 0; i < I; ++i) {
-            const T gw = wave_total(d * A(aoff[l] + i));
-            if (lane == 0) atomicAdd(&gacc[woff[l] + o * I + i], gw);
+          if (lane == 0) lds_add(&gacc[boff[l] + o], gb);
+          T* grow = gacc + woff[l] + o * I;
+          int i = 0;
+          for (; i + 4 <= I; i += 4) {                      // four reductions in flight (each is a chain of six dependent DPP adds)
+            T gq[4] = {d * Ar[i * 64], d * Ar[(i + 1) * 64], d * Ar[(i + 2) * 64], d * Ar[(i + 3) * 64]};
+            wave_total4(gq);
+            if (lane < 4) lds_add(&grow[i + lane], lane == 0 ? gq[0] : lane == 1 ? gq[1] : lane == 2 ? gq[2] : gq[3]);
+          }
+          for (; i < I; ++i) {
+            const T gw = wave_total(d * Ar[i * 64]);
+            if (lane == 0) lds_add(&grow[i], gw);
           }
         }
         if (l > 0) {
           for (int i = 0; i < I; ++i) {
             T s = 0;
-            for (int o = 0; o < O; ++o) s = fma(dcur[o * 64 + lane], W[o * I + i], s);
-            dprev[i * 64 + lane] = s * netn_act_deriv<T>(a.act, A(aoff[l] + i));
+            int o = 0;
+            for (; o + 4 <= O; o += 4) {
+              const T d0 = dcur[o * 64 + lane], d1 = dcur[(o + 1) * 64 + lane], d2 = dcur[(o + 2) * 64 + lane], d3 = dcur[(o + 3) * 64 + lane];
+              const T w0 = W[o * I + i], w1 = W[(o + 1) * I + i], w2 = W[(o + 2) * I + i], w3 = W[(o + 3) * I + i];
+              s = fma(d0, w0, s); s = fma(d1, w1, s); s = fma(d2, w2, s); s = fma(d3, w3, s);
+            }
+            for (; o < O; ++o) s = fma(dcur[o * 64 + lane], W[o * I + i], s);
+            dprev[i * 64 + lane] = s * netn_act_deriv<T>(a.act, Ar[i * 64]);
           }
           T* t = dcur; dcur = dprev; dprev = t;
         }
@@ -171,19 +226,16 @@ struct NetChain {
     return wave_total(esum);
   }
 
-  // d log p_m / d theta over points [lo, hi) + prior / prior_scale  (S:1156); returns the log-likelihood part
-  __device__ __forceinline__ T grad_range(const Rec& q, int lo, int hi, Rec& g) {
-    const T esum = pass(q, lo, hi, true);
-    __syncthreads();                                        // lane 0's atomics
+  // after a gradient pass: d log p_m / d theta = the summed likelihood gradient + prior gradient / prior_scale  (S:1156)
+  __device__ __forceinline__ void collect_gradient(const Rec& q, Rec& g) {
+    __syncthreads();                                        // lane 0's LDS adds
     const T ips = (T)1 / a.prior_scale;
 #pragma unroll
     for (int k = 0; k < NETN_KMAX; ++k) {
       const int pid = 64 * k + lane;
       g.v[k] = pid < D ? gacc[pid] - ips * tauv.v[k] * q.v[k] : (T)0;
     }
-    return (T)-0.5 * a.tau_out * esum;
   }
-  __device__ __forceinline__ T loglik_range(const Rec& q, int lo, int hi) { return (T)-0.5 * a.tau_out * pass(q, lo, hi, false); }
 
   // prior log-density (whole, not divided): sum_t [ -1/2 tau_t sum w^2 + n_t (1/2 log tau_t - 1/2 log 2 pi) ]
   __device__ __forceinline__ T log_prior(const Rec& w) {
@@ -191,10 +243,6 @@ struct NetChain {
 #pragma unroll
     for (int k = 0; k < NETN_KMAX; ++k) qq = fma(tauv.v[k] * w.v[k], w.v[k], qq);       // entries beyond D are exactly 0
     return (T)-0.5 * wave_total(qq) + prior_const;
-  }
-  // sum_m log p_m(theta) = full-data log-likelihood + (M / prior_scale) * prior   (S:787-796)
-  __device__ __forceinline__ T logp_total(const Rec& w) {
-    return loglik_range(w, 0, a.M * a.Nb) + ((T)a.M / a.prior_scale) * log_prior(w);
   }
   __device__ __forceinline__ T kinetic(const Rec& p, const Rec& im) {
     T k = 0;
@@ -276,72 +324,108 @@ __global__ __launch_bounds__(64) void netn_hmc_kernel(NetArgs<T> a, int D, int S
     for (int k = 0; k < NETN_KMAX; ++k) { const int pid = 64 * k + lane; if (pid < D) dst[pid] = w.v[k]; }
   };
 
+  // The likelihood pass (forward, loss, backward: the bulk of the kernel's code, unrolled over the layers) has ONE call site:
+  // a chain's run is a sequence of passes - [log p of the current point when it is not known] then, per trajectory, the
+  // integrator's gradient stages and the log p of the proposal - driven by a small state machine around that call.  (Four
+  // inlined copies - initial log p, stages, proposal, reset - tripled the code and spilled 226 scalar registers.)
+  const T eps = a.eps, heps = (T)0.5 * a.eps;
+  const int M = a.M;
+  const int nstage = a.n_traj > 0 ? split_stage_count(a.integ, M, a.L) : 0;
+  const int all_pts = M * a.Nb;
   for (int64_t c = blockIdx.x; c < a.C; c += gridDim.x) {
     const uint64_t chain = a.chain_offset + (uint64_t)c;
-    Rec cur;
+    Rec cur, q, p, g;
     load_rec(a.theta + c * D, cur);
-
-    if (a.n_traj == 0) {          // evaluation-only: gradient and value of one split closure (parity tests)
-      Rec g;
-      const int lo = a.eval_split * a.Nb;
-      const T ll = ch.grad_range(cur, lo, lo + a.Nb, g);
-      const T lp = ll + ch.log_prior(cur) / a.prior_scale;
-      if (a.grad_out) store_rec(a.grad_out + c * D, g);
-      if (a.logp_out && lane == 0) a.logp_out[c] = lp;
-      continue;
-    }
-
-    T lp_cur = ch.logp_total(cur);
-    int32_t rejected = 0;
-    const T eps = a.eps, heps = (T)0.5 * a.eps;
-    const int M = a.M;
-    for (int t = 0; t < a.n_traj; ++t) {
-      const int n = a.traj_offset + t;
-      // ---- gibbs (S:185-186 / S:200-201)
-      Rec p;
+    q = cur;
 #pragma unroll
-      for (int k = 0; k < NETN_KMAX; ++k) {
-        const int pid = 64 * k + lane;
-        p.v[k] = pid < D ? mf.v[k] * normal_elem<T>(a.seed, chain, (uint32_t)n, 0, pid) : (T)0;
-      }
-      const T h_old = -lp_cur + ch.kinetic(p, im);                        // S:971
-      Rec q = cur, g;
-      const int nstage = split_stage_count(a.integ, M, a.L);
-      if (a.integ == HTA_SPLIT_RAND) {                                    // S:549: one subset order per trajectory
-        __syncthreads();
-        if (lane == 0) split_permutation(a.seed, (uint32_t)n, M, ch.perm);
-        __syncthreads();
-      }
-      for (int st = 0; st < nstage; ++st) {
-        int m; T kick, dr;
-        split_stage<T>(a.integ, M, a.L, st, eps, ch.perm, m, kick, dr);
-        const int lo = m * a.Nb;
-        ch.grad_range(q, lo, lo + a.Nb, g);
-        Ch::axpy(p, kick, g);
-        if (dr != (T)0) Ch::drift(q, dr, im, p);
-      }
-      if (M == 1 && a.integ == HTA_SPLIT_SYMMETRIC) Ch::axpy(p, -heps, g);                                  // S:302
-      const T lp_new = ch.logp_total(q);                                  // S:995
-      const T h_new = -lp_new + ch.kinetic(p, im);
-      const T u = u23<T>(philox_block(a.seed, chain, (uint32_t)n, PURPOSE_MH, 0, 0).x);
-      const bool acc = mh_accept<T>(h_old, h_new, lp_new, u);             // S:1000-1004
-      if (acc) { cur = q; lp_cur = lp_new; }
+    for (int k = 0; k < NETN_KMAX; ++k) { p.v[k] = 0; g.v[k] = 0; }
+    T lp_cur = 0, h_old = 0;
+    bool lp_known = false;
+    int32_t rejected = 0;
+    int t = 0, st = -1;                // st: -1 = before the trajectory's first pass, 0 .. nstage-1 = stages, nstage = proposal's log p
+    for (;;) {
+      // ---- what the next pass evaluates
+      int lo, hi; bool grad;
+      int m = 0; T kick = 0, dr = 0;
+      if (a.n_traj == 0) { lo = a.eval_split * a.Nb; hi = lo + a.Nb; grad = true; }          // evaluation-only (parity tests)
       else {
-        ++rejected;
-        if (n == a.burn + 1) {                                            // Q2 reset to params_init (S:1018)
-          load_rec(a.theta_init + c * D, cur);
-          lp_cur = ch.logp_total(cur);
+        if (t >= a.n_traj) break;
+        if (st < 0) {                  // trajectory start: gibbs (S:185-186 / S:200-201), the subset order of SPLITTING_RAND (S:549)
+          const int n = a.traj_offset + t;
+#pragma unroll
+          for (int k = 0; k < NETN_KMAX; ++k) {
+            const int pid = 64 * k + lane;
+            p.v[k] = pid < D ? mf.v[k] * normal_elem<T>(a.seed, chain, (uint32_t)n, 0, pid) : (T)0;
+          }
+          q = cur;
+          if (a.integ == HTA_SPLIT_RAND) {
+            __syncthreads();
+            if (lane == 0) split_permutation(a.seed, (uint32_t)n, M, ch.perm);
+            __syncthreads();
+          }
+          if (lp_known) st = 0;        // else: this pass is log p of the current point (first trajectory / after the Q2 reset)
+        }
+        if (st < 0 || st >= nstage) { lo = 0; hi = all_pts; grad = false; }
+        else {
+          split_stage<T>(a.integ, M, a.L, st, eps, ch.perm, m, kick, dr);
+          lo = m * a.Nb; hi = lo + a.Nb; grad = true;
         }
       }
-      if (a.samples && n > a.burn) store_rec(a.samples + ((int64_t)(n - a.burn) * a.C + c) * D, cur);
-      if (lane == 0) {
-        if (a.H_old) a.H_old[(int64_t)t * a.C + c] = h_old;
-        if (a.H_new) a.H_new[(int64_t)t * a.C + c] = h_new;
-        if (a.accept) a.accept[(int64_t)t * a.C + c] = acc ? 1 : 0;
+      // ---- the pass
+      const T esum = ch.pass(q, lo, hi, grad);
+      const T ll = (T)-0.5 * a.tau_out * esum;
+      if (grad) ch.collect_gradient(q, g);
+      // ---- what it was for
+      if (a.n_traj == 0) {
+        const T lp = ll + ch.log_prior(q) / a.prior_scale;
+        if (a.grad_out) store_rec(a.grad_out + c * D, g);
+        if (a.logp_out && lane == 0) a.logp_out[c] = lp;
+        break;
+      }
+      if (st < 0) {                    // log p of the current point (q == cur)
+        lp_cur = ll + ((T)M / a.prior_scale) * ch.log_prior(q);                              // S:787-796
+        lp_known = true;
+        st = 0;
+        if (nstage > 0) continue;
+      }
+      if (st == 0) h_old = -lp_cur + ch.kinetic(p, im);                                        // S:971 (before the first stage's kick)
+      if (st < nstage) {
+        if (grad) {
+          Ch::axpy(p, kick, g);
+          if (dr != (T)0) Ch::drift(q, dr, im, p);
+          ++st;
+          if (st == nstage && M == 1 && a.integ == HTA_SPLIT_SYMMETRIC) Ch::axpy(p, -heps, g);   // S:302
+          continue;
+        }
+      }
+      // ---- the proposal's log p (S:995), the MH test (S:1000-1004), bookkeeping (S:1006-1026)
+      {
+        const int n = a.traj_offset + t;
+        const T lp_new = ll + ((T)M / a.prior_scale) * ch.log_prior(q);
+        const T h_new = -lp_new + ch.kinetic(p, im);
+        const T u = u23<T>(philox_block(a.seed, chain, (uint32_t)n, PURPOSE_MH, 0, 0).x);
+        const bool acc = mh_accept<T>(h_old, h_new, lp_new, u);
+        if (acc) { cur = q; lp_cur = lp_new; }
+        else {
+          ++rejected;
+          if (n == a.burn + 1) {                                            // Q2 reset to params_init (S:1018)
+            load_rec(a.theta_init + c * D, cur);
+            lp_known = false;                                               // its log p: the next trajectory's first pass
+          }
+        }
+        if (a.samples && n > a.burn) store_rec(a.samples + ((int64_t)(n - a.burn) * a.C + c) * D, cur);
+        if (lane == 0) {
+          if (a.H_old) a.H_old[(int64_t)t * a.C + c] = h_old;
+          if (a.H_new) a.H_new[(int64_t)t * a.C + c] = h_new;
+          if (a.accept) a.accept[(int64_t)t * a.C + c] = acc ? 1 : 0;
+        }
+        ++t; st = -1;
       }
     }
-    store_rec(a.theta + c * D, cur);
-    if (lane == 0 && a.reject_count) a.reject_count[c] += rejected;
+    if (a.n_traj > 0) {
+      store_rec(a.theta + c * D, cur);
+      if (lane == 0 && a.reject_count) a.reject_count[c] += rejected;
+    }
   }
 }
 
