@@ -17,6 +17,17 @@
 #include "mlp.hpp"
 #include "philox.hpp"
 
+#ifndef NETN_TIMING
+#define NETN_TIMING 0   // developer cycle counters per phase of a pass (block 0): tools/scratch/netn_time.py prints them
+#endif
+#if NETN_TIMING
+__device__ unsigned long long hta_netn_dbg[8];
+extern "C" void hta_netn_dbg_read(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(hta_netn_dbg), sizeof(hta_netn_dbg)); }
+#define NETN_TICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[k] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define NETN_TICK(k) do {} while (0)
+#endif
+
 namespace hta {
 
 void profile_begin(hipStream_t s);
@@ -97,9 +108,13 @@ template <typename T> __device__ __forceinline__ T netn_act_deriv(int act, T h) 
   return h * ((T)1 - h);
 }
 
-template <typename T>
+// PB: points per lane and sweep (a sweep covers 64 PB points).  More points per lane = PB independent FMA chains that share
+// every weight operand, and PB points folded into a lane's partial product BEFORE the reduction over the lanes: a weight costs
+// one reduction per 64 PB points.  The launcher takes the smallest PB that covers a pass's points in one or two sweeps.
+template <typename T, int PB>
 struct NetChain {
   struct Rec { T v[NETN_KMAX]; };
+  static constexpr int RS = 64 * PB;     // floats per row of the activation / delta matrices
   const NetArgs<T>& a;
   int lane, D, nl, n_out, out_row;
   int woff[NETN_MAX_LAYERS], boff[NETN_MAX_LAYERS], aoff[NETN_MAX_LAYERS + 1];
@@ -107,9 +122,10 @@ struct NetChain {
   int* perm;
   Rec tauv;                              // prior precision of every parameter this lane owns (0 beyond D)
   T prior_const;                         // sum_t n_t (1/2 log tau_t - 1/2 log 2 pi)
+#if NETN_TIMING
+  unsigned long long tacc[8] = {0}, tlast = 0;
+#endif
   __device__ NetChain(const NetArgs<T>& a_) : a(a_) {}
-
-  __device__ __forceinline__ T& A(int row) { return act[row * 64 + lane]; }
 
   __device__ __forceinline__ void publish(const Rec& q) {     // the wave's copy of the parameters; gradient vector cleared
     __syncthreads();
@@ -121,54 +137,101 @@ struct NetChain {
     __syncthreads();
   }
 
-  // this lane's point through the layers; returns nothing, the outputs sit in rows aoff[nl] .. of `act`
-  __device__ __forceinline__ void forward(int p, bool valid) {
+  // this lane's PB points (p0 + 64 b + lane) through the layers; the outputs sit in rows out_row .. of `act`
+  __device__ __forceinline__ void forward(int p0, int hi) {
     const int n_in = a.dims[0];
-    for (int i = 0; i < n_in; ++i) A(i) = valid ? a.X[(int64_t)p * n_in + i] : (T)0;
+    T* Al = act + lane;
+    for (int i = 0; i < n_in; ++i)
+#pragma unroll
+      for (int b = 0; b < PB; ++b) {
+        const int p = p0 + 64 * b + lane;
+        Al[i * RS + 64 * b] = p < hi ? a.X[(int64_t)p * n_in + i] : (T)0;
+      }
+    NETN_TICK(1);
 #pragma unroll
     for (int l = 0; l < NETN_MAX_LAYERS; ++l) {             // (unrolled with a guard: the per-layer tables stay in scalar registers)
       if (l >= nl) break;
       const int I = a.dims[l], O = a.dims[l + 1];
       const T* W = th + woff[l];
-      // one wave per SIMD and a chain of dependent FMAs: every LDS round trip would be exposed - four operand pairs are
-      // requested before the first of their FMAs (the sum keeps its order i = 0, 1, 2, ...)
-      for (int o = 0; o < O; ++o) {
-        T acc = th[boff[l] + o];
-        const T* Wr = W + o * I;
-        const T* Ar = act + aoff[l] * 64 + lane;
-        int i = 0;
-        for (; i + 4 <= I; i += 4) {
-          const T w0 = Wr[i], w1 = Wr[i + 1], w2 = Wr[i + 2], w3 = Wr[i + 3];
-          const T a0 = Ar[i * 64], a1 = Ar[(i + 1) * 64], a2 = Ar[(i + 2) * 64], a3 = Ar[(i + 3) * 64];
-          acc = fma(w0, a0, acc); acc = fma(w1, a1, acc); acc = fma(w2, a2, acc); acc = fma(w3, a3, acc);
+      const T* Ar = Al + aoff[l] * RS;
+      T* Ao = Al + aoff[l + 1] * RS;
+      // One wave per SIMD (at 1024 chains) and chains of dependent FMAs: an iteration costs an LDS round trip whatever it
+      // computes, so an iteration carries a block of FOUR output units x PB points = 4 PB independent chains fed by 4 + PB
+      // operand reads (measured before the blocking: 76 clocks per FMA - tools/scratch/netn_time.py).  A unit's sum keeps its
+      // order i = 0, 1, 2, ...
+      int o = 0;
+      for (; o + 4 <= O; o += 4) {
+        T acc[4][PB];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const T bias = th[boff[l] + o + u];
+#pragma unroll
+          for (int b = 0; b < PB; ++b) acc[u][b] = bias;
         }
-        for (; i < I; ++i) acc = fma(Wr[i], Ar[i * 64], acc);
-        A(aoff[l + 1] + o) = (l + 1 < nl) ? netn_act<T>(a.act, acc) : acc;
+        const T* Wr = W + o * I;
+        for (int i = 0; i < I; ++i) {
+          T w[4], av[PB];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) w[u] = Wr[u * I + i];
+#pragma unroll
+          for (int b = 0; b < PB; ++b) av[b] = Ar[i * RS + 64 * b];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int b = 0; b < PB; ++b) acc[u][b] = fma(w[u], av[b], acc[u][b]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int b = 0; b < PB; ++b) Ao[(o + u) * RS + 64 * b] = (l + 1 < nl) ? netn_act<T>(a.act, acc[u][b]) : acc[u][b];
+      }
+      for (; o < O; ++o) {
+        T acc[PB];
+        const T bias = th[boff[l] + o];
+#pragma unroll
+        for (int b = 0; b < PB; ++b) acc[b] = bias;
+        const T* Wr = W + o * I;
+        int i = 0;
+        for (; i + 2 <= I; i += 2) {
+          const T w0 = Wr[i], w1 = Wr[i + 1];
+          T a0[PB], a1[PB];
+#pragma unroll
+          for (int b = 0; b < PB; ++b) { a0[b] = Ar[i * RS + 64 * b]; a1[b] = Ar[(i + 1) * RS + 64 * b]; }
+#pragma unroll
+          for (int b = 0; b < PB; ++b) { acc[b] = fma(w0, a0[b], acc[b]); acc[b] = fma(w1, a1[b], acc[b]); }
+        }
+        for (; i < I; ++i) {
+          const T w0 = Wr[i];
+#pragma unroll
+          for (int b = 0; b < PB; ++b) acc[b] = fma(w0, Ar[i * RS + 64 * b], acc[b]);
+        }
+#pragma unroll
+        for (int b = 0; b < PB; ++b) Ao[o * RS + 64 * b] = (l + 1 < nl) ? netn_act<T>(a.act, acc[b]) : acc[b];
       }
     }
   }
 
-  // likelihood of this lane's point (S:1170-1184): e with log-lik = -1/2 tau_out e, and d log-lik / d output into dl (rows 0 .. n_out)
-  __device__ __forceinline__ T point_loss(int p, bool valid, T* dl, bool want_delta) {
-    const int O = n_out, orow = out_row;
+  // likelihood of one of this lane's points (S:1170-1184): e with log-lik = -1/2 tau_out e, and d log-lik / d output into dl
+  __device__ __forceinline__ T point_loss(int p, bool valid, const T* Ao, T* dl, bool want_delta) {
+    const int O = n_out;
     T e = 0;
     if (a.loss == HTA_LOSS_SOFTMAX_CE) {                     // S:1173-1178: CrossEntropyLoss(reduction='sum') on logits, integer labels
       const int y = valid ? (int)a.Y[p] : 0;
-      T m = A(orow);
-      for (int o = 1; o < O; ++o) m = fmax(m, A(orow + o));
+      T m = Ao[0];
+      for (int o = 1; o < O; ++o) m = fmax(m, Ao[o * RS]);
       T s = 0;
-      for (int o = 0; o < O; ++o) s += exp(A(orow + o) - m);
+      for (int o = 0; o < O; ++o) s += exp(Ao[o * RS] - m);
       const T lse = m + log(s);
-      e = (T)2 * (lse - A(orow + (y >= 0 && y < O ? y : 0)));
+      e = (T)2 * (lse - Ao[(y >= 0 && y < O ? y : 0) * RS]);
       if (want_delta)
-        for (int o = 0; o < O; ++o) dl[o * 64 + lane] = valid ? -a.tau_out * (exp(A(orow + o) - lse) - (o == y ? (T)1 : (T)0)) : (T)0;
+        for (int o = 0; o < O; ++o) dl[o * RS] = valid ? -a.tau_out * (exp(Ao[o * RS] - lse) - (o == y ? (T)1 : (T)0)) : (T)0;
     } else {
       for (int o = 0; o < O; ++o) {
-        const T f = A(orow + o), y = valid ? a.Y[(int64_t)p * O + o] : (T)0;
+        const T f = Ao[o * RS], y = valid ? a.Y[(int64_t)p * O + o] : (T)0;
         T d, ee;
         mlp_point_loss<T>(a.loss, f, y, a.tau_out, d, ee);
         e += ee;
-        if (want_delta) dl[o * 64 + lane] = valid ? d : (T)0;
+        if (want_delta) dl[o * RS] = valid ? d : (T)0;
       }
     }
     return valid ? e : (T)0;
@@ -176,50 +239,92 @@ struct NetChain {
 
   // d log-lik / d theta of split points [lo, hi) summed into gacc (through publish()'s zero), returns sum of e over the points
   __device__ __forceinline__ T pass(const Rec& q, int lo, int hi, bool grad) {
+    NETN_TICK(6);
     publish(q);
+    NETN_TICK(0);
     T esum = 0;
-    for (int p0 = lo; p0 < hi; p0 += 64) {
-      const int p = p0 + lane;
-      const bool valid = p < hi;
-      forward(p, valid);
-      T* dcur = dl0; T* dprev = dl1;
-      esum += point_loss(p, valid, dcur, grad);
+    for (int p0 = lo; p0 < hi; p0 += RS) {
+      forward(p0, hi);
+      NETN_TICK(2);
+      T* dcur = dl0 + lane; T* dprev = dl1 + lane;
+#pragma unroll
+      for (int b = 0; b < PB; ++b) {
+        const int p = p0 + 64 * b + lane;
+        esum += point_loss(p, p < hi, act + lane + out_row * RS + 64 * b, dcur + 64 * b, grad);
+      }
+      NETN_TICK(3);
       if (!grad) continue;
 #pragma unroll
       for (int l = NETN_MAX_LAYERS - 1; l >= 0; --l) {
         if (l >= nl) continue;
         const int I = a.dims[l], O = a.dims[l + 1];
         const T* W = th + woff[l];
-        const T* Ar = act + aoff[l] * 64 + lane;
+        const T* Ar = act + lane + aoff[l] * RS;
         for (int o = 0; o < O; ++o) {
-          const T d = dcur[o * 64 + lane];
-          const T gb = wave_total(d);
+          T d[PB], ds = 0;
+#pragma unroll
+          for (int b = 0; b < PB; ++b) { d[b] = dcur[o * RS + 64 * b]; ds += d[b]; }
+          const T gb = wave_total(ds);
           if (lane == 0) lds_add(&gacc[boff[l] + o], gb);
           T* grow = gacc + woff[l] + o * I;
           int i = 0;
           for (; i + 4 <= I; i += 4) {                      // four reductions in flight (each is a chain of six dependent DPP adds)
-            T gq[4] = {d * Ar[i * 64], d * Ar[(i + 1) * 64], d * Ar[(i + 2) * 64], d * Ar[(i + 3) * 64]};
+            T gq[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int b = 0; b < PB; ++b) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) gq[u] = fma(d[b], Ar[(i + u) * RS + 64 * b], gq[u]);
+            }
             wave_total4(gq);
             if (lane < 4) lds_add(&grow[i + lane], lane == 0 ? gq[0] : lane == 1 ? gq[1] : lane == 2 ? gq[2] : gq[3]);
           }
           for (; i < I; ++i) {
-            const T gw = wave_total(d * Ar[i * 64]);
+            T gw = 0;
+#pragma unroll
+            for (int b = 0; b < PB; ++b) gw = fma(d[b], Ar[i * RS + 64 * b], gw);
+            gw = wave_total(gw);
             if (lane == 0) lds_add(&grow[i], gw);
           }
         }
+        NETN_TICK(4);
         if (l > 0) {
-          for (int i = 0; i < I; ++i) {
-            T s = 0;
-            int o = 0;
-            for (; o + 4 <= O; o += 4) {
-              const T d0 = dcur[o * 64 + lane], d1 = dcur[(o + 1) * 64 + lane], d2 = dcur[(o + 2) * 64 + lane], d3 = dcur[(o + 3) * 64 + lane];
-              const T w0 = W[o * I + i], w1 = W[(o + 1) * I + i], w2 = W[(o + 2) * I + i], w3 = W[(o + 3) * I + i];
-              s = fma(d0, w0, s); s = fma(d1, w1, s); s = fma(d2, w2, s); s = fma(d3, w3, s);
+          int i = 0;
+          for (; i + 4 <= I; i += 4) {                      // (blocks of four input units: see forward())
+            T sacc[4][PB];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int b = 0; b < PB; ++b) sacc[u][b] = 0;
+            for (int o = 0; o < O; ++o) {
+              T w[4], dv[PB];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) w[u] = W[o * I + i + u];
+#pragma unroll
+              for (int b = 0; b < PB; ++b) dv[b] = dcur[o * RS + 64 * b];
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int b = 0; b < PB; ++b) sacc[u][b] = fma(dv[b], w[u], sacc[u][b]);
             }
-            for (; o < O; ++o) s = fma(dcur[o * 64 + lane], W[o * I + i], s);
-            dprev[i * 64 + lane] = s * netn_act_deriv<T>(a.act, Ar[i * 64]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int b = 0; b < PB; ++b) dprev[(i + u) * RS + 64 * b] = sacc[u][b] * netn_act_deriv<T>(a.act, Ar[(i + u) * RS + 64 * b]);
+          }
+          for (; i < I; ++i) {
+            T sacc[PB];
+#pragma unroll
+            for (int b = 0; b < PB; ++b) sacc[b] = 0;
+            for (int o = 0; o < O; ++o) {
+              const T w0 = W[o * I + i];
+#pragma unroll
+              for (int b = 0; b < PB; ++b) sacc[b] = fma(dcur[o * RS + 64 * b], w0, sacc[b]);
+            }
+#pragma unroll
+            for (int b = 0; b < PB; ++b) dprev[i * RS + 64 * b] = sacc[b] * netn_act_deriv<T>(a.act, Ar[i * RS + 64 * b]);
           }
           T* t = dcur; dcur = dprev; dprev = t;
+          NETN_TICK(5);
         }
       }
     }
@@ -260,10 +365,10 @@ struct NetChain {
   }
 };
 
-template <typename T>
+template <typename T, int PB>
 __global__ __launch_bounds__(64) void netn_hmc_kernel(NetArgs<T> a, int D, int SW, int WM) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  typedef NetChain<T> Ch;
+  typedef NetChain<T, PB> Ch;
   typedef typename Ch::Rec Rec;
   Ch ch(a);
   const int lane = threadIdx.x;
@@ -272,9 +377,9 @@ __global__ __launch_bounds__(64) void netn_hmc_kernel(NetArgs<T> a, int D, int S
   ch.th = reinterpret_cast<T*>(smem_raw);
   ch.gacc = ch.th + Dp;
   ch.act = ch.gacc + Dp;
-  ch.dl0 = ch.act + (size_t)SW * 64;
-  ch.dl1 = ch.dl0 + (size_t)WM * 64;
-  ch.perm = reinterpret_cast<int*>(ch.dl1 + (size_t)WM * 64);
+  ch.dl0 = ch.act + (size_t)SW * Ch::RS;
+  ch.dl1 = ch.dl0 + (size_t)WM * Ch::RS;
+  ch.perm = reinterpret_cast<int*>(ch.dl1 + (size_t)WM * Ch::RS);
   {
     int off = 0, ao = 0;
     T pc = 0;
@@ -426,6 +531,9 @@ __global__ __launch_bounds__(64) void netn_hmc_kernel(NetArgs<T> a, int D, int S
       store_rec(a.theta + c * D, cur);
       if (lane == 0 && a.reject_count) a.reject_count[c] += rejected;
     }
+#if NETN_TIMING
+    if (lane == 0 && blockIdx.x == 0) for (int k = 0; k < 8; ++k) hta_netn_dbg[k] = ch.tacc[k];
+#endif
   }
 }
 
@@ -452,19 +560,33 @@ template <typename T> int netn_hmc(const NetArgs<T>& a, hipStream_t s) {
   HTA_REQUIRE(a.integ >= HTA_SPLIT_SYMMETRIC && a.integ <= HTA_SPLIT_KMID, "hta_netn_hmc: unknown integrator %d", a.integ);
   HTA_REQUIRE(a.integ != HTA_SPLIT_RAND || a.M <= 64, "hta_netn_hmc: SPLITTING_RAND supports at most 64 subsets natively (M=%d)", a.M);
   HTA_REQUIRE(a.integ != HTA_SPLIT_KMID || a.M >= 2, "hta_netn_hmc: SPLITTING_KMID needs at least 2 subsets");
+  // Points per lane and sweep, from the size of a GRADIENT pass (Nb points; the two full-data log p passes of a trajectory
+  // are the minority): the largest of 4, 2, 1 whose sweep of 64 PB points a pass more than half fills - and whose LDS
+  // footprint still lets four workgroups share a CU (1024 chains = 4 per CU: a second round costs more than PB buys).
   const int Dp = (D + 63) & ~63;
-  const size_t lds = ((size_t)2 * Dp + (size_t)(SW + 2 * WM) * 64) * sizeof(T) + 64 * sizeof(int);
+  auto lds_for = [&](int pb) { return ((size_t)2 * Dp + (size_t)(SW + 2 * WM) * 64 * pb) * sizeof(T) + 64 * sizeof(int); };
+  int PB = 4;
+  while (PB > 1 && (a.Nb <= 32 * PB || lds_for(PB) > 38 * 1024)) PB >>= 1;
+  const size_t lds = lds_for(PB);
   HTA_REQUIRE(lds <= 150 * 1024, "hta_netn_hmc: the layer widths need %zu bytes of LDS", lds);
-  static DevOnce done;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&netn_hmc_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { set_error("hta_netn_hmc: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
-    done = true;
-  }
   const int grid = (int)(a.C < 65536 ? a.C : 65536);
-  profile_begin(s);
-  netn_hmc_kernel<T><<<grid, 64, lds, s>>>(a, D, SW, WM);
-  profile_end(s);
+  auto launch = [&](auto kern, DevOnce& done) -> int {
+    if (!done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) { set_error("hta_netn_hmc: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
+      done = true;
+    }
+    profile_begin(s);
+    kern<<<grid, 64, lds, s>>>(a, D, SW, WM);
+    profile_end(s);
+    return HTA_OK;
+  };
+  static DevOnce done[3];
+  int rc;
+  if (PB == 1) rc = launch(&netn_hmc_kernel<T, 1>, done[0]);
+  else if (PB == 2) rc = launch(&netn_hmc_kernel<T, 2>, done[1]);
+  else rc = launch(&netn_hmc_kernel<T, 4>, done[2]);
+  if (rc) return rc;
   HTA_CHECK_LAUNCH("hta_netn_hmc");
   return HTA_OK;
 }
