@@ -8,10 +8,15 @@
 // Work layout.  These nets have tens to a few hundred parameters and layers 1 .. 32 wide: nothing for a matrix core to hold on
 // to, but a data set of hundreds of points.  ONE WAVE PER CHAIN, lanes = points: a lane carries its point through the layers
 // (activations and deltas of the point in this lane's column of two small LDS matrices, [unit][lane]: conflict-free), the
-// parameters of the chain are a broadcast operand (one LDS copy per wave, every lane reads the same address), and a weight's
-// gradient sum_p delta[p][o] a[p][i] is a reduction over the lanes - six DPP steps (fp32) whose total lane 0 adds into the
-// wave's gradient vector with one LDS atomic.  Leapfrog state (q, p, gradient, masses) lives in registers, parameter
+// parameters of the chain are a broadcast operand (one LDS copy per wave, every lane reads the same address).  A weight's
+// gradient sum_p delta[p][o] a[p][i] is a sum of outer products over the points: in fp32 it runs on the matrix cores
+// (v_mfma_f32_4x4x1_16b_f32: the weight matrices of all layers, bias columns included, cut into 4 x 4 blocks, 16 blocks per
+// instruction - one or a few instructions per point, blocks accumulated in registers over a whole pass; pass()), in fp64 it
+// is a reduction over the lanes per weight.  Leapfrog state (q, p, gradient, masses) lives in registers, parameter
 // 64 k + lane in register k of lane `lane`.  One wave per workgroup: barriers cost nothing, 1024 chains put a wave on every SIMD.
+// How it got here (tools/scratch/netn_time.py, profiles/r02z_netn_speed.txt; Net([1,10,10,1]), 400 points, 1024 chains):
+// 3.6e6 chain-steps/s with one point per lane and a DPP reduction per weight -> 5.4e6 (interleaved reductions, plain ds_add) ->
+// 8.6e6 (several points per lane, blocks of four units) -> 1.46e7 (gradient on the matrix cores); the callback path: 6.8e5.
 // Layer shapes are run-time values (uniform loops); limits: D <= 512 parameters, widths <= 64, N <= what L2 holds (X is read
 // from global memory, coalesced over the lanes).
 #include "mlp.hpp"
@@ -36,6 +41,7 @@ void profile_end(hipStream_t s);
 constexpr int NETN_MAX_LAYERS = 4;      // Linear layers
 constexpr int NETN_KMAX = 8;            // parameters per lane: D <= 512
 constexpr int NETN_MAX_WIDTH = 64;
+constexpr int NETN_NSET = 6;            // matrix instructions per point of the gradient: up to 96 blocks of 4 x 4 weights
 
 template <typename T> struct NetArgs {
   T* theta; const T* theta_init; int64_t C;
@@ -114,12 +120,20 @@ template <typename T> __device__ __forceinline__ T netn_act_deriv(int act, T h) 
 template <typename T, int PB>
 struct NetChain {
   struct Rec { T v[NETN_KMAX]; };
-  static constexpr int RS = 64 * PB;     // floats per row of the activation / delta matrices
+  // floats per row of the activation / delta matrices [unit][point column]: odd, so that a lane's own column (stride 1 over
+  // the lanes) AND one column read across the rows (the matrix-core gradient below) are both free of bank conflicts
+  static constexpr int RS = 64 * PB + 1;
+  static constexpr int SWEEP = 64 * PB;  // points per sweep
+  static constexpr bool MATRIX_GRAD = sizeof(T) == 4;
   const NetArgs<T>& a;
   int lane, D, nl, n_out, out_row;
   int woff[NETN_MAX_LAYERS], boff[NETN_MAX_LAYERS], aoff[NETN_MAX_LAYERS + 1];
-  T *th, *gacc, *act, *dl0, *dl1;
+  T *th, *gacc, *act, *dmat;             // dmat: the deltas of EVERY layer, same row numbering as act (+ one row of zeros)
   int* perm;
+  // the matrix-core gradient: per instruction set, this lane's operand rows and what its accumulator block is (see grad_blocks)
+  int n_set, rowA[NETN_NSET], rowB[NETN_NSET], desc[NETN_NSET], ones_row, zero_row;
+  typedef float acc4 __attribute__((ext_vector_type(4)));
+  acc4 gblk[NETN_NSET];
   Rec tauv;                              // prior precision of every parameter this lane owns (0 beyond D)
   T prior_const;                         // sum_t n_t (1/2 log tau_t - 1/2 log 2 pi)
 #if NETN_TIMING
@@ -243,51 +257,56 @@ struct NetChain {
     publish(q);
     NETN_TICK(0);
     T esum = 0;
-    for (int p0 = lo; p0 < hi; p0 += RS) {
+    for (int p0 = lo; p0 < hi; p0 += SWEEP) {
       forward(p0, hi);
       NETN_TICK(2);
-      T* dcur = dl0 + lane; T* dprev = dl1 + lane;
+      T* Dl = dmat + lane;
 #pragma unroll
       for (int b = 0; b < PB; ++b) {
         const int p = p0 + 64 * b + lane;
-        esum += point_loss(p, p < hi, act + lane + out_row * RS + 64 * b, dcur + 64 * b, grad);
+        esum += point_loss(p, p < hi, act + lane + out_row * RS + 64 * b, Dl + out_row * RS + 64 * b, grad);
       }
       NETN_TICK(3);
       if (!grad) continue;
+      // ---- deltas of every layer (rows as in act: delta of layer l's input unit i sits in row aoff[l] + i)
 #pragma unroll
       for (int l = NETN_MAX_LAYERS - 1; l >= 0; --l) {
         if (l >= nl) continue;
         const int I = a.dims[l], O = a.dims[l + 1];
         const T* W = th + woff[l];
         const T* Ar = act + lane + aoff[l] * RS;
-        for (int o = 0; o < O; ++o) {
-          T d[PB], ds = 0;
+        const T* dcur = Dl + aoff[l + 1] * RS;
+        if constexpr (!MATRIX_GRAD) {                       // fp64: a weight's gradient = a reduction over the lanes
+          for (int o = 0; o < O; ++o) {
+            T d[PB], ds = 0;
 #pragma unroll
-          for (int b = 0; b < PB; ++b) { d[b] = dcur[o * RS + 64 * b]; ds += d[b]; }
-          const T gb = wave_total(ds);
-          if (lane == 0) lds_add(&gacc[boff[l] + o], gb);
-          T* grow = gacc + woff[l] + o * I;
-          int i = 0;
-          for (; i + 4 <= I; i += 4) {                      // four reductions in flight (each is a chain of six dependent DPP adds)
-            T gq[4] = {0, 0, 0, 0};
+            for (int b = 0; b < PB; ++b) { d[b] = dcur[o * RS + 64 * b]; ds += d[b]; }
+            const T gb = wave_total(ds);
+            if (lane == 0) lds_add(&gacc[boff[l] + o], gb);
+            T* grow = gacc + woff[l] + o * I;
+            int i = 0;
+            for (; i + 4 <= I; i += 4) {
+              T gq[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int b = 0; b < PB; ++b) {
+              for (int b = 0; b < PB; ++b) {
 #pragma unroll
-              for (int u = 0; u < 4; ++u) gq[u] = fma(d[b], Ar[(i + u) * RS + 64 * b], gq[u]);
+                for (int u = 0; u < 4; ++u) gq[u] = fma(d[b], Ar[(i + u) * RS + 64 * b], gq[u]);
+              }
+              wave_total4(gq);
+              if (lane < 4) lds_add(&grow[i + lane], lane == 0 ? gq[0] : lane == 1 ? gq[1] : lane == 2 ? gq[2] : gq[3]);
             }
-            wave_total4(gq);
-            if (lane < 4) lds_add(&grow[i + lane], lane == 0 ? gq[0] : lane == 1 ? gq[1] : lane == 2 ? gq[2] : gq[3]);
-          }
-          for (; i < I; ++i) {
-            T gw = 0;
+            for (; i < I; ++i) {
+              T gw = 0;
 #pragma unroll
-            for (int b = 0; b < PB; ++b) gw = fma(d[b], Ar[i * RS + 64 * b], gw);
-            gw = wave_total(gw);
-            if (lane == 0) lds_add(&grow[i], gw);
+              for (int b = 0; b < PB; ++b) gw = fma(d[b], Ar[i * RS + 64 * b], gw);
+              gw = wave_total(gw);
+              if (lane == 0) lds_add(&grow[i], gw);
+            }
           }
+          NETN_TICK(4);
         }
-        NETN_TICK(4);
         if (l > 0) {
+          T* dprev = Dl + aoff[l] * RS;
           int i = 0;
           for (; i + 4 <= I; i += 4) {                      // (blocks of four input units: see forward())
             T sacc[4][PB];
@@ -323,12 +342,85 @@ struct NetChain {
 #pragma unroll
             for (int b = 0; b < PB; ++b) dprev[i * RS + 64 * b] = sacc[b] * netn_act_deriv<T>(a.act, Ar[i * RS + 64 * b]);
           }
-          T* t = dcur; dcur = dprev; dprev = t;
           NETN_TICK(5);
         }
       }
+      // ---- fp32: the gradient on the matrix cores.  G_l[o][i] = sum_p delta_l[p][o] a_(l-1)[p][i] is a sum of outer products
+      // over the points; v_mfma_f32_4x4x1_16b_f32 forms 16 independent 4 x 4 outer products per instruction, so the weight
+      // matrices of ALL layers (bias = an input column of ones) are cut into 4 x 4 blocks, 16 blocks per instruction, and one
+      // point costs n_set instructions + 2 n_set LDS reads per lane (lane (block, k) reads row rowA of the deltas and row rowB of
+      // the activations at the point's column) - where a reduction over the lanes per weight cost ~200 clocks each.  The
+      // blocks accumulate in registers over all the points of the pass; scatter_gradient() adds them into gacc once.
+      if constexpr (MATRIX_GRAD) {
+        __syncthreads();                                    // the columns written above are read across the lanes
+        const int cnt = min(SWEEP, hi - p0);                 // (columns beyond cnt hold zero deltas: whole groups of 8 are safe)
+        for (int c = 0; c < cnt; c += 8) {                  // 16 operand reads in flight per LDS round trip, then 8 instructions
+#pragma unroll
+          for (int s_ = 0; s_ < NETN_NSET; ++s_) {
+            if (s_ >= n_set) break;
+            const T* pa = dmat + rowA[s_] * RS + c;
+            const T* pb = act + rowB[s_] * RS + c;
+            float av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { av[u] = pa[u]; bv[u] = pb[u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gblk[s_] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[u], bv[u], gblk[s_], 0, 0, 0);
+          }
+        }
+        __syncthreads();                                    // before the next sweep overwrites the columns
+        NETN_TICK(4);
+      }
     }
+    if constexpr (MATRIX_GRAD) { if (grad) scatter_gradient(); }
     return wave_total(esum);
+  }
+
+  // which 4 x 4 block of which layer's [O x (I + 1)] gradient (weights | bias) every (instruction set, 4-lane block) holds
+  __device__ __forceinline__ void grad_blocks() {
+    const int blk = lane >> 2, idx = lane & 3;
+#pragma unroll
+    for (int s_ = 0; s_ < NETN_NSET; ++s_) { rowA[s_] = zero_row; rowB[s_] = zero_row; desc[s_] = -1; gblk[s_] = acc4{0.f, 0.f, 0.f, 0.f}; }
+    int k = 0;
+#pragma unroll
+    for (int l = 0; l < NETN_MAX_LAYERS; ++l) {
+      if (l >= nl) break;
+      const int I = a.dims[l], O = a.dims[l + 1];
+      const int OB = (O + 3) >> 2, IB = (I + 4) >> 2;      // I + 1 columns: the weights and the bias
+      for (int ob = 0; ob < OB; ++ob)
+        for (int ib = 0; ib < IB; ++ib, ++k) {
+          if ((k & 15) != blk) continue;
+          const int o = 4 * ob + idx, i = 4 * ib + idx;
+          const int ra = o < O ? aoff[l + 1] + o : zero_row;
+          const int rbb = i < I ? aoff[l] + i : (i == I ? ones_row : zero_row);
+#pragma unroll
+          for (int s_ = 0; s_ < NETN_NSET; ++s_)
+            if (s_ == (k >> 4)) { rowA[s_] = ra; rowB[s_] = rbb; desc[s_] = l | (ob << 4) | (ib << 12); }
+        }
+    }
+    n_set = (k + 15) >> 4;
+  }
+
+  // after the last sweep of a gradient pass: the accumulated blocks into the wave's gradient vector; accumulators cleared
+  __device__ __forceinline__ void scatter_gradient() {
+    const int n = lane & 3;
+#pragma unroll
+    for (int s_ = 0; s_ < NETN_NSET; ++s_) {
+      if (s_ >= n_set) break;
+      const int dsc = desc[s_];
+      if (dsc >= 0) {
+        const int l = dsc & 15, ob = (dsc >> 4) & 255, ib = dsc >> 12;
+        int I = a.dims[0], O = a.dims[1], wo = woff[0], bo = boff[0];
+#pragma unroll
+        for (int ll = 1; ll < NETN_MAX_LAYERS; ++ll) if (l == ll) { I = a.dims[ll]; O = a.dims[ll + 1]; wo = woff[ll]; bo = boff[ll]; }
+        const int i = 4 * ib + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = 4 * ob + r;
+          if (o < O && i <= I) lds_add(i < I ? &gacc[wo + o * I + i] : &gacc[bo + o], (T)gblk[s_][r]);
+        }
+      }
+      gblk[s_] = acc4{0.f, 0.f, 0.f, 0.f};
+    }
   }
 
   // after a gradient pass: d log p_m / d theta = the summed likelihood gradient + prior gradient / prior_scale  (S:1156)
@@ -377,9 +469,11 @@ __global__ __launch_bounds__(64) void netn_hmc_kernel(NetArgs<T> a, int D, int S
   ch.th = reinterpret_cast<T*>(smem_raw);
   ch.gacc = ch.th + Dp;
   ch.act = ch.gacc + Dp;
-  ch.dl0 = ch.act + (size_t)SW * Ch::RS;
-  ch.dl1 = ch.dl0 + (size_t)WM * Ch::RS;
-  ch.perm = reinterpret_cast<int*>(ch.dl1 + (size_t)WM * Ch::RS);
+  ch.dmat = ch.act + (size_t)(SW + 2) * Ch::RS;            // both: SW rows + two special rows (act: ones, zeros; dmat: zeros, zeros)
+  ch.perm = reinterpret_cast<int*>(ch.dmat + (size_t)(SW + 2) * Ch::RS);
+  ch.ones_row = SW; ch.zero_row = SW + 1;
+  for (int e = lane; e < Ch::RS; e += 64) { ch.act[(size_t)SW * Ch::RS + e] = (T)1; ch.act[(size_t)(SW + 1) * Ch::RS + e] = (T)0; }
+  for (int e = lane; e < (SW + 2) * Ch::RS; e += 64) ch.dmat[e] = (T)0;
   {
     int off = 0, ao = 0;
     T pc = 0;
@@ -401,6 +495,8 @@ __global__ __launch_bounds__(64) void netn_hmc_kernel(NetArgs<T> a, int D, int S
     for (int l = 1; l < NETN_MAX_LAYERS; ++l) if (l < a.n_layers) no = a.dims[l + 1];
     ch.n_out = no;
   }
+  if constexpr (Ch::MATRIX_GRAD) ch.grad_blocks();
+  __syncthreads();
   Rec im, mf;
   const bool dg = a.mass_kind == HTA_MASS_DIAG;
 #pragma unroll
@@ -564,7 +660,12 @@ template <typename T> int netn_hmc(const NetArgs<T>& a, hipStream_t s) {
   // are the minority): the largest of 4, 2, 1 whose sweep of 64 PB points a pass more than half fills - and whose LDS
   // footprint still lets four workgroups share a CU (1024 chains = 4 per CU: a second round costs more than PB buys).
   const int Dp = (D + 63) & ~63;
-  auto lds_for = [&](int pb) { return ((size_t)2 * Dp + (size_t)(SW + 2 * WM) * 64 * pb) * sizeof(T) + 64 * sizeof(int); };
+  auto lds_for = [&](int pb) { return ((size_t)2 * Dp + (size_t)2 * (SW + 2) * (64 * pb + 1)) * sizeof(T) + 64 * sizeof(int); };
+  if (sizeof(T) == 4) {                                     // the matrix-core gradient holds at most 16 NETN_NSET blocks of 4 x 4
+    int nb = 0;
+    for (int l = 0; l < a.n_layers; ++l) nb += ((a.dims[l + 1] + 3) / 4) * ((a.dims[l] + 4) / 4);
+    HTA_REQUIRE(nb <= 16 * NETN_NSET, "hta_netn_hmc: %d blocks of 4 x 4 weights exceed the native limit of %d", nb, 16 * NETN_NSET);
+  }
   int PB = 4;
   while (PB > 1 && (a.Nb <= 32 * PB || lds_for(PB) > 38 * 1024)) PB >>= 1;
   const size_t lds = lds_for(PB);

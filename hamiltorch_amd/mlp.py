@@ -41,6 +41,7 @@ def _kernel_for(spec):
     if len(dims) == 3 and dims[-1] == 1 and dims[0] <= 32 and dims[1] <= 1024 and loss in _abi.LOSSES:
         return "mlp1"
     if 2 <= len(dims) <= _abi.NETN_MAX_LAYERS + 1 and max(dims) <= _abi.NETN_MAX_WIDTH and _n_params(dims) <= _abi.NETN_MAX_PARAMS \
+            and sum(((dims[i + 1] + 3) // 4) * ((dims[i] + 4) // 4) for i in range(len(dims) - 1)) <= _abi.NETN_MAX_BLOCKS \
             and loss in _abi.NET_LOSSES:
         return "netn"
     return None
