@@ -16,6 +16,7 @@ int g_rmhmc_batch = 1;     // fused RMHMC: 16 chains per workgroup on the matrix
 int g_rmhmc_momwave = 1;   // fused RMHMC: momentum draws by the wave-per-task kernel (fp32, jitter, D <= 104); 0: workgroup-per-task kernel
 int g_rmhmc_mfma4 = 1;     // fused RMHMC: four chains per workgroup on v_mfma_f32_4x4x1_16b (0 off, 1 for lo <= chains < hi, 2 always)
 int g_rmhmc_mfma4_lo = 513, g_rmhmc_mfma4_hi = 2049;   // round 2 (tracked products): 544 / 640 / 700 chains 1.40x / 1.37x / 1.38x the one-chain kernel, below 513 rmhmc_uv_kernel; round 1: 3072: 0.87x, 4096: 0.88x the 16-chain kernel (a third workgroup per CU doubles a SIMD's load)
+int g_netn_waves = 1;        // csrc/netn_hmc.hip: waves per chain (2 / 4 where they fit; measured slower at 1024 chains)
 int g_rmhmc_uv = 1;          // rmhmc_uv.hip (one or two chains per workgroup as columns of the matrix instruction): 1 up to 2 x CUs chains, 0 off, 2 always
 int g_rmhmc_pair = 1;        // four-chain kernels: consecutive half steps share product phases (0: one half step at a time)
 int g_rmhmc_mfma4_waves = 4; // fused RMHMC, four chains per workgroup: 4 = four waves (rows x k parity inside a wave), 2 = two waves
@@ -87,6 +88,7 @@ int hta_set_tuning(const char* key, int value) {
   if (!strcmp(key, "rmhmc_mfma4_lo")) { hta::g_rmhmc_mfma4_lo = value; return HTA_OK; }
   if (!strcmp(key, "rmhmc_mfma4_hi")) { hta::g_rmhmc_mfma4_hi = value; return HTA_OK; }
   if (!strcmp(key, "rmhmc_mfma4_waves")) { hta::g_rmhmc_mfma4_waves = value; return HTA_OK; }
+  if (!strcmp(key, "netn_waves")) { hta::g_netn_waves = value; return HTA_OK; }
   if (!strcmp(key, "rmhmc_uv")) { hta::g_rmhmc_uv = value; return HTA_OK; }
   if (!strcmp(key, "rmhmc_pair")) { hta::g_rmhmc_pair = value; return HTA_OK; }
   if (!strcmp(key, "rmhmc_wide")) { hta::g_rmhmc_wide = value; return HTA_OK; }

@@ -37,6 +37,7 @@ namespace hta {
 
 void profile_begin(hipStream_t s);
 void profile_end(hipStream_t s);
+extern int g_netn_waves;                // tuning key "netn_waves" (default 1)
 
 constexpr int NETN_MAX_LAYERS = 4;      // Linear layers
 constexpr int NETN_KMAX = 8;            // parameters per lane: D <= 512
@@ -117,7 +118,11 @@ template <typename T> __device__ __forceinline__ T netn_act_deriv(int act, T h) 
 // PB: points per lane and sweep (a sweep covers 64 PB points).  More points per lane = PB independent FMA chains that share
 // every weight operand, and PB points folded into a lane's partial product BEFORE the reduction over the lanes: a weight costs
 // one reduction per 64 PB points.  The launcher takes the smallest PB that covers a pass's points in one or two sweeps.
-template <typename T, int PB>
+// WV: waves per chain (workgroup = 64 WV threads).  Every wave keeps the whole leapfrog state (duplicates, as cheap as
+// idle lanes) and takes every WV-th sweep of a pass with its own activation / delta matrices; the waves share the parameter copy
+// and the gradient vector (LDS adds) and exchange their likelihood sums through LDS.  At 1024 chains one wave per chain is one
+// wave per SIMD with nothing to hide its LDS round trips behind; WV = 2 doubles the waves on the chip.
+template <typename T, int PB, int WV>
 struct NetChain {
   struct Rec { T v[NETN_KMAX]; };
   // floats per row of the activation / delta matrices [unit][point column]: odd, so that a lane's own column (stride 1 over
@@ -126,7 +131,9 @@ struct NetChain {
   static constexpr int SWEEP = 64 * PB;  // points per sweep
   static constexpr bool MATRIX_GRAD = sizeof(T) == 4;
   const NetArgs<T>& a;
-  int lane, D, nl, n_out, out_row;
+  int lane, wave, D, nl, n_out, out_row;
+  T* esh;                                // [2] likelihood sums of the workgroup's waves (alternating slots)
+  int eslot;
   int woff[NETN_MAX_LAYERS], boff[NETN_MAX_LAYERS], aoff[NETN_MAX_LAYERS + 1];
   T *th, *gacc, *act, *dmat;             // dmat: the deltas of EVERY layer, same row numbering as act (+ one row of zeros)
   int* perm;
@@ -141,12 +148,21 @@ struct NetChain {
 #endif
   __device__ NetChain(const NetArgs<T>& a_) : a(a_) {}
 
-  __device__ __forceinline__ void publish(const Rec& q) {     // the wave's copy of the parameters; gradient vector cleared
-    __syncthreads();
+  // LDS traffic between the lanes of ONE wave (its own matrices): ordered by waiting for the wave's outstanding LDS operations;
+  // no workgroup barrier - the waves of a chain run different numbers of sweeps
+  static __device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ __forceinline__ void publish(const Rec& q) {     // the chain's copy of the parameters; gradient vector cleared
+    __syncthreads();                                           // (every wave holds the same q: wave 0 writes)
+    if (wave == 0) {
 #pragma unroll
-    for (int k = 0; k < NETN_KMAX; ++k) {
-      const int pid = 64 * k + lane;
-      if (pid < D) { th[pid] = q.v[k]; gacc[pid] = (T)0; }
+      for (int k = 0; k < NETN_KMAX; ++k) {
+        const int pid = 64 * k + lane;
+        if (pid < D) { th[pid] = q.v[k]; gacc[pid] = (T)0; }
+      }
+      if (lane == 0) esh[eslot] = (T)0;                        // this pass's slot of the likelihood sums (slots alternate)
     }
     __syncthreads();
   }
@@ -257,7 +273,7 @@ struct NetChain {
     publish(q);
     NETN_TICK(0);
     T esum = 0;
-    for (int p0 = lo; p0 < hi; p0 += SWEEP) {
+    for (int p0 = lo + wave * SWEEP; p0 < hi; p0 += WV * SWEEP) {
       forward(p0, hi);
       NETN_TICK(2);
       T* Dl = dmat + lane;
@@ -352,7 +368,7 @@ struct NetChain {
       // the activations at the point's column) - where a reduction over the lanes per weight cost ~200 clocks each.  The
       // blocks accumulate in registers over all the points of the pass; scatter_gradient() adds them into gacc once.
       if constexpr (MATRIX_GRAD) {
-        __syncthreads();                                    // the columns written above are read across the lanes
+        wave_sync();                                        // the columns written above are read across the lanes (of THIS wave)
         const int cnt = min(SWEEP, hi - p0);                 // (columns beyond cnt hold zero deltas: whole groups of 8 are safe)
         for (int c = 0; c < cnt; c += 8) {                  // 16 operand reads in flight per LDS round trip, then 8 instructions
 #pragma unroll
@@ -367,12 +383,19 @@ struct NetChain {
             for (int u = 0; u < 8; ++u) gblk[s_] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[u], bv[u], gblk[s_], 0, 0, 0);
           }
         }
-        __syncthreads();                                    // before the next sweep overwrites the columns
+        wave_sync();                                        // before the next sweep overwrites the columns
         NETN_TICK(4);
       }
     }
     if constexpr (MATRIX_GRAD) { if (grad) scatter_gradient(); }
-    return wave_total(esum);
+    T etot = wave_total(esum);
+    if constexpr (WV > 1) {                                   // the waves' sums through LDS: every wave reads the same total
+      if (lane == 0) lds_add(&esh[eslot], etot);
+      __syncthreads();
+      etot = esh[eslot];
+      eslot ^= 1;
+    }
+    return etot;
   }
 
   // which 4 x 4 block of which layer's [O x (I + 1)] gradient (weights | bias) every (instruction set, 4-lane block) holds
@@ -457,20 +480,22 @@ struct NetChain {
   }
 };
 
-template <typename T, int PB>
-__global__ __launch_bounds__(64) void netn_hmc_kernel(NetArgs<T> a, int D, int SW, int WM) {
+template <typename T, int PB, int WV>
+__global__ __launch_bounds__(64 * WV) void netn_hmc_kernel(NetArgs<T> a, int D, int SW, int WM) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  typedef NetChain<T, PB> Ch;
+  typedef NetChain<T, PB, WV> Ch;
   typedef typename Ch::Rec Rec;
   Ch ch(a);
-  const int lane = threadIdx.x;
-  ch.lane = lane; ch.D = D; ch.nl = a.n_layers;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  ch.lane = lane; ch.wave = wave; ch.D = D; ch.nl = a.n_layers; ch.eslot = 0;
   const int Dp = (D + 63) & ~63;
   ch.th = reinterpret_cast<T*>(smem_raw);
   ch.gacc = ch.th + Dp;
-  ch.act = ch.gacc + Dp;
-  ch.dmat = ch.act + (size_t)(SW + 2) * Ch::RS;            // both: SW rows + two special rows (act: ones, zeros; dmat: zeros, zeros)
-  ch.perm = reinterpret_cast<int*>(ch.dmat + (size_t)(SW + 2) * Ch::RS);
+  ch.esh = ch.gacc + Dp;
+  T* mats = ch.esh + 4;
+  ch.act = mats + (size_t)wave * 2 * (SW + 2) * Ch::RS;    // per wave: act and dmat, SW rows + two special rows each (act: ones, zeros; dmat: zeros, zeros)
+  ch.dmat = ch.act + (size_t)(SW + 2) * Ch::RS;
+  ch.perm = reinterpret_cast<int*>(mats + (size_t)WV * 2 * (SW + 2) * Ch::RS);
   ch.ones_row = SW; ch.zero_row = SW + 1;
   for (int e = lane; e < Ch::RS; e += 64) { ch.act[(size_t)SW * Ch::RS + e] = (T)1; ch.act[(size_t)(SW + 1) * Ch::RS + e] = (T)0; }
   for (int e = lane; e < (SW + 2) * Ch::RS; e += 64) ch.dmat[e] = (T)0;
@@ -561,7 +586,7 @@ __global__ __launch_bounds__(64) void netn_hmc_kernel(NetArgs<T> a, int D, int S
           q = cur;
           if (a.integ == HTA_SPLIT_RAND) {
             __syncthreads();
-            if (lane == 0) split_permutation(a.seed, (uint32_t)n, M, ch.perm);
+            if (threadIdx.x == 0) split_permutation(a.seed, (uint32_t)n, M, ch.perm);
             __syncthreads();
           }
           if (lp_known) st = 0;        // else: this pass is log p of the current point (first trajectory / after the Q2 reset)
@@ -579,8 +604,8 @@ __global__ __launch_bounds__(64) void netn_hmc_kernel(NetArgs<T> a, int D, int S
       // ---- what it was for
       if (a.n_traj == 0) {
         const T lp = ll + ch.log_prior(q) / a.prior_scale;
-        if (a.grad_out) store_rec(a.grad_out + c * D, g);
-        if (a.logp_out && lane == 0) a.logp_out[c] = lp;
+        if (a.grad_out && wave == 0) store_rec(a.grad_out + c * D, g);
+        if (a.logp_out && threadIdx.x == 0) a.logp_out[c] = lp;
         break;
       }
       if (st < 0) {                    // log p of the current point (q == cur)
@@ -614,8 +639,8 @@ __global__ __launch_bounds__(64) void netn_hmc_kernel(NetArgs<T> a, int D, int S
             lp_known = false;                                               // its log p: the next trajectory's first pass
           }
         }
-        if (a.samples && n > a.burn) store_rec(a.samples + ((int64_t)(n - a.burn) * a.C + c) * D, cur);
-        if (lane == 0) {
+        if (a.samples && n > a.burn && wave == 0) store_rec(a.samples + ((int64_t)(n - a.burn) * a.C + c) * D, cur);
+        if (threadIdx.x == 0) {
           if (a.H_old) a.H_old[(int64_t)t * a.C + c] = h_old;
           if (a.H_new) a.H_new[(int64_t)t * a.C + c] = h_new;
           if (a.accept) a.accept[(int64_t)t * a.C + c] = acc ? 1 : 0;
@@ -624,11 +649,11 @@ __global__ __launch_bounds__(64) void netn_hmc_kernel(NetArgs<T> a, int D, int S
       }
     }
     if (a.n_traj > 0) {
-      store_rec(a.theta + c * D, cur);
-      if (lane == 0 && a.reject_count) a.reject_count[c] += rejected;
+      if (wave == 0) store_rec(a.theta + c * D, cur);
+      if (threadIdx.x == 0 && a.reject_count) a.reject_count[c] += rejected;
     }
 #if NETN_TIMING
-    if (lane == 0 && blockIdx.x == 0) for (int k = 0; k < 8; ++k) hta_netn_dbg[k] = ch.tacc[k];
+    if (threadIdx.x == 0 && blockIdx.x == 0) for (int k = 0; k < 8; ++k) hta_netn_dbg[k] = ch.tacc[k];
 #endif
   }
 }
@@ -656,37 +681,57 @@ template <typename T> int netn_hmc(const NetArgs<T>& a, hipStream_t s) {
   HTA_REQUIRE(a.integ >= HTA_SPLIT_SYMMETRIC && a.integ <= HTA_SPLIT_KMID, "hta_netn_hmc: unknown integrator %d", a.integ);
   HTA_REQUIRE(a.integ != HTA_SPLIT_RAND || a.M <= 64, "hta_netn_hmc: SPLITTING_RAND supports at most 64 subsets natively (M=%d)", a.M);
   HTA_REQUIRE(a.integ != HTA_SPLIT_KMID || a.M >= 2, "hta_netn_hmc: SPLITTING_KMID needs at least 2 subsets");
-  // Points per lane and sweep, from the size of a GRADIENT pass (Nb points; the two full-data log p passes of a trajectory
-  // are the minority): the largest of 4, 2, 1 whose sweep of 64 PB points a pass more than half fills - and whose LDS
-  // footprint still lets four workgroups share a CU (1024 chains = 4 per CU: a second round costs more than PB buys).
+  // Waves per chain (WV) and points per lane (PB), from the size of a GRADIENT pass (Nb points; the two full-data log p passes
+  // of a trajectory are the minority).  A sweep of a wave covers 64 PB points.  Both: the largest of 4, 2, 1 that a pass keeps
+  // more than half busy - while the LDS footprint still lets every chain of the launch be resident (a second round of
+  // workgroups costs more than either buys: at 1024 chains four workgroups share a CU).
   const int Dp = (D + 63) & ~63;
-  auto lds_for = [&](int pb) { return ((size_t)2 * Dp + (size_t)2 * (SW + 2) * (64 * pb + 1)) * sizeof(T) + 64 * sizeof(int); };
+  auto lds_for = [&](int pb, int wv) {
+    return ((size_t)2 * Dp + 4 + (size_t)wv * 2 * (SW + 2) * (64 * pb + 1)) * sizeof(T) + 64 * sizeof(int);
+  };
   if (sizeof(T) == 4) {                                     // the matrix-core gradient holds at most 16 NETN_NSET blocks of 4 x 4
     int nb = 0;
     for (int l = 0; l < a.n_layers; ++l) nb += ((a.dims[l + 1] + 3) / 4) * ((a.dims[l] + 4) / 4);
     HTA_REQUIRE(nb <= 16 * NETN_NSET, "hta_netn_hmc: %d blocks of 4 x 4 weights exceed the native limit of %d", nb, 16 * NETN_NSET);
   }
-  int PB = 4;
-  while (PB > 1 && (a.Nb <= 32 * PB || lds_for(PB) > 38 * 1024)) PB >>= 1;
-  const size_t lds = lds_for(PB);
+  int cus = 256;
+  {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  }
+  auto resident = [&](int pb, int wv) {
+    const size_t per_cu = (size_t)(150 * 1024) / lds_for(pb, wv);
+    const size_t by_waves = (size_t)32 / wv;                // 8 waves per SIMD at most
+    return (int64_t)cus * (int64_t)(per_cu < by_waves ? per_cu : by_waves);
+  };
+  // Measured (profiles/r02z_netn_speed.txt): more waves per chain LOSE at 1024 chains - 1.46e7 -> 1.11e7 chain-steps/s on
+  // Net([1,10,10,1]) with two waves and one point per lane instead of one wave and two points, 7.9e7 -> 4.3e7 on the softmax
+  // regression with four: the real barriers and the LDS exchange cost more than the second wave's latency hiding buys (the
+  // RMHMC kernels found the same).  So one wave per chain unless the tuning key "netn_waves" asks for more.
+  int WV = g_netn_waves >= 4 ? 4 : (g_netn_waves >= 2 ? 2 : 1), PB = 4;
+  while (WV > 1 && (a.Nb <= 32 * WV || resident(1, WV) < a.C)) WV >>= 1;
+  while (PB > 1 && (a.Nb <= 32 * PB * WV || resident(PB, WV) < a.C)) PB >>= 1;
+  const size_t lds = lds_for(PB, WV);
   HTA_REQUIRE(lds <= 150 * 1024, "hta_netn_hmc: the layer widths need %zu bytes of LDS", lds);
   const int grid = (int)(a.C < 65536 ? a.C : 65536);
-  auto launch = [&](auto kern, DevOnce& done) -> int {
+  auto launch = [&](auto kern, DevOnce& done, int threads) -> int {
     if (!done) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) { set_error("hta_netn_hmc: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
       done = true;
     }
     profile_begin(s);
-    kern<<<grid, 64, lds, s>>>(a, D, SW, WM);
+    kern<<<grid, threads, lds, s>>>(a, D, SW, WM);
     profile_end(s);
     return HTA_OK;
   };
-  static DevOnce done[3];
-  int rc;
-  if (PB == 1) rc = launch(&netn_hmc_kernel<T, 1>, done[0]);
-  else if (PB == 2) rc = launch(&netn_hmc_kernel<T, 2>, done[1]);
-  else rc = launch(&netn_hmc_kernel<T, 4>, done[2]);
+  static DevOnce done[9];
+  int rc = HTA_OK;
+#define NETN_CASE(P, W, IDX) if (PB == P && WV == W) rc = launch(&netn_hmc_kernel<T, P, W>, done[IDX], 64 * W);
+  NETN_CASE(1, 1, 0) NETN_CASE(1, 2, 1) NETN_CASE(1, 4, 2)
+  NETN_CASE(2, 1, 3) NETN_CASE(2, 2, 4) NETN_CASE(2, 4, 5)
+  NETN_CASE(4, 1, 6) NETN_CASE(4, 2, 7) NETN_CASE(4, 4, 8)
+#undef NETN_CASE
   if (rc) return rc;
   HTA_CHECK_LAUNCH("hta_netn_hmc");
   return HTA_OK;

@@ -336,6 +336,7 @@ int hta_netn_logp_grad_f64(const double* theta, int64_t C, int n_layers, const i
  * on the caller's stream), "rmhmc_batch" (1 default: 16 chains per workgroup on the matrix cores from 2048 chains on; 0 off, 2 always),
  * "rmhmc_mfma4" (1 default: 4 chains per workgroup on v_mfma_f32_4x4x1_16b for "rmhmc_mfma4_lo" = 513 <= chains < "rmhmc_mfma4_hi" = 2049;
  * 0 off, 2 always; "rmhmc_mfma4_waves" 4 default: four waves per group - rows x contraction parity inside a wave; 2 = two waves;
+ * "netn_waves" 1 default: waves per chain of the small-network kernel (2 / 4: a chain's sweeps over several waves where they fit);
  * "rmhmc_uv" 1 default: up to 2 x (compute units) chains run one or two per workgroup with their state sets as columns of the
  * matrix instruction - csrc/rmhmc_uv.hip; 0 off, 2 at any chain count;
  * "rmhmc_pair" 1 default: two consecutive half steps share K + 2 product phases, 0 = one half step at a time), "rmhmc_wide" (1 default: the spill-free one-workgroup-per-CU

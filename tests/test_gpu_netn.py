@@ -210,3 +210,38 @@ def test_netn_limits_fall_back_to_the_callback_path(ht):
         sizes = [w.nelement() for w in net.parameters()]; shapes = [w.shape for w in net.parameters()]
         f = bnn.define_model_log_prob(net, loss, X, Y, sizes, shapes, [1.0] * len(sizes), 1.0, device=dev())
         assert mlp.hmc_engine(f, torch.zeros(1, n_params(dims), device=dev())) is None
+
+
+@pytest.mark.parametrize("waves", [2, 4])
+def test_netn_several_waves_per_chain(ht, waves):
+    """The tuning key "netn_waves": a chain's sweeps over 2 / 4 waves of one workgroup (shared parameter copy and gradient vector,
+    likelihood sums exchanged through LDS).  Slower than one wave per chain at 1024 chains, kept as a measured variant: same
+    run as with one wave, chain by chain to rounding - gradients, a split run with SPLITTING_RAND's shared subset order."""
+    from hamiltorch_amd import _abi
+    dims, act, loss, N, M = [3, 7, 5, 2], "tanh", "multi_class_linear_output", 330, 3
+    X, Y = make_data(dims, loss, N)
+    D, C, Nb = n_params(dims), 9, N // M
+    taus = [1.0 + 0.25 * k for k in range(2 * (len(dims) - 1))]
+    th0 = torch.tensor((0.3 * np.random.default_rng(4).standard_normal((C, D))).astype(np.float32), device=dev())
+    Xd, Yd = X.to(dev()).contiguous(), abi_y(Y, loss, torch.float32)
+    outs = []
+    try:
+        for wv in (1, waves):
+            _abi.set_tuning("netn_waves", wv)
+            g = torch.empty_like(th0); lp = torch.empty(C, device=dev())
+            _abi.netn_logp_grad(th0, dims, act, Xd, Yd, M, Nb, 1, taus, 2.0, float(M), g, lp, loss=loss)
+            cur = th0.clone(); rej = torch.zeros(C, dtype=torch.int32, device=dev()); T = 6
+            samples = torch.zeros(T + 1, C, D, device=dev())
+            _abi.netn_hmc_sample(cur, th0, dims, act, Xd, Yd, M, Nb, taus, 2.0, float(M), _abi.MASS_NONE, None, None, 4, 5e-3, T, 0, 0, 7, 0,
+                                 samples, rej, integrator=_abi.SPLIT_RAND, loss=loss)
+            torch.cuda.synchronize()
+            outs.append((g.cpu().numpy(), lp.cpu().numpy(), samples.cpu().numpy(), rej.cpu().numpy()))
+    finally:
+        _abi.set_tuning("netn_waves", 1)
+    np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=2e-5, atol=2e-5 * np.abs(outs[0][0]).max())
+    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=2e-6)
+    assert np.abs(outs[0][2][1:]).max() > 0
+    err = np.abs(outs[1][2] - outs[0][2]).max(axis=(0, 2))
+    assert (err > 2e-4).mean() <= 0.12, "max err %.3g" % err.max()
+    good = err <= 2e-4
+    assert np.array_equal(outs[1][3][good], outs[0][3][good])
