@@ -25,8 +25,23 @@ def _mlp_structure(model):
     its parameters are flattened in that order (U:121-122): an ``nn.Sequential`` of those modules, or any module whose
     ``forward`` traces (``torch.fx``) to such a chain - the reference notebooks' ``Net`` classes (``self.l1 .. self.l3`` and
     ``torch.relu`` calls in ``forward``); else None."""
+    try:
+        return _STRUCTURE_CACHE[model]                    # (define_split_model_log_prob asks once per batch: trace a model once)
+    except (KeyError, TypeError):
+        pass
     st = _sequential_structure(model)
-    return st if st is not None else _traced_structure(model)
+    if st is None:
+        st = _traced_structure(model)
+    try:
+        _STRUCTURE_CACHE[model] = st
+    except TypeError:
+        pass
+    return st
+
+
+import weakref  # noqa: E402
+
+_STRUCTURE_CACHE = weakref.WeakKeyDictionary()
 
 
 _ACT_FUNCS = {"relu": "relu", "tanh": "tanh", "sigmoid": "sigmoid"}

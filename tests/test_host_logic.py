@@ -298,3 +298,92 @@ def test_graphed_callable_is_transparent_on_cpu_and_logs_refusals():
     x = torch.randn(3, 4)
     assert torch.equal(g(x), (x * x).sum(-1)) and g.cache == {}          # host tensors: plain call, nothing captured
     assert isinstance(util.graph_log, list)
+
+
+def test_model_structure_recognition_of_notebook_style_modules():
+    """bnn._mlp_structure: Sequential chains and plain nn.Module classes whose forward() is Linear / activation calls in order
+    (the reference notebooks' Net) are recognised by tracing; residual connections, parameters flattened in another order than
+    they are used, mixed activations, convolutions are not (they keep the callback path)."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from hamiltorch_amd import bnn
+
+    class Net(nn.Module):
+        def __init__(self, ls):
+            super().__init__()
+            self.l1 = nn.Linear(ls[0], ls[1]); self.l2 = nn.Linear(ls[1], ls[2]); self.l3 = nn.Linear(ls[2], ls[3])
+
+        def forward(self, x):
+            x = self.l1(x); x = torch.relu(x); x = self.l2(x); x = torch.relu(x); x = self.l3(x)
+            return x
+
+    class Lin(nn.Module):
+        def __init__(self):
+            super().__init__(); self.l1 = nn.Linear(4, 3)
+
+        def forward(self, x):
+            return self.l1(x)
+
+    class Fn(nn.Module):
+        def __init__(self):
+            super().__init__(); self.a = nn.Linear(2, 5); self.b = nn.Linear(5, 2)
+
+        def forward(self, x):
+            return self.b(F.relu(self.a(x)))
+
+    class Meth(nn.Module):
+        def __init__(self):
+            super().__init__(); self.a = nn.Linear(2, 5); self.b = nn.Linear(5, 2)
+
+        def forward(self, x):
+            return self.b(self.a(x).tanh())
+
+    class Swapped(nn.Module):                       # flattening order (l2, l1) is not the order of use
+        def __init__(self):
+            super().__init__(); self.l2 = nn.Linear(3, 1); self.l1 = nn.Linear(4, 3)
+
+        def forward(self, x):
+            return self.l2(torch.tanh(self.l1(x)))
+
+    class Res(nn.Module):
+        def __init__(self):
+            super().__init__(); self.l1 = nn.Linear(4, 4)
+
+        def forward(self, x):
+            return self.l1(x) + x
+
+    class Mixed(nn.Module):
+        def __init__(self):
+            super().__init__(); self.a = nn.Linear(2, 3); self.b = nn.Linear(3, 3); self.c = nn.Linear(3, 1)
+
+        def forward(self, x):
+            return self.c(torch.tanh(self.b(torch.relu(self.a(x)))))
+
+    class Conv(nn.Module):
+        def __init__(self):
+            super().__init__(); self.c = nn.Conv2d(1, 2, 3); self.f = nn.Linear(8, 2)
+
+        def forward(self, x):
+            return self.f(torch.relu(self.c(x)).view(-1, 8))
+
+    assert bnn._mlp_structure(Net([1, 10, 10, 1])) == ([1, 10, 10, 1], "relu")
+    assert bnn._mlp_structure(Lin()) == ([4, 3], "relu")
+    assert bnn._mlp_structure(Fn()) == ([2, 5, 2], "relu")
+    assert bnn._mlp_structure(Meth()) == ([2, 5, 2], "tanh")
+    assert bnn._mlp_structure(nn.Sequential(nn.Linear(3, 5), nn.Sigmoid(), nn.Linear(5, 1))) == ([3, 5, 1], "sigmoid")
+    for bad in (Swapped(), Res(), Mixed(), Conv(), nn.Sequential(nn.Linear(3, 5, bias=False), nn.ReLU(), nn.Linear(5, 1))):
+        assert bnn._mlp_structure(bad) is None, type(bad).__name__
+    # the closures carry a native spec exactly for the likelihoods with a kernel
+    X = torch.randn(12, 4); yc = torch.randint(0, 3, (12, 1)).float()
+    net = Lin(); sizes = [w.nelement() for w in net.parameters()]; shapes = [w.shape for w in net.parameters()]
+    f = bnn.define_model_log_prob(net, "multi_class_linear_output", X, yc, sizes, shapes, [1.0, 1.0], 1.0)
+    assert f._hta_spec["dims"] == [4, 3] and f._hta_spec["loss"] == "multi_class_linear_output" and f._hta_spec["Y"].shape == (12,)
+    f = bnn.define_model_log_prob(net, "regression", X, torch.randn(12, 3), sizes, shapes, [1.0, 1.0], 1.0)
+    assert not hasattr(f, "_hta_spec")              # multi-output regression returns one value per output (S:1184): callback path
+    from hamiltorch_amd import mlp
+    assert mlp._kernel_for(dict(dims=[8, 100, 1], loss="regression")) == "mlp1"
+    assert mlp._kernel_for(dict(dims=[1, 10, 10, 1], loss="regression")) == "netn"
+    assert mlp._kernel_for(dict(dims=[4, 3], loss="multi_class_linear_output")) == "netn"
+    assert mlp._kernel_for(dict(dims=[8, 100, 3], loss="multi_class_linear_output")) is None       # wider than the small-net kernel
+    assert mlp._kernel_for(dict(dims=[2, 3, 3, 3, 3, 1], loss="regression")) is None               # five Linear layers
