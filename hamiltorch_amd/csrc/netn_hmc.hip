@@ -17,6 +17,9 @@
 // How it got here (tools/scratch/netn_time.py, profiles/r02z_netn_speed.txt; Net([1,10,10,1]), 400 points, 1024 chains):
 // 3.6e6 chain-steps/s with one point per lane and a DPP reduction per weight -> 5.4e6 (interleaved reductions, plain ds_add) ->
 // 8.6e6 (several points per lane, blocks of four units) -> 1.46e7 (gradient on the matrix cores); the callback path: 6.8e5.
+// Tried and dropped: the forward products and the delta propagation as matrix instructions as well ((4 points) x (4 units)
+// blocks, the lane's own activation as the A operand, the result written back transposed inside the quad): 1.16e7 - its
+// per-input loop with run-time layer shapes issues more than the blocked FMA loops it replaces.
 // Layer shapes are run-time values (uniform loops); limits: D <= 512 parameters, widths <= 64, N <= what L2 holds (X is read
 // from global memory, coalesced over the lanes).
 #include "mlp.hpp"
