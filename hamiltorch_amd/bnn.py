@@ -56,7 +56,7 @@ def _traced_structure(model):
     except Exception:                     # data-dependent control flow etc.: not a plain chain
         return None
     mods = dict(gm.named_modules())
-    dims, act, linears = [], None, []
+    dims, act, linears, tail = [], None, [], None
     prev, expect_linear, seen_input = None, True, False
     for node in gm.graph.nodes:
         if node.op == "placeholder":
@@ -66,12 +66,21 @@ def _traced_structure(model):
             continue
         if node.op == "output":
             out = node.args[0]
-            if out is not prev or expect_linear or len(dims) < 2:
+            if out is not prev or (expect_linear and tail is None) or len(dims) < 2:
                 return None
             continue
         tensor_args = [a for a in node.args if isinstance(a, torch.fx.Node)]
-        if tensor_args != [prev] or any(isinstance(v, torch.fx.Node) for v in node.kwargs.values()):
+        if tensor_args != [prev] or any(isinstance(v, torch.fx.Node) for v in node.kwargs.values()) or tail is not None:
             return None
+        is_lsm = (node.op == "call_module" and isinstance(mods.get(node.target), nn.LogSoftmax) and mods[node.target].dim in (1, -1)) or \
+                 (node.op in ("call_function", "call_method") and getattr(node.target, "__name__", node.target) == "log_softmax"
+                  and (tuple(node.args[1:]) in ((1,), (-1,)) or node.kwargs.get("dim") in (1, -1)))
+        if is_lsm:                                  # a log-softmax over the outputs closes the chain ('multi_class_log_softmax_output')
+            if expect_linear or len(dims) < 2:
+                return None
+            tail = "log_softmax"
+            prev = node
+            continue
         if node.op == "call_module" and isinstance(mods.get(node.target), nn.Linear):
             m = mods[node.target]
             if not expect_linear or m.bias is None or (dims and dims[-1] != m.in_features):
@@ -100,13 +109,16 @@ def _traced_structure(model):
     want = [t for m in linears for t in (m.weight, m.bias)]
     if len(params) != len(want) or any(a is not b for a, b in zip(params, want)) or list(model.buffers()):
         return None                       # other parameters, shared layers, or a flattening order that is not the order of use
-    return dims, (act or "relu")
+    return (dims, (act or "relu")) if tail is None else (dims, (act or "relu"), tail)
 
 
 def _sequential_structure(model):
     if not isinstance(model, nn.Sequential):
         return None
     mods = list(model.children())
+    tail = None
+    if mods and isinstance(mods[-1], nn.LogSoftmax) and mods[-1].dim in (1, -1):
+        mods, tail = mods[:-1], "log_softmax"
     dims, act = [], None
     expect_linear = True
     for m in mods:
@@ -127,7 +139,7 @@ def _sequential_structure(model):
             expect_linear = True
     if expect_linear or len(dims) < 2:
         return None
-    return dims, (act or "relu")
+    return (dims, (act or "relu")) if tail is None else (dims, (act or "relu"), tail)
 
 
 def define_model_log_prob(model, model_loss, x, y, params_flattened_list, params_shape_list, tau_list, tau_out,
@@ -173,22 +185,31 @@ def define_model_log_prob(model, model_loss, x, y, params_flattened_list, params
         return ll + l_prior / prior_scale
 
     st = _mlp_structure(model) if (x is not None and not predict and x.dim() == 2) else None
+    spec_tau_out, spec_loss = float(tau_out), model_loss
+    if st is not None and len(st) == 3:
+        # the model ends in a log-softmax: with 'multi_class_log_softmax_output' (nll_loss, MEAN reduction, S:1180) the closure is
+        # -(tau_out / N) * cross-entropy of the logits - the softmax kernel with a scaled precision; other pairings: callback path
+        if model_loss == 'multi_class_log_softmax_output' and st[0][-1] >= 2 and y_dev.numel() == x_dev.shape[0]:
+            spec_tau_out, spec_loss, st = float(tau_out) / x_dev.shape[0], 'multi_class_linear_output', st[:2]
+        else:
+            st = None
     if st is not None:
+        model_loss_ = spec_loss
         n_pts, n_out = x_dev.shape[0], st[0][-1]
         # the likelihoods with a native kernel: Gaussian on one output, Bernoulli with logits (any number of outputs, summed),
         # softmax cross-entropy on integer labels; the other kinds (and multi-output regression, whose closure returns one
         # value per output, S:1184) stay on the callback path
-        if model_loss == 'regression' and n_out == 1 and y_dev.numel() == n_pts:
+        if model_loss_ == 'regression' and n_out == 1 and y_dev.numel() == n_pts:
             y_spec = y_dev.reshape(n_pts, 1)
-        elif model_loss == 'binary_class_linear_output' and y_dev.numel() == n_pts * n_out:
+        elif model_loss_ == 'binary_class_linear_output' and y_dev.numel() == n_pts * n_out:
             y_spec = y_dev.reshape(n_pts, n_out)
-        elif model_loss == 'multi_class_linear_output' and n_out >= 2 and y_dev.numel() == n_pts:
+        elif model_loss_ == 'multi_class_linear_output' and n_out >= 2 and y_dev.numel() == n_pts:
             y_spec = y_dev.reshape(n_pts)
         else:
             y_spec = None
         if y_spec is not None:
-            log_prob_func._hta_spec = dict(dims=st[0], act=st[1], X=x_dev, Y=y_spec, tau_list=list(taus), tau_out=float(tau_out),
-                                           prior_scale=float(prior_scale), loss=model_loss)
+            log_prob_func._hta_spec = dict(dims=st[0], act=st[1], X=x_dev, Y=y_spec, tau_list=list(taus), tau_out=spec_tau_out,
+                                           prior_scale=float(prior_scale), loss=model_loss_)
     return log_prob_func
 
 

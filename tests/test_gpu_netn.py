@@ -245,3 +245,29 @@ def test_netn_several_waves_per_chain(ht, waves):
     assert (err > 2e-4).mean() <= 0.12, "max err %.3g" % err.max()
     good = err <= 2e-4
     assert np.array_equal(outs[1][3][good], outs[0][3][good])
+
+
+def test_log_softmax_models_run_on_the_softmax_kernel(ht, golden):
+    """'multi_class_log_softmax_output' (nll_loss with its MEAN reduction, S:1180) on a model that ends in LogSoftmax(dim=1) is
+    -(tau_out / N) x the cross-entropy of the logits: the softmax kernel with a scaled precision.  Pinned to the reference's own
+    value and gradient (losses.npz 'logsoftmax': Linear(4,6)-Tanh-Linear(6,3)-LogSoftmax, tau_out = 2, N = 10), then
+    sample_model natively (one launch) against the callback path on the same draws."""
+    from hamiltorch_amd import _abi
+    g = golden("losses")
+    th = torch.tensor(g["logsoftmax_theta"][None].astype(np.float64), device=dev())
+    grad = torch.empty_like(th); lp = torch.empty(1, dtype=torch.float64, device=dev())
+    _abi.netn_logp_grad(th, [4, 6, 3], "tanh", torch.tensor(g["logsoftmax_X"], dtype=torch.float64, device=dev()),
+                        torch.tensor(g["logsoftmax_Y"].reshape(-1), dtype=torch.float64, device=dev()), 1, 10, 0, list(g["logsoftmax_tau_list"]),
+                        2.0 / 10, 1.0, grad, lp, loss="multi_class_linear_output")
+    np.testing.assert_allclose(lp.cpu().numpy(), g["logsoftmax_logp"], rtol=2e-6)
+    np.testing.assert_allclose(grad.cpu().numpy()[0], g["logsoftmax_grad"], rtol=2e-5, atol=2e-6)
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 6), torch.nn.Tanh(), torch.nn.Linear(6, 3), torch.nn.LogSoftmax(dim=1)).to(dev())
+    X, Y = make_data([4, 6, 3], "multi_class_linear_output", 90)
+    C, NS, L, seed = 16, 6, 4, 3
+    th0 = torch.tensor((0.3 * O.philox_normals(seed, np.arange(C), 0, 51, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32), device=dev())
+    kw = dict(model_loss="multi_class_log_softmax_output", num_samples=NS, num_steps_per_sample=L, step_size=0.05, tau_out=40.0, verbose=False, seed=seed)
+    out, launches = _launch_count(lambda: ht.sample_model(net, X, Y, th0, **kw))
+    assert launches == 1, launches
+    ref = ht.sample_model(net, X, Y, th0, native=False, **kw)
+    _cmp(out, [r.cpu().numpy() for r in ref], 5e-4)

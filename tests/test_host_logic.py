@@ -374,6 +374,31 @@ def test_model_structure_recognition_of_notebook_style_modules():
     assert bnn._mlp_structure(nn.Sequential(nn.Linear(3, 5), nn.Sigmoid(), nn.Linear(5, 1))) == ([3, 5, 1], "sigmoid")
     for bad in (Swapped(), Res(), Mixed(), Conv(), nn.Sequential(nn.Linear(3, 5, bias=False), nn.ReLU(), nn.Linear(5, 1))):
         assert bnn._mlp_structure(bad) is None, type(bad).__name__
+    # a log-softmax over the outputs closes the chain (module, function or method form; dim 1 only)
+    class LsmF(nn.Module):
+        def __init__(self):
+            super().__init__(); self.a = nn.Linear(4, 6); self.b = nn.Linear(6, 3)
+
+        def forward(self, x):
+            return F.log_softmax(self.b(torch.tanh(self.a(x))), dim=1)
+
+    class LsmDim0(nn.Module):
+        def __init__(self):
+            super().__init__(); self.a = nn.Linear(4, 3)
+
+        def forward(self, x):
+            return F.log_softmax(self.a(x), dim=0)
+
+    assert bnn._mlp_structure(nn.Sequential(nn.Linear(4, 6), nn.Tanh(), nn.Linear(6, 3), nn.LogSoftmax(dim=1))) == ([4, 6, 3], "tanh", "log_softmax")
+    assert bnn._mlp_structure(LsmF()) == ([4, 6, 3], "tanh", "log_softmax")
+    assert bnn._mlp_structure(LsmDim0()) is None
+    lsm = nn.Sequential(nn.Linear(4, 6), nn.Tanh(), nn.Linear(6, 3), nn.LogSoftmax(dim=1))
+    ls_sizes = [w.nelement() for w in lsm.parameters()]; ls_shapes = [w.shape for w in lsm.parameters()]
+    yl = torch.randint(0, 3, (12, 1)).float()
+    f = bnn.define_model_log_prob(lsm, "multi_class_log_softmax_output", torch.randn(12, 4), yl, ls_sizes, ls_shapes, [1.0] * 4, 3.0)
+    assert f._hta_spec["loss"] == "multi_class_linear_output" and abs(f._hta_spec["tau_out"] - 3.0 / 12) < 1e-12     # nll_loss: mean reduction (S:1180)
+    f = bnn.define_model_log_prob(lsm, "multi_class_linear_output", torch.randn(12, 4), yl, ls_sizes, ls_shapes, [1.0] * 4, 3.0)
+    assert not hasattr(f, "_hta_spec")
     # the closures carry a native spec exactly for the likelihoods with a kernel
     X = torch.randn(12, 4); yc = torch.randint(0, 3, (12, 1)).float()
     net = Lin(); sizes = [w.nelement() for w in net.parameters()]; shapes = [w.shape for w in net.parameters()]
