@@ -174,7 +174,9 @@ __global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
     }
   };
   // H = -log p + D/2 log 2 pi + 1/2 log|G| + 1/2 g^T G^-1 g  (S:731) of this column's (X, g); also returns P (X - mu) and S g
-  auto hamiltonian = [&](uint32_t n, uint32_t sub, const T (&X)[4], const T (&g)[4], T& H, T& logp, T (&Pd_out)[4], T (&Sg_out)[4]) {
+  // (n, sub: per lane - in the Hamiltonian at a trajectory's end the V column evaluates the NEXT trajectory's momentum terms)
+  auto hamiltonian = [&](uint32_t n, uint32_t sub, const T (&X)[4], const T (&g)[4], T& H, T& logp, T (&Pd_out)[4], T (&Sg_out)[4],
+                         T& kin_out, T& ld_out) {
     T ev[4] = {0.f, 0.f, 0.f, 0.f}, dr[4];
     if (a.has_jitter) jitter_raw(n, sub, ev);
     centred(X, dr);
@@ -200,6 +202,10 @@ __global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
     const float pi_term = (float)D * 1.8378770351409912f;   // S:712
     logp = a.log_norm - 0.5f * v[0];
     H = -logp + 0.5f * pi_term + 0.5f * (a.logdetP + v[2]) + 0.5f * v[1];
+    kin_out = v[1]; ld_out = v[2];
+  };
+  auto of_set_v = [&](T v) {                                 // the V column's value of this chain: lane l | 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xF5 /* quad_perm:[1,1,3,3] */, 0xf, 0xf, false));
   };
 
   const int64_t ngroup = (a.C + G - 1) / G;
@@ -212,16 +218,34 @@ __global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
     for (int e = 0; e < 4; ++e) scur[e] = (live && rok[e]) ? a.cur[c * D + row0 + e] : 0.f;
     int32_t rejected = 0;
     __syncthreads();                                        // the previous group's last reads of the vector matrices
+    // H_old of trajectory t + 1 needs, besides -log p of the current point, only terms of the NEW momentum and jitter
+    // (1/2 p^T G^-1 p and log |G|: the curvature is constant) - none of them waits for trajectory t's outcome.  So the
+    // Hamiltonian at the END of trajectory t evaluates them on the side: the V column, idle there, takes p(t+1) and the jitter
+    // of (t+1, sub-stream 1) through the same phases, and trajectory t + 1 starts without a Hamiltonian of its own
+    // (log p, y = P (theta - mu) of the accepted / kept point are known; z = S p(t+1) comes out of the V column).  The same
+    // products in the same order as the separate evaluation: bit-identical results, four phases less per trajectory.  Not
+    // taken for a launch's first trajectory and after the Q2 reset to params_init (its log p is not known).
+    bool have_next = false;
+    T gn[4] = {0.f, 0.f, 0.f, 0.f}, y_next[4], z_next[4], H0_next = 0.f, lp_next = 0.f;
     for (int t = 0; t < a.n_traj; ++t) {
       const uint32_t n = (uint32_t)(a.traj_offset + t);
       // ---- gibbs: p = chol(G(theta)) z, drawn ahead by the momentum kernel (S:183-184); theta_c = theta, p_c = p (S:425-426)
+      T H0, H1, lp0, lp1, kin, ld;
+      if (have_next) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        g[e] = (live && rok[e]) ? a.p_ws[((int64_t)t * a.C + c) * D + row0 + e] : 0.f;
-        X[e] = scur[e];
+        for (int e = 0; e < 4; ++e) { g[e] = gn[e]; X[e] = scur[e]; y[e] = y_next[e]; z[e] = z_next[e]; }
+        H0 = H0_next; lp0 = lp_next;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          g[e] = (live && rok[e]) ? a.p_ws[((int64_t)t * a.C + c) * D + row0 + e] : 0.f;
+          X[e] = scur[e];
+        }
+        hamiltonian(n, 1, X, g, H0, lp0, y, z, kin, ld);    // S:971 -> S:822
       }
-      T H0, H1, lp0, lp1;
-      hamiltonian(n, 1, X, g, H0, lp0, y, z);               // S:971 -> S:822
+      T y_start[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y_start[e] = y[e];
       // one pair of half steps for this column; WB: the pair's two refinement matrices
       auto half_pair = [&](bool first, const T (&e)[4], T* WB) {
         if (first) {
@@ -297,13 +321,34 @@ __global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
         half_pair(setV, e2, WS + 2 * MSZ);                  // phi_B/2, phi_A/2  S:454-458
       }
       if (a.K == 0) __syncthreads();
-      T unused1[4], unused2[4];
-      hamiltonian(n, 2u + 8u * (uint32_t)a.L, X, g, H1, lp1, unused1, unused2);   // S:989 (Q4): the un-augmented pair = set U
+      // ---- H_new on the un-augmented pair = set U (S:989, Q4); in the V column: the next trajectory's momentum terms
+      const bool pre = t + 1 < a.n_traj;
+      T Pd1[4], Sg1[4], Xh[4], gh[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (pre) gn[e] = (live && rok[e]) ? a.p_ws[((int64_t)(t + 1) * a.C + c) * D + row0 + e] : 0.f;
+        const T xu = of_set_u(X[e]);
+        Xh[e] = xu;                                          // both columns at the proposal theta': the V column's P (theta' - mu) is not used
+        gh[e] = (setV && pre) ? gn[e] : (setV ? of_set_u(g[e]) : g[e]);
+      }
+      const bool nextcol = setV && pre;
+      hamiltonian(nextcol ? n + 1u : n, nextcol ? 1u : 2u + 8u * (uint32_t)a.L, Xh, gh, H1, lp1, Pd1, Sg1, kin, ld);
       // ---- Metropolis test + bookkeeping (S:1000-1026, S:1045-1057) on the U column's values, mirrored in the V column
       const T H0u = of_set_u(H0), H1u = of_set_u(H1), lp1u = of_set_u(lp1);
       const T u = u23<T>(philox_block(a.seed, chain, n, PURPOSE_MH, 0, 0).x);
       const bool acc = mh_accept<T>(H0u, H1u, lp1u, u);
       const bool reset = (!acc) && ((int)n == a.burn + 1);  // Q2
+      have_next = pre && !reset;
+      if (have_next) {                                       // H_old, y, z of trajectory t + 1 (the expression of hamiltonian(), same order)
+        const float pi_term = (float)D * 1.8378770351409912f;
+        lp_next = acc ? lp1u : of_set_u(lp0);
+        H0_next = -lp_next + 0.5f * pi_term + 0.5f * (a.logdetP + of_set_v(ld)) + 0.5f * of_set_v(kin);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          y_next[e] = acc ? of_set_u(Pd1[e]) : y_start[e];
+          z_next[e] = of_set_v(Sg1[e]);
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const T xu = of_set_u(X[e]);
