@@ -502,7 +502,8 @@ def result_of(w, W, dt, call_ms, prof_ms, prof_n, steps, warmup, world):
         roof["traffic"] = phys.get("hbm_bytes_per_step")
     from hamiltorch_amd.ess import ess_min
     ess = ess_min(w.samples[1:]) if w.T >= 8 else float("nan")
-    return {"workload": W.name, "value": units / dt, "unit": "leapfrog-steps/s", "steps": steps, "warmup": warmup,
+    return {"key": W.key + ("-eig" if getattr(w, "jacobi", False) else ""), "workload": W.name, "value": units / dt,
+            "unit": "leapfrog-steps/s", "steps": steps, "warmup": warmup,
             "ms_per_step": dt / steps * 1e3, "dtype": W.dtype_name,
             "config": {"workload": W.name, "chains_per_gpu": w.C, "chains_total": w.C * world,
                        "trajectories_per_step": w.T, "leapfrog_steps_per_trajectory": W.L, "D": W.D,
@@ -522,6 +523,125 @@ def api_timing(w, reps=5):
         ts.append((time.perf_counter() - t0) * 1e3)
         del out
     return statistics.median(ts)
+
+
+
+# ---------------------------------------------------------------------------------------------------
+# the driver's line: the contract keys only, numbers rounded, no prose (the driver keeps an 8 KB stdout tail;
+# round 2's 21 KB line could not be parsed).  The complete record goes to bench_detail.json and to an EARLIER line.
+# ---------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096
+
+
+def _r(x, sig=5):
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (sig, x))
+    return x
+
+
+def _short_key(rec):
+    """cfg2 | cfg3@1024 | cfg3 | cfg3-eig | cfg4 | nbmlp ... from a full record's workload name."""
+    if rec.get("key"):
+        return rec["key"]
+    name = rec.get("workload") or rec.get("config", {}).get("workload", "")
+    key = name.split(":")[0].strip()
+    if name.startswith("north-star RMHMC"):
+        key = "cfg3@1024"
+    if "eigendecomposition route" in name:
+        key += "-eig"
+    return key
+
+
+def _compact_roofline(roof):
+    phys = roof.get("physical") or {}
+    out = {"bound": roof.get("bound"), "achieved": _r(roof.get("achieved")), "peak": roof.get("peak"), "unit": roof.get("unit"),
+           "frac": _r(roof.get("frac"), 4), "traffic": _r(roof.get("traffic")),
+           "kernel": str(roof.get("kernel", "")).split(" (")[0][:64],
+           "kernel_ms": _r(roof.get("kernel_ms", roof.get("kernel_ms_per_step"))),
+           "mfma_busy": _r(phys.get("mfma_busy_frac"), 3),
+           "simds_occupied_frac": _r(roof.get("simds_occupied_frac", phys.get("simds_occupied_frac")), 3)}
+    if roof.get("traffic") is not None:
+        out["traffic_src"] = "profiles/physical.json"
+    lat = roof.get("latency_model")
+    if lat:
+        out["frac_of_latency_floor"] = _r(lat.get("frac_of_latency_floor"), 3)
+    if roof.get("mfma_issued_over_useful") is not None:
+        out["mfma_issued_over_useful"] = _r(roof["mfma_issued_over_useful"], 3)
+    return out
+
+
+def _compact_cpu(cb):
+    if not cb:
+        return None
+    return {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+            "sample": str(cb.get("sample", "")).split(" (")[0][:96], "pinned_to": str(cb.get("pinned_to", "")).split(" (")[0][:40],
+            "host_cpu": str(cb.get("host_cpu", ""))[:48], "ess_per_sec": _r(cb.get("ess_per_sec"))}
+
+
+def compact_line(full, detail_path="bench_detail.json"):
+    """The ONE JSON line the driver parses: contract keys + roofline + cpu_baseline + a compact `secondary` list with the
+    north-star RMHMC size first.  Always < LINE_LIMIT bytes (secondary entries are dropped from the tail if a future
+    workload list would not fit; the complete record is in `detail`)."""
+    cfg = full.get("config", {})
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    out["value"], out["ms_per_step"] = _r(out["value"], 6), _r(out["ms_per_step"], 6)
+    out["config"] = {"workload": _short_key(full), "chains_per_gpu": cfg.get("chains_per_gpu"), "chains_total": cfg.get("chains_total"),
+                     "trajectories_per_step": cfg.get("trajectories_per_step"), "L": cfg.get("leapfrog_steps_per_trajectory"),
+                     "D": cfg.get("D"), "parallelism": str(cfg.get("parallelism", ""))[:48]}
+    out["roofline"] = _compact_roofline(full.get("roofline", {}))
+    if full.get("cpu_baseline"):
+        out["cpu_baseline"] = _compact_cpu(full["cpu_baseline"])
+        out["speedup_vs_cpu_baseline"] = _r(full.get("speedup_vs_cpu_baseline"), 4)
+    for k in ("api_ms_per_step", "api_value", "acceptance_rate", "ess_per_sec", "ess_per_sec_vs_cpu_baseline", "gather_ms"):
+        if full.get(k) is not None:
+            out[k] = _r(full[k])
+    for k in ("ranks_seen", "rank_devices", "launcher", "collective_backend", "route"):
+        if k in full:
+            out[k] = full[k]
+    sec = []
+    for r in full.get("secondary", []) or []:
+        if "error" in r:
+            sec.append({"key": _short_key(r), "error": r["error"][:80]})
+            continue
+        roof, cb = _compact_roofline(r.get("roofline", {})), r.get("cpu_baseline") or {}
+        e = {"key": _short_key(r), "chains": r.get("config", {}).get("chains_per_gpu"), "value": _r(r.get("value")),
+             "ms_per_step": _r(r.get("ms_per_step")), "steps": r.get("steps"), "frac": roof["frac"], "bound": roof["bound"],
+             "achieved": roof["achieved"], "unit": roof["unit"], "mfma_busy": roof["mfma_busy"], "traffic": roof["traffic"],
+             "kernel": roof["kernel"][:40], "kernel_ms": roof["kernel_ms"], "cpu": {"value": _r(cb.get("value"), 4), "cores": cb.get("cores")}}
+        if r.get("route"):
+            e["route"] = r["route"]
+        if r.get("published"):
+            e["published"] = r["published"]
+        sec.append(e)
+    if sec:
+        out["secondary"] = sec
+    out["detail"] = detail_path
+    line = json.dumps(out, separators=(",", ":"))
+    while len(line) >= LINE_LIMIT and out.get("secondary"):          # never print a line the driver cannot keep
+        out["secondary"].pop()
+        out["secondary_truncated"] = True
+        line = json.dumps(out, separators=(",", ":"))
+    return line
+
+
+def emit(full):
+    """Complete record -> bench_detail.json (+ gpurun_out/) and an earlier stdout line; the compact line LAST."""
+    detail = json.dumps(full)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(detail + "\n")
+        except OSError:
+            pass
+    sys.stdout.write("BENCH_DETAIL " + detail + "\n")
+    sys.stdout.flush()
+    print(compact_line(full), flush=True)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -614,7 +734,7 @@ def main():
         del gathered
 
     if rank == 0:
-        out = {"metric": METRIC, "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        out = {"key": res["key"], "metric": METRIC, "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": W.dtype_name, "data": "synthetic", "config": res["config"], "roofline": res["roofline"],
                "acceptance_rate": res["acceptance_rate"], "ess_per_sec": res["ess_per_sec"],
@@ -645,7 +765,7 @@ def main():
             del w
             torch.cuda.empty_cache()
             out["secondary"] = secondary(dev, a)
-        print(json.dumps(out), flush=True)
+        emit(out)
         if a.sweep and a.workload == "cfg2":
             for C in (1024, 4096, 16384, 65536, 262144, 1048576):
                 ws = W(dev, C, max(10, min(1000, (1 << 24) // C)), 0)

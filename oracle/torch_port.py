@@ -172,7 +172,7 @@ def port_sample_rmhmc(log_prob_func, params_init, num_samples, num_steps_per_sam
         q_new, p_new = port_explicit_leapfrog(params, p, log_prob_func, num_steps_per_sample, step_size, omega, alpha, softabs, jitter)
         params = q_new.detach().requires_grad_()
         new_ham = port_rm_hamiltonian(params, p_new, log_prob_func, alpha, softabs, jitter)       # S:989
-        rho = min(0., float(-new_ham + ham))
+        rho = min(0., float((-new_ham + ham).detach()))
         if rho >= torch.log(torch.rand(1)):
             if n > burn:
                 ret.append(q_new.detach())

@@ -1,0 +1,108 @@
+"""The driver keeps an 8 KB tail of bench.py's stdout and parses its LAST line (round 2's 21 KB line came back as
+`parsed: null`).  These tests pin the shape and size of that line on a complete record of a real run
+(profiles/r02zz_bench.json, 21 KB) and on an inflated one."""
+import copy
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+ROOF = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "mfma_busy", "simds_occupied_frac")
+CPU = ("value", "unit", "cores", "kind", "sample", "pinned_to", "host_cpu")
+
+
+def _full():
+    return json.load(open(os.path.join(ROOT, "profiles", "r02zz_bench.json")))
+
+
+def _driver_view(stdout, tail=8000):
+    """What the driver does: keep the tail, parse the last line."""
+    return json.loads(stdout[-tail:].splitlines()[-1])
+
+
+def test_compact_line_is_small_and_complete():
+    full = _full()
+    assert len(json.dumps(full)) > 16000                  # the record that could not be parsed in round 2
+    line = bench.compact_line(full)
+    assert len(line.encode()) < bench.LINE_LIMIT == 4096
+    assert "\n" not in line
+    rec = json.loads(line)
+    for k in CONTRACT:
+        assert k in rec, k
+    for k in ROOF:
+        assert k in rec["roofline"], k
+    for k in CPU:
+        assert k in rec["cpu_baseline"], k
+    assert rec["value"] == pytest.approx(full["value"], rel=1e-5)
+    assert rec["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-3)
+    assert rec["cpu_baseline"]["cores"] == full["cpu_baseline"]["cores"]
+    assert rec["config"]["workload"] == "cfg2" and rec["config"]["chains_per_gpu"] == 1024
+    sec = rec["secondary"]
+    assert [s["key"] for s in sec] == ["cfg3@1024", "cfg3", "cfg3-eig", "cfg4"]          # the north-star RMHMC size first
+    for s, f in zip(sec, full["secondary"]):
+        assert s["value"] == pytest.approx(f["value"], rel=1e-4)
+        assert s["frac"] == pytest.approx(f["roofline"]["frac"], rel=1e-3)
+        assert s["cpu"]["cores"] == 1 and s["cpu"]["value"] > 0
+        assert s["chains"] == f["config"]["chains_per_gpu"]
+    assert "note" not in line and "physical" not in rec["roofline"]                       # no prose, no inlined profile
+
+
+def test_last_line_survives_the_drivers_tail(tmp_path, monkeypatch, capsys):
+    full = _full()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench.emit(full)
+    out = capsys.readouterr().out
+    assert out.count("\n") == 2 and out.startswith("BENCH_DETAIL ")
+    rec = _driver_view(out)
+    assert rec["value"] == pytest.approx(full["value"], rel=1e-5)
+    assert rec["secondary"][0]["key"] == "cfg3@1024"
+    assert rec["roofline"]["kernel"].startswith("hmc_gauss_quad_kernel")
+    # also with a stderr suffix interleaved before it (warnings printed earlier cannot cut the last line)
+    rec2 = _driver_view("x" * 5000 + "\n" + out)
+    assert rec2 == rec
+    # the complete record went to the side file
+    side = json.load(open(tmp_path / "bench_detail.json"))
+    assert side["secondary"][0]["roofline"]["physical"] is not None
+    assert json.loads(out.splitlines()[0][len("BENCH_DETAIL "):]) == side
+
+
+def test_line_never_exceeds_the_limit_even_with_many_workloads():
+    full = _full()
+    extra = copy.deepcopy(full["secondary"])
+    for i in range(6):
+        for e in copy.deepcopy(extra):
+            e["workload"] = "extra%d: " % i + "x" * 200
+            e["roofline"]["kernel"] = "k" * 300
+            full["secondary"].append(e)
+    line = bench.compact_line(full)
+    assert len(line.encode()) < 4096
+    rec = json.loads(line)
+    assert rec["secondary"][0]["key"] == "cfg3@1024" and rec["secondary_truncated"] is True
+    for k in CONTRACT:
+        assert k in rec
+
+
+def test_multi_gpu_keys_are_in_the_line():
+    full = _full()
+    full.update({"n_gpus": 8, "ranks_seen": 8, "rank_devices": [[r, r] for r in range(8)], "collective_backend": "rccl",
+                 "launcher": "torch.distributed.run", "gather_ms": 1.25})
+    full.pop("secondary"); full.pop("cpu_baseline")
+    rec = json.loads(bench.compact_line(full))
+    assert rec["n_gpus"] == 8 and rec["ranks_seen"] == 8 and rec["collective_backend"] == "rccl"
+    assert rec["gather_ms"] == 1.25 and len(rec["rank_devices"]) == 8
+
+
+def test_nonfinite_numbers_do_not_break_the_json():
+    full = _full()
+    full["ess_per_sec"] = float("nan")
+    full["secondary"][0]["value"] = float("inf")
+    rec = json.loads(bench.compact_line(full))          # strict JSON: NaN / Infinity would not parse elsewhere
+    assert "NaN" not in bench.compact_line(full) and "Infinity" not in bench.compact_line(full)
+    assert rec["secondary"][0]["value"] is None
