@@ -204,7 +204,13 @@ def define_model_log_prob(model, model_loss, x, y, params_flattened_list, params
         elif model_loss_ == 'binary_class_linear_output' and y_dev.numel() == n_pts * n_out:
             y_spec = y_dev.reshape(n_pts, n_out)
         elif model_loss_ == 'multi_class_linear_output' and n_out >= 2 and y_dev.numel() == n_pts:
-            y_spec = y_dev.reshape(n_pts)
+            # the kernel indexes the logits with the label: only integer-valued labels in [0, n_out) may reach it (the
+            # reference's CrossEntropyLoss raises on anything else; a closure with such labels stays on the callback path,
+            # where torch raises the same error) -- one reduction on the device per closure, at definition time
+            yl = y_dev.reshape(n_pts)
+            yd = yl.double()
+            ok = bool(((yd == yd.round()) & (yd >= 0) & (yd < n_out)).all()) if n_pts > 0 else False
+            y_spec = yl if ok else None
         else:
             y_spec = None
         if y_spec is not None:
@@ -287,9 +293,12 @@ predict_stats = {"batched": 0, "looped": 0}
 
 
 def _eval_all(f, samples, dev):
-    """(log_prob, output) of the predict-closure `f` for every sample: ONE batched evaluation over the stacked samples
-    (`torch.func.vmap`, in chunks that keep the activations under ~256 MB) instead of the reference's Python loop over samples
-    (S:1530-1552); a closure vmap cannot batch falls back to that loop.  Returns (list of log-probs, list of outputs)."""
+    """(log_prob, output) of the predict-closure `f` for every sample: batched evaluations over the stacked samples
+    (`torch.func.vmap`) instead of the reference's Python loop over samples (S:1530-1552).  The chunk is sized from the
+    MEASURED peak memory of one single-sample evaluation (hidden and convolution activations included, not only the
+    output) against a 256 MB budget; an out-of-memory error frees the cache and halves the chunk, down to the reference's
+    per-sample loop -- predict_model never fails where the loop would succeed.  A closure vmap cannot batch falls back to
+    that loop as well.  Returns (list of log-probs, list of outputs)."""
     S = len(samples)
     if S == 0:
         return [], []
@@ -297,25 +306,57 @@ def _eval_all(f, samples, dev):
     if all(t.dim() == 1 and t.shape == flat[0].shape for t in flat):
         try:
             with torch.no_grad():
+                on_gpu = flat[0].is_cuda
+                if on_gpu:
+                    torch.cuda.synchronize(dev)
+                    torch.cuda.reset_peak_memory_stats(dev)
+                    base = torch.cuda.memory_allocated(dev)
                 v0, o0 = f(flat[0])
-                per = max(1, int(o0.numel()) * 64)                       # rough activation footprint of one sample
-                chunk = max(1, min(S, (64 << 20) // per))
+                if on_gpu:
+                    torch.cuda.synchronize(dev)
+                    per = max(1, torch.cuda.max_memory_allocated(dev) - base)
+                else:
+                    per = max(1, int(o0.numel()) * 64)
+                per = max(per, int(o0.numel()) * o0.element_size() * 4)
+                chunk = max(1, min(S, (256 << 20) // per))
                 vs, os_ = [], []
-                for c0 in range(0, S, chunk):
-                    v, o = torch.func.vmap(f)(torch.stack(flat[c0:c0 + chunk]))
+                c0 = 0
+                while c0 < S:
+                    try:
+                        v, o = torch.func.vmap(f)(torch.stack(flat[c0:c0 + chunk]))
+                    except torch.OutOfMemoryError:
+                        v = o = None
+                        if on_gpu:
+                            torch.cuda.empty_cache()
+                        if chunk == 1:
+                            raise _LoopInstead()
+                        chunk = max(1, chunk // 2)
+                        predict_stats["oom_halvings"] = predict_stats.get("oom_halvings", 0) + 1
+                        continue
                     vs.append(v); os_.append(o)
+                    c0 += chunk
                 v = torch.cat(vs); o = torch.cat(os_)
             predict_stats["batched"] += 1
             return [v[k].reshape(v0.shape) for k in range(S)], [o[k] for k in range(S)]
+        except _LoopInstead:
+            pass
         except (RuntimeError, TypeError, ValueError, NotImplementedError) as e:
-            if isinstance(e, (torch.OutOfMemoryError, torch.AcceleratorError)):
+            if isinstance(e, torch.AcceleratorError):
                 raise
+            if isinstance(e, torch.OutOfMemoryError):
+                if flat[0].is_cuda:
+                    torch.cuda.empty_cache()
     predict_stats["looped"] += 1
     vs, os_ = [], []
-    for t in flat:
-        v, o = f(t)
-        vs.append(v); os_.append(o)
+    with torch.no_grad():
+        for t in flat:
+            v, o = f(t)
+            vs.append(v); os_.append(o)
     return vs, os_
+
+
+class _LoopInstead(Exception):
+    """internal: the batched evaluation ran out of memory even one sample at a time under vmap"""
 
 
 def predict_model(model, samples, x=None, y=None, test_loader=None, model_loss='multi_class_linear_output',

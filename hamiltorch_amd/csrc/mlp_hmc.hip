@@ -498,6 +498,7 @@ template <typename T> int mlp_hmc(const MlpArgs<T>& a, hipStream_t s) {
   HTA_REQUIRE(a.mass_kind == HTA_MASS_NONE || (a.mass_kind == HTA_MASS_DIAG && a.inv_mass && a.mass_factor),
               "hta_mlp_hmc: only identity / diagonal inv_mass are supported natively");
   if (a.n_traj > 0) HTA_REQUIRE(a.theta_init && a.L >= 0, "hta_mlp_hmc: bad trajectory arguments");
+  if (a.n_traj == 0) HTA_REQUIRE(a.eval_split >= 0 && a.eval_split < a.M, "hta_mlp_logp_grad: split %d not in [0, %d)", a.eval_split, a.M);
   HTA_REQUIRE(a.integ >= HTA_SPLIT_SYMMETRIC && a.integ <= HTA_SPLIT_KMID, "hta_mlp_hmc: unknown integrator %d", a.integ);
   HTA_REQUIRE(a.integ != HTA_SPLIT_RAND || a.M <= 64, "hta_mlp_hmc: SPLITTING_RAND supports at most 64 subsets natively (M=%d)", a.M);
   HTA_REQUIRE(a.integ != HTA_SPLIT_KMID || a.M >= 2, "hta_mlp_hmc: SPLITTING_KMID needs at least 2 subsets");

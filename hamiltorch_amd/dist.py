@@ -69,18 +69,19 @@ def sample_sharded(sample_fn, params_init_all: torch.Tensor, *args, gather=True,
     off, cnt = shard_chains(C, rank, world)
     local_init = params_init_all[off:off + cnt].contiguous()
     from . import samplers
-    prev = samplers._nuts_reduce
+    token = None
     if world > 1:
         def reduce_(a_sum, a_cnt, bad):          # Sampler.HMC_NUTS: one step size adapted on the chains of ALL ranks
             t = torch.tensor([a_sum, a_cnt, float(bad)], dtype=torch.float64,
                              device=local_init.device if dist.get_backend(group) != "gloo" else "cpu")
             dist.all_reduce(t, group=group)
             return float(t[0]), float(t[1]), bool(t[2] > 0)
-        samplers._nuts_reduce = reduce_
+        token = samplers._nuts_reduce.set(reduce_)          # context-local: other threads' sample() calls do not see it
     try:
         out = sample_fn(*args, params_init=local_init, chain_offset=off, **kwargs)
     finally:
-        samplers._nuts_reduce = prev
+        if token is not None:
+            samplers._nuts_reduce.reset(token)
     extra = None
     if isinstance(out, tuple):
         out, extra = out

@@ -184,8 +184,15 @@ def probe_gaussian(log_prob_func, theta0, max_dim=MAX_NATIVE_DIM):
 
 
 def verify_gaussian(tgt, log_prob_func, samples, max_rows=2048):
-    """True if the closed form ``tgt`` reproduces ``log_prob_func`` on rows drawn evenly from ``samples[S, C, D]``
-    (the states a run actually visited) -- the guard behind ``probe_gaussian``."""
+    """True if the closed form ``tgt`` reproduces ``log_prob_func`` -- VALUE AND GRADIENT -- on rows drawn evenly from
+    ``samples[S, C, D]`` (the states a run actually visited), on the midpoints of random pairs of them and on their
+    reflection to twice the distance from the sample mean (states the surrogate run may have avoided) -- the guard
+    behind ``probe_gaussian``.
+
+    Tolerances are those of fp32 / fp64 ROUNDING of a quadratic form, not a fraction of the log-density: a value may
+    differ by ``2e-5 (|quad| + |log_norm|) + 2e-4`` (fp64: ``1e-10 (...) + 1e-9``), a gradient component by ``1e-3``
+    (fp64 ``1e-8``) of the gradient scale of the rows.  (Round 2 accepted ``2e-2 (1 + |log p|)``: more than one nat at
+    D = 50, enough to hide a unit-height bump on a Gaussian.)"""
     rows = samples.reshape(-1, samples.shape[-1])
     if rows.shape[0] > max_rows:
         idx = torch.linspace(0, rows.shape[0] - 1, max_rows, device=rows.device).long()
@@ -193,19 +200,46 @@ def verify_gaussian(tgt, log_prob_func, samples, max_rows=2048):
     rows = rows[torch.isfinite(rows).all(dim=1)]
     if rows.numel() == 0:
         return True
+    n = rows.shape[0]
+    g = torch.Generator(device="cpu").manual_seed(0x5EED)
+    perm = torch.randperm(n, generator=g).to(rows.device)
+    k = min(n, 512)
+    centre = rows.mean(dim=0, keepdim=True)
+    extra = torch.cat([0.5 * (rows[:k] + rows[perm[:k]]), centre + 2.0 * (rows[perm[:k]] - centre)])
+    extra = extra[torch.isfinite(extra).all(dim=1)]
+    rows = torch.cat([rows, extra.to(rows.dtype)])
 
     def f(w):
         return log_prob_func(w).sum()
+    gr = None
     try:
-        with torch.no_grad():
-            v = torch.func.vmap(f)(rows)
-    except (RuntimeError, TypeError, ValueError, NotImplementedError) as e:
+        with torch.enable_grad():
+            gr, v = torch.func.vmap(torch.func.grad_and_value(f))(rows)
+    except (RuntimeError, TypeError, ValueError, NotImplementedError, AttributeError, IndexError) as e:
         if isinstance(e, (torch.OutOfMemoryError, torch.AcceleratorError)):
             raise
-        v = torch.stack([f(r) for r in rows[:64]])
-        rows = rows[:64]
+        rows = rows[torch.linspace(0, rows.shape[0] - 1, min(96, rows.shape[0]), device=rows.device).long()]
+        vs, gs = [], []
+        for r in rows:
+            w = r.detach().clone().requires_grad_(True)
+            with torch.enable_grad():
+                val = f(w)
+                gs.append(torch.autograd.grad(val, w)[0].detach())
+            vs.append(val.detach())
+        v, gr = torch.stack(vs), torch.stack(gs)
+    f32 = rows.dtype == torch.float32
     d = rows.double() - tgt.mean.double()
-    want = tgt.log_norm - 0.5 * ((d @ tgt.precision.double()) * d).sum(-1)
-    err = (v.double() - want).abs()
-    ok = err <= 100 * _tol(rows.dtype) * (1.0 + want.abs())
-    return bool(ok.all())
+    Pd = d @ tgt.precision.double()
+    quad = 0.5 * (Pd * d).sum(-1)
+    want = tgt.log_norm - quad
+    v = v.detach().double()
+    if not torch.isfinite(v).all():
+        return False
+    tol_v = (2e-5 if f32 else 1e-10) * (quad.abs() + abs(tgt.log_norm)) + (2e-4 if f32 else 1e-9)
+    if not bool(((v - want).abs() <= tol_v).all()):
+        return False
+    gr = gr.detach().double()
+    if not torch.isfinite(gr).all():
+        return False
+    gscale = float(Pd.abs().max()) + float(tgt.precision.double().abs().max())
+    return bool(((gr + Pd).abs().max() <= (1e-3 if f32 else 1e-8) * gscale))

@@ -484,9 +484,12 @@ def _probe_mismatch(log_prob_func):
                   "the sampled states; re-running on the generic-callback path" % (log_prob_func,))
 
 
-#: set by dist.sample_sharded: (sum, count) -> (global sum, global count) over the process group, so that a sharded
-#: HMC_NUTS run adapts ONE step size on all chains of all ranks, as the single-process run does
-_nuts_reduce = None
+#: set by dist.sample_sharded for the duration of ITS call, in ITS thread / context only (a ContextVar, not a module
+#: global: concurrent sample() calls of multi_chain(parallel=True) never see another call's reducer):
+#: (sum, count, bad) -> the same over the process group, so that a sharded HMC_NUTS run adapts ONE step size on all
+#: chains of all ranks, as the single-process run does
+import contextvars  # noqa: E402
+_nuts_reduce = contextvars.ContextVar("hamiltorch_amd_nuts_reduce", default=None)
 
 
 class _Engine:
@@ -531,8 +534,9 @@ class _Engine:
             alpha = torch.where(torch.isfinite(rho), torch.exp(rho.float()), torch.zeros_like(rho.float()))
             bad = bool((~torch.isfinite(rho)).any())
             a_sum, a_cnt = float(alpha.double().sum()), float(alpha.numel())
-            if _nuts_reduce is not None:                                      # sharded run: the statistic of ALL chains
-                a_sum, a_cnt, bad = _nuts_reduce(a_sum, a_cnt, bad)
+            reduce_ = _nuts_reduce.get()
+            if reduce_ is not None:                                           # sharded run: the statistic of ALL chains
+                a_sum, a_cnt, bad = reduce_(a_sum, a_cnt, bad)
             if n < burn or bad:                                               # S:1031-1032 / S:1060-1064
                 eps, eps_bar, H_t = _dual_average(a_sum / a_cnt, n, eps0, H_t, eps_bar, desired)
             if n == burn:

@@ -126,14 +126,17 @@ def _accepts_seed(fn):
         ps = inspect.signature(fn).parameters
     except (TypeError, ValueError):
         return False
-    return "seed" in ps or any(p.kind == p.VAR_KEYWORD for p in ps.values())
+    return "seed" in ps          # an explicit parameter only: a **kwargs wrapper may forward to a function without one
 
 
 def setup_chain(sampler, prior, kwargs):
     """U:385-390.  The reference's chain seeds the GLOBAL generator and then samples from it, which is racy under
     multi_chain(parallel=True) (threads interleave seeding and drawing).  Here seeding, the draw of params_init and the
-    derivation of the chain's Philox key happen under one lock and the key is handed to the sampler explicitly, so a chain's
-    result depends on its seed alone - serial, threaded or batched."""
+    derivation of the chain's Philox key happen under one lock and the key is handed to the sampler explicitly (when `seed`
+    is an explicit parameter of the sampler, as it is for this package's `sample*` functions), so a chain's result depends
+    on its seed alone for serial and threaded runs.  `multi_chain(batched=True)` is a different stream layout: every
+    chain's `params_init` comes from its own seed, but the device streams are keyed (seeds[0], chain index), so a batched
+    run is reproducible from `seeds` as a whole and does not equal the serial per-seed results."""
     takes_seed = _accepts_seed(sampler)
 
     def chain(seed):

@@ -42,13 +42,19 @@ def _worker(rank, world, port, C, q):
 
         def probe_sampler(params_init, chain_offset, seed, **kw):
             from hamiltorch_amd import samplers
-            seen["hook"] = samplers._nuts_reduce
-            seen["red"] = samplers._nuts_reduce(float(params_init.shape[0]) * 0.5, float(params_init.shape[0]), rank == 1)
+            seen["hook"] = samplers._nuts_reduce.get()
+            seen["red"] = samplers._nuts_reduce.get()(float(params_init.shape[0]) * 0.5, float(params_init.shape[0]), rank == 1)
+            import threading
+            other = []
+            t = threading.Thread(target=lambda: other.append(samplers._nuts_reduce.get()))     # multi_chain(parallel=True)'s threads
+            t.start(); t.join()
+            seen["other_thread"] = other[0]
             return [params_init]
         hd.sample_sharded(probe_sampler, init, seed=1, gather=False)
         from hamiltorch_amd import samplers
-        assert seen["hook"] is not None and samplers._nuts_reduce is None        # installed for the call only
+        assert seen["hook"] is not None and samplers._nuts_reduce.get() is None        # installed for the call only
         assert seen["red"] == (0.5 * C, float(C), True), seen["red"]
+        assert seen["other_thread"] is None                                              # context-local, not a module global
         q.put((rank, full.numpy(), None if only0 is None else only0.numpy()))
     finally:
         dist.destroy_process_group()

@@ -404,6 +404,9 @@ def test_model_structure_recognition_of_notebook_style_modules():
     net = Lin(); sizes = [w.nelement() for w in net.parameters()]; shapes = [w.shape for w in net.parameters()]
     f = bnn.define_model_log_prob(net, "multi_class_linear_output", X, yc, sizes, shapes, [1.0, 1.0], 1.0)
     assert f._hta_spec["dims"] == [4, 3] and f._hta_spec["loss"] == "multi_class_linear_output" and f._hta_spec["Y"].shape == (12,)
+    for bad in (yc + 0.5, yc - 1.0, yc + 3.0):      # non-integer / negative / >= n_out labels never reach the kernel
+        f = bnn.define_model_log_prob(net, "multi_class_linear_output", X, bad, sizes, shapes, [1.0, 1.0], 1.0)
+        assert not hasattr(f, "_hta_spec")
     f = bnn.define_model_log_prob(net, "regression", X, torch.randn(12, 3), sizes, shapes, [1.0, 1.0], 1.0)
     assert not hasattr(f, "_hta_spec")              # multi-output regression returns one value per output (S:1184): callback path
     from hamiltorch_amd import mlp
@@ -412,3 +415,67 @@ def test_model_structure_recognition_of_notebook_style_modules():
     assert mlp._kernel_for(dict(dims=[4, 3], loss="multi_class_linear_output")) == "netn"
     assert mlp._kernel_for(dict(dims=[8, 100, 3], loss="multi_class_linear_output")) is None       # wider than the small-net kernel
     assert mlp._kernel_for(dict(dims=[2, 3, 3, 3, 3, 1], loss="regression")) is None               # five Linear layers
+
+
+def test_verify_gaussian_catches_a_unit_bump_on_a_wide_gaussian():
+    """a D=50 fp32 MVN log-prob plus exp(-0.5 ((w_k - 1.5) / 0.15)^2).  Wherever the probe accepts it, the
+    verification on Gaussian samples (which visit the bump) must reject: the tolerance is rounding-sized, not 1 nat."""
+    from hamiltorch_amd.models import GaussianTarget, probe_gaussian, verify_gaussian
+    D = 50
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(D, D, generator=g)
+    cov = A @ A.T / D + 0.5 * torch.eye(D)
+    mvn = torch.distributions.MultivariateNormal(torch.zeros(D), cov)
+    exact = GaussianTarget(torch.zeros(D), covariance=cov)
+    xs = mvn.sample((40, 16))
+    xs[0, 0, :] = 0.0
+    assert verify_gaussian(exact, lambda w: mvn.log_prob(w).sum(), xs)                 # the true closure still verifies
+    accepted = 0
+    for k in range(12):
+        def bumpy(w, k=k):
+            return mvn.log_prob(w).sum() + 1.0 * torch.exp(-0.5 * ((w[k] - 1.5) / 0.15) ** 2)
+        t = probe_gaussian(bumpy, torch.zeros(4, D))
+        if t is None:
+            continue
+        accepted += 1
+        x = xs.clone()
+        x[1, :, k] = 1.5 + 0.1 * torch.randn(16, generator=g)                        # rows inside the bump, as HMC would visit
+        assert not verify_gaussian(t, bumpy, x), k
+    # a smooth 1e-2-nat ripple is also beyond rounding
+    t = probe_gaussian(lambda w: mvn.log_prob(w).sum(), torch.zeros(4, D))
+    assert t is not None
+    assert not verify_gaussian(t, lambda w: mvn.log_prob(w).sum() + 1e-2 * torch.sin(3.0 * w[0]), xs)
+
+
+def test_predict_eval_all_survives_out_of_memory(monkeypatch):
+    """an out-of-memory error in the batched evaluation halves the chunk (down to the reference's
+    per-sample loop) instead of propagating."""
+    from hamiltorch_amd import bnn
+    samples = [torch.full((3,), float(k)) for k in range(20)]
+
+    def f(w):
+        return w.sum(), torch.stack([w[0], 2 * w[1]])
+    real_vmap = torch.func.vmap
+    seen = []
+
+    def picky_vmap(fn, limit):
+        def run(batch):
+            seen.append(batch.shape[0])
+            if batch.shape[0] > limit:
+                raise torch.OutOfMemoryError("simulated")
+            return real_vmap(fn)(batch)
+        return run
+    monkeypatch.setattr(bnn.torch.func, "vmap", lambda fn: picky_vmap(fn, 3))
+    bnn.predict_stats.pop("oom_halvings", None)
+    before = dict(bnn.predict_stats)
+    vs, os_ = bnn._eval_all(f, samples, torch.device("cpu"))
+    assert [float(v) for v in vs] == [3.0 * k for k in range(20)]
+    assert torch.equal(torch.stack(os_)[:, 1], 2.0 * torch.arange(20.0))
+    assert seen[0] == 20 and max(seen[-5:]) <= 3 and bnn.predict_stats["oom_halvings"] >= 2
+    assert bnn.predict_stats["batched"] == before["batched"] + 1
+    # even one sample under vmap does not fit: the reference's loop
+    seen.clear()
+    monkeypatch.setattr(bnn.torch.func, "vmap", lambda fn: picky_vmap(fn, 0))
+    vs, os_ = bnn._eval_all(f, samples, torch.device("cpu"))
+    assert [float(v) for v in vs] == [3.0 * k for k in range(20)]
+    assert bnn.predict_stats["looped"] == before["looped"] + 1
