@@ -476,6 +476,7 @@ def measure(w, steps, warmup, world, dist, dev, profile_every=1):
     barrier()
     dt = time.perf_counter() - t0
     w._steps_done = steps
+    w.route = abi.last_route()                                            # the kernel the library dispatched to (hta_last_route)
     call_ms = ev[0].elapsed_time(ev[1]) / max(1, steps)                   # device time per C-ABI call (all its kernels)
     prof_ms, prof_n = abi.profile_collect()
     abi.set_tuning("profile", 0)
@@ -495,6 +496,8 @@ def result_of(w, W, dt, call_ms, prof_ms, prof_n, steps, warmup, world):
     else:
         kernel_ms = prof_ms / max(1, steps)                               # every profiled launch of one step
     roof = w.roofline(kernel_ms, call_ms, prof_n, steps)
+    if getattr(w, "route", ""):
+        roof["kernel_expected"], roof["kernel"] = roof.get("kernel"), w.route          # what ran, as the library reports it
     pkey = "%s%s@%d" % (W.key.split("@")[0], "jacobi" if getattr(w, "jacobi", False) else "", w.C)
     phys = _physical(pkey)
     roof["physical"] = phys
@@ -508,22 +511,30 @@ def result_of(w, W, dt, call_ms, prof_ms, prof_n, steps, warmup, world):
             "config": {"workload": W.name, "chains_per_gpu": w.C, "chains_total": w.C * world,
                        "trajectories_per_step": w.T, "leapfrog_steps_per_trajectory": W.L, "D": W.D,
                        "samples_stored": True, "parallelism": "chains sharded, %d per GPU, no collective" % w.C},
-            "roofline": roof, "acceptance_rate": acc, "ess_per_sec": ess / (call_ms * 1e-3)}
+            "roofline": roof, "route": getattr(w, "route", ""), "acceptance_rate": acc, "ess_per_sec": ess / (call_ms * 1e-3)}
 
 
-def api_timing(w, reps=5):
-    """Wall time of the same work through hamiltorch_amd.sample() (synchronised): median of `reps` calls after one warm-up."""
-    w.api_call(0)
+def api_timing(w, steps, warmup, reps=5):
+    """The same work through hamiltorch_amd.sample(): (pipelined ms per call, synchronised ms per call).
+    Pipelined = the headline's own bracket (W untimed calls, K timed calls, one synchronize on either side): what a
+    program that keeps calling sample() sees.  Synchronised = median wall time of `reps` single calls each followed by
+    a synchronize: the latency of one call (launch path + kernels + wake-up)."""
+    for k in range(max(1, warmup)):
+        w.api_call(k)
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        out = w.api_call(warmup + k)
+    torch.cuda.synchronize()
+    pipelined = (time.perf_counter() - t0) * 1e3 / max(1, steps)
     ts = []
     for k in range(reps):
         t0 = time.perf_counter()
         out = w.api_call(1 + k)
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
-        del out
-    return statistics.median(ts)
-
+    del out
+    return pipelined, statistics.median(ts)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -597,10 +608,10 @@ def compact_line(full, detail_path="bench_detail.json"):
     if full.get("cpu_baseline"):
         out["cpu_baseline"] = _compact_cpu(full["cpu_baseline"])
         out["speedup_vs_cpu_baseline"] = _r(full.get("speedup_vs_cpu_baseline"), 4)
-    for k in ("api_ms_per_step", "api_value", "acceptance_rate", "ess_per_sec", "ess_per_sec_vs_cpu_baseline", "gather_ms"):
+    for k in ("api_ms_per_step", "api_value", "api_sync_ms", "acceptance_rate", "ess_per_sec", "ess_per_sec_vs_cpu_baseline", "gather_ms"):
         if full.get(k) is not None:
             out[k] = _r(full[k])
-    for k in ("ranks_seen", "rank_devices", "launcher", "collective_backend", "route"):
+    for k in ("ranks_seen", "rank_devices", "launcher", "collective_backend"):
         if k in full:
             out[k] = full[k]
     sec = []
@@ -613,8 +624,6 @@ def compact_line(full, detail_path="bench_detail.json"):
              "ms_per_step": _r(r.get("ms_per_step")), "steps": r.get("steps"), "frac": roof["frac"], "bound": roof["bound"],
              "achieved": roof["achieved"], "unit": roof["unit"], "mfma_busy": roof["mfma_busy"], "traffic": roof["traffic"],
              "kernel": roof["kernel"][:40], "kernel_ms": roof["kernel_ms"], "cpu": {"value": _r(cb.get("value"), 4), "cores": cb.get("cores")}}
-        if r.get("route"):
-            e["route"] = r["route"]
         if r.get("published"):
             e["published"] = r["published"]
         sec.append(e)
@@ -737,7 +746,7 @@ def main():
         out = {"key": res["key"], "metric": METRIC, "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": W.dtype_name, "data": "synthetic", "config": res["config"], "roofline": res["roofline"],
-               "acceptance_rate": res["acceptance_rate"], "ess_per_sec": res["ess_per_sec"],
+               "route": res["route"], "acceptance_rate": res["acceptance_rate"], "ess_per_sec": res["ess_per_sec"],
                "ranks_seen": ranks_seen, "rank_devices": devices,
                "launcher": "torch.distributed.run" if world > 1 else "single process",
                "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None}
@@ -746,11 +755,12 @@ def main():
             out["config"]["parallelism"] += "; one gather of samples[%d, %d, %d] per rank to rank 0 after the timed region" % (
                 w.T + 1, w.C, W.D)
         if hasattr(w, "api_call") and world == 1 and not a.no_api:
-            api_ms = api_timing(w)
+            api_ms, api_sync_ms = api_timing(w, a.steps, a.warmup)
             out["api_ms_per_step"] = api_ms
             out["api_value"] = w.units_per_step() / (api_ms * 1e-3)
-            out["api_note"] = "the same step through hamiltorch_amd.sample() (route selection, sample-tensor allocation, list of " \
-                              "views), host wall time incl. synchronize, median of 5"
+            out["api_sync_ms"] = api_sync_ms
+            out["api_note"] = "api_ms_per_step: the same K steps through hamiltorch_amd.sample() in the headline's bracket (route " \
+                              "selection, sample-tensor allocation, the returned list); api_sync_ms: one call + synchronize, median of 5"
         if world == 1 and not a.no_cpu_baseline:
             cb = w.cpu_baseline(a.cpu_seconds)
             if cb is not None:

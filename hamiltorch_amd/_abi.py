@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhamiltorch_amd.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 MASS_NONE, MASS_DIAG, MASS_FULL = 0, 1, 2
 
@@ -80,7 +80,8 @@ def _sig(scalar):
 
 
 #: every symbol include/hamiltorch_amd.h declares (checked by tests/test_abi_symbols.py)
-PLAIN_SYMBOLS = ["hta_abi_version", "hta_last_error", "hta_device_info", "hta_set_tuning", "hta_profile_collect", "hta_counter_add",
+PLAIN_SYMBOLS = ["hta_abi_version", "hta_last_error", "hta_device_info", "hta_set_tuning", "hta_get_tuning", "hta_reset_tuning",
+                 "hta_last_route", "hta_profile_collect", "hta_counter_add",
                  "hta_hmc_gaussian_workspace_bytes", "hta_rmhmc_workspace_bytes"]
 TYPED_SYMBOLS = sorted(_sig(c_f32).keys())
 
@@ -103,6 +104,10 @@ def load():
         lib.hta_last_error.restype = ctypes.c_char_p
         lib.hta_device_info.argtypes = [c_int, ctypes.POINTER(HtaDeviceInfo)]
         lib.hta_set_tuning.argtypes = [ctypes.c_char_p, c_int]
+        lib.hta_get_tuning.argtypes = [ctypes.c_char_p, ctypes.POINTER(c_int)]
+        lib.hta_reset_tuning.argtypes = []
+        lib.hta_last_route.argtypes = []
+        lib.hta_last_route.restype = ctypes.c_char_p
         lib.hta_profile_collect.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]
         lib.hta_hmc_gaussian_workspace_bytes.argtypes = [c_i64, c_int, c_int, c_int]
         lib.hta_hmc_gaussian_workspace_bytes.restype = c_i64
@@ -176,6 +181,22 @@ def device_info(device=0) -> dict:
 
 def set_tuning(key: str, value: int):
     _check(load().hta_set_tuning(key.encode(), int(value)), "hta_set_tuning")
+
+
+def get_tuning(key: str) -> int:
+    v = c_int(0)
+    _check(load().hta_get_tuning(key.encode(), ctypes.byref(v)), "hta_get_tuning")
+    return v.value
+
+
+def reset_tuning():
+    """Every route key back to its default (the keys are process-global: test fixtures call this between tests)."""
+    _check(load().hta_reset_tuning(), "hta_reset_tuning")
+
+
+def last_route() -> str:
+    """The dominant kernel this thread's last sampling / evaluation call dispatched to, with its template arguments."""
+    return load().hta_last_route().decode()
 
 
 # ---- thin typed wrappers ------------------------------------------------------------------------

@@ -302,8 +302,16 @@ def _eval_all(f, samples, dev):
     S = len(samples)
     if S == 0:
         return [], []
-    flat = [t.to(dev) for t in samples]
-    if all(t.dim() == 1 and t.shape == flat[0].shape for t in flat):
+    from .samplelist import SampleList
+    if isinstance(samples, SampleList) and not samples._done:      # sample()'s lazy list: the rows already are one tensor
+        stacked = samples.tensor.to(dev)
+        flat = stacked
+        uniform = stacked.dim() == 2
+    else:
+        flat = [t.to(dev) for t in samples]
+        uniform = all(t.dim() == 1 and t.shape == flat[0].shape for t in flat)
+        stacked = torch.stack(flat) if uniform else None
+    if uniform:
         try:
             with torch.no_grad():
                 on_gpu = flat[0].is_cuda
@@ -323,7 +331,7 @@ def _eval_all(f, samples, dev):
                 c0 = 0
                 while c0 < S:
                     try:
-                        v, o = torch.func.vmap(f)(torch.stack(flat[c0:c0 + chunk]))
+                        v, o = torch.func.vmap(f)(stacked[c0:c0 + chunk])
                     except torch.OutOfMemoryError:
                         v = o = None
                         if on_gpu:

@@ -10,6 +10,14 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+// ---- which kernel a C-ABI call dispatched to (hta_last_route): the dominant kernel of the calling thread's last call ----
+static thread_local char g_route[160] = "";
+void note_route(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_route, sizeof(g_route), fmt, ap);
+  va_end(ap);
+}
 int g_small_chains_per_block = 0;  // 0 = default (64)
 int g_force_general = 0;
 int g_rmhmc_batch = 1;     // fused RMHMC: 16 chains per workgroup on the matrix cores from 2048 chains on (0 off, 2 always)
@@ -27,6 +35,8 @@ int g_quad_max_chains = 65536;   // up to here a chain takes a DPP quad (one eig
 int g_rmhmc_fused = 1;           // 0 = per-evaluation Jacobi path, 3 = fused with two chains per workgroup (parity tests)
 extern int g_metric_mfma, g_rmhmc_wide;         // rmhmc_metric_mfma.hip
 int g_mlp_valu = 0;               // 1 = keep the Bayesian-MLP sampler on the VALU kernel (parity tests of both)
+int g_metric_persist = 1;         // eigendecomposition route: one persistent launch per trajectory (0 = one launch per metric evaluation)
+int g_mlp3_route = 1;             // csrc/mlp3_mfma.hip (two wide hidden layers on the matrix cores); 0 = such models stay on the callback path
 
 // ---- optional HIP-event timing of the dominant kernel of each call (measurement only) -----------
 // hta_set_tuning("profile", N) arms it; every N-th bracketed launch then records a start/stop event pair
@@ -78,31 +88,47 @@ int hta_device_info(int device, HtaDeviceInfo* out) {
   return HTA_OK;
 }
 
+namespace {
+struct TuneKey { const char* key; int* var; int dflt; };
+// every route key with its default: hta_reset_tuning() restores the column on the right
+const TuneKey kTune[] = {
+    {"small_chains_per_block", &hta::g_small_chains_per_block, 0}, {"force_general", &hta::g_force_general, 0},
+    {"gauss_eig", &hta::g_gauss_eig, 1}, {"rmhmc_momwave", &hta::g_rmhmc_momwave, 1}, {"rmhmc_mfma4", &hta::g_rmhmc_mfma4, 1},
+    {"rmhmc_mfma4_lo", &hta::g_rmhmc_mfma4_lo, 513}, {"rmhmc_mfma4_hi", &hta::g_rmhmc_mfma4_hi, 2049},
+    {"rmhmc_mfma4_waves", &hta::g_rmhmc_mfma4_waves, 4}, {"netn_waves", &hta::g_netn_waves, 1}, {"rmhmc_uv", &hta::g_rmhmc_uv, 1},
+    {"rmhmc_pair", &hta::g_rmhmc_pair, 1}, {"rmhmc_wide", &hta::g_rmhmc_wide, 1}, {"rmhmc_overlap", &hta::g_rmhmc_overlap, 1},
+    {"rmhmc_batch", &hta::g_rmhmc_batch, 1}, {"quad_max_chains", &hta::g_quad_max_chains, 65536}, {"fill_blocks", &hta::g_fill_blocks, 4096},
+    {"mlp_valu", &hta::g_mlp_valu, 0}, {"metric_mfma", &hta::g_metric_mfma, 1}, {"rmhmc_fused", &hta::g_rmhmc_fused, 1},
+    {"metric_persist", &hta::g_metric_persist, 1}, {"mlp3_route", &hta::g_mlp3_route, 1},
+};
+}  // namespace
+
 int hta_set_tuning(const char* key, int value) {
   if (!key) return HTA_ERR_INVALID;
-  if (!strcmp(key, "small_chains_per_block")) { hta::g_small_chains_per_block = value; return HTA_OK; }
-  if (!strcmp(key, "force_general")) { hta::g_force_general = value; return HTA_OK; }
-  if (!strcmp(key, "gauss_eig")) { hta::g_gauss_eig = value; return HTA_OK; }
-  if (!strcmp(key, "rmhmc_momwave")) { hta::g_rmhmc_momwave = value; return HTA_OK; }
-  if (!strcmp(key, "rmhmc_mfma4")) { hta::g_rmhmc_mfma4 = value; return HTA_OK; }
-  if (!strcmp(key, "rmhmc_mfma4_lo")) { hta::g_rmhmc_mfma4_lo = value; return HTA_OK; }
-  if (!strcmp(key, "rmhmc_mfma4_hi")) { hta::g_rmhmc_mfma4_hi = value; return HTA_OK; }
-  if (!strcmp(key, "rmhmc_mfma4_waves")) { hta::g_rmhmc_mfma4_waves = value; return HTA_OK; }
-  if (!strcmp(key, "netn_waves")) { hta::g_netn_waves = value; return HTA_OK; }
-  if (!strcmp(key, "rmhmc_uv")) { hta::g_rmhmc_uv = value; return HTA_OK; }
-  if (!strcmp(key, "rmhmc_pair")) { hta::g_rmhmc_pair = value; return HTA_OK; }
-  if (!strcmp(key, "rmhmc_wide")) { hta::g_rmhmc_wide = value; return HTA_OK; }
-  if (!strcmp(key, "rmhmc_overlap")) { hta::g_rmhmc_overlap = value; return HTA_OK; }
-  if (!strcmp(key, "rmhmc_batch")) { hta::g_rmhmc_batch = value; return HTA_OK; }
-  if (!strcmp(key, "quad_max_chains")) { hta::g_quad_max_chains = value; return HTA_OK; }
-  if (!strcmp(key, "fill_blocks")) { hta::g_fill_blocks = value > 0 ? value : 4096; return HTA_OK; }
-  if (!strcmp(key, "mlp_valu")) { hta::g_mlp_valu = value; return HTA_OK; }
-  if (!strcmp(key, "metric_mfma")) { hta::g_metric_mfma = value; return HTA_OK; }
-  if (!strcmp(key, "rmhmc_fused")) { hta::g_rmhmc_fused = value; return HTA_OK; }
   if (!strcmp(key, "profile")) { hta::g_profile = value; hta::g_ev_used = 0; hta::g_prof_seen = 0; return HTA_OK; }
+  for (const TuneKey& t : kTune)
+    if (!strcmp(key, t.key)) {
+      *t.var = (t.var == &hta::g_fill_blocks && value <= 0) ? 4096 : value;
+      return HTA_OK;
+    }
   hta::set_error("hta_set_tuning: unknown key %s", key);
   return HTA_ERR_INVALID;
 }
+
+int hta_get_tuning(const char* key, int* value) {
+  if (!key || !value) return HTA_ERR_INVALID;
+  for (const TuneKey& t : kTune)
+    if (!strcmp(key, t.key)) { *value = *t.var; return HTA_OK; }
+  hta::set_error("hta_get_tuning: unknown key %s", key);
+  return HTA_ERR_INVALID;
+}
+
+int hta_reset_tuning(void) {
+  for (const TuneKey& t : kTune) *t.var = t.dflt;
+  return HTA_OK;
+}
+
+const char* hta_last_route(void) { return hta::g_route; }
 
 int hta_profile_collect(double* total_ms, int* launches) {
   double tot = 0;

@@ -9,6 +9,8 @@
 namespace hta {
 
 void set_error(const char* fmt, ...);
+// names the kernel a C-ABI call dispatched to (read back by hta_last_route(); tests assert the route they claim to test)
+void note_route(const char* fmt, ...);
 
 #define HTA_REQUIRE(cond, ...)                  \
   do {                                          \

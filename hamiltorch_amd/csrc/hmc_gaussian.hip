@@ -1312,6 +1312,7 @@ template <typename T, int D, int MASS> void launch_small(const GaussArgs<T>& a, 
         const int qgrid = (int)((a.C * 4 + 63) / 64);
         profile_begin(s);
         const int lb = g_gauss_eig == 3 ? 0 : a.L;       // gauss_eig = 3: the any-L instance (tests compare the two)
+        note_route("hmc_gauss_quad_kernel<%d,%s,%d>", D, diag ? "true" : "false", diag ? 0 : (lb == 25 || lb == 10 || lb == 5) ? lb : 0);
         if (diag) hmc_gauss_quad_kernel<D, true, 0><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
         else if (lb == 25) hmc_gauss_quad_kernel<D, false, 25><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
         else if (lb == 10) hmc_gauss_quad_kernel<D, false, 10><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
@@ -1322,12 +1323,14 @@ template <typename T, int D, int MASS> void launch_small(const GaussArgs<T>& a, 
       }
     }
     profile_begin(s);
+    note_route("hmc_gauss_eig_kernel<%s,%d,%s>", sizeof(T) == 4 ? "float" : "double", D, diag ? "true" : "false");
     if (diag) hmc_gauss_eig_kernel<T, D, true><<<grid, block, 0, s>>>(a, a.ws_logu);
     else hmc_gauss_eig_kernel<T, D, false><<<grid, block, 0, s>>>(a, a.ws_logu);
     profile_end(s);
     return;
   }
   profile_begin(s);
+  note_route("hmc_gauss_small_kernel<%s,%d,%d,%s,%s>", sizeof(T) == 4 ? "float" : "double", D, MASS, a.ws_z ? "true" : "false", diag ? "true" : "false");
   if (a.ws_z) {
     if (diag) hmc_gauss_small_kernel<T, D, MASS, true, true><<<grid, block, 0, s>>>(a);
     else hmc_gauss_small_kernel<T, D, MASS, true, false><<<grid, block, 0, s>>>(a);
@@ -1347,6 +1350,7 @@ template <typename T, int R, int MASS> void launch_wave(const GaussArgs<T>& a, b
   const size_t lds = (size_t)GEN_WAVES * 64 * R * sizeof(T);
   if (lf_only) { leapfrog_gauss_wave_kernel<T, R, MASS><<<grid, 64 * GEN_WAVES, lds, s>>>(a); return; }
   profile_begin(s);
+  note_route("hmc_gauss_wave_kernel<%s,%d,%d>", sizeof(T) == 4 ? "float" : "double", R, MASS);
   hmc_gauss_wave_kernel<T, R, MASS><<<grid, 64 * GEN_WAVES, lds, s>>>(a);
   profile_end(s);
 }
@@ -1367,6 +1371,7 @@ template <typename T, int R> int launch_wave_eig(const GaussArgs<T>& a, hipStrea
   const int grid = (int)((a.C + GEN_WAVES - 1) / GEN_WAVES);
   const size_t lds = (size_t)GEN_WAVES * 64 * R * sizeof(T);
   profile_begin(s);
+  note_route("hmc_gauss_wave_eig_kernel<%s,%d>", sizeof(T) == 4 ? "float" : "double", R);
   hmc_gauss_wave_eig_kernel<T, R><<<grid, 64 * GEN_WAVES, lds, s>>>(a, V);
   profile_end(s);
   return HTA_OK;

@@ -466,6 +466,7 @@ template <typename T, int INMAX, int NT, int ACT, bool EXACT> int launch_mlp_act
   }
   const int grid = (int)(a.C < 4096 ? a.C : 4096);
   profile_begin(s);
+  note_route("mlp1_hmc_kernel<%s,%d,%d,%d,%s>", sizeof(T) == 4 ? "float" : "double", INMAX, NT, ACT, EXACT ? "true" : "false");
   mlp1_hmc_kernel<T, INMAX, NT, ACT, EXACT><<<grid, NT, lds, s>>>(a, nbch, ldc, (int)cmsz, Hp, PS, UG);
   profile_end(s);
   HTA_CHECK_LAUNCH("hta_mlp_hmc");

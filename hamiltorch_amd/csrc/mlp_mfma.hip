@@ -432,6 +432,7 @@ template <int NK, int NPT, int ACT, int NTMAX> static int launch_mfma(const MlpA
   }
   const int grid = (int)(a.C < 8192 ? a.C : 8192);
   profile_begin(s);
+  note_route("mlp_mfma_kernel<%d,%d,%d,%d>", NK, NPT, ACT, NTMAX);
   mlp_mfma_kernel<NK, NPT, ACT, NTMAX><<<grid, 64 * NU, lds, s>>>(a, NU, Npad);
   profile_end(s);
   HTA_CHECK_LAUNCH("hta_mlp_hmc (mfma)");

@@ -725,6 +725,7 @@ template <typename T> int netn_hmc(const NetArgs<T>& a, hipStream_t s) {
       done = true;
     }
     profile_begin(s);
+    note_route("netn_hmc_kernel<%s,%d,%d>", sizeof(T) == 4 ? "float" : "double", PB, WV);
     kern<<<grid, threads, lds, s>>>(a, D, SW, WM);
     profile_end(s);
     return HTA_OK;

@@ -2336,7 +2336,9 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
           profile_begin(s);
           // four waves per group while the groups fit one per CU (<= 1024 chains on 256 CUs): beyond that two groups share a CU
           // and the two-wave kernel already fills its four SIMDs
-          if (g_rmhmc_mfma4_waves == 2 || (g_rmhmc_mfma4_waves != 5 && ngroup > 256)) {
+          const bool two_wave = g_rmhmc_mfma4_waves == 2 || (g_rmhmc_mfma4_waves != 5 && ngroup > 256);
+          note_route("%s<%s>", two_wave ? "rmhmc_mfma4_kernel" : "rmhmc_mfma4x4_kernel", g_rmhmc_pair ? "true" : "false");
+          if (two_wave) {
             const size_t qlds = (size_t)(QBUF * QNC * QLD + QWV * QNC * 4) * sizeof(float);
             if (g_rmhmc_pair) rmhmc_mfma4_kernel<true><<<(int)(ngroup < 8192 ? ngroup : 8192), QNT, qlds, s>>>(a);
             else rmhmc_mfma4_kernel<false><<<(int)(ngroup < 8192 ? ngroup : 8192), QNT, qlds, s>>>(a);
@@ -2366,6 +2368,7 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
           const size_t blds = (size_t)(BBUF * BNC * BLD + BWV * BNC * 4) * sizeof(float);      // 88 KB: one workgroup per CU
           const int bgrid = (int)(ngroup < 4096 ? ngroup : 4096);
           profile_begin(s);
+          note_route("rmhmc_batch_kernel<%d,%s>", D <= 100 ? 25 : 28, g_rmhmc_pair ? "true" : "false");
           if (g_rmhmc_pair) {
             if (D <= 100) rmhmc_batch_kernel<25, true><<<bgrid, BNT, blds, s>>>(a);
             else rmhmc_batch_kernel<28, true><<<bgrid, BNT, blds, s>>>(a);
@@ -2385,6 +2388,7 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
         }
         const int64_t npair = (C + 1) / 2;
         profile_begin(s);
+        note_route("rmhmc_fused_kernel<%s,%d,2>", sizeof(T) == 4 ? "float" : "double", KH);
         kern2<<<(int)(npair < 8192 ? npair : 8192), FNT, fused_lds_bytes<T>(D, nullptr, 2, false), s>>>(a, ld, 0);
         profile_end(s);
         return HTA_OK;
@@ -2406,12 +2410,14 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
             dwf = true;
           }
           profile_begin(s);
+          note_route("rmhmc_fused_kernel_wide<%d,%s>", KH, g_rmhmc_pair ? "true" : "false");
           wide<<<grid, FNT, fused_lds_bytes<T>(D, nullptr, 1, need_w), s>>>(a, ld, need_w ? 1 : 0);
           profile_end(s);
           return HTA_OK;
         }
       }
       profile_begin(s);
+      note_route("rmhmc_fused_kernel<%s,%d,1,%s>", sizeof(T) == 4 ? "float" : "double", KH, (sizeof(T) == 4 && g_rmhmc_pair) ? "true" : "false");
       kern<<<grid, FNT, fused_lds_bytes<T>(D, nullptr, 1, need_w), s>>>(a, ld, need_w ? 1 : 0);
       profile_end(s);
       return HTA_OK;

@@ -353,6 +353,7 @@ template <typename T> int metric_eval(const MetricArgsT<T>& a, hipStream_t s) {
       done = true;
     }
     profile_begin(s);
+    note_route("metric_eval_kernel<%s>", sizeof(T) == 4 ? "float" : "double");
     kern<<<grid, MT, lds, s>>>(k, ne, lda, ldv, v0_lds);
     profile_end(s);
     return HTA_OK;

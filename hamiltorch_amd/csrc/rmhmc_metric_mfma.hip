@@ -705,6 +705,7 @@ int metric_warm_mfma(const MetricArgsT<float>& a, hipStream_t s) {
   }
   const int grid = (int)(a.B < 65536 ? a.B : 65536);
   profile_begin(s);
+  note_route("metric_warm_mfma_kernel");
   metric_warm_mfma_kernel<<<grid, MT, lds, s>>>(k, DP, LD);
   profile_end(s);
   HTA_CHECK_LAUNCH("hta_metric_eval (mfma)");

@@ -375,6 +375,7 @@ __global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
 
 int rmhmc_uv_launch(const FusedArgs<float>& a, int cus, hipStream_t s) {
   const size_t bytes = (size_t)(UBUF * XNC * XLD + XWV * XNC * 4) * sizeof(float);
+  note_route("rmhmc_uv_kernel<%d>", a.C <= cus ? 1 : 2);
   if (a.C <= cus) rmhmc_uv_kernel<1><<<(int)a.C, XNT, bytes, s>>>(a);
   else {
     const int64_t ngroup = (a.C + 1) / 2;

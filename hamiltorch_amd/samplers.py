@@ -26,6 +26,7 @@ import torch.nn as nn
 from . import _abi, util
 from .enums import Integrator, Metric, Sampler
 from .models import GaussianTarget, as_gaussian, probe_gaussian, verify_gaussian, MAX_NATIVE_DIM
+from .samplelist import rows_of
 
 _sample_lock = threading.RLock()  # multi_chain(parallel=True) calls sample() from threads (U:396-398)
 
@@ -459,8 +460,11 @@ def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, 
 
     if not store_on_GPU:
         samples = samples.cpu()                                                 # S:1012 / S:1024
-    rows = [row[0] for row in samples.unbind(0)] if one else list(samples.unbind(0))
-    acc = 1.0 - rejected.to(torch.float64) / float(num_samples)                # S:1085 / S:1089 (burn-in included)
+    # the reference's list of rows; long device-resident runs come back as a lazily materialised list (samplelist.py: the
+    # 1001 view objects of a BASELINE-config-2 call cost more host time than its kernels take)
+    rows = rows_of(samples, one)
+    if verbose or debug == 2:
+        acc = 1.0 - rejected.to(torch.float64) / float(num_samples)            # S:1085 / S:1089 (burn-in included)
     if verbose:
         print('Acceptance Rate {:.2f}'.format(float(acc.mean())))
     if nuts and debug == 2:

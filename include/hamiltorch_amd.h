@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HTA_ABI_VERSION 4
+#define HTA_ABI_VERSION 5
 
 #define HTA_OK 0
 #define HTA_ERR_INVALID (-1)   /* bad argument                           */
@@ -342,8 +342,20 @@ int hta_netn_logp_grad_f64(const double* theta, int64_t C, int n_layers, const i
  * "rmhmc_pair" 1 default: two consecutive half steps share K + 2 product phases, 0 = one half step at a time), "rmhmc_wide" (1 default: the spill-free one-workgroup-per-CU
  * instances of the one-chain kernel when chains <= compute units; 0 = always the two-workgroups-per-CU instances), "rmhmc_momwave" (1 default: one wave per momentum draw, fp32 with jitter, D <= 104; 0 = one workgroup per draw), "mlp_valu" (1 = VALU MLP kernel instead of the MFMA one),
  * "metric_mfma" (1 default: fp32 metric evaluations that share an eigenbasis, and Metric.HESSIAN ones, run on the matrix cores -
- * csrc/rmhmc_metric_mfma.hip, D <= 112; 0 = always the Jacobi kernel of csrc/rmhmc_metric.hip). */
+ * csrc/rmhmc_metric_mfma.hip, D <= 112; 0 = always the Jacobi kernel of csrc/rmhmc_metric.hip),
+ * "metric_persist" (1 default: on the eigendecomposition route of hta_rmhmc_gaussian_sample the metric evaluations of a
+ * whole trajectory run in ONE persistent launch per trajectory - csrc/rmhmc_traj_mfma.hip; 0 = one launch per evaluation),
+ * "mlp3_route" (1 default: Bayesian MLPs with two wide hidden layers run on csrc/mlp3_mfma.hip; 0 = callback path). */
 int hta_set_tuning(const char* key, int value);
+/* current value of a route key; every key back to its default (test fixtures call this between tests: the keys are
+ * process-global). */
+int hta_get_tuning(const char* key, int* value);
+int hta_reset_tuning(void);
+/* Name (with template arguments) of the dominant kernel the calling thread's last sampling / evaluation call dispatched
+ * to, e.g. "hmc_gauss_quad_kernel<3,false,25>", "rmhmc_uv_kernel<1>", "rmhmc_mfma4x4_kernel<true>", "mlp_mfma_kernel<2,7,0,512>".
+ * The string lives in thread-local storage until the next call.  Parity tests and bench.py assert / report the route
+ * they exercise with it (the dispatch depends on the chain count and on the process-global tuning keys). */
+const char* hta_last_route(void);
 /* waits for the recorded event pairs; returns their summed elapsed time and count, then resets. */
 int hta_profile_collect(double* total_ms, int* launches);
 

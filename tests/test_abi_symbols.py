@@ -49,20 +49,29 @@ def test_product_does_not_import_oracle():
 
 
 def test_every_tuning_key_is_documented_and_accepted():
-    """every key hta_set_tuning accepts (csrc/abi.cpp) is described in the header, and setting it back to its default works
-    without a GPU (the keys only select routes / launch shapes)."""
+    """every key hta_set_tuning accepts (the table in csrc/abi.cpp) is described in the header; hta_get_tuning reads a key
+    back, hta_reset_tuning restores the table's defaults (no GPU needed: the keys only select routes / launch shapes)."""
+    import ctypes
     from hamiltorch_amd import _abi
     src = open(os.path.join(ROOT, "hamiltorch_amd", "csrc", "abi.cpp")).read()
-    keys = re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', src)
-    assert len(keys) >= 10 and len(set(keys)) == len(keys)
+    table = re.findall(r'\{"([a-z0-9_]+)", &hta::g_[a-z0-9_]+, (\d+)\}', src)
+    keys = [k for k, _ in table]
+    assert len(keys) >= 18 and len(set(keys)) == len(keys)
     header = open(os.path.join(ROOT, "include", "hamiltorch_amd.h")).read()
-    for k in keys:
+    for k in keys + ["profile"]:
         assert '"%s"' % k in header, "tuning key %s is not documented in include/hamiltorch_amd.h" % k
-    defaults = dict(re.findall(r"int g_([a-z0-9_]+) = (\d+)", src))
     lib = _abi.load()
-    for k in keys:
-        if k in defaults:
-            assert lib.hta_set_tuning(k.encode(), int(defaults[k])) == 0
+    assert lib.hta_reset_tuning() == 0
+    for k, d in table:
+        assert _abi.get_tuning(k) == int(d), k
+        _abi.set_tuning(k, int(d) + 1)
+        assert _abi.get_tuning(k) == int(d) + 1
+    _abi.reset_tuning()
+    for k, d in table:
+        assert _abi.get_tuning(k) == int(d), k
+    v = ctypes.c_int(0)
+    assert lib.hta_get_tuning(b"nope", ctypes.byref(v)) == -1
+    assert _abi.last_route() == ""                       # nothing dispatched yet in this thread (no GPU here)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -202,23 +202,30 @@ def test_cfg3_shape_smoke_and_errors(ht):
 
 def test_cfg3_statistical_parity_with_jitter(ht):
     """T2 at BASELINE config 3: D=100, 256 chains, softabs alpha=1e6, omega=10, eps=0.1, L=10,
-    jitter=1e-3 (stochastic Hamiltonian: only distributional parity exists).  Pooled marginal variances must match
-    diag(P^-1) and the acceptance rate the reference's 1.0."""
+    jitter=1e-3 (stochastic Hamiltonian: only distributional parity exists).  600 trajectories per chain from stationary
+    starts; the pooled marginal variances of the last 500 must match diag(P^-1) within SURVEY 8c's +-5 % (128 000 rows,
+    lag-1 autocorrelation ~0.5: the Monte-Carlo sd of a variance ratio is ~0.7 %) and the acceptance rate the
+    reference's 1.0."""
+    from hamiltorch_amd import _abi
     t, o = cfg3_target(ht, 100, torch.float32)
-    C, N = 256, 60
-    g = torch.Generator().manual_seed(0)
+    C, N, keep = 256, 600, 500
     cov = np.linalg.inv(o.P.astype(np.float64))
     th0 = torch.tensor(np.random.default_rng(0).multivariate_normal(np.zeros(100), cov, size=C), dtype=torch.float32, device=dev())
     out, acc = ht.sample(t, th0, num_samples=N, num_steps_per_sample=10, step_size=0.1, burn=-1, jitter=1e-3,
                          softabs_const=1e6, explicit_binding_const=10, sampler=ht.Sampler.RMHMC,
                          integrator=ht.Integrator.EXPLICIT, metric=ht.Metric.SOFTABS, debug=2, verbose=False, seed=7)
-    s = torch.stack(out[N // 2:]).double().cpu().numpy().reshape(-1, 100)
+    assert _abi.last_route() == "rmhmc_uv_kernel<1>"
+    a = torch.stack(out).double().cpu().numpy()
+    s = a[-keep:].reshape(-1, 100)
     assert float(acc.mean()) > 0.97
     var = s.var(axis=0)
-    np.testing.assert_allclose(var, np.diag(cov), rtol=0.12)
-    assert abs(s.mean()) < 0.02
-    # the chains actually move: lag-N/2 autocorrelation of the slowest coordinate is far from 1
-    a = torch.stack(out).double().cpu().numpy()
+    np.testing.assert_allclose(var, np.diag(cov), rtol=0.05)
+    sd_mean = np.sqrt(np.diag(cov) / (keep * C) * 4.0)                    # 4 ~ (1 + rho) / (1 - rho) at rho ~ 0.6
+    assert (np.abs(s.mean(axis=0)) <= 4.5 * sd_mean).all()                # SURVEY 8c: |mean| <= 4 sd / sqrt(ESS) per dimension
+    # off-diagonal structure too: the pooled covariance matches P^-1 in the operator norm
+    emp = np.cov(s.T)
+    assert np.linalg.norm(emp - cov, 2) <= 0.08 * np.linalg.norm(cov, 2)
+    # the chains actually move
     assert np.abs(a[-1] - a[0]).mean() > 0.3
 
 
@@ -747,21 +754,26 @@ def _warm_eval(ht, P, X, m, alpha, jitter, seed, mode, want_g=True):
         _abi.metric_eval(Pd, B, D, _abi.METRIC_SOFTABS, Pd, 0, alpha, jitter, seed, 3, 7, 2, X=tt(X, dt), Pm=Pd, mu=mu, log_norm=0.25,
                          m=tt(m, dt), upd_x=out["x"], cx=0.5, upd_g=out["ug"], cg=-0.5, lam_out=out["lam"], logdet_out=out["ld"],
                          quad_out=out["q"], H_out=out["H"], logp_out=out["lp"], V0=V0, lam0=lam0)
+        route = _abi.last_route()
         if want_g:
             _abi.metric_eval(Pd, B, D, _abi.METRIC_SOFTABS, Pd, 0, alpha, jitter, seed, 3, 7, 0, p_out=out["p"], G_out=out["G"],
                              V0=V0, lam0=lam0)
         torch.cuda.synchronize()
     finally:
         _abi.set_tuning("metric_mfma", 1)
+    assert route == ("metric_warm_mfma_kernel" if mode else "metric_eval_kernel<float>"), route      # the kernel under test ran
     return {k: v.cpu().numpy() for k, v in out.items()}
 
 
 @pytest.mark.parametrize("D,kind,alpha,jitter", [(1, "spd", 1e6, 1e-3), (2, "indef", 1.3, 1e-2), (3, "spd", 1e6, 1e-3), (10, "spd", 1e6, None), (16, "indef", 1.3, 1e-3), (31, "spd", 1e6, 1e-3),
                                                  (64, "indef", 2.0, 1e-2), (100, "spd", 1e6, 1e-3), (100, "spd", 1e6, 0.3),
-                                                 (101, "degenerate", 3.0, 1e-3), (112, "spd", 1e6, 1e-3), (9, "identity", 1e6, 1e-3)])
-def test_metric_mfma_kernel_equals_jacobi_kernel(ht, D, kind, alpha, jitter):
-    """csrc/rmhmc_metric_mfma.hip (eigenvectors refined from the shared basis with MFMA GEMMs; MFMA Cholesky) against the
-    Jacobi kernel on the same systems and jitter streams, and both against the oracle's eigh: G^-1 m, log|G|, m^T G^-1 m,
+                                                 (101, "degenerate", 3.0, 1e-3), (112, "spd", 1e6, 1e-3), (9, "identity", 1e6, 1e-3),
+                                                 (100, "indef", 0.05, 1e-3), (100, "indef", 1.0, 1e-3), (48, "degenerate", 1e6, 1e-3),
+                                                 (100, "spd", 0.05, 1e-3), (64, "degenerate", 1.0, 1e-2)])
+def test_metric_mfma_kernel_vs_oracle_and_jacobi_kernel(ht, D, kind, alpha, jitter):
+    """csrc/rmhmc_metric_mfma.hip (eigenvectors refined from the shared basis with MFMA GEMMs; MFMA Cholesky) DIRECTLY against
+    the oracle's float64 eigh (`for got in (a, j)`: the matrix-core kernel `a` and the Jacobi kernel `j` are each compared with
+    the oracle, then with each other; `_warm_eval` asserts through hta_last_route that `a` really ran metric_warm_mfma_kernel): G^-1 m, log|G|, m^T G^-1 m,
     H, log p, P (X - mu), the soft-abs spectrum, the assembled G and the momentum draw p = chol(G) z.  Cases: well separated
     spectra (refinement converges), an indefinite curvature with finite alpha, a large jitter and (nearly) degenerate /
     identity spectra (the in-kernel fallback to Jacobi)."""
