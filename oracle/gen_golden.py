@@ -753,6 +753,99 @@ def gen_cfg4():
     np.savez_compressed(os.path.join(OUT, "cfg4.npz"), **out)
 
 
+def nbmlp_data(N=400):
+    """Stand-in for the notebook's agw_1d data set (notebooks/hamiltorch_split_HMC_BNN_example.ipynb cell 5 downloads it;
+    there is no network here): N = 400 one-dimensional inputs in three clusters with gaps, a smooth target plus noise,
+    both standardised as the notebook's loader does.  torch generator seed 0."""
+    g = torch.Generator().manual_seed(0)
+    n3 = N // 3
+    x = torch.cat([-7.2 + 2.4 * torch.rand(n3, generator=g), -1.2 + 2.4 * torch.rand(n3, generator=g),
+                   4.8 + 2.4 * torch.rand(N - 2 * n3, generator=g)])
+    x = x[torch.randperm(N, generator=g)]
+    y = 0.3 * x + torch.sin(1.2 * x) * torch.cos(0.4 * x) + 0.25 * torch.randn(N, generator=g)
+    X = ((x - x.mean()) / x.std(unbiased=False)).reshape(-1, 1).float()
+    Y = ((y - y.mean()) / y.std(unbiased=False)).reshape(-1, 1).float()
+    return X, Y
+
+
+class NotebookNet(nn.Module):
+    """notebooks/hamiltorch_split_HMC_BNN_example.ipynb cell 9, verbatim in structure: fc1 (1,100), fc2 (100,100), fc3 (100,1),
+    F.relu between them (D = 10401)."""
+
+    def __init__(self):
+        super().__init__()
+        self.fc1 = nn.Linear(1, 100)
+        self.fc2 = nn.Linear(100, 100)
+        self.fc3 = nn.Linear(100, 1)
+
+    def forward(self, x):
+        x = torch.relu(self.fc1(x))
+        x = torch.relu(self.fc2(x))
+        return self.fc3(x)
+
+
+def gen_nbmlp():
+    """The one model the reference publishes a GPU number for (notebook cells 9-14, 23-25):
+    Linear(1,100)-ReLU-Linear(100,100)-ReLU-Linear(100,1), D = 10401, 400 points, M = 4 splits of 100, tau = 1 for all six
+    parameter tensors, tau_out = 110.4439498986428, inv_mass = ones(D), step_size = 5e-4 (notebook cell 12; L = 30 there, short
+    paths here): full-data log-prob + gradient, the four split closures (value + gradient), H, a 3-step SPLITTING path, a
+    4-step plain leapfrog path, and short end-to-end sample_split_model / sample_model runs with the reference's draws
+    recorded.  Same key layout as cfg4.npz."""
+    out = {}
+    name, dims, N, M, tau_out, eps = "nbmlp", [1, 100, 100, 1], 400, 4, 110.4439498986428, 5e-4
+    X, Y = nbmlp_data(N)
+    torch.manual_seed(0)
+    net = NotebookNet()
+    theta = hamiltorch.util.flatten(net).clone().detach()
+    D = theta.numel()
+    assert D == 10401
+    tau_list = torch.ones(6)
+    pfl = [t.nelement() for t in net.parameters()]
+    psl = [t.shape for t in net.parameters()]
+    out[f"{name}_dims"] = np.array(dims); out[f"{name}_X"] = npy(X); out[f"{name}_Y"] = npy(Y)
+    out[f"{name}_theta"] = npy(theta); out[f"{name}_tau_list"] = npy(tau_list)
+    out[f"{name}_cfg"] = np.array([M, tau_out, eps, 3, 4])
+    f = S.define_model_log_prob(net, "regression", X, Y, pfl, psl, tau_list, tau_out)
+    th = theta.clone().requires_grad_()
+    v = f(th)
+    out[f"{name}_logp"] = npy(v).reshape(-1)
+    out[f"{name}_grad"] = npy(torch.autograd.grad(v.sum(), th)[0])
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(X, Y), batch_size=N // M, shuffle=False)
+    fl = S.define_split_model_log_prob(net, "regression", loader, M, pfl, psl, tau_list, tau_out, verbose=False)
+    out[f"{name}_split_logp"] = np.array([float(fm(theta).sum()) for fm in fl])
+    th = theta.clone().requires_grad_()
+    out[f"{name}_split1_grad"] = npy(torch.autograd.grad(fl[1](th).sum(), th)[0])
+    p0 = torch.randn(D, generator=torch.Generator().manual_seed(2))
+    inv_mass = torch.ones(D)
+    out[f"{name}_p0"] = npy(p0)
+    out[f"{name}_H0"] = npy(S.hamiltonian(theta, p0, fl, inv_mass=inv_mass, sampler=hamiltorch.Sampler.HMC)).reshape(-1)
+    lp_, lm_ = S.leapfrog(theta.clone(), p0.clone(), fl, steps=3, step_size=eps, inv_mass=inv_mass,
+                          sampler=hamiltorch.Sampler.HMC, integrator=hamiltorch.Integrator.SPLITTING)
+    out[f"{name}_lf_theta"] = npy(lp_[-1]); out[f"{name}_lf_p"] = npy(lm_[-1])
+    lp_, lm_ = S.leapfrog(theta.clone(), p0.clone(), f, steps=4, step_size=eps, inv_mass=inv_mass,
+                          sampler=hamiltorch.Sampler.HMC, integrator=hamiltorch.Integrator.EXPLICIT)
+    out[f"{name}_full_lf_theta"] = npy(lp_[-1]); out[f"{name}_full_lf_p"] = npy(lm_[-1])
+    hamiltorch.set_random_seed(33)
+    with Recorder() as rec:
+        ret, acc = hamiltorch.sample_split_model(net, loader, theta.clone(), M, model_loss="regression", num_samples=2,
+                                                 num_steps_per_sample=4, step_size=eps, burn=-1, inv_mass=inv_mass,
+                                                 tau_out=tau_out, tau_list=tau_list, debug=2, verbose=False)
+    out[f"{name}_e2e_samples"] = np.stack([npy(t) for t in ret])
+    out[f"{name}_e2e_momenta"] = np.stack(rec.momenta)
+    out[f"{name}_e2e_uniforms"] = np.concatenate(rec.uniforms)
+    out[f"{name}_e2e_acc"] = np.array(acc)
+    hamiltorch.set_random_seed(34)
+    with Recorder() as rec:
+        ret, acc = hamiltorch.sample_model(net, X, Y, theta.clone(), model_loss="regression", num_samples=2,
+                                           num_steps_per_sample=5, step_size=eps, burn=-1, inv_mass=inv_mass, tau_out=tau_out,
+                                           tau_list=tau_list, debug=2, verbose=False)
+    out[f"{name}_full_samples"] = np.stack([npy(t) for t in ret])
+    out[f"{name}_full_momenta"] = np.stack(rec.momenta)
+    out[f"{name}_full_uniforms"] = np.concatenate(rec.uniforms)
+    out[f"{name}_full_acc"] = np.array(acc)
+    np.savez_compressed(os.path.join(OUT, "nbmlp.npz"), **out)
+
+
 def gen_cfg3():
     """BASELINE config 3 at full size: D=100, P = Q diag(linspace(.5, 2, 100)) Q^T (generator seed 0), soft-abs
     metric alpha=1e6, omega=10, eps=0.1 - metric pieces, Hamiltonian, a 3-step explicit leapfrog path without jitter
@@ -824,5 +917,6 @@ if __name__ == "__main__":
     gen_cfg2()
     gen_cfg3()
     gen_cfg4()
+    gen_nbmlp()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

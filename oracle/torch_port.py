@@ -287,6 +287,23 @@ def cfg2_worker(args):
     return n, L, dt, acc, torch.stack(ret[1:]).tolist()
 
 
+def notebook_net():
+    """notebooks/hamiltorch_split_HMC_BNN_example.ipynb cell 9: Linear(1,100)-ReLU-Linear(100,100)-ReLU-Linear(100,1) as a
+    module with the notebook's parameter names (fc1, fc2, fc3): D = 10401."""
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1 = torch.nn.Linear(1, 100)
+            self.fc2 = torch.nn.Linear(100, 100)
+            self.fc3 = torch.nn.Linear(100, 1)
+
+        def forward(self, x):
+            x = torch.relu(self.fc1(x))
+            x = torch.relu(self.fc2(x))
+            return self.fc3(x)
+    return Net()
+
+
 if __name__ == "__main__":          # python oracle/torch_port.py cfg2 <seed> <L> <eps> <seconds>  -> one JSON line
     import json
     import sys

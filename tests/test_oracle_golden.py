@@ -612,3 +612,75 @@ def test_deep_and_linear_nets_vs_reference_fixture(golden):
             lp, gr = o.logp_and_grad(g[name + "_theta"][None].astype(np.float64))
             np.testing.assert_allclose(lp, g[name + "_logp"][m], rtol=3e-6)
             np.testing.assert_allclose(gr[0], g[name + "_grad"][m], rtol=3e-5, atol=3e-6)
+
+
+# ---- the reference's published split-HMC model: Linear(1,100)-ReLU-Linear(100,100)-ReLU-Linear(100,1), D = 10401 --------------
+def _nb_targets(g):
+    name = "nbmlp"
+    M, tau_out = int(g[f"{name}_cfg"][0]), float(g[f"{name}_cfg"][1])
+    X, Y = g[f"{name}_X"], g[f"{name}_Y"]
+    nb = X.shape[0] // M
+    full = O.MLPRegressionTarget([1, 100, 100, 1], X, Y, g[f"{name}_tau_list"], tau_out, 1.0, "relu")
+    splits = [O.MLPRegressionTarget([1, 100, 100, 1], X[m * nb:(m + 1) * nb], Y[m * nb:(m + 1) * nb], g[f"{name}_tau_list"],
+                                    tau_out, M, "relu") for m in range(M)]
+    return full, splits
+
+
+def test_nbmlp_oracle_vs_reference_fixture(golden):
+    """tests/golden/nbmlp.npz (oracle/gen_golden.py::gen_nbmlp from the unmodified reference): the notebook's model
+    (notebooks/hamiltorch_split_HMC_BNN_example.ipynb cells 9-14, 23-25; D = 10401, 400 points, M = 4, tau_out = 110.44,
+    eps = 5e-4) - full-data log-prob + gradient, the split closures, H, a 3-step SPLITTING path, a 4-step leapfrog path and the
+    two end-to-end runs replayed with the reference's recorded draws."""
+    g = golden("nbmlp")
+    name = "nbmlp"
+    M, tau_out, eps, Ls, Lf = g[f"{name}_cfg"]
+    M, Ls, Lf = int(M), int(Ls), int(Lf)
+    full, splits = _nb_targets(g)
+    assert full.D == 10401
+    theta = g[f"{name}_theta"][None].astype(np.float32)
+    lp, gr = full.logp_and_grad(theta)
+    np.testing.assert_allclose(lp, g[f"{name}_logp"], rtol=2e-5)
+    gs = np.abs(g[f"{name}_grad"]).max()
+    np.testing.assert_allclose(gr[0], g[f"{name}_grad"], rtol=2e-4, atol=2e-5 * gs)
+    np.testing.assert_allclose([s.logp(theta)[0] for s in splits], g[f"{name}_split_logp"], rtol=2e-5)
+    np.testing.assert_allclose(splits[1].grad(theta)[0], g[f"{name}_split1_grad"], rtol=2e-4, atol=2e-5 * gs)
+    p0 = g[f"{name}_p0"][None].astype(np.float32)
+    im = np.ones(theta.shape[1], np.float32)
+    H0, _ = O.hmc_hamiltonian(theta, p0, [s.logp for s in splits], im)
+    np.testing.assert_allclose(H0, g[f"{name}_H0"], rtol=2e-5)
+    th, pm = O.split_leapfrog(theta, p0, [s.grad for s in splits], Ls, eps, im)
+    np.testing.assert_allclose(th[0], g[f"{name}_lf_theta"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(pm[0], g[f"{name}_lf_p"], rtol=1e-3, atol=2e-3)
+    th, pm = O.hmc_leapfrog(theta, p0, full.grad, Lf, eps, im)
+    np.testing.assert_allclose(th[0], g[f"{name}_full_lf_theta"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(pm[0], g[f"{name}_full_lf_p"], rtol=1e-3, atol=2e-3)
+    draws = O.ReplayDraws(g[f"{name}_e2e_momenta"], g[f"{name}_e2e_uniforms"])
+    ret, info = O.sample_hmc(None, theta, 2, 4, eps, -1, im, draws, grad_fns=[s.grad for s in splits], logp_fns=[s.logp for s in splits])
+    np.testing.assert_allclose(np.concatenate(ret), g[f"{name}_e2e_samples"], rtol=1e-3, atol=1e-4)
+    assert abs(info["acc_rate"][0] - float(g[f"{name}_e2e_acc"])) < 1e-9
+    draws = O.ReplayDraws(g[f"{name}_full_momenta"], g[f"{name}_full_uniforms"])
+    ret, info = O.sample_hmc(full, theta, 2, 5, eps, -1, im, draws)
+    np.testing.assert_allclose(np.concatenate(ret), g[f"{name}_full_samples"], rtol=1e-3, atol=1e-4)
+    assert abs(info["acc_rate"][0] - float(g[f"{name}_full_acc"])) < 1e-9
+
+
+def test_torch_port_nbmlp_matches_reference_run(golden):
+    """bench.py's cpu_baseline for the notebook model (split-HMC port over functional-model closures, per-half-kick autograd):
+    the reference's own sample_split_model run at D = 10401 from the same torch seed."""
+    import torch
+    import torch_port as TP
+    g = golden("nbmlp")
+    name = "nbmlp"
+    M, tau_out, eps = int(g[f"{name}_cfg"][0]), float(g[f"{name}_cfg"][1]), float(g[f"{name}_cfg"][2])
+    net = TP.notebook_net()
+    X, Y = torch.tensor(g[f"{name}_X"]), torch.tensor(g[f"{name}_Y"])
+    tau_list = torch.tensor(g[f"{name}_tau_list"])
+    nb = X.shape[0] // M
+    fl = [TP.port_mlp_closure(net, X[m * nb:(m + 1) * nb], Y[m * nb:(m + 1) * nb], tau_list, tau_out, M) for m in range(M)]
+    torch.manual_seed(33)
+    for _ in torch.utils.data.DataLoader(torch.utils.data.TensorDataset(X, Y), batch_size=nb, shuffle=False):
+        pass                                       # the loader's base-seed draw, as the reference's run consumed it
+    ret, acc = TP.port_sample_split(fl, torch.tensor(g[f"{name}_theta"]), 2, 4, eps, -1, torch.ones(10401))
+    got = np.stack([t.numpy() for t in ret])
+    np.testing.assert_allclose(got, g[f"{name}_e2e_samples"], rtol=1e-5, atol=1e-6)
+    assert acc == float(g[f"{name}_e2e_acc"])
