@@ -372,6 +372,7 @@ ACTS = {"relu": 0, "tanh": 1, "sigmoid": 2}
 LOSSES = {"regression": 0, "binary_class_linear_output": 1}       # HTA_LOSS_REGRESSION / HTA_LOSS_BINARY_LOGITS
 NET_LOSSES = dict(LOSSES, multi_class_linear_output=2)             # + HTA_LOSS_SOFTMAX_CE (hta_netn_* only)
 NETN_MAX_LAYERS, NETN_MAX_WIDTH, NETN_MAX_PARAMS, NETN_MAX_BLOCKS = 4, 64, 512, 96     # csrc/netn_hmc.hip (blocks of 4 x 4 weights)
+MLP3_MAX_IN, MLP3_MAX_WIDTH = 4, 104                                                   # csrc/mlp3_mfma.hip (M3_NIN, M3_HMAX)
 
 
 def _tau4(like, tau):

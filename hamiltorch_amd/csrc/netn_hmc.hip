@@ -23,6 +23,7 @@
 // Layer shapes are run-time values (uniform loops); limits: D <= 512 parameters, widths <= 64, N <= what L2 holds (X is read
 // from global memory, coalesced over the lanes).
 #include "mlp.hpp"
+#include "netn.hpp"
 #include "philox.hpp"
 
 #ifndef NETN_TIMING
@@ -41,24 +42,6 @@ namespace hta {
 void profile_begin(hipStream_t s);
 void profile_end(hipStream_t s);
 extern int g_netn_waves;                // tuning key "netn_waves" (default 1)
-
-constexpr int NETN_MAX_LAYERS = 4;      // Linear layers
-constexpr int NETN_KMAX = 8;            // parameters per lane: D <= 512
-constexpr int NETN_MAX_WIDTH = 64;
-constexpr int NETN_NSET = 6;            // matrix instructions per point of the gradient: up to 96 blocks of 4 x 4 weights
-
-template <typename T> struct NetArgs {
-  T* theta; const T* theta_init; int64_t C;
-  int n_layers; int dims[NETN_MAX_LAYERS + 1]; int act; int loss;
-  const T* X; const T* Y; int N; int M; int Nb;
-  T tau[2 * NETN_MAX_LAYERS]; T tau_out; T prior_scale;
-  int mass_kind; const T* inv_mass; const T* mass_factor;
-  int L; T eps; int n_traj; int traj_offset; int burn;
-  uint64_t seed; uint64_t chain_offset;
-  T* samples; int32_t* reject_count; T* H_old; T* H_new; uint8_t* accept;
-  T* grad_out; T* logp_out; int eval_split;
-  int integ;
-};
 
 template <int CTRL, int ROWMASK> __device__ __forceinline__ float dpp_add(float v) {
   const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false);
@@ -663,6 +646,9 @@ __global__ __launch_bounds__(64 * WV) void netn_hmc_kernel(NetArgs<T> a, int D, 
 
 template <typename T> int netn_hmc(const NetArgs<T>& a, hipStream_t s) {
   HTA_REQUIRE(a.theta && a.X && a.Y && a.C > 0, "hta_netn_hmc: NULL pointer / empty batch");
+  if constexpr (sizeof(T) == 4) {          // two wide hidden layers, one output, Gaussian likelihood: the matrix-core kernel (mlp3_mfma.hip)
+    if (a.n_layers == 3 && mlp3_eligible(a)) return mlp3_mfma(a, s);
+  }
   HTA_REQUIRE(a.n_layers >= 1 && a.n_layers <= NETN_MAX_LAYERS, "hta_netn_hmc: %d Linear layers not in [1, %d]", a.n_layers, NETN_MAX_LAYERS);
   int D = 0, SW = a.dims[0], WM = 1;
   for (int l = 0; l <= a.n_layers; ++l)

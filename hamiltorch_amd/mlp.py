@@ -33,13 +33,24 @@ def _n_params(dims):
     return sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(len(dims) - 1))
 
 
+def _is_mlp3(dims, loss):
+    """Two wide hidden layers and one output with a Gaussian likelihood - Linear(n_in, H1)-act-Linear(H1, H2)-act-Linear(H2, 1),
+    n_in <= 4, H1, H2 <= 104, beyond the small-net kernel's widths: csrc/mlp3_mfma.hip (the reference's published split-HMC
+    model, notebooks/hamiltorch_split_HMC_BNN_example.ipynb cell 9: 1-100-100-1)."""
+    return (len(dims) == 4 and dims[-1] == 1 and 1 <= dims[0] <= _abi.MLP3_MAX_IN and max(dims[1], dims[2]) <= _abi.MLP3_MAX_WIDTH
+            and loss == "regression" and (max(dims[1], dims[2]) > _abi.NETN_MAX_WIDTH or _n_params(dims) > _abi.NETN_MAX_PARAMS))
+
+
 def _kernel_for(spec):
     """'mlp1': csrc/mlp_hmc.hip / mlp_mfma.hip (one hidden layer, one output, Gaussian or Bernoulli likelihood, any width up to
-    1024); 'netn': csrc/netn_hmc.hip (1 .. 4 Linear layers, widths <= 64, <= 512 parameters, also softmax cross-entropy);
+    1024); 'netn': the hta_netn_* entry points - csrc/netn_hmc.hip (1 .. 4 Linear layers, widths <= 64, <= 512 parameters, also
+    softmax cross-entropy) or csrc/mlp3_mfma.hip (two hidden layers up to 104 wide, one output, Gaussian likelihood, fp32);
     None: the callback path."""
     dims, loss = spec["dims"], spec["loss"]
     if len(dims) == 3 and dims[-1] == 1 and dims[0] <= 32 and dims[1] <= 1024 and loss in _abi.LOSSES:
         return "mlp1"
+    if _is_mlp3(dims, loss):
+        return "netn"          # same entry points (hta_netn_*): the library dispatches to csrc/mlp3_mfma.hip (fp32)
     if 2 <= len(dims) <= _abi.NETN_MAX_LAYERS + 1 and max(dims) <= _abi.NETN_MAX_WIDTH and _n_params(dims) <= _abi.NETN_MAX_PARAMS \
             and sum(((dims[i + 1] + 3) // 4) * ((dims[i] + 4) // 4) for i in range(len(dims) - 1)) <= _abi.NETN_MAX_BLOCKS \
             and loss in _abi.NET_LOSSES:
@@ -72,6 +83,10 @@ class _MLPEngine:
                     return self._fb.begin(theta0, N, burn, inv_mass, seed, chain_offset)
                 self._begin_args = (theta0, N, burn, inv_mass, seed, chain_offset)
                 super().begin(theta0, N, burn, inv_mass, seed, chain_offset)
+                if self.kind == _abi.MASS_DIAG and bool((self.im == 1).all()):
+                    # the notebooks pass inv_mass = ones(D): multiplying by 1.0 is exact, so the identity-mass kernels give the
+                    # same bits without loading a mass vector at every drift
+                    self.kind, self.im, self.mf = _abi.MASS_NONE, None, None
                 self.X = torch.cat([s["X"].reshape(self.Nb, self.n_in) for s in self.specs]).to(theta0).contiguous()
                 self.Y = torch.cat([s["Y"].reshape(self.Nb, -1) for s in self.specs]).to(theta0).contiguous()
 

@@ -81,7 +81,7 @@ def port_sample(log_prob_func, params_init, num_samples, num_steps_per_sample, s
             q_new, p_new = port_leapfrog(params, p, log_prob_func, num_steps_per_sample, step_size, inv_mass)
             params = q_new.detach()
             new_ham = port_hamiltonian(params, p_new, log_prob_func, inv_mass)        # S:995
-            rho = min(0., float(-new_ham + ham))                                      # S:1000, S:626
+            rho = min(0., float((-new_ham + ham).detach()))                                      # S:1000, S:626
             accept = bool(rho >= torch.log(torch.rand(1)))                            # S:1004
         except FloatingPointError:                                                    # S:1045
             accept = False
@@ -251,7 +251,7 @@ def port_sample_split(closures, params_init, num_samples, num_steps_per_sample, 
                     if m > 0:
                         q += (step_size / ((M - 1) * 2)) * (p if inv_mass is None else inv_mass * p)
         h1 = ham(q, p)
-        rho = min(0., float(-h1 + h0))
+        rho = min(0., float((-h1 + h0).detach()))
         if rho >= torch.log(torch.rand(1)):
             params = q.clone()
             if n > burn:

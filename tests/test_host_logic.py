@@ -479,3 +479,34 @@ def test_predict_eval_all_survives_out_of_memory(monkeypatch):
     vs, os_ = bnn._eval_all(f, samples, torch.device("cpu"))
     assert [float(v) for v in vs] == [3.0 * k for k in range(20)]
     assert bnn.predict_stats["looped"] == before["looped"] + 1
+
+
+def test_wide_two_hidden_layer_models_route_to_the_matrix_core_kernel():
+    """mlp._kernel_for: the notebook's split-HMC model (1-100-100-1) and its relatives go to the hta_netn_* entry points, where
+    the library dispatches csrc/mlp3_mfma.hip; shapes outside its range keep their previous route."""
+    from hamiltorch_amd import mlp
+    k = lambda dims, loss="regression": mlp._kernel_for(dict(dims=dims, loss=loss))     # noqa: E731
+    assert k([1, 100, 100, 1]) == "netn" and mlp._is_mlp3([1, 100, 100, 1], "regression")
+    assert k([4, 104, 72, 1]) == "netn" and mlp._is_mlp3([4, 104, 72, 1], "regression")
+    assert k([1, 10, 10, 1]) == "netn" and not mlp._is_mlp3([1, 10, 10, 1], "regression")        # the small-net kernel's own
+    assert k([1, 105, 100, 1]) is None and k([5, 100, 100, 1]) is None                              # beyond the kernel: callback path
+    assert k([1, 100, 100, 2]) is None and k([1, 100, 100, 1], "binary_class_linear_output") is None
+    assert k([8, 100, 1]) == "mlp1"
+    # the notebook's class is recognised structurally (fc1 / fc2 / fc3 with F.relu in forward)
+    import torch.nn as nn
+    from hamiltorch_amd import bnn
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1, self.fc2, self.fc3 = nn.Linear(1, 100), nn.Linear(100, 100), nn.Linear(100, 1)
+
+        def forward(self, x):
+            x = torch.nn.functional.relu(self.fc1(x))
+            x = torch.nn.functional.relu(self.fc2(x))
+            return self.fc3(x)
+    net = Net()
+    assert bnn._mlp_structure(net)[:2] == ([1, 100, 100, 1], "relu")
+    sizes = [w.nelement() for w in net.parameters()]; shapes = [w.shape for w in net.parameters()]
+    f = bnn.define_model_log_prob(net, "regression", torch.randn(40, 1), torch.randn(40, 1), sizes, shapes, [1.0] * 6, 110.44)
+    assert f._hta_spec["dims"] == [1, 100, 100, 1] and mlp._kernel_for(f._hta_spec) == "netn"
