@@ -27,9 +27,23 @@
 // f(x_p) = b3 + sum_u w3_u a2[p, u]: reduce-scatter over the 16 unit lanes (DPP), over the waves through LDS.  The thin layers
 // (W1, b1, b2, w3, b3: 401 of 10401 parameters) are per-unit registers with copies in the 4 lane groups.
 // LDS (151 KB): A1 [112][104] | D2 [112][104] (delta2; doubles as the W2 staging copy) | A1T [112][120] | X, Y of the chunk | partials.
+#include <map>
+#include <mutex>
+#include <utility>
 #include "netn.hpp"
 #include "mlp.hpp"
 #include "philox.hpp"
+
+#ifndef M3_TIMING
+#define M3_TIMING 0   // developer cycle counters per phase of a pass (wave 0 of workgroup 0): tools/scratch/m3_time.py prints them
+#endif
+#if M3_TIMING
+__device__ unsigned long long hta_m3_dbg[20];
+extern "C" void hta_m3_dbg_read(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(hta_m3_dbg), sizeof(hta_m3_dbg)); }
+#define M3_TICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[k] += now_ - tacc[19]; tacc[19] = now_; } while (0)
+#else
+#define M3_TICK(k) do {} while (0)
+#endif
 
 namespace hta {
 
@@ -72,96 +86,168 @@ struct M3State {
   float b1, b2, w3, b3;
 };
 
+// The per-lane description of where a state vector's elements live in the flat parameter vector (passed BY VALUE to the
+// out-of-line helpers below: the rarely executed code - loads, stores, momentum draws, hundreds of instructions with their own
+// register needs - must not share the register allocation of the gradient pass, or the allocator parks the momentum in scratch
+// memory across every pass: measured, 12 000 of a pass's 74 000 cycles were serial scratch round trips in the kick).
+struct M3Lay {
+  int w, g, c, n_in, H1, H2, rq1;
+  int o_w1, o_b1, o_w2, o_b2, o_w3, o_b3;       // flat offsets (torch parameter order: W1, b1, W2, b2, W3, b3)
+  bool jval, uval, vecd;                         // layer-1 unit / layer-2 unit 16 w + c exists; rows of W2 start on a multiple of 4 elements
+  // column of register [s][t] and whether the element exists
+  __device__ __forceinline__ int col(int s, int t) const { return s < 6 ? 16 * s + 4 * g + t : 96 + 4 * t + g; }
+  __device__ __forceinline__ bool ok(int s, int t) const { return uval && col(s, t) < H1 && (s < 6 || t < rq1); }
+};
+
+// element idx of `base` if it exists, else 0 - an unconditional load from a clamped address and a select (no branch per element)
+static __device__ __forceinline__ float m3_pick(const float* base, int idx, bool exists) {
+  const float v = base[exists ? idx : 0];
+  return exists ? v : 0.0f;
+}
+
+// vec4: th + o_w2 + u H1 is 16-byte aligned for every row (the caller knows the base's alignment)
+static __device__ __forceinline__ void m3_load_inline(const M3Lay& L, const float* th, bool vec4, M3State& q) {
+  const int u = 16 * L.w + L.c;
+  const float* row = th + L.o_w2 + (size_t)(L.uval ? u : 0) * L.H1;
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const int j0 = 16 * s + 4 * L.g;
+    if (vec4 && L.uval && j0 + 4 <= L.H1) q.w2[s] = *reinterpret_cast<const V4f*>(row + j0);
+    else
+#pragma unroll
+      for (int t = 0; t < 4; ++t) q.w2[s][t] = m3_pick(row, j0 + t, L.ok(s, t));
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) q.w2[6][t] = m3_pick(row, L.col(6, t), L.ok(6, t));
+  const int j1 = L.jval ? 16 * L.w + L.c : 0, u2 = L.uval ? u : 0;
+#pragma unroll
+  for (int k = 0; k < M3_NIN; ++k) q.w1[k] = m3_pick(th + L.o_w1 + j1 * L.n_in, k, L.jval && k < L.n_in);
+  q.b1 = m3_pick(th + L.o_b1, j1, L.jval);
+  q.b2 = m3_pick(th + L.o_b2, u2, L.uval);
+  q.w3 = m3_pick(th + L.o_w3, u2, L.uval);
+  q.b3 = th[L.o_b3];
+}
+__device__ __attribute__((noinline)) void m3_load(M3Lay L, const float* th, bool vec4, M3State* qp) {
+  M3State q;
+  m3_load_inline(L, th, vec4, q);
+  *qp = q;
+}
+// every copy lane stores (same value, same address): a lane later reloads exactly what it stored itself
+__device__ __attribute__((noinline)) void m3_store(M3Lay L, float* th, bool vec4, const M3State* qp) {
+  const M3State q = *qp;
+  const int u = 16 * L.w + L.c;
+  float* row = th + L.o_w2 + (size_t)(L.uval ? u : 0) * L.H1;
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const int j0 = 16 * s + 4 * L.g;
+    if (vec4 && L.uval && j0 + 4 <= L.H1) *reinterpret_cast<V4f*>(row + j0) = q.w2[s];
+    else
+#pragma unroll
+      for (int t = 0; t < 4; ++t) if (L.ok(s, t)) row[j0 + t] = q.w2[s][t];
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) if (L.ok(6, t)) row[L.col(6, t)] = q.w2[6][t];
+#pragma unroll
+  for (int k = 0; k < M3_NIN; ++k) if (L.jval && k < L.n_in) th[L.o_w1 + (16 * L.w + L.c) * L.n_in + k] = q.w1[k];
+  if (L.jval) th[L.o_b1 + 16 * L.w + L.c] = q.b1;
+  if (L.uval) { th[L.o_b2 + u] = q.b2; th[L.o_w3 + u] = q.w3; }
+  th[L.o_b3] = q.b3;
+}
+// p = sqrt(M) z, z a standard-normal draw in the state layout (element i of the D-vector = Philox block i / 4, slot i % 4: the
+// oracle's stream; S:185-186 / S:200-201); mass_factor NULL = identity mass
+__device__ __attribute__((noinline)) void m3_draw(M3Lay L, uint64_t seed, uint64_t chain, uint32_t n, const float* mass_factor, M3State* zp) {
+  M3State z;
+  const int u = 16 * L.w + L.c;
+  const int rowoff = L.o_w2 + (L.uval ? u : 0) * L.H1;
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const int j0 = 16 * s + 4 * L.g;
+    if (L.vecd && L.uval && j0 + 4 <= L.H1) {                   // four consecutive elements = one Philox block
+      float zz[4];
+      normal4<float>(philox_block(seed, chain, n, PURPOSE_MOMENTUM, 0, (uint32_t)((rowoff + j0) >> 2)), zz);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) z.w2[s][t] = zz[t];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { const float v = normal_elem<float>(seed, chain, n, 0, rowoff + j0 + t); z.w2[s][t] = L.ok(s, t) ? v : 0.0f; }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { const float v = normal_elem<float>(seed, chain, n, 0, rowoff + L.col(6, t)); z.w2[6][t] = L.ok(6, t) ? v : 0.0f; }
+  const int j1 = L.jval ? 16 * L.w + L.c : 0, u2 = L.uval ? u : 0;
+#pragma unroll
+  for (int k = 0; k < M3_NIN; ++k) {
+    float v = 0.0f;
+    if (k < L.n_in) v = normal_elem<float>(seed, chain, n, 0, L.o_w1 + j1 * L.n_in + k);      // (uniform branch)
+    z.w1[k] = L.jval ? v : 0.0f;
+  }
+  { const float v = normal_elem<float>(seed, chain, n, 0, L.o_b1 + j1); z.b1 = L.jval ? v : 0.0f; }
+  { const float v = normal_elem<float>(seed, chain, n, 0, L.o_b2 + u2); z.b2 = L.uval ? v : 0.0f; }
+  { const float v = normal_elem<float>(seed, chain, n, 0, L.o_w3 + u2); z.w3 = L.uval ? v : 0.0f; }
+  z.b3 = normal_elem<float>(seed, chain, n, 0, L.o_b3);
+  if (mass_factor) {
+    M3State mf;
+    m3_load(L, mass_factor, L.vecd, &mf);
+#pragma unroll
+    for (int s = 0; s < 7; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) z.w2[s][t] *= mf.w2[s][t];
+#pragma unroll
+    for (int k = 0; k < M3_NIN; ++k) z.w1[k] *= mf.w1[k];
+    z.b1 *= mf.b1; z.b2 *= mf.b2; z.w3 *= mf.w3; z.b3 *= mf.b3;
+  }
+  *zp = z;
+}
+
 template <int ACT>
 struct M3Chain {
   const NetArgs<float>& a;
-  float *A1, *D2, *A1T, *XS, *YS, *fpart, *rbuf, *red, *dump;
+  float *A1, *D2, *A1T, *XS, *YS, *fpart, *rbuf, *red;
+  const float *XALL, *YALL;                      // the whole data set in LDS ([k][NP] and [NP], zero padded) when it fits: NP > 0
+  int NP;
   int tid, w, g, c, n_in, H1, H2, rq1, rq2;
+#if M3_TIMING
+  unsigned long long* tacc;                      // [20] in the kernel's frame; [19] = the last stamp
+#endif
   int o_w1, o_b1, o_w2, o_b2, o_w3, o_b3;       // flat offsets (torch parameter order: W1, b1, W2, b2, W3, b3)
   bool jval, uval, vecd;                         // layer-1 unit / layer-2 unit 16 w + c exists; rows of W2 start on a multiple of 4 elements
   __device__ M3Chain(const NetArgs<float>& a_) : a(a_) {}
 
-  // column of register [s][t] and whether the element exists
-  __device__ __forceinline__ int col(int s, int t) const { return s < 6 ? 16 * s + 4 * g + t : 96 + 4 * t + g; }
-  __device__ __forceinline__ bool ok(int s, int t) const { return uval && col(s, t) < H1 && (s < 6 || t < rq1); }
-
-  // element idx of `base` if it exists, else 0 - an unconditional load from a clamped address and a select (no branch per element)
-  static __device__ __forceinline__ float pick(const float* base, int idx, bool exists) {
-    const float v = base[exists ? idx : 0];
-    return exists ? v : 0.0f;
+  M3Lay lay;
+  // The W2 share of the MOMENTUM lives in global memory (this workgroup's slot of a workspace, [7][448] float4: one 16-byte
+  // access per lane and block, L2 resident) except between its prefetch - issued under GEMM2 - and the end of the pass
+  // (kick, drift, write back).  Left to the register allocator, those 28 registers were "spilled" across the pass anyway, to
+  // scratch memory, reloaded in the kick by six SERIAL round trips to HBM (12 000 of a pass's 74 000 cycles, measured).
+  V4f* pw;                                       // (uniform) this workgroup's slot
+  // this lane's index into a block of the slot.  Opaque to the optimiser on purpose: seven loop-invariant 64-bit addresses
+  // were hoisted out of the stage loop and then SPILLED - each access became "reload the address from scratch, wait, load".
+  __device__ __forceinline__ int pw_lane() const {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    return t;
   }
-  // vec4: th + o_w2 + u H1 is 16-byte aligned for every row (the caller knows the base's alignment)
-  __device__ __forceinline__ void load(const float* th, M3State& q, bool vec4) const {
-    const int u = 16 * w + c;
-    const float* row = th + o_w2 + (size_t)(uval ? u : 0) * H1;
+  __device__ __forceinline__ void park(const M3State& x) const {
+    const int t = pw_lane();
 #pragma unroll
-    for (int s = 0; s < 6; ++s) {
-      const int j0 = 16 * s + 4 * g;
-      if (vec4 && uval && j0 + 4 <= H1) q.w2[s] = *reinterpret_cast<const V4f*>(row + j0);
-      else
-#pragma unroll
-        for (int t = 0; t < 4; ++t) q.w2[s][t] = pick(row, j0 + t, ok(s, t));
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) q.w2[6][t] = pick(row, col(6, t), ok(6, t));
-    const int j1 = jval ? 16 * w + c : 0, u2 = uval ? u : 0;
-#pragma unroll
-    for (int k = 0; k < M3_NIN; ++k) q.w1[k] = pick(th + o_w1 + j1 * n_in, k, jval && k < n_in);
-    q.b1 = pick(th + o_b1, j1, jval);
-    q.b2 = pick(th + o_b2, u2, uval);
-    q.w3 = pick(th + o_w3, u2, uval);
-    q.b3 = th[o_b3];
+    for (int s = 0; s < 7; ++s) pw[s * M3_NT + t] = x.w2[s];
   }
-  // every copy lane stores (same value, same address): a lane later reloads exactly what it stored itself
-  __device__ __forceinline__ void store(float* th, const M3State& q, bool vec4) const {
-    const int u = 16 * w + c;
-    float* row = th + o_w2 + (size_t)(uval ? u : 0) * H1;
+  __device__ __forceinline__ void unpark(M3State& x) const {
+    const int t = pw_lane();
 #pragma unroll
-    for (int s = 0; s < 6; ++s) {
-      const int j0 = 16 * s + 4 * g;
-      if (vec4 && uval && j0 + 4 <= H1) *reinterpret_cast<V4f*>(row + j0) = q.w2[s];
-      else
-#pragma unroll
-        for (int t = 0; t < 4; ++t) if (ok(s, t)) row[j0 + t] = q.w2[s][t];
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) if (ok(6, t)) row[col(6, t)] = q.w2[6][t];
-#pragma unroll
-    for (int k = 0; k < M3_NIN; ++k) if (jval && k < n_in) th[o_w1 + (16 * w + c) * n_in + k] = q.w1[k];
-    if (jval) th[o_b1 + 16 * w + c] = q.b1;
-    if (uval) { th[o_b2 + u] = q.b2; th[o_w3 + u] = q.w3; }
-    th[o_b3] = q.b3;
+    for (int s = 0; s < 7; ++s) x.w2[s] = pw[s * M3_NT + t];
   }
-  // standard-normal draw in the state layout (element i of the D-vector = Philox block i / 4, slot i % 4: the oracle's stream)
+  __device__ __forceinline__ bool ok(int s, int t) const { return lay.ok(s, t); }
+  // loads, stores and draws run out of line (see M3Lay) and hand the state over through memory: once per trajectory
+  __device__ __forceinline__ void load(const float* th, M3State& q, bool vec4) const { M3State t; m3_load(lay, th, vec4, &t); q = t; }
+  __device__ __forceinline__ void store(float* th, const M3State& q, bool vec4) const { M3State t = q; m3_store(lay, th, vec4, &t); }
+  // the momentum draw: its W2 share goes straight to the workspace, the thin layers' share into z (z.w2 is not used)
   __device__ __forceinline__ void draw(uint64_t chain, uint32_t n, M3State& z) const {
-    const int u = 16 * w + c;
-    const int rowoff = o_w2 + (uval ? u : 0) * H1;
+    M3State t;
+    m3_draw(lay, a.seed, chain, n, a.mass_kind == HTA_MASS_DIAG ? a.mass_factor : nullptr, &t);
+    park(t);
 #pragma unroll
-    for (int s = 0; s < 6; ++s) {
-      const int j0 = 16 * s + 4 * g;
-      if (vecd && uval && j0 + 4 <= H1) {                       // four consecutive elements = one Philox block
-        float zz[4];
-        normal4<float>(philox_block(a.seed, chain, n, PURPOSE_MOMENTUM, 0, (uint32_t)((rowoff + j0) >> 2)), zz);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) z.w2[s][t] = zz[t];
-      } else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { const float v = normal_elem<float>(a.seed, chain, n, 0, rowoff + j0 + t); z.w2[s][t] = ok(s, t) ? v : 0.0f; }
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { const float v = normal_elem<float>(a.seed, chain, n, 0, rowoff + col(6, t)); z.w2[6][t] = ok(6, t) ? v : 0.0f; }
-    const int j1 = jval ? 16 * w + c : 0, u2 = uval ? u : 0;
-#pragma unroll
-    for (int k = 0; k < M3_NIN; ++k) {
-      float v = 0.0f;
-      if (k < n_in) v = normal_elem<float>(a.seed, chain, n, 0, o_w1 + j1 * n_in + k);      // (uniform branch)
-      z.w1[k] = jval ? v : 0.0f;
-    }
-    { const float v = normal_elem<float>(a.seed, chain, n, 0, o_b1 + j1); z.b1 = jval ? v : 0.0f; }
-    { const float v = normal_elem<float>(a.seed, chain, n, 0, o_b2 + u2); z.b2 = uval ? v : 0.0f; }
-    { const float v = normal_elem<float>(a.seed, chain, n, 0, o_w3 + u2); z.w3 = uval ? v : 0.0f; }
-    z.b3 = normal_elem<float>(a.seed, chain, n, 0, o_b3);
+    for (int k = 0; k < M3_NIN; ++k) z.w1[k] = t.w1[k];
+    z.b1 = t.b1; z.b2 = t.b2; z.w3 = t.w3; z.b3 = t.b3;
   }
 
   __device__ __forceinline__ float block_sum(float v) {
@@ -195,7 +281,8 @@ struct M3Chain {
   // a second state vector - 36 registers; k2 is the half kick S:302 takes back).  Returns the sum of squared residuals of the
   // points (every thread) when !grad.  ONE call site in the kernel (a state machine drives it): the body is 560 matrix
   // instructions of straight-line code.
-  __device__ __forceinline__ float pass(const M3State& q, int lo, int hi, M3State& pm, float k1, float k2, bool grad) {
+  __device__ __forceinline__ float pass(M3State& q, int lo, int hi, M3State& pm, float k1, float k2, float dr, bool grad) {
+    V4f pv[7];                                // the momentum's W2 share between its load and its write-back
     V4f G[7];
     float gw1[M3_NIN] = {0, 0, 0, 0};
     float gb1 = 0, gb2 = 0, gw3 = 0, gb3 = 0, sse = 0;
@@ -205,14 +292,23 @@ struct M3Chain {
     const bool odd = c & 1, bit1 = c & 2;
     for (int c0 = lo; c0 < hi; c0 += M3_CP) {
       const int cnt = min(M3_CP, hi - c0);
+      M3_TICK(0);
       __syncthreads();                        // everyone is done with A1 / D2 / XS / fpart of the previous chunk or pass
-      for (int i = tid; i < M3_CP; i += M3_NT) {
-        const bool in = i < cnt;
+      M3_TICK(1);
+      const float* xs = XS; const float* ys = YS;
+      int xst = M3_CP;                        // x of input k, point i of the chunk: xs[k * xst + i]
+      if (NP > 0) {                           // (uniform) the data set lives in LDS: points beyond the chunk are other points / zeros,
+        xs = XALL + c0; ys = YALL + c0; xst = NP;        // finite either way, and their residuals are masked below
+      } else {
+        for (int i = tid; i < M3_CP; i += M3_NT) {
+          const bool in = i < cnt;
 #pragma unroll
-        for (int k = 0; k < M3_NIN; ++k) XS[k * M3_CP + i] = (in && k < n_in) ? a.X[(size_t)(c0 + i) * n_in + k] : 0.0f;
-        YS[i] = in ? a.Y[c0 + i] : 0.0f;
+          for (int k = 0; k < M3_NIN; ++k) XS[k * M3_CP + i] = (in && k < n_in) ? a.X[(size_t)(c0 + i) * n_in + k] : 0.0f;
+          YS[i] = in ? a.Y[c0 + i] : 0.0f;
+        }
+        __syncthreads();
       }
-      __syncthreads();
+      M3_TICK(2);
       // ---- layer 1 (element-wise): a1[p][j] for this lane's unit j = u and 4 consecutive points per tile, stored both ways
 #pragma unroll
       for (int tp = 0; tp < 7; ++tp) {
@@ -220,7 +316,7 @@ struct M3Chain {
 #pragma unroll
         for (int k = 0; k < M3_NIN; ++k)
           if (k < n_in) {
-            const V4f x4 = *reinterpret_cast<const V4f*>(XS + k * M3_CP + 16 * tp + 4 * g);
+            const V4f x4 = *reinterpret_cast<const V4f*>(xs + k * xst + 16 * tp + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[r] = fmaf(q.w1[k], x4[r], z[r]);
           }
@@ -232,7 +328,9 @@ struct M3Chain {
           for (int r = 0; r < 4; ++r) A1[(size_t)(16 * tp + 4 * g + r) * M3_LDJ + u] = z[r];
         }
       }
+      M3_TICK(3);
       __syncthreads();
+      M3_TICK(4);
       // ---- forward: Z[tp] (C layout: register r = point 16 tp + 4 g + r, unit u), bias in the accumulator
       V4f Z[7];
 #pragma unroll
@@ -258,9 +356,10 @@ struct M3Chain {
               Z[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[(size_t)(16 * tp + c) * M3_LDJ + 96 + 4 * t + g], q.w2[6][t], Z[tp], 0, 0, 0);
           }
       }
+      M3_TICK(5);
       // activations and this tile's share of f(x_p) = sum_u w3_u a2[p][u]: reduce-scatter over the quad, rotations by 4 and 8
       {
-        float* fw = (c < 4) ? fpart + (size_t)w * M3_CP + 4 * g + c : dump + (tid & 63);
+        float* fw = fpart + (size_t)w * M3_CP + 4 * g + (c & 3);
 #pragma unroll
         for (int tp = 0; tp < 7; ++tp) {
           float fp[4];
@@ -271,16 +370,18 @@ struct M3Chain {
           float sq = (bit1 ? s23 : s01) + m3_dpp<0x4E>(bit1 ? s01 : s23);
           sq += m3_dpp<0x124>(sq);
           sq += m3_dpp<0x128>(sq);
-          fw[16 * tp] = sq;
+          if (c < 4) fw[16 * tp] = sq;
         }
       }
+      M3_TICK(6);
       __syncthreads();                        // every wave is past its forward product: A1 is free
+      M3_TICK(7);
       // once per point: delta_p = -tau_out r_p (grad) or r_p, r_p = b3 + sum over the unit tiles - y_p; 0 beyond the chunk
       for (int i = tid; i < M3_CP; i += M3_NT) {
         float f = q.b3;
 #pragma unroll
         for (int tt = 0; tt < M3_NW; ++tt) f += fpart[tt * M3_CP + i];
-        const float r = f - YS[i];
+        const float r = f - ys[i];
         rbuf[i] = (i < cnt) ? (grad ? -a.tau_out * r : r) : 0.0f;
         if (!grad && i < cnt) sse = fmaf(r, r, sse);
       }
@@ -293,7 +394,9 @@ struct M3Chain {
 #pragma unroll
         for (int t = 0; t < 2; ++t) srow[96 + 4 * t + g] = q.w2[6][t];
       }
+      M3_TICK(8);
       __syncthreads();
+      M3_TICK(9);
       // ---- delta2 (in the forward accumulator's registers), the thin last layer's gradient, delta2 -> LDS for delta1
 #pragma unroll
       for (int tp = 0; tp < 7; ++tp) {
@@ -309,6 +412,7 @@ struct M3Chain {
           if (u < M3_LDJ) D2[(size_t)(16 * tp + 4 * g + r) * M3_LDJ + u] = d;
         }
       }
+      M3_TICK(10);
       // ---- dW2^T[j][u] += sum_p A1T[j][p] delta2[p][u]: the accumulators come out in the theta register layout
       {
         // rows of the last tile follow the remainder block's register order: row 4 g' + r' <-> j = 96 + 4 r' + g'
@@ -328,7 +432,9 @@ struct M3Chain {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      M3_TICK(11);
       __syncthreads();                        // delta2 of every unit tile is in LDS
+      M3_TICK(12);
       // ---- delta1[p][j = u] = sum_u' delta2[p][u'] W2[u'][j]  (before the activation derivative); the B operand streams from
       //      the staging copy, one block of 4 registers at a time (column reads, 4 per 28 matrix instructions)
       V4f E[7];
@@ -361,6 +467,7 @@ struct M3Chain {
               E[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(D2[(size_t)(16 * tp + c) * M3_LDJ + 96 + 4 * t + g], bf, E[tp], 0, 0, 0);
           }
       }
+      M3_TICK(13);
       // the thin first layer's gradient: db1[j] = sum_p delta1, dW1[j][k] = sum_p delta1 x[p][k]
 #pragma unroll
       for (int tp = 0; tp < 7; ++tp) {
@@ -374,14 +481,30 @@ struct M3Chain {
 #pragma unroll
         for (int k = 0; k < M3_NIN; ++k)
           if (k < n_in) {
-            const V4f x4 = *reinterpret_cast<const V4f*>(XS + k * M3_CP + 16 * tp + 4 * g);
+            const V4f x4 = *reinterpret_cast<const V4f*>(xs + k * xst + 16 * tp + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) gw1[k] = fmaf(d1[r], x4[r], gw1[k]);
           }
       }
     }
+    M3_TICK(14);
     float ret = 0;
     if (grad) {
+      // the momentum's W2 share comes back from the workspace: seven independent 16-byte loads, ONE round trip to the L2
+      // (prefetching them under GEMM2 was tried: the register allocator answers by spilling the prefetched values at once)
+      const int pwl = pw_lane();
+#pragma unroll
+      for (int s = 0; s < 7; ++s) pv[s] = pw[s * M3_NT + pwl];
+      // W2 comes back from its staging copy (same rows, same columns as the registers it was written from): between the
+      // staging write and here - delta2, GEMM3, GEMM2: the registers' busiest stretch - theta's 28 W2 registers are free
+      {
+        const float* srow = A1 + (size_t)u * M3_LDJ;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) q.w2[s] = *reinterpret_cast<const V4f*>(srow + 16 * s + 4 * g);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) q.w2[6][t] = srow[96 + 4 * t + g];
+        q.w2[6][2] = 0.0f; q.w2[6][3] = 0.0f;
+      }
       const float ips = 1.0f / a.prior_scale;
       const float t0 = ips * a.tau[0], t1 = ips * a.tau[1], t2 = ips * a.tau[2], t3 = ips * a.tau[3], t4 = ips * a.tau[4], t5 = ips * a.tau[5];
       auto kick = [&](float& pv, float gg) { pv = fmaf(k1, gg, pv); pv = fmaf(k2, gg, pv); };
@@ -389,9 +512,9 @@ struct M3Chain {
       for (int s = 0; s < 7; ++s)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          float pv = pm.w2[s][t];
-          kick(pv, ok(s, t) ? fmaf(-t2, q.w2[s][t], G[s][t]) : 0.0f);
-          pm.w2[s][t] = pv;
+          float v = pv[s][t];
+          kick(v, ok(s, t) ? fmaf(-t2, q.w2[s][t], G[s][t]) : 0.0f);
+          pv[s][t] = v;
         }
 #pragma unroll
       for (int k = 0; k < M3_NIN; ++k) { const float v = m3_groups_sum(gw1[k]); kick(pm.w1[k], (jval && k < n_in) ? fmaf(-t0, q.w1[k], v) : 0.0f); }
@@ -400,9 +523,35 @@ struct M3Chain {
       kick(pm.b2, uval ? fmaf(-t3, q.b2, vb2) : 0.0f);
       kick(pm.w3, uval ? fmaf(-t4, q.w3, vw3) : 0.0f);
       kick(pm.b3, fmaf(-t5, q.b3, m3_groups_sum(gb3)));          // every lane group saw every point once: all lanes hold the same sum
+      // the drift that follows this kick (q += dr M^-1 p), while the momentum is in registers; then the W2 share goes back
+      if (dr != 0.0f) {
+        if (a.mass_kind == HTA_MASS_DIAG) {
+          M3State im;
+          m3_load_inline(lay, a.inv_mass, vecd, im);
+#pragma unroll
+          for (int s = 0; s < 7; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) q.w2[s][t] = fmaf(dr * im.w2[s][t], pv[s][t], q.w2[s][t]);
+#pragma unroll
+          for (int k = 0; k < M3_NIN; ++k) q.w1[k] = fmaf(dr * im.w1[k], pm.w1[k], q.w1[k]);
+          q.b1 = fmaf(dr * im.b1, pm.b1, q.b1); q.b2 = fmaf(dr * im.b2, pm.b2, q.b2);
+          q.w3 = fmaf(dr * im.w3, pm.w3, q.w3); q.b3 = fmaf(dr * im.b3, pm.b3, q.b3);
+        } else {
+#pragma unroll
+          for (int s = 0; s < 7; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) q.w2[s][t] = fmaf(dr, pv[s][t], q.w2[s][t]);
+#pragma unroll
+          for (int k = 0; k < M3_NIN; ++k) q.w1[k] = fmaf(dr, pm.w1[k], q.w1[k]);
+          q.b1 = fmaf(dr, pm.b1, q.b1); q.b2 = fmaf(dr, pm.b2, q.b2); q.w3 = fmaf(dr, pm.w3, q.w3); q.b3 = fmaf(dr, pm.b3, q.b3);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 7; ++s) pw[s * M3_NT + pwl] = pv[s];
     } else {
       ret = block_sum(sse);
     }
+    M3_TICK(15);
     return ret;
   }
 
@@ -416,7 +565,10 @@ struct M3Chain {
     for (int i = 0; i < 6; ++i) cst += n[i] * (0.5f * logf(a.tau[i]) - hl2p);
     return -0.5f * qq + cst;
   }
-  __device__ __forceinline__ float kinetic(const M3State& p) {
+  // 1/2 p^T M^-1 p; the momentum's W2 share comes from the workspace
+  __device__ __forceinline__ float kinetic(const M3State& psmall) {
+    M3State p = psmall;
+    unpark(p);
     if (a.mass_kind == HTA_MASS_DIAG) {
       M3State im;
       load(a.inv_mass, im, vecd);
@@ -440,26 +592,10 @@ struct M3Chain {
     for (int k = 0; k < M3_NIN; ++k) y.w1[k] = fmaf(cc, x.w1[k], y.w1[k]);
     y.b1 = fmaf(cc, x.b1, y.b1); y.b2 = fmaf(cc, x.b2, y.b2); y.w3 = fmaf(cc, x.w3, y.w3); y.b3 = fmaf(cc, x.b3, y.b3);
   }
-  __device__ __forceinline__ void drift(M3State& q, float cc, const M3State& p) {              // q += c M^-1 p
-    if (a.mass_kind == HTA_MASS_DIAG) {
-      M3State im;
-      load(a.inv_mass, im, vecd);
-#pragma unroll
-      for (int s = 0; s < 7; ++s)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) q.w2[s][t] = fmaf(cc * im.w2[s][t], p.w2[s][t], q.w2[s][t]);
-#pragma unroll
-      for (int k = 0; k < M3_NIN; ++k) q.w1[k] = fmaf(cc * im.w1[k], p.w1[k], q.w1[k]);
-      q.b1 = fmaf(cc * im.b1, p.b1, q.b1); q.b2 = fmaf(cc * im.b2, p.b2, q.b2);
-      q.w3 = fmaf(cc * im.w3, p.w3, q.w3); q.b3 = fmaf(cc * im.b3, p.b3, q.b3);
-    } else {
-      axpy(q, cc, p);
-    }
-  }
 };
 
 template <int ACT>
-__global__ __launch_bounds__(M3_NT) void mlp3_mfma_kernel(NetArgs<float> a) {
+__global__ __launch_bounds__(M3_NT) void mlp3_mfma_kernel(NetArgs<float> a, int NP, float* pws) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   typedef M3Chain<ACT> Ch;
   Ch ch(a);
@@ -476,6 +612,8 @@ __global__ __launch_bounds__(M3_NT) void mlp3_mfma_kernel(NetArgs<float> a) {
   ch.jval = 16 * ch.w + ch.c < H1;
   ch.uval = 16 * ch.w + ch.c < H2;
   ch.vecd = (H1 % 4 == 0) && (ch.o_w2 % 4 == 0);        // a row of W2 starts on a multiple of four ELEMENTS of the flat vector
+  ch.lay = M3Lay{ch.w, ch.g, ch.c, n_in, H1, H2, ch.rq1, ch.o_w1, ch.o_b1, ch.o_w2, ch.o_b2, ch.o_w3, ch.o_b3, ch.jval, ch.uval, ch.vecd};
+  ch.pw = reinterpret_cast<V4f*>(pws) + (size_t)blockIdx.x * 7 * M3_NT;
   float* base = reinterpret_cast<float*>(smem_raw);
   ch.A1 = base;
   ch.D2 = ch.A1 + (size_t)M3_CP * M3_LDJ;
@@ -485,10 +623,18 @@ __global__ __launch_bounds__(M3_NT) void mlp3_mfma_kernel(NetArgs<float> a) {
   ch.fpart = ch.YS + M3_CP;
   ch.rbuf = ch.fpart + M3_NW * M3_CP;
   ch.red = ch.rbuf + M3_CP;
-  ch.dump = ch.red + 16 + (size_t)ch.w * (64 + M3_CP);
-  int* perm = reinterpret_cast<int*>(ch.red + 16 + (size_t)M3_NW * (64 + M3_CP));
+  int* perm = reinterpret_cast<int*>(ch.red + 16);
+  float* xall = ch.red + 16 + 64;
+  ch.NP = NP; ch.XALL = xall; ch.YALL = xall + (size_t)n_in * NP;
+  if (NP > 0) {                            // the data set, once per workgroup: [k][NP] inputs and [NP] targets, zeros beyond N
+    for (int i = tid; i < NP; i += M3_NT) {
+      const bool in = i < a.N;
+      for (int k = 0; k < n_in; ++k) xall[(size_t)k * NP + i] = in ? a.X[(size_t)i * n_in + k] : 0.0f;
+      xall[(size_t)n_in * NP + i] = in ? a.Y[i] : 0.0f;
+    }
+  }
 
-  enum { EV_GRAD, EV_LOGP, LOGP_INIT, GRAD, LOGP_END, LOGP_RESET };
+  enum { EV_GRAD, EV_LOGP, LOGP_INIT, LOGP_END, LOGP_RESET };
   const float eps = a.eps, heps = 0.5f * a.eps;
   const int M = a.M;
   const int nstage = split_stage_count(a.integ, M, a.L);
@@ -503,42 +649,36 @@ __global__ __launch_bounds__(M3_NT) void mlp3_mfma_kernel(NetArgs<float> a) {
     M3State q, p;
     ch.load(cur_row, q, vrow);
     Ch::zero(p);
+    ch.park(p);
     __syncthreads();
+#if M3_TIMING
+    unsigned long long tacc_store[20] = {0};
+    ch.tacc = tacc_store;
+    tacc_store[19] = __builtin_readcyclecounter();
+#endif
 
-    // One call site of the likelihood pass, driven by a state machine: evaluation-only (gradient, then value, of one split
-    // closure: the parity tests), or per trajectory nstage gradient passes (S:499-596 / S:281-302) and a full-data log p pass
-    // (S:995), plus one more after a Q2 reset (S:1018).
+    // TWO call sites of the likelihood pass.  The rare one, driven by a small state machine: evaluation-only (gradient, then
+    // value, of one split closure: the parity tests), the full-data log p of a trajectory's start / end point (S:971, S:995)
+    // and of params_init after a Q2 reset (S:1018).  The hot one: the stage loop of a trajectory (S:499-596 / S:281-302), whose
+    // live state is (q, p) and nothing else.
     int mode = a.n_traj == 0 ? EV_GRAD : LOGP_INIT;
-    int tr = 0, st = 0, n = a.traj_offset;
+    int tr = 0, n = a.traj_offset;
     float lp_cur = 0, h_old = 0, h_new = 0;
     bool acc = false;
     int32_t rejected = 0;
     for (bool done = false; !done;) {
-      int lo = 0, hi = M * a.Nb;
-      float k1 = 0, k2 = 0, dr = 0;
-      bool grad = false;
-      if (mode == EV_GRAD || mode == EV_LOGP) {
-        lo = a.eval_split * a.Nb; hi = lo + a.Nb;
-        grad = mode == EV_GRAD; k1 = 1.0f;
-      } else if (mode == GRAD) {
-        int m;
-        split_stage<float>(a.integ, M, a.L, st, eps, perm, m, k1, dr);
-        lo = m * a.Nb; hi = lo + a.Nb;
-        grad = true;
-        k2 = (plain && st == nstage - 1) ? -heps : 0.0f;    // plain leapfrog: a full kick at the last step, half of it taken back (S:298, S:302)
-      }
-      const float sse = ch.pass(q, lo, hi, p, k1, k2, grad);
+      const bool ev = mode == EV_GRAD || mode == EV_LOGP;
+      const int lo = ev ? a.eval_split * a.Nb : 0, hi = ev ? lo + a.Nb : M * a.Nb;
+      const float sse = ch.pass(q, lo, hi, p, 1.0f, 0.0f, 0.0f, mode == EV_GRAD);
       bool finish = false, begin = false;
       if (mode == EV_GRAD) {
+        ch.unpark(p);                                                        // (the gradient: 0 + 1 * gg, W2 share in the workspace)
         if (a.grad_out) ch.store(a.grad_out + cidx * D, p, vrow);
         mode = EV_LOGP;
       } else if (mode == EV_LOGP) {
         const float lp = -0.5f * a.tau_out * sse + ch.log_prior(q) / a.prior_scale;
         if (a.logp_out && tid == 0) a.logp_out[cidx] = lp;
         done = true;
-      } else if (mode == GRAD) {
-        if (dr != 0.0f) ch.drift(q, dr, p);
-        if (++st == nstage) mode = LOGP_END;
       } else {
         // sum_m log p_m(theta) = full-data log-likelihood + (M / prior_scale) * prior   (S:787-796)
         const float lp = -0.5f * a.tau_out * sse + ((float)M / a.prior_scale) * ch.log_prior(q);
@@ -576,36 +716,51 @@ __global__ __launch_bounds__(M3_NT) void mlp3_mfma_kernel(NetArgs<float> a) {
       }
       if (begin) {
         n = a.traj_offset + tr;
-        // ---- gibbs (S:185-186 / S:200-201): p = sqrt(M) z; the Philox element index is the flat parameter index
-        ch.draw(chain, (uint32_t)n, p);
-        if (a.mass_kind == HTA_MASS_DIAG) {
-          M3State mf;
-          ch.load(a.mass_factor, mf, ch.vecd);
-#pragma unroll
-          for (int s = 0; s < 7; ++s)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) p.w2[s][t] *= mf.w2[s][t];
-#pragma unroll
-          for (int k = 0; k < M3_NIN; ++k) p.w1[k] *= mf.w1[k];
-          p.b1 *= mf.b1; p.b2 *= mf.b2; p.w3 *= mf.w3; p.b3 *= mf.b3;
-        }
+        ch.draw(chain, (uint32_t)n, p);                                      // gibbs (S:185-186 / S:200-201)
         h_old = -lp_cur + ch.kinetic(p);                                     // S:971
         if (a.integ == HTA_SPLIT_RAND) {                                     // S:549: one subset order per trajectory
           __syncthreads();
           if (tid == 0) split_permutation(a.seed, (uint32_t)n, M, perm);
           __syncthreads();
         }
-        st = 0;
-        mode = nstage > 0 ? GRAD : LOGP_END;
+#if M3_TIMING
+        { const unsigned long long now_ = __builtin_readcyclecounter(); ch.tacc[16] += now_ - ch.tacc[19]; ch.tacc[19] = now_; }
+#endif
+        {
+          // ---- the stage loop (S:499-596 / S:281-302) on LOCAL copies of the state: q and p are live across the out-of-line
+          // calls of the state machine, which makes the register allocator give parts of them a home in scratch memory and
+          // touch it in every pass; the copies' live ranges cross no call
+          M3State ql = q, pl = p;
+          for (int st = 0; st < nstage; ++st) {
+            int m; float kick, dr;
+            split_stage<float>(a.integ, M, a.L, st, eps, perm, m, kick, dr);
+            // plain leapfrog: a full kick at the last step, half of it taken back (S:298, S:302); the drift runs inside the pass
+            ch.pass(ql, m * a.Nb, m * a.Nb + a.Nb, pl, kick, (plain && st == nstage - 1) ? -heps : 0.0f, dr, true);
+#if M3_TIMING
+            { const unsigned long long now_ = __builtin_readcyclecounter(); ch.tacc[17] += now_ - ch.tacc[19]; ch.tacc[19] = now_; }
+#endif
+          }
+          q = ql; p = pl;
+        }
+        mode = LOGP_END;
       }
     }
     if (tid == 0 && a.reject_count && a.n_traj > 0) a.reject_count[cidx] += rejected;
+#if M3_TIMING
+    if (tid == 0 && blockIdx.x == 0) for (int k = 0; k < 20; ++k) hta_m3_dbg[k] = tacc_store[k];
+#endif
   }
 }
 
-static size_t mlp3_lds_bytes() {
-  return ((size_t)2 * M3_CP * M3_LDJ + (size_t)M3_CP * M3_LDP + M3_NIN * M3_CP + M3_CP + M3_NW * M3_CP + M3_CP + 16 +
-          (size_t)M3_NW * (64 + M3_CP) + 64) * sizeof(float);
+static size_t mlp3_lds_floats() {          // without the data set
+  return (size_t)2 * M3_CP * M3_LDJ + (size_t)M3_CP * M3_LDP + M3_NIN * M3_CP + M3_CP + M3_NW * M3_CP + M3_CP + 16 + 64;
+}
+// padded length of the LDS copy of the data set, or 0 when it does not fit (or the 16-byte reads of a chunk would be
+// misaligned: every chunk starts at m Nb + 112 i): then every pass stages its chunk from global memory
+static int mlp3_data_np(const NetArgs<float>& a) {
+  const int NP = (a.N + 3) / 4 * 4 + M3_CP;
+  if (a.Nb % 4 != 0) return 0;
+  return (mlp3_lds_floats() + (size_t)(a.dims[0] + 1) * NP) * sizeof(float) <= 160 * 1024 ? NP : 0;
 }
 
 bool mlp3_eligible(const NetArgs<float>& a) {
@@ -618,18 +773,47 @@ bool mlp3_eligible(const NetArgs<float>& a) {
   return a.dims[1] > NETN_MAX_WIDTH || a.dims[2] > NETN_MAX_WIDTH || D > 64 * NETN_KMAX || g_mlp3_route == 2;
 }
 
+// The momentum workspace (see M3Chain::pw): one slot of 7 x 448 float4 per workgroup, cached per (device, stream) - launches
+// on one stream are ordered, launches on different streams get different buffers - grown on demand, never freed (a handful
+// of entries of a few MB: like the side stream of the RMHMC path, a resource created on first use).
+static float* mlp3_workspace(hipStream_t s, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, std::pair<void*, size_t>> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  auto& e = cache[{dev, s}];
+  if (e.second < bytes) {
+    if (e.first) { (void)hipStreamSynchronize(s); (void)hipFree(e.first); e.first = nullptr; e.second = 0; }
+    if (hipMalloc(&e.first, bytes) != hipSuccess) { e.first = nullptr; return nullptr; }
+    e.second = bytes;
+  }
+  return static_cast<float*>(e.first);
+}
+
 template <int ACT> static int launch_mlp3(const NetArgs<float>& a, hipStream_t s) {
   static DevOnce done;
-  const size_t lds = mlp3_lds_bytes();
+  const int NP = mlp3_data_np(a);
+  const size_t lds = (mlp3_lds_floats() + (size_t)(a.dims[0] + 1) * NP) * sizeof(float);
   if (!done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp3_mfma_kernel<ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { set_error("hta_netn_hmc (mlp3): hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
     done = true;
   }
-  const int grid = (int)(a.C < 8192 ? a.C : 8192);
+  int cus = 256;
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  }
+  // one workgroup per CU is resident (151 KB of LDS); twice that many in the grid keeps the tail short, each workgroup walks
+  // its chains in a grid-stride loop
+  const int64_t gmax = 2 * (int64_t)cus;
+  const int grid = (int)(a.C < gmax ? a.C : gmax);
+  float* pws = mlp3_workspace(s, (size_t)grid * 7 * M3_NT * 4 * sizeof(float));
+  if (!pws) { set_error("hta_netn_hmc (mlp3): no memory for the momentum workspace (%d workgroups)", grid); return HTA_ERR_LAUNCH; }
   profile_begin(s);
   note_route("mlp3_mfma_kernel<%d>", ACT);
-  mlp3_mfma_kernel<ACT><<<grid, M3_NT, lds, s>>>(a);
+  mlp3_mfma_kernel<ACT><<<grid, M3_NT, lds, s>>>(a, NP, pws);
   profile_end(s);
   HTA_CHECK_LAUNCH("hta_netn_hmc (mlp3)");
   return HTA_OK;

@@ -202,6 +202,43 @@ def test_bench_gpus_flag_launches_the_ranks_itself(ht):
     assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)
 
 
+def _free_port():
+    import socket
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+    so.close()
+    return port
+
+
+@pytest.mark.parametrize("extra", [[], ["--workload", "cfg5", "--traj", "4"]])
+def test_drivers_eight_rank_command_line_prints_the_compact_line(ht, extra):
+    """The exact launcher line of the driver's scaling run - `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 --steps K --warmup W` - for the default workload (cfg2 weak
+    scaling) and for `--workload cfg5` (cfg3 sharded, with the gather): eight ranks share this box's one GPU over gloo
+    (HTA_BENCH_BACKEND; RCCL needs eight devices), so that the first real 8-GPU run cannot fail on plumbing.  The LAST stdout
+    line must be the < 4 KB record with n_gpus / ranks_seen / rank_devices / collective_backend / gather_ms."""
+    env = dict(os.environ, HTA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last.encode()) < 4096 and last.startswith("{")
+    j = json.loads(last)
+    assert j["n_gpus"] == 8 and j["ranks_seen"] == 8 and len(j["rank_devices"]) == 8
+    assert sorted(rd[0] for rd in j["rank_devices"]) == list(range(8))
+    assert j["collective_backend"] == "gloo" and j["launcher"] == "torch.distributed.run"        # "rccl" on the driver's node
+    assert j["scaling"] == "weak" and j["config"]["chains_total"] == 8 * j["config"]["chains_per_gpu"] == 8192
+    assert j["value"] > 0 and "roofline" in j and j["roofline"]["kernel"]
+    if extra:
+        assert j["gather_ms"] > 0 and j["config"]["workload"] == "cfg5"
+    else:
+        assert j["config"]["workload"] == "cfg2" and "gather_ms" not in j
+
+
 _SHARD_WORKER = r'''
 import os, sys, json
 import numpy as np, torch, torch.distributed as dist
