@@ -617,6 +617,10 @@ def result_of(w, W, dt, call_ms, prof_ms, prof_n, steps, warmup, world):
     roof["physical"] = phys
     if phys is not None and phys.get("trajectories_per_step") == w.T:      # bytes per step only at the shape they were counted at
         roof["traffic"] = phys.get("hbm_bytes_per_step")
+    if phys is not None and roof.get("unit") == "TFLOP/s" and phys.get("mfma_tflops_issued"):
+        # matrix-instruction flops ISSUED (PMC) over the useful flops of the roofline: > 1 = padding rows / idle columns of the
+        # instruction (cfg3 at 256 chains: one chain per workgroup fills two of the four columns of v_mfma_f32_4x4x1_16b)
+        roof["mfma_issued_over_useful"] = phys["mfma_tflops_issued"] / max(roof["achieved"], 1e-9)
     from hamiltorch_amd.ess import ess_min
     ess = ess_min(w.samples[1:]) if w.T >= 8 else float("nan")
     return {"key": W.key + ("-eig" if getattr(w, "jacobi", False) else ""), "workload": W.name, "value": units / dt,
@@ -738,6 +742,8 @@ def compact_line(full, detail_path="bench_detail.json"):
              "ms_per_step": _r(r.get("ms_per_step")), "steps": r.get("steps"), "frac": roof["frac"], "bound": roof["bound"],
              "achieved": roof["achieved"], "unit": roof["unit"], "mfma_busy": roof["mfma_busy"], "traffic": roof["traffic"],
              "kernel": roof["kernel"][:40], "kernel_ms": roof["kernel_ms"], "cpu": {"value": _r(cb.get("value"), 4), "cores": cb.get("cores")}}
+        if roof.get("mfma_issued_over_useful") is not None:
+            e["issued_over_useful"] = roof["mfma_issued_over_useful"]
         if r.get("published"):
             e["samples_per_s"] = _r(r.get("samples_per_s"), 4)
             e["published"] = {"samples_per_s": r["published"].get("samples_per_s"), "hw": str(r["published"].get("hw", ""))[:24]}

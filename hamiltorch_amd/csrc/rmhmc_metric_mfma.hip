@@ -470,6 +470,17 @@ __device__ __attribute__((noinline)) float ph_mv8_lower(int offM, int ld, int of
   return mv8_lower(lds + HTA_U(offM), HTA_U(ld), lds + HTA_U(offV), HTA_U(n));
 }
 
+// The thread index, opaque to the optimiser.  Per-lane global addresses (a.m + b D + i, a.upd_x + b D + row, ...) derived from
+// the plain index were computed at the top of the kernel and kept across its 30 out-of-line phase calls - i.e. spilled to
+// scratch memory at the 128-register cap of a 1024-thread workgroup (14 stores at the top, 13 reloads scattered over the
+// phases, each a round trip beyond the L2: profiles/r02zz WRITE_SIZE 20.7 MB per launch against 0.2 MB of outputs).
+// Deriving them from an opaque copy at the point of use keeps them out of the calls' live ranges.
+__device__ __forceinline__ int opaque_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
 __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float> a, int DP, int LD) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = a.D, tid = threadIdx.x;
@@ -497,7 +508,7 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
     HTA_STAMP(0);
     // ---- 0. operands: jitter, the solve vector, d = X - mu; V0 into LDS
     if (tid < DP) {
-      const int i = tid;
+      const int i = opaque_tid();
       vjit[i] = (i < D && a.has_jitter) ? (float)a.jitter * uniform_elem<float>(a.seed, chain, a.draw, PURPOSE_JITTER, a.sub, i) : 0.f;
       vm[i] = (i < D && a.m) ? a.m[b * D + i] : 0.f;
       vd[i] = (i < D && a.X) ? a.X[b * D + i] - a.mu[i] : 0.f;
@@ -519,7 +530,7 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
     if (softabs) {
       lds_gemm<true, false, true, true>(oB1, oB1, oB0, -1, oJit, nt, k4, LD);
       __syncthreads();
-      if (tid < D) lds0[oB0 + tid * LD + tid] += a.lam0[tid];
+      { const int i = opaque_tid(); if (i < D) lds0[oB0 + i * LD + i] += a.lam0[i]; }
     }
     __syncthreads();
     HTA_STAMP(3);
@@ -584,7 +595,7 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
     if (softabs) {
       float ld = 0.f;
       if (tid < DP) {
-        const int i = tid;
+        const int i = opaque_tid();
         float lt = 1.f;
         if (i < D) {
           const float lam = vlam[i];
@@ -599,7 +610,7 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
       // ---- 4. x = V0 X (X^T m' / lam~)
       if (a.m) {
         const float y = ph_mv8(1, bx, LD, oM, D);
-        const int row = tid >> 3;
+        const int row = opaque_tid() >> 3;
         float qd = 0.f;
         if ((tid & 7) == 0 && row < DP) {
           const float w = (row < D) ? y / vlt[row] : 0.f;
@@ -613,9 +624,10 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
         ph_stage(a.V0, by, D, DP, LD);                          // (the E buffer is dead)
         __syncthreads();
         const float x = ph_mv8(0, by, LD, oX, D);
-        if ((tid & 7) == 0 && row < D) {
-          if (a.x_out) a.x_out[b * D + row] = x;
-          if (a.upd_x) a.upd_x[b * D + row] += (float)a.cx * x;
+        const int orow = opaque_tid() >> 3;
+        if ((tid & 7) == 0 && orow < D) {
+          if (a.x_out) a.x_out[b * D + orow] = x;
+          if (a.upd_x) a.upd_x[b * D + orow] += (float)a.cx * x;
         }
       }
     }
@@ -667,7 +679,8 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
           if (tid < DP) vd[tid] = (tid < D) ? normal_elem<float>(a.seed, chain, a.draw, 0, tid) : 0.f;
           __syncthreads();
           const float p = ph_mv8_lower(g, LD, oD, D);
-          if ((tid & 7) == 0 && (tid >> 3) < D) a.p_out[b * D + (tid >> 3)] = p;
+          const int prow = opaque_tid() >> 3;
+          if ((tid & 7) == 0 && prow < D) a.p_out[b * D + prow] = p;
         }
       }
     }
