@@ -3,7 +3,7 @@
 # kernel-stat summaries.  One workload per block; per workload: --kernel-trace --stats, then three SEPARATE --pmc passes
 # (kernel-trace only beside them).  Run on the GPU box (gpurun); writes gpurun_out/<tag>_*.
 export TMPDIR=/tmp
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/${R}_phys
 mkdir -p $O
 t0=$(date +%s)
@@ -24,7 +24,9 @@ one cfg3@1024 3 1 100 X=1 --workload cfg3@1024
 one cfg3@256 2 1 400 X=1 --workload cfg3
 one cfg3jacobi@256 1 1 20 HTA_RMHMC_FUSED=0 --workload cfg3 --traj 20
 one cfg4@512 5 1 20 X=1 --workload cfg4
-python tools/physical.py cfg2@1024=$O/cfg2@1024 cfg3@1024=$O/cfg3@1024 cfg3@256=$O/cfg3@256 cfg3jacobi@256=$O/cfg3jacobi@256 cfg4@512=$O/cfg4@512 > gpurun_out/${R}_physical.json
+one nbmlp@1024 2 1 1 X=1 --workload nbmlp
+one nbmlp-full@1024 2 1 1 X=1 --workload nbmlp-full
+python tools/physical.py cfg2@1024=$O/cfg2@1024 cfg3@1024=$O/cfg3@1024 cfg3@256=$O/cfg3@256 cfg3jacobi@256=$O/cfg3jacobi@256 cfg4@512=$O/cfg4@512 nbmlp@1024=$O/nbmlp@1024 nbmlp-full@1024=$O/nbmlp-full@1024 > gpurun_out/${R}_physical.json
 python tools/pmc_summarize.py $(find $O -name "*counter_collection.csv" | sort) > gpurun_out/${R}_pmc_all.txt
 # keep the merge small: raw traces stay on the box
 find $O -name "*.csv" -size +2M -delete
