@@ -61,8 +61,14 @@ def test_spill_budget_of_the_hot_kernels(kernels):
         assert kernels[k]["scratch"] <= 256 and kernels[k]["spill"] <= 64, (k, kernels[k])
     # the matrix-core metric kernel: its GEMM / Cholesky / element-wise phases are separate functions without scratch; the
     # kernel body (calls only) parks a few values around the calls
+    # (round 3: per-lane addresses are derived from an opaque index at the point of use - vgpr_spill 20 -> 1, scratch 112 -> 32)
     for k in _find(kernels, "metric_warm_mfma_kernel"):
-        assert kernels[k]["spill"] <= 32 and kernels[k]["scratch"] <= 160, (k, kernels[k])
+        assert kernels[k]["spill"] <= 4 and kernels[k]["scratch"] <= 48, (k, kernels[k])
+    # the notebook-model kernel (round 3): its loads / stores / momentum draws run out of line and the momentum's W2 share lives
+    # in a workspace, so the code object's scratch is a stack for those calls (three 160-byte state vectors and change), not a
+    # home for the gradient pass's values: < 1 KB per lane (the first version: 2.4 KB and six serial reloads in every kick)
+    for k in _find(kernels, "mlp3_mfma_kernel"):
+        assert kernels[k]["scratch"] <= 1024 and kernels[k]["vgpr"] <= 256, (k, kernels[k])
 
 
 def test_register_budgets_behind_the_occupancy_claims(kernels):
@@ -102,3 +108,18 @@ def test_cfg4_kernel_keeps_its_scratch_traffic_off_the_matrix_blocks():
     assert sum(v["mfma"] for v in hot) >= 100
     assert all(v["scratch"] == 0 for v in hot), [v for v in hot if v["scratch"]]
     assert sum(v["scratch"] for v in res.values()) <= 200
+
+
+def test_notebook_model_kernel_keeps_scratch_off_its_matrix_blocks():
+    """csrc/mlp3_mfma.hip: the basic blocks that hold the 560 matrix instructions of a gradient pass (twice: the stage loop's call
+    site and the log-p / evaluation one) touch scratch at most a handful of times; what the allocator spills sits in the
+    per-trajectory code (tools/scratch_in_loops.py; one assembly-only compile)."""
+    import sys
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("needs hipcc")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scratch_in_loops as SL
+    res = SL.blocks(os.path.join(ROOT, "hamiltorch_amd", "csrc", "mlp3_mfma.hip"), "mlp3_mfma_kernelILi0E", [])
+    hot = [v for v in res.values() if v["mfma"]]
+    assert sum(v["mfma"] for v in hot) == 2 * 560
+    assert sum(v["scratch"] for v in hot) <= 8, [v for v in hot if v["scratch"]]
