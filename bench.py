@@ -256,6 +256,7 @@ class Cfg3:
         self.rej = torch.zeros(self.C, dtype=torch.int32, device=dev)
         self.ws = torch.empty(_abi.rmhmc_workspace_bytes(self.C, self.D, 4, self.T), dtype=torch.uint8, device=dev)
         self.jacobi = jacobi or os.environ.get("HTA_RMHMC_FUSED", "1") == "0"
+        self._prepared = False
         if self.jacobi:      # the general route: an eigendecomposition per metric evaluation (what SURVEY 8d's flop count describes)
             self.name = self.name + " [eigendecomposition route forced: hta_set_tuning('rmhmc_fused', 0)]"
 
@@ -288,6 +289,10 @@ class Cfg3:
         if self.jacobi:
             self.abi.set_tuning("rmhmc_fused", 0)
         try:
+            if not self._prepared:      # once per target, as hamiltorch_amd.sample() does (rmhmc._prepared_workspace): the cold
+                self._prepared = True   # eigendecomposition of P, the fused route's plan, the shared inverse - not per call
+                self.abi.rmhmc_gaussian_prepare(self.cur, self.tgt.precision, self.tgt.mean, self.abi.METRIC_SOFTABS, self.alpha,
+                                                self.jitter, self.C, self.ws)
             self.abi.rmhmc_gaussian_sample(self.cur, self.theta0, self.tgt.precision, self.tgt.mean, self.tgt.log_norm,
                                            self.abi.METRIC_SOFTABS, self.alpha, self.jitter, self.L, self.eps, self.omega,
                                            self.T, 0, -1, self.seed + k, self.off, self.samples, self.rej, self.ws)

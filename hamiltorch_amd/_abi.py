@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhamiltorch_amd.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 MASS_NONE, MASS_DIAG, MASS_FULL = 0, 1, 2
 
@@ -76,12 +76,13 @@ def _sig(scalar):
         "hta_rmhmc_gaussian_sample": [c_vp, c_vp, c_vp, c_vp, c_f64, c_int, c_f64, c_int, c_f64, c_i64, c_int, c_int,
                                       c_f64, c_f64, c_int, c_int, c_int, c_u64, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                       c_vp, c_i64, c_vp],
+        "hta_rmhmc_gaussian_prepare": [c_vp, c_vp, c_int, c_f64, c_int, c_f64, c_i64, c_int, c_vp, c_i64, c_vp],
     }
 
 
 #: every symbol include/hamiltorch_amd.h declares (checked by tests/test_abi_symbols.py)
 PLAIN_SYMBOLS = ["hta_abi_version", "hta_last_error", "hta_device_info", "hta_set_tuning", "hta_get_tuning", "hta_reset_tuning",
-                 "hta_last_route", "hta_profile_collect", "hta_counter_add",
+                 "hta_last_route", "hta_profile_collect", "hta_counter_add", "hta_rmhmc_gaussian_forget",
                  "hta_hmc_gaussian_workspace_bytes", "hta_rmhmc_workspace_bytes"]
 TYPED_SYMBOLS = sorted(_sig(c_f32).keys())
 
@@ -115,6 +116,8 @@ def load():
         lib.hta_counter_add.restype = c_int
         lib.hta_rmhmc_workspace_bytes.argtypes = [c_i64, c_int, c_int]
         lib.hta_rmhmc_workspace_bytes.restype = c_i64
+        lib.hta_rmhmc_gaussian_forget.argtypes = [c_vp]
+        lib.hta_rmhmc_gaussian_forget.restype = c_int
         for suf, scalar in (("f32", c_f32), ("f64", c_f64)):
             for name, args in _sig(scalar).items():
                 fn = getattr(lib, "%s_%s" % (name, suf))
@@ -365,6 +368,22 @@ def rmhmc_gaussian_sample(theta, theta_init, P, mu, log_norm, metric, alpha, jit
                   int(traj_offset), int(burn), int(seed), int(chain_offset), _p(samples, theta), _p(reject_count),
                   _p(H_old, theta), _p(H_new, theta), _p(accept), c_vp(workspace.data_ptr()),
                   workspace.numel() * workspace.element_size(), _stream(theta)), "hta_rmhmc_gaussian_sample")
+
+
+def rmhmc_gaussian_prepare(like, P, mu, metric, alpha, jitter, C, workspace):
+    """The once-per-target setup of rmhmc_gaussian_sample (eigenbasis of P, the fused route's plan, the shared inverse) into
+    `workspace`; later sample calls on that workspace with the same P / metric / alpha / jitter skip it."""
+    require_device(like, "params")
+    D = P.shape[0]
+    fn = getattr(load(), "hta_rmhmc_gaussian_prepare_" + _suffix(like))
+    with torch.cuda.device(like.device):
+        _check(fn(_p(P, like), _p(mu, like), int(metric), float(alpha if alpha is not None else 0.0), 0 if jitter is None else 1,
+                  0.0 if jitter is None else float(jitter), int(C), int(D), c_vp(workspace.data_ptr()),
+                  workspace.numel() * workspace.element_size(), _stream(like)), "hta_rmhmc_gaussian_prepare")
+
+
+def rmhmc_gaussian_forget(workspace):
+    _check(load().hta_rmhmc_gaussian_forget(c_vp(workspace.data_ptr())), "hta_rmhmc_gaussian_forget")
 
 
 # ---- Bayesian MLP (regression) -----------------------------------------------------------------------

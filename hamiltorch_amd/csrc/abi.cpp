@@ -35,7 +35,6 @@ int g_quad_max_chains = 65536;   // up to here a chain takes a DPP quad (one eig
 int g_rmhmc_fused = 1;           // 0 = per-evaluation Jacobi path, 3 = fused with two chains per workgroup (parity tests)
 extern int g_metric_mfma, g_rmhmc_wide;         // rmhmc_metric_mfma.hip
 int g_mlp_valu = 0;               // 1 = keep the Bayesian-MLP sampler on the VALU kernel (parity tests of both)
-int g_metric_persist = 1;         // eigendecomposition route: one persistent launch per trajectory (0 = one launch per metric evaluation)
 int g_mlp3_route = 1;             // csrc/mlp3_mfma.hip (two wide hidden layers on the matrix cores); 0 = such models stay on the callback path
 
 // ---- optional HIP-event timing of the dominant kernel of each call (measurement only) -----------
@@ -99,7 +98,7 @@ const TuneKey kTune[] = {
     {"rmhmc_pair", &hta::g_rmhmc_pair, 1}, {"rmhmc_wide", &hta::g_rmhmc_wide, 1}, {"rmhmc_overlap", &hta::g_rmhmc_overlap, 1},
     {"rmhmc_batch", &hta::g_rmhmc_batch, 1}, {"quad_max_chains", &hta::g_quad_max_chains, 65536}, {"fill_blocks", &hta::g_fill_blocks, 4096},
     {"mlp_valu", &hta::g_mlp_valu, 0}, {"metric_mfma", &hta::g_metric_mfma, 1}, {"rmhmc_fused", &hta::g_rmhmc_fused, 1},
-    {"metric_persist", &hta::g_metric_persist, 1}, {"mlp3_route", &hta::g_mlp3_route, 1},
+    {"mlp3_route", &hta::g_mlp3_route, 1},
 };
 }  // namespace
 

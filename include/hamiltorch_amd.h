@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HTA_ABI_VERSION 5
+#define HTA_ABI_VERSION 6
 
 #define HTA_OK 0
 #define HTA_ERR_INVALID (-1)   /* bad argument                           */
@@ -253,6 +253,20 @@ int hta_rmhmc_gaussian_sample_f64(double* theta, const double* theta_init, const
                                   int32_t* reject_count, double* H_old, double* H_new, uint8_t* accept,
                                   void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Once-per-TARGET setup of hta_rmhmc_gaussian_sample, hoisted out of it for callers that keep sampling one target in
+ * several calls (a long run cut into blocks, bench.py's steps): the cold eigendecomposition of the curvature matrix P, the
+ * host-side plan of the fused route (one D-element read-back and a stream synchronise) and the shared inverse are written
+ * into `workspace` (the same buffer the sample calls get; >= hta_rmhmc_workspace_bytes) and remembered for it.  A later
+ * hta_rmhmc_gaussian_sample on that workspace with the SAME P pointer, D, metric, alpha, jitter and element type skips
+ * them (1.2 ms, 14 % of a 100-trajectory call at 1024 chains and D = 100); anything else runs the setup as before.
+ * Contract: the CONTENTS of P must not change between prepare and sample (prepare again, or hta_rmhmc_gaussian_forget),
+ * and the workspace must not be used for anything else in between.  Results are bit-identical with and without. */
+int hta_rmhmc_gaussian_prepare_f32(const float* P, const float* mu, int metric, double alpha, int has_jitter, double jitter,
+                                   int64_t C, int D, void* workspace, int64_t workspace_bytes, void* stream);
+int hta_rmhmc_gaussian_prepare_f64(const double* P, const double* mu, int metric, double alpha, int has_jitter, double jitter,
+                                   int64_t C, int D, void* workspace, int64_t workspace_bytes, void* stream);
+int hta_rmhmc_gaussian_forget(void* workspace);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused (split-)HMC for a one-hidden-layer Bayesian MLP with one output (BASELINE config 4):
  * the closures of define_model_log_prob / define_split_model_log_prob (S:1093-1258) and the
@@ -343,8 +357,6 @@ int hta_netn_logp_grad_f64(const double* theta, int64_t C, int n_layers, const i
  * instances of the one-chain kernel when chains <= compute units; 0 = always the two-workgroups-per-CU instances), "rmhmc_momwave" (1 default: one wave per momentum draw, fp32 with jitter, D <= 104; 0 = one workgroup per draw), "mlp_valu" (1 = VALU MLP kernel instead of the MFMA one),
  * "metric_mfma" (1 default: fp32 metric evaluations that share an eigenbasis, and Metric.HESSIAN ones, run on the matrix cores -
  * csrc/rmhmc_metric_mfma.hip, D <= 112; 0 = always the Jacobi kernel of csrc/rmhmc_metric.hip),
- * "metric_persist" (1 default: on the eigendecomposition route of hta_rmhmc_gaussian_sample the metric evaluations of a
- * whole trajectory run in ONE persistent launch per trajectory - csrc/rmhmc_traj_mfma.hip; 0 = one launch per evaluation),
  * "mlp3_route" (1 default: Bayesian MLPs with two wide hidden layers run on csrc/mlp3_mfma.hip; 0 = callback path). */
 int hta_set_tuning(const char* key, int value);
 /* current value of a route key; every key back to its default (test fixtures call this between tests: the keys are

@@ -838,3 +838,53 @@ def test_metric_mfma_kernel_issues_matrix_instructions_on_cfg3(ht):
         _abi.set_tuning("rmhmc_fused", 1); _abi.set_tuning("metric_mfma", 1)
     err = np.abs(outs[0] - outs[1]).max(axis=(0, 2))
     assert (err > 3e-4).sum() <= 1, err.max()
+
+
+def test_prepared_workspace_gives_identical_results_and_skips_the_setup(ht):
+    """hta_rmhmc_gaussian_prepare (ABI 6): the once-per-target setup of hta_rmhmc_gaussian_sample - cold eigendecomposition of P,
+    the fused route's plan, the shared inverse - hoisted out of the sample call.  Same bits with and without; a prepared call
+    launches no metric_eval_kernel; a call whose jitter / alpha / P pointer differ from the preparation runs the setup itself;
+    hamiltorch_amd.sample() prepares once per target and again after an in-place edit of the target."""
+    from hamiltorch_amd import _abi, rmhmc
+    t, o = cfg3_target(ht, 100, torch.float32)
+    C, D, T, L = 96, 100, 6, 4
+    th0 = tt((0.1 * O.philox_normals(3, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32), torch.float32)
+
+    def run(ws, jitter=1e-3, prepare=False, fused=1):
+        _abi.set_tuning("rmhmc_fused", fused)
+        cur = th0.clone(); samples = torch.empty(T + 1, C, D, device=dev()); rej = torch.zeros(C, dtype=torch.int32, device=dev())
+        if prepare:
+            _abi.rmhmc_gaussian_prepare(cur, t.precision, t.mean, _abi.METRIC_SOFTABS, 1e6, jitter, C, ws)
+        _abi.set_tuning("profile", 1)
+        _abi.rmhmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, _abi.METRIC_SOFTABS, 1e6, jitter, L, 0.1, 10.0, T, 0, -1, 5, 0,
+                                   samples, rej, ws)
+        torch.cuda.synchronize()
+        n = _abi.profile_collect()[1]
+        _abi.set_tuning("profile", 0)
+        return samples.clone(), rej.clone(), n
+    nbytes = _abi.rmhmc_workspace_bytes(C, D, 4, T)
+    for fused in (1, 0):                                  # the closed-form route and the eigendecomposition route
+        ws_a = torch.empty(nbytes, dtype=torch.uint8, device=dev()); ws_b = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+        s0, r0, n0 = run(ws_a, fused=fused)
+        s1, r1, n1 = run(ws_b, prepare=True, fused=fused)
+        s2, r2, n2 = run(ws_b, fused=fused)               # prepared by the previous call's prepare: setup skipped
+        assert torch.equal(s0, s1) and torch.equal(s0, s2) and torch.equal(r0, r2)
+        assert n2 == n0 - 1, (n0, n1, n2)                 # exactly the cold eigendecomposition launch is gone
+        s3, _, n3 = run(ws_b, jitter=2e-3, fused=fused)   # another jitter: the preparation does not apply, the call sets up itself
+        s4, _, _ = run(ws_a, jitter=2e-3, fused=fused)
+        assert torch.equal(s3, s4) and n3 == n0 and not torch.equal(s3, s0)
+        _abi.rmhmc_gaussian_forget(ws_b)
+        assert run(ws_b, fused=fused)[2] == n0
+    _abi.reset_tuning()
+    # through sample(): prepared once per target, again after an in-place edit of the precision matrix
+    kw = dict(num_samples=5, num_steps_per_sample=3, step_size=0.1, jitter=1e-3, softabs_const=1e6, explicit_binding_const=10,
+              sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT, metric=ht.Metric.SOFTABS, verbose=False, seed=9)
+    a = torch.stack(ht.sample(t, th0, **kw))
+    ws_id = next(iter(t._hta_rm_ws.values()))[0].ws.data_ptr()
+    b = torch.stack(ht.sample(t, th0, **kw))
+    assert torch.equal(a, b) and next(iter(t._hta_rm_ws.values()))[0].ws.data_ptr() == ws_id
+    t.precision.mul_(1.5)
+    c = torch.stack(ht.sample(t, th0, **kw))
+    t2 = ht.GaussianTarget(t.mean.clone(), precision=t.precision.clone(), normalized=False)
+    d = torch.stack(ht.sample(t2, th0, **kw))
+    assert torch.equal(c, d) and not torch.equal(c, a)
