@@ -28,7 +28,10 @@ int g_netn_waves = 1;        // csrc/netn_hmc.hip: waves per chain (2 / 4 where 
 int g_rmhmc_uv = 1;          // rmhmc_uv.hip (one or two chains per workgroup as columns of the matrix instruction): 1 up to 2 x CUs chains, 0 off, 2 always
 int g_rmhmc_pair = 1;        // four-chain kernels: consecutive half steps share product phases (0: one half step at a time)
 int g_rmhmc_mfma4_waves = 4; // fused RMHMC, four chains per workgroup: 4 = four waves (rows x k parity inside a wave), 2 = two waves
-int g_rmhmc_overlap = 1;   // fused RMHMC: momentum draws of the next block of trajectories on a side stream
+int g_rmhmc_overlap = 0;   // fused RMHMC: 1 = momentum draws of the next block of trajectories on a side stream (round 3: off -
+                           // run beside the trajectory kernel the draws slow it by a third; serial is 3-8 % faster at every chain count)
+int g_rmhmc_momsplit = 1;  // fused RMHMC with jitter: p = chol(P) z1 + sqrt(jitter u) . z2 (exactly N(0, P + diag(jitter u)) like
+                           // chol(P + diag(jitter u)) z, without a Cholesky per draw); 0 = the per-draw factorisation
 int g_gauss_eig = 1;       // small-D identity-mass Gaussian HMC integrates in the eigenbasis of P (0: direct kernel, 2: chain per lane only)
 int g_fill_blocks = 4096;        // grid cap of the pre-draw pass (256-thread blocks, grid-stride)
 int g_quad_max_chains = 65536;   // up to here a chain takes a DPP quad (one eigen-coordinate per lane), beyond a lane
@@ -95,7 +98,8 @@ const TuneKey kTune[] = {
     {"gauss_eig", &hta::g_gauss_eig, 1}, {"rmhmc_momwave", &hta::g_rmhmc_momwave, 1}, {"rmhmc_mfma4", &hta::g_rmhmc_mfma4, 1},
     {"rmhmc_mfma4_lo", &hta::g_rmhmc_mfma4_lo, 513}, {"rmhmc_mfma4_hi", &hta::g_rmhmc_mfma4_hi, 2049},
     {"rmhmc_mfma4_waves", &hta::g_rmhmc_mfma4_waves, 4}, {"netn_waves", &hta::g_netn_waves, 1}, {"rmhmc_uv", &hta::g_rmhmc_uv, 1},
-    {"rmhmc_pair", &hta::g_rmhmc_pair, 1}, {"rmhmc_wide", &hta::g_rmhmc_wide, 1}, {"rmhmc_overlap", &hta::g_rmhmc_overlap, 1},
+    {"rmhmc_pair", &hta::g_rmhmc_pair, 1}, {"rmhmc_wide", &hta::g_rmhmc_wide, 1}, {"rmhmc_overlap", &hta::g_rmhmc_overlap, 0},
+    {"rmhmc_momsplit", &hta::g_rmhmc_momsplit, 1},
     {"rmhmc_batch", &hta::g_rmhmc_batch, 1}, {"quad_max_chains", &hta::g_quad_max_chains, 65536}, {"fill_blocks", &hta::g_fill_blocks, 4096},
     {"mlp_valu", &hta::g_mlp_valu, 0}, {"metric_mfma", &hta::g_metric_mfma, 1}, {"rmhmc_fused", &hta::g_rmhmc_fused, 1},
     {"mlp3_route", &hta::g_mlp3_route, 1},

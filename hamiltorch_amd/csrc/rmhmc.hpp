@@ -39,7 +39,8 @@ extern int g_rmhmc_mfma4_waves;                             // tuning key "rmhmc
 extern int g_rmhmc_uv;                                      // tuning key "rmhmc_uv" (default 1: rmhmc_uv.hip up to 2 x CUs chains; 0 off; 2 always)
 extern int g_rmhmc_pair;                                    // tuning key "rmhmc_pair" (default 1: two half steps per K + 2 product phases)
 extern int g_rmhmc_mfma4, g_rmhmc_mfma4_lo, g_rmhmc_mfma4_hi;    // tuning keys "rmhmc_mfma4" (default 1), "rmhmc_mfma4_lo", "rmhmc_mfma4_hi"
-extern int g_rmhmc_overlap;                                 // tuning key "rmhmc_overlap" (default 1)
+extern int g_rmhmc_overlap;                                 // tuning key "rmhmc_overlap" (default 0 since round 3)
+extern int g_rmhmc_momsplit;                                // tuning key "rmhmc_momsplit" (default 1): p = chol(P) z1 + sqrt(e) z2
 template <typename T>
 int fused_plan(const T* lam0_host, int D, int metric, double alpha, int has_jitter, double jitter, double* logdetP, int* series);
 template <typename T> int inverse_from_eigen(const T* V0, const T* lam0, T* S, int D, hipStream_t s);
@@ -47,6 +48,7 @@ template <typename T>
 int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, const T* mu, double log_norm, double logdetP,
                        int has_jitter, double jitter, int K, int series, int64_t C, int D, int L, double eps, double omega,
                        int n_traj, int traj_offset, int burn, uint64_t seed, uint64_t chain_offset, T* samples,
-                       int32_t* reject_count, T* H_old, T* H_new, uint8_t* accept, T* p_ws, int64_t p_ws_elems, hipStream_t s);
+                       int32_t* reject_count, T* H_old, T* H_new, uint8_t* accept, T* p_ws, int64_t p_ws_elems, const T* LP,
+                       hipStream_t s);
 
 }  // namespace hta

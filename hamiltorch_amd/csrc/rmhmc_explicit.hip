@@ -15,6 +15,7 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include <vector>
 #include "common.hpp"
 #include "rmhmc.hpp"
 
@@ -95,6 +96,7 @@ int rmhmc_leapfrog(T* th, T* pm, T* thc, T* pmc, const T* P, const T* mu, int me
 struct RmPrepared {
   const void* P; int D, metric, has_jitter, elem; double alpha, jitter;      // what it was prepared for
   int K, series; double logdetP;                                              // the fused route's plan (K < 0: not eligible)
+  int split;                                                                  // chol(P) is in the workspace (the split momentum draw)
   int fused_keys;                                                             // g_rmhmc_fused at preparation time
 };
 static std::mutex g_prep_mu;
@@ -114,10 +116,10 @@ static bool prepared_lookup(const void* ws, const void* P, int D, int metric, do
 }
 
 template <typename T>
-static int rmhmc_setup(RmModel<T>& m, T* V0, T* lam0, T* Sinv, bool want_plan, RmPrepared& pr, hipStream_t s) {
+static int rmhmc_setup(RmModel<T>& m, T* V0, T* lam0, T* Sinv, T* LP, bool want_plan, RmPrepared& pr, hipStream_t s) {
   const char* who = "hta_rmhmc_gaussian_sample";
   const int D = m.D;
-  pr = RmPrepared{m.P, D, m.metric, m.has_jitter, (int)sizeof(T), m.alpha, m.jitter, -1, 0, 0.0, g_rmhmc_fused};
+  pr = RmPrepared{m.P, D, m.metric, m.has_jitter, (int)sizeof(T), m.alpha, m.jitter, -1, 0, 0.0, 0, g_rmhmc_fused};
   if (m.metric == HTA_METRIC_SOFTABS || g_rmhmc_fused) {
     // the target's curvature is one matrix for all chains and all evaluation points: diagonalise it once
     MetricArgsT<T> a0 = base_args(m, 0, 0);
@@ -136,6 +138,39 @@ static int rmhmc_setup(RmModel<T>& m, T* V0, T* lam0, T* Sinv, bool want_plan, R
     if (pr.K >= 0) {
       int rc = inverse_from_eigen<T>(V0, lam0, Sinv, D, s);
       if (rc) return rc;
+      if (m.has_jitter && D <= 128) {
+        // chol(P) for the split momentum draw (rmhmc_fused.hip: rmhmc_momentum_split_kernel): one 100 x 100 factorisation per
+        // TARGET, on the host in double (0.3 MFLOP) from a copy of P, rounded to T
+        std::vector<T> hp((size_t)D * D);
+        if (hipMemcpyAsync(hp.data(), m.P, hp.size() * sizeof(T), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+          set_error("%s: reading the curvature matrix back failed: %s", who, hipGetErrorString(hipGetLastError()));
+          return HTA_ERR_LAUNCH;
+        }
+        std::vector<double> Lh((size_t)D * D, 0.0);
+        bool pd = true;
+        for (int j = 0; j < D && pd; ++j) {
+          double d = 0.5 * ((double)hp[(size_t)j * D + j] + (double)hp[(size_t)j * D + j]);
+          for (int k = 0; k < j; ++k) d -= Lh[(size_t)j * D + k] * Lh[(size_t)j * D + k];
+          if (!(d > 0.0)) { pd = false; break; }
+          const double dj = sqrt(d);
+          Lh[(size_t)j * D + j] = dj;
+          for (int i = j + 1; i < D; ++i) {
+            double v = 0.5 * ((double)hp[(size_t)i * D + j] + (double)hp[(size_t)j * D + i]);      // the symmetric part, as the kernels read P
+            for (int k = 0; k < j; ++k) v -= Lh[(size_t)i * D + k] * Lh[(size_t)j * D + k];
+            Lh[(size_t)i * D + j] = v / dj;
+          }
+        }
+        if (pd) {
+          for (size_t e = 0; e < hp.size(); ++e) hp[e] = (T)Lh[e];
+          if (hipMemcpyAsync(LP, hp.data(), hp.size() * sizeof(T), hipMemcpyHostToDevice, s) != hipSuccess ||
+              hipStreamSynchronize(s) != hipSuccess) {
+            set_error("%s: uploading chol(P) failed: %s", who, hipGetErrorString(hipGetLastError()));
+            return HTA_ERR_LAUNCH;
+          }
+          pr.split = 1;
+        }
+      }
     }
   }
   return HTA_OK;
@@ -148,12 +183,12 @@ int rmhmc_prepare(const T* P, const T* mu, int metric, double alpha, int has_jit
   const char* who = "hta_rmhmc_gaussian_prepare";
   HTA_REQUIRE(P && mu && C > 0 && D > 0, "%s: bad arguments", who);
   const int64_t total = C * D;
-  const int64_t need = (4 * total + 3 * C + 2 * (int64_t)D * D + D) * (int64_t)sizeof(T);
+  const int64_t need = (4 * total + 3 * C + 3 * (int64_t)D * D + D) * (int64_t)sizeof(T);
   HTA_REQUIRE(workspace && workspace_bytes >= need, "%s: workspace of %lld bytes required", who, (long long)need);
-  T* V0 = (T*)workspace + 4 * total + 3 * C; T* lam0 = V0 + (int64_t)D * D; T* Sinv = lam0 + D;
+  T* V0 = (T*)workspace + 4 * total + 3 * C; T* lam0 = V0 + (int64_t)D * D; T* Sinv = lam0 + D; T* LP = Sinv + (int64_t)D * D;
   RmModel<T> m{P, mu, 0.0, metric, alpha, has_jitter, jitter, 0, 0, C, D, nullptr, nullptr};
   RmPrepared pr;
-  const int rc = rmhmc_setup<T>(m, V0, lam0, Sinv, true, pr, s);
+  const int rc = rmhmc_setup<T>(m, V0, lam0, Sinv, LP, true, pr, s);
   std::lock_guard<std::mutex> lock(g_prep_mu);
   if (rc) { g_prepared.erase({current_device(), workspace}); return rc; }
   g_prepared[{current_device(), workspace}] = pr;
@@ -169,11 +204,11 @@ int rmhmc_sample(T* cur, const T* theta_init, const T* P, const T* mu, double lo
   const char* who = "hta_rmhmc_gaussian_sample";
   HTA_REQUIRE(cur && theta_init && P && mu && reject_count && C > 0 && D > 0 && L >= 0 && n_traj >= 0, "%s: bad arguments", who);
   const int64_t total = C * D;
-  const int64_t need = (4 * total + 3 * C + 2 * (int64_t)D * D + D) * (int64_t)sizeof(T);
+  const int64_t need = (4 * total + 3 * C + 3 * (int64_t)D * D + D) * (int64_t)sizeof(T);
   HTA_REQUIRE(workspace && workspace_bytes >= need, "%s: workspace of %lld bytes required", who, (long long)need);
   T* th = (T*)workspace; T* pm = th + total; T* thc = pm + total; T* pmc = thc + total;
   T* H0 = pmc + total; T* H1 = H0 + C; T* lp1 = H1 + C;
-  T* V0 = lp1 + C; T* lam0 = V0 + (int64_t)D * D; T* Sinv = lam0 + D;
+  T* V0 = lp1 + C; T* lam0 = V0 + (int64_t)D * D; T* Sinv = lam0 + D; T* LP = Sinv + (int64_t)D * D;
   RmModel<T> m{P, mu, log_norm, metric, alpha, has_jitter, jitter, seed, chain_offset, C, D, nullptr, nullptr};
   // Once per TARGET: the eigenbasis of the curvature matrix (every evaluation only adds its own jitter to the diagonal and
   // starts from that basis), the host-side plan of the fused route (needs the spectrum on the host: one D-element copy and a
@@ -181,7 +216,7 @@ int rmhmc_sample(T* cur, const T* theta_init, const T* P, const T* mu, double lo
   // once (hta_rmhmc_gaussian_prepare): the cold Jacobi + inverse are 1.2 ms, 14 % of a 100-trajectory call at 1024 chains.
   RmPrepared pr;
   if (!prepared_lookup(workspace, P, D, metric, alpha, has_jitter, jitter, sizeof(T), pr)) {
-    const int rcp = rmhmc_setup<T>(m, V0, lam0, Sinv, n_traj > 0, pr, s);
+    const int rcp = rmhmc_setup<T>(m, V0, lam0, Sinv, LP, n_traj > 0, pr, s);
     if (rcp) return rcp;
   }
   if (metric == HTA_METRIC_SOFTABS) { m.V0 = V0; m.lam0 = lam0; }
@@ -189,12 +224,12 @@ int rmhmc_sample(T* cur, const T* theta_init, const T* P, const T* mu, double lo
     // the soft-abs map is the identity on this spectrum (or the metric is the Hessian itself): the whole run is one launch
     // sequence of rmhmc_fused.hip.  Room for pre-drawn momenta: whatever the caller's workspace holds beyond the base
     // layout, else the (unused on this path) augmented-state area at its head: 4 trajectories per pass
-    T* p_ws = Sinv + (int64_t)D * D;
+    T* p_ws = LP + (int64_t)D * D;
     int64_t p_elems = workspace_bytes / (int64_t)sizeof(T) - (p_ws - (T*)workspace);
     if (p_elems < total) { p_ws = th; p_elems = 4 * total; }
     return rmhmc_fused_sample<T>(cur, theta_init, P, Sinv, mu, log_norm, pr.logdetP, has_jitter, jitter, pr.K, pr.series, C, D, L, eps,
                                  omega, n_traj, traj_offset, burn, seed, chain_offset, samples, reject_count, H_old_out,
-                                 H_new_out, accept_out, p_ws, p_elems, s);
+                                 H_new_out, accept_out, p_ws, p_elems, pr.split ? LP : nullptr, s);
   }
   for (int t = 0; t < n_traj; ++t) {
     const int n = traj_offset + t;
@@ -233,7 +268,7 @@ int rmhmc_sample(T* cur, const T* theta_init, const T* P, const T* mu, double lo
 
 extern "C" {
 int64_t hta_rmhmc_workspace_bytes(int64_t C, int D, int elem_size) {
-  return (4 * C * D + 3 * C + 2 * (int64_t)D * D + D) * (int64_t)elem_size;
+  return (4 * C * D + 3 * C + 3 * (int64_t)D * D + D) * (int64_t)elem_size;
 }
 
 #define HTA_DEFINE_ROT(SUF, T)                                                                                  \

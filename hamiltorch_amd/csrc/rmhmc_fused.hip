@@ -1972,6 +1972,59 @@ __global__ __launch_bounds__(FNT) void rmhmc_momentum_kernel(const T* __restrict
   }
 }
 
+// The same draws WITHOUT a factorisation per draw (round 3; tuning key "rmhmc_momsplit", default 1).  On the fused route the
+// metric of an evaluation is G = P + diag(e), e = jitter * u (S:113-121 with the soft-abs map the identity), and S:183-184
+// asks for p ~ N(0, G).  With L_P = chol(P) - ONE factor per target, computed by the setup on the host in double - and two
+// independent standard-normal vectors,
+//     p = L_P z1 + sqrt(e) . z2      has covariance  L_P L_P^T + diag(e) = G  exactly,
+// the distribution MultivariateNormal(0, G).sample() draws from, given the same u; what changes is the map from the
+// uniform / normal draws to p (the reference's, and "rmhmc_momsplit" = 0: chol(G) z), i.e. the realisation, not the law -
+// like every other draw of this engine against torch's generator.  z1 is the momentum stream the factorising kernels use
+// (normal sub-stream 0), u their jitter stream (sub-stream 0), z2 normal sub-stream 1; oracle/hmc_oracle.py::rm_gibbs_split
+// is the same map.  Cost per draw: a D x D triangular matrix-vector product and three Philox passes instead of D^3 / 3
+// flops of latency-bound panels: 1.9 ms -> 0.1 ms per 100 trajectories at 1024 chains.
+// One wave per task; L_P transposed in LDS ([k][i]: the lanes of a wave read consecutive rows i); lanes l < D / 4 draw the
+// Philox blocks of the three streams, every lane accumulates its rows i = l, l + 64.
+template <typename T>
+__global__ __launch_bounds__(256) void rmhmc_momentum_split_kernel(const T* __restrict__ LP, T jitter, int64_t C, int D, int n_traj,
+                                                                   int traj_offset, uint64_t seed, uint64_t chain_offset,
+                                                                   T* __restrict__ p_ws) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* Lt = reinterpret_cast<T*>(smem_raw);                 // [D][ldt]: Lt[k * ldt + i] = L_P[i][k]
+  const int ldt = D | 1;
+  T* zb = Lt + (size_t)D * ldt;                           // per wave: z1[128] | sqrt(e) z2 [128]
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  T* z1 = zb + w * 256; T* sz = z1 + 128;
+  for (int e = tid; e < D * D; e += blockDim.x) { const int i = e / D, k = e - i * D; Lt[k * ldt + i] = (k <= i) ? LP[e] : (T)0; }
+  __syncthreads();
+  const int64_t ntask = (int64_t)n_traj * C;
+  const int nblk = (D + 3) / 4;
+  for (int64_t task = (int64_t)blockIdx.x * 4 + w; task < ntask; task += (int64_t)gridDim.x * 4) {
+    const int t = (int)(task / C);
+    const int64_t c = task - (int64_t)t * C;
+    const uint64_t chain = chain_offset + (uint64_t)c;
+    const uint32_t n = (uint32_t)(traj_offset + t);
+    for (int b = l; b < nblk; b += 64) {                  // element j of a stream = Philox block j / 4, slot j % 4 (philox.hpp)
+      T a[4], bz[4];
+      normal4<T>(philox_block(seed, chain, n, PURPOSE_MOMENTUM, 0, (uint32_t)b), a);
+      normal4<T>(philox_block(seed, chain, n, PURPOSE_MOMENTUM, 1, (uint32_t)b), bz);
+      const U4 r = philox_block(seed, chain, n, PURPOSE_JITTER, 0, (uint32_t)b);
+      const T u[4] = {u23<T>(r.x), u23<T>(r.y), u23<T>(r.z), u23<T>(r.w)};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { z1[4 * b + q] = a[q]; sz[4 * b + q] = sqrt(jitter * u[q]) * bz[q]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = l; i < D; i += 64) {
+      T acc = 0;
+      for (int k = 0; k <= i; ++k) acc = fma(Lt[k * ldt + i], z1[k], acc);      // ascending k, one accumulator: the oracle's order
+      p_ws[task * D + i] = acc + sz[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // The same draws, one WAVE per task, the work matrix in registers (fp32, jitter on, D <= 8 NB).  The workgroup kernel above
 // is bound by its LDS round trips: every trailing-update FMA reads its operands from LDS and writes its result back (1.5
 // LDS operations per FMA, 2 workgroup barriers per panel, 3 tasks per CU: 53 us per task at D = 100).  Here lane
@@ -2227,7 +2280,8 @@ template <typename T>
 int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, const T* mu, double log_norm, double logdetP,
                        int has_jitter, double jitter, int K, int series, int64_t C, int D, int L, double eps, double omega,
                        int n_traj, int traj_offset, int burn, uint64_t seed, uint64_t chain_offset, T* samples,
-                       int32_t* reject_count, T* H_old, T* H_new, uint8_t* accept, T* p_ws, int64_t p_ws_elems, hipStream_t s) {
+                       int32_t* reject_count, T* H_old, T* H_new, uint8_t* accept, T* p_ws, int64_t p_ws_elems, const T* LP,
+                       hipStream_t s) {
   int ld;
   (void)fused_lds_bytes<T>(D, &ld);
   const float ang = (float)(2.0 * omega * eps);                      // S:435-436: float32 cos / sin whatever the state dtype
@@ -2272,9 +2326,31 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
       const int64_t ntask = (int64_t)nt * C;
       const int mgrid = (int)(ntask < 256 * 12 ? ntask : 256 * 12);
       bool wave_done = false;
+      if (LP && has_jitter && g_rmhmc_momsplit && D <= 128) {
+        // p = chol(P) z1 + sqrt(e) . z2: no factorisation per draw (see rmhmc_momentum_split_kernel)
+        static DevOnce done_split;
+        if (!done_split) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rmhmc_momentum_split_kernel<T>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          if (e != hipSuccess) { set_error("hta_rmhmc_gaussian_sample: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
+          done_split = true;
+        }
+        hipStream_t ms = ov ? ov->side : s;
+        const size_t slds = ((size_t)D * (D | 1) + 4 * 256) * sizeof(T);
+        const int64_t sg = (ntask + 3) / 4;
+        const int sgrid = (int)(sg < 256 * 8 ? sg : 256 * 8);
+        if (ov) { if (bidx >= 2) (void)hipStreamWaitEvent(ov->side, ov->freed[bidx & 1], 0); }
+        else profile_begin(s);
+        rmhmc_momentum_split_kernel<T><<<sgrid, 256, slds, ms>>>(LP, (T)jitter, C, D, nt, traj_offset + t0, seed, chain_offset, p_blk);
+        if (ov) {
+          (void)hipEventRecord(ov->ready[bidx & 1], ov->side);
+          (void)hipStreamWaitEvent(s, ov->ready[bidx & 1], 0);
+        } else profile_end(s);
+        wave_done = true;
+      }
       if constexpr (sizeof(T) == 4) {
         // fp32 with jitter (a factorisation per task), D <= 104: one wave per task, work matrix in registers
-        if (g_rmhmc_momwave && has_jitter && D <= 104) {
+        if (!wave_done && g_rmhmc_momwave && has_jitter && D <= 104) {
           hipStream_t ms = ov ? ov->side : s;
           const int wgrid = (int)(ntask < 256 * 16 ? ntask : 256 * 16);
           if (ov) { if (bidx >= 2) (void)hipStreamWaitEvent(ov->side, ov->freed[bidx & 1], 0); }
@@ -2458,7 +2534,7 @@ template <typename T> int inverse_from_eigen(const T* V0, const T* lam0, T* S, i
   template int inverse_from_eigen<T>(const T*, const T*, T*, int, hipStream_t);                                       \
   template int rmhmc_fused_sample<T>(T*, const T*, const T*, const T*, const T*, double, double, int, double, int,   \
                                      int, int64_t, int, int, double, double, int, int, int, uint64_t, uint64_t, T*,   \
-                                     int32_t*, T*, T*, uint8_t*, T*, int64_t, hipStream_t);
+                                     int32_t*, T*, T*, uint8_t*, T*, int64_t, const T*, hipStream_t);
 HTA_INST(float)
 HTA_INST(double)
 

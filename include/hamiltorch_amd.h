@@ -236,9 +236,11 @@ int hta_rmhmc_gaussian_leapfrog_f64(double* theta, double* p, double* theta_copy
  * launch of `n_traj` trajectories; arguments as hta_hmc_gaussian_sample.  workspace:
  * hta_rmhmc_workspace_bytes(C, D, sizeof(T)) bytes at least (required).  Every further C*D*sizeof(T) bytes let the
  * fused path (soft-abs map == identity on the target's spectrum, csrc/rmhmc_fused.hip) draw the momenta of one more
- * trajectory per pass ahead of the chains (full-chip Cholesky batch); with the minimum it works in passes of 4.  With
- * room for >= 16 trajectories the draws of the next block run on an internal side stream (forked from and joined back into
- * `stream` inside the call) under the trajectories of the current one. */
+ * trajectory per pass ahead of the chains (one full-chip batch of draws); with the minimum it works in passes of 4.  With
+ * hta_set_tuning("rmhmc_overlap", 1) and room for >= 16 trajectories the draws of the next block run on an internal side
+ * stream (forked from and joined back into `stream` inside the call) under the trajectories of the current one.
+ * Momenta on the fused path with jitter: p = chol(P) z1 + sqrt(jitter u) . z2 (z1, z2: normal sub-streams 0 and 1 of the
+ * trajectory, u: jitter sub-stream 0), distributed as the reference's chol(P + diag(jitter u)) z; see "rmhmc_momsplit". */
 int64_t hta_rmhmc_workspace_bytes(int64_t C, int D, int elem_size);
 int hta_rmhmc_gaussian_sample_f32(float* theta, const float* theta_init, const float* P, const float* mu,
                                   double log_norm, int metric, double alpha, int has_jitter, double jitter,
@@ -346,8 +348,11 @@ int hta_netn_logp_grad_f64(const double* theta, int64_t C, int n_layers, const i
  * event pair around the dominant kernel of every N-th fused call, on the launch stream);
  * route selectors kept for the parity tests: "gauss_eig" (1 default; 0 = direct small-D Gaussian kernel, 2 = eigenbasis with
  * one chain per lane only, 3 = quad kernel without the compiled-in step counts), "quad_max_chains" (65536), "rmhmc_fused"
- * (1 default; 0 = per-evaluation Jacobi path, 3 = two chains per workgroup), "rmhmc_overlap" (1 default; 0 = momentum draws
- * on the caller's stream), "rmhmc_batch" (1 default: 16 chains per workgroup on the matrix cores from 2048 chains on; 0 off, 2 always),
+ * (1 default; 0 = per-evaluation Jacobi path, 3 = two chains per workgroup), "rmhmc_overlap" (0 default: momentum draws
+ * on the caller's stream; 1 = on an internal side stream under the previous block's trajectories - slower at every measured chain
+ * count, the two kernels compete for the same SIMDs), "rmhmc_momsplit" (1 default: with jitter on, the fused route draws
+ * p = chol(P) z1 + sqrt(jitter u) . z2 - covariance P + diag(jitter u) = G exactly, the law of S:183-184, chol(P) once per target;
+ * 0 = chol(G) z with a factorisation per draw, the reference's arithmetic), "rmhmc_batch" (1 default: 16 chains per workgroup on the matrix cores from 2048 chains on; 0 off, 2 always),
  * "rmhmc_mfma4" (1 default: 4 chains per workgroup on v_mfma_f32_4x4x1_16b for "rmhmc_mfma4_lo" = 513 <= chains < "rmhmc_mfma4_hi" = 2049;
  * 0 off, 2 always; "rmhmc_mfma4_waves" 4 default: four waves per group - rows x contraction parity inside a wave; 2 = two waves;
  * "netn_waves" 1 default: waves per chain of the small-network kernel (2 / 4: a chain's sweeps over several waves where they fit);

@@ -181,7 +181,7 @@ def test_cfg3_bench_instances_vs_oracle_L10(ht, C, N, nsel, route):
     assert got.shape == (N, C, D) and np.isfinite(got).all()
     sel = np.unique(np.r_[0:4, np.linspace(4, C - 5, nsel - 8).astype(int), C - 4:C])
     ref, info = O.sample_rmhmc_explicit(o, th0[sel], N, L, eps, omega, alpha, 0, jitter,
-                                        O.PhiloxDraws(seed, off + sel, np.float32), "softabs")
+                                        O.PhiloxDraws(seed, off + sel, np.float32), "softabs", momentum="split")
     err = _chain_err(got[:, sel], np.stack(ref))
     bad = err > 5e-4
     assert bad.sum() <= max(1, len(sel) // 64), "%s: %d of %d chains differ (max %.3g)" % (route, bad.sum(), len(sel), err.max())

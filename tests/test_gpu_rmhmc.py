@@ -29,6 +29,15 @@ def tt(a, dtype):
     return None if a is None else torch.tensor(np.asarray(a), dtype=dtype, device=dev())
 
 
+def oracle_momentum(jitter):
+    """Which momentum draw the oracle must replay for the sample call that just returned: the fused Gaussian routes
+    (kernel names rmhmc_*) draw p = chol(P) z1 + sqrt(jitter u) . z2 when jitter is on (tuning key "rmhmc_momsplit",
+    default 1; oracle: rm_gibbs_split, same law as chol(G) z); every other route and jitter-free runs draw chol(G) z."""
+    from hamiltorch_amd import _abi
+    fused = _abi.last_route().startswith("rmhmc_")
+    return "split" if (jitter is not None and fused and _abi.get_tuning("rmhmc_momsplit")) else "chol"
+
+
 def sym_batch(B, D, kind, seed):
     rng = np.random.default_rng(seed)
     out = []
@@ -163,11 +172,18 @@ def test_explicit_leapfrog_and_hamiltonian_vs_oracle(ht, dtype, tol, D, jitter):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-4), (torch.float64, 1e-8)])
-@pytest.mark.parametrize("D,jitter,metric,burn", [(3, None, "softabs", 0), (3, 1e-3, "softabs", 2), (10, None, "hessian", -1),
-                                                  (20, 1e-3, "softabs", 0)])
-def test_sample_rmhmc_vs_oracle(ht, dtype, tol, D, jitter, metric, burn):
+@pytest.mark.parametrize("D,jitter,metric,burn,split", [(3, None, "softabs", 0, 1), (3, 1e-3, "softabs", 2, 1), (10, None, "hessian", -1, 1),
+                                                        (20, 1e-3, "softabs", 0, 1), (20, 1e-3, "softabs", 0, 0), (3, 1e-3, "softabs", 2, 0),
+                                                        (100, 1e-3, "softabs", 0, 1), (128, 2e-3, "hessian", 0, 1)])
+def test_sample_rmhmc_vs_oracle(ht, dtype, tol, D, jitter, metric, burn, split):
     """End to end sample(sampler=RMHMC, integrator=EXPLICIT): momentum draw, both Hamiltonians, L explicit steps,
-    MH, burn bookkeeping -- same Philox streams in the kernels and the oracle."""
+    MH, burn bookkeeping -- same Philox streams in the kernels and the oracle.  split 1 (default): the momenta of the
+    fused routes are chol(P) z1 + sqrt(jitter u) . z2 (oracle: rm_gibbs_split); 0: chol(G) z, a factorisation per draw
+    as the reference (S:183-184)."""
+    from hamiltorch_amd import _abi
+    if dtype == torch.float64 and D > 64:
+        pytest.skip("fp64: three D x D matrices exceed the LDS of one CU (Jacobi route; covered at D <= 64)")
+    _abi.set_tuning("rmhmc_momsplit", split)
     t, o = cfg3_target(ht, D, dtype, seed=5)
     C, N, L, eps, omega, alpha, seed, off = 24, 7, 3, 0.15, 10.0, 1e6, 2025, 3
     th0 = (0.3 * O.philox_normals(seed, off + np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(NP[dtype])
@@ -175,7 +191,8 @@ def test_sample_rmhmc_vs_oracle(ht, dtype, tol, D, jitter, metric, burn):
     out, acc = ht.sample(t, tt(th0, dtype), num_samples=N, num_steps_per_sample=L, step_size=eps, burn=burn, jitter=jitter,
                          softabs_const=alpha, explicit_binding_const=omega, sampler=ht.Sampler.RMHMC,
                          integrator=ht.Integrator.EXPLICIT, metric=M, debug=2, verbose=False, seed=seed, chain_offset=off)
-    ref, info = O.sample_rmhmc_explicit(o, th0, N, L, eps, omega, alpha, burn, jitter, O.PhiloxDraws(seed, off + np.arange(C), NP[dtype]), metric)
+    ref, info = O.sample_rmhmc_explicit(o, th0, N, L, eps, omega, alpha, burn, jitter, O.PhiloxDraws(seed, off + np.arange(C), NP[dtype]), metric,
+                                        momentum=oracle_momentum(jitter))
     got = np.stack([x.cpu().numpy() for x in out]); want = np.stack(ref)
     assert got.shape == want.shape
     bad = np.abs(got - want).max(axis=(0, 2)) > tol
@@ -370,6 +387,7 @@ def test_fused_path_equals_jacobi_path(ht, dtype, tol, D, jitter, metric):
               explicit_binding_const=omega, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT, metric=M, debug=2,
               verbose=False, seed=seed)
     outs = []
+    _abi.set_tuning("rmhmc_momsplit", 0)          # chol(G) z on both routes (the Jacobi route has no split draw)
     for fused in (1, 0):
         _abi.set_tuning("rmhmc_fused", fused)
         try:
@@ -491,13 +509,16 @@ def test_fused_workspace_passes_are_equivalent(ht):
     assert np.abs(outs[0][0][-1] - outs[0][0][0]).max() > 1e-3
 
 
+@pytest.mark.parametrize("split", [1, 0])
 @pytest.mark.parametrize("T", [32, 75, 200])
-def test_fused_momentum_overlap_equals_serial(ht, T):
-    """With room for two blocks the momentum draws of block b+1 run on a side stream under the trajectories of block b
-    (hta_set_tuning('rmhmc_overlap', 0) keeps everything on the caller's stream).  Same kernels, same draws: bit-identical
-    samples / reject counts, also when the call is repeated back to back (event reuse) and followed by work on the
-    caller's stream that reads the results."""
+def test_fused_momentum_overlap_equals_serial(ht, T, split):
+    """hta_set_tuning('rmhmc_overlap', 1): with room for two blocks the momentum draws of block b+1 run on a side stream under
+    the trajectories of block b (the default, 0, keeps everything on the caller's stream - measured faster at every chain
+    count, profiles/r03h_*).  Same kernels, same draws: bit-identical samples / reject counts, also when the call is repeated
+    back to back (event reuse) and followed by work on the caller's stream that reads the results; with the split draw
+    and with the factorisation per draw."""
     from hamiltorch_amd import _abi
+    _abi.set_tuning("rmhmc_momsplit", split)
     D, C, L = 24, 40, 2
     t, _ = cfg3_target(ht, D, torch.float32, seed=9)
     th0 = tt((0.3 * O.philox_normals(3, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32), torch.float32)
@@ -514,7 +535,7 @@ def test_fused_momentum_overlap_equals_serial(ht, T):
                                            T, 0, -1, 21 + rep, 0, samples, rej, ws)
                 res.append((samples.sum(dim=0).cpu().numpy(), samples.cpu().numpy(), rej.cpu().numpy()))   # no explicit sync
         finally:
-            _abi.set_tuning("rmhmc_overlap", 1)
+            _abi.set_tuning("rmhmc_overlap", 0)
         outs.append(res)
     for a_, b_ in zip(outs[0], outs[1]):
         for x, y in zip(a_, b_):
@@ -568,6 +589,7 @@ def test_wave_momentum_kernel_equals_workgroup_kernel(ht, D, C, jit, batch):
     t, _ = cfg3_target(ht, D, torch.float32, seed=11)
     th0 = tt((0.3 * O.philox_normals(5, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32), torch.float32)
     outs = []
+    _abi.set_tuning("rmhmc_momsplit", 0)          # the draws with a factorisation each (the default is the split draw)
     _abi.set_tuning("rmhmc_batch", batch)
     try:
         for mode in (1, 0):
@@ -717,7 +739,7 @@ def test_mfma4_kernel_equals_fused_kernel(ht, D, C, jit):
 @pytest.mark.parametrize("C", [1024, 2050, 4100])
 def test_sample_rmhmc_cfg5_shapes_vs_oracle(ht, C):
     """sample(RMHMC, EXPLICIT, SOFTABS) at D=100 on the default routes of large batches (1024 chains:
-    rmhmc_mfma4_kernel; 2050 and 4100: rmhmc_batch_kernel; momenta from rmhmc_momentum_wave_kernel) against the oracle on the
+    rmhmc_mfma4_kernel; 2050 and 4100: rmhmc_batch_kernel; momenta from rmhmc_momentum_split_kernel) against the oracle on the
     first and last chains of the batch (same Philox streams; SURVEY 8c tolerance 1e-4 on theta)."""
     D, N, L, eps, omega, alpha, seed, off, jitter = 100, 4, 2, 0.1, 10.0, 1e6, 77, 5, 1e-3
     t, o = cfg3_target(ht, D, torch.float32, seed=0)
@@ -727,7 +749,8 @@ def test_sample_rmhmc_cfg5_shapes_vs_oracle(ht, C):
                     integrator=ht.Integrator.EXPLICIT, metric=ht.Metric.SOFTABS, verbose=False, seed=seed, chain_offset=off)
     got = np.stack([x.cpu().numpy() for x in out])
     sel = np.r_[0:3, C - 3:C]
-    ref, _ = O.sample_rmhmc_explicit(o, th0[sel], N, L, eps, omega, alpha, 0, jitter, O.PhiloxDraws(seed, off + sel, np.float32), "softabs")
+    ref, _ = O.sample_rmhmc_explicit(o, th0[sel], N, L, eps, omega, alpha, 0, jitter, O.PhiloxDraws(seed, off + sel, np.float32), "softabs",
+                                     momentum=oracle_momentum(jitter))
     want = np.stack(ref)
     assert np.isfinite(got).all() and got.shape == (N, C, D)
     err = np.abs(got[:, sel] - want).max(axis=(0, 2))
