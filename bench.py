@@ -300,6 +300,14 @@ class Cfg3:
             if self.jacobi:
                 self.abi.set_tuning("rmhmc_fused", 1)
 
+    def api_call(self, k):
+        """The same work through hamiltorch_amd.sample(sampler=RMHMC, integrator=EXPLICIT, metric=SOFTABS)."""
+        import hamiltorch_amd as ht
+        return ht.sample(self.tgt, self.theta0, num_samples=self.T, num_steps_per_sample=self.L, step_size=self.eps, burn=-1,
+                         jitter=self.jitter, softabs_const=self.alpha, explicit_binding_const=self.omega, sampler=ht.Sampler.RMHMC,
+                         integrator=ht.Integrator.EXPLICIT, metric=ht.Metric.SOFTABS, verbose=False, seed=self.seed + k,
+                         chain_offset=self.off)
+
     def check(self):
         assert torch.isfinite(self.samples).all()
         return 1.0 - float(self.rej.double().mean()) / (self.T * max(1, self._steps_done))
@@ -389,6 +397,7 @@ class Cfg4:
         self.X, self.Y = X.to(dev).contiguous(), Y.reshape(-1).to(dev).contiguous()
         torch.manual_seed(0)
         net = torch.nn.Sequential(torch.nn.Linear(8, 100), torch.nn.ReLU(), torch.nn.Linear(100, 1))
+        self.net = net.to(dev)
         flat = torch.cat([p.detach().flatten() for p in net.parameters()])
         self.theta0 = flat.repeat(self.C, 1).to(dev).contiguous()
         self.cur = self.theta0.clone()
@@ -406,6 +415,16 @@ class Cfg4:
         return 16 * self.D
 
     roof_kernel = "mlp_mfma_kernel"
+
+    def api_call(self, k):
+        """The same work through hamiltorch_amd.sample_split_model (the module is recognised by tracing; S:1364-1466)."""
+        import hamiltorch_amd as ht
+        if not hasattr(self, "_loader"):
+            ds = torch.utils.data.TensorDataset(self.X, self.Y.reshape(-1, 1))
+            self._loader = torch.utils.data.DataLoader(ds, batch_size=100, shuffle=False)
+        return ht.sample_split_model(self.net, self._loader, self.theta0, 4, model_loss="regression", num_samples=self.T,
+                                     num_steps_per_sample=self.L, step_size=self.eps, burn=-1, inv_mass=self.im, tau_out=100.0,
+                                     tau_list=torch.ones(4), verbose=False, seed=self.seed + k, chain_offset=self.off)
 
     def step(self, k):
         self.abi.mlp_hmc_sample(self.cur, self.theta0, 8, 100, "relu", self.X, self.Y, 4, 100, [1.0] * 4, 100.0, 4.0,
@@ -472,6 +491,7 @@ class NbMlp:
         self.X, self.Y = X.to(dev).contiguous(), Y.reshape(-1).to(dev).contiguous()
         torch.manual_seed(0)
         net = self._net()
+        self.net = net.to(dev)
         flat = torch.cat([p.detach().flatten() for p in net.parameters()])
         self.theta0 = flat.repeat(self.C, 1).to(dev).contiguous()
         self.cur = self.theta0.clone()
@@ -505,6 +525,18 @@ class NbMlp:
         return 16 * self.D
 
     roof_kernel = "mlp3_mfma_kernel<0>"
+
+    def api_call(self, k):
+        """The same work through sample_split_model (M = 4) / sample_model (full HMC) on the notebook's module."""
+        import hamiltorch_amd as ht
+        kw = dict(model_loss="regression", num_samples=self.T, num_steps_per_sample=self.L, step_size=self.eps, burn=-1,
+                  tau_out=self.tau_out, tau_list=torch.ones(6), verbose=False, seed=self.seed + k, chain_offset=self.off)
+        if self.M == 1:
+            return ht.sample_model(self.net, self.X, self.Y.reshape(-1, 1), self.theta0, **kw)
+        if not hasattr(self, "_loader"):
+            ds = torch.utils.data.TensorDataset(self.X, self.Y.reshape(-1, 1))
+            self._loader = torch.utils.data.DataLoader(ds, batch_size=self.Nb, shuffle=False)
+        return ht.sample_split_model(self.net, self._loader, self.theta0, self.M, **kw)
 
     def step(self, k):
         self.abi.netn_hmc_sample(self.cur, self.theta0, self.dims, "relu", self.X, self.Y, self.M, self.Nb, [1.0] * 6, self.tau_out,
@@ -749,6 +781,8 @@ def compact_line(full, detail_path="bench_detail.json"):
              "kernel": roof["kernel"][:40], "kernel_ms": roof["kernel_ms"], "cpu": {"value": _r(cb.get("value"), 4), "cores": cb.get("cores")}}
         if roof.get("mfma_issued_over_useful") is not None:
             e["issued_over_useful"] = roof["mfma_issued_over_useful"]
+        if r.get("api_ms_per_step") is not None:
+            e["api_ms"] = _r(r["api_ms_per_step"], 4)
         if r.get("published"):
             e["samples_per_s"] = _r(r.get("samples_per_s"), 4)
             e["published"] = {"samples_per_s": r["published"].get("samples_per_s"), "hw": str(r["published"].get("hw", ""))[:24]}
@@ -947,6 +981,12 @@ def secondary(dev, a):
             if getattr(W, "published", None):
                 r["published"] = W.published
                 r["samples_per_s"] = r["value"] / W.L
+            if hasattr(w, "api_call") and not a.no_api and not getattr(w, "jacobi", False):
+                try:        # the same steps through the public API (sample / sample_split_model / sample_model)
+                    r["api_ms_per_step"], r["api_sync_ms"] = api_timing(w, steps, warmup, reps=3)
+                    r["api_route"] = w.abi.last_route()
+                except Exception as e:
+                    r["api_error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
             out.append(r)
             del w
             torch.cuda.empty_cache()
