@@ -56,7 +56,10 @@ __device__ __forceinline__ float groups_sum(float v) {
 }
 
 template <int ACT> __device__ __forceinline__ float mact(float z) {
-  if (ACT == 0) return __builtin_amdgcn_fmed3f(z, 0.0f, __builtin_inff());   // max(z, 0) in one VALU op (fmaxf adds a canonicalize)
+  // max(z, 0) in ONE VALU op, v_med3_f32(z, 0, FLT_MAX): fmaxf - and med3 against +inf, which the compiler folds into it -
+  // compile to v_max(z, z) (a canonicalize) + v_max(0, .): 56 instead of 28 instructions per gradient at BASELINE config 4.
+  // (An activation of +inf - a diverged chain - becomes FLT_MAX: the log-probability still overflows, the proposal is rejected.)
+  if (ACT == 0) return __builtin_amdgcn_fmed3f(z, 0.0f, 3.4028234663852886e38f);
   if (ACT == 1) return tanhf(z);
   return 1.0f / (1.0f + expf(-z));
 }

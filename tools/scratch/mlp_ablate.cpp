@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
   float best = 1e30f;
   for (int rep = 0; rep < 4; ++rep) {
     hipEventRecord(e0, 0);
-    int rc = hta_mlp_hmc_sample_f32(dth, dth0, C, n_in, H, 0, dX, dY, N, M, Nb, tau, 100.0f, 1.0f, 0, nullptr, nullptr, HTA_SPLIT_SYMMETRIC, L, 5e-4f, NT,
+    int rc = hta_mlp_hmc_sample_f32(dth, dth0, C, n_in, H, 0, HTA_LOSS_REGRESSION, dX, dY, N, M, Nb, tau, 100.0f, 1.0f, 0, nullptr, nullptr, HTA_SPLIT_SYMMETRIC, L, 5e-4f, NT,
                                     rep * NT, 0, 7, 0, nullptr, rej, nullptr, nullptr, nullptr, nullptr);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     if (rc) { printf("error: %s\n", hta_last_error()); return 1; }
