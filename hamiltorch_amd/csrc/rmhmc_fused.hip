@@ -1983,44 +1983,77 @@ __global__ __launch_bounds__(FNT) void rmhmc_momentum_kernel(const T* __restrict
 // (normal sub-stream 0), u their jitter stream (sub-stream 0), z2 normal sub-stream 1; oracle/hmc_oracle.py::rm_gibbs_split
 // is the same map.  Cost per draw: a D x D triangular matrix-vector product and three Philox passes instead of D^3 / 3
 // flops of latency-bound panels: 1.9 ms -> 0.1 ms per 100 trajectories at 1024 chains.
-// One wave per task; L_P transposed in LDS ([k][i]: the lanes of a wave read consecutive rows i); lanes l < D / 4 draw the
-// Philox blocks of the three streams, every lane accumulates its rows i = l, l + 64.
+// One wave per task; L_P transposed and zero-filled above the diagonal in LDS ([k][i]: the lanes of a wave read consecutive
+// rows i, and the k loop has ONE trip count for every lane - the terms beyond the diagonal add an exact zero, so the sums
+// are the ascending-k single-accumulator sums of the oracle); a lane carries its rows i = l and l + 64 through the same loop
+// (two accumulators, z1 read as 16-byte broadcasts).  The three Philox streams of a draw go to three groups of lanes (z1:
+// lanes 0 .., z2: lanes 32 .., u: lanes 0 .. again behind z1 when D > 128 never happens: D <= 128 means <= 32 blocks per
+// stream), so a wave's critical path holds one normal4 and one uniform pass instead of three Philox passes and two normal4.
+// Staging walks rows (no integer division).  First version: 0.33 ms per 102 400 draws at D = 100 (rocprofv3, profiles/r03p_*).
 template <typename T>
 __global__ __launch_bounds__(256) void rmhmc_momentum_split_kernel(const T* __restrict__ LP, T jitter, int64_t C, int D, int n_traj,
                                                                    int traj_offset, uint64_t seed, uint64_t chain_offset,
                                                                    T* __restrict__ p_ws) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T* Lt = reinterpret_cast<T*>(smem_raw);                 // [D][ldt]: Lt[k * ldt + i] = L_P[i][k]
+  T* Lt = reinterpret_cast<T*>(smem_raw);                 // [D + 4][ldt] (+ 128): Lt[k * ldt + i] = L_P[i][k]; 0 for k > i and in the rows k >= D
   const int ldt = D | 1;
-  T* zb = Lt + (size_t)D * ldt;                           // per wave: z1[128] | sqrt(e) z2 [128]
+  const int lt_elems = ((D + 4) * ldt + 128 + 3) & ~3;
+  T* zb = Lt + lt_elems;                                  // per wave: z1[128] | sqrt(e) [128] | z2[128], 16-byte aligned
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-  T* z1 = zb + w * 256; T* sz = z1 + 128;
-  for (int e = tid; e < D * D; e += blockDim.x) { const int i = e / D, k = e - i * D; Lt[k * ldt + i] = (k <= i) ? LP[e] : (T)0; }
+  T* z1 = zb + w * 384; T* se = z1 + 128; T* z2 = se + 128;
+  for (int i = w; i < D; i += 4)
+    for (int k = l; k < D; k += 64) Lt[k * ldt + i] = (k <= i) ? LP[(size_t)i * D + k] : (T)0;
+  for (int e = D * ldt + tid; e < lt_elems; e += 256) Lt[e] = (T)0;
+  for (int e = l; e < 128; e += 64) z1[e] = (T)0;         // the k loop runs to a multiple of 4
   __syncthreads();
   const int64_t ntask = (int64_t)n_traj * C;
-  const int nblk = (D + 3) / 4;
+  const int nblk = (D + 3) / 4;                           // <= 32
+  const int D4 = (D + 3) & ~3;
+  const bool row2 = l + 64 < D;
+  const T* Lc = Lt + l;
   for (int64_t task = (int64_t)blockIdx.x * 4 + w; task < ntask; task += (int64_t)gridDim.x * 4) {
     const int t = (int)(task / C);
     const int64_t c = task - (int64_t)t * C;
     const uint64_t chain = chain_offset + (uint64_t)c;
     const uint32_t n = (uint32_t)(traj_offset + t);
-    for (int b = l; b < nblk; b += 64) {                  // element j of a stream = Philox block j / 4, slot j % 4 (philox.hpp)
-      T a[4], bz[4];
-      normal4<T>(philox_block(seed, chain, n, PURPOSE_MOMENTUM, 0, (uint32_t)b), a);
-      normal4<T>(philox_block(seed, chain, n, PURPOSE_MOMENTUM, 1, (uint32_t)b), bz);
-      const U4 r = philox_block(seed, chain, n, PURPOSE_JITTER, 0, (uint32_t)b);
-      const T u[4] = {u23<T>(r.x), u23<T>(r.y), u23<T>(r.z), u23<T>(r.w)};
+    // element j of a stream = Philox block j / 4, slot j % 4 (philox.hpp)
+    const int b = l & 31;
+    if (b < nblk) {
+      T a[4];
+      if (l < 32) {
+        normal4<T>(philox_block(seed, chain, n, PURPOSE_MOMENTUM, 0, (uint32_t)b), a);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { z1[4 * b + q] = a[q]; sz[4 * b + q] = sqrt(jitter * u[q]) * bz[q]; }
+        for (int q = 0; q < 4; ++q) z1[4 * b + q] = (4 * b + q < D) ? a[q] : (T)0;
+        const U4 r = philox_block(seed, chain, n, PURPOSE_JITTER, 0, (uint32_t)b);
+        const T u[4] = {u23<T>(r.x), u23<T>(r.y), u23<T>(r.z), u23<T>(r.w)};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) se[4 * b + q] = sqrt(jitter * u[q]);
+      } else {
+        normal4<T>(philox_block(seed, chain, n, PURPOSE_MOMENTUM, 1, (uint32_t)b), a);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) z2[4 * b + q] = a[q];
+      }
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int i = l; i < D; i += 64) {
-      T acc = 0;
-      for (int k = 0; k <= i; ++k) acc = fma(Lt[k * ldt + i], z1[k], acc);      // ascending k, one accumulator: the oracle's order
-      p_ws[task * D + i] = acc + sz[i];
+    T acc0 = 0, acc1 = 0;
+#pragma unroll 2
+    for (int k = 0; k < D4; k += 4) {                     // ascending k, one accumulator per row: the oracle's order
+      T zz[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) zz[q] = z1[k + q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc0 = fma(Lc[(k + q) * ldt], zz[q], acc0);       // rows k + q >= D: the zeroed slack / z1 = 0
+        acc1 = fma(Lc[(k + q) * ldt + 64], zz[q], acc1);
+      }
     }
+    // (the products are rounded before they are added - the oracle's arithmetic; the empty asm keeps them out of an fma)
+    T s0 = se[l] * z2[l], s1 = se[l + 64] * z2[l + 64];
+    asm volatile("" : "+v"(s0), "+v"(s1));
+    if (l < D) p_ws[task * D + l] = acc0 + s0;
+    if (row2) p_ws[task * D + l + 64] = acc1 + s1;
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -2336,9 +2369,10 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
           done_split = true;
         }
         hipStream_t ms = ov ? ov->side : s;
-        const size_t slds = ((size_t)D * (D | 1) + 4 * 256) * sizeof(T);
+        const size_t slds = ((size_t)((((D + 4) * (D | 1)) + 128 + 3) & ~3) + 4 * 384) * sizeof(T);
         const int64_t sg = (ntask + 3) / 4;
-        const int sgrid = (int)(sg < 256 * 8 ? sg : 256 * 8);
+        const int64_t sres = (int64_t)fused_cu_count() * (slds <= 52 * 1024 ? 3 : (slds <= 78 * 1024 ? 2 : 1));   // resident workgroups: L_P is staged once each
+        const int sgrid = (int)(sg < sres ? sg : sres);
         if (ov) { if (bidx >= 2) (void)hipStreamWaitEvent(ov->side, ov->freed[bidx & 1], 0); }
         else profile_begin(s);
         rmhmc_momentum_split_kernel<T><<<sgrid, 256, slds, ms>>>(LP, (T)jitter, C, D, nt, traj_offset + t0, seed, chain_offset, p_blk);
