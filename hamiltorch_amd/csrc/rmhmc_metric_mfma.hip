@@ -537,6 +537,8 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
     // ---- 2. eigenvectors X of A by iterative refinement from X = I; bx: X, by: A / S / E, bz: scratch
     int bx = oB1, by = oB0, bz = oB2;
     bool have_x = false, converged = false, fallback = !softabs;     // Metric.HESSIAN: G = A, no decomposition needed
+    bool implicit_e = false;          // the last update X (I + E) is applied to the vectors of the solve instead of being formed
+    const bool want_matrix = a.G_out || a.p_out;
     if (softabs) {
       for (int it = 0; it < 4 && !converged && !fallback; ++it) {
         if (it >= 2) {                                               // rare: A was consumed by the previous pass, form it again
@@ -562,6 +564,12 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
         HTA_STAMP(6 + 4 * it);
         if (emax > kFallbackE) { fallback = true; break; }
         __syncthreads();
+        if (have_x && !want_matrix && emax <= kConvE) {
+          // the converging pass of an evaluation that only solves: X2 = X (I + E) enters through X2^T m' = (I + E^T) X^T m'
+          // and X2 w = X (w + E w) - four matrix-vector products instead of one D^3 product (14.8 k of 116 k cycles at cfg3)
+          implicit_e = true; converged = true;
+          break;
+        }
         if (have_x) {
           lds_gemm<false, false, false, false>(bx, by, bz, bx, -1, nt, k4, LD);       // X <- X + X E
           __syncthreads();
@@ -609,16 +617,32 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
       logdet = block_sum(ld, red);
       // ---- 4. x = V0 X (X^T m' / lam~)
       if (a.m) {
-        const float y = ph_mv8(1, bx, LD, oM, D);
+        float y = ph_mv8(1, bx, LD, oM, D);
         const int row = opaque_tid() >> 3;
+        if (implicit_e) {                                       // y <- (I + E^T) y
+          __syncthreads();
+          if ((tid & 7) == 0 && row < DP) vy[row] = (row < D) ? y : 0.f;
+          __syncthreads();
+          y += ph_mv8(1, by, LD, oY, D);
+          __syncthreads();
+        }
         float qd = 0.f;
+        float wreg = 0.f;
         if ((tid & 7) == 0 && row < DP) {
           const float w = (row < D) ? y / vlt[row] : 0.f;
-          vy[row] = w;
+          wreg = w;
+          (implicit_e ? vx : vy)[row] = w;
           qd = (row < D) ? y * w : 0.f;
         }
         quad = block_sum(qd, red);
+        if (implicit_e) {                                       // w <- w + E w
+          const float ew = ph_mv8(0, by, LD, oX, D);
+          __syncthreads();
+          if ((tid & 7) == 0 && row < DP) vy[row] = (row < D) ? wreg + ew : 0.f;
+          __syncthreads();
+        }
         const float xp = ph_mv8(0, bx, LD, oY, D);
+        __syncthreads();
         if ((tid & 7) == 0 && row < DP) vx[row] = (row < D) ? xp : 0.f;
         __syncthreads();
         ph_stage(a.V0, by, D, DP, LD);                          // (the E buffer is dead)
