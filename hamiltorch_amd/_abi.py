@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhamiltorch_amd.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 MASS_NONE, MASS_DIAG, MASS_FULL = 0, 1, 2
 
@@ -37,7 +37,7 @@ class HtaMetricArgs(ctypes.Structure):
                 ("mu", c_vp), ("log_norm", c_f64), ("m", c_vp), ("p_out", c_vp), ("x_out", c_vp), ("G_out", c_vp),
                 ("lam_out", c_vp), ("V_out", c_vp), ("L_out", c_vp), ("logdet_out", c_vp), ("quad_out", c_vp),
                 ("H_out", c_vp), ("logp_out", c_vp), ("upd_x", c_vp), ("cx", c_f64), ("upd_g", c_vp), ("cg", c_f64),
-                ("V0", c_vp), ("lam0", c_vp), ("lamraw_out", c_vp), ("dmetric_out", c_vp)]
+                ("V0", c_vp), ("lam0", c_vp), ("lamraw_out", c_vp), ("dmetric_out", c_vp), ("v0_stride", c_i64)]
 
 
 METRIC_HESSIAN, METRIC_SOFTABS = 0, 1
@@ -305,7 +305,7 @@ def hmc_gaussian_leapfrog(theta, p, P, mu, mass_kind, inv_mass, steps, eps, path
 def metric_eval(like, B, D, metric, Hs, hs_stride, alpha, jitter=None, seed=0, chain_offset=0, draw=0, sub=0, X=None,
                 Pm=None, mu=None, log_norm=0.0, m=None, p_out=None, x_out=None, G_out=None, lam_out=None, V_out=None,
                 L_out=None, logdet_out=None, quad_out=None, H_out=None, logp_out=None, upd_x=None, cx=0.0, upd_g=None,
-                cg=0.0, max_sweeps=0, V0=None, lam0=None, lamraw_out=None, dmetric_out=None):
+                cg=0.0, max_sweeps=0, V0=None, lam0=None, lamraw_out=None, dmetric_out=None, v0_stride=0):
     """One batched metric evaluation (see HtaMetricArgs in include/hamiltorch_amd.h).  `like` fixes dtype/device."""
     require_device(like, "params")
     a = HtaMetricArgs()
@@ -313,6 +313,7 @@ def metric_eval(like, B, D, metric, Hs, hs_stride, alpha, jitter=None, seed=0, c
     a.has_jitter, a.jitter, a.max_sweeps = (0, 0.0, int(max_sweeps)) if jitter is None else (1, float(jitter), int(max_sweeps))
     a.seed, a.chain_offset, a.draw, a.sub = int(seed), int(chain_offset), int(draw) & 0xFFFFFFFF, int(sub)
     a.log_norm, a.cx, a.cg = float(log_norm), float(cx), float(cg)
+    a.v0_stride = int(v0_stride)
     keep = []
     for name, t in (("Hs", Hs), ("X", X), ("Pm", Pm), ("mu", mu), ("m", m), ("p_out", p_out), ("x_out", x_out),
                     ("G_out", G_out), ("lam_out", lam_out), ("V_out", V_out), ("L_out", L_out),
@@ -391,6 +392,7 @@ ACTS = {"relu": 0, "tanh": 1, "sigmoid": 2}
 LOSSES = {"regression": 0, "binary_class_linear_output": 1}       # HTA_LOSS_REGRESSION / HTA_LOSS_BINARY_LOGITS
 NET_LOSSES = dict(LOSSES, multi_class_linear_output=2)             # + HTA_LOSS_SOFTMAX_CE (hta_netn_* only)
 NETN_MAX_LAYERS, NETN_MAX_WIDTH, NETN_MAX_PARAMS, NETN_MAX_BLOCKS = 4, 64, 512, 96     # csrc/netn_hmc.hip (blocks of 4 x 4 weights)
+METRIC_MFMA_MAX_D = 112                                                                # csrc/rmhmc_metric_mfma.hip (metric_warm_mfma_eligible)
 MLP3_MAX_IN, MLP3_MAX_WIDTH = 4, 104                                                   # csrc/mlp3_mfma.hip (M3_NIN, M3_HMAX)
 
 

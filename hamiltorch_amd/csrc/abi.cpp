@@ -36,7 +36,7 @@ int g_gauss_eig = 1;       // small-D identity-mass Gaussian HMC integrates in t
 int g_fill_blocks = 4096;        // grid cap of the pre-draw pass (256-thread blocks, grid-stride)
 int g_quad_max_chains = 65536;   // up to here a chain takes a DPP quad (one eigen-coordinate per lane), beyond a lane
 int g_rmhmc_fused = 1;           // 0 = per-evaluation Jacobi path, 3 = fused with two chains per workgroup (parity tests)
-extern int g_metric_mfma, g_rmhmc_wide;         // rmhmc_metric_mfma.hip
+extern int g_metric_mfma, g_metric_general, g_rmhmc_wide;         // rmhmc_metric_mfma.hip, rmhmc_fused.hip
 int g_mlp_valu = 0;               // 1 = keep the Bayesian-MLP sampler on the VALU kernel (parity tests of both)
 int g_mlp3_route = 1;             // csrc/mlp3_mfma.hip (two wide hidden layers on the matrix cores); 0 = such models stay on the callback path
 
@@ -101,7 +101,7 @@ const TuneKey kTune[] = {
     {"rmhmc_pair", &hta::g_rmhmc_pair, 1}, {"rmhmc_wide", &hta::g_rmhmc_wide, 1}, {"rmhmc_overlap", &hta::g_rmhmc_overlap, 0},
     {"rmhmc_momsplit", &hta::g_rmhmc_momsplit, 1},
     {"rmhmc_batch", &hta::g_rmhmc_batch, 1}, {"quad_max_chains", &hta::g_quad_max_chains, 65536}, {"fill_blocks", &hta::g_fill_blocks, 4096},
-    {"mlp_valu", &hta::g_mlp_valu, 0}, {"metric_mfma", &hta::g_metric_mfma, 1}, {"rmhmc_fused", &hta::g_rmhmc_fused, 1},
+    {"mlp_valu", &hta::g_mlp_valu, 0}, {"metric_mfma", &hta::g_metric_mfma, 1}, {"metric_general", &hta::g_metric_general, 1}, {"rmhmc_fused", &hta::g_rmhmc_fused, 1},
     {"mlp3_route", &hta::g_mlp3_route, 1},
 };
 }  // namespace

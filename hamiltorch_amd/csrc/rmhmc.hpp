@@ -16,11 +16,13 @@ template <typename T> struct MetricArgsT {   // typed view of HtaMetricArgs (inc
   T* upd_x; double cx; T* upd_g; double cg;
   const T* V0; const T* lam0; T* lamraw_out;
   T* dmetric_out;
+  int64_t v0_stride;           // elements between consecutive systems' V0 (0: one basis shared by all systems)
 };
 static_assert(sizeof(MetricArgsT<float>) == sizeof(HtaMetricArgs), "HtaMetricArgs layout drifted from MetricArgsT");
 
 template <typename T> int metric_eval(const MetricArgsT<T>& a, hipStream_t s);
 extern int g_metric_mfma;                                   // tuning key "metric_mfma" (default 1)
+extern int g_metric_general;                                // tuning key "metric_general" (default 1): per-system bases on the matrix cores
 bool metric_warm_mfma_eligible(const MetricArgsT<float>& a);
 int metric_warm_mfma(const MetricArgsT<float>& a, hipStream_t s);     // rmhmc_metric_mfma.hip
 

@@ -30,6 +30,7 @@
 namespace hta {
 
 int g_metric_mfma = 1;   // tuning key "metric_mfma": 1 = warm fp32 evaluations run here, 0 = always the Jacobi kernel
+int g_metric_general = 1;   // tuning key "metric_general": 1 = evaluations with per-system curvature AND per-system bases run here too
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -470,6 +471,62 @@ __device__ __attribute__((noinline)) float ph_mv8_lower(int offM, int ld, int of
   return mv8_lower(lds + HTA_U(offM), HTA_U(ld), lds + HTA_U(offV), HTA_U(n));
 }
 
+// a zero-padded [DP][LD] copy of the symmetric matrix whose LOWER triangle is in global memory (eigh UPLO = 'L', S:119), jitter
+// (LDS vector at offJit) added on the diagonal
+__device__ __attribute__((noinline)) void ph_stage_sym(const float* src, int offDst, int offJit, int D, int DP, int LD) {
+  HTA_LDS_BASE();
+  D = HTA_U(D); DP = HTA_U(DP); LD = HTA_U(LD);
+  float* dst = lds + HTA_U(offDst); const float* vj = lds + HTA_U(offJit);
+  gcf g = (gcf)src;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float v[7];
+    const int j = lane + 64 * h;
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const int i = wave + 16 * t;
+      v[t] = (i < D && j < D) ? (i >= j ? g[i * D + j] : g[j * D + i]) : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 7; ++t) { const int i = wave + 16 * t; if (i < DP && j < LD) dst[i * LD + j] = v[t] + ((i == j && i < D) ? vj[i] : 0.f); }
+  }
+}
+
+// [D][D] row-major global <- the leading block of an LDS matrix
+__device__ __attribute__((noinline)) void ph_store_dense(float* dstg, int offSrc, int D, int LD) {
+  HTA_LDS_BASE();
+  D = HTA_U(D); LD = HTA_U(LD);
+  const float* src = lds + HTA_U(offSrc);
+  __attribute__((address_space(1))) float* g = (__attribute__((address_space(1))) float*)dstg;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = wave; i < D; i += MT / 64)
+    for (int j = lane; j < D; j += 64) g[i * D + j] = src[i * LD + j];
+}
+
+// W of the derivative matrix M = Q W Q^T (HtaMetricArgs::dmetric_out; the same formula as metric_eval_kernel):
+// W_kl = 1/2 [k == l] lam~'_k / lam~_k - 1/2 J_kl u_k u_l,  J = divided differences of lam -> lam~, zero padded
+__device__ __attribute__((noinline)) void ph_dmetric_w(int offDst, int offLam, int offLt, int offU, float alpha, int D, int DP, int LD) {
+  HTA_LDS_BASE();
+  D = HTA_U(D); DP = HTA_U(DP); LD = HTA_U(LD);
+  float* dst = lds + HTA_U(offDst);
+  const float* vlam = lds + HTA_U(offLam); const float* vlt = lds + HTA_U(offLt); const float* vu = lds + HTA_U(offU);
+  const int l = threadIdx.x & 127;
+  for (int k = threadIdx.x >> 7; k < DP; k += MT / 128) {
+    if (l >= LD) continue;
+    float w = 0.f;
+    if (k < D && l < D) {
+      const float lk = vlam[k], ll = vlam[l], dl = lk - ll;
+      float J;
+      if (k == l || fabsf(dl) <= 1e-3f * (fabsf(lk) + fabsf(ll))) J = softabs_slope<float>(alpha, 0.5f * (lk + ll));
+      else J = (vlt[k] - vlt[l]) / dl;
+      w = -0.5f * J * vu[k] * vu[l];
+      if (k == l) w += 0.5f * softabs_slope<float>(alpha, lk) / vlt[k];
+    }
+    dst[k * LD + l] = w;
+  }
+}
+
 // The thread index, opaque to the optimiser.  Per-lane global addresses (a.m + b D + i, a.upd_x + b D + row, ...) derived from
 // the plain index were computed at the top of the kernel and kept across its 30 out-of-line phase calls - i.e. spilled to
 // scratch memory at the 128-register cap of a 1024-thread workgroup (14 stores at the top, 13 reloads scattered over the
@@ -501,9 +558,15 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
   float* vjit = lds0 + oJit; float* vlam = lds0 + oLam; float* vlt = lds0 + oLt; float* vm = lds0 + oM; float* vy = lds0 + oY;
   float* vx = lds0 + oX; float* vd = lds0 + oD; float* red = lds0 + oRed;
   const bool softabs = a.metric == 1;
+  // GENERAL mode (round 3): every system has its own curvature Hs_b AND its own approximate eigenbasis V0_b (the caller's
+  // previous evaluation at that chain): A = V0_b^T (Hs_b + diag(e)) V0_b by two products, the refinement where its coupling
+  // test passes, the in-launch Jacobi (on the nearly diagonal A: few sweeps) where it does not; V_out = V0_b X is the
+  // basis for the caller's next call.  lam0 is not used.
+  const bool general = softabs && a.hs_stride != 0;
 
   for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
     const uint64_t chain = a.chain_offset + (uint64_t)b;
+    const float* V0b = a.V0 + (general ? b * a.v0_stride : 0);
     __syncthreads();
     HTA_STAMP(0);
     // ---- 0. operands: jitter, the solve vector, d = X - mu; V0 into LDS
@@ -513,7 +576,7 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
       vm[i] = (i < D && a.m) ? a.m[b * D + i] : 0.f;
       vd[i] = (i < D && a.X) ? a.X[b * D + i] - a.mu[i] : 0.f;
     }
-    if (softabs) ph_stage(a.V0, oB1, D, DP, LD);
+    if (softabs) ph_stage(V0b, oB1, D, DP, LD);
     __syncthreads();
     HTA_STAMP(1);
     // ---- Gaussian log-prob and P (X - mu)
@@ -526,21 +589,29 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
       if ((tid & 7) == 0 && (tid >> 3) < DP) vm[tid >> 3] = ((tid >> 3) < D) ? v : 0.f;
     }
     HTA_STAMP(2);
-    // ---- 1. A = diag(lam0) + V0^T diag(e) V0 into buffer 0 (symmetric, zero padded)
-    if (softabs) {
+    // ---- 1. A = diag(lam0) + V0^T diag(e) V0 into buffer 0 (symmetric, zero padded); general: A = V0^T (Hs + diag(e)) V0 into buffer 2
+    int bx = oB1, by = oB0, bz = oB2;
+    if (softabs && !general) {
       lds_gemm<true, false, true, true>(oB1, oB1, oB0, -1, oJit, nt, k4, LD);
       __syncthreads();
       { const int i = opaque_tid(); if (i < D) lds0[oB0 + i * LD + i] += a.lam0[i]; }
+    } else if (general) {
+      ph_stage_sym(a.Hs + b * a.hs_stride, oB2, oJit, D, DP, LD);
+      __syncthreads();
+      lds_gemm<false, false, false, false>(oB2, oB1, oB0, -1, -1, nt, k4, LD);          // T = (Hs + diag e) V0
+      __syncthreads();
+      lds_gemm<true, false, true, false>(oB1, oB0, oB2, -1, -1, nt, k4, LD);            // A = V0^T T
+      by = oB2; bz = oB0;
     }
     __syncthreads();
     HTA_STAMP(3);
     // ---- 2. eigenvectors X of A by iterative refinement from X = I; bx: X, by: A / S / E, bz: scratch
-    int bx = oB1, by = oB0, bz = oB2;
     bool have_x = false, converged = false, fallback = !softabs;     // Metric.HESSIAN: G = A, no decomposition needed
     bool implicit_e = false;          // the last update X (I + E) is applied to the vectors of the solve instead of being formed
-    const bool want_matrix = a.G_out || a.p_out;
+    const bool want_matrix = a.G_out || a.p_out || a.V_out || a.dmetric_out;
     if (softabs) {
       for (int it = 0; it < 4 && !converged && !fallback; ++it) {
+        if (it >= 2 && general) { fallback = true; break; }          // (forming A again needs all three buffers: the Jacobi path does it)
         if (it >= 2) {                                               // rare: A was consumed by the previous pass, form it again
           ph_stage(a.V0, bz, D, DP, LD);
           __syncthreads();
@@ -584,11 +655,22 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
       if (fallback) {
         // cyclic Jacobi on A (rmhmc_metric_dev.hpp): no assumption on gaps or perturbation size
         __syncthreads();
-        ph_stage(a.V0, bz, D, DP, LD);
+        if (general) {                                               // A again: V0 -> bx, Hs -> bz, T -> by, A -> bz; then A lives in `by`
+          ph_stage(V0b, bx, D, DP, LD);
+          ph_stage_sym(a.Hs + b * a.hs_stride, bz, oJit, D, DP, LD);
+          __syncthreads();
+          lds_gemm<false, false, false, false>(bz, bx, by, -1, -1, nt, k4, LD);
+          __syncthreads();
+          lds_gemm<true, false, true, false>(bx, by, bz, -1, -1, nt, k4, LD);
+          const int t = by; by = bz; bz = t;
+        } else {
+          ph_stage(a.V0, bz, D, DP, LD);
+          __syncthreads();
+          lds_gemm<true, false, true, true>(bz, bz, by, -1, oJit, nt, k4, LD);
+          __syncthreads();
+          if (tid < D) lds0[by + tid * LD + tid] += a.lam0[tid];
+        }
         __syncthreads();
-        lds_gemm<true, false, true, true>(bz, bz, by, -1, oJit, nt, k4, LD);
-        __syncthreads();
-        if (tid < D) lds0[by + tid * LD + tid] += a.lam0[tid];
         for (int e = tid; e < DP * LD; e += MT) { const int i = e / LD, j = e - i * LD; lds0[bz + e] = (i == j && i < D) ? 1.f : 0.f; }
         __syncthreads();
         jacobi_fallback(by, bz, D, ne, LD, oJit, oRed, a.max_sweeps);
@@ -645,7 +727,7 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
         __syncthreads();
         if ((tid & 7) == 0 && row < DP) vx[row] = (row < D) ? xp : 0.f;
         __syncthreads();
-        ph_stage(a.V0, by, D, DP, LD);                          // (the E buffer is dead)
+        ph_stage(V0b, by, D, DP, LD);                           // (the E buffer is dead)
         __syncthreads();
         const float x = ph_mv8(0, by, LD, oX, D);
         const int orow = opaque_tid() >> 3;
@@ -655,15 +737,40 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
         }
       }
     }
+    // ---- 4b. the eigenbasis itself (V_out: the next call's warm start) and the derivative matrix M = Q W Q^T (dmetric_out)
+    bool q_ready = false;
+    if (softabs && (a.V_out || a.dmetric_out)) {
+      __syncthreads();
+      if (!a.m && tid < DP) vy[tid] = 0.f;                            // u = Q^T m / lam~ (vy holds it after the solve)
+      ph_stage(V0b, by, D, DP, LD);
+      __syncthreads();
+      lds_gemm<false, false, false, false>(by, bx, bz, -1, -1, nt, k4, LD);             // Q = V0 X
+      __syncthreads();
+      if (a.V_out) ph_store_dense(a.V_out + b * D * D, bz, D, LD);
+      if (a.dmetric_out) {
+        ph_dmetric_w(by, oLam, oLt, oY, (float)a.alpha, D, DP, LD);
+        __syncthreads();
+        lds_gemm<false, true, false, false>(by, bz, bx, -1, -1, nt, k4, LD);            // T = W Q^T
+        __syncthreads();
+        lds_gemm<false, false, true, false>(bz, bx, by, -1, -1, nt, k4, LD);            // M = Q T (symmetric)
+        __syncthreads();
+        ph_store_dense(a.dmetric_out + b * D * D, by, D, LD);
+        __syncthreads();
+      } else {
+        q_ready = true;                                               // bz = Q, bx = X still: step 5 must not stage V0 again (V_out may alias it)
+      }
+    }
     HTA_STAMP(21);
     // ---- 5. G = Q diag(lam~) Q^T, Q = V0 X  (S:121) for fisher() / the momentum draw; Metric.HESSIAN: G = Hs itself
     if (a.G_out || a.p_out || !softabs) {
       __syncthreads();
       int g = bz;
       if (softabs) {
-        ph_stage(a.V0, by, D, DP, LD);
-        __syncthreads();
-        lds_gemm<false, false, false, false>(by, bx, bz, -1, -1, nt, k4, LD);         // Q = V0 X
+        if (!q_ready) {
+          ph_stage(V0b, by, D, DP, LD);
+          __syncthreads();
+          lds_gemm<false, false, false, false>(by, bx, bz, -1, -1, nt, k4, LD);       // Q = V0 X
+        }
         __syncthreads();
         lds_gemm<false, true, true, true>(bz, bz, by, -1, oLt, nt, k4, LD);           // G = Q (diag(lam~) Q^T)
         g = by;
@@ -722,9 +829,14 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
 }
 
 bool metric_warm_mfma_eligible(const MetricArgsT<float>& a) {
-  if (!g_metric_mfma || a.D < 1 || a.D > 112 || a.dmetric_out || a.V_out || a.L_out) return false;
-  if (a.metric == 1) return a.V0 && a.lam0 && a.hs_stride == 0;      // soft-abs: evaluations that share an eigenbasis
-  return a.metric == 0;                                               // Metric.HESSIAN: Cholesky + solve, any curvature input
+  if (!g_metric_mfma || a.D < 1 || a.D > 112 || a.L_out) return false;
+  if (a.metric == 1) {
+    if (a.hs_stride == 0) return a.V0 && a.lam0 && !a.dmetric_out && !a.V_out;      // soft-abs: evaluations that share an eigenbasis
+    // per-system curvature with per-system bases (a general target's chains, each warm-started from its previous evaluation);
+    // G_out / p_out together with dmetric_out is not a combination the kernel keeps X for
+    return g_metric_general && a.V0 && a.v0_stride != 0 && !(a.dmetric_out && (a.G_out || a.p_out));
+  }
+  return a.metric == 0 && !a.dmetric_out && !a.V_out;                 // Metric.HESSIAN: Cholesky + solve, any curvature input
 }
 
 int metric_warm_mfma(const MetricArgsT<float>& a, hipStream_t s) {

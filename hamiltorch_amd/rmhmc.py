@@ -21,6 +21,8 @@ with ``vmap``.  Eight metric evaluations per step, each with its own jitter sub-
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _abi, util
@@ -186,30 +188,60 @@ class _Curvature:
         return self._try(self._third, looped, theta, M).to(theta.dtype, copy=True).contiguous()
 
 
-def _generic_steps(cv, kind, th, pm, thc, pmc, steps, eps, omega, alpha, jitter, seed, chain_offset, draw, path=None):
+class _WarmBases:
+    """Per-chain eigenbases carried from one metric evaluation of a general target to the next (HtaMetricArgs.v0_stride,
+    ABI 7): `kw(slot)` = the V0 / v0_stride / V_out arguments of `_abi.metric_eval` for the chains' state `slot` ("a": the
+    state set (theta, p), "b": the explicit integrator's copy) - a [C, D, D] tensor, the identity before the first call,
+    updated in place by every call.  The evaluation then runs on the matrix cores (csrc/rmhmc_metric_mfma.hip): the
+    curvature rotated into the previous basis is nearly diagonal, so it is refined (or finished by a few Jacobi sweeps
+    inside the launch) instead of being diagonalised from scratch - a hint only, results agree to rounding.
+    fp32, soft-abs, D <= 112 on the device; otherwise `kw` is empty and the evaluation is the cold one."""
+
+    def __init__(self, like, kind):
+        C, D = like.shape
+        self.on = (kind == _abi.METRIC_SOFTABS and like.dtype == torch.float32 and like.is_cuda and D <= _abi.METRIC_MFMA_MAX_D
+                   and os.environ.get("HAMILTORCH_AMD_WARM_METRIC", "1") != "0")
+        self.like, self.bufs = like, {}
+
+    def kw(self, slot):
+        if not self.on:
+            return {}
+        buf = self.bufs.get(slot)
+        if buf is None:
+            C, D = self.like.shape
+            buf = torch.eye(D, dtype=self.like.dtype, device=self.like.device).repeat(C, 1, 1).contiguous()
+            self.bufs[slot] = buf
+        D = buf.shape[-1]
+        return {"V0": buf, "v0_stride": D * D, "V_out": buf}
+
+
+def _generic_steps(cv, kind, th, pm, thc, pmc, steps, eps, omega, alpha, jitter, seed, chain_offset, draw, path=None, warm=None):
     """S:425-461 on the augmented state, in place.  Unlike the constant-curvature path, dH/dtheta depends on the
     metric here, so each of the reference's 8 gradient calls per step keeps its own metric evaluation and jitter
     sub-stream (2 + 8 l + k, k = 0..7 in the reference's call order)."""
     C, D = th.shape                 # Metric.HESSIAN needs a log-concave target (G = -Hessian positive definite), as in the reference
     eh = 0.5 * eps
     M = torch.empty(C, D, D, dtype=th.dtype, device=th.device)
+    warm = warm if warm is not None else _WarmBases(th, kind)
 
-    def kick(theta, mvec, upd, sub):            # upd -= eh dH/dtheta(theta, mvec),  dH/dtheta = -(g + c)   (S:395-398)
+    def kick(theta, mvec, upd, sub, slot):      # upd -= eh dH/dtheta(theta, mvec),  dH/dtheta = -(g + c)   (S:395-398)
         g, Hs = cv.grad_neg_hessian(theta)
-        _abi.metric_eval(theta, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, draw, sub, m=mvec, dmetric_out=M)
+        _abi.metric_eval(theta, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, draw, sub, m=mvec, dmetric_out=M,
+                         **warm.kw(slot))
         upd.add_(g + cv.contract(theta, M), alpha=eh)
 
-    def drift(theta, mvec, upd, sub):           # upd += eh dH/dp(theta, mvec) = eh G^-1 mvec              (S:415-422)
+    def drift(theta, mvec, upd, sub, slot):     # upd += eh dH/dp(theta, mvec) = eh G^-1 mvec              (S:415-422)
         _, Hs = cv.grad_neg_hessian(theta)
-        _abi.metric_eval(theta, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, draw, sub, m=mvec, upd_x=upd, cx=eh)
+        _abi.metric_eval(theta, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, draw, sub, m=mvec, upd_x=upd, cx=eh,
+                         **warm.kw(slot))
 
     for l in range(steps):
         k0 = 2 + 8 * l
-        kick(th, pmc, pm, k0 + 0); drift(th, pmc, thc, k0 + 1)                     # phi_A(1/2)  S:429-430
-        drift(thc, pm, th, k0 + 2); kick(thc, pm, pmc, k0 + 3)                     # phi_B(1/2)  S:432-433
+        kick(th, pmc, pm, k0 + 0, "a"); drift(th, pmc, thc, k0 + 1, "a")           # phi_A(1/2)  S:429-430
+        drift(thc, pm, th, k0 + 2, "b"); kick(thc, pm, pmc, k0 + 3, "b")           # phi_B(1/2)  S:432-433
         _abi.rmhmc_binding_rotation(th, pm, thc, pmc, eps, omega)                  # phi_C       S:447-450
-        drift(thc, pm, th, k0 + 4); kick(thc, pm, pmc, k0 + 5)                     # phi_B(1/2)  S:454-455
-        kick(th, pmc, pm, k0 + 6); drift(th, pmc, thc, k0 + 7)                     # phi_A(1/2)  S:457-458
+        drift(thc, pm, th, k0 + 4, "b"); kick(thc, pm, pmc, k0 + 5, "b")           # phi_B(1/2)  S:454-455
+        kick(th, pmc, pm, k0 + 6, "a"); drift(th, pmc, thc, k0 + 7, "a")           # phi_A(1/2)  S:457-458
         if path is not None:
             path[0][l].copy_(th); path[1][l].copy_(pm)
 
@@ -314,17 +346,19 @@ def _sample_explicit_generic(log_prob_func, theta0, N, L, eps, burn, jitter, alp
     rejected = torch.zeros(C, dtype=torch.int32, device=dev)
     H0 = torch.empty(C, dtype=dt, device=dev); H1 = torch.empty_like(H0)
     pm = torch.empty_like(cur)
+    warm = _WarmBases(cur, kind)
     prog = util._Progress('Sampling (Sampler.RMHMC; Integrator.EXPLICIT)', N, verbose)
     for n in range(N):
         _, Hs = cv.grad_neg_hessian(cur)
-        _abi.metric_eval(cur, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, n, 0, p_out=pm)        # S:183-184
-        _abi.metric_eval(cur, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, n, 1, m=pm, H_out=H0)  # S:971
+        _abi.metric_eval(cur, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, n, 0, p_out=pm, **warm.kw("a"))        # S:183-184
+        _abi.metric_eval(cur, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, n, 1, m=pm, H_out=H0, **warm.kw("a"))  # S:971
         H0.sub_(cv.value(cur))
         th, thc, pmc = cur.clone(), cur.clone(), pm.clone()
-        _generic_steps(cv, kind, th, pm, thc, pmc, L, eps, omega, alpha, jitter, seed, chain_offset, n)
+        _generic_steps(cv, kind, th, pm, thc, pmc, L, eps, omega, alpha, jitter, seed, chain_offset, n, warm=warm)
         _, Hs1 = cv.grad_neg_hessian(th)
         lp1 = cv.value(th)
-        _abi.metric_eval(th, C, D, kind, Hs1, D * D, alpha, jitter, seed, chain_offset, n, 2 + 8 * L, m=pm, H_out=H1)  # S:989
+        _abi.metric_eval(th, C, D, kind, Hs1, D * D, alpha, jitter, seed, chain_offset, n, 2 + 8 * L, m=pm, H_out=H1,
+                         **warm.kw("a"))                                                                                          # S:989
         H1.sub_(lp1)
         row = samples[n - burn] if n > burn else None
         _abi.mh_select(cur, th, theta0, H0, H1, lp1, row, rejected, None, n, burn, seed, chain_offset)
@@ -341,22 +375,26 @@ def _implicit_subs(max_it):
     return 2 * int(max_it) + 2
 
 
-def _implicit_steps(cv, kind, th, pm, steps, eps, alpha, jitter, seed, chain_offset, draw, thr, max_it, sub0=2, path=None):
+def _implicit_steps(cv, kind, th, pm, steps, eps, alpha, jitter, seed, chain_offset, draw, thr, max_it, sub0=2, path=None,
+                    warm=None):
     """S:312-383 for a batch of chains, in place on (th, pm).  Chains leave a fixed-point loop individually once their
     own max squared update is below `thr` (the reference's `break`); the loop ends when none is left or after max_it."""
     C, D = th.shape
     hs = 0.5 * eps
     M = torch.empty(C, D, D, dtype=th.dtype, device=th.device)
     x = torch.empty_like(th)
+    warm = warm if warm is not None else _WarmBases(th, kind)
 
     def dH_dtheta(theta, mvec, sub):                     # S:318-319 / S:368-369: -(g + c)
         g, Hs = cv.grad_neg_hessian(theta)
-        _abi.metric_eval(theta, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, draw, sub, m=mvec, dmetric_out=M)
+        _abi.metric_eval(theta, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, draw, sub, m=mvec, dmetric_out=M,
+                         **warm.kw("a"))
         return -(g + cv.contract(theta, M))
 
     def dH_dp(theta, mvec, sub):                         # S:346-347, S:352-353: G^-1 p
         _, Hs = cv.grad_neg_hessian(theta)
-        _abi.metric_eval(theta, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, draw, sub, m=mvec, x_out=x)
+        _abi.metric_eval(theta, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, draw, sub, m=mvec, x_out=x,
+                         **warm.kw("a"))
         return x.clone()
 
     def fixed_point(state, update):
@@ -415,18 +453,19 @@ def sample_implicit(log_prob_func, theta0, N, L, eps, burn, jitter, alpha, metri
     rejected = torch.zeros(C, dtype=torch.int32, device=dev)
     H0 = torch.empty(C, dtype=dt, device=dev); H1 = torch.empty_like(H0)
     pm = torch.empty_like(cur)
+    warm = _WarmBases(cur, kind)
     prog = util._Progress('Sampling (Sampler.RMHMC; Integrator.IMPLICIT)', N, verbose)
     for n in range(N):
         _, Hs = cv.grad_neg_hessian(cur)
-        _abi.metric_eval(cur, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, n, 0, p_out=pm)        # S:183-184
-        _abi.metric_eval(cur, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, n, 1, m=pm, H_out=H0)  # S:971
+        _abi.metric_eval(cur, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, n, 0, p_out=pm, **warm.kw("a"))        # S:183-184
+        _abi.metric_eval(cur, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, n, 1, m=pm, H_out=H0, **warm.kw("a"))  # S:971
         H0.sub_(cv.value(cur))
         th = cur.clone()
-        _implicit_steps(cv, kind, th, pm, L, eps, alpha, jitter, seed, chain_offset, n, thr, max_it)
+        _implicit_steps(cv, kind, th, pm, L, eps, alpha, jitter, seed, chain_offset, n, thr, max_it, warm=warm)
         _, Hs1 = cv.grad_neg_hessian(th)
         lp1 = cv.value(th)
         _abi.metric_eval(th, C, D, kind, Hs1, D * D, alpha, jitter, seed, chain_offset, n, 2 + L * _implicit_subs(max_it),
-                         m=pm, H_out=H1)                                                                      # S:989
+                         m=pm, H_out=H1, **warm.kw("a"))                                                      # S:989
         H1.sub_(lp1)
         row = samples[n - burn] if n > burn else None
         _abi.mh_select(cur, th, theta0, H0, H1, lp1, row, rejected, None, n, burn, seed, chain_offset)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HTA_ABI_VERSION 6
+#define HTA_ABI_VERSION 7
 
 #define HTA_OK 0
 #define HTA_ERR_INVALID (-1)   /* bad argument                           */
@@ -206,6 +206,15 @@ typedef struct HtaMetricArgs {
                                                 M = Q W Q^T, W_kl = 1/2 [k==l] lam~'_k / lam~_k - 1/2 J_kl u_k u_l,
                                                 u = Q^T m / lam~, J = divided differences of lam -> lam~ (Daleckii-Krein);
                                                 HESSIAN metric: M = 1/2 G^-1 - 1/2 v v^T, v = G^-1 m                */
+  int64_t v0_stride;                         /* (ABI 7) elements between consecutive systems' V0; 0 = one shared basis (above).
+                                                D*D together with hs_stride = D*D: PER-SYSTEM warm start for general targets -
+                                                V0[b] is an approximate orthonormal eigenbasis of Hs[b] (columns), typically the
+                                                V_out of the previous evaluation at that chain (V_out may alias V0: the basis is
+                                                updated in place); lam0 is not used.  fp32, D <= 112, SOFTABS: the evaluation runs
+                                                on the matrix cores (csrc/rmhmc_metric_mfma.hip: V0^T Hs V0, iterative refinement,
+                                                Jacobi inside the launch where the refinement's coupling test fails); elsewhere
+                                                the hint is ignored (cold Jacobi), results agree to rounding either way.
+                                                A first call passes the identity.                                    */
 } HtaMetricArgs;
 
 int hta_metric_eval_f32(const HtaMetricArgs* args, void* stream);
@@ -362,6 +371,8 @@ int hta_netn_logp_grad_f64(const double* theta, int64_t C, int n_layers, const i
  * instances of the one-chain kernel when chains <= compute units; 0 = always the two-workgroups-per-CU instances), "rmhmc_momwave" (1 default: one wave per momentum draw, fp32 with jitter, D <= 104; 0 = one workgroup per draw), "mlp_valu" (1 = VALU MLP kernel instead of the MFMA one),
  * "metric_mfma" (1 default: fp32 metric evaluations that share an eigenbasis, and Metric.HESSIAN ones, run on the matrix cores -
  * csrc/rmhmc_metric_mfma.hip, D <= 112; 0 = always the Jacobi kernel of csrc/rmhmc_metric.hip),
+ * "metric_general" (1 default: evaluations with per-system curvature and per-system warm bases - HtaMetricArgs::v0_stride - run on
+ * that kernel too; 0 = the Jacobi kernel, cold),
  * "mlp3_route" (1 default: Bayesian MLPs with two wide hidden layers run on csrc/mlp3_mfma.hip; 0 = callback path). */
 int hta_set_tuning(const char* key, int value);
 /* current value of a route key; every key back to its default (test fixtures call this between tests: the keys are

@@ -911,3 +911,93 @@ def test_prepared_workspace_gives_identical_results_and_skips_the_setup(ht):
     t2 = ht.GaussianTarget(t.mean.clone(), precision=t.precision.clone(), normalized=False)
     d = torch.stack(ht.sample(t2, th0, **kw))
     assert torch.equal(c, d) and not torch.equal(c, a)
+
+
+# ---- per-system curvature with per-system warm bases on the matrix cores (HtaMetricArgs.v0_stride, ABI 7) -------------------
+@pytest.mark.parametrize("D,kind,alpha,jitter,start", [(100, "spd", 1e6, 1e-3, "near"), (100, "indef", 1.0, None, "near"),
+                                                       (37, "indef", 0.7, 1e-3, "near"), (64, "spd", 1e6, None, "identity"),
+                                                       (100, "indef", 1e6, 1e-3, "identity"), (48, "degenerate", 1e6, 1e-3, "near"),
+                                                       (16, "degenerate", 2.0, None, "identity"), (112, "spd", 0.05, 1e-3, "far"),
+                                                       (11, "indef", 1e6, 1e-2, "near"), (5, "spd", 1e6, None, "identity")])
+def test_metric_general_targets_on_the_matrix_cores_vs_oracle(ht, D, kind, alpha, jitter, start):
+    """hta_metric_eval with one curvature matrix AND one approximate eigenbasis per system (what the chains of a general target
+    hand over from their previous evaluation): metric_warm_mfma_kernel rotates Hs_b into V0_b, refines (start "near": the exact
+    basis of a slightly different matrix) or finishes with Jacobi inside the launch (start "identity" / "far", degenerate spectra),
+    and returns G^-1 m, log|G|, the soft-abs spectrum, the derivative matrix M (dmetric_out), G, the momentum draw and the NEW
+    basis (V_out, written over V0) - each against the oracle's float64 eigh, and against the cold Jacobi kernel
+    (hta_set_tuning("metric_general", 0)).  A second call from the returned basis must reproduce the results."""
+    from hamiltorch_amd import _abi
+    rng = np.random.default_rng(7 * D + len(kind))
+    B, seed, off, draw = 9, 5, 2, 4
+    Hs = sym_batch(B, D, kind, D + 3)
+    if start == "near":      # eigenvectors of Hs + a 1 % symmetric perturbation
+        E = rng.standard_normal((B, D, D)); E = 0.01 * (E + E.transpose(0, 2, 1)) / np.sqrt(D)
+        V0 = np.linalg.eigh(Hs + E)[1]
+    elif start == "far":
+        V0 = np.stack([np.linalg.qr(rng.standard_normal((D, D)))[0] for _ in range(B)])
+    else:
+        V0 = np.broadcast_to(np.eye(D), (B, D, D)).copy()
+    m = rng.standard_normal((B, D)).astype(np.float32)
+    dt = torch.float32
+    Hd, md = tt(Hs, dt), tt(m, dt)
+
+    def run(general, V0np, sub, want):
+        _abi.set_tuning("metric_general", general)
+        out = {k: torch.empty(s, device=dev()) for k, s in (("x", (B, D)), ("ld", (B,)), ("q", (B,)), ("lam", (B, D)), ("M", (B, D, D)),
+                                                              ("G", (B, D, D)), ("p", (B, D)))}
+        Vb = tt(V0np, dt).contiguous()
+        kw = dict(V0=Vb, v0_stride=D * D, V_out=Vb)
+        if want == "solve":
+            _abi.metric_eval(md, B, D, _abi.METRIC_SOFTABS, Hd, D * D, alpha, jitter, seed, off, draw, sub, m=md, x_out=out["x"],
+                             logdet_out=out["ld"], quad_out=out["q"], lam_out=out["lam"], dmetric_out=out["M"], **kw)
+        else:
+            _abi.metric_eval(md, B, D, _abi.METRIC_SOFTABS, Hd, D * D, alpha, jitter, seed, off, draw, sub, G_out=out["G"], p_out=out["p"], **kw)
+        route = _abi.last_route()
+        torch.cuda.synchronize()
+        res = {k: v.cpu().numpy().astype(np.float64) for k, v in out.items()}
+        res["V"] = Vb.cpu().numpy().astype(np.float64)
+        return res, route
+
+    a, route = run(1, V0, 2, "solve")
+    assert route == "metric_warm_mfma_kernel", route
+    j, route_j = run(0, V0, 2, "solve")
+    assert route_j.startswith("metric_eval_kernel"), route_j
+    ju = None if jitter is None else O.philox_uniforms(seed, off + np.arange(B), draw, D, O.PURPOSE_JITTER, 2, dtype=np.float64)
+    G, lam, _ = O.softabs_metric(Hs, alpha, jitter, ju)
+    M64, x64 = O.softabs_dmetric(Hs, alpha, m, jitter, ju)
+    cond = np.abs(lam).max() / np.abs(lam).min()
+    tol = 4e-4
+    for got in (a, j):
+        np.testing.assert_allclose(got["x"], x64, rtol=tol * cond, atol=tol * cond * np.abs(x64).max())
+        np.testing.assert_allclose(got["ld"], np.log(lam).sum(1), rtol=tol, atol=tol * D)
+        np.testing.assert_allclose(got["q"], (m * x64).sum(1), rtol=tol * cond, atol=tol * cond)
+        np.testing.assert_allclose(np.sort(got["lam"], axis=1), np.sort(lam, axis=1), rtol=tol, atol=tol * np.abs(lam).max())
+    # the derivative matrix: the divided differences are sensitive where eigenvalues nearly coincide - compare the kernels with
+    # each other tightly and the matrix-core kernel with float64 on the scale of M
+    np.testing.assert_allclose(a["M"], j["M"], rtol=0, atol=3e-3 * cond * np.abs(M64).max())
+    if kind != "degenerate":
+        np.testing.assert_allclose(a["M"], M64, rtol=0, atol=3e-3 * cond * np.abs(M64).max())
+    # the returned basis: orthonormal, and it diagonalises Hs (+ jitter) to the soft-abs spectrum's raw eigenvalues
+    Hj = Hs.copy()
+    if jitter is not None:
+        Hj[:, np.arange(D), np.arange(D)] += jitter * ju
+    Vn = a["V"]
+    np.testing.assert_allclose(np.einsum("bij,bik->bjk", Vn, Vn), np.broadcast_to(np.eye(D), (B, D, D)), atol=2e-5 * D)
+    Dg = np.einsum("bij,bik,bkl->bjl", Vn, Hj, Vn)
+    offd = Dg - np.einsum("bii->bi", Dg)[:, :, None] * np.eye(D)
+    assert np.abs(offd).max() <= 2e-5 * D * np.abs(lam).max(), np.abs(offd).max()
+    # second call from the returned basis (nearly exact: the refinement path) reproduces the results
+    a2, route2 = run(1, Vn, 2, "solve")
+    assert route2 == "metric_warm_mfma_kernel"
+    np.testing.assert_allclose(a2["x"], a["x"], rtol=2e-4 * cond, atol=2e-5 * cond * np.abs(x64).max())
+    np.testing.assert_allclose(a2["ld"], a["ld"], rtol=1e-5, atol=1e-4 * D)
+    # fisher() and the momentum draw (jitter sub-stream 0), basis updated in place as well
+    g, route_g = run(1, V0, 0, "matrix")
+    assert route_g == "metric_warm_mfma_kernel"
+    ju0 = None if jitter is None else O.philox_uniforms(seed, off + np.arange(B), draw, D, O.PURPOSE_JITTER, 0, dtype=np.float64)
+    G0, _, _ = O.softabs_metric(Hs, alpha, jitter, ju0)
+    z = O.philox_normals(seed, off + np.arange(B), draw, D, dtype=np.float64)
+    p64 = np.einsum("bij,bj->bi", np.linalg.cholesky(G0), z)
+    np.testing.assert_allclose(g["G"], G0, rtol=tol, atol=tol * np.abs(G0).max())
+    np.testing.assert_allclose(g["p"], p64, rtol=tol * cond, atol=tol * cond * np.abs(p64).max())
+    np.testing.assert_allclose(np.einsum("bij,bik->bjk", g["V"], g["V"]), np.broadcast_to(np.eye(D), (B, D, D)), atol=2e-5 * D)
