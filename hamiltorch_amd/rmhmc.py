@@ -138,6 +138,8 @@ class _Curvature:
         f = lambda w: log_prob_func(w).sum()  # noqa: E731
         self.f = f
         self._loop = False
+        self._gh_last = None          # (theta tensor, its version counter, g, -H): see grad_neg_hessian
+        self.stats = {"gh_evaluated": 0, "gh_reused": 0}
         # each of these is replayed as a HIP graph (util.GraphedCallable): eager torch.func is hundreds of tiny launches
         self._val = util.GraphedCallable(torch.func.vmap(f))
         # gradient and Hessian in one forward-over-reverse pass: jacfwd of (grad, aux = grad)
@@ -168,6 +170,28 @@ class _Curvature:
         return self._try(self._val, looped, theta).to(theta.dtype, copy=True).contiguous()
 
     def grad_neg_hessian(self, theta):
+        """(gradient, negative Hessian) of log p at every chain's theta.  The integrators ask for them several times at the SAME
+        state: both calls of a half step of the explicit integrator are evaluated at one (theta, p) pair (S:429-430, S:432-433:
+        the momentum moves by dH/dtheta(theta, p_c), the copy's position by dH/dp(theta, p_c)), every iteration of the implicit
+        momentum fixed point at one theta (S:313-340), H_new at the theta the last half step was evaluated at.  The reference
+        differentiates again each time; here the last result is kept and handed back while `theta` is the same tensor object
+        with the same version counter (an in-place update bumps it), so the callback's derivatives are evaluated once per
+        state - only the metric evaluation (its own jitter draw) and the contraction are per call."""
+        last = self._gh_last
+        if last is not None and last[0] is theta and last[1] == theta._version:
+            self.stats["gh_reused"] += 1
+            return last[2], last[3]
+        g, nH = self._grad_neg_hessian(theta)
+        self._gh_last = (theta, theta._version, g, nH)
+        self.stats["gh_evaluated"] += 1
+        return g, nH
+
+    def touched(self, *tensors):
+        """The native kernels update states through raw pointers (no version bump): whoever hands a state to one says so."""
+        if self._gh_last is not None and any(t is self._gh_last[0] for t in tensors):
+            self._gh_last = None
+
+    def _grad_neg_hessian(self, theta):
         def looped(th):
             H = torch.stack([torch.autograd.functional.hessian(self.f, t) for t in th])
             g = torch.stack([torch.autograd.grad(self.f(t_), t_)[0] for t_ in (t.detach().requires_grad_() for t in th)])
@@ -234,12 +258,14 @@ def _generic_steps(cv, kind, th, pm, thc, pmc, steps, eps, omega, alpha, jitter,
         _, Hs = cv.grad_neg_hessian(theta)
         _abi.metric_eval(theta, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, draw, sub, m=mvec, upd_x=upd, cx=eh,
                          **warm.kw(slot))
+        cv.touched(upd)
 
     for l in range(steps):
         k0 = 2 + 8 * l
         kick(th, pmc, pm, k0 + 0, "a"); drift(th, pmc, thc, k0 + 1, "a")           # phi_A(1/2)  S:429-430
         drift(thc, pm, th, k0 + 2, "b"); kick(thc, pm, pmc, k0 + 3, "b")           # phi_B(1/2)  S:432-433
         _abi.rmhmc_binding_rotation(th, pm, thc, pmc, eps, omega)                  # phi_C       S:447-450
+        cv.touched(th, thc)
         drift(thc, pm, th, k0 + 4, "b"); kick(thc, pm, pmc, k0 + 5, "b")           # phi_B(1/2)  S:454-455
         kick(th, pmc, pm, k0 + 6, "a"); drift(th, pmc, thc, k0 + 7, "a")           # phi_A(1/2)  S:457-458
         if path is not None:
@@ -362,6 +388,7 @@ def _sample_explicit_generic(log_prob_func, theta0, N, L, eps, burn, jitter, alp
         H1.sub_(lp1)
         row = samples[n - burn] if n > burn else None
         _abi.mh_select(cur, th, theta0, H0, H1, lp1, row, rejected, None, n, burn, seed, chain_offset)
+        cv.touched(cur)
         prog.update(n)
     prog.end()
     return samples, rejected
@@ -469,6 +496,7 @@ def sample_implicit(log_prob_func, theta0, N, L, eps, burn, jitter, alpha, metri
         H1.sub_(lp1)
         row = samples[n - burn] if n > burn else None
         _abi.mh_select(cur, th, theta0, H0, H1, lp1, row, rejected, None, n, burn, seed, chain_offset)
+        cv.touched(cur)
         prog.update(n)
     prog.end()
     return samples, rejected

@@ -1001,3 +1001,40 @@ def test_metric_general_targets_on_the_matrix_cores_vs_oracle(ht, D, kind, alpha
     np.testing.assert_allclose(g["G"], G0, rtol=tol, atol=tol * np.abs(G0).max())
     np.testing.assert_allclose(g["p"], p64, rtol=tol * cond, atol=tol * cond * np.abs(p64).max())
     np.testing.assert_allclose(np.einsum("bij,bik->bjk", g["V"], g["V"]), np.broadcast_to(np.eye(D), (B, D, D)), atol=2e-5 * D)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_general_integrators_differentiate_the_callback_once_per_state(ht, dtype):
+    """Both calls of an explicit half step are evaluated at one (theta, p) pair (S:429-430, S:432-433), the implicit momentum
+    fixed point iterates at one theta (S:313-340): `_Curvature.grad_neg_hessian` hands the derivatives of the callback back
+    while the state tensor is unchanged (same object, same version; the native in-place updates are announced through
+    `touched`) - 10 evaluations instead of 24 for three explicit steps, and the SAME results as differentiating every time."""
+    from hamiltorch_amd import rmhmc, _abi
+    D, C = 6, 5
+    lp = funnel_logp(np.array([0.5, 1.0, 1.7, 2.4, 0.8]))
+    rng = np.random.default_rng(3)
+    th0 = tt(0.4 * rng.standard_normal((C, D)), dtype); p0 = tt(rng.standard_normal((C, D)), dtype)
+
+    def run(cache):
+        cv = rmhmc._Curvature(lp)
+        if not cache:
+            cv.grad_neg_hessian = cv._grad_neg_hessian
+        th, pm, thc, pmc = th0.clone(), p0.clone(), th0.clone(), p0.clone()
+        rmhmc._generic_steps(cv, _abi.METRIC_SOFTABS, th, pm, thc, pmc, 3, 0.05, 10.0, 1.3, 1e-3, 7, 0, 2)
+        return cv, [t.cpu().numpy() for t in (th, pm, thc, pmc)]
+
+    cv, got = run(True)
+    assert cv.stats == {"gh_evaluated": 10, "gh_reused": 14}, cv.stats
+    _, want = run(False)
+    for a_, b_ in zip(got, want):
+        np.testing.assert_array_equal(a_, b_)
+    # implicit: the momentum fixed point reuses, the position fixed point (theta moves every iteration) does not
+    cv2 = rmhmc._Curvature(lp)
+    th, pm = th0.clone(), p0.clone()
+    rmhmc._implicit_steps(cv2, _abi.METRIC_SOFTABS, th, pm, 2, 0.05, 1.3, None, 7, 0, 2, 1e-12, 4)
+    cv3 = rmhmc._Curvature(lp); cv3.grad_neg_hessian = cv3._grad_neg_hessian
+    th3, pm3 = th0.clone(), p0.clone()
+    rmhmc._implicit_steps(cv3, _abi.METRIC_SOFTABS, th3, pm3, 2, 0.05, 1.3, None, 7, 0, 2, 1e-12, 4)
+    assert cv2.stats["gh_reused"] >= 2 * 3 and cv2.stats["gh_evaluated"] < cv2.stats["gh_evaluated"] + cv2.stats["gh_reused"]
+    np.testing.assert_array_equal(th.cpu().numpy(), th3.cpu().numpy())
+    np.testing.assert_array_equal(pm.cpu().numpy(), pm3.cpu().numpy())
