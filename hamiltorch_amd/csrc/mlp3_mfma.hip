@@ -735,7 +735,15 @@ __global__ __launch_bounds__(M3_NT) void mlp3_mfma_kernel(NetArgs<float> a, int 
             int m; float kick, dr;
             split_stage<float>(a.integ, M, a.L, st, eps, perm, m, kick, dr);
             // plain leapfrog: a full kick at the last step, half of it taken back (S:298, S:302); the drift runs inside the pass
-            ch.pass(ql, m * a.Nb, m * a.Nb + a.Nb, pl, kick, (plain && st == nstage - 1) ? -heps : 0.0f, dr, true);
+            float k2 = (plain && st == nstage - 1) ? -heps : 0.0f;
+            if (!plain && st + 1 < nstage) {
+              // the next stage evaluates the same subset at the same parameters (this one does not drift): both kicks from this
+              // gradient, (p + k1 g) + k2 g, and the next stage's drift (mlp.hpp: split_stage_reuses)
+              int m2; float kick2, dr2;
+              split_stage<float>(a.integ, M, a.L, st + 1, eps, perm, m2, kick2, dr2);
+              if (split_stage_reuses<float>(m, dr, m2)) { k2 = kick2; dr = dr2; ++st; }
+            }
+            ch.pass(ql, m * a.Nb, m * a.Nb + a.Nb, pl, kick, k2, dr, true);
 #if M3_TIMING
             { const unsigned long long now_ = __builtin_readcyclecounter(); ch.tacc[17] += now_ - ch.tacc[19]; ch.tacc[19] = now_; }
 #endif

@@ -385,13 +385,15 @@ __global__ __launch_bounds__(NT, 4) void mlp1_hmc_kernel(MlpArgs<T> a, int nbch,
         if (tid == 0) split_permutation(a.seed, (uint32_t)n, M, ch.perm);
         __syncthreads();
       }
+      int prev_m = -1; T prev_dr = (T)1;
       for (int st = 0; st < nstage; ++st) {
         int m; T kick, dr;
         split_stage<T>(a.integ, M, a.L, st, eps, ch.perm, m, kick, dr);
         const int lo = m * a.Nb;
-        ch.grad_range(q, lo, lo + a.Nb, g);
+        if (!split_stage_reuses<T>(prev_m, prev_dr, m)) ch.grad_range(q, lo, lo + a.Nb, g);   // else: the gradient of the stage before (mlp.hpp)
         Ch::axpy(p, kick, g);
         if (dr != (T)0) Ch::drift(q, dr, im, p);
+        prev_m = m; prev_dr = dr;
       }
       if (M == 1 && a.integ == HTA_SPLIT_SYMMETRIC) Ch::axpy(p, -heps, g);                                  // S:302
       const T lp_new = ch.logp_total(q);                                  // S:995

@@ -366,13 +366,16 @@ __global__ __launch_bounds__(NTMAX, 4) void mlp_mfma_kernel(MlpArgs<float> a, in
         if (tid == 0) split_permutation(a.seed, (uint32_t)n, M, perm);
         __syncthreads();
       }
+      int prev_m = -1; float prev_dr = 1.0f;
       for (int st = 0; st < nstage; ++st) {
         int m; float kick, dr;
         split_stage<float>(a.integ, M, a.L, st, eps, perm, m, kick, dr);
         const int lo = m * a.Nb;
-        ch.grad_range(q, lo, lo + a.Nb, gr);
+        // the same subset at the same parameters as the stage before (no drift since): its gradient is still in `gr` (mlp.hpp)
+        if (!split_stage_reuses<float>(prev_m, prev_dr, m)) ch.grad_range(q, lo, lo + a.Nb, gr);
         Ch::axpy(p, kick, gr);
         if (dr != 0.0f) Ch::drift(q, dr, im, p);
+        prev_m = m; prev_dr = dr;
       }
       if (M == 1 && a.integ == HTA_SPLIT_SYMMETRIC) Ch::axpy(p, -heps, gr);                                 // S:302
       const float lp_new = ch.logp_total(q);                              // S:995

@@ -606,6 +606,15 @@ __global__ __launch_bounds__(64 * WV) void netn_hmc_kernel(NetArgs<T> a, int D, 
           Ch::axpy(p, kick, g);
           if (dr != (T)0) Ch::drift(q, dr, im, p);
           ++st;
+          // the stages that evaluate the same subset at the same parameters (no drift since) take this gradient (mlp.hpp)
+          while (st < nstage) {
+            int m2; T k2, d2;
+            split_stage<T>(a.integ, M, a.L, st, eps, ch.perm, m2, k2, d2);
+            if (!split_stage_reuses<T>(m, dr, m2)) break;
+            Ch::axpy(p, k2, g);
+            if (d2 != (T)0) Ch::drift(q, d2, im, p);
+            dr = d2; ++st;
+          }
           if (st == nstage && M == 1 && a.integ == HTA_SPLIT_SYMMETRIC) Ch::axpy(p, -heps, g);   // S:302
           continue;
         }

@@ -304,8 +304,9 @@ def leapfrog(params, momentum, log_prob_func, steps=10, step_size=0.1, jitter=0.
         # S:549: one subset order per leapfrog call
         perm = util.split_permutation(util.next_stream_seed(), 0, len(cbs)) if integrator == Integrator.SPLITTING_RAND else None
         ret_t, ret_p = [], []
+        carry = None
         for _ in range(steps):
-            _split_step(theta, p, cbs, step_size, kind, im, integrator, perm)
+            carry = _split_step(theta, p, cbs, step_size, kind, im, integrator, perm, carry)
             ret_t.append(unb(theta.clone())); ret_p.append(unb(p.clone()))
         return ret_t, ret_p
 
@@ -324,11 +325,15 @@ def leapfrog(params, momentum, log_prob_func, steps=10, step_size=0.1, jitter=0.
     raise NotImplementedError("Integrator.S3 (semi-separable Hamiltonians through a user ham_func) is outside the accelerated path")
 
 
-def _split_step(theta, p, cbs, eps, kind, im, integrator=Integrator.SPLITTING, perm=None):
+def _split_step(theta, p, cbs, eps, kind, im, integrator=Integrator.SPLITTING, perm=None, carry=None):
     """One step of a split integrator on (theta, p), in place.
     SPLITTING (S:499-540): 2M half-kicks m = 0..M-1, M-1..0 with 2(M-1) drifts of eps / (2(M-1));
     SPLITTING_RAND (S:547-566): for each subset in the order `perm`: half kick, drift eps / M, half kick;
-    SPLITTING_KMID (S:572-596): M half kicks, one drift of eps, M half kicks in reverse order."""
+    SPLITTING_KMID (S:572-596): M half kicks, one drift of eps, M half kicks in reverse order.
+    A kick without a drift is followed by a kick of the SAME subset at the same parameters (the turning point of the
+    symmetric scheme; the step boundary, m = 0): the reference differentiates twice, here the gradient is evaluated once
+    and applied twice - the same numbers, (2M - 2) L + 1 instead of 2 M L callback gradients per trajectory.  `carry`:
+    the gradient the previous step of the same trajectory ended with (returned by this function), or None."""
     M = len(cbs)
     if integrator == Integrator.SPLITTING_RAND:
         for m in range(M):
@@ -337,24 +342,26 @@ def _split_step(theta, p, cbs, eps, kind, im, integrator=Integrator.SPLITTING, p
             _abi.kick_drift(theta, p, g, 0.5 * eps, eps / M, kind, im)
             g, _ = cb.grad(theta)
             _abi.kick_drift(theta, p, g, 0.5 * eps, 0.0, kind, im)
-        return
+        return None
     if M == 1:
         raise RuntimeError('For symmetric splitting log_prob_func must be list of functions greater than length 1')
     if integrator == Integrator.SPLITTING_KMID:
         for m in range(M):
-            g, _ = cbs[m].grad(theta)
+            g = carry if (m == 0 and carry is not None) else cbs[m].grad(theta)[0]
             _abi.kick_drift(theta, p, g, 0.5 * eps, eps if m == M - 1 else 0.0, kind, im)
         for m in reversed(range(M)):
             g, _ = cbs[m].grad(theta)
             _abi.kick_drift(theta, p, g, 0.5 * eps, 0.0, kind, im)
-        return
+        return g
     dq = eps / ((M - 1) * 2)
     for m in range(M):
-        g, _ = cbs[m].grad(theta)
+        g = carry if (m == 0 and carry is not None) else cbs[m].grad(theta)[0]
         _abi.kick_drift(theta, p, g, 0.5 * eps, dq if m < M - 1 else 0.0, kind, im)
     for m in reversed(range(M)):
-        g, _ = cbs[m].grad(theta)
+        if m < M - 1:                                  # m = M - 1: the forward sweep's last gradient, at the same parameters
+            g, _ = cbs[m].grad(theta)
         _abi.kick_drift(theta, p, g, 0.5 * eps, dq if m > 0 else 0.0, kind, im)
+    return g
 
 
 # =================================================================================================
@@ -647,8 +654,9 @@ class _GenericHMC(_Engine):
         prop.copy_(cur)
         if self.split:
             perm = util.split_permutation(self.seed, n, len(self.cbs)) if self.integrator == Integrator.SPLITTING_RAND else None
+            carry = None
             for _ in range(L):
-                _split_step(prop, p, self.cbs, eps, kind, im, self.integrator, perm)       # S:499-596
+                carry = _split_step(prop, p, self.cbs, eps, kind, im, self.integrator, perm, carry)   # S:499-596
             logp1 = self._logp(prop)
         else:
             g, logp1 = cb.grad(prop)

@@ -231,6 +231,9 @@ class _RecordedJitterCurvature:
     def contract(self, theta, M):
         return torch.zeros_like(theta)                      # third derivatives of a quadratic form
 
+    def touched(self, *tensors):                            # (rmhmc._Curvature's cache invalidation: nothing is cached here)
+        pass
+
     def value(self, theta):
         return -0.5 * ((theta @ self.P) * theta).sum(-1)
 

@@ -122,4 +122,6 @@ def test_notebook_model_kernel_keeps_scratch_off_its_matrix_blocks():
     res = SL.blocks(os.path.join(ROOT, "hamiltorch_amd", "csrc", "mlp3_mfma.hip"), "mlp3_mfma_kernelILi0E", [])
     hot = [v for v in res.values() if v["mfma"]]
     assert sum(v["mfma"] for v in hot) == 2 * 560
-    assert sum(v["scratch"] for v in hot) <= 8, [v for v in hot if v["scratch"]]
+    # (8 before the stage loop merged the two kicks that share a gradient - a second run-time kick coefficient; 9 with it.  The
+    #  guard is against the first version's hundreds: its kick reloaded the momentum's 28 registers from scratch every pass.)
+    assert sum(v["scratch"] for v in hot) <= 12, [v for v in hot if v["scratch"]]
