@@ -440,7 +440,8 @@ def _implicit_steps(cv, kind, th, pm, steps, eps, alpha, jitter, seed, chain_off
         p_old = pm.clone()
         fixed_point(pm, lambda i: p_old - hs * dH_dtheta(th, pm, base + i))                       # S:313-340
         th_old = th.clone()
-        g0 = dH_dp(th_old, pm, base + max_it)                                                     # S:344-348
+        g0 = dH_dp(th, pm, base + max_it)                                                         # S:344-348 (th == th_old here: the first
+                                                                                                  #  iteration below reuses its Hessian)
         fixed_point(th, lambda i: th_old + hs * dH_dp(th, pm, base + max_it + 1 + i) + hs * g0)   # S:349-361
         pm.sub_(hs * dH_dtheta(th, pm, base + 2 * max_it + 1))                                    # S:368-383
         if path is not None:
