@@ -510,3 +510,34 @@ def test_wide_two_hidden_layer_models_route_to_the_matrix_core_kernel():
     sizes = [w.nelement() for w in net.parameters()]; shapes = [w.shape for w in net.parameters()]
     f = bnn.define_model_log_prob(net, "regression", torch.randn(40, 1), torch.randn(40, 1), sizes, shapes, [1.0] * 6, 110.44)
     assert f._hta_spec["dims"] == [1, 100, 100, 1] and mlp._kernel_for(f._hta_spec) == "netn"
+
+
+@pytest.mark.parametrize("kind,M,L", [("symmetric", 4, 10), ("symmetric", 2, 3), ("symmetric", 7, 1), ("kmid", 4, 5), ("kmid", 2, 1),
+                                      ("rand", 4, 3), ("rand", 3, 2)])
+def test_split_schedules_repeat_a_gradient_exactly_where_the_kernels_share_it(kind, M, L):
+    """csrc/mlp.hpp `split_stage_reuses`: two kicks share one gradient evaluation when the second differentiates the same subset at
+    the same parameters.  Walk the oracle's restatement of the reference's loops (S:494-596) with gradient functions that log
+    (subset, parameters): the number of DISTINCT consecutive evaluations is the pass count the kernels execute -
+    (2M - 2) L + 1 for the symmetric scheme, 2 M L - (L - 1) for KMID, 2 M L for RAND - and in the symmetric scheme every repeated
+    evaluation directly follows its twin (so keeping ONE gradient is enough)."""
+    import numpy as np
+    import hmc_oracle as O
+    log = []
+
+    def gf(m):
+        def f(theta):
+            log.append((m, theta.tobytes()))
+            return -(m + 1.0) * theta
+        return f
+    th = np.linspace(0.1, 0.5, 5).astype(np.float64)[None]
+    p = np.ones_like(th)
+    perm = list(range(M))[::-1] if kind == "rand" else None
+    O.split_leapfrog(th, p, [gf(m) for m in range(M)], L, 0.01, None, kind, perm)
+    assert len(log) == 2 * M * L
+    distinct = 1 + sum(1 for a, b in zip(log, log[1:]) if a != b)
+    if kind == "kmid":       # its second half sweep is repeated by the next step's first one, subset by subset; only subset 0's twin
+        assert len(set(log)) == (L + 1) * M        # is adjacent - the one the kernels share (one stored gradient, not M)
+    else:
+        assert len(set(log)) == distinct           # a repeated evaluation always directly follows its twin
+    want = {"symmetric": (2 * M - 2) * L + 1, "kmid": 2 * M * L - (L - 1), "rand": 2 * M * L}[kind]
+    assert distinct == want, (distinct, want)
