@@ -746,7 +746,16 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
       __syncthreads();
       lds_gemm<false, false, false, false>(by, bx, bz, -1, -1, nt, k4, LD);             // Q = V0 X
       __syncthreads();
-      if (a.V_out) ph_store_dense(a.V_out + b * D * D, bz, D, LD);
+      if (a.V_out) {
+        // a system that went non-finite (a diverged chain: NaN curvature, or a NaN basis handed in) must not poison its NEXT
+        // evaluation: its basis restarts from the identity
+        if (!(fabsf(logdet) <= 3.0e38f)) {
+          __attribute__((address_space(1))) float* vg = (__attribute__((address_space(1))) float*)(a.V_out + b * D * D);
+          for (int e = tid; e < D * D; e += MT) vg[e] = (e / D == e % D) ? 1.f : 0.f;
+        } else {
+          ph_store_dense(a.V_out + b * D * D, bz, D, LD);
+        }
+      }
       if (a.dmetric_out) {
         ph_dmetric_w(by, oLam, oLt, oY, (float)a.alpha, D, DP, LD);
         __syncthreads();

@@ -1038,3 +1038,26 @@ def test_general_integrators_differentiate_the_callback_once_per_state(ht, dtype
     assert cv2.stats["gh_reused"] >= 2 * 3 and cv2.stats["gh_evaluated"] < cv2.stats["gh_evaluated"] + cv2.stats["gh_reused"]
     np.testing.assert_array_equal(th.cpu().numpy(), th3.cpu().numpy())
     np.testing.assert_array_equal(pm.cpu().numpy(), pm3.cpu().numpy())
+
+
+def test_metric_general_mode_restarts_the_basis_of_a_system_that_went_non_finite(ht):
+    """A diverged chain hands hta_metric_eval a NaN curvature (or, afterwards, would hand back a NaN basis): its V_out is the
+    identity, so that the chain's next evaluation - after the Metropolis step has put it back on a finite state - is a cold start
+    and not NaN forever; the other systems of the batch are unaffected."""
+    from hamiltorch_amd import _abi
+    D, B = 24, 5
+    Hs = sym_batch(B, D, "spd", 3)
+    bad = Hs.copy(); bad[2, 3, 1] = np.nan
+    m = np.random.default_rng(0).standard_normal((B, D)).astype(np.float32)
+    V = tt(np.broadcast_to(np.eye(D), (B, D, D)).copy(), torch.float32).contiguous()
+    x = torch.empty(B, D, device=dev()); md = tt(m, torch.float32)
+    kw = dict(V0=V, v0_stride=D * D, V_out=V)
+    _abi.metric_eval(md, B, D, _abi.METRIC_SOFTABS, tt(bad, torch.float32), D * D, 1e6, None, 0, 0, 0, 0, m=md, x_out=x, **kw)
+    assert _abi.last_route() == "metric_warm_mfma_kernel"
+    Vn = V.cpu().numpy()
+    assert not np.isfinite(x.cpu().numpy()[2]).all()
+    np.testing.assert_array_equal(Vn[2], np.eye(D, dtype=np.float32))
+    assert np.isfinite(Vn).all() and np.isfinite(x.cpu().numpy()[[0, 1, 3, 4]]).all()
+    _abi.metric_eval(md, B, D, _abi.METRIC_SOFTABS, tt(Hs, torch.float32), D * D, 1e6, None, 0, 0, 0, 0, m=md, x_out=x, **kw)
+    want = np.linalg.solve(Hs, m.astype(np.float64)[..., None])[..., 0]
+    np.testing.assert_allclose(x.cpu().numpy(), want, rtol=2e-3, atol=2e-3)
