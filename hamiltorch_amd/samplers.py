@@ -641,6 +641,15 @@ class _GenericHMC(_Engine):
         self.prop, self.p = torch.empty_like(theta0), torch.empty_like(theta0)
         self.Ho = torch.empty(C, dtype=theta0.dtype, device=theta0.device)
         self.Hn = torch.empty_like(self.Ho)
+        # plain HMC: log p and its gradient AT THE CURRENT POINT, carried from trajectory to trajectory (see _trajectory)
+        self._g_cur, self._lp_cur = torch.empty_like(theta0), torch.empty_like(self.Ho)
+        self._acc = torch.zeros(C, dtype=torch.uint8, device=theta0.device)
+        self._cache_valid = False
+
+    def _refresh_cache(self):
+        g, lp = self.cbs[0].grad(self.cur)
+        self._g_cur.copy_(g); self._lp_cur.copy_(lp.to(self.cur.dtype))
+        self._cache_valid = True
 
     def _trajectory(self, n, L, eps, Ho, Hn, n_dev=None):
         """One trajectory (S:969-1026).  n_dev: the trajectory index lives in device memory - the form a HIP graph replays."""
@@ -650,7 +659,13 @@ class _GenericHMC(_Engine):
             _abi.momentum_resample(p, kind, mf, self.seed, self.off, n)                    # S:969
         else:
             _abi.momentum_resample_at(p, kind, mf, self.seed, self.off, n_dev)
-        _abi.hamiltonian(p, self._logp(cur), kind, im, Ho)                                 # S:971
+        # Plain HMC: the reference evaluates log p at the current point for H_old (S:971) and differentiates it again for the
+        # first half kick (S:281) - the point the previous trajectory ended at when it was accepted, the point it started from
+        # when it was rejected.  Both values are known: (g_cur, lp_cur) follow the Metropolis decision chain by chain, so a
+        # trajectory costs L callback evaluations instead of L + 2 (the native kernels carry lp_cur the same way).
+        if not self.split and not self._cache_valid:
+            self._refresh_cache()
+        _abi.hamiltonian(p, self._logp(cur) if self.split else self._lp_cur, kind, im, Ho)     # S:971
         prop.copy_(cur)
         if self.split:
             perm = util.split_permutation(self.seed, n, len(self.cbs)) if self.integrator == Integrator.SPLITTING_RAND else None
@@ -659,7 +674,7 @@ class _GenericHMC(_Engine):
                 carry = _split_step(prop, p, self.cbs, eps, kind, im, self.integrator, perm, carry)   # S:499-596
             logp1 = self._logp(prop)
         else:
-            g, logp1 = cb.grad(prop)
+            g, logp1 = self._g_cur, self._lp_cur
             _abi.kick_drift(prop, p, g, 0.5 * eps, eps if L > 0 else 0.0, kind, im)        # S:281, S:284
             for l in range(L):
                 g, logp1 = cb.grad(prop)                                                   # S:297
@@ -667,14 +682,21 @@ class _GenericHMC(_Engine):
             _abi.kick_drift(prop, p, g, -0.5 * eps, 0.0, kind, im)                         # S:302
             logp1 = logp1.to(cur.dtype).contiguous()   # log-prob at the end point, from the last gradient call
         _abi.hamiltonian(p, logp1, kind, im, Hn)                                           # S:995
+        acc = None if self.split else self._acc
         if n_dev is None:
             row = self.samples[n - self.burn] if n > self.burn else None
-            _abi.mh_select(cur, prop, self.theta0, Ho, Hn, logp1, row, self.rejected, None, n, self.burn, self.seed,
+            _abi.mh_select(cur, prop, self.theta0, Ho, Hn, logp1, row, self.rejected, acc, n, self.burn, self.seed,
                            self.off)                                                       # S:1000-1026
         else:
-            _abi.mh_select_at(cur, prop, self.theta0, Ho, Hn, logp1, self.samples, self.rejected, None, n_dev, self.burn,
+            _abi.mh_select_at(cur, prop, self.theta0, Ho, Hn, logp1, self.samples, self.rejected, acc, n_dev, self.burn,
                               self.seed, self.off)
             _abi.counter_add(n_dev, 1)
+        if not self.split and L > 0:
+            took = acc.bool()
+            self._g_cur.copy_(torch.where(took[:, None], g, self._g_cur))
+            self._lp_cur.copy_(torch.where(took, logp1, self._lp_cur))
+            if n_dev is None and n == self.burn + 1:                                       # Q2 (S:1018): rejected chains restart from
+                self._cache_valid = False                                                  # params_init - their pair is recomputed
 
     def _graph_eligible(self, count, H_old):
         return (H_old is None and count >= 4 and not getattr(self, "_no_graph", False)
@@ -700,6 +722,8 @@ class _GenericHMC(_Engine):
                     if progress is not None:
                         progress.update(n)
                     graph.replay()
+                    if not self.split and n == self.burn + 1:          # Q2 reset inside the replayed trajectory: refresh the carried pair
+                        self._refresh_cache()
                     n += 1
         while n < end:
             if progress is not None:
@@ -715,6 +739,8 @@ class _GenericHMC(_Engine):
         with torch.cuda.stream(side):
             self._trajectory(n, L, eps, Ho, Hn, n_dev)                                     # warm-up = trajectory n itself
         torch.cuda.current_stream(dev).wait_stream(side)
+        if not self.split and n == self.burn + 1:      # the warm-up ran the Q2 trajectory: the carried pair is refreshed OUTSIDE the graph
+            self._refresh_cache()
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
