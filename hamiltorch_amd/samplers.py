@@ -647,8 +647,11 @@ class _GenericHMC(_Engine):
         self._cache_valid = False
 
     def _refresh_cache(self):
-        g, lp = self.cbs[0].grad(self.cur)
-        self._g_cur.copy_(g); self._lp_cur.copy_(lp.to(self.cur.dtype))
+        if self.split:                                  # the split integrators carry log p only (their first kick is one subset's)
+            self._lp_cur.copy_(self._logp(self.cur))
+        else:
+            g, lp = self.cbs[0].grad(self.cur)
+            self._g_cur.copy_(g); self._lp_cur.copy_(lp.to(self.cur.dtype))
         self._cache_valid = True
 
     def _trajectory(self, n, L, eps, Ho, Hn, n_dev=None):
@@ -663,9 +666,9 @@ class _GenericHMC(_Engine):
         # first half kick (S:281) - the point the previous trajectory ended at when it was accepted, the point it started from
         # when it was rejected.  Both values are known: (g_cur, lp_cur) follow the Metropolis decision chain by chain, so a
         # trajectory costs L callback evaluations instead of L + 2 (the native kernels carry lp_cur the same way).
-        if not self.split and not self._cache_valid:
+        if not self._cache_valid:
             self._refresh_cache()
-        _abi.hamiltonian(p, self._logp(cur) if self.split else self._lp_cur, kind, im, Ho)     # S:971
+        _abi.hamiltonian(p, self._lp_cur, kind, im, Ho)                                    # S:971
         prop.copy_(cur)
         if self.split:
             perm = util.split_permutation(self.seed, n, len(self.cbs)) if self.integrator == Integrator.SPLITTING_RAND else None
@@ -682,7 +685,7 @@ class _GenericHMC(_Engine):
             _abi.kick_drift(prop, p, g, -0.5 * eps, 0.0, kind, im)                         # S:302
             logp1 = logp1.to(cur.dtype).contiguous()   # log-prob at the end point, from the last gradient call
         _abi.hamiltonian(p, logp1, kind, im, Hn)                                           # S:995
-        acc = None if self.split else self._acc
+        acc = self._acc
         if n_dev is None:
             row = self.samples[n - self.burn] if n > self.burn else None
             _abi.mh_select(cur, prop, self.theta0, Ho, Hn, logp1, row, self.rejected, acc, n, self.burn, self.seed,
@@ -691,9 +694,10 @@ class _GenericHMC(_Engine):
             _abi.mh_select_at(cur, prop, self.theta0, Ho, Hn, logp1, self.samples, self.rejected, acc, n_dev, self.burn,
                               self.seed, self.off)
             _abi.counter_add(n_dev, 1)
-        if not self.split and L > 0:
+        if L > 0:
             took = acc.bool()
-            self._g_cur.copy_(torch.where(took[:, None], g, self._g_cur))
+            if not self.split:
+                self._g_cur.copy_(torch.where(took[:, None], g, self._g_cur))
             self._lp_cur.copy_(torch.where(took, logp1, self._lp_cur))
             if n_dev is None and n == self.burn + 1:                                       # Q2 (S:1018): rejected chains restart from
                 self._cache_valid = False                                                  # params_init - their pair is recomputed
@@ -722,7 +726,7 @@ class _GenericHMC(_Engine):
                     if progress is not None:
                         progress.update(n)
                     graph.replay()
-                    if not self.split and n == self.burn + 1:          # Q2 reset inside the replayed trajectory: refresh the carried pair
+                    if n == self.burn + 1:                             # Q2 reset inside the replayed trajectory: refresh the carried pair
                         self._refresh_cache()
                     n += 1
         while n < end:
@@ -739,7 +743,7 @@ class _GenericHMC(_Engine):
         with torch.cuda.stream(side):
             self._trajectory(n, L, eps, Ho, Hn, n_dev)                                     # warm-up = trajectory n itself
         torch.cuda.current_stream(dev).wait_stream(side)
-        if not self.split and n == self.burn + 1:      # the warm-up ran the Q2 trajectory: the carried pair is refreshed OUTSIDE the graph
+        if n == self.burn + 1:                         # the warm-up ran the Q2 trajectory: the carried pair is refreshed OUTSIDE the graph
             self._refresh_cache()
         try:
             graph = torch.cuda.CUDAGraph()
