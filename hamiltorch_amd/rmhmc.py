@@ -373,12 +373,16 @@ def _sample_explicit_generic(log_prob_func, theta0, N, L, eps, burn, jitter, alp
     H0 = torch.empty(C, dtype=dt, device=dev); H1 = torch.empty_like(H0)
     pm = torch.empty_like(cur)
     warm = _WarmBases(cur, kind)
+    acc = torch.zeros(C, dtype=torch.uint8, device=dev)
+    Hs = lp0 = None               # curvature and log p AT THE CURRENT POINT, carried across trajectories (see the end of the loop)
     prog = util._Progress('Sampling (Sampler.RMHMC; Integrator.EXPLICIT)', N, verbose)
     for n in range(N):
-        _, Hs = cv.grad_neg_hessian(cur)
+        if Hs is None:
+            _, Hs = cv.grad_neg_hessian(cur)
+            lp0 = cv.value(cur)
         _abi.metric_eval(cur, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, n, 0, p_out=pm, **warm.kw("a"))        # S:183-184
         _abi.metric_eval(cur, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, n, 1, m=pm, H_out=H0, **warm.kw("a"))  # S:971
-        H0.sub_(cv.value(cur))
+        H0.sub_(lp0)
         th, thc, pmc = cur.clone(), cur.clone(), pm.clone()
         _generic_steps(cv, kind, th, pm, thc, pmc, L, eps, omega, alpha, jitter, seed, chain_offset, n, warm=warm)
         _, Hs1 = cv.grad_neg_hessian(th)
@@ -387,8 +391,13 @@ def _sample_explicit_generic(log_prob_func, theta0, N, L, eps, burn, jitter, alp
                          **warm.kw("a"))                                                                                          # S:989
         H1.sub_(lp1)
         row = samples[n - burn] if n > burn else None
-        _abi.mh_select(cur, th, theta0, H0, H1, lp1, row, rejected, None, n, burn, seed, chain_offset)
+        _abi.mh_select(cur, th, theta0, H0, H1, lp1, row, rejected, acc, n, burn, seed, chain_offset)
         cv.touched(cur)
+        # the next trajectory starts where this one ended (accepted) or started (rejected): both points' curvature and log p are
+        # known - the reference differentiates again (S:971 -> S:822); after the Q2 reset (S:1018) they are recomputed
+        took = acc.bool()
+        Hs = None if n == burn + 1 else torch.where(took[:, None, None], Hs1, Hs)
+        lp0 = None if n == burn + 1 else torch.where(took, lp1, lp0)
         prog.update(n)
     prog.end()
     return samples, rejected
@@ -482,12 +491,16 @@ def sample_implicit(log_prob_func, theta0, N, L, eps, burn, jitter, alpha, metri
     H0 = torch.empty(C, dtype=dt, device=dev); H1 = torch.empty_like(H0)
     pm = torch.empty_like(cur)
     warm = _WarmBases(cur, kind)
+    acc = torch.zeros(C, dtype=torch.uint8, device=dev)
+    Hs = lp0 = None               # as in _sample_explicit_generic: carried across trajectories
     prog = util._Progress('Sampling (Sampler.RMHMC; Integrator.IMPLICIT)', N, verbose)
     for n in range(N):
-        _, Hs = cv.grad_neg_hessian(cur)
+        if Hs is None:
+            _, Hs = cv.grad_neg_hessian(cur)
+            lp0 = cv.value(cur)
         _abi.metric_eval(cur, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, n, 0, p_out=pm, **warm.kw("a"))        # S:183-184
         _abi.metric_eval(cur, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, n, 1, m=pm, H_out=H0, **warm.kw("a"))  # S:971
-        H0.sub_(cv.value(cur))
+        H0.sub_(lp0)
         th = cur.clone()
         _implicit_steps(cv, kind, th, pm, L, eps, alpha, jitter, seed, chain_offset, n, thr, max_it, warm=warm)
         _, Hs1 = cv.grad_neg_hessian(th)
@@ -496,8 +509,11 @@ def sample_implicit(log_prob_func, theta0, N, L, eps, burn, jitter, alpha, metri
                          m=pm, H_out=H1, **warm.kw("a"))                                                      # S:989
         H1.sub_(lp1)
         row = samples[n - burn] if n > burn else None
-        _abi.mh_select(cur, th, theta0, H0, H1, lp1, row, rejected, None, n, burn, seed, chain_offset)
+        _abi.mh_select(cur, th, theta0, H0, H1, lp1, row, rejected, acc, n, burn, seed, chain_offset)
         cv.touched(cur)
+        took = acc.bool()
+        Hs = None if n == burn + 1 else torch.where(took[:, None, None], Hs1, Hs)
+        lp0 = None if n == burn + 1 else torch.where(took, lp1, lp0)
         prog.update(n)
     prog.end()
     return samples, rejected
