@@ -666,7 +666,9 @@ class _GenericHMC(_Engine):
         # first half kick (S:281) - the point the previous trajectory ended at when it was accepted, the point it started from
         # when it was rejected.  Both values are known: (g_cur, lp_cur) follow the Metropolis decision chain by chain, so a
         # trajectory costs L callback evaluations instead of L + 2 (the native kernels carry lp_cur the same way).
-        if not self._cache_valid:
+        # (HAMILTORCH_AMD_CARRY=0: evaluate both afresh every trajectory, as the reference does - for a callback whose value
+        #  is not a pure function of its argument)
+        if not self._cache_valid or os.environ.get("HAMILTORCH_AMD_CARRY", "1") == "0":
             self._refresh_cache()
         _abi.hamiltonian(p, self._lp_cur, kind, im, Ho)                                    # S:971
         prop.copy_(cur)
