@@ -642,7 +642,8 @@ class _GenericHMC(_Engine):
         self.Ho = torch.empty(C, dtype=theta0.dtype, device=theta0.device)
         self.Hn = torch.empty_like(self.Ho)
         # plain HMC: log p and its gradient AT THE CURRENT POINT, carried from trajectory to trajectory (see _trajectory)
-        self._g_cur, self._lp_cur = torch.empty_like(theta0), torch.empty_like(self.Ho)
+        self._g_cur = None if self.split else torch.empty_like(theta0)
+        self._lp_cur = torch.empty_like(self.Ho)
         self._acc = torch.zeros(C, dtype=torch.uint8, device=theta0.device)
         self._cache_valid = False
 
