@@ -740,9 +740,23 @@ __device__ __forceinline__ float quad_sum(float v) {
 
 // LB > 0: a.L == LB is known at compile time (straight-line steps, no loop bookkeeping: at this size every scalar
 // instruction on the hot path costs what a vector one does); LB == 0: any L.
-template <int D, bool DIAG, int LB>
+//
+// VAR (tuning key "quad_variant", default 0) - the same arithmetic, fewer instructions around it (a lone wave pays ~2 ns for
+// ANY instruction, so the 28 that are not the trajectory's 52 dependent FMAs are a third of its time):
+//   bit 0  addresses as a wave-uniform base (an SGPR pair, advanced once per pass of the unrolled loop) plus a 32-bit lane
+//          offset per position of that loop (loop-invariant registers): no 64-bit vector add per record load and per row store
+//          (the VAR = 0 loop spends 27 of its 320 instructions per four trajectories on address arithmetic, this one 8);
+//   bit 1  no NaN guard in front of the accept compare: the record's 2 log u is finite by construction (u23: 23-bit uniforms
+//          in (0, 1)), the energy difference is finite, -inf or NaN (sums of squares cannot reach -inf, the current point is
+//          finite), and both -inf >= x and NaN >= x are false - the guard never changes a decision.
+// Results are bit-identical to VAR = 0 (tests/test_gpu_hmc.py::test_quad_variants_are_bit_identical).
+template <int I, int N, typename F> __device__ __forceinline__ void quad_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); quad_static_for<I + 1, N>(f); }
+}
+template <int D, bool DIAG, int LB, int VAR = 0>
 __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, const float* __restrict__ eig) {
   typedef float T;
+  constexpr bool UADDR = (VAR & 1) != 0, NOGUARD = (VAR & 2) != 0, TAIL = (VAR & 4) != 0;
   const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t c = gt >> 2;
   const int k = (int)(gt & 3);
@@ -813,6 +827,19 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
   typedef __attribute__((address_space(1))) char* gwbytes_t;
   auto put = [&](gwbytes_t row, T v) { *(__attribute__((address_space(1))) T*)(row + qoff) = v; };
   put((gwbytes_t)a.theta, to_q(yc));
+  // UADDR: the record of the trajectory at position i of the unrolled loop is recb + roff[i] (recb: the row NS ahead of the
+  // pass's first trajectory), its stored row element rowb + soff[i]; both bases are wave-uniform and move once per pass.
+  // (the dispatcher bounds C so that the offsets stay below 2^32)
+  constexpr int NU = UADDR ? 4 * NS : 2 * NS;       // trajectories per pass of the unrolled loop (the scalar bookkeeping of a pass is shared)
+  typedef const __attribute__((address_space(1))) char* gcbytes_t;
+  gcbytes_t recb = (gcbytes_t)a.ws_z + (size_t)NS * (rec_step * sizeof(T));
+  uint32_t roff[NU], uoff[NU], soff[NU];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) {
+    roff[i] = (uint32_t)((c * W + k) * sizeof(T)) + (uint32_t)i * (uint32_t)(rec_step * sizeof(T));
+    uoff[i] = roff[i] + (uint32_t)(ushift * sizeof(T));
+    soff[i] = qoff;
+  }
   // Two phases, one loop body: trajectories with n <= burn rewrite the chain's slot of `theta` (row step 0), the others
   // walk the sample rows.
   const int n_burn = a.samples ? min(max(a.burn - a.traj_offset + 1, 0), a.n_traj) : a.n_traj;
@@ -825,12 +852,16 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
       row = (gwbytes_t)(a.samples + (size_t)max(a.traj_offset + t - a.burn, 1) * C * D);
       row_step = C * D * sizeof(T);
     }
+    if constexpr (UADDR) {
+#pragma unroll
+      for (int i = 0; i < NU; ++i) soff[i] = qoff + (uint32_t)i * (uint32_t)row_step;
+    }
     // one trajectory; `slot` holds its record element and is refilled with the one two trajectories ahead (the loop is
     // unrolled by two over the slots, so the newest load is never touched by a register rotation)
     // `q2`: this is trajectory burn+1, the one the reference resets to params_init when it is rejected (S:1016-1018);
     // a separate instance, so that the others carry no check for it.
-    auto trajectory = [&](T& slot, T& slot_u, auto q2) {
-      rec += rec_step;
+    auto trajectory = [&](T& slot, T& slot_u, auto q2, auto pos) {
+      if constexpr (!UADDR) rec += rec_step;
       // everything that reads the record first, so that its register is free for the refill
       // ---- gibbs S:185-186 (rotated draws), H_old S:971, half kick S:281
       T y = yc, r, eo, logu;
@@ -844,9 +875,15 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
       }
       // (the empty asm orders the refill after the record's last use, so the load can target the record's own register;
       //  otherwise the scheduler hoists the load and the back-edge copy of its result waits for it)
-      asm volatile("" : "+v"(rec) : "v"(r), "v"(eo), "v"(logu));
-      slot = *rec;
-      if (D == 4) slot_u = *(rec + ushift);
+      if constexpr (UADDR) {
+        asm volatile("" : "+v"(roff[pos]) : "v"(r), "v"(eo), "v"(logu));
+        slot = *(grec_t)(recb + roff[pos]);
+        if (D == 4) slot_u = *(grec_t)(recb + uoff[pos]);
+      } else {
+        asm volatile("" : "+v"(rec) : "v"(r), "v"(eo), "v"(logu));
+        slot = *rec;
+        if (D == 4) slot_u = *(rec + ushift);
+      }
       if constexpr (LB > 0) {                                                       // S:283-298
 #pragma unroll
         for (int l = 0; l < LB; ++l) { y = fmaf(eps, r, y); r = fmaf(nel, y, r); }
@@ -859,9 +896,35 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
       const T en = fmaf(r, r, pot1);
       // the proposal's row element q_k = mu_k + sum_j Tout[k][j] y_j: v_fmac_f32 with a DPP-broadcast operand.  Ordered after
       // `en` (dummy operand): the instructions since the last write of y are the wait states its DPP read needs.
-      T qp;
+      T qp, dH;
       static_assert(D >= 1 && D <= 4, "quad kernel");
 #define HTA_QF(J, OP) "\n\tv_fmac_f32_dpp %0, %1, %" #OP " quad_perm:[" #J "," #J "," #J "," #J "] row_mask:0xf bank_mask:0xf"
+      if constexpr (TAIL) {
+        // One block for the row element AND the quad butterfly of the energy difference, interleaved so that every DPP read of
+        // a freshly written register has its two wait states from useful instructions (the compiler does not look into inline
+        // assembly and pads its own DPP pairs with s_nop: one issue slot per trajectory):
+        //   d = eo - en (compiler) | mov qp, mu | qp += Q[k][0] y_0 | d += d[lane^1] | qp += Q[k][1] y_1 | ... | d += d[lane^2]
+#define HTA_QG(J, OP) "\n\tv_fmac_f32_dpp %0, %2, %" #OP " quad_perm:[" #J "," #J "," #J "," #J "] row_mask:0xf bank_mask:0xf"
+#define HTA_B1 "\n\tv_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define HTA_B2 "\n\tv_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        dH = eo - en;
+        if constexpr (D == 1)
+          asm volatile("v_mov_b32 %0, %3" HTA_QG(0, 4) HTA_B1 "\n\ts_nop 1" HTA_B2
+                       : "=&v"(qp), "+v"(dH) : "v"(y), "v"(mu), "v"(Qrow[0]));
+        else if constexpr (D == 2)
+          asm volatile("v_mov_b32 %0, %3" HTA_QG(0, 4) HTA_B1 HTA_QG(1, 5) "\n\ts_nop 0" HTA_B2
+                       : "=&v"(qp), "+v"(dH) : "v"(y), "v"(mu), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]));
+        else if constexpr (D == 3)
+          asm volatile("v_mov_b32 %0, %3" HTA_QG(0, 4) HTA_B1 HTA_QG(1, 5) HTA_QG(2, 6) HTA_B2
+                       : "=&v"(qp), "+v"(dH) : "v"(y), "v"(mu), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]), "v"(Qrow[D > 2 ? 2 : 0]));
+        else
+          asm volatile("v_mov_b32 %0, %3" HTA_QG(0, 4) HTA_B1 HTA_QG(1, 5) HTA_QG(2, 6) HTA_B2 HTA_QG(3, 7)
+                       : "=&v"(qp), "+v"(dH) : "v"(y), "v"(mu), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]), "v"(Qrow[D > 2 ? 2 : 0]),
+                         "v"(Qrow[D > 3 ? 3 : 0]));
+#undef HTA_QG
+#undef HTA_B1
+#undef HTA_B2
+      } else {
       if constexpr (D == 1)
         asm volatile("v_mov_b32 %0, %2" HTA_QF(0, 4) : "=&v"(qp) : "v"(y), "v"(mu), "v"(en), "v"(Qrow[0]));
       else if constexpr (D == 2)
@@ -874,12 +937,13 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
         asm volatile("v_mov_b32 %0, %2" HTA_QF(0, 4) HTA_QF(1, 5) HTA_QF(2, 6) HTA_QF(3, 7)
                      : "=&v"(qp) : "v"(y), "v"(mu), "v"(en), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]), "v"(Qrow[D > 2 ? 2 : 0]),
                        "v"(Qrow[D > 3 ? 3 : 0]));
+      dH = quad_sum(eo - en);                                                       // 2 (h_old - h_new)
+      }
 #undef HTA_QF
-      const T dH = quad_sum(eo - en);                                               // 2 (h_old - h_new)
       // the decision as a lane mask (v_cmp into an SGPR pair), consumed by a carry-in add and two selects
       // rho = min(0, dH) >= log u  <=>  dH >= log u, because log u <= 0 (S:1000-1004).  A non-finite dH must reject:
       // fma(dH, 0, dH) is dH when dH is finite and NaN otherwise (inf * 0), and NaN >= x is false - one compare in all.
-      const uint64_t accmask = __builtin_amdgcn_fcmpf(__builtin_fmaf(dH, 0.0f, dH), logu, 3 /* oge */);
+      const uint64_t accmask = __builtin_amdgcn_fcmpf(NOGUARD ? dH : __builtin_fmaf(dH, 0.0f, dH), logu, 3 /* oge */);
       if constexpr (!decltype(q2)::value) {
         // accepted += acc; yc, potc, qc <- accepted point: a carry-in add and three selects on the accept mask
         uint64_t carry_out;
@@ -897,8 +961,13 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
           yc = to_y(a.theta_init); potc = lam * yc * yc; qc = a.theta_init[c * D + kk];
         }
       }
-      put(row, qc);
-      row += row_step;
+      if constexpr (UADDR) {
+        asm volatile("" : "+v"(soff[pos]));            // keeps the zero-extension next to its use: base + 32-bit offset addressing
+        *(__attribute__((address_space(1))) T*)(row + soff[pos]) = qc;
+      } else {
+        put(row, qc);
+        row += row_step;
+      }
       if (DIAG) {
         const bool acc = (accmask >> (threadIdx.x & 63)) & 1;
         const T ho = 0.5f * quad_sum(eo) - a.log_norm, hn = 0.5f * quad_sum(en) - a.log_norm;
@@ -911,25 +980,45 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
       ++t;
     };
     std::false_type plain;
+    std::integral_constant<int, 0> first;
     auto rotate = [&]() {                       // slot 0 was consumed and refilled with the newest row: it becomes the last
       const T z = zs[0], u = lus[0];
 #pragma unroll
       for (int i = 0; i + 1 < NS; ++i) { zs[i] = zs[i + 1]; lus[i] = lus[i + 1]; }
       zs[NS - 1] = z; lus[NS - 1] = u;
     };
+    if constexpr (UADDR) {
+      // the same schedule with the bases moved once per group of trajectories
+      auto moved = [&](int g) { recb += (size_t)g * (rec_step * sizeof(T)); row += (size_t)g * row_step; };
+      if (phase == 1 && t < t_end && a.traj_offset + t == a.burn + 1) {
+        trajectory(zs[0], lus[0], std::true_type{}, first);
+        moved(1);
+        rotate();
+      }
+      while (t + NU - 1 < t_end) {
+        quad_static_for<0, NU>([&](auto I) { trajectory(zs[I % NS], lus[I % NS], plain, I); });
+        moved(NU);
+      }
+      while (t + NS - 1 < t_end) {
+        quad_static_for<0, NS>([&](auto I) { trajectory(zs[I], lus[I], plain, I); });
+        moved(NS);
+      }
+      while (t < t_end) { trajectory(zs[0], lus[0], plain, first); moved(1); rotate(); }
+    } else {
     if (phase == 1 && t < t_end && a.traj_offset + t == a.burn + 1) {              // the Q2 trajectory opens the stored phase
-      trajectory(zs[0], lus[0], std::true_type{});
+      trajectory(zs[0], lus[0], std::true_type{}, first);
       rotate();
     }
     while (t + 2 * NS - 1 < t_end) {            // unrolled over the slots (twice): no register rotation on the hot path
 #pragma unroll
-      for (int i = 0; i < 2 * NS; ++i) trajectory(zs[i % NS], lus[i % NS], plain);
+      for (int i = 0; i < 2 * NS; ++i) trajectory(zs[i % NS], lus[i % NS], plain, first);
     }
     if (t + NS - 1 < t_end) {
 #pragma unroll
-      for (int i = 0; i < NS; ++i) trajectory(zs[i], lus[i], plain);
+      for (int i = 0; i < NS; ++i) trajectory(zs[i], lus[i], plain, first);
     }
-    while (t < t_end) { trajectory(zs[0], lus[0], plain); rotate(); }
+    while (t < t_end) { trajectory(zs[0], lus[0], plain, first); rotate(); }
+    }
   }
   put((gwbytes_t)a.theta, qc);
   if (a.reject_count && k == 0) a.reject_count[c] += a.n_traj - accepted;
@@ -1313,7 +1402,23 @@ template <typename T, int D, int MASS> void launch_small(const GaussArgs<T>& a, 
         profile_begin(s);
         const int lb = g_gauss_eig == 3 ? 0 : a.L;       // gauss_eig = 3: the any-L instance (tests compare the two)
         note_route("hmc_gauss_quad_kernel<%d,%s,%d>", D, diag ? "true" : "false", diag ? 0 : (lb == 25 || lb == 10 || lb == 5) ? lb : 0);
-        if (diag) hmc_gauss_quad_kernel<D, true, 0><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
+        if (!diag && (g_quad_variant == 3 || g_quad_variant == 7) && a.C <= (1 << 20)) {
+          // "quad_variant": 3 = uniform bases + 32-bit lane offsets, no NaN guard; 7 = also the fused row / butterfly block
+          const int lbv = (lb == 25 || lb == 10 || lb == 5) ? lb : 0;
+          note_route("hmc_gauss_quad_kernel<%d,false,%d,%d>", D, lbv, g_quad_variant);
+          if (g_quad_variant == 3) {
+            if (lbv == 25) hmc_gauss_quad_kernel<D, false, 25, 3><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
+            else if (lbv == 10) hmc_gauss_quad_kernel<D, false, 10, 3><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
+            else if (lbv == 5) hmc_gauss_quad_kernel<D, false, 5, 3><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
+            else hmc_gauss_quad_kernel<D, false, 0, 3><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
+          } else {
+            if (lbv == 25) hmc_gauss_quad_kernel<D, false, 25, 7><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
+            else if (lbv == 10) hmc_gauss_quad_kernel<D, false, 10, 7><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
+            else if (lbv == 5) hmc_gauss_quad_kernel<D, false, 5, 7><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
+            else hmc_gauss_quad_kernel<D, false, 0, 7><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
+          }
+        }
+        else if (diag) hmc_gauss_quad_kernel<D, true, 0><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
         else if (lb == 25) hmc_gauss_quad_kernel<D, false, 25><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
         else if (lb == 10) hmc_gauss_quad_kernel<D, false, 10><<<qgrid, 64, 0, s>>>(a, a.ws_logu);
         else if (lb == 5) hmc_gauss_quad_kernel<D, false, 5><<<qgrid, 64, 0, s>>>(a, a.ws_logu);

@@ -373,10 +373,14 @@ int hta_netn_logp_grad_f64(const double* theta, int64_t C, int n_layers, const i
  * csrc/rmhmc_metric_mfma.hip, D <= 112; 0 = always the Jacobi kernel of csrc/rmhmc_metric.hip),
  * "metric_general" (1 default: evaluations with per-system curvature and per-system warm bases - HtaMetricArgs::v0_stride - run on
  * that kernel too; 0 = the Jacobi kernel, cold),
- * "mlp3_route" (1 default: Bayesian MLPs with two wide hidden layers run on csrc/mlp3_mfma.hip; 0 = callback path). */
+ * "mlp3_route" (1 default: Bayesian MLPs with two wide hidden layers run on csrc/mlp3_mfma.hip; 0 = callback path),
+ * "quad_variant" (0 default; 3 = the quad kernel with wave-uniform base addresses + 32-bit lane offsets and without the NaN
+ * guard of the accept compare, 7 = also the row element and the energy butterfly in one interleaved block: bit-identical
+ * results, 5.25 instructions fewer per trajectory of a lone wave). */
 int hta_set_tuning(const char* key, int value);
 /* current value of a route key; every key back to its default (test fixtures call this between tests: the keys are
- * process-global). */
+ * process-global).  The environment variable HTA_TUNING_DEFAULTS="key=value,..." moves the DEFAULT of the named keys for the
+ * process (read when the library is loaded and by hta_reset_tuning): A/B runs of unmodified callers under another route. */
 int hta_get_tuning(const char* key, int* value);
 int hta_reset_tuning(void);
 /* Name (with template arguments) of the dominant kernel the calling thread's last sampling / evaluation call dispatched

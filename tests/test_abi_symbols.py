@@ -74,6 +74,21 @@ def test_every_tuning_key_is_documented_and_accepted():
     assert _abi.last_route() == ""                       # nothing dispatched yet in this thread (no GPU here)
 
 
+def test_tuning_defaults_from_the_environment():
+    """HTA_TUNING_DEFAULTS moves the default of the named route keys for the process: in force when the library is loaded and
+    restored by hta_reset_tuning (A/B runs of unmodified test files under another route); unknown names are ignored."""
+    import subprocess
+    import sys
+    code = ("from hamiltorch_amd import _abi\n"
+            "g = _abi.get_tuning\n"
+            "a = (g('quad_variant'), g('rmhmc_uv'), g('gauss_eig'))\n"
+            "_abi.set_tuning('quad_variant', 0); _abi.set_tuning('rmhmc_uv', 1); _abi.reset_tuning()\n"
+            "print(a, (g('quad_variant'), g('rmhmc_uv'), g('gauss_eig')))\n")
+    env = dict(os.environ, HTA_TUNING_DEFAULTS="quad_variant=7,nope=3,rmhmc_uv=2", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    assert out.strip() == "(7, 2, 1) (7, 2, 1)", out
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     """without the built HIP extension the package raises (no CPU path, no silent fallback)."""
     import pytest

@@ -550,6 +550,47 @@ def test_quad_kernel_step_count_instances_agree(ht, D, C, L):
         assert bool((outs[0][0][1] == th0.cpu()).all(dim=1).any())
 
 
+@pytest.mark.parametrize("D,C,L,N,burn", [(3, 1024, 25, 61, 3), (3, 1024, 25, 40, -1), (1, 17, 5, 37, 3), (2, 100, 10, 44, 0),
+                                           (4, 333, 25, 23, 5), (3, 5, 7, 30, 2), (4, 64, 10, 52, 7)])
+def test_quad_kernel_variants_are_bit_identical(ht, D, C, L, N, burn):
+    """hta_set_tuning('quad_variant', 3 | 7): the quad kernel with wave-uniform base addresses + 32-bit lane offsets (no 64-bit
+    vector add per record load / row store), without the NaN guard in front of the accept compare (2 log u is finite by
+    construction) and - 7 - with the row element and the energy butterfly in one interleaved block.  The arithmetic of a
+    trajectory is untouched: samples, reject counts and the final state are bit-identical to the default instance, over launch
+    boundaries, the burn-in / stored phases, the Q2 trajectory and every tail length of the eight-trajectory pass."""
+    from hamiltorch_amd import _abi
+    rng = np.random.default_rng(D * 1000 + C + N)
+    P = rand_spd(D, 5 + D)
+    mu = rng.normal(size=D)
+    t, _ = targets(ht, P, torch.float32, mu=mu)
+    th0 = tt(mu + rng.normal(size=(C, D)), torch.float32)
+    eps = 0.9 / np.sqrt(np.linalg.eigvalsh(P).max()) * (25.0 / L) ** 0.25
+    rows = N - max(0, min(N, burn + 1)) + 1
+    outs, routes = [], []
+    for var in (0, 3, 7):
+        _abi.set_tuning("quad_variant", var)
+        try:
+            cur = th0.clone()
+            samples = torch.zeros(rows, C, D, device=dev())
+            rej = torch.zeros(C, dtype=torch.int32, device=dev())
+            ws = torch.zeros(_abi.gaussian_workspace_bytes(C, D, N, 4), dtype=torch.uint8, device=dev())
+            for start, cnt in ((0, 2), (2, 11), (13, N - 13)):
+                _abi.hmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, 0, None, None, L, float(eps), cnt, start, burn,
+                                         31, 7, samples, rej, workspace=ws)
+            routes.append(_abi.last_route())
+            torch.cuda.synchronize()
+        finally:
+            _abi.set_tuning("quad_variant", 0)
+        outs.append((samples.cpu(), rej.cpu(), cur.cpu()))
+    lb = L if L in (5, 10, 25) else 0
+    assert routes == ["hmc_gauss_quad_kernel<%d,false,%d>" % (D, lb)] + ["hmc_gauss_quad_kernel<%d,false,%d,%d>" % (D, lb, v) for v in (3, 7)]
+    for other in outs[1:]:
+        for a_, b_ in zip(outs[0], other):
+            assert torch.equal(a_, b_)
+    if C >= 100:
+        assert 0 < int(outs[0][1].sum()) < C * N
+
+
 def test_edge_sizes_against_oracle(ht):
     """Edges of the Gaussian path: the maximum dimension (D = 1024, wave-per-chain kernel), a single chain, an empty launch
     (n_traj = 0 leaves everything untouched) and a chain count beyond the quad kernel's range (one chain per lane,
