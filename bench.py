@@ -140,6 +140,10 @@ class Cfg2:
         self.samples[0].copy_(self.theta0)
         self.rej = torch.zeros(self.C, dtype=torch.int32, device=dev)
         self.ws = torch.empty(_abi.gaussian_workspace_bytes(self.C, 3, self.T, 4), dtype=torch.uint8, device=dev)
+        # once per target, as hamiltorch_amd.sample() does: the eig block of the workspace (HTA_BENCH_PREPARE=0: every call
+        # diagonalises P itself, the behaviour before ABI 8)
+        if os.environ.get("HTA_BENCH_PREPARE", "1") != "0":
+            _abi.hmc_gaussian_prepare(self.theta0, self.tgt.precision, 0, None, self.C, 3, self.T, self.ws)
 
     def units_per_step(self):
         return self.C * self.T * self.L

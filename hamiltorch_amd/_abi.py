@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhamiltorch_amd.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 MASS_NONE, MASS_DIAG, MASS_FULL = 0, 1, 2
 
@@ -59,6 +59,7 @@ def _sig(scalar):
                                     c_int, c_int, c_int, c_u64, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
         "hta_hmc_gaussian_leapfrog": [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_int, c_int, scalar, c_vp, c_vp,
                                       c_vp],
+        "hta_hmc_gaussian_prepare": [c_vp, c_int, c_vp, c_i64, c_int, c_int, c_vp, c_i64, c_vp],
         "hta_metric_eval": [ctypes.POINTER(HtaMetricArgs), c_vp],
         "hta_mlp_hmc_sample": [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int,
                                ctypes.POINTER(scalar), scalar, scalar, c_int, c_vp, c_vp, c_int, c_int, scalar, c_int,
@@ -82,7 +83,7 @@ def _sig(scalar):
 
 #: every symbol include/hamiltorch_amd.h declares (checked by tests/test_abi_symbols.py)
 PLAIN_SYMBOLS = ["hta_abi_version", "hta_last_error", "hta_device_info", "hta_set_tuning", "hta_get_tuning", "hta_reset_tuning",
-                 "hta_last_route", "hta_profile_collect", "hta_counter_add", "hta_rmhmc_gaussian_forget",
+                 "hta_last_route", "hta_profile_collect", "hta_counter_add", "hta_rmhmc_gaussian_forget", "hta_hmc_gaussian_forget",
                  "hta_hmc_gaussian_workspace_bytes", "hta_rmhmc_workspace_bytes"]
 TYPED_SYMBOLS = sorted(_sig(c_f32).keys())
 
@@ -118,6 +119,8 @@ def load():
         lib.hta_rmhmc_workspace_bytes.restype = c_i64
         lib.hta_rmhmc_gaussian_forget.argtypes = [c_vp]
         lib.hta_rmhmc_gaussian_forget.restype = c_int
+        lib.hta_hmc_gaussian_forget.argtypes = [c_vp]
+        lib.hta_hmc_gaussian_forget.restype = c_int
         for suf, scalar in (("f32", c_f32), ("f64", c_f64)):
             for name, args in _sig(scalar).items():
                 fn = getattr(lib, "%s_%s" % (name, suf))
@@ -289,6 +292,20 @@ def hmc_gaussian_sample(theta, theta_init, P, mu, log_norm, mass_kind, inv_mass,
                   None if workspace is None else c_vp(workspace.data_ptr()),
                   0 if workspace is None else workspace.numel() * workspace.element_size(),
                   _stream(theta)), "hta_hmc_gaussian_sample")
+
+
+def hmc_gaussian_prepare(like, P, mass_kind, mass_factor, C, D, n_traj, workspace):
+    """hta_hmc_gaussian_prepare: the eig block of `workspace` filled once for sample calls of `n_traj` trajectories on this
+    target (contract in include/hamiltorch_amd.h: P / mass_factor unchanged until the next prepare or forget)."""
+    require_device(like, "params")
+    fn = getattr(load(), "hta_hmc_gaussian_prepare_" + _suffix(like))
+    with torch.cuda.device(like.device):
+        _check(fn(_p(P, like), int(mass_kind), _p(mass_factor, like), int(C), int(D), int(n_traj), c_vp(workspace.data_ptr()),
+                  workspace.numel() * workspace.element_size(), _stream(like)), "hta_hmc_gaussian_prepare")
+
+
+def hmc_gaussian_forget(workspace):
+    _check(load().hta_hmc_gaussian_forget(c_vp(workspace.data_ptr())), "hta_hmc_gaussian_forget")
 
 
 def hmc_gaussian_leapfrog(theta, p, P, mu, mass_kind, inv_mass, steps, eps, path_theta=None, path_p=None):

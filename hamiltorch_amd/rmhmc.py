@@ -343,10 +343,11 @@ def _prepared_workspace(tgt, theta0, kind, alpha, jitter, N):
     need = _abi.rmhmc_workspace_bytes(C, D, theta0.element_size(), N)
     key = (theta0.device, theta0.dtype, C, D, int(kind), None if alpha is None else float(alpha), None if jitter is None else float(jitter),
            torch.cuda.current_stream(theta0.device).cuda_stream)
-    sig = (tgt.precision.data_ptr(), tgt.precision._version, tgt.mean.data_ptr(), tgt.mean._version)
+    # (the entry holds the tensor OBJECTS: while they are cached their storage cannot be freed and handed to another matrix)
+    sig = (tgt.precision, tgt.mean, tgt.precision.data_ptr(), tgt.precision._version, tgt.mean.data_ptr(), tgt.mean._version)
     cache = tgt.__dict__.setdefault("_hta_rm_ws", {})
     hit = cache.get(key)
-    if hit is not None and hit[1] == sig and hit[0].ws.numel() >= need:
+    if hit is not None and hit[1][0] is sig[0] and hit[1][1] is sig[1] and hit[1][2:] == sig[2:] and hit[0].ws.numel() >= need:
         return hit[0].ws
     ws = torch.empty(need, dtype=torch.uint8, device=theta0.device)
     _abi.rmhmc_gaussian_prepare(theta0, tgt.precision, tgt.mean, kind, alpha, jitter, C, ws)

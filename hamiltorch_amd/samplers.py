@@ -606,10 +606,14 @@ class _GaussianHMC(_Engine):
         chunk = max(1, min(count, (self.WS_CAP - fixed) // per_traj)) if (fits and per_traj > 0) else count
         ws = None
         if fits and (H_old is None):
-            ws = getattr(self, "_ws", None)
-            need = _abi.gaussian_workspace_bytes(C, D, chunk, theta0.element_size())
-            if ws is None or ws.numel() < need:
-                ws = self._ws = torch.empty(need, dtype=torch.uint8, device=theta0.device)
+            if self.kind == _abi.MASS_NONE and per_traj > 0:
+                # identity mass, eigenbasis route: the workspace lives on the target, its eig block PREPARED once
+                ws = _prepared_hmc_workspace(self.t, theta0, chunk)
+            else:
+                ws = getattr(self, "_ws", None)
+                need = _abi.gaussian_workspace_bytes(C, D, chunk, theta0.element_size())
+                if ws is None or ws.numel() < need:
+                    ws = self._ws = torch.empty(need, dtype=torch.uint8, device=theta0.device)
         if H_old is not None:
             chunk = 1                      # diagnostics are [n_traj, C]: one trajectory per call (NUTS burn-in)
         for start in range(n0, n0 + count, chunk):
@@ -618,6 +622,41 @@ class _GaussianHMC(_Engine):
                                      self.seed, self.off, self.samples, self.rejected, H_old, H_new, workspace=ws)
             if progress is not None:
                 progress.update(min(self.N, start + chunk) - 1)
+
+
+class _HmcWorkspaceHandle:
+    """Owns a prepared Gaussian-HMC workspace: the library's (device, eig block) -> plan entry goes when the buffer does."""
+
+    def __init__(self, ws):
+        self.ws = ws
+
+    def __del__(self):
+        try:
+            _abi.hmc_gaussian_forget(self.ws)
+        except Exception:       # interpreter shutdown
+            pass
+
+
+def _prepared_hmc_workspace(tgt, theta0, chunk):
+    """The workspace of hta_hmc_gaussian_sample for launches of `chunk` trajectories on this target, its eig block PREPARED
+    once (hta_hmc_gaussian_prepare: the diagonalisation of the precision matrix, a single-wave kernel in front of every
+    launch otherwise - 3 % of a BASELINE-config-2 call) and kept on the target object: repeated sample() calls and the
+    launches of a chunked run pay it once.  Keyed by everything the eig block's content and position depend on, by the stream
+    the kernels run on and by the precision tensor's version counter (an in-place edit of the target prepares again)."""
+    C, D = theta0.shape
+    key = (theta0.device, theta0.dtype, C, D, int(chunk), torch.cuda.current_stream(theta0.device).cuda_stream)
+    # (the entry holds the tensor OBJECT: while it is cached its storage cannot be freed and handed to another matrix)
+    sig = (tgt.precision, tgt.precision.data_ptr(), tgt.precision._version)
+    cache = tgt.__dict__.setdefault("_hta_hmc_ws", {})
+    hit = cache.get(key)
+    if hit is not None and hit[1][0] is sig[0] and hit[1][1:] == sig[1:]:
+        return hit[0].ws
+    ws = torch.empty(_abi.gaussian_workspace_bytes(C, D, chunk, theta0.element_size()), dtype=torch.uint8, device=theta0.device)
+    _abi.hmc_gaussian_prepare(theta0, tgt.precision, _abi.MASS_NONE, None, C, D, chunk, ws)
+    if len(cache) >= 2:                 # the buffers are up to WS_CAP bytes each: two shapes per target at most
+        cache.clear()
+    cache[key] = (_HmcWorkspaceHandle(ws), sig)
+    return ws
 
 
 class _GenericHMC(_Engine):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HTA_ABI_VERSION 7
+#define HTA_ABI_VERSION 8
 
 #define HTA_OK 0
 #define HTA_ERR_INVALID (-1)   /* bad argument                           */
@@ -155,6 +155,23 @@ int hta_hmc_gaussian_sample_f64(double* theta, const double* theta_init, const d
                                 uint8_t* accept, void* workspace, int64_t workspace_bytes, void* stream);
 
 int64_t hta_hmc_gaussian_workspace_bytes(int64_t C, int D, int n_traj, int elem_size);
+
+/* Once-per-TARGET setup of hta_hmc_gaussian_sample, hoisted (ABI 8; the Gaussian-HMC counterpart of
+ * hta_rmhmc_gaussian_prepare).  On the eigenbasis route (workspace given, D <= 6, fp64: 4) every sample call first
+ * diagonalises the mass-whitened precision matrix into the workspace's eig block - one single-wave kernel, ~5 us plus a launch
+ * gap in front of the draw pass: 3 % of a 1000-trajectory call at BASELINE config 2, and the same matrix every time for a
+ * caller that keeps sampling one target (hamiltorch.sample()'s loop over trajectories has no such setup: S:965-1026).
+ * hta_hmc_gaussian_prepare runs that kernel into `workspace` for calls of `n_traj` trajectories (the eig block sits behind the
+ * records: its position depends on n_traj) and remembers (device, eig block) -> (P, mass_kind, mass_factor, D, element type);
+ * a sample call with the same workspace, n_traj, P / mass_factor POINTERS, mass kind, D and element type skips the kernel,
+ * any other call runs it as before.  Contract: the CONTENTS of P / mass_factor must not change between prepare and sample
+ * (prepare again, or hta_hmc_gaussian_forget), and the workspace must not be used for anything else in between.  Results are
+ * bit-identical with and without.  Routes without an eig block (D > 6, "gauss_eig" 0): prepare is a no-op. */
+int hta_hmc_gaussian_prepare_f32(const float* P, int mass_kind, const float* mass_factor, int64_t C, int D, int n_traj,
+                                 void* workspace, int64_t workspace_bytes, void* stream);
+int hta_hmc_gaussian_prepare_f64(const double* P, int mass_kind, const double* mass_factor, int64_t C, int D, int n_traj,
+                                 void* workspace, int64_t workspace_bytes, void* stream);
+int hta_hmc_gaussian_forget(void* workspace);
 
 /* leapfrog() only (S:267-304) for the same target: theta, p [C,D] in/out after `steps` steps.
  * path_theta / path_p: optional [steps,C,D] record of every step (the lists of S:299-300, last

@@ -57,6 +57,14 @@ def _replay_reference_run(init, N, propose):
 
 # =====================================================================================================================
 # cfg2: 3-D Gaussian HMC, 1024 chains, L = 25, eps = 0.3 -- hmc_gauss_quad_kernel<3,false,25>
+def _CFG2_ROUTE():
+    """The quad kernel's instance for L = 25 in the variant the route key "quad_variant" selects (0: the name without a
+    fourth template argument)."""
+    from hamiltorch_amd import _abi
+    v = _abi.get_tuning("quad_variant")
+    return "hmc_gauss_quad_kernel<3,false,25%s>" % (",%d" % v if v else "")
+
+
 # =====================================================================================================================
 def _cfg2(ht):
     P = np.linalg.inv(SIGMA3)
@@ -80,7 +88,7 @@ def test_cfg2_bench_instance_vs_oracle_every_chain(ht):
     for start in (0, 40, 80):
         _abi.hmc_gaussian_sample(cur, theta0, t.precision, t.mean, t.log_norm, 0, None, None, L, eps, 40, start, -1, seed, off,
                                  samples, rej, workspace=ws)
-    assert _abi.last_route() == "hmc_gauss_quad_kernel<3,false,25>"          # the instance bench.py times (and names)
+    assert _abi.last_route() == _CFG2_ROUTE()                                # the instance bench.py times (and names)
     ref, info = O.sample_hmc(o, th0, T, L, eps, -1, None, O.PhiloxDraws(seed, off + np.arange(C)))
     err = _chain_err(samples.cpu().numpy(), np.stack(ref))
     bad = err > 2e-4
@@ -100,7 +108,7 @@ def test_cfg2_sample_api_full_size_with_burn_vs_oracle(ht):
                          seed=seed, chain_offset=off)
     ref, info = O.sample_hmc(o, th0, N, L, eps, burn, None, O.PhiloxDraws(seed, off + np.arange(C)))
     from hamiltorch_amd import _abi
-    assert _abi.last_route() == "hmc_gauss_quad_kernel<3,false,25>"
+    assert _abi.last_route() == _CFG2_ROUTE()
     assert len(out) == len(ref) == N - burn
     err = _chain_err(torch.stack(out).cpu().numpy(), np.stack(ref))
     bad = err > 2e-4

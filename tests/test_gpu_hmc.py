@@ -591,6 +591,56 @@ def test_quad_kernel_variants_are_bit_identical(ht, D, C, L, N, burn):
         assert 0 < int(outs[0][1].sum()) < C * N
 
 
+def test_hmc_prepared_workspace_is_bit_identical_and_skips_the_setup(ht):
+    """hta_hmc_gaussian_prepare (ABI 8): the diagonalisation of the precision matrix - a single-wave kernel in front of every
+    launch of the eigenbasis route - hoisted out of the sample call.  Same bits with and without; a prepared call does not look
+    at P again (shown by breaking the contract on purpose: P edited in place after the preparation changes nothing until
+    hta_hmc_gaussian_forget); another trajectory count (= another eig block position) runs the setup itself;
+    hamiltorch_amd.sample() prepares once per target and again after an in-place edit of the target."""
+    from hamiltorch_amd import _abi
+    rng = np.random.default_rng(77)
+    mu = rng.normal(size=3)
+    t, _ = targets(ht, rand_spd(3, 8), torch.float32, mu=mu)
+    C, N, L, eps = 256, 40, 25, 0.3
+    th0 = tt(mu + rng.normal(size=(C, 3)), torch.float32)
+    nbytes = _abi.gaussian_workspace_bytes(C, 3, N, 4)
+    ws_a = torch.zeros(nbytes, dtype=torch.uint8, device=dev()); ws_b = torch.zeros(nbytes, dtype=torch.uint8, device=dev())
+
+    def run(ws, n=N):
+        cur = th0.clone(); samples = torch.zeros(n + 1, C, 3, device=dev()); rej = torch.zeros(C, dtype=torch.int32, device=dev())
+        _abi.hmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, 0, None, None, L, eps, n, 0, -1, 13, 0, samples, rej,
+                                 workspace=ws)
+        assert _abi.last_route().startswith("hmc_gauss_quad_kernel<3,false,25")
+        torch.cuda.synchronize()
+        return torch.cat([samples.reshape(-1), rej.float(), cur.reshape(-1)]).cpu()
+    s0 = run(ws_a)
+    _abi.hmc_gaussian_prepare(th0, t.precision, 0, None, C, 3, N, ws_b)
+    s1 = run(ws_b)
+    assert torch.equal(s0, s1)
+    t.precision.mul_(1.7)                        # contract broken on purpose
+    assert torch.equal(run(ws_b), s1)            # prepared: the old eigenbasis, P is not read again
+    s3 = run(ws_a)
+    assert not torch.equal(s3, s0)               # unprepared: the call diagonalises what P holds now
+    assert torch.equal(run(ws_b, N - 7), run(ws_a, N - 7))       # another n_traj: not the prepared eig block -> own setup
+    assert torch.equal(run(ws_b), s1)            # ... and the preparation for N is still in force
+    _abi.hmc_gaussian_forget(ws_b)
+    assert torch.equal(run(ws_b), s3)
+    _abi.hmc_gaussian_prepare(th0, t.precision, 0, None, C, 3, N, ws_b)
+    assert torch.equal(run(ws_b), s3)
+    _abi.hmc_gaussian_forget(ws_b)
+    # through sample(): one prepared workspace per target, prepared again after an in-place edit of the precision matrix
+    kw = dict(num_samples=30, num_steps_per_sample=L, step_size=eps, verbose=False, seed=9)
+    a = torch.stack(list(ht.sample(t, th0, **kw)))
+    ws_id = next(iter(t._hta_hmc_ws.values()))[0].ws.data_ptr()
+    b = torch.stack(list(ht.sample(t, th0, **kw)))
+    assert torch.equal(a, b) and next(iter(t._hta_hmc_ws.values()))[0].ws.data_ptr() == ws_id
+    t.precision.mul_(1.5)
+    c = torch.stack(list(ht.sample(t, th0, **kw)))
+    t2 = ht.GaussianTarget(t.mean.clone(), precision=t.precision.clone(), normalized=False)
+    d = torch.stack(list(ht.sample(t2, th0, **kw)))
+    assert torch.equal(c, d) and not torch.equal(c, a)
+
+
 def test_edge_sizes_against_oracle(ht):
     """Edges of the Gaussian path: the maximum dimension (D = 1024, wave-per-chain kernel), a single chain, an empty launch
     (n_traj = 0 leaves everything untouched) and a chain count beyond the quad kernel's range (one chain per lane,

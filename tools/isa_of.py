@@ -50,14 +50,24 @@ def kernel_lines(path, pattern):
 
 def classify(ins):
     op = ins.split()[0]
+    if op.startswith("v_mfma") or op.startswith("v_smfmac"):
+        return "mfma"
+    if op.startswith(("v_accvgpr", "v_accvgpr_read", "v_accvgpr_write")):
+        return "acc"
     if op.startswith(("v_fmac_f32", "v_fma_f32", "v_pk_fma_f32")) and "dpp" not in ins:
         return "fma"
-    if op.startswith(("s_waitcnt", "s_nop")):
+    if op.startswith("s_waitcnt"):
         return "wait"
-    if op.startswith(("global_", "buffer_", "flat_", "scratch_", "ds_")):
+    if op.startswith("s_nop"):
+        return "nop"
+    if op.startswith("s_barrier"):
+        return "barrier"
+    if op.startswith("ds_"):
+        return "lds"
+    if op.startswith(("global_", "buffer_", "flat_", "scratch_")):
         return "mem"
     if op.startswith("v_"):
-        return "valu"
+        return "dpp" if ("dpp" in ins or "quad_perm" in ins or "row_" in ins) else "valu"
     return "salu"
 
 
