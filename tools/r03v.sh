@@ -21,7 +21,7 @@ for vp in 0:0 0:1 3:1 7:1 7:0; do
   HTA_BENCH_PREPARE=$pz HTA_TUNING=quad_variant=$v timeout 90 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2> gpurun_out/${R}_ab_v${v}_p${pz}.err | tail -1 >> gpurun_out/${R}_ab_lines.txt
   stamp "ab v=$v prepare=$pz rc=$?"
 done
-HTA_TUNING_DEFAULTS=quad_variant=7 timeout 420 python -m pytest tests -m gpu -q -x --durations=10 > gpurun_out/${R}_gpu_tests_variant7.txt 2>&1
+HTA_TUNING_DEFAULTS=quad_variant=7 timeout 420 python -m pytest tests -m gpu -q --durations=10 > gpurun_out/${R}_gpu_tests_variant7.txt 2>&1
 stamp "suite under quad_variant=7 rc=$?"
 timeout 150 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${R}_bench_stdout.txt 2> gpurun_out/${R}_bench.err
 stamp "driver bench rc=$?"
