@@ -745,7 +745,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 // LB > 0: a.L == LB is known at compile time (straight-line steps, no loop bookkeeping: at this size every scalar
 // instruction on the hot path costs what a vector one does); LB == 0: any L.
 //
-// VAR (tuning key "quad_variant", default 0) - the same arithmetic, fewer instructions around it (a lone wave pays ~2 ns for
+// VAR (tuning key "quad_variant", default 7) - the same arithmetic, fewer instructions around it (a lone wave pays ~2 ns for
 // ANY instruction, so the 28 that are not the trajectory's 52 dependent FMAs are a third of its time):
 //   bit 0  addresses as a wave-uniform base (an SGPR pair, advanced once per pass of the unrolled loop) plus a 32-bit lane
 //          offset per position of that loop (loop-invariant registers): no 64-bit vector add per record load and per row store
@@ -753,7 +753,10 @@ __device__ __forceinline__ float quad_sum(float v) {
 //   bit 1  no NaN guard in front of the accept compare: the record's 2 log u is finite by construction (u23: 23-bit uniforms
 //          in (0, 1)), the energy difference is finite, -inf or NaN (sums of squares cannot reach -inf, the current point is
 //          finite), and both -inf >= x and NaN >= x are false - the guard never changes a decision.
-// Results are bit-identical to VAR = 0 (tests/test_gpu_hmc.py::test_quad_variants_are_bit_identical).
+//   bit 2  the row element and the quad butterfly of the energy difference as ONE interleaved block (see TAIL below).
+// Results are bit-identical to VAR = 0 (tests/test_gpu_hmc.py::test_quad_kernel_variants_are_bit_identical).  Measured at BASELINE
+// config 2 (profiles/r03v_*): 166.3 us (VAR 0) -> 157.5 us (VAR 7) per 1000-trajectory launch; the static count 78.5 -> 73.25
+// instructions per trajectory (tools/isa_of.py --loops) predicted 155.
 template <int I, int N, typename F> __device__ __forceinline__ void quad_static_for(F&& f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); quad_static_for<I + 1, N>(f); }
 }

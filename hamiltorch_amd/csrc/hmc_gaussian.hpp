@@ -19,7 +19,7 @@ extern int g_small_chains_per_block;
 extern int g_force_general;
 extern int g_gauss_eig;
 extern int g_quad_max_chains;
-extern int g_quad_variant;                                  // tuning key "quad_variant" (default 0; 3: see hmc_gauss_quad_kernel's VAR)
+extern int g_quad_variant;                                  // tuning key "quad_variant" (default 7; 0 / 3: see hmc_gauss_quad_kernel's VAR)
 extern int g_fill_blocks;
 void profile_begin(hipStream_t s);
 void profile_end(hipStream_t s);

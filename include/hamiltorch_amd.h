@@ -391,9 +391,10 @@ int hta_netn_logp_grad_f64(const double* theta, int64_t C, int n_layers, const i
  * "metric_general" (1 default: evaluations with per-system curvature and per-system warm bases - HtaMetricArgs::v0_stride - run on
  * that kernel too; 0 = the Jacobi kernel, cold),
  * "mlp3_route" (1 default: Bayesian MLPs with two wide hidden layers run on csrc/mlp3_mfma.hip; 0 = callback path),
- * "quad_variant" (0 default; 3 = the quad kernel with wave-uniform base addresses + 32-bit lane offsets and without the NaN
- * guard of the accept compare, 7 = also the row element and the energy butterfly in one interleaved block: bit-identical
- * results, 5.25 instructions fewer per trajectory of a lone wave). */
+ * "quad_variant" (7 default: the quad kernel with wave-uniform base addresses + 32-bit lane offsets, without the NaN guard of
+ * the accept compare, and with the row element and the energy butterfly in one interleaved block; 3 = without that block;
+ * 0 = the round-1 instance.  Bit-identical results; 78.5 / 74.1 / 73.25 instructions per trajectory of a lone wave at L = 25:
+ * 166.3 -> 157.5 us per 1000 trajectories of BASELINE config 2). */
 int hta_set_tuning(const char* key, int value);
 /* current value of a route key; every key back to its default (test fixtures call this between tests: the keys are
  * process-global).  The environment variable HTA_TUNING_DEFAULTS="key=value,..." moves the DEFAULT of the named keys for the

@@ -84,9 +84,9 @@ def test_tuning_defaults_from_the_environment():
             "a = (g('quad_variant'), g('rmhmc_uv'), g('gauss_eig'))\n"
             "_abi.set_tuning('quad_variant', 0); _abi.set_tuning('rmhmc_uv', 1); _abi.reset_tuning()\n"
             "print(a, (g('quad_variant'), g('rmhmc_uv'), g('gauss_eig')))\n")
-    env = dict(os.environ, HTA_TUNING_DEFAULTS="quad_variant=7,nope=3,rmhmc_uv=2", PYTHONPATH=ROOT)
+    env = dict(os.environ, HTA_TUNING_DEFAULTS="quad_variant=3,nope=3,rmhmc_uv=2", PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
-    assert out.strip() == "(7, 2, 1) (7, 2, 1)", out
+    assert out.strip() == "(3, 2, 1) (3, 2, 1)", out
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -553,10 +553,10 @@ def test_quad_kernel_step_count_instances_agree(ht, D, C, L):
 @pytest.mark.parametrize("D,C,L,N,burn", [(3, 1024, 25, 61, 3), (3, 1024, 25, 40, -1), (1, 17, 5, 37, 3), (2, 100, 10, 44, 0),
                                            (4, 333, 25, 23, 5), (3, 5, 7, 30, 2), (4, 64, 10, 52, 7)])
 def test_quad_kernel_variants_are_bit_identical(ht, D, C, L, N, burn):
-    """hta_set_tuning('quad_variant', 3 | 7): the quad kernel with wave-uniform base addresses + 32-bit lane offsets (no 64-bit
+    """hta_set_tuning('quad_variant', 0 | 3 | 7 (default)): the quad kernel with wave-uniform base addresses + 32-bit lane offsets (no 64-bit
     vector add per record load / row store), without the NaN guard in front of the accept compare (2 log u is finite by
     construction) and - 7 - with the row element and the energy butterfly in one interleaved block.  The arithmetic of a
-    trajectory is untouched: samples, reject counts and the final state are bit-identical to the default instance, over launch
+    trajectory is untouched: samples, reject counts and the final state are bit-identical to the round-1 instance (0), over launch
     boundaries, the burn-in / stored phases, the Q2 trajectory and every tail length of the eight-trajectory pass."""
     from hamiltorch_amd import _abi
     rng = np.random.default_rng(D * 1000 + C + N)
@@ -580,7 +580,7 @@ def test_quad_kernel_variants_are_bit_identical(ht, D, C, L, N, burn):
             routes.append(_abi.last_route())
             torch.cuda.synchronize()
         finally:
-            _abi.set_tuning("quad_variant", 0)
+            _abi.reset_tuning()
         outs.append((samples.cpu(), rej.cpu(), cur.cpu()))
     lb = L if L in (5, 10, 25) else 0
     assert routes == ["hmc_gauss_quad_kernel<%d,false,%d>" % (D, lb)] + ["hmc_gauss_quad_kernel<%d,false,%d,%d>" % (D, lb, v) for v in (3, 7)]
