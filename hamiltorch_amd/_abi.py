@@ -83,7 +83,7 @@ def _sig(scalar):
 
 #: every symbol include/hamiltorch_amd.h declares (checked by tests/test_abi_symbols.py)
 PLAIN_SYMBOLS = ["hta_abi_version", "hta_last_error", "hta_device_info", "hta_set_tuning", "hta_get_tuning", "hta_reset_tuning",
-                 "hta_last_route", "hta_profile_collect", "hta_counter_add", "hta_rmhmc_gaussian_forget", "hta_hmc_gaussian_forget",
+                 "hta_last_route", "hta_profile_collect", "hta_counter_add", "hta_run_begin", "hta_rmhmc_gaussian_forget", "hta_hmc_gaussian_forget",
                  "hta_hmc_gaussian_workspace_bytes", "hta_rmhmc_workspace_bytes"]
 TYPED_SYMBOLS = sorted(_sig(c_f32).keys())
 
@@ -115,6 +115,8 @@ def load():
         lib.hta_hmc_gaussian_workspace_bytes.restype = c_i64
         lib.hta_counter_add.argtypes = [c_vp, c_int, c_vp]
         lib.hta_counter_add.restype = c_int
+        lib.hta_run_begin.argtypes = [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]
+        lib.hta_run_begin.restype = c_int
         lib.hta_rmhmc_workspace_bytes.argtypes = [c_i64, c_int, c_int]
         lib.hta_rmhmc_workspace_bytes.restype = c_i64
         lib.hta_rmhmc_gaussian_forget.argtypes = [c_vp]
@@ -292,6 +294,16 @@ def hmc_gaussian_sample(theta, theta_init, P, mu, log_norm, mass_kind, inv_mass,
                   None if workspace is None else c_vp(workspace.data_ptr()),
                   0 if workspace is None else workspace.numel() * workspace.element_size(),
                   _stream(theta)), "hta_hmc_gaussian_sample")
+
+
+def run_begin(init, cur, row0, reject_count):
+    """hta_run_begin: cur <- init, row0 <- init, reject_count <- 0 in one launch (the first lines of every run)."""
+    require_device(init, "params_init")
+    C, D = init.shape
+    assert cur.is_contiguous() and init.is_contiguous() and (row0 is None or row0.is_contiguous())
+    with torch.cuda.device(init.device):
+        _check(load().hta_run_begin(_p(init), _p(cur, init), _p(row0, init), _p(reject_count), C, D, init.element_size(),
+                                    _stream(init)), "hta_run_begin")
 
 
 def hmc_gaussian_prepare(like, P, mass_kind, mass_factor, C, D, n_traj, workspace):

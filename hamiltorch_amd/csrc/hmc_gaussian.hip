@@ -837,7 +837,7 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
   // UADDR: the record of the trajectory at position i of the unrolled loop is recb + roff[i] (recb: the row NS ahead of the
   // pass's first trajectory), its stored row element rowb + soff[i]; both bases are wave-uniform and move once per pass.
   // (the dispatcher bounds C so that the offsets stay below 2^32)
-  constexpr int NU = UADDR ? 4 * NS : 2 * NS;       // trajectories per pass of the unrolled loop (the scalar bookkeeping of a pass is shared)
+  constexpr int NU = UADDR ? (LB == 25 ? 8 : 4) * NS : 2 * NS;       // trajectories per pass of the unrolled loop (the scalar bookkeeping of a pass is shared)
   typedef const __attribute__((address_space(1))) char* gcbytes_t;
   gcbytes_t recb = (gcbytes_t)a.ws_z + (size_t)NS * (rec_step * sizeof(T));
   uint32_t roff[NU], uoff[NU], soff[NU];

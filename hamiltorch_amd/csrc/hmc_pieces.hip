@@ -165,6 +165,16 @@ int momentum_resample(T* p, int kind, const T* mf, int64_t C, int D, uint64_t se
   return HTA_OK;
 }
 
+__global__ void run_begin_kernel(const uint32_t* __restrict__ init, uint32_t* __restrict__ cur, uint32_t* __restrict__ row0,
+                                 int32_t* __restrict__ rej, int64_t words, int64_t C) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t v = init[i];
+    cur[i] = v;
+    if (row0) row0[i] = v;
+    if (rej && i < C) rej[i] = 0;
+  }
+}
+
 template <typename T>
 int kick_drift(T* theta, T* p, const T* grad, T kick, T drift, int kind, const T* im, int64_t C, int D,
                hipStream_t s) {
@@ -300,6 +310,19 @@ int hta_mh_select_at_f64(double* cur, const double* prop, const double* init, co
                          const int32_t* n_dev, int burn, uint64_t seed, uint64_t off, void* s) {
   if (!n_dev) { hta::set_error("hta_mh_select_at: n_dev is NULL"); return HTA_ERR_INVALID; }
   return hta::mh_select_impl<double>(cur, prop, init, Ho, Hn, lpn, samples_base, rej, acc, C, D, 0, burn, seed, off, (hipStream_t)s, n_dev);
+}
+/* what every sample() run starts with (S:959-963: params = params_init.clone(), ret_params = [params.clone()], num_rejected = 0)
+ * as ONE launch: cur <- init, row0 <- init, reject_count <- 0.  elem_size 4 or 8; total = C * D elements. */
+int hta_run_begin(const void* init, void* cur, void* row0, int32_t* reject_count, int64_t C, int D, int elem_size, void* s) {
+  if (!init || !cur || C <= 0 || D <= 0 || (elem_size != 4 && elem_size != 8)) {
+    hta::set_error("hta_run_begin: bad arguments");
+    return HTA_ERR_INVALID;
+  }
+  const int64_t words = C * D * (elem_size / 4);
+  int grid = (int)((words + 255) / 256); if (grid > 4096) grid = 4096;
+  hta::run_begin_kernel<<<grid, 256, 0, (hipStream_t)s>>>((const uint32_t*)init, (uint32_t*)cur, (uint32_t*)row0, reject_count, words, C);
+  HTA_CHECK_LAUNCH("hta_run_begin");
+  return HTA_OK;
 }
 int hta_counter_add(int32_t* counter, int delta, void* s) {
   if (!counter) { hta::set_error("hta_counter_add: NULL counter"); return HTA_ERR_INVALID; }

@@ -513,9 +513,9 @@ class _Engine:
         self.theta0, self.N, self.burn, self.seed, self.off = theta0, N, burn, seed, chain_offset
         self.kind, self.im, self.mf = _mass_operands(inv_mass, theta0)
         self.samples = torch.empty((_num_rows(N, burn), C, D), dtype=theta0.dtype, device=theta0.device)
-        self.samples[0].copy_(theta0)
-        self.cur = theta0.clone()
-        self.rejected = torch.zeros(C, dtype=torch.int32, device=theta0.device)
+        self.cur = torch.empty_like(theta0)
+        self.rejected = torch.empty(C, dtype=torch.int32, device=theta0.device)
+        _abi.run_begin(theta0, self.cur, self.samples[0], self.rejected)      # S:959-963 as one launch instead of three
 
     def finish(self):
         return self.samples, self.rejected

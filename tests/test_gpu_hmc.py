@@ -591,6 +591,21 @@ def test_quad_kernel_variants_are_bit_identical(ht, D, C, L, N, burn):
         assert 0 < int(outs[0][1].sum()) < C * N
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_run_begin_is_the_three_initial_copies(ht, dtype):
+    """hta_run_begin: params = params_init.clone(), ret_params = [params.clone()], num_rejected = 0 (S:959-963) in one launch."""
+    from hamiltorch_amd import _abi
+    for C, D in ((37, 5), (1, 1), (1024, 3), (5000, 129)):
+        init = torch.randn(C, D, dtype=dtype, device=dev())
+        cur = torch.full_like(init, float("nan")); rows = torch.full((2, C, D), float("nan"), dtype=dtype, device=dev())
+        rej = torch.full((C,), 7, dtype=torch.int32, device=dev())
+        _abi.run_begin(init, cur, rows[0], rej)
+        assert torch.equal(cur, init) and torch.equal(rows[0], init) and bool(torch.isnan(rows[1]).all()) and int(rej.abs().sum()) == 0
+        cur2 = torch.zeros_like(init)
+        _abi.run_begin(init, cur2, None, None)
+        assert torch.equal(cur2, init)
+
+
 def test_hmc_prepared_workspace_is_bit_identical_and_skips_the_setup(ht):
     """hta_hmc_gaussian_prepare (ABI 8): the diagonalisation of the precision matrix - a single-wave kernel in front of every
     launch of the eigenbasis route - hoisted out of the sample call.  Same bits with and without; a prepared call does not look
