@@ -541,3 +541,48 @@ def test_split_schedules_repeat_a_gradient_exactly_where_the_kernels_share_it(ki
         assert len(set(log)) == distinct           # a repeated evaluation always directly follows its twin
     want = {"symmetric": (2 * M - 2) * L + 1, "kmid": 2 * M * L - (L - 1), "rand": 2 * M * L}[kind]
     assert distinct == want, (distinct, want)
+
+
+def test_prepared_workspace_caches_follow_the_target(monkeypatch):
+    """The per-target caches of prepared workspaces (samplers._prepared_hmc_workspace, rmhmc._prepared_workspace): one
+    preparation per (target, shape, stream); an in-place edit of the precision / mean (version counter) or a replaced tensor
+    prepares again; a cached entry keeps the tensor object alive (its storage cannot be handed to another matrix while the
+    entry could match it); dropping the target forgets the workspace in the library.  The C entry points are stubbed: this is
+    the host logic only."""
+    import gc
+    import types
+    from hamiltorch_amd import _abi, rmhmc
+    calls = {"hmc_prepare": 0, "hmc_forget": 0, "rm_prepare": 0, "rm_forget": 0}
+    monkeypatch.setattr(_abi, "gaussian_workspace_bytes", lambda C, D, n, es: 64 + C * D * n)
+    monkeypatch.setattr(_abi, "hmc_gaussian_prepare", lambda *a, **k: calls.__setitem__("hmc_prepare", calls["hmc_prepare"] + 1))
+    monkeypatch.setattr(_abi, "hmc_gaussian_forget", lambda ws: calls.__setitem__("hmc_forget", calls["hmc_forget"] + 1))
+    monkeypatch.setattr(_abi, "rmhmc_workspace_bytes", lambda C, D, es, N: 64 + C * D)
+    monkeypatch.setattr(_abi, "rmhmc_gaussian_prepare", lambda *a, **k: calls.__setitem__("rm_prepare", calls["rm_prepare"] + 1))
+    monkeypatch.setattr(_abi, "rmhmc_gaussian_forget", lambda ws: calls.__setitem__("rm_forget", calls["rm_forget"] + 1))
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda dev=None: types.SimpleNamespace(cuda_stream=0))
+    th0 = torch.zeros(8, 3)
+    t = ht.GaussianTarget(torch.zeros(3), precision=torch.eye(3), normalized=False)
+
+    ws1 = samplers._prepared_hmc_workspace(t, th0, 10)
+    assert samplers._prepared_hmc_workspace(t, th0, 10) is ws1 and calls["hmc_prepare"] == 1          # reused
+    ws2 = samplers._prepared_hmc_workspace(t, th0, 7)                                                  # another launch length
+    assert ws2 is not ws1 and calls["hmc_prepare"] == 2
+    t.precision.mul_(2.0)                                                                              # in-place edit
+    ws3 = samplers._prepared_hmc_workspace(t, th0, 10)
+    assert ws3 is not ws1 and calls["hmc_prepare"] == 3
+    old = t.precision
+    t.precision = torch.eye(3) * 3.0                                                                   # replaced tensor
+    assert samplers._prepared_hmc_workspace(t, th0, 10) is not ws3 and calls["hmc_prepare"] == 4
+    assert any(sig[0] is old or sig[0] is t.precision for _, sig in t._hta_hmc_ws.values())            # entries hold tensor objects
+    assert len(t._hta_hmc_ws) <= 2                                                                     # bounded per target
+    # RMHMC: keyed by metric / alpha / jitter too, signed by precision AND mean
+    r1 = rmhmc._prepared_workspace(t, th0, 1, 1e6, 1e-3, 20)
+    assert rmhmc._prepared_workspace(t, th0, 1, 1e6, 1e-3, 20) is r1 and calls["rm_prepare"] == 1
+    assert rmhmc._prepared_workspace(t, th0, 1, 1e6, 2e-3, 20) is not r1 and calls["rm_prepare"] == 2
+    t.mean.add_(1.0)
+    assert rmhmc._prepared_workspace(t, th0, 1, 1e6, 1e-3, 20) is not r1 and calls["rm_prepare"] == 3
+    n_hmc, n_rm = len(t._hta_hmc_ws), len(t._hta_rm_ws)
+    forgot = (calls["hmc_forget"], calls["rm_forget"])
+    del t, ws1, ws2, ws3, r1, old
+    gc.collect()
+    assert calls["hmc_forget"] >= forgot[0] + n_hmc and calls["rm_forget"] >= forgot[1] + n_rm          # handles forget in the library
