@@ -311,7 +311,7 @@ int hta_mh_select_at_f64(double* cur, const double* prop, const double* init, co
   if (!n_dev) { hta::set_error("hta_mh_select_at: n_dev is NULL"); return HTA_ERR_INVALID; }
   return hta::mh_select_impl<double>(cur, prop, init, Ho, Hn, lpn, samples_base, rej, acc, C, D, 0, burn, seed, off, (hipStream_t)s, n_dev);
 }
-/* what every sample() run starts with (S:959-963: params = params_init.clone(), ret_params = [params.clone()], num_rejected = 0)
+/* what every sample() run starts with (S:954-961: params = params_init.clone(), ret_params = [params.clone()], num_rejected = 0)
  * as ONE launch: cur <- init, row0 <- init, reject_count <- 0.  elem_size 4 or 8; total = C * D elements. */
 int hta_run_begin(const void* init, void* cur, void* row0, int32_t* reject_count, int64_t C, int D, int elem_size, void* s) {
   if (!init || !cur || C <= 0 || D <= 0 || (elem_size != 4 && elem_size != 8)) {

@@ -515,7 +515,7 @@ class _Engine:
         self.samples = torch.empty((_num_rows(N, burn), C, D), dtype=theta0.dtype, device=theta0.device)
         self.cur = torch.empty_like(theta0)
         self.rejected = torch.empty(C, dtype=torch.int32, device=theta0.device)
-        _abi.run_begin(theta0, self.cur, self.samples[0], self.rejected)      # S:959-963 as one launch instead of three
+        _abi.run_begin(theta0, self.cur, self.samples[0], self.rejected)      # S:954-961 as one launch instead of three
 
     def finish(self):
         return self.samples, self.rejected

@@ -75,7 +75,7 @@ int hta_momentum_resample_at_f64(double* p, int mass_kind, const double* mass_fa
                                  uint64_t chain_offset, const int32_t* n_dev, void* stream);
 int hta_counter_add(int32_t* counter, int delta, void* stream);
 
-/* The first lines of every run (S:959-963: params = params_init.clone(), ret_params = [params.clone()], num_rejected = 0)
+/* The first lines of every run (S:954-961: params = params_init.clone(), ret_params = [params.clone()], num_rejected = 0)
  * as ONE launch instead of three: cur[C,D] <- init, row0[C,D] <- init (the stored row 0; NULL = none),
  * reject_count[C] <- 0 (NULL = none).  elem_size = 4 | 8 bytes per element (ABI 8). */
 int hta_run_begin(const void* init, void* cur, void* row0, int32_t* reject_count, int64_t C, int D, int elem_size,

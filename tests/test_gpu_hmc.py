@@ -593,7 +593,7 @@ def test_quad_kernel_variants_are_bit_identical(ht, D, C, L, N, burn):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_run_begin_is_the_three_initial_copies(ht, dtype):
-    """hta_run_begin: params = params_init.clone(), ret_params = [params.clone()], num_rejected = 0 (S:959-963) in one launch."""
+    """hta_run_begin: params = params_init.clone(), ret_params = [params.clone()], num_rejected = 0 (S:954-961) in one launch."""
     from hamiltorch_amd import _abi
     for C, D in ((37, 5), (1, 1), (1024, 3), (5000, 129)):
         init = torch.randn(C, D, dtype=dtype, device=dev())
