@@ -1523,7 +1523,10 @@ __global__ __launch_bounds__(QNT) void rmhmc_mfma4_kernel(FusedArgs<float> a) {
 //    barriers; the sums run over even k then odd k (results agree to rounding).
 // =============================================================================================
 // (layout constants and the operand helpers: rmhmc_fused_dev.hpp)
-template <bool TRACK>
+// LEAN ("rmhmc_lean"): see rmhmc_uv_kernel - no selects on the padding rows (TRACK paths): 2 897 -> 2 857 instructions per step.
+// (The stores keep their lane predicate here: without it the allocator of this 456-register kernel spills 22 values to scratch
+//  inside the step loop - tools/isa_of.py on the instance.)
+template <bool TRACK, bool LEAN = false>
 __global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) {
   typedef float T;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1742,7 +1745,7 @@ __global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       g1[e] -= eh * y1[e];                                  // a's momentum update ...
-      z1[e] -= eh * (rok[e] ? X1[e] - mu_r[e] : 0.f);       // ... and S g1 with it
+      z1[e] -= eh * ((LEAN || rok[e]) ? X1[e] - mu_r[e] : 0.f);       // ... and S g1 with it
     }
     T xa[4], xb[4], wa[4], wb[4];
     solve2(WB, ea, eb, z2, z1, xa, xb, wa, wb);
@@ -1751,7 +1754,7 @@ __global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) 
       X2[e] += eh * xa[e];                                  // a's position update; P x_a = g2 - e_a . x_a(K-1)
       y2[e] += eh * (g2[e] - wa[e]);
       g2[e] -= eh * y2[e];                                  // b's momentum update
-      z2[e] -= eh * (rok[e] ? X2[e] - mu_r[e] : 0.f);
+      z2[e] -= eh * ((LEAN || rok[e]) ? X2[e] - mu_r[e] : 0.f);
       X1[e] += eh * xb[e];                                  // b's position update
       y1[e] += eh * (g1[e] - wb[e]);
     }
@@ -1873,7 +1876,7 @@ __global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) 
         if (TRACK) {                                        // the four tracked products of the rotated state, afresh
           T dt[4], dc[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { dt[e] = rok[e] ? sth[e] - mu_r[e] : 0.f; dc[e] = rok[e] ? sthc[e] - mu_r[e] : 0.f; }
+          for (int e = 0; e < 4; ++e) { dt[e] = (LEAN || rok[e]) ? sth[e] - mu_r[e] : 0.f; dc[e] = (LEAN || rok[e]) ? sthc[e] - mu_r[e] : 0.f; }
           put4(D1, dt);
           put4(DC, dc);
           HTA_XTICK(4);
@@ -2454,7 +2457,11 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
             else rmhmc_mfma4_kernel<false><<<(int)(ngroup < 8192 ? ngroup : 8192), QNT, qlds, s>>>(a);
           } else {
             const size_t xlds = (size_t)(XBUF * XNC * XLD + XWV * XNC * 4) * sizeof(float);
-            if (g_rmhmc_pair) rmhmc_mfma4x4_kernel<true><<<(int)(ngroup < 8192 ? ngroup : 8192), XNT, xlds, s>>>(a);
+            if (g_rmhmc_pair && g_rmhmc_lean) {
+              note_route("rmhmc_mfma4x4_kernel<true,lean>");
+              rmhmc_mfma4x4_kernel<true, true><<<(int)(ngroup < 8192 ? ngroup : 8192), XNT, xlds, s>>>(a);
+            }
+            else if (g_rmhmc_pair) rmhmc_mfma4x4_kernel<true><<<(int)(ngroup < 8192 ? ngroup : 8192), XNT, xlds, s>>>(a);
             else rmhmc_mfma4x4_kernel<false><<<(int)(ngroup < 8192 ? ngroup : 8192), XNT, xlds, s>>>(a);
           }
           profile_end(s);

@@ -23,7 +23,15 @@ namespace hta {
 
 constexpr int UBUF = 9;            // LDS vector matrices: DV GV EV W0 W1 + 4 solve buffers [pair][iteration parity]
 
-template <int G>                   // chains per workgroup
+// LEAN (tuning key "rmhmc_lean", default 0): the same arithmetic with fewer instructions around it - these kernels run one
+// wave per SIMD and are ISSUE bound (a step's clocks = its instruction count x 4.5), so every instruction
+// that is not arithmetic counts.  (i) put4 without its lane predicate: the upper lane half holds bit-identical duplicates of
+// the lower one's values ("duplicate state, one writer"), so both halves store - same address, same value - and the
+// s_and_saveexec / s_cbranch_execz / s_or_b64 around every store go; (ii) the padding rows (>= D) of every state vector are
+// exact zeros by construction (zero matrix rows, zero jitter, zero mu_r), so X - mu needs no select there.  A chain that went
+// non-finite may carry NaN into its own padding rows; it is rejected, and every vector is rewritten from the clean current
+// point before the next trajectory reads it.
+template <int G, bool LEAN = false>                   // chains per workgroup
 __global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
   typedef float T;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -69,14 +77,14 @@ __global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
 
   typedef float bf2 __attribute__((ext_vector_type(2)));
   auto put4 = [&](T* X, const T (&v)[4]) {
-    if (!upper) {
+    if (LEAN || !upper) {
       *reinterpret_cast<bf2*>(X + own_off) = bf2{v[0], v[2]};
       *reinterpret_cast<bf2*>(X + own_off + XHL) = bf2{v[1], v[3]};
     }
   };
   auto centred = [&](const T (&X)[4], T (&d)[4]) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) d[e] = rok[e] ? X[e] - mu_r[e] : 0.f;
+    for (int e = 0; e < 4; ++e) d[e] = (LEAN || rok[e]) ? X[e] - mu_r[e] : 0.f;
   };
   // the jitter of this lane's four rows for one sub-stream (uniform_elem layout: rows 4b..4b+3 are Philox block b)
   auto jitter_raw = [&](uint32_t n, uint32_t sub, T (&out)[4]) {
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             g[i] -= eh * y[i];
-            z[i] -= eh * (rok[i] ? X[i] - mu_r[i] : 0.f);
+            z[i] -= eh * ((LEAN || rok[i]) ? X[i] - mu_r[i] : 0.f);
           }
         }
         T x[4], wv[4];
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             g[i] -= eh * y[i];
-            z[i] -= eh * (rok[i] ? X[i] - mu_r[i] : 0.f);
+            z[i] -= eh * ((LEAN || rok[i]) ? X[i] - mu_r[i] : 0.f);
           }
         }
       };
@@ -375,12 +383,16 @@ __global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
 
 int rmhmc_uv_launch(const FusedArgs<float>& a, int cus, hipStream_t s) {
   const size_t bytes = (size_t)(UBUF * XNC * XLD + XWV * XNC * 4) * sizeof(float);
+  const int64_t ngroup = (a.C + 1) / 2;
+  if (g_rmhmc_lean) {
+    note_route("rmhmc_uv_kernel<%d,lean>", a.C <= cus ? 1 : 2);
+    if (a.C <= cus) rmhmc_uv_kernel<1, true><<<(int)a.C, XNT, bytes, s>>>(a);
+    else rmhmc_uv_kernel<2, true><<<(int)(ngroup < 8192 ? ngroup : 8192), XNT, bytes, s>>>(a);
+    return HTA_OK;
+  }
   note_route("rmhmc_uv_kernel<%d>", a.C <= cus ? 1 : 2);
   if (a.C <= cus) rmhmc_uv_kernel<1><<<(int)a.C, XNT, bytes, s>>>(a);
-  else {
-    const int64_t ngroup = (a.C + 1) / 2;
-    rmhmc_uv_kernel<2><<<(int)(ngroup < 8192 ? ngroup : 8192), XNT, bytes, s>>>(a);
-  }
+  else rmhmc_uv_kernel<2><<<(int)(ngroup < 8192 ? ngroup : 8192), XNT, bytes, s>>>(a);
   return HTA_OK;
 }
 

@@ -1061,3 +1061,37 @@ def test_metric_general_mode_restarts_the_basis_of_a_system_that_went_non_finite
     _abi.metric_eval(md, B, D, _abi.METRIC_SOFTABS, tt(Hs, torch.float32), D * D, 1e6, None, 0, 0, 0, 0, m=md, x_out=x, **kw)
     want = np.linalg.solve(Hs, m.astype(np.float64)[..., None])[..., 0]
     np.testing.assert_allclose(x.cpu().numpy(), want, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("C,D,route", [(256, 100, "rmhmc_uv_kernel<1"), (512, 100, "rmhmc_uv_kernel<2"), (1024, 100, "rmhmc_mfma4x4_kernel<true"),
+                                       (300, 37, "rmhmc_uv_kernel<2"), (700, 90, "rmhmc_mfma4x4_kernel<true")])
+def test_lean_instances_of_the_lone_wave_kernels_are_bit_identical(ht, C, D, route):
+    """hta_set_tuning('rmhmc_lean', 1): rmhmc_uv_kernel without the lane predicate around its LDS stores (both lane halves
+    hold the same values) and, with rmhmc_mfma4x4_kernel, without the selects that zero the padding rows (exact zeros by
+    construction) - fewer instructions per step of kernels whose time is their instruction count.  Same samples, reject
+    counts and final state bit for bit, with jitter, with a mean offset, with padding rows (D = 37, 90, 100 < 128) and with a
+    chain that diverges (it is rejected and must sample on, exactly as in the default instance)."""
+    from hamiltorch_amd import _abi
+    t, _ = cfg3_target(ht, D, torch.float32, seed=D)
+    t.mean.add_(torch.linspace(-1.0, 1.0, D, device=dev()))
+    T, L = 5, 6
+    th0 = 0.1 * torch.randn(C, D, generator=torch.Generator().manual_seed(C), dtype=torch.float32).to(dev()) + t.mean
+    th0[3] = 1e30                                          # a chain that starts where the energy overflows
+    outs = []
+    for lean in (0, 1):
+        _abi.set_tuning("rmhmc_lean", lean)
+        try:
+            cur = th0.clone(); samples = torch.zeros(T + 1, C, D, device=dev()); rej = torch.zeros(C, dtype=torch.int32, device=dev())
+            ws = torch.zeros(_abi.rmhmc_workspace_bytes(C, D, 4, T), dtype=torch.uint8, device=dev())
+            _abi.rmhmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, _abi.METRIC_SOFTABS, 1e6, 1e-3, L, 0.1, 10.0, T, 0, -1, 5, 0,
+                                       samples, rej, ws)
+            r = _abi.last_route()
+            torch.cuda.synchronize()
+        finally:
+            _abi.reset_tuning()
+        assert r.startswith(route) and (",lean>" in r) == bool(lean), r
+        outs.append((samples[1:].cpu(), rej.cpu(), cur.cpu()))
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
+    assert int(outs[0][1][3]) == T and 0 <= int(outs[0][1].sum()) - T < C * T // 2      # the diverged chain rejects every proposal
+    assert bool(torch.isfinite(outs[0][0][:, 4:]).all())
