@@ -32,7 +32,7 @@ int g_rmhmc_overlap = 0;   // fused RMHMC: 1 = momentum draws of the next block 
                            // run beside the trajectory kernel the draws slow it by a third; serial is 3-8 % faster at every chain count)
 int g_rmhmc_momsplit = 1;  // fused RMHMC with jitter: p = chol(P) z1 + sqrt(jitter u) . z2 (exactly N(0, P + diag(jitter u)) like
                            // chol(P + diag(jitter u)) z, without a Cholesky per draw); 0 = the per-draw factorisation
-int g_rmhmc_lean = 0;      // rmhmc_uv / rmhmc_mfma4x4: 1 = the instances without lane-predicated stores and padding selects (bit-identical on finite chains)
+int g_rmhmc_lean = 1;      // rmhmc_uv / rmhmc_mfma4x4: 1 = the instances without lane-predicated stores and padding selects (bit-identical; 0 = the round-2 instances)
 int g_gauss_eig = 1;       // small-D identity-mass Gaussian HMC integrates in the eigenbasis of P (0: direct kernel, 2: chain per lane only)
 int g_fill_blocks = 4096;        // grid cap of the pre-draw pass (256-thread blocks, grid-stride)
 int g_quad_max_chains = 65536;   // up to here a chain takes a DPP quad (one eigen-coordinate per lane), beyond a lane
@@ -104,7 +104,7 @@ const TuneKey kTune[] = {
     {"rmhmc_momsplit", &hta::g_rmhmc_momsplit, 1},
     {"rmhmc_batch", &hta::g_rmhmc_batch, 1}, {"quad_max_chains", &hta::g_quad_max_chains, 65536}, {"fill_blocks", &hta::g_fill_blocks, 4096},
     {"mlp_valu", &hta::g_mlp_valu, 0}, {"metric_mfma", &hta::g_metric_mfma, 1}, {"metric_general", &hta::g_metric_general, 1}, {"rmhmc_fused", &hta::g_rmhmc_fused, 1},
-    {"mlp3_route", &hta::g_mlp3_route, 1}, {"quad_variant", &hta::g_quad_variant, 7}, {"rmhmc_lean", &hta::g_rmhmc_lean, 0},
+    {"mlp3_route", &hta::g_mlp3_route, 1}, {"quad_variant", &hta::g_quad_variant, 7}, {"rmhmc_lean", &hta::g_rmhmc_lean, 1},
 };
 // HTA_TUNING_DEFAULTS=key=value,...: moves the DEFAULT of route keys for this process (applied when the library is loaded and by
 // hta_reset_tuning) - A/B runs of whole test files under another route without touching the tests' own set / reset calls

@@ -23,7 +23,8 @@ namespace hta {
 
 constexpr int UBUF = 9;            // LDS vector matrices: DV GV EV W0 W1 + 4 solve buffers [pair][iteration parity]
 
-// LEAN (tuning key "rmhmc_lean", default 0): the same arithmetic with fewer instructions around it - these kernels run one
+// LEAN (tuning key "rmhmc_lean", default 1; measured: profiles/r03y_ab_lines.txt - 256 chains 8.12e7 -> 8.25e7, 1024 chains
+// (rmhmc_mfma4x4_kernel) 1.847e8 -> 1.870e8 explicit steps/s): the same arithmetic with fewer instructions around it - these kernels run one
 // wave per SIMD and are ISSUE bound (a step's clocks = its instruction count x 4.5), so every instruction
 // that is not arithmetic counts.  (i) put4 without its lane predicate: the upper lane half holds bit-identical duplicates of
 // the lower one's values ("duplicate state, one writer"), so both halves store - same address, same value - and the

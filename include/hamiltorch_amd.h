@@ -401,9 +401,10 @@ int hta_netn_logp_grad_f64(const double* theta, int64_t C, int n_layers, const i
  * the accept compare, and with the row element and the energy butterfly in one interleaved block; 3 = without that block;
  * 0 = the round-1 instance.  Bit-identical results; 78.5 / 74.1 / 73.25 instructions per trajectory of a lone wave at L = 25:
  * 166.3 -> 157.5 us per 1000 trajectories of BASELINE config 2),
- * "rmhmc_lean" (0 default; 1 = rmhmc_uv_kernel / rmhmc_mfma4x4_kernel without the lane predicate around their LDS stores - both
- * lane halves hold the same values - and without the selects that zero the padding rows, which are exact zeros by
- * construction: the same results on finite chains, fewer instructions per step of these issue-bound kernels). */
+ * "rmhmc_lean" (1 default: rmhmc_uv_kernel without the lane predicate around its LDS stores - both lane halves hold the same
+ * values - and, with rmhmc_mfma4x4_kernel, without the selects that zero the padding rows, which are exact zeros by
+ * construction: the same results bit for bit, 2.5 % / 1.4 % fewer instructions per step of these issue-bound kernels;
+ * 0 = the round-2 instances, the parity partners). */
 int hta_set_tuning(const char* key, int value);
 /* current value of a route key; every key back to its default (test fixtures call this between tests: the keys are
  * process-global).  The environment variable HTA_TUNING_DEFAULTS="key=value,..." moves the DEFAULT of the named keys for the

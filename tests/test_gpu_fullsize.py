@@ -184,6 +184,8 @@ def test_cfg3_bench_instances_vs_oracle_L10(ht, C, N, nsel, route):
                          explicit_binding_const=omega, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT,
                          metric=ht.Metric.SOFTABS, debug=2, verbose=False, seed=seed, chain_offset=off)
     from hamiltorch_amd import _abi
+    if _abi.get_tuning("rmhmc_lean") and route.startswith(("rmhmc_uv_kernel", "rmhmc_mfma4x4_kernel")):
+        route = route[:-1] + ",lean>"                              # the instance the route key "rmhmc_lean" selects (the default)
     assert _abi.last_route() == route, _abi.last_route()          # the dispatch at this chain count IS the kernel named here
     got = torch.stack(out).cpu().numpy()
     assert got.shape == (N, C, D) and np.isfinite(got).all()

@@ -231,7 +231,7 @@ def test_cfg3_statistical_parity_with_jitter(ht):
     out, acc = ht.sample(t, th0, num_samples=N, num_steps_per_sample=10, step_size=0.1, burn=-1, jitter=1e-3,
                          softabs_const=1e6, explicit_binding_const=10, sampler=ht.Sampler.RMHMC,
                          integrator=ht.Integrator.EXPLICIT, metric=ht.Metric.SOFTABS, debug=2, verbose=False, seed=7)
-    assert _abi.last_route() == "rmhmc_uv_kernel<1>"
+    assert _abi.last_route() == ("rmhmc_uv_kernel<1,lean>" if _abi.get_tuning("rmhmc_lean") else "rmhmc_uv_kernel<1>")
     a = torch.stack(out).double().cpu().numpy()
     s = a[-keep:].reshape(-1, 100)
     assert float(acc.mean()) > 0.97
