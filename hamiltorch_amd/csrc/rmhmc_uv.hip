@@ -25,8 +25,8 @@ constexpr int UBUF = 9;            // LDS vector matrices: DV GV EV W0 W1 + 4 so
 
 // LEAN (tuning key "rmhmc_lean", default 1; measured: profiles/r03y_ab_lines.txt - 256 chains 8.12e7 -> 8.25e7, 1024 chains
 // (rmhmc_mfma4x4_kernel) 1.847e8 -> 1.870e8 explicit steps/s): the same arithmetic with fewer instructions around it - these kernels run one
-// wave per SIMD and are ISSUE bound (a step's clocks = its instruction count x 4.5), so every instruction
-// that is not arithmetic counts.  (i) put4 without its lane predicate: the upper lane half holds bit-identical duplicates of
+// wave per SIMD: nothing hides an instruction of the element-wise / bookkeeping stretches between their matrix phases
+// ("what comes next").  (i) put4 without its lane predicate: the upper lane half holds bit-identical duplicates of
 // the lower one's values ("duplicate state, one writer"), so both halves store - same address, same value - and the
 // s_and_saveexec / s_cbranch_execz / s_or_b64 around every store go; (ii) the padding rows (>= D) of every state vector are
 // exact zeros by construction (zero matrix rows, zero jitter, zero mu_r), so X - mu needs no select there.  A chain that went

@@ -403,7 +403,7 @@ int hta_netn_logp_grad_f64(const double* theta, int64_t C, int n_layers, const i
  * 166.3 -> 157.5 us per 1000 trajectories of BASELINE config 2),
  * "rmhmc_lean" (1 default: rmhmc_uv_kernel without the lane predicate around its LDS stores - both lane halves hold the same
  * values - and, with rmhmc_mfma4x4_kernel, without the selects that zero the padding rows, which are exact zeros by
- * construction: the same results bit for bit, 2.5 % / 1.4 % fewer instructions per step of these issue-bound kernels;
+ * construction: the same results bit for bit, ~30 instructions fewer per step of these one-wave-per-SIMD kernels (+1.6 % / +1.2 %);
  * 0 = the round-2 instances, the parity partners). */
 int hta_set_tuning(const char* key, int value);
 /* current value of a route key; every key back to its default (test fixtures call this between tests: the keys are
