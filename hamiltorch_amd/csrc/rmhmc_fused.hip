@@ -1827,6 +1827,25 @@ __global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) 
 #pragma unroll
     for (int e = 0; e < 4; ++e) scur[e] = (live && rok[e]) ? a.cur[c * D + row0 + e] : 0.f;
     int32_t rejected = 0;
+    // this lane's four rows of the pre-drawn momentum of local trajectory tt as four UNCONDITIONAL loads (a lane without a row
+    // reads element 0 of the block and discards it; offsets masked with masks the optimiser cannot trace back to `live` - a
+    // select comes back as a branch around each load with its own s_waitcnt vmcnt(0)): issued back to back, and for trajectory
+    // t + 1 a whole trajectory before their use (momentum_use pins the first use of the loaded registers where it stands)
+    int lmask = -(int)live, rmask[4];
+    asm volatile("" : "+v"(lmask));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { rmask[e] = -(int)rok[e]; asm volatile("" : "+v"(rmask[e])); }
+    auto momentum_raw = [&](int tt, T (&v)[4]) {
+      const T* prow = a.p_ws + ((int64_t)tt * a.C + (int64_t)((int)c & lmask)) * D;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = prow[(row0 + e) & rmask[e] & lmask];
+    };
+    auto momentum_use = [&](T (&v)[4], T (&out)[4]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { asm volatile("" : "+v"(v[e])); out[e] = (live && rok[e]) ? v[e] : 0.f; }
+    };
+    T pnext[4];
+    if (a.n_traj > 0) momentum_raw(0, pnext);
     __syncthreads();                                        // the previous group's last reads of the vector matrices
 #if HTA_RM_TIMING
     xlast = __builtin_readcyclecounter();
@@ -1834,8 +1853,8 @@ __global__ __launch_bounds__(XNT) void rmhmc_mfma4x4_kernel(FusedArgs<float> a) 
     for (int t = 0; t < a.n_traj; ++t) {
       const uint32_t n = (uint32_t)(a.traj_offset + t);
       // ---- gibbs: p = chol(G(theta)) z, drawn ahead by the momentum kernel (S:183-184)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) spm[e] = (live && rok[e]) ? a.p_ws[((int64_t)t * a.C + c) * D + row0 + e] : 0.f;
+      momentum_use(pnext, spm);
+      if (t + 1 < a.n_traj) momentum_raw(t + 1, pnext);
       put4(PM, spm);
       HTA_XTICK(7);
       T H0, H1, lp0, lp1;

@@ -225,6 +225,24 @@ __global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
     T scur[4], X[4], g[4], y[4], z[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) scur[e] = (live && rok[e]) ? a.cur[c * D + row0 + e] : 0.f;
+    int lmask = -(int)live, rmask[4];
+    asm volatile("" : "+v"(lmask));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { rmask[e] = -(int)rok[e]; asm volatile("" : "+v"(rmask[e])); }
+    // this lane's four rows of the pre-drawn momentum of local trajectory tt: four UNCONDITIONAL loads (a lane without a row
+    // reads element 0 of the row block and discards it), so that they issue back to back and are waited for once
+    auto momentum_row_raw = [&](int tt, T (&v)[4]) {
+      // (offsets masked arithmetically with masks the optimiser cannot see through: a select on the index - or a mask it can
+      //  trace back to `live` - comes back as a branch around each load, with a wait inside)
+      const T* prow = a.p_ws + ((int64_t)tt * a.C + (int64_t)((int)c & lmask)) * D;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = prow[(row0 + e) & rmask[e] & lmask];
+    };
+    auto momentum_row_use = [&](T (&v)[4], T (&out)[4]) {     // (the empty asm pins the first use of the loaded registers HERE)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { asm volatile("" : "+v"(v[e])); out[e] = (live && rok[e]) ? v[e] : 0.f; }
+    };
+    auto momentum_row = [&](int tt, T (&out)[4]) { T v[4]; momentum_row_raw(tt, v); momentum_row_use(v, out); };
     int32_t rejected = 0;
     __syncthreads();                                        // the previous group's last reads of the vector matrices
     // H_old of trajectory t + 1 needs, besides -log p of the current point, only terms of the NEW momentum and jitter
@@ -245,13 +263,17 @@ __global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
         for (int e = 0; e < 4; ++e) { g[e] = gn[e]; X[e] = scur[e]; y[e] = y_next[e]; z[e] = z_next[e]; }
         H0 = H0_next; lp0 = lp_next;
       } else {
+        momentum_row(t, g);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          g[e] = (live && rok[e]) ? a.p_ws[((int64_t)t * a.C + c) * D + row0 + e] : 0.f;
-          X[e] = scur[e];
-        }
+        for (int e = 0; e < 4; ++e) X[e] = scur[e];
         hamiltonian(n, 1, X, g, H0, lp0, y, z, kin, ld);    // S:971 -> S:822
       }
+      // the NEXT trajectory's momentum row is requested here, a whole trajectory before its first use (the V column of this
+      // trajectory's last Hamiltonian): requested there, each of its four loads was followed by its own s_waitcnt vmcnt(0) -
+      // four exposed memory round trips per trajectory of a wave that has nothing else to issue
+      const bool pre = t + 1 < a.n_traj;
+      T gn_raw[4] = {0.f, 0.f, 0.f, 0.f};
+      if (pre) momentum_row_raw(t + 1, gn_raw);
       T y_start[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) y_start[e] = y[e];
@@ -331,11 +353,10 @@ __global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
       }
       if (a.K == 0) __syncthreads();
       // ---- H_new on the un-augmented pair = set U (S:989, Q4); in the V column: the next trajectory's momentum terms
-      const bool pre = t + 1 < a.n_traj;
       T Pd1[4], Sg1[4], Xh[4], gh[4];
+      if (pre) momentum_row_use(gn_raw, gn);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (pre) gn[e] = (live && rok[e]) ? a.p_ws[((int64_t)(t + 1) * a.C + c) * D + row0 + e] : 0.f;
         const T xu = of_set_u(X[e]);
         Xh[e] = xu;                                          // both columns at the proposal theta': the V column's P (theta' - mu) is not used
         gh[e] = (setV && pre) ? gn[e] : (setV ? of_set_u(g[e]) : g[e]);
