@@ -756,7 +756,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 //   bit 2  the row element and the quad butterfly of the energy difference as ONE interleaved block (see TAIL below).
 // Results are bit-identical to VAR = 0 (tests/test_gpu_hmc.py::test_quad_kernel_variants_are_bit_identical).  Measured at BASELINE
 // config 2 (profiles/r03v_*): 166.3 us (VAR 0) -> 157.5 us (VAR 7) per 1000-trajectory launch; the static count 78.5 -> 73.25
-// instructions per trajectory (tools/isa_of.py --loops) predicted 155.
+// instructions per trajectory (tools/isa_of.py --loops) predicted 155.  With 16 trajectories per pass at L = 25: 72.6, 156.6 us.
 template <int I, int N, typename F> __device__ __forceinline__ void quad_static_for(F&& f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); quad_static_for<I + 1, N>(f); }
 }
@@ -932,19 +932,19 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
 #undef HTA_B1
 #undef HTA_B2
       } else {
-      if constexpr (D == 1)
-        asm volatile("v_mov_b32 %0, %2" HTA_QF(0, 4) : "=&v"(qp) : "v"(y), "v"(mu), "v"(en), "v"(Qrow[0]));
-      else if constexpr (D == 2)
-        asm volatile("v_mov_b32 %0, %2" HTA_QF(0, 4) HTA_QF(1, 5)
-                     : "=&v"(qp) : "v"(y), "v"(mu), "v"(en), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]));
-      else if constexpr (D == 3)
-        asm volatile("v_mov_b32 %0, %2" HTA_QF(0, 4) HTA_QF(1, 5) HTA_QF(2, 6)
-                     : "=&v"(qp) : "v"(y), "v"(mu), "v"(en), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]), "v"(Qrow[D > 2 ? 2 : 0]));
-      else
-        asm volatile("v_mov_b32 %0, %2" HTA_QF(0, 4) HTA_QF(1, 5) HTA_QF(2, 6) HTA_QF(3, 7)
-                     : "=&v"(qp) : "v"(y), "v"(mu), "v"(en), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]), "v"(Qrow[D > 2 ? 2 : 0]),
-                       "v"(Qrow[D > 3 ? 3 : 0]));
-      dH = quad_sum(eo - en);                                                       // 2 (h_old - h_new)
+        if constexpr (D == 1)
+          asm volatile("v_mov_b32 %0, %2" HTA_QF(0, 4) : "=&v"(qp) : "v"(y), "v"(mu), "v"(en), "v"(Qrow[0]));
+        else if constexpr (D == 2)
+          asm volatile("v_mov_b32 %0, %2" HTA_QF(0, 4) HTA_QF(1, 5)
+                       : "=&v"(qp) : "v"(y), "v"(mu), "v"(en), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]));
+        else if constexpr (D == 3)
+          asm volatile("v_mov_b32 %0, %2" HTA_QF(0, 4) HTA_QF(1, 5) HTA_QF(2, 6)
+                       : "=&v"(qp) : "v"(y), "v"(mu), "v"(en), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]), "v"(Qrow[D > 2 ? 2 : 0]));
+        else
+          asm volatile("v_mov_b32 %0, %2" HTA_QF(0, 4) HTA_QF(1, 5) HTA_QF(2, 6) HTA_QF(3, 7)
+                       : "=&v"(qp) : "v"(y), "v"(mu), "v"(en), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]), "v"(Qrow[D > 2 ? 2 : 0]),
+                         "v"(Qrow[D > 3 ? 3 : 0]));
+        dH = quad_sum(eo - en);                                                       // 2 (h_old - h_new)
       }
 #undef HTA_QF
       // the decision as a lane mask (v_cmp into an SGPR pair), consumed by a carry-in add and two selects
@@ -1012,19 +1012,19 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
       }
       while (t < t_end) { trajectory(zs[0], lus[0], plain, first); moved(1); rotate(); }
     } else {
-    if (phase == 1 && t < t_end && a.traj_offset + t == a.burn + 1) {              // the Q2 trajectory opens the stored phase
-      trajectory(zs[0], lus[0], std::true_type{}, first);
-      rotate();
-    }
-    while (t + 2 * NS - 1 < t_end) {            // unrolled over the slots (twice): no register rotation on the hot path
+      if (phase == 1 && t < t_end && a.traj_offset + t == a.burn + 1) {              // the Q2 trajectory opens the stored phase
+        trajectory(zs[0], lus[0], std::true_type{}, first);
+        rotate();
+      }
+      while (t + 2 * NS - 1 < t_end) {            // unrolled over the slots (twice): no register rotation on the hot path
 #pragma unroll
-      for (int i = 0; i < 2 * NS; ++i) trajectory(zs[i % NS], lus[i % NS], plain, first);
-    }
-    if (t + NS - 1 < t_end) {
+        for (int i = 0; i < 2 * NS; ++i) trajectory(zs[i % NS], lus[i % NS], plain, first);
+      }
+      if (t + NS - 1 < t_end) {
 #pragma unroll
-      for (int i = 0; i < NS; ++i) trajectory(zs[i], lus[i], plain, first);
-    }
-    while (t < t_end) { trajectory(zs[0], lus[0], plain, first); rotate(); }
+        for (int i = 0; i < NS; ++i) trajectory(zs[i], lus[i], plain, first);
+      }
+      while (t < t_end) { trajectory(zs[0], lus[0], plain, first); rotate(); }
     }
   }
   put((gwbytes_t)a.theta, qc);
