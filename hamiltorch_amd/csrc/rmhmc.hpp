@@ -43,6 +43,7 @@ extern int g_rmhmc_pair;                                    // tuning key "rmhmc
 extern int g_rmhmc_mfma4, g_rmhmc_mfma4_lo, g_rmhmc_mfma4_hi;    // tuning keys "rmhmc_mfma4" (default 1), "rmhmc_mfma4_lo", "rmhmc_mfma4_hi"
 extern int g_rmhmc_overlap;                                 // tuning key "rmhmc_overlap" (default 0 since round 3)
 extern int g_rmhmc_lean;                                    // tuning key "rmhmc_lean" (default 1): rmhmc_uv / rmhmc_mfma4x4 without lane-predicated stores and padding selects
+extern int g_rmhmc_uv_co, g_rmhmc_uv_acc, g_rmhmc_uv_g;    // tuning keys "rmhmc_uv_co" / "rmhmc_uv_acc" / "rmhmc_uv_g" (rmhmc_uv.hip)
 extern int g_rmhmc_momsplit;                                // tuning key "rmhmc_momsplit" (default 1): p = chol(P) z1 + sqrt(e) z2
 template <typename T>
 int fused_plan(const T* lam0_host, int D, int metric, double alpha, int has_jitter, double jitter, double* logdetP, int* series);

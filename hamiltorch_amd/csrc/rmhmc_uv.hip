@@ -32,8 +32,15 @@ constexpr int UBUF = 9;            // LDS vector matrices: DV GV EV W0 W1 + 4 so
 // exact zeros by construction (zero matrix rows, zero jitter, zero mu_r), so X - mu needs no select there.  A chain that went
 // non-finite may carry NaN into its own padding rows; it is rejected, and every vector is rewritten from the clean current
 // point before the next trajectory reads it.
-template <int G, bool LEAN = false>                   // chains per workgroup
-__global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
+// CO (round 4, tuning key "rmhmc_uv_co"): the same code under a 256-register cap, so that TWO workgroups share a CU (one wave of
+// each per SIMD): a phase is a latency chain (LDS publish - barrier - operand fetch - 52 dependent matrix instructions - combine)
+// that leaves the matrix pipe idle more than half of the time; a second, independent workgroup fills those gaps.  The capped
+// build keeps S and P in VGPRs (no accumulation registers at all: the matrix instructions write VGPRs directly) and spills
+// nothing inside the trajectory (tests/test_kernel_resources.py).  NACC ("rmhmc_uv_acc"): accumulator chains per product - with
+// two, the compiler pads every dependent pair of v_mfma_f32_4x4x1 with an s_nop (22 per phase); four need none.  The sums of a
+// row are then taken in another order: not bit-identical to NACC = 2, the same to rounding (tests/test_gpu_rmhmc.py).
+template <int G, bool LEAN = false, bool CO = false, int NACC = 2>                   // chains per workgroup
+__global__ __launch_bounds__(XNT, CO ? 2 : 1) void rmhmc_uv_kernel(FusedArgs<float> a) {
   typedef float T;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
@@ -114,14 +121,30 @@ __global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
     fetch(X1, c1);
     fetch(X2, c2);
     __builtin_amdgcn_sched_barrier(0);
-    static_for(std::make_integer_sequence<int, XQ>{}, [&](auto qc) {
-      constexpr int q = decltype(qc)::value;
+    if constexpr (NACC == 4) {
+      bf4 b1 = {0.f, 0.f, 0.f, 0.f}, b2 = {0.f, 0.f, 0.f, 0.f};
+      static_for(std::make_integer_sequence<int, XQ>{}, [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        acc1 = mfma_from_group<q % 4>(A1[4 * q + u], c1[q / 4][u], acc1);
-        acc2 = mfma_from_group<q % 4>(A2[4 * q + u], c2[q / 4][u], acc2);
-      }
-    });
+        for (int u = 0; u < 4; u += 2) {
+          acc1 = mfma_from_group<q % 4>(A1[4 * q + u], c1[q / 4][u], acc1);
+          acc2 = mfma_from_group<q % 4>(A2[4 * q + u], c2[q / 4][u], acc2);
+          b1 = mfma_from_group<q % 4>(A1[4 * q + u + 1], c1[q / 4][u + 1], b1);
+          b2 = mfma_from_group<q % 4>(A2[4 * q + u + 1], c2[q / 4][u + 1], b2);
+        }
+      });
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc1[e] += b1[e]; acc2[e] += b2[e]; }
+    } else {
+      static_for(std::make_integer_sequence<int, XQ>{}, [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc1 = mfma_from_group<q % 4>(A1[4 * q + u], c1[q / 4][u], acc1);
+          acc2 = mfma_from_group<q % 4>(A2[4 * q + u], c2[q / 4][u], acc2);
+        }
+      });
+    }
     both(acc1); both(acc2);
   };
   // one product on two accumulator chains (k in the order 0 2 | 1 3 of every chunk)
@@ -129,17 +152,31 @@ __global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
     bf4 c1[XSQ], sb = {0.f, 0.f, 0.f, 0.f};
     fetch(X1, c1);
     __builtin_amdgcn_sched_barrier(0);
-    static_for(std::make_integer_sequence<int, XQ>{}, [&](auto qc) {
-      constexpr int q = decltype(qc)::value;
+    if constexpr (NACC == 4) {
+      bf4 sc = {0.f, 0.f, 0.f, 0.f}, sd = {0.f, 0.f, 0.f, 0.f};
+      static_for(std::make_integer_sequence<int, XQ>{}, [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const T a0 = A1[4 * q], a1 = A1[4 * q + 1], a2 = A1[4 * q + 2], a3 = A1[4 * q + 3];
+        acc = mfma_from_group<q % 4>(squared ? a0 * a0 : a0, c1[q / 4][0], acc);
+        sb = mfma_from_group<q % 4>(squared ? a1 * a1 : a1, c1[q / 4][1], sb);
+        sc = mfma_from_group<q % 4>(squared ? a2 * a2 : a2, c1[q / 4][2], sc);
+        sd = mfma_from_group<q % 4>(squared ? a3 * a3 : a3, c1[q / 4][3], sd);
+      });
 #pragma unroll
-      for (int u = 0; u < 4; u += 2) {
-        const T a0 = A1[4 * q + u], a1 = A1[4 * q + u + 1];
-        acc = mfma_from_group<q % 4>(squared ? a0 * a0 : a0, c1[q / 4][u], acc);
-        sb = mfma_from_group<q % 4>(squared ? a1 * a1 : a1, c1[q / 4][u + 1], sb);
-      }
-    });
+      for (int e = 0; e < 4; ++e) acc[e] = (acc[e] + sc[e]) + (sb[e] + sd[e]);
+    } else {
+      static_for(std::make_integer_sequence<int, XQ>{}, [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] += sb[e];
+        for (int u = 0; u < 4; u += 2) {
+          const T a0 = A1[4 * q + u], a1 = A1[4 * q + u + 1];
+          acc = mfma_from_group<q % 4>(squared ? a0 * a0 : a0, c1[q / 4][u], acc);
+          sb = mfma_from_group<q % 4>(squared ? a1 * a1 : a1, c1[q / 4][u + 1], sb);
+        }
+      });
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += sb[e];
+    }
     both(acc);
   };
   // x = (P + diag(e))^-1 g from x0 = S g: K phases (one barrier, one product each); w returns e . x_(K-1) (zero without jitter).
@@ -403,18 +440,33 @@ __global__ __launch_bounds__(XNT) void rmhmc_uv_kernel(FusedArgs<float> a) {
   }
 }
 
+int g_rmhmc_uv_co = 0;       // tuning key "rmhmc_uv_co": 1 = the 256-register instances, two workgroups per CU
+int g_rmhmc_uv_acc = 2;      // tuning key "rmhmc_uv_acc": accumulator chains per product (2 or 4)
+int g_rmhmc_uv_g = 0;        // tuning key "rmhmc_uv_g": chains per workgroup (0 = by chain count, 1, 2)
+
 int rmhmc_uv_launch(const FusedArgs<float>& a, int cus, hipStream_t s) {
   const size_t bytes = (size_t)(UBUF * XNC * XLD + XWV * XNC * 4) * sizeof(float);
-  const int64_t ngroup = (a.C + 1) / 2;
-  if (g_rmhmc_lean) {
-    note_route("rmhmc_uv_kernel<%d,lean>", a.C <= cus ? 1 : 2);
-    if (a.C <= cus) rmhmc_uv_kernel<1, true><<<(int)a.C, XNT, bytes, s>>>(a);
-    else rmhmc_uv_kernel<2, true><<<(int)(ngroup < 8192 ? ngroup : 8192), XNT, bytes, s>>>(a);
+  const int g = g_rmhmc_uv_g == 1 || g_rmhmc_uv_g == 2 ? g_rmhmc_uv_g : (a.C <= cus ? 1 : 2);
+  const int64_t ngroup = (a.C + g - 1) / g;
+  const int grid = (int)(ngroup < 8192 ? ngroup : 8192);
+  const bool co = g_rmhmc_uv_co != 0, acc4 = g_rmhmc_uv_acc == 4;
+  if (!g_rmhmc_lean) {
+    note_route("rmhmc_uv_kernel<%d>", g);
+    if (g == 1) rmhmc_uv_kernel<1><<<grid, XNT, bytes, s>>>(a);
+    else rmhmc_uv_kernel<2><<<grid, XNT, bytes, s>>>(a);
     return HTA_OK;
   }
-  note_route("rmhmc_uv_kernel<%d>", a.C <= cus ? 1 : 2);
-  if (a.C <= cus) rmhmc_uv_kernel<1><<<(int)a.C, XNT, bytes, s>>>(a);
-  else rmhmc_uv_kernel<2><<<(int)(ngroup < 8192 ? ngroup : 8192), XNT, bytes, s>>>(a);
+  if (!co && !acc4) note_route("rmhmc_uv_kernel<%d,lean>", g);
+  else note_route("rmhmc_uv_kernel<%d,lean,%s,%d>", g, co ? "co" : "solo", acc4 ? 4 : 2);
+#define HTA_UV(GG, CO_, NA) rmhmc_uv_kernel<GG, true, CO_, NA><<<grid, XNT, bytes, s>>>(a)
+  if (g == 1) {
+    if (co) { if (acc4) HTA_UV(1, true, 4); else HTA_UV(1, true, 2); }
+    else { if (acc4) HTA_UV(1, false, 4); else HTA_UV(1, false, 2); }
+  } else {
+    if (co) { if (acc4) HTA_UV(2, true, 4); else HTA_UV(2, true, 2); }
+    else { if (acc4) HTA_UV(2, false, 4); else HTA_UV(2, false, 2); }
+  }
+#undef HTA_UV
   return HTA_OK;
 }
 

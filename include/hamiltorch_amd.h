@@ -404,7 +404,12 @@ int hta_netn_logp_grad_f64(const double* theta, int64_t C, int n_layers, const i
  * "rmhmc_lean" (1 default: rmhmc_uv_kernel without the lane predicate around its LDS stores - both lane halves hold the same
  * values - and, with rmhmc_mfma4x4_kernel, without the selects that zero the padding rows, which are exact zeros by
  * construction: the same results bit for bit, ~30 instructions fewer per step of these one-wave-per-SIMD kernels (+1.6 % / +1.2 %);
- * 0 = the round-2 instances, the parity partners). */
+ * 0 = the round-2 instances, the parity partners),
+ * "rmhmc_uv_co" (round 4; 1 = rmhmc_uv_kernel under a 256-register cap, two workgroups per CU: the phase latency of one is
+ * filled by the other's matrix instructions; bit-identical to 0; also extends the kernel's range to 4 x CUs chains),
+ * "rmhmc_uv_acc" (2 | 4 accumulator chains per product of rmhmc_uv_kernel; 4 needs no s_nop between dependent matrix
+ * instructions; another summation order, equal to rounding),
+ * "rmhmc_uv_g" (0 = chains per workgroup by chain count; 1 or 2 force it). */
 int hta_set_tuning(const char* key, int value);
 /* current value of a route key; every key back to its default (test fixtures call this between tests: the keys are
  * process-global).  The environment variable HTA_TUNING_DEFAULTS="key=value,..." moves the DEFAULT of the named keys for the

@@ -1095,3 +1095,43 @@ def test_lean_instances_of_the_lone_wave_kernels_are_bit_identical(ht, C, D, rou
         assert torch.equal(a_, b_)
     assert int(outs[0][1][3]) == T and 0 <= int(outs[0][1].sum()) - T < C * T // 2      # the diverged chain rejects every proposal
     assert bool(torch.isfinite(outs[0][0][:, 4:]).all())
+
+
+@pytest.mark.parametrize("C,D", [(256, 100), (512, 100), (1024, 100), (300, 37)])
+def test_uv_kernel_coresident_and_four_chain_instances(ht, C, D):
+    """Round 4: rmhmc_uv_kernel under a 256-register cap ("rmhmc_uv_co": two workgroups per CU fill each other's phase latency;
+    the same arithmetic - bit-identical samples, reject counts and final state) and with four accumulator chains per product
+    ("rmhmc_uv_acc" = 4: no s_nop between dependent matrix instructions; another summation order - equal to rounding, a
+    Metropolis decision may flip in a few chains).  1024 chains reach the kernel through the co-resident route (512 two-chain
+    workgroups on 256 CUs)."""
+    from hamiltorch_amd import _abi
+    t, _ = cfg3_target(ht, D, torch.float32, seed=D)
+    t.mean.add_(torch.linspace(-1.0, 1.0, D, device=dev()))
+    T, L = 4, 6
+    th0 = 0.1 * torch.randn(C, D, generator=torch.Generator().manual_seed(C), dtype=torch.float32).to(dev()) + t.mean
+    th0[3] = 1e30
+    outs = {}
+    for name, keys in (("base", {"rmhmc_uv": 2}), ("co", {"rmhmc_uv": 2, "rmhmc_uv_co": 1}), ("acc4", {"rmhmc_uv": 2, "rmhmc_uv_acc": 4}),
+                       ("co_acc4", {"rmhmc_uv_co": 1, "rmhmc_uv_acc": 4})):
+        for k, v in keys.items():
+            _abi.set_tuning(k, v)
+        try:
+            cur = th0.clone(); samples = torch.zeros(T + 1, C, D, device=dev()); rej = torch.zeros(C, dtype=torch.int32, device=dev())
+            ws = torch.zeros(_abi.rmhmc_workspace_bytes(C, D, 4, T), dtype=torch.uint8, device=dev())
+            _abi.rmhmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, _abi.METRIC_SOFTABS, 1e6, 1e-3, L, 0.1, 10.0, T, 0, -1, 5, 0,
+                                       samples, rej, ws)
+            r = _abi.last_route()
+            torch.cuda.synchronize()
+        finally:
+            _abi.reset_tuning()
+        assert r.startswith("rmhmc_uv_kernel<"), (name, r)
+        assert ("co" in r.split(",")) == ("co" in name) and r.endswith(",4>") == ("acc4" in name), (name, r)
+        outs[name] = (samples[1:].cpu(), rej.cpu(), cur.cpu())
+    for a_, b_ in zip(outs["base"], outs["co"]):
+        assert torch.equal(a_, b_)
+    for a_, b_ in zip(outs["acc4"], outs["co_acc4"]):
+        assert torch.equal(a_, b_)
+    live = torch.ones(C, dtype=torch.bool); live[3] = False
+    d = (outs["base"][0] - outs["acc4"][0]).abs().amax(dim=(0, 2))[live]
+    assert int((d > 1e-4).sum()) <= max(1, C // 100), float(d.max())
+    assert int(outs["acc4"][1][3]) == T
