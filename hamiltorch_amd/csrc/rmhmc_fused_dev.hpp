@@ -40,5 +40,8 @@ template <int... I, typename F> __device__ __forceinline__ void static_for(std::
 
 // rmhmc_uv.hip: the same run for at most 2 x (compute units) chains; cus = compute units of the current device
 int rmhmc_uv_launch(const FusedArgs<float>& a, int cus, hipStream_t s);
+// rmhmc_uvc.hip: one chain per workgroup, compact element-wise layout, three product phases per step (K == 2 with jitter only)
+int rmhmc_uvc_launch(const FusedArgs<float>& a, bool co, hipStream_t s);
+extern int g_rmhmc_uvc;
 
 }  // namespace hta

@@ -19,6 +19,13 @@
 #include <math.h>
 #include "rmhmc_fused_dev.hpp"
 
+// developer ablation builds (tools/uv_ablate.sh: wrong results, honest timing): 1 = no Philox (constant jitter), 2 = 4 instead
+// of 52 matrix instructions per product, 4 = no workgroup barriers inside the step loop, 8 = operands not fetched from LDS,
+// 16 = vectors not published to LDS
+#ifndef HTA_UV_ABLATE
+#define HTA_UV_ABLATE 0
+#endif
+
 namespace hta {
 
 constexpr int UBUF = 9;            // LDS vector matrices: DV GV EV W0 W1 + 4 solve buffers [pair][iteration parity]
@@ -85,6 +92,7 @@ __global__ __launch_bounds__(XNT, CO ? 2 : 1) void rmhmc_uv_kernel(FusedArgs<flo
 
   typedef float bf2 __attribute__((ext_vector_type(2)));
   auto put4 = [&](T* X, const T (&v)[4]) {
+    if (HTA_UV_ABLATE & 16) return;
     if (LEAN || !upper) {
       *reinterpret_cast<bf2*>(X + own_off) = bf2{v[0], v[2]};
       *reinterpret_cast<bf2*>(X + own_off + XHL) = bf2{v[1], v[3]};
@@ -96,7 +104,8 @@ __global__ __launch_bounds__(XNT, CO ? 2 : 1) void rmhmc_uv_kernel(FusedArgs<flo
   };
   // the jitter of this lane's four rows for one sub-stream (uniform_elem layout: rows 4b..4b+3 are Philox block b)
   auto jitter_raw = [&](uint32_t n, uint32_t sub, T (&out)[4]) {
-    const U4 r = philox_block(a.seed, chain, n, PURPOSE_JITTER, sub, (uint32_t)(row0 >> 2));
+    const U4 r = (HTA_UV_ABLATE & 1) ? U4{n * 2654435761u + sub, sub * 40503u + n, n ^ (sub << 16), (uint32_t)tid * 77u + sub}
+                                     : philox_block(a.seed, chain, n, PURPOSE_JITTER, sub, (uint32_t)(row0 >> 2));
     const T u[4] = {u23<T>(r.x), u23<T>(r.y), u23<T>(r.z), u23<T>(r.w)};
 #pragma unroll
     for (int e = 0; e < 4; ++e) out[e] = (live && rok[e]) ? a.jitter * u[e] : 0.f;
@@ -109,7 +118,10 @@ __global__ __launch_bounds__(XNT, CO ? 2 : 1) void rmhmc_uv_kernel(FusedArgs<flo
   };
   auto fetch = [&](const T* X, bf4 (&c)[XSQ]) {
 #pragma unroll
-    for (int Q = 0; Q < XSQ; ++Q) c[Q] = *reinterpret_cast<const bf4*>(X + b_off + 16 * Q);
+    for (int Q = 0; Q < XSQ; ++Q) {
+      if (HTA_UV_ABLATE & 8) { const float f = (float)(Q + 1) * 1e-3f * mu_r[Q & 3]; c[Q] = bf4{f, f + 1.f, f, f - 1.f}; }
+      else c[Q] = *reinterpret_cast<const bf4*>(X + b_off + 16 * Q);
+    }
   };
   auto both = [&](bf4& acc) {                                // lanes l and l ^ 8 both end with (even k) + (odd k)
 #pragma unroll
@@ -125,6 +137,7 @@ __global__ __launch_bounds__(XNT, CO ? 2 : 1) void rmhmc_uv_kernel(FusedArgs<flo
       bf4 b1 = {0.f, 0.f, 0.f, 0.f}, b2 = {0.f, 0.f, 0.f, 0.f};
       static_for(std::make_integer_sequence<int, XQ>{}, [&](auto qc) {
         constexpr int q = decltype(qc)::value;
+      if constexpr ((HTA_UV_ABLATE & 2) && q >= 1) return;
 #pragma unroll
         for (int u = 0; u < 4; u += 2) {
           acc1 = mfma_from_group<q % 4>(A1[4 * q + u], c1[q / 4][u], acc1);
@@ -138,6 +151,7 @@ __global__ __launch_bounds__(XNT, CO ? 2 : 1) void rmhmc_uv_kernel(FusedArgs<flo
     } else {
       static_for(std::make_integer_sequence<int, XQ>{}, [&](auto qc) {
         constexpr int q = decltype(qc)::value;
+      if constexpr ((HTA_UV_ABLATE & 2) && q >= 1) return;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           acc1 = mfma_from_group<q % 4>(A1[4 * q + u], c1[q / 4][u], acc1);
@@ -156,6 +170,7 @@ __global__ __launch_bounds__(XNT, CO ? 2 : 1) void rmhmc_uv_kernel(FusedArgs<flo
       bf4 sc = {0.f, 0.f, 0.f, 0.f}, sd = {0.f, 0.f, 0.f, 0.f};
       static_for(std::make_integer_sequence<int, XQ>{}, [&](auto qc) {
         constexpr int q = decltype(qc)::value;
+      if constexpr ((HTA_UV_ABLATE & 2) && q >= 1) return;
         const T a0 = A1[4 * q], a1 = A1[4 * q + 1], a2 = A1[4 * q + 2], a3 = A1[4 * q + 3];
         acc = mfma_from_group<q % 4>(squared ? a0 * a0 : a0, c1[q / 4][0], acc);
         sb = mfma_from_group<q % 4>(squared ? a1 * a1 : a1, c1[q / 4][1], sb);
@@ -167,6 +182,7 @@ __global__ __launch_bounds__(XNT, CO ? 2 : 1) void rmhmc_uv_kernel(FusedArgs<flo
     } else {
       static_for(std::make_integer_sequence<int, XQ>{}, [&](auto qc) {
         constexpr int q = decltype(qc)::value;
+      if constexpr ((HTA_UV_ABLATE & 2) && q >= 1) return;
 #pragma unroll
         for (int u = 0; u < 4; u += 2) {
           const T a0 = A1[4 * q + u], a1 = A1[4 * q + u + 1];
@@ -189,7 +205,7 @@ __global__ __launch_bounds__(XNT, CO ? 2 : 1) void rmhmc_uv_kernel(FusedArgs<flo
 #pragma unroll
       for (int i = 0; i < 4; ++i) wv[i] = e[i] * x[i];
       put4(A, wv);
-      __syncthreads();
+      if (HTA_UV_ABLATE & 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads();
       bf4 r = {0.f, 0.f, 0.f, 0.f};
       prod1(Sa, A, false, r);
 #pragma unroll
@@ -380,7 +396,7 @@ __global__ __launch_bounds__(XNT, CO ? 2 : 1) void rmhmc_uv_kernel(FusedArgs<flo
           centred(X, dv);                                   // the tracked products of the rotated state, afresh
           put4(DV, dv);
           put4(GV, g);
-          __syncthreads();
+          if (HTA_UV_ABLATE & 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads();
           bf4 p1 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
           prod2(Pa, DV, Sa, GV, p1, s1);
 #pragma unroll
@@ -450,6 +466,7 @@ int rmhmc_uv_launch(const FusedArgs<float>& a, int cus, hipStream_t s) {
   const int64_t ngroup = (a.C + g - 1) / g;
   const int grid = (int)(ngroup < 8192 ? ngroup : 8192);
   const bool co = g_rmhmc_uv_co != 0, acc4 = g_rmhmc_uv_acc == 4;
+  if (g == 1 && g_rmhmc_uvc && g_rmhmc_lean && a.K == 2 && a.has_jitter) return rmhmc_uvc_launch(a, co, s);
   if (!g_rmhmc_lean) {
     note_route("rmhmc_uv_kernel<%d>", g);
     if (g == 1) rmhmc_uv_kernel<1><<<grid, XNT, bytes, s>>>(a);

@@ -409,7 +409,10 @@ int hta_netn_logp_grad_f64(const double* theta, int64_t C, int n_layers, const i
  * filled by the other's matrix instructions; bit-identical to 0; also extends the kernel's range to 4 x CUs chains),
  * "rmhmc_uv_acc" (2 | 4 accumulator chains per product of rmhmc_uv_kernel; 4 needs no s_nop between dependent matrix
  * instructions; another summation order, equal to rounding),
- * "rmhmc_uv_g" (0 = chains per workgroup by chain count; 1 or 2 force it). */
+ * "rmhmc_uv_g" (0 = chains per workgroup by chain count; 1 or 2 force it),
+ * "rmhmc_uvc" (round 4; 1 = one-chain workgroups with K == 2 refinements and jitter run on rmhmc_uvc_kernel: one value per
+ * lane in the element-wise work and three product phases per step - the second-order term of a solve rides in the idle columns
+ * of the next phase's matrix instructions; equal to the K = 2 iteration up to third-order terms in jitter / lambda_min). */
 int hta_set_tuning(const char* key, int value);
 /* current value of a route key; every key back to its default (test fixtures call this between tests: the keys are
  * process-global).  The environment variable HTA_TUNING_DEFAULTS="key=value,..." moves the DEFAULT of the named keys for the

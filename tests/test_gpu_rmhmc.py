@@ -1135,3 +1135,76 @@ def test_uv_kernel_coresident_and_four_chain_instances(ht, C, D):
     d = (outs["base"][0] - outs["acc4"][0]).abs().amax(dim=(0, 2))[live]
     assert int((d > 1e-4).sum()) <= max(1, C // 100), float(d.max())
     assert int(outs["acc4"][1][3]) == T
+
+
+@pytest.mark.parametrize("D,C,burn", [(100, 256, 2), (100, 37, -1), (37, 30, 1), (64, 20, 0), (7, 9, 2), (99, 256, 3)])
+def test_uvc_kernel_equals_uv_kernel(ht, D, C, burn):
+    """Round 4: rmhmc_uvc_kernel (csrc/rmhmc_uvc.hip: one chain per workgroup, ONE value per lane in the element-wise work, the
+    second-order term of every solve deferred into the idle matrix-instruction columns of the next phase: three product phases
+    per step instead of five) against rmhmc_uv_kernel<1> (K = 2 refinement phases per solve): the same streams and update
+    order; the results differ by third-order terms in jitter / lambda_min and by rounding.  Padding rows (D = 37, 99 < 128), a
+    mean offset, burn-in (Q2 reset), H_old / H_new / accept, several launches over traj_offset, a chain that diverges."""
+    from hamiltorch_amd import _abi
+    T, L, jit = 9, 6, 1e-3
+    t, _ = cfg3_target(ht, D, torch.float32, seed=5)
+    t.mean.add_(torch.linspace(-1.0, 1.0, D, device=dev()))
+    th0 = tt((0.3 * O.philox_normals(3, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32), torch.float32) + t.mean
+    th0[min(3, C - 1)] = 1e30
+    bad = min(3, C - 1)
+    outs = []
+    try:
+        for uvc in (1, 0):
+            _abi.set_tuning("rmhmc_uvc", uvc); _abi.set_tuning("rmhmc_uv_g", 1); _abi.set_tuning("rmhmc_uv", 2)
+            nb = max(burn, 0)
+            cur = th0.clone(); rej = torch.zeros(C, dtype=torch.int32, device=dev())
+            samples = torch.zeros(T - nb + 1, C, D, device=dev())
+            Ho = torch.zeros(T, C, device=dev()); Hn = torch.zeros(T, C, device=dev()); ac = torch.zeros(T, C, dtype=torch.uint8, device=dev())
+            ws = torch.empty(_abi.rmhmc_workspace_bytes(C, D, 4, T), dtype=torch.uint8, device=dev())
+            for t0, nt in ((0, 5), (5, T - 5)):                     # two launches: the state travels through `cur`
+                _abi.rmhmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, _abi.METRIC_SOFTABS, 1e6, jit, L, 0.1, 10.0,
+                                           nt, t0, burn, 21, 0, samples, rej, ws, H_old=Ho[t0:], H_new=Hn[t0:], accept=ac[t0:])
+                r = _abi.last_route()
+            torch.cuda.synchronize()
+            assert r.startswith("rmhmc_uvc_kernel<" if uvc else "rmhmc_uv_kernel<1"), r
+            outs.append((samples.cpu().numpy(), rej.cpu().numpy(), cur.cpu().numpy(), Ho.cpu().numpy(), Hn.cpu().numpy(), ac.cpu().numpy()))
+    finally:
+        _abi.reset_tuning()
+    keep = np.arange(C) != bad
+    assert np.isfinite(outs[0][0][:, keep]).all()
+    np.testing.assert_allclose(outs[0][3][0][keep], outs[1][3][0][keep], rtol=2e-5, atol=2e-4)      # H_old / H_new of the first
+    np.testing.assert_allclose(outs[0][4][0][keep], outs[1][4][0][keep], rtol=2e-5, atol=2e-4)      # trajectory: before any decision
+    err = np.abs(outs[0][0] - outs[1][0])[:, keep].max(axis=(0, 2))
+    assert (err > 1e-4).mean() <= 0.05, "max err %.3g (%d chains differ)" % (err.max(), (err > 1e-4).sum())
+    good = np.where(keep)[0][err <= 1e-4]
+    assert np.array_equal(outs[0][1][good], outs[1][1][good])
+    assert np.array_equal(outs[0][5][:, good], outs[1][5][:, good])
+    np.testing.assert_allclose(outs[0][2][good], outs[1][2][good], atol=1e-4)
+    assert int(outs[0][1][bad]) == T and np.array_equal(outs[0][2][bad], outs[1][2][bad])
+    assert np.abs(outs[0][0][-1] - outs[0][0][1])[keep].max() > 1e-3
+
+
+@pytest.mark.parametrize("co", [0, 1])
+def test_uvc_kernel_vs_oracle_at_cfg3(ht, co):
+    """BASELINE config 3 on rmhmc_uvc_kernel (256 chains, D = 100, L = 10, jitter 1e-3) against the oracle, which does the
+    reference's eigendecomposition per metric evaluation (S:108-122), on the same Philox streams: 32 chains spread over the
+    batch, chain by chain; both register budgets of the kernel (one and two workgroups per CU)."""
+    from hamiltorch_amd import _abi
+    C, N, nsel, D, L, eps, omega, alpha, jitter, seed, off = 256, 4, 32, 100, 10, 0.1, 10.0, 1e6, 1e-3, 2026, 7
+    t, o = cfg3_target(ht, D, torch.float32)
+    th0 = (0.1 * O.philox_normals(seed, off + np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32)
+    try:
+        _abi.set_tuning("rmhmc_uvc", 1); _abi.set_tuning("rmhmc_uv_co", co)
+        out, acc = ht.sample(t, tt(th0, torch.float32), num_samples=N, num_steps_per_sample=L, step_size=eps, jitter=jitter, softabs_const=alpha,
+                             explicit_binding_const=omega, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT,
+                             metric=ht.Metric.SOFTABS, debug=2, verbose=False, seed=seed, chain_offset=off)
+        assert _abi.last_route() == "rmhmc_uvc_kernel<%s>" % ("co" if co else "solo"), _abi.last_route()
+    finally:
+        _abi.reset_tuning()
+    got = torch.stack(out).cpu().numpy()
+    assert got.shape == (N, C, D) and np.isfinite(got).all()
+    sel = np.unique(np.r_[0:4, np.linspace(4, C - 5, nsel - 8).astype(int), C - 4:C])
+    ref, info = O.sample_rmhmc_explicit(o, th0[sel], N, L, eps, omega, alpha, 0, jitter,
+                                        O.PhiloxDraws(seed, off + sel, np.float32), "softabs", momentum="split")
+    err = np.abs(got[:, sel] - np.stack(ref)).max(axis=(0, 2))
+    assert (err > 5e-4).sum() <= 1, "%d of %d chains differ (max %.3g)" % ((err > 5e-4).sum(), len(sel), err.max())
+    np.testing.assert_allclose(acc.cpu().numpy()[sel][err <= 5e-4], info["acc_rate"][err <= 5e-4], atol=1e-12)

@@ -14,11 +14,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import hamiltorch_amd as ht            # noqa: E402
 from hamiltorch_amd import _abi        # noqa: E402
+if os.environ.get("HTA_LIB"):          # a developer build of the library (tools/uv_ablate.sh)
+    _abi.LIB_PATH = os.path.join(ROOT, os.environ["HTA_LIB"])
 
 
 def main():
     dev = torch.device("cuda:0")
-    D, L, eps, omega, alpha, jitter = 100, 10, 0.1, 10.0, 1e6, 1e-3
+    D, L, eps, omega, alpha, jitter = 100, int(os.environ.get("AB_L", "10")), 0.1, 10.0, 1e6, 1e-3
     g = torch.Generator().manual_seed(0)
     Q = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))[0]
     P = (Q * torch.linspace(0.5, 2.0, D, dtype=torch.float64)) @ Q.T
