@@ -277,11 +277,12 @@ class Cfg3:
     def roof_kernel(self):      # the trajectory kernel the library picks at this chain count (csrc/rmhmc_fused.hip dispatch)
         if self.jacobi:
             return "metric_eval_kernel<float> (+ phi_c_kernel, mh_select)"
-        if self.C <= 512:
-            return "rmhmc_uv_kernel<%d> (%s per workgroup: state set and copy as columns of v_mfma_f32_4x4x1_16b)" % (
-                (1, "one chain") if self.C <= 256 else (2, "two chains"))
-        if self.C <= 1024:
-            return "rmhmc_mfma4x4_kernel<true> (4 chains per four-wave workgroup, v_mfma_f32_4x4x1_16b)"
+        if self.C <= 256:
+            return ("rmhmc_uvc_kernel (one chain per workgroup: state set and copy as columns of v_mfma_f32_4x4x1_16b, one value per "
+                    "lane, three product phases per step)")
+        if self.C <= 1792:
+            return ("rmhmc_uvc2_kernel (two chains per workgroup, two workgroups per CU beyond 512 chains: four columns of "
+                    "v_mfma_f32_4x4x1_16b, two values per lane)")
         if self.C <= 2048:
             return "rmhmc_mfma4_kernel (4 chains per two-wave workgroup, v_mfma_f32_4x4x1_16b)"
         return "rmhmc_batch_kernel<25> (16 chains per workgroup, v_mfma_f32_16x16x4) + rmhmc_momentum_wave_kernel<13>"

@@ -23,7 +23,7 @@ int g_force_general = 0;
 int g_rmhmc_batch = 1;     // fused RMHMC: 16 chains per workgroup on the matrix cores from 2048 chains on (0 off, 2 always)
 int g_rmhmc_momwave = 1;   // fused RMHMC: momentum draws by the wave-per-task kernel (fp32, jitter, D <= 104); 0: workgroup-per-task kernel
 int g_rmhmc_mfma4 = 1;     // fused RMHMC: four chains per workgroup on v_mfma_f32_4x4x1_16b (0 off, 1 for lo <= chains < hi, 2 always)
-int g_rmhmc_mfma4_lo = 513, g_rmhmc_mfma4_hi = 2049;   // round 2 (tracked products): 544 / 640 / 700 chains 1.40x / 1.37x / 1.38x the one-chain kernel, below 513 rmhmc_uv_kernel; round 1: 3072: 0.87x, 4096: 0.88x the 16-chain kernel (a third workgroup per CU doubles a SIMD's load)
+int g_rmhmc_mfma4_lo = 1793, g_rmhmc_mfma4_hi = 2049;   // round 4: up to 7 x CUs chains the two-chain kernel of rmhmc_uvc.hip, two workgroups per CU (1536 chains: 2.25e8 against 1.97e8); before:   // round 2 (tracked products): 544 / 640 / 700 chains 1.40x / 1.37x / 1.38x the one-chain kernel, below 513 rmhmc_uv_kernel; round 1: 3072: 0.87x, 4096: 0.88x the 16-chain kernel (a third workgroup per CU doubles a SIMD's load)
 int g_netn_waves = 1;        // csrc/netn_hmc.hip: waves per chain (2 / 4 where they fit; measured slower at 1024 chains)
 int g_rmhmc_uv = 1;          // rmhmc_uv.hip (one or two chains per workgroup as columns of the matrix instruction): 1 up to 2 x CUs chains, 0 off, 2 always
 int g_rmhmc_pair = 1;        // four-chain kernels: consecutive half steps share product phases (0: one half step at a time)
@@ -98,14 +98,14 @@ struct TuneKey { const char* key; int* var; int dflt; };
 const TuneKey kTune[] = {
     {"small_chains_per_block", &hta::g_small_chains_per_block, 0}, {"force_general", &hta::g_force_general, 0},
     {"gauss_eig", &hta::g_gauss_eig, 1}, {"rmhmc_momwave", &hta::g_rmhmc_momwave, 1}, {"rmhmc_mfma4", &hta::g_rmhmc_mfma4, 1},
-    {"rmhmc_mfma4_lo", &hta::g_rmhmc_mfma4_lo, 513}, {"rmhmc_mfma4_hi", &hta::g_rmhmc_mfma4_hi, 2049},
+    {"rmhmc_mfma4_lo", &hta::g_rmhmc_mfma4_lo, 1793}, {"rmhmc_mfma4_hi", &hta::g_rmhmc_mfma4_hi, 2049},
     {"rmhmc_mfma4_waves", &hta::g_rmhmc_mfma4_waves, 4}, {"netn_waves", &hta::g_netn_waves, 1}, {"rmhmc_uv", &hta::g_rmhmc_uv, 1},
     {"rmhmc_pair", &hta::g_rmhmc_pair, 1}, {"rmhmc_wide", &hta::g_rmhmc_wide, 1}, {"rmhmc_overlap", &hta::g_rmhmc_overlap, 0},
     {"rmhmc_momsplit", &hta::g_rmhmc_momsplit, 1},
     {"rmhmc_batch", &hta::g_rmhmc_batch, 1}, {"quad_max_chains", &hta::g_quad_max_chains, 65536}, {"fill_blocks", &hta::g_fill_blocks, 4096},
     {"mlp_valu", &hta::g_mlp_valu, 0}, {"metric_mfma", &hta::g_metric_mfma, 1}, {"metric_general", &hta::g_metric_general, 1}, {"rmhmc_fused", &hta::g_rmhmc_fused, 1},
     {"mlp3_route", &hta::g_mlp3_route, 1}, {"quad_variant", &hta::g_quad_variant, 7}, {"rmhmc_lean", &hta::g_rmhmc_lean, 1},
-    {"rmhmc_uv_co", &hta::g_rmhmc_uv_co, 0}, {"rmhmc_uv_acc", &hta::g_rmhmc_uv_acc, 2}, {"rmhmc_uv_g", &hta::g_rmhmc_uv_g, 0}, {"rmhmc_uvc", &hta::g_rmhmc_uvc, 0},
+    {"rmhmc_uv_co", &hta::g_rmhmc_uv_co, 1}, {"rmhmc_uv_acc", &hta::g_rmhmc_uv_acc, 2}, {"rmhmc_uv_g", &hta::g_rmhmc_uv_g, 0}, {"rmhmc_uvc", &hta::g_rmhmc_uvc, 1},
 };
 // HTA_TUNING_DEFAULTS=key=value,...: moves the DEFAULT of route keys for this process (applied when the library is loaded and by
 // hta_reset_tuning) - A/B runs of whole test files under another route without touching the tests' own set / reset calls

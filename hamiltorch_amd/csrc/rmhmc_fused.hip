@@ -2453,7 +2453,7 @@ int rmhmc_fused_sample(T* cur, const T* theta_init, const T* P, const T* Sinv, c
         // one or two chains per workgroup, their state sets as columns of the 16-block matrix instruction (rmhmc_uv.hip): up to
         // 2 x (compute units) chains (tuning key "rmhmc_uv": 0 off, 2 at any chain count)
         const bool uv = g_rmhmc_uv && g_rmhmc_mfma4 != 2 && g_rmhmc_batch != 2 && !pair && block > 0 && (series || !has_jitter) && D <= QK &&
-                        (C <= (g_rmhmc_uv_co ? 4 : 2) * (int64_t)fused_cu_count() || g_rmhmc_uv == 2);
+                        (C <= (g_rmhmc_uv_co ? 7 : 2) * (int64_t)fused_cu_count() || g_rmhmc_uv == 2);
         if (uv) {
           profile_begin(s);
           const int rc_uv = rmhmc_uv_launch(a, fused_cu_count(), s);

@@ -42,6 +42,7 @@ template <int... I, typename F> __device__ __forceinline__ void static_for(std::
 int rmhmc_uv_launch(const FusedArgs<float>& a, int cus, hipStream_t s);
 // rmhmc_uvc.hip: one chain per workgroup, compact element-wise layout, three product phases per step (K == 2 with jitter only)
 int rmhmc_uvc_launch(const FusedArgs<float>& a, bool co, hipStream_t s);
+int rmhmc_uvc2_launch(const FusedArgs<float>& a, bool co, hipStream_t s);    // two chains per workgroup, two values per lane, any K
 extern int g_rmhmc_uvc;
 
 }  // namespace hta

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(XNT, CO ? 2 : 1) void rmhmc_uv_kernel(FusedArgs<flo
   }
 }
 
-int g_rmhmc_uv_co = 0;       // tuning key "rmhmc_uv_co": 1 = the 256-register instances, two workgroups per CU
+int g_rmhmc_uv_co = 1;       // tuning key "rmhmc_uv_co" (default 1): the 256-register instances, two workgroups per CU; 0 = the uncapped ones
 int g_rmhmc_uv_acc = 2;      // tuning key "rmhmc_uv_acc": accumulator chains per product (2 or 4)
 int g_rmhmc_uv_g = 0;        // tuning key "rmhmc_uv_g": chains per workgroup (0 = by chain count, 1, 2)
 
@@ -467,6 +467,7 @@ int rmhmc_uv_launch(const FusedArgs<float>& a, int cus, hipStream_t s) {
   const int grid = (int)(ngroup < 8192 ? ngroup : 8192);
   const bool co = g_rmhmc_uv_co != 0, acc4 = g_rmhmc_uv_acc == 4;
   if (g == 1 && g_rmhmc_uvc && g_rmhmc_lean && a.K == 2 && a.has_jitter) return rmhmc_uvc_launch(a, co, s);
+  if (g == 2 && g_rmhmc_uvc && g_rmhmc_lean) return rmhmc_uvc2_launch(a, co, s);
   if (!g_rmhmc_lean) {
     note_route("rmhmc_uv_kernel<%d>", g);
     if (g == 1) rmhmc_uv_kernel<1><<<grid, XNT, bytes, s>>>(a);

@@ -368,7 +368,325 @@ __global__ __launch_bounds__(XNT, CO ? 2 : 1) void rmhmc_uvc_kernel(FusedArgs<fl
   }
 }
 
-int g_rmhmc_uvc = 0;         // tuning key "rmhmc_uvc": 1 = one-chain groups with K == 2 and jitter run on rmhmc_uvc_kernel
+// ---- TWO chains per workgroup (513 ... 1024 chains: two workgroups per CU under the 256-register cap; 257 ... 512 chains: one) ----
+// All four columns of the matrix instruction are in use (chain 0's U and V, chain 1's U and V), so there are no idle columns to
+// defer into: the schedule is rmhmc_uv_kernel<2>'s (K refinement phases per pair of half steps + one phase after the rotation,
+// any K).  What is taken over from the one-chain kernel above is the element-wise layout: the two parities of a row block hold
+// the same four rows of a column; here lane (column cl, parity kp) OWNS rows row0 + kp and row0 + 2 + kp - two values per lane
+// instead of four duplicated ones, half the element-wise instructions, one 8-byte LDS store per published vector - and the
+// branch-free half steps (the set that moves first is selected by a per-lane coefficient, not by divergent control flow).
+template <bool CO>
+__global__ __launch_bounds__(XNT, CO ? 2 : 1) void rmhmc_uvc2_kernel(FusedArgs<float> a) {
+  typedef float T;
+  typedef float bf2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* lds = reinterpret_cast<T*>(smem_raw);
+  constexpr int MSZ = XNC * XLD;
+  T* DV = lds; T* GV = DV + MSZ; T* EV = GV + MSZ; T* W0 = EV + MSZ; T* W1 = W0 + MSZ;
+  T* WS = W1 + MSZ;                // half steps: refinement vectors [pair of the step][iteration parity]
+  T* red = WS + 4 * MSZ;           // [XWV][XNC][4]
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cl = l & 3, grp = l >> 4;
+  const int kpar = (l >> 3) & 1, rb = 2 * grp + ((l >> 2) & 1);
+  const bool khi = kpar != 0, setV = (cl & 1) != 0;
+  const int cidx = cl >> 1;
+  const int D = a.D;
+  const int row0 = 32 * w + 4 * rb, arow = row0 + cl;
+  const int rowa = row0 + kpar, rowb = rowa + 2;           // the two rows this lane owns (column cl)
+  const bool roka = rowa < D, rokb = rowb < D, roka_p = (rowa ^ 1) < D, rokb_p = (rowb ^ 1) < D;
+  T Sa[XKJ], Pa[XKJ];
+#pragma unroll
+  for (int j = 0; j < XKJ; ++j) {
+    const int k = 2 * j + kpar;
+    const bool ok = arow < D && k < D;
+    Sa[j] = ok ? a.S[(int64_t)k * D + arow] : 0.f;
+    Pa[j] = ok ? a.P[(int64_t)k * D + arow] : 0.f;
+  }
+  const T mu_a = roka ? a.mu[rowa] : 0.f, mu_b = rokb ? a.mu[rowb] : 0.f;
+  const T sd_a = roka ? a.S[(int64_t)rowa * D + rowa] : 0.f, sd_b = rokb ? a.S[(int64_t)rowb * D + rowb] : 0.f;
+  for (int e = tid; e < 9 * MSZ + XWV * XNC * 4; e += XNT) lds[e] = 0.f;
+  const T eh = 0.5f * a.eps;
+  const T ehU = setV ? 0.f : eh, ehV = setV ? eh : 0.f;
+  const T hc = 0.5f, rc = a.rot_c, rs = a.rot_s;
+  const int own_off = cl * XLD + kpar * XHL + (row0 >> 1);  // rows rowa, rowb: two consecutive floats of this parity's half
+  const int b_off = cl * XLD + kpar * XHL + 4 * grp;
+  uint64_t chain = 0;
+  bool live = false;
+
+  auto partner = [&](T v) { return quad_dpp<0xB1>(v); };
+  auto of_set_u = [&](T v) { return quad_dpp<0xA0>(v); };
+  auto of_set_v = [&](T v) { return quad_dpp<0xF5>(v); };
+  auto put2 = [&](T* X, T va, T vb) { *reinterpret_cast<bf2*>(X + own_off) = bf2{va, vb}; };
+  // rows rowa, rowb of this lane's column: the parity sums
+  auto extract = [&](const bf4& acc, T& va, T& vb) {
+    const T m01 = khi ? acc[1] : acc[0], o01 = khi ? acc[0] : acc[1];
+    const T m23 = khi ? acc[3] : acc[2], o23 = khi ? acc[2] : acc[3];
+    va = m01 + other_parity(o01);
+    vb = m23 + other_parity(o23);
+  };
+  auto fetch = [&](const T* X, bf4 (&c)[XSQ]) {
+#pragma unroll
+    for (int Q = 0; Q < XSQ; ++Q) c[Q] = *reinterpret_cast<const bf4*>(X + b_off + 16 * Q);
+  };
+  auto prod2 = [&](const T (&A1)[XKJ], const T* X1, const T (&A2)[XKJ], const T* X2, bf4& acc1, bf4& acc2) {
+    bf4 c1[XSQ], c2[XSQ];
+    fetch(X1, c1);
+    fetch(X2, c2);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for(std::make_integer_sequence<int, XQ>{}, [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc1 = mfma_from_group<q % 4>(A1[4 * q + u], c1[q / 4][u], acc1);
+        acc2 = mfma_from_group<q % 4>(A2[4 * q + u], c2[q / 4][u], acc2);
+      }
+    });
+  };
+  auto prod1 = [&](const T (&A1)[XKJ], const T* X1, bool squared, bf4& acc) {
+    bf4 c1[XSQ], sb = {0.f, 0.f, 0.f, 0.f};
+    fetch(X1, c1);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for(std::make_integer_sequence<int, XQ>{}, [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+#pragma unroll
+      for (int u = 0; u < 4; u += 2) {
+        const T a0 = A1[4 * q + u], a1 = A1[4 * q + u + 1];
+        acc = mfma_from_group<q % 4>(squared ? a0 * a0 : a0, c1[q / 4][u], acc);
+        sb = mfma_from_group<q % 4>(squared ? a1 * a1 : a1, c1[q / 4][u + 1], sb);
+      }
+    });
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += sb[e];
+  };
+  auto jitter_one = [&](uint32_t n, uint32_t sub, T& ea, T& eb) {
+    const U4 r = philox_block(a.seed, chain, n, PURPOSE_JITTER, sub, (uint32_t)(row0 >> 2));
+    ea = (live && roka) ? a.jitter * u23<T>(khi ? r.y : r.x) : 0.f;
+    eb = (live && rokb) ? a.jitter * u23<T>(khi ? r.w : r.z) : 0.f;
+  };
+  // both jitter vectors of a step for this column: the even parity draws the A pair's block, the odd parity the B pair's, each
+  // hands the other the elements of the other's rows
+  auto jitter_pair = [&](uint32_t n, uint32_t subA, uint32_t subB, T (&eA)[2], T (&eB)[2]) {
+    const U4 r = philox_block(a.seed, chain, n, PURPOSE_JITTER, khi ? subB : subA, (uint32_t)(row0 >> 2));
+    const T ma = (live && roka) ? a.jitter * u23<T>(khi ? r.y : r.x) : 0.f;
+    const T mb = (live && rokb) ? a.jitter * u23<T>(khi ? r.w : r.z) : 0.f;
+    const T oa = other_parity((live && roka_p) ? a.jitter * u23<T>(khi ? r.x : r.y) : 0.f);
+    const T ob = other_parity((live && rokb_p) ? a.jitter * u23<T>(khi ? r.z : r.w) : 0.f);
+    eA[0] = khi ? oa : ma; eA[1] = khi ? ob : mb;
+    eB[0] = khi ? ma : oa; eB[1] = khi ? mb : ob;
+  };
+  // x = (P + diag(e))^-1 g from x0 = S g: K phases; w returns e . x_(K-1)
+  auto solve = [&](T* WB, const T (&e)[2], const T (&x0)[2], T (&x)[2], T (&wv)[2]) {
+    x[0] = x0[0]; x[1] = x0[1]; wv[0] = 0.f; wv[1] = 0.f;
+    for (int it = 0; it < a.K; ++it) {
+      T* A = WB + (it & 1) * MSZ;
+      wv[0] = e[0] * x[0]; wv[1] = e[1] * x[1];
+      put2(A, wv[0], wv[1]);
+      __syncthreads();
+      bf4 r = {0.f, 0.f, 0.f, 0.f};
+      prod1(Sa, A, false, r);
+      T ra, rbv;
+      extract(r, ra, rbv);
+      x[0] = x0[0] - ra; x[1] = x0[1] - rbv;
+    }
+  };
+  auto col_sums = [&](T (&v)[3]) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      v[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[e]), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
+      v[e] += other_parity(v[e]);
+      v[e] += __shfl_xor(v[e], 16, 64);
+      v[e] += __shfl_xor(v[e], 32, 64);
+    }
+    __syncthreads();
+    if (l < 4) {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) red[(w * XNC + l) * 4 + e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      T s = 0.f;
+#pragma unroll
+      for (int i = 0; i < XWV; ++i) s += red[(i * XNC + cl) * 4 + e];
+      v[e] = s;
+    }
+  };
+  auto hamiltonian = [&](uint32_t n, uint32_t sub, const T (&X)[2], const T (&g)[2], T& H, T& logp, T (&Pd_out)[2], T (&Sg_out)[2],
+                         T& kin_out, T& ld_out) {
+    T ev[2] = {0.f, 0.f};
+    if (a.has_jitter) jitter_one(n, sub, ev[0], ev[1]);
+    const T dra = X[0] - mu_a, drb = X[1] - mu_b;
+    put2(EV, ev[0], ev[1]);
+    put2(DV, dra, drb);
+    put2(GV, g[0], g[1]);
+    __syncthreads();
+    bf4 Pdv = {0.f, 0.f, 0.f, 0.f}, x0v = {0.f, 0.f, 0.f, 0.f}, s2v = {0.f, 0.f, 0.f, 0.f};
+    prod2(Pa, DV, Sa, GV, Pdv, x0v);
+    T x0[2], s2a = 0.f, s2b = 0.f;
+    extract(Pdv, Pd_out[0], Pd_out[1]);
+    extract(x0v, x0[0], x0[1]);
+    if (a.has_jitter) { prod1(Sa, EV, true, s2v); extract(s2v, s2a, s2b); }
+    Sg_out[0] = x0[0]; Sg_out[1] = x0[1];
+    T v[3];
+    v[0] = dra * Pd_out[0] + drb * Pd_out[1];
+    v[2] = a.has_jitter ? ev[0] * (sd_a - 0.5f * s2a) + ev[1] * (sd_b - 0.5f * s2b) : 0.f;
+    T xr[2], wv[2];
+    solve(W0, ev, x0, xr, wv);
+    v[1] = g[0] * xr[0] + g[1] * xr[1];
+    col_sums(v);
+    const float pi_term = (float)D * 1.8378770351409912f;   // S:712
+    logp = a.log_norm - 0.5f * v[0];
+    H = -logp + 0.5f * pi_term + 0.5f * (a.logdetP + v[2]) + 0.5f * v[1];
+    kin_out = v[1]; ld_out = v[2];
+  };
+
+  const int64_t ngroup = (a.C + 1) / 2;
+  for (int64_t cg = blockIdx.x; cg < ngroup; cg += gridDim.x) {
+    const int64_t c = 2 * cg + cidx;
+    live = c < a.C;
+    chain = a.chain_offset + (uint64_t)(live ? c : 0);
+    const int64_t cs = live ? c : 0;                        // (a dead column reads chain 0's rows and discards them)
+    T scur[2];
+    scur[0] = (live && roka) ? a.cur[cs * D + rowa] : 0.f;
+    scur[1] = (live && rokb) ? a.cur[cs * D + rowb] : 0.f;
+    int ma = -(int)roka, mb = -(int)rokb;
+    asm volatile("" : "+v"(ma));
+    asm volatile("" : "+v"(mb));
+    auto momentum_raw = [&](int tt, T (&v)[2]) {
+      const T* prow = a.p_ws + ((int64_t)tt * a.C + cs) * D;
+      v[0] = prow[rowa & ma]; v[1] = prow[rowb & mb];
+    };
+    auto momentum_use = [&](T (&v)[2], T (&out)[2]) {
+      asm volatile("" : "+v"(v[0])); asm volatile("" : "+v"(v[1]));
+      out[0] = (live && roka) ? v[0] : 0.f; out[1] = (live && rokb) ? v[1] : 0.f;
+    };
+    int32_t rejected = 0;
+    __syncthreads();
+    bool have_next = false;
+    T gn[2] = {0.f, 0.f}, y_next[2] = {0.f, 0.f}, z_next[2] = {0.f, 0.f}, H0_next = 0.f, lp_next = 0.f;
+    for (int t = 0; t < a.n_traj; ++t) {
+      const uint32_t n = (uint32_t)(a.traj_offset + t);
+      T H0, H1, lp0, lp1, kin, ld, X[2], g[2], y[2], z[2];
+      if (have_next) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { g[i] = gn[i]; X[i] = scur[i]; y[i] = y_next[i]; z[i] = z_next[i]; }
+        H0 = H0_next; lp0 = lp_next;
+      } else {
+        T raw[2];
+        momentum_raw(t, raw);
+        momentum_use(raw, g);
+        X[0] = scur[0]; X[1] = scur[1];
+        hamiltonian(n, 1, X, g, H0, lp0, y, z, kin, ld);    // S:971 -> S:822
+      }
+      const bool pre = t + 1 < a.n_traj;
+      T gn_raw[2] = {0.f, 0.f};
+      if (pre) momentum_raw(t + 1, gn_raw);
+      const T y_start[2] = {y[0], y[1]};
+      // one pair of half steps: the set with the non-zero `pre` coefficient moves its momentum first, the other one after its solve
+      auto half_pair = [&](T cpre, T cpost, const T (&e)[2], T* WB) {
+        g[0] = fmaf(-cpre, y[0], g[0]); g[1] = fmaf(-cpre, y[1], g[1]);
+        z[0] = fmaf(-cpre, X[0] - mu_a, z[0]); z[1] = fmaf(-cpre, X[1] - mu_b, z[1]);
+        T x[2], wv[2];
+        solve(WB, e, z, x, wv);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          X[i] = fmaf(eh, x[i], X[i]);
+          y[i] = fmaf(eh, g[i] - wv[i], y[i]);              // P x = g - e . x_(K-1)
+        }
+        g[0] = fmaf(-cpost, y[0], g[0]); g[1] = fmaf(-cpost, y[1], g[1]);
+        z[0] = fmaf(-cpost, X[0] - mu_a, z[0]); z[1] = fmaf(-cpost, X[1] - mu_b, z[1]);
+      };
+      for (int lstep = 0; lstep < a.L; ++lstep) {           // S:427-461
+        const uint32_t k0 = 2u + 8u * (uint32_t)lstep;
+        T eA[2] = {0.f, 0.f}, eB[2] = {0.f, 0.f};
+        if (a.has_jitter) jitter_pair(n, setV ? k0 + 1u : k0 + 2u, setV ? k0 + 7u : k0 + 4u, eA, eB);
+        half_pair(ehU, ehV, eA, WS);                        // phi_A/2, phi_B/2  S:429-433
+        if (a.K == 0) __syncthreads();                      // (no solve phase since the last reads of DV / GV)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                       // phi_C  S:447-450, sequential (Q1), both sets compute it
+          const T pX = partner(X[i]), pg = partner(g[i]);
+          T xx = setV ? pX : X[i], b = setV ? pg : g[i], xc = setV ? X[i] : pX, bc = setV ? g[i] : pg;
+          xx = hc * ((xx + xc) + rc * (xx - xc) + rs * (b - bc));
+          b = hc * ((b + bc) - rs * (xx - xc) + rc * (b - bc));
+          xc = hc * ((xx + xc) - rc * (xx - xc) - rs * (b - bc));
+          bc = hc * ((b + bc) + rs * (xx - xc) - rc * (b - bc));
+          X[i] = setV ? xc : xx; g[i] = setV ? bc : b;
+        }
+        put2(DV, X[0] - mu_a, X[1] - mu_b);                 // the tracked products of the rotated state, afresh
+        put2(GV, g[0], g[1]);
+        __syncthreads();
+        bf4 p1 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        prod2(Pa, DV, Sa, GV, p1, s1);
+        extract(p1, y[0], y[1]);
+        extract(s1, z[0], z[1]);
+        half_pair(ehV, ehU, eB, WS + 2 * MSZ);              // phi_B/2, phi_A/2  S:454-458
+      }
+      if (a.K == 0) __syncthreads();
+      // ---- H_new on the un-augmented pair = set U (S:989, Q4); in the V column: the next trajectory's momentum terms
+      T Pd1[2], Sg1[2], Xh[2], gh[2];
+      if (pre) momentum_use(gn_raw, gn);
+      const bool nextcol = setV && pre;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        Xh[i] = of_set_u(X[i]);
+        const T gu = of_set_u(g[i]);
+        gh[i] = nextcol ? gn[i] : gu;
+      }
+      hamiltonian(nextcol ? n + 1u : n, nextcol ? 1u : 2u + 8u * (uint32_t)a.L, Xh, gh, H1, lp1, Pd1, Sg1, kin, ld);
+      // ---- Metropolis test + bookkeeping (S:1000-1026, S:1045-1057) on the U column's values, mirrored in the V column
+      const T H0u = of_set_u(H0), H1u = of_set_u(H1), lp1u = of_set_u(lp1);
+      const T u = u23<T>(philox_block(a.seed, chain, n, PURPOSE_MH, 0, 0).x);
+      const bool acc = mh_accept<T>(H0u, H1u, lp1u, u);
+      const bool reset = (!acc) && ((int)n == a.burn + 1);  // Q2
+      have_next = pre && !reset;
+      {
+        const T lp0u = of_set_u(lp0), ldv = of_set_v(ld), kinv = of_set_v(kin);
+        const T Pa0 = of_set_u(Pd1[0]), Pa1 = of_set_u(Pd1[1]), Sv0 = of_set_v(Sg1[0]), Sv1 = of_set_v(Sg1[1]);
+        if (have_next) {
+          const float pi_term = (float)D * 1.8378770351409912f;
+          lp_next = acc ? lp1u : lp0u;
+          H0_next = -lp_next + 0.5f * pi_term + 0.5f * (a.logdetP + ldv) + 0.5f * kinv;
+          y_next[0] = acc ? Pa0 : y_start[0]; y_next[1] = acc ? Pa1 : y_start[1];
+          z_next[0] = Sv0; z_next[1] = Sv1;
+        }
+      }
+      if (live) {
+        if (roka) {
+          const T vnew = acc ? Xh[0] : (reset ? a.theta_init[c * D + rowa] : scur[0]);
+          scur[0] = vnew;
+          if (!setV && a.samples && (int)n > a.burn) a.samples[((int64_t)((int)n - a.burn) * a.C + c) * D + rowa] = vnew;
+        }
+        if (rokb) {
+          const T vnew = acc ? Xh[1] : (reset ? a.theta_init[c * D + rowb] : scur[1]);
+          scur[1] = vnew;
+          if (!setV && a.samples && (int)n > a.burn) a.samples[((int64_t)((int)n - a.burn) * a.C + c) * D + rowb] = vnew;
+        }
+      }
+      if (live && !setV && w == 0 && (l >> 2) == 0) {
+        if (a.H_old) a.H_old[(int64_t)t * a.C + c] = H0u;
+        if (a.H_new) a.H_new[(int64_t)t * a.C + c] = H1u;
+        if (a.accept) a.accept[(int64_t)t * a.C + c] = acc ? 1 : 0;
+      }
+      if (!acc) ++rejected;
+    }
+    if (live && !setV) {
+      if (roka) a.cur[c * D + rowa] = scur[0];
+      if (rokb) a.cur[c * D + rowb] = scur[1];
+      if (w == 0 && (l >> 2) == 0) a.reject_count[c] += rejected;
+    }
+  }
+}
+
+int g_rmhmc_uvc = 1;         // tuning key "rmhmc_uvc" (default 1): one-chain groups with K == 2 and jitter run on rmhmc_uvc_kernel, two-chain groups on rmhmc_uvc2_kernel; 0 = rmhmc_uv_kernel
+
+int rmhmc_uvc2_launch(const FusedArgs<float>& a, bool co, hipStream_t s) {
+  const size_t bytes = (size_t)(9 * XNC * XLD + XWV * XNC * 4) * sizeof(float);
+  const int64_t ngroup = (a.C + 1) / 2;
+  const int grid = (int)(ngroup < 8192 ? ngroup : 8192);
+  note_route("rmhmc_uvc2_kernel<%s>", co ? "co" : "solo");
+  if (co) rmhmc_uvc2_kernel<true><<<grid, XNT, bytes, s>>>(a);
+  else rmhmc_uvc2_kernel<false><<<grid, XNT, bytes, s>>>(a);
+  return HTA_OK;
+}
 
 int rmhmc_uvc_launch(const FusedArgs<float>& a, bool co, hipStream_t s) {
   const size_t bytes = (size_t)(CBUF * XNC * XLD + XWV * 2 * 4) * sizeof(float);

@@ -385,10 +385,10 @@ int hta_netn_logp_grad_f64(const double* theta, int64_t C, int n_layers, const i
  * count, the two kernels compete for the same SIMDs), "rmhmc_momsplit" (1 default: with jitter on, the fused route draws
  * p = chol(P) z1 + sqrt(jitter u) . z2 - covariance P + diag(jitter u) = G exactly, the law of S:183-184, chol(P) once per target;
  * 0 = chol(G) z with a factorisation per draw, the reference's arithmetic), "rmhmc_batch" (1 default: 16 chains per workgroup on the matrix cores from 2048 chains on; 0 off, 2 always),
- * "rmhmc_mfma4" (1 default: 4 chains per workgroup on v_mfma_f32_4x4x1_16b for "rmhmc_mfma4_lo" = 513 <= chains < "rmhmc_mfma4_hi" = 2049;
+ * "rmhmc_mfma4" (1 default: 4 chains per workgroup on v_mfma_f32_4x4x1_16b for "rmhmc_mfma4_lo" = 1793 (round 4; before: 513) <= chains < "rmhmc_mfma4_hi" = 2049;
  * 0 off, 2 always; "rmhmc_mfma4_waves" 4 default: four waves per group - rows x contraction parity inside a wave; 2 = two waves;
  * "netn_waves" 1 default: waves per chain of the small-network kernel (2 / 4: a chain's sweeps over several waves where they fit);
- * "rmhmc_uv" 1 default: up to 2 x (compute units) chains run one or two per workgroup with their state sets as columns of the
+ * "rmhmc_uv" 1 default: up to 7 x (compute units) chains (2 x with "rmhmc_uv_co" = 0) run one or two per workgroup with their state sets as columns of the
  * matrix instruction - csrc/rmhmc_uv.hip; 0 off, 2 at any chain count;
  * "rmhmc_pair" 1 default: two consecutive half steps share K + 2 product phases, 0 = one half step at a time), "rmhmc_wide" (1 default: the spill-free one-workgroup-per-CU
  * instances of the one-chain kernel when chains <= compute units; 0 = always the two-workgroups-per-CU instances), "rmhmc_momwave" (1 default: one wave per momentum draw, fp32 with jitter, D <= 104; 0 = one workgroup per draw), "mlp_valu" (1 = VALU MLP kernel instead of the MFMA one),
@@ -405,14 +405,16 @@ int hta_netn_logp_grad_f64(const double* theta, int64_t C, int n_layers, const i
  * values - and, with rmhmc_mfma4x4_kernel, without the selects that zero the padding rows, which are exact zeros by
  * construction: the same results bit for bit, ~30 instructions fewer per step of these one-wave-per-SIMD kernels (+1.6 % / +1.2 %);
  * 0 = the round-2 instances, the parity partners),
- * "rmhmc_uv_co" (round 4; 1 = rmhmc_uv_kernel under a 256-register cap, two workgroups per CU: the phase latency of one is
+ * "rmhmc_uv_co" (round 4; 1 default = rmhmc_uv_kernel / rmhmc_uvc*_kernel under a 256-register cap, two workgroups per CU: the phase latency of one is
  * filled by the other's matrix instructions; bit-identical to 0; also extends the kernel's range to 4 x CUs chains),
  * "rmhmc_uv_acc" (2 | 4 accumulator chains per product of rmhmc_uv_kernel; 4 needs no s_nop between dependent matrix
  * instructions; another summation order, equal to rounding),
  * "rmhmc_uv_g" (0 = chains per workgroup by chain count; 1 or 2 force it),
- * "rmhmc_uvc" (round 4; 1 = one-chain workgroups with K == 2 refinements and jitter run on rmhmc_uvc_kernel: one value per
+ * "rmhmc_uvc" (round 4; 1 default = one-chain workgroups with K == 2 refinements and jitter run on rmhmc_uvc_kernel: one value per
  * lane in the element-wise work and three product phases per step - the second-order term of a solve rides in the idle columns
- * of the next phase's matrix instructions; equal to the K = 2 iteration up to third-order terms in jitter / lambda_min). */
+ * of the next phase's matrix instructions; equal to the K = 2 iteration up to third-order terms in jitter / lambda_min; two-chain
+ * workgroups run on rmhmc_uvc2_kernel: two values per lane, branch-free half steps, the schedule of rmhmc_uv_kernel<2>;
+ * 0 = rmhmc_uv_kernel, the parity partner of both). */
 int hta_set_tuning(const char* key, int value);
 /* current value of a route key; every key back to its default (test fixtures call this between tests: the keys are
  * process-global).  The environment variable HTA_TUNING_DEFAULTS="key=value,..." moves the DEFAULT of the named keys for the

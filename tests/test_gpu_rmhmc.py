@@ -231,7 +231,7 @@ def test_cfg3_statistical_parity_with_jitter(ht):
     out, acc = ht.sample(t, th0, num_samples=N, num_steps_per_sample=10, step_size=0.1, burn=-1, jitter=1e-3,
                          softabs_const=1e6, explicit_binding_const=10, sampler=ht.Sampler.RMHMC,
                          integrator=ht.Integrator.EXPLICIT, metric=ht.Metric.SOFTABS, debug=2, verbose=False, seed=7)
-    assert _abi.last_route() == ("rmhmc_uv_kernel<1,lean>" if _abi.get_tuning("rmhmc_lean") else "rmhmc_uv_kernel<1>")
+    assert _abi.last_route() == "rmhmc_uvc_kernel<co>"        # (round 4; before: rmhmc_uv_kernel<1,lean>)
     a = torch.stack(out).double().cpu().numpy()
     s = a[-keep:].reshape(-1, 100)
     assert float(acc.mean()) > 0.97
@@ -1080,6 +1080,7 @@ def test_lean_instances_of_the_lone_wave_kernels_are_bit_identical(ht, C, D, rou
     outs = []
     for lean in (0, 1):
         _abi.set_tuning("rmhmc_lean", lean)
+        _abi.set_tuning("rmhmc_uvc", 0); _abi.set_tuning("rmhmc_uv_co", 0); _abi.set_tuning("rmhmc_mfma4_lo", 513)   # the round-3 routes
         try:
             cur = th0.clone(); samples = torch.zeros(T + 1, C, D, device=dev()); rej = torch.zeros(C, dtype=torch.int32, device=dev())
             ws = torch.zeros(_abi.rmhmc_workspace_bytes(C, D, 4, T), dtype=torch.uint8, device=dev())
@@ -1111,8 +1112,9 @@ def test_uv_kernel_coresident_and_four_chain_instances(ht, C, D):
     th0 = 0.1 * torch.randn(C, D, generator=torch.Generator().manual_seed(C), dtype=torch.float32).to(dev()) + t.mean
     th0[3] = 1e30
     outs = {}
-    for name, keys in (("base", {"rmhmc_uv": 2}), ("co", {"rmhmc_uv": 2, "rmhmc_uv_co": 1}), ("acc4", {"rmhmc_uv": 2, "rmhmc_uv_acc": 4}),
-                       ("co_acc4", {"rmhmc_uv_co": 1, "rmhmc_uv_acc": 4})):
+    for name, keys in (("base", {"rmhmc_uv": 2, "rmhmc_uv_co": 0}), ("co", {"rmhmc_uv": 2, "rmhmc_uv_co": 1}),
+                       ("acc4", {"rmhmc_uv": 2, "rmhmc_uv_acc": 4, "rmhmc_uv_co": 0}), ("co_acc4", {"rmhmc_uv_co": 1, "rmhmc_uv_acc": 4})):
+        _abi.set_tuning("rmhmc_uvc", 0)
         for k, v in keys.items():
             _abi.set_tuning(k, v)
         try:
@@ -1208,3 +1210,50 @@ def test_uvc_kernel_vs_oracle_at_cfg3(ht, co):
     err = np.abs(got[:, sel] - np.stack(ref)).max(axis=(0, 2))
     assert (err > 5e-4).sum() <= 1, "%d of %d chains differ (max %.3g)" % ((err > 5e-4).sum(), len(sel), err.max())
     np.testing.assert_allclose(acc.cpu().numpy()[sel][err <= 5e-4], info["acc_rate"][err <= 5e-4], atol=1e-12)
+
+
+@pytest.mark.parametrize("D,C,burn,jit", [(100, 512, 2, 1e-3), (100, 37, -1, 1e-3), (37, 30, 1, 4e-3), (64, 21, 0, None), (7, 9, 2, 1e-3), (99, 1024, 3, 1e-3)])
+def test_uvc2_kernel_equals_uv_kernel(ht, D, C, burn, jit):
+    """Round 4: rmhmc_uvc2_kernel (csrc/rmhmc_uvc.hip: two chains per workgroup, TWO values per lane in the element-wise work,
+    branch-free half steps; the schedule of rmhmc_uv_kernel<2>, any K) against rmhmc_uv_kernel<2>: same streams, same products
+    in the same order - results equal to rounding of the element-wise expressions.  Odd chain counts (half-empty last group),
+    padding rows, no jitter (K = 0), more refinements (jitter 4e-3), burn-in (Q2), two launches, a diverging chain; 1024 chains
+    run two workgroups per CU."""
+    from hamiltorch_amd import _abi
+    T, L = 9, 6
+    t, _ = cfg3_target(ht, D, torch.float32, seed=5)
+    t.mean.add_(torch.linspace(-1.0, 1.0, D, device=dev()))
+    th0 = tt((0.3 * O.philox_normals(3, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32), torch.float32) + t.mean
+    bad = min(3, C - 1)
+    th0[bad] = 1e30
+    outs = []
+    try:
+        for uvc in (1, 0):
+            _abi.set_tuning("rmhmc_uvc", uvc); _abi.set_tuning("rmhmc_uv_g", 2); _abi.set_tuning("rmhmc_uv", 2)
+            _abi.set_tuning("rmhmc_uv_co", 1 if C > 512 else 0)
+            nb = max(burn, 0)
+            cur = th0.clone(); rej = torch.zeros(C, dtype=torch.int32, device=dev())
+            samples = torch.zeros(T - nb + 1, C, D, device=dev())
+            Ho = torch.zeros(T, C, device=dev()); Hn = torch.zeros(T, C, device=dev()); ac = torch.zeros(T, C, dtype=torch.uint8, device=dev())
+            ws = torch.empty(_abi.rmhmc_workspace_bytes(C, D, 4, T), dtype=torch.uint8, device=dev())
+            for t0, nt in ((0, 5), (5, T - 5)):
+                _abi.rmhmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, _abi.METRIC_SOFTABS, 1e6, jit, L, 0.1, 10.0,
+                                           nt, t0, burn, 21, 0, samples, rej, ws, H_old=Ho[t0:], H_new=Hn[t0:], accept=ac[t0:])
+                r = _abi.last_route()
+            torch.cuda.synchronize()
+            assert r.startswith("rmhmc_uvc2_kernel<" if uvc else "rmhmc_uv_kernel<2"), r
+            outs.append((samples.cpu().numpy(), rej.cpu().numpy(), cur.cpu().numpy(), Ho.cpu().numpy(), Hn.cpu().numpy(), ac.cpu().numpy()))
+    finally:
+        _abi.reset_tuning()
+    keep = np.arange(C) != bad
+    assert np.isfinite(outs[0][0][:, keep]).all()
+    np.testing.assert_allclose(outs[0][3][0][keep], outs[1][3][0][keep], rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(outs[0][4][0][keep], outs[1][4][0][keep], rtol=2e-5, atol=2e-4)
+    err = np.abs(outs[0][0] - outs[1][0])[:, keep].max(axis=(0, 2))
+    assert (err > 1e-4).mean() <= 0.05, "max err %.3g (%d chains differ)" % (err.max(), (err > 1e-4).sum())
+    good = np.where(keep)[0][err <= 1e-4]
+    assert np.array_equal(outs[0][1][good], outs[1][1][good])
+    assert np.array_equal(outs[0][5][:, good], outs[1][5][:, good])
+    np.testing.assert_allclose(outs[0][2][good], outs[1][2][good], atol=1e-4)
+    assert int(outs[0][1][bad]) == T and np.array_equal(outs[0][2][bad], outs[1][2][bad])
+    assert np.abs(outs[0][0][-1] - outs[0][0][1])[keep].max() > 1e-3
