@@ -317,7 +317,10 @@ def hmc_gaussian_prepare(like, P, mass_kind, mass_factor, C, D, n_traj, workspac
 
 
 def hmc_gaussian_forget(workspace):
-    _check(load().hta_hmc_gaussian_forget(c_vp(workspace.data_ptr())), "hta_hmc_gaussian_forget")
+    # (the library keys its plans by (current device, pointer): forget on the workspace's device, whatever is current - a
+    #  finaliser may run while another GPU is selected)
+    with torch.cuda.device(workspace.device):
+        _check(load().hta_hmc_gaussian_forget(c_vp(workspace.data_ptr())), "hta_hmc_gaussian_forget")
 
 
 def hmc_gaussian_leapfrog(theta, p, P, mu, mass_kind, inv_mass, steps, eps, path_theta=None, path_p=None):
@@ -413,7 +416,8 @@ def rmhmc_gaussian_prepare(like, P, mu, metric, alpha, jitter, C, workspace):
 
 
 def rmhmc_gaussian_forget(workspace):
-    _check(load().hta_rmhmc_gaussian_forget(c_vp(workspace.data_ptr())), "hta_rmhmc_gaussian_forget")
+    with torch.cuda.device(workspace.device):
+        _check(load().hta_rmhmc_gaussian_forget(c_vp(workspace.data_ptr())), "hta_rmhmc_gaussian_forget")
 
 
 # ---- Bayesian MLP (regression) -----------------------------------------------------------------------

@@ -95,6 +95,7 @@ int rmhmc_leapfrog(T* th, T* pm, T* thc, T* pmc, const T* P, const T* mu, int me
 // ---- the per-target setup of hta_rmhmc_gaussian_sample and its cache -------------------------------------------------------
 struct RmPrepared {
   const void* P; int D, metric, has_jitter, elem; double alpha, jitter;      // what it was prepared for
+  int64_t C;                                                                  // ... and for how many chains: the prepared block sits behind 4 C D + 3 C elements
   int K, series; double logdetP;                                              // the fused route's plan (K < 0: not eligible)
   int split;                                                                  // chol(P) is in the workspace (the split momentum draw)
   int fused_keys;                                                             // g_rmhmc_fused at preparation time
@@ -102,13 +103,13 @@ struct RmPrepared {
 static std::mutex g_prep_mu;
 static std::map<std::pair<int, const void*>, RmPrepared> g_prepared;         // (device, workspace) -> plan
 static int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
-static bool prepared_lookup(const void* ws, const void* P, int D, int metric, double alpha, int has_jitter, double jitter, size_t elem,
-                            RmPrepared& out) {
+static bool prepared_lookup(const void* ws, const void* P, int64_t C, int D, int metric, double alpha, int has_jitter, double jitter,
+                            size_t elem, RmPrepared& out) {
   std::lock_guard<std::mutex> lock(g_prep_mu);
   auto it = g_prepared.find({current_device(), ws});
   if (it == g_prepared.end()) return false;
   const RmPrepared& p = it->second;
-  if (p.P != P || p.D != D || p.metric != metric || p.alpha != alpha || p.has_jitter != has_jitter || p.jitter != jitter ||
+  if (p.P != P || p.C != C || p.D != D || p.metric != metric || p.alpha != alpha || p.has_jitter != has_jitter || p.jitter != jitter ||
       p.elem != (int)elem || p.fused_keys != g_rmhmc_fused)
     return false;
   out = p;
@@ -119,7 +120,7 @@ template <typename T>
 static int rmhmc_setup(RmModel<T>& m, T* V0, T* lam0, T* Sinv, T* LP, bool want_plan, RmPrepared& pr, hipStream_t s) {
   const char* who = "hta_rmhmc_gaussian_sample";
   const int D = m.D;
-  pr = RmPrepared{m.P, D, m.metric, m.has_jitter, (int)sizeof(T), m.alpha, m.jitter, -1, 0, 0.0, 0, g_rmhmc_fused};
+  pr = RmPrepared{m.P, D, m.metric, m.has_jitter, (int)sizeof(T), m.alpha, m.jitter, m.C, -1, 0, 0.0, 0, g_rmhmc_fused};
   if (m.metric == HTA_METRIC_SOFTABS || g_rmhmc_fused) {
     // the target's curvature is one matrix for all chains and all evaluation points: diagonalise it once
     MetricArgsT<T> a0 = base_args(m, 0, 0);
@@ -215,7 +216,7 @@ int rmhmc_sample(T* cur, const T* theta_init, const T* P, const T* mu, double lo
   // synchronise) and the shared inverse S.  A caller that keeps sampling one target in several calls prepares its workspace
   // once (hta_rmhmc_gaussian_prepare): the cold Jacobi + inverse are 1.2 ms, 14 % of a 100-trajectory call at 1024 chains.
   RmPrepared pr;
-  if (!prepared_lookup(workspace, P, D, metric, alpha, has_jitter, jitter, sizeof(T), pr)) {
+  if (!prepared_lookup(workspace, P, C, D, metric, alpha, has_jitter, jitter, sizeof(T), pr)) {
     const int rcp = rmhmc_setup<T>(m, V0, lam0, Sinv, LP, n_traj > 0, pr, s);
     if (rcp) return rcp;
   }

@@ -218,7 +218,8 @@ class _WarmBases:
     state set (theta, p), "b": the explicit integrator's copy) - a [C, D, D] tensor, the identity before the first call,
     updated in place by every call.  The evaluation then runs on the matrix cores (csrc/rmhmc_metric_mfma.hip): the
     curvature rotated into the previous basis is nearly diagonal, so it is refined (or finished by a few Jacobi sweeps
-    inside the launch) instead of being diagonalised from scratch - a hint only, results agree to rounding.
+    inside the launch) instead of being diagonalised from scratch - a hint only, results agree to rounding (the samplers
+    reset the bases once per trajectory: `reset`).
     fp32, soft-abs, D <= 112 on the device; otherwise `kw` is empty and the evaluation is the cold one."""
 
     def __init__(self, like, kind):
@@ -237,6 +238,14 @@ class _WarmBases:
             self.bufs[slot] = buf
         D = buf.shape[-1]
         return {"V0": buf, "v0_stride": D * D, "V_out": buf}
+
+    def reset(self):
+        """Back to the identity (a cold evaluation next): the kernel treats V0 as exactly orthogonal, and `V <- V0 X` in place
+        lets rounding accumulate in V^T V - I over a long run.  The samplers call this once per trajectory:
+        one cold evaluation in 8 L + 3, the drift bounded by a trajectory's products."""
+        for buf in self.bufs.values():
+            buf.zero_()
+            buf.diagonal(dim1=-2, dim2=-1).fill_(1.0)
 
 
 def _generic_steps(cv, kind, th, pm, thc, pmc, steps, eps, omega, alpha, jitter, seed, chain_offset, draw, path=None, warm=None):
@@ -376,8 +385,10 @@ def _sample_explicit_generic(log_prob_func, theta0, N, L, eps, burn, jitter, alp
     warm = _WarmBases(cur, kind)
     acc = torch.zeros(C, dtype=torch.uint8, device=dev)
     Hs = lp0 = None               # curvature and log p AT THE CURRENT POINT, carried across trajectories (see the end of the loop)
+    carry = os.environ.get("HAMILTORCH_AMD_CARRY", "1") != "0"       # 0: differentiate again every trajectory (an impure callback)
     prog = util._Progress('Sampling (Sampler.RMHMC; Integrator.EXPLICIT)', N, verbose)
     for n in range(N):
+        warm.reset()
         if Hs is None:
             _, Hs = cv.grad_neg_hessian(cur)
             lp0 = cv.value(cur)
@@ -397,8 +408,9 @@ def _sample_explicit_generic(log_prob_func, theta0, N, L, eps, burn, jitter, alp
         # the next trajectory starts where this one ended (accepted) or started (rejected): both points' curvature and log p are
         # known - the reference differentiates again (S:971 -> S:822); after the Q2 reset (S:1018) they are recomputed
         took = acc.bool()
-        Hs = None if n == burn + 1 else torch.where(took[:, None, None], Hs1, Hs)
-        lp0 = None if n == burn + 1 else torch.where(took, lp1, lp0)
+        fresh = n == burn + 1 or not carry
+        Hs = None if fresh else torch.where(took[:, None, None], Hs1, Hs)
+        lp0 = None if fresh else torch.where(took, lp1, lp0)
         prog.update(n)
     prog.end()
     return samples, rejected
@@ -494,8 +506,10 @@ def sample_implicit(log_prob_func, theta0, N, L, eps, burn, jitter, alpha, metri
     warm = _WarmBases(cur, kind)
     acc = torch.zeros(C, dtype=torch.uint8, device=dev)
     Hs = lp0 = None               # as in _sample_explicit_generic: carried across trajectories
+    carry = os.environ.get("HAMILTORCH_AMD_CARRY", "1") != "0"
     prog = util._Progress('Sampling (Sampler.RMHMC; Integrator.IMPLICIT)', N, verbose)
     for n in range(N):
+        warm.reset()
         if Hs is None:
             _, Hs = cv.grad_neg_hessian(cur)
             lp0 = cv.value(cur)
@@ -513,8 +527,9 @@ def sample_implicit(log_prob_func, theta0, N, L, eps, burn, jitter, alpha, metri
         _abi.mh_select(cur, th, theta0, H0, H1, lp1, row, rejected, acc, n, burn, seed, chain_offset)
         cv.touched(cur)
         took = acc.bool()
-        Hs = None if n == burn + 1 else torch.where(took[:, None, None], Hs1, Hs)
-        lp0 = None if n == burn + 1 else torch.where(took, lp1, lp0)
+        fresh = n == burn + 1 or not carry
+        Hs = None if fresh else torch.where(took[:, None, None], Hs1, Hs)
+        lp0 = None if fresh else torch.where(took, lp1, lp0)
         prog.update(n)
     prog.end()
     return samples, rejected

@@ -42,23 +42,31 @@ class _Row:
             if name in ("cat", "concat", "concatenate") and len(args) <= 2 and set(kwargs) <= {"dim"} and lst._t.dim() >= 2 \
                     and dim in (0, -(lst._t.dim() - 1)):
                 return lst._t.reshape((-1,) + tuple(lst._t.shape[2:])).clone()
-        args = _materialise_in(args)
-        kwargs = {k: _materialise_in(v) for k, v in kwargs.items()}
+        found = [False]
+        args = _materialise_in(args, found)
+        kwargs = {k: _materialise_in(v, found) for k, v in kwargs.items()}
+        if not found[0]:
+            # a placeholder reached torch outside its SampleList (a C-level copy of the list's slots): calling `func` again
+            # would dispatch straight back here
+            raise TypeError("hamiltorch_amd.SampleList placeholder outside its list (the list's storage was copied at the C "
+                            "level); use list(samples) or samples.tensor")
         return func(*args, **kwargs)
 
 
 _ROW = _Row()
 
 
-def _materialise_in(obj):
+def _materialise_in(obj, found=None):
     if isinstance(obj, SampleList):
+        if found is not None and not obj._done:
+            found[0] = True
         obj._materialise()
         return obj
     if isinstance(obj, tuple):
-        return tuple(_materialise_in(o) for o in obj)
+        return tuple(_materialise_in(o, found) for o in obj)
     if type(obj) is list:
         for o in obj:
-            _materialise_in(o)
+            _materialise_in(o, found)
     return obj
 
 
@@ -114,6 +122,12 @@ class SampleList(list):
     def __copy__(self):
         self._materialise()
         return list(self)
+
+    def __radd__(self, other):
+        # `plain_list + samples`: without this CPython's list_concat accepts the subclass and copies its raw slots (the
+        # placeholders); a subclass's reflected method is tried first
+        self._materialise()
+        return other + list(self)
 
     def __deepcopy__(self, memo):
         import copy

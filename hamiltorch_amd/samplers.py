@@ -685,6 +685,9 @@ class _GenericHMC(_Engine):
         self._lp_cur = torch.empty_like(self.Ho)
         self._acc = torch.zeros(C, dtype=torch.uint8, device=theta0.device)
         self._cache_valid = False
+        # HAMILTORCH_AMD_CARRY=0: evaluate (log p, gradient) at the current point afresh every trajectory, as the reference does
+        # (S:971, S:281) - for a callback whose value is not a pure function of its argument.  Read once per run.
+        self._carry = os.environ.get("HAMILTORCH_AMD_CARRY", "1") != "0"
 
     def _refresh_cache(self):
         if self.split:                                  # the split integrators carry log p only (their first kick is one subset's)
@@ -708,7 +711,7 @@ class _GenericHMC(_Engine):
         # trajectory costs L callback evaluations instead of L + 2 (the native kernels carry lp_cur the same way).
         # (HAMILTORCH_AMD_CARRY=0: evaluate both afresh every trajectory, as the reference does - for a callback whose value
         #  is not a pure function of its argument)
-        if not self._cache_valid or os.environ.get("HAMILTORCH_AMD_CARRY", "1") == "0":
+        if not self._cache_valid or not self._carry:
             self._refresh_cache()
         _abi.hamiltonian(p, self._lp_cur, kind, im, Ho)                                    # S:971
         prop.copy_(cur)

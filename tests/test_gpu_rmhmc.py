@@ -898,6 +898,13 @@ def test_prepared_workspace_gives_identical_results_and_skips_the_setup(ht):
         assert torch.equal(s3, s4) and n3 == n0 and not torch.equal(s3, s0)
         _abi.rmhmc_gaussian_forget(ws_b)
         assert run(ws_b, fused=fused)[2] == n0
+        # the prepared block sits behind 4 C D + 3 C elements - a preparation for ANOTHER chain count must not
+        # apply (the call would read basis, inverse and chol(P) from the wrong offsets): it sets up itself, same bits
+        big = torch.empty(_abi.rmhmc_workspace_bytes(2 * C, D, 4, T), dtype=torch.uint8, device=dev())
+        _abi.rmhmc_gaussian_prepare(th0.repeat(2, 1), t.precision, t.mean, _abi.METRIC_SOFTABS, 1e6, 1e-3, 2 * C, big)
+        s5, r5, n5 = run(big, fused=fused)
+        assert torch.equal(s5, s0) and torch.equal(r5, r0) and n5 == n0
+        _abi.rmhmc_gaussian_forget(big)
     _abi.reset_tuning()
     # through sample(): prepared once per target, again after an in-place edit of the precision matrix
     kw = dict(num_samples=5, num_steps_per_sample=3, step_size=0.1, jitter=1e-3, softabs_const=1e6, explicit_binding_const=10,

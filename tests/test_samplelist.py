@@ -114,3 +114,22 @@ def test_predict_model_reads_the_lazy_list_without_materialising():
     p2, l2 = ht.predict_model(net, plain, x=X, y=Y, model_loss="regression", tau_out=2.0)
     assert torch.equal(p1, p2) and all(torch.equal(a, b) for a, b in zip(l1, l2))
     assert bnn.predict_stats["batched"] >= 2
+
+
+def test_plain_list_plus_samplelist_holds_real_rows():
+    """`[params_init] + samples` went through CPython's list_concat, which copies a list SUBCLASS's raw slots -
+    the placeholders.  `__radd__` (tried first for a subclass) materialises; and a placeholder that does reach torch outside
+    its list raises instead of dispatching to itself for ever."""
+    from hamiltorch_amd.samplelist import SampleList, _ROW
+    t = torch.randn(70, 3)
+    first = torch.zeros(3)
+    both = [first] + SampleList(t)
+    assert type(both) is list and len(both) == 71 and all(isinstance(r, torch.Tensor) for r in both)
+    assert torch.equal(torch.stack(both)[1:], t)
+    s = SampleList(t)
+    burn = [torch.ones(3)] * 2
+    burn += s                                               # list_inplace_concat -> iteration
+    assert len(burn) == 72 and torch.equal(torch.stack(burn[2:]), t)
+    assert torch.equal(torch.stack(SampleList(t) + [first])[:-1], t)
+    with pytest.raises(TypeError, match="placeholder"):
+        torch.stack([_ROW, _ROW])
