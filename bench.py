@@ -100,6 +100,65 @@ def _median3(fn):
     return out
 
 
+PINNED = {
+    "cfg2": "tests/golden/cfg2.npz (test_torch_port_cfg2_bit_identical: the port reproduces the unmodified reference's sample() bit for bit)",
+    "cfg3": "tests/golden/cfg3.npz (test_torch_port_cfg3_with_jitter_matches_reference_run)",
+    "cfg4": "tests/golden/cfg4.npz (test_torch_port_cfg4_full_size_matches_reference_run)",
+    "nbmlp": "tests/golden/nbmlp.npz (test_torch_port_nbmlp_matches_reference_run)",
+    "nbmlp-full": "tests/golden/nbmlp.npz (test_torch_port_nbmlp_matches_reference_run)",
+    "funnel-hmc": "tests/golden/funnel_hmc.npz (test_torch_port_funnel_hmc_matches_reference_run)",
+    "funnel-rmhmc": "tests/golden/funnel.npz (the oracle's explicit RMHMC on the funnel against the reference's recorded paths)",
+}
+
+
+def cpu_baseline_procs(key, seconds, rounds=1):
+    """SURVEY 8(d): one single-threaded chain per process, one process per usable host core (affinity mask / cgroup quota;
+    HTA_BENCH_CPU_PROCS caps it), rate = all leapfrog steps / the slowest process's sampling time.  Each process is
+    oracle/cpu_baseline.py: the UNMODIFIED reference when it is importable on this host (`kind: "reference"`), else the
+    per-chain port pinned to the reference's recorded runs (`kind: "port"`).  `rounds` > 1: the median round."""
+    import subprocess
+    avail, procs = _usable_cores()
+    procs = max(1, min(procs, int(os.environ.get("HTA_BENCH_CPU_PROCS", "64"))))
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="",
+               PYTHONDONTWRITEBYTECODE="1")
+    from hamiltorch_amd.ess import ess_min
+
+    def once(rep):
+        t0 = time.time()
+        ps = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), key, str(1000 + 97 * rep + i),
+                                repr(float(seconds) / rounds)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
+              for i in range(procs)]
+        res, failed = [], 0
+        for p_ in ps:
+            out_, _ = p_.communicate(timeout=300 + 30 * seconds)
+            try:
+                res.append(json.loads(out_.strip().splitlines()[-1]))
+            except (IndexError, ValueError):
+                failed += 1                                   # a chain that ended in an exception of the reference's own code path
+        if not res:
+            raise RuntimeError("cpu_baseline: every worker of %s failed" % key)
+        procs_ok = len(res)
+        wall = time.time() - t0
+        L = res[0]["L"]
+        steps = sum(r["n"] * r["L"] for r in res)
+        dt = max(r["dt"] for r in res)
+        out = {"value": steps / dt, "unit": "leapfrog-steps/s", "cores": procs_ok, "kind": res[0]["kind"], "workers_failed": failed,
+               "sample": "%d processes x 1 chain x ~%d trajectories x L=%d, one thread each (%s), %.1f s sampling, %.1f s with "
+                         "process start-up%s" % (procs, res[0]["n"], L, res[0]["impl"], dt, wall,
+                                                 "; median of %d such rounds" % rounds if rounds > 1 else ""),
+               "per_core": steps / dt / procs_ok, "samples_per_s": sum(r["n"] for r in res) / dt,
+               "samples_per_s_per_core": sum(r["n"] for r in res) / dt / procs_ok, "acceptance": sum(r["acc"] for r in res) / procs_ok, "host_cores_available": avail, "host_cores_usable": procs}
+        if "samples" in res[0]:
+            out["ess_per_sec"] = sum(ess_min(torch.tensor(r["samples"]).unsqueeze(1)) for r in res) / dt
+        return out
+    reps = sorted((once(r) for r in range(rounds)), key=lambda r: r["value"])
+    out = reps[len(reps) // 2]
+    if rounds > 1:
+        out["repeats"] = [r["value"] for r in reps]
+    out["pinned_to"] = PINNED.get(key, "")
+    return out
+
+
 _PHYSICAL = None
 
 
@@ -194,42 +253,8 @@ class Cfg2:
                         "quad): see latency_model and physical"}
 
     def cpu_baseline(self, seconds):
-        """The reference's CPU cost structure on this host: one single-threaded chain per process (autograd
-        callback, torch CPU RNG), one process per usable host core (affinity mask / cgroup CPU quota; HTA_BENCH_CPU_PROCS
-        caps it); rate = all leapfrog steps / the slowest process's sampling time.  Median of three rounds."""
-        import subprocess
-        avail, procs = _usable_cores()
-        procs = max(1, min(procs, int(os.environ.get("HTA_BENCH_CPU_PROCS", "64"))))
-        env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
-        from hamiltorch_amd.ess import ess_min
-
-        def once(rep):
-            t0 = time.time()
-            ps = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "torch_port.py"), "cfg2", str(1000 + 97 * rep + i),
-                                    str(self.L), repr(self.eps), repr(float(seconds) / 3)], stdout=subprocess.PIPE,
-                                   stderr=subprocess.DEVNULL, env=env, text=True) for i in range(procs)]
-            res = []
-            for p_ in ps:
-                out_, _ = p_.communicate(timeout=120 + 20 * seconds)
-                r = json.loads(out_.strip().splitlines()[-1])
-                res.append((r["n"], r["L"], r["dt"], r["acc"], r["samples"]))
-            wall = time.time() - t0
-            steps = sum(n * L for n, L, _, _, _ in res)
-            dt = max(r[2] for r in res)
-            ess = sum(ess_min(torch.tensor(r[4]).unsqueeze(1)) for r in res)
-            return {"value": steps / dt, "unit": "leapfrog-steps/s", "cores": procs, "kind": "port",
-                    "sample": "%d processes x 1 chain x ~%d trajectories x L=%d, one thread each (oracle/torch_port.py: per-step "
-                              "autograd on a MultivariateNormal.log_prob callback, as the reference), %.1f s sampling, %.1f s with "
-                              "process start-up; median of 3 such rounds" % (procs, res[0][0], self.L, dt, wall),
-                    "per_core": steps / dt / procs, "ess_per_sec": ess / dt,
-                    "acceptance": sum(r[3] for r in res) / procs, "host_cores_available": avail, "host_cores_usable": procs}
-        reps = [once(r) for r in range(3)]
-        reps.sort(key=lambda r: r["value"])
-        out = reps[1]
-        out["repeats"] = [r["value"] for r in reps]
-        out["pinned_to"] = "tests/golden/cfg2.npz (tests/test_oracle_golden.py::test_torch_port_cfg2_bit_identical: the port " \
-                           "reproduces the unmodified reference's sample() bit for bit from the same torch seed)"
-        return out
+        """The reference's CPU path on this host: see cpu_baseline_procs.  Median of three rounds."""
+        return cpu_baseline_procs("cfg2", seconds, rounds=3)
 
 
 class Cfg3:
@@ -337,31 +362,9 @@ class Cfg3:
                                                "shared-inverse solves + one Cholesky per trajectory")}
 
     def cpu_baseline(self, seconds):
-        """Reference cost structure: every dH/dtheta, dH/dp is an autograd pass through hessian + eigh (S:395-422)."""
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import torch_port as TP
-        torch.set_num_threads(1)
-        P = self.P64.float()
-
-        def lp(w):
-            return -0.5 * torch.dot(w, torch.mv(P, w))
-        init = 0.1 * torch.randn(self.D, generator=torch.Generator().manual_seed(0))
-        torch.manual_seed(0)
-        for _ in range(2):          # the first call pays torch's lazy initialisation
-            t0 = time.time(); TP.port_sample_rmhmc(lp, init, 1, 1, self.eps, self.omega, self.alpha, jitter=self.jitter); dt1 = time.time() - t0
-        n = max(1, int(seconds / 3 / (dt1 * self.L)))
-
-        def once():
-            t0 = time.time()
-            _, acc = TP.port_sample_rmhmc(lp, init, n, self.L, self.eps, self.omega, self.alpha, burn=-1, jitter=self.jitter)
-            dt = time.time() - t0
-            return {"value": n * self.L / dt, "unit": "leapfrog-steps/s", "cores": 1, "kind": "port",
-                    "sample": "1 chain x %d trajectories x L=%d explicit steps, jitter=%g (oracle/torch_port.py: autograd "
-                              "through hessian+eigh per gradient, as the reference), %.1f s; median of 3" % (n, self.L, self.jitter, dt),
-                    "acceptance": acc}
-        out = _median3(once)
-        out["pinned_to"] = "tests/golden/cfg3.npz (test_torch_port_cfg3_with_jitter_matches_reference_run)"
-        return out
+        """Reference cost structure: every dH/dtheta, dH/dp is an autograd pass through hessian + eigh (S:395-422); one chain
+        per usable host core."""
+        return cpu_baseline_procs("cfg3", seconds)
 
 
 class Cfg5(Cfg3):
@@ -456,28 +459,8 @@ class Cfg4:
                 "note": "2M x 6 flop per (point, weight) per split step (SURVEY 8d) against the fp32 matrix peak"}
 
     def cpu_baseline(self, seconds):
-        """Reference cost structure: per-split closure + autograd gradient for every half kick (S:499-540)."""
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import torch_port as TP
-        torch.set_num_threads(1)
-        torch.manual_seed(0)
-        net = torch.nn.Sequential(torch.nn.Linear(8, 100), torch.nn.ReLU(), torch.nn.Linear(100, 1))
-        X, Y = self.X.cpu(), self.Y.cpu().reshape(-1, 1)
-        fl = [TP.port_mlp_closure(net, X[m * 100:(m + 1) * 100], Y[m * 100:(m + 1) * 100], torch.ones(4), 100.0, 4)
-              for m in range(4)]
-        init = self.theta0[0].cpu()
-        im = torch.ones(self.D)
-        t0 = time.time(); TP.port_sample_split(fl, init, 2, self.L, self.eps, -1, im); dt2 = time.time() - t0
-        n = max(2, int(seconds / 3 / (dt2 / 2)))
-
-        def once():
-            t0 = time.time(); _, acc = TP.port_sample_split(fl, init, n, self.L, self.eps, -1, im); dt = time.time() - t0
-            return {"value": n * self.L / dt, "unit": "leapfrog-steps/s", "cores": 1, "kind": "port",
-                    "sample": "1 chain x %d trajectories x L=%d split steps (oracle/torch_port.py: functional model + "
-                              "autograd per half kick, as the reference), %.1f s; median of 3" % (n, self.L, dt), "acceptance": acc}
-        out = _median3(once)
-        out["pinned_to"] = "tests/golden/cfg4.npz (test_torch_port_cfg4_full_size_matches_reference_run)"
-        return out
+        """Reference cost structure: per-split closure + autograd gradient for every half kick (S:499-540); one chain per core."""
+        return cpu_baseline_procs("cfg4", seconds)
 
 
 class NbMlp:
@@ -574,33 +557,8 @@ class NbMlp:
                 "frac_by_reference_flops": self.reference_flops_per_unit() * self.units_per_step() / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
 
     def cpu_baseline(self, seconds):
-        """Reference cost structure: functional model + autograd per half kick (S:499-540) on the notebook's module."""
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import torch_port as TP
-        torch.set_num_threads(1)
-        torch.manual_seed(0)
-        net = TP.notebook_net()
-        X, Y = self.X.cpu(), self.Y.cpu().reshape(-1, 1)
-        tl = torch.ones(6)
-        if self.M > 1:
-            fl = [TP.port_mlp_closure(net, X[m * self.Nb:(m + 1) * self.Nb], Y[m * self.Nb:(m + 1) * self.Nb], tl, self.tau_out, self.M)
-                  for m in range(self.M)]
-            run = lambda n: TP.port_sample_split(fl, self.theta0[0].cpu(), n, self.L, self.eps, -1, torch.ones(self.D))      # noqa: E731
-        else:
-            f = TP.port_mlp_closure(net, X, Y, tl, self.tau_out, 1.0)
-            run = lambda n: TP.port_sample(f, self.theta0[0].cpu(), n, self.L, self.eps, -1, torch.ones(self.D))             # noqa: E731
-        t0 = time.time(); run(1); dt1 = time.time() - t0
-        n = max(1, int(seconds / 3 / dt1))
-
-        def once():
-            t0 = time.time(); _, acc = run(n); dt = time.time() - t0
-            return {"value": n * self.L / dt, "unit": "leapfrog-steps/s", "cores": 1, "kind": "port", "samples_per_s": n / dt,
-                    "sample": "1 chain x %d trajectories x L=%d %s steps (oracle/torch_port.py: functional model + autograd per "
-                              "half kick, as the reference), %.1f s; median of 3" % (n, self.L, "split" if self.M > 1 else "leapfrog", dt),
-                    "acceptance": acc}
-        out = _median3(once)
-        out["pinned_to"] = "tests/golden/nbmlp.npz (test_torch_port_nbmlp_matches_reference_run)"
-        return out
+        """Reference cost structure: functional model + autograd per half kick (S:499-540) on the notebook's module; one chain per core."""
+        return cpu_baseline_procs(self.key, seconds)
 
 
 class NbMlpFull(NbMlp):
@@ -617,7 +575,159 @@ class NbMlpFull(NbMlp):
         return self.flops_per_unit()
 
 
-WORKLOADS = {"nbmlp": NbMlp, "nbmlp-full": NbMlpFull, "cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4, "cfg5": Cfg5, "cfg3@1024": Cfg3N}
+
+def funnel_ll_device(w):
+    """The funnel of notebooks/hamiltorch_log_prob_examples.ipynb cell 22 (v = w[0] ~ N(0, 3^2), x = w[1:] ~ N(0, exp(-v))) written
+    with device-side arithmetic only - the form a HIP graph can replay (examples/funnel.py).  An OPAQUE closure for the library:
+    models.probe_gaussian rejects it, every evaluation goes through the callback contract (S:272-274)."""
+    v, x = w[0], w[1:]
+    hl2p = 0.9189385332046727
+    ll_v = -v * v / 18.0 - 1.0986122886681098 - hl2p
+    ll_x = -0.5 * torch.exp(v) * (x * x).sum() + 0.5 * x.numel() * v - x.numel() * hl2p
+    return ll_v + ll_x
+
+
+def funnel_ll_notebook(w, dim=10):
+    """Cell 22 verbatim (torch.distributions with host scalars: not capturable, evaluated eagerly under vmap)."""
+    v_dist = torch.distributions.Normal(0, 3)
+    ll = v_dist.log_prob(w[0])
+    x_dist = torch.distributions.Normal(0, torch.exp(-w[0]) ** 0.5)
+    ll += x_dist.log_prob(w[1:]).sum()
+    return ll
+
+
+class FunnelHMC:
+    """The callback contract on the driver's line: the reference's published 11-D funnel run
+    (notebook cell 24: HMC, eps = 0.2, L = 25: 56.10 samples/s, one chain) at 1024 chains through hamiltorch_amd.sample() with
+    an opaque closure - torch evaluates the callback for all chains (vmap(grad_and_value)), the kicks / drifts / energies /
+    Metropolis step are the HIP pieces kernels, a whole trajectory is replayed as one captured HIP graph."""
+    key = "funnel-hmc"
+    name = "funnel-hmc: 11-D funnel (notebook cell 22-24), HMC eps=0.2 L=25, opaque log_prob_func closure -> generic path"
+    D, L, eps, chains, traj = 11, 25, 0.2, 1024, 50
+    dtype_name = "f32"
+    published = {"samples_per_s": 56.10, "hw": "notebook host, 1 chain", "src": "log_prob_examples nb cell 24 (JSON lines 401-402)"}
+    sampler_kw = {}
+
+    def __init__(self, dev, chains, traj, chain_offset, seed=1):
+        from hamiltorch_amd import _abi
+        self.abi = _abi
+        self.C, self.T = chains or self.chains, traj or self.traj
+        self.off, self.seed, self.dev = chain_offset, seed, dev
+        self.theta0 = torch.ones(self.C, self.D, device=dev)
+        self.theta0[:, 0] = 0.0
+        self.rej = torch.zeros(self.C, dtype=torch.int32, device=dev)
+        self.samples = None
+        self._acc = []
+        self.fn = funnel_ll_device
+
+    def units_per_step(self):
+        return self.C * self.T * self.L
+
+    def bytes_per_unit(self):
+        return 16 * self.D
+
+    def _sample(self, fn, k, T):
+        import hamiltorch_amd as ht
+        return ht.sample(fn, self.theta0, num_samples=T, num_steps_per_sample=self.L, step_size=self.eps, burn=-1, debug=2,
+                         verbose=False, seed=self.seed + k, chain_offset=self.off, **self.sampler_kw)
+
+    def step(self, k):
+        from hamiltorch_amd.samplelist import as_tensor
+        out, acc = self._sample(self.fn, k, self.T)
+        self.samples = as_tensor(out)
+        self._acc.append(acc)
+
+    def check(self):
+        assert self.samples is not None and self.samples.shape[1:] == (self.C, self.D)
+        fin = torch.isfinite(self.samples).all(dim=(0, 2))
+        assert float(fin.float().mean()) > 0.99
+        return float(torch.stack([a.float().mean() if torch.is_tensor(a) else torch.tensor(float(a)) for a in self._acc[-3:]]).mean())
+
+    def _rate(self, fn, T, reps=2, env=None):
+        old = {}
+        for kk, vv in (env or {}).items():
+            old[kk] = os.environ.get(kk); os.environ[kk] = vv
+        try:
+            self._sample(fn, 100, T)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for r in range(reps):
+                self._sample(fn, 101 + r, T)
+            torch.cuda.synchronize()
+            return self.C * T * self.L * reps / (time.perf_counter() - t0)
+        finally:
+            for kk, vv in old.items():
+                if vv is None:
+                    os.environ.pop(kk, None)
+                else:
+                    os.environ[kk] = vv
+
+    def _launches(self):
+        """Device launches of one sample() call (torch.profiler, one untimed call); None if the profiler is unavailable."""
+        try:
+            from torch.profiler import profile, ProfilerActivity
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                self._sample(self.fn, 200, self.T)
+                torch.cuda.synchronize()
+            return sum(e.count for e in prof.key_averages() if getattr(e, "device_type", None) is not None and "cuda" in str(e.device_type).lower())
+        except Exception:
+            return None
+
+    def extras(self):
+        """Graph replay on / off and the notebook's verbatim closure, each on a shorter run (not part of `value`)."""
+        from hamiltorch_amd import util
+        T = max(4, self.T // 5)
+        out = {"graph_replay": not any("trajectory" in g_ for g_ in util.graph_log[-8:]),
+               "value_graphs_off": self._rate(self.fn, T, env={"HAMILTORCH_AMD_GRAPHS": "0"}),
+               "value_notebook_closure": self._rate(funnel_ll_notebook, T),
+               "launches_per_step": self._launches(),
+               "callback_evaluations_per_step": self.T * (self.L + 1)}
+        return out
+
+    def roofline(self, kernel_ms, call_ms, prof_n, steps):
+        gbs = self.units_per_step() * self.bytes_per_unit() / (call_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "torch callback (vmap grad_and_value) + hmc_pieces kernels, one HIP graph per trajectory",
+                "kernel_ms_per_step": call_ms, "call_ms": call_ms, "launches_per_step": None,
+                "note": "SURVEY 8(d) byte model (16 D bytes per chain-step) over the whole call; the path is launch / latency bound "
+                        "at this size (D = 11): the fraction is reported, not claimed"}
+
+    def cpu_baseline(self, seconds):
+        return cpu_baseline_procs(self.key, seconds)
+
+
+class FunnelRMHMC(FunnelHMC):
+    """SURVEY 8(f) N1 on the driver's line: explicit RMHMC with the soft-abs metric on the same funnel (notebook cell 30:
+    eps = 0.14, L = 25, omega = 10, jitter = 1e-3; the reference's progress bar shows < 1 sample/s and its run ends in NaN
+    after 14 samples) at 256 chains: per-chain Hessians by torch.func, hta_metric_eval with dmetric_out on the matrix cores."""
+    key = "funnel-rmhmc"
+    name = "funnel-rmhmc: 11-D funnel, explicit RMHMC softabs alpha=1e6 omega=10 eps=0.14 L=25 jitter=1e-3, opaque closure"
+    D, L, eps, chains, traj = 11, 25, 0.14, 256, 2
+    published = {"samples_per_s": 0.19, "hw": "notebook host, 1 chain", "src": "log_prob_examples nb cell 30 (JSON lines 637-638)"}
+
+    def __init__(self, dev, chains, traj, chain_offset, seed=1):
+        super().__init__(dev, chains, traj, chain_offset, seed)
+        import hamiltorch_amd as ht
+        self.sampler_kw = dict(sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT, metric=ht.Metric.SOFTABS, softabs_const=1e6,
+                               explicit_binding_const=10.0, jitter=1e-3)
+
+    def extras(self):
+        T = self.T
+        return {"value_graphs_off": self._rate(self.fn, T, reps=1, env={"HAMILTORCH_AMD_GRAPHS": "0"}),
+                "metric_evaluations_per_step": self.T * (8 * self.L + 3), "launches_per_step": None}
+
+    def roofline(self, kernel_ms, call_ms, prof_n, steps):
+        # SURVEY 8(d)'s count at D = 11: 8 metric evaluations per step (the reference-faithful count: dH/dtheta depends on the metric
+        # here) x 11.3 D^3 + the third-derivative contraction D^4 per kick
+        flops = 8 * 11.3 * self.D ** 3 + 4 * 2 * self.D ** 4
+        tf = flops * self.units_per_step() / (call_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "traffic": None,
+                "kernel": "torch.func hessian / jacobian callbacks + metric_warm_mfma_kernel (per-chain bases)",
+                "kernel_ms_per_step": call_ms, "call_ms": call_ms, "launches_per_step": None,
+                "note": "launch bound: D = 11 systems on kernels sized for D = 100; the fraction is reported, not claimed"}
+
+
+WORKLOADS = {"funnel-hmc": FunnelHMC, "funnel-rmhmc": FunnelRMHMC, "nbmlp": NbMlp, "nbmlp-full": NbMlpFull, "cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4, "cfg5": Cfg5, "cfg3@1024": Cfg3N}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -806,6 +916,11 @@ def compact_line(full, detail_path="bench_detail.json"):
             e["issued_over_useful"] = roof["mfma_issued_over_useful"]
         if r.get("api_ms_per_step") is not None:
             e["api_ms"] = _r(r["api_ms_per_step"], 4)
+        for k in ("gather_ms", "n_gpus", "ranks_seen"):
+            if r.get(k) is not None:
+                e[k] = _r(r[k], 4)
+        if r.get("extras"):
+            e["extras"] = {k: _r(v, 4) for k, v in r["extras"].items() if not isinstance(v, (dict, list))}
         if r.get("published"):
             e["samples_per_s"] = _r(r.get("samples_per_s"), 4)
             e["published"] = {"samples_per_s": r["published"].get("samples_per_s"), "hw": str(r["published"].get("hw", ""))[:24]}
@@ -926,6 +1041,28 @@ def main():
             assert gathered.shape[1] == w.C * world
         del gathered
 
+    # --gpus N > 1 (the driver's scaling runs): the SECOND north-star target on every rank as well - D = 100 explicit RMHMC at
+    # 1024 chains per GPU (cfg5) - and the path's only collective, the gather of its samples to rank 0 (after the timed region)
+    res5 = None
+    if world > 1 and a.workload == "cfg2" and not a.no_secondary and a.chains is None and a.traj is None:
+        del w
+        torch.cuda.empty_cache()
+        w5 = Cfg5(dev, None, None, chain_offset=rank * Cfg5.chains)
+        m5 = measure(w5, 10, 2, world, dist, dev, 1)
+        res5 = result_of(w5, Cfg5, *m5, 10, 2, world)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter()
+        gathered = w5.gather(world)
+        torch.cuda.synchronize()
+        dist.barrier()
+        res5["gather_ms"] = (time.perf_counter() - tg) * 1e3
+        res5["n_gpus"], res5["ranks_seen"] = world, ranks_seen
+        if rank == 0:
+            assert gathered.shape[1] == w5.C * world
+        del gathered
+        w = w5
+
     if rank == 0:
         out = {"key": res["key"], "metric": METRIC, "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -955,6 +1092,8 @@ def main():
                 out["speedup_vs_cpu_baseline_1core"] = res["value"] / (cb["value"] / max(1, cb.get("cores", 1)))
                 if cb.get("ess_per_sec"):                                              # the metric's second half: ESS/sec vs the CPU reference
                     out["ess_per_sec_vs_cpu_baseline"] = res["ess_per_sec"] / cb["ess_per_sec"]
+        if res5 is not None:
+            out["secondary"] = [res5]
         if world == 1 and a.workload == "cfg2" and not a.no_secondary and a.chains is None and a.traj is None:
             del w
             torch.cuda.empty_cache()
@@ -982,8 +1121,8 @@ def secondary(dev, a):
     (1024 chains), config 3 (256 chains) on the default route and on the eigendecomposition route SURVEY 8(d)'s flop
     count describes, config 4 (512 chains)."""
     out = []
-    plan = [(Cfg3N, {}, 4, 1, True), (Cfg3, {}, 3, 1, True), (Cfg3, {"jacobi": True, "traj": 20}, 2, 1, False), (Cfg4, {}, 10, 2, True),
-            (NbMlp, {}, 3, 1, True), (NbMlpFull, {}, 3, 1, True)]
+    plan = [(Cfg3N, {}, 10, 2, True), (Cfg3, {}, 10, 2, True), (Cfg3, {"jacobi": True, "traj": 20}, 10, 1, False), (Cfg4, {}, 10, 2, True),
+            (NbMlp, {}, 10, 1, True), (NbMlpFull, {}, 10, 1, True), (FunnelHMC, {}, 10, 2, True), (FunnelRMHMC, {}, 3, 1, True)]
     cpu_cache = {}
     for W, kw, steps, warmup, want_cpu in plan:
         try:
@@ -1004,6 +1143,13 @@ def secondary(dev, a):
             if getattr(W, "published", None):
                 r["published"] = W.published
                 r["samples_per_s"] = r["value"] / W.L
+            if hasattr(w, "extras"):
+                try:
+                    r["extras"] = w.extras()
+                    if r["extras"].get("launches_per_step") is not None:
+                        r["roofline"]["launches_per_step"] = r["extras"]["launches_per_step"]
+                except Exception as e:
+                    r["extras"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
             if hasattr(w, "api_call") and not a.no_api and not getattr(w, "jacobi", False):
                 try:        # the same steps through the public API (sample / sample_split_model / sample_model)
                     r["api_ms_per_step"], r["api_sync_ms"] = api_timing(w, steps, warmup, reps=3)

@@ -896,6 +896,28 @@ def gen_cfg3():
     np.savez_compressed(os.path.join(OUT, "cfg3.npz"), **out)
 
 
+def gen_funnel_hmc():
+    """The reference's published funnel run (notebooks/hamiltorch_log_prob_examples.ipynb cells 22-24: the verbatim
+    funnel_ll closure, HMC, eps = 0.2, L = 25, params_init = (0, 1, ..., 1)): 30 trajectories end to end with the draws
+    recorded, and an explicit-RMHMC run of cell 30's settings (eps = 0.14, L = 25, omega = 10, soft-abs 1e6, jitter 1e-3:
+    2 trajectories) - what bench.py's funnel-hmc / funnel-rmhmc cpu_baseline legs run (oracle/cpu_baseline.py)."""
+    from cpu_baseline import funnel_ll
+    out = {}
+    init = torch.ones(11); init[0] = 0.0
+    hamiltorch.set_random_seed(123)
+    with Recorder() as rec:
+        ret, acc = hamiltorch.sample(funnel_ll, init, num_samples=30, num_steps_per_sample=25, step_size=0.2, burn=0, debug=2, verbose=False)
+    out["hmc_samples"] = np.stack([npy(t) for t in ret]); out["hmc_acc"] = np.array(acc)
+    out["hmc_momenta"] = np.stack(rec.momenta); out["hmc_uniforms"] = np.concatenate(rec.uniforms)
+    hamiltorch.set_random_seed(123)
+    with Recorder() as rec:
+        ret, acc = hamiltorch.sample(funnel_ll, init, num_samples=2, num_steps_per_sample=25, step_size=0.14, burn=-1, jitter=1e-3,
+                                     softabs_const=1e6, explicit_binding_const=10.0, sampler=hamiltorch.Sampler.RMHMC,
+                                     integrator=hamiltorch.Integrator.EXPLICIT, metric=hamiltorch.Metric.SOFTABS, debug=2, verbose=False)
+    out["rm_samples"] = np.stack([npy(t) for t in ret]); out["rm_acc"] = np.array(acc)
+    np.savez_compressed(os.path.join(OUT, "funnel_hmc.npz"), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                      # python oracle/gen_golden.py funnel  -> only that family
         for name in sys.argv[1:]:
@@ -918,5 +940,6 @@ if __name__ == "__main__":
     gen_cfg3()
     gen_cfg4()
     gen_nbmlp()
+    gen_funnel_hmc()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

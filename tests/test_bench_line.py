@@ -106,3 +106,45 @@ def test_nonfinite_numbers_do_not_break_the_json():
     rec = json.loads(bench.compact_line(full))          # strict JSON: NaN / Infinity would not parse elsewhere
     assert "NaN" not in bench.compact_line(full) and "Infinity" not in bench.compact_line(full)
     assert rec["secondary"][0]["value"] is None
+
+
+def test_multi_gpu_line_carries_the_second_north_star_target_with_its_gather():
+    """under --gpus N > 1 the line's `secondary[0]` is cfg5 (D = 100 explicit RMHMC, 1024 chains per
+    GPU, measured on every rank) with gather_ms / n_gpus / ranks_seen - one scaling run yields both north-star curves."""
+    full = _full()
+    cfg5 = copy.deepcopy(full["secondary"][0])
+    cfg5.update({"key": "cfg5", "workload": "cfg5: cfg3 sharded, 1024 chains per GPU", "gather_ms": 3.4567, "n_gpus": 8, "ranks_seen": 8})
+    cfg5["config"]["chains_per_gpu"] = 1024
+    full.update({"n_gpus": 8, "ranks_seen": 8, "rank_devices": [[r, r] for r in range(8)], "collective_backend": "rccl",
+                 "launcher": "torch.distributed.run", "secondary": [cfg5]})
+    full.pop("cpu_baseline")
+    line = bench.compact_line(full)
+    assert len(line.encode()) < bench.LINE_LIMIT
+    rec = json.loads(line)
+    s5 = rec["secondary"][0]
+    assert s5["key"] == "cfg5" and s5["gather_ms"] == pytest.approx(3.457, rel=1e-3) and s5["n_gpus"] == 8 and s5["ranks_seen"] == 8
+    assert s5["chains"] == 1024 and s5["value"] > 0 and s5["frac"] > 0
+
+
+def test_funnel_entries_carry_their_extras_and_stay_inside_the_limit():
+    """The callback-contract entries (funnel-hmc / funnel-rmhmc): graph replay on / off, the notebook's closure, launches per
+    step and the published samples/s travel in the compact entry; with eight secondary workloads the line still fits."""
+    full = _full()
+    base = copy.deepcopy(full["secondary"][0])
+    while len(full["secondary"]) < 6:
+        e = copy.deepcopy(base); e["key"] = "w%d" % len(full["secondary"]); full["secondary"].append(e)
+    for key, pub in (("funnel-hmc", 56.10), ("funnel-rmhmc", 0.19)):
+        e = copy.deepcopy(base)
+        e.update({"key": key, "workload": key + ": 11-D funnel", "samples_per_s": 1234.5,
+                  "published": {"samples_per_s": pub, "hw": "notebook host, 1 chain", "src": "nb"},
+                  "extras": {"graph_replay": True, "value_graphs_off": 1.23456e6, "value_notebook_closure": 2.5e5, "launches_per_step": 1300,
+                             "callback_evaluations_per_step": 1300}})
+        full["secondary"].append(e)
+    line = bench.compact_line(full)
+    assert len(line.encode()) < bench.LINE_LIMIT
+    rec = json.loads(line)
+    keys = [s["key"] for s in rec["secondary"]]
+    assert "funnel-hmc" in keys and "funnel-rmhmc" in keys and not rec.get("secondary_truncated")
+    fh = rec["secondary"][keys.index("funnel-hmc")]
+    assert fh["extras"]["graph_replay"] is True and fh["extras"]["value_graphs_off"] == pytest.approx(1.235e6, rel=1e-3)
+    assert fh["published"]["samples_per_s"] == 56.10

@@ -234,11 +234,23 @@ def test_cfg3_statistical_parity_with_jitter(ht):
     assert _abi.last_route() == "rmhmc_uvc_kernel<co>"        # (round 4; before: rmhmc_uv_kernel<1,lean>)
     a = torch.stack(out).double().cpu().numpy()
     s = a[-keep:].reshape(-1, 100)
-    assert float(acc.mean()) > 0.97
+    # acceptance: SURVEY 8c asks +-0.01 of the reference / oracle on >= 1e5 pooled trajectories.  Device: 256 x 600 = 153 600
+    # trajectories.  Oracle side: the eigendecomposing restatement from the same stationary starts and Philox streams on 24
+    # chains x 4 trajectories (all it can afford: 8 L + 3 eigendecompositions of a 100 x 100 matrix per trajectory and chain);
+    # the reference itself accepts every proposal at this configuration (acc 1.0)
+    sel = np.linspace(0, C - 1, 24).astype(int)
+    _, info = O.sample_rmhmc_explicit(o, th0.cpu().numpy()[sel], 4, 10, 0.1, 10.0, 1e6, -1, 1e-3, O.PhiloxDraws(7, sel, np.float32),
+                                      "softabs", momentum="split")
+    assert abs(float(acc.mean()) - float(np.mean(info["acc_rate"]))) <= 0.01, (float(acc.mean()), float(np.mean(info["acc_rate"])))
     var = s.var(axis=0)
     np.testing.assert_allclose(var, np.diag(cov), rtol=0.05)
-    sd_mean = np.sqrt(np.diag(cov) / (keep * C) * 4.0)                    # 4 ~ (1 + rho) / (1 - rho) at rho ~ 0.6
-    assert (np.abs(s.mean(axis=0)) <= 4.5 * sd_mean).all()                # |mean| <= 4 sd / sqrt(ESS) per dimension
+    # means: SURVEY 8c's |mean| <= 4 sd / sqrt(ESS_pooled) per dimension with the ESS COMPUTED (hamiltorch_amd.ess: FFT
+    # autocorrelation + Geyer truncation, pooled over the 256 chains), not assumed
+    from hamiltorch_amd.ess import ess_bulk
+    kept = torch.tensor(a[-keep:])
+    ess = np.array([ess_bulk(kept[:, :, d]) for d in range(100)])
+    assert ess.min() > 0.05 * keep * C, ess.min()                         # (antithetic-looking chains may exceed S C; a collapse may not)
+    assert (np.abs(s.mean(axis=0)) <= 4.0 * np.sqrt(np.diag(cov) / ess)).all(), (np.abs(s.mean(axis=0)) / np.sqrt(np.diag(cov) / ess)).max()
     # off-diagonal structure too: the pooled covariance matches P^-1 in the operator norm
     emp = np.cov(s.T)
     assert np.linalg.norm(emp - cov, 2) <= 0.08 * np.linalg.norm(cov, 2)

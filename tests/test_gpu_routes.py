@@ -237,6 +237,11 @@ def test_drivers_eight_rank_command_line_prints_the_compact_line(ht, extra):
         assert j["gather_ms"] > 0 and j["config"]["workload"] == "cfg5"
     else:
         assert j["config"]["workload"] == "cfg2" and "gather_ms" not in j
+        # round 4: the default multi-GPU line also carries the SECOND north-star target - D = 100 explicit RMHMC
+        # at 1024 chains per GPU on every rank - with the gather, so one scaling run yields both curves
+        s5 = j["secondary"][0]
+        assert s5["key"] == "cfg5" and s5["n_gpus"] == 8 and s5["ranks_seen"] == 8 and s5["gather_ms"] > 0 and s5["value"] > 0
+        assert s5["chains"] == 1024 and s5["kernel"].startswith("rmhmc_uvc2_kernel")
 
 
 _SHARD_WORKER = r'''

@@ -709,3 +709,53 @@ def test_split_momentum_draw_has_the_reference_covariance():
     emp = p.T @ p / n
     se = np.sqrt((np.outer(np.diag(G[0]), np.diag(G[0])) + G[0] ** 2) / n)
     assert (np.abs(emp - G[0]) < 4.5 * se).all()
+
+
+def test_torch_port_funnel_hmc_matches_reference_run(golden):
+    """bench.py's funnel-hmc / funnel-rmhmc cpu_baseline legs (oracle/cpu_baseline.py, `kind: "port"` on a box without the
+    reference): the port on the notebook's verbatim funnel_ll closure reproduces the unmodified reference's runs
+    (tests/golden/funnel_hmc.npz: cell 24's HMC settings bit for bit from the same torch seed - hamiltorch.set_random_seed
+    seeds torch like torch.manual_seed; cell 30's explicit-RMHMC settings to rounding of eigh's backward)."""
+    import random
+    import torch
+    import torch_port as TP
+    from cpu_baseline import funnel_ll
+    g = golden("funnel_hmc")
+    init = torch.ones(11); init[0] = 0.0
+
+    def seed(v):                                             # hamiltorch.util.set_random_seed (U:11-20) without the package
+        random.seed(v); np.random.seed(v); torch.manual_seed(v)
+    seed(123)
+    ret, acc = TP.port_sample(funnel_ll, init, 30, 25, 0.2, 0, None)
+    got = np.stack([t.numpy() for t in ret])
+    assert got.shape == g["hmc_samples"].shape and np.array_equal(got, g["hmc_samples"])
+    assert acc == float(g["hmc_acc"])
+    seed(123)
+    ret, acc = TP.port_sample_rmhmc(funnel_ll, init, 2, 25, 0.14, 10.0, 1e6, burn=-1, jitter=1e-3)
+    got = np.stack([t.numpy() for t in ret])
+    assert got.shape == g["rm_samples"].shape
+    np.testing.assert_allclose(got, g["rm_samples"], rtol=0, atol=5e-4)
+    assert acc == float(g["rm_acc"])
+
+
+def test_cpu_baseline_worker_runs_the_reference_when_it_is_there_and_the_port_otherwise():
+    """oracle/cpu_baseline.py (one process of bench.py's cpu_baseline leg): `kind: "reference"` = the unmodified package from
+    HAMILTORCH_REFERENCE / /root/reference (only in the build container), `kind: "port"` = oracle/torch_port.py; both give one
+    JSON line with n / L / dt / acc, and agree on the cost (same work per trajectory: within 2x of each other)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "cpu_baseline.py")
+    rates = {}
+    for mode in ("port", ""):
+        env = dict(os.environ, HTA_CPU_BASELINE=mode, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", PYTHONDONTWRITEBYTECODE="1")
+        out = subprocess.run([sys.executable, script, "funnel-hmc", "5", "1.0"], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+        assert r["L"] == 25 and r["n"] >= 1 and r["dt"] > 0 and 0.0 <= r["acc"] <= 1.0 and len(r["samples"]) == r["n"]
+        rates[r["kind"]] = r["n"] * r["L"] / r["dt"]
+        if mode == "port":
+            assert r["kind"] == "port"
+    if os.path.isdir("/root/reference/hamiltorch"):
+        assert set(rates) == {"port", "reference"} and 0.5 < rates["port"] / rates["reference"] < 2.0, rates
