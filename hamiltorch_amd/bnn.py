@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from . import util  # noqa: F401
 from .enums import Integrator, Metric, Sampler
+from .host import host_inputs
 
 _ACTS = {nn.ReLU: "relu", nn.Tanh: "tanh", nn.Sigmoid: "sigmoid"}
 
@@ -248,6 +249,7 @@ def _shapes_and_tau(model, tau_list):
     return shapes, sizes, tau_list
 
 
+@host_inputs
 def sample_model(model, x, y, params_init, model_loss='multi_class_linear_output', num_samples=10,
                  num_steps_per_sample=10, step_size=0.1, burn=0, inv_mass=None, jitter=None, normalizing_const=1.,
                  softabs_const=None, explicit_binding_const=100, fixed_point_threshold=1e-5,
@@ -268,6 +270,7 @@ def sample_model(model, x, y, params_init, model_loss='multi_class_linear_output
                     desired_accept_rate=desired_accept_rate, store_on_GPU=store_on_GPU, verbose=verbose, **ext)
 
 
+@host_inputs
 def sample_split_model(model, train_loader, params_init, num_splits, model_loss='multi_class_linear_output',
                        num_samples=10, num_steps_per_sample=10, step_size=0.1, burn=0, inv_mass=None, jitter=None,
                        normalizing_const=1., softabs_const=None, explicit_binding_const=100,

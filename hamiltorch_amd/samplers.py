@@ -27,6 +27,7 @@ from . import _abi, util
 from .enums import Integrator, Metric, Sampler
 from .models import GaussianTarget, as_gaussian, probe_gaussian, verify_gaussian, MAX_NATIVE_DIM
 from .samplelist import rows_of
+from .host import host_inputs
 
 _sample_lock = threading.RLock()  # multi_chain(parallel=True) calls sample() from threads (U:396-398)
 
@@ -183,6 +184,7 @@ def acceptance(h_old, h_new):
     return float(-h_new + h_old)
 
 
+@host_inputs
 def gibbs(params, sampler=Sampler.HMC, log_prob_func=None, jitter=None, normalizing_const=1., softabs_const=None,
           mass=None, metric=Metric.HESSIAN, seed=None, chain_offset=0, draw=0):
     """Momentum resampling (S:152-202) on-device.  ``mass`` is None | (D,) | (D,D) | list of blocks.
@@ -207,6 +209,7 @@ def gibbs(params, sampler=Sampler.HMC, log_prob_func=None, jitter=None, normaliz
     return p[0] if one else p
 
 
+@host_inputs
 def hamiltonian(params, momentum, log_prob_func, jitter=0.01, normalizing_const=1., softabs_const=1e6,
                 explicit_binding_const=100, inv_mass=None, ham_func=None, sampler=Sampler.HMC,
                 integrator=Integrator.EXPLICIT, metric=Metric.HESSIAN):
@@ -236,6 +239,7 @@ def hamiltonian(params, momentum, log_prob_func, jitter=0.01, normalizing_const=
     raise NotImplementedError()
 
 
+@host_inputs
 def rm_hamiltonian(params, momentum, log_prob_func, jitter, normalizing_const, softabs_const=1e6,
                    sampler=Sampler.HMC, integrator=Integrator.EXPLICIT, metric=Metric.HESSIAN):
     """S:677-736: -log p + D/2 log 2pi + 1/2 log|G| + 1/2 p^T G^-1 p, shape (1,1) for one chain."""
@@ -243,12 +247,14 @@ def rm_hamiltonian(params, momentum, log_prob_func, jitter, normalizing_const, s
     return rmhmc.rm_hamiltonian(params, momentum, log_prob_func, jitter, softabs_const, metric)
 
 
+@host_inputs
 def fisher(params, log_prob_func=None, jitter=None, normalizing_const=1., softabs_const=1e6, metric=Metric.HESSIAN):
     """S:69-127: metric G(theta) and (for SOFTABS) the soft-absolute eigenvalues."""
     from . import rmhmc
     return rmhmc.fisher(params, log_prob_func, jitter, softabs_const, metric)
 
 
+@host_inputs
 def cholesky_inverse(fish, momentum):
     """S:130-149: G^-1 p by Cholesky + two triangular solves; returns (D,1) for one system."""
     from . import rmhmc
@@ -258,6 +264,7 @@ def cholesky_inverse(fish, momentum):
 # =================================================================================================
 # leapfrog (S:205-606)
 # =================================================================================================
+@host_inputs
 def leapfrog(params, momentum, log_prob_func, steps=10, step_size=0.1, jitter=0.01, normalizing_const=1.,
              softabs_const=1e6, explicit_binding_const=100, fixed_point_threshold=1e-20,
              fixed_point_max_iterations=6, jitter_max_tries=10, inv_mass=None, ham_func=None, sampler=Sampler.HMC,
@@ -367,6 +374,7 @@ def _split_step(theta, p, cbs, eps, kind, im, integrator=Integrator.SPLITTING, p
 # =================================================================================================
 # sample (S:850-1091)
 # =================================================================================================
+@host_inputs
 def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, step_size=0.1, burn=0, jitter=None,
            inv_mass=None, normalizing_const=1., softabs_const=None, explicit_binding_const=100,
            fixed_point_threshold=1e-5, fixed_point_max_iterations=1000, jitter_max_tries=10, sampler=Sampler.HMC,
