@@ -21,14 +21,21 @@
 
 namespace hta {
 
-template <typename T, int MAXB, int MAXV>
-__global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int ne, int lda, int ldv, int v0_lds) {
+// VG (round 4): the eigenvector matrix VT lives in a per-workgroup slab of GLOBAL memory (L2-resident: 80 KB at D = 100 fp64)
+// instead of LDS - the instance for the sizes whose A + VT exceed the 160 KiB of a CU (fp64 from D = 100, fp32 from D = 141,
+// up to the per-thread work lists' D ~ 110 / 156).  Same code, same barriers (a workgroup's waves share one CU: a barrier
+// orders its global accesses as it orders its LDS accesses); every round pays L2 latency instead of LDS latency - the slow
+// answer the reference also has there (S:108-122 has no size limit), not an error.
+template <typename T, int MAXB, int MAXV, bool VG = false>
+__global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int ne, int lda, int ldv, int v0_lds, T* vws) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = a.D, tid = threadIdx.x;
   // LDS layout (16-byte aligned regions first): VT | [V0 copy] | (c,s) pairs | A | 4 vectors | reduction | pair table
   const int cs_len = (ne + 3) & ~3;
-  T* V = reinterpret_cast<T*>(smem_raw);                 // VT[D][ldv], row k = eigenvector k
-  T* V0s = V + D * ldv;
+  T* V;                                                  // VT[D][ldv], row k = eigenvector k
+  T* V0s;
+  if constexpr (VG) { V = vws + (int64_t)blockIdx.x * D * ldv; V0s = reinterpret_cast<T*>(smem_raw); }
+  else { V = reinterpret_cast<T*>(smem_raw); V0s = V + D * ldv; }
   T* cs = V0s + (v0_lds ? D * ldv : 0);
   T* A = cs + cs_len;
   T* vec0 = A + ne * lda;         // lam~ (ne)
@@ -338,10 +345,19 @@ template <typename T> int metric_eval(const MetricArgsT<T>& a, hipStream_t s) {
   const bool warm = a.metric == 1 && a.V0 && a.lam0 && a.hs_stride == 0;
   int v0_lds = 0;
   if (warm && lds + (size_t)D * ldv * sizeof(T) <= 160 * 1024) { v0_lds = 1; lds += (size_t)D * ldv * sizeof(T); }
-  HTA_REQUIRE(lds <= 160 * 1024, "hta_metric_eval: D=%d does not fit the 160 KiB LDS of a CU for this dtype (max ~140 fp32 / ~99 fp64)", D);
+  // beyond one CU's LDS: the eigenvector matrix moves to a global-memory slab per workgroup (metric_eval_kernel<.., VG = true>)
+  bool vglobal = false;
+  if (lds > 160 * 1024) {
+    lda = ne + 1;
+    if (bytes(lda, 0) > 160 * 1024) lda = ne;
+    lds = bytes(lda, 0);
+    vglobal = true;
+  }
+  HTA_REQUIRE(lds <= 160 * 1024, "hta_metric_eval: D=%d does not fit the 160 KiB LDS of a CU for this dtype even with the eigenvectors "
+              "in global memory (max ~156 fp32 / ~110 fp64)", D);
   MetricArgsT<T> k = a;
   if (k.max_sweeps <= 0) k.max_sweeps = sizeof(T) == 4 ? 16 : 24;
-  const int grid = (int)(a.B < 65536 ? a.B : 65536);
+  const int grid = (int)(a.B < (vglobal ? 512 : 65536) ? a.B : (vglobal ? 512 : 65536));
   // per-thread work-list lengths of the Jacobi rounds (register arrays): 2/2 up to D ~ 126, 4/3 beyond
   const int NP = ne / 2, nv = ldv / vn;
   const bool small = NP * (NP + 1) / 2 <= 2 * MT && NP * nv <= 2 * MT;
@@ -352,14 +368,21 @@ template <typename T> int metric_eval(const MetricArgsT<T>& a, hipStream_t s) {
       if (e != hipSuccess) { set_error("hta_metric_eval: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
       done = true;
     }
+    T* vws = nullptr;
+    if (vglobal) {                                   // stream-ordered scratch: nothing persists, nothing synchronises
+      hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&vws), (size_t)grid * D * ldv * sizeof(T), s);
+      if (e != hipSuccess) { set_error("hta_metric_eval: hipMallocAsync of the eigenvector slabs: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
+    }
     profile_begin(s);
-    note_route("metric_eval_kernel<%s>", sizeof(T) == 4 ? "float" : "double");
-    kern<<<grid, MT, lds, s>>>(k, ne, lda, ldv, v0_lds);
+    note_route("metric_eval_kernel<%s%s>", sizeof(T) == 4 ? "float" : "double", vglobal ? ",vglobal" : "");
+    kern<<<grid, MT, lds, s>>>(k, ne, lda, ldv, v0_lds, vws);
     profile_end(s);
+    if (vws) (void)hipFreeAsync(vws, s);
     return HTA_OK;
   };
-  static DevOnce done_small, done_big;   // per T instantiation
-  const int rc = small ? launch(&metric_eval_kernel<T, 2, 2>, done_small) : launch(&metric_eval_kernel<T, 4, 3>, done_big);
+  static DevOnce done_small, done_big, done_vg;   // per T instantiation
+  const int rc = vglobal ? launch(&metric_eval_kernel<T, 4, 3, true>, done_vg)
+                         : (small ? launch(&metric_eval_kernel<T, 2, 2>, done_small) : launch(&metric_eval_kernel<T, 4, 3>, done_big));
   if (rc) return rc;
   HTA_CHECK_LAUNCH("hta_metric_eval");
   return HTA_OK;
