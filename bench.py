@@ -560,8 +560,38 @@ class NbMlp:
         """Reference cost structure: functional model + autograd per half kick (S:499-540) on the notebook's module; one chain per core."""
         return cpu_baseline_procs(self.key, seconds)
 
+    def extras(self):
+        """SURVEY 8(f) N2, the step after sampling in every BNN notebook: predict_model over 1000 of the samples just drawn x the
+        400 points - natively (one hta_net_forward launch + batched log-probs) and on the torch path it replaces (vmap of the
+        closure); the reference loops over the samples (S:1530-1552)."""
+        import hamiltorch_amd as ht
+        from hamiltorch_amd import bnn
+        from hamiltorch_amd.samplelist import SampleList
+        S = 1000
+        rows = self.samples[1:].reshape(-1, self.D)[:S].contiguous()
+        kw = dict(x=self.X, y=self.Y.reshape(-1, 1), model_loss="regression", tau_out=self.tau_out, tau_list=torch.ones(6))
+
+        def timed(reps):
+            ht.predict_model(self.net, SampleList(rows), **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                pred, lps = ht.predict_model(self.net, SampleList(rows), **kw)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e3 / reps, bnn.predict_route["last"], tuple(pred.shape)
+        ms, route, shape = timed(5)
+        keep = bnn._native_forward_ok
+        bnn._native_forward_ok = lambda *a, **k: None
+        try:
+            ms_t, route_t, _ = timed(2)
+        finally:
+            bnn._native_forward_ok = keep
+        return {"predict_route": route, "predict_samples": S, "predict_ms": ms, "predict_ms_torch_path": ms_t,
+                "predict_samples_per_s": S / (ms * 1e-3)}
+
 
 class NbMlpFull(NbMlp):
+    extras = None
     """The same model under full HMC (sample_model, notebook cell 14: 13.47 samples/s): plain leapfrog, every gradient over all 400 points."""
     key = "nbmlp-full"
     name = "nbmlp-full: the same model, full HMC (plain leapfrog over all 400 points), eps=5e-4, L=30"
@@ -1143,7 +1173,7 @@ def secondary(dev, a):
             if getattr(W, "published", None):
                 r["published"] = W.published
                 r["samples_per_s"] = r["value"] / W.L
-            if hasattr(w, "extras"):
+            if callable(getattr(w, "extras", None)):
                 try:
                     r["extras"] = w.extras()
                     if r["extras"].get("launches_per_step") is not None:

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhamiltorch_amd.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 MASS_NONE, MASS_DIAG, MASS_FULL = 0, 1, 2
 
@@ -71,6 +71,7 @@ def _sig(scalar):
                                 c_int, c_int, c_u64, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
         "hta_netn_logp_grad": [c_vp, c_i64, c_int, ctypes.POINTER(c_int), c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                ctypes.POINTER(scalar), scalar, scalar, c_vp, c_vp, c_vp],
+        "hta_net_forward": [c_vp, c_i64, c_int, ctypes.POINTER(c_int), c_int, c_vp, c_int, c_vp, c_vp],
         "hta_rmhmc_gaussian_leapfrog": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_f64, c_int, c_f64, c_u64, c_u64,
                                         c_u32, c_i64, c_int, c_int, c_f64, c_f64, c_vp, c_vp, c_vp],
         "hta_rmhmc_binding_rotation": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f64, c_f64, c_vp],
@@ -481,6 +482,16 @@ def netn_hmc_sample(theta, theta_init, dims, act, X, Y, M, Nb, taus, tau_out, pr
                   _p(mass_factor, theta), int(integrator), int(L), float(eps), int(n_traj), int(traj_offset), int(burn),
                   int(seed), int(chain_offset), _p(samples, theta), _p(reject_count), _p(H_old, theta), _p(H_new, theta),
                   _p(accept), _stream(theta)), "hta_netn_hmc_sample")
+
+
+def net_forward(theta, dims, act, X, out):
+    """out[S, N, O] = f(x_p; theta_s) for every row of theta [S, D] (include/hamiltorch_amd.h: hta_net_forward)."""
+    require_device(theta, "samples")
+    S, N = theta.shape[0], X.shape[0]
+    cd = (c_int * len(dims))(*[int(v) for v in dims])
+    fn = getattr(load(), "hta_net_forward_" + _suffix(theta))
+    with torch.cuda.device(theta.device):
+        _check(fn(_p(theta), S, len(dims) - 1, cd, ACTS[act], _p(X, theta), N, _p(out, theta), _stream(theta)), "hta_net_forward")
 
 
 def netn_logp_grad(theta, dims, act, X, Y, M, Nb, split, taus, tau_out, prior_scale, grad_out, logp_out, loss="regression"):

@@ -370,10 +370,94 @@ class _LoopInstead(Exception):
     """internal: the batched evaluation ran out of memory even one sample at a time under vmap"""
 
 
+#: how predict_model produced its last result: "native" (hta_net_forward + element-wise log-probs) or "torch" (vmap of the closure)
+predict_route = {"last": None, "native": 0, "torch": 0}
+_NATIVE_LOSSES = ("regression", "binary_class_linear_output", "multi_class_linear_output")
+
+
+def _stacked_samples(samples, dev):
+    """[S, D] tensor of a list of (D,) samples on `dev` (zero-copy for sample()'s lazy list), or None if the rows are not that."""
+    from .samplelist import SampleList
+    if isinstance(samples, SampleList) and not samples._done:
+        t = samples.tensor
+    else:
+        rows = list(samples)
+        if not rows or any((not torch.is_tensor(r)) or r.dim() != 1 or r.shape != rows[0].shape for r in rows):
+            return None
+        t = torch.stack([r.to(dev) for r in rows])
+    return t.to(dev).contiguous() if t.dim() == 2 else None
+
+
+def _native_forward_ok(model, stacked, x, model_loss):
+    st = _mlp_structure(model)
+    if st is None or len(st) != 2 or model_loss not in _NATIVE_LOSSES:
+        return None
+    dims, act = st
+    if stacked is None or not stacked.is_cuda or stacked.dtype not in (torch.float32, torch.float64):
+        return None
+    if x.dim() != 2 or x.shape[1] != dims[0] or stacked.shape[1] != sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(len(dims) - 1)):
+        return None
+    nl = len(dims) - 1
+    if not ((nl == 2 and dims[-1] <= 16) or (nl <= 8 and max(dims[:-1]) <= 256)):        # csrc/net_forward.hip
+        return None
+    return dims, act
+
+
+def _native_log_probs(stacked, out, y, sizes, tau_list, tau_out, model_loss, prior_scale):
+    """The closure's predict-mode value (S:1141-1199) for every sample from the network outputs `out` [S, N, O]: element-wise /
+    reduction kernels over the whole batch of samples.  Returns [S] or [S, O] (regression keeps one value per output, S:1184),
+    or None when `y` does not have the shape the closure's own arithmetic would treat element for element."""
+    S, N, O = out.shape
+    taus = [float(t) for t in tau_list]
+    prior = torch.zeros(S, dtype=out.dtype, device=out.device)
+    i0 = 0
+    for n, tau in zip(sizes, taus):
+        w = stacked[:, i0:i0 + n]
+        prior = prior + (-0.5 * tau * (w * w) + (0.5 * math.log(tau) - 0.9189385332046727)).sum(1)      # S:1143, S:1156
+        i0 += n
+    yd = y.to(device=out.device)
+    if model_loss == "regression":
+        if tuple(yd.shape) != (N, O):
+            return None
+        ll = -0.5 * tau_out * ((out - yd.to(out.dtype)) ** 2).sum(1)                                      # [S, O]  (S:1184)
+        return ll + (prior / prior_scale)[:, None]
+    if model_loss == "binary_class_linear_output":
+        if tuple(yd.shape) != (N, O):
+            return None
+        ll = -tau_out * nn.functional.binary_cross_entropy_with_logits(out, yd.to(out.dtype).expand(S, N, O), reduction="none").sum((1, 2))
+        return ll + prior / prior_scale
+    if yd.numel() != N:
+        return None
+    lab = yd.long().view(-1)
+    ll = -tau_out * nn.functional.cross_entropy(out.reshape(S * N, O), lab.repeat(S), reduction="none").view(S, N).sum(1)
+    return ll + prior / prior_scale
+
+
+def _predict_batch_native(model, stacked, x, y, sizes, tau_list, tau_out, model_loss, prior_scale):
+    ok = _native_forward_ok(model, stacked, x, model_loss)
+    if ok is None:
+        return None
+    from . import _abi
+    dims, act = ok
+    X = x.to(device=stacked.device, dtype=stacked.dtype).contiguous()
+    out = torch.empty(stacked.shape[0], X.shape[0], dims[-1], dtype=stacked.dtype, device=stacked.device)
+    lp = None
+    _abi.net_forward(stacked, dims, act, X, out)
+    lp = _native_log_probs(stacked, out, y, sizes, tau_list, tau_out, model_loss, prior_scale)
+    if lp is None:
+        return None
+    return lp, out
+
+
 def predict_model(model, samples, x=None, y=None, test_loader=None, model_loss='multi_class_linear_output',
                   tau_out=1., tau_list=None, verbose=False):
-    """S:1468-1562: evaluate every sample; returns (stack(pred)[S, N, O], list of log-probs).  All samples are evaluated in
-    one batched pass on the device (`_eval_all`)."""
+    """S:1468-1562: evaluate every sample; returns (stack(pred)[S, N, O], list of log-probs).
+
+    Recognised model families (Linear / activation chains: `_mlp_structure`; the losses with a native likelihood) run
+    NATIVELY: one forward-only launch over all S parameter rows (csrc/net_forward.hip: `hta_net_forward`) per batch of
+    points, log-probs by batched element-wise reductions on the device, one device-to-host copy for the loader form (the
+    reference moves every sample's value to the host, S:1536).  Anything else: the closure under `torch.func.vmap`
+    (`_eval_all`), chunked by measured memory, down to the reference's loop."""
     shapes, sizes, tau_list = _shapes_and_tau(model, tau_list)
     dev = samples[0].device
     with torch.no_grad():
@@ -387,21 +471,42 @@ def predict_model(model, samples, x=None, y=None, test_loader=None, model_loss='
             else:                                                                  # any other iterable of (x, y) batches
                 test_loader = list(test_loader)
                 num_batches = len(test_loader)
+            stacked = _stacked_samples(samples, dev) if dev.type == "cuda" else None
+            if stacked is not None:
+                parts, lp_sum = [], None
+                for batch_idx, (data, target) in enumerate(test_loader):
+                    if batch_idx > num_batches - 1:                                # (define_split_model_log_prob's own cut, S:1246)
+                        break
+                    r = _predict_batch_native(model, stacked, data, target, sizes, tau_list, tau_out, model_loss, num_batches)
+                    if r is None:
+                        parts = None
+                        break
+                    lp_sum = r[0] if lp_sum is None else lp_sum + r[0]
+                    parts.append(r[1])
+                if parts:
+                    predict_route["last"] = "native"; predict_route["native"] += 1
+                    return torch.cat(parts, 1), list(lp_sum.cpu().unbind(0))       # S:1536: the values live on the host
             fns = define_split_model_log_prob(model, model_loss, test_loader, num_batches, sizes, shapes, tau_list, tau_out,
                                               predict=True, device=dev, verbose=verbose)
             per_batch = [_eval_all(f, samples, dev) for f in fns]
-            preds, lps = [], []
-            for k in range(len(samples)):
-                lp = 0.
-                for vs, _ in per_batch:
-                    lp = lp + vs[k].cpu()                                          # S:1536
-                preds.append(torch.cat([os_[k] for _, os_ in per_batch], 0))
-                lps.append(lp)
+            lp_all = None
+            for vs, _ in per_batch:                                                # one copy per batch, not one per (sample, batch)
+                v = torch.stack([t.reshape(vs[0].shape) for t in vs]).cpu()
+                lp_all = v if lp_all is None else lp_all + v
+            preds = [torch.cat([os_[k] for _, os_ in per_batch], 0) for k in range(len(samples))]
+            lps = list(lp_all.unbind(0))
+            predict_route["last"] = "torch"; predict_route["torch"] += 1
         elif x is not None and y is not None:
             if x.device != dev:                                                    # S:1544-1545
                 raise RuntimeError('x on device: {} and samples on device: {}'.format(x.device, dev))
+            stacked = _stacked_samples(samples, dev) if dev.type == "cuda" else None
+            r = _predict_batch_native(model, stacked, x, y, sizes, tau_list, tau_out, model_loss, 1.0) if stacked is not None else None
+            if r is not None:
+                predict_route["last"] = "native"; predict_route["native"] += 1
+                return r[1], list(r[0].unbind(0))
             f = define_model_log_prob(model, model_loss, x, y, sizes, shapes, tau_list, tau_out, predict=True, device=dev)
             lps, preds = _eval_all(f, samples, dev)
+            predict_route["last"] = "torch"; predict_route["torch"] += 1
         else:
             raise RuntimeError('Val data not defined (i.e. arguments x, y, val_loader are all not defined)')   # S:1557
     return torch.stack(preds), lps

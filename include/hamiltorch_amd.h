@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HTA_ABI_VERSION 8
+#define HTA_ABI_VERSION 9
 
 #define HTA_OK 0
 #define HTA_ERR_INVALID (-1)   /* bad argument                           */
@@ -373,6 +373,18 @@ int hta_netn_logp_grad_f32(const float* theta, int64_t C, int n_layers, const in
 int hta_netn_logp_grad_f64(const double* theta, int64_t C, int n_layers, const int* dims, int act, int loss_kind, const double* X,
                            const double* Y, int N, int M, int Nb, int split, const double* taus, double tau_out, double prior_scale,
                            double* grad_out, double* logp_out, void* stream);
+
+/* Posterior predictive: out[s, p, :] = f(x_p; theta_s) for S parameter vectors at once (forward only) - replaces the per-sample
+ * forward passes of hamiltorch.predict_model (hamiltorch/samplers.py:1530-1552: a Python loop over the samples, one functional
+ * call each); SURVEY 8(f) N2.  theta [S, D]: rows of the samples sample_model / sample_split_model returned (flattened in
+ * model.parameters() order, U:121-122: weight [out, in] row-major then bias [out] per Linear); dims [n_layers + 1] = (in, h1, ...,
+ * out); act 0 relu | 1 tanh | 2 sigmoid between the layers (none after the last); X [N, dims[0]]; out [S, N, dims[n_layers]].
+ * Nets with one hidden layer and <= 16 outputs: any width; deeper nets: widths <= 256, <= 8 layers.  The log-probabilities
+ * predict_model also returns are element-wise reductions of `out` (hamiltorch_amd/bnn.py). */
+int hta_net_forward_f32(const float* theta, int64_t S, int n_layers, const int* dims, int act, const float* X, int N, float* out,
+                        void* stream);
+int hta_net_forward_f64(const double* theta, int64_t S, int n_layers, const int* dims, int act, const double* X, int N, double* out,
+                        void* stream);
 
 /* measurement knobs: "small_chains_per_block" (launch shape of the thread-per-chain kernel), "fill_blocks" (grid cap of the
  * pre-draw pass of the Gaussian path: 256-thread blocks, grid-stride; 4096),
