@@ -591,8 +591,8 @@ class NbMlp:
 
 
 class NbMlpFull(NbMlp):
-    extras = None
     """The same model under full HMC (sample_model, notebook cell 14: 13.47 samples/s): plain leapfrog, every gradient over all 400 points."""
+    extras = None
     key = "nbmlp-full"
     name = "nbmlp-full: the same model, full HMC (plain leapfrog over all 400 points), eps=5e-4, L=30"
     M, Nb = 1, 400
@@ -717,7 +717,7 @@ class FunnelHMC:
     def roofline(self, kernel_ms, call_ms, prof_n, steps):
         gbs = self.units_per_step() * self.bytes_per_unit() / (call_ms * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "torch callback (vmap grad_and_value) + hmc_pieces kernels, one HIP graph per trajectory",
+                "kernel": "torch callback + hmc_pieces kernels (HIP graph per trajectory)", "kernel_fixed": True,
                 "kernel_ms_per_step": call_ms, "call_ms": call_ms, "launches_per_step": None,
                 "note": "SURVEY 8(d) byte model (16 D bytes per chain-step) over the whole call; the path is launch / latency bound "
                         "at this size (D = 11): the fraction is reported, not claimed"}
@@ -752,7 +752,7 @@ class FunnelRMHMC(FunnelHMC):
         flops = 8 * 11.3 * self.D ** 3 + 4 * 2 * self.D ** 4
         tf = flops * self.units_per_step() / (call_ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "traffic": None,
-                "kernel": "torch.func hessian / jacobian callbacks + metric_warm_mfma_kernel (per-chain bases)",
+                "kernel": "torch.func callbacks + metric_warm_mfma_kernel", "kernel_fixed": True,
                 "kernel_ms_per_step": call_ms, "call_ms": call_ms, "launches_per_step": None,
                 "note": "launch bound: D = 11 systems on kernels sized for D = 100; the fraction is reported, not claimed"}
 
@@ -810,7 +810,7 @@ def result_of(w, W, dt, call_ms, prof_ms, prof_n, steps, warmup, world):
     else:
         kernel_ms = prof_ms / max(1, steps)                               # every profiled launch of one step
     roof = w.roofline(kernel_ms, call_ms, prof_n, steps)
-    if getattr(w, "route", ""):
+    if getattr(w, "route", "") and not roof.get("kernel_fixed"):
         roof["kernel_expected"], roof["kernel"] = roof.get("kernel"), w.route          # what ran, as the library reports it
     pkey = "%s%s@%d" % (W.key.split("@")[0], "jacobi" if getattr(w, "jacobi", False) else "", w.C)
     phys = _physical(pkey)
@@ -930,7 +930,7 @@ def compact_line(full, detail_path="bench_detail.json"):
         if full.get(k) is not None:
             out[k] = _r(full[k])
     for k in ("ranks_seen", "rank_devices", "launcher", "collective_backend"):
-        if k in full:
+        if k in full and (full.get("n_gpus", 1) > 1 or k == "ranks_seen"):
             out[k] = full[k]
     sec = []
     for r in full.get("secondary", []) or []:
@@ -938,10 +938,14 @@ def compact_line(full, detail_path="bench_detail.json"):
             sec.append({"key": _short_key(r), "error": r["error"][:80]})
             continue
         roof, cb = _compact_roofline(r.get("roofline", {})), r.get("cpu_baseline") or {}
+        # one entry per workload, short: bound / unit / achieved follow from `frac` (bound "mfma": frac x 157.3 TFLOP/s; "hbm":
+        # frac x 8000 GB/s) and are spelled out in bench_detail.json
         e = {"key": _short_key(r), "chains": r.get("config", {}).get("chains_per_gpu"), "value": _r(r.get("value")),
-             "ms_per_step": _r(r.get("ms_per_step")), "steps": r.get("steps"), "frac": roof["frac"], "bound": roof["bound"],
-             "achieved": roof["achieved"], "unit": roof["unit"], "mfma_busy": roof["mfma_busy"], "traffic": roof["traffic"],
-             "kernel": roof["kernel"][:40], "kernel_ms": roof["kernel_ms"], "cpu": {"value": _r(cb.get("value"), 4), "cores": cb.get("cores")}}
+             "ms_per_step": _r(r.get("ms_per_step")), "frac": roof["frac"], "bound": roof["bound"], "mfma_busy": roof["mfma_busy"],
+             "traffic": roof["traffic"], "kernel": roof["kernel"][:32], "kernel_ms": roof["kernel_ms"],
+             "cpu": {"value": _r(cb.get("value"), 4), "cores": cb.get("cores"), "kind": cb.get("kind")}}
+        if cb.get("workers_failed"):
+            e["cpu"]["failed"] = cb["workers_failed"]
         if roof.get("mfma_issued_over_useful") is not None:
             e["issued_over_useful"] = roof["mfma_issued_over_useful"]
         if r.get("api_ms_per_step") is not None:
@@ -950,10 +954,14 @@ def compact_line(full, detail_path="bench_detail.json"):
             if r.get(k) is not None:
                 e[k] = _r(r[k], 4)
         if r.get("extras"):
-            e["extras"] = {k: _r(v, 4) for k, v in r["extras"].items() if not isinstance(v, (dict, list))}
+            short = {"graph_replay": "graph", "value_graphs_off": "graphs_off", "value_notebook_closure": "nb_closure",
+                     "launches_per_step": "launches", "callback_evaluations_per_step": "cb_evals", "metric_evaluations_per_step": "metric_evals",
+                     "predict_route": "predict", "predict_samples": "predict_S", "predict_ms_torch_path": "predict_ms_torch"}
+            e["extras"] = {short.get(k, k): _r(v, 4) for k, v in r["extras"].items()
+                           if not isinstance(v, (dict, list)) and v is not None and k != "predict_samples_per_s"}
         if r.get("published"):
             e["samples_per_s"] = _r(r.get("samples_per_s"), 4)
-            e["published"] = {"samples_per_s": r["published"].get("samples_per_s"), "hw": str(r["published"].get("hw", ""))[:24]}
+            e["published_sps"] = r["published"].get("samples_per_s")
             e["cpu"]["samples_per_s"] = _r(cb.get("samples_per_s"), 3)
         sec.append(e)
     if sec:

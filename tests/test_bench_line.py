@@ -146,5 +146,5 @@ def test_funnel_entries_carry_their_extras_and_stay_inside_the_limit():
     keys = [s["key"] for s in rec["secondary"]]
     assert "funnel-hmc" in keys and "funnel-rmhmc" in keys and not rec.get("secondary_truncated")
     fh = rec["secondary"][keys.index("funnel-hmc")]
-    assert fh["extras"]["graph_replay"] is True and fh["extras"]["value_graphs_off"] == pytest.approx(1.235e6, rel=1e-3)
-    assert fh["published"]["samples_per_s"] == 56.10
+    assert fh["extras"]["graph"] is True and fh["extras"]["graphs_off"] == pytest.approx(1.235e6, rel=1e-3)
+    assert fh["published_sps"] == 56.10
