@@ -731,6 +731,9 @@ __global__ __launch_bounds__(256) void hmc_gauss_eig_kernel(GaussArgs<T> a, cons
 // dispatcher takes this kernel while the chip has idle SIMDs for the extra waves (C <= g_quad_max_chains) and the
 // chain-per-lane kernel beyond, where instruction count per chain decides.
 // =============================================================================================
+#ifndef QUAD_FUSED_NS
+#define QUAD_FUSED_NS 4
+#endif
 constexpr int QUAD_SLOTS_MAX = 4;     // record look-ahead of the quad kernel = rows of slack in the workspace
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
@@ -760,14 +763,45 @@ __device__ __forceinline__ float quad_sum(float v) {
 template <int I, int N, typename F> __device__ __forceinline__ void quad_static_for(F&& f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); quad_static_for<I + 1, N>(f); }
 }
-template <int D, bool DIAG, int LB, int VAR = 0>
-__global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, const float* __restrict__ eig) {
+// FUSED (round 4, tuning key "quad_fused"): the pre-draw pass runs INSIDE the same launch - the blocks behind the consumers' are
+// producers (quad_fused_kernel below) that write the records chunk by chunk (CH whole trajectories: no 128-byte line straddles two
+// chunks) and count themselves into `flags[chunk]` with a release at agent scope; a consumer checks, once per pass of its unrolled
+// loop, that the rows the pass prefetches are complete (`ready`: a register compare), polling a chunk's counter only when it
+// crosses into that chunk, with the next chunk's counter requested one chunk ahead.  Same records, same arithmetic: results are
+// bit-identical to the two-launch form.
+struct QuadFused { uint32_t* flags; int ch; uint32_t target; int nchunks; };
+template <int D, bool DIAG, int LB, int VAR, bool FUSED>
+__device__ __forceinline__ void quad_body(const GaussArgs<float>& a, const float* __restrict__ eig, const int64_t gt, const QuadFused fz) {
   typedef float T;
   constexpr bool UADDR = (VAR & 1) != 0, NOGUARD = (VAR & 2) != 0, TAIL = (VAR & 4) != 0;
-  const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t c = gt >> 2;
   const int k = (int)(gt & 3);
   if (c >= a.C) return;                         // whole quads leave together
+  // FUSED: rows [0, ready) are known complete; the counter of the chunk that starts at row `ready` was requested when the previous
+  // chunk was confirmed (pf).  The hot path pays one compare per pass; the poll runs once per chunk, out of the straight line.
+  int ready = 0;
+  uint32_t pf = 0;
+  if constexpr (FUSED) pf = __hip_atomic_load(fz.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  auto need_rows = [&](int upto) {              // rows up to `upto` are about to be read (rows >= n_traj are slack: never produced)
+    if constexpr (FUSED) {
+      if (__builtin_expect(upto >= ready, 0)) {
+        do {
+          const int chn = ready / fz.ch;
+          if (chn >= fz.nchunks) { ready = 0x7fffffff; break; }
+          uint32_t v = pf;
+          // (bounded: a producer that never counts - which cannot happen: producers wait for nothing - would otherwise hang the
+          //  queue; after ~1 s of polling the consumer reads on, and the parity tests see the difference)
+          for (int spin = 0; v < fz.target && spin < (1 << 20); ++spin) {
+            __builtin_amdgcn_s_sleep(4);
+            v = __hip_atomic_load(fz.flags + chn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          ready += fz.ch;
+          pf = chn + 1 < fz.nchunks ? __hip_atomic_load(fz.flags + chn + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        } while (upto >= ready);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the record loads below stay below
+      }
+    }
+  };
   const bool live = k < D;
   const int kk = live ? k : 0;                  // a dummy lane (k >= D) mirrors lane 0 on the output side (same address, same value)
   const T lam = live ? eig[kk] : 0.f;
@@ -820,9 +854,10 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
   const size_t rec_step = C * W;
   // Records are read NS trajectories ahead: a trajectory (~90 ns at L = 5, ~180 ns at L = 25) is shorter than the ~250 ns
   // an HBM load takes to return, and the look-ahead has to cover it.  The workspace carries QUAD_SLOTS_MAX rows of slack.
-  constexpr int NS = LB == 5 ? 4 : (LB == 10 ? 3 : 2);
+  constexpr int NS = FUSED ? QUAD_FUSED_NS : (LB == 5 ? 4 : (LB == 10 ? 3 : 2));     // (FUSED: the records come from memory, not from this XCD's L2)
   static_assert(NS <= QUAD_SLOTS_MAX, "workspace slack");
   T zs[NS], lus[NS];
+  need_rows(NS - 1);
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     if (i) rec += rec_step;
@@ -997,20 +1032,24 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
     if constexpr (UADDR) {
       // the same schedule with the bases moved once per group of trajectories
       auto moved = [&](int g) { recb += (size_t)g * (rec_step * sizeof(T)); row += (size_t)g * row_step; };
+      // (FUSED: a pass of G trajectories starting at t prefetches the rows up to t + G - 1 + NS)
       if (phase == 1 && t < t_end && a.traj_offset + t == a.burn + 1) {
+        need_rows(t + NS);
         trajectory(zs[0], lus[0], std::true_type{}, first);
         moved(1);
         rotate();
       }
       while (t + NU - 1 < t_end) {
+        need_rows(t + NU - 1 + NS);
         quad_static_for<0, NU>([&](auto I) { trajectory(zs[I % NS], lus[I % NS], plain, I); });
         moved(NU);
       }
       while (t + NS - 1 < t_end) {
+        need_rows(t + NS - 1 + NS);
         quad_static_for<0, NS>([&](auto I) { trajectory(zs[I], lus[I], plain, I); });
         moved(NS);
       }
-      while (t < t_end) { trajectory(zs[0], lus[0], plain, first); moved(1); rotate(); }
+      while (t < t_end) { need_rows(t + NS); trajectory(zs[0], lus[0], plain, first); moved(1); rotate(); }
     } else {
       if (phase == 1 && t < t_end && a.traj_offset + t == a.burn + 1) {              // the Q2 trajectory opens the stored phase
         trajectory(zs[0], lus[0], std::true_type{}, first);
@@ -1029,6 +1068,79 @@ __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, 
   }
   put((gwbytes_t)a.theta, qc);
   if (a.reject_count && k == 0) a.reject_count[c] += a.n_traj - accepted;
+}
+
+template <int D, bool DIAG, int LB, int VAR = 0>
+__global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, const float* __restrict__ eig) {
+  quad_body<D, DIAG, LB, VAR, false>(a, eig, blockIdx.x * (int64_t)blockDim.x + threadIdx.x, QuadFused{nullptr, 1, 0u, 0});
+}
+
+// one record (csrc: rng_fill_small_kernel's body): the draws of (trajectory t, chain c), rotated into the eigenbasis
+template <int D>
+__device__ __forceinline__ void quad_fill_record(float* __restrict__ ws, int64_t idx, int64_t C, int traj_offset, uint64_t seed,
+                                                 uint64_t chain_offset, const float* __restrict__ eig) {
+  typedef float T;
+  constexpr int W = rec_elems<T, D>();
+  const int64_t t = idx / C, c = idx - t * C;
+  T z[D], lu;
+  draw_inline<T, D>(seed, chain_offset + (uint64_t)c, (uint32_t)(traj_offset + (int)t), z, lu);
+  T rec[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) rec[i] = 0;
+#pragma unroll
+  for (int kk = 0; kk < D; ++kk) {
+    T acc = eig[EIG_QT(D) + kk * D + 0] * z[0];
+#pragma unroll
+    for (int i = 1; i < D; ++i) acc = fma(eig[EIG_QT(D) + kk * D + i], z[i], acc);
+    rec[kk] = acc;
+  }
+  rec[D] = 2.0f * lu;
+  // write-through stores at agent scope (sc1): the record is in memory, visible to the consumers' XCDs, once the store is
+  // acknowledged - no L2 write-back per producer block (a buffer_wbl2 per 64 records made the producers 40x slower)
+  // (one 16-byte store with the agent-scope bit: four dword stores quadrupled the write transactions)
+  typedef float V4f __attribute__((ext_vector_type(4)));
+  static_assert(W % 4 == 0, "records are whole 16-byte words");
+#pragma unroll
+  for (int i = 0; i < W / 4; ++i) {
+    const V4f v = {rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]};
+    const __attribute__((address_space(1))) V4f* dst = (const __attribute__((address_space(1))) V4f*)(ws + idx * W + 4 * i);
+    // (s_nop: a store wider than 8 bytes reads its data registers after issue; the compiler pads that hazard for stores it
+    //  knows, not for inline assembly - without it the next VALU write into v's registers corrupted the record: D = 4 caught it)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" :: "v"(dst), "v"(v) : "memory");
+  }
+}
+
+// consumers (blocks [0, nc): the quad kernel's body) and producers (the blocks behind them, chunk-major: block b writes the
+// 64-record slice b % spc of chunk b / spc) in ONE launch.  `done` counts the consumer blocks that finished: the last one
+// zeroes the counters for the next launch (no memset node, nothing the host has to track: the launch stays graph-capturable).
+constexpr int QUAD_FUSED_NT = 256;         // four waves per block: a producer block counts itself ONCE per chunk (the counter of a chunk
+                                           // is one address: its atomic adds serialise - 512 one-wave producers were 3x slower than 128)
+template <int D, int LB>
+__global__ __launch_bounds__(QUAD_FUSED_NT) void hmc_gauss_quad_fused_kernel(GaussArgs<float> a, const float* __restrict__ eig, QuadFused fz,
+                                                                             int nc, int spc, uint32_t* done) {
+  if ((int)blockIdx.x >= nc) {
+    // producer block b of spc: its slices of every chunk, chunk by chunk; one count per block and chunk
+    const int b = (int)blockIdx.x - nc;
+    const int64_t per_chunk = (int64_t)fz.ch * a.C, total = (int64_t)a.n_traj * a.C;
+    for (int chn = 0; chn < fz.nchunks; ++chn) {
+      const int64_t base = (int64_t)chn * per_chunk, end = min(base + per_chunk, total);
+      for (int64_t idx = base + (int64_t)b * QUAD_FUSED_NT + threadIdx.x; idx < end; idx += (int64_t)spc * QUAD_FUSED_NT)
+        quad_fill_record<D>(a.ws_z, idx, a.C, a.traj_offset, a.seed, a.chain_offset, eig);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // this wave's records are acknowledged ...
+      __syncthreads();                                                          // ... and so are the block's other waves' ...
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(fz.flags + chn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before they are counted
+    }
+    return;
+  }
+  __builtin_amdgcn_s_setprio(3);                 // a consumer's time is its issue rate: it goes first where a producer shares its SIMD
+  quad_body<D, false, LB, 7, true>(a, eig, blockIdx.x * (int64_t)blockDim.x + threadIdx.x, fz);
+  if (threadIdx.x == 0) {
+    const uint32_t old = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (uint32_t)nc - 1u) {                                             // every consumer has read every chunk
+      for (int i = 0; i < fz.nchunks; ++i) __hip_atomic_store(fz.flags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(done, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 
@@ -1393,6 +1505,24 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void leapfrog_gauss_wave_kernel(Gau
 // dispatch
 // =============================================================================================
 // the quad kernel's eligibility
+constexpr int QUAD_FUSED_CHUNKS = 64, QUAD_FUSED_OFF = 56;      // (capacity; "quad_chunks" of them are used)
+int g_quad_chunks = 8;       // tuning key "quad_chunks": chunks per fused launch (<= 64; measured 4 ... 60: profiles/r04k_quad_fused_sweep.txt)      // counters in the free tail of the eig block (D <= 4 uses 52 of 128 elements)
+int g_quad_producers = 64;   // tuning key "quad_producers": producer blocks (four waves each) of the fused launch per 1024 chains
+int g_quad_fused = 1;        // tuning key "quad_fused" (default 1): records produced inside the trajectory launch (prepared workspaces only); 0 = a pre-draw launch in front of it
+template <typename T> static bool eig_block_prepared(const GaussArgs<T>& a, int mass_kind);
+template <typename T> static bool quad_route(const GaussArgs<T>& a);
+// the fused launch: the quad route with the default instance on a PREPARED workspace (its counters were zeroed by the preparation
+// and are zeroed again by every fused launch's last consumer), rows that are whole 128-byte lines, at least one trajectory per chunk
+template <typename T> static bool quad_fused_route(const GaussArgs<T>& a, int mass_kind, bool diag) {
+  if constexpr (sizeof(T) != 4) return false;
+  else {
+    // (up to 4096 chains: the regime where the trajectory kernel leaves most of the chip to the producers)
+    if (!g_quad_fused || diag || g_quad_variant != 7 || !quad_route(a) || a.D > 4 || a.C > 4096 || a.n_traj < 8) return false;
+    const int W = ((a.D + 1 + 3) / 4) * 4;
+    if (((int64_t)a.C * W * 4) % 128 != 0 || ((uintptr_t)a.ws_z % 128) != 0) return false;
+    return eig_block_prepared(a, mass_kind);
+  }
+}
 template <typename T> static bool quad_route(const GaussArgs<T>& a) {
   return sizeof(T) == 4 && a.D <= 4 && a.ws_z && a.ws_logu && g_gauss_eig >= 1 && g_gauss_eig != 2 &&
          a.C <= g_quad_max_chains && a.C <= (1 << 24);
@@ -1409,7 +1539,30 @@ template <typename T, int D, int MASS> void launch_small(const GaussArgs<T>& a, 
         profile_begin(s);
         const int lb = g_gauss_eig == 3 ? 0 : a.L;       // gauss_eig = 3: the any-L instance (tests compare the two)
         note_route("hmc_gauss_quad_kernel<%d,%s,%d>", D, diag ? "true" : "false", diag ? 0 : (lb == 25 || lb == 10 || lb == 5) ? lb : 0);
-        if (!diag && (g_quad_variant == 3 || g_quad_variant == 7) && a.C <= (1 << 20)) {
+        if (quad_fused_route(a, MASS, diag)) {
+          // one launch: consumers + producers (see quad_body / hmc_gauss_quad_fused_kernel)
+          constexpr int W = rec_elems<T, D>();
+          const int lbv = (lb == 25 || lb == 10 || lb == 5) ? lb : 0;
+          QuadFused fz;
+          const int nch = g_quad_chunks < 1 ? 1 : (g_quad_chunks > QUAD_FUSED_CHUNKS ? QUAD_FUSED_CHUNKS : g_quad_chunks);
+          fz.ch = (a.n_traj + nch - 1) / nch;
+          fz.nchunks = (a.n_traj + fz.ch - 1) / fz.ch;
+          int spc = (int)(((int64_t)fz.ch * a.C + QUAD_FUSED_NT - 1) / QUAD_FUSED_NT);   // producer blocks (four waves each): at most
+          const int pmax = g_quad_producers * (int)((a.C + 1023) / 1024);                 // g_quad_producers per 1024 chains, each walks
+          if (spc > pmax) spc = pmax;                                                     // its slices of every chunk
+          fz.target = (uint32_t)spc;
+          const int qgrid = (int)((a.C * 4 + QUAD_FUSED_NT - 1) / QUAD_FUSED_NT);         // consumer blocks of this launch shape
+          fz.flags = reinterpret_cast<uint32_t*>(a.ws_logu + QUAD_FUSED_OFF);
+          uint32_t* done = fz.flags + QUAD_FUSED_CHUNKS;
+          (void)W;
+          note_route("hmc_gauss_quad_fused_kernel<%d,%d>", D, lbv);
+          const int fgrid = qgrid + spc;
+          if (lbv == 25) hmc_gauss_quad_fused_kernel<D, 25><<<fgrid, QUAD_FUSED_NT, 0, s>>>(a, a.ws_logu, fz, qgrid, spc, done);
+          else if (lbv == 10) hmc_gauss_quad_fused_kernel<D, 10><<<fgrid, QUAD_FUSED_NT, 0, s>>>(a, a.ws_logu, fz, qgrid, spc, done);
+          else if (lbv == 5) hmc_gauss_quad_fused_kernel<D, 5><<<fgrid, QUAD_FUSED_NT, 0, s>>>(a, a.ws_logu, fz, qgrid, spc, done);
+          else hmc_gauss_quad_fused_kernel<D, 0><<<fgrid, QUAD_FUSED_NT, 0, s>>>(a, a.ws_logu, fz, qgrid, spc, done);
+        }
+        else if (!diag && (g_quad_variant == 3 || g_quad_variant == 7) && a.C <= (1 << 20)) {
           // "quad_variant": 3 = uniform bases + 32-bit lane offsets, no NaN guard; 7 = also the fused row / butterfly block
           const int lbv = (lb == 25 || lb == 10 || lb == 5) ? lb : 0;
           note_route("hmc_gauss_quad_kernel<%d,false,%d,%d>", D, lbv, g_quad_variant);
@@ -1518,6 +1671,7 @@ template <typename T, int D> static void launch_rng_fill_d(const GaussArgs<T>& a
   int64_t g = (total + 255) / 256;
   if (g > g_fill_blocks) g = g_fill_blocks;
   if (a.ws_logu && !eig_block_prepared(a, mass_kind)) eig_small_kernel<T, D><<<1, 64, 0, s>>>(a.P, mass_kind, a.mass_factor, a.ws_logu);
+  if (quad_fused_route(a, mass_kind, a.H_old || a.H_new || a.accept)) return;      // the records are produced inside the trajectory launch
   rng_fill_small_kernel<T, D><<<(int)g, 256, 0, s>>>(a.ws_z, a.C, a.n_traj, a.traj_offset, a.seed, a.chain_offset,
                                                      a.ws_logu, quad_route(a) ? (T)2 : (T)1);
 }
@@ -1598,6 +1752,12 @@ int gaussian_prepare(const T* P, int mass_kind, const T* mass_factor, int64_t C,
     case 4: eig_small_kernel<T, 4><<<1, 64, 0, s>>>(P, mass_kind, mass_factor, eig); break;
     case 5: eig_small_kernel<T, 5><<<1, 64, 0, s>>>(P, mass_kind, mass_factor, eig); break;
     default: eig_small_kernel<T, 6><<<1, 64, 0, s>>>(P, mass_kind, mass_factor, eig); break;
+  }
+  if (D <= 4 && sizeof(T) == 4) {       // the fused quad launch's chunk counters + consumer count live in the block's free tail
+    if (hipMemsetAsync(eig + QUAD_FUSED_OFF, 0, (QUAD_FUSED_CHUNKS + 2) * sizeof(uint32_t), s) != hipSuccess) {
+      set_error("%s: hipMemsetAsync failed", who);
+      return HTA_ERR_LAUNCH;
+    }
   }
   HTA_CHECK_LAUNCH(who);
   g_eig_prepared[{eig_device(), (const void*)eig}] = EigPrepared{workspace, P, mass_factor, mass_kind, D, (int)sizeof(T)};

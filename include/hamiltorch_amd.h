@@ -426,7 +426,12 @@ int hta_net_forward_f64(const double* theta, int64_t S, int n_layers, const int*
  * lane in the element-wise work and three product phases per step - the second-order term of a solve rides in the idle columns
  * of the next phase's matrix instructions; equal to the K = 2 iteration up to third-order terms in jitter / lambda_min; two-chain
  * workgroups run on rmhmc_uvc2_kernel: two values per lane, branch-free half steps, the schedule of rmhmc_uv_kernel<2>;
- * 0 = rmhmc_uv_kernel, the parity partner of both). */
+ * 0 = rmhmc_uv_kernel, the parity partner of both),
+ * "quad_fused" (round 4; 1 default = on a PREPARED workspace, up to 4096 chains whose record rows are whole 128-byte lines, the quad
+ * route of hta_hmc_gaussian_sample produces its draw records inside the trajectory launch - producer blocks behind the consumer
+ * blocks, write-through stores, one counter per chunk of whole trajectories, the consumers' look-ahead gated per pass - instead
+ * of a pre-draw launch in front of it: bit-identical results, BASELINE config 2 0.175 -> 0.151 ms per call; 0 = the two-launch
+ * form; "quad_producers": producer blocks of that launch per 1024 chains, 64; "quad_chunks": hand-over chunks per launch, 8). */
 int hta_set_tuning(const char* key, int value);
 /* current value of a route key; every key back to its default (test fixtures call this between tests: the keys are
  * process-global).  The environment variable HTA_TUNING_DEFAULTS="key=value,..." moves the DEFAULT of the named keys for the

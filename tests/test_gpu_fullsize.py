@@ -57,11 +57,14 @@ def _replay_reference_run(init, N, propose):
 
 # =====================================================================================================================
 # cfg2: 3-D Gaussian HMC, 1024 chains, L = 25, eps = 0.3 -- hmc_gauss_quad_kernel<3,false,25>
-def _CFG2_ROUTE():
-    """The quad kernel's instance for L = 25 in the variant the route key "quad_variant" selects (0: the name without a
-    fourth template argument)."""
+def _CFG2_ROUTE(prepared=True):
+    """The quad kernel's instance for L = 25: on a PREPARED workspace (bench.py, sample()) the fused launch of round 4 (records
+    produced inside the trajectory launch, "quad_fused" = 1), else the two-launch form in the variant the route key
+    "quad_variant" selects (0: the name without a fourth template argument)."""
     from hamiltorch_amd import _abi
     v = _abi.get_tuning("quad_variant")
+    if prepared and _abi.get_tuning("quad_fused") and v == 7:
+        return "hmc_gauss_quad_fused_kernel<3,25>"
     return "hmc_gauss_quad_kernel<3,false,25%s>" % (",%d" % v if v else "")
 
 
@@ -73,9 +76,11 @@ def _cfg2(ht):
     return t, o, P
 
 
-def test_cfg2_bench_instance_vs_oracle_every_chain(ht):
-    """The exact C-ABI call bench.py times (1024 chains, L = 25, burn = -1, pre-drawn workspace, 3 launches over traj_offset)
-    against the oracle on the same Philox streams: all 1024 chains x 120 trajectories, and the reject counts."""
+@pytest.mark.parametrize("prepared", [True, False])
+def test_cfg2_bench_instance_vs_oracle_every_chain(ht, prepared):
+    """The exact C-ABI call bench.py times (1024 chains, L = 25, burn = -1, prepared workspace: the fused launch; 3 launches over
+    traj_offset) against the oracle on the same Philox streams: all 1024 chains x 120 trajectories, and the reject counts.
+    Also on an unprepared workspace: the two-launch form (pre-draw pass + trajectory kernel)."""
     from hamiltorch_amd import _abi
     t, o, _ = _cfg2(ht)
     C, T, L, eps, seed, off = 1024, 120, 25, 0.3, 0, 0
@@ -85,10 +90,15 @@ def test_cfg2_bench_instance_vs_oracle_every_chain(ht):
     samples = torch.empty(T + 1, C, 3, device=dev()); samples[0].copy_(theta0)
     rej = torch.zeros(C, dtype=torch.int32, device=dev())
     ws = torch.empty(_abi.gaussian_workspace_bytes(C, 3, 40, 4), dtype=torch.uint8, device=dev())
+    if prepared:
+        _abi.hmc_gaussian_prepare(theta0, t.precision, 0, None, C, 3, 40, ws)
     for start in (0, 40, 80):
         _abi.hmc_gaussian_sample(cur, theta0, t.precision, t.mean, t.log_norm, 0, None, None, L, eps, 40, start, -1, seed, off,
                                  samples, rej, workspace=ws)
-    assert _abi.last_route() == _CFG2_ROUTE()                                # the instance bench.py times (and names)
+    assert _abi.last_route() == _CFG2_ROUTE(prepared)                        # the instance bench.py times (and names)
+    torch.cuda.synchronize()
+    if prepared:
+        _abi.hmc_gaussian_forget(ws)
     ref, info = O.sample_hmc(o, th0, T, L, eps, -1, None, O.PhiloxDraws(seed, off + np.arange(C)))
     err = _chain_err(samples.cpu().numpy(), np.stack(ref))
     bad = err > 2e-4

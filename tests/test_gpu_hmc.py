@@ -625,7 +625,7 @@ def test_hmc_prepared_workspace_is_bit_identical_and_skips_the_setup(ht):
         cur = th0.clone(); samples = torch.zeros(n + 1, C, 3, device=dev()); rej = torch.zeros(C, dtype=torch.int32, device=dev())
         _abi.hmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, 0, None, None, L, eps, n, 0, -1, 13, 0, samples, rej,
                                  workspace=ws)
-        assert _abi.last_route().startswith("hmc_gauss_quad_kernel<3,false,25")
+        assert _abi.last_route().startswith(("hmc_gauss_quad_kernel<3,false,25", "hmc_gauss_quad_fused_kernel<3,25"))
         torch.cuda.synchronize()
         return torch.cat([samples.reshape(-1), rej.float(), cur.reshape(-1)]).cpu()
     s0 = run(ws_a)
@@ -753,3 +753,59 @@ def test_eigenbasis_routes_with_indefinite_curvature_and_divergence(ht, D):
     assert torch.isfinite(s).all()
     # every proposal diverged and was rejected: the rows repeat params_init bit for bit (S:1018), as in the reference
     assert torch.equal(s[-1], s[0])
+
+
+@pytest.mark.parametrize("D,C,N,L,burn", [(3, 1024, 1000, 25, -1), (3, 1024, 200, 25, 20), (2, 512, 333, 10, 5), (4, 264, 97, 5, -1),
+                                          (1, 64, 40, 7, 3), (3, 4096, 120, 25, -1)])
+def test_fused_quad_launch_is_bit_identical(ht, D, C, N, L, burn):
+    """Round 4, "quad_fused": the draw records produced INSIDE the trajectory launch (producer blocks behind the consumer blocks,
+    chunk counters released at agent scope, the consumers' look-ahead gated per pass) instead of by a pre-draw launch in front of
+    it.  Same records, same arithmetic: samples, reject counts and final state equal bit for bit - at BASELINE config 2's exact
+    shape, with burn-in (two phases, the Q2 trajectory), every step-count instance, D = 1 ... 4, chain counts whose rows are
+    whole 128-byte lines, and REPEATED launches on one workspace (the last consumer of a launch resets the counters; a stale
+    counter or a record read before its chunk was released would show here as a difference or a hang)."""
+    from hamiltorch_amd import _abi
+    rng = np.random.default_rng(100 * D + L)
+    mu = rng.normal(size=D)
+    t, _ = targets(ht, rand_spd(D, 8 + D), torch.float32, mu=mu)
+    th0 = tt(mu + rng.normal(size=(C, D)), torch.float32)
+    nbytes = _abi.gaussian_workspace_bytes(C, D, N, 4)
+    outs = {}
+    for fused in (0, 1):
+        _abi.set_tuning("quad_fused", fused)
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev())
+        _abi.hmc_gaussian_prepare(th0, t.precision, 0, None, C, D, N, ws)
+        res = []
+        cur = th0.clone()
+        for rep in range(4):                                  # the state travels from launch to launch (another seed each)
+            nrow = N - max(burn, 0) + 1
+            samples = torch.zeros(nrow, C, D, device=dev()); rej = torch.zeros(C, dtype=torch.int32, device=dev())
+            _abi.hmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, 0, None, None, L, 0.3, N, 0, burn, 13 + rep, 0, samples, rej,
+                                     workspace=ws)
+            route = _abi.last_route()
+            res.append(torch.cat([samples.reshape(-1), rej.float()]))
+        torch.cuda.synchronize()
+        assert route.startswith("hmc_gauss_quad_fused_kernel<%d" % D if fused else "hmc_gauss_quad_kernel<%d,false" % D), route
+        outs[fused] = (torch.cat(res).cpu(), cur.cpu())
+        _abi.hmc_gaussian_forget(ws)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[1][0]).all()
+
+
+def test_fused_quad_launch_needs_a_prepared_workspace_and_whole_lines(ht):
+    """The fused launch is only taken where its assumptions hold: a prepared workspace (zeroed counters), rows that are whole
+    128-byte lines (C a multiple of 8), no diagnostics outputs; anything else keeps the two-launch form - same results."""
+    from hamiltorch_amd import _abi
+    t, _ = targets(ht, rand_spd(3, 8), torch.float32)
+    _abi.set_tuning("quad_fused", 1)
+    for C, prepare, want in ((256, False, "hmc_gauss_quad_kernel<3"), (260, True, "hmc_gauss_quad_kernel<3"), (256, True, "hmc_gauss_quad_fused_kernel<3")):
+        th0 = torch.randn(C, 3, generator=torch.Generator().manual_seed(C)).to(dev())
+        N = 50
+        ws = torch.zeros(_abi.gaussian_workspace_bytes(C, 3, N, 4), dtype=torch.uint8, device=dev())
+        if prepare:
+            _abi.hmc_gaussian_prepare(th0, t.precision, 0, None, C, 3, N, ws)
+        cur = th0.clone(); samples = torch.zeros(N + 1, C, 3, device=dev()); rej = torch.zeros(C, dtype=torch.int32, device=dev())
+        _abi.hmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, 0, None, None, 25, 0.3, N, 0, -1, 5, 0, samples, rej, workspace=ws)
+        assert _abi.last_route().startswith(want), (C, prepare, _abi.last_route())
+        torch.cuda.synchronize()
+        _abi.hmc_gaussian_forget(ws)
