@@ -235,12 +235,14 @@ class Cfg2:
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         quad = self.C <= 65536
         waves = (self.C * 4 + 63) // 64 if quad else (self.C + 63) // 64
+        if "fused" in getattr(self, "route", ""):      # round 4: the producers of the draw records run in the same launch
+            waves += 4 * self.abi.get_tuning("quad_producers") * ((self.C + 1023) // 1024)
         # the bound that physically applies at 1024 chains: one dependent FMA chain per wave.  2 L dependent v_fma_f32 per
         # trajectory at the 4-cycle dependent-issue latency (MI355X_MICROARCH.md) against the measured cycles per trajectory
         clk_ghz = self.abi.device_info(0)["clock_khz"] / 1e6
         cyc_per_traj = kernel_ms * 1e-3 * clk_ghz * 1e9 / self.T
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "hmc_gauss_quad_kernel<3,false,25>" if quad else "hmc_gauss_eig_kernel<float,3,false>",
+                "traffic": None, "kernel": "hmc_gauss_quad_fused_kernel<3,25>" if quad else "hmc_gauss_eig_kernel<float,3,false>",
                 "kernel_ms": kernel_ms, "call_ms": call_ms, "algorithmic_bytes_per_launch": alg_bytes,
                 "latency_model": {"dependent_fma_per_trajectory": 2 * self.L, "floor_cycles_per_trajectory": 8 * self.L,
                                   "measured_cycles_per_trajectory": cyc_per_traj, "frac_of_latency_floor": 8 * self.L / cyc_per_traj,
