@@ -98,6 +98,31 @@ def test_coresident_uv_instances_fit_two_workgroups_and_keep_scratch_out_of_the_
             assert not any(i.startswith("scratch_") for _, i in lines[s_:e_ + 1]), k
 
 
+def test_round4_rmhmc_kernels_fit_two_workgroups_per_cu_and_keep_scratch_out_of_the_step_loop(kernels):
+    """rmhmc_uvc_kernel<co> (BASELINE config 3) and rmhmc_uvc2_kernel<co> (257 ... 1792 chains: the north-star size) are capped at
+    256 registers so that two four-wave workgroups share a CU; the one-chain kernel spills nothing, the two-chain kernel parks
+    <= 32 per-launch / per-trajectory values in scratch and none inside the leapfrog step loop; no accumulation registers."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_of
+    obj = os.path.join(ROOT, "hamiltorch_amd", "csrc", "build", "rmhmc_uvc.o")
+    if not os.path.exists(obj):
+        pytest.skip("needs the object file of rmhmc_uvc.hip")
+    for k in _find(kernels, "rmhmc_uvc_kernelILb1E"):
+        assert kernels[k]["vgpr"] <= 256 and kernels[k]["agpr"] == 0 and kernels[k]["spill"] == 0 and kernels[k]["scratch"] == 0, (k, kernels[k])
+    for k in _find(kernels, "rmhmc_uvc2_kernelILb1E"):
+        assert kernels[k]["vgpr"] <= 256 and kernels[k]["agpr"] == 0 and kernels[k]["spill"] <= 32 and kernels[k]["scratch"] <= 128, (k, kernels[k])
+        _, lines = isa_of.kernel_lines(obj, re.escape(k))
+        hot = []
+        for s_, e_ in isa_of.loops(lines):
+            ops = [isa_of.classify(i) for _, i in lines[s_:e_ + 1]]
+            if ops.count("mfma") >= 156 and ops.count("barrier") >= 3 and e_ - s_ < 1200:      # the step loop and its rotated forms
+                hot.append((s_, e_))
+        assert hot, k
+        for s_, e_ in hot:
+            assert not any(i.startswith("scratch_") for _, i in lines[s_:e_ + 1]), (k, s_, e_)
+
+
 def test_register_budgets_behind_the_occupancy_claims(kernels):
     # 512 registers per SIMD lane; .vgpr_count is the unified count (architectural + accumulation registers)
     def waves(k):
