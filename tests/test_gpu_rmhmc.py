@@ -887,8 +887,8 @@ def test_prepared_workspace_gives_identical_results_and_skips_the_setup(ht):
 
     def run(ws, jitter=1e-3, prepare=False, fused=1):
         _abi.set_tuning("rmhmc_fused", fused)
-        cur = th0.clone(); samples = torch.empty(T + 1, C, D, device=dev()); rej = torch.zeros(C, dtype=torch.int32, device=dev())
-        if prepare:
+        cur = th0.clone(); samples = torch.zeros(T + 1, C, D, device=dev()); rej = torch.zeros(C, dtype=torch.int32, device=dev())
+        if prepare:                                           # (zeros: row 0 is the caller's to fill - the runs are compared whole)
             _abi.rmhmc_gaussian_prepare(cur, t.precision, t.mean, _abi.METRIC_SOFTABS, 1e6, jitter, C, ws)
         _abi.set_tuning("profile", 1)
         _abi.rmhmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, _abi.METRIC_SOFTABS, 1e6, jitter, L, 0.1, 10.0, T, 0, -1, 5, 0,
