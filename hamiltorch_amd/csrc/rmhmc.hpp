@@ -26,6 +26,21 @@ extern int g_metric_general;                                // tuning key "metri
 bool metric_warm_mfma_eligible(const MetricArgsT<float>& a);
 int metric_warm_mfma(const MetricArgsT<float>& a, hipStream_t s);     // rmhmc_metric_mfma.hip
 
+// the binding rotation phi_C of one element with the reference's SEQUENTIAL update order (S:447-450)
+template <typename T> __device__ __forceinline__ void phi_c_elem(T& a, T& b, T& ac, T& bc, T c, T s) {
+  const T h = (T)0.5;
+  a = h * ((a + ac) + c * (a - ac) + s * (b - bc));       // S:447 (old values)
+  b = h * ((b + bc) - s * (a - ac) + c * (b - bc));       // S:448 (NEW theta)
+  ac = h * ((a + ac) - c * (a - ac) - s * (b - bc));      // S:449 (NEW theta, NEW p)
+  bc = h * ((b + bc) + s * (a - ac) - c * (b - bc));      // S:450 (NEW theta, p, theta~)
+}
+
+// rmhmc_metric_mfma.hip: one launch per trajectory of the eigendecomposition route (fp32, D <= 112)
+struct MetricTrajArgs { float* cur; float* th; float* pm; float* thc; float* pmc; float* H0; float* H1; float* lp1; int L; double eh; float c, s; };
+extern int g_metric_traj;                                   // tuning key "metric_traj" (default 1)
+bool metric_traj_mfma_eligible(const MetricArgsT<float>& a);
+int metric_traj_mfma(const MetricArgsT<float>& a, const MetricTrajArgs& t, hipStream_t s);
+
 template <typename T>
 int mh_select(T* cur, const T* prop, const T* init, const T* Ho, const T* Hn, const T* lpn, T* row, int32_t* rej,
               uint8_t* acc, int64_t C, int D, int n, int burn, uint64_t seed, uint64_t off, hipStream_t s);

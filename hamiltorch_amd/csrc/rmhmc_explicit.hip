@@ -26,11 +26,7 @@ __global__ void phi_c_kernel(T* __restrict__ th, T* __restrict__ pm, T* __restri
                              T s, int64_t total) {
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     T a = th[t], b = pm[t], ac = thc[t], bc = pmc[t];
-    const T h = (T)0.5;
-    a = h * ((a + ac) + c * (a - ac) + s * (b - bc));       // S:447 (old values)
-    b = h * ((b + bc) - s * (a - ac) + c * (b - bc));       // S:448 (NEW theta)
-    ac = h * ((a + ac) - c * (a - ac) - s * (b - bc));      // S:449 (NEW theta, NEW p)
-    bc = h * ((b + bc) + s * (a - ac) - c * (b - bc));      // S:450 (NEW theta, p, theta~)
+    phi_c_elem<T>(a, b, ac, bc, c, s);                      // S:447-450
     th[t] = a; pm[t] = b; thc[t] = ac; pmc[t] = bc;
   }
 }
@@ -232,9 +228,24 @@ int rmhmc_sample(T* cur, const T* theta_init, const T* P, const T* mu, double lo
                                  omega, n_traj, traj_offset, burn, seed, chain_offset, samples, reject_count, H_old_out,
                                  H_new_out, accept_out, p_ws, p_elems, pr.split ? LP : nullptr, s);
   }
+  bool traj_kernel = false;
+  if constexpr (sizeof(T) == 4) {
+    const MetricArgsT<T> probe = base_args(m, 0, 0);
+    traj_kernel = metric_traj_mfma_eligible(reinterpret_cast<const MetricArgsT<float>&>(probe));
+  }
   for (int t = 0; t < n_traj; ++t) {
     const int n = traj_offset + t;
     int rc;
+    if constexpr (sizeof(T) == 4) {
+      if (traj_kernel) {       // one launch: draw, H_old, L steps, H_new (rmhmc_metric_mfma.hip: metric_traj_mfma_kernel)
+        const MetricArgsT<T> a = base_args(m, (uint32_t)n, 0);
+        const float ang = (float)(2.0 * omega * eps);        // S:435-436
+        const MetricTrajArgs ta{(float*)cur, (float*)th, (float*)pm, (float*)thc, (float*)pmc, (float*)H0, (float*)H1, (float*)lp1, L, 0.5 * eps,
+                                cosf(ang), sinf(ang)};
+        if ((rc = metric_traj_mfma(reinterpret_cast<const MetricArgsT<float>&>(a), ta, s))) return rc;
+      }
+    }
+    if (!traj_kernel) {
     {   // gibbs: p ~ N(0, G(theta))  (S:183-184)
       MetricArgsT<T> a = base_args(m, (uint32_t)n, 0);
       a.p_out = pm;
@@ -253,6 +264,7 @@ int rmhmc_sample(T* cur, const T* theta_init, const T* P, const T* mu, double lo
       MetricArgsT<T> a = base_args(m, (uint32_t)n, 2u + 8u * (uint32_t)L);
       a.X = th; a.m = pm; a.H_out = H1; a.logp_out = lp1;
       if ((rc = metric_eval<T>(a, s))) return rc;
+    }
     }
     T* row = (samples && n > burn) ? samples + (int64_t)(n - burn) * total : nullptr;
     if ((rc = mh_select<T>(cur, th, theta_init, H0, H1, lp1, row, reject_count,

@@ -538,7 +538,10 @@ __device__ __forceinline__ int opaque_tid() {
   return t;
 }
 
-__global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float> a, int DP, int LD) {
+// One evaluation of system b (everything of the file's header); the workgroup's 1024 threads, state in the dynamic LDS block.
+// `vres`: the matrix buffer (offset) that holds the staged shared basis V0 on entry, or -1; on return, the buffer that holds it
+// now (a solve ends with V0 staged for x = V0 x': the next evaluation of a trajectory kernel starts from that copy), or -1.
+__device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, int DP, int LD, int64_t b, int& vres) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = a.D, tid = threadIdx.x;
   const int nt = DP / 16, k4 = (D + 3) / 4;
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
   // basis for the caller's next call.  lam0 is not used.
   const bool general = softabs && a.hs_stride != 0;
 
-  for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+  {
     const uint64_t chain = a.chain_offset + (uint64_t)b;
     const float* V0b = a.V0 + (general ? b * a.v0_stride : 0);
     __syncthreads();
@@ -576,25 +579,29 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
       vm[i] = (i < D && a.m) ? a.m[b * D + i] : 0.f;
       vd[i] = (i < D && a.X) ? a.X[b * D + i] - a.mu[i] : 0.f;
     }
-    if (softabs) ph_stage(V0b, oB1, D, DP, LD);
+    // buffer roles: bx = V0 (then X), by = A / S / E, bz = scratch
+    int bx = oB1, by = oB0, bz = oB2;
+    const bool resident = softabs && !general && vres >= 0;
+    if (resident) { bx = vres; by = vres == oB0 ? oB1 : oB0; bz = vres == oB2 ? oB1 : oB2; }
+    vres = -1;
+    if (softabs && !resident) ph_stage(V0b, bx, D, DP, LD);
     __syncthreads();
     HTA_STAMP(1);
     // ---- Gaussian log-prob and P (X - mu)
     float logp = 0.f;
-    if (a.X) logp = (float)a.log_norm - 0.5f * ph_logp(a.Pm, oD, D, oB2, oRed, a.upd_g ? a.upd_g + b * D : nullptr, (float)a.cg);
+    if (a.X) logp = (float)a.log_norm - 0.5f * ph_logp(a.Pm, oD, D, bz, oRed, a.upd_g ? a.upd_g + b * D : nullptr, (float)a.cg);
     // ---- m' = V0^T m
     if (a.m && softabs) {
-      const float v = ph_mv8(1, oB1, LD, oM, D);
+      const float v = ph_mv8(1, bx, LD, oM, D);
       __syncthreads();
       if ((tid & 7) == 0 && (tid >> 3) < DP) vm[tid >> 3] = ((tid >> 3) < D) ? v : 0.f;
     }
     HTA_STAMP(2);
     // ---- 1. A = diag(lam0) + V0^T diag(e) V0 into buffer 0 (symmetric, zero padded); general: A = V0^T (Hs + diag(e)) V0 into buffer 2
-    int bx = oB1, by = oB0, bz = oB2;
     if (softabs && !general) {
-      lds_gemm<true, false, true, true>(oB1, oB1, oB0, -1, oJit, nt, k4, LD);
+      lds_gemm<true, false, true, true>(bx, bx, by, -1, oJit, nt, k4, LD);
       __syncthreads();
-      { const int i = opaque_tid(); if (i < D) lds0[oB0 + i * LD + i] += a.lam0[i]; }
+      { const int i = opaque_tid(); if (i < D) lds0[by + i * LD + i] += a.lam0[i]; }
     } else if (general) {
       ph_stage_sym(a.Hs + b * a.hs_stride, oB2, oJit, D, DP, LD);
       __syncthreads();
@@ -729,6 +736,7 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
         __syncthreads();
         ph_stage(V0b, by, D, DP, LD);                           // (the E buffer is dead)
         __syncthreads();
+        if (!general) vres = by;
         const float x = ph_mv8(0, by, LD, oX, D);
         const int orow = opaque_tid() >> 3;
         if ((tid & 7) == 0 && orow < D) {
@@ -740,6 +748,7 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
     // ---- 4b. the eigenbasis itself (V_out: the next call's warm start) and the derivative matrix M = Q W Q^T (dmetric_out)
     bool q_ready = false;
     if (softabs && (a.V_out || a.dmetric_out)) {
+      vres = -1;
       __syncthreads();
       if (!a.m && tid < DP) vy[tid] = 0.f;                            // u = Q^T m / lam~ (vy holds it after the solve)
       ph_stage(V0b, by, D, DP, LD);
@@ -772,6 +781,7 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
     HTA_STAMP(21);
     // ---- 5. G = Q diag(lam~) Q^T, Q = V0 X  (S:121) for fisher() / the momentum draw; Metric.HESSIAN: G = Hs itself
     if (a.G_out || a.p_out || !softabs) {
+      vres = -1;
       __syncthreads();
       int g = bz;
       if (softabs) {
@@ -835,6 +845,83 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
       }
     }
   }
+}
+
+__global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float> a, int DP, int LD) {
+  for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) { int vres = -1; metric_warm_system(a, DP, LD, b, vres); }
+}
+
+// One explicit-RMHMC trajectory of chain b in ONE launch (S:969-989 with S:425-461 inside): the 4 L + 3 metric evaluations of
+// rmhmc_explicit.hip's launch sequence - momentum draw (sub-stream 0), H_old (1), per step the four half steps (2 + 8 l + {1, 2,
+// 4, 7}) with the binding rotation between the second and the third, H_new (2 + 8 L) - run back to back by the chain's
+// workgroup.  A chain's evaluations depend on nothing but that chain's own rows of th / pm / thc / pmc: the sequence needs no
+// grid-wide step, only the workgroup barrier between an evaluation's row updates and the next evaluation's reads.  Same
+// evaluation code as metric_warm_mfma_kernel (metric_warm_system), same arithmetic: bit-identical to the launch sequence
+// (tests/test_gpu_rmhmc.py::test_trajectory_kernel_equals_the_launch_sequence); what goes away is 57 launches per trajectory
+// with their ramps and the gaps between them (profiles/r04q: 12 % of the step).
+__global__ __launch_bounds__(MT) void metric_traj_mfma_kernel(MetricArgsT<float> a, MetricTrajArgs t, int DP, int LD) {
+  const int D = a.D;
+  const int nops = 4 * t.L + 3;
+  for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+    int vres = -1;                       // the buffer a solve left the staged V0 in: the next evaluation starts from it
+    for (int op = 0; op < nops; ++op) {
+      MetricArgsT<float> o = a;
+      int j = -1;
+      if (op == 0) { o.sub = 0; o.p_out = t.pm; }                                                  // gibbs: p ~ N(0, G(theta))  S:183-184
+      else if (op == 1) { o.sub = 1; o.X = t.cur; o.m = t.pm; o.H_out = t.H0; }                    // H_old  S:971
+      else if (op == nops - 1) { o.sub = 2u + 8u * (uint32_t)t.L; o.X = t.th; o.m = t.pm; o.H_out = t.H1; o.logp_out = t.lp1; }   // H_new  S:989
+      else {
+        const int q = op - 2, l = q >> 2;
+        j = q & 3;
+        const bool fa = j == 0 || j == 3;                                                          // phi_A/2 (S:429-430, S:457-458) : phi_B/2
+        o.sub = 2u + 8u * (uint32_t)l + (j == 0 ? 1u : j == 1 ? 2u : j == 2 ? 4u : 7u);
+        o.X = fa ? t.th : t.thc; o.m = fa ? t.pmc : t.pm; o.upd_x = fa ? t.thc : t.th; o.upd_g = fa ? t.pm : t.pmc;
+        o.cx = t.eh; o.cg = -t.eh;
+      }
+      metric_warm_system(o, DP, LD, b, vres);
+      if (op == 1 || j == 1) {
+        __syncthreads();
+        const int i = opaque_tid();
+        if (i < D) {
+          const int64_t e = b * D + i;
+          if (op == 1) {                                                                           // S:425-426
+            const float x = t.cur[e];
+            t.th[e] = x; t.thc[e] = x; t.pmc[e] = t.pm[e];
+          } else {
+            phi_c_elem<float>(t.th[e], t.pm[e], t.thc[e], t.pmc[e], t.c, t.s);                     // phi_C  S:447-450
+          }
+        }
+      }
+    }
+  }
+}
+
+int g_metric_traj = 1;   // tuning key "metric_traj": 1 = a trajectory of the eigendecomposition route is one launch, 0 = one launch per evaluation
+
+bool metric_traj_mfma_eligible(const MetricArgsT<float>& a) {
+  return g_metric_traj && a.hs_stride == 0 && !a.V_out && !a.dmetric_out && !a.G_out && metric_warm_mfma_eligible(a);
+}
+
+int metric_traj_mfma(const MetricArgsT<float>& a, const MetricTrajArgs& t, hipStream_t s) {
+  const int D = a.D;
+  const int DP = (D + 15) / 16 * 16, LD = DP + 4;
+  const size_t lds = ((size_t)3 * (DP * LD > 1024 ? DP * LD : 1024) + 8 * DP + MT / 64 + 16 * 20) * sizeof(float);
+  HTA_REQUIRE(lds <= 160 * 1024, "hta_rmhmc_gaussian_sample (trajectory kernel): D=%d does not fit the LDS", D);
+  MetricArgsT<float> k = a;
+  if (k.max_sweeps <= 0) k.max_sweeps = 16;
+  static DevOnce done;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&metric_traj_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { set_error("hta_rmhmc_gaussian_sample: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
+    done = true;
+  }
+  const int grid = (int)(a.B < 65536 ? a.B : 65536);
+  profile_begin(s);
+  note_route("metric_traj_mfma_kernel");
+  metric_traj_mfma_kernel<<<grid, MT, lds, s>>>(k, t, DP, LD);
+  profile_end(s);
+  HTA_CHECK_LAUNCH("hta_rmhmc_gaussian_sample (trajectory kernel)");
+  return HTA_OK;
 }
 
 bool metric_warm_mfma_eligible(const MetricArgsT<float>& a) {

@@ -408,6 +408,10 @@ int hta_net_forward_f64(const double* theta, int64_t S, int n_layers, const int*
  * csrc/rmhmc_metric_mfma.hip, D <= 112; 0 = always the Jacobi kernel of csrc/rmhmc_metric.hip),
  * "metric_general" (1 default: evaluations with per-system curvature and per-system warm bases - HtaMetricArgs::v0_stride - run on
  * that kernel too; 0 = the Jacobi kernel, cold),
+ * "metric_traj" (round 4; 1 default: a trajectory of hta_rmhmc_gaussian_sample's eigendecomposition route - momentum draw, H_old, 4 L
+ * half steps with the binding rotation, H_new - is ONE launch of metric_traj_mfma_kernel per trajectory (fp32, D <= 112: each chain's
+ * workgroup runs the chain's 4 L + 3 evaluations back to back) + the accept/reject launch; 0 = one launch per evaluation, the
+ * parity partner: bit-identical results),
  * "mlp3_route" (1 default: Bayesian MLPs with two wide hidden layers run on csrc/mlp3_mfma.hip; 0 = callback path),
  * "quad_variant" (7 default: the quad kernel with wave-uniform base addresses + 32-bit lane offsets, without the NaN guard of
  * the accept compare, and with the row element and the energy butterfly in one interleaved block; 3 = without that block;

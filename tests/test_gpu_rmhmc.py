@@ -416,6 +416,41 @@ def test_fused_path_equals_jacobi_path(ht, dtype, tol, D, jitter, metric):
     np.testing.assert_allclose(outs[0][1][~bad], outs[1][1][~bad], atol=1e-12)
 
 
+@pytest.mark.parametrize("D,jitter,metric,alpha,C", [(100, 1e-3, "softabs", 1e6, 300), (100, 1e-3, "softabs", 1.3, 9), (37, 5e-2, "softabs", 1e6, 17),
+                                                     (20, None, "softabs", 2.0, 5), (20, 1e-3, "hessian", 1e6, 33), (112, 1e-3, "softabs", 1e6, 4)])
+def test_trajectory_kernel_equals_the_launch_sequence(ht, D, jitter, metric, alpha, C):
+    """Round 4: on the eigendecomposition route (rmhmc_fused = 0) a trajectory is ONE launch of metric_traj_mfma_kernel (momentum
+    draw, H_old, 4 L half steps with the binding rotation, H_new: each chain's workgroup runs its 4 L + 3 evaluations back to
+    back) + the accept/reject launch.  Same evaluation code as the launch-per-evaluation sequence ("metric_traj" = 0): samples,
+    acceptance and both Hamiltonians are bit-identical; more chains than workgroup slots, a finite alpha (the soft-abs map is
+    not the identity), Metric.HESSIAN (Cholesky instead of the refinement) and the largest D the kernel takes included."""
+    from hamiltorch_amd import _abi
+    t, o = cfg3_target(ht, D, torch.float32, seed=7)
+    N, L, eps, omega, seed = 3, 3, 0.1, 10.0, 11
+    th0 = (0.3 * O.philox_normals(seed, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32)
+    M = ht.Metric.SOFTABS if metric == "softabs" else ht.Metric.HESSIAN
+    kw = dict(num_samples=N, num_steps_per_sample=L, step_size=eps, burn=0, jitter=jitter, softabs_const=alpha,
+              explicit_binding_const=omega, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT, metric=M, debug=2,
+              verbose=False, seed=seed)
+    outs = []
+    _abi.set_tuning("rmhmc_fused", 0)
+    try:
+        for traj in (1, 0):
+            _abi.set_tuning("metric_traj", traj)
+            _abi.set_tuning("profile", 1)
+            out, acc = ht.sample(t, tt(th0, torch.float32), **kw)
+            ms, launches = _abi.profile_collect()
+            _abi.set_tuning("profile", 0)
+            outs.append((np.stack([x.cpu().numpy() for x in out]), acc.cpu().numpy(), launches))
+    finally:
+        _abi.set_tuning("metric_traj", 1)
+        _abi.set_tuning("rmhmc_fused", 1)
+    assert outs[0][2] < outs[1][2] / 5, "the trajectory kernel was not taken (%d vs %d profiled launches)" % (outs[0][2], outs[1][2])
+    assert np.isfinite(outs[0][0]).all()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("D,jitter", [(100, 1e-3), (20, None), (37, 2e-3)])
 def test_fused_pair_kernel_equals_single_chain_kernel(ht, D, jitter):
     """The fused kernel can carry two chains per workgroup (tuning value 3; an odd chain count leaves the last pair half

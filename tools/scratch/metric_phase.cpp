@@ -1,15 +1,11 @@
 // Phase timer of metric_warm_mfma_kernel (developer tool): s_memtime stamps of workgroup 0 at the phase boundaries.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DHTA_TIMING=1 -ffp-contract=on -fno-slp-vectorize -x hip tools/scratch/metric_phase.cpp -o tools/scratch/metric_phase.bin
-#include "../../hamiltorch_amd/csrc/abi.cpp"
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DHTA_TIMING=1 -ffp-contract=on -fno-slp-vectorize -x hip tools/scratch/metric_phase.cpp -o tools/scratch/metric_phase.bin \
+//         -Lhamiltorch_amd -lhamiltorch_amd -Wl,-rpath,'$ORIGIN/../../hamiltorch_amd'      (the rest of the library: error strings, profile hooks)
 #include "../../hamiltorch_amd/csrc/rmhmc_metric_mfma.hip"
+#include "../../include/hamiltorch_amd.h"
 #include <vector>
 #include <cmath>
 #include <cstdlib>
-namespace hta {   // the symbols the two sources expect from the rest of the library
-int g_rmhmc_wide = 1;
-
-template <typename T> int metric_eval(const MetricArgsT<T>&, hipStream_t) { return 0; }
-}
 int main(int argc, char** argv) {
   const int D = argc > 1 ? atoi(argv[1]) : 100, B = argc > 2 ? atoi(argv[2]) : 256, gibbs = argc > 3 ? atoi(argv[3]) : 0;
   const double jitter = argc > 4 ? atof(argv[4]) : 1e-3;
@@ -43,7 +39,7 @@ int main(int argc, char** argv) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("D=%d B=%d gibbs=%d jitter=%g: %.1f us per launch\n", D, B, gibbs, jitter, ms * 100);
   }
-  long long t[32]; hipMemcpyFromSymbol(t, HIP_SYMBOL(hta::hta_metric_dbg), sizeof(t));
+  long long t[32] = {0}; { hipError_t e = hipMemcpyFromSymbol(t, HIP_SYMBOL(hta::hta_metric_dbg), sizeof(t)); if (e != hipSuccess) printf("hipMemcpyFromSymbol: %s\n", hipGetErrorString(e)); }
   const char* names[32] = {"start", "operands+V0 stage", "logp + V0^T m", "formation", "it0 begin", "it0 gemms", "it0 E", "it0 X", "it1 begin", "it1 gemms(T,S,Gm)", "it1 E", "it1 X update",
                            "it2 begin", "it2 gemms", "it2 E", "it2 X", "it3 begin", "it3 gemms", "it3 E", "it3 X", "refine end", "softabs+solve", "G assembly", "cholesky", "end"};
   long long prev = t[0];
