@@ -39,9 +39,14 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #endif
 #if HTA_TIMING      // developer builds (tools/scratch/metric_phase.cpp): s_memtime stamps of workgroup 0 at the phase boundaries
 __device__ long long hta_metric_dbg[32];
+__device__ long long hta_metric_wdbg[16][4];        // per wave of workgroup 0: entry / k loop begins / k loop ends / return of the formation product
+#define HTA_WVSTAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) hta_metric_wdbg[threadIdx.x >> 6][k] = clock64(); } while (0)
 #define HTA_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) hta_metric_dbg[k] = clock64(); } while (0)
+#define HTA_WSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) hta_metric_dbg[k] = clock64(); } while (0)      // wave 0's own progress: no barrier
 #else
 #define HTA_STAMP(k) do { } while (0)
+#define HTA_WSTAMP(k) do { } while (0)
+#define HTA_WVSTAMP(k) do { } while (0)
 #endif
 
 constexpr float kFallbackE = 0.03f;   // max |E_ij| beyond which the refinement is not trusted
@@ -64,7 +69,7 @@ __device__ __forceinline__ void upper_tile(int t, int nt, int& I, int& J) {
 // wave; they are dealt out by size (full 2 x 2 tiles, then the 1 x 2 / 2 x 1 edges of an odd nt, then the corner) in
 // boustrophedon order over the four SIMDs - wave w runs on SIMD w & 3 - so that the matrix pipes get equal shares.
 // The contraction covers k4 steps of four indices (k4 = ceil(D / 4)): chunks of four steps, the operands of the next chunk
-// in flight while the current one is on the pipe.
+// in flight while the current one is on the pipe; the steps beyond the last full chunk take indices 4 ks + lk.
 // the k loop of one macro tile; R2 / C2: the macro tile has a second tile row / column
 template <bool TA, bool TB, bool SCALE, bool R2, bool C2>
 __device__ __forceinline__ void gemm_macro(const float* pa0, const float* pb0, const float* kscale, int k4, int LD, int lk, f4 (&acc)[2][2]) {
@@ -80,6 +85,15 @@ __device__ __forceinline__ void gemm_macro(const float* pa0, const float* pb0, c
     bv[buf][0][u] = SCALE ? pb0[(ks) * bs] * sc__ : pb0[(ks) * bs];                      \
     if (C2) bv[buf][1][u] = SCALE ? pb1[(ks) * bs] * sc__ : pb1[(ks) * bs];              \
   } while (0)
+#if defined(HTA_GEMM_ABLATE) && HTA_GEMM_ABLATE == 1      // developer build (tools/scratch/metric_phase.cpp): no matrix instructions
+#define HTA_MMA_STEP(buf, u)                                                                                              \
+  do {                                                                                                                    \
+    acc[0][0][0] = fmaf(av[buf][0][u], bv[buf][0][u], acc[0][0][0]);                                                      \
+    if (C2) acc[0][1][0] = fmaf(av[buf][0][u], bv[buf][1][u], acc[0][1][0]);                                              \
+    if (R2) acc[1][0][0] = fmaf(av[buf][1][u], bv[buf][0][u], acc[1][0][0]);                                              \
+    if (R2 && C2) acc[1][1][0] = fmaf(av[buf][1][u], bv[buf][1][u], acc[1][1][0]);                                        \
+  } while (0)
+#else
 #define HTA_MMA_STEP(buf, u)                                                                                              \
   do {                                                                                                                    \
     acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][0][u], bv[buf][0][u], acc[0][0], 0, 0, 0);                   \
@@ -87,24 +101,74 @@ __device__ __forceinline__ void gemm_macro(const float* pa0, const float* pb0, c
     if (R2) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][1][u], bv[buf][0][u], acc[1][0], 0, 0, 0);           \
     if (R2 && C2) acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][1][u], bv[buf][1][u], acc[1][1], 0, 0, 0);     \
   } while (0)
+#endif
+  // A chunk = 16 contraction indices = four instructions.  Inside a chunk, lane group lk takes the indices 16 c + 4 lk + u at
+  // step u (not 16 c + 4 u + lk: any assignment serves as long as both operands use it): an operand that is contiguous
+  // in k (A[m][k], B[n][k], the scale vector) arrives as ONE 16-byte read per chunk, and an operand that is strided in k
+  // (A[k][m], B[k][n]) is read from rows 4 lk + u - with LD = 4 mod 8 the four lane groups of an instruction fall on four
+  // different bank quarters.  (Rounds 2-3 read rows 4 u + lk: groups 0 / 1 of LD = 116 overlapped in four banks, and the
+  // k-contiguous operand took four 4-byte reads with rows li and li + 8 in the same banks: every operand read of every
+  // product was a two-way bank conflict, and LDS time - not the matrix pipe - bounded the products.)
+  const float* qa0 = pa0 + (TA ? 3 * lk * LD : 3 * lk);
+  const float* qa1 = pa1 + (TA ? 3 * lk * LD : 3 * lk);
+  const float* qb0 = pb0 + (TB ? 3 * lk : 3 * lk * LD);
+  const float* qb1 = pb1 + (TB ? 3 * lk : 3 * lk * LD);
+  const float* qsc = SCALE ? kscale + 4 * lk : nullptr;
+#define HTA_LOAD_CHUNK(buf, c)                                                                                            \
+  do {                                                                                                                    \
+    if (TA) {                                                                                                             \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                     \
+        av[buf][0][u] = qa0[(16 * (c) + u) * LD];                                                                         \
+        if (R2) av[buf][1][u] = qa1[(16 * (c) + u) * LD];                                                                 \
+      }                                                                                                                   \
+    } else {                                                                                                              \
+      const f4 t0__ = *reinterpret_cast<const f4*>(qa0 + 16 * (c));                                                       \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) av[buf][0][u] = t0__[u];                                              \
+      if (R2) {                                                                                                           \
+        const f4 t1__ = *reinterpret_cast<const f4*>(qa1 + 16 * (c));                                                     \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) av[buf][1][u] = t1__[u];                                            \
+      }                                                                                                                   \
+    }                                                                                                                     \
+    f4 sc__ = f4{1.f, 1.f, 1.f, 1.f};                                                                                     \
+    if (SCALE) sc__ = *reinterpret_cast<const f4*>(qsc + 16 * (c));                                                       \
+    if (TB) {                                                                                                             \
+      const f4 t0__ = *reinterpret_cast<const f4*>(qb0 + 16 * (c));                                                       \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) bv[buf][0][u] = SCALE ? t0__[u] * sc__[u] : t0__[u];                  \
+      if (C2) {                                                                                                           \
+        const f4 t1__ = *reinterpret_cast<const f4*>(qb1 + 16 * (c));                                                     \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) bv[buf][1][u] = SCALE ? t1__[u] * sc__[u] : t1__[u];                \
+      }                                                                                                                   \
+    } else {                                                                                                              \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                     \
+        bv[buf][0][u] = SCALE ? qb0[(16 * (c) + u) * LD] * sc__[u] : qb0[(16 * (c) + u) * LD];                            \
+        if (C2) bv[buf][1][u] = SCALE ? qb1[(16 * (c) + u) * LD] * sc__[u] : qb1[(16 * (c) + u) * LD];                    \
+      }                                                                                                                   \
+    }                                                                                                                     \
+  } while (0)
+#if defined(HTA_GEMM_ABLATE) && HTA_GEMM_ABLATE == 2      // developer build: no operand reads (the matrix instructions alone)
+#undef HTA_LOAD_CHUNK
+#define HTA_LOAD_CHUNK(buf, c)                                                                                            \
+  do {                                                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                       \
+      av[buf][0][u] = av[buf][1][u] = __int_as_float(0x3f800000 + (c));                                                   \
+      bv[buf][0][u] = bv[buf][1][u] = __int_as_float(0x3f800000 + lk);                                                    \
+    }                                                                                                                     \
+  } while (0)
+#endif
   const int nchunk = k4 >> 2;
   if (nchunk > 0) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) HTA_LOAD_STEP(0, u, u);
+    HTA_LOAD_CHUNK(0, 0);
     int ch = 0;
     for (; ch + 2 < nchunk; ch += 2) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) HTA_LOAD_STEP(1, u, 4 * (ch + 1) + u);
+      HTA_LOAD_CHUNK(1, ch + 1);
 #pragma unroll
       for (int u = 0; u < 4; ++u) HTA_MMA_STEP(0, u);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) HTA_LOAD_STEP(0, u, 4 * (ch + 2) + u);
+      HTA_LOAD_CHUNK(0, ch + 2);
 #pragma unroll
       for (int u = 0; u < 4; ++u) HTA_MMA_STEP(1, u);
     }
     if (ch + 1 < nchunk) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) HTA_LOAD_STEP(1, u, 4 * (ch + 1) + u);
+      HTA_LOAD_CHUNK(1, ch + 1);
 #pragma unroll
       for (int u = 0; u < 4; ++u) HTA_MMA_STEP(0, u);
 #pragma unroll
@@ -119,6 +183,7 @@ __device__ __forceinline__ void gemm_macro(const float* pa0, const float* pb0, c
     HTA_MMA_STEP(0, 0);
   }
 #undef HTA_LOAD_STEP
+#undef HTA_LOAD_CHUNK
 #undef HTA_MMA_STEP
 }
 
@@ -136,18 +201,35 @@ __device__ __attribute__((noinline)) void lds_gemm(int offA, int offB, int offC,
   offCinit = __builtin_amdgcn_readfirstlane(offCinit);
   const float* Cinit = offCinit >= 0 ? lds + offCinit : nullptr;
   const float* kscale = SCALE ? lds + __builtin_amdgcn_readfirstlane(offScale) : nullptr;
+  if (SYM && SCALE && TA) { HTA_WSTAMP(25); HTA_WVSTAMP(0); }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform: scalar branches below
   const int li = lane & 15, lk = lane >> 4;
-  const int nf = nt >> 1, odd = nt & 1;
-  const int s = wave & 3, q = wave >> 2;
-  int k = (q & 1) ? 4 * q + 3 - s : 4 * q + s;                  // position in the size-sorted macro list
-  int r, c;
+  int I0, J0;
+  bool r2, c2;
   if (SYM) {
-    const int nfull = nf * (nf + 1) / 2;
-    if (k < nfull) upper_tile(k, nf, r, c);
-    else { k -= nfull; if (!odd || k > nf) return; if (k < nf) { r = k; c = nf; } else { r = nf; c = nf; } }
+    // upper block triangle only, as 1 x 2 macro tiles (pairs of neighbours in a tile row) and the odd tile that ends a row of odd
+    // length: nt = 7 gives 12 pairs + 4 singles = one item per wave, pairs first - every SIMD (wave & 3) gets three pairs and a
+    // single, 7 of the 28 tiles.  (Round 3 dealt 2 x 2 macro tiles here too: 10 items for 16 waves, three full ones - 12 tiles -
+    // on one SIMD: a symmetric product took as long as a full one.)
+    int npairs = 0;
+    for (int I = 0; I < nt; ++I) npairs += (nt - I) >> 1;
+    int w = wave, I = 0;
+    if (w < npairs) {
+      for (;; ++I) { const int pr = (nt - I) >> 1; if (w < pr) break; w -= pr; }
+      I0 = I; J0 = I + 2 * w; c2 = true;
+    } else {
+      w -= npairs;
+      for (; I < nt; ++I) if ((nt - I) & 1) { if (w == 0) break; --w; }
+      if (I >= nt) return;
+      I0 = I; J0 = nt - 1; c2 = false;
+    }
+    r2 = false;
   } else {
+    const int nf = nt >> 1, odd = nt & 1;
+    const int s = wave & 3, q = wave >> 2;
+    int k = (q & 1) ? 4 * q + 3 - s : 4 * q + s;                  // position in the size-sorted macro list
+    int r, c;
     const int nfull = nf * nf;
     if (k < nfull) { r = k / nf; c = k - r * nf; }
     else {
@@ -155,9 +237,9 @@ __device__ __attribute__((noinline)) void lds_gemm(int offA, int offB, int offC,
       if (!odd || k > 2 * nf) return;
       if (k < nf) { r = k; c = nf; } else if (k < 2 * nf) { r = nf; c = k - nf; } else { r = nf; c = nf; }
     }
+    I0 = 2 * r; J0 = 2 * c;
+    r2 = I0 + 1 < nt; c2 = J0 + 1 < nt;
   }
-  const int I0 = 2 * r, J0 = 2 * c;
-  const bool r2 = I0 + 1 < nt, c2 = J0 + 1 < nt;
   const float* pa0 = TA ? A + lk * LD + 16 * I0 + li : A + (16 * I0 + li) * LD + lk;
   const float* pb0 = TB ? B + (16 * J0 + li) * LD + lk : B + lk * LD + 16 * J0 + li;
   f4 acc[2][2];
@@ -171,10 +253,12 @@ __device__ __attribute__((noinline)) void lds_gemm(int offA, int offB, int offC,
         for (int t = 0; t < 4; ++t) acc[x][y][t] = Cinit[(16 * (I0 + x) + 4 * lk + t) * LD + 16 * (J0 + y) + li];
       }
     }
+  if (SYM && SCALE && TA) { HTA_WSTAMP(26); HTA_WVSTAMP(1); }
   if (r2 && c2) gemm_macro<TA, TB, SCALE, true, true>(pa0, pb0, kscale, k4, LD, lk, acc);
   else if (r2) gemm_macro<TA, TB, SCALE, true, false>(pa0, pb0, kscale, k4, LD, lk, acc);
   else if (c2) gemm_macro<TA, TB, SCALE, false, true>(pa0, pb0, kscale, k4, LD, lk, acc);
   else gemm_macro<TA, TB, SCALE, false, false>(pa0, pb0, kscale, k4, LD, lk, acc);
+  if (SYM && SCALE && TA) { HTA_WSTAMP(27); HTA_WVSTAMP(2); }
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -184,7 +268,7 @@ __device__ __attribute__((noinline)) void lds_gemm(int offA, int offB, int offC,
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         C[(16 * I + 4 * lk + t) * LD + 16 * J + li] = acc[x][y][t];
-        if (SYM && r != c) C[(16 * J + li) * LD + 16 * I + 4 * lk + t] = acc[x][y][t];
+        if (SYM && I != J) C[(16 * J + li) * LD + 16 * I + 4 * lk + t] = acc[x][y][t];
       }
     }
 }
@@ -441,22 +525,35 @@ __device__ __attribute__((noinline)) float ph_refine_E(int offS, int offG, int o
   scale = block_max(scale, red);                                   // (its barriers also publish vlam)
   const float tiny = 8.f * Eps<float>::v * scale;
   float emax = 0.f;
-  const int j = tid & 127;                                         // 8 rows of up to 128 columns per pass: no index division
-  const float lj = j < D ? vlam[j] : 0.f;
-#pragma unroll 7
-  for (int p8 = 0; p8 < 14; ++p8) {
-    const int i = (tid >> 7) + 8 * p8;
-    if (i >= D || j >= D) continue;
-    const float gm = have_x ? bz[i * LD + j] : (i == j ? 1.f : 0.f);
-    float E;
-    if (i == j) E = 0.5f * (1.f - gm) + (have_x ? 0.f : 1.f);
-    else {
-      const float num = by[i * LD + j] - lj * gm;
-      E = (fabsf(num) <= tiny) ? -0.5f * gm : __fdividef(num, lj - vlam[i]);
-      emax = fmaxf(emax, fabsf(E));
-      if (!(fabsf(E) <= kFallbackE)) emax = 1.f;                   // NaN / inf / too large
-    }
-    edst[i * LD + j] = E;
+  // The off-diagonal elements in PAIRS (i, j), (j, i), i < j: S and Gm are symmetric (the products mirror their upper tiles), the
+  // two quotients share the reciprocal of lam_j - lam_i.  Row r and row D - 1 - r have D - 1 upper elements between them: the
+  // pairs form a [ceil(D / 2)][D - 1] rectangle - thread (c = tid & 127, r = tid >> 7 + 8 p) needs no index division.
+  // (Rounds 2-3 walked all D^2 elements, a division each: 12.8 k + 10.7 k of an evaluation's 108 k cycles.)
+  const int c = tid & 127, H = (D + 1) >> 1;
+  if (tid < D) {                                                   // the diagonal: E_ii = (1 - Gm_ii) / 2 (+ 1: the first pass writes X = I + E)
+    const float gm = have_x ? bz[tid * LD + tid] : 1.f;
+    edst[tid * LD + tid] = 0.5f * (1.f - gm) + (have_x ? 0.f : 1.f);
+  }
+#pragma unroll
+  for (int p8 = 0; p8 < 7; ++p8) {
+    const int r = (tid >> 7) + 8 * p8;
+    if (r >= H || c >= D - 1) continue;
+    const int n1 = D - 1 - r;
+    int i, j;
+    if (c < n1) { i = r; j = r + 1 + c; }
+    else { i = D - 1 - r; j = D - r + (c - n1); if (i == r) continue; }          // (odd D: the middle row is its own partner)
+    const float li = vlam[i], lj = vlam[j];
+    const float sij = by[i * LD + j];
+    const float gm = have_x ? bz[i * LD + j] : 0.f;
+    const float rinv = __builtin_amdgcn_rcpf(lj - li);
+    const float nu = sij - lj * gm, nl = sij - li * gm;
+    const float eu = (fabsf(nu) <= tiny) ? -0.5f * gm : nu * rinv;                // E_ij = (S_ij - lam_j Gm_ij) / (lam_j - lam_i)
+    const float el = (fabsf(nl) <= tiny) ? -0.5f * gm : -(nl * rinv);             // E_ji = (S_ij - lam_i Gm_ij) / (lam_i - lam_j)
+    const float em = fmaxf(fabsf(eu), fabsf(el));
+    emax = fmaxf(emax, em);
+    if (!(fabsf(eu) <= kFallbackE) || !(fabsf(el) <= kFallbackE)) emax = 1.f;     // NaN / inf / too large
+    edst[i * LD + j] = eu;
+    edst[j * LD + i] = el;
   }
   return block_max(emax, red);
 }
@@ -600,8 +697,11 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
     // ---- 1. A = diag(lam0) + V0^T diag(e) V0 into buffer 0 (symmetric, zero padded); general: A = V0^T (Hs + diag(e)) V0 into buffer 2
     if (softabs && !general) {
       lds_gemm<true, false, true, true>(bx, bx, by, -1, oJit, nt, k4, LD);
+      HTA_WSTAMP(28); HTA_WVSTAMP(3);
       __syncthreads();
+      HTA_WSTAMP(29);
       { const int i = opaque_tid(); if (i < D) lds0[by + i * LD + i] += a.lam0[i]; }
+      HTA_WSTAMP(30);
     } else if (general) {
       ph_stage_sym(a.Hs + b * a.hs_stride, oB2, oJit, D, DP, LD);
       __syncthreads();

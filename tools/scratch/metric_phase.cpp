@@ -45,7 +45,9 @@ int main(int argc, char** argv) {
   long long prev = t[0];
   for (int k = 1; k <= 24; ++k) { if (t[k] > prev) { printf("  %-22s %8lld cycles\n", names[k], t[k] - prev); prev = t[k]; } }
   printf("  total %lld cycles\n", prev - t[0]);
-  printf("  fine stamps (cycles since start): Pd gmv %lld | logp sum %lld | (m' at %lld) ... lt/logdet %lld | y %lld | x' %lld | V0 x' gmv %lld | end %lld\n",
-         t[25] - t[0], t[26] - t[0], t[2] - t[0], t[27] - t[0], t[28] - t[0], t[29] - t[0], t[30] - t[0], t[24] - t[0]);
+  printf("  formation product, wave 0 (cycles since the phase began): entry %lld | k loop begins %lld | k loop ends %lld | returned %lld | after the barrier %lld | diagonal added %lld | phase ends %lld\n",
+         t[25] - t[2], t[26] - t[2], t[27] - t[2], t[28] - t[2], t[29] - t[2], t[30] - t[2], t[3] - t[2]);
+  long long w[16][4]; hipMemcpyFromSymbol(w, HIP_SYMBOL(hta::hta_metric_wdbg), sizeof(w));
+  for (int k = 0; k < 16; ++k) printf("    wave %2d: entry %6lld  k loop %6lld .. %6lld  returned %6lld\n", k, w[k][0] - t[2], w[k][1] - t[2], w[k][2] - t[2], w[k][3] - t[2]);
   return 0;
 }
