@@ -30,6 +30,7 @@
 namespace hta {
 
 int g_metric_mfma = 1;   // tuning key "metric_mfma": 1 = warm fp32 evaluations run here, 0 = always the Jacobi kernel
+int g_metric_second = 1;    // tuning key "metric_second": 1 = the refinement's second pass in closed form (one product: ph_refine_E2) where the first pass's update is small, 0 = always the full pass (three products)
 int g_metric_general = 1;   // tuning key "metric_general": 1 = evaluations with per-system curvature AND per-system bases run here too
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -51,6 +52,8 @@ __device__ long long hta_metric_wdbg[16][4];        // per wave of workgroup 0: 
 
 constexpr float kFallbackE = 0.03f;   // max |E_ij| beyond which the refinement is not trusted
 constexpr float kConvE = 3e-4f;       // an update with max |E_ij| below this leaves an error of order 1e-7
+constexpr float kSecondE = 8e-3f;     // a first pass with max |E_ij| below this is followed by the second-order pass (ph_refine_E2): its
+                                      // truncation leaves ||A X - X Lam|| of order |F| d^2 (d = max |E_ij|): < 1e-8 here, below fp32 rounding
 
 // tile index -> (I, J), I <= J, row-major over the upper block triangle
 __device__ __forceinline__ void upper_tile(int t, int nt, int& I, int& J) {
@@ -558,6 +561,70 @@ __device__ __attribute__((noinline)) float ph_refine_E(int offS, int offG, int o
   return block_max(emax, red);
 }
 
+// The SECOND pass in closed form (round 4).  After the first pass X = I + E1 with E1 antisymmetric (the pairs above) and zero on the
+// diagonal, the refinement's quantities are, up to terms of third order in the perturbation F = A - diag(A):
+//     S_ij - lam_j Gm_ij = (F E1)_ij =: M_ij  (i != j),    lam_i' = S_ii / Gm_ii = lam_i + M_ii,    Gm_ii = 1 + sum_k E1_ki^2
+// (the first-order terms cancel by the choice of E1; (E1^T Lam E1 - lam_j E1^T E1)_ij = -(E1^T F)_ij cancels one of the two
+// mixed terms) - i.e. second-order perturbation theory: ONE full product M = F E1 instead of T = A X, S = X^T T and Gm = X^T X
+// (2.1 full products), with E2_ij = M_ij / (lam_j' - lam_i'), E2_ii = -1/2 sum_k E1_ki^2.  The caller zeroed the diagonals of A and
+// X before the product; this pass reads M (offM) and E1 (offX, whose unit diagonal it restores), writes E2 to offDst and the
+// corrected eigenvalues to offLam.  Returns max |E2_ij| (1 for NaN / inf / > kFallbackE).  Truncation: |A X2 - X2 Lam'| ~ |F| d^2.
+__device__ __attribute__((noinline)) float ph_refine_E2(int offM, int offX, int offDst, int offLam, int offRed, int D, int LD) {
+  HTA_LDS_BASE();
+  D = HTA_U(D); LD = HTA_U(LD);
+  const float* M = lds + HTA_U(offM); float* X = lds + HTA_U(offX);
+  float* edst = lds + HTA_U(offDst); float* vlam = lds + HTA_U(offLam); float* red = lds + HTA_U(offRed);
+  const int tid = threadIdx.x;
+  float scale = 0.f;
+  {
+    const int row = tid >> 3, seg = tid & 7;                       // sum_k E1_ki^2 = sum_k E1_ik^2: 8 lanes per row
+    float c0 = 0.f, c1 = 0.f;
+    if (row < D) {
+#pragma unroll
+      for (int u = 0; u < 14; ++u) {
+        const int k = seg + 8 * u;
+        const float v = k < D ? X[row * LD + k] : 0.f;
+        if (u & 1) c1 = fmaf(v, v, c1); else c0 = fmaf(v, v, c0);
+      }
+    }
+    float cs = c0 + c1;
+    cs += __shfl_xor(cs, 1, 64);
+    cs += __shfl_xor(cs, 2, 64);
+    cs += __shfl_xor(cs, 4, 64);
+    if (seg == 0 && row < D) {
+      const float l2 = vlam[row] + M[row * LD + row];
+      vlam[row] = l2;
+      scale = fabsf(l2);
+      edst[row * LD + row] = -0.5f * cs;
+      X[row * LD + row] = 1.f;
+    }
+  }
+  scale = block_max(scale, red);                                   // (its barriers also publish vlam)
+  // M is a product of small factors, not a difference of large ones: its rounding noise is RELATIVE (eps |F| d per term), far below
+  // the full pass's threshold 8 eps |lam| on S_ij - lam_j Gm_ij (which would zero M itself: |M_ij| ~ 1e-6 at BASELINE config 3)
+  const float tiny = 8.f * Eps<float>::v * scale * kSecondE;
+  float emax = 0.f;
+  const int c = tid & 127, H = (D + 1) >> 1;
+#pragma unroll
+  for (int p8 = 0; p8 < 7; ++p8) {
+    const int r = (tid >> 7) + 8 * p8;
+    if (r >= H || c >= D - 1) continue;
+    const int n1 = D - 1 - r;
+    int i, j;
+    if (c < n1) { i = r; j = r + 1 + c; }
+    else { i = D - 1 - r; j = D - r + (c - n1); if (i == r) continue; }
+    const float rinv = __builtin_amdgcn_rcpf(vlam[j] - vlam[i]);
+    const float nu = M[i * LD + j], nl = M[j * LD + i];
+    const float eu = (fabsf(nu) <= tiny) ? 0.f : nu * rinv;
+    const float el = (fabsf(nl) <= tiny) ? 0.f : -(nl * rinv);
+    emax = fmaxf(emax, fmaxf(fabsf(eu), fabsf(el)));
+    if (!(fabsf(eu) <= kFallbackE) || !(fabsf(el) <= kFallbackE)) emax = 1.f;
+    edst[i * LD + j] = eu;
+    edst[j * LD + i] = el;
+  }
+  return block_max(emax, red);
+}
+
 __device__ __attribute__((noinline)) void ph_chol_solve(int offG, int D, int LD, int offV) {
   HTA_LDS_BASE();
   lds_chol_solve<float>(lds + HTA_U(offG), HTA_U(D), HTA_U(LD), lds + HTA_U(offV));
@@ -638,7 +705,7 @@ __device__ __forceinline__ int opaque_tid() {
 // One evaluation of system b (everything of the file's header); the workgroup's 1024 threads, state in the dynamic LDS block.
 // `vres`: the matrix buffer (offset) that holds the staged shared basis V0 on entry, or -1; on return, the buffer that holds it
 // now (a solve ends with V0 staged for x = V0 x': the next evaluation of a trajectory kernel starts from that copy), or -1.
-__device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, int DP, int LD, int64_t b, int& vres) {
+__device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, int DP, int LD, int64_t b, int& vres, bool second) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = a.D, tid = threadIdx.x;
   const int nt = DP / 16, k4 = (D + 3) / 4;
@@ -714,6 +781,7 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
     HTA_STAMP(3);
     // ---- 2. eigenvectors X of A by iterative refinement from X = I; bx: X, by: A / S / E, bz: scratch
     bool have_x = false, converged = false, fallback = !softabs;     // Metric.HESSIAN: G = A, no decomposition needed
+    float emax_prev = 1.f;
     bool implicit_e = false;          // the last update X (I + E) is applied to the vectors of the solve instead of being formed
     const bool want_matrix = a.G_out || a.p_out || a.V_out || a.dmetric_out;
     if (softabs) {
@@ -728,17 +796,29 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
           __syncthreads();
         }
         HTA_STAMP(4 + 4 * it);
-        if (have_x) {
-          lds_gemm<false, false, false, false>(by, bx, bz, -1, -1, nt, k4, LD);       // T = A X
+        float emax;
+        if (it == 1 && have_x && second && emax_prev <= kSecondE) {
+          // second pass in closed form: M = F E1 (F = A, E1 = X without their diagonals), then ph_refine_E2
+          { const int i = opaque_tid(); if (i < D) { lds0[by + i * LD + i] = 0.f; lds0[bx + i * LD + i] = 0.f; } }
           __syncthreads();
-          lds_gemm<true, false, true, false>(bx, bz, by, -1, -1, nt, k4, LD);         // S = X^T T
+          lds_gemm<false, false, false, false>(by, bx, bz, -1, -1, nt, k4, LD);       // M = F E1
           __syncthreads();
-          lds_gemm<true, false, true, false>(bx, bx, bz, -1, -1, nt, k4, LD);         // Gm = X^T X
-          __syncthreads();
+          HTA_STAMP(5 + 4 * it);
+          emax = ph_refine_E2(bz, bx, by, oLam, oRed, D, LD);
+        } else {
+          if (have_x) {
+            lds_gemm<false, false, false, false>(by, bx, bz, -1, -1, nt, k4, LD);     // T = A X
+            __syncthreads();
+            lds_gemm<true, false, true, false>(bx, bz, by, -1, -1, nt, k4, LD);       // S = X^T T
+            __syncthreads();
+            lds_gemm<true, false, true, false>(bx, bx, bz, -1, -1, nt, k4, LD);       // Gm = X^T X
+            __syncthreads();
+          }
+          HTA_STAMP(5 + 4 * it);
+          // first pass: X = I + E goes next to A (still needed for A X); later passes: E in place of S
+          emax = ph_refine_E(by, bz, have_x ? by : bx, oLam, oRed, have_x ? 1 : 0, D, LD);
         }
-        HTA_STAMP(5 + 4 * it);
-        // first pass: X = I + E goes next to A (still needed for A X); later passes: E in place of S
-        const float emax = ph_refine_E(by, bz, have_x ? by : bx, oLam, oRed, have_x ? 1 : 0, D, LD);
+        emax_prev = emax;
         HTA_STAMP(6 + 4 * it);
         if (emax > kFallbackE) { fallback = true; break; }
         __syncthreads();
@@ -947,8 +1027,8 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
   }
 }
 
-__global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float> a, int DP, int LD) {
-  for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) { int vres = -1; metric_warm_system(a, DP, LD, b, vres); }
+__global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float> a, int DP, int LD, int second) {
+  for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) { int vres = -1; metric_warm_system(a, DP, LD, b, vres, second != 0); }
 }
 
 // One explicit-RMHMC trajectory of chain b in ONE launch (S:969-989 with S:425-461 inside): the 4 L + 3 metric evaluations of
@@ -959,7 +1039,7 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
 // evaluation code as metric_warm_mfma_kernel (metric_warm_system), same arithmetic: bit-identical to the launch sequence
 // (tests/test_gpu_rmhmc.py::test_trajectory_kernel_equals_the_launch_sequence); what goes away is 57 launches per trajectory
 // with their ramps and the gaps between them (profiles/r04q: 12 % of the step).
-__global__ __launch_bounds__(MT) void metric_traj_mfma_kernel(MetricArgsT<float> a, MetricTrajArgs t, int DP, int LD) {
+__global__ __launch_bounds__(MT) void metric_traj_mfma_kernel(MetricArgsT<float> a, MetricTrajArgs t, int DP, int LD, int second) {
   const int D = a.D;
   const int nops = 4 * t.L + 3;
   for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
@@ -978,7 +1058,7 @@ __global__ __launch_bounds__(MT) void metric_traj_mfma_kernel(MetricArgsT<float>
         o.X = fa ? t.th : t.thc; o.m = fa ? t.pmc : t.pm; o.upd_x = fa ? t.thc : t.th; o.upd_g = fa ? t.pm : t.pmc;
         o.cx = t.eh; o.cg = -t.eh;
       }
-      metric_warm_system(o, DP, LD, b, vres);
+      metric_warm_system(o, DP, LD, b, vres, second != 0);
       if (op == 1 || j == 1) {
         __syncthreads();
         const int i = opaque_tid();
@@ -1018,7 +1098,7 @@ int metric_traj_mfma(const MetricArgsT<float>& a, const MetricTrajArgs& t, hipSt
   const int grid = (int)(a.B < 65536 ? a.B : 65536);
   profile_begin(s);
   note_route("metric_traj_mfma_kernel");
-  metric_traj_mfma_kernel<<<grid, MT, lds, s>>>(k, t, DP, LD);
+  metric_traj_mfma_kernel<<<grid, MT, lds, s>>>(k, t, DP, LD, g_metric_second);
   profile_end(s);
   HTA_CHECK_LAUNCH("hta_rmhmc_gaussian_sample (trajectory kernel)");
   return HTA_OK;
@@ -1051,7 +1131,7 @@ int metric_warm_mfma(const MetricArgsT<float>& a, hipStream_t s) {
   const int grid = (int)(a.B < 65536 ? a.B : 65536);
   profile_begin(s);
   note_route("metric_warm_mfma_kernel");
-  metric_warm_mfma_kernel<<<grid, MT, lds, s>>>(k, DP, LD);
+  metric_warm_mfma_kernel<<<grid, MT, lds, s>>>(k, DP, LD, g_metric_second);
   profile_end(s);
   HTA_CHECK_LAUNCH("hta_metric_eval (mfma)");
   return HTA_OK;

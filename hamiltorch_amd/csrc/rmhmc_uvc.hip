@@ -184,26 +184,17 @@ __global__ __launch_bounds__(XNT, CO ? 2 : 1) void rmhmc_uvc_kernel(FusedArgs<fl
   };
   // H = -log p + D/2 log 2 pi + 1/2 log|G| + 1/2 g^T G^-1 g  (S:731) of this set's (X, g); also returns P (X - mu) and S g
   // (n, sub: per lane - in the Hamiltonian at a trajectory's end the V set evaluates the NEXT trajectory's momentum terms)
-  // qpend: e . r1 of the trajectory's last B pair, of set U, in every lane (0 at a trajectory's start): its c2 = S qpend is still
-  // owed to theta.  It rides in the idle columns of this evaluation's first product and is applied here - theta += eh c2,
-  // P (theta - mu) += eh qpend (P S = 1) - instead of in a flush phase of its own; X returns corrected.
   // The kinetic term of the K = 2 solve needs ONE product: with x2 = z - r1 + c2, z = S g, r1 = S (e . z), c2 = S (e . r1) and S
   // symmetric, g . r1 = z . (e . z) and g . c2 = z . (e . r1), so g . x2 = sum_i [g_i z_i - e_i z_i (z_i - r1_i)].
-  auto hamiltonian = [&](uint32_t n, uint32_t sub, T& X, T g, T qpend, T& H, T& logp, T& Pd_out, T& Sg_out, T& kin_out, T& ld_out) {
-    const T ev = a.has_jitter ? jitter_one(n, sub) : 0.f;
-    T dr = X - mu_r;
+  auto hamiltonian = [&](uint32_t n, uint32_t sub, T X, T g, T& H, T& logp, T& Pd_out, T& Sg_out, T& kin_out, T& ld_out) {
+    const T ev = a.has_jitter ? jitter_one(n, sub) : 0.f, dr = X - mu_r;
     EV[own_off] = ev;
     DV[own_off] = dr;
     GV[own_off] = g;
-    GV[def_off] = qpend;
     __syncthreads();
     bf4 Pdv = {0.f, 0.f, 0.f, 0.f}, x0v = {0.f, 0.f, 0.f, 0.f}, s2v = {0.f, 0.f, 0.f, 0.f};
     prod2(Pa, DV, Sa, GV, Pdv, x0v);
-    T Pd = extract1(Pdv), x0, c2;
-    extract2(x0v, x0, c2);
-    X = fmaf(eh, c2, X);
-    dr = fmaf(eh, c2, dr);
-    Pd = fmaf(eh, qpend, Pd);
+    const T Pd = extract1(Pdv), x0 = extract1(x0v);
     T s2 = 0.f;
     if (a.has_jitter) { prod1(Sa, EV, true, s2v); s2 = extract1(s2v); }     // second-order log-det term: (S . S) e
     Pd_out = Pd; Sg_out = x0;
@@ -245,7 +236,7 @@ __global__ __launch_bounds__(XNT, CO ? 2 : 1) void rmhmc_uvc_kernel(FusedArgs<fl
       } else {
         g = momentum_use(momentum_raw(t));
         X = scur;
-        hamiltonian(n, 1, X, g, 0.f, H0, lp0, y, z, kin, ld);    // S:971 -> S:822
+        hamiltonian(n, 1, X, g, H0, lp0, y, z, kin, ld);    // S:971 -> S:822
       }
       const bool pre = t + 1 < a.n_traj;
       T gn_raw = 0.f;
@@ -317,15 +308,28 @@ __global__ __launch_bounds__(XNT, CO ? 2 : 1) void rmhmc_uvc_kernel(FusedArgs<fl
         g = fmaf(-ehU, y, g);
         z = fmaf(-ehU, X - mu_r, z);
       }
+      // ---- flush: c2 of the last B pair.  (It could ride in the idle columns of the closing Hamiltonian's first product, with
+      // P (theta - mu) += eh qB through P S = 1 - measured +3 % - but then the P (theta' - mu) a trajectory hands to the next one
+      // is not the product a fresh launch computes from theta': results would depend, in the last bit, on how a run is cut
+      // into launches.  tests/test_gpu_rmhmc.py::test_fused_workspace_passes_are_equivalent holds that line.)
+      {
+        WA[own_off] = 0.f;
+        WA[def_off] = qB;
+        __syncthreads();
+        bf4 r = {0.f, 0.f, 0.f, 0.f};
+        prod1(Sa, WA, false, r);
+        T r1, c2;
+        extract2(r, r1, c2);
+        X = fmaf(eh, c2, X);
+      }
       // ---- H_new on the un-augmented pair = set U (S:989, Q4); in the V set: the next trajectory's momentum terms
       if (pre) gn = momentum_use(gn_raw);
-      T Xh = of_set_u(X);                                    // both sets at the proposal theta' (still lacking eh c2 of the last B
-      const T qh = of_set_u(qB);                             // pair: applied inside); the V set's P (theta' - mu) is not used
+      const T Xh = of_set_u(X);                              // both sets at the proposal theta': the V set's P (theta' - mu) is not used
       const bool nextcol = setV && pre;
       const T gu = of_set_u(g);
       const T gh = nextcol ? gn : gu;
       T Pd1, Sg1;
-      hamiltonian(nextcol ? n + 1u : n, nextcol ? 1u : 2u + 8u * (uint32_t)a.L, Xh, gh, qh, H1, lp1, Pd1, Sg1, kin, ld);
+      hamiltonian(nextcol ? n + 1u : n, nextcol ? 1u : 2u + 8u * (uint32_t)a.L, Xh, gh, H1, lp1, Pd1, Sg1, kin, ld);
       // ---- Metropolis test + bookkeeping (S:1000-1026, S:1045-1057) on the U set's values, mirrored in the V set
       const T H0u = of_set_u(H0), H1u = of_set_u(H1), lp1u = of_set_u(lp1);
       const T u = u23<T>(philox_block(a.seed, chain, n, PURPOSE_MH, 0, 0).x);

@@ -412,6 +412,10 @@ int hta_net_forward_f64(const double* theta, int64_t S, int n_layers, const int*
  * half steps with the binding rotation, H_new - is ONE launch of metric_traj_mfma_kernel per trajectory (fp32, D <= 112: each chain's
  * workgroup runs the chain's 4 L + 3 evaluations back to back) + the accept/reject launch; 0 = one launch per evaluation, the
  * parity partner: bit-identical results),
+ * "metric_second" (round 4; 1 default: where the first refinement pass of a matrix-core metric evaluation moves no eigenvector entry by
+ * more than 8e-3, the second pass is second-order perturbation theory in closed form - ONE product F E1 instead of A X, X^T A X and
+ * X^T X; truncation error |F| d^2 < 1e-8 in ||A X - X Lam||, below fp32 rounding; 0 = always the three-product pass: the parity
+ * partner, equal results to rounding),
  * "mlp3_route" (1 default: Bayesian MLPs with two wide hidden layers run on csrc/mlp3_mfma.hip; 0 = callback path),
  * "quad_variant" (7 default: the quad kernel with wave-uniform base addresses + 32-bit lane offsets, without the NaN guard of
  * the accept compare, and with the row element and the energy butterfly in one interleaved block; 3 = without that block;

@@ -889,6 +889,48 @@ def test_metric_mfma_kernel_vs_oracle_and_jacobi_kernel(ht, D, kind, alpha, jitt
         np.testing.assert_allclose(got["p"], p64, rtol=tol * cond, atol=tol * cond * np.abs(p64).max())
 
 
+@pytest.mark.parametrize("D,alpha,jitter", [(100, 1e6, 1e-3), (100, 1.3, 1e-3), (100, 0.7, 3e-3), (64, 2.0, 5e-4), (37, 1e6, 1e-3), (112, 1e6, 1e-3)])
+def test_second_pass_in_closed_form_equals_the_three_product_pass(ht, D, alpha, jitter):
+    """Round 4 ("metric_second"): where the first refinement pass moves no eigenvector entry by more than 8e-3, the second pass
+    is second-order perturbation theory - one product F E1, E2_ij = (F E1)_ij / (lam_j' - lam_i'), lam_i' = lam_i + (F E1)_ii -
+    instead of A X, X^T A X, X^T X.  Same evaluations with the closed form (1) and with the three-product pass (0): solves,
+    log-determinants, quadratic forms, Hamiltonians, soft-abs spectra, the assembled metric and the momentum draw agree to fp32
+    rounding (an order tighter than either agrees with the float64 oracle), and the closed form is as close to the oracle as
+    the full pass.  BASELINE config 3's spectrum (jitter 1e-3: first-pass updates of ~5e-3) with the identity soft-abs map and
+    with a finite alpha, a larger jitter (mixed: some systems exceed the bound and take the full pass), smaller D, the largest D."""
+    from hamiltorch_amd import _abi
+    rng = np.random.default_rng(D + 1)
+    P = cfg3_target(ht, D, torch.float32, seed=7)[1].P.astype(np.float64)
+    B, seed = 41, 123
+    X = (0.3 * rng.standard_normal((B, D))).astype(np.float32)
+    m = rng.standard_normal((B, D)).astype(np.float32)
+    outs = []
+    try:
+        for second in (1, 0):
+            _abi.set_tuning("metric_second", second)
+            outs.append(_warm_eval(ht, P, X, m, alpha, jitter, seed, 1))
+    finally:
+        _abi.set_tuning("metric_second", 1)
+    a, f = outs
+    Hs = np.broadcast_to(P, (B, D, D)).astype(np.float64).copy()
+    ju = O.philox_uniforms(seed, 3 + np.arange(B), 7, D, O.PURPOSE_JITTER, 2, dtype=np.float64)
+    G, lam, _ = O.softabs_metric(Hs, alpha, jitter, ju)
+    x64 = 0.5 * np.linalg.solve(G, m.astype(np.float64)[..., None])[..., 0]
+    sx = np.abs(x64).max()
+    # (measured, tools/scratch/second_pass_err.py, D = 100: max |x - x64| / max |x64| = 3.6e-6 closed form, 1.5e-5 full pass - whose
+    # S_ij - lam_j Gm_ij is a difference of O(1) numbers -, 2.5e-6 Jacobi kernel; closed against full 1.6e-5)
+    np.testing.assert_allclose(a["x"], f["x"], rtol=0, atol=4e-5 * sx)
+    np.testing.assert_allclose(a["ld"], f["ld"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(a["q"], f["q"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(a["H"], f["H"], rtol=2e-5, atol=5e-5)
+    np.testing.assert_allclose(np.sort(a["lam"], axis=1), np.sort(f["lam"], axis=1), rtol=0, atol=2e-6 * np.abs(lam).max())
+    np.testing.assert_allclose(a["G"], f["G"], rtol=0, atol=2e-5 * np.abs(G).max())
+    np.testing.assert_allclose(a["p"], f["p"], rtol=0, atol=1e-4 * np.abs(f["p"]).max())
+    ea, ef = np.abs(a["x"] - x64).max() / sx, np.abs(f["x"] - x64).max() / sx
+    assert ea <= max(1.2 * ef, 8e-6), (ea, ef)                      # no further from float64 than the full pass is
+    assert np.abs(np.sort(a["lam"], axis=1) - np.sort(lam, axis=1)).max() <= 8e-6 * np.abs(lam).max()
+
+
 def test_metric_mfma_kernel_issues_matrix_instructions_on_cfg3(ht):
     """The eigendecomposition route of BASELINE config 3 (hta_set_tuning('rmhmc_fused', 0)) runs its metric evaluations on
     rmhmc_metric_mfma.hip and agrees with the Jacobi kernel chain by chain over a short run."""
