@@ -303,7 +303,8 @@ class Cfg3:
     @property
     def roof_kernel(self):      # the trajectory kernel the library picks at this chain count (csrc/rmhmc_fused.hip dispatch)
         if self.jacobi:
-            return "metric_eval_kernel<float> (+ phi_c_kernel, mh_select)"
+            return ("metric_traj_mfma_kernel (one launch per trajectory: a chain's workgroup runs its 4 L + 3 metric evaluations - "
+                    "eigenvector refinement on v_mfma_f32_16x16x4_f32 - back to back) + mh_select_kernel")
         if self.C <= 256:
             return ("rmhmc_uvc_kernel (one chain per workgroup: state set and copy as columns of v_mfma_f32_4x4x1_16b, one value per "
                     "lane, three product phases per step)")

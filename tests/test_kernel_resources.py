@@ -66,6 +66,12 @@ def test_spill_budget_of_the_hot_kernels(kernels):
     # (round 3: per-lane addresses are derived from an opaque index at the point of use - vgpr_spill 20 -> 1, scratch 112 -> 32)
     for k in _find(kernels, "metric_warm_mfma_kernel"):
         assert kernels[k]["spill"] <= 4 and kernels[k]["scratch"] <= 48, (k, kernels[k])
+    # round 4: the trajectory kernel of the eigendecomposition route (the same evaluation body inside a loop over the trajectory's
+    # 4 L + 3 evaluations): nothing of the loop's state lives in scratch
+    hits = _find(kernels, "metric_traj_mfma_kernel")
+    assert hits
+    for k in hits:
+        assert kernels[k]["spill"] <= 2 and kernels[k]["scratch"] <= 32, (k, kernels[k])
     # the notebook-model kernel (round 3): its loads / stores / momentum draws run out of line and the momentum's W2 share lives
     # in a workspace, so the code object's scratch is a stack for those calls (three 160-byte state vectors and change), not a
     # home for the gradient pass's values: < 1 KB per lane (the first version: 2.4 KB and six serial reloads in every kick)

@@ -7,8 +7,13 @@ R=${1:-r03}
 O=gpurun_out/${R}_phys
 mkdir -p $O
 t0=$(date +%s)
+# ONLY="cfg3@256 cfg3jacobi@256" tools/physical.sh <tag>: just these workloads (the others' kernels did not change); their entries
+# replace the ones in profiles/physical.json, the rest of that file is carried over (each entry names the pass it came from).
+KEYS=""
 one() {  # key steps warmup traj env -- bench args
   local key=$1 steps=$2 warm=$3 traj=$4 envs=$5; shift 5
+  if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $key "; then return; fi
+  KEYS="$KEYS $key=$O/$key"
   local d=$O/$key; mkdir -p $d
   local cmd="python bench.py --no-cpu-baseline --no-secondary --no-api --steps $steps --warmup $warm $*"
   echo "{\"command\": \"$envs $cmd\", \"steps\": $steps, \"warmup\": $warm, \"traj\": $traj, \"source\": \"tools/physical.sh $R\"}" > $d/meta.json
@@ -26,7 +31,14 @@ one cfg3jacobi@256 1 1 20 HTA_RMHMC_FUSED=0 --workload cfg3 --traj 20
 one cfg4@512 5 1 20 X=1 --workload cfg4
 one nbmlp@1024 2 1 1 X=1 --workload nbmlp
 one nbmlp-full@1024 2 1 1 X=1 --workload nbmlp-full
-python tools/physical.py cfg2@1024=$O/cfg2@1024 cfg3@1024=$O/cfg3@1024 cfg3@256=$O/cfg3@256 cfg3jacobi@256=$O/cfg3jacobi@256 cfg4@512=$O/cfg4@512 nbmlp@1024=$O/nbmlp@1024 nbmlp-full@1024=$O/nbmlp-full@1024 > gpurun_out/${R}_physical.json
+python tools/physical.py $KEYS > gpurun_out/${R}_physical_new.json
+python - <<P
+import json
+new = json.load(open("gpurun_out/${R}_physical_new.json"))
+old = json.load(open("profiles/physical.json")) if "$ONLY" else {}
+old.update(new)
+json.dump(old, open("gpurun_out/${R}_physical.json", "w"), indent=1)
+P
 python tools/pmc_summarize.py $(find $O -name "*counter_collection.csv" | sort) > gpurun_out/${R}_pmc_all.txt
 # keep the merge small: raw traces stay on the box
 find $O -name "*.csv" -size +2M -delete
