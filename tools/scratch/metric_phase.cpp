@@ -9,6 +9,7 @@
 int main(int argc, char** argv) {
   const int D = argc > 1 ? atoi(argv[1]) : 100, B = argc > 2 ? atoi(argv[2]) : 256, gibbs = argc > 3 ? atoi(argv[3]) : 0;
   const double jitter = argc > 4 ? atof(argv[4]) : 1e-3;
+  hta::g_metric_second = argc > 5 ? atoi(argv[5]) : 1;      // 0: the three-product second pass
   std::vector<double> Q(D * D);
   srand(1);
   for (auto& v : Q) v = rand() / (double)RAND_MAX - 0.5;
@@ -37,10 +38,10 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 10; ++k) { int rc = hta::metric_warm_mfma(a, 0); if (rc) { printf("error %s\n", hta_last_error()); return 1; } }
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("D=%d B=%d gibbs=%d jitter=%g: %.1f us per launch\n", D, B, gibbs, jitter, ms * 100);
+    printf("D=%d B=%d gibbs=%d jitter=%g second=%d: %.1f us per launch\n", D, B, gibbs, jitter, hta::g_metric_second, ms * 100);
   }
   long long t[32] = {0}; { hipError_t e = hipMemcpyFromSymbol(t, HIP_SYMBOL(hta::hta_metric_dbg), sizeof(t)); if (e != hipSuccess) printf("hipMemcpyFromSymbol: %s\n", hipGetErrorString(e)); }
-  const char* names[32] = {"start", "operands+V0 stage", "logp + V0^T m", "formation", "it0 begin", "it0 gemms", "it0 E", "it0 X", "it1 begin", "it1 gemms(T,S,Gm)", "it1 E", "it1 X update",
+  const char* names[32] = {"start", "operands+V0 stage", "logp + V0^T m", "formation", "it0 begin", "it0 gemms", "it0 E", "it0 X", "it1 begin", "it1 products (F E1 | T,S,Gm)", "it1 E", "it1 X update",
                            "it2 begin", "it2 gemms", "it2 E", "it2 X", "it3 begin", "it3 gemms", "it3 E", "it3 X", "refine end", "softabs+solve", "G assembly", "cholesky", "end"};
   long long prev = t[0];
   for (int k = 1; k <= 24; ++k) { if (t[k] > prev) { printf("  %-22s %8lld cycles\n", names[k], t[k] - prev); prev = t[k]; } }
