@@ -14,13 +14,18 @@
 // Aishima (Japan J. Indust. Appl. Math. 35, 2018: "Iterative refinement for symmetric eigenvalue decomposition"):
 //     S = X^T A X,  Gm = X^T X,  lam_i = S_ii / Gm_ii,
 //     E_ii = (1 - Gm_ii) / 2,   E_ij = (S_ij - lam_j Gm_ij) / (lam_j - lam_i),   X <- X (I + E),
-// quadratically convergent, and nothing but dense products: five D^3 GEMMs per evaluation (formation of A, A X, X^T (A X),
-// X^T X, X E) as v_mfma_f32_16x16x4_f32 tiles (exact fp32 products, fp32 accumulation) on [DP][LD] buffers in LDS.  The
+// quadratically convergent, and nothing but dense products (formation of A, A X, X^T (A X), X^T X, X E) as
+// v_mfma_f32_16x16x4_f32 tiles (exact fp32 products, fp32 accumulation) on [DP][LD] buffers in LDS.  The
 // iteration needs the coupling to be small against the eigenvalue gaps; max |E_ij| says whether it is: above 0.03 (a
 // nearly degenerate spectrum, a large jitter, a stalled iteration) the system falls back - inside the same launch - to
 // the cyclic Jacobi solver of rmhmc_metric.hip, which needs no such assumption.  Results agree with that solver to
 // rounding (tests/test_gpu_rmhmc.py::test_metric_mfma_kernel_equals_jacobi_kernel); hta_set_tuning("metric_mfma", 0)
 // selects it outright.
+// Round 4: the first pass starts from X = I, so X = I + E1 with E1 antisymmetric; where max |E1_ij| <= 8e-3 (BASELINE config 3:
+// 5e-3) the SECOND pass is taken in closed form - second-order perturbation theory, ONE product F E1 (ph_refine_E2) instead of
+// A X, X^T A X and X^T X - and applied to the vectors of a solve without being formed: two D^3 products per solve evaluation
+// (formation, F E1); hta_set_tuning("metric_second", 0) keeps the three-product pass.  And a TRAJECTORY of the Gaussian-target
+// sampler is one launch (metric_traj_mfma_kernel below): the chain's workgroup runs its 4 L + 3 evaluations back to back.
 //
 // The momentum draw / fisher() outputs add Q = V0 X, G = Q diag(lam~) Q^T (two more GEMMs) and a right-looking Cholesky in
 // 16-column panels whose triangular solve and trailing update are MFMA tiles as well.
