@@ -198,11 +198,14 @@ __device__ __forceinline__ void gemm_macro(const float* pa0, const float* pb0, c
 // (Operands are OFFSETS, in floats, into the kernel's dynamic LDS block: an out-of-line function only sees generic pointers
 // in its arguments - flat loads, every wait a full one; and its integer arguments arrive in vector registers: readfirstlane
 // makes them scalars again so that the tile bookkeeping compiles to scalar branches.)
-template <bool TA, bool TB, bool SYM, bool SCALE>
-__device__ __attribute__((noinline)) void lds_gemm(int offA, int offB, int offC, int offCinit, int offScale, int nt, int k4, int LD) {
+// LDC: the leading dimension as a compile-time constant (0: the run-time value) - with it the four rows of a chunk's operand
+// reads are immediate offsets of one address register instead of an address computation per read
+template <bool TA, bool TB, bool SYM, bool SCALE, int LDC>
+__device__ __attribute__((noinline)) void lds_gemm_ld(int offA, int offB, int offC, int offCinit, int offScale, int nt, int k4, int LDr) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* const lds = reinterpret_cast<float*>(smem_raw);
-  nt = __builtin_amdgcn_readfirstlane(nt); k4 = __builtin_amdgcn_readfirstlane(k4); LD = __builtin_amdgcn_readfirstlane(LD);
+  nt = __builtin_amdgcn_readfirstlane(nt); k4 = __builtin_amdgcn_readfirstlane(k4);
+  const int LD = LDC ? LDC : __builtin_amdgcn_readfirstlane(LDr);
   const float* A = lds + __builtin_amdgcn_readfirstlane(offA);
   const float* B = lds + __builtin_amdgcn_readfirstlane(offB);
   float* C = lds + __builtin_amdgcn_readfirstlane(offC);
@@ -279,6 +282,13 @@ __device__ __attribute__((noinline)) void lds_gemm(int offA, int offB, int offC,
         if (SYM && I != J) C[(16 * J + li) * LD + 16 * I + 4 * lk + t] = acc[x][y][t];
       }
     }
+}
+
+constexpr int kLdCfg3 = 116;             // LD of 97 <= D <= 112 (BASELINE config 3's D = 100)
+template <bool TA, bool TB, bool SYM, bool SCALE>
+__device__ __forceinline__ void lds_gemm(int offA, int offB, int offC, int offCinit, int offScale, int nt, int k4, int LD) {
+  if (LD == kLdCfg3) lds_gemm_ld<TA, TB, SYM, SCALE, kLdCfg3>(offA, offB, offC, offCinit, offScale, nt, k4, LD);
+  else lds_gemm_ld<TA, TB, SYM, SCALE, 0>(offA, offB, offC, offCinit, offScale, nt, k4, LD);
 }
 
 __device__ __forceinline__ float block_max(float v, float* red) {
