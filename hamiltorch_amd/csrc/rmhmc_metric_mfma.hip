@@ -291,25 +291,78 @@ __device__ __forceinline__ void lds_gemm(int offA, int offB, int offC, int offCi
   else lds_gemm_ld<TA, TB, SYM, SCALE, 0>(offA, offB, offC, offCinit, offScale, nt, k4, LD);
 }
 
-__device__ __forceinline__ float block_max(float v, float* red) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+// Cross-lane sums / maxima as DPP operands of the adding instruction (quad permutes, row_half_mirror, row_mirror; the four rows
+// of a wave through v_readlane): __shfl_xor compiles to ds_bpermute_b32 - an LDS round trip per butterfly step, six in a row for
+// a wave sum (~700 cycles; a block reduction in this file cost ~1.9 k, measured).  Every lane gets the result.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_f(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+__device__ __forceinline__ float sum8_dpp(float v) {            // aligned groups of 8 lanes
+  v += dpp_f<0xB1>(v);                                          // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);                                          // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);                                         // row_half_mirror: the other quad of the 8
+  return v;
+}
+__device__ __forceinline__ float sum16_dpp(float v) { v = sum8_dpp(v); v += dpp_f<0x140>(v); return v; }      // row_mirror: the other half of the 16
+__device__ __forceinline__ float max16_dpp(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = sum16_dpp(v);
+  return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = max16_dpp(v);
+  return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
+}
+static_assert(MT / 64 == 16, "the block reductions below fold the 16 wave results in one DPP row");
+__device__ __forceinline__ float block_sum_dpp(float v, float* red) {
+  v = wave_sum_dpp(v);
   const int w = threadIdx.x >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[w] = v;
   __syncthreads();
-  float m = red[0];
-#pragma unroll
-  for (int i = 1; i < MT / 64; ++i) m = fmaxf(m, red[i]);
-  return m;
+  return sum16_dpp(red[threadIdx.x & 15]);
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max_dpp(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return max16_dpp(red[threadIdx.x & 15]);
 }
 
 // out[row] = sum_k M(row, k) v[k] with 8 lanes per row (rows 0 .. 127 of the workgroup's 1024 threads); M(row, k) =
 // TRANS ? M[k * ld + row] : M[row * ld + k]; n = vector length (rows and columns).  Every lane of a row's group returns the sum.
+// Row-wise (TRANS = false) the 8 lanes of a row read it as 16-byte quads - quad seg + 8 u of the row and of v, zero padded to a
+// multiple of 4 - : 8 LDS instructions per lane instead of 28 (the 4-byte form is bound by the LDS instruction rate: 448
+// wave-reads of 2+ clocks for a 40 KB matrix - 3 k cycles per product, measured; the quads: ~1 k).  Column-wise (TRANS) keeps
+// 4-byte reads of 8 consecutive rows per k.
 template <bool TRANS> __device__ __forceinline__ float mv8(const float* M, int ld, const float* v, int n) {
   const int row = threadIdx.x >> 3, seg = threadIdx.x & 7;
   float acc0 = 0.f, acc1 = 0.f;
-  if (row < n) {
+  if (!TRANS) {
+    if (row < n) {
+      const int nq = (n + 3) >> 2;
+      const float* mr = M + row * ld;
+      f4 mq[4], vq[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = seg + 8 * u;
+        const bool on = q < nq;
+        mq[u] = on ? *reinterpret_cast<const f4*>(mr + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+        vq[u] = on ? *reinterpret_cast<const f4*>(v + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc0 = fmaf(mq[u][0], vq[u][0], acc0); acc1 = fmaf(mq[u][1], vq[u][1], acc1);
+        acc0 = fmaf(mq[u][2], vq[u][2], acc0); acc1 = fmaf(mq[u][3], vq[u][3], acc1);
+      }
+    }
+  } else if (row < n) {
     // n <= 112: 14 steps of 8, seven operand pairs in flight at a time
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -326,10 +379,7 @@ template <bool TRANS> __device__ __forceinline__ float mv8(const float* M, int l
     }
   }
   float acc = acc0 + acc1;
-  acc += __shfl_xor(acc, 1, 64);
-  acc += __shfl_xor(acc, 2, 64);
-  acc += __shfl_xor(acc, 4, 64);
-  return acc;
+  return sum8_dpp(acc);
 }
 
 // y = M v for a SYMMETRIC dense row-major [n][n] matrix in global memory (P; L2 resident): thread (column c = tid & 127,
@@ -370,10 +420,7 @@ __device__ __forceinline__ float mv8_lower(const float* M, int ld, const float* 
   float acc = 0.f;
   if (row < n)
     for (int k = seg; k <= row; k += 8) acc = fmaf(M[row * ld + k], v[k], acc);
-  acc += __shfl_xor(acc, 1, 64);
-  acc += __shfl_xor(acc, 2, 64);
-  acc += __shfl_xor(acc, 4, 64);
-  return acc;
+  return sum8_dpp(acc);
 }
 
 // a zero-padded [DP][LD] copy of a dense row-major [D][D] matrix in global memory
@@ -515,7 +562,7 @@ __device__ __attribute__((noinline)) float ph_logp(const float* P, int offVd, in
     part = vd[threadIdx.x] * pd;
     if (upd_g) { __attribute__((address_space(1))) float* g = (__attribute__((address_space(1))) float*)upd_g; g[threadIdx.x] += cg * pd; }
   }
-  return block_sum(part, lds + HTA_U(offRed));
+  return block_sum_dpp(part, lds + HTA_U(offRed));
 }
 
 // M (or M^T) v with M [n][ld] and v in LDS; every lane of row (tid >> 3)'s group of 8 returns the row's sum
@@ -582,12 +629,12 @@ __device__ __attribute__((noinline)) float ph_refine_E(int offS, int offG, int o
 // (the first-order terms cancel by the choice of E1; (E1^T Lam E1 - lam_j E1^T E1)_ij = -(E1^T F)_ij cancels one of the two
 // mixed terms) - i.e. second-order perturbation theory: ONE full product M = F E1 instead of T = A X, S = X^T T and Gm = X^T X
 // (2.1 full products), with E2_ij = M_ij / (lam_j' - lam_i'), E2_ii = -1/2 sum_k E1_ki^2.  The caller zeroed the diagonals of A and
-// X before the product; this pass reads M (offM) and E1 (offX, whose unit diagonal it restores), writes E2 to offDst and the
-// corrected eigenvalues to offLam.  Returns max |E2_ij| (1 for NaN / inf / > kFallbackE).  Truncation: |A X2 - X2 Lam'| ~ |F| d^2.
+// X before the product; this pass reads M (offM) and E1 (offX, whose unit diagonal it restores), writes E2 to offDst, E2^T in M's
+// place (a pair owns its two entries of M: the solve then reads both E2 and E2^T row-wise) and the corrected eigenvalues to offLam.  Returns max |E2_ij| (1 for NaN / inf / > kFallbackE).  Truncation: |A X2 - X2 Lam'| ~ |F| d^2.
 __device__ __attribute__((noinline)) float ph_refine_E2(int offM, int offX, int offDst, int offLam, int offRed, int D, int LD) {
   HTA_LDS_BASE();
   D = HTA_U(D); LD = HTA_U(LD);
-  const float* M = lds + HTA_U(offM); float* X = lds + HTA_U(offX);
+  float* M = lds + HTA_U(offM); float* X = lds + HTA_U(offX);
   float* edst = lds + HTA_U(offDst); float* vlam = lds + HTA_U(offLam); float* red = lds + HTA_U(offRed);
   const int tid = threadIdx.x;
   float scale = 0.f;
@@ -603,14 +650,13 @@ __device__ __attribute__((noinline)) float ph_refine_E2(int offM, int offX, int 
       }
     }
     float cs = c0 + c1;
-    cs += __shfl_xor(cs, 1, 64);
-    cs += __shfl_xor(cs, 2, 64);
-    cs += __shfl_xor(cs, 4, 64);
+    cs = sum8_dpp(cs);
     if (seg == 0 && row < D) {
       const float l2 = vlam[row] + M[row * LD + row];
       vlam[row] = l2;
       scale = fabsf(l2);
       edst[row * LD + row] = -0.5f * cs;
+      M[row * LD + row] = -0.5f * cs;
       X[row * LD + row] = 1.f;
     }
   }
@@ -636,6 +682,8 @@ __device__ __attribute__((noinline)) float ph_refine_E2(int offM, int offX, int 
     if (!(fabsf(eu) <= kFallbackE) || !(fabsf(el) <= kFallbackE)) emax = 1.f;
     edst[i * LD + j] = eu;
     edst[j * LD + i] = el;
+    M[i * LD + j] = el;                                            // E2^T
+    M[j * LD + i] = eu;
   }
   return block_max(emax, red);
 }
@@ -798,6 +846,8 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
     bool have_x = false, converged = false, fallback = !softabs;     // Metric.HESSIAN: G = A, no decomposition needed
     float emax_prev = 1.f;
     bool implicit_e = false;          // the last update X (I + E) is applied to the vectors of the solve instead of being formed
+    bool x_antisym = false;           // X = I + E1 straight from the first pass: X + X^T = 2 I exactly (the pairs), so X^T v = 2 v - X v
+    bool et_in_bz = false;            // the closed-form second pass left E2^T in bz (next to E2 in by)
     const bool want_matrix = a.G_out || a.p_out || a.V_out || a.dmetric_out;
     if (softabs) {
       for (int it = 0; it < 4 && !converged && !fallback; ++it) {
@@ -820,6 +870,7 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
           __syncthreads();
           HTA_STAMP(5 + 4 * it);
           emax = ph_refine_E2(bz, bx, by, oLam, oRed, D, LD);
+          et_in_bz = true;
         } else {
           if (have_x) {
             lds_gemm<false, false, false, false>(by, bx, bz, -1, -1, nt, k4, LD);     // T = A X
@@ -847,8 +898,10 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
           lds_gemm<false, false, false, false>(bx, by, bz, bx, -1, nt, k4, LD);       // X <- X + X E
           __syncthreads();
           const int t = bx; bx = bz; bz = t;
+          x_antisym = false; et_in_bz = false;
         } else {
           have_x = true;                                                              // bx = I + E, by = A still
+          x_antisym = true;
         }
         converged = emax <= kConvE;
         HTA_STAMP(7 + 4 * it);
@@ -898,18 +951,24 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
         }
         vlt[i] = lt;
       }
-      logdet = block_sum(ld, red);
+      logdet = block_sum_dpp(ld, red);
+      HTA_STAMP(12);                                            // (12 .. 18: the solve's sub-phases; the passes it = 2, 3 reuse the slots when they run)
       // ---- 4. x = V0 X (X^T m' / lam~)
       if (a.m) {
-        float y = ph_mv8(1, bx, LD, oM, D);
+        // y = X^T m': row-wise products only where the structure allows it (mv8: a third of the column-wise product's time)
+        float y;
         const int row = opaque_tid() >> 3;
+        if (x_antisym && !fallback) { const float xm = ph_mv8(0, bx, LD, oM, D); y = 2.f * vm[row < DP ? row : 0] - xm; }
+        else y = ph_mv8(1, bx, LD, oM, D);
+        HTA_STAMP(13);
         if (implicit_e) {                                       // y <- (I + E^T) y
           __syncthreads();
           if ((tid & 7) == 0 && row < DP) vy[row] = (row < D) ? y : 0.f;
           __syncthreads();
-          y += ph_mv8(1, by, LD, oY, D);
+          y += et_in_bz ? ph_mv8(0, bz, LD, oY, D) : ph_mv8(1, by, LD, oY, D);
           __syncthreads();
         }
+        HTA_STAMP(14);
         float qd = 0.f;
         float wreg = 0.f;
         if ((tid & 7) == 0 && row < DP) {
@@ -918,19 +977,23 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
           (implicit_e ? vx : vy)[row] = w;
           qd = (row < D) ? y * w : 0.f;
         }
-        quad = block_sum(qd, red);
+        quad = block_sum_dpp(qd, red);
+        HTA_STAMP(15);
         if (implicit_e) {                                       // w <- w + E w
           const float ew = ph_mv8(0, by, LD, oX, D);
           __syncthreads();
           if ((tid & 7) == 0 && row < DP) vy[row] = (row < D) ? wreg + ew : 0.f;
           __syncthreads();
         }
+        HTA_STAMP(16);
         const float xp = ph_mv8(0, bx, LD, oY, D);
         __syncthreads();
         if ((tid & 7) == 0 && row < DP) vx[row] = (row < D) ? xp : 0.f;
         __syncthreads();
+        HTA_STAMP(17);
         ph_stage(V0b, by, D, DP, LD);                           // (the E buffer is dead)
         __syncthreads();
+        HTA_STAMP(18);
         if (!general) vres = by;
         const float x = ph_mv8(0, by, LD, oX, D);
         const int orow = opaque_tid() >> 3;
@@ -1006,7 +1069,7 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
         if (!softabs) {
           float ld = 0.f;
           if (tid < D) ld = 2.f * logf(lds0[g + tid * LD + tid]);                     // slogdet (S:728) for a PD metric
-          logdet = block_sum(ld, red);
+          logdet = block_sum_dpp(ld, red);
           if (a.m) {
             if (tid < D) { vy[tid] = a.m[b * D + tid]; vx[tid] = vy[tid]; }
             ph_chol_solve(g, D, LD, oY);
@@ -1016,7 +1079,7 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
               if (a.x_out) a.x_out[b * D + tid] = vy[tid];
               if (a.upd_x) a.upd_x[b * D + tid] += (float)a.cx * vy[tid];
             }
-            quad = block_sum(qd, red);
+            quad = block_sum_dpp(qd, red);
           }
         }
         if (a.p_out) {                   // p = L z  (S:184 via MultivariateNormal.rsample)

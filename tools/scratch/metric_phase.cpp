@@ -44,10 +44,16 @@ int main(int argc, char** argv) {
   const char* names[32] = {"start", "operands+V0 stage", "logp + V0^T m", "formation", "it0 begin", "it0 gemms", "it0 E", "it0 X", "it1 begin", "it1 products (F E1 | T,S,Gm)", "it1 E", "it1 X update",
                            "it2 begin", "it2 gemms", "it2 E", "it2 X", "it3 begin", "it3 gemms", "it3 E", "it3 X", "refine end", "softabs+solve", "G assembly", "cholesky", "end"};
   long long prev = t[0];
-  for (int k = 1; k <= 24; ++k) { if (t[k] > prev) { printf("  %-22s %8lld cycles\n", names[k], t[k] - prev); prev = t[k]; } }
+  for (int k = 1; k <= 24; ++k) {
+    if (k >= 12 && k <= 19 && t[k] > t[20]) continue;      // the slots of the passes it = 2, 3 hold the solve's sub-phase stamps when those passes do not run
+    if (t[k] > prev) { printf("  %-22s %8lld cycles\n", names[k], t[k] - prev); prev = t[k]; }
+  }
   printf("  total %lld cycles\n", prev - t[0]);
   printf("  formation product, wave 0 (cycles since the phase began): entry %lld | k loop begins %lld | k loop ends %lld | returned %lld | after the barrier %lld | diagonal added %lld | phase ends %lld\n",
          t[25] - t[2], t[26] - t[2], t[27] - t[2], t[28] - t[2], t[29] - t[2], t[30] - t[2], t[3] - t[2]);
+  if (!gibbs)
+    printf("  solve sub-phases: soft-abs map + log-det sum %lld | X^T m' %lld | + E^T y %lld | w, quad sum %lld | + E w %lld | X w %lld | V0 stage %lld | V0 x', store %lld\n",
+           t[12] - t[20], t[13] - t[12], t[14] - t[13], t[15] - t[14], t[16] - t[15], t[17] - t[16], t[18] - t[17], t[21] - t[18]);
   long long w[16][4]; hipMemcpyFromSymbol(w, HIP_SYMBOL(hta::hta_metric_wdbg), sizeof(w));
   for (int k = 0; k < 16; ++k) printf("    wave %2d: entry %6lld  k loop %6lld .. %6lld  returned %6lld\n", k, w[k][0] - t[2], w[k][1] - t[2], w[k][2] - t[2], w[k][3] - t[2]);
   return 0;
