@@ -179,8 +179,8 @@ def _cfg3(ht, dtype=torch.float32):
     return t, o
 
 
-@pytest.mark.parametrize("C,N,nsel,route", [(256, 4, 32, "rmhmc_uvc_kernel<co>"), (512, 3, 32, "rmhmc_uvc2_kernel<co>"),
-                                            (1024, 3, 64, "rmhmc_uvc2_kernel<co>"), (2048, 3, 32, "rmhmc_mfma4_kernel<true>"),
+@pytest.mark.parametrize("C,N,nsel,route", [(256, 5, 32, "rmhmc_uvc_kernel<co>"), (512, 3, 32, "rmhmc_uvc2_kernel<co>"),
+                                            (1024, 3, 128, "rmhmc_uvc2_kernel<co>"), (2048, 3, 32, "rmhmc_mfma4_kernel<true>"),
                                             (4096, 3, 32, "rmhmc_batch_kernel<25,true>")])
 def test_cfg3_bench_instances_vs_oracle_L10(ht, C, N, nsel, route):
     """The trajectory kernels bench.py times for cfg3 (256 chains), the north-star 1024-chain size and cfg5's 4096-chain

@@ -1287,7 +1287,7 @@ def test_uvc_kernel_vs_oracle_at_cfg3(ht, co):
     reference's eigendecomposition per metric evaluation (S:108-122), on the same Philox streams: 32 chains spread over the
     batch, chain by chain; both register budgets of the kernel (one and two workgroups per CU)."""
     from hamiltorch_amd import _abi
-    C, N, nsel, D, L, eps, omega, alpha, jitter, seed, off = 256, 4 if co else 2, 32, 100, 10, 0.1, 10.0, 1e6, 1e-3, 2026, 7      # (the oracle's eigendecompositions are the test's time: the default instance gets the longer run)
+    C, N, nsel, D, L, eps, omega, alpha, jitter, seed, off = 256, 4, 32, 100, 10, 0.1, 10.0, 1e6, 1e-3, 2026, 7
     t, o = cfg3_target(ht, D, torch.float32)
     th0 = (0.1 * O.philox_normals(seed, off + np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32)
     try:
