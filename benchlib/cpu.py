@@ -1,0 +1,122 @@
+"""bench.py's `cpu_baseline` leg: one single-threaded chain of the reference (or its pinned port) per usable host core."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _usable_cores():
+    """(logical CPUs visible, CPUs this process may actually keep busy: affinity mask and cgroup CPU quota)."""
+    avail = os.cpu_count() or 1
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else avail
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())          # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return avail, n
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _median3(fn):
+    """Median-by-value of three runs of fn() -> dict with "value" (repeat >= 3x, report the median)."""
+    runs = [fn() for _ in range(3)]
+    runs.sort(key=lambda r: r["value"])
+    out = runs[1]
+    out["repeats"] = [r["value"] for r in runs]
+    return out
+
+
+PINNED = {
+    "cfg2": "tests/golden/cfg2.npz (test_torch_port_cfg2_bit_identical: the port reproduces the unmodified reference's sample() bit for bit)",
+    "cfg3": "tests/golden/cfg3.npz (test_torch_port_cfg3_with_jitter_matches_reference_run)",
+    "cfg4": "tests/golden/cfg4.npz (test_torch_port_cfg4_full_size_matches_reference_run)",
+    "nbmlp": "tests/golden/nbmlp.npz (test_torch_port_nbmlp_matches_reference_run)",
+    "nbmlp-full": "tests/golden/nbmlp.npz (test_torch_port_nbmlp_matches_reference_run)",
+    "funnel-hmc": "tests/golden/funnel_hmc.npz (test_torch_port_funnel_hmc_matches_reference_run)",
+    "funnel-rmhmc": "tests/golden/funnel.npz (the oracle's explicit RMHMC on the funnel against the reference's recorded paths)",
+}
+
+
+def cpu_baseline_procs(key, seconds, rounds=1):
+    """one single-threaded chain per process, one process per usable host core (affinity mask / cgroup quota;
+    HTA_BENCH_CPU_PROCS caps it), rate = all leapfrog steps / the slowest process's sampling time.  Each process is
+    oracle/cpu_baseline.py: the UNMODIFIED reference when it is importable on this host (`kind: "reference"`), else the
+    per-chain port pinned to the reference's recorded runs (`kind: "port"`).  `rounds` > 1: the median round."""
+    import subprocess
+    avail, procs = _usable_cores()
+    procs = max(1, min(procs, int(os.environ.get("HTA_BENCH_CPU_PROCS", "64"))))
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="",
+               PYTHONDONTWRITEBYTECODE="1")
+    from hamiltorch_amd.ess import ess_min
+
+    def once(rep):
+        t0 = time.time()
+        ps = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), key, str(1000 + 97 * rep + i),
+                                repr(float(seconds) / rounds)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True)
+              for i in range(procs)]
+        res, causes = [], {}
+        for p_ in ps:
+            out_, err_ = p_.communicate(timeout=300 + 30 * seconds)
+            try:
+                res.append(json.loads(out_.strip().splitlines()[-1]))
+            except (IndexError, ValueError):
+                # a worker that ended in an exception: the last line of its traceback, counted per cause (a
+                # baseline over the survivors is survivorship - the port rejects where the reference rejects, S:1045, so this stays 0)
+                last = (err_.strip().splitlines() or ["no output"])[-1][:120]
+                causes[last] = causes.get(last, 0) + 1
+        failed = sum(causes.values())
+        if not res:
+            raise RuntimeError("cpu_baseline: every worker of %s failed: %r" % (key, causes))
+        procs_ok = len(res)
+        wall = time.time() - t0
+        L = res[0]["L"]
+        steps = sum(r["n"] * r["L"] for r in res)
+        dt = max(r["dt"] for r in res)
+        out = {"value": steps / dt, "unit": "leapfrog-steps/s", "cores": procs_ok, "kind": res[0]["kind"], "workers_failed": failed,
+               "sample": "%d processes x 1 chain x ~%d trajectories x L=%d, one thread each (%s), %.1f s sampling, %.1f s with "
+                         "process start-up%s" % (procs, res[0]["n"], L, res[0]["impl"], dt, wall,
+                                                 "; median of %d such rounds" % rounds if rounds > 1 else ""),
+               "per_core": steps / dt / procs_ok, "samples_per_s": sum(r["n"] for r in res) / dt,
+               "samples_per_s_per_core": sum(r["n"] for r in res) / dt / procs_ok, "acceptance": sum(r["acc"] for r in res) / procs_ok, "host_cores_available": avail, "host_cores_usable": procs}
+        if failed:
+            out["workers_failed_causes"] = causes
+        if "samples" in res[0]:
+            # ESS / s with the device side's estimator: the workers' chains pooled as [S, chains, dims] (truncated to the shortest
+            # chain), min over the coordinates that travelled (`ess_dims`: the first 128 at most)
+            S = min(len(r["samples"]) for r in res)
+            out["ess_dims"] = res[0].get("ess_dims")
+            if S >= 4:
+                pooled = torch.tensor([r["samples"][:S] for r in res], dtype=torch.float64).permute(1, 0, 2)
+                ess = ess_min(pooled)
+                out["ess"] = ess
+                out["ess_draws"] = [S, procs_ok]
+                out["ess_per_sec"] = ess / dt
+        return out
+    reps = sorted((once(r) for r in range(rounds)), key=lambda r: r["value"])
+    out = reps[len(reps) // 2]
+    if rounds > 1:
+        out["repeats"] = [r["value"] for r in reps]
+    out["pinned_to"] = PINNED.get(key, "")
+    return out
+

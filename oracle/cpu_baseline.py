@@ -26,6 +26,7 @@ sys.path.insert(0, HERE)
 import torch  # noqa: E402
 
 SIGMA = [[1.0, 0.6, 0.2], [0.6, 2.0, 0.5], [0.2, 0.5, 0.5]]          # KAT2 / cfg2
+ESS_DIMS = 128                                                       # coordinates of a sample that travel to bench.py for ESS / s
 
 
 def load_reference():
@@ -187,8 +188,11 @@ def main():
     ret, acc = run(n)
     dt = time.time() - t0
     out = {"kind": "reference" if ref else "port", "impl": note, "n": n, "L": L, "dt": dt, "acc": float(acc)}
-    if workload in ("cfg2", "funnel-hmc"):                        # small states: the samples travel, for ESS / s
-        out["samples"] = torch.stack([r.detach().reshape(-1) for r in ret[1:]]).tolist()
+    # the samples travel (first ESS_DIMS coordinates, 6 significant digits), for ESS / s with the estimator bench.py applies to the
+    # device samples (hamiltorch_amd/ess.py over the same coordinates); the reference's output is this list (S:1086-1091)
+    rows = torch.stack([r.detach().reshape(-1)[:ESS_DIMS] for r in ret[1:]])
+    out["ess_dims"] = int(rows.shape[1])
+    out["samples"] = [[float("%.6g" % v) for v in row] for row in rows.tolist()]
     print(json.dumps(out))
 
 

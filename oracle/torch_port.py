@@ -104,10 +104,21 @@ def port_sample(log_prob_func, params_init, num_samples, num_steps_per_sample, s
 # Explicit RMHMC (soft-abs / Hessian metric) -- same cost structure as the reference: every gradient
 # of the Riemannian Hamiltonian is an autograd pass through hessian + eigh + Cholesky (S:395-422).
 # ---------------------------------------------------------------------------------------------------
+class PortLogProbError(Exception):
+    """The port's util.LogProbError (U:23-24): raised where the reference raises it, caught where the reference catches it (S:1045)."""
+
+
+def _bad(t):
+    return not bool(torch.isfinite(t).all())               # util.has_nan_or_inf (U:27-41)
+
+
 def port_fisher(q, log_prob_func, alpha, softabs=True, jitter=None):
-    """S:96-122; jitter draws torch.rand(D) from the global generator exactly where the reference does (S:113-115)."""
+    """S:96-122; jitter draws torch.rand(D) from the global generator exactly where the reference does (S:113-115).  A non-finite
+    Hessian raises (S:110-112) - BEFORE eigh, which today's LAPACK would end with a LinAlgError the reference does not catch."""
     hess = torch.autograd.functional.hessian(log_prob_func, q, create_graph=True)   # S:108
     fish = -hess
+    if _bad(fish):
+        raise PortLogProbError                                                       # S:110-112
     if jitter is not None:
         n = fish.shape[0]
         fish = fish + torch.eye(n) * torch.rand(n) * jitter                         # S:115
@@ -119,23 +130,35 @@ def port_fisher(q, log_prob_func, alpha, softabs=True, jitter=None):
 
 
 def port_rm_hamiltonian(q, p, log_prob_func, alpha, softabs=True, jitter=None):
-    """S:710-731."""
+    """S:710-736, with its three rejection checks (S:715-722, S:733-735)."""
     from numpy import pi
     lp = log_prob_func(q)
     pi_term = q.nelement() * torch.log(2. * torch.tensor(pi))                        # S:712 (float32)
     fish, lam_t = port_fisher(q, log_prob_func, alpha, softabs, jitter)
+    if _bad(fish) or (lam_t is not None and _bad(lam_t)):
+        raise PortLogProbError                                                       # S:715-722
     logdet = lam_t.log().sum() if softabs else torch.slogdet(fish)[1]                # S:726 / S:728
     low = torch.linalg.cholesky(fish)                                                # S:146-148
     y = torch.linalg.solve_triangular(low, p.view(-1, 1), upper=False)
     x = torch.linalg.solve_triangular(low.t(), y, upper=True)
-    return -lp + 0.5 * pi_term + 0.5 * logdet + 0.5 * torch.matmul(p.view(1, -1), x)
+    ham = -lp + 0.5 * pi_term + 0.5 * logdet + 0.5 * torch.matmul(p.view(1, -1), x)
+    if _bad(ham):
+        raise PortLogProbError                                                       # S:733-735
+    return ham
 
 
-def port_explicit_leapfrog(q, p, log_prob_func, steps, step_size, omega, alpha, softabs=True, jitter=None):
-    """S:425-461."""
-    def dH_dq(qq, pp):                                                               # S:395-398
-        qq = qq.detach().requires_grad_()
-        return torch.autograd.grad(port_rm_hamiltonian(qq, pp.detach(), log_prob_func, alpha, softabs, jitter), qq)[0]
+def port_explicit_leapfrog(q, p, log_prob_func, steps, step_size, omega, alpha, softabs=True, jitter=None, jitter_max_tries=10):
+    """S:425-461; a non-finite dH/dtheta redraws the jitter and tries again, at most jitter_max_tries times (S:402-410)."""
+    def dH_dq(qq, pp):                                                               # S:395-412
+        tries = 0
+        while True:
+            qq = qq.detach().requires_grad_()
+            g = torch.autograd.grad(port_rm_hamiltonian(qq, pp.detach(), log_prob_func, alpha, softabs, jitter), qq)[0]
+            if not _bad(g):
+                return g
+            tries += 1
+            if tries > jitter_max_tries:
+                raise PortLogProbError                                               # S:407-409
 
     def dH_dp(qq, pp):                                                               # S:415-422
         pp = pp.detach().requires_grad_(); qq = qq.detach().requires_grad_()
@@ -160,20 +183,24 @@ def port_explicit_leapfrog(q, p, log_prob_func, steps, step_size, omega, alpha, 
 
 def port_sample_rmhmc(log_prob_func, params_init, num_samples, num_steps_per_sample, step_size, omega, alpha, burn=0,
                       softabs=True, jitter=None):
-    """S:969-1026, RMHMC / EXPLICIT branch."""
+    """S:969-1057, RMHMC / EXPLICIT branch; a trajectory that raises the reference's LogProbError is rejected (S:1045-1057)."""
     params = params_init.clone().requires_grad_()
     burn_prev = params_init.clone()
     ret = [params_init.clone()]
     rejected = 0
     for n in range(num_samples):
-        G, _ = port_fisher(params, log_prob_func, alpha, softabs, jitter)
-        p = torch.distributions.MultivariateNormal(torch.zeros_like(params), G).sample()   # S:183-184
-        ham = 2 * port_rm_hamiltonian(params, p, log_prob_func, alpha, softabs, jitter) / 2       # S:822, S:977
-        q_new, p_new = port_explicit_leapfrog(params, p, log_prob_func, num_steps_per_sample, step_size, omega, alpha, softabs, jitter)
-        params = q_new.detach().requires_grad_()
-        new_ham = port_rm_hamiltonian(params, p_new, log_prob_func, alpha, softabs, jitter)       # S:989
-        rho = min(0., float((-new_ham + ham).detach()))
-        if rho >= torch.log(torch.rand(1)):
+        try:
+            G, _ = port_fisher(params, log_prob_func, alpha, softabs, jitter)
+            p = torch.distributions.MultivariateNormal(torch.zeros_like(params), G).sample()   # S:183-184
+            ham = 2 * port_rm_hamiltonian(params, p, log_prob_func, alpha, softabs, jitter) / 2       # S:822, S:977
+            q_new, p_new = port_explicit_leapfrog(params, p, log_prob_func, num_steps_per_sample, step_size, omega, alpha, softabs, jitter)
+            params = q_new.detach().requires_grad_()
+            new_ham = port_rm_hamiltonian(params, p_new, log_prob_func, alpha, softabs, jitter)       # S:989
+            rho = min(0., float((-new_ham + ham).detach()))
+            accept = bool(rho >= torch.log(torch.rand(1)))
+        except PortLogProbError:                                                                  # S:1045
+            accept = False
+        if accept:
             if n > burn:
                 ret.append(q_new.detach())
             else:
@@ -181,10 +208,10 @@ def port_sample_rmhmc(log_prob_func, params_init, num_samples, num_steps_per_sam
         else:
             rejected += 1
             if n > burn:
-                params = ret[-1]
+                params = ret[-1].detach().clone().requires_grad_()
                 ret.append(ret[-1])
             else:
-                params = burn_prev.clone()
+                params = burn_prev.clone().requires_grad_()
     return [t.detach() for t in ret], 1 - rejected / num_samples
 
 
