@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhamiltorch_amd.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 MASS_NONE, MASS_DIAG, MASS_FULL = 0, 1, 2
 
@@ -37,7 +37,8 @@ class HtaMetricArgs(ctypes.Structure):
                 ("mu", c_vp), ("log_norm", c_f64), ("m", c_vp), ("p_out", c_vp), ("x_out", c_vp), ("G_out", c_vp),
                 ("lam_out", c_vp), ("V_out", c_vp), ("L_out", c_vp), ("logdet_out", c_vp), ("quad_out", c_vp),
                 ("H_out", c_vp), ("logp_out", c_vp), ("upd_x", c_vp), ("cx", c_f64), ("upd_g", c_vp), ("cg", c_f64),
-                ("V0", c_vp), ("lam0", c_vp), ("lamraw_out", c_vp), ("dmetric_out", c_vp), ("v0_stride", c_i64)]
+                ("V0", c_vp), ("lam0", c_vp), ("lamraw_out", c_vp), ("dmetric_out", c_vp), ("v0_stride", c_i64),
+                ("workspace", c_vp), ("workspace_bytes", c_i64)]
 
 
 METRIC_HESSIAN, METRIC_SOFTABS = 0, 1
@@ -68,12 +69,12 @@ def _sig(scalar):
                               ctypes.POINTER(scalar), scalar, scalar, c_vp, c_vp, c_vp],
         "hta_netn_hmc_sample": [c_vp, c_vp, c_i64, c_int, ctypes.POINTER(c_int), c_int, c_int, c_vp, c_vp, c_int, c_int, c_int,
                                 ctypes.POINTER(scalar), scalar, scalar, c_int, c_vp, c_vp, c_int, c_int, scalar, c_int,
-                                c_int, c_int, c_u64, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+                                c_int, c_int, c_u64, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
         "hta_netn_logp_grad": [c_vp, c_i64, c_int, ctypes.POINTER(c_int), c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
-                               ctypes.POINTER(scalar), scalar, scalar, c_vp, c_vp, c_vp],
+                               ctypes.POINTER(scalar), scalar, scalar, c_vp, c_vp, c_vp, c_i64, c_vp],
         "hta_net_forward": [c_vp, c_i64, c_int, ctypes.POINTER(c_int), c_int, c_vp, c_int, c_vp, c_vp],
         "hta_rmhmc_gaussian_leapfrog": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_f64, c_int, c_f64, c_u64, c_u64,
-                                        c_u32, c_i64, c_int, c_int, c_f64, c_f64, c_vp, c_vp, c_vp],
+                                        c_u32, c_i64, c_int, c_int, c_f64, c_f64, c_vp, c_vp, c_vp, c_i64, c_vp],
         "hta_rmhmc_binding_rotation": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f64, c_f64, c_vp],
         "hta_rmhmc_gaussian_sample": [c_vp, c_vp, c_vp, c_vp, c_f64, c_int, c_f64, c_int, c_f64, c_i64, c_int, c_int,
                                       c_f64, c_f64, c_int, c_int, c_int, c_u64, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp,
@@ -85,7 +86,8 @@ def _sig(scalar):
 #: every symbol include/hamiltorch_amd.h declares (checked by tests/test_abi_symbols.py)
 PLAIN_SYMBOLS = ["hta_abi_version", "hta_last_error", "hta_device_info", "hta_set_tuning", "hta_get_tuning", "hta_reset_tuning",
                  "hta_last_route", "hta_profile_collect", "hta_counter_add", "hta_run_begin", "hta_rmhmc_gaussian_forget", "hta_hmc_gaussian_forget",
-                 "hta_hmc_gaussian_workspace_bytes", "hta_rmhmc_workspace_bytes"]
+                 "hta_hmc_gaussian_workspace_bytes", "hta_rmhmc_workspace_bytes", "hta_hmc_gaussian_status_offset",
+                 "hta_metric_eval_workspace_bytes", "hta_netn_hmc_workspace_bytes"]
 TYPED_SYMBOLS = sorted(_sig(c_f32).keys())
 
 
@@ -114,6 +116,12 @@ def load():
         lib.hta_profile_collect.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]
         lib.hta_hmc_gaussian_workspace_bytes.argtypes = [c_i64, c_int, c_int, c_int]
         lib.hta_hmc_gaussian_workspace_bytes.restype = c_i64
+        lib.hta_hmc_gaussian_status_offset.argtypes = [c_i64, c_int, c_int, c_int]
+        lib.hta_hmc_gaussian_status_offset.restype = c_i64
+        lib.hta_metric_eval_workspace_bytes.argtypes = [c_i64, c_int, c_int]
+        lib.hta_metric_eval_workspace_bytes.restype = c_i64
+        lib.hta_netn_hmc_workspace_bytes.argtypes = [c_i64, c_int, ctypes.POINTER(c_int), c_int]
+        lib.hta_netn_hmc_workspace_bytes.restype = c_i64
         lib.hta_counter_add.argtypes = [c_vp, c_int, c_vp]
         lib.hta_counter_add.restype = c_int
         lib.hta_run_begin.argtypes = [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]
@@ -338,7 +346,7 @@ def hmc_gaussian_leapfrog(theta, p, P, mu, mass_kind, inv_mass, steps, eps, path
 def metric_eval(like, B, D, metric, Hs, hs_stride, alpha, jitter=None, seed=0, chain_offset=0, draw=0, sub=0, X=None,
                 Pm=None, mu=None, log_norm=0.0, m=None, p_out=None, x_out=None, G_out=None, lam_out=None, V_out=None,
                 L_out=None, logdet_out=None, quad_out=None, H_out=None, logp_out=None, upd_x=None, cx=0.0, upd_g=None,
-                cg=0.0, max_sweeps=0, V0=None, lam0=None, lamraw_out=None, dmetric_out=None, v0_stride=0):
+                cg=0.0, max_sweeps=0, V0=None, lam0=None, lamraw_out=None, dmetric_out=None, v0_stride=0, workspace=None):
     """One batched metric evaluation (see HtaMetricArgs in include/hamiltorch_amd.h).  `like` fixes dtype/device."""
     require_device(like, "params")
     a = HtaMetricArgs()
@@ -355,9 +363,32 @@ def metric_eval(like, B, D, metric, Hs, hs_stride, alpha, jitter=None, seed=0, c
                     ("dmetric_out", dmetric_out)):
         setattr(a, name, None if t is None else _p(t, like).value)
         keep.append(t)
+    ws = scratch(like, metric_eval_workspace_bytes(B, D, like.element_size()), "metric") if workspace is None else workspace
+    a.workspace, a.workspace_bytes = (None, 0) if ws is None else (ws.data_ptr(), ws.numel() * ws.element_size())
     fn = getattr(load(), "hta_metric_eval_" + _suffix(like))
     with torch.cuda.device(like.device):
         _check(fn(ctypes.byref(a), _stream(like)), "hta_metric_eval")
+
+
+def metric_eval_workspace_bytes(B, D, itemsize):
+    """Bytes of HtaMetricArgs::workspace for B systems of size D (0 while both matrices of a system fit one CU's LDS)."""
+    return int(load().hta_metric_eval_workspace_bytes(int(B), int(D), int(itemsize)))
+
+
+_scratch = {}
+
+
+def scratch(like, nbytes, tag):
+    """Caller-side scratch for the ABI's `*_workspace_bytes` contracts (ABI 10: the library allocates nothing): one uint8 tensor per
+    (device, stream, purpose), grown on demand, owned by torch's allocator - visible in its accounting, capturable in a HIP graph.
+    Calls on one stream are ordered, so they may share it; another stream gets another buffer."""
+    if nbytes <= 0:
+        return None
+    key = (like.device, torch.cuda.current_stream(like.device).cuda_stream, tag)
+    t = _scratch.get(key)
+    if t is None or t.numel() < nbytes:
+        t = _scratch[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=like.device)
+    return t
 
 
 def rmhmc_workspace_bytes(C, D, itemsize, n_traj=0, cap_bytes=256 << 20):
@@ -373,11 +404,13 @@ def rmhmc_gaussian_leapfrog(theta, p, theta_c, p_c, P, mu, metric, alpha, jitter
     require_device(theta, "params")
     C, D = theta.shape
     fn = getattr(load(), "hta_rmhmc_gaussian_leapfrog_" + _suffix(theta))
+    ws = scratch(theta, metric_eval_workspace_bytes(C, D, theta.element_size()), "metric")
     with torch.cuda.device(theta.device):
         _check(fn(_p(theta), _p(p, theta), _p(theta_c, theta), _p(p_c, theta), _p(P, theta), _p(mu, theta), int(metric),
                   float(alpha if alpha is not None else 0.0), 0 if jitter is None else 1,
                   0.0 if jitter is None else float(jitter), int(seed), int(chain_offset), int(draw) & 0xFFFFFFFF, C, D,
-                  int(steps), float(eps), float(omega), _p(path_theta, theta), _p(path_p, theta), _stream(theta)),
+                  int(steps), float(eps), float(omega), _p(path_theta, theta), _p(path_p, theta),
+                  None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), _stream(theta)),
                "hta_rmhmc_gaussian_leapfrog")
 
 
@@ -471,17 +504,19 @@ def _net_operands(like, dims, taus):
 
 def netn_hmc_sample(theta, theta_init, dims, act, X, Y, M, Nb, taus, tau_out, prior_scale, mass_kind, inv_mass, mass_factor,
                     L, eps, n_traj, traj_offset, burn, seed, chain_offset, samples, reject_count, H_old=None, H_new=None,
-                    accept=None, integrator=0, loss="regression"):
+                    accept=None, integrator=0, loss="regression", workspace=None):
     require_device(theta, "params")
     C = theta.shape[0]
     nl, cd, ct = _net_operands(theta, dims, taus)
     fn = getattr(load(), "hta_netn_hmc_sample_" + _suffix(theta))
+    ws = scratch(theta, netn_hmc_workspace_bytes(C, dims, theta.element_size()), "netn") if workspace is None else workspace
     with torch.cuda.device(theta.device):
         _check(fn(_p(theta), _p(theta_init, theta), C, nl, cd, ACTS[act], NET_LOSSES[loss], _p(X, theta), _p(Y, theta),
                   X.shape[0], int(M), int(Nb), ct, float(tau_out), float(prior_scale), mass_kind, _p(inv_mass, theta),
                   _p(mass_factor, theta), int(integrator), int(L), float(eps), int(n_traj), int(traj_offset), int(burn),
                   int(seed), int(chain_offset), _p(samples, theta), _p(reject_count), _p(H_old, theta), _p(H_new, theta),
-                  _p(accept), _stream(theta)), "hta_netn_hmc_sample")
+                  _p(accept), None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), _stream(theta)),
+               "hta_netn_hmc_sample")
 
 
 def net_forward(theta, dims, act, X, out):
@@ -499,7 +534,24 @@ def netn_logp_grad(theta, dims, act, X, Y, M, Nb, split, taus, tau_out, prior_sc
     C = theta.shape[0]
     nl, cd, ct = _net_operands(theta, dims, taus)
     fn = getattr(load(), "hta_netn_logp_grad_" + _suffix(theta))
+    ws = scratch(theta, netn_hmc_workspace_bytes(C, dims, theta.element_size()), "netn")
     with torch.cuda.device(theta.device):
         _check(fn(_p(theta), C, nl, cd, ACTS[act], NET_LOSSES[loss], _p(X, theta), _p(Y, theta), X.shape[0], int(M), int(Nb),
                   int(split), ct, float(tau_out), float(prior_scale), _p(grad_out, theta), _p(logp_out, theta),
-                  _stream(theta)), "hta_netn_logp_grad")
+                  None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), _stream(theta)), "hta_netn_logp_grad")
+
+
+def netn_hmc_workspace_bytes(C, dims, itemsize):
+    """Bytes of the `workspace` argument of hta_netn_hmc_sample / hta_netn_logp_grad (non-zero on the matrix-core route's shapes only)."""
+    cd = (c_int * len(dims))(*[int(v) for v in dims])
+    return int(load().hta_netn_hmc_workspace_bytes(int(C), len(dims) - 1, cd, int(itemsize)))
+
+
+def hmc_gaussian_status_word(workspace, C, D, n_traj, itemsize):
+    """The sticky status word of a prepared Gaussian-HMC workspace as a 1-element int32 view of it (include/hamiltorch_amd.h:
+    hta_hmc_gaussian_status_offset), or None for shapes without the fused route.  Non-zero after a synchronise = a fused launch
+    gave up waiting for its draw records: the samples since the preparation are invalid (and NaN)."""
+    off = int(load().hta_hmc_gaussian_status_offset(int(C), int(D), int(n_traj), int(itemsize)))
+    if off < 0 or workspace is None or off + 4 > workspace.numel():
+        return None
+    return workspace[off:off + 4].view(torch.int32)

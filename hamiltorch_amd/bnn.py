@@ -397,10 +397,31 @@ def _native_forward_ok(model, stacked, x, model_loss):
         return None
     if x.dim() != 2 or x.shape[1] != dims[0] or stacked.shape[1] != sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(len(dims) - 1)):
         return None
-    nl = len(dims) - 1
-    if not ((nl == 2 and dims[-1] <= 16) or (nl <= 8 and max(dims[:-1]) <= 256)):        # csrc/net_forward.hip
+    if not native_forward_fits(dims, stacked.element_size()):
         return None
     return dims, act
+
+
+#: csrc/net_forward.hip: FW_MAXW (widest staged layer), FW_MAXO (outputs of the streamed one-hidden-layer form), FW_TPB (points per
+#: workgroup), FW_MAXL (Linear layers), and the LDS of one CU
+_FW_MAXW, _FW_MAXO, _FW_TPB, _FW_MAXL, _FW_LDS = 256, 16, 64, 8, 160 * 1024
+
+
+def native_forward_fits(dims, itemsize):
+    """The limits hta_net_forward checks (csrc/net_forward.hip: net_forward), mirrored so that a model outside them takes the
+    torch path instead of raising: the activations of one layer for FW_TPB points are staged twice in LDS, so the widest staged
+    layer - the input alone in the streamed form (one hidden layer wider than FW_MAXW, <= FW_MAXO outputs), every input / hidden
+    width otherwise - is bounded by FW_MAXW AND by 160 KiB / (2 x FW_TPB x itemsize): 784 inputs or 200-wide float64 layers do
+    not fit (the gate admitted them and predict_model raised)."""
+    nl = len(dims) - 1
+    if nl < 1 or nl > _FW_MAXL or min(dims) < 1:
+        return False
+    streamed = nl == 2 and dims[2] <= _FW_MAXO and dims[1] > _FW_MAXW
+    wmax = dims[0] if streamed else max(dims[:-1])
+    wmax = (wmax + 3) & ~3
+    if wmax > _FW_MAXW and not streamed:
+        return False
+    return 2 * wmax * _FW_TPB * itemsize <= _FW_LDS
 
 
 def _native_log_probs(stacked, out, y, sizes, tau_list, tau_out, model_loss, prior_scale):
@@ -442,7 +463,11 @@ def _predict_batch_native(model, stacked, x, y, sizes, tau_list, tau_out, model_
     X = x.to(device=stacked.device, dtype=stacked.dtype).contiguous()
     out = torch.empty(stacked.shape[0], X.shape[0], dims[-1], dtype=stacked.dtype, device=stacked.device)
     lp = None
-    _abi.net_forward(stacked, dims, act, X, out)
+    try:
+        _abi.net_forward(stacked, dims, act, X, out)
+    except RuntimeError:                 # a limit of the kernel the gate above does not know: the torch path answers
+        predict_route["native_refused"] = _abi.last_error() if hasattr(_abi, "last_error") else "hta_net_forward refused"
+        return None
     lp = _native_log_probs(stacked, out, y, sizes, tau_list, tau_out, model_loss, prior_scale)
     if lp is None:
         return None

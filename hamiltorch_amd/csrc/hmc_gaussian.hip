@@ -769,7 +769,15 @@ template <int I, int N, typename F> __device__ __forceinline__ void quad_static_
 // loop, that the rows the pass prefetches are complete (`ready`: a register compare), polling a chunk's counter only when it
 // crosses into that chunk, with the next chunk's counter requested one chunk ahead.  Same records, same arithmetic: results are
 // bit-identical to the two-launch form.
-struct QuadFused { uint32_t* flags; int ch; uint32_t target; int nchunks; };
+// HAND-OVER FAILURE (round 5).  The consumers wait for producers of the SAME grid: that is safe only while both are resident, which
+// a launch of 80-320 blocks on an idle 256-CU chip is, and a shared or preempted GPU need not be.  The wait is bounded; a consumer
+// whose bound expires does NOT read on (round 4 did: plausible, wrong samples with rc 0): it raises the workspace's STICKY status
+// word (`err`: set with an atomic OR, zeroed only by hta_hmc_gaussian_prepare, readable by the host at the byte offset
+// hta_hmc_gaussian_status_offset returns), stops waiting, and when its trajectories are done overwrites every row it stored in this
+// launch and its slot of the chain state with NaN - the failure is in the data as well as in the word.  All of it is off the hot
+// path (inside the once-per-chunk poll and after the loops).  Debug key "quad_starve" makes the producers leave at once (the test
+// of this path: tests/test_gpu_hmc.py::test_fused_launch_reports_starved_producers).
+struct QuadFused { uint32_t* flags; int ch; uint32_t target; int nchunks; uint32_t* err; int starve; };
 template <int D, bool DIAG, int LB, int VAR, bool FUSED>
 __device__ __forceinline__ void quad_body(const GaussArgs<float>& a, const float* __restrict__ eig, const int64_t gt, const QuadFused fz) {
   typedef float T;
@@ -781,6 +789,7 @@ __device__ __forceinline__ void quad_body(const GaussArgs<float>& a, const float
   // chunk was confirmed (pf).  The hot path pays one compare per pass; the poll runs once per chunk, out of the straight line.
   int ready = 0;
   uint32_t pf = 0;
+  bool starved = false;
   if constexpr (FUSED) pf = __hip_atomic_load(fz.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   auto need_rows = [&](int upto) {              // rows up to `upto` are about to be read (rows >= n_traj are slack: never produced)
     if constexpr (FUSED) {
@@ -789,11 +798,17 @@ __device__ __forceinline__ void quad_body(const GaussArgs<float>& a, const float
           const int chn = ready / fz.ch;
           if (chn >= fz.nchunks) { ready = 0x7fffffff; break; }
           uint32_t v = pf;
-          // (bounded: a producer that never counts - which cannot happen: producers wait for nothing - would otherwise hang the
-          //  queue; after ~1 s of polling the consumer reads on, and the parity tests see the difference)
+          // (bounded - ~1 s of polling: producers wait for nothing, so they count as soon as they are scheduled; one that is not
+          //  would otherwise hang the queue)
           for (int spin = 0; v < fz.target && spin < (1 << 20); ++spin) {
             __builtin_amdgcn_s_sleep(4);
             v = __hip_atomic_load(fz.flags + chn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (__builtin_expect(v < fz.target, 0)) {          // the bound expired: sticky status word, no more waiting, NaN rows at the end
+            __hip_atomic_fetch_or(fz.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            starved = true;
+            ready = 0x7fffffff;
+            break;
           }
           ready += fz.ch;
           pf = chn + 1 < fz.nchunks ? __hip_atomic_load(fz.flags + chn + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -1066,13 +1081,22 @@ __device__ __forceinline__ void quad_body(const GaussArgs<float>& a, const float
       while (t < t_end) { trajectory(zs[0], lus[0], plain, first); rotate(); }
     }
   }
+  if constexpr (FUSED) {
+    if (__builtin_expect(starved, 0)) {           // see QuadFused: the rows of this launch and the chain state become NaN
+      qc = __builtin_nanf("");
+      if (a.samples) {
+        const size_t r0 = (size_t)max(a.traj_offset + n_burn - a.burn, 1);
+        for (int tt = n_burn; tt < a.n_traj; ++tt) put((gwbytes_t)(a.samples + (r0 + (size_t)(tt - n_burn)) * C * D), qc);
+      }
+    }
+  }
   put((gwbytes_t)a.theta, qc);
   if (a.reject_count && k == 0) a.reject_count[c] += a.n_traj - accepted;
 }
 
 template <int D, bool DIAG, int LB, int VAR = 0>
 __global__ __launch_bounds__(64) void hmc_gauss_quad_kernel(GaussArgs<float> a, const float* __restrict__ eig) {
-  quad_body<D, DIAG, LB, VAR, false>(a, eig, blockIdx.x * (int64_t)blockDim.x + threadIdx.x, QuadFused{nullptr, 1, 0u, 0});
+  quad_body<D, DIAG, LB, VAR, false>(a, eig, blockIdx.x * (int64_t)blockDim.x + threadIdx.x, QuadFused{nullptr, 1, 0u, 0, nullptr, 0});
 }
 
 // one record (csrc: rng_fill_small_kernel's body): the draws of (trajectory t, chain c), rotated into the eigenbasis
@@ -1121,6 +1145,7 @@ __global__ __launch_bounds__(QUAD_FUSED_NT) void hmc_gauss_quad_fused_kernel(Gau
   if ((int)blockIdx.x >= nc) {
     // producer block b of spc: its slices of every chunk, chunk by chunk; one count per block and chunk
     const int b = (int)blockIdx.x - nc;
+    if (fz.starve) return;                                                        // debug key "quad_starve": a producer that is never scheduled
     const int64_t per_chunk = (int64_t)fz.ch * a.C, total = (int64_t)a.n_traj * a.C;
     for (int chn = 0; chn < fz.nchunks; ++chn) {
       const int64_t base = (int64_t)chn * per_chunk, end = min(base + per_chunk, total);
@@ -1508,6 +1533,9 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void leapfrog_gauss_wave_kernel(Gau
 constexpr int QUAD_FUSED_CHUNKS = 64, QUAD_FUSED_OFF = 56;      // (capacity; "quad_chunks" of them are used)
 int g_quad_chunks = 8;       // tuning key "quad_chunks": chunks per fused launch (<= 64; measured 4 ... 60: profiles/r04k_quad_fused_sweep.txt)      // counters in the free tail of the eig block (D <= 4 uses 52 of 128 elements)
 int g_quad_producers = 64;   // tuning key "quad_producers": producer blocks (four waves each) of the fused launch per 1024 chains
+int g_quad_starve = 0;       // debug key "quad_starve": 1 = the producers of the fused launch leave without producing (exercises the consumers' bounded wait)
+constexpr int QUAD_STATUS_OFF = QUAD_FUSED_OFF + QUAD_FUSED_CHUNKS + 1;         // element of the eig block that holds the sticky status word
+static_assert(QUAD_STATUS_OFF < 128, "the status word lives in the eig block's free tail");
 int g_quad_fused = 1;        // tuning key "quad_fused" (default 1): records produced inside the trajectory launch (prepared workspaces only); 0 = a pre-draw launch in front of it
 template <typename T> static bool eig_block_prepared(const GaussArgs<T>& a, int mass_kind);
 template <typename T> static bool quad_route(const GaussArgs<T>& a);
@@ -1554,6 +1582,8 @@ template <typename T, int D, int MASS> void launch_small(const GaussArgs<T>& a, 
           const int qgrid = (int)((a.C * 4 + QUAD_FUSED_NT - 1) / QUAD_FUSED_NT);         // consumer blocks of this launch shape
           fz.flags = reinterpret_cast<uint32_t*>(a.ws_logu + QUAD_FUSED_OFF);
           uint32_t* done = fz.flags + QUAD_FUSED_CHUNKS;
+          fz.err = done + 1;                                                                  // the sticky status word (QUAD_STATUS_OFF)
+          fz.starve = g_quad_starve;
           (void)W;
           note_route("hmc_gauss_quad_fused_kernel<%d,%d>", D, lbv);
           const int fgrid = qgrid + spc;
@@ -1621,8 +1651,10 @@ template <typename T, int R, int MASS> void launch_wave(const GaussArgs<T>& a, b
 }
 // eigenbasis route of the wave kernel: identity mass, an eig area in the workspace, D within the Jacobi kernel's reach
 template <typename T> static bool wave_eig_route(const GaussArgs<T>& a, int kind, bool lf_only) {
-  return !lf_only && kind == HTA_MASS_NONE && g_gauss_eig && a.ws_logu && a.D <= (sizeof(T) == 4 ? 128 : 96);
+  return !lf_only && kind == HTA_MASS_NONE && g_gauss_eig && a.ws_logu && a.D <= 128;     // (R <= 2; fp64 beyond 99: the diagonalisation works in the workspace's slab)
 }
+// the eig area V | Vt | lam of the wave kernels' eigenbasis route, rounded to 16 bytes (a metric slab may follow)
+static int64_t wave_eig_area_bytes(int D, int elem) { return (((int64_t)2 * D * D + D + 64) * elem + 15) & ~(int64_t)15; }
 template <typename T, int R> int launch_wave_eig(const GaussArgs<T>& a, hipStream_t s) {
   const int D = a.D;
   T* V = a.ws_logu; T* Vt = V + (int64_t)D * D; T* lam = Vt + (int64_t)D * D;
@@ -1630,6 +1662,8 @@ template <typename T, int R> int launch_wave_eig(const GaussArgs<T>& a, hipStrea
   memset(&m0, 0, sizeof(m0));
   m0.B = 1; m0.D = D; m0.metric = HTA_METRIC_SOFTABS; m0.Hs = a.P; m0.hs_stride = 0; m0.alpha = 1.0;
   m0.V_out = V; m0.lamraw_out = lam;
+  m0.workspace_bytes = metric_eval_workspace_bytes(1, D, (int)sizeof(T));             // behind the eig area (hta_hmc_gaussian_workspace_bytes)
+  m0.workspace = m0.workspace_bytes ? (char*)V + wave_eig_area_bytes(D, (int)sizeof(T)) : nullptr;
   const int rc = metric_eval<T>(m0, s);
   if (rc) return rc;
   transpose_kernel<T><<<(D * D + 255) / 256, 256, 0, s>>>(V, Vt, D);
@@ -1776,12 +1810,18 @@ int hta_hmc_gaussian_forget(void* workspace) {
 }
 
 int64_t hta_hmc_gaussian_workspace_bytes(int64_t C, int D, int n_traj, int elem_size) {
-  if (D > 6)      /* wave-per-chain kernels draw inline: only the eig area V | Vt | lam of the eigenbasis route */
-    return ((int64_t)2 * D * D + D + 64) * elem_size;
+  if (D > 6)      /* wave-per-chain kernels draw inline: only the eig area V | Vt | lam of the eigenbasis route (+ the slab of its one
+                     diagonalisation where D x D does not fit one CU's LDS twice: fp64 from D = 100) */
+    return hta::wave_eig_area_bytes(D, elem_size) + (D <= 128 ? hta::metric_eval_workspace_bytes(1, D, elem_size) : 0);
   const int per_vec = 16 / elem_size;
   const int64_t rec = ((int64_t)(D + 1 + per_vec - 1) / per_vec) * per_vec;
   /* + four rows read ahead by the last trajectories, + the eigen block (lam, Qt, Tin, Tout; D <= 6) of the eigenbasis route */
   return ((int64_t)n_traj + 4) * C * rec * elem_size + (D <= 6 ? hta::EIG_ELEMS * elem_size : 0);
+}
+
+int64_t hta_hmc_gaussian_status_offset(int64_t C, int D, int n_traj, int elem_size) {
+  if (D < 1 || D > 4 || elem_size != 4 || C <= 0 || n_traj < 0) return -1;                /* the fused quad route: fp32, D <= 4 */
+  return hta_hmc_gaussian_workspace_bytes(C, D, n_traj, elem_size) - hta::EIG_ELEMS * elem_size + hta::QUAD_STATUS_OFF * 4;
 }
 
 #define HTA_DEFINE_GAUSS(SUF, T)                                                                               \

@@ -781,22 +781,25 @@ bool mlp3_eligible(const NetArgs<float>& a) {
   return a.dims[1] > NETN_MAX_WIDTH || a.dims[2] > NETN_MAX_WIDTH || D > 64 * NETN_KMAX || g_mlp3_route == 2;
 }
 
-// The momentum workspace (see M3Chain::pw): one slot of 7 x 448 float4 per workgroup, cached per (device, stream) - launches
-// on one stream are ordered, launches on different streams get different buffers - grown on demand, never freed (a handful
-// of entries of a few MB: like the side stream of the RMHMC path, a resource created on first use).
-static float* mlp3_workspace(hipStream_t s, size_t bytes) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, std::pair<void*, size_t>> cache;
-  std::lock_guard<std::mutex> lock(mu);
+// The momentum workspace (see M3Chain::pw): one slot of 7 x 448 float4 per workgroup.  ABI 10: it is the CALLER's memory
+// (hta_netn_hmc_workspace_bytes -> the `workspace` argument of hta_netn_hmc_sample / hta_netn_logp_grad); rounds 3-4 kept a
+// hipMalloc'ed buffer per (device, stream) behind the ABI, grown with a hipStreamSynchronize + hipFree - an allocation and a
+// synchronisation the boundary promises not to make, and a launch that could not be captured in a HIP graph.
+static int mlp3_grid(int64_t C) {
+  int cus = 256;
   int dev = 0;
-  (void)hipGetDevice(&dev);
-  auto& e = cache[{dev, s}];
-  if (e.second < bytes) {
-    if (e.first) { (void)hipStreamSynchronize(s); (void)hipFree(e.first); e.first = nullptr; e.second = 0; }
-    if (hipMalloc(&e.first, bytes) != hipSuccess) { e.first = nullptr; return nullptr; }
-    e.second = bytes;
-  }
-  return static_cast<float*>(e.first);
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  // one workgroup per CU is resident (151 KB of LDS); twice that many in the grid keeps the tail short, each workgroup walks
+  // its chains in a grid-stride loop
+  const int64_t gmax = 2 * (int64_t)cus;
+  return (int)(C < gmax ? C : gmax);
+}
+int64_t mlp3_workspace_bytes(int64_t C, int n_layers, const int* dims) {
+  if (n_layers != 3 || !dims || C <= 0 || dims[3] != 1) return 0;
+  if (dims[0] < 1 || dims[0] > M3_NIN || dims[1] < 1 || dims[1] > M3_HMAX || dims[2] < 1 || dims[2] > M3_HMAX) return 0;
+  const int D = dims[0] * dims[1] + dims[1] + dims[1] * dims[2] + 2 * dims[2] + 1;
+  if (!(dims[1] > NETN_MAX_WIDTH || dims[2] > NETN_MAX_WIDTH || D > 64 * NETN_KMAX || g_mlp3_route == 2)) return 0;   // mlp3_eligible's size test
+  return (int64_t)mlp3_grid(C) * 7 * M3_NT * 4 * (int64_t)sizeof(float);
 }
 
 template <int ACT> static int launch_mlp3(const NetArgs<float>& a, hipStream_t s) {
@@ -808,17 +811,11 @@ template <int ACT> static int launch_mlp3(const NetArgs<float>& a, hipStream_t s
     if (e != hipSuccess) { set_error("hta_netn_hmc (mlp3): hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
     done = true;
   }
-  int cus = 256;
-  {
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  }
-  // one workgroup per CU is resident (151 KB of LDS); twice that many in the grid keeps the tail short, each workgroup walks
-  // its chains in a grid-stride loop
-  const int64_t gmax = 2 * (int64_t)cus;
-  const int grid = (int)(a.C < gmax ? a.C : gmax);
-  float* pws = mlp3_workspace(s, (size_t)grid * 7 * M3_NT * 4 * sizeof(float));
-  if (!pws) { set_error("hta_netn_hmc (mlp3): no memory for the momentum workspace (%d workgroups)", grid); return HTA_ERR_LAUNCH; }
+  const int grid = mlp3_grid(a.C);
+  const int64_t need = (int64_t)grid * 7 * M3_NT * 4 * (int64_t)sizeof(float);
+  HTA_REQUIRE(a.workspace && a.workspace_bytes >= need, "hta_netn_hmc (mlp3): workspace of %lld bytes required (hta_netn_hmc_workspace_bytes)",
+              (long long)need);
+  float* pws = static_cast<float*>(a.workspace);
   profile_begin(s);
   note_route("mlp3_mfma_kernel<%d>", ACT);
   mlp3_mfma_kernel<ACT><<<grid, M3_NT, lds, s>>>(a, NP, pws);

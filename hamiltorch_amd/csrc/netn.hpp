@@ -21,11 +21,13 @@ template <typename T> struct NetArgs {
   T* samples; int32_t* reject_count; T* H_old; T* H_new; uint8_t* accept;
   T* grad_out; T* logp_out; int eval_split;
   int integ;
+  void* workspace; int64_t workspace_bytes;     // ABI 10: caller-owned scratch (hta_netn_hmc_workspace_bytes; mlp3 route: the momentum slots)
 };
 
 // csrc/mlp3_mfma.hip: Linear(n_in, H1)-act-Linear(H1, H2)-act-Linear(H2, 1), Gaussian likelihood, fp32, H1, H2 <= 104
 extern int g_mlp3_route;                                      // tuning key "mlp3_route" (default 1)
 bool mlp3_eligible(const NetArgs<float>& a);
 int mlp3_mfma(const NetArgs<float>& a, hipStream_t s);
+int64_t mlp3_workspace_bytes(int64_t C, int n_layers, const int* dims);     // 0 = these shapes never take the matrix-core route
 
 }  // namespace hta

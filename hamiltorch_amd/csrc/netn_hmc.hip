@@ -755,28 +755,34 @@ extern "C" {
                                 int loss_kind, const T* X, const T* Y, int N, int M, int Nb, const T* taus, T tau_out,   \
                                 T prior_scale, int mass_kind, const T* inv_mass, const T* mass_factor, int integrator,   \
                                 int L, T eps, int n_traj, int traj_offset, int burn, uint64_t seed, uint64_t chain_offset, \
-                                T* samples, int32_t* reject_count, T* H_old, T* H_new, uint8_t* accept, void* stream) {  \
+                                T* samples, int32_t* reject_count, T* H_old, T* H_new, uint8_t* accept, void* workspace, \
+                                int64_t workspace_bytes, void* stream) {                                                 \
     hta::NetArgs<T> a{};                                                                                                 \
     if (int rc = hta::netn_fill<T>(a, n_layers, dims, taus)) return rc;                                                  \
     a.theta = theta; a.theta_init = theta_init; a.C = C; a.act = act; a.loss = loss_kind; a.X = X; a.Y = Y; a.N = N;      \
     a.M = M; a.Nb = Nb; a.tau_out = tau_out; a.prior_scale = prior_scale; a.mass_kind = mass_kind; a.inv_mass = inv_mass; \
     a.mass_factor = mass_factor; a.L = L; a.eps = eps; a.n_traj = n_traj; a.traj_offset = traj_offset; a.burn = burn;    \
     a.seed = seed; a.chain_offset = chain_offset; a.samples = samples; a.reject_count = reject_count; a.H_old = H_old;   \
-    a.H_new = H_new; a.accept = accept; a.integ = integrator;                                                            \
+    a.H_new = H_new; a.accept = accept; a.integ = integrator; a.workspace = workspace; a.workspace_bytes = workspace_bytes; \
     if (n_traj <= 0) return HTA_OK;                                                                                      \
     return hta::netn_hmc<T>(a, (hipStream_t)stream);                                                                     \
   }                                                                                                                      \
   int hta_netn_logp_grad_##SUF(const T* theta, int64_t C, int n_layers, const int* dims, int act, int loss_kind, const T* X, \
                                const T* Y, int N, int M, int Nb, int split, const T* taus, T tau_out, T prior_scale,     \
-                               T* grad_out, T* logp_out, void* stream) {                                                 \
+                               T* grad_out, T* logp_out, void* workspace, int64_t workspace_bytes, void* stream) {       \
     hta::NetArgs<T> a{};                                                                                                 \
     if (int rc = hta::netn_fill<T>(a, n_layers, dims, taus)) return rc;                                                  \
     a.theta = const_cast<T*>(theta); a.C = C; a.act = act; a.loss = loss_kind; a.X = X; a.Y = Y; a.N = N; a.M = M;        \
     a.Nb = Nb; a.tau_out = tau_out; a.prior_scale = prior_scale; a.mass_kind = HTA_MASS_NONE; a.grad_out = grad_out;     \
-    a.logp_out = logp_out; a.eval_split = split; a.integ = HTA_SPLIT_SYMMETRIC;                                          \
+    a.logp_out = logp_out; a.eval_split = split; a.integ = HTA_SPLIT_SYMMETRIC; a.workspace = workspace;                 \
+    a.workspace_bytes = workspace_bytes;                                                                                 \
     return hta::netn_hmc<T>(a, (hipStream_t)stream);                                                                     \
   }
 HTA_DEFINE_NETN(f32, float)
 HTA_DEFINE_NETN(f64, double)
 #undef HTA_DEFINE_NETN
+
+int64_t hta_netn_hmc_workspace_bytes(int64_t C, int n_layers, const int* dims, int elem_size) {
+  return elem_size == 4 ? hta::mlp3_workspace_bytes(C, n_layers, dims) : 0;      /* the one-wave-per-chain kernels need none */
+}
 }

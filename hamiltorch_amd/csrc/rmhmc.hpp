@@ -17,10 +17,12 @@ template <typename T> struct MetricArgsT {   // typed view of HtaMetricArgs (inc
   const T* V0; const T* lam0; T* lamraw_out;
   T* dmetric_out;
   int64_t v0_stride;           // elements between consecutive systems' V0 (0: one basis shared by all systems)
+  void* workspace; int64_t workspace_bytes;   // ABI 10: caller-owned scratch for the sizes whose matrices exceed one CU's LDS (hta_metric_eval_workspace_bytes)
 };
 static_assert(sizeof(MetricArgsT<float>) == sizeof(HtaMetricArgs), "HtaMetricArgs layout drifted from MetricArgsT");
 
 template <typename T> int metric_eval(const MetricArgsT<T>& a, hipStream_t s);
+int64_t metric_eval_workspace_bytes(int64_t B, int D, int elem_size);       // 0 while both matrices of a system fit the LDS of a CU
 extern int g_metric_mfma;                                   // tuning key "metric_mfma" (default 1)
 extern int g_metric_general;                                // tuning key "metric_general" (default 1): per-system bases on the matrix cores
 bool metric_warm_mfma_eligible(const MetricArgsT<float>& a);

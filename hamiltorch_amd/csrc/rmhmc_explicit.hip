@@ -35,6 +35,7 @@ template <typename T> struct RmModel {
   const T* P; const T* mu; double log_norm; int metric; double alpha; int has_jitter; double jitter;
   uint64_t seed; uint64_t chain_offset; int64_t C; int D;
   const T* V0; const T* lam0;     // eigenbasis of the jitter-free P (warm start), or NULL
+  void* mws; int64_t mws_bytes;   // the metric evaluations' slab area inside the caller's workspace (sizes beyond one CU's LDS), or NULL
 };
 
 template <typename T> static MetricArgsT<T> base_args(const RmModel<T>& m, uint32_t draw, uint32_t sub) {
@@ -44,6 +45,7 @@ template <typename T> static MetricArgsT<T> base_args(const RmModel<T>& m, uint3
   a.has_jitter = m.has_jitter; a.jitter = m.jitter; a.seed = m.seed; a.chain_offset = m.chain_offset;
   a.draw = draw; a.sub = sub; a.Pm = m.P; a.mu = m.mu; a.log_norm = m.log_norm;
   a.V0 = m.V0; a.lam0 = m.lam0;
+  a.workspace = m.mws; a.workspace_bytes = m.mws_bytes;
   return a;
 }
 
@@ -82,9 +84,9 @@ static int explicit_steps(const RmModel<T>& m, uint32_t draw, T* th, T* pm, T* t
 template <typename T>
 int rmhmc_leapfrog(T* th, T* pm, T* thc, T* pmc, const T* P, const T* mu, int metric, double alpha, int has_jitter,
                    double jitter, uint64_t seed, uint64_t chain_offset, uint32_t draw, int64_t C, int D, int steps,
-                   double eps, double omega, T* path_theta, T* path_p, hipStream_t s) {
+                   double eps, double omega, T* path_theta, T* path_p, void* workspace, int64_t workspace_bytes, hipStream_t s) {
   HTA_REQUIRE(th && pm && thc && pmc && P && mu && C > 0 && D > 0 && steps >= 0, "hta_rmhmc_gaussian_leapfrog: bad arguments");
-  RmModel<T> m{P, mu, 0.0, metric, alpha, has_jitter, jitter, seed, chain_offset, C, D, nullptr, nullptr};
+  RmModel<T> m{P, mu, 0.0, metric, alpha, has_jitter, jitter, seed, chain_offset, C, D, nullptr, nullptr, workspace, workspace_bytes};
   return explicit_steps<T>(m, draw, th, pm, thc, pmc, steps, eps, omega, path_theta, path_p, s);
 }
 
@@ -110,6 +112,12 @@ static bool prepared_lookup(const void* ws, const void* P, int64_t C, int D, int
     return false;
   out = p;
   return true;
+}
+
+// the base layout: augmented state 4 C D | H_old, H_new, log p: 3 C | V0, S, chol(P): 3 D^2 | lam0: D - rounded up to 16 bytes so
+// that the metric slabs behind it (sizes beyond one CU's LDS: metric_eval_workspace_bytes) and the pre-drawn momenta start aligned
+static int64_t rm_base_bytes(int64_t C, int D, int elem) {
+  return ((4 * C * D + 3 * C + 3 * (int64_t)D * D + D) * (int64_t)elem + 15) & ~(int64_t)15;
 }
 
 template <typename T>
@@ -180,10 +188,11 @@ int rmhmc_prepare(const T* P, const T* mu, int metric, double alpha, int has_jit
   const char* who = "hta_rmhmc_gaussian_prepare";
   HTA_REQUIRE(P && mu && C > 0 && D > 0, "%s: bad arguments", who);
   const int64_t total = C * D;
-  const int64_t need = (4 * total + 3 * C + 3 * (int64_t)D * D + D) * (int64_t)sizeof(T);
+  const int64_t base = rm_base_bytes(C, D, (int)sizeof(T)), mslab = metric_eval_workspace_bytes(C, D, (int)sizeof(T));
+  const int64_t need = base + mslab;
   HTA_REQUIRE(workspace && workspace_bytes >= need, "%s: workspace of %lld bytes required", who, (long long)need);
   T* V0 = (T*)workspace + 4 * total + 3 * C; T* lam0 = V0 + (int64_t)D * D; T* Sinv = lam0 + D; T* LP = Sinv + (int64_t)D * D;
-  RmModel<T> m{P, mu, 0.0, metric, alpha, has_jitter, jitter, 0, 0, C, D, nullptr, nullptr};
+  RmModel<T> m{P, mu, 0.0, metric, alpha, has_jitter, jitter, 0, 0, C, D, nullptr, nullptr, mslab ? (char*)workspace + base : nullptr, mslab};
   RmPrepared pr;
   const int rc = rmhmc_setup<T>(m, V0, lam0, Sinv, LP, true, pr, s);
   std::lock_guard<std::mutex> lock(g_prep_mu);
@@ -201,12 +210,14 @@ int rmhmc_sample(T* cur, const T* theta_init, const T* P, const T* mu, double lo
   const char* who = "hta_rmhmc_gaussian_sample";
   HTA_REQUIRE(cur && theta_init && P && mu && reject_count && C > 0 && D > 0 && L >= 0 && n_traj >= 0, "%s: bad arguments", who);
   const int64_t total = C * D;
-  const int64_t need = (4 * total + 3 * C + 3 * (int64_t)D * D + D) * (int64_t)sizeof(T);
+  const int64_t base = rm_base_bytes(C, D, (int)sizeof(T)), mslab = metric_eval_workspace_bytes(C, D, (int)sizeof(T));
+  const int64_t need = base + mslab;
   HTA_REQUIRE(workspace && workspace_bytes >= need, "%s: workspace of %lld bytes required", who, (long long)need);
   T* th = (T*)workspace; T* pm = th + total; T* thc = pm + total; T* pmc = thc + total;
   T* H0 = pmc + total; T* H1 = H0 + C; T* lp1 = H1 + C;
   T* V0 = lp1 + C; T* lam0 = V0 + (int64_t)D * D; T* Sinv = lam0 + D; T* LP = Sinv + (int64_t)D * D;
-  RmModel<T> m{P, mu, log_norm, metric, alpha, has_jitter, jitter, seed, chain_offset, C, D, nullptr, nullptr};
+  RmModel<T> m{P, mu, log_norm, metric, alpha, has_jitter, jitter, seed, chain_offset, C, D, nullptr, nullptr,
+               mslab ? (char*)workspace + base : nullptr, mslab};
   // Once per TARGET: the eigenbasis of the curvature matrix (every evaluation only adds its own jitter to the diagonal and
   // starts from that basis), the host-side plan of the fused route (needs the spectrum on the host: one D-element copy and a
   // synchronise) and the shared inverse S.  A caller that keeps sampling one target in several calls prepares its workspace
@@ -221,7 +232,7 @@ int rmhmc_sample(T* cur, const T* theta_init, const T* P, const T* mu, double lo
     // the soft-abs map is the identity on this spectrum (or the metric is the Hessian itself): the whole run is one launch
     // sequence of rmhmc_fused.hip.  Room for pre-drawn momenta: whatever the caller's workspace holds beyond the base
     // layout, else the (unused on this path) augmented-state area at its head: 4 trajectories per pass
-    T* p_ws = LP + (int64_t)D * D;
+    T* p_ws = (T*)((char*)workspace + need);             // behind the base layout and the metric slabs
     int64_t p_elems = workspace_bytes / (int64_t)sizeof(T) - (p_ws - (T*)workspace);
     if (p_elems < total) { p_ws = th; p_elems = 4 * total; }
     return rmhmc_fused_sample<T>(cur, theta_init, P, Sinv, mu, log_norm, pr.logdetP, has_jitter, jitter, pr.K, pr.series, C, D, L, eps,
@@ -281,7 +292,7 @@ int rmhmc_sample(T* cur, const T* theta_init, const T* P, const T* mu, double lo
 
 extern "C" {
 int64_t hta_rmhmc_workspace_bytes(int64_t C, int D, int elem_size) {
-  return (4 * C * D + 3 * C + 3 * (int64_t)D * D + D) * (int64_t)elem_size;
+  return hta::rm_base_bytes(C, D, elem_size) + hta::metric_eval_workspace_bytes(C, D, elem_size);
 }
 
 #define HTA_DEFINE_ROT(SUF, T)                                                                                  \
@@ -305,10 +316,11 @@ HTA_DEFINE_ROT(f64, double)
   int hta_rmhmc_gaussian_leapfrog_##SUF(T* theta, T* p, T* theta_copy, T* p_copy, const T* P, const T* mu,       \
                                         int metric, double alpha, int has_jitter, double jitter, uint64_t seed,  \
                                         uint64_t chain_offset, uint32_t draw, int64_t C, int D, int steps,       \
-                                        double eps, double omega, T* path_theta, T* path_p, void* stream) {      \
+                                        double eps, double omega, T* path_theta, T* path_p, void* workspace,     \
+                                        int64_t workspace_bytes, void* stream) {                                 \
     return hta::rmhmc_leapfrog<T>(theta, p, theta_copy, p_copy, P, mu, metric, alpha, has_jitter, jitter, seed,  \
-                                  chain_offset, draw, C, D, steps, eps, omega, path_theta, path_p,               \
-                                  (hipStream_t)stream);                                                          \
+                                  chain_offset, draw, C, D, steps, eps, omega, path_theta, path_p, workspace,    \
+                                  workspace_bytes, (hipStream_t)stream);                                         \
   }                                                                                                              \
   int hta_rmhmc_gaussian_sample_##SUF(T* theta, const T* theta_init, const T* P, const T* mu, double log_norm,   \
                                       int metric, double alpha, int has_jitter, double jitter, int64_t C, int D, \

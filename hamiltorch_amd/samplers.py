@@ -398,6 +398,7 @@ def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, 
         sampler, nuts = Sampler.HMC, True                                       # S:935-936
     _abi.require_device(params_init, "params_init")
     _abi.load()
+    util._poll_status()             # a failure an EARLIER run's kernels reported (sticky status word, copied asynchronously): raise now
     theta0, one = _as_batch(params_init, "params_init")
     seed = util.next_stream_seed() if seed is None else int(seed)
     burn_k = max(int(burn), -1)
@@ -480,6 +481,9 @@ def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, 
     rows = rows_of(samples, one)
     if verbose or debug == 2:
         acc = 1.0 - rejected.to(torch.float64) / float(num_samples)            # S:1085 / S:1089 (burn-in included)
+        if samples.is_cuda:
+            torch.cuda.current_stream(samples.device).synchronize()              # (the acceptance rate is read below anyway)
+        util._poll_status()                                                      # a launch that reported a failure raises HERE, not later
     if verbose:
         print('Acceptance Rate {:.2f}'.format(float(acc.mean())))
     if nuts and debug == 2:
@@ -624,12 +628,34 @@ class _GaussianHMC(_Engine):
                     ws = self._ws = torch.empty(need, dtype=torch.uint8, device=theta0.device)
         if H_old is not None:
             chunk = 1                      # diagnostics are [n_traj, C]: one trajectory per call (NUTS burn-in)
+        watch = _status_watch(self.t, ws, C, D, chunk, theta0) if ws is not None else None
         for start in range(n0, n0 + count, chunk):
             _abi.hmc_gaussian_sample(self.cur, theta0, self.t.precision, self.t.mean, self.t.log_norm, self.kind,
                                      self.im, self.mf, L, eps, min(chunk, n0 + count - start), start, self.burn,
                                      self.seed, self.off, self.samples, self.rejected, H_old, H_new, workspace=ws)
             if progress is not None:
                 progress.update(min(self.N, start + chunk) - 1)
+        if watch is not None:
+            watch.refresh()                # non-blocking copy of the sticky status word: looked at by the next entry / at the next synchronise
+            self.status_watch = watch
+
+
+def _status_watch(tgt, ws, C, D, chunk, theta0):
+    """The status watch of a prepared workspace (util._StatusWatch), created once per workspace and kept with it on the target."""
+    cache = tgt.__dict__.setdefault("_hta_hmc_watch", {})
+    key = (ws.data_ptr(), int(chunk))
+    w = cache.get(key)
+    if w is None:
+        word = _abi.hmc_gaussian_status_word(ws, C, D, chunk, theta0.element_size())
+        if word is None:
+            return None
+        if len(cache) >= 4:
+            cache.clear()
+        def forget(d=tgt.__dict__):      # reported: the flagged workspace goes, the next run prepares a fresh one (word zeroed)
+            d.pop("_hta_hmc_ws", None)
+            d.pop("_hta_hmc_watch", None)
+        w = cache[key] = util._watch_status(word, "hta_hmc_gaussian_sample (%d chains, D = %d)" % (C, D), forget)
+    return w
 
 
 class _HmcWorkspaceHandle:

@@ -88,6 +88,72 @@ def has_nan_or_inf(value):
     return v != v or v in (float("inf"), float("-inf"))
 
 
+class DeviceStatusError(RuntimeError):
+    """A kernel reported a failure through a sticky status word in its workspace (include/hamiltorch_amd.h:
+    hta_hmc_gaussian_status_offset): the samples drawn since the workspace was prepared are invalid (and were overwritten with NaN)."""
+
+
+class _StatusWatch:
+    """Surfaces a device-side sticky status word without synchronising.  The library never synchronises and neither does
+    ``sample(verbose=False)``: after every run that used the workspace the word is copied to a pinned host int (non-blocking); the
+    copy that has landed by the NEXT entry into the library is looked at there.  A word is sticky and only ever goes 0 -> non-zero, so a
+    copy that has not landed yet reads as 0 and is seen one call later; ``check_device_status()`` synchronises and looks at all of them;
+    ``sample(verbose=True)`` / ``debug=2`` synchronise anyway (the acceptance rate) and check on the spot."""
+
+    def __init__(self, word, what, on_error=None):
+        self.word, self.what, self.on_error = word, what, on_error
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+
+    def refresh(self):
+        self.host.copy_(self.word, non_blocking=True)
+
+    def landed(self):
+        return int(self.host[0])
+
+    def error(self, value):
+        return DeviceStatusError("hamiltorch_amd: %s reported status %d: a fused HMC launch gave up waiting for its draw records (its "
+                                 "producer blocks were not scheduled - a shared or preempted GPU); the samples of that run are invalid "
+                                 "and were overwritten with NaN.  hta_set_tuning('quad_fused', 0) selects the two-launch form, which "
+                                 "needs no co-residency." % (self.what, value))
+
+
+_watches = []
+_watch_lock = threading.Lock()
+
+
+def _watch_status(word, what, on_error=None):
+    """`on_error()` runs when the word is reported (the owner drops its prepared workspace: the next run prepares a fresh one, which
+    zeroes the word)."""
+    w = _StatusWatch(word, what, on_error)
+    with _watch_lock:
+        _watches.append(w)
+        if len(_watches) > 64:          # workspaces come and go with their targets; a word that was fine for 64 newer ones stays fine
+            del _watches[0]
+    return w
+
+
+def _poll_status():
+    """Raise for any watched word whose last copy landed non-zero (no synchronisation)."""
+    for w in list(_watches):
+        v = w.landed()
+        if v:
+            with _watch_lock:
+                if w in _watches:
+                    _watches.remove(w)
+            if w.on_error is not None:
+                w.on_error()
+            raise w.error(v)
+
+
+def check_device_status(device=None):
+    """Synchronise and raise DeviceStatusError if any kernel reported a failure since its workspace was prepared."""
+    if torch.cuda.is_available():
+        for w in list(_watches):
+            w.refresh()
+        torch.cuda.synchronize(device)
+    _poll_status()
+
+
 class LogProbError(Exception):
     pass
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HTA_ABI_VERSION 9
+#define HTA_ABI_VERSION 10
 
 #define HTA_OK 0
 #define HTA_ERR_INVALID (-1)   /* bad argument                           */
@@ -179,6 +179,18 @@ int hta_hmc_gaussian_prepare_f64(const double* P, int mass_kind, const double* m
                                  void* workspace, int64_t workspace_bytes, void* stream);
 int hta_hmc_gaussian_forget(void* workspace);
 
+/* STATUS WORD of a prepared workspace (ABI 10).  The fused launch of the D <= 4 route (csrc/hmc_gaussian.hip:
+ * hmc_gauss_quad_fused_kernel, the kernel of BASELINE config 2) hands the pre-drawn records from producer blocks to consumer blocks
+ * of ONE grid; the consumers' wait is bounded, and a consumer whose bound expires (producers not scheduled: a shared or preempted GPU)
+ * ORs 1 into a uint32 word inside the caller's workspace, stops waiting and - when its trajectories are done - overwrites the sample
+ * rows it stored in that launch and its slot of `theta` with NaN.  The word is STICKY: launches never clear it, only
+ * hta_hmc_gaussian_prepare does.  The library never synchronises; the caller reads the word (its own memory) whenever it does:
+ *   byte offset of the word inside a workspace of hta_hmc_gaussian_workspace_bytes(C, D, n_traj, elem_size) bytes, or -1 for
+ *   shapes without that route (D > 4, fp64).  0 = every launch since the preparation got its records.
+ * The reference has no such failure mode (one chain, one process: S:965-1026); this is the error contract of the batched path.
+ * Debug key "quad_starve" (hta_set_tuning) makes the producers leave at once, for tests. */
+int64_t hta_hmc_gaussian_status_offset(int64_t C, int D, int n_traj, int elem_size);
+
 /* leapfrog() only (S:267-304) for the same target: theta, p [C,D] in/out after `steps` steps.
  * path_theta / path_p: optional [steps,C,D] record of every step (the lists of S:299-300, last
  * momentum corrected as in S:302); NULL = final state only.
@@ -238,10 +250,17 @@ typedef struct HtaMetricArgs {
                                                 Jacobi inside the launch where the refinement's coupling test fails); elsewhere
                                                 the hint is ignored (cold Jacobi), results agree to rounding either way.
                                                 A first call passes the identity.                                    */
+  void* workspace; int64_t workspace_bytes;  /* (ABI 10) caller-owned scratch of >= hta_metric_eval_workspace_bytes(B, D, sizeof(T)) bytes:
+                                                needed (else HTA_ERR_INVALID) where a system's two D x D matrices exceed the 160 KiB
+                                                LDS of one CU - fp64 from D = 100, fp32 from D = 141: the eigenvector matrix, from
+                                                D ~ 140 / ~198 also the work matrix, live in one slab per workgroup (<= 512
+                                                workgroups), up to D = 254 fp32 / 180 fp64.  Rounds 3-4 allocated it behind the
+                                                ABI (hipMallocAsync per call).  NULL where the function returns 0.            */
 } HtaMetricArgs;
 
 int hta_metric_eval_f32(const HtaMetricArgs* args, void* stream);
 int hta_metric_eval_f64(const HtaMetricArgs* args, void* stream);
+int64_t hta_metric_eval_workspace_bytes(int64_t B, int D, int elem_size);
 
 /* Explicit RMHMC integrator (S:389-462) for a Gaussian target, `steps` steps on the augmented state
  * (theta, p, theta_copy, p_copy), all [C,D] in/out.  omega = explicit_binding_const.
@@ -257,16 +276,19 @@ int hta_rmhmc_gaussian_leapfrog_f32(float* theta, float* p, float* theta_copy, f
                                     const float* mu, int metric, double alpha, int has_jitter, double jitter,
                                     uint64_t seed, uint64_t chain_offset, uint32_t draw, int64_t C, int D,
                                     int steps, double eps, double omega, float* path_theta, float* path_p,
-                                    void* stream);
+                                    void* workspace, int64_t workspace_bytes, void* stream);
 int hta_rmhmc_gaussian_leapfrog_f64(double* theta, double* p, double* theta_copy, double* p_copy, const double* P,
                                     const double* mu, int metric, double alpha, int has_jitter, double jitter,
                                     uint64_t seed, uint64_t chain_offset, uint32_t draw, int64_t C, int D,
                                     int steps, double eps, double omega, double* path_theta, double* path_p,
-                                    void* stream);
+                                    void* workspace, int64_t workspace_bytes, void* stream);
+/* (ABI 10) workspace of hta_rmhmc_gaussian_leapfrog: hta_metric_eval_workspace_bytes(C, D, sizeof(T)) bytes - 0 (NULL) up to
+ * D = 99 fp64 / 140 fp32. */
 
 /* sample(sampler=RMHMC, integrator=EXPLICIT) (S:969-1026) for a Gaussian target: enqueues every
  * launch of `n_traj` trajectories; arguments as hta_hmc_gaussian_sample.  workspace:
- * hta_rmhmc_workspace_bytes(C, D, sizeof(T)) bytes at least (required).  Every further C*D*sizeof(T) bytes let the
+ * hta_rmhmc_workspace_bytes(C, D, sizeof(T)) bytes at least (required; ABI 10: includes the metric evaluations' slabs for sizes
+ * beyond one CU's LDS, hta_metric_eval_workspace_bytes).  Every further C*D*sizeof(T) bytes let the
  * fused path (soft-abs map == identity on the target's spectrum, csrc/rmhmc_fused.hip) draw the momenta of one more
  * trajectory per pass ahead of the chains (one full-chip batch of draws); with the minimum it works in passes of 4.  With
  * hta_set_tuning("rmhmc_overlap", 1) and room for >= 16 trajectories the draws of the next block run on an internal side
@@ -361,18 +383,24 @@ int hta_netn_hmc_sample_f32(float* theta, const float* theta_init, int64_t C, in
                             const float* X, const float* Y, int N, int M, int Nb, const float* taus, float tau_out,
                             float prior_scale, int mass_kind, const float* inv_mass, const float* mass_factor, int integrator,
                             int L, float eps, int n_traj, int traj_offset, int burn, uint64_t seed, uint64_t chain_offset,
-                            float* samples, int32_t* reject_count, float* H_old, float* H_new, uint8_t* accept, void* stream);
+                            float* samples, int32_t* reject_count, float* H_old, float* H_new, uint8_t* accept, void* workspace,
+                            int64_t workspace_bytes, void* stream);
 int hta_netn_hmc_sample_f64(double* theta, const double* theta_init, int64_t C, int n_layers, const int* dims, int act, int loss_kind,
                             const double* X, const double* Y, int N, int M, int Nb, const double* taus, double tau_out,
                             double prior_scale, int mass_kind, const double* inv_mass, const double* mass_factor, int integrator,
                             int L, double eps, int n_traj, int traj_offset, int burn, uint64_t seed, uint64_t chain_offset,
-                            double* samples, int32_t* reject_count, double* H_old, double* H_new, uint8_t* accept, void* stream);
+                            double* samples, int32_t* reject_count, double* H_old, double* H_new, uint8_t* accept, void* workspace,
+                            int64_t workspace_bytes, void* stream);
 int hta_netn_logp_grad_f32(const float* theta, int64_t C, int n_layers, const int* dims, int act, int loss_kind, const float* X,
                            const float* Y, int N, int M, int Nb, int split, const float* taus, float tau_out, float prior_scale,
-                           float* grad_out, float* logp_out, void* stream);
+                           float* grad_out, float* logp_out, void* workspace, int64_t workspace_bytes, void* stream);
 int hta_netn_logp_grad_f64(const double* theta, int64_t C, int n_layers, const int* dims, int act, int loss_kind, const double* X,
                            const double* Y, int N, int M, int Nb, int split, const double* taus, double tau_out, double prior_scale,
-                           double* grad_out, double* logp_out, void* stream);
+                           double* grad_out, double* logp_out, void* workspace, int64_t workspace_bytes, void* stream);
+/* (ABI 10) `workspace`: caller-owned scratch of >= hta_netn_hmc_workspace_bytes(C, n_layers, dims, sizeof(T)) bytes - non-zero only for
+ * the shapes of the matrix-core route (csrc/mlp3_mfma.hip: two hidden layers of <= 104 units, n_in <= 4, one output, fp32: the momentum
+ * slots of its workgroups; rounds 3-4 kept a hipMalloc'ed buffer per stream behind the ABI).  NULL / 0 elsewhere. */
+int64_t hta_netn_hmc_workspace_bytes(int64_t C, int n_layers, const int* dims, int elem_size);
 
 /* Posterior predictive: out[s, p, :] = f(x_p; theta_s) for S parameter vectors at once (forward only) - replaces the per-sample
  * forward passes of hamiltorch.predict_model (hamiltorch/samplers.py:1530-1552: a Python loop over the samples, one functional

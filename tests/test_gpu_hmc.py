@@ -479,17 +479,16 @@ def test_block_list_inv_mass_vs_oracle_and_reference_fixture(ht, route):
     assert 0.3 < info["acc_rate"].mean() < 1.0
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.float64, 1e-11)])
+# (float64: the register-resident kernels stop at D = 4 - beyond, both settings of 'gauss_eig' are the wave kernels, covered by
+#  test_wave_eigenbasis_route_vs_direct_and_oracle; those combinations are not generated rather than skipped)
+@pytest.mark.parametrize("dtype,tol,D", [(torch.float32, 1e-4, D) for D in (1, 2, 3, 4, 5, 6)] + [(torch.float64, 1e-11, D) for D in (1, 2, 3, 4)])
 @pytest.mark.parametrize("mass", ["none", "diag", "full"])
-@pytest.mark.parametrize("D", [1, 2, 3, 4, 5, 6])
 def test_eigenbasis_route_equals_direct_route(ht, dtype, tol, D, mass):
     """Small-D Gaussian HMC integrates in the eigenbasis of the (mass-whitened) precision matrix (2 D FMAs per step);
     hta_set_tuning('gauss_eig', 0) selects the direct kernel (D + D^2 FMAs per step, more with a mass matrix).  Same draws,
     same map: samples agree to rounding, chain by chain, for identity / diagonal / full mass, with a mean offset, burn-in
     (Q2 reset) and nearly degenerate / widely spread spectra."""
     from hamiltorch_amd import _abi
-    if dtype == torch.float64 and D > 4:
-        pytest.skip("fp64 register-resident kernels stop at D=4")
     C, N, L, eps, seed = 128, 30, 7, 0.2, 5 + D
     rng = np.random.default_rng(D)
     Qm, _ = np.linalg.qr(rng.normal(size=(D, D)))
@@ -697,8 +696,6 @@ def test_wave_eigenbasis_route_vs_direct_and_oracle(ht, dtype, tol, D):
     the Jacobi kernel; two D x D products per trajectory instead of one per step).  Against the direct wave kernel
     (hta_set_tuning('gauss_eig', 0)) and the oracle on the same Philox draws, with burn-in (Q2 reset) and a mean offset."""
     from hamiltorch_amd import _abi
-    if dtype == torch.float64 and D > 110:
-        pytest.skip("fp64 Jacobi kernel stops at D ~ 110")
     C, N, L, eps, seed, burn = 37, 12, 6, 0.15, 40 + D, 2
     rng = np.random.default_rng(D)
     P = rand_spd(D, 3)
@@ -790,6 +787,73 @@ def test_fused_quad_launch_is_bit_identical(ht, D, C, N, L, burn):
         _abi.hmc_gaussian_forget(ws)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert torch.isfinite(outs[1][0]).all()
+
+
+def test_fused_launch_reports_starved_producers(ht):
+    """VERDICT r04 item 6 / ADVICE r04 (medium): the consumers of the fused launch wait for producer blocks of the same grid; a
+    producer that is never scheduled (debug key "quad_starve": the producers leave at once) used to turn, after the bounded wait,
+    into consumers that READ ON - plausible wrong samples with rc 0.  Now: the workspace's STICKY status word (ABI 10:
+    hta_hmc_gaussian_status_offset) goes non-zero, every row the starved launch stored and the chain state are NaN, later launches on
+    that workspace stay flagged (and NaN) until it is prepared again, and the Python layer raises DeviceStatusError - on the spot
+    where it synchronises anyway (verbose / debug = 2), at the next entry or at check_device_status() otherwise."""
+    from hamiltorch_amd import _abi, util
+    C, D, N, L = 256, 3, 64, 5
+    t, _ = targets(ht, rand_spd(D, 8), torch.float32)
+    th0 = torch.randn(C, D, generator=torch.Generator().manual_seed(3)).to(dev())
+    ws = torch.zeros(_abi.gaussian_workspace_bytes(C, D, N, 4), dtype=torch.uint8, device=dev())
+    _abi.hmc_gaussian_prepare(th0, t.precision, 0, None, C, D, N, ws)
+    word = _abi.hmc_gaussian_status_word(ws, C, D, N, 4)
+    assert word is not None and _abi.hmc_gaussian_status_word(ws, C, 7, N, 4) is None
+
+    def launch(seed):
+        cur = th0.clone()
+        samples = torch.zeros(N + 1, C, D, device=dev()); rej = torch.zeros(C, dtype=torch.int32, device=dev())
+        _abi.hmc_gaussian_sample(cur, th0, t.precision, t.mean, t.log_norm, 0, None, None, L, 0.3, N, 0, -1, seed, 0, samples, rej, workspace=ws)
+        torch.cuda.synchronize()
+        return cur, samples[1:]
+    cur, s = launch(1)
+    assert _abi.last_route().startswith("hmc_gauss_quad_fused_kernel<3") and int(word) == 0 and torch.isfinite(s).all()
+    good = s.clone()
+    _abi.set_tuning("quad_starve", 1)
+    cur, s = launch(1)                                       # ~1 s: every consumer wave polls out its bound
+    assert int(word) != 0, "the starved launch did not raise the status word"
+    assert torch.isnan(s).all() and torch.isnan(cur).all(), "a starved launch must not leave plausible rows behind"
+    _abi.set_tuning("quad_starve", 0)
+    cur, s = launch(1)                                       # the word is sticky: the launch itself is healthy again ...
+    assert int(word) != 0 and torch.equal(s, good)           # ... and says so in its data, but the workspace stays flagged
+    _abi.hmc_gaussian_prepare(th0, t.precision, 0, None, C, D, N, ws)      # only a new preparation clears it
+    cur, s = launch(1)
+    assert int(word) == 0 and torch.equal(s, good)
+    _abi.hmc_gaussian_forget(ws)
+
+    # through the public API
+    tgt = ht.GaussianTarget(t.mean, precision=t.precision)
+    kw = dict(num_samples=N, num_steps_per_sample=L, step_size=0.3, burn=-1, seed=5)
+    ok = ht.sample(tgt, th0, verbose=False, **kw)
+    assert torch.isfinite(torch.stack(ok)).all()
+    _abi.set_tuning("quad_starve", 1)
+    with pytest.raises(util.DeviceStatusError, match="draw records"):
+        ht.sample(tgt, th0, debug=2, verbose=False, **kw)              # synchronises for the acceptance rate: raises on the spot
+    tgt2 = ht.GaussianTarget(t.mean, precision=t.precision.clone())    # (a fresh target = a fresh workspace)
+    bad = ht.sample(tgt2, th0, verbose=False, **kw)                    # no synchronisation inside: returns ...
+    assert torch.isnan(torch.stack(bad)[1:]).all()                     # ... NaN rows, never plausible ones
+    _abi.set_tuning("quad_starve", 0)
+    with pytest.raises(util.DeviceStatusError):
+        util.check_device_status()                                       # the explicit check
+    tgt3 = ht.GaussianTarget(t.mean, precision=t.precision.clone())
+    bad = ht.sample(tgt3, th0, verbose=False, **kw)
+    util.check_device_status()                                           # healthy again: nothing pending
+    assert torch.isfinite(torch.stack(bad)).all()
+    _abi.set_tuning("quad_starve", 1)
+    tgt4 = ht.GaussianTarget(t.mean, precision=t.precision.clone())
+    ht.sample(tgt4, th0, verbose=False, **kw)
+    torch.cuda.synchronize()                                             # the asynchronous copy of the word has landed
+    _abi.set_tuning("quad_starve", 0)
+    with pytest.raises(util.DeviceStatusError):
+        ht.sample(tgt, th0, verbose=False, **kw)                         # the NEXT entry into the library raises for the earlier run
+    again = ht.sample(tgt, th0, verbose=False, **kw)                     # reported once; the flagged workspace went with the report:
+    util.check_device_status()                                           # `tgt` runs on a freshly prepared one
+    assert torch.equal(torch.stack(again), torch.stack(ok))
 
 
 def test_fused_quad_launch_needs_a_prepared_workspace_and_whole_lines(ht):

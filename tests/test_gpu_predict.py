@@ -115,3 +115,35 @@ def test_predict_model_reads_sample_models_lazy_list_natively(ht):
         want = torch.stack([torch.func.functional_call(net, dict(zip([n for n, _ in net.named_parameters()],
                                                                     ht.util.unflatten(net, r))), (X,)) for r in rows])
     np.testing.assert_allclose(pred.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dims,dtype,loss", [([784, 100, 10], torch.float32, "multi_class_linear_output"),
+                                            ([784, 512, 10], torch.float32, "multi_class_linear_output"),
+                                            ([1, 200, 200, 1], torch.float64, "regression")])
+def test_models_outside_the_forward_kernels_limits_take_the_torch_path(ht, dims, dtype, loss):
+    """a flattened-MNIST MLP (784 inputs: 401 KB of LDS staging) and 200-wide float64 nets passed the native gate
+    and predict_model RAISED (InvalidArguments / a failed launch); before the native route they ran under vmap.  The gate mirrors
+    the kernel's limits now (bnn.native_forward_fits) and a refusal by the kernel falls back as well: these models predict on the torch
+    path, values equal to a plain forward pass."""
+    from hamiltorch_amd import bnn
+    net = make_net(dims, "relu").to(dtype)
+    D = sum(p.numel() for p in net.parameters())
+    g = torch.Generator().manual_seed(1)
+    S, N = 3, 17
+    samples = [0.05 * torch.randn(D, generator=g, dtype=dtype).to(dev()) for _ in range(S)]
+    X = torch.randn(N, dims[0], generator=g, dtype=dtype).to(dev())
+    Y = torch.randint(0, dims[-1], (N,), generator=g).to(dev()) if loss != "regression" else torch.randn(N, 1, generator=g, dtype=dtype).to(dev())
+    pred, lps = ht.predict_model(net, samples, x=X, y=Y, model_loss=loss, tau_out=1.0, tau_list=torch.ones(2 * (len(dims) - 1)))
+    assert bnn.predict_route["last"] == "torch"
+    assert tuple(pred.shape) == (S, N, dims[-1]) and len(lps) == S
+    for s_ in range(S):
+        torch.nn.utils.vector_to_parameters(samples[s_], net.parameters())
+        np.testing.assert_allclose(pred[s_].cpu().numpy(), net(X).detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    # and if the kernel itself refuses (a limit the gate does not know), the call still answers
+    keep = bnn.native_forward_fits
+    bnn.native_forward_fits = lambda *a, **k: True
+    try:
+        pred2, _ = ht.predict_model(net, samples, x=X, y=Y, model_loss=loss, tau_out=1.0, tau_list=torch.ones(2 * (len(dims) - 1)))
+    finally:
+        bnn.native_forward_fits = keep
+    assert bnn.predict_route["last"] == "torch" and torch.allclose(pred2, pred)

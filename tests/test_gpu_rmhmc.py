@@ -63,8 +63,6 @@ def sym_batch(B, D, kind, seed):
 def test_metric_eval_vs_oracle(ht, dtype, tol, D, kind, alpha):
     """fisher(): G, soft-abs eigenvalues; cholesky_inverse(): G^-1 m; log|G| and m^T G^-1 m -- batched, arbitrary symmetric Hs."""
     from hamiltorch_amd import _abi
-    if dtype == torch.float64 and D > 110:
-        pytest.skip("fp64 D > 110 exceeds the per-thread work lists of the Jacobi kernel (round 4: 100 and 101 run with the eigenvectors in global memory)")
     B = 5
     Hs = sym_batch(B, D, kind, D).astype(NP[dtype])
     rng = np.random.default_rng(1)
@@ -145,8 +143,6 @@ def cfg3_target(ht, D, dtype, seed=0):
 @pytest.mark.parametrize("D,jitter", [(4, None), (10, 1e-3), (31, None), (100, None), (100, 1e-3)])
 def test_explicit_leapfrog_and_hamiltonian_vs_oracle(ht, dtype, tol, D, jitter):
     """T1 at cfg3's shape: same (theta, p) and the same Philox jitter stream into kernel sequence and oracle."""
-    if dtype == torch.float64 and D > 110:
-        pytest.skip("fp64 D > 110 exceeds the per-thread work lists of the Jacobi kernel (round 4: 100 and 101 run with the eigenvectors in global memory)")
     t, o = cfg3_target(ht, D, dtype)
     C, steps, eps, omega, alpha, seed, off, n = 6, 3, 0.1, 10.0, 1e6, 77, 40, 9
     rng = np.random.default_rng(D)
@@ -181,8 +177,6 @@ def test_sample_rmhmc_vs_oracle(ht, dtype, tol, D, jitter, metric, burn, split):
     fused routes are chol(P) z1 + sqrt(jitter u) . z2 (oracle: rm_gibbs_split); 0: chol(G) z, a factorisation per draw
     as the reference (S:183-184)."""
     from hamiltorch_amd import _abi
-    if dtype == torch.float64 and D > 110:
-        pytest.skip("fp64 D > 110: beyond the Jacobi kernel")
     _abi.set_tuning("rmhmc_momsplit", split)
     t, o = cfg3_target(ht, D, dtype, seed=5)
     C, N, L, eps, omega, alpha, seed, off = 24, 7, 3, 0.15, 10.0, 1e6, 2025, 3
@@ -277,8 +271,6 @@ def test_softabs_dmetric_vs_oracle(ht, dtype, tol, D, kind, alpha):
     """dmetric_out: M = Q W Q^T (the derivative of 1/2 log|G| + 1/2 m^T G^-1 m with respect to the entries of Hs),
     including repeated eigenvalues, |alpha lam| << 1 (series branch) and >> 1."""
     from hamiltorch_amd import _abi
-    if dtype == torch.float64 and D > 110:
-        pytest.skip("fp64 D > 110 exceeds the per-thread work lists of the Jacobi kernel (round 4: 100 and 101 run with the eigenvectors in global memory)")
     B = 4
     Hs = sym_batch(B, D, kind, D + 1).astype(NP[dtype])
     m = np.random.default_rng(2).standard_normal((B, D)).astype(NP[dtype])
@@ -389,8 +381,6 @@ def test_fused_path_equals_jacobi_path(ht, dtype, tol, D, jitter, metric):
     """The same run through the fused whole-trajectory kernel and through the eigendecomposition per evaluation:
     G = softabs(P + jitter) equals P + jitter on this spectrum, so both must agree chain by chain."""
     from hamiltorch_amd import _abi
-    if dtype == torch.float64 and D > 110:
-        pytest.skip("fp64 D > 110: beyond the Jacobi kernel")
     t, o = cfg3_target(ht, D, dtype, seed=7)
     C, N, L, eps, omega, alpha, seed = 16, 4, 3, 0.1, 10.0, 1e6, 11
     th0 = (0.3 * O.philox_normals(seed, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(NP[dtype])
@@ -1390,3 +1380,54 @@ def test_metric_eval_fp32_beyond_one_cu_of_lds(ht, D):
     np.testing.assert_allclose(np.sort(lam.cpu().numpy(), axis=1), np.sort(lam_t, axis=1), rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(x.cpu().numpy(), want, rtol=2e-3, atol=2e-3)
     np.testing.assert_allclose(ld.cpu().numpy(), np.log(lam_t).sum(1), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype,D,rt,tol", [(torch.float32, 200, "float,aglobal", 3e-3), (torch.float32, 254, "float,aglobal", 4e-3),
+                                            (torch.float64, 128, "double,aglobal", 1e-8), (torch.float64, 180, "double,aglobal", 2e-8),
+                                            (torch.float64, 110, "double,vglobal", 1e-8)])
+def test_metric_eval_beyond_the_round_4_size_limits(ht, dtype, D, rt, tol):
+    """VERDICT r04 "missing" #4: fisher / cholesky_inverse / rm_hamiltonian have no size limit in the reference (S:108-122, S:146-148,
+    S:710-731); hta_metric_eval stopped at D ~ 156 fp32 / 110 fp64 (the Jacobi kernel's per-thread work lists).  Round 5: the instance
+    with both matrices in the caller's workspace slab (ABI 10: HtaMetricArgs::workspace) and 8 work-list entries per thread runs up to
+    D = 254 fp32 / 180 fp64 - slow (every rotation is an L2 round trip), not an error.  Against the oracle's float64 eigh."""
+    from hamiltorch_amd import _abi
+    B = 3
+    Hs = sym_batch(B, D, "indef", D).astype(NP[dtype])
+    m = np.random.default_rng(1).standard_normal((B, D)).astype(NP[dtype])
+    assert _abi.metric_eval_workspace_bytes(B, D, Hs.itemsize) > 0
+    x = torch.empty(B, D, device=dev(), dtype=dtype); lam = torch.empty_like(x); ld = torch.empty(B, device=dev(), dtype=dtype)
+    _abi.metric_eval(x, B, D, _abi.METRIC_SOFTABS, tt(Hs, dtype), D * D, 1.3, None, 0, 0, 0, 0, m=tt(m, dtype), x_out=x, lam_out=lam, logdet_out=ld)
+    assert _abi.last_route() == "metric_eval_kernel<%s>" % rt, _abi.last_route()
+    G, lam_t, _ = O.softabs_metric(Hs.astype(np.float64), 1.3)
+    want = np.linalg.solve(G, m.astype(np.float64)[..., None])[..., 0]
+    np.testing.assert_allclose(np.sort(lam.cpu().numpy(), axis=1), np.sort(lam_t, axis=1), rtol=0.2 * tol, atol=0.2 * tol)
+    np.testing.assert_allclose(x.cpu().numpy(), want, rtol=tol, atol=tol)
+    np.testing.assert_allclose(ld.cpu().numpy(), np.log(lam_t).sum(1), rtol=0.1 * tol, atol=tol)
+    # the workspace is the caller's: without one the call is refused (no hidden allocation behind the ABI), with a short one too
+    with pytest.raises(_abi.InvalidArguments, match="workspace"):
+        _abi.metric_eval(x, B, D, _abi.METRIC_SOFTABS, tt(Hs, dtype), D * D, 1.3, None, 0, 0, 0, 0, m=tt(m, dtype), x_out=x,
+                         workspace=torch.empty(16, dtype=torch.uint8, device=dev()))
+    # the Hessian metric (Cholesky of the slab-resident matrix)
+    P = np.einsum("bij,bkj->bik", Hs, Hs).astype(NP[dtype]) / D + np.eye(D, dtype=NP[dtype])
+    _abi.metric_eval(x, B, D, _abi.METRIC_HESSIAN, tt(P, dtype), D * D, 0.0, None, 0, 0, 0, 0, m=tt(m, dtype), x_out=x, logdet_out=ld)
+    want = np.linalg.solve(P.astype(np.float64), m.astype(np.float64)[..., None])[..., 0]
+    np.testing.assert_allclose(x.cpu().numpy(), want, rtol=tol, atol=tol)
+    np.testing.assert_allclose(ld.cpu().numpy(), np.linalg.slogdet(P.astype(np.float64))[1], rtol=0.1 * tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype,D,tol", [(torch.float32, 200, 2e-3), (torch.float64, 128, 1e-7)])
+def test_sample_rmhmc_softabs_beyond_the_round_4_size_limits(ht, dtype, D, tol):
+    """sample(RMHMC, EXPLICIT, SOFTABS) at D = 200 fp32 / D = 128 fp64 with a finite soft-abs constant (an eigendecomposition per
+    metric evaluation) returns and matches the oracle chain by chain - VERDICT r04 next-round item 9's "done" line."""
+    from hamiltorch_amd import _abi
+    t, o = cfg3_target(ht, D, dtype)
+    C, N, L, eps, omega, alpha, jitter, seed = 4, 2, 2, 0.05, 10.0, 1.3, 1e-3, 5
+    th0 = (0.3 * O.philox_normals(seed, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=NP[dtype]))
+    out, acc = ht.sample(t, tt(th0, dtype), num_samples=N, num_steps_per_sample=L, step_size=eps, jitter=jitter, softabs_const=alpha,
+                         explicit_binding_const=omega, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT,
+                         metric=ht.Metric.SOFTABS, debug=2, verbose=False, seed=seed)
+    assert _abi.last_route().startswith("metric_eval_kernel<%s,aglobal" % ("float" if dtype == torch.float32 else "double")), _abi.last_route()
+    got = torch.stack(out).cpu().numpy()
+    ref, info = O.sample_rmhmc_explicit(o, th0, N, L, eps, omega, alpha, 0, jitter, O.PhiloxDraws(seed, np.arange(C), NP[dtype]), "softabs")
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, np.stack(ref), rtol=tol, atol=tol)

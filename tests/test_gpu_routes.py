@@ -291,6 +291,33 @@ def test_sample_sharded_on_the_device_equals_single_process(ht, tmp_path):
     assert j["nuts_err"] < 1e-3, j
 
 
+def test_rccl_selftest(ht):
+    """tools/rccl_selftest.py with the devices this box shows.  >= 2 GPUs: one rank per GPU over RCCL -
+    gather_samples (even / uneven, dst=None / dst=0), sample_sharded (HMC bit for bit, RMHMC to rounding, NUTS step size) and the timed
+    cfg5-sized gather.  One GPU (the builder's box): the same checks with two ranks over gloo sharing it, and RCCL as a world-size-1
+    group.  Never skipped: the record says which form ran."""
+    import torch
+    tool = os.path.join(ROOT, "tools", "rccl_selftest.py")
+    runs = [[]] if torch.cuda.device_count() >= 2 else [["--world", "2", "--backend", "gloo"], ["--world", "1", "--backend", "nccl"]]
+    for extra in runs:
+        r = subprocess.run([sys.executable, tool] + extra, capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert lines, (r.returncode, r.stderr[-2000:])
+        j = json.loads(lines[-1])
+        assert j["ok"], j
+        assert j["ranks_seen"] == j["world"]
+        for k in ("gather_even_all_gather", "gather_even_dst0", "gather_uneven_all_gather", "gather_uneven_dst0",
+                  "sample_sharded_hmc_bit_identical", "nuts_step_size_equal", "sample_sharded_rmhmc_equal_to_rounding"):
+            assert j["checks"][k] is True, (k, j)
+        assert j["gather_cfg5_ms"] > 0
+        if torch.cuda.device_count() >= 2:
+            assert j["backend"] == "rccl" and j["form"] == "one rank per GPU over RCCL"
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out_dir):
+            with open(os.path.join(out_dir, "rccl_selftest_%s_world%d.json" % (j["backend"], j["world"])), "w") as f:
+                json.dump(j, f)
+
+
 def test_reference_cnn_example_runs_on_the_callback_path(ht):
     """The reference's largest model (notebooks/hamiltorch_Bayesian_NN_example.ipynb cells 24-27: two convolutions, two
     linear layers, D = 431 080, softmax likelihood) has no native kernel: sample_model evaluates the functional model for all

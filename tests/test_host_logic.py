@@ -1,10 +1,14 @@
 """CPU: host-side logic of the API mirror (argument checks, list lengths, closures) -- no kernels run."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 import hamiltorch_amd as ht
 from hamiltorch_amd import bnn, samplers, util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_exports_match_reference_init():
@@ -586,3 +590,50 @@ def test_prepared_workspace_caches_follow_the_target(monkeypatch):
     del t, ws1, ws2, ws3, r1, old
     gc.collect()
     assert calls["hmc_forget"] >= forgot[0] + n_hmc and calls["rm_forget"] >= forgot[1] + n_rm          # handles forget in the library
+
+
+def test_native_forward_gate_mirrors_the_kernel_limits():
+    """ADVICE r04 (high): `_native_forward_ok` admitted shapes hta_net_forward refuses (784 inputs: 2 x 784 x 64 x 4 B = 401 KB of LDS;
+    200-wide float64 layers: 205 KB) and predict_model raised instead of taking the torch path.  The gate is the kernel's own
+    arithmetic now (csrc/net_forward.hip: net_forward)."""
+    from hamiltorch_amd import bnn
+    fits = bnn.native_forward_fits
+    assert fits([1, 100, 100, 1], 4) and fits([8, 100, 1], 4) and fits([4, 3], 4) and fits([1, 10, 10, 1], 8)
+    assert fits([256, 256, 256, 10], 4)                       # 2 x 256 x 64 x 4 = 128 KB
+    assert not fits([784, 100, 10], 4)                        # flattened MNIST: the input layer is staged, 401 KB
+    assert not fits([784, 512, 10], 4)                        # streamed form: still stages its 784 inputs
+    assert fits([16, 512, 10], 4)                             # streamed: only the inputs are staged
+    assert not fits([16, 512, 32], 4)                         # > FW_MAXO outputs: not the streamed form, 512 > FW_MAXW
+    assert not fits([1, 200, 200, 1], 8)                      # float64: 2 x 200 x 64 x 8 = 205 KB
+    assert fits([1, 160, 160, 1], 8) and not fits([1, 164, 1, 1], 8)
+    assert not fits([1] * 11, 4)                              # > FW_MAXL layers
+    # the kernel's constants have not drifted from the mirror
+    src = open(os.path.join(ROOT, "hamiltorch_amd", "csrc", "net_forward.hip")).read()
+    assert "FW_TPB = %d, FW_MAXL = %d, FW_MAXW = %d, FW_MAXO = %d" % (bnn._FW_TPB, bnn._FW_MAXL, bnn._FW_MAXW, bnn._FW_MAXO) in src
+    # and the model-level gate uses it
+    net = torch.nn.Sequential(torch.nn.Linear(784, 100), torch.nn.ReLU(), torch.nn.Linear(100, 10))
+    D = sum(p.numel() for p in net.parameters())
+
+    class FakeCuda(torch.Tensor):
+        is_cuda = True
+    stacked = torch.zeros(3, D).as_subclass(FakeCuda)
+    assert bnn._native_forward_ok(net, stacked, torch.zeros(5, 784), "multi_class_linear_output") is None
+
+
+def test_lift_callable_does_not_touch_distribution_means_and_keeps_user_errors():
+    """distributions without a closed-form mean raised NotImplementedError inside the wrapper; a buggy log_prob_func
+    was wrapped as host-evaluated with a PCIe warning instead of surfacing as itself."""
+    import warnings
+    from hamiltorch_amd import host
+    base = torch.distributions.Normal(torch.zeros(3), torch.ones(3))
+    td = torch.distributions.TransformedDistribution(base, [torch.distributions.transforms.ExpTransform()])
+    with pytest.raises(NotImplementedError):
+        td.mean
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = host.lift_callable(td.log_prob, torch.ones(2, 3))          # no NotImplementedError
+    assert callable(out)
+
+    def buggy(w):
+        raise ValueError("the user's own bug")
+    assert host.lift_callable(buggy, torch.ones(2, 3)) is buggy             # not wrapped: the engine's first call raises the ValueError
