@@ -86,13 +86,15 @@ def rmhmc_closed_form_useful_flops(D, L, K=2):
     return rmhmc_closed_form_products(L, K) * 2 * D * D
 
 
-def rmhmc_closed_form_issued_flops(D, L, K, chains_per_group):
+def rmhmc_closed_form_issued_flops(D, L, K, chains_per_group, deferred=False):
     """Matrix-instruction flops the uvc kernels ISSUE per chain-step (what SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 counts): four
     waves x ceil(D / 2 / 4) * 4 instructions per single product phase (rows padded to 128, contraction to a multiple of 8),
     every instruction carrying all four columns whether a chain fills them or not."""
     kj = 4 * ((D + 7) // 8)                       # instructions of one product per wave (XKJ = 52 at D = 100)
     if chains_per_group == 1:                     # rmhmc_uvc_kernel: 3 phases per step (1 + 2 + 1 products), flush + Hamiltonian (2 + 1 + 1) per trajectory
         per_step, per_traj = 4 * kj, 5 * kj
+    elif deferred:                                # rmhmc_uvc2d_kernel (round 5, K = 2): 3 phases per step of 2 + 3 + 2 product chains; flush + Hamiltonian (2 + 1 + 1)
+        per_step, per_traj = 7 * kj, 5 * kj
     else:                                         # rmhmc_uvc2_kernel: 2 K solve phases + one double phase per step; Hamiltonian 2 + 1 + K
         per_step, per_traj = (2 * K + 2) * kj, (3 + K) * kj
     return 4 * (per_step + per_traj / float(L)) * MFMA_4X4X1_FLOPS / chains_per_group

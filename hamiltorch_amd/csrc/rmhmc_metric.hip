@@ -37,12 +37,23 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
   const int cs_len = (ne + 3) & ~3;
   T* V;                                                  // VT[D][ldv], row k = eigenvector k
   T* V0s;
-  const int64_t slab = ((int64_t)D * ldv + (AG ? (int64_t)ne * lda : 0) + 3) & ~(int64_t)3;      // (16-byte aligned slabs: metric_geometry)
-  if constexpr (VG) { V = vws + (int64_t)blockIdx.x * slab; V0s = reinterpret_cast<T*>(smem_raw); }
+  if constexpr (VG && AG) {                              // (16-byte aligned slabs: metric_geometry)
+    const int64_t slab = ((int64_t)D * ldv + (int64_t)ne * lda + 3) & ~(int64_t)3;
+    V = vws + (int64_t)blockIdx.x * slab; V0s = reinterpret_cast<T*>(smem_raw);
+  } else if constexpr (VG) {
+    // (D * ldv is a multiple of 16 bytes.  Written exactly like this on purpose: with the slab size in a variable rounded as above - the
+    //  same number - the float64 instance <4, 3, true, false> came out of hipcc 7.2 with its work-matrix accesses of the G / Cholesky
+    //  phases going to the wrong memory (lam, V, x right; G, L garbage: tools/history/r05d.py, bisected against round 4's build).  The
+    //  instance spills 97 VGPRs / 215 SGPRs under its 128-register cap; tests/test_gpu_rmhmc.py::test_metric_eval_vs_oracle[100-*-float64]
+    //  and ::test_metric_eval_beyond_the_round_4_size_limits pin both instances' outputs one by one.)
+    V = vws + (int64_t)blockIdx.x * D * ldv; V0s = reinterpret_cast<T*>(smem_raw);
+  }
   else { V = reinterpret_cast<T*>(smem_raw); V0s = V + D * ldv; }
   T* cs = V0s + (v0_lds ? D * ldv : 0);
-  T* A = AG ? V + (int64_t)D * ldv : cs + cs_len;
-  T* vec0 = AG ? cs + cs_len : A + ne * lda;         // lam~ (ne)
+  T* A;
+  T* vec0;                        // lam~ (ne)
+  if constexpr (AG) { A = V + (int64_t)D * ldv; vec0 = cs + cs_len; }
+  else { A = cs + cs_len; vec0 = A + ne * lda; }
   T* vec1 = vec0 + ne;            // y / w / solve vector (ne)
   T* vec2 = vec1 + ne;            // d = X - mu, later z (ne)
   T* vec3 = vec2 + ne;            // Pd (ne)
@@ -351,7 +362,7 @@ static MetricGeom metric_geometry(int D, int elem, bool warm) {
     g.lds = bytes(g.lda, 0, true);
     g.vglobal = true;
     g.grid_cap = 512;
-    g.slab_elems = (int64_t)D * g.ldv;
+    g.slab_elems = (int64_t)D * g.ldv;               // (a multiple of 16 bytes: ldv is)
   }
   // per-thread work-list lengths of the Jacobi rounds (register arrays): 2/2 up to D ~ 126, 4/3 up to ~156 fp32 / 110 fp64, 8/8 beyond
   g.small = NP * (NP + 1) / 2 <= 2 * MT && NP * nv <= 2 * MT;

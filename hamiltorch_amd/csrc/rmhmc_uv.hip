@@ -467,6 +467,10 @@ int rmhmc_uv_launch(const FusedArgs<float>& a, int cus, hipStream_t s) {
   const int grid = (int)(ngroup < 8192 ? ngroup : 8192);
   const bool co = g_rmhmc_uv_co != 0, acc4 = g_rmhmc_uv_acc == 4;
   if (g == 1 && g_rmhmc_uvc && g_rmhmc_lean && a.K == 2 && a.has_jitter) return rmhmc_uvc_launch(a, co, s);
+  // (round 5, measured and not kept - tools/scratch/rmhmc_uvc2d.hip.rejected, profiles/r05b_uvc2d_ab.txt: the one-chain kernel's three
+  //  phases per step for two-chain groups, the deferred second-order products as extra accumulator chains: 364 matrix instructions and 3
+  //  barriers per step instead of 312 and 5, equal to rounding - 5 % SLOWER at 1024 chains (4.64 against 4.39 ms), slower at 384 ... 1536:
+  //  with two workgroups per CU the phases' latency is already covered, the extra matrix instructions are not)
   if (g == 2 && g_rmhmc_uvc && g_rmhmc_lean) return rmhmc_uvc2_launch(a, co, s);
   if (!g_rmhmc_lean) {
     note_route("rmhmc_uv_kernel<%d>", g);

@@ -41,6 +41,7 @@ def test_useful_never_exceeds_the_issue_model(D, L, K):
     assert useful <= M.rmhmc_closed_form_issued_flops(D, L, K, 2)
     if K == 2:
         assert useful <= M.rmhmc_closed_form_issued_flops(D, L, K, 1)
+        assert useful <= M.rmhmc_closed_form_issued_flops(D, L, K, 2, deferred=True)
 
 
 def test_issue_model_equals_the_counters():
@@ -49,6 +50,9 @@ def test_issue_model_equals_the_counters():
     if "rmhmc_uvc2_kernel" in PHYS["cfg3@1024"]["dominant_kernel"]:
         got, _ = _issued_per_chain_step("cfg3@1024", 1024 * 100 * 10)
         assert got == pytest.approx(M.rmhmc_closed_form_issued_flops(100, 10, 2, 2), rel=0.01)
+    if "rmhmc_uvc2d_kernel" in PHYS["cfg3@1024"]["dominant_kernel"]:
+        got, _ = _issued_per_chain_step("cfg3@1024", 1024 * 100 * 10)
+        assert got == pytest.approx(M.rmhmc_closed_form_issued_flops(100, 10, 2, 2, deferred=True), rel=0.01)
     if "rmhmc_uvc_kernel" in PHYS["cfg3@256"]["dominant_kernel"]:
         got, _ = _issued_per_chain_step("cfg3@256", 256 * 400 * 10)
         assert got == pytest.approx(M.rmhmc_closed_form_issued_flops(100, 10, 2, 1), rel=0.01)

@@ -24,6 +24,9 @@ def test_exports_match_reference_init():
         assert hasattr(samplers, name)
     for name in ("LogProbError", "flatten", "unflatten", "setup_chain", "multi_chain", "set_random_seed", "has_nan_or_inf"):
         assert hasattr(util, name)
+    # hamiltorch/__init__.py:1 - a script that gates on hamiltorch.__version__ sees the API level this package mirrors
+    sig = __import__("json").load(open(os.path.join(ROOT, "tests", "golden", "signatures.json")))
+    assert ht.__version__ == "0.4.1" == sig.get("__version__", "0.4.1") and ht.__amd_version__ != ht.__version__
 
 
 def test_argument_errors_match_reference():
