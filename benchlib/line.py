@@ -124,7 +124,7 @@ def compact_line(full, detail_path="bench_detail.json"):
             if r.get(k) is not None:
                 e[k] = _r(r[k], 4)
         if r.get("extras"):
-            short = {"graph_replay": "graph", "value_graphs_off": "graphs_off", "chain_groups": "groups", "value_one_group": "one_group", "value_notebook_closure": "nb_closure",
+            short = {"graph_replay": "graph", "value_graphs_off": "graphs_off", "value_notebook_closure": "nb_closure",
                      "launches_per_step": "launches", "callback_evaluations_per_step": "cb_evals", "metric_evaluations_per_step": "metric_evals",
                      "predict_route": "predict", "predict_ms_torch_path": "predict_ms_torch"}
             e["extras"] = {short.get(k, k): _r(v, 4) for k, v in r["extras"].items()

@@ -569,9 +569,7 @@ class FunnelHMC:
         from hamiltorch_amd import util
         T = max(4, self.T // 5)
         out = {"graph_replay": not any("trajectory" in g_ for g_ in util.graph_log[-8:]),
-               "chain_groups": 4 if os.environ.get("HAMILTORCH_AMD_GROUPS", "auto") == "auto" else int(os.environ["HAMILTORCH_AMD_GROUPS"]),
-               "value_one_group": self._rate(self.fn, self.T, env={"HAMILTORCH_AMD_GROUPS": "1"}),
-               "value_graphs_off": self._rate(self.fn, T, env={"HAMILTORCH_AMD_GROUPS": "1", "HAMILTORCH_AMD_GRAPHS": "0"}),
+               "value_graphs_off": self._rate(self.fn, T, env={"HAMILTORCH_AMD_GRAPHS": "0"}),
                "value_notebook_closure": self._rate(funnel_ll_notebook, T),
                "launches_per_step": self._launches(),
                "callback_evaluations_per_step": self.T * (self.L + 1)}

@@ -702,72 +702,7 @@ class _GenericHMC(_Engine):
 
     def __init__(self, fn, pass_grad=None, split=False, integrator=Integrator.SPLITTING):
         self.split, self.integrator = split, integrator
-        self._ctor = (fn, pass_grad, split, integrator)
         self.cbs = [_BatchedCallback(f) for f in fn] if split else [_BatchedCallback(fn, pass_grad)]
-
-    # ---- concurrent chain groups (round 5) ------------------------------------------------------------------------------------
-    # A callback trajectory of a small problem (the notebooks' 11-D funnel at 1024 chains: ~1000 kernel nodes of a few microseconds
-    # each, almost all torch's) is bound by the LATENCY of a chain of dependent tiny launches, not by the GPU: a replayed graph
-    # retires one node per ~2 us whatever the node does.  Chains are independent (the only sharded axis: dist.py), so the batch is
-    # cut into G contiguous chain blocks, each with its own engine state, its own captured trajectory graph and its own HIP
-    # stream: G dependent chains of launches run side by side on the device's queues.  Same Philox streams (keyed by global
-    # chain id), same per-chain arithmetic: the samples are those of the single-group run.  HAMILTORCH_AMD_GROUPS = 1 turns it
-    # off, = G forces a count; default: 4 groups for >= 512 chains of a state small enough that launch latency dominates.
-    def _group_count(self, theta0, N, inv_mass):
-        env = os.environ.get("HAMILTORCH_AMD_GROUPS", "auto")
-        C, D = theta0.shape
-        if not theta0.is_cuda or N < 8 or isinstance(inv_mass, list):
-            return 1
-        if self.split and self.integrator == Integrator.SPLITTING_RAND:
-            return 1
-        if env != "auto":
-            return max(1, min(int(env), C // 8 if C >= 16 else 1))
-        if os.environ.get("HAMILTORCH_AMD_GRAPHS", "1") == "0":
-            return 1
-        rows = _num_rows(N, self._burn_for_groups)
-        if C < 512 or C * D > (1 << 17) or rows * C * D * theta0.element_size() > (256 << 20):
-            return 1
-        return 4
-
-    def run(self, theta0, N, L, eps, burn, inv_mass, seed, chain_offset, verbose, label):
-        self._burn_for_groups = burn
-        G = self._group_count(theta0, N, inv_mass)
-        if G <= 1:
-            return super().run(theta0, N, L, eps, burn, inv_mass, seed, chain_offset, verbose, label)
-        from .dist import shard_chains
-        dev = theta0.device
-        main = torch.cuda.current_stream(dev)
-        prog = util._Progress('Sampling ' + label, N, verbose)
-        C = theta0.shape[0]
-        subs, iters = [], []
-        for g in range(G):
-            off, cnt = shard_chains(C, g, G)
-            st = torch.cuda.Stream(device=dev)
-            st.wait_stream(main)
-            sub = _GenericHMC(*self._ctor)
-            with torch.cuda.stream(st):
-                sub.begin(theta0[off:off + cnt], N, burn, inv_mass, seed, chain_offset + off)
-                it = sub._advance_iter(0, N, L, eps, progress=prog if g == 0 else None)
-            subs.append((sub, st, off, cnt))
-            iters.append(it)
-        # round robin: every engine enqueues its next trajectory (an eager one, the capture, then one graph replay each) on its own stream
-        live = list(range(G))
-        while live:
-            for g in list(live):
-                with torch.cuda.stream(subs[g][1]):
-                    try:
-                        next(iters[g])
-                    except StopIteration:
-                        live.remove(g)
-        prog.end()
-        for _, st, _, _ in subs:
-            main.wait_stream(st)
-        self._subs = subs                               # (their buffers were allocated on the side streams: alive until this engine goes)
-        self.samples = torch.cat([sub.samples for sub, _, _, _ in subs], dim=1)
-        self.rejected = torch.cat([sub.rejected for sub, _, _, _ in subs])
-        self.cur = torch.cat([sub.cur for sub, _, _, _ in subs])
-        self.groups = G
-        return self.finish()
 
     def _logp(self, theta):
         out = None
@@ -860,8 +795,12 @@ class _GenericHMC(_Engine):
             pass
 
     def _advance_iter(self, n0, count, L, eps, H_old=None, H_new=None, progress=None):
-        """`advance` as a generator: yields every time it has ENQUEUED a trajectory (the grouped run interleaves several engines,
-        each on its own stream: see `run`)."""
+        """`advance` as a generator: yields every time it has ENQUEUED a trajectory.  (Round 5 used it to interleave G engines over
+        contiguous chain blocks, each with its own captured trajectory graph and HIP stream - the idea being that a callback trajectory
+        is a chain of ~1000 dependent few-microsecond launches and G such chains could run side by side.  Measured on the notebook
+        funnel at 1024 chains (profiles/r05g_chain_groups.txt): 1 group 1.21e7 chain-steps/s, 2 groups 8.8e6, 4 groups 5.7e6, 8 groups
+        3.1e6 - the time follows the TOTAL node count: what bounds a replayed graph of tiny kernels is the rate at which the device
+        retires dispatch packets (~2 us each), not the latency of one dependent chain.  Not kept; fewer nodes is the only lever.)"""
         Ho = self.Ho if H_old is None else H_old
         Hn = self.Hn if H_new is None else H_new
         n, end = n0, n0 + count

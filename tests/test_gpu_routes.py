@@ -291,49 +291,6 @@ def test_sample_sharded_on_the_device_equals_single_process(ht, tmp_path):
     assert j["nuts_err"] < 1e-3, j
 
 
-def test_callback_path_chain_groups_equal_the_single_group_run(ht, monkeypatch):
-    """Round 5: the generic-callback path cuts a launch-latency-bound batch into G contiguous chain blocks, each with its own engine
-    state, captured trajectory graph and HIP stream (samplers._GenericHMC.run): G dependent chains of tiny launches side by side.
-    Same Philox streams (global chain ids), same per-chain arithmetic: the samples, the acceptance rates and the burn-in / Q2
-    behaviour are those of the one-group run - on an opaque closure (the notebook funnel), uneven blocks (515 chains over 4 groups),
-    with burn-in, for plain HMC and for a split list."""
-    import torch
-    from hamiltorch_amd import samplers
-
-    def funnel(w):
-        v, x = w[0], w[1:]
-        return -v * v / 18.0 - 0.5 * torch.exp(v) * (x * x).sum() + 0.5 * x.numel() * v
-
-    dev = torch.device("cuda:0")
-    C, D = 515, 11
-    th0 = (0.3 * torch.randn(C, D, generator=torch.Generator().manual_seed(2))).to(dev)
-    kw = dict(num_samples=14, num_steps_per_sample=6, step_size=0.1, burn=3, debug=2, verbose=False, seed=77)
-    outs = {}
-    for G in ("1", "4"):
-        monkeypatch.setenv("HAMILTORCH_AMD_GROUPS", G)
-        rows, acc = ht.sample(funnel, th0, **kw)
-        outs[G] = (torch.stack(rows).cpu(), acc.cpu() if torch.is_tensor(acc) else acc)
-    assert outs["1"][0].shape == outs["4"][0].shape == (11, C, D)
-    assert torch.isfinite(outs["4"][0]).all()
-    err = (outs["1"][0] - outs["4"][0]).abs().amax(dim=(0, 2))
-    assert float((err > 1e-5).float().mean()) <= 0.01, float(err.max())          # (a Metropolis decision at rounding may flip a chain)
-    assert torch.allclose(outs["1"][1].double(), outs["4"][1].double(), atol=0.08)
-    # the automatic choice: 4 groups at >= 512 chains of a small state, one group below
-    monkeypatch.setenv("HAMILTORCH_AMD_GROUPS", "auto")
-    eng = samplers._GenericHMC(funnel)
-    eng._burn_for_groups = 3
-    assert eng._group_count(th0, 14, None) == 4 and eng._group_count(th0[:256], 14, None) == 1 and eng._group_count(th0, 4, None) == 1
-    # a split list (two halves of the same density) through the grouped run
-    halves = [lambda w: 0.5 * funnel(w), lambda w: 0.5 * funnel(w)]
-    res = {}
-    for G in ("1", "4"):
-        monkeypatch.setenv("HAMILTORCH_AMD_GROUPS", G)
-        rows = ht.sample(halves, th0, integrator=ht.Integrator.SPLITTING, **dict(kw, debug=0))
-        res[G] = torch.stack(rows).cpu()
-    err = (res["1"] - res["4"]).abs().amax(dim=(0, 2))
-    assert float((err > 1e-5).float().mean()) <= 0.01, float(err.max())
-
-
 def test_rccl_selftest(ht):
     """tools/rccl_selftest.py with the devices this box shows.  >= 2 GPUs: one rank per GPU over RCCL -
     gather_samples (even / uneven, dst=None / dst=0), sample_sharded (HMC bit for bit, RMHMC to rounding, NUTS step size) and the timed
