@@ -70,6 +70,17 @@ class GaussianTarget:
     def grad(self, w):
         return -((w - self.mean) @ self.precision.t())
 
+    def _hta_batched_grad(self, theta):
+        """(grad[C, D], logp[C]) for all chains from ONE [C, D] x [D, D] product (the callback path's form of params_grad, S:270-278,
+        for a target beyond the fused kernels' D <= 1024: GEMM-shaped work, rocBLAS on the matrix cores - instead of autograd's
+        forward and backward matrix-vector products under vmap)."""
+        d = theta - self.mean
+        Pd = d @ self.precision                               # symmetric
+        return -Pd, self.log_norm - 0.5 * (d * Pd).sum(dim=1)
+
+    def _hta_batched_logp(self, theta):
+        return self._hta_batched_grad(theta)[1]
+
     def neg_hessian(self):
         return self.precision
 

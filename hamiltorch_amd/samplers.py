@@ -109,6 +109,11 @@ class _BatchedCallback:
         # replayed as HIP graphs on the device (util.GraphedCallable): a trajectory calls these hundreds of times
         self._v_logp = util.GraphedCallable(torch.func.vmap(f))
         self._v_gv = util.GraphedCallable(torch.func.vmap(torch.func.grad_and_value(f)))
+        # a callback that brings its own batched closed form (GaussianTarget beyond the fused kernels' size: one GEMM per gradient)
+        if pass_grad is None and callable(getattr(fn, "_hta_batched_grad", None)):
+            self._v_logp = util.GraphedCallable(fn._hta_batched_logp)
+            self._v_gv = util.GraphedCallable(fn._hta_batched_grad)
+            self.closed_form = True
         self._v_pg = util.GraphedCallable(torch.func.vmap(pass_grad)) if callable(pass_grad) else None
 
     def _loop(self, theta, want_grad):

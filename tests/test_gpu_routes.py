@@ -117,6 +117,17 @@ def test_gaussian_beyond_kernel_range_uses_generic_path(ht):
     out, acc = ht.sample(t, th0, num_samples=4, num_steps_per_sample=3, step_size=0.05, debug=2, verbose=False, seed=1)
     s = torch.stack(out)
     assert s.shape == (4, C, D) and torch.isfinite(s).all() and float(acc.mean()) > 0.5
+    # round 5: on that path the target brings its batched closed form - ONE [C, D] x [D, D] product per gradient (rocBLAS) instead
+    # of autograd under vmap; same values as the opaque closure over the same matrix
+    from hamiltorch_amd import samplers
+    cb = samplers._BatchedCallback(t)
+    assert getattr(cb, "closed_form", False)
+    g, lp = cb.grad(th0)
+    opaque = samplers._BatchedCallback(lambda w: t(w))
+    g2, lp2 = opaque.grad(th0)
+    assert torch.allclose(g, g2, rtol=1e-5, atol=1e-6) and torch.allclose(lp, lp2, rtol=1e-5, atol=1e-5)
+    out2, acc2 = ht.sample(lambda w: t(w), th0, num_samples=4, num_steps_per_sample=3, step_size=0.05, debug=2, verbose=False, seed=1, native=False)
+    assert torch.allclose(torch.stack(out2), s, rtol=1e-4, atol=1e-5)
 
 
 def test_mlp_with_large_data_set_falls_back_instead_of_raising(ht):
