@@ -243,6 +243,8 @@ class _WarmBases:
         """Back to the identity (a cold evaluation next): the kernel treats V0 as exactly orthogonal, and `V <- V0 X` in place
         lets rounding accumulate in V^T V - I over a long run.  The samplers call this once per trajectory:
         one cold evaluation in 8 L + 3, the drift bounded by a trajectory's products."""
+        if os.environ.get("HAMILTORCH_AMD_WARM_RESET", "1") == "0":     # measurement knob (ADVICE r04): what the reset costs - see CHANGELOG round 5
+            return
         for buf in self.bufs.values():
             buf.zero_()
             buf.diagonal(dim1=-2, dim2=-1).fill_(1.0)
