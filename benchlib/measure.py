@@ -98,14 +98,29 @@ def result_of(w, W, dt, call_ms, prof_ms, prof_n, steps, warmup, world):
     from hamiltorch_amd.ess import ess_min
     # ESS over the first ESS_DIMS coordinates - the ones the CPU baseline's samples travel with (oracle/cpu_baseline.py), so that
     # both sides of `ess_per_sec_vs_cpu_baseline` are the same estimator on the same coordinates
-    ess = ess_min(w.samples[1:, :, :ESS_DIMS]) if w.T >= 8 else float("nan")
+    ess_seconds = call_ms * 1e-3
+    if w.T >= 8:
+        ess = ess_min(w.samples[1:, :, :ESS_DIMS])
+    elif getattr(W, "ess_extra_steps", 0) and w.samples is not None:
+        # workloads whose step is one or two trajectories (the published-model runs, funnel-rmhmc): an UNTIMED run of consecutive steps
+        # after the measurement - the chain state travels from step to step - supplies the draws; ESS / s = ESS of those draws / (their
+        # steps x the measured time per step)
+        draws = []
+        for k in range(W.ess_extra_steps):
+            w.step(100000 + k)
+            draws.append(w.samples[1:, :, :ESS_DIMS].clone())
+        torch.cuda.synchronize()
+        ess = ess_min(torch.cat(draws))
+        ess_seconds = W.ess_extra_steps * call_ms * 1e-3
+    else:
+        ess = float("nan")
     return {"key": W.key + ("-eig" if getattr(w, "jacobi", False) else ""), "workload": W.name, "value": units / dt,
             "unit": "leapfrog-steps/s", "steps": steps, "warmup": warmup,
             "ms_per_step": dt / steps * 1e3, "dtype": W.dtype_name,
             "config": {"workload": W.name, "chains_per_gpu": w.C, "chains_total": w.C * world,
                        "trajectories_per_step": w.T, "leapfrog_steps_per_trajectory": W.L, "D": W.D,
                        "samples_stored": True, "parallelism": "chains sharded, %d per GPU, no collective" % w.C},
-            "roofline": roof, "route": getattr(w, "route", ""), "acceptance_rate": acc, "ess_per_sec": ess / (call_ms * 1e-3),
+            "roofline": roof, "route": getattr(w, "route", ""), "acceptance_rate": acc, "ess_per_sec": ess / ess_seconds,
             "ess_dims": min(W.D, ESS_DIMS)}
 
 

@@ -335,6 +335,7 @@ class NbMlp:
     D, L, eps, chains, traj = 10401, 30, 5e-4, 1024, 1
     M, Nb = 4, 100
     dtype_name = "f32"
+    ess_extra_steps = 16           # one trajectory per step: ESS from 16 consecutive untimed steps (benchlib/measure.py)
     dims = [1, 100, 100, 1]
     tau_out = 110.4439498986428
     published = {"samples_per_s": 1.83, "hw": "RTX 2080 Max-Q, 1 chain", "src": "split_HMC_BNN nb cell 25"}
