@@ -101,7 +101,7 @@ def result_of(w, W, dt, call_ms, prof_ms, prof_n, steps, warmup, world):
     ess_seconds = call_ms * 1e-3
     if w.T >= 8:
         ess = ess_min(w.samples[1:, :, :ESS_DIMS])
-    elif getattr(W, "ess_extra_steps", 0) and w.samples is not None:
+    elif getattr(W, "ess_extra_steps", 0) and w.samples is not None and os.environ.get("HTA_BENCH_ESS_EXTRA", "1") != "0":
         # workloads whose step is one or two trajectories (the published-model runs, funnel-rmhmc): an UNTIMED run of consecutive steps
         # after the measurement - the chain state travels from step to step - supplies the draws; ESS / s = ESS of those draws / (their
         # steps x the measured time per step)

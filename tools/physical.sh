@@ -1,8 +1,11 @@
 #!/bin/bash
+# (round 5: the step counts of the workloads are the bench line's own - 10 timed + 2 warm-up for the RMHMC / cfg4 secondaries - so that the
+#  average kernel duration of a pass is the duration the line's HIP events see, not that of the first three calls after a cold start)
 # tools/physical.sh <tag>: the rocprofv3 passes behind profiles/physical.json (bench.py's `roofline.physical`) and the per-round
 # kernel-stat summaries.  One workload per block; per workload: --kernel-trace --stats, then three SEPARATE --pmc passes
 # (kernel-trace only beside them).  Run on the GPU box (gpurun); writes gpurun_out/<tag>_*.
 export TMPDIR=/tmp
+export HTA_BENCH_ESS_EXTRA=0     # (no untimed ESS continuation steps under the profiler: launches per step must be the timed region's)
 R=${1:-r03}
 O=gpurun_out/${R}_phys
 mkdir -p $O
@@ -25,12 +28,12 @@ one() {  # key steps warmup traj env -- bench args
   echo "$key done ($(( $(date +%s) - t0 )) s)"
 }
 one cfg2@1024 20 3 1000 X=1
-one cfg3@1024 3 1 100 X=1 --workload cfg3@1024
-one cfg3@256 2 1 400 X=1 --workload cfg3
-one cfg3jacobi@256 1 1 20 HTA_RMHMC_FUSED=0 --workload cfg3 --traj 20
-one cfg4@512 5 1 20 X=1 --workload cfg4
-one nbmlp@1024 2 1 1 X=1 --workload nbmlp
-one nbmlp-full@1024 2 1 1 X=1 --workload nbmlp-full
+one cfg3@1024 10 2 100 X=1 --workload cfg3@1024
+one cfg3@256 10 2 400 X=1 --workload cfg3
+one cfg3jacobi@256 3 1 20 HTA_RMHMC_FUSED=0 --workload cfg3 --traj 20
+one cfg4@512 10 2 20 X=1 --workload cfg4
+one nbmlp@1024 6 2 1 X=1 --workload nbmlp
+one nbmlp-full@1024 6 2 1 X=1 --workload nbmlp-full
 python tools/physical.py $KEYS > gpurun_out/${R}_physical_new.json
 python - <<P
 import json
