@@ -28,7 +28,7 @@ one() {  # key steps warmup traj env -- bench args
   echo "$key done ($(( $(date +%s) - t0 )) s)"
 }
 one cfg2@1024 20 3 1000 X=1
-one cfg3@1024 10 2 100 X=1 --workload cfg3@1024
+one cfg3@1024 20 5 100 X=1 --workload cfg3@1024
 one cfg3@256 10 2 400 X=1 --workload cfg3
 one cfg3jacobi@256 3 1 20 HTA_RMHMC_FUSED=0 --workload cfg3 --traj 20
 one cfg4@512 10 2 20 X=1 --workload cfg4
