@@ -43,8 +43,7 @@ def _compact_roofline(roof):
            "simds_occupied_frac": _r(roof.get("simds_occupied_frac", phys.get("simds_occupied_frac")), 3)}
     lat = roof.get("latency_model")
     if lat:            # cfg2: the bound is the dependent-FMA chain; the other candidate bounds as named side fields
-        out["cycles_per_trajectory"] = _r(lat.get("measured_cycles_per_trajectory"), 4)
-        out["floor_cycles_per_trajectory"] = lat.get("floor_cycles_per_trajectory")
+        out["cycles_per_trajectory"] = _r(lat.get("measured_cycles_per_trajectory"), 4)      # (floor: 2 L x 4 = frac x this)
     if roof.get("hbm_model_8d"):
         out["hbm_model_8d_ratio"] = _r(roof["hbm_model_8d"].get("ratio_to_hbm_peak"), 4)      # SURVEY 8(d) streaming convention: not a utilisation
     for k in ("hbm_counter_frac", "valu_frac"):
@@ -85,7 +84,7 @@ def compact_line(full, detail_path="bench_detail.json"):
         if full.get(k) is not None:
             out[k] = _r(full[k])
     for k in ("ranks_seen", "rank_devices", "launcher", "collective_backend"):
-        if k in full and (full.get("n_gpus", 1) > 1 or k == "ranks_seen"):
+        if k in full and full.get("n_gpus", 1) > 1:
             out[k] = full[k]
     sec = []
     for r in full.get("secondary", []) or []:
@@ -95,11 +94,12 @@ def compact_line(full, detail_path="bench_detail.json"):
         roof, cb = _compact_roofline(r.get("roofline", {})), r.get("cpu_baseline") or {}
         # one entry per workload, short: bound / unit / achieved follow from `frac` (bound "mfma": frac x 157.3 TFLOP/s; "hbm":
         # frac x 8000 GB/s) and are spelled out in bench_detail.json
+        # (`bound` is spelled out only where it is not "mfma" = useful flops / kernel time / 157.3 TFLOP/s)
         # (sizes: the line must stay < LINE_LIMIT with nine workloads - wall ms per step = chains x T x L / value and padding = issued /
         # useful follow from the fields kept; `cores` / `kind` of a CPU baseline are spelled out only where they differ from the primary's)
         pcb = full.get("cpu_baseline") or {}
         e = {"key": _short_key(r), "chains": r.get("config", {}).get("chains_per_gpu"), "value": _r(r.get("value")),
-             "frac": roof["frac"], "bound": roof["bound"], "mfma_busy": roof["mfma_busy"],
+             "frac": roof["frac"], "bound": roof["bound"] if roof["bound"] != "mfma" else None, "mfma_busy": roof["mfma_busy"],
              "traffic": _r(roof["traffic"], 4), "kernel": roof["kernel"][:28], "kernel_ms": _r(roof["kernel_ms"], 4),
              "cpu": {"value": _r(cb.get("value"), 4)}}
         if cb.get("cores") != pcb.get("cores"):
@@ -132,7 +132,6 @@ def compact_line(full, detail_path="bench_detail.json"):
         if r.get("published"):
             e["samples_per_s"] = _r(r.get("samples_per_s"), 4)
             e["published_sps"] = r["published"].get("samples_per_s")
-            e["cpu"]["samples_per_s"] = _r(cb.get("samples_per_s"), 3)
         sec.append({k: v for k, v in e.items() if v is not None or k in ("value", "frac", "chains")})
     if sec:
         out["secondary"] = sec
