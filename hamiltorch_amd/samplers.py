@@ -796,16 +796,12 @@ class _GenericHMC(_Engine):
                 and all(cb.capturable() for cb in self.cbs))
 
     def advance(self, n0, count, L, eps, H_old=None, H_new=None, progress=None):
-        for _ in self._advance_iter(n0, count, L, eps, H_old, H_new, progress):
-            pass
-
-    def _advance_iter(self, n0, count, L, eps, H_old=None, H_new=None, progress=None):
-        """`advance` as a generator: yields every time it has ENQUEUED a trajectory.  (Round 5 used it to interleave G engines over
-        contiguous chain blocks, each with its own captured trajectory graph and HIP stream - the idea being that a callback trajectory
-        is a chain of ~1000 dependent few-microsecond launches and G such chains could run side by side.  Measured on the notebook
-        funnel at 1024 chains (profiles/r05g_chain_groups.txt): 1 group 1.21e7 chain-steps/s, 2 groups 8.8e6, 4 groups 5.7e6, 8 groups
-        3.1e6 - the time follows the TOTAL node count: what bounds a replayed graph of tiny kernels is the rate at which the device
-        retires dispatch packets (~2 us each), not the latency of one dependent chain.  Not kept; fewer nodes is the only lever.)"""
+        # (Round 5 tried to run G of these loops side by side - G engines over contiguous chain blocks, each with its own captured
+        #  trajectory graph and HIP stream: a callback trajectory is a chain of ~1000 dependent few-microsecond launches, and G such chains
+        #  might overlap.  Measured on the notebook funnel at 1024 chains (profiles/r05g_chain_groups.txt): 1 group 1.21e7 chain-steps/s,
+        #  2 groups 8.8e6, 4 groups 5.7e6, 8 groups 3.1e6 - the time follows the TOTAL node count: what bounds a replayed graph of tiny
+        #  kernels is the rate at which the device retires dispatch packets (~2 us each), not the latency of one dependent chain.
+        #  Not kept; fewer nodes is the only lever.)
         Ho = self.Ho if H_old is None else H_old
         Hn = self.Hn if H_new is None else H_new
         n, end = n0, n0 + count
@@ -816,11 +812,9 @@ class _GenericHMC(_Engine):
                 progress.update(n)
             self._trajectory(n, L, eps, Ho, Hn)                                            # eager: settles vmap / capture fallbacks
             n += 1
-            yield n
             graph = self._capture_trajectory(n, L, eps, Ho, Hn) if self._graph_eligible(end - n, H_old) else None
             if graph is not None:
                 n += 1                                                                     # the capture warm-up ran trajectory n
-                yield n
                 while n < end:
                     if progress is not None:
                         progress.update(n)
@@ -828,13 +822,11 @@ class _GenericHMC(_Engine):
                     if n == self.burn + 1:                             # Q2 reset inside the replayed trajectory: refresh the carried pair
                         self._refresh_cache()
                     n += 1
-                    yield n
         while n < end:
             if progress is not None:
                 progress.update(n)
             self._trajectory(n, L, eps, Ho, Hn)
             n += 1
-            yield n
 
     def _capture_trajectory(self, n, L, eps, Ho, Hn):
         dev = self.cur.device
