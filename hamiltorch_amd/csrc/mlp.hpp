@@ -81,4 +81,5 @@ extern int g_mlp_valu;                                        // tuning key "mlp
 bool mlp_mfma_eligible(const MlpArgs<float>& a);
 int mlp_mfma(const MlpArgs<float>& a, hipStream_t s);         // mlp_mfma.hip
 
+
 }  // namespace hta
