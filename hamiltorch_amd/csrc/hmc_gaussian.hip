@@ -734,7 +734,12 @@ __global__ __launch_bounds__(256) void hmc_gauss_eig_kernel(GaussArgs<T> a, cons
 #ifndef QUAD_FUSED_NS
 #define QUAD_FUSED_NS 4
 #endif
-constexpr int QUAD_SLOTS_MAX = 4;     // record look-ahead of the quad kernel = rows of slack in the workspace
+// Developer builds only (profiles/r05y_quad_ablation.txt: timing of the trajectory's parts, wrong samples): -DQUAD_FUSED_NS=n -DQUAD_SLOTS=m (a deeper
+// record look-ahead: measured, no effect), -DQUAD_ABLATE_STORE / _LOAD / _ACC / _TAIL (one cost of a trajectory removed at a time).
+#ifndef QUAD_SLOTS
+#define QUAD_SLOTS 4
+#endif
+constexpr int QUAD_SLOTS_MAX = QUAD_SLOTS;     // record look-ahead of the quad kernel = rows of slack in the workspace
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
@@ -887,7 +892,7 @@ __device__ __forceinline__ void quad_body(const GaussArgs<float>& a, const float
   // UADDR: the record of the trajectory at position i of the unrolled loop is recb + roff[i] (recb: the row NS ahead of the
   // pass's first trajectory), its stored row element rowb + soff[i]; both bases are wave-uniform and move once per pass.
   // (the dispatcher bounds C so that the offsets stay below 2^32)
-  constexpr int NU = UADDR ? (LB == 25 ? 8 : 4) * NS : 2 * NS;       // trajectories per pass of the unrolled loop (the scalar bookkeeping of a pass is shared)
+  constexpr int NU = UADDR ? (LB == 25 ? (NS > 4 ? 4 : 8) : 4) * NS : 2 * NS;       // trajectories per pass of the unrolled loop (the scalar bookkeeping of a pass is shared)
   typedef const __attribute__((address_space(1))) char* gcbytes_t;
   gcbytes_t recb = (gcbytes_t)a.ws_z + (size_t)NS * (rec_step * sizeof(T));
   uint32_t roff[NU], uoff[NU], soff[NU];
@@ -934,7 +939,9 @@ __device__ __forceinline__ void quad_body(const GaussArgs<float>& a, const float
       //  otherwise the scheduler hoists the load and the back-edge copy of its result waits for it)
       if constexpr (UADDR) {
         asm volatile("" : "+v"(roff[pos]) : "v"(r), "v"(eo), "v"(logu));
+#if !defined(QUAD_ABLATE_LOAD)
         slot = *(grec_t)(recb + roff[pos]);
+#endif
         if (D == 4) slot_u = *(grec_t)(recb + uoff[pos]);
       } else {
         asm volatile("" : "+v"(rec) : "v"(r), "v"(eo), "v"(logu));
@@ -971,6 +978,9 @@ __device__ __forceinline__ void quad_body(const GaussArgs<float>& a, const float
         else if constexpr (D == 2)
           asm volatile("v_mov_b32 %0, %3" HTA_QG(0, 4) HTA_B1 HTA_QG(1, 5) "\n\ts_nop 0" HTA_B2
                        : "=&v"(qp), "+v"(dH) : "v"(y), "v"(mu), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]));
+#if defined(QUAD_ABLATE_TAIL)
+        else if constexpr (D == 3) qp = y;
+#endif
         else if constexpr (D == 3)
           asm volatile("v_mov_b32 %0, %3" HTA_QG(0, 4) HTA_B1 HTA_QG(1, 5) HTA_QG(2, 6) HTA_B2
                        : "=&v"(qp), "+v"(dH) : "v"(y), "v"(mu), "v"(Qrow[0]), "v"(Qrow[D > 1 ? 1 : 0]), "v"(Qrow[D > 2 ? 2 : 0]));
@@ -1000,7 +1010,11 @@ __device__ __forceinline__ void quad_body(const GaussArgs<float>& a, const float
       // the decision as a lane mask (v_cmp into an SGPR pair), consumed by a carry-in add and two selects
       // rho = min(0, dH) >= log u  <=>  dH >= log u, because log u <= 0 (S:1000-1004).  A non-finite dH must reject:
       // fma(dH, 0, dH) is dH when dH is finite and NaN otherwise (inf * 0), and NaN >= x is false - one compare in all.
+#if defined(QUAD_ABLATE_ACC)
+      const uint64_t accmask = ~0ull; asm volatile("" :: "v"(dH), "v"(logu));
+#else
       const uint64_t accmask = __builtin_amdgcn_fcmpf(NOGUARD ? dH : __builtin_fmaf(dH, 0.0f, dH), logu, 3 /* oge */);
+#endif
       if constexpr (!decltype(q2)::value) {
         // accepted += acc; yc, potc, qc <- accepted point: a carry-in add and three selects on the accept mask
         uint64_t carry_out;
@@ -1020,7 +1034,9 @@ __device__ __forceinline__ void quad_body(const GaussArgs<float>& a, const float
       }
       if constexpr (UADDR) {
         asm volatile("" : "+v"(soff[pos]));            // keeps the zero-extension next to its use: base + 32-bit offset addressing
+#if !defined(QUAD_ABLATE_STORE)
         *(__attribute__((address_space(1))) T*)(row + soff[pos]) = qc;
+#endif
       } else {
         put(row, qc);
         row += row_step;
@@ -1816,7 +1832,7 @@ int64_t hta_hmc_gaussian_workspace_bytes(int64_t C, int D, int n_traj, int elem_
   const int per_vec = 16 / elem_size;
   const int64_t rec = ((int64_t)(D + 1 + per_vec - 1) / per_vec) * per_vec;
   /* + four rows read ahead by the last trajectories, + the eigen block (lam, Qt, Tin, Tout; D <= 6) of the eigenbasis route */
-  return ((int64_t)n_traj + 4) * C * rec * elem_size + (D <= 6 ? hta::EIG_ELEMS * elem_size : 0);
+  return ((int64_t)n_traj + hta::QUAD_SLOTS_MAX) * C * rec * elem_size + (D <= 6 ? hta::EIG_ELEMS * elem_size : 0);
 }
 
 int64_t hta_hmc_gaussian_status_offset(int64_t C, int D, int n_traj, int elem_size) {
