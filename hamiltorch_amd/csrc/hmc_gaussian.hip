@@ -939,7 +939,14 @@ __device__ __forceinline__ void quad_body(const GaussArgs<float>& a, const float
       //  otherwise the scheduler hoists the load and the back-edge copy of its result waits for it)
       if constexpr (UADDR) {
         asm volatile("" : "+v"(roff[pos]) : "v"(r), "v"(eo), "v"(logu));
-#if !defined(QUAD_ABLATE_LOAD)
+#if defined(QUAD_ABLATE_LOAD4)      // timing only (needs -DQUAD_FUSED_NS=8 -DQUAD_SLOTS=8): ONE 16-byte load per four trajectories into the four slots just consumed
+        if constexpr (decltype(pos)::value % 4 == 3 && NS == 8) {
+          typedef float V4f __attribute__((ext_vector_type(4)));
+          const V4f q4 = *(const __attribute__((address_space(1))) V4f*)(recb + roff[pos]);
+          constexpr int b0 = (decltype(pos)::value % 8) - 3;
+          zs[b0] = q4[0]; zs[b0 + 1] = q4[1]; zs[b0 + 2] = q4[2]; zs[b0 + 3] = q4[3];
+        }
+#elif !defined(QUAD_ABLATE_LOAD)
         slot = *(grec_t)(recb + roff[pos]);
 #endif
         if (D == 4) slot_u = *(grec_t)(recb + uoff[pos]);
