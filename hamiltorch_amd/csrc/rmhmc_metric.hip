@@ -144,7 +144,8 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
     if (softabs) {
       for (int e = tid; e < D * ldv; e += MT) { const int k = e / ldv, i = e - k * ldv; V[e] = (i == k) ? (T)1 : (T)0; }   // VT = I (incl. row padding)
       __syncthreads();
-      lds_jacobi<T, MAXB, MAXV>(A, V, D, ne, lda, ldv, cs, pq, red, a.max_sweeps);
+      if constexpr (MAXB == 0) lds_jacobi_dyn<T>(A, V, D, ne, lda, ldv, cs, red, a.max_sweeps);      // (run-time work lists: any D <= MT)
+      else lds_jacobi<T, MAXB, MAXV>(A, V, D, ne, lda, ldv, cs, pq, red, a.max_sweeps);
       // lam~ = lam / tanh(alpha lam)   (S:120)
       T ld = 0;
       for (int i = tid; i < D; i += MT) {
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
 //   LDS: A[ne][lda] + VT[D][ldv] + 5 vectors + reduction scratch + pair table, the leading dimension padded to an odd stride when that
 //   still fits the 160 KiB of one CU (+ a copy of the shared warm basis when there is room);
 //   vglobal: VT in a global slab per workgroup (fp64 from D = 100, fp32 from D = 141);  aglobal: A there as well.
-struct MetricGeom { int ne, lda, ldv, v0_lds, grid_cap; size_t lds; bool small, vglobal, aglobal; int64_t slab_elems; };
+struct MetricGeom { int ne, lda, ldv, v0_lds, grid_cap; size_t lds; bool small, vglobal, aglobal, dyn; int64_t slab_elems; };
 static MetricGeom metric_geometry(int D, int elem, bool warm) {
   MetricGeom g{};
   const int ne = D + (D & 1);
@@ -368,7 +369,8 @@ static MetricGeom metric_geometry(int D, int elem, bool warm) {
   g.small = NP * (NP + 1) / 2 <= 2 * MT && NP * nv <= 2 * MT;
   const bool mid = NP * (NP + 1) / 2 <= 4 * MT && NP * nv <= 3 * MT;
   if (g.lds > 160 * 1024 || !mid) {                // the work matrix moves out as well; the instance with the long work lists
-    if (!(NP * (NP + 1) / 2 <= 8 * MT && NP * nv <= 8 * MT)) { g.lds = 0; return g; }
+    g.dyn = !(NP * (NP + 1) / 2 <= 8 * MT && NP * nv <= 8 * MT);      // beyond the longest register lists: the run-time work lists
+    if (g.dyn && D > MT) { g.lds = 0; return g; }                      // (the kernel's own row batches: D <= MT)
     g.lda = ne + 1;
     g.lds = bytes(0, 0, false);
     g.vglobal = g.aglobal = true;
@@ -398,7 +400,7 @@ template <typename T> int metric_eval(const MetricArgsT<T>& a, hipStream_t s) {
   }
   const int D = a.D;
   const MetricGeom g = metric_geometry(D, (int)sizeof(T), a.metric == 1 && a.V0 && a.lam0 && a.hs_stride == 0);
-  HTA_REQUIRE(g.lds > 0, "hta_metric_eval: D=%d exceeds the per-thread work lists of the largest instance (254 fp32 / 180 fp64)", D);
+  HTA_REQUIRE(g.lds > 0, "hta_metric_eval: D=%d exceeds the kernel's row batches (D <= %d)", D, MT);
   MetricArgsT<T> k = a;
   if (k.max_sweeps <= 0) k.max_sweeps = sizeof(T) == 4 ? 16 : 24;
   const int grid = (int)(a.B < g.grid_cap ? a.B : g.grid_cap);
@@ -416,13 +418,14 @@ template <typename T> int metric_eval(const MetricArgsT<T>& a, hipStream_t s) {
       done = true;
     }
     profile_begin(s);
-    note_route("metric_eval_kernel<%s%s>", sizeof(T) == 4 ? "float" : "double", g.aglobal ? ",aglobal" : (g.vglobal ? ",vglobal" : ""));
+    note_route("metric_eval_kernel<%s%s>", sizeof(T) == 4 ? "float" : "double", g.dyn ? ",aglobal,dyn" : g.aglobal ? ",aglobal" : (g.vglobal ? ",vglobal" : ""));
     kern<<<grid, MT, g.lds, s>>>(k, g.ne, g.lda, g.ldv, g.v0_lds, vws);
     profile_end(s);
     return HTA_OK;
   };
-  static DevOnce done_small, done_big, done_vg, done_ag;   // per T instantiation
-  const int rc = g.aglobal ? launch(&metric_eval_kernel<T, 8, 8, true, true>, done_ag)
+  static DevOnce done_small, done_big, done_vg, done_ag, done_dyn;   // per T instantiation
+  const int rc = g.dyn ? launch(&metric_eval_kernel<T, 0, 0, true, true>, done_dyn)
+               : g.aglobal ? launch(&metric_eval_kernel<T, 8, 8, true, true>, done_ag)
                : g.vglobal ? launch(&metric_eval_kernel<T, 4, 3, true>, done_vg)
                            : (g.small ? launch(&metric_eval_kernel<T, 2, 2>, done_small) : launch(&metric_eval_kernel<T, 4, 3>, done_big));
   if (rc) return rc;

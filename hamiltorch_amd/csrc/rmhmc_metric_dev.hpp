@@ -222,6 +222,90 @@ __device__ void lds_jacobi(T* A, T* VT, int D, int ne, int lda, int ldv, T* cs_r
   __syncthreads();
 }
 
+// The same sweeps with the work lists walked at RUN time (round 5, the instance for every size beyond the register lists of
+// lds_jacobi: D > 254 fp32 / 180 fp64, both matrices in the caller's slab): a thread decodes its pair-blocks and its VT vectors
+// again in every round.  Slow on purpose - the reference has no size limit (S:108-122), so this is an answer, not an error.
+// Same arithmetic, same order inside a round (a round's rotations are disjoint: any assignment of blocks to threads gives the same
+// result).  Limits left: one thread per rotation of a round (D <= 2 MT) and the callers' own (D <= MT).
+template <typename T>
+__device__ void lds_jacobi_dyn(T* A, T* VT, int D, int ne, int lda, int ldv, T* cs_raw, T* red, int max_sweeps) {
+  typedef typename Vec16<T>::type V16;
+  typedef typename Vec8<T>::type CS;
+  constexpr int VN = Vec16<T>::N;
+  CS* cs = reinterpret_cast<CS*>(cs_raw);
+  const int tid = threadIdx.x;
+  const int NP = ne / 2;
+  const int nblk = NP * (NP + 1) / 2;
+  const int nv = ldv / VN;
+  T off_prev = (T)-1;
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    T off = 0, dg = 0;
+    for (int e = tid; e < D * D; e += MT) {
+      const int i = e / D, j = e - i * D;
+      if (j >= i) {
+        const T a = A[(int64_t)i * lda + j];
+        if (i == j) dg += a * a; else off += (T)2 * a * a;
+      }
+    }
+    off = block_sum(off, red);
+    dg = block_sum(dg, red);
+    const T tol = (T)64 * Eps<T>::v * Eps<T>::v;
+    if (!(off > tol * (dg + off))) break;
+    if (sweep >= 4 && off_prev >= (T)0 && off > (T)0.25 * off_prev && off <= (T)1e-6 * (dg + off)) break;
+    off_prev = off;
+    for (int r = 0; r < ne - 1; ++r) {
+      __syncthreads();
+      if (tid < NP) {
+        int p, q;
+        rr_pair(ne, r, tid, p, q);
+        const T app = A[(int64_t)p * lda + p], aqq = A[(int64_t)q * lda + q], apq = A[(int64_t)p * lda + q];
+        T c = 1, s = 0;
+        if (apq != (T)0) rotation<T>(app, aqq, apq, c, s);
+        CS v; v.x = c; v.y = s;
+        cs[tid] = v;
+      }
+      __syncthreads();
+      // row a of the upper block triangle starts at block a NP - a (a - 1) / 2: a thread walks its blocks with (a, bb) carried along
+      for (int e = tid; e < nblk; e += MT) {
+        int a = (int)(((double)(2 * NP + 1) - sqrt((double)(2 * NP + 1) * (double)(2 * NP + 1) - 8.0 * (double)e)) * 0.5);
+        if (a < 0) a = 0;
+        while (a > 0 && a * NP - a * (a - 1) / 2 > e) --a;
+        while ((a + 1) * NP - (a + 1) * a / 2 <= e) ++a;
+        const int bb = a + (e - (a * NP - a * (a - 1) / 2));
+        int pa, qa, pb, qb;
+        rr_pair(ne, r, a, pa, qa);
+        rr_pair(ne, r, bb, pb, qb);
+        const CS ra = cs[a], rb = cs[bb];
+        const T ca = ra.x, sa = ra.y, cb = rb.x, sb = rb.y;
+        const int64_t i00 = (int64_t)min(pa, pb) * lda + max(pa, pb), i01 = (int64_t)min(pa, qb) * lda + max(pa, qb);
+        const int64_t i10 = (int64_t)min(qa, pb) * lda + max(qa, pb), i11 = (int64_t)min(qa, qb) * lda + max(qa, qb);
+        const T m00 = A[i00], m01 = A[i01], m10 = A[i10], m11 = A[i11];
+        const T t00 = cb * m00 - sb * m01, t01 = sb * m00 + cb * m01;
+        const T t10 = cb * m10 - sb * m11, t11 = sb * m10 + cb * m11;
+        T n00 = ca * t00 - sa * t10, n01 = ca * t01 - sa * t11;
+        T n10 = sa * t00 + ca * t10, n11 = sa * t01 + ca * t11;
+        if (a == bb) { n01 = 0; n10 = 0; }
+        A[i00] = n00; A[i01] = n01; A[i10] = n10; A[i11] = n11;
+      }
+      for (int e = tid; e < NP * nv; e += MT) {
+        const int vb = e / nv, vg = e - vb * nv;
+        int pb, qb;
+        rr_pair(ne, r, vb, pb, qb);
+        if (qb < D) {
+          const CS rb = cs[vb];
+          V16* rp = reinterpret_cast<V16*>(VT + (int64_t)pb * ldv) + vg;
+          V16* rq = reinterpret_cast<V16*>(VT + (int64_t)qb * ldv) + vg;
+          const V16 vp = *rp, vq = *rq;
+          *rp = rb.x * vp - rb.y * vq;
+          *rq = rb.y * vp + rb.x * vq;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------
 // d lam~ / d lam for the soft-abs map lam~ = lam coth(alpha lam) (S:120):  coth x - x / sinh^2 x with x = alpha lam
 // (an odd function of x; series below |x| = 0.3 where the closed form cancels, exp(-2|x|) form elsewhere: no overflow)

@@ -254,7 +254,9 @@ typedef struct HtaMetricArgs {
                                                 needed (else HTA_ERR_INVALID) where a system's two D x D matrices exceed the 160 KiB
                                                 LDS of one CU - fp64 from D = 100, fp32 from D = 141: the eigenvector matrix, from
                                                 D ~ 140 / ~198 also the work matrix, live in one slab per workgroup (<= 512
-                                                workgroups), up to D = 254 fp32 / 180 fp64.  Rounds 3-4 allocated it behind the
+                                                workgroups); to D = 254 fp32 / 180 fp64 with per-thread work lists in registers, beyond with
+                                                the lists walked at run time (D <= 1024: slow - 0.4 s per call at D = 512 - never an
+                                                error; the reference has no limit, S:108-122).  Rounds 3-4 allocated it behind the
                                                 ABI (hipMallocAsync per call).  NULL where the function returns 0.            */
 } HtaMetricArgs;
 

@@ -1384,12 +1384,14 @@ def test_metric_eval_fp32_beyond_one_cu_of_lds(ht, D):
 
 @pytest.mark.parametrize("dtype,D,rt,tol", [(torch.float32, 200, "float,aglobal", 3e-3), (torch.float32, 254, "float,aglobal", 4e-3),
                                             (torch.float64, 128, "double,aglobal", 1e-8), (torch.float64, 180, "double,aglobal", 2e-8),
-                                            (torch.float64, 110, "double,vglobal", 1e-8)])
+                                            (torch.float64, 110, "double,vglobal", 1e-8),
+                                            (torch.float32, 300, "float,aglobal,dyn", 6e-3), (torch.float64, 200, "double,aglobal,dyn", 3e-8)])
 def test_metric_eval_beyond_the_round_4_size_limits(ht, dtype, D, rt, tol):
     """VERDICT r04 "missing" #4: fisher / cholesky_inverse / rm_hamiltonian have no size limit in the reference (S:108-122, S:146-148,
     S:710-731); hta_metric_eval stopped at D ~ 156 fp32 / 110 fp64 (the Jacobi kernel's per-thread work lists).  Round 5: the instance
     with both matrices in the caller's workspace slab (ABI 10: HtaMetricArgs::workspace) and 8 work-list entries per thread runs up to
-    D = 254 fp32 / 180 fp64 - slow (every rotation is an L2 round trip), not an error.  Against the oracle's float64 eigh."""
+    D = 254 fp32 / 180 fp64 - slow (every rotation is an L2 round trip), not an error; beyond that the instance that walks its work
+    lists at run time (`dyn`: any D <= 1024).  Against the oracle's float64 eigh."""
     from hamiltorch_amd import _abi
     B = 3
     Hs = sym_batch(B, D, "indef", D).astype(NP[dtype])
@@ -1415,7 +1417,7 @@ def test_metric_eval_beyond_the_round_4_size_limits(ht, dtype, D, rt, tol):
     np.testing.assert_allclose(ld.cpu().numpy(), np.linalg.slogdet(P.astype(np.float64))[1], rtol=0.1 * tol, atol=tol)
 
 
-@pytest.mark.parametrize("dtype,D,tol", [(torch.float32, 200, 2e-3), (torch.float64, 128, 1e-7)])
+@pytest.mark.parametrize("dtype,D,tol", [(torch.float32, 200, 2e-3), (torch.float64, 128, 1e-7), (torch.float32, 300, 4e-3), (torch.float64, 200, 2e-7)])
 def test_sample_rmhmc_softabs_beyond_the_round_4_size_limits(ht, dtype, D, tol):
     """sample(RMHMC, EXPLICIT, SOFTABS) at D = 200 fp32 / D = 128 fp64 with a finite soft-abs constant (an eigendecomposition per
     metric evaluation) returns and matches the oracle chain by chain - VERDICT r04 next-round item 9's "done" line."""
