@@ -125,7 +125,7 @@ def compact_line(full, detail_path="bench_detail.json"):
                 e[k] = _r(r[k], 4)
         if r.get("extras"):
             short = {"graph_replay": "graph", "value_graphs_off": "graphs_off", "value_notebook_closure": "nb_closure",
-                     "launches_per_step": "launches", "callback_evaluations_per_step": "cb_evals", "metric_evaluations_per_step": "metric_evals",
+                     "launches_per_step": "launches", "hta_launches_per_step": "hta_launches", "callback_evaluations_per_step": "cb_evals", "metric_evaluations_per_step": "metric_evals",
                      "predict_route": "predict", "predict_ms_torch_path": "predict_ms_torch"}
             e["extras"] = {short.get(k, k): _r(v, 4) for k, v in r["extras"].items()
                            if not isinstance(v, (dict, list)) and v is not None and k not in ("predict_samples_per_s", "predict_samples", "predict_ms_torch_path", "trajectories_per_step_1024", "kernel_ms_1024")}

@@ -561,7 +561,10 @@ class FunnelHMC:
             with profile(activities=[ProfilerActivity.CUDA]) as prof:
                 self._sample(self.fn, 200, self.T)
                 torch.cuda.synchronize()
-            return sum(e.count for e in prof.key_averages() if getattr(e, "device_type", None) is not None and "cuda" in str(e.device_type).lower())
+            evs = [e for e in prof.key_averages() if getattr(e, "device_type", None) is not None and "cuda" in str(e.device_type).lower()]
+            # the library's own share (kernel names in namespace hta) next to the callback's (torch's kernels: VERDICT r04 item 7)
+            self._hta_launches = sum(e.count for e in evs if "hta::" in str(e.key))
+            return sum(e.count for e in evs)
         except Exception:
             return None
 
@@ -574,6 +577,7 @@ class FunnelHMC:
                "value_notebook_closure": self._rate(funnel_ll_notebook, T),
                "launches_per_step": self._launches(),
                "callback_evaluations_per_step": self.T * (self.L + 1)}
+        out["hta_launches_per_step"] = getattr(self, "_hta_launches", None)
         return out
 
     def roofline(self, kernel_ms, call_ms, prof_n, steps):

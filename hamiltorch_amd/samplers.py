@@ -139,8 +139,10 @@ class _BatchedCallback:
                 self._fallback(e)
         return self._loop(theta, False)[1].contiguous()
 
-    def grad(self, theta):
-        """(grad[C,D], logp[C]) at theta."""
+    def grad(self, theta, own=True):
+        """(grad[C,D], logp[C]) at theta.  own=False: the results may be the replayed graph's own output buffers - valid until this
+        callback is evaluated again (a caller that consumes them at once saves two copy launches per evaluation: 5 % of a callback
+        trajectory's ~39 launches per leapfrog step, profiles/r05ac_callback_launches.txt)."""
         if self.pass_grad is not None and not callable(self.pass_grad):
             g = self.pass_grad.to(theta).expand_as(theta).contiguous()
             return g, self.logp(theta)
@@ -149,7 +151,7 @@ class _BatchedCallback:
                 if self._v_pg is not None:
                     return _own(self._v_pg(theta)), self.logp(theta)
                 g, v = self._v_gv(theta)
-                return _own(g), _own(v)
+                return (_own(g), _own(v)) if own else (g.contiguous(), v.contiguous())      # (contiguous(): no launch unless strided)
             except Exception as e:
                 if not _not_batchable(e):
                     raise
@@ -767,7 +769,7 @@ class _GenericHMC(_Engine):
             g, logp1 = self._g_cur, self._lp_cur
             _abi.kick_drift(prop, p, g, 0.5 * eps, eps if L > 0 else 0.0, kind, im)        # S:281, S:284
             for l in range(L):
-                g, logp1 = cb.grad(prop)                                                   # S:297
+                g, logp1 = cb.grad(prop, own=False)                                        # S:297 (consumed before the next evaluation)
                 _abi.kick_drift(prop, p, g, eps, 0.0 if l == L - 1 else eps, kind, im)     # S:298 (+ next drift)
             _abi.kick_drift(prop, p, g, -0.5 * eps, 0.0, kind, im)                         # S:302
             logp1 = logp1.to(cur.dtype).contiguous()   # log-prob at the end point, from the last gradient call
