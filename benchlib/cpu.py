@@ -113,16 +113,22 @@ def cpu_baseline_procs(key, seconds, rounds=1):
                 out["ess_draws"] = [S, procs_ok]
                 out["ess_per_sec"] = ess / dt
         return out
-    reps = sorted((once(r) for r in range(rounds)), key=lambda r: r["value"])
+    out = pick_round([once(r) for r in range(rounds)])
+    out["pinned_to"] = PINNED.get(key, "")
+    return out
+
+
+def pick_round(reps):
+    """The record of several rounds of one baseline: the median round by `value`, with `repeats`; ESS / s - the noisier
+    number (short chains: one chain that sits in a slow region decides the minimum over dimensions; the notebook funnel moved between 3.8
+    and 35 from run to run with one round) - is the median of the rounds' own values, listed in `ess_per_sec_rounds`."""
+    reps = sorted(reps, key=lambda r: r["value"])
     out = reps[len(reps) // 2]
-    if rounds > 1:
+    if len(reps) > 1:
         out["repeats"] = [r["value"] for r in reps]
-        # ESS / s is the noisier number (short chains: one chain that sits in a slow region decides the minimum over dimensions -
-        # the notebook funnel moved between 3.8 and 35 from run to run): the median round's, like `value`, but by its own order
         es = sorted(r["ess_per_sec"] for r in reps if r.get("ess_per_sec") is not None and r["ess_per_sec"] == r["ess_per_sec"])
         if len(es) == len(reps):
             out["ess_per_sec_rounds"] = es
             out["ess_per_sec"] = es[len(es) // 2]
-    out["pinned_to"] = PINNED.get(key, "")
     return out
 

@@ -148,3 +148,16 @@ def test_funnel_entries_carry_their_extras_and_stay_inside_the_limit():
     fh = rec["secondary"][keys.index("funnel-hmc")]
     assert fh["extras"]["graph"] is True and fh["extras"]["graphs_off"] == pytest.approx(1.235e6, rel=1e-3)
     assert fh["published_sps"] == 56.10
+
+
+def test_cpu_baseline_rounds_report_the_median_of_each_number():
+    """benchlib/cpu.py: `value` is the median round's, ESS / s the median of the rounds' own (the funnel's moved 9 x between single rounds)."""
+    from benchlib.cpu import pick_round
+    out = pick_round([{"value": 3.0, "ess_per_sec": 34.5}, {"value": 1.0, "ess_per_sec": 6.7}, {"value": 2.0, "ess_per_sec": 3.8}])
+    assert out["value"] == 2.0 and out["repeats"] == [1.0, 2.0, 3.0]
+    assert out["ess_per_sec"] == 6.7 and out["ess_per_sec_rounds"] == [3.8, 6.7, 34.5]
+    one = pick_round([{"value": 5.0, "ess_per_sec": 1.5}])
+    assert one == {"value": 5.0, "ess_per_sec": 1.5}
+    nan = float("nan")
+    out = pick_round([{"value": 1.0, "ess_per_sec": nan}, {"value": 2.0, "ess_per_sec": 4.0}, {"value": 3.0, "ess_per_sec": 5.0}])
+    assert out["value"] == 2.0 and out["ess_per_sec"] == 4.0 and "ess_per_sec_rounds" not in out      # a round without an estimate: the median round's own
