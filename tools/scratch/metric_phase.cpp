@@ -1,6 +1,8 @@
 // Phase timer of metric_warm_mfma_kernel (developer tool): s_memtime stamps of workgroup 0 at the phase boundaries.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DHTA_TIMING=1 -ffp-contract=on -fno-slp-vectorize -x hip tools/scratch/metric_phase.cpp -o tools/scratch/metric_phase.bin \
-//         -Lhamiltorch_amd -lhamiltorch_amd -Wl,-rpath,'$ORIGIN/../../hamiltorch_amd'      (the rest of the library: error strings, profile hooks)
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DHTA_TIMING=1 -ffp-contract=on -fno-slp-vectorize -x hip tools/scratch/metric_phase.cpp -x none \
+//         $(ls hamiltorch_amd/csrc/build/*.o | grep -v rmhmc_metric_mfma.o) -o tools/scratch/metric_phase.bin
+//   (the rest of the library as objects: linked against the shared library the process holds TWO copies of this file's kernels, and the one
+//    without the stamps may be the one that is launched)
 #include "../../hamiltorch_amd/csrc/rmhmc_metric_mfma.hip"
 #include "../../include/hamiltorch_amd.h"
 #include <vector>
