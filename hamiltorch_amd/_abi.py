@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhamiltorch_amd.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 MASS_NONE, MASS_DIAG, MASS_FULL = 0, 1, 2
 
@@ -39,6 +39,20 @@ class HtaMetricArgs(ctypes.Structure):
                 ("H_out", c_vp), ("logp_out", c_vp), ("upd_x", c_vp), ("cx", c_f64), ("upd_g", c_vp), ("cg", c_f64),
                 ("V0", c_vp), ("lam0", c_vp), ("lamraw_out", c_vp), ("dmetric_out", c_vp), ("v0_stride", c_i64),
                 ("workspace", c_vp), ("workspace_bytes", c_i64)]
+
+
+class HtaCbHmcArgs(ctypes.Structure):
+    """csrc/jit/jit_args.h: HtaCbHmcArgs."""
+    _fields_ = [("cur", c_vp), ("init", c_vp), ("inv_mass", c_vp), ("mass_factor", c_vp), ("samples", c_vp),
+                ("reject_count", c_vp), ("H_old", c_vp), ("H_new", c_vp), ("accept", c_vp), ("gcur", c_vp), ("lp_out", c_vp),
+                ("C", ctypes.c_longlong), ("eps", c_f64), ("seed", c_u64), ("chain_offset", c_u64), ("L", c_int),
+                ("n_traj", c_int), ("traj_offset", c_int), ("burn", c_int), ("resume", c_int), ("reserved", c_int)]
+
+
+class HtaCbDerivArgs(ctypes.Structure):
+    """csrc/jit/jit_args.h: HtaCbDerivArgs."""
+    _fields_ = [("theta", c_vp), ("logp", c_vp), ("grad", c_vp), ("neg_hess", c_vp), ("M", c_vp), ("contract", c_vp),
+                ("C", ctypes.c_longlong)]
 
 
 METRIC_HESSIAN, METRIC_SOFTABS = 0, 1
@@ -87,7 +101,9 @@ def _sig(scalar):
 PLAIN_SYMBOLS = ["hta_abi_version", "hta_last_error", "hta_device_info", "hta_set_tuning", "hta_get_tuning", "hta_reset_tuning",
                  "hta_last_route", "hta_profile_collect", "hta_counter_add", "hta_run_begin", "hta_rmhmc_gaussian_forget", "hta_hmc_gaussian_forget",
                  "hta_hmc_gaussian_workspace_bytes", "hta_rmhmc_workspace_bytes", "hta_hmc_gaussian_status_offset",
-                 "hta_metric_eval_workspace_bytes", "hta_netn_hmc_workspace_bytes"]
+                 "hta_metric_eval_workspace_bytes", "hta_netn_hmc_workspace_bytes",
+                 "hta_jit_available", "hta_jit_last_log", "hta_jit_note_fallback", "hta_jit_compile", "hta_jit_free", "hta_jit_load", "hta_jit_unload",
+                 "hta_jit_module_info", "hta_jit_hmc_workspace_bytes", "hta_jit_hmc_sample", "hta_jit_derivs"]
 TYPED_SYMBOLS = sorted(_sig(c_f32).keys())
 
 
@@ -132,6 +148,22 @@ def load():
         lib.hta_rmhmc_gaussian_forget.restype = c_int
         lib.hta_hmc_gaussian_forget.argtypes = [c_vp]
         lib.hta_hmc_gaussian_forget.restype = c_int
+        cpp = ctypes.POINTER(ctypes.c_char_p)
+        lib.hta_jit_available.argtypes = []
+        lib.hta_jit_note_fallback.argtypes = [ctypes.c_char_p]
+        lib.hta_jit_last_log.argtypes = []
+        lib.hta_jit_last_log.restype = ctypes.c_char_p
+        lib.hta_jit_compile.argtypes = [ctypes.c_char_p, ctypes.c_char_p, c_int, cpp, cpp, c_int, cpp, ctypes.POINTER(c_vp),
+                                        ctypes.POINTER(c_i64)]
+        lib.hta_jit_free.argtypes = [c_vp]
+        lib.hta_jit_free.restype = None
+        lib.hta_jit_load.argtypes = [c_vp, c_i64, ctypes.POINTER(c_vp)]
+        lib.hta_jit_unload.argtypes = [c_vp]
+        lib.hta_jit_module_info.argtypes = [c_vp, ctypes.POINTER(c_int)]
+        lib.hta_jit_hmc_workspace_bytes.argtypes = [c_i64, c_int, c_int]
+        lib.hta_jit_hmc_workspace_bytes.restype = c_i64
+        lib.hta_jit_hmc_sample.argtypes = [c_vp, ctypes.POINTER(HtaCbHmcArgs), c_int, c_int, c_int, c_vp, c_i64, c_vp]
+        lib.hta_jit_derivs.argtypes = [c_vp, ctypes.POINTER(HtaCbDerivArgs), c_int, c_int, c_int, c_vp]
         for suf, scalar in (("f32", c_f32), ("f64", c_f64)):
             for name, args in _sig(scalar).items():
                 fn = getattr(lib, "%s_%s" % (name, suf))

@@ -7,8 +7,10 @@
 // so results do not depend on how chains are sharded over GPUs.
 // oracle/hmc_oracle.py implements the identical bit stream on the CPU.
 #pragma once
+#ifndef __HIPCC_RTC__      // (hipRTC has the device runtime built in and no system headers: csrc/jit/ supplies the integer types)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 namespace hta {
 

@@ -434,6 +434,10 @@ def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, 
                 if eng is None and native and pass_grad is None:
                     from . import bnn
                     eng = bnn.native_hmc_engine(log_prob_func, theta0)
+                if eng is None and native and pass_grad is None:
+                    eng = _compiled_engine(log_prob_func, theta0, inv_mass)    # the callback compiler (jit/): opaque callable, fused kernel
+                elif eng is None:
+                    _abi.load().hta_jit_note_fallback(b"native=False" if not native else b"pass_grad supplies the gradient")
                 if eng is None:
                     eng = _GenericHMC(log_prob_func, pass_grad)
             label = '({}; {})'.format(sampler, integrator)
@@ -448,6 +452,17 @@ def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, 
             if probed is not None and not verify_gaussian(probed, log_prob_func, samples):
                 _probe_mismatch(log_prob_func)
                 (samples, rejected), step_size_out = run(_GenericHMC(log_prob_func, pass_grad))
+            if isinstance(eng, _CompiledHMC) and not eng.verify():
+                # the compiled code disagrees with the callable on the states the run ended in: a reused trace whose captured
+                # state changed in place (trace again, once), or a callable that is not a pure function of its argument
+                eng2 = _compiled_engine(log_prob_func, theta0, inv_mass, fresh=True) if eng.reused else None
+                if eng2 is not None:
+                    (samples, rejected), step_size_out = run(eng2)
+                if eng2 is None or not eng2.verify():
+                    warnings.warn("hamiltorch_amd: the compiled form of %r disagrees with the callable itself on the sampled "
+                                  "states; re-running on the torch-evaluated callback path" % (log_prob_func,))
+                    _abi.load().hta_jit_note_fallback(b"compiled code disagrees with the callable")
+                    (samples, rejected), step_size_out = run(_GenericHMC(log_prob_func, pass_grad))
             step_size = step_size_out
         elif sampler == Sampler.RMHMC and integrator == Integrator.EXPLICIT:
             if pass_grad is not None:
@@ -506,7 +521,27 @@ def _probe(log_prob_func, theta0):
     ``HAMILTORCH_AMD_PROBE=0`` (or ``native=False``) keeps every unrecognised callable on the generic path."""
     if os.environ.get("HAMILTORCH_AMD_PROBE", "1") == "0" or hasattr(log_prob_func, "_hta_spec"):
         return None
-    return probe_gaussian(log_prob_func, theta0)
+    # a callable the probe has already turned down is not probed again while its closure signature is unchanged (the probe is
+    # ~10 torch.func evaluations and a synchronise: 1.1 ms per sample() call, four times a compiled 50-trajectory launch)
+    from .jit import _signature
+    key = None
+    try:
+        key = (_signature(log_prob_func)[0], tuple(theta0.shape[1:]), theta0.dtype)
+        if _probe_said_no.get(log_prob_func) == key:
+            return None
+    except TypeError:
+        key = None
+    tgt = probe_gaussian(log_prob_func, theta0)
+    if tgt is None and key is not None:
+        try:
+            _probe_said_no[log_prob_func] = key
+        except TypeError:
+            pass
+    return tgt
+
+
+import weakref  # noqa: E402
+_probe_said_no = weakref.WeakKeyDictionary()
 
 
 def _probe_mismatch(log_prob_func):
@@ -701,6 +736,73 @@ def _prepared_hmc_workspace(tgt, theta0, chunk):
         cache.clear()
     cache[key] = (_HmcWorkspaceHandle(ws), sig)
     return ws
+
+
+def _mass_kind_of(inv_mass):
+    if inv_mass is None:
+        return _abi.MASS_NONE
+    if isinstance(inv_mass, list):
+        return _abi.MASS_FULL
+    return _abi.MASS_DIAG if inv_mass.dim() == 1 else _abi.MASS_FULL
+
+
+def _compiled_engine(log_prob_func, theta0, inv_mass, fresh=False):
+    """The callback compiler's engine for this callable, or None (the reason goes to hta_last_route() / jit.last_reason())."""
+    from . import jit
+    if not jit.enabled() or not callable(log_prob_func):
+        _abi.load().hta_jit_note_fallback(b"HAMILTORCH_AMD_JIT=0" if callable(log_prob_func) else b"not a callable")
+        return None
+    before = jit.stats["trace_hits"]
+    try:
+        comp = jit.compile_hmc(log_prob_func, theta0[0], theta0.dtype, _mass_kind_of(inv_mass), fresh=fresh)
+    except jit.Unsupported as e:
+        _abi.load().hta_jit_note_fallback(str(e)[:140].encode("utf-8", "replace"))
+        return None
+    return _CompiledHMC(log_prob_func, comp, reused=jit.stats["trace_hits"] > before)
+
+
+class _CompiledHMC(_Engine):
+    """An opaque callable compiled into the trajectory kernel (hamiltorch_amd/jit/, csrc/jit/hmc_callback.hip.in): a block of
+    trajectories per launch - momentum draw, leapfrog with the callable's value + gradient inlined, energies, Metropolis, burn /
+    Q2 bookkeeping and row stores in one kernel, one chain per lane."""
+
+    def __init__(self, fn, compiled, reused=False):
+        self.fn, self.comp, self.reused = fn, compiled, reused
+
+    def begin(self, theta0, N, burn, inv_mass, seed, chain_offset):
+        from .jit import runtime
+        super().begin(theta0, N, burn, inv_mass, seed, chain_offset)
+        C, D = theta0.shape
+        self.module = self.comp.module(theta0.device)
+        self.ws = torch.empty(runtime.hmc_workspace_bytes(C, D, theta0.element_size()), dtype=torch.uint8, device=theta0.device)
+        self._ran = False
+
+    def advance(self, n0, count, L, eps, H_old=None, H_new=None, progress=None):
+        from .jit import runtime
+        # one launch per block of trajectories; a visible progress bar cuts the run into ~20 launches so that it moves
+        chunk = 1 if H_old is not None else (max(1, -(-count // 20)) if (progress is not None and progress.enabled) else count)
+        for start in range(n0, n0 + count, chunk):
+            k = min(chunk, n0 + count - start)
+            runtime.hmc_sample(self.module, self.cur, self.theta0, self.kind, self.im, self.mf, L, eps, k, start, self.burn,
+                               self.seed, self.off, self.samples, self.rejected, self.ws, H_old, H_new, resume=self._ran)
+            self._ran = True
+            if progress is not None:
+                progress.update(min(self.N, start + k) - 1)
+
+    def verify(self, k=128):
+        """log p of the states the run ended in: the kernel's own value against the callable evaluated by torch (one vmap call on up
+        to `k` chains).  False = the compiled code does not compute this callable (see sample())."""
+        from . import jit
+        if not self._ran or os.environ.get("HAMILTORCH_AMD_JIT_VERIFY", "1") == "0":
+            return True
+        C, D = self.cur.shape
+        idx = slice(0, min(C, k))
+        mine = jit.runtime.hmc_final_logp(self.ws, C, D, self.cur.dtype)[idx]
+        ref = jit.torch_logp(self.fn, self.cur[idx]).to(mine.dtype).reshape(-1)
+        fin_a, fin_b = torch.isfinite(mine), torch.isfinite(ref)
+        tol = (2e-4 if mine.dtype == torch.float32 else 1e-9)
+        close = (mine - ref).abs() <= tol * (10.0 + ref.abs())
+        return bool(((fin_a == fin_b) & (close | ~fin_b)).all())
 
 
 class _GenericHMC(_Engine):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HTA_ABI_VERSION 10
+#define HTA_ABI_VERSION 11
 
 #define HTA_OK 0
 #define HTA_ERR_INVALID (-1)   /* bad argument                           */
@@ -415,6 +415,44 @@ int hta_net_forward_f32(const float* theta, int64_t S, int n_layers, const int* 
                         void* stream);
 int hta_net_forward_f64(const double* theta, int64_t S, int n_layers, const int* dims, int act, const double* X, int N, double* out,
                         void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Compiled callbacks (ABI 11): an OPAQUE user `log_prob_func` (the callback contract, S:272-274) inside fused kernels.
+ * hamiltorch_amd/jit/ traces the callable once (torch.fx), differentiates the trace itself and writes value + gradient
+ * (`params_grad`, S:270-278, S:33-66; for the Riemannian samplers also the Hessian of S:108 and the third-derivative
+ * contraction behind S:397-398) as straight-line device code; that text is compiled here by hipRTC for gfx950 INTO the
+ * hand-written kernels of csrc/jit/ (hmc_callback.hip.in: the sample() loop of S:965-1026 - momentum draw, leapfrog,
+ * both energies, Metropolis, burn-in / Q2 bookkeeping, row stores - one chain per lane, a block of trajectories per launch).
+ *
+ *   hta_jit_compile   host work: HIP source (+ named headers, compiler options) -> malloc'ed gfx950 code object
+ *                     (hta_jit_free releases it; needs no GPU).  On HTA_ERR_INVALID hta_jit_last_log() holds the compiler's
+ *                     messages.  HTA_ERR_UNSUPPORTED: libhiprtc.so is not loadable.
+ *   hta_jit_load      code object -> module on the CURRENT device (a preparation step: reads the module's info block back
+ *                     once); hta_jit_unload frees it.  hta_jit_module_info: {magic, D, sizeof(T), mass kind, kernel set,
+ *                     scalar operations, 0, 0}.
+ *   hta_jit_hmc_sample  trajectories [traj_offset, traj_offset + n_traj) of plain HMC for C chains; the argument block is
+ *                     HtaCbHmcArgs (csrc/jit/jit_args.h; `gcur` / `lp_out` are placed in `workspace`,
+ *                     hta_jit_hmc_workspace_bytes(C, D, itemsize) bytes).  Same streams, rules and outputs as the pieces
+ *                     above; D / itemsize / mass_kind must be the module's (else HTA_ERR_INVALID, nothing is launched).
+ *   hta_jit_derivs    which = 0: logp[C], grad[C,D], neg_hess[C,D,D] (each optional) at theta[C,D]; which = 1:
+ *                     contract[C,D] = d_k < Hess log p, M > with M[C,D,D] held fixed.
+ *   hta_jit_note_fallback  records in hta_last_route() WHY a callable was not compiled (the caller then runs the pieces path).
+ * Launches are enqueued on `stream`; nothing is allocated or synchronised on the launch path. */
+#include "../hamiltorch_amd/csrc/jit/jit_args.h"
+int hta_jit_available(void);
+const char* hta_jit_last_log(void);
+int hta_jit_note_fallback(const char* reason);
+int hta_jit_compile(const char* source, const char* name, int n_headers, const char* const* header_names,
+                    const char* const* header_sources, int n_options, const char* const* options, void** code_out,
+                    int64_t* code_bytes);
+void hta_jit_free(void* code);
+int hta_jit_load(const void* code, int64_t bytes, void** module_out);
+int hta_jit_unload(void* module);
+int hta_jit_module_info(void* module, int* info_out);
+int64_t hta_jit_hmc_workspace_bytes(int64_t C, int D, int itemsize);
+int hta_jit_hmc_sample(void* module, const HtaCbHmcArgs* args, int D, int itemsize, int mass_kind, void* workspace,
+                       int64_t workspace_bytes, void* stream);
+int hta_jit_derivs(void* module, const HtaCbDerivArgs* args, int which, int D, int itemsize, void* stream);
 
 /* measurement knobs: "small_chains_per_block" (launch shape of the thread-per-chain kernel), "fill_blocks" (grid cap of the
  * pre-draw pass of the Gaussian path: 256-thread blocks, grid-stride; 4096),
