@@ -49,10 +49,18 @@ class HtaCbHmcArgs(ctypes.Structure):
                 ("n_traj", c_int), ("traj_offset", c_int), ("burn", c_int), ("resume", c_int), ("reserved", c_int)]
 
 
+class HtaCbRmhmcArgs(ctypes.Structure):
+    """csrc/jit/jit_args.h: HtaCbRmhmcArgs."""
+    _fields_ = [("cur", c_vp), ("init", c_vp), ("samples", c_vp), ("reject_count", c_vp), ("H_old", c_vp), ("H_new", c_vp),
+                ("accept", c_vp), ("lp_out", c_vp), ("C", ctypes.c_longlong), ("eps", c_f64), ("alpha", c_f64), ("jitter", c_f64),
+                ("omega", c_f64), ("seed", c_u64), ("chain_offset", c_u64), ("L", c_int), ("n_traj", c_int), ("traj_offset", c_int),
+                ("burn", c_int)]
+
+
 class HtaCbDerivArgs(ctypes.Structure):
     """csrc/jit/jit_args.h: HtaCbDerivArgs."""
     _fields_ = [("theta", c_vp), ("logp", c_vp), ("grad", c_vp), ("neg_hess", c_vp), ("M", c_vp), ("contract", c_vp),
-                ("C", ctypes.c_longlong)]
+                ("upd", c_vp), ("grad_in", c_vp), ("coef", c_f64), ("C", ctypes.c_longlong)]
 
 
 METRIC_HESSIAN, METRIC_SOFTABS = 0, 1
@@ -103,7 +111,8 @@ PLAIN_SYMBOLS = ["hta_abi_version", "hta_last_error", "hta_device_info", "hta_se
                  "hta_hmc_gaussian_workspace_bytes", "hta_rmhmc_workspace_bytes", "hta_hmc_gaussian_status_offset",
                  "hta_metric_eval_workspace_bytes", "hta_netn_hmc_workspace_bytes",
                  "hta_jit_available", "hta_jit_last_log", "hta_jit_note_fallback", "hta_jit_compile", "hta_jit_free", "hta_jit_load", "hta_jit_unload",
-                 "hta_jit_module_info", "hta_jit_hmc_workspace_bytes", "hta_jit_hmc_sample", "hta_jit_derivs"]
+                 "hta_jit_module_info", "hta_jit_hmc_workspace_bytes", "hta_jit_hmc_sample", "hta_jit_derivs",
+                 "hta_jit_rmhmc_workspace_bytes", "hta_jit_rmhmc_sample"]
 TYPED_SYMBOLS = sorted(_sig(c_f32).keys())
 
 
@@ -164,6 +173,9 @@ def load():
         lib.hta_jit_hmc_workspace_bytes.restype = c_i64
         lib.hta_jit_hmc_sample.argtypes = [c_vp, ctypes.POINTER(HtaCbHmcArgs), c_int, c_int, c_int, c_vp, c_i64, c_vp]
         lib.hta_jit_derivs.argtypes = [c_vp, ctypes.POINTER(HtaCbDerivArgs), c_int, c_int, c_int, c_vp]
+        lib.hta_jit_rmhmc_workspace_bytes.argtypes = [c_i64, c_int, c_int]
+        lib.hta_jit_rmhmc_workspace_bytes.restype = c_i64
+        lib.hta_jit_rmhmc_sample.argtypes = [c_vp, ctypes.POINTER(HtaCbRmhmcArgs), c_int, c_int, c_int, c_vp, c_i64, c_vp]
         for suf, scalar in (("f32", c_f32), ("f64", c_f64)):
             for name, args in _sig(scalar).items():
                 fn = getattr(lib, "%s_%s" % (name, suf))

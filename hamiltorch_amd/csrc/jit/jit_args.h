@@ -10,6 +10,7 @@
 /* kernel sets (hta_cb_info[4]): which entry points the module exports */
 #define HTA_CB_SET_HMC 1    /* hta_cb_hmc_kernel                                            */
 #define HTA_CB_SET_DERIVS 2 /* hta_cb_derivs_kernel + hta_cb_contract_kernel (Riemannian)   */
+#define HTA_CB_SET_RMHMC 3  /* hta_cb_rmhmc_kernel: explicit RMHMC trajectories, D <= 16     */
 
 typedef struct HtaCbHmcArgs {
   void* cur;               /* [C, D] current state, in / out                                                    */
@@ -31,13 +32,31 @@ typedef struct HtaCbHmcArgs {
   int reserved;
 } HtaCbHmcArgs;
 
+typedef struct HtaCbRmhmcArgs {
+  void* cur;             /* [C, D] current state, in / out                                     */
+  const void* init;      /* [C, D] params_init (Q2 reset)                                      */
+  void* samples;         /* [S, C, D] or NULL                                                  */
+  int* reject_count;     /* [C]                                                                */
+  void* H_old;           /* [C] of the launch's last trajectory, or NULL                       */
+  void* H_new;
+  unsigned char* accept;
+  void* lp_out;          /* [C] log p at the state the launch ended in, or NULL                */
+  long long C;
+  double eps, alpha, jitter, omega;
+  unsigned long long seed, chain_offset;
+  int L, n_traj, traj_offset, burn;
+} HtaCbRmhmcArgs;
+
 typedef struct HtaCbDerivArgs {
   const void* theta; /* [C, D]                                              */
   void* logp;        /* [C] or NULL                                         */
   void* grad;        /* [C, D] or NULL                                      */
   void* neg_hess;    /* [C, D, D] or NULL: -Hessian of log p (samplers.py:108) */
   const void* M;     /* [C, D, D] (contract kernel)                         */
-  void* contract;    /* [C, D]: c_i = d_i < Hess log p, M >, M held fixed   */
+  void* contract;    /* [C, D] or NULL: c_i = d_i < Hess log p, M >, M held fixed */
+  void* upd;         /* [C, D] or NULL: upd += coef * (grad_in + c) - the momentum update of S:395-398 fused into the contraction */
+  const void* grad_in; /* [C, D]: gradient of log p at theta (with upd)      */
+  double coef;
   long long C;
 } HtaCbDerivArgs;
 

@@ -65,7 +65,7 @@ thread_local std::string g_jit_log;
 
 struct Module {
   hipModule_t mod = nullptr;
-  hipFunction_t hmc = nullptr, derivs = nullptr, contract = nullptr;
+  hipFunction_t hmc = nullptr, derivs = nullptr, contract = nullptr, rmhmc = nullptr;
   int info[HTA_CB_INFO_WORDS] = {};
   int device = -1;
 };
@@ -185,6 +185,8 @@ int hta_jit_load(const void* code, int64_t bytes, void** module_out) {
   } else if (m->info[4] == HTA_CB_SET_DERIVS) {
     e = hipModuleGetFunction(&m->derivs, m->mod, "hta_cb_derivs_kernel");
     if (e == hipSuccess) e = hipModuleGetFunction(&m->contract, m->mod, "hta_cb_contract_kernel");
+  } else if (m->info[4] == HTA_CB_SET_RMHMC) {
+    e = hipModuleGetFunction(&m->rmhmc, m->mod, "hta_cb_rmhmc_kernel");
   } else {
     e = hipErrorInvalidValue;
   }
@@ -241,13 +243,39 @@ int hta_jit_hmc_sample(void* module, const HtaCbHmcArgs* args, int D, int itemsi
   return rc;
 }
 
+int64_t hta_jit_rmhmc_workspace_bytes(int64_t C, int D, int itemsize) {
+  if (C <= 0 || D <= 0 || (itemsize != 4 && itemsize != 8)) return -1;
+  return C * itemsize;                          // lp_out[C]
+}
+
+int hta_jit_rmhmc_sample(void* module, const HtaCbRmhmcArgs* args, int D, int itemsize, int has_jitter, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
+  using namespace hta;
+  Module* m = (Module*)module;
+  if (int rc = check_module(m, "hta_jit_rmhmc_sample", D, itemsize, has_jitter ? 1 : 0, HTA_CB_SET_RMHMC)) return rc;
+  HTA_REQUIRE(args && args->cur && args->init && args->reject_count && args->C > 0 && args->L >= 0 && args->n_traj >= 0,
+              "hta_jit_rmhmc_sample: bad arguments");
+  HTA_REQUIRE(workspace && workspace_bytes >= hta_jit_rmhmc_workspace_bytes(args->C, D, itemsize),
+              "hta_jit_rmhmc_sample: workspace of %lld bytes, %lld needed (hta_jit_rmhmc_workspace_bytes)", (long long)workspace_bytes,
+              (long long)hta_jit_rmhmc_workspace_bytes(args->C, D, itemsize));
+  if (args->n_traj == 0) return HTA_OK;
+  HtaCbRmhmcArgs a = *args;
+  a.lp_out = workspace;
+  note_route("hta_cb_rmhmc_kernel<D=%d,%s,jitter=%d,nodes=%d+%d>", D, itemsize == 4 ? "f32" : "f64", has_jitter ? 1 : 0, m->info[5],
+             m->info[6]);
+  profile_begin((hipStream_t)stream);
+  const int rc = launch(m->rmhmc, "hta_jit_rmhmc_sample", a.C, &a, sizeof(a), (hipStream_t)stream);
+  profile_end((hipStream_t)stream);
+  return rc;
+}
+
 /* which: 0 = derivatives (logp / grad / neg_hess, each optional), 1 = third-order contraction (M, contract) */
 int hta_jit_derivs(void* module, const HtaCbDerivArgs* args, int which, int D, int itemsize, void* stream) {
   using namespace hta;
   Module* m = (Module*)module;
   if (int rc = check_module(m, "hta_jit_derivs", D, itemsize, -1, HTA_CB_SET_DERIVS)) return rc;
   HTA_REQUIRE(args && args->theta && args->C > 0, "hta_jit_derivs: bad arguments");
-  HTA_REQUIRE(which == 0 || (args->M && args->contract), "hta_jit_derivs: M / contract are NULL");
+  HTA_REQUIRE(which == 0 || (args->M && (args->contract || (args->upd && args->grad_in))), "hta_jit_derivs: M / contract / upd are NULL");
   HtaCbDerivArgs a = *args;
   note_route("%s<D=%d,%s,nodes=%d>", which ? "hta_cb_contract_kernel" : "hta_cb_derivs_kernel", D, itemsize == 4 ? "f32" : "f64",
              m->info[5]);

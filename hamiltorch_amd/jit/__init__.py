@@ -87,11 +87,32 @@ class CompiledHMC:
         return runtime.module_for(self.key, self.blob, device)
 
 
+class CompiledDerivs(CompiledHMC):
+    """A traced callable compiled into the derivative kernels of the Riemannian samplers (csrc/jit/derivs_callback.hip.in)."""
+
+
 def compile_hmc(fn, example, dtype, mass_kind, fresh=False):
     """CompiledHMC for ``fn`` at points shaped like the (D,) tensor ``example``; raises ``Unsupported``.  A trace is reused while the
     callable's closure signature is unchanged (``fresh=True`` traces again)."""
+    return _compile(fn, example, dtype, int(mass_kind), fresh)
+
+
+def compile_derivs(fn, example, dtype, fresh=False):
+    """CompiledDerivs (value / gradient / Hessian + third-derivative contraction kernels) for ``fn``; raises ``Unsupported``."""
+    return _compile(fn, example, dtype, "derivs", fresh)
+
+
+def compile_rmhmc(fn, example, dtype, jitter, fresh=False):
+    """The callable built into the explicit-RMHMC trajectory kernel (csrc/jit/rmhmc_callback.hip.in; D <= 16); raises ``Unsupported``."""
+    if example.numel() > runtime.MAX_RMHMC_DIM:
+        _note("D = %d: the chain-per-lane Riemannian kernel holds a chain's matrices in registers (D <= %d)" % (example.numel(), runtime.MAX_RMHMC_DIM))
+        raise Unsupported(last_reason())
+    return _compile(fn, example, dtype, "rmhmc-jitter" if jitter else "rmhmc", fresh)
+
+
+def _compile(fn, example, dtype, mass_kind, fresh):
     _note("")
-    cfg = (int(example.numel()), dtype, int(mass_kind), example.device.type)
+    cfg = (int(example.numel()), dtype, mass_kind, example.device.type)
     sig = objs = None
     try:
         sig, objs = _signature(fn)
@@ -109,9 +130,15 @@ def compile_hmc(fn, example, dtype, mass_kind, fresh=False):
     try:
         traced = trace_callback(fn, example)
         stats["traced"] += 1
-        src = runtime.hmc_generated_source(traced, dtype, mass_kind)
-        key, blob = runtime.compile_source(src, runtime.SKELETON_HMC)
-        out = CompiledHMC(traced, key, blob, dtype, mass_kind)
+        if mass_kind == "derivs":
+            key, blob = runtime.compile_source(runtime.derivs_generated_source(traced, dtype), runtime.SKELETON_DERIVS)
+            out = CompiledDerivs(traced, key, blob, dtype, mass_kind)
+        elif mass_kind in ("rmhmc", "rmhmc-jitter"):
+            key, blob = runtime.compile_source(runtime.derivs_generated_source(traced, dtype, mass_kind == "rmhmc-jitter"), runtime.SKELETON_RMHMC)
+            out = CompiledDerivs(traced, key, blob, dtype, mass_kind)
+        else:
+            key, blob = runtime.compile_source(runtime.hmc_generated_source(traced, dtype, mass_kind), runtime.SKELETON_HMC)
+            out = CompiledHMC(traced, key, blob, dtype, mass_kind)
     except Unsupported as e:
         stats["unsupported"] += 1
         _note(str(e))

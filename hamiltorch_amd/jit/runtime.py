@@ -22,6 +22,7 @@ _HEADERS = (("cb_math.hpp", "jit/cb_math.hpp"), ("philox.hpp", "philox.hpp"), ("
             ("jit_args.h", "jit/jit_args.h"))
 SKELETON_HMC = "jit/hmc_callback.hip.in"
 SKELETON_DERIVS = "jit/derivs_callback.hip.in"
+SKELETON_RMHMC = "jit/rmhmc_callback.hip.in"
 # (SLP vectorisation ON: the straight-line callback code packs into v_pk_mul / v_pk_fma pairs - 67 -> 59 instructions per
 #  leapfrog step of the notebook funnel, tools/jit_isa.py; -ffp-contract=fast fuses across the generated statements)
 OPTIONS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast")
@@ -182,3 +183,86 @@ def hmc_final_logp(workspace, C, D, dtype):
     """log p at the state the last launch ended in ([C] view of the workspace's second block)."""
     item = torch.empty((), dtype=dtype).element_size()
     return workspace[C * D * item:C * D * item + C * item].view(dtype)
+
+
+# ---- derivatives for the Riemannian samplers ---------------------------------------------------------------------------
+MAX_DERIV_DIM = 32
+MAX_DERIV_NODES = 20000         # live scalar operations of each generated function
+
+
+MAX_RMHMC_DIM = 16              # a chain's matrices in one lane's registers (csrc/jit/rmhmc_callback.hip.in)
+
+
+def derivs_generated_source(traced, dtype, jitter=False):
+    """Value, gradient, Hessian (D reverse passes over the gradient's graph) and the third derivatives (one pass per Hessian
+    entry of the lower triangle) of a traced callable, as the generated include of csrc/jit/derivs_callback.hip.in."""
+    D = traced.D
+    if D > MAX_DERIV_DIM:
+        raise Unsupported("D = %d: third derivatives are generated entry by entry (D <= %d)" % (D, MAX_DERIV_DIM))
+    g = traced.graph
+    grads = traced.grad()
+    hess = [g.grad(gi) for gi in grads]
+    if len(g.reachable([traced.value] + grads + [hess[i][j] for i in range(D) for j in range(i + 1)])) > MAX_DERIV_NODES:
+        raise Unsupported("value + gradient + Hessian exceed %d scalar operations" % MAX_DERIV_NODES)
+    third = {}
+    for i in range(D):
+        for j in range(i + 1):
+            third[(i, j)] = g.grad(hess[i][j])
+            if len(g.nodes) > 40 * MAX_DERIV_NODES:
+                raise Unsupported("the third derivatives exceed the graph size limit")
+    if len(g.reachable([t for v in third.values() for t in v])) > MAX_DERIV_NODES:
+        raise Unsupported("the third derivatives exceed %d scalar operations" % MAX_DERIV_NODES)
+    return emit.derivs_source(g, traced.value, grads, hess, third, dtype_name(dtype), jitter)
+
+
+def rmhmc_workspace_bytes(C, D, itemsize):
+    return int(_abi.load().hta_jit_rmhmc_workspace_bytes(int(C), int(D), int(itemsize)))
+
+
+def rmhmc_sample(module, cur, init, L, eps, alpha, jitter, omega, n_traj, traj_offset, burn, seed, chain_offset, samples,
+                 reject_count, workspace):
+    """hta_jit_rmhmc_sample: explicit soft-abs RMHMC trajectories [traj_offset, traj_offset + n_traj) on the compiled callable."""
+    _abi.require_device(cur, "params")
+    C, D = cur.shape
+    a = _abi.HtaCbRmhmcArgs()
+    a.cur, a.init = cur.data_ptr(), _abi._p(init, cur).value
+    a.samples = None if samples is None else _abi._p(samples, cur).value
+    a.reject_count = reject_count.data_ptr()
+    a.C, a.eps, a.alpha, a.omega = C, float(eps), float(alpha), float(omega)
+    a.jitter = 0.0 if jitter is None else float(jitter)
+    a.seed, a.chain_offset = int(seed) & 0xFFFFFFFFFFFFFFFF, int(chain_offset)
+    a.L, a.n_traj, a.traj_offset, a.burn = int(L), int(n_traj), int(traj_offset), int(burn)
+    with torch.cuda.device(cur.device):
+        _abi._check(_abi.load().hta_jit_rmhmc_sample(module.handle, ctypes.byref(a), D, cur.element_size(), 0 if jitter is None else 1,
+                                                     workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                                     _abi._stream(cur)), "hta_jit_rmhmc_sample")
+
+
+def _deriv_call(module, a, which, like):
+    C, D = like.shape
+    with torch.cuda.device(like.device):
+        _abi._check(_abi.load().hta_jit_derivs(module.handle, ctypes.byref(a), int(which), D, like.element_size(), _abi._stream(like)),
+                    "hta_jit_derivs")
+
+
+def derivs(module, theta, logp, grad, neg_hess):
+    """One launch: logp[C], grad[C, D], neg_hess[C, D, D] of the compiled callable at theta[C, D]."""
+    _abi.require_device(theta, "params")
+    a = _abi.HtaCbDerivArgs()
+    a.theta, a.C = _abi._p(theta).value, theta.shape[0]
+    a.logp = None if logp is None else _abi._p(logp, theta).value
+    a.grad = None if grad is None else _abi._p(grad, theta).value
+    a.neg_hess = _abi._p(neg_hess, theta).value
+    _deriv_call(module, a, 0, theta)
+
+
+def contract(module, theta, M, out=None, upd=None, grad_in=None, coef=0.0):
+    """One launch: c = d < Hess log p (theta), M >|_(M fixed) per chain, to `out` and / or as upd += coef (grad_in + c)."""
+    _abi.require_device(theta, "params")
+    a = _abi.HtaCbDerivArgs()
+    a.theta, a.C, a.M = _abi._p(theta).value, theta.shape[0], _abi._p(M, theta).value
+    a.contract = None if out is None else _abi._p(out, theta).value
+    a.upd = None if upd is None else _abi._p(upd, theta).value
+    a.grad_in = None if grad_in is None else _abi._p(grad_in, theta).value
+    a.coef = float(coef)
+    _deriv_call(module, a, 1, theta)

@@ -199,6 +199,10 @@ class _Curvature:
         H, g = self._try(self._gh, looped, theta)
         return g.to(theta.dtype, copy=True).contiguous(), (-H).to(theta.dtype).contiguous()
 
+    def kick_update(self, theta, M, g, upd, coef):
+        """upd += coef (g + c),  c_i = d_i < Hess log p (theta), M >: the momentum update of S:395-398 given the metric's M."""
+        upd.add_(g + self.contract(theta, M), alpha=coef)
+
     def contract(self, theta, M):
         """c_i = d_i < Hess log p (theta), M >, M held fixed: [C, D]."""
         def looped(th, Mm):
@@ -210,6 +214,93 @@ class _Curvature:
                 out.append(torch.autograd.grad(Hm, t, allow_unused=True)[0] if Hm.requires_grad else torch.zeros_like(t))
             return torch.stack([o if o is not None else torch.zeros_like(th[0]) for o in out])
         return self._try(self._third, looped, theta, M).to(theta.dtype, copy=True).contiguous()
+
+
+class _CompiledCurvature:
+    """The same three requests answered by COMPILED code (hamiltorch_amd/jit/, csrc/jit/derivs_callback.hip.in): the callable is
+    traced once, differentiated three times on its scalar graph and built into two kernels - (log p, gradient, -Hessian) in ONE
+    launch per state, the third-derivative contraction (fused with the momentum update) in one launch per kick - where
+    `_Curvature` replays ~100 torch.func launches per request."""
+
+    def __init__(self, log_prob_func, compiled, like):
+        self.fn, self.comp = log_prob_func, compiled
+        self.module = compiled.module(like.device)
+        self._last = None             # (theta tensor, version, lp, g, -H)
+        self.stats = {"gh_evaluated": 0, "gh_reused": 0, "compiled": True}
+
+    def _eval(self, theta):
+        from .jit import runtime
+        last = self._last
+        if last is not None and last[0] is theta and last[1] == theta._version:
+            self.stats["gh_reused"] += 1
+            return last
+        C, D = theta.shape
+        lp = torch.empty(C, dtype=theta.dtype, device=theta.device)
+        g = torch.empty_like(theta)
+        nH = torch.empty(C, D, D, dtype=theta.dtype, device=theta.device)
+        runtime.derivs(self.module, theta, lp, g, nH)
+        self.stats["gh_evaluated"] += 1
+        self._last = (theta, theta._version, lp, g, nH)
+        return self._last
+
+    def value(self, theta):
+        return self._eval(theta)[2]
+
+    def grad_neg_hessian(self, theta):
+        e = self._eval(theta)
+        return e[3], e[4]
+
+    def touched(self, *tensors):
+        if self._last is not None and any(t is self._last[0] for t in tensors):
+            self._last = None
+
+    def contract(self, theta, M):
+        from .jit import runtime
+        out = torch.empty_like(theta)
+        runtime.contract(self.module, theta, M, out=out)
+        return out
+
+    def kick_update(self, theta, M, g, upd, coef):
+        from .jit import runtime
+        runtime.contract(self.module, theta, M, upd=upd, grad_in=g, coef=coef)
+        self.touched(upd)
+
+    def agrees_with_callable(self, theta, k=16):
+        """Value and gradient of the compiled code against torch's evaluation of the callable on up to k rows of theta."""
+        th = theta[:k].contiguous()
+        e = self._eval(th)
+        self._last = None
+        self.stats["gh_evaluated"] -= 1
+        f = lambda w: self.fn(w).sum()  # noqa: E731
+        try:
+            g, v = torch.func.vmap(torch.func.grad_and_value(f))(th)
+        except Exception:
+            return True                 # torch cannot batch it: nothing to compare with here (the samplers' own guards apply)
+        tol = 2e-4 if th.dtype == torch.float32 else 1e-9
+        ok = True
+        for mine, ref in ((e[2], v.to(th.dtype)), (e[3], g.to(th.dtype))):
+            fa, fb = torch.isfinite(mine), torch.isfinite(ref)
+            ok = ok and bool(((fa == fb) & (((mine - ref).abs() <= tol * (10.0 + ref.abs())) | ~fb)).all())
+        return ok
+
+
+def _curvature_for(log_prob_func, theta):
+    """Compiled derivatives when the callback compiler covers the callable (checked against torch on this call's states), else the
+    torch.func evaluation."""
+    from . import jit
+    if jit.enabled() and callable(log_prob_func) and theta.is_cuda:
+        for fresh in (False, True):
+            try:
+                cv = _CompiledCurvature(log_prob_func, jit.compile_derivs(log_prob_func, theta[0], theta.dtype, fresh=fresh), theta)
+            except jit.Unsupported as e:
+                _abi.load().hta_jit_note_fallback(str(e)[:140].encode("utf-8", "replace"))
+                break
+            if cv.agrees_with_callable(theta):
+                return cv
+        else:
+            import warnings
+            warnings.warn("hamiltorch_amd: the compiled derivatives of %r disagree with torch's; using torch.func" % (log_prob_func,))
+    return _Curvature(log_prob_func)
 
 
 class _WarmBases:
@@ -263,7 +354,11 @@ def _generic_steps(cv, kind, th, pm, thc, pmc, steps, eps, omega, alpha, jitter,
         g, Hs = cv.grad_neg_hessian(theta)
         _abi.metric_eval(theta, C, D, kind, Hs, D * D, alpha, jitter, seed, chain_offset, draw, sub, m=mvec, dmetric_out=M,
                          **warm.kw(slot))
-        upd.add_(g + cv.contract(theta, M), alpha=eh)
+        fused = getattr(cv, "kick_update", None)         # (a curvature object only has to provide grad_neg_hessian / contract / value / touched)
+        if fused is not None:
+            fused(theta, M, g, upd, eh)
+        else:
+            upd.add_(g + cv.contract(theta, M), alpha=eh)
 
     def drift(theta, mvec, upd, sub, slot):     # upd += eh dH/dp(theta, mvec) = eh G^-1 mvec              (S:415-422)
         _, Hs = cv.grad_neg_hessian(theta)
@@ -299,7 +394,7 @@ def explicit_leapfrog(params, momentum, log_prob_func, steps, step_size, jitter,
         _abi.rmhmc_gaussian_leapfrog(theta, p, thc, pc, tgt.precision, tgt.mean, _metric_kind(metric), softabs_const,
                                      jitter, seed, chain_offset, draw, steps, step_size, omega, pt, pp)
     else:
-        _generic_steps(_Curvature(log_prob_func), _metric_kind(metric), theta, p, thc, pc, steps, step_size, omega,
+        _generic_steps(_curvature_for(log_prob_func, theta), _metric_kind(metric), theta, p, thc, pc, steps, step_size, omega,
                        softabs_const, jitter, seed, chain_offset, draw, path=(pt, pp))
     unb = (lambda t: t[0]) if one else (lambda t: t)
     return [[unb(t) for t in pt.unbind(0)], unb(thc)], [[unb(t) for t in pp.unbind(0)], unb(pc)]
@@ -314,6 +409,10 @@ def sample_explicit(log_prob_func, theta0, N, L, eps, burn, jitter, softabs_cons
     if softabs_const is None and kind == _abi.METRIC_SOFTABS:
         raise TypeError("softabs_const must be set for Metric.SOFTABS")
     if tgt is None:
+        out = _sample_explicit_compiled(log_prob_func, theta0, N, L, eps, burn, jitter, softabs_const, omega, kind, seed,
+                                        chain_offset, verbose)
+        if out is not None:
+            return out
         return _sample_explicit_generic(log_prob_func, theta0, N, L, eps, burn, jitter, softabs_const, omega, kind, seed,
                                         chain_offset, verbose)
     C, D = theta0.shape
@@ -368,6 +467,56 @@ def _prepared_workspace(tgt, theta0, kind, alpha, jitter, N):
     return ws
 
 
+def _sample_explicit_compiled(log_prob_func, theta0, N, L, eps, burn, jitter, alpha, omega, kind, seed, chain_offset, verbose):
+    """The whole run inside the compiled chain-per-lane kernel (hamiltorch_amd/jit/, csrc/jit/rmhmc_callback.hip.in) when the callback
+    compiler covers the callable: soft-abs metric, D <= 16.  None = not applicable (the reason is in hta_last_route()); the result is
+    checked against the callable itself on the states the run ended in, a mismatch re-traces once and else returns None."""
+    from . import jit
+    from .samplers import _num_rows
+    C, D = theta0.shape
+    if not (jit.enabled() and callable(log_prob_func) and theta0.is_cuda and kind == _abi.METRIC_SOFTABS):
+        return None
+    for fresh in (False, True):
+        hits = jit.stats["trace_hits"]
+        try:
+            comp = jit.compile_rmhmc(log_prob_func, theta0[0], theta0.dtype, jitter is not None, fresh=fresh)
+        except jit.Unsupported as e:
+            _abi.load().hta_jit_note_fallback(str(e)[:140].encode("utf-8", "replace"))
+            return None
+        reused = jit.stats["trace_hits"] > hits
+        module = comp.module(theta0.device)
+        S = _num_rows(N, burn)
+        samples = torch.empty((S, C, D), dtype=theta0.dtype, device=theta0.device)
+        cur = torch.empty_like(theta0)
+        rejected = torch.empty(C, dtype=torch.int32, device=theta0.device)
+        _abi.run_begin(theta0, cur, samples[0], rejected)
+        ws = torch.empty(jit.runtime.rmhmc_workspace_bytes(C, D, theta0.element_size()), dtype=torch.uint8, device=theta0.device)
+        prog = util._Progress('Sampling (Sampler.RMHMC; Integrator.EXPLICIT)', N, verbose)
+        chunk = max(1, -(-N // 20)) if verbose else N
+        for start in range(0, N, chunk):
+            k = min(chunk, N - start)
+            jit.runtime.rmhmc_sample(module, cur, theta0, L, eps, alpha, jitter, omega, k, start, burn, seed, chain_offset, samples,
+                                     rejected, ws)
+            prog.update(start + k - 1)
+        prog.end()
+        if os.environ.get("HAMILTORCH_AMD_JIT_VERIFY", "1") == "0" or N == 0:
+            return samples, rejected
+        kk = min(C, 128)
+        mine = ws[:C * theta0.element_size()].view(theta0.dtype)[:kk]
+        ref = jit.torch_logp(log_prob_func, cur[:kk]).to(mine.dtype).reshape(-1)
+        fa, fb = torch.isfinite(mine), torch.isfinite(ref)
+        tol = 2e-4 if mine.dtype == torch.float32 else 1e-9
+        if bool(((fa == fb) & (((mine - ref).abs() <= tol * (10.0 + ref.abs())) | ~fb)).all()):
+            return samples, rejected
+        if not reused:
+            break
+    import warnings
+    warnings.warn("hamiltorch_amd: the compiled form of %r disagrees with the callable itself on the sampled states; re-running "
+                  "on the launch-per-evaluation path" % (log_prob_func,))
+    _abi.load().hta_jit_note_fallback(b"compiled code disagrees with the callable")
+    return None
+
+
 def _sample_explicit_generic(log_prob_func, theta0, N, L, eps, burn, jitter, alpha, omega, kind, seed, chain_offset,
                              verbose):
     """The same trajectory loop as csrc/rmhmc_explicit.hip:rmhmc_sample with the target's derivatives coming from
@@ -376,7 +525,7 @@ def _sample_explicit_generic(log_prob_func, theta0, N, L, eps, burn, jitter, alp
     from .samplers import _num_rows
     C, D = theta0.shape
     dt, dev = theta0.dtype, theta0.device
-    cv = _Curvature(log_prob_func)
+    cv = _curvature_for(log_prob_func, theta0)
     S = _num_rows(N, burn)
     samples = torch.empty((S, C, D), dtype=dt, device=dev)
     samples[0].copy_(theta0)
@@ -482,7 +631,7 @@ def implicit_leapfrog(params, momentum, log_prob_func, steps, step_size, jitter,
     pt = torch.empty((steps,) + theta.shape, dtype=theta.dtype, device=theta.device)
     pp = torch.empty_like(pt)
     seed = util.next_stream_seed() if (seed is None and jitter is not None) else (seed or 0)
-    _implicit_steps(_Curvature(log_prob_func), _metric_kind(metric), theta, p, steps, step_size, softabs_const, jitter, seed,
+    _implicit_steps(_curvature_for(log_prob_func, theta), _metric_kind(metric), theta, p, steps, step_size, softabs_const, jitter, seed,
                     chain_offset, draw, fixed_point_threshold, fixed_point_max_iterations, path=(pt, pp))
     unb = (lambda t: t[0]) if one else (lambda t: t)
     return [unb(t) for t in pt.unbind(0)], [unb(t) for t in pp.unbind(0)]
@@ -497,7 +646,7 @@ def sample_implicit(log_prob_func, theta0, N, L, eps, burn, jitter, alpha, metri
         raise TypeError("softabs_const must be set for Metric.SOFTABS")
     C, D = theta0.shape
     dt, dev = theta0.dtype, theta0.device
-    cv = _Curvature(log_prob_func)
+    cv = _curvature_for(log_prob_func, theta0)
     S = _num_rows(N, burn)
     samples = torch.empty((S, C, D), dtype=dt, device=dev)
     samples[0].copy_(theta0)

@@ -453,6 +453,13 @@ int64_t hta_jit_hmc_workspace_bytes(int64_t C, int D, int itemsize);
 int hta_jit_hmc_sample(void* module, const HtaCbHmcArgs* args, int D, int itemsize, int mass_kind, void* workspace,
                        int64_t workspace_bytes, void* stream);
 int hta_jit_derivs(void* module, const HtaCbDerivArgs* args, int which, int D, int itemsize, void* stream);
+/* Explicit RMHMC (S:389-462 inside the RMHMC branch of sample(), S:969-1026; Metric.SOFTABS) for a GENERAL target of small dimension
+ * (D <= 16) on a compiled callable: trajectories [traj_offset, traj_offset + n_traj), a chain per lane, the 8 L + 3 metric evaluations
+ * of a trajectory (Hessian, jitter, eigendecomposition, soft-abs map, solves, the derivative of the metric) in the lane's registers -
+ * csrc/jit/rmhmc_callback.hip.in.  `workspace`: hta_jit_rmhmc_workspace_bytes(C, D, itemsize) bytes (log p at the final states). */
+int64_t hta_jit_rmhmc_workspace_bytes(int64_t C, int D, int itemsize);
+int hta_jit_rmhmc_sample(void* module, const HtaCbRmhmcArgs* args, int D, int itemsize, int has_jitter, void* workspace,
+                         int64_t workspace_bytes, void* stream);
 
 /* measurement knobs: "small_chains_per_block" (launch shape of the thread-per-chain kernel), "fill_blocks" (grid cap of the
  * pre-draw pass of the Gaussian path: 256-thread blocks, grid-stride; 4096),

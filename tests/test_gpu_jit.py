@@ -247,3 +247,108 @@ def test_funnel_pooled_acceptance_matches_the_oracle(ht):
     assert "hta_cb_hmc_kernel" in route()
     ref, info = O.sample_hmc(O.FunnelTarget(11), th0, N, L, eps, -1, None, O.PhiloxDraws(seed, np.arange(C), np.float32))
     assert abs(float(acc.mean()) - float(info["acc_rate"].mean())) <= 0.01
+
+
+# ---- compiled derivatives for the Riemannian samplers (csrc/jit/derivs_callback.hip.in) --------------------------------------
+def scaled_funnel(scales):
+    def f(w):
+        s = torch.as_tensor(scales, dtype=w.dtype, device=w.device)
+        v, x = w[0], w[1:]
+        return -v * v / 18.0 - 1.0986122886681098 - HL2P + (-0.5 * torch.exp(v) * (x * x / s).sum() + 0.5 * x.numel() * v
+                                                             - x.numel() * HL2P - 0.5 * torch.log(s).sum())
+    return f
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float64, 1e-10)])
+def test_compiled_derivatives_vs_oracle_and_torch_func(ht, dtype, tol):
+    """log p, gradient, -Hessian and the third-derivative contraction of the compiled funnel: against oracle.FunnelTarget's analytic
+    forms and against the torch.func evaluation rmhmc._Curvature performs (the path they replace), fused momentum update included."""
+    from hamiltorch_amd import rmhmc
+    D, C = 7, 100
+    scales = np.array([0.5, 1.0, 1.7, 2.4, 3.3, 0.8])
+    fn, o = scaled_funnel(scales), O.FunnelTarget(D, scales)
+    th = start(C, D, 3, dtype, scale=0.8)
+    M = np.random.default_rng(1).standard_normal((C, D, D)).astype(NP[dtype])
+    cv = rmhmc._curvature_for(fn, tt(th, dtype))
+    assert isinstance(cv, rmhmc._CompiledCurvature) and "hta_cb_derivs_kernel<D=7" in route()
+    tht, Mt = tt(th, dtype), tt(M, dtype)
+    g, nH = cv.grad_neg_hessian(tht)
+    lp = cv.value(tht)
+    assert cv.stats["gh_evaluated"] == 1 and cv.stats["gh_reused"] == 1                  # one launch serves all three
+    t64 = th.astype(np.float64)
+    scale = lambda a: tol * (1.0 + np.abs(a).max())  # noqa: E731
+    np.testing.assert_allclose(lp.cpu().numpy(), o.logp(t64), atol=scale(o.logp(t64)))
+    np.testing.assert_allclose(g.cpu().numpy(), o.grad(t64), atol=scale(o.grad(t64)))
+    np.testing.assert_allclose(nH.cpu().numpy(), o.neg_hessian(t64), atol=scale(o.neg_hessian(t64)))
+    Ms = 0.5 * (M + np.swapaxes(M, 1, 2)).astype(np.float64)
+    want_c = o.third_contract(t64, Ms)
+    c = cv.contract(tht, Mt)
+    assert "hta_cb_contract_kernel" in route()
+    np.testing.assert_allclose(c.cpu().numpy(), want_c, atol=scale(want_c))
+    upd = torch.ones_like(tht)
+    cv.kick_update(tht, Mt, g, upd, 0.25)
+    np.testing.assert_allclose(upd.cpu().numpy(), 1.0 + 0.25 * (o.grad(t64) + want_c), atol=scale(want_c))
+    ref = rmhmc._Curvature(fn)
+    g2, nH2 = ref.grad_neg_hessian(tht)
+    np.testing.assert_allclose(nH.cpu().numpy(), nH2.cpu().numpy(), atol=scale(nH2.cpu().numpy()) * 5)
+    np.testing.assert_allclose(c.cpu().numpy(), ref.contract(tht, Mt).cpu().numpy(), atol=scale(want_c) * 5)
+
+
+def test_rmhmc_on_compiled_derivatives_equals_the_torch_func_route(ht):
+    """sample(RMHMC, EXPLICIT, SOFTABS) with jitter on the notebook funnel: compiled derivatives against HAMILTORCH_AMD_JIT=0
+    (torch.func) on the same Philox streams, float64 - and the implicit integrator likewise."""
+    fn = scaled_funnel(np.ones(5))
+    th0 = tt(start(24, 6, 2, torch.float64, scale=0.4), torch.float64)
+    for integ, extra in ((ht.Integrator.EXPLICIT, dict(explicit_binding_const=10.0)),
+                         (ht.Integrator.IMPLICIT, dict(fixed_point_threshold=1e-10, fixed_point_max_iterations=30))):
+        kw = dict(num_samples=4, num_steps_per_sample=3, step_size=0.08, jitter=1e-3, softabs_const=1e6, sampler=ht.Sampler.RMHMC,
+                  integrator=integ, metric=ht.Metric.SOFTABS, verbose=False, seed=21, **extra)
+        a = torch.stack(list(ht.sample(fn, th0, **kw)))
+        os.environ["HAMILTORCH_AMD_JIT"] = "0"
+        try:
+            b = torch.stack(list(ht.sample(fn, th0, **kw)))
+        finally:
+            del os.environ["HAMILTORCH_AMD_JIT"]
+        err = (a - b).abs().amax(dim=(0, 2))
+        assert float((err > 1e-6).double().mean()) <= 0.1, (integ, float(err.max()))
+
+
+# ---- the fused explicit-RMHMC trajectory kernel for small general targets (csrc/jit/rmhmc_callback.hip.in) ----------------------
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-7), (torch.float32, 5e-3)])
+@pytest.mark.parametrize("D,scaled,jitter,alpha,burn", [(5, True, None, 1e6, 0), (5, False, 1e-2, 1e6, 2), (11, False, 1e-3, 1.0, -1),
+                                                        (3, True, 1e-3, 0.7, 0)])
+def test_fused_rmhmc_kernel_vs_oracle(ht, dtype, tol, D, scaled, jitter, alpha, burn):
+    """sample(RMHMC, EXPLICIT, SOFTABS) on the funnel, one launch for the run: every chain against oracle.sample_rmhmc_explicit on the
+    same Philox streams (momentum by chol(G) z, 8 jitter sub-streams per step in the reference's order, Q1 / Q2 / Q4) - the test the
+    launch-per-evaluation route passes (tests/test_gpu_rmhmc.py::test_generic_sample_rmhmc_vs_oracle), same tolerances."""
+    scales = np.array([0.5, 1.0, 1.7, 2.4, 3.3, 0.8, 1.2, 2.0, 2.9, 0.6])[:D - 1] if scaled else np.ones(D - 1)
+    lp, o = scaled_funnel(scales), O.FunnelTarget(D, scales)
+    C, N, L, eps, omega, seed, off = 70, 6, 3, 0.08, 10.0, 99, 7
+    th0 = (0.4 * O.philox_normals(seed, off + np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(NP[dtype])
+    out, acc = ht.sample(lp, tt(th0, dtype), num_samples=N, num_steps_per_sample=L, step_size=eps, burn=burn, jitter=jitter,
+                         softabs_const=alpha, explicit_binding_const=omega, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT,
+                         metric=ht.Metric.SOFTABS, debug=2, verbose=False, seed=seed, chain_offset=off)
+    assert "hta_cb_rmhmc_kernel<D=%d" % D in route(), route()
+    with np.errstate(all="ignore"):
+        ref, info = O.sample_rmhmc_explicit(o, th0, N, L, eps, omega, alpha, burn, jitter, O.PhiloxDraws(seed, off + np.arange(C), NP[dtype]))
+    got = np.stack([x.cpu().numpy() for x in out]); want = np.stack(ref)
+    assert got.shape == want.shape
+    bad = ~(np.abs(got - want).max(axis=(0, 2)) <= tol)
+    assert bad.mean() <= 0.1, "%d of %d chains differ, max err %.3g" % (bad.sum(), C, np.nanmax(np.abs(got - want)))
+    np.testing.assert_allclose(acc.cpu().numpy()[~bad], info["acc_rate"][~bad], atol=1e-12)
+
+
+def test_fused_rmhmc_kernel_equals_the_launch_sequence(ht, monkeypatch):
+    """The same run on the launch-per-evaluation route (HAMILTORCH_AMD_JIT=0: torch.func derivatives + hta_metric_eval) and in the
+    fused kernel: float64, the notebook's funnel with jitter."""
+    fn = scaled_funnel(np.ones(10))
+    th0 = tt(start(40, 11, 2, torch.float64, scale=0.4), torch.float64)
+    kw = dict(num_samples=4, num_steps_per_sample=4, step_size=0.1, jitter=1e-3, softabs_const=1e6, explicit_binding_const=10.0,
+              sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT, metric=ht.Metric.SOFTABS, verbose=False, seed=21)
+    a = torch.stack(list(ht.sample(fn, th0, **kw)))
+    assert "hta_cb_rmhmc_kernel<D=11,f64,jitter=1" in route()
+    monkeypatch.setenv("HAMILTORCH_AMD_JIT", "0")
+    b = torch.stack(list(ht.sample(fn, th0, **kw)))
+    assert "hta_cb_rmhmc_kernel" not in route()
+    err = (a - b).abs().amax(dim=(0, 2))
+    assert float((err > 1e-6).double().mean()) <= 0.1, float(err.max())
