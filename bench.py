@@ -153,7 +153,7 @@ def main():
 
     # --gpus N > 1 (the driver's scaling runs): the SECOND north-star target on every rank as well - D = 100 explicit RMHMC at
     # 1024 chains per GPU (cfg5) - and the path's only collective, the gather of its samples to rank 0 (after the timed region)
-    res5 = None
+    res5 = res5s = None
     if world > 1 and a.workload == "cfg2" and not a.no_secondary and a.chains is None and a.traj is None:
         del w
         torch.cuda.empty_cache()
@@ -172,13 +172,25 @@ def main():
             assert gathered.shape[1] == w5.C * world
         del gathered
         w = w5
+        # "also report 1/2/4 GPUs at 8192 total" - the STRONG-scaling form next to the weak one: 8192 chains in all,
+        # 8192 / N per GPU (N = 8: the same 1024 per GPU as the weak line), so the driver's N = 1, 2, 4, 8 runs yield both curves
+        if 8192 % world == 0:
+            del w5
+            torch.cuda.empty_cache()
+            per = 8192 // world
+            w5s = Cfg5(dev, per, 20 if per > 2048 else None, chain_offset=rank * per)
+            m5s = measure(w5s, 5, 1, world, dist, dev, 1)
+            res5s = result_of(w5s, Cfg5, *m5s, 5, 1, world)
+            res5s["key"], res5s["scaling"] = "cfg5-strong", "strong"
+            res5s["n_gpus"], res5s["ranks_seen"] = world, ranks_seen
+            w = w5s
 
     if rank == 0:
         out = {"key": res["key"], "metric": METRIC, "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": W.dtype_name, "data": "synthetic", "config": res["config"], "roofline": res["roofline"],
                "route": res["route"], "acceptance_rate": res["acceptance_rate"], "ess_per_sec": res["ess_per_sec"],
-               "ranks_seen": ranks_seen, "rank_devices": devices,
+               "ess_draws": res.get("ess_draws"), "rhat": res.get("rhat"), "ranks_seen": ranks_seen, "rank_devices": devices,
                "launcher": "torch.distributed.run" if world > 1 else "single process",
                "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None}
         if gather_ms is not None:
@@ -203,7 +215,7 @@ def main():
                 if cb.get("ess_per_sec"):                                              # the metric's second half: ESS/sec vs the CPU reference
                     out["ess_per_sec_vs_cpu_baseline"] = res["ess_per_sec"] / cb["ess_per_sec"]
         if res5 is not None:
-            out["secondary"] = [res5]
+            out["secondary"] = [res5] + ([res5s] if res5s is not None else [])
         if world == 1 and a.workload == "cfg2" and not a.no_secondary and a.chains is None and a.traj is None:
             del w
             torch.cuda.empty_cache()
@@ -249,8 +261,10 @@ def secondary(dev, a):
     out = []
     # (the north-star RMHMC size gets the headline's own bracket, 20 timed steps after 5: with 2 warm-up steps of 4 ms the first timed
     #  steps still run on ramping clocks - 2.40 ... 2.43e8 against a steady 2.47e8, tools/history/r05n.sh)
-    plan = [(Cfg3N, {}, 20, 5, True), (Cfg3, {}, 10, 2, True), (Cfg3, {"jacobi": True, "traj": 20}, 10, 1, False), (Cfg4, {}, 10, 2, True),
-            (NbMlp, {}, 10, 1, True), (NbMlpFull, {}, 10, 1, True), (FunnelHMC, {}, 10, 2, True), (FunnelRMHMC, {}, 3, 1, True)]
+    # (the callback contract - the round's subject - right behind the north-star RMHMC size: the compact line drops entries from the TAIL
+    #  if it would exceed its 4 KB)
+    plan = [(Cfg3N, {}, 20, 5, True), (FunnelHMC, {}, 10, 2, True), (FunnelRMHMC, {}, 5, 1, True), (Cfg3, {}, 10, 2, True),
+            (Cfg3, {"jacobi": True, "traj": 20}, 10, 1, False), (Cfg4, {}, 10, 2, True), (NbMlp, {}, 10, 1, True), (NbMlpFull, {}, 10, 1, True)]
     cpu_cache = {}
     for W, kw, steps, warmup, want_cpu in plan:
         try:
@@ -273,13 +287,29 @@ def secondary(dev, a):
             if not a.no_cpu_baseline:
                 ck = "cfg3" if isinstance(w, Cfg3) else W.key
                 if ck not in cpu_cache and want_cpu:
-                    cpu_cache[ck] = w.cpu_baseline(a.cpu_seconds)
+                    if callable(getattr(w, "burn_in_states", None)) and getattr(w, "cpu_takes_start", True) and os.environ.get("HTA_BENCH_BURNED_IN", "1") != "0":
+                        # both sides of the ESS comparison start from the device's burned-in chains
+                        import tempfile
+                        with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as tf_:
+                            torch.save(w.burn_in_states(64), tf_.name)
+                        try:
+                            cpu_cache[ck] = w.cpu_baseline(a.cpu_seconds, init_file=tf_.name)
+                        finally:
+                            os.unlink(tf_.name)
+                    else:
+                        cpu_cache[ck] = w.cpu_baseline(a.cpu_seconds)
                     cpu_cache[ck]["host_cpu"] = _cpu_model()
                 if ck in cpu_cache:
                     r["cpu_baseline"] = cpu_cache[ck]
                     r["speedup_vs_cpu_baseline_1core"] = r["value"] / (cpu_cache[ck]["value"] / max(1, cpu_cache[ck].get("cores", 1)))
                     if cpu_cache[ck].get("ess_per_sec") and r.get("ess_per_sec") == r.get("ess_per_sec"):
-                        r["ess_per_sec_vs_cpu_baseline"] = r["ess_per_sec"] / cpu_cache[ck]["ess_per_sec"]
+                        # a ratio of sampling efficiencies only where both sides' chains have mixed (split R-hat <= 1.1); otherwise the
+                        # two ESS numbers measure how far the chains still are from each other and the ratio is withheld
+                        rh = [v for v in (r.get("rhat"), cpu_cache[ck].get("rhat")) if v is not None and v == v]
+                        if rh and max(rh) > 1.1:
+                            r["ess_ratio_withheld"] = "split R-hat %.2f (device) / %.2f (cpu) > 1.1" % (r.get("rhat") or float("nan"), cpu_cache[ck].get("rhat") or float("nan"))
+                        else:
+                            r["ess_per_sec_vs_cpu_baseline"] = r["ess_per_sec"] / cpu_cache[ck]["ess_per_sec"]
             if getattr(W, "published", None):
                 r["published"] = W.published
                 r["samples_per_s"] = r["value"] / W.L

@@ -62,7 +62,8 @@ def _compact_cpu(cb):
         return None
     return {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
             "sample": str(cb.get("sample", "")).split(" (")[0].replace("processes", "proc").replace("trajectories", "traj")[:72], "pinned_to": str(cb.get("pinned_to", "")).split(" (")[0][:40],
-            "host_cpu": str(cb.get("host_cpu", ""))[:48], "ess_per_sec": _r(cb.get("ess_per_sec"))}
+            "host_cpu": str(cb.get("host_cpu", ""))[:48], "ess_per_sec": _r(cb.get("ess_per_sec")), "ess_draws": cb.get("ess_draws"),
+            "rhat": _r(cb.get("rhat"), 3), "rounds": len(cb.get("repeats") or [1])}
 
 
 def compact_line(full, detail_path="bench_detail.json"):
@@ -80,13 +81,13 @@ def compact_line(full, detail_path="bench_detail.json"):
     if full.get("cpu_baseline"):
         out["cpu_baseline"] = _compact_cpu(full["cpu_baseline"])
         out["speedup_vs_cpu_baseline"] = _r(full.get("speedup_vs_cpu_baseline"), 4)
-    for k in ("api_ms_per_step", "acceptance_rate", "ess_per_sec", "ess_per_sec_vs_cpu_baseline", "gather_ms"):
+    for k in ("api_ms_per_step", "acceptance_rate", "ess_per_sec", "ess_per_sec_vs_cpu_baseline", "gather_ms", "ess_draws", "rhat"):
         if full.get(k) is not None:
-            out[k] = _r(full[k])
+            out[k] = _r(full[k]) if not isinstance(full[k], list) else full[k]
     for k in ("ranks_seen", "rank_devices", "launcher", "collective_backend"):
         if k in full and full.get("n_gpus", 1) > 1:
             out[k] = full[k]
-    sec = []
+    sec, withheld = [], []
     for r in full.get("secondary", []) or []:
         if "error" in r:
             sec.append({"key": _short_key(r), "error": r["error"][:80]})
@@ -100,7 +101,7 @@ def compact_line(full, detail_path="bench_detail.json"):
         pcb = full.get("cpu_baseline") or {}
         e = {"key": _short_key(r), "chains": r.get("config", {}).get("chains_per_gpu"), "value": _r(r.get("value")),
              "frac": roof["frac"], "bound": roof["bound"] if roof["bound"] != "mfma" else None, "mfma_busy": roof["mfma_busy"],
-             "traffic": _r(roof["traffic"], 4), "kernel": roof["kernel"][:28], "kernel_ms": _r(roof["kernel_ms"], 4),
+             "traffic": _r(roof["traffic"], 3), "kernel": roof["kernel"].split("<")[0].replace("_kernel", "")[:20], "kernel_ms": _r(roof["kernel_ms"], 4),
              "cpu": {"value": _r(cb.get("value"), 4)}}
         if cb.get("cores") != pcb.get("cores"):
             e["cpu"]["cores"] = cb.get("cores")
@@ -108,33 +109,39 @@ def compact_line(full, detail_path="bench_detail.json"):
             e["cpu"]["kind"] = cb.get("kind")
         if cb.get("workers_failed"):
             e["cpu"]["failed"] = cb["workers_failed"]
-        for k in ("useful", "issued"):          # flops per chain-step: the algorithm's / the matrix instructions' (PMC counter)
-            if roof.get(k) is not None:
-                e[k] = roof[k]
+        if roof.get("padding") is not None:     # issued (PMC) / useful flops per chain-step; both spelled out in bench_detail.json
+            e["padding"] = roof["padding"]
         # BASELINE.json's metric, second half: ESS / s on the device and against the CPU reference (same estimator, same coordinates)
         if r.get("ess_per_sec") is not None and r["ess_per_sec"] == r["ess_per_sec"]:
             e["ess_per_sec"] = _r(r["ess_per_sec"], 4)
+        if r.get("ess_draws"):                       # [draws per chain, chains] behind the device's ESS, and their split R-hat
+            e["ess_draws"], e["rhat"] = r["ess_draws"], _r(r.get("rhat"), 3)
         if cb.get("ess_per_sec"):
             e["cpu"]["ess_per_sec"] = _r(cb["ess_per_sec"], 4)
+            if cb.get("ess_draws"):
+                e["cpu"]["ess_draws"], e["cpu"]["rhat"] = cb["ess_draws"], _r(cb.get("rhat"), 3)
         if r.get("ess_per_sec_vs_cpu_baseline") is not None:
             e["ess_per_sec_vs_cpu"] = _r(r["ess_per_sec_vs_cpu_baseline"], 4)
-        if r.get("api_ms_per_step") is not None:
-            e["api_ms"] = _r(r["api_ms_per_step"], 4)
+        elif r.get("ess_ratio_withheld"):
+            withheld.append(e["key"])
         for k in ("gather_ms", "n_gpus", "ranks_seen"):
             if r.get(k) is not None:
                 e[k] = _r(r[k], 4)
+        if r.get("scaling"):                         # "strong": a fixed total (cfg5-strong: 8192 chains over the node)
+            e["scaling"], e["chains_total"] = r["scaling"], r.get("config", {}).get("chains_total")
         if r.get("extras"):
-            short = {"graph_replay": "graph", "value_graphs_off": "graphs_off", "value_notebook_closure": "nb_closure",
+            short = {"graph_replay": "graph", "value_graphs_off": "graphs_off", "value_notebook_closure": "nb_closure", "value_callback_path": "cb_path", "value_launch_sequence_256": "launch_seq_256", "trace_compile_s": "compile_s",
                      "launches_per_step": "launches", "hta_launches_per_step": "hta_launches", "callback_evaluations_per_step": "cb_evals", "metric_evaluations_per_step": "metric_evals",
                      "predict_route": "predict", "predict_ms_torch_path": "predict_ms_torch"}
             e["extras"] = {short.get(k, k): _r(v, 4) for k, v in r["extras"].items()
-                           if not isinstance(v, (dict, list)) and v is not None and k not in ("predict_samples_per_s", "predict_samples", "predict_ms_torch_path", "trajectories_per_step_1024", "kernel_ms_1024")}
-        if r.get("published"):
-            e["samples_per_s"] = _r(r.get("samples_per_s"), 4)
+                           if not isinstance(v, (dict, list)) and v is not None and k not in ("predict_samples_per_s", "predict_samples", "predict_ms_torch_path", "trajectories_per_step_1024", "kernel_ms_1024", "callback_evaluations_per_step", "metric_evaluations_per_step", "hta_launches_per_step", "traces", "predict_route", "frac_1024")}
+        if r.get("published"):          # the reference's published samples / s (one chain); ours = value / L, spelled out in bench_detail.json
             e["published_sps"] = r["published"].get("samples_per_s")
         sec.append({k: v for k, v in e.items() if v is not None or k in ("value", "frac", "chains")})
     if sec:
         out["secondary"] = sec
+    if withheld:        # ESS ratios are printed only where both sides' chains have mixed (split R-hat <= 1.1); `rhat` is beside every ESS
+        out["ess_ratio_withheld_rhat_gt_1.1"] = withheld
     out["detail"] = detail_path
     line = json.dumps(out, separators=(",", ":"))
     while len(line) >= LINE_LIMIT and out.get("secondary"):          # never print a line the driver cannot keep

@@ -95,12 +95,14 @@ def result_of(w, W, dt, call_ms, prof_ms, prof_n, steps, warmup, world):
         roof["issued_flops_per_chain_step"] = issued
         roof["padding"] = issued / roof["useful_flops_per_chain_step"]
         roof["mfma_issued_over_useful"] = roof["padding"]
-    from hamiltorch_amd.ess import ess_min
+    from hamiltorch_amd.ess import ess_min, rhat_max
     # ESS over the first ESS_DIMS coordinates - the ones the CPU baseline's samples travel with (oracle/cpu_baseline.py), so that
     # both sides of `ess_per_sec_vs_cpu_baseline` are the same estimator on the same coordinates
     ess_seconds = call_ms * 1e-3
-    if w.T >= 8:
-        ess = ess_min(w.samples[1:, :, :ESS_DIMS])
+    ess_draws = rhat = None
+    if w.T >= 8 and not getattr(W, "ess_extra_steps", 0):
+        used = w.samples[1:, :, :ESS_DIMS]
+        ess, ess_draws, rhat = ess_min(used), [int(used.shape[0]), int(used.shape[1])], rhat_max(used)
     elif getattr(W, "ess_extra_steps", 0) and w.samples is not None and os.environ.get("HTA_BENCH_ESS_EXTRA", "1") != "0":
         # workloads whose step is one or two trajectories (the published-model runs, funnel-rmhmc): an UNTIMED run of consecutive steps
         # after the measurement - the chain state travels from step to step - supplies the draws; ESS / s = ESS of those draws / (their
@@ -110,7 +112,8 @@ def result_of(w, W, dt, call_ms, prof_ms, prof_n, steps, warmup, world):
             w.step(100000 + k)
             draws.append(w.samples[1:, :, :ESS_DIMS].clone())
         torch.cuda.synchronize()
-        ess = ess_min(torch.cat(draws))
+        used = torch.cat(draws)
+        ess, ess_draws, rhat = ess_min(used), [int(used.shape[0]), int(used.shape[1])], rhat_max(used)
         ess_seconds = W.ess_extra_steps * call_ms * 1e-3
     else:
         ess = float("nan")
@@ -121,7 +124,7 @@ def result_of(w, W, dt, call_ms, prof_ms, prof_n, steps, warmup, world):
                        "trajectories_per_step": w.T, "leapfrog_steps_per_trajectory": W.L, "D": W.D,
                        "samples_stored": True, "parallelism": "chains sharded, %d per GPU, no collective" % w.C},
             "roofline": roof, "route": getattr(w, "route", ""), "acceptance_rate": acc, "ess_per_sec": ess / ess_seconds,
-            "ess_dims": min(W.D, ESS_DIMS)}
+            "ess_dims": min(W.D, ESS_DIMS), "ess_draws": ess_draws, "rhat": rhat}
 
 
 def api_timing(w, steps, warmup, reps=5):

@@ -101,7 +101,7 @@ class Cfg2:
 
     def cpu_baseline(self, seconds):
         """The reference's CPU path on this host: see cpu_baseline_procs.  Median of three rounds."""
-        return cpu_baseline_procs("cfg2", seconds, rounds=3)
+        return cpu_baseline_procs("cfg2", seconds)
 
 
 class Cfg3:
@@ -222,10 +222,17 @@ class Cfg3:
                             "refinement route: (4 L + 3) x 3 D^3 + 3.33 D^3 per trajectory" if self.jacobi else
                             "(4 K + 4 + (2 K + 5) / L) x 2 D^2 per step, K = 2")}
 
-    def cpu_baseline(self, seconds):
+    def burn_in_states(self, k):
+        """The first k chains where the timed steps left them (thousands of trajectories in): the CPU baseline's chains start from these
+        posterior draws, so their ESS measures within-chain mixing from the first draw on (benchlib/cpu.py)."""
+        torch.cuda.synchronize()
+        return self.cur[:k].detach().cpu().clone()
+
+    def cpu_baseline(self, seconds, init_file=None):
         """Reference cost structure: every dH/dtheta, dH/dp is an autograd pass through hessian + eigh (S:395-422); one chain
-        per usable host core."""
-        return cpu_baseline_procs("cfg3", seconds)
+        per usable host core.  ~1 trajectory per second and core: four times the common budget (three rounds of 12 s at the default) so
+        that a chain has more than a handful of draws behind its ESS."""
+        return cpu_baseline_procs("cfg3", 4 * seconds, init_file=init_file)
 
 
 class Cfg5(Cfg3):
@@ -289,6 +296,19 @@ class Cfg4:
     def bytes_per_unit(self):
         return 16 * self.D
 
+
+    #: untimed steps the chains are advanced by before ESS is measured and before the CPU baseline's workers are started FROM THE
+    #: DEVICE'S STATES (every chain of both sides used to start at one point - the ESS of 16 short CPU chains was the
+    #: spread they had not yet acquired).  `burn_in_states(k)` returns the first k chains' states after that run.
+    burn_in_trajectories = 2000
+
+    def burn_in_states(self, k):
+        n = -(-self.burn_in_trajectories // self.T)
+        for i in range(n):
+            self.step(200000 + i)
+        torch.cuda.synchronize()
+        return self.cur[:k].detach().cpu().clone()
+
     roof_kernel = "mlp_mfma_kernel"
 
     def api_call(self, k):
@@ -319,9 +339,9 @@ class Cfg4:
                 "frac_by_reference_flops": self.reference_flops_per_unit() * self.units_per_step() / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
                 "note": "2M x 6 flop per (point, weight) per split step (SURVEY 8d) against the fp32 matrix peak"}
 
-    def cpu_baseline(self, seconds):
+    def cpu_baseline(self, seconds, init_file=None):
         """Reference cost structure: per-split closure + autograd gradient for every half kick (S:499-540); one chain per core."""
-        return cpu_baseline_procs("cfg4", seconds)
+        return cpu_baseline_procs("cfg4", seconds, init_file=init_file)
 
 
 class NbMlp:
@@ -387,6 +407,19 @@ class NbMlp:
     def bytes_per_unit(self):
         return 16 * self.D
 
+
+    #: untimed steps the chains are advanced by before ESS is measured and before the CPU baseline's workers are started FROM THE
+    #: DEVICE'S STATES (every chain of both sides used to start at one point - the ESS of 16 short CPU chains was the
+    #: spread they had not yet acquired).  `burn_in_states(k)` returns the first k chains' states after that run.
+    burn_in_trajectories = 300
+
+    def burn_in_states(self, k):
+        n = -(-self.burn_in_trajectories // self.T)
+        for i in range(n):
+            self.step(200000 + i)
+        torch.cuda.synchronize()
+        return self.cur[:k].detach().cpu().clone()
+
     roof_kernel = "mlp3_mfma_kernel<0>"
 
     def api_call(self, k):
@@ -418,9 +451,9 @@ class NbMlp:
                 "reference_flops_per_chain_step": self.reference_flops_per_unit(),
                 "frac_by_reference_flops": self.reference_flops_per_unit() * self.units_per_step() / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
 
-    def cpu_baseline(self, seconds):
+    def cpu_baseline(self, seconds, init_file=None):
         """Reference cost structure: functional model + autograd per half kick (S:499-540) on the notebook's module; one chain per core."""
-        return cpu_baseline_procs(self.key, seconds)
+        return cpu_baseline_procs(self.key, seconds, init_file=init_file)
 
     def extras(self):
         """SURVEY 8(f) N2, the step after sampling in every BNN notebook: predict_model over 1000 of the samples just drawn x the
@@ -489,16 +522,19 @@ def funnel_ll_notebook(w, dim=10):
 
 
 class FunnelHMC:
-    """The callback contract on the driver's line: the reference's published 11-D funnel run
-    (notebook cell 24: HMC, eps = 0.2, L = 25: 56.10 samples/s, one chain) at 1024 chains through hamiltorch_amd.sample() with
-    an opaque closure - torch evaluates the callback for all chains (vmap(grad_and_value)), the kicks / drifts / energies /
-    Metropolis step are the HIP pieces kernels, a whole trajectory is replayed as one captured HIP graph."""
+    """The callback contract on the driver's line: the reference's published 11-D funnel run (notebook cell 24: HMC, eps = 0.2, L = 25:
+    56.10 samples/s, one chain) at 1024 chains through hamiltorch_amd.sample() with an OPAQUE closure.  Round 6: the callback compiler
+    (hamiltorch_amd/jit/) traces the closure, differentiates and emits it, and hipRTC builds it into the fused trajectory kernel
+    (csrc/jit/hmc_callback.hip.in) - one launch per sample() call; rounds 3-5 evaluated the closure with torch (vmap(grad_and_value),
+    ~38 launches per leapfrog step) between the pieces kernels: `extras.value_callback_path` is that route today (HAMILTORCH_AMD_JIT=0)."""
     key = "funnel-hmc"
-    name = "funnel-hmc: 11-D funnel (notebook cell 22-24), HMC eps=0.2 L=25, opaque log_prob_func closure -> generic path"
-    D, L, eps, chains, traj = 11, 25, 0.2, 1024, 50
+    name = "funnel-hmc: 11-D funnel (notebook cell 22-24), HMC eps=0.2 L=25, opaque log_prob_func closure -> compiled callback kernel"
+    D, L, eps, chains, traj = 11, 25, 0.2, 1024, 200
     dtype_name = "f32"
+    ess_extra_steps = 5            # ESS from 5 consecutive untimed steps continuing the chains (1000 draws each) instead of one step from the common start
     published = {"samples_per_s": 56.10, "hw": "notebook host, 1 chain", "src": "log_prob_examples nb cell 24 (JSON lines 401-402)"}
     sampler_kw = {}
+    kernel_name = "hta_cb_hmc_kernel"
 
     def __init__(self, dev, chains, traj, chain_offset, seed=1):
         from hamiltorch_amd import _abi
@@ -511,6 +547,7 @@ class FunnelHMC:
         self.samples = None
         self._acc = []
         self.fn = funnel_ll_device
+        self._start = self.theta0
 
     def units_per_step(self):
         return self.C * self.T * self.L
@@ -518,14 +555,16 @@ class FunnelHMC:
     def bytes_per_unit(self):
         return 16 * self.D
 
-    def _sample(self, fn, k, T):
+    def _sample(self, fn, k, T, start=None):
         import hamiltorch_amd as ht
-        return ht.sample(fn, self.theta0, num_samples=T, num_steps_per_sample=self.L, step_size=self.eps, burn=-1, debug=2,
-                         verbose=False, seed=self.seed + k, chain_offset=self.off, **self.sampler_kw)
+        return ht.sample(fn, self.theta0 if start is None else start, num_samples=T, num_steps_per_sample=self.L, step_size=self.eps,
+                         burn=-1, debug=2, verbose=False, seed=self.seed + k, chain_offset=self.off, **self.sampler_kw)
 
     def step(self, k):
+        # steps >= 100000 are the untimed ESS extension (benchlib/measure.py): the chains CONTINUE from where the previous step ended
         from hamiltorch_amd.samplelist import as_tensor
-        out, acc = self._sample(self.fn, k, self.T)
+        cont = k >= 100000 and self.samples is not None
+        out, acc = self._sample(self.fn, k, self.T, self.samples[-1].contiguous() if cont else None)
         self.samples = as_tensor(out)
         self._acc.append(acc)
 
@@ -562,46 +601,80 @@ class FunnelHMC:
                 self._sample(self.fn, 200, self.T)
                 torch.cuda.synchronize()
             evs = [e for e in prof.key_averages() if getattr(e, "device_type", None) is not None and "cuda" in str(e.device_type).lower()]
-            # the library's own share (kernel names in namespace hta) next to the callback's (torch's kernels: VERDICT r04 item 7)
-            self._hta_launches = sum(e.count for e in evs if "hta::" in str(e.key))
+            self._hta_launches = sum(e.count for e in evs if "hta" in str(e.key))
             return sum(e.count for e in evs)
         except Exception:
             return None
 
+    def _graph_flops(self):
+        """Useful flops of one leapfrog step from the compiled graph itself: the scalar operations of value + gradient (a transcendental
+        counted as one) + 4 D for the kick and the drift."""
+        try:
+            from hamiltorch_amd import jit
+            comp = jit.compile_hmc(self.fn, self.theta0[0], self.theta0.dtype, 0)
+            g = comp.traced.graph
+            live = g.reachable([comp.traced.value] + comp.traced.grad())
+            return sum(1 for i in live if g.nodes[i][0] not in ("const", "bconst", "in", "detach")) + 4 * self.D
+        except Exception:
+            return None
+
     def extras(self):
-        """Graph replay on / off and the notebook's verbatim closure, each on a shorter run (not part of `value`)."""
-        from hamiltorch_amd import util
-        T = max(4, self.T // 5)
-        out = {"graph_replay": not any("trajectory" in g_ for g_ in util.graph_log[-8:]),
-               "value_graphs_off": self._rate(self.fn, T, env={"HAMILTORCH_AMD_GRAPHS": "0"}),
-               "value_notebook_closure": self._rate(funnel_ll_notebook, T),
+        """The torch-evaluated callback path the compiled kernel replaces, the notebook's verbatim closure (torch.distributions: compiled as
+        well), a saturating chain count, the one-off trace / compile cost, launches per sample() call - each on a short run, not part of `value`."""
+        from hamiltorch_amd import jit
+        T = max(4, self.T // 10)
+        out = {"value_callback_path": self._rate(self.fn, T, env={"HAMILTORCH_AMD_JIT": "0"}),
+               "value_notebook_closure": self._rate(funnel_ll_notebook, self.T),
                "launches_per_step": self._launches(),
-               "callback_evaluations_per_step": self.T * (self.L + 1)}
+               "callback_evaluations_per_step": self.T * (self.L + 1),
+               "trace_compile_s": round(jit.runtime.stats["compile_seconds"], 3), "traces": jit.stats["traced"]}
         out["hta_launches_per_step"] = getattr(self, "_hta_launches", None)
+        try:
+            big = type(self)(self.dev, 65536, max(4, self.T // 10), 0)
+            out["value_65536"] = big._rate(big.fn, big.T)
+            del big
+        except Exception as e:
+            out["value_65536_error"] = str(e)[:80]
         return out
 
     def roofline(self, kernel_ms, call_ms, prof_n, steps):
-        gbs = self.units_per_step() * self.bytes_per_unit() / (call_ms * 1e-3) / 1e9
-        return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "torch callback + hmc_pieces kernels (HIP graph per trajectory)", "kernel_fixed": True,
-                "kernel_ms_per_step": call_ms, "call_ms": call_ms, "launches_per_step": None,
-                "note": "SURVEY 8(d) byte model (16 D bytes per chain-step) over the whole call; the path is launch / latency bound "
-                        "at this size (D = 11): the fraction is reported, not claimed"}
+        """The kernel is one chain per lane, straight-line VALU code: at 1024 chains 16 waves hold 16 of the 1024 SIMDs, so the fraction of
+        the vector peak is small by construction (`simds_occupied_frac`); what binds a lone wave is its instruction issue (~4.5 cycles per
+        instruction).  frac = useful flops (the compiled graph's own operations + the 4 D of the leapfrog) / kernel time / fp32 vector peak."""
+        sec = kernel_ms * 1e-3
+        flops = self._graph_flops()
+        tf = (flops or 0) * self.units_per_step() / sec / 1e12
+        waves = (self.C + 63) // 64
+        clk_ghz = self.abi.device_info(0)["clock_khz"] / 1e6
+        return {"bound": "valu", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "traffic": None,
+                "kernel": self.kernel_name, "kernel_ms_per_step": kernel_ms, "call_ms": call_ms, "launches_per_step": prof_n / max(1, steps),
+                "useful_flops_per_chain_step": flops, "simds_occupied_frac": min(1.0, waves / N_SIMDS),
+                "cycles_per_leapfrog_step": sec * clk_ghz * 1e9 / (self.T * self.L),
+                "hbm_model_8d": {"ratio_to_hbm_peak": self.units_per_step() * self.bytes_per_unit() / sec / 1e9 / HBM_PEAK_GBS},
+                "note": "chain per lane, state in registers for the launch; one launch per sample() call; kernel time from HIP events inside "
+                        "the library; the wall time of `value` adds the host side of sample() (trace-cache lookup, the run-time check of the "
+                        "compiled code against the callable, the sample tensor)"}
 
-    def cpu_baseline(self, seconds):
-        # the fast workload (hundreds of trajectories per second and core) in three rounds: ESS / s of the funnel from 16 short chains is the
-        # noisiest number of the line (3.8 ... 35 from run to run with one round) - the median round's is reported (benchlib/cpu.py)
-        return cpu_baseline_procs(self.key, seconds, rounds=3 if self.key == "funnel-hmc" else 1)
+    def burn_in_states(self, k):
+        torch.cuda.synchronize()
+        return self.samples[-1][:k].detach().cpu().clone()
+
+    def cpu_baseline(self, seconds, init_file=None):
+        return cpu_baseline_procs(self.key, (2 if self.key == "funnel-rmhmc" else 1) * seconds, init_file=init_file)
 
 
 class FunnelRMHMC(FunnelHMC):
-    """SURVEY 8(f) N1 on the driver's line: explicit RMHMC with the soft-abs metric on the same funnel (notebook cell 30:
-    eps = 0.14, L = 25, omega = 10, jitter = 1e-3; the reference's progress bar shows < 1 sample/s and its run ends in NaN
-    after 14 samples) at 256 chains: per-chain Hessians by torch.func, hta_metric_eval with dmetric_out on the matrix cores."""
+    """SURVEY 8(f) N1 on the driver's line: explicit RMHMC with the soft-abs metric on the same funnel (notebook cell 30: eps = 0.14, L = 25,
+    omega = 10, jitter = 1e-3; the reference's progress bar shows < 1 sample/s and its run ends in NaN after 14 samples).  Round 6: the
+    compiled callable (derivatives up to the third order from its traced graph) inside the chain-per-lane trajectory kernel
+    csrc/jit/rmhmc_callback.hip.in - Hessian, jitter, Jacobi eigendecomposition, soft-abs map, solves and the derivative of the metric in
+    registers, one launch per sample() call; `extras.value_launch_sequence` is the round-5 route (torch.func derivatives + hta_metric_eval)."""
     key = "funnel-rmhmc"
-    name = "funnel-rmhmc: 11-D funnel, explicit RMHMC softabs alpha=1e6 omega=10 eps=0.14 L=25 jitter=1e-3, opaque closure"
-    D, L, eps, chains, traj = 11, 25, 0.14, 256, 2
+    name = "funnel-rmhmc: 11-D funnel, explicit RMHMC softabs alpha=1e6 omega=10 eps=0.14 L=25 jitter=1e-3, opaque closure -> compiled trajectory kernel"
+    D, L, eps, chains, traj = 11, 25, 0.14, 1024, 2
+    ess_extra_steps = 60           # 2 trajectories per step: ESS from 60 consecutive untimed steps = 120 draws per chain (benchlib/measure.py)
     published = {"samples_per_s": 0.19, "hw": "notebook host, 1 chain", "src": "log_prob_examples nb cell 30 (JSON lines 637-638)"}
+    kernel_name = "hta_cb_rmhmc_kernel"
 
     def __init__(self, dev, chains, traj, chain_offset, seed=1):
         super().__init__(dev, chains, traj, chain_offset, seed)
@@ -610,19 +683,21 @@ class FunnelRMHMC(FunnelHMC):
                                explicit_binding_const=10.0, jitter=1e-3)
 
     def extras(self):
-        T = self.T
-        return {"value_graphs_off": self._rate(self.fn, T, reps=1, env={"HAMILTORCH_AMD_GRAPHS": "0"}),
-                "metric_evaluations_per_step": self.T * (8 * self.L + 3), "launches_per_step": None}
+        small = type(self)(self.dev, 256, 1, 0)
+        return {"value_launch_sequence_256": small._rate(small.fn, 1, reps=1, env={"HAMILTORCH_AMD_JIT": "0"}),
+                "metric_evaluations_per_step": self.T * (8 * self.L + 3), "launches_per_step": self._launches()}
+
+    def _graph_flops(self):
+        """Per explicit step: 8 metric evaluations, each ~ 2 D^3 (basis change) + ~2 x 6 D^2 x D(D-1)/2 / ... - counted simply as the
+        reference-faithful 8 x 11.3 D^3 of SURVEY 8(d) + the third-derivative contraction 4 x 2 D^2 (the funnel's is sparse)."""
+        return 8 * 11.3 * self.D ** 3 + 4 * 2 * self.D ** 2
 
     def roofline(self, kernel_ms, call_ms, prof_n, steps):
-        # SURVEY 8(d)'s count at D = 11: 8 metric evaluations per step (the reference-faithful count: dH/dtheta depends on the metric
-        # here) x 11.3 D^3 + the third-derivative contraction D^4 per kick
-        flops = 8 * 11.3 * self.D ** 3 + 4 * 2 * self.D ** 4
-        tf = flops * self.units_per_step() / (call_ms * 1e-3) / 1e12
-        return {"bound": "mfma", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "traffic": None,
-                "kernel": "torch.func callbacks + metric_warm_mfma_kernel", "kernel_fixed": True,
-                "kernel_ms_per_step": call_ms, "call_ms": call_ms, "launches_per_step": None,
-                "note": "launch bound: D = 11 systems on kernels sized for D = 100; the fraction is reported, not claimed"}
+        r = super().roofline(kernel_ms, call_ms, prof_n, steps)
+        r["note"] = ("SURVEY 8(d)'s count at D = 11 (8 metric evaluations per step x 11.3 D^3) / kernel time / fp32 vector peak; chain per "
+                     "lane, a lone wave per SIMD at 1024 chains: instruction issue binds (profiles/r06b_rmhmc_callback_pmc.json: VALU active "
+                     "69 % of the wave's cycles, 29 k VALU instructions per metric evaluation)")
+        return r
 
 
 WORKLOADS = {"funnel-hmc": FunnelHMC, "funnel-rmhmc": FunnelRMHMC, "nbmlp": NbMlp, "nbmlp-full": NbMlpFull, "cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4, "cfg5": Cfg5, "cfg3@1024": Cfg3N}

@@ -407,7 +407,8 @@ def metric_eval(like, B, D, metric, Hs, hs_stride, alpha, jitter=None, seed=0, c
                     ("dmetric_out", dmetric_out)):
         setattr(a, name, None if t is None else _p(t, like).value)
         keep.append(t)
-    ws = scratch(like, metric_eval_workspace_bytes(B, D, like.element_size()), "metric") if workspace is None else workspace
+    with torch.cuda.device(like.device):       # (the size query reads the CURRENT device's geometry: ask on the tensors' device)
+        ws = scratch(like, metric_eval_workspace_bytes(B, D, like.element_size()), "metric") if workspace is None else workspace
     a.workspace, a.workspace_bytes = (None, 0) if ws is None else (ws.data_ptr(), ws.numel() * ws.element_size())
     fn = getattr(load(), "hta_metric_eval_" + _suffix(like))
     with torch.cuda.device(like.device):
@@ -433,6 +434,13 @@ def scratch(like, nbytes, tag):
     if t is None or t.numel() < nbytes:
         t = _scratch[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=like.device)
     return t
+
+
+def free_scratch(min_bytes=0):
+    """Drop the cached scratch buffers of at least `min_bytes` bytes (all of them by default): torch's allocator gets the memory back.
+    sample() calls this with 256 MiB at its end - a metric evaluation at D = 1024 in fp64 needs 8.6 GB once, not for the life of the process."""
+    for k in [k for k, t in _scratch.items() if t.numel() >= min_bytes]:
+        del _scratch[k]
 
 
 def rmhmc_workspace_bytes(C, D, itemsize, n_traj=0, cap_bytes=256 << 20):
@@ -553,7 +561,8 @@ def netn_hmc_sample(theta, theta_init, dims, act, X, Y, M, Nb, taus, tau_out, pr
     C = theta.shape[0]
     nl, cd, ct = _net_operands(theta, dims, taus)
     fn = getattr(load(), "hta_netn_hmc_sample_" + _suffix(theta))
-    ws = scratch(theta, netn_hmc_workspace_bytes(C, dims, theta.element_size()), "netn") if workspace is None else workspace
+    with torch.cuda.device(theta.device):
+        ws = scratch(theta, netn_hmc_workspace_bytes(C, dims, theta.element_size()), "netn") if workspace is None else workspace
     with torch.cuda.device(theta.device):
         _check(fn(_p(theta), _p(theta_init, theta), C, nl, cd, ACTS[act], NET_LOSSES[loss], _p(X, theta), _p(Y, theta),
                   X.shape[0], int(M), int(Nb), ct, float(tau_out), float(prior_scale), mass_kind, _p(inv_mass, theta),
@@ -578,7 +587,8 @@ def netn_logp_grad(theta, dims, act, X, Y, M, Nb, split, taus, tau_out, prior_sc
     C = theta.shape[0]
     nl, cd, ct = _net_operands(theta, dims, taus)
     fn = getattr(load(), "hta_netn_logp_grad_" + _suffix(theta))
-    ws = scratch(theta, netn_hmc_workspace_bytes(C, dims, theta.element_size()), "netn")
+    with torch.cuda.device(theta.device):
+        ws = scratch(theta, netn_hmc_workspace_bytes(C, dims, theta.element_size()), "netn")
     with torch.cuda.device(theta.device):
         _check(fn(_p(theta), C, nl, cd, ACTS[act], NET_LOSSES[loss], _p(X, theta), _p(Y, theta), X.shape[0], int(M), int(Nb),
                   int(split), ct, float(tau_out), float(prior_scale), _p(grad_out, theta), _p(logp_out, theta),

@@ -31,6 +31,40 @@ __global__ void phi_c_kernel(T* __restrict__ th, T* __restrict__ pm, T* __restri
   }
 }
 
+// chol(P) of ONE matrix in double precision: a single workgroup, the symmetric part of P in LDS (row stride D + 1), right-looking
+// factorisation (column scale + trailing update per step), the lower factor rounded to T and written row-major with a zero upper part.
+template <typename T>
+__global__ void __launch_bounds__(256) chol_p_kernel(const T* __restrict__ P, T* __restrict__ L, int D) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* A = reinterpret_cast<double*>(smem_raw);
+  const int lda = D + 1, tid = threadIdx.x;
+  for (int e = tid; e < D * D; e += 256) {
+    const int i = e / D, j = e - i * D;
+    A[i * lda + j] = 0.5 * ((double)P[(int64_t)i * D + j] + (double)P[(int64_t)j * D + i]);      // the symmetric part, as the kernels read P
+  }
+  for (int j = 0; j < D; ++j) {
+    __syncthreads();
+    const double djj = sqrt(A[j * lda + j]);
+    const double inv = 1.0 / djj;
+    __syncthreads();
+    for (int i = j + tid; i < D; i += 256) A[i * lda + j] = (i == j) ? djj : A[i * lda + j] * inv;
+    __syncthreads();
+    const int r = D - j - 1;
+    for (int e = tid; e < r * r; e += 256) {
+      const int ii = e / r, kk = e - ii * r;
+      if (kk <= ii) {
+        const int i = j + 1 + ii, k = j + 1 + kk;
+        A[i * lda + k] -= A[i * lda + j] * A[k * lda + j];
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < D * D; e += 256) {
+    const int i = e / D, j = e - i * D;
+    L[e] = (j <= i) ? (T)A[i * lda + j] : (T)0;
+  }
+}
+
 template <typename T> struct RmModel {
   const T* P; const T* mu; double log_norm; int metric; double alpha; int has_jitter; double jitter;
   uint64_t seed; uint64_t chain_offset; int64_t C; int D;
@@ -144,35 +178,21 @@ static int rmhmc_setup(RmModel<T>& m, T* V0, T* lam0, T* Sinv, T* LP, bool want_
       int rc = inverse_from_eigen<T>(V0, lam0, Sinv, D, s);
       if (rc) return rc;
       if (m.has_jitter && D <= 128) {
-        // chol(P) for the split momentum draw (rmhmc_fused.hip: rmhmc_momentum_split_kernel): one 100 x 100 factorisation per
-        // TARGET, on the host in double (0.3 MFLOP) from a copy of P, rounded to T
-        std::vector<T> hp((size_t)D * D);
-        if (hipMemcpyAsync(hp.data(), m.P, hp.size() * sizeof(T), hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipStreamSynchronize(s) != hipSuccess) {
-          set_error("%s: reading the curvature matrix back failed: %s", who, hipGetErrorString(hipGetLastError()));
-          return HTA_ERR_LAUNCH;
-        }
-        std::vector<double> Lh((size_t)D * D, 0.0);
-        bool pd = true;
-        for (int j = 0; j < D && pd; ++j) {
-          double d = 0.5 * ((double)hp[(size_t)j * D + j] + (double)hp[(size_t)j * D + j]);
-          for (int k = 0; k < j; ++k) d -= Lh[(size_t)j * D + k] * Lh[(size_t)j * D + k];
-          if (!(d > 0.0)) { pd = false; break; }
-          const double dj = sqrt(d);
-          Lh[(size_t)j * D + j] = dj;
-          for (int i = j + 1; i < D; ++i) {
-            double v = 0.5 * ((double)hp[(size_t)i * D + j] + (double)hp[(size_t)j * D + i]);      // the symmetric part, as the kernels read P
-            for (int k = 0; k < j; ++k) v -= Lh[(size_t)i * D + k] * Lh[(size_t)j * D + k];
-            Lh[(size_t)i * D + j] = v / dj;
+        // chol(P) for the split momentum draw (rmhmc_fused.hip: rmhmc_momentum_split_kernel): one 100 x 100 factorisation per TARGET, in
+        // double, on the DEVICE (round 6: chol_p_kernel - a single workgroup, the matrix in LDS; rounds 2-5 read P back and factorised
+        // on the host: two more synchronisations).  P is positive definite iff its smallest eigenvalue is: the spectrum is on the host
+        // already (the plan above), so whether the split draw applies needs no second read-back.
+        double lmin = (double)lam_host[0], lmax = fabs((double)lam_host[0]);
+        for (int i = 1; i < D; ++i) { lmin = fmin(lmin, (double)lam_host[i]); lmax = fmax(lmax, fabs((double)lam_host[i])); }
+        if (lmin > 1e-6 * lmax) {
+          const size_t lds = (size_t)D * (D + 1) * sizeof(double);
+          static DevOnce chol_attr;
+          if (!chol_attr) {
+            (void)hipFuncSetAttribute((const void*)chol_p_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            chol_attr = true;
           }
-        }
-        if (pd) {
-          for (size_t e = 0; e < hp.size(); ++e) hp[e] = (T)Lh[e];
-          if (hipMemcpyAsync(LP, hp.data(), hp.size() * sizeof(T), hipMemcpyHostToDevice, s) != hipSuccess ||
-              hipStreamSynchronize(s) != hipSuccess) {
-            set_error("%s: uploading chol(P) failed: %s", who, hipGetErrorString(hipGetLastError()));
-            return HTA_ERR_LAUNCH;
-          }
+          chol_p_kernel<T><<<1, 256, lds, s>>>(m.P, LP, D);
+          HTA_CHECK_LAUNCH(who);
           pr.split = 1;
         }
       }

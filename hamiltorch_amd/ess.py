@@ -41,3 +41,27 @@ def ess_bulk(x: torch.Tensor) -> float:
 def ess_min(samples: torch.Tensor) -> float:
     """samples[S, C, D] -> min over dimensions of ess_bulk."""
     return min(ess_bulk(samples[:, :, d]) for d in range(samples.shape[2]))
+
+
+def rhat_split(x: torch.Tensor) -> float:
+    """x[S, C] -> split-R-hat (Gelman et al. 2013: each chain cut in halves, between- over within-half variance); 1 = the halves of all
+    chains agree.  The measurement's guard on its own ESS numbers: chains that have not left their starting points give R-hat >> 1,
+    and an ESS computed from them measures the spread of the starts, not mixing."""
+    x = x.to(torch.float64)
+    S, C = x.shape
+    h = S // 2
+    if h < 2:
+        return float("nan")
+    y = torch.cat([x[:h], x[S - h:]], dim=1)                      # [h, 2 C]
+    w = y.var(dim=0, unbiased=True).mean()
+    b = h * y.mean(dim=0).var(unbiased=True)
+    if float(w) <= 0.0:
+        return float("inf") if float(b) > 0.0 else float("nan")
+    return float(torch.sqrt(((h - 1.0) / h * w + b / h) / w))
+
+
+def rhat_max(samples: torch.Tensor) -> float:
+    """samples[S, C, D] -> max over dimensions of rhat_split (NaN dimensions ignored)."""
+    vals = [rhat_split(samples[:, :, d]) for d in range(samples.shape[2])]
+    vals = [v for v in vals if v == v]
+    return max(vals) if vals else float("nan")

@@ -501,6 +501,10 @@ def sample(log_prob_func, params_init, num_samples=10, num_steps_per_sample=10, 
     # the reference's list of rows; long device-resident runs come back as a lazily materialised list (samplelist.py: the
     # 1001 view objects of a BASELINE-config-2 call cost more host time than its kernels take)
     rows = rows_of(samples, one)
+    _abi.free_scratch(256 << 20)                # (the ABI's caller-side scratch: buffers beyond 256 MiB do not outlive the call)
+    if not (verbose or debug == 2):
+        util._poll_status()                     # a status copy that has ALREADY completed is looked at here (no wait): a run that failed
+                                                # early is reported by the call that made it, not by the next one
     if verbose or debug == 2:
         acc = 1.0 - rejected.to(torch.float64) / float(num_samples)            # S:1085 / S:1089 (burn-in included)
         if samples.is_cuda:
@@ -686,20 +690,26 @@ class _GaussianHMC(_Engine):
 
 
 def _status_watch(tgt, ws, C, D, chunk, theta0):
-    """The status watch of a prepared workspace (util._StatusWatch), created once per workspace and kept with it on the target."""
-    cache = tgt.__dict__.setdefault("_hta_hmc_watch", {})
-    key = (ws.data_ptr(), int(chunk))
-    w = cache.get(key)
+    """The status watch of a prepared workspace (util._StatusWatch): created once per workspace and kept ON THE WORKSPACE'S HANDLE in
+    the target's cache entry, so that it is dropped with the workspace (the watch holds a view of it)."""
+    for hit in tgt.__dict__.get("_hta_hmc_ws", {}).values():
+        if hit[0].ws is ws:
+            handle = hit[0]
+            break
+    else:
+        return None
+    w = handle.watches.get(int(chunk))
     if w is None:
         word = _abi.hmc_gaussian_status_word(ws, C, D, chunk, theta0.element_size())
         if word is None:
             return None
-        if len(cache) >= 4:
-            cache.clear()
-        def forget(d=tgt.__dict__):      # reported: the flagged workspace goes, the next run prepares a fresh one (word zeroed)
-            d.pop("_hta_hmc_ws", None)
-            d.pop("_hta_hmc_watch", None)
-        w = cache[key] = util._watch_status(word, "hta_hmc_gaussian_sample (%d chains, D = %d)" % (C, D), forget)
+        d = weakref.ref(tgt)
+
+        def forget():      # reported: the flagged workspace goes, the next run prepares a fresh one (word zeroed)
+            t = d()
+            if t is not None:
+                t.__dict__.pop("_hta_hmc_ws", None)
+        w = handle.watches[int(chunk)] = util._watch_status(word, "hta_hmc_gaussian_sample (%d chains, D = %d)" % (C, D), forget)
     return w
 
 
@@ -708,6 +718,7 @@ class _HmcWorkspaceHandle:
 
     def __init__(self, ws):
         self.ws = ws
+        self.watches = {}          # chunk -> util._StatusWatch of this workspace's sticky status word
 
     def __del__(self):
         try:

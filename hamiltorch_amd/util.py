@@ -11,6 +11,7 @@ import os
 import random
 import sys
 import threading
+import weakref
 import time
 
 import numpy as np
@@ -103,11 +104,17 @@ class _StatusWatch:
     def __init__(self, word, what, on_error=None):
         self.word, self.what, self.on_error = word, what, on_error
         self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._event = None
 
     def refresh(self):
         self.host.copy_(self.word, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record(torch.cuda.current_stream(self.word.device))      # the copy is complete when this event is
 
     def landed(self):
+        """The word as of the last COMPLETED copy (0 while a copy is still in flight: the pinned int is not read under a write)."""
+        if self._event is not None and not self._event.query():
+            return 0
         return int(self.host[0])
 
     def error(self, value):
@@ -117,29 +124,30 @@ class _StatusWatch:
                                  "needs no co-residency." % (self.what, value))
 
 
-_watches = []
+# WEAK references: a watch keeps a view of its (up to 128 MiB) workspace; it lives exactly as long as the workspace's cache entry on
+# the target (samplers._prepared_hmc_workspace keeps the watch on the workspace's handle) - a dropped target frees both
+_watches = weakref.WeakSet()
 _watch_lock = threading.Lock()
 
 
 def _watch_status(word, what, on_error=None):
     """`on_error()` runs when the word is reported (the owner drops its prepared workspace: the next run prepares a fresh one, which
-    zeroes the word)."""
+    zeroes the word).  The caller owns the returned watch; this module only holds it weakly."""
     w = _StatusWatch(word, what, on_error)
     with _watch_lock:
-        _watches.append(w)
-        if len(_watches) > 64:          # workspaces come and go with their targets; a word that was fine for 64 newer ones stays fine
-            del _watches[0]
+        _watches.add(w)
     return w
 
 
 def _poll_status():
-    """Raise for any watched word whose last copy landed non-zero (no synchronisation)."""
-    for w in list(_watches):
+    """Raise for any live watched word whose last completed copy is non-zero (no synchronisation)."""
+    with _watch_lock:
+        live = list(_watches)
+    for w in live:
         v = w.landed()
         if v:
             with _watch_lock:
-                if w in _watches:
-                    _watches.remove(w)
+                _watches.discard(w)
             if w.on_error is not None:
                 w.on_error()
             raise w.error(v)
@@ -148,7 +156,9 @@ def _poll_status():
 def check_device_status(device=None):
     """Synchronise and raise DeviceStatusError if any kernel reported a failure since its workspace was prepared."""
     if torch.cuda.is_available():
-        for w in list(_watches):
+        with _watch_lock:
+            live = list(_watches)
+        for w in live:
             w.refresh()
         torch.cuda.synchronize(device)
     _poll_status()

@@ -2,7 +2,10 @@
 
 *** TEST / MEASUREMENT INFRASTRUCTURE ONLY *** (see oracle/hmc_oracle.py for the rules) - never imported by the product.
 
-    python oracle/cpu_baseline.py <workload> <seed> <seconds>      ->  one JSON line
+    python oracle/cpu_baseline.py <workload> <seed> <seconds> [<init.pt|-> <row> [<rounds>]]      ->  one JSON line per round
+
+(`init.pt`: a torch-saved [k, D] tensor; the chain starts from row `row` mod k instead of the workload's initial point - bench.py
+hands the device's burned-in states over so that both sides of an ESS comparison start inside the posterior.)
 
 SURVEY 8(d): "the unmodified reference from /root/reference (shim, no bytecode), same log_prob_func object, one chain per
 process, torch.set_num_threads(1), one process per usable host core".  When the reference is importable here
@@ -80,16 +83,19 @@ def funnel_ll(w, dim=10):
     return ll
 
 
-def build(workload, ref):
-    """(run(n) -> (samples list or None, acceptance), L, note): one chain of `workload` for n trajectories."""
+def build(workload, ref, start=None):
+    """(run(n) -> (samples list or None, acceptance), L, note): one chain of `workload` for n trajectories (from `start` if given)."""
     import torch_port as TP
+
+    def at(init):
+        return init if start is None else start.to(init.dtype).reshape(init.shape)
     if workload == "cfg2":
         L, eps = 25, 0.3
         cov = torch.tensor(SIGMA)
 
         def lp(w):
             return torch.distributions.MultivariateNormal(torch.zeros(3), cov).log_prob(w).sum()
-        init = torch.zeros(3)
+        init = at(torch.zeros(3))
         if ref:
             return (lambda n: ref.sample(lp, init, num_samples=n, num_steps_per_sample=L, step_size=eps, burn=-1, debug=2, verbose=False)), L, \
                 "hamiltorch.sample, HMC"
@@ -100,7 +106,7 @@ def build(workload, ref):
 
         def lp(w):
             return -0.5 * torch.dot(w, torch.mv(P, w))
-        init = 0.1 * torch.randn(100, generator=torch.Generator().manual_seed(0))
+        init = at(0.1 * torch.randn(100, generator=torch.Generator().manual_seed(0)))
         if ref:
             return (lambda n: ref.sample(lp, init, num_samples=n, num_steps_per_sample=L, step_size=eps, burn=-1, jitter=jitter,
                                          softabs_const=alpha, explicit_binding_const=omega, sampler=ref.Sampler.RMHMC,
@@ -109,6 +115,7 @@ def build(workload, ref):
         return (lambda n: TP.port_sample_rmhmc(lp, init, n, L, eps, omega, alpha, burn=-1, jitter=jitter)), L, "torch_port.port_sample_rmhmc"
     if workload in ("funnel-hmc", "funnel-rmhmc"):
         init = torch.ones(11); init[0] = 0.0
+        init = at(init)
         if workload == "funnel-hmc":                         # notebook cell 24
             L, eps = 25, 0.2
             if ref:
@@ -128,7 +135,7 @@ def build(workload, ref):
         X, Y = cfg4_data()
         torch.manual_seed(0)
         net = torch.nn.Sequential(torch.nn.Linear(8, 100), torch.nn.ReLU(), torch.nn.Linear(100, 1))
-        init = torch.cat([p.detach().flatten() for p in net.parameters()])
+        init = at(torch.cat([p.detach().flatten() for p in net.parameters()]))
         D = init.numel()
         if ref:
             loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(X, Y), batch_size=100, shuffle=False)
@@ -146,7 +153,7 @@ def build(workload, ref):
         # the same initial point as bench.py (its Sequential has the same parameter order and the same seed)
         torch.manual_seed(0)
         seq = torch.nn.Sequential(torch.nn.Linear(1, 100), torch.nn.ReLU(), torch.nn.Linear(100, 100), torch.nn.ReLU(), torch.nn.Linear(100, 1))
-        init = torch.cat([p.detach().flatten() for p in seq.parameters()])
+        init = at(torch.cat([p.detach().flatten() for p in seq.parameters()]))
         D = init.numel()
         tl = torch.ones(6)
         if ref:
@@ -168,32 +175,39 @@ def build(workload, ref):
 
 def main():
     workload, seed, seconds = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
+    rounds = int(sys.argv[6]) if len(sys.argv) > 6 else 1
     torch.set_num_threads(1)
     ref = load_reference()
-    run, L, note = build(workload, ref)
+    states = torch.load(sys.argv[4]) if len(sys.argv) > 5 and sys.argv[4] != "-" else None
     import warnings
     warnings.filterwarnings("ignore")
     # The notebooks ran on a torch whose distributions did not validate their arguments: a diverged trajectory handed NaN to
     # funnel_ll, got NaN back and was REJECTED (has_nan_or_inf -> LogProbError, S:783-785, S:1045).  Today's default raises a
     # ValueError inside log_prob instead, which the reference does not catch - its explicit-RMHMC funnel run would end the process.
     torch.distributions.Distribution.set_default_validate_args(False)
-    torch.manual_seed(seed)
-    if ref:
-        ref.set_random_seed(seed)
-    n0 = 20 if workload == "cfg2" else 1
-    run(n0)                                                       # the first call pays torch's lazy initialisation
-    t0 = time.time(); run(n0); dt0 = (time.time() - t0) / n0
-    n = max(40 if workload == "cfg2" else 1, int(seconds / max(dt0, 1e-6)))
-    t0 = time.time()
-    ret, acc = run(n)
-    dt = time.time() - t0
-    out = {"kind": "reference" if ref else "port", "impl": note, "n": n, "L": L, "dt": dt, "acc": float(acc)}
-    # the samples travel (first ESS_DIMS coordinates, 6 significant digits), for ESS / s with the estimator bench.py applies to the
-    # device samples (hamiltorch_amd/ess.py over the same coordinates); the reference's output is this list (S:1086-1091)
-    rows = torch.stack([r.detach().reshape(-1)[:ESS_DIMS] for r in ret[1:]])
-    out["ess_dims"] = int(rows.shape[1])
-    out["samples"] = [[float("%.6g" % v) for v in row] for row in rows.tolist()]
-    print(json.dumps(out))
+    dt0 = None
+    for rep in range(rounds):
+        # every round is a NEW chain: its own seed, its own start state (row + rep * stride of the device's burned-in states)
+        start = None if states is None else states[(int(sys.argv[5]) + 17 * rep) % states.shape[0]].clone()
+        run, L, note = build(workload, ref, start)
+        torch.manual_seed(seed + 97 * rep)
+        if ref:
+            ref.set_random_seed(seed + 97 * rep)
+        n0 = 20 if workload == "cfg2" else 1
+        if dt0 is None:
+            run(n0)                                                       # the first call pays torch's lazy initialisation
+            t0 = time.time(); run(n0); dt0 = (time.time() - t0) / n0
+        n = max(40 if workload == "cfg2" else 1, int(seconds / max(dt0, 1e-6)))
+        t0 = time.time()
+        ret, acc = run(n)
+        dt = time.time() - t0
+        out = {"kind": "reference" if ref else "port", "impl": note, "n": n, "L": L, "dt": dt, "acc": float(acc), "round": rep}
+        # the samples travel (first ESS_DIMS coordinates, 6 significant digits), for ESS / s with the estimator bench.py applies to the
+        # device samples (hamiltorch_amd/ess.py over the same coordinates); the reference's output is this list (S:1086-1091)
+        rows = torch.stack([r.detach().reshape(-1)[:ESS_DIMS] for r in ret[1:]])
+        out["ess_dims"] = int(rows.shape[1])
+        out["samples"] = [[float("%.6g" % v) for v in row] for row in rows.tolist()]
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -252,7 +252,11 @@ def test_drivers_eight_rank_command_line_prints_the_compact_line(ht, extra):
         # at 1024 chains per GPU on every rank - with the gather, so one scaling run yields both curves
         s5 = j["secondary"][0]
         assert s5["key"] == "cfg5" and s5["n_gpus"] == 8 and s5["ranks_seen"] == 8 and s5["gather_ms"] > 0 and s5["value"] > 0
-        assert s5["chains"] == 1024 and s5["kernel"].startswith("rmhmc_uvc2_kernel")
+        assert s5["chains"] == 1024 and s5["kernel"].startswith("rmhmc_uvc2")
+        # round 6: the STRONG-scaling form beside it - 8192 chains in all, 8192 / N per GPU
+        ss = j["secondary"][1]
+        assert ss["key"] == "cfg5-strong" and ss["scaling"] == "strong" and ss["chains_total"] == 8192 and ss["chains"] == 1024
+        assert ss["n_gpus"] == 8 and ss["value"] > 0
 
 
 _SHARD_WORKER = r'''
