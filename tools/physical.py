@@ -37,17 +37,17 @@ def main():
         dur, geom = collections.defaultdict(list), {}
         for r in rows(os.path.join(d, "stats"), "*kernel_trace.csv"):
             k = short(r["Kernel_Name"])
-            if "hta::" not in k:
+            if "hta::" not in k and not k.startswith("hta_cb"):          # (the library's kernels and the run-time compiled callback kernels)
                 continue
             dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
             wg = int(r["Workgroup_Size_X"]) * int(r.get("Workgroup_Size_Y", 1) or 1) * int(r.get("Workgroup_Size_Z", 1) or 1)
             gr = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
             geom[k] = (gr // max(1, wg), wg)
         ctr = collections.defaultdict(lambda: collections.defaultdict(list))
-        for sub in ("pmc_rd", "pmc_wr", "pmc_sq"):
+        for sub in ("pmc_rd", "pmc_wr", "pmc_sq", "pmc_valu"):
             for r in rows(os.path.join(d, sub), "*counter_collection.csv"):
                 k = short(r["Kernel_Name"])
-                if "hta::" in k:
+                if "hta::" in k or k.startswith("hta_cb"):
                     ctr[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         steps = meta["steps"] + meta["warmup"]
         kernels = {}
@@ -70,6 +70,9 @@ def main():
                 simd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * N_SIMDS           # the counter sums the 8 XCDs
                 rec["mfma_busy_frac_of_all_simd_cycles"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / simd_cycles
                 rec["mfma_tflops_issued"] = c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512.0 / (rec["ms_per_launch"] * 1e-3) / 1e12
+            if "SQ_INSTS_VALU" in c and c.get("SQ_WAVE_CYCLES", 0) > 0:      # the VALU kernels (compiled callbacks): optional fourth pass
+                rec["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / max(1.0, c.get("SQ_WAVES", waves))
+                rec["valu_active_frac_of_wave_cycles"] = c.get("SQ_ACTIVE_INST_VALU", 0.0) / c["SQ_WAVE_CYCLES"]
             kernels[k] = rec
             tot_ms += ms_per_step
         dom = next(iter(kernels))
@@ -80,6 +83,8 @@ def main():
                     "simds_occupied_frac": kernels[dom]["simds_occupied_frac"],
                     "mfma_busy_frac": kernels[dom].get("mfma_busy_frac_of_all_simd_cycles"),
                     "mfma_tflops_issued": kernels[dom].get("mfma_tflops_issued"),
+                    "valu_active_frac": kernels[dom].get("valu_active_frac_of_wave_cycles"),
+                    "valu_insts_per_wave": kernels[dom].get("valu_insts_per_wave"),
                     "kernels": kernels, "source": meta.get("source", "tools/physical.sh")}
     json.dump(out, sys.stdout, indent=1)
 

@@ -24,6 +24,9 @@ one() {  # key steps warmup traj env -- bench args
   env $envs timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $d/pmc_rd -o r -- $cmd > /dev/null 2>&1
   env $envs timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $d/pmc_wr -o w -- $cmd > /dev/null 2>&1
   env $envs timeout 120 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES GRBM_GUI_ACTIVE -f csv -d $d/pmc_sq -o q -- $cmd > /dev/null 2>&1
+  case $key in funnel*)      # the compiled-callback kernels are VALU code: instruction count and VALU-active share of the waves' cycles
+    env $envs timeout 120 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES -f csv -d $d/pmc_valu -o v -- $cmd > /dev/null 2>&1;;
+  esac
   cp $(find $d/stats -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_${key}_kernel_stats.csv 2> /dev/null
   echo "$key done ($(( $(date +%s) - t0 )) s)"
 }
@@ -34,6 +37,8 @@ one cfg3jacobi@256 3 1 20 HTA_RMHMC_FUSED=0 --workload cfg3 --traj 20
 one cfg4@512 10 2 20 X=1 --workload cfg4
 one nbmlp@1024 6 2 1 X=1 --workload nbmlp
 one nbmlp-full@1024 6 2 1 X=1 --workload nbmlp-full
+one funnel-hmc@1024 10 2 200 X=1 --workload funnel-hmc
+one funnel-rmhmc@1024 5 1 2 X=1 --workload funnel-rmhmc
 python tools/physical.py $KEYS > gpurun_out/${R}_physical_new.json
 python - <<P
 import json
