@@ -46,7 +46,8 @@ class HtaCbHmcArgs(ctypes.Structure):
     _fields_ = [("cur", c_vp), ("init", c_vp), ("inv_mass", c_vp), ("mass_factor", c_vp), ("samples", c_vp),
                 ("reject_count", c_vp), ("H_old", c_vp), ("H_new", c_vp), ("accept", c_vp), ("gcur", c_vp), ("lp_out", c_vp),
                 ("C", ctypes.c_longlong), ("eps", c_f64), ("seed", c_u64), ("chain_offset", c_u64), ("L", c_int),
-                ("n_traj", c_int), ("traj_offset", c_int), ("burn", c_int), ("resume", c_int), ("reserved", c_int)]
+                ("n_traj", c_int), ("traj_offset", c_int), ("burn", c_int), ("resume", c_int), ("reserved", c_int), ("pre", c_vp),
+                ("pre_bytes", ctypes.c_longlong)]
 
 
 class HtaCbRmhmcArgs(ctypes.Structure):
@@ -111,7 +112,7 @@ PLAIN_SYMBOLS = ["hta_abi_version", "hta_last_error", "hta_device_info", "hta_se
                  "hta_hmc_gaussian_workspace_bytes", "hta_rmhmc_workspace_bytes", "hta_hmc_gaussian_status_offset",
                  "hta_metric_eval_workspace_bytes", "hta_netn_hmc_workspace_bytes",
                  "hta_jit_available", "hta_jit_last_log", "hta_jit_note_fallback", "hta_jit_compile", "hta_jit_free", "hta_jit_load", "hta_jit_unload",
-                 "hta_jit_module_info", "hta_jit_hmc_workspace_bytes", "hta_jit_hmc_sample", "hta_jit_derivs",
+                 "hta_jit_module_info", "hta_jit_hmc_workspace_bytes", "hta_jit_hmc_predraw_bytes", "hta_jit_hmc_sample", "hta_jit_derivs",
                  "hta_jit_rmhmc_workspace_bytes", "hta_jit_rmhmc_sample"]
 TYPED_SYMBOLS = sorted(_sig(c_f32).keys())
 
@@ -171,6 +172,8 @@ def load():
         lib.hta_jit_module_info.argtypes = [c_vp, ctypes.POINTER(c_int)]
         lib.hta_jit_hmc_workspace_bytes.argtypes = [c_i64, c_int, c_int]
         lib.hta_jit_hmc_workspace_bytes.restype = c_i64
+        lib.hta_jit_hmc_predraw_bytes.argtypes = [c_i64, c_int, c_int, c_int]
+        lib.hta_jit_hmc_predraw_bytes.restype = c_i64
         lib.hta_jit_hmc_sample.argtypes = [c_vp, ctypes.POINTER(HtaCbHmcArgs), c_int, c_int, c_int, c_vp, c_i64, c_vp]
         lib.hta_jit_derivs.argtypes = [c_vp, ctypes.POINTER(HtaCbDerivArgs), c_int, c_int, c_int, c_vp]
         lib.hta_jit_rmhmc_workspace_bytes.argtypes = [c_i64, c_int, c_int]

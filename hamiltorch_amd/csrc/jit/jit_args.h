@@ -30,6 +30,9 @@ typedef struct HtaCbHmcArgs {
   int L, n_traj, traj_offset, burn;
   int resume;              /* 1: (log p, gradient) at `cur` are in the workspace from the previous launch of this run */
   int reserved;
+  void* pre;               /* NULL, or [n_traj, D + 1, C] pre-drawn records of this launch (momentum after the mass factor, log u):
+                              filled by hta_cb_predraw_kernel in front of the trajectory kernel (hta_jit_hmc_predraw_bytes)       */
+  long long pre_bytes;
 } HtaCbHmcArgs;
 
 typedef struct HtaCbRmhmcArgs {

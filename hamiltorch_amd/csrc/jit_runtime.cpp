@@ -65,7 +65,7 @@ thread_local std::string g_jit_log;
 
 struct Module {
   hipModule_t mod = nullptr;
-  hipFunction_t hmc = nullptr, derivs = nullptr, contract = nullptr, rmhmc = nullptr;
+  hipFunction_t hmc = nullptr, predraw = nullptr, derivs = nullptr, contract = nullptr, rmhmc = nullptr;
   int info[HTA_CB_INFO_WORDS] = {};
   int device = -1;
 };
@@ -84,10 +84,10 @@ int check_module(const Module* m, const char* who, int D, int itemsize, int mass
   return HTA_OK;
 }
 
-int launch(hipFunction_t fn, const char* who, int64_t C, void* args, size_t bytes, hipStream_t s) {
+int launch(hipFunction_t fn, const char* who, int64_t C, void* args, size_t bytes, hipStream_t s, unsigned block = 64) {
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
-  const unsigned grid = (unsigned)((C + 63) / 64);
-  hipError_t e = hipModuleLaunchKernel(fn, grid, 1, 1, 64, 1, 1, 0, s, nullptr, config);
+  const unsigned grid = (unsigned)((C + block - 1) / block);
+  hipError_t e = hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, s, nullptr, config);
   if (e != hipSuccess) {
     set_error("%s: launch failed: %s", who, hipGetErrorString(e));
     return HTA_ERR_LAUNCH;
@@ -182,6 +182,7 @@ int hta_jit_load(const void* code, int64_t bytes, void** module_out) {
   }
   if (m->info[4] == HTA_CB_SET_HMC) {
     e = hipModuleGetFunction(&m->hmc, m->mod, "hta_cb_hmc_kernel");
+    if (e == hipSuccess) e = hipModuleGetFunction(&m->predraw, m->mod, "hta_cb_predraw_kernel");
   } else if (m->info[4] == HTA_CB_SET_DERIVS) {
     e = hipModuleGetFunction(&m->derivs, m->mod, "hta_cb_derivs_kernel");
     if (e == hipSuccess) e = hipModuleGetFunction(&m->contract, m->mod, "hta_cb_contract_kernel");
@@ -220,6 +221,11 @@ int64_t hta_jit_hmc_workspace_bytes(int64_t C, int D, int itemsize) {
   return C * D * itemsize + C * itemsize;       // gcur[C, D] + lp_out[C]
 }
 
+int64_t hta_jit_hmc_predraw_bytes(int64_t C, int D, int n_traj, int itemsize) {
+  if (C <= 0 || D <= 0 || n_traj < 0 || (itemsize != 4 && itemsize != 8)) return -1;
+  return (int64_t)n_traj * (D + 1) * C * itemsize;      // [n_traj, D + 1, C]
+}
+
 int hta_jit_hmc_sample(void* module, const HtaCbHmcArgs* args, int D, int itemsize, int mass_kind, void* workspace,
                        int64_t workspace_bytes, void* stream) {
   using namespace hta;
@@ -231,14 +237,20 @@ int hta_jit_hmc_sample(void* module, const HtaCbHmcArgs* args, int D, int itemsi
   HTA_REQUIRE(workspace && workspace_bytes >= hta_jit_hmc_workspace_bytes(args->C, D, itemsize),
               "hta_jit_hmc_sample: workspace of %lld bytes, %lld needed (hta_jit_hmc_workspace_bytes)", (long long)workspace_bytes,
               (long long)hta_jit_hmc_workspace_bytes(args->C, D, itemsize));
+  HTA_REQUIRE(!args->pre || args->pre_bytes >= hta_jit_hmc_predraw_bytes(args->C, D, args->n_traj, itemsize),
+              "hta_jit_hmc_sample: pre-draw buffer of %lld bytes, %lld needed (hta_jit_hmc_predraw_bytes)", (long long)args->pre_bytes,
+              (long long)hta_jit_hmc_predraw_bytes(args->C, D, args->n_traj, itemsize));
   if (args->n_traj == 0) return HTA_OK;
   HtaCbHmcArgs a = *args;
   a.resume = args->resume ? 1 : 0;
   a.gcur = workspace;
   a.lp_out = (char*)workspace + args->C * D * itemsize;
-  note_route("hta_cb_hmc_kernel<D=%d,%s,mass=%d,nodes=%d>", D, itemsize == 4 ? "f32" : "f64", mass_kind, m->info[5]);
+  note_route("hta_cb_hmc_kernel<D=%d,%s,mass=%d,nodes=%d%s>", D, itemsize == 4 ? "f32" : "f64", mass_kind, m->info[5],
+             a.pre ? ",predrawn" : "");
   profile_begin((hipStream_t)stream);
-  const int rc = launch(m->hmc, "hta_jit_hmc_sample", a.C, &a, sizeof(a), (hipStream_t)stream);
+  int rc = HTA_OK;
+  if (a.pre) rc = launch(m->predraw, "hta_jit_hmc_sample (pre-draw)", a.C * (int64_t)a.n_traj, &a, sizeof(a), (hipStream_t)stream, 256);
+  if (rc == HTA_OK) rc = launch(m->hmc, "hta_jit_hmc_sample", a.C, &a, sizeof(a), (hipStream_t)stream);
   profile_end((hipStream_t)stream);
   return rc;
 }

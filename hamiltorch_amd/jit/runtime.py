@@ -152,12 +152,16 @@ def hmc_generated_source(traced, dtype, mass_kind):
     return emit.value_grad_source(traced.graph, traced.value, grads, dtype_name(dtype), mass_kind)
 
 
+def hmc_predraw_bytes(C, D, n_traj, itemsize):
+    return int(_abi.load().hta_jit_hmc_predraw_bytes(int(C), int(D), int(n_traj), int(itemsize)))
+
+
 def hmc_workspace_bytes(C, D, itemsize):
     return int(_abi.load().hta_jit_hmc_workspace_bytes(int(C), int(D), int(itemsize)))
 
 
 def hmc_sample(module, cur, init, mass_kind, inv_mass, mass_factor, L, eps, n_traj, traj_offset, burn, seed, chain_offset,
-               samples, reject_count, workspace, H_old=None, H_new=None, accept=None, resume=False):
+               samples, reject_count, workspace, H_old=None, H_new=None, accept=None, resume=False, pre=None):
     """hta_jit_hmc_sample: trajectories [traj_offset, traj_offset + n_traj) on the compiled callback, one launch."""
     _abi.require_device(cur, "params")
     C, D = cur.shape
@@ -173,6 +177,8 @@ def hmc_sample(module, cur, init, mass_kind, inv_mass, mass_factor, L, eps, n_tr
     a.C, a.eps, a.seed, a.chain_offset = C, float(eps), int(seed) & 0xFFFFFFFFFFFFFFFF, int(chain_offset)
     a.L, a.n_traj, a.traj_offset, a.burn = int(L), int(n_traj), int(traj_offset), int(burn)
     a.resume = 1 if resume else 0
+    if pre is not None:
+        a.pre, a.pre_bytes = pre.data_ptr(), pre.numel() * pre.element_size()
     with torch.cuda.device(cur.device):
         _abi._check(_abi.load().hta_jit_hmc_sample(module.handle, ctypes.byref(a), D, cur.element_size(), int(mass_kind),
                                                    workspace.data_ptr(), workspace.numel() * workspace.element_size(),

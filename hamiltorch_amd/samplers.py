@@ -777,6 +777,9 @@ class _CompiledHMC(_Engine):
     trajectories per launch - momentum draw, leapfrog with the callable's value + gradient inlined, energies, Metropolis, burn /
     Q2 bookkeeping and row stores in one kernel, one chain per lane."""
 
+    PREDRAW_MAX_CHAINS = 16384
+    PREDRAW_CAP = 64 << 20          # bytes of pre-drawn records per launch (longer runs are cut into several launches)
+
     def __init__(self, fn, compiled, reused=False):
         self.fn, self.comp, self.reused = fn, compiled, reused
 
@@ -787,15 +790,28 @@ class _CompiledHMC(_Engine):
         self.module = self.comp.module(theta0.device)
         self.ws = torch.empty(runtime.hmc_workspace_bytes(C, D, theta0.element_size()), dtype=torch.uint8, device=theta0.device)
         self._ran = False
+        # few chains = few waves (1024 chains: 16 of 1024 SIMDs hold one): the draws of a launch are then produced by a kernel of their
+        # own that uses the whole GPU, and the trajectory kernel reads them (csrc/jit/hmc_callback.hip.in: hta_cb_predraw_kernel);
+        # from PREDRAW_MAX_CHAINS on the chains fill the machine themselves and draw in the lane.  Bit-identical either way.
+        self._predraw = C <= self.PREDRAW_MAX_CHAINS and os.environ.get("HAMILTORCH_AMD_JIT_PREDRAW", "1") != "0"
+        self._pre = None
 
     def advance(self, n0, count, L, eps, H_old=None, H_new=None, progress=None):
         from .jit import runtime
         # one launch per block of trajectories; a visible progress bar cuts the run into ~20 launches so that it moves
         chunk = 1 if H_old is not None else (max(1, -(-count // 20)) if (progress is not None and progress.enabled) else count)
+        C, D = self.cur.shape
+        if self._predraw:
+            per = runtime.hmc_predraw_bytes(C, D, 1, self.cur.element_size())
+            chunk = max(1, min(chunk, self.PREDRAW_CAP // per))
+            need = per * min(chunk, count)
+            if self._pre is None or self._pre.numel() < need:
+                self._pre = torch.empty(need, dtype=torch.uint8, device=self.cur.device)
         for start in range(n0, n0 + count, chunk):
             k = min(chunk, n0 + count - start)
             runtime.hmc_sample(self.module, self.cur, self.theta0, self.kind, self.im, self.mf, L, eps, k, start, self.burn,
-                               self.seed, self.off, self.samples, self.rejected, self.ws, H_old, H_new, resume=self._ran)
+                               self.seed, self.off, self.samples, self.rejected, self.ws, H_old, H_new, resume=self._ran,
+                               pre=self._pre if self._predraw else None)
             self._ran = True
             if progress is not None:
                 progress.update(min(self.N, start + k) - 1)

@@ -450,6 +450,9 @@ int hta_jit_load(const void* code, int64_t bytes, void** module_out);
 int hta_jit_unload(void* module);
 int hta_jit_module_info(void* module, int* info_out);
 int64_t hta_jit_hmc_workspace_bytes(int64_t C, int D, int itemsize);
+/* bytes of HtaCbHmcArgs::pre for a launch of n_traj trajectories: with it the launch's momentum draws and log-uniforms are produced by a
+ * kernel of their own in front of the trajectory kernel (the whole GPU instead of the chains' few waves; bit-identical results) */
+int64_t hta_jit_hmc_predraw_bytes(int64_t C, int D, int n_traj, int itemsize);
 int hta_jit_hmc_sample(void* module, const HtaCbHmcArgs* args, int D, int itemsize, int mass_kind, void* workspace,
                        int64_t workspace_bytes, void* stream);
 int hta_jit_derivs(void* module, const HtaCbDerivArgs* args, int which, int D, int itemsize, void* stream);

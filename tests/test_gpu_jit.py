@@ -352,3 +352,25 @@ def test_fused_rmhmc_kernel_equals_the_launch_sequence(ht, monkeypatch):
     assert "hta_cb_rmhmc_kernel" not in route()
     err = (a - b).abs().amax(dim=(0, 2))
     assert float((err > 1e-6).double().mean()) <= 0.1, float(err.max())
+
+
+def test_predrawn_records_equal_the_in_lane_draw(ht, monkeypatch):
+    """With few chains the launch's momentum draws and log-uniforms come from hta_cb_predraw_kernel (the whole GPU) and the trajectory kernel
+    reads them a trajectory ahead; HAMILTORCH_AMD_JIT_PREDRAW=0 draws in the lane.  Same generator and formulas: a run cut into launches by a
+    small record cap is BIT-IDENTICAL to the one-launch run; against the in-lane draw the chains agree to rounding (there the compiler may fuse
+    the draw's last multiplication into the first half kick: one rounding fewer) - float64, full mass matrix, burn-in, 200 chains."""
+    from hamiltorch_amd import samplers
+    D = 11
+    th0 = tt(start(200, D, 4, torch.float64), torch.float64)
+    im = tt(masses(D, torch.float64)["full"], torch.float64)
+    kw = dict(num_samples=30, num_steps_per_sample=6, step_size=0.1, burn=3, inv_mass=im, debug=2, verbose=False, seed=17)
+    a, acc_a = ht.sample(funnel_device, th0, **kw)
+    assert ",predrawn>" in route(), route()
+    monkeypatch.setattr(samplers._CompiledHMC, "PREDRAW_CAP", 7 * 200 * (D + 1) * 8)          # 7 trajectories per launch
+    c, acc_c = ht.sample(funnel_device, th0, **kw)
+    assert torch.equal(torch.stack(list(a)), torch.stack(list(c))) and torch.equal(acc_a, acc_c)
+    monkeypatch.setenv("HAMILTORCH_AMD_JIT_PREDRAW", "0")
+    b, acc_b = ht.sample(funnel_device, th0, **kw)
+    assert "hta_cb_hmc_kernel" in route() and "predrawn" not in route()
+    bad = compare(a, [x.cpu().numpy() for x in b], 1e-9, 0.02)
+    assert torch.equal(acc_a.cpu()[~bad], acc_b.cpu()[~bad])
