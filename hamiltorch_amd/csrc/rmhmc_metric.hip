@@ -41,11 +41,7 @@ __global__ __launch_bounds__(MT) void metric_eval_kernel(MetricArgsT<T> a, int n
     const int64_t slab = ((int64_t)D * ldv + (int64_t)ne * lda + 3) & ~(int64_t)3;
     V = vws + (int64_t)blockIdx.x * slab; V0s = reinterpret_cast<T*>(smem_raw);
   } else if constexpr (VG) {
-    // (D * ldv is a multiple of 16 bytes.  Written exactly like this on purpose: with the slab size in a variable rounded as above - the
-    //  same number - the float64 instance <4, 3, true, false> came out of hipcc 7.2 with its work-matrix accesses of the G / Cholesky
-    //  phases going to the wrong memory (lam, V, x right; G, L garbage: tools/history/r05d.py, bisected against round 4's build).  The
-    //  instance spills 97 VGPRs / 215 SGPRs under its 128-register cap; tests/test_gpu_rmhmc.py::test_metric_eval_vs_oracle[100-*-float64]
-    //  and ::test_metric_eval_beyond_the_round_4_size_limits pin both instances' outputs one by one.)
+    // (D * ldv is a multiple of 16 bytes.  float32 only since round 6: metric_geometry sends float64 past this instance - see there.)
     V = vws + (int64_t)blockIdx.x * D * ldv; V0s = reinterpret_cast<T*>(smem_raw);
   }
   else { V = reinterpret_cast<T*>(smem_raw); V0s = V + D * ldv; }
@@ -368,7 +364,13 @@ static MetricGeom metric_geometry(int D, int elem, bool warm) {
   // per-thread work-list lengths of the Jacobi rounds (register arrays): 2/2 up to D ~ 126, 4/3 up to ~156 fp32 / 110 fp64, 8/8 beyond
   g.small = NP * (NP + 1) / 2 <= 2 * MT && NP * nv <= 2 * MT;
   const bool mid = NP * (NP + 1) / 2 <= 4 * MT && NP * nv <= 3 * MT;
-  if (g.lds > 160 * 1024 || !mid) {                // the work matrix moves out as well; the instance with the long work lists
+  // float64 never runs on the VT-only-in-global instance <4, 3, true, false> (round 6): that instance - 97 VGPR / 215 SGPR spills under its
+  // 128-register cap - came out of hipcc 7.2 with wrong G / Cholesky accesses whenever its slab offset was spelled through a rounded
+  // variable (round 5, bisected, never root-caused: tools/history/r05d.py).  A kernel whose correctness depends on the spelling of an
+  // address expression is not kept in service: the sizes it served (fp64, D = 100 ... 110) take the instance with both matrices in the
+  // slab, which tests/test_gpu_rmhmc.py pins at D = 100, 101, 128 and 200 against the float64 oracle.
+  const bool retire_vg64 = g.vglobal && elem == 8;
+  if (g.lds > 160 * 1024 || !mid || retire_vg64) {  // the work matrix moves out as well; the instance with the long work lists
     g.dyn = !(NP * (NP + 1) / 2 <= 8 * MT && NP * nv <= 8 * MT);      // beyond the longest register lists: the run-time work lists
     if (g.dyn && D > MT) { g.lds = 0; return g; }                      // (the kernel's own row batches: D <= MT)
     g.lda = ne + 1;
