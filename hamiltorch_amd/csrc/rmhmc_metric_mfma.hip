@@ -32,6 +32,15 @@
 // Matrix-vector products (V0^T m, X^T m', X w, V0 x', P d) use all 1024 threads: 8 lanes per row, DPP-free shuffles.
 #include "rmhmc_metric_dev.hpp"
 
+// The phase functions are real calls (s_swappc) by default: inlined, the trajectory kernel's body no longer fits the instruction cache a
+// lone workgroup per CU has to itself and its register allocation degrades.  -DHTA_PH_INLINE=1 builds the all-inlined variant (the A/B of
+// profiles/r06e_metric_inline_ab.txt).
+#if defined(HTA_PH_INLINE) && HTA_PH_INLINE
+#define HTA_PH_ATTR __forceinline__
+#else
+#define HTA_PH_ATTR __attribute__((noinline))
+#endif
+
 namespace hta {
 
 int g_metric_mfma = 1;   // tuning key "metric_mfma": 1 = warm fp32 evaluations run here, 0 = always the Jacobi kernel
@@ -201,7 +210,7 @@ __device__ __forceinline__ void gemm_macro(const float* pa0, const float* pb0, c
 // LDC: the leading dimension as a compile-time constant (0: the run-time value) - with it the four rows of a chunk's operand
 // reads are immediate offsets of one address register instead of an address computation per read
 template <bool TA, bool TB, bool SYM, bool SCALE, int LDC>
-__device__ __attribute__((noinline)) void lds_gemm_ld(int offA, int offB, int offC, int offCinit, int offScale, int nt, int k4, int LDr) {
+__device__ HTA_PH_ATTR void lds_gemm_ld(int offA, int offB, int offC, int offCinit, int offScale, int nt, int k4, int LDr) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* const lds = reinterpret_cast<float*>(smem_raw);
   nt = __builtin_amdgcn_readfirstlane(nt); k4 = __builtin_amdgcn_readfirstlane(k4);
@@ -446,7 +455,7 @@ __device__ __forceinline__ float lane_bcast(float x, int lane) {       // v_read
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
 }
 
-__device__ __attribute__((noinline)) void mfma_cholesky(int offG, int D, int DP, int LD, int offW) {
+__device__ HTA_PH_ATTR void mfma_cholesky(int offG, int D, int DP, int LD, int offW) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* const G = reinterpret_cast<float*>(smem_raw) + __builtin_amdgcn_readfirstlane(offG);
   float* const W = reinterpret_cast<float*>(smem_raw) + __builtin_amdgcn_readfirstlane(offW);
@@ -540,19 +549,19 @@ typedef const __attribute__((address_space(1))) float* gcf;
 #define HTA_LDS_BASE() extern __shared__ __attribute__((aligned(16))) char smem_raw[]; float* const lds = reinterpret_cast<float*>(smem_raw)
 #define HTA_U(x) __builtin_amdgcn_readfirstlane(x)
 
-__device__ __attribute__((noinline)) void jacobi_fallback(int offA, int offVT, int D, int ne, int LD, int offCs, int offRed, int max_sweeps) {
+__device__ HTA_PH_ATTR void jacobi_fallback(int offA, int offVT, int D, int ne, int LD, int offCs, int offRed, int max_sweeps) {
   HTA_LDS_BASE();
   D = HTA_U(D); ne = HTA_U(ne); LD = HTA_U(LD); max_sweeps = HTA_U(max_sweeps);
   lds_jacobi<float, 2, 2>(lds + HTA_U(offA), lds + HTA_U(offVT), D, ne, LD, LD, lds + HTA_U(offCs), nullptr, lds + HTA_U(offRed), max_sweeps);
 }
 
-__device__ __attribute__((noinline)) void ph_stage(const float* src, int offDst, int D, int DP, int LD) {
+__device__ HTA_PH_ATTR void ph_stage(const float* src, int offDst, int D, int DP, int LD) {
   HTA_LDS_BASE();
   stage_dense((gcf)src, lds + HTA_U(offDst), HTA_U(D), HTA_U(DP), HTA_U(LD));
 }
 
 // sum_i d_i (P d)_i over the block, upd_g += cg P d  (d in LDS at offVd; P symmetric, global)
-__device__ __attribute__((noinline)) float ph_logp(const float* P, int offVd, int D, int offPart, int offRed, float* upd_g, float cg) {
+__device__ HTA_PH_ATTR float ph_logp(const float* P, int offVd, int D, int offPart, int offRed, float* upd_g, float cg) {
   HTA_LDS_BASE();
   D = HTA_U(D);
   const float* vd = lds + HTA_U(offVd);
@@ -566,7 +575,7 @@ __device__ __attribute__((noinline)) float ph_logp(const float* P, int offVd, in
 }
 
 // M (or M^T) v with M [n][ld] and v in LDS; every lane of row (tid >> 3)'s group of 8 returns the row's sum
-__device__ __attribute__((noinline)) float ph_mv8(int trans, int offM, int ld, int offV, int n) {
+__device__ HTA_PH_ATTR float ph_mv8(int trans, int offM, int ld, int offV, int n) {
   HTA_LDS_BASE();
   ld = HTA_U(ld); n = HTA_U(n);
   const float* M = lds + HTA_U(offM); const float* v = lds + HTA_U(offV);
@@ -575,7 +584,7 @@ __device__ __attribute__((noinline)) float ph_mv8(int trans, int offM, int ld, i
 
 // One pass of the refinement's element-wise step: lam_i = S_ii / Gm_ii, then E from S (at offS) and Gm (at offG; the
 // identity when have_x == 0) into offDst (which may be offS).  Returns max |E_ij|, i != j (1 for NaN / inf / > kFallbackE).
-__device__ __attribute__((noinline)) float ph_refine_E(int offS, int offG, int offDst, int offLam, int offRed, int have_x, int D, int LD) {
+__device__ HTA_PH_ATTR float ph_refine_E(int offS, int offG, int offDst, int offLam, int offRed, int have_x, int D, int LD) {
   HTA_LDS_BASE();
   D = HTA_U(D); LD = HTA_U(LD); have_x = HTA_U(have_x);
   const float* by = lds + HTA_U(offS); const float* bz = lds + HTA_U(offG);
@@ -631,7 +640,7 @@ __device__ __attribute__((noinline)) float ph_refine_E(int offS, int offG, int o
 // (2.1 full products), with E2_ij = M_ij / (lam_j' - lam_i'), E2_ii = -1/2 sum_k E1_ki^2.  The caller zeroed the diagonals of A and
 // X before the product; this pass reads M (offM) and E1 (offX, whose unit diagonal it restores), writes E2 to offDst, E2^T in M's
 // place (a pair owns its two entries of M: the solve then reads both E2 and E2^T row-wise) and the corrected eigenvalues to offLam.  Returns max |E2_ij| (1 for NaN / inf / > kFallbackE).  Truncation: |A X2 - X2 Lam'| ~ |F| d^2.
-__device__ __attribute__((noinline)) float ph_refine_E2(int offM, int offX, int offDst, int offLam, int offRed, int D, int LD) {
+__device__ HTA_PH_ATTR float ph_refine_E2(int offM, int offX, int offDst, int offLam, int offRed, int D, int LD) {
   HTA_LDS_BASE();
   D = HTA_U(D); LD = HTA_U(LD);
   float* M = lds + HTA_U(offM); float* X = lds + HTA_U(offX);
@@ -688,19 +697,19 @@ __device__ __attribute__((noinline)) float ph_refine_E2(int offM, int offX, int 
   return block_max(emax, red);
 }
 
-__device__ __attribute__((noinline)) void ph_chol_solve(int offG, int D, int LD, int offV) {
+__device__ HTA_PH_ATTR void ph_chol_solve(int offG, int D, int LD, int offV) {
   HTA_LDS_BASE();
   lds_chol_solve<float>(lds + HTA_U(offG), HTA_U(D), HTA_U(LD), lds + HTA_U(offV));
 }
 
-__device__ __attribute__((noinline)) float ph_mv8_lower(int offM, int ld, int offV, int n) {
+__device__ HTA_PH_ATTR float ph_mv8_lower(int offM, int ld, int offV, int n) {
   HTA_LDS_BASE();
   return mv8_lower(lds + HTA_U(offM), HTA_U(ld), lds + HTA_U(offV), HTA_U(n));
 }
 
 // a zero-padded [DP][LD] copy of the symmetric matrix whose LOWER triangle is in global memory (eigh UPLO = 'L', S:119), jitter
 // (LDS vector at offJit) added on the diagonal
-__device__ __attribute__((noinline)) void ph_stage_sym(const float* src, int offDst, int offJit, int D, int DP, int LD) {
+__device__ HTA_PH_ATTR void ph_stage_sym(const float* src, int offDst, int offJit, int D, int DP, int LD) {
   HTA_LDS_BASE();
   D = HTA_U(D); DP = HTA_U(DP); LD = HTA_U(LD);
   float* dst = lds + HTA_U(offDst); const float* vj = lds + HTA_U(offJit);
@@ -721,7 +730,7 @@ __device__ __attribute__((noinline)) void ph_stage_sym(const float* src, int off
 }
 
 // [D][D] row-major global <- the leading block of an LDS matrix
-__device__ __attribute__((noinline)) void ph_store_dense(float* dstg, int offSrc, int D, int LD) {
+__device__ HTA_PH_ATTR void ph_store_dense(float* dstg, int offSrc, int D, int LD) {
   HTA_LDS_BASE();
   D = HTA_U(D); LD = HTA_U(LD);
   const float* src = lds + HTA_U(offSrc);
@@ -733,7 +742,7 @@ __device__ __attribute__((noinline)) void ph_store_dense(float* dstg, int offSrc
 
 // W of the derivative matrix M = Q W Q^T (HtaMetricArgs::dmetric_out; the same formula as metric_eval_kernel):
 // W_kl = 1/2 [k == l] lam~'_k / lam~_k - 1/2 J_kl u_k u_l,  J = divided differences of lam -> lam~, zero padded
-__device__ __attribute__((noinline)) void ph_dmetric_w(int offDst, int offLam, int offLt, int offU, float alpha, int D, int DP, int LD) {
+__device__ HTA_PH_ATTR void ph_dmetric_w(int offDst, int offLam, int offLt, int offU, float alpha, int D, int DP, int LD) {
   HTA_LDS_BASE();
   D = HTA_U(D); DP = HTA_U(DP); LD = HTA_U(LD);
   float* dst = lds + HTA_U(offDst);
