@@ -130,6 +130,7 @@ def _compile(fn, example, dtype, mass_kind, fresh):
     try:
         traced = trace_callback(fn, example)
         stats["traced"] += 1
+        _check_against_autograd(traced, fn, example)
         if mass_kind == "derivs":
             key, blob = runtime.compile_source(runtime.derivs_generated_source(traced, dtype), runtime.SKELETON_DERIVS)
             out = CompiledDerivs(traced, key, blob, dtype, mass_kind)
@@ -143,6 +144,13 @@ def _compile(fn, example, dtype, mass_kind, fresh):
         stats["unsupported"] += 1
         _note(str(e))
         out = e
+    except runtime.CompileError as e:
+        # hipRTC turned the generated text down (an emitter bug, a device function hipRTC lacks): not the user's problem - the callable
+        # runs on the previous path, the reason (the compiler's first error line) is reported like any other refusal
+        stats["unsupported"] += 1
+        first = next((ln for ln in e.log.splitlines() if "error" in ln), str(e).splitlines()[0])
+        out = Unsupported("hipRTC rejected the generated code: %s" % first.strip()[:160])
+        _note(str(out))
     if sig is not None:
         try:
             with _lock:
@@ -152,6 +160,35 @@ def _compile(fn, example, dtype, mass_kind, fresh):
     if isinstance(out, Unsupported):
         raise out
     return out
+
+
+def _check_against_autograd(traced, fn, example, points=4):
+    """A fresh trace is believed only after its VALUE AND GRADIENT (the graph's own reverse mode, evaluated in numpy) reproduce the callable
+    under torch.autograd at a few points around the example.  The trace records operations, not autograd semantics: a `torch.no_grad()`
+    block, a custom `autograd.Function` backward or a gradient hook inside the callable would compile to the derivative of what is
+    COMPUTED, not to what autograd returns - such callables are refused here (the run-time check of sample() compares values only)."""
+    import numpy as np
+    g = torch.Generator(device="cpu").manual_seed(0x5EED)
+    base = example.detach().double().cpu()
+    pts = torch.cat([base[None], base[None] + 0.05 * (1.0 + base.abs())[None] * torch.randn(points - 1, base.numel(), generator=g, dtype=torch.float64)])
+    grads = traced.grad()
+    mine = traced.graph.evaluate([traced.value] + grads, pts.numpy(), np.float64)
+    tol = 2e-3 if example.dtype == torch.float32 else 1e-7
+    for k in range(pts.shape[0]):
+        x = pts[k].to(device=example.device, dtype=example.dtype).requires_grad_(True)
+        try:
+            with torch.enable_grad():
+                v = fn(x)
+                v = v.sum() if v.dim() else v
+                gr, = torch.autograd.grad(v, x, allow_unused=True)
+        except Exception as e:
+            raise Unsupported("autograd of the callable failed at a check point (%s)" % str(e).split("\n")[0][:100]) from None
+        ref = np.concatenate([[float(v)], (torch.zeros_like(x) if gr is None else gr).detach().double().cpu().numpy()])
+        if not np.all(np.isfinite(ref)) or not np.all(np.isfinite(mine[k])):
+            continue
+        if np.abs(mine[k] - ref).max() > tol * (1.0 + np.abs(ref).max()):
+            raise Unsupported("the traced graph's value / gradient disagree with torch.autograd at a check point (max difference %.3g): "
+                              "a no_grad block, a custom backward or a hook inside the callable?" % np.abs(mine[k] - ref).max())
 
 
 def torch_logp(fn, theta):

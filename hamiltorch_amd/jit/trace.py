@@ -267,10 +267,17 @@ def _build_table():
         return out
 
     # ---- identities / dtype / copies ----------------------------------------------------------------------------
-    @reg(*_ov("clone"), *_ov("detach"), *_ov("alias"), *_ov("lift_fresh_copy"), *_ov("lift_fresh"), *_ov("contiguous"),
-         *_ov("detach_"), *_ov("positive"), *_ov("view_as_real"), *_ov("alias_copy"), *_ov("detach_copy"), *_ov("_conj"), *_ov("conj"),
+    @reg(*_ov("clone"), *_ov("alias"), *_ov("lift_fresh_copy"), *_ov("lift_fresh"), *_ov("contiguous"),
+         *_ov("positive"), *_ov("view_as_real"), *_ov("alias_copy"), *_ov("_conj"), *_ov("conj"),
          *_ov("resolve_conj"), *_ov("resolve_neg"))
     def _identity(L, x, *a, **k):
+        return x
+
+    @reg(*_ov("detach"), *_ov("detach_"), *_ov("detach_copy"))
+    def _detach(L, x):
+        """`w.detach()` inside the callable: the value flows on, the derivative does not (ir.py's 'detach' node)."""
+        if isinstance(x, TV) and x.kind == "f" and x.concrete is None:
+            return L.un("detach", x)
         return x
 
     @reg(*_ov("_to_copy"), *_ov("to", "dtype", "dtype_layout", "device", "other"), *_ov("type_as"))

@@ -76,13 +76,17 @@ def gathers(w):
     return -(w[idx] * w[[1, 1, 3]]).sum() ** 2 - torch.cumsum(w, 0).pow(2).mean() - (m.t() @ m).diagonal().sum() - torch.stack([w, 2 * w]).std()
 
 
+def stopgrad(w):            # detach() stops the derivative, not the value
+    return -(w * w.detach()).sum() - torch.exp(w[0]).detach() * w[1] ** 2
+
+
 def linear_layer(w):
     lin = torch.nn.functional.linear(w[:4].reshape(2, 2), _A[:3, :2], _A[:3, 4])
     return -lin.pow(2).sum() - torch.nn.functional.gelu(w).sum() - torch.erf(w[4]) - torch.nn.functional.silu(w[0])
 
 
 ZOO = [(funnel, 6), (funnel_dist, 6), (logistic, 5), (mixture, 5), (student, 5), (piecewise, 5), (inplace, 5), (gathers, 5),
-       (linear_layer, 5)]
+       (linear_layer, 5), (stopgrad, 5)]
 
 
 def autograd_reference(fn, pts, order):
@@ -191,6 +195,38 @@ def test_what_cannot_be_compiled_says_why():
         assert frag in str(e.value), (fn.__name__, str(e.value))
     with pytest.raises(Unsupported, match="registers"):
         runtime.hmc_generated_source(trace_callback(lambda w: -(w * w).sum(), torch.ones(200)), torch.float32, 0)
+
+
+def test_callables_whose_autograd_differs_from_their_operations_are_refused():
+    """A trace records what is COMPUTED; torch.no_grad() / a custom backward change what autograd RETURNS.  compile_hmc checks every fresh
+    trace's value and gradient against torch.autograd around the example and refuses such callables (they stay on the callback path)."""
+    def nograd_scale(w):
+        with torch.no_grad():
+            s = (w * w).sum()
+        return -s * (w * w).sum()
+
+    class Clip(torch.autograd.Function):
+        @staticmethod
+        def forward(x):
+            return x * 2.0
+
+        @staticmethod
+        def setup_context(ctx, inputs, output):
+            pass
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 0.5          # not the derivative of forward
+
+    def custom(w):
+        return -(Clip.apply(w) ** 2).sum()
+
+    ex = torch.ones(3)
+    with pytest.raises(Unsupported, match="disagree with torch.autograd"):
+        compile_hmc(nograd_scale, ex, torch.float32, 0)
+    with pytest.raises(Unsupported):                         # (a custom Function does not even trace: torch has no functionalisation rule for it)
+        compile_hmc(custom, ex, torch.float32, 0)
+    compile_hmc(stopgrad, torch.ones(5), torch.float32, 0)          # detach() itself is understood
 
 
 def _symbols(blob, tmp_path):
