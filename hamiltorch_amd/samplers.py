@@ -777,8 +777,9 @@ class _CompiledHMC(_Engine):
     trajectories per launch - momentum draw, leapfrog with the callable's value + gradient inlined, energies, Metropolis, burn /
     Q2 bookkeeping and row stores in one kernel, one chain per lane."""
 
-    PREDRAW_MAX_CHAINS = 16384
-    PREDRAW_CAP = 64 << 20          # bytes of pre-drawn records per launch (longer runs are cut into several launches)
+    PREDRAW_MAX_CHAINS = 131072     # (tools/jit_sweep.py: with the draws produced apart 16 384 chains run at 2.3e11 chain-steps/s, the in-lane
+                                    #  draw reaches that only from 262 144 chains on - two and more waves per SIMD)
+    PREDRAW_CAP = 128 << 20         # bytes of pre-drawn records per launch (longer runs are cut into several launches); inside the 256 MB Infinity Cache
 
     def __init__(self, fn, compiled, reused=False):
         self.fn, self.comp, self.reused = fn, compiled, reused
