@@ -267,10 +267,12 @@ def secondary(dev, a):
             (Cfg3, {"jacobi": True, "traj": 20}, 10, 1, False), (Cfg4, {}, 10, 2, True), (NbMlp, {}, 10, 1, True), (NbMlpFull, {}, 10, 1, True)]
     cpu_cache = {}
     for W, kw, steps, warmup, want_cpu in plan:
+        t_w = time.perf_counter()
         try:
             w = W(dev, None, kw.get("traj"), 0, **{k: v for k, v in kw.items() if k != "traj"})
             dt, call_ms, prof_ms, prof_n = measure(w, steps, warmup, 1, None, dev, 1)
             r = result_of(w, W, dt, call_ms, prof_ms, prof_n, steps, warmup, 1)
+            t_parts = {"measure+ess": time.perf_counter() - t_w}
             if getattr(w, "jacobi", False):
                 r["workload"] = w.name
                 r["config"]["workload"] = w.name
@@ -310,6 +312,7 @@ def secondary(dev, a):
                             r["ess_ratio_withheld"] = "split R-hat %.2f (device) / %.2f (cpu) > 1.1" % (r.get("rhat") or float("nan"), cpu_cache[ck].get("rhat") or float("nan"))
                         else:
                             r["ess_per_sec_vs_cpu_baseline"] = r["ess_per_sec"] / cpu_cache[ck]["ess_per_sec"]
+            t_parts["cpu"] = time.perf_counter() - t_w - sum(t_parts.values())
             if getattr(W, "published", None):
                 r["published"] = W.published
                 r["samples_per_s"] = r["value"] / W.L
@@ -320,6 +323,7 @@ def secondary(dev, a):
                         r["roofline"]["launches_per_step"] = r["extras"]["launches_per_step"]
                 except Exception as e:
                     r["extras"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            t_parts["extras"] = time.perf_counter() - t_w - sum(t_parts.values())
             if hasattr(w, "api_call") and not a.no_api and not getattr(w, "jacobi", False):
                 try:        # the same steps through the public API (sample / sample_split_model / sample_model)
                     r["api_ms_per_step"], r["api_sync_ms"] = api_timing(w, steps, warmup, reps=3)
@@ -329,6 +333,7 @@ def secondary(dev, a):
             out.append(r)
             del w
             torch.cuda.empty_cache()
+            print("bench: %-14s %6.1f s  %s" % (r["key"], time.perf_counter() - t_w, {k: round(v, 1) for k, v in t_parts.items()}), file=sys.stderr, flush=True)
         except Exception as e:          # a secondary line must never take the headline down with it
             out.append({"workload": W.name, "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
     return out

@@ -79,12 +79,20 @@ def cpu_baseline_procs(key, seconds, rounds=3, init_file=None):
     # ONE process per core runs all the rounds (a fresh chain each: own seed, own start state): the rounds share the interpreter's and
     # torch's start-up, ~4 s per process that three separate launches of 16 processes paid three times
     t_all = time.time()
-    ps = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), key, str(1000 + i),
-                            repr(float(seconds) / rounds), init_file or "-", str(i), str(rounds)],
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True) for i in range(procs)]
+    # (the workers write to temporary FILES: a round's samples are more than a pipe holds, and a worker blocked on a full pipe would not
+    #  start its next round before the parent has read every worker in front of it - the rounds would run one process after the other)
+    import tempfile
+    ps = []
+    for i in range(procs):
+        fo, fe = tempfile.TemporaryFile(mode="w+"), tempfile.TemporaryFile(mode="w+")
+        ps.append((subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), key, str(1000 + i),
+                                     repr(float(seconds) / rounds), init_file or "-", str(i), str(rounds)], stdout=fo, stderr=fe, env=env, text=True), fo, fe))
     per_round, causes = [[] for _ in range(rounds)], {}
-    for p_ in ps:
-        out_, err_ = p_.communicate(timeout=300 + 30 * seconds)
+    for p_, fo, fe in ps:
+        p_.wait(timeout=300 + 30 * seconds)
+        fo.seek(0); fe.seek(0)
+        out_, err_ = fo.read(), fe.read()
+        fo.close(); fe.close()
         got = 0
         for ln in out_.strip().splitlines():
             try:

@@ -137,6 +137,8 @@ def compact_line(full, detail_path="bench_detail.json"):
                            if not isinstance(v, (dict, list)) and v is not None and k not in ("predict_samples_per_s", "predict_samples", "predict_ms_torch_path", "trajectories_per_step_1024", "kernel_ms_1024", "callback_evaluations_per_step", "metric_evaluations_per_step", "hta_launches_per_step", "traces", "predict_route", "frac_1024")}
         if r.get("published"):          # the reference's published samples / s (one chain); ours = value / L, spelled out in bench_detail.json
             e["published_sps"] = r["published"].get("samples_per_s")
+        if e.get("bound") == "valu":                 # (no matrix instructions, a few MB of HBM per launch: both are in bench_detail.json)
+            e.pop("mfma_busy", None); e.pop("traffic", None)
         sec.append({k: v for k, v in e.items() if v is not None or k in ("value", "frac", "chains")})
     if sec:
         out["secondary"] = sec

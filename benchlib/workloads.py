@@ -230,9 +230,9 @@ class Cfg3:
 
     def cpu_baseline(self, seconds, init_file=None):
         """Reference cost structure: every dH/dtheta, dH/dp is an autograd pass through hessian + eigh (S:395-422); one chain
-        per usable host core.  ~1 trajectory per second and core: four times the common budget (three rounds of 12 s at the default) so
+        per usable host core.  ~1 trajectory per second and core: six times the common budget (three rounds of 18 s at the default) so
         that a chain has more than a handful of draws behind its ESS."""
-        return cpu_baseline_procs("cfg3", 4 * seconds, init_file=init_file)
+        return cpu_baseline_procs("cfg3", 6 * seconds, init_file=init_file)
 
 
 class Cfg5(Cfg3):

@@ -22,6 +22,7 @@ import os
 import sys
 import time
 
+_T_PROC = time.time()
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
@@ -186,6 +187,10 @@ def main():
     # ValueError inside log_prob instead, which the reference does not catch - its explicit-RMHMC funnel run would end the process.
     torch.distributions.Distribution.set_default_validate_args(False)
     dt0 = None
+    t_start = time.time()
+    stamp = (lambda what: print("cpu_baseline[%d] %6.2f s %s" % (os.getpid(), time.time() - t_start, what), file=sys.stderr, flush=True)) \
+        if os.environ.get("HTA_CPU_BASELINE_TIMING") else (lambda what: None)
+    stamp("imports done (process age %.2f s)" % (time.time() - _T_PROC))
     for rep in range(rounds):
         # every round is a NEW chain: its own seed, its own start state (row + rep * stride of the device's burned-in states)
         start = None if states is None else states[(int(sys.argv[5]) + 17 * rep) % states.shape[0]].clone()
@@ -198,9 +203,11 @@ def main():
             run(n0)                                                       # the first call pays torch's lazy initialisation
             t0 = time.time(); run(n0); dt0 = (time.time() - t0) / n0
         n = max(40 if workload == "cfg2" else 1, int(seconds / max(dt0, 1e-6)))
+        stamp("round %d: built, warm, n = %d" % (rep, n))
         t0 = time.time()
         ret, acc = run(n)
         dt = time.time() - t0
+        stamp("round %d: sampled in %.2f s" % (rep, dt))
         out = {"kind": "reference" if ref else "port", "impl": note, "n": n, "L": L, "dt": dt, "acc": float(acc), "round": rep}
         # the samples travel (first ESS_DIMS coordinates, 6 significant digits), for ESS / s with the estimator bench.py applies to the
         # device samples (hamiltorch_amd/ess.py over the same coordinates); the reference's output is this list (S:1086-1091)
@@ -208,6 +215,7 @@ def main():
         out["ess_dims"] = int(rows.shape[1])
         out["samples"] = [[float("%.6g" % v) for v in row] for row in rows.tolist()]
         print(json.dumps(out), flush=True)
+        stamp("round %d: printed" % rep)
 
 
 if __name__ == "__main__":
