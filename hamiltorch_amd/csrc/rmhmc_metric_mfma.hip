@@ -45,6 +45,7 @@ namespace hta {
 
 int g_metric_mfma = 1;   // tuning key "metric_mfma": 1 = warm fp32 evaluations run here, 0 = always the Jacobi kernel
 int g_metric_second = 1;    // tuning key "metric_second": 1 = the refinement's second pass in closed form (one product: ph_refine_E2) where the first pass's update is small, 0 = always the full pass (three products)
+int g_metric_bx3 = 1;       // tuning key "metric_bx3": 1 = the fast solve's second-pass product F E1 as three bfloat16 products (operands split hi + lo), 0 = exact fp32 products
 int g_metric_general = 1;   // tuning key "metric_general": 1 = evaluations with per-system curvature AND per-system bases run here too
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -54,7 +55,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #endif
 #if HTA_TIMING      // developer builds (tools/scratch/metric_phase.cpp): s_memtime stamps of workgroup 0 at the phase boundaries
 __device__ long long hta_metric_dbg[32];
-__device__ long long hta_metric_wdbg[16][4];        // per wave of workgroup 0: entry / k loop begins / k loop ends / return of the formation product
+__device__ long long hta_metric_wdbg[16][16];       // per wave of workgroup 0: entry / k loop begins / k loop ends / return of the formation product (0 .. 3: general sequence; 4 .. 9 / 10 .. 15: ph_fast_form / ph_fast_second)
 #define HTA_WVSTAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) hta_metric_wdbg[threadIdx.x >> 6][k] = clock64(); } while (0)
 #define HTA_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) hta_metric_dbg[k] = clock64(); } while (0)
 #define HTA_WSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) hta_metric_dbg[k] = clock64(); } while (0)      // wave 0's own progress: no barrier
@@ -94,6 +95,9 @@ __device__ __forceinline__ void gemm_macro(const float* pa0, const float* pb0, c
   const float* pa1 = pa0 + (TA ? 16 : 16 * LD);
   const float* pb1 = pb0 + (TB ? 16 * LD : 16);
   float av[2][2][4], bv[2][2][4];                               // [buffer][tile row / column][step]
+  float scv[2][4];                                              // the chunk's scale factors: applied where the operand is consumed (applied
+                                                                // where it is loaded, the multiply - and with it the wait for the NEXT chunk's reads -
+                                                                // sits in front of the CURRENT chunk's matrix instructions: no read was ever in flight)
 #define HTA_LOAD_STEP(buf, u, ks)                                                        \
   do {                                                                                   \
     av[buf][0][u] = pa0[(ks) * as];                                                      \
@@ -101,6 +105,7 @@ __device__ __forceinline__ void gemm_macro(const float* pa0, const float* pb0, c
     const float sc__ = SCALE ? kscale[4 * (ks) + lk] : 1.f;                              \
     bv[buf][0][u] = SCALE ? pb0[(ks) * bs] * sc__ : pb0[(ks) * bs];                      \
     if (C2) bv[buf][1][u] = SCALE ? pb1[(ks) * bs] * sc__ : pb1[(ks) * bs];              \
+    scv[buf][u] = 1.f;                                                                   \
   } while (0)
 #if defined(HTA_GEMM_ABLATE) && HTA_GEMM_ABLATE == 1      // developer build (tools/scratch/metric_phase.cpp): no matrix instructions
 #define HTA_MMA_STEP(buf, u)                                                                                              \
@@ -113,10 +118,12 @@ __device__ __forceinline__ void gemm_macro(const float* pa0, const float* pb0, c
 #else
 #define HTA_MMA_STEP(buf, u)                                                                                              \
   do {                                                                                                                    \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][0][u], bv[buf][0][u], acc[0][0], 0, 0, 0);                   \
-    if (C2) acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][0][u], bv[buf][1][u], acc[0][1], 0, 0, 0);           \
-    if (R2) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][1][u], bv[buf][0][u], acc[1][0], 0, 0, 0);           \
-    if (R2 && C2) acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][1][u], bv[buf][1][u], acc[1][1], 0, 0, 0);     \
+    const float b0__ = SCALE ? bv[buf][0][u] * scv[buf][u] : bv[buf][0][u];                                               \
+    const float b1__ = (SCALE && C2) ? bv[buf][1][u] * scv[buf][u] : bv[buf][1][u];                                       \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][0][u], b0__, acc[0][0], 0, 0, 0);                            \
+    if (C2) acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][0][u], b1__, acc[0][1], 0, 0, 0);                    \
+    if (R2) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][1][u], b0__, acc[1][0], 0, 0, 0);                    \
+    if (R2 && C2) acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][1][u], b1__, acc[1][1], 0, 0, 0);              \
   } while (0)
 #endif
   // A chunk = 16 contraction indices = four instructions.  Inside a chunk, lane group lk takes the indices 16 c + 4 lk + u at
@@ -146,21 +153,24 @@ __device__ __forceinline__ void gemm_macro(const float* pa0, const float* pb0, c
         _Pragma("unroll") for (int u = 0; u < 4; ++u) av[buf][1][u] = t1__[u];                                            \
       }                                                                                                                   \
     }                                                                                                                     \
-    f4 sc__ = f4{1.f, 1.f, 1.f, 1.f};                                                                                     \
-    if (SCALE) sc__ = *reinterpret_cast<const f4*>(qsc + 16 * (c));                                                       \
+    if (SCALE) {                                                                                                          \
+      const f4 sc__ = *reinterpret_cast<const f4*>(qsc + 16 * (c));                                                       \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) scv[buf][u] = sc__[u];                                                \
+    }                                                                                                                     \
     if (TB) {                                                                                                             \
       const f4 t0__ = *reinterpret_cast<const f4*>(qb0 + 16 * (c));                                                       \
-      _Pragma("unroll") for (int u = 0; u < 4; ++u) bv[buf][0][u] = SCALE ? t0__[u] * sc__[u] : t0__[u];                  \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) bv[buf][0][u] = t0__[u];                                              \
       if (C2) {                                                                                                           \
         const f4 t1__ = *reinterpret_cast<const f4*>(qb1 + 16 * (c));                                                     \
-        _Pragma("unroll") for (int u = 0; u < 4; ++u) bv[buf][1][u] = SCALE ? t1__[u] * sc__[u] : t1__[u];                \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) bv[buf][1][u] = t1__[u];                                            \
       }                                                                                                                   \
     } else {                                                                                                              \
       _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                     \
-        bv[buf][0][u] = SCALE ? qb0[(16 * (c) + u) * LD] * sc__[u] : qb0[(16 * (c) + u) * LD];                            \
-        if (C2) bv[buf][1][u] = SCALE ? qb1[(16 * (c) + u) * LD] * sc__[u] : qb1[(16 * (c) + u) * LD];                    \
+        bv[buf][0][u] = qb0[(16 * (c) + u) * LD];                                                                         \
+        if (C2) bv[buf][1][u] = qb1[(16 * (c) + u) * LD];                                                                 \
       }                                                                                                                   \
     }                                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
   } while (0)
 #if defined(HTA_GEMM_ABLATE) && HTA_GEMM_ABLATE == 2      // developer build: no operand reads (the matrix instructions alone)
 #undef HTA_LOAD_CHUNK
@@ -169,6 +179,7 @@ __device__ __forceinline__ void gemm_macro(const float* pa0, const float* pb0, c
     _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                       \
       av[buf][0][u] = av[buf][1][u] = __int_as_float(0x3f800000 + (c));                                                   \
       bv[buf][0][u] = bv[buf][1][u] = __int_as_float(0x3f800000 + lk);                                                    \
+      scv[buf][u] = 1.f;                                                                                                  \
     }                                                                                                                     \
   } while (0)
 #endif
@@ -180,9 +191,11 @@ __device__ __forceinline__ void gemm_macro(const float* pa0, const float* pb0, c
       HTA_LOAD_CHUNK(1, ch + 1);
 #pragma unroll
       for (int u = 0; u < 4; ++u) HTA_MMA_STEP(0, u);
+      __builtin_amdgcn_sched_barrier(0);
       HTA_LOAD_CHUNK(0, ch + 2);
 #pragma unroll
       for (int u = 0; u < 4; ++u) HTA_MMA_STEP(1, u);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (ch + 1 < nchunk) {
       HTA_LOAD_CHUNK(1, ch + 1);
@@ -202,6 +215,115 @@ __device__ __forceinline__ void gemm_macro(const float* pa0, const float* pb0, c
 #undef HTA_LOAD_STEP
 #undef HTA_LOAD_CHUNK
 #undef HTA_MMA_STEP
+}
+
+// The same macro tile for M = F E1 with the operands split on the fly into two bfloat16 terms each (x = hi + lo + O(2^-16 x)) and three
+// products on v_mfma_f32_16x16x32_bf16 (hi hi + hi lo + lo hi, fp32 accumulation): 48 cycles of the matrix pipe per 32 contraction
+// indices instead of 256.  M is a second-order CORRECTION - |E2| = |M| / gap <= 1e-4 where this pass is taken (kSecondE) - so its
+// relative error 2^-16 is an absolute error below 2e-9 in the eigenvectors: under fp32 rounding of the first-order terms, which stay
+// exact fp32 products (formation, and every matrix-vector product of the solve).  Both operands are read along k: A = F[m][k]
+// (symmetric), B = E1[k][n] = -E1[n][k] (antisymmetric: the caller negates the result); lane l feeds row / column l & 15 and the
+// indices 8 (l >> 4) .. + 7 of a 32-step (16-byte reads, rows 464 bytes apart: conflict free), 4 (l >> 4) .. + 3 of the 16-step that
+// ends an odd number of tiles.
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(float x0, float x1, int& hi, int& lo) {
+  const unsigned a = __float_as_uint(x0), b = __float_as_uint(x1);
+  hi = (int)__builtin_amdgcn_perm(b, a, 0x07060302);                     // the upper halves: truncation to bfloat16
+  const f2v x = {x0, x1}, h = {__uint_as_float(a & 0xffff0000u), __uint_as_float(b & 0xffff0000u)};
+  const f2v r = x - h;
+  lo = (int)__builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302);
+}
+template <bool R2, bool C2>
+__device__ __forceinline__ void gemm_macro_bx3(const float* pa0, const float* pb0, int nt, int LD, f4 (&acc)[2][2]) {
+  // pa0 = F + (16 I0 + li) LD, pb0 = E1 + (16 J0 + li) LD (row starts; the lane's k offset is added here)
+  const int kg = (threadIdx.x & 63) >> 4;
+  const float* pa[2] = {pa0 + 8 * kg, pa0 + 16 * LD + 8 * kg};
+  const float* pb[2] = {pb0 + 8 * kg, pb0 + 16 * LD + 8 * kg};
+  const int nfull = nt >> 1;
+  // Register budget: a phase function that needs more than the 80 caller-saved VGPRs saves and restores the rest through scratch memory
+  // in its prologue / epilogue - measured at 4-7 k cycles per call (16 waves x 15 dwords, a round trip beyond the L2 each).  So: the B
+  // tiles are split first (their raw registers take the next step's loads at once), the A tiles one at a time, each requested while the
+  // previous one's products run.
+  f4 rb[2][2];                                                           // [tile][half] raw fp32 of the B tiles of the step in flight
+#define HTA_BX_LOAD_B(s)                                                                                 \
+  do {                                                                                                   \
+    rb[0][0] = *reinterpret_cast<const f4*>(pb[0] + 32 * (s)); rb[0][1] = *reinterpret_cast<const f4*>(pb[0] + 32 * (s) + 4); \
+    if (C2) { rb[1][0] = *reinterpret_cast<const f4*>(pb[1] + 32 * (s)); rb[1][1] = *reinterpret_cast<const f4*>(pb[1] + 32 * (s) + 4); } \
+  } while (0)
+  f4 ra0, ra1;                                                           // the A tile in flight (the next one is requested as soon as this one is split)
+  if (nfull > 0) {
+    HTA_BX_LOAD_B(0);
+    ra0 = *reinterpret_cast<const f4*>(pa[0]); ra1 = *reinterpret_cast<const f4*>(pa[0] + 4);
+  }
+  for (int s = 0; s < nfull; ++s) {
+    i4v bh[2], bl[2];
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      if (y == 1 && !C2) continue;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) { int h, l; split_pair(rb[y][p >> 1][2 * (p & 1)], rb[y][p >> 1][2 * (p & 1) + 1], h, l); bh[y][p] = h; bl[y][p] = l; }
+    }
+    if (s + 1 < nfull) HTA_BX_LOAD_B(s + 1);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      if (x == 1 && !R2) continue;
+      i4v ah, al;
+      {
+        int h, l;
+        split_pair(ra0[0], ra0[1], h, l); ah[0] = h; al[0] = l;
+        split_pair(ra0[2], ra0[3], h, l); ah[1] = h; al[1] = l;
+        split_pair(ra1[0], ra1[1], h, l); ah[2] = h; al[2] = l;
+        split_pair(ra1[2], ra1[3], h, l); ah[3] = h; al[3] = l;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (R2 && x == 0) { ra0 = *reinterpret_cast<const f4*>(pa[1] + 32 * s); ra1 = *reinterpret_cast<const f4*>(pa[1] + 32 * s + 4); }
+      else if (s + 1 < nfull) { ra0 = *reinterpret_cast<const f4*>(pa[0] + 32 * (s + 1)); ra1 = *reinterpret_cast<const f4*>(pa[0] + 32 * (s + 1) + 4); }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, ah), __builtin_bit_cast(bf8v, bh[0]), acc[x][0], 0, 0, 0);
+      if (C2) acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, ah), __builtin_bit_cast(bf8v, bh[1]), acc[x][1], 0, 0, 0);
+      acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, ah), __builtin_bit_cast(bf8v, bl[0]), acc[x][0], 0, 0, 0);
+      if (C2) acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, ah), __builtin_bit_cast(bf8v, bl[1]), acc[x][1], 0, 0, 0);
+      acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, al), __builtin_bit_cast(bf8v, bh[0]), acc[x][0], 0, 0, 0);
+      if (C2) acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, al), __builtin_bit_cast(bf8v, bh[1]), acc[x][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#undef HTA_BX_LOAD_B
+  if (nt & 1) {                                                          // the last 16 indices
+    const int k0 = 16 * (nt - 1) + 4 * kg - 8 * kg;                      // (pa / pb carry 8 kg)
+    i2v ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      if (x == 1 && !R2) continue;
+      const f4 v = *reinterpret_cast<const f4*>(pa[x] + k0);
+      int h, l;
+      split_pair(v[0], v[1], h, l); ah[x][0] = h; al[x][0] = l;
+      split_pair(v[2], v[3], h, l); ah[x][1] = h; al[x][1] = l;
+    }
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      if (y == 1 && !C2) continue;
+      const f4 v = *reinterpret_cast<const f4*>(pb[y] + k0);
+      int h, l;
+      split_pair(v[0], v[1], h, l); bh[y][0] = h; bl[y][0] = l;
+      split_pair(v[2], v[3], h, l); bh[y][1] = h; bl[y][1] = l;
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      if (x == 1 && !R2) continue;
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        if (y == 1 && !C2) continue;
+        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, ah[x]), __builtin_bit_cast(s4v, bh[y]), acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, ah[x]), __builtin_bit_cast(s4v, bl[y]), acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, al[x]), __builtin_bit_cast(s4v, bh[y]), acc[x][y], 0, 0, 0);
+      }
+    }
+  }
 }
 
 // (Operands are OFFSETS, in floats, into the kernel's dynamic LDS block: an out-of-line function only sees generic pointers
@@ -340,6 +462,14 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   const int w = threadIdx.x >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return max16_dpp(red[threadIdx.x & 15]);
+}
+
+// the same with ONE barrier, for call sites whose previous use of `red` is already fenced by a barrier every wave has passed
+__device__ __forceinline__ float block_max1(float v, float* red) {
+  v = wave_max_dpp(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
   return max16_dpp(red[threadIdx.x & 15]);
 }
@@ -763,6 +893,500 @@ __device__ HTA_PH_ATTR void ph_dmetric_w(int offDst, int offLam, int offLt, int 
   }
 }
 
+// ======== Round 6: the SOLVE evaluation of a Gaussian target on the shared basis - 4 L + 2 of a trajectory's 4 L + 3 =============
+// Same mathematics as the general sequence in metric_warm_system (formation, first pass from X = I, second pass in closed form applied
+// to the vectors), reorganised around what the phase table of round 5 showed (profiles/r05ad: 71 k cycles, of which the two
+// products' k loops are 19.5 k): (1) V0 never leaves its buffer - X = I + E1 is not stored over it, E1 and E2 live in the other two,
+// so nothing is staged again (3.0 k + the first staging); (2) the element-wise passes run in the EPILOGUES of the two products on
+// the accumulators (no LDS round trip of S / M, no pair bookkeeping, 16-byte mirror stores: 6.5 k + 8.0 k -> ~4 k); (3) log p and
+// P d come from the eigenbasis the workgroup already holds - d' = V0^T d rides in the pass that computes m' = V0^T m, d^T P d =
+// sum lam0 d'^2, P d = V0 (lam0 d') rides in the pass that computes x = V0 x' - instead of a pass over P in global memory with an
+// L2 read-modify-write behind it (8.3 k -> ~2 k); (4) the three block sums (log-det, quadratic form, d^T P d) share the chain's
+// barriers.  Anything this path does not cover (per-system curvature, outputs that need G or Q, a first pass above kSecondE, a second
+// pass above kConvE) returns false BEFORE any global write and the general sequence runs, V0 still resident.
+constexpr int kFastScratch = 320;        // floats at oW: the Cholesky's [16][20] panel scratch; the fast solve parks its [10][4] wave partials there
+
+// Cost model of the vector phases (measured, round 6: profiles/r06i_metric_fast_phases.txt): with 16 waves on the CU every instruction a
+// wave executes costs the workgroup ~16 cycles (4 waves per SIMD x 4 cycles of issue; the ONE scalar unit of the CU serves all 16 waves),
+// whatever it does - a matrix-vector product spread over all 1024 threads is bound by its address / predicate / reduction instructions,
+// not by its 12.5 k multiply-adds.  So these phases run on the first 8 waves only, 4 lanes per row with 32 multiply-adds each as packed
+// FMAs; the other waves go straight to the next barrier.  Lane c of a row takes the 16-byte quads 4c .. 4c+3 and 16+4c .. 16+4c+3: the 16
+// lanes of a ds_read_b128 group (4 rows x 4 lanes, rows 29 quads apart) then fall on 16 different quads of the bank row.
+__device__ __forceinline__ f2v pk_fma(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float quad_sum(float s) { s += dpp_f<0xB1>(s); s += dpp_f<0x4E>(s); return s; }
+
+// (M v)_row, row = tid >> 2, tid < 512; nq = quads per row (DP / 4, a multiple of 4); every lane of the row's quad returns the sum
+__device__ __forceinline__ float mv4(const float* M, int ld, const float* v, int nq, int nrow) {
+  const int row = threadIdx.x >> 2, c = threadIdx.x & 3;
+  f2v a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+  if (row < nrow) {
+    const float* mr = M + row * ld + 16 * c;
+    const float* vr = v + 16 * c;
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      if (16 * rd + 4 * c < nq) {
+        f4 mq[4], vq[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { mq[t] = *reinterpret_cast<const f4*>(mr + 64 * rd + 4 * t); vq[t] = *reinterpret_cast<const f4*>(vr + 64 * rd + 4 * t); }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          a0 = pk_fma(f2v{mq[t][0], mq[t][1]}, f2v{vq[t][0], vq[t][1]}, a0);
+          a1 = pk_fma(f2v{mq[t][2], mq[t][3]}, f2v{vq[t][2], vq[t][3]}, a1);
+        }
+      }
+    }
+  }
+  return quad_sum((a0[0] + a0[1]) + (a1[0] + a1[1]));
+}
+
+// two products on one pass over M: (M v0, M v1)
+__device__ __forceinline__ void mv4_dual(const float* M, int ld, const float* v0, const float* v1, int nq, int nrow, float& o0, float& o1) {
+  const int row = threadIdx.x >> 2, c = threadIdx.x & 3;
+  f2v a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, b0 = {0.f, 0.f}, b1 = {0.f, 0.f};
+  if (row < nrow) {
+    const float* mr = M + row * ld + 16 * c;
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      if (16 * rd + 4 * c < nq) {
+        f4 mq[4], xq[4], yq[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          mq[t] = *reinterpret_cast<const f4*>(mr + 64 * rd + 4 * t);
+          xq[t] = *reinterpret_cast<const f4*>(v0 + 16 * c + 64 * rd + 4 * t);
+          yq[t] = *reinterpret_cast<const f4*>(v1 + 16 * c + 64 * rd + 4 * t);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          a0 = pk_fma(f2v{mq[t][0], mq[t][1]}, f2v{xq[t][0], xq[t][1]}, a0);
+          a1 = pk_fma(f2v{mq[t][2], mq[t][3]}, f2v{xq[t][2], xq[t][3]}, a1);
+          b0 = pk_fma(f2v{mq[t][0], mq[t][1]}, f2v{yq[t][0], yq[t][1]}, b0);
+          b1 = pk_fma(f2v{mq[t][2], mq[t][3]}, f2v{yq[t][2], yq[t][3]}, b1);
+        }
+      }
+    }
+  }
+  o0 = quad_sum((a0[0] + a0[1]) + (a1[0] + a1[1]));
+  o1 = quad_sum((b0[0] + b0[1]) + (b1[0] + b1[1]));
+}
+
+// (M^T v)_k, k = tid >> 2, tid < 512: lane c sums the rows 4u + c (4-byte reads along the row: the 32 lanes of a read group touch
+// 4 banks twice); nrow = DP (a multiple of 16).  Every lane of the column's quad returns the sum.
+__device__ __forceinline__ float mv4t(const float* M, int ld, const float* v, int nrow) {
+  const int k = threadIdx.x >> 2, c = threadIdx.x & 3;
+  float a0 = 0.f, a1 = 0.f;
+  if (k < nrow) {
+    const float* mc = M + c * ld + k;
+    const float* vc = v + c;
+    for (int u0 = 0; 4 * u0 < nrow; u0 += 8) {                     // rows 4 (u0 + t) + c, eight (or four: nrow / 4 is a multiple of 4) in flight
+      float mv[8], vv[8];
+      const bool two = 4 * (u0 + 4) < nrow;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { mv[t] = mc[4 * (u0 + t) * ld]; vv[t] = vc[4 * (u0 + t)]; }
+      if (two) {
+#pragma unroll
+        for (int t = 4; t < 8; ++t) { mv[t] = mc[4 * (u0 + t) * ld]; vv[t] = vc[4 * (u0 + t)]; }
+      } else {
+#pragma unroll
+        for (int t = 4; t < 8; ++t) { mv[t] = 0.f; vv[t] = 0.f; }
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { if (t & 1) a1 = fmaf(mv[t], vv[t], a1); else a0 = fmaf(mv[t], vv[t], a0); }
+    }
+  }
+  return quad_sum(a0 + a1);
+}
+
+// m' = V0^T m and d' = V0^T d in one pass over V0 (mv4t's layout, (m_i, d_i) interleaved at offMD), waves 0 .. 7
+__device__ HTA_PH_ATTR void ph_fast_vt(int offV, int offMD, int offM, int offD, int DP, int LD) {
+  HTA_LDS_BASE();
+  DP = HTA_U(DP); LD = HTA_U(LD);
+  if (threadIdx.x < 512) {
+    const float* V = lds + HTA_U(offV);
+    const f2v* md = reinterpret_cast<const f2v*>(lds + HTA_U(offMD));
+    const int k = threadIdx.x >> 2, c = threadIdx.x & 3;
+    f2v a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+    if (k < DP) {
+      const float* mc = V + c * LD + k;
+      for (int u0 = 0; 4 * u0 < DP; u0 += 8) {
+        float mv[8]; f2v w[8];
+        const bool two = 4 * (u0 + 4) < DP;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { mv[t] = mc[4 * (u0 + t) * LD]; w[t] = md[4 * (u0 + t) + c]; }
+        if (two) {
+#pragma unroll
+          for (int t = 4; t < 8; ++t) { mv[t] = mc[4 * (u0 + t) * LD]; w[t] = md[4 * (u0 + t) + c]; }
+        } else {
+#pragma unroll
+          for (int t = 4; t < 8; ++t) { mv[t] = 0.f; w[t] = f2v{0.f, 0.f}; }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { if (t & 1) a1 = pk_fma(f2v{mv[t], mv[t]}, w[t], a1); else a0 = pk_fma(f2v{mv[t], mv[t]}, w[t], a0); }
+      }
+    }
+    const float sm = quad_sum(a0[0] + a1[0]), sd = quad_sum(a0[1] + a1[1]);
+    if (c == 0 && k < DP) { (lds + HTA_U(offM))[k] = sm; (lds + HTA_U(offD))[k] = sd; }
+  }
+  __syncthreads();
+}
+
+// The work items of the two products, once per launch (the scalar loops that deal them out cost every wave ~100 instructions per call
+// on the CU's one scalar unit: the waves entered their k loops 1 .. 3.4 k cycles apart).  Bits 0 .. 9: the wave's item of the upper block
+// triangle as lds_gemm_ld's SYM branch deals them (I0 | J0 << 4 | second tile << 8 | active << 9); bits 16 .. 26: its 2 x 2 macro tile
+// of a full product as the other branch does (I0 | J0 << 4 | second row << 8 | second column << 9 | active << 10).
+__device__ __forceinline__ int fast_tiles(int nt) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int lo, hi;
+  {
+    int npairs = 0;
+    for (int I = 0; I < nt; ++I) npairs += (nt - I) >> 1;
+    int w = wave, I = 0, I0, J0, c2 = 0, active = 1;
+    if (w < npairs) {
+      for (;; ++I) { const int pr = (nt - I) >> 1; if (w < pr) break; w -= pr; }
+      I0 = I; J0 = I + 2 * w; c2 = 1;
+    } else {
+      w -= npairs;
+      for (; I < nt; ++I) if ((nt - I) & 1) { if (w == 0) break; --w; }
+      if (I >= nt) { active = 0; I = 0; }
+      I0 = I; J0 = nt - 1;
+    }
+    lo = I0 | (J0 << 4) | (c2 << 8) | (active << 9);
+  }
+  {
+    const int nf = nt >> 1, odd = nt & 1;
+    const int s = wave & 3, q = wave >> 2;
+    int k = (q & 1) ? 4 * q + 3 - s : 4 * q + s;
+    int r = 0, c = 0, active = 1;
+    const int nfull = nf * nf;
+    if (k < nfull) { r = k / nf; c = k - r * nf; }
+    else {
+      k -= nfull;
+      if (!odd || k > 2 * nf) active = 0;
+      else if (k < nf) { r = k; c = nf; } else if (k < 2 * nf) { r = nf; c = k - nf; } else { r = nf; c = nf; }
+    }
+    const int I0 = 2 * r, J0 = 2 * c;
+    hi = I0 | (J0 << 4) | ((I0 + 1 < nt ? 1 : 0) << 8) | ((J0 + 1 < nt ? 1 : 0) << 9) | (active << 10);
+  }
+  return lo | (hi << 16);
+}
+
+// F = V0^T diag(e) V0 (upper tiles, as lds_gemm_ld<true, false, true, true>) with the first pass in the epilogue: the diagonal tiles
+// publish lam_i = lam0_i + F_ii, then every tile turns its accumulators into E1_ij = F_ij / (lam_j - lam_i) (ph_refine_E's
+// arithmetic with X = I: the same quotients, the same threshold) and stores F (zero diagonal) and E1 (antisymmetric, zero
+// diagonal) with their mirror images as 16-byte rows.  Returns max |E1_ij| (1 for NaN / inf / > kFallbackE).
+template <int LDC>
+__device__ HTA_PH_ATTR float ph_fast_form(int offV, int offF, int offE, int offJit, int offLam0, int offLam, int offRed, int tile, int k4, int D, int LDr) {
+  HTA_LDS_BASE();
+  k4 = HTA_U(k4); D = HTA_U(D);
+  const int LD = LDC ? LDC : HTA_U(LDr);
+  const float* V = lds + HTA_U(offV);
+  float* F = lds + HTA_U(offF); float* E = lds + HTA_U(offE);
+  const float* kscale = lds + HTA_U(offJit);
+  const float* vlam0 = lds + HTA_U(offLam0);
+  float* vlam = lds + HTA_U(offLam); float* red = lds + HTA_U(offRed);
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  tile = HTA_U(tile);                                              // fast_tiles(): this wave's item of the upper block triangle
+  const int I0 = tile & 15, J0 = (tile >> 4) & 15;
+  const bool c2 = (tile >> 8) & 1, active = (tile >> 9) & 1;
+  HTA_WVSTAMP(4);
+  f4 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) acc[x][y] = f4{0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const float* pa0 = V + lk * LD + 16 * I0 + li;
+    const float* pb0 = V + lk * LD + 16 * J0 + li;
+    if (c2) gemm_macro<true, false, true, false, true>(pa0, pb0, kscale, k4, LD, lk, acc);
+    else gemm_macro<true, false, true, false, false>(pa0, pb0, kscale, k4, LD, lk, acc);
+    HTA_WVSTAMP(5);
+    if (I0 == J0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (4 * lk + t == li) { const int i = 16 * I0 + li; if (i < D) vlam[i] = acc[0][0][t] + vlam0[i]; }
+    }
+  }
+  HTA_WVSTAMP(6);
+  __syncthreads();
+  HTA_WVSTAMP(7);
+  float sc = 0.f;
+  if (lane < D) sc = fabsf(vlam[lane]);
+  if (lane + 64 < D) sc = fmaxf(sc, fabsf(vlam[lane + 64]));
+  sc = wave_max_dpp(sc);
+  const float tiny = 8.f * Eps<float>::v * sc;
+  unsigned ebits = 0u;                                             // max |E1_ij| as a bit pattern: inf and NaN order above every finite value
+  if (active) {
+    const f4 lamI = *reinterpret_cast<const f4*>(vlam + 16 * I0 + 4 * lk);
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      if (y == 1 && !c2) continue;
+      const int J = J0 + y, j = 16 * J + li;
+      const float lamJ = vlam[j];
+      if (I0 != J) {
+        const f4 a = acc[0][y];
+        const f2v lamJ2 = {lamJ, lamJ};
+        const f2v d01 = lamJ2 - f2v{lamI[0], lamI[1]}, d23 = lamJ2 - f2v{lamI[2], lamI[3]};
+        const f2v r01 = {__builtin_amdgcn_rcpf(d01[0]), __builtin_amdgcn_rcpf(d01[1])}, r23 = {__builtin_amdgcn_rcpf(d23[0]), __builtin_amdgcn_rcpf(d23[1])};
+        const f2v q01 = f2v{a[0], a[1]} * r01, q23 = f2v{a[2], a[3]} * r23;
+        f4 e;
+        e[0] = (fabsf(a[0]) <= tiny) ? 0.f : q01[0];
+        e[1] = (fabsf(a[1]) <= tiny) ? 0.f : q01[1];
+        e[2] = (fabsf(a[2]) <= tiny) ? 0.f : q23[0];
+        e[3] = (fabsf(a[3]) <= tiny) ? 0.f : q23[1];
+        float* fd = F + (16 * I0 + 4 * lk) * LD + j;
+        float* ed = E + (16 * I0 + 4 * lk) * LD + j;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          ebits = max(ebits, __float_as_uint(e[t]) & 0x7fffffffu);
+          fd[t * LD] = a[t]; ed[t * LD] = e[t];
+        }
+        const f2v n01 = f2v{e[0], e[1]} * f2v{-1.f, -1.f}, n23 = f2v{e[2], e[3]} * f2v{-1.f, -1.f};
+        *reinterpret_cast<f4*>(F + j * LD + 16 * I0 + 4 * lk) = a;
+        *reinterpret_cast<f4*>(E + j * LD + 16 * I0 + 4 * lk) = f4{n01[0], n01[1], n23[0], n23[1]};
+      } else {
+        // a diagonal tile holds both triangles of its block: every lane stores its own four elements, no mirror.  (F_ij and F_ji differ
+        // in the last bit there - the scale factor enters through the B operand only - so E1 + E1^T is zero to rounding of a 5e-3
+        // quantity, not exactly: 1e-10, far below anything the solve resolves.)
+        const f4 a = acc[0][y];
+        const f2v lamJ2 = {lamJ, lamJ};
+        const f2v d01 = lamJ2 - f2v{lamI[0], lamI[1]}, d23 = lamJ2 - f2v{lamI[2], lamI[3]};
+        const f2v r01 = {__builtin_amdgcn_rcpf(d01[0]), __builtin_amdgcn_rcpf(d01[1])}, r23 = {__builtin_amdgcn_rcpf(d23[0]), __builtin_amdgcn_rcpf(d23[1])};
+        const f2v q01 = f2v{a[0], a[1]} * r01, q23 = f2v{a[2], a[3]} * r23;
+        f4 e, f;
+        e[0] = (fabsf(a[0]) <= tiny) ? 0.f : q01[0];
+        e[1] = (fabsf(a[1]) <= tiny) ? 0.f : q01[1];
+        e[2] = (fabsf(a[2]) <= tiny) ? 0.f : q23[0];
+        e[3] = (fabsf(a[3]) <= tiny) ? 0.f : q23[1];
+        float* fd = F + (16 * I0 + 4 * lk) * LD + j;
+        float* ed = E + (16 * I0 + 4 * lk) * LD + j;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bool dg = 4 * lk + t == li;
+          e[t] = dg ? 0.f : e[t]; f[t] = dg ? 0.f : a[t];
+          ebits = max(ebits, __float_as_uint(e[t]) & 0x7fffffffu);
+          fd[t * LD] = f[t]; ed[t * LD] = e[t];
+        }
+      }
+    }
+  }
+  float emax = (ebits > __float_as_uint(kFallbackE)) ? 1.f : __uint_as_float(ebits);      // NaN / inf / too large
+  HTA_WVSTAMP(8);
+  emax = block_max1(emax, red);         // (`red` was last read before this function's barrier above)
+  HTA_WVSTAMP(9);
+  return emax;
+}
+
+// M = F E1 (as lds_gemm_ld<false, false, false, false>) with the closed-form second pass in the epilogue (ph_refine_E2's arithmetic
+// on the accumulators): lam_i' = lam_i + M_ii from the diagonal tiles, E2_ij = M_ij / (lam_j' - lam_i'), E2_ii = -1/2 sum_k E1_ik^2
+// (row sums taken before the product), E2 stored over F once every wave has left its k loop.  Returns max |E2_ij|.
+template <int LDC, bool BX3>
+__device__ HTA_PH_ATTR float ph_fast_second(int offF, int offE, int offLam, int offCs, int offRed, int nt, int tile, int k4, int D, int LDr) {
+  HTA_LDS_BASE();
+  nt = HTA_U(nt); k4 = HTA_U(k4); D = HTA_U(D);
+  const int LD = LDC ? LDC : HTA_U(LDr);
+  float* F = lds + HTA_U(offF); const float* E = lds + HTA_U(offE);
+  float* vlam = lds + HTA_U(offLam); float* vcs = lds + HTA_U(offCs); float* red = lds + HTA_U(offRed);
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  {
+    const int row = threadIdx.x >> 3, seg = threadIdx.x & 7;
+    float c0 = 0.f, c1 = 0.f;
+    if (row < 16 * nt) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = seg + 8 * u;
+        if (q < 4 * nt) {
+          const f4 v = *reinterpret_cast<const f4*>(E + row * LD + 4 * q);
+          c0 = fmaf(v[0], v[0], c0); c1 = fmaf(v[1], v[1], c1); c0 = fmaf(v[2], v[2], c0); c1 = fmaf(v[3], v[3], c1);
+        }
+      }
+    }
+    const float cs = sum8_dpp(c0 + c1);
+    if (seg == 0 && row < 16 * nt) vcs[row] = cs;
+  }
+  HTA_WVSTAMP(10);
+  tile = HTA_U(tile) >> 16;                                        // fast_tiles(): this wave's 2 x 2 macro tile of the full product
+  const int I0 = tile & 15, J0 = (tile >> 4) & 15;
+  const bool r2 = (tile >> 8) & 1, c2 = (tile >> 9) & 1, active = (tile >> 10) & 1;
+  // The instruction computes the TRANSPOSED tile: its rows run over j (operand A = rows of E1), its columns over i (operand B = rows of
+  // the symmetric F), acc[x][y][t] = sum_k E1[j][k] F[i][k] = -M[i][j] at i = 16 (I0 + y) + li, j = 16 (J0 + x) + 4 lk + t - a lane
+  // holds four consecutive columns of ONE row of M, so E2 leaves as one 16-byte store per tile and lane and the element-wise step runs
+  // on register pairs (v_pk_add / v_pk_mul).  The sign goes into the reciprocal: E2_ij = M_ij / (lam_j - lam_i) = acc / (lam_i - lam_j).
+  f4 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) acc[x][y] = f4{0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    if (BX3) {
+      const float* pa0 = E + (16 * J0 + li) * LD;
+      const float* pb0 = F + (16 * I0 + li) * LD;
+      if (r2 && c2) gemm_macro_bx3<true, true>(pa0, pb0, nt, LD, acc);
+      else if (c2) gemm_macro_bx3<true, false>(pa0, pb0, nt, LD, acc);
+      else if (r2) gemm_macro_bx3<false, true>(pa0, pb0, nt, LD, acc);
+      else gemm_macro_bx3<false, false>(pa0, pb0, nt, LD, acc);
+    } else {
+      const float* pa0 = E + (16 * J0 + li) * LD + lk;
+      const float* pb0 = F + lk * LD + 16 * I0 + li;
+      if (r2 && c2) gemm_macro<false, false, false, true, true>(pa0, pb0, nullptr, k4, LD, lk, acc);
+      else if (c2) gemm_macro<false, false, false, true, false>(pa0, pb0, nullptr, k4, LD, lk, acc);
+      else if (r2) gemm_macro<false, false, false, false, true>(pa0, pb0, nullptr, k4, LD, lk, acc);
+      else gemm_macro<false, false, false, false, false>(pa0, pb0, nullptr, k4, LD, lk, acc);
+    }
+    HTA_WVSTAMP(11);
+    if (I0 == J0) {                                                // lam_i' = lam_i + M_ii
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        if (x == 1 && !r2) continue;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (4 * lk + t == li) { const int i = 16 * (I0 + x) + li; if (i < D) vlam[i] = vlam[i] - acc[x][x][t]; }
+      }
+    }
+  }
+  HTA_WVSTAMP(12);
+  __syncthreads();
+  HTA_WVSTAMP(13);
+  float sc = 0.f;
+  if (lane < D) sc = fabsf(vlam[lane]);
+  if (lane + 64 < D) sc = fmaxf(sc, fabsf(vlam[lane + 64]));
+  sc = wave_max_dpp(sc);
+  const float tiny = 8.f * Eps<float>::v * sc * kSecondE;
+  unsigned ebits = 0u;                                             // max |E2_ij| as a bit pattern: inf and NaN order above every finite value
+  if (active) {
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      if (y == 1 && !r2) continue;
+      const int I = I0 + y, i = 16 * I + li;
+      const float lamI = vlam[i];
+      const f2v lamI2 = {lamI, lamI};
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        if (x == 1 && !c2) continue;
+        const int J = J0 + x;
+        const f4 lamJ = *reinterpret_cast<const f4*>(vlam + 16 * J + 4 * lk);
+        const f4 a = acc[x][y];
+        const f2v d01 = lamI2 - f2v{lamJ[0], lamJ[1]}, d23 = lamI2 - f2v{lamJ[2], lamJ[3]};
+        const f2v r01 = {__builtin_amdgcn_rcpf(d01[0]), __builtin_amdgcn_rcpf(d01[1])}, r23 = {__builtin_amdgcn_rcpf(d23[0]), __builtin_amdgcn_rcpf(d23[1])};
+        const f2v q01 = f2v{a[0], a[1]} * r01, q23 = f2v{a[2], a[3]} * r23;
+        f4 e;
+        e[0] = (fabsf(a[0]) <= tiny) ? 0.f : q01[0];
+        e[1] = (fabsf(a[1]) <= tiny) ? 0.f : q01[1];
+        e[2] = (fabsf(a[2]) <= tiny) ? 0.f : q23[0];
+        e[3] = (fabsf(a[3]) <= tiny) ? 0.f : q23[1];
+        if (I == J) {                                              // (wave-uniform) the diagonal element: E2_ii = -1/2 sum_k E1_ik^2, not an update
+          const float dg = -0.5f * vcs[i];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) if (4 * lk + t == li) e[t] = 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) ebits = max(ebits, __float_as_uint(e[t]) & 0x7fffffffu);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) if (4 * lk + t == li) e[t] = dg;
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) ebits = max(ebits, __float_as_uint(e[t]) & 0x7fffffffu);
+        }
+        *reinterpret_cast<f4*>(F + i * LD + 16 * J + 4 * lk) = e;
+      }
+    }
+  }
+  float emax = (ebits > __float_as_uint(kFallbackE)) ? 1.f : __uint_as_float(ebits);      // NaN / inf / too large
+  HTA_WVSTAMP(14);
+  emax = block_max1(emax, red);
+  HTA_WVSTAMP(15);
+  return emax;
+}
+
+// The vectors of the solve: soft-abs map, y = (I + E2^T)(I - E1) m', w = y / lam~, x' = (I + E1)(I + E2) w, x = V0 x', P d = V0 (lam0 d'),
+// the two row updates; the block sums (log-det, y^T w, sum lam0 d'^2) as wave partials at oS (waves 0 .. 9, stride 4: the caller adds them).
+// Waves 0 .. 7 carry the products (mv4: a row's value stays in its four lanes from one stage to the next), waves 8 .. 9 the soft-abs
+// map under the second product; five barriers.  Vector block at oVec: e | lam | lam0 -> lam~ | m' | y | x | d' -> lam0 d' | cs, then 16 floats, then oS.
+__device__ HTA_PH_ATTR void ph_fast_chain(int offV, int offE1, int offE2, int oVec, int D, int DP, int LD, int flags, float alpha,
+                                          float* lam_out, float* lamraw_out, float* x_out, float* upd_x, float cx, float* upd_g, float cg) {
+  HTA_LDS_BASE();
+  D = HTA_U(D); DP = HTA_U(DP); LD = HTA_U(LD); flags = HTA_U(flags); oVec = HTA_U(oVec);
+  const bool skip2 = flags & 1, has_x = flags & 2;
+  const float* V = lds + HTA_U(offV); const float* E1 = lds + HTA_U(offE1); const float* E2 = lds + HTA_U(offE2);
+  float* vlam = lds + oVec + DP; float* vlt = vlam + DP; float* vm = vlt + DP; float* vy = vm + DP; float* vx = vy + DP; float* vd = vx + DP;
+  float* red3 = vd + 2 * DP + MT / 64;
+  typedef __attribute__((address_space(1))) float* gf;
+  const int tid = threadIdx.x, wave = HTA_U(tid >> 6);
+  const int nq = DP >> 2;
+  if (wave >= 10) {                                              // nothing to compute: the five barriers of the chain
+    __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+    return;
+  }
+  if (wave >= 8) {                                               // soft-abs map (S:120), log-determinant (S:726), d^T P d, lam0 d': one wave's 1.5 k-cycle
+    const int i = tid - 512;                                     // instruction sequence (tanhf, a division, logf) - the map under the product E1 m' of
+    float ld = 0.f, lq = 0.f, lt = 1.f, l0 = 0.f;                // waves 0 .. 7, the logarithm and the sums under their product E2^T y0
+    if (i < D) {
+      const float lam = vlam[i];
+      lt = (1.f / tanhf(alpha * lam)) * lam;
+      l0 = vlt[i];                                               // (lam0 is parked where lam~ goes)
+      if (lamraw_out) ((gf)lamraw_out)[i] = lam;
+    }
+    if (i < DP) vlt[i] = lt;
+    __syncthreads();                                             // 1
+    if (i < D) {
+      ld = logf(lt);
+      if (lam_out) ((gf)lam_out)[i] = lt;
+      if (has_x) { const float dp = vd[i]; lq = l0 * dp * dp; vd[i] = l0 * dp; }
+    }
+    const float s0 = wave_sum_dpp(ld), s2 = wave_sum_dpp(lq);
+    if ((tid & 63) == 0) { float* r = red3 + 4 * wave; r[0] = s0; r[1] = 0.f; r[2] = s2; }
+    __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+    return;
+  }
+  const int row = tid >> 2, c = tid & 3;
+  const bool wr = c == 0 && row < D;
+  float ux = 0.f, ug = 0.f;                                      // the rows the updates add to: requested now, used at the end
+  if (wr && upd_x) ux = ((gf)upd_x)[row];
+  if (wr && upd_g) ug = ((gf)upd_g)[row];
+  HTA_WSTAMP(12);
+  // y0 = m' - E1 m'
+  float y = 0.f;
+  {
+    const float e1m = mv4(E1, LD, vm, nq, DP);
+    if (row < D) y = vm[row] - e1m;
+  }
+  if (c == 0 && row < DP) vy[row] = y;
+  __syncthreads();                                               // 1: y0
+  HTA_WSTAMP(13);
+  if (!skip2) y += mv4t(E2, LD, vy, DP);                         // y += E2^T y0
+  __syncthreads();                                               // 2: lam~, lam0 d'
+  HTA_WSTAMP(14);
+  float w = 0.f, qd = 0.f;
+  if (row < D) { w = y / vlt[row]; if (c == 0) qd = y * w; }
+  if (c == 0 && row < DP) vx[row] = w;
+  {
+    const float s1 = wave_sum_dpp(qd);
+    if ((tid & 63) == 0) { float* r = red3 + 4 * wave; r[0] = 0.f; r[1] = s1; r[2] = 0.f; }
+  }
+  __syncthreads();                                               // 3: w
+  HTA_WSTAMP(15);
+  const float* vsrc = vx;
+  if (!skip2) {                                                  // w <- w + E2 w
+    w += mv4(E2, LD, vx, nq, DP);
+    if (c == 0 && row < DP) vy[row] = (row < D) ? w : 0.f;
+    vsrc = vy;
+  }
+  __syncthreads();                                               // 4
+  HTA_WSTAMP(16);
+  const float xp = w + mv4(E1, LD, vsrc, nq, DP);                // x' = w + E1 w
+  float* vdst = skip2 ? vy : vx;
+  if (c == 0 && row < DP) vdst[row] = (row < D) ? xp : 0.f;
+  __syncthreads();                                               // 5
+  HTA_WSTAMP(17);
+  float x, g;
+  mv4_dual(V, LD, vdst, vd, nq, DP, x, g);                       // x = V0 x', P d = V0 (lam0 d')
+  if (wr) {
+    if (x_out) ((gf)x_out)[row] = x;
+    if (upd_x) ((gf)upd_x)[row] = ux + cx * x;
+    if (upd_g) ((gf)upd_g)[row] = ug + cg * g;
+  }
+  HTA_WSTAMP(18);
+}
+
 // The thread index, opaque to the optimiser.  Per-lane global addresses (a.m + b D + i, a.upd_x + b D + row, ...) derived from
 // the plain index were computed at the top of the kernel and kept across its 30 out-of-line phase calls - i.e. spilled to
 // scratch memory at the 128-register cap of a 1024-thread workgroup (14 stores at the top, 13 reloads scattered over the
@@ -774,10 +1398,75 @@ __device__ __forceinline__ int opaque_tid() {
   return t;
 }
 
+// the fast solve evaluation of system b (see the block comment above ph_fast_vt); false: nothing written, run the general sequence
+__device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, int DP, int LD, int64_t b, int& vres, bool bx3, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int D = a.D, tid = threadIdx.x;
+  const int nt = DP / 16, k4 = (D + 3) / 4;
+  float* const lds0 = reinterpret_cast<float*>(smem_raw);
+  const int BS = DP * LD > 1024 ? DP * LD : 1024;
+  const int oJit = 3 * BS, oLam = oJit + DP, oLt = oLam + DP, oM = oLt + DP, oY = oM + DP, oD = oY + 2 * DP, oRed = oD + 2 * DP, oS = oRed + MT / 64;
+  const int bx = vres >= 0 ? vres : BS;                              // V0: where the previous evaluation left it, else staged into buffer 1
+  const int by = bx == 0 ? BS : 0, bz = bx == 2 * BS ? BS : 2 * BS;  // F then E2 | E1
+  const uint64_t chain = a.chain_offset + (uint64_t)b;
+  __syncthreads();
+  HTA_STAMP(0);
+  if (tid < DP) {
+    const int i = opaque_tid();
+    const bool in = i < D;
+    lds0[oJit + i] = (in && a.has_jitter) ? (float)a.jitter * uniform_elem<float>(a.seed, chain, a.draw, PURPOSE_JITTER, a.sub, i) : 0.f;
+    lds0[oY + 2 * i] = in ? a.m[b * D + i] : 0.f;
+    lds0[oY + 2 * i + 1] = (in && a.X) ? a.X[b * D + i] - a.mu[i] : 0.f;
+    lds0[oLt + i] = in ? a.lam0[i] : 0.f;                            // lam0 (the soft-abs map overwrites it element by element at the end)
+    lds0[oLam + i] = 0.f;
+  }
+  if (vres < 0) ph_stage(a.V0, bx, D, DP, LD);
+  vres = bx;
+  __syncthreads();
+  HTA_STAMP(1);
+  ph_fast_vt(bx, oY, oM, oD, DP, LD);
+  HTA_STAMP(2);
+  const float e1 = LD == kLdCfg3 ? ph_fast_form<kLdCfg3>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD)
+                                 : ph_fast_form<0>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD);
+  HTA_STAMP(3);
+  if (!(e1 <= kSecondE)) return false;
+  const bool skip2 = e1 <= kConvE;                                   // (no jitter: F = 0, the shared basis is the answer)
+  if (!skip2) {
+    float e2;
+    // (the bfloat16 form only where the leading dimension is a compile-time constant: the run-time instance needs four registers beyond
+    // the caller-saved set, i.e. a save / restore through scratch memory per call that costs more than the product saves)
+    if (bx3 && LD == kLdCfg3) e2 = ph_fast_second<kLdCfg3, true>(by, bz, oLam, oD + DP, oRed, nt, tiles, k4, D, LD);
+    else e2 = LD == kLdCfg3 ? ph_fast_second<kLdCfg3, false>(by, bz, oLam, oD + DP, oRed, nt, tiles, k4, D, LD)
+                            : ph_fast_second<0, false>(by, bz, oLam, oD + DP, oRed, nt, tiles, k4, D, LD);
+    if (!(e2 <= kConvE)) return false;
+  }
+  HTA_STAMP(9);
+  ph_fast_chain(bx, bz, by, oJit, D, DP, LD, (skip2 ? 1 : 0) | (a.X ? 2 : 0), (float)a.alpha,
+                a.lam_out ? a.lam_out + b * D : nullptr, a.lamraw_out ? a.lamraw_out + b * D : nullptr, a.x_out ? a.x_out + b * D : nullptr,
+                a.upd_x ? a.upd_x + b * D : nullptr, (float)a.cx, a.upd_g ? a.upd_g + b * D : nullptr, (float)a.cg);
+  HTA_STAMP(21);
+  if (tid == 0) {
+    const float* r = lds0 + oS;
+    float logdet = 0.f, quad = 0.f, dpd = 0.f;
+#pragma unroll
+    for (int w = 0; w < 10; ++w) { logdet += r[4 * w]; quad += r[4 * w + 1]; dpd += r[4 * w + 2]; }
+    const float logp = a.X ? (float)a.log_norm - 0.5f * dpd : 0.f;
+    if (a.logdet_out) a.logdet_out[b] = logdet;
+    if (a.quad_out) a.quad_out[b] = quad;
+    if (a.logp_out) a.logp_out[b] = logp;
+    if (a.H_out) {
+      const float pi_term = (float)D * 1.8378770351409912f;                              // S:712 in float32
+      a.H_out[b] = -logp + 0.5f * pi_term + 0.5f * logdet + 0.5f * quad;                 // S:731
+    }
+  }
+  HTA_STAMP(24);
+  return true;
+}
+
 // One evaluation of system b (everything of the file's header); the workgroup's 1024 threads, state in the dynamic LDS block.
 // `vres`: the matrix buffer (offset) that holds the staged shared basis V0 on entry, or -1; on return, the buffer that holds it
 // now (a solve ends with V0 staged for x = V0 x': the next evaluation of a trajectory kernel starts from that copy), or -1.
-__device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, int DP, int LD, int64_t b, int& vres, bool second) {
+__device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, int DP, int LD, int64_t b, int& vres, int second, int tiles) {      // second: bit 0 = the closed-form second pass, bit 1 = its product as three bfloat16 products (the fast solve)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = a.D, tid = threadIdx.x;
   const int nt = DP / 16, k4 = (D + 3) / 4;
@@ -802,6 +1491,9 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
   // test passes, the in-launch Jacobi (on the nearly diagonal A: few sweeps) where it does not; V_out = V0_b X is the
   // basis for the caller's next call.  lam0 is not used.
   const bool general = softabs && a.hs_stride != 0;
+  if ((second & 1) && softabs && !general && a.m && !(a.G_out || a.p_out || a.V_out || a.dmetric_out) && (!a.X || a.Pm == a.Hs)) {
+    if (metric_fast_solve(a, DP, LD, b, vres, (second & 2) != 0, tiles)) return;
+  }
 
   {
     const uint64_t chain = a.chain_offset + (uint64_t)b;
@@ -871,7 +1563,7 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
         }
         HTA_STAMP(4 + 4 * it);
         float emax;
-        if (it == 1 && have_x && second && emax_prev <= kSecondE) {
+        if (it == 1 && have_x && (second & 1) && emax_prev <= kSecondE) {
           // second pass in closed form: M = F E1 (F = A, E1 = X without their diagonals), then ph_refine_E2
           { const int i = opaque_tid(); if (i < D) { lds0[by + i * LD + i] = 0.f; lds0[bx + i * LD + i] = 0.f; } }
           __syncthreads();
@@ -1115,7 +1807,8 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
 }
 
 __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float> a, int DP, int LD, int second) {
-  for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) { int vres = -1; metric_warm_system(a, DP, LD, b, vres, second != 0); }
+  const int tiles = fast_tiles(DP / 16);
+  for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) { int vres = -1; metric_warm_system(a, DP, LD, b, vres, second, tiles); }
 }
 
 // One explicit-RMHMC trajectory of chain b in ONE launch (S:969-989 with S:425-461 inside): the 4 L + 3 metric evaluations of
@@ -1129,6 +1822,7 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
 __global__ __launch_bounds__(MT) void metric_traj_mfma_kernel(MetricArgsT<float> a, MetricTrajArgs t, int DP, int LD, int second) {
   const int D = a.D;
   const int nops = 4 * t.L + 3;
+  const int tiles = fast_tiles(DP / 16);
   for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
     int vres = -1;                       // the buffer a solve left the staged V0 in: the next evaluation starts from it
     for (int op = 0; op < nops; ++op) {
@@ -1145,7 +1839,7 @@ __global__ __launch_bounds__(MT) void metric_traj_mfma_kernel(MetricArgsT<float>
         o.X = fa ? t.th : t.thc; o.m = fa ? t.pmc : t.pm; o.upd_x = fa ? t.thc : t.th; o.upd_g = fa ? t.pm : t.pmc;
         o.cx = t.eh; o.cg = -t.eh;
       }
-      metric_warm_system(o, DP, LD, b, vres, second != 0);
+      metric_warm_system(o, DP, LD, b, vres, second, tiles);
       if (op == 1 || j == 1) {
         __syncthreads();
         const int i = opaque_tid();
@@ -1172,7 +1866,7 @@ bool metric_traj_mfma_eligible(const MetricArgsT<float>& a) {
 int metric_traj_mfma(const MetricArgsT<float>& a, const MetricTrajArgs& t, hipStream_t s) {
   const int D = a.D;
   const int DP = (D + 15) / 16 * 16, LD = DP + 4;
-  const size_t lds = ((size_t)3 * (DP * LD > 1024 ? DP * LD : 1024) + 8 * DP + MT / 64 + 16 * 20) * sizeof(float);
+  const size_t lds = ((size_t)3 * (DP * LD > 1024 ? DP * LD : 1024) + 8 * DP + MT / 64 + kFastScratch) * sizeof(float);
   HTA_REQUIRE(lds <= 160 * 1024, "hta_rmhmc_gaussian_sample (trajectory kernel): D=%d does not fit the LDS", D);
   MetricArgsT<float> k = a;
   if (k.max_sweeps <= 0) k.max_sweeps = 16;
@@ -1185,7 +1879,7 @@ int metric_traj_mfma(const MetricArgsT<float>& a, const MetricTrajArgs& t, hipSt
   const int grid = (int)(a.B < 65536 ? a.B : 65536);
   profile_begin(s);
   note_route("metric_traj_mfma_kernel");
-  metric_traj_mfma_kernel<<<grid, MT, lds, s>>>(k, t, DP, LD, g_metric_second);
+  metric_traj_mfma_kernel<<<grid, MT, lds, s>>>(k, t, DP, LD, (g_metric_second ? 1 : 0) | (g_metric_bx3 ? 2 : 0));
   profile_end(s);
   HTA_CHECK_LAUNCH("hta_rmhmc_gaussian_sample (trajectory kernel)");
   return HTA_OK;
@@ -1205,7 +1899,7 @@ bool metric_warm_mfma_eligible(const MetricArgsT<float>& a) {
 int metric_warm_mfma(const MetricArgsT<float>& a, hipStream_t s) {
   const int D = a.D;
   const int DP = (D + 15) / 16 * 16, LD = DP + 4;
-  const size_t lds = ((size_t)3 * (DP * LD > 1024 ? DP * LD : 1024) + 8 * DP + MT / 64 + 16 * 20) * sizeof(float);   // = oW + 320 floats
+  const size_t lds = ((size_t)3 * (DP * LD > 1024 ? DP * LD : 1024) + 8 * DP + MT / 64 + kFastScratch) * sizeof(float);    // = oW + kFastScratch floats (the Cholesky's [16][20] panel scratch and the fast solve's partials share them)
   HTA_REQUIRE(lds <= 160 * 1024, "hta_metric_eval (mfma): D=%d does not fit the LDS", D);
   MetricArgsT<float> k = a;
   if (k.max_sweeps <= 0) k.max_sweeps = 16;
@@ -1218,7 +1912,7 @@ int metric_warm_mfma(const MetricArgsT<float>& a, hipStream_t s) {
   const int grid = (int)(a.B < 65536 ? a.B : 65536);
   profile_begin(s);
   note_route("metric_warm_mfma_kernel");
-  metric_warm_mfma_kernel<<<grid, MT, lds, s>>>(k, DP, LD, g_metric_second);
+  metric_warm_mfma_kernel<<<grid, MT, lds, s>>>(k, DP, LD, (g_metric_second ? 1 : 0) | (g_metric_bx3 ? 2 : 0));
   profile_end(s);
   HTA_CHECK_LAUNCH("hta_metric_eval (mfma)");
   return HTA_OK;

@@ -494,6 +494,11 @@ int hta_jit_rmhmc_sample(void* module, const HtaCbRmhmcArgs* args, int D, int it
  * more than 8e-3, the second pass is second-order perturbation theory in closed form - ONE product F E1 instead of A X, X^T A X and
  * X^T X; truncation error |F| d^2 < 1e-8 in ||A X - X Lam||, below fp32 rounding; 0 = always the three-product pass: the parity
  * partner, equal results to rounding),
+ * "metric_bx3" (round 6; 1 default: in the SOLVE evaluations of a Gaussian target on the shared basis - the fast sequence of
+ * csrc/rmhmc_metric_mfma.hip: V0 resident, the element-wise passes in the products' epilogues, log p and P d from the eigenbasis -
+ * the closed-form second pass takes its product F E1 as three bfloat16 products, the operands split hi + lo on the fly: relative
+ * error 2^-16 of a correction that is itself below 1e-4, i.e. under fp32 rounding of the first-order terms, which stay exact fp32
+ * products; 0 = that product in exact fp32 as well: the parity partner),
  * "mlp3_route" (1 default: Bayesian MLPs with two wide hidden layers run on csrc/mlp3_mfma.hip; 0 = callback path),
  * "quad_variant" (7 default: the quad kernel with wave-uniform base addresses + 32-bit lane offsets, without the NaN guard of
  * the accept compare, and with the row element and the energy butterfly in one interleaved block; 3 = without that block;

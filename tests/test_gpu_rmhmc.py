@@ -921,6 +921,47 @@ def test_second_pass_in_closed_form_equals_the_three_product_pass(ht, D, alpha, 
     assert np.abs(np.sort(a["lam"], axis=1) - np.sort(lam, axis=1)).max() <= 8e-6 * np.abs(lam).max()
 
 
+@pytest.mark.parametrize("D,alpha,jitter", [(100, 1e6, 1e-3), (100, 1.3, 1e-3), (100, 1e6, None), (64, 2.0, 5e-4), (37, 1e6, 1e-3), (112, 1e6, 1e-3), (3, 1e6, 1e-3)])
+def test_fast_solve_with_bfloat16_products_equals_exact_products(ht, D, alpha, jitter):
+    """Round 6 ("metric_bx3"): the solve evaluations of a Gaussian target on the shared basis run a reorganised sequence (V0 resident,
+    the element-wise passes in the products' epilogues, log p and P d from the eigenbasis) whose second-pass product F E1 is taken
+    as three bfloat16 products of operands split hi + lo (1) or in exact fp32 (0).  F E1 is a second-order correction: its 2^-16
+    relative error must not be visible - the two agree an order tighter than either agrees with float64, and (1) is as close to the
+    float64 oracle as (0).  Every output of the solve: x through upd_x, P d through upd_g, log|G|, the quadratic form, H, log p, the
+    soft-abs spectrum; no jitter (F = 0: the second pass is skipped), the smallest and the largest tile counts."""
+    from hamiltorch_amd import _abi
+    rng = np.random.default_rng(D + 5)
+    P = cfg3_target(ht, D, torch.float32, seed=7)[1].P.astype(np.float64)
+    B, seed = 41, 321
+    X = (0.3 * rng.standard_normal((B, D))).astype(np.float32)
+    m = rng.standard_normal((B, D)).astype(np.float32)
+    outs = []
+    try:
+        for bx3 in (1, 0):
+            _abi.set_tuning("metric_bx3", bx3)
+            outs.append(_warm_eval(ht, P, X, m, alpha, jitter, seed, 1, want_g=False))
+    finally:
+        _abi.set_tuning("metric_bx3", 1)
+    a, f = outs
+    Hs = np.broadcast_to(P, (B, D, D)).astype(np.float64).copy()
+    ju = None if jitter is None else O.philox_uniforms(seed, 3 + np.arange(B), 7, D, O.PURPOSE_JITTER, 2, dtype=np.float64)
+    G, lam, _ = O.softabs_metric(Hs, alpha, jitter, ju)
+    x64 = 0.5 * np.linalg.solve(G, m.astype(np.float64)[..., None])[..., 0]
+    sx = np.abs(x64).max()
+    np.testing.assert_allclose(a["x"], f["x"], rtol=0, atol=2e-6 * sx)
+    np.testing.assert_allclose(a["ug"], f["ug"], rtol=0, atol=0)                     # P d does not pass through the second pass at all
+    np.testing.assert_allclose(a["lp"], f["lp"], rtol=0, atol=0)
+    np.testing.assert_allclose(a["ld"], f["ld"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(a["q"], f["q"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(a["H"], f["H"], rtol=2e-6, atol=2e-5)
+    np.testing.assert_allclose(a["lam"], f["lam"], rtol=0, atol=1e-6 * np.abs(lam).max())
+    ea, ef = np.abs(a["x"] - x64).max() / sx, np.abs(f["x"] - x64).max() / sx
+    assert ea <= max(1.2 * ef, 8e-6), (ea, ef)
+    want_lp = 0.25 - 0.5 * np.einsum("bi,ij,bj->b", X.astype(np.float64), P, X.astype(np.float64))
+    np.testing.assert_allclose(a["lp"], want_lp, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(a["ug"], -0.5 * (X.astype(np.float64) @ P), rtol=2e-5, atol=2e-5)
+
+
 def test_metric_mfma_kernel_issues_matrix_instructions_on_cfg3(ht):
     """The eigendecomposition route of BASELINE config 3 (hta_set_tuning('rmhmc_fused', 0)) runs its metric evaluations on
     rmhmc_metric_mfma.hip and agrees with the Jacobi kernel chain by chain over a short run."""

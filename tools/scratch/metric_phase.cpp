@@ -56,7 +56,15 @@ int main(int argc, char** argv) {
   if (!gibbs)
     printf("  solve sub-phases: soft-abs map + log-det sum %lld | X^T m' %lld | + E^T y %lld | w, quad sum %lld | + E w %lld | X w %lld | V0 stage %lld | V0 x', store %lld\n",
            t[12] - t[20], t[13] - t[12], t[14] - t[13], t[15] - t[14], t[16] - t[15], t[17] - t[16], t[18] - t[17], t[21] - t[18]);
-  long long w[16][4]; hipMemcpyFromSymbol(w, HIP_SYMBOL(hta::hta_metric_wdbg), sizeof(w));
-  for (int k = 0; k < 16; ++k) printf("    wave %2d: entry %6lld  k loop %6lld .. %6lld  returned %6lld\n", k, w[k][0] - t[2], w[k][1] - t[2], w[k][2] - t[2], w[k][3] - t[2]);
+  long long w[16][16]; { hipError_t e = hipMemcpyFromSymbol(w, HIP_SYMBOL(hta::hta_metric_wdbg), sizeof(w)); (void)e; }
+  if (w[0][4]) {       // the fast solve ran (round 6): per wave, cycles since the formation phase / the second product began
+    for (int k = 0; k < 16; ++k) printf("    wave %2d form: entry %6lld  k loop %6lld .. %6lld  at barrier %6lld  past %6lld  epilogue done %6lld  returned %6lld | second: entry %6lld  k loop %6lld .. %6lld  at barrier %6lld  past %6lld  epilogue done %6lld  returned %6lld\n", k,
+        w[k][4] - t[2], w[k][4] - t[2], w[k][5] - t[2], w[k][6] - t[2], w[k][7] - t[2], w[k][8] - t[2], w[k][9] - t[2],
+        w[k][10] - t[3], w[k][10] - t[3], w[k][11] - t[3], w[k][12] - t[3], w[k][13] - t[3], w[k][14] - t[3], w[k][15] - t[3]);
+    printf("  chain, wave 0 (cycles since it began):");
+    for (int k = 12; k <= 18; ++k) printf(" %lld", t[k] - t[9]);
+    printf("\n");
+  } else
+    for (int k = 0; k < 16; ++k) printf("    wave %2d: entry %6lld  k loop %6lld .. %6lld  returned %6lld\n", k, w[k][0] - t[2], w[k][1] - t[2], w[k][2] - t[2], w[k][3] - t[2]);
   return 0;
 }
