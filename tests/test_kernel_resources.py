@@ -202,7 +202,7 @@ def test_fast_solve_phase_functions_stay_inside_the_caller_saved_registers():
     for pat in ["ph_fast_vt", "ph_fast_formILi116E", "ph_fast_secondILi116ELb1E", "ph_fast_secondILi116ELb0E", "ph_fast_chain"]:
         name, lines = isa_of.kernel_lines(obj, pat)
         assert not any(i.startswith("scratch_") for _, i in lines), name
-    # the bfloat16 instance really is one: three v_mfma_f32_16x16x32_bf16 per tile pair and 32 indices, none of the fp32 form
+    # the bfloat16 instance really is one: three v_mfma_f32_16x16x32_bf16 per tile and 32 indices in the four macro-tile shapes (12 + 6 + 6 + 3 static instructions), none of the fp32 form
     _, lines = isa_of.kernel_lines(obj, "ph_fast_secondILi116ELb1E")
     ops = [i.split()[0] for _, i in lines]
-    assert ops.count("v_mfma_f32_16x16x32_bf16") >= 36 and ops.count("v_mfma_f32_16x16x4_f32") == 0
+    assert ops.count("v_mfma_f32_16x16x32_bf16") >= 27 and ops.count("v_mfma_f32_16x16x4_f32") == 0
