@@ -904,7 +904,9 @@ __device__ HTA_PH_ATTR void ph_dmetric_w(int offDst, int offLam, int offLt, int 
 // L2 read-modify-write behind it (8.3 k -> ~2 k); (4) the three block sums (log-det, quadratic form, d^T P d) share the chain's
 // barriers.  Anything this path does not cover (per-system curvature, outputs that need G or Q, a first pass above kSecondE, a second
 // pass above kConvE) returns false BEFORE any global write and the general sequence runs, V0 still resident.
-constexpr int kFastScratch = 320;        // floats at oW: the Cholesky's [16][20] panel scratch; the fast solve parks its [10][4] wave partials there
+constexpr int kFastScratch = 320 + 4 * 112;   // floats at oW: the Cholesky's [16][20] panel scratch (the fast solve parks its [10][4] wave partials there), then the
+                                              // trajectory kernel's four state vectors in eigen-coordinates (kFastState: theta', p', theta~', p~', DP floats each)
+constexpr int kFastState = 320;
 
 // Cost model of the vector phases (measured, round 6: profiles/r06i_metric_fast_phases.txt): with 16 waves on the CU every instruction a
 // wave executes costs the workgroup ~16 cycles (4 waves per SIMD x 4 cycles of issue; the ONE scalar unit of the CU serves all 16 waves),
@@ -1301,19 +1303,23 @@ __device__ HTA_PH_ATTR float ph_fast_second(int offF, int offE, int offLam, int 
 // the two row updates; the block sums (log-det, y^T w, sum lam0 d'^2) as wave partials at oS (waves 0 .. 9, stride 4: the caller adds them).
 // Waves 0 .. 7 carry the products (mv4: a row's value stays in its four lanes from one stage to the next), waves 8 .. 9 the soft-abs
 // map under the second product; five barriers.  Vector block at oVec: e | lam | lam0 -> lam~ | m' | y | x | d' -> lam0 d' | cs, then 16 floats, then oS.
+// flags: 1 = no second pass (E2 = 0), 2 = log p / P d wanted, 4 = RESIDENT: the state lives in LDS in eigen-coordinates (the trajectory
+// kernel) - the updates are theta~'[row] += cx x'[row] and p'[row] += cg lam0 d'[row] on the LDS vectors at 4 (resoff & 0xffff) / 4 (resoff >> 16)
+// (0: none), the last product and its barrier do not exist.
 __device__ HTA_PH_ATTR void ph_fast_chain(int offV, int offE1, int offE2, int oVec, int D, int DP, int LD, int flags, float alpha,
-                                          float* lam_out, float* lamraw_out, float* x_out, float* upd_x, float cx, float* upd_g, float cg) {
+                                          float* lam_out, float* lamraw_out, float* x_out, float* upd_x, float cx, float* upd_g, float cg, int resoff) {
   HTA_LDS_BASE();
-  D = HTA_U(D); DP = HTA_U(DP); LD = HTA_U(LD); flags = HTA_U(flags); oVec = HTA_U(oVec);
-  const bool skip2 = flags & 1, has_x = flags & 2;
+  D = HTA_U(D); DP = HTA_U(DP); LD = HTA_U(LD); flags = HTA_U(flags); oVec = HTA_U(oVec); resoff = HTA_U(resoff);
+  const bool skip2 = flags & 1, has_x = flags & 2, resident = flags & 4;
   const float* V = lds + HTA_U(offV); const float* E1 = lds + HTA_U(offE1); const float* E2 = lds + HTA_U(offE2);
   float* vlam = lds + oVec + DP; float* vlt = vlam + DP; float* vm = vlt + DP; float* vy = vm + DP; float* vx = vy + DP; float* vd = vx + DP;
   float* red3 = vd + 2 * DP + MT / 64;
   typedef __attribute__((address_space(1))) float* gf;
   const int tid = threadIdx.x, wave = HTA_U(tid >> 6);
   const int nq = DP >> 2;
-  if (wave >= 10) {                                              // nothing to compute: the five barriers of the chain
-    __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+  if (wave >= 10) {                                              // nothing to compute: the five (resident: four) barriers of the chain
+    __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+    if (!resident) __syncthreads();
     return;
   }
   if (wave >= 8) {                                               // soft-abs map (S:120), log-determinant (S:726), d^T P d, lam0 d': one wave's 1.5 k-cycle
@@ -1334,14 +1340,17 @@ __device__ HTA_PH_ATTR void ph_fast_chain(int offV, int offE1, int offE2, int oV
     }
     const float s0 = wave_sum_dpp(ld), s2 = wave_sum_dpp(lq);
     if ((tid & 63) == 0) { float* r = red3 + 4 * wave; r[0] = s0; r[1] = 0.f; r[2] = s2; }
-    __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+    __syncthreads(); __syncthreads(); __syncthreads();
+    if (!resident) __syncthreads();
     return;
   }
   const int row = tid >> 2, c = tid & 3;
   const bool wr = c == 0 && row < D;
   float ux = 0.f, ug = 0.f;                                      // the rows the updates add to: requested now, used at the end
-  if (wr && upd_x) ux = ((gf)upd_x)[row];
-  if (wr && upd_g) ug = ((gf)upd_g)[row];
+  if (!resident) {
+    if (wr && upd_x) ux = ((gf)upd_x)[row];
+    if (wr && upd_g) ug = ((gf)upd_g)[row];
+  }
   HTA_WSTAMP(12);
   // y0 = m' - E1 m'
   float y = 0.f;
@@ -1373,6 +1382,15 @@ __device__ HTA_PH_ATTR void ph_fast_chain(int offV, int offE1, int offE2, int oV
   __syncthreads();                                               // 4
   HTA_WSTAMP(16);
   const float xp = w + mv4(E1, LD, vsrc, nq, DP);                // x' = w + E1 w
+  if (resident) {
+    if (wr && resoff) {
+      float* sx = lds + 4 * (resoff & 0xffff); float* sg = lds + 4 * (resoff >> 16);
+      sx[row] += cx * xp;
+      sg[row] += cg * vd[row];
+    }
+    HTA_WSTAMP(18);
+    return;
+  }
   float* vdst = skip2 ? vy : vx;
   if (c == 0 && row < DP) vdst[row] = (row < D) ? xp : 0.f;
   __syncthreads();                                               // 5
@@ -1399,7 +1417,10 @@ __device__ __forceinline__ int opaque_tid() {
 }
 
 // the fast solve evaluation of system b (see the block comment above ph_fast_vt); false: nothing written, run the general sequence
-__device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, int DP, int LD, int64_t b, int& vres, bool bx3, int tiles) {
+// res_xm >= 0: RESIDENT operands - d' at LDS offset 4 (res_xm & 0xffff), m' at 4 (res_xm >> 16) (offsets are multiples of 4: 14 bits each) (eigen-coordinates: no V0 product), the updates
+// go to the LDS vectors of res_upd (see ph_fast_chain; 0: none)
+__device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, int DP, int LD, int64_t b, int& vres, bool bx3, int tiles,
+                                                  int res_xm = -1, int res_upd = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = a.D, tid = threadIdx.x;
   const int nt = DP / 16, k4 = (D + 3) / 4;
@@ -1415,8 +1436,13 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
     const int i = opaque_tid();
     const bool in = i < D;
     lds0[oJit + i] = (in && a.has_jitter) ? (float)a.jitter * uniform_elem<float>(a.seed, chain, a.draw, PURPOSE_JITTER, a.sub, i) : 0.f;
-    lds0[oY + 2 * i] = in ? a.m[b * D + i] : 0.f;
-    lds0[oY + 2 * i + 1] = (in && a.X) ? a.X[b * D + i] - a.mu[i] : 0.f;
+    if (res_xm >= 0) {
+      lds0[oM + i] = lds0[4 * (res_xm >> 16) + i];
+      lds0[oD + i] = lds0[4 * (res_xm & 0xffff) + i];
+    } else {
+      lds0[oY + 2 * i] = in ? a.m[b * D + i] : 0.f;
+      lds0[oY + 2 * i + 1] = (in && a.X) ? a.X[b * D + i] - a.mu[i] : 0.f;
+    }
     lds0[oLt + i] = in ? a.lam0[i] : 0.f;                            // lam0 (the soft-abs map overwrites it element by element at the end)
     lds0[oLam + i] = 0.f;
   }
@@ -1424,7 +1450,7 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
   vres = bx;
   __syncthreads();
   HTA_STAMP(1);
-  ph_fast_vt(bx, oY, oM, oD, DP, LD);
+  if (res_xm < 0) ph_fast_vt(bx, oY, oM, oD, DP, LD);
   HTA_STAMP(2);
   const float e1 = LD == kLdCfg3 ? ph_fast_form<kLdCfg3>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD)
                                  : ph_fast_form<0>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD);
@@ -1441,16 +1467,19 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
     if (!(e2 <= kConvE)) return false;
   }
   HTA_STAMP(9);
-  ph_fast_chain(bx, bz, by, oJit, D, DP, LD, (skip2 ? 1 : 0) | (a.X ? 2 : 0), (float)a.alpha,
-                a.lam_out ? a.lam_out + b * D : nullptr, a.lamraw_out ? a.lamraw_out + b * D : nullptr, a.x_out ? a.x_out + b * D : nullptr,
-                a.upd_x ? a.upd_x + b * D : nullptr, (float)a.cx, a.upd_g ? a.upd_g + b * D : nullptr, (float)a.cg);
+  if (res_xm >= 0)
+    ph_fast_chain(bx, bz, by, oJit, D, DP, LD, (skip2 ? 1 : 0) | 2 | 4, (float)a.alpha, nullptr, nullptr, nullptr, nullptr, (float)a.cx, nullptr, (float)a.cg, res_upd);
+  else
+    ph_fast_chain(bx, bz, by, oJit, D, DP, LD, (skip2 ? 1 : 0) | (a.X ? 2 : 0), (float)a.alpha,
+                  a.lam_out ? a.lam_out + b * D : nullptr, a.lamraw_out ? a.lamraw_out + b * D : nullptr, a.x_out ? a.x_out + b * D : nullptr,
+                  a.upd_x ? a.upd_x + b * D : nullptr, (float)a.cx, a.upd_g ? a.upd_g + b * D : nullptr, (float)a.cg, 0);
   HTA_STAMP(21);
   if (tid == 0) {
     const float* r = lds0 + oS;
     float logdet = 0.f, quad = 0.f, dpd = 0.f;
 #pragma unroll
     for (int w = 0; w < 10; ++w) { logdet += r[4 * w]; quad += r[4 * w + 1]; dpd += r[4 * w + 2]; }
-    const float logp = a.X ? (float)a.log_norm - 0.5f * dpd : 0.f;
+    const float logp = (a.X || res_xm >= 0) ? (float)a.log_norm - 0.5f * dpd : 0.f;
     if (a.logdet_out) a.logdet_out[b] = logdet;
     if (a.quad_out) a.quad_out[b] = quad;
     if (a.logp_out) a.logp_out[b] = logp;
@@ -1461,6 +1490,36 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
   }
   HTA_STAMP(24);
   return true;
+}
+
+// ---- the trajectory kernel's resident state (round 6) ----------------------------------------------------------------------------
+// (ga, gb) = (mu + V0 a', V0 b') for two LDS vectors in eigen-coordinates (mu = nullptr: none): the way back to the caller's coordinates
+__device__ HTA_PH_ATTR void ph_res_out(int offV, int offA, int offB, float* ga, float* gb, const float* mu, int D, int DP, int LD) {
+  HTA_LDS_BASE();
+  D = HTA_U(D); DP = HTA_U(DP); LD = HTA_U(LD);
+  typedef __attribute__((address_space(1))) float* gf;
+  if (threadIdx.x < 512) {
+    float x, g;
+    mv4_dual(lds + HTA_U(offV), LD, lds + HTA_U(offA), lds + HTA_U(offB), DP >> 2, DP, x, g);
+    const int row = threadIdx.x >> 2;
+    if ((threadIdx.x & 3) == 0 && row < D) {
+      ((gf)ga)[row] = x + (mu ? ((gcf)mu)[row] : 0.f);
+      ((gf)gb)[row] = g;
+    }
+  }
+}
+// (a', b') = V0^T (ga - mu, gb): into eigen-coordinates ((m_i, d_i) pairs staged at offMD, then ph_fast_vt)
+__device__ __forceinline__ void res_in(int offV, int offMD, int offA, int offB, const float* ga, const float* gb, const float* mu, int D, int DP, int LD) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* const lds0 = reinterpret_cast<float*>(smem_raw);
+  __syncthreads();
+  if ((int)threadIdx.x < DP) {
+    const int i = opaque_tid();
+    lds0[offMD + 2 * i] = i < D ? gb[i] : 0.f;
+    lds0[offMD + 2 * i + 1] = i < D ? ga[i] - (mu ? mu[i] : 0.f) : 0.f;
+  }
+  __syncthreads();
+  ph_fast_vt(offV, offMD, offB, offA, DP, LD);
 }
 
 // One evaluation of system b (everything of the file's header); the workgroup's 1024 threads, state in the dynamic LDS block.
@@ -1823,21 +1882,71 @@ __global__ __launch_bounds__(MT) void metric_traj_mfma_kernel(MetricArgsT<float>
   const int D = a.D;
   const int nops = 4 * t.L + 3;
   const int tiles = fast_tiles(DP / 16);
+  // RESIDENT mode (round 6, second & 4: tuning key "metric_resident"): after the momentum draw the chain's four state vectors are taken
+  // into the eigenbasis ONCE - theta' = V0^T (theta - mu), p' = V0^T p - and live in LDS for the trajectory: a solve evaluation then has
+  // no V0 product at either end (m' and d' ARE the state, x' and lam0 d' update it element-wise), no global read or write but its
+  // scalars; the binding rotation is element-wise in any orthonormal basis.  theta = mu + V0 theta' once at the end.  The rounding of
+  // the 4 L + 2 round trips through V0 is gone, not added: results agree with the launch sequence to fp32 rounding, not bit for bit
+  // (second & 4 == 0 keeps the bit-identical form: tests/test_gpu_rmhmc.py::test_trajectory_kernel_equals_the_launch_sequence).
+  const bool resident = (second & 4) && (second & 1) && a.metric == 1 && a.hs_stride == 0 && a.Pm == a.Hs && a.V0 && a.lam0;
+  const int BS = DP * LD > 1024 ? DP * LD : 1024;
+  const int oY = 3 * BS + 4 * DP, oSt = 3 * BS + 8 * DP + MT / 64 + kFastState;
+  const int sTh = oSt, sP = oSt + DP, sThc = oSt + 2 * DP, sPc = oSt + 3 * DP;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* const lds0 = reinterpret_cast<float*>(smem_raw);
   for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
     int vres = -1;                       // the buffer a solve left the staged V0 in: the next evaluation starts from it
     for (int op = 0; op < nops; ++op) {
       MetricArgsT<float> o = a;
       int j = -1;
+      bool fa = false;
       if (op == 0) { o.sub = 0; o.p_out = t.pm; }                                                  // gibbs: p ~ N(0, G(theta))  S:183-184
       else if (op == 1) { o.sub = 1; o.X = t.cur; o.m = t.pm; o.H_out = t.H0; }                    // H_old  S:971
       else if (op == nops - 1) { o.sub = 2u + 8u * (uint32_t)t.L; o.X = t.th; o.m = t.pm; o.H_out = t.H1; o.logp_out = t.lp1; }   // H_new  S:989
       else {
         const int q = op - 2, l = q >> 2;
         j = q & 3;
-        const bool fa = j == 0 || j == 3;                                                          // phi_A/2 (S:429-430, S:457-458) : phi_B/2
+        fa = j == 0 || j == 3;                                                                     // phi_A/2 (S:429-430, S:457-458) : phi_B/2
         o.sub = 2u + 8u * (uint32_t)l + (j == 0 ? 1u : j == 1 ? 2u : j == 2 ? 4u : 7u);
         o.X = fa ? t.th : t.thc; o.m = fa ? t.pmc : t.pm; o.upd_x = fa ? t.thc : t.th; o.upd_g = fa ? t.pm : t.pmc;
         o.cx = t.eh; o.cg = -t.eh;
+      }
+      if (resident && op > 0) {
+        const int64_t e0 = b * D;
+        if (op == 1) {                                             // into the eigenbasis: (theta', p') = V0^T (cur - mu, pm); theta~' = theta', p~' = p'
+          __syncthreads();
+          if (vres < 0) { ph_stage(a.V0, BS, D, DP, LD); vres = BS; }
+          res_in(vres, oY, sTh, sP, t.cur + e0, t.pm + e0, a.mu, D, DP, LD);
+          if ((int)threadIdx.x < DP) { const int i = opaque_tid(); lds0[sThc + i] = lds0[sTh + i]; lds0[sPc + i] = lds0[sP + i]; }
+          __syncthreads();
+        }
+        const bool step = op > 1 && op < nops - 1;
+        const int rx = (step && !fa) ? sThc : sTh, rm = (step && fa) ? sPc : sP;
+        const int upd = step ? (((fa ? sThc : sTh) >> 2) | (((fa ? sP : sPc) >> 2) << 16)) : 0;
+        if (!metric_fast_solve(o, DP, LD, b, vres, (second & 2) != 0, tiles, (rx >> 2) | ((rm >> 2) << 16), upd)) {
+          // (rare: a first pass above kSecondE, a non-finite state) the general sequence on the caller's coordinates: state out, evaluation, state in
+          __syncthreads();
+          if (vres < 0) { ph_stage(a.V0, BS, D, DP, LD); vres = BS; __syncthreads(); }
+          ph_res_out(vres, sTh, sP, t.th + e0, t.pm + e0, a.mu, D, DP, LD);
+          ph_res_out(vres, sThc, sPc, t.thc + e0, t.pmc + e0, a.mu, D, DP, LD);
+          __syncthreads();
+          if (op == 1) o.X = t.th;
+          metric_warm_system(o, DP, LD, b, vres, second & 2, tiles);                               // (bit 0 off: not the fast solve again)
+          __syncthreads();
+          if (vres < 0) { ph_stage(a.V0, BS, D, DP, LD); vres = BS; }
+          res_in(vres, oY, sTh, sP, t.th + e0, t.pm + e0, a.mu, D, DP, LD);
+          res_in(vres, oY, sThc, sPc, t.thc + e0, t.pmc + e0, a.mu, D, DP, LD);
+        }
+        if (j == 1) {                                                                              // phi_C  S:447-450 (element-wise: any orthonormal basis)
+          __syncthreads();
+          const int i = opaque_tid();
+          if (i < D) phi_c_elem<float>(lds0[sTh + i], lds0[sP + i], lds0[sThc + i], lds0[sPc + i], t.c, t.s);
+        }
+        if (op == nops - 1) {                                      // back: theta = mu + V0 theta' (and the final momentum, as the other form leaves it)
+          __syncthreads();
+          ph_res_out(vres, sTh, sP, t.th + e0, t.pm + e0, a.mu, D, DP, LD);
+        }
+        continue;
       }
       metric_warm_system(o, DP, LD, b, vres, second, tiles);
       if (op == 1 || j == 1) {
@@ -1857,6 +1966,7 @@ __global__ __launch_bounds__(MT) void metric_traj_mfma_kernel(MetricArgsT<float>
   }
 }
 
+int g_metric_resident = 1;   // tuning key "metric_resident": 1 = the trajectory kernel keeps the chain's state in LDS in eigen-coordinates, 0 = in the caller's (bit-identical to the launch sequence)
 int g_metric_traj = 1;   // tuning key "metric_traj": 1 = a trajectory of the eigendecomposition route is one launch, 0 = one launch per evaluation
 
 bool metric_traj_mfma_eligible(const MetricArgsT<float>& a) {
@@ -1879,7 +1989,7 @@ int metric_traj_mfma(const MetricArgsT<float>& a, const MetricTrajArgs& t, hipSt
   const int grid = (int)(a.B < 65536 ? a.B : 65536);
   profile_begin(s);
   note_route("metric_traj_mfma_kernel");
-  metric_traj_mfma_kernel<<<grid, MT, lds, s>>>(k, t, DP, LD, (g_metric_second ? 1 : 0) | (g_metric_bx3 ? 2 : 0));
+  metric_traj_mfma_kernel<<<grid, MT, lds, s>>>(k, t, DP, LD, (g_metric_second ? 1 : 0) | (g_metric_bx3 ? 2 : 0) | (g_metric_resident ? 4 : 0));
   profile_end(s);
   HTA_CHECK_LAUNCH("hta_rmhmc_gaussian_sample (trajectory kernel)");
   return HTA_OK;

@@ -494,6 +494,10 @@ int hta_jit_rmhmc_sample(void* module, const HtaCbRmhmcArgs* args, int D, int it
  * more than 8e-3, the second pass is second-order perturbation theory in closed form - ONE product F E1 instead of A X, X^T A X and
  * X^T X; truncation error |F| d^2 < 1e-8 in ||A X - X Lam||, below fp32 rounding; 0 = always the three-product pass: the parity
  * partner, equal results to rounding),
+ * "metric_resident" (round 6; 1 default: that trajectory kernel takes the chain's four state vectors into the eigenbasis once after the
+ * momentum draw - theta' = V0^T (theta - mu), p' = V0^T p - and keeps them in LDS: a solve evaluation has no V0 product and no global
+ * traffic but its scalars, theta = mu + V0 theta' at the end; agreement with the launch sequence to fp32 rounding; 0 = the state in the
+ * caller's coordinates in global memory: bit-identical to the launch sequence),
  * "metric_bx3" (round 6; 1 default: in the SOLVE evaluations of a Gaussian target on the shared basis - the fast sequence of
  * csrc/rmhmc_metric_mfma.hip: V0 resident, the element-wise passes in the products' epilogues, log p and P d from the eigenbasis -
  * the closed-form second pass takes its product F E1 as three bfloat16 products, the operands split hi + lo on the fly: relative

@@ -424,6 +424,7 @@ def test_trajectory_kernel_equals_the_launch_sequence(ht, D, jitter, metric, alp
               verbose=False, seed=seed)
     outs = []
     _abi.set_tuning("rmhmc_fused", 0)
+    _abi.set_tuning("metric_resident", 0)       # (round 6: the state in the caller's coordinates - the form that shares every operation with the launch sequence)
     try:
         for traj in (1, 0):
             _abi.set_tuning("metric_traj", traj)
@@ -434,11 +435,48 @@ def test_trajectory_kernel_equals_the_launch_sequence(ht, D, jitter, metric, alp
             outs.append((np.stack([x.cpu().numpy() for x in out]), acc.cpu().numpy(), launches))
     finally:
         _abi.set_tuning("metric_traj", 1)
+        _abi.set_tuning("metric_resident", 1)
         _abi.set_tuning("rmhmc_fused", 1)
     assert outs[0][2] < outs[1][2] / 5, "the trajectory kernel was not taken (%d vs %d profiled launches)" % (outs[0][2], outs[1][2])
     assert np.isfinite(outs[0][0]).all()
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("D,jitter,alpha,C,L", [(100, 1e-3, 1e6, 300, 3), (100, 1e-3, 1.3, 9, 3), (100, 3e-3, 0.7, 40, 2), (37, 5e-2, 1e6, 17, 3),
+                                                (20, None, 2.0, 5, 3), (112, 1e-3, 1e6, 4, 3), (3, 1e-3, 1e6, 7, 4)])
+def test_resident_trajectory_state_equals_the_callers_coordinates(ht, D, jitter, alpha, C, L):
+    """Round 6 ("metric_resident"): the trajectory kernel takes the chain's state into the eigenbasis once - theta' = V0^T (theta - mu),
+    p' = V0^T p - keeps it in LDS for the trajectory (no V0 product, no global traffic in a solve evaluation; the binding rotation is
+    element-wise in any orthonormal basis) and returns theta = mu + V0 theta' at the end.  Against the same kernel with the state in the
+    caller's coordinates (0: bit-identical to the launch sequence, the test above): samples and Hamiltonians to fp32 rounding, the
+    accept decisions equal wherever the two acceptance probabilities do not straddle the uniform draw, and both as close to the
+    float64 oracle as each other.  jitter 3e-3 with alpha 0.7: some evaluations exceed the first-pass bound and take the general
+    sequence in the middle of a resident trajectory (state out, evaluation, state in); jitter 5e-2: all of them do."""
+    from hamiltorch_amd import _abi
+    t, o = cfg3_target(ht, D, torch.float32, seed=7)
+    N, eps, omega, seed = 3, 0.1, 10.0, 11
+    th0 = (0.3 * O.philox_normals(seed, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32)
+    kw = dict(num_samples=N, num_steps_per_sample=L, step_size=eps, burn=0, jitter=jitter, softabs_const=alpha,
+              explicit_binding_const=omega, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT, metric=ht.Metric.SOFTABS, debug=2,
+              verbose=False, seed=seed)
+    outs = []
+    _abi.set_tuning("rmhmc_fused", 0)
+    try:
+        for res in (1, 0):
+            _abi.set_tuning("metric_resident", res)
+            out, acc = ht.sample(t, tt(th0, torch.float32), **kw)
+            outs.append((np.stack([x.cpu().numpy() for x in out]), acc.cpu().numpy()))
+    finally:
+        _abi.set_tuning("metric_resident", 1)
+        _abi.set_tuning("rmhmc_fused", 1)
+    a, f = outs
+    assert np.isfinite(a[0]).all() and np.isfinite(f[0]).all()
+    scale = np.abs(f[0]).max()
+    same = (a[1] == f[1]).all(axis=0) if a[1].ndim == 2 else np.ones(C, bool)
+    err = np.abs(a[0] - f[0]).max(axis=(0, 2))
+    assert (err[same] <= 2e-4 * scale).all(), (err.max(), scale)
+    assert same.mean() >= 0.95, same.mean()
 
 
 @pytest.mark.parametrize("D,jitter", [(100, 1e-3), (20, None), (37, 2e-3)])
