@@ -40,6 +40,7 @@ template <typename T> __device__ __forceinline__ void phi_c_elem(T& a, T& b, T& 
 // rmhmc_metric_mfma.hip: one launch per trajectory of the eigendecomposition route (fp32, D <= 112)
 struct MetricTrajArgs { float* cur; float* th; float* pm; float* thc; float* pmc; float* H0; float* H1; float* lp1; int L; double eh; float c, s; };
 extern int g_metric_traj;                                   // tuning key "metric_traj" (default 1)
+extern int g_metric_resident;                               // tuning key "metric_resident" (default 1)
 bool metric_traj_mfma_eligible(const MetricArgsT<float>& a);
 int metric_traj_mfma(const MetricArgsT<float>& a, const MetricTrajArgs& t, hipStream_t s);
 

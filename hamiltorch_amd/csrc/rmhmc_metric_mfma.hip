@@ -237,22 +237,28 @@ __device__ __forceinline__ void split_pair(float x0, float x1, int& hi, int& lo)
   const f2v r = x - h;
   lo = (int)__builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302);
 }
+// The B operand (F) arrives already split: the formation's epilogue stores it as two bfloat16 planes [DP][DP] (hi, then lo; rows 2 DP bytes
+// apart - with an odd tile count the 16 lanes of a ds_read_b128 group fall on 16 different quads of the bank row) in the buffer fp32 F
+// would take.  Measured (HTA_GEMM_ABLATE builds): the k loop's time is the SUM of its matrix instructions' time and its other
+// instructions' time, not the larger - every split saved is time saved.
 template <bool R2, bool C2>
-__device__ __forceinline__ void gemm_macro_bx3(const float* pa0, const float* pb0, int nt, int LD, f4 (&acc)[2][2]) {
-  // pa0 = F + (16 I0 + li) LD, pb0 = E1 + (16 J0 + li) LD (row starts; the lane's k offset is added here)
+__device__ __forceinline__ void gemm_macro_bx3(const float* pa0, const unsigned short* pb0, int nt, int LD, f4 (&acc)[2][2]) {
+  // pa0 = E1 + (16 J0 + li) LD (row start, fp32), pb0 = Fhi + (16 I0 + li) DP (row start of the hi plane); the lane's k offset is added here
   const int kg = (threadIdx.x & 63) >> 4;
+  const int DPh = 16 * nt, plane = DPh * DPh;
   const float* pa[2] = {pa0 + 8 * kg, pa0 + 16 * LD + 8 * kg};
-  const float* pb[2] = {pb0 + 8 * kg, pb0 + 16 * LD + 8 * kg};
+  const unsigned short* pb[2] = {pb0 + 8 * kg, pb0 + 16 * DPh + 8 * kg};
   const int nfull = nt >> 1;
   // Register budget: a phase function that needs more than the 80 caller-saved VGPRs saves and restores the rest through scratch memory
   // in its prologue / epilogue - measured at 4-7 k cycles per call (16 waves x 15 dwords, a round trip beyond the L2 each).  So: the B
-  // tiles are split first (their raw registers take the next step's loads at once), the A tiles one at a time, each requested while the
-  // previous one's products run.
-  f4 rb[2][2];                                                           // [tile][half] raw fp32 of the B tiles of the step in flight
-#define HTA_BX_LOAD_B(s)                                                                                 \
+  // tiles
+  // of the next step are requested as soon as this step's are taken, the A tiles are split one at a time, each requested while the previous
+  // one's products run.
+  i4v bh[2], bl[2];                                                      // the B tiles: the next step's are requested into the same registers right behind
+#define HTA_BX_LOAD_B(s)                                                 /* this step's last products (the A split of the next step covers the latency) */ \
   do {                                                                                                   \
-    rb[0][0] = *reinterpret_cast<const f4*>(pb[0] + 32 * (s)); rb[0][1] = *reinterpret_cast<const f4*>(pb[0] + 32 * (s) + 4); \
-    if (C2) { rb[1][0] = *reinterpret_cast<const f4*>(pb[1] + 32 * (s)); rb[1][1] = *reinterpret_cast<const f4*>(pb[1] + 32 * (s) + 4); } \
+    bh[0] = *reinterpret_cast<const i4v*>(pb[0] + 32 * (s)); bl[0] = *reinterpret_cast<const i4v*>(pb[0] + plane + 32 * (s)); \
+    if (C2) { bh[1] = *reinterpret_cast<const i4v*>(pb[1] + 32 * (s)); bl[1] = *reinterpret_cast<const i4v*>(pb[1] + plane + 32 * (s)); } \
   } while (0)
   f4 ra0, ra1;                                                           // the A tile in flight (the next one is requested as soon as this one is split)
   if (nfull > 0) {
@@ -260,14 +266,6 @@ __device__ __forceinline__ void gemm_macro_bx3(const float* pa0, const float* pb
     ra0 = *reinterpret_cast<const f4*>(pa[0]); ra1 = *reinterpret_cast<const f4*>(pa[0] + 4);
   }
   for (int s = 0; s < nfull; ++s) {
-    i4v bh[2], bl[2];
-#pragma unroll
-    for (int y = 0; y < 2; ++y) {
-      if (y == 1 && !C2) continue;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) { int h, l; split_pair(rb[y][p >> 1][2 * (p & 1)], rb[y][p >> 1][2 * (p & 1) + 1], h, l); bh[y][p] = h; bl[y][p] = l; }
-    }
-    if (s + 1 < nfull) HTA_BX_LOAD_B(s + 1);
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
       if (x == 1 && !R2) continue;
@@ -291,11 +289,13 @@ __device__ __forceinline__ void gemm_macro_bx3(const float* pa0, const float* pb
       if (C2) acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, al), __builtin_bit_cast(bf8v, bh[1]), acc[x][1], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (s + 1 < nfull) HTA_BX_LOAD_B(s + 1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 #undef HTA_BX_LOAD_B
   if (nt & 1) {                                                          // the last 16 indices
     const int k0 = 16 * (nt - 1) + 4 * kg - 8 * kg;                      // (pa / pb carry 8 kg)
-    i2v ah[2], al[2], bh[2], bl[2];
+    i2v ah[2], al[2], th[2], tl[2];
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
       if (x == 1 && !R2) continue;
@@ -307,10 +307,8 @@ __device__ __forceinline__ void gemm_macro_bx3(const float* pa0, const float* pb
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
       if (y == 1 && !C2) continue;
-      const f4 v = *reinterpret_cast<const f4*>(pb[y] + k0);
-      int h, l;
-      split_pair(v[0], v[1], h, l); bh[y][0] = h; bl[y][0] = l;
-      split_pair(v[2], v[3], h, l); bh[y][1] = h; bl[y][1] = l;
+      th[y] = *reinterpret_cast<const i2v*>(pb[y] + k0);
+      tl[y] = *reinterpret_cast<const i2v*>(pb[y] + plane + k0);
     }
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
@@ -318,9 +316,9 @@ __device__ __forceinline__ void gemm_macro_bx3(const float* pa0, const float* pb
 #pragma unroll
       for (int y = 0; y < 2; ++y) {
         if (y == 1 && !C2) continue;
-        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, ah[x]), __builtin_bit_cast(s4v, bh[y]), acc[x][y], 0, 0, 0);
-        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, ah[x]), __builtin_bit_cast(s4v, bl[y]), acc[x][y], 0, 0, 0);
-        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, al[x]), __builtin_bit_cast(s4v, bh[y]), acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, ah[x]), __builtin_bit_cast(s4v, th[y]), acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, ah[x]), __builtin_bit_cast(s4v, tl[y]), acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, al[x]), __builtin_bit_cast(s4v, th[y]), acc[x][y], 0, 0, 0);
       }
     }
   }
@@ -1071,14 +1069,32 @@ __device__ __forceinline__ int fast_tiles(int nt) {
   return lo | (hi << 16);
 }
 
+// F as two bfloat16 planes (PL: what the bfloat16 form of the second product reads): hi = the upper half of the fp32 word, lo = the upper
+// half of (x - hi); a lane's four values are four ROWS of the tile (2-byte stores) and four consecutive columns of its mirror image (8 bytes)
+__device__ __forceinline__ void plane_store_col(unsigned short* ph, unsigned short* pl, int stride, const f4& a) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const unsigned b = __float_as_uint(a[t]);
+    const float r = a[t] - __uint_as_float(b & 0xffff0000u);
+    ph[t * stride] = (unsigned short)(b >> 16);
+    pl[t * stride] = (unsigned short)(__float_as_uint(r) >> 16);
+  }
+}
+__device__ __forceinline__ void plane_store_row(unsigned short* ph, unsigned short* pl, const f4& a) {
+  int h0, l0, h1, l1;
+  split_pair(a[0], a[1], h0, l0); split_pair(a[2], a[3], h1, l1);
+  *reinterpret_cast<i2v*>(ph) = i2v{h0, h1};
+  *reinterpret_cast<i2v*>(pl) = i2v{l0, l1};
+}
+
 // F = V0^T diag(e) V0 (upper tiles, as lds_gemm_ld<true, false, true, true>) with the first pass in the epilogue: the diagonal tiles
 // publish lam_i = lam0_i + F_ii, then every tile turns its accumulators into E1_ij = F_ij / (lam_j - lam_i) (ph_refine_E's
 // arithmetic with X = I: the same quotients, the same threshold) and stores F (zero diagonal) and E1 (antisymmetric, zero
 // diagonal) with their mirror images as 16-byte rows.  Returns max |E1_ij| (1 for NaN / inf / > kFallbackE).
-template <int LDC>
-__device__ HTA_PH_ATTR float ph_fast_form(int offV, int offF, int offE, int offJit, int offLam0, int offLam, int offRed, int tile, int k4, int D, int LDr) {
+template <int LDC, bool PL>
+__device__ HTA_PH_ATTR float ph_fast_form(int offV, int offF, int offE, int offJit, int offLam0, int offLam, int offRed, int tile, int k4, int D, int LDr, int nt) {
   HTA_LDS_BASE();
-  k4 = HTA_U(k4); D = HTA_U(D);
+  k4 = HTA_U(k4); D = HTA_U(D); nt = HTA_U(nt);
   const int LD = LDC ? LDC : HTA_U(LDr);
   const float* V = lds + HTA_U(offV);
   float* F = lds + HTA_U(offF); float* E = lds + HTA_U(offE);
@@ -1140,10 +1156,18 @@ __device__ HTA_PH_ATTR float ph_fast_form(int offV, int offF, int offE, int offJ
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           ebits = max(ebits, __float_as_uint(e[t]) & 0x7fffffffu);
-          fd[t * LD] = a[t]; ed[t * LD] = e[t];
+          if (!PL) fd[t * LD] = a[t];
+          ed[t * LD] = e[t];
         }
         const f2v n01 = f2v{e[0], e[1]} * f2v{-1.f, -1.f}, n23 = f2v{e[2], e[3]} * f2v{-1.f, -1.f};
-        *reinterpret_cast<f4*>(F + j * LD + 16 * I0 + 4 * lk) = a;
+        if (PL) {
+          unsigned short* Fh = reinterpret_cast<unsigned short*>(F);
+          const int DPh = 16 * nt, plane = DPh * DPh;
+          plane_store_col(Fh + (16 * I0 + 4 * lk) * DPh + j, Fh + plane + (16 * I0 + 4 * lk) * DPh + j, DPh, a);
+          plane_store_row(Fh + j * DPh + 16 * I0 + 4 * lk, Fh + plane + j * DPh + 16 * I0 + 4 * lk, a);
+        } else {
+          *reinterpret_cast<f4*>(F + j * LD + 16 * I0 + 4 * lk) = a;
+        }
         *reinterpret_cast<f4*>(E + j * LD + 16 * I0 + 4 * lk) = f4{n01[0], n01[1], n23[0], n23[1]};
       } else {
         // a diagonal tile holds both triangles of its block: every lane stores its own four elements, no mirror.  (F_ij and F_ji differ
@@ -1154,19 +1178,26 @@ __device__ HTA_PH_ATTR float ph_fast_form(int offV, int offF, int offE, int offJ
         const f2v d01 = lamJ2 - f2v{lamI[0], lamI[1]}, d23 = lamJ2 - f2v{lamI[2], lamI[3]};
         const f2v r01 = {__builtin_amdgcn_rcpf(d01[0]), __builtin_amdgcn_rcpf(d01[1])}, r23 = {__builtin_amdgcn_rcpf(d23[0]), __builtin_amdgcn_rcpf(d23[1])};
         const f2v q01 = f2v{a[0], a[1]} * r01, q23 = f2v{a[2], a[3]} * r23;
-        f4 e, f;
+        f4 e;
         e[0] = (fabsf(a[0]) <= tiny) ? 0.f : q01[0];
         e[1] = (fabsf(a[1]) <= tiny) ? 0.f : q01[1];
         e[2] = (fabsf(a[2]) <= tiny) ? 0.f : q23[0];
         e[3] = (fabsf(a[3]) <= tiny) ? 0.f : q23[1];
         float* fd = F + (16 * I0 + 4 * lk) * LD + j;
         float* ed = E + (16 * I0 + 4 * lk) * LD + j;
+        f4 f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const bool dg = 4 * lk + t == li;
           e[t] = dg ? 0.f : e[t]; f[t] = dg ? 0.f : a[t];
           ebits = max(ebits, __float_as_uint(e[t]) & 0x7fffffffu);
-          fd[t * LD] = f[t]; ed[t * LD] = e[t];
+          if (!PL) fd[t * LD] = f[t];
+          ed[t * LD] = e[t];
+        }
+        if (PL) {
+          unsigned short* Fh = reinterpret_cast<unsigned short*>(F);
+          const int DPh = 16 * nt, plane = DPh * DPh;
+          plane_store_col(Fh + (16 * I0 + 4 * lk) * DPh + j, Fh + plane + (16 * I0 + 4 * lk) * DPh + j, DPh, f);
         }
       }
     }
@@ -1222,7 +1253,7 @@ __device__ HTA_PH_ATTR float ph_fast_second(int offF, int offE, int offLam, int 
   if (active) {
     if (BX3) {
       const float* pa0 = E + (16 * J0 + li) * LD;
-      const float* pb0 = F + (16 * I0 + li) * LD;
+      const unsigned short* pb0 = reinterpret_cast<const unsigned short*>(F) + (16 * I0 + li) * (16 * nt);      // F as bfloat16 planes (ph_fast_form<.., true>)
       if (r2 && c2) gemm_macro_bx3<true, true>(pa0, pb0, nt, LD, acc);
       else if (c2) gemm_macro_bx3<true, false>(pa0, pb0, nt, LD, acc);
       else if (r2) gemm_macro_bx3<false, true>(pa0, pb0, nt, LD, acc);
@@ -1431,6 +1462,9 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
   const int by = bx == 0 ? BS : 0, bz = bx == 2 * BS ? BS : 2 * BS;  // F then E2 | E1
   const uint64_t chain = a.chain_offset + (uint64_t)b;
   __syncthreads();
+#if HTA_TIMING
+  if (threadIdx.x == 0 && blockIdx.x == 0) hta_metric_dbg[31] = clock64() - hta_metric_dbg[24];      // the gap since the previous evaluation's last stamp
+#endif
   HTA_STAMP(0);
   if (tid < DP) {
     const int i = opaque_tid();
@@ -1452,8 +1486,10 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
   HTA_STAMP(1);
   if (res_xm < 0) ph_fast_vt(bx, oY, oM, oD, DP, LD);
   HTA_STAMP(2);
-  const float e1 = LD == kLdCfg3 ? ph_fast_form<kLdCfg3>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD)
-                                 : ph_fast_form<0>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD);
+  const bool planes = bx3 && LD == kLdCfg3;                          // F as bfloat16 planes for the bfloat16 form of the second product
+  const float e1 = planes ? ph_fast_form<kLdCfg3, true>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD, nt)
+                   : LD == kLdCfg3 ? ph_fast_form<kLdCfg3, false>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD, nt)
+                                   : ph_fast_form<0, false>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD, nt);
   HTA_STAMP(3);
   if (!(e1 <= kSecondE)) return false;
   const bool skip2 = e1 <= kConvE;                                   // (no jitter: F = 0, the shared basis is the answer)
@@ -1461,7 +1497,7 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
     float e2;
     // (the bfloat16 form only where the leading dimension is a compile-time constant: the run-time instance needs four registers beyond
     // the caller-saved set, i.e. a save / restore through scratch memory per call that costs more than the product saves)
-    if (bx3 && LD == kLdCfg3) e2 = ph_fast_second<kLdCfg3, true>(by, bz, oLam, oD + DP, oRed, nt, tiles, k4, D, LD);
+    if (planes) e2 = ph_fast_second<kLdCfg3, true>(by, bz, oLam, oD + DP, oRed, nt, tiles, k4, D, LD);
     else e2 = LD == kLdCfg3 ? ph_fast_second<kLdCfg3, false>(by, bz, oLam, oD + DP, oRed, nt, tiles, k4, D, LD)
                             : ph_fast_second<0, false>(by, bz, oLam, oD + DP, oRed, nt, tiles, k4, D, LD);
     if (!(e2 <= kConvE)) return false;
@@ -1878,10 +1914,92 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
 // evaluation code as metric_warm_mfma_kernel (metric_warm_system), same arithmetic: bit-identical to the launch sequence
 // (tests/test_gpu_rmhmc.py::test_trajectory_kernel_equals_the_launch_sequence); what goes away is 57 launches per trajectory
 // with their ramps and the gaps between them (profiles/r04q: 12 % of the step).
+// The evaluations of a trajectory that are NOT the fast solve - the momentum draw, every evaluation of the form that keeps the state in the
+// caller's coordinates, the resident form's rare way out - run out of line and read the kernel's arguments again from the kernel-argument
+// segment: inlined into the kernel they kept all ~90 argument dwords live across the resident loop (404 scalar registers parked in vector
+// lanes, a v_readlane per use - and with 16 waves on the CU every instruction a wave executes costs the workgroup 16 cycles).
+// op: the evaluation's index in the trajectory (0 draw, 1 H_old, 2 .. 4 L + 1 half steps, 4 L + 2 H_new); mode 0: the state in global memory
+// (t.th / t.pm / t.thc / t.pmc), the copies / the binding rotation after the evaluation included; mode 1: the state is resident in LDS in
+// eigen-coordinates - state out, evaluation, state in.  Returns the buffer that holds V0 afterwards (-1: none).
+constexpr int kTrajArgOff = (int)((sizeof(MetricArgsT<float>) + 7) / 8 * 8);
+typedef const __attribute__((address_space(4))) char* kernarg_ptr;
+// (the segment pointer is read in the KERNEL and handed down: __builtin_amdgcn_kernarg_segment_ptr() in a called function returned null here)
+template <typename S> __device__ __forceinline__ S load_kernarg(kernarg_ptr ka, int off) {      // dword by dword from the constant address space: scalar loads
+  S v;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) uint32_t* kp;
+  kp src = (kp)(ka + off);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(S) / 4); ++i) dst[i] = src[i];
+#else
+  memset(&v, 0, sizeof(v));
+#endif
+  return v;
+}
+static_assert(alignof(MetricTrajArgs) == 8 && alignof(MetricArgsT<float>) == 8, "kernel-argument layout of metric_traj_mfma_kernel");
+__device__ __attribute__((noinline)) int traj_general_eval(kernarg_ptr ka, int DP, int LD, int64_t b, int vres, int op, int second, int tiles, int mode) {
+  {                                                                 // (uniform: an argument arrives in vector registers)
+    const uint64_t u = (uint64_t)ka;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    ka = (kernarg_ptr)(((uint64_t)hi << 32) | lo);
+  }
+  const MetricArgsT<float> a = load_kernarg<MetricArgsT<float>>(ka, 0);
+  const MetricTrajArgs t = load_kernarg<MetricTrajArgs>(ka, kTrajArgOff);
+  DP = HTA_U(DP); LD = HTA_U(LD); vres = HTA_U(vres); op = HTA_U(op); second = HTA_U(second); mode = HTA_U(mode);
+  const int D = a.D, nops = 4 * t.L + 3;
+  const int BS = DP * LD > 1024 ? DP * LD : 1024;
+  const int oY = 3 * BS + 4 * DP, oSt = 3 * BS + 8 * DP + MT / 64 + kFastState;
+  const int sTh = oSt, sP = oSt + DP, sThc = oSt + 2 * DP, sPc = oSt + 3 * DP;
+  MetricArgsT<float> o = a;
+  int j = -1;
+  if (op == 0) { o.sub = 0; o.p_out = t.pm; }                                                  // gibbs: p ~ N(0, G(theta))  S:183-184
+  else if (op == 1) { o.sub = 1; o.X = mode ? t.th : t.cur; o.m = t.pm; o.H_out = t.H0; }      // H_old  S:971
+  else if (op == nops - 1) { o.sub = 2u + 8u * (uint32_t)t.L; o.X = t.th; o.m = t.pm; o.H_out = t.H1; o.logp_out = t.lp1; }   // H_new  S:989
+  else {
+    const int q = op - 2, l = q >> 2;
+    j = q & 3;
+    const bool fa = j == 0 || j == 3;                                                          // phi_A/2 (S:429-430, S:457-458) : phi_B/2
+    o.sub = 2u + 8u * (uint32_t)l + (j == 0 ? 1u : j == 1 ? 2u : j == 2 ? 4u : 7u);
+    o.X = fa ? t.th : t.thc; o.m = fa ? t.pmc : t.pm; o.upd_x = fa ? t.thc : t.th; o.upd_g = fa ? t.pm : t.pmc;
+    o.cx = t.eh; o.cg = -t.eh;
+  }
+  const int64_t e0 = b * D;
+  if (mode == 1) {
+    __syncthreads();
+    if (vres < 0) { ph_stage(a.V0, BS, D, DP, LD); vres = BS; __syncthreads(); }
+    ph_res_out(vres, sTh, sP, t.th + e0, t.pm + e0, a.mu, D, DP, LD);
+    ph_res_out(vres, sThc, sPc, t.thc + e0, t.pmc + e0, a.mu, D, DP, LD);
+    __syncthreads();
+    metric_warm_system(o, DP, LD, b, vres, second & 2, tiles);                                 // (bit 0 off: not the fast solve again)
+    __syncthreads();
+    if (vres < 0) { ph_stage(a.V0, BS, D, DP, LD); vres = BS; }
+    res_in(vres, oY, sTh, sP, t.th + e0, t.pm + e0, a.mu, D, DP, LD);
+    res_in(vres, oY, sThc, sPc, t.thc + e0, t.pmc + e0, a.mu, D, DP, LD);
+    return vres;
+  }
+  metric_warm_system(o, DP, LD, b, vres, second, tiles);
+  if ((op == 1 || j == 1) && !(second & 8)) {                                                  // (second & 8: the caller is resident and does this itself)
+    __syncthreads();
+    const int i = opaque_tid();
+    if (i < D) {
+      const int64_t e = e0 + i;
+      if (op == 1) {                                                                           // S:425-426
+        const float x = t.cur[e];
+        t.th[e] = x; t.thc[e] = x; t.pmc[e] = t.pm[e];
+      } else {
+        phi_c_elem<float>(t.th[e], t.pm[e], t.thc[e], t.pmc[e], t.c, t.s);                     // phi_C  S:447-450
+      }
+    }
+  }
+  return vres;
+}
+
 __global__ __launch_bounds__(MT) void metric_traj_mfma_kernel(MetricArgsT<float> a, MetricTrajArgs t, int DP, int LD, int second) {
   const int D = a.D;
   const int nops = 4 * t.L + 3;
   const int tiles = fast_tiles(DP / 16);
+  const kernarg_ptr ka = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
   // RESIDENT mode (round 6, second & 4: tuning key "metric_resident"): after the momentum draw the chain's four state vectors are taken
   // into the eigenbasis ONCE - theta' = V0^T (theta - mu), p' = V0^T p - and live in LDS for the trajectory: a solve evaluation then has
   // no V0 product at either end (m' and d' ARE the state, x' and lam0 d' update it element-wise), no global read or write but its
@@ -1896,73 +2014,47 @@ __global__ __launch_bounds__(MT) void metric_traj_mfma_kernel(MetricArgsT<float>
   float* const lds0 = reinterpret_cast<float*>(smem_raw);
   for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
     int vres = -1;                       // the buffer a solve left the staged V0 in: the next evaluation starts from it
-    for (int op = 0; op < nops; ++op) {
+    if (!resident) {
+      for (int op = 0; op < nops; ++op) vres = traj_general_eval(ka, DP, LD, b, vres, op, second, tiles, 0);
+      continue;
+    }
+    const int64_t e0 = b * D;
+    vres = traj_general_eval(ka, DP, LD, b, vres, 0, second, tiles, 0);                        // the momentum draw
+    // into the eigenbasis: (theta', p') = V0^T (cur - mu, pm); theta~' = theta', p~' = p'
+    __syncthreads();
+    if (vres < 0) { ph_stage(a.V0, BS, D, DP, LD); vres = BS; }
+    res_in(vres, oY, sTh, sP, t.cur + e0, t.pm + e0, a.mu, D, DP, LD);
+    if ((int)threadIdx.x < DP) { const int i = opaque_tid(); lds0[sThc + i] = lds0[sTh + i]; lds0[sPc + i] = lds0[sP + i]; }
+    __syncthreads();
+    for (int op = 1; op < nops; ++op) {
+      // the fields the fast solve reads (everything else of `a` is dead here)
       MetricArgsT<float> o = a;
+      o.X = t.cur; o.m = t.pm;                                                                 // (non-null: the operands themselves are the resident vectors)
       int j = -1;
       bool fa = false;
-      if (op == 0) { o.sub = 0; o.p_out = t.pm; }                                                  // gibbs: p ~ N(0, G(theta))  S:183-184
-      else if (op == 1) { o.sub = 1; o.X = t.cur; o.m = t.pm; o.H_out = t.H0; }                    // H_old  S:971
-      else if (op == nops - 1) { o.sub = 2u + 8u * (uint32_t)t.L; o.X = t.th; o.m = t.pm; o.H_out = t.H1; o.logp_out = t.lp1; }   // H_new  S:989
+      if (op == 1) { o.sub = 1; o.H_out = t.H0; }                                              // H_old  S:971
+      else if (op == nops - 1) { o.sub = 2u + 8u * (uint32_t)t.L; o.H_out = t.H1; o.logp_out = t.lp1; }   // H_new  S:989
       else {
         const int q = op - 2, l = q >> 2;
         j = q & 3;
-        fa = j == 0 || j == 3;                                                                     // phi_A/2 (S:429-430, S:457-458) : phi_B/2
+        fa = j == 0 || j == 3;                                                                 // phi_A/2 (S:429-430, S:457-458) : phi_B/2
         o.sub = 2u + 8u * (uint32_t)l + (j == 0 ? 1u : j == 1 ? 2u : j == 2 ? 4u : 7u);
-        o.X = fa ? t.th : t.thc; o.m = fa ? t.pmc : t.pm; o.upd_x = fa ? t.thc : t.th; o.upd_g = fa ? t.pm : t.pmc;
         o.cx = t.eh; o.cg = -t.eh;
       }
-      if (resident && op > 0) {
-        const int64_t e0 = b * D;
-        if (op == 1) {                                             // into the eigenbasis: (theta', p') = V0^T (cur - mu, pm); theta~' = theta', p~' = p'
-          __syncthreads();
-          if (vres < 0) { ph_stage(a.V0, BS, D, DP, LD); vres = BS; }
-          res_in(vres, oY, sTh, sP, t.cur + e0, t.pm + e0, a.mu, D, DP, LD);
-          if ((int)threadIdx.x < DP) { const int i = opaque_tid(); lds0[sThc + i] = lds0[sTh + i]; lds0[sPc + i] = lds0[sP + i]; }
-          __syncthreads();
-        }
-        const bool step = op > 1 && op < nops - 1;
-        const int rx = (step && !fa) ? sThc : sTh, rm = (step && fa) ? sPc : sP;
-        const int upd = step ? (((fa ? sThc : sTh) >> 2) | (((fa ? sP : sPc) >> 2) << 16)) : 0;
-        if (!metric_fast_solve(o, DP, LD, b, vres, (second & 2) != 0, tiles, (rx >> 2) | ((rm >> 2) << 16), upd)) {
-          // (rare: a first pass above kSecondE, a non-finite state) the general sequence on the caller's coordinates: state out, evaluation, state in
-          __syncthreads();
-          if (vres < 0) { ph_stage(a.V0, BS, D, DP, LD); vres = BS; __syncthreads(); }
-          ph_res_out(vres, sTh, sP, t.th + e0, t.pm + e0, a.mu, D, DP, LD);
-          ph_res_out(vres, sThc, sPc, t.thc + e0, t.pmc + e0, a.mu, D, DP, LD);
-          __syncthreads();
-          if (op == 1) o.X = t.th;
-          metric_warm_system(o, DP, LD, b, vres, second & 2, tiles);                               // (bit 0 off: not the fast solve again)
-          __syncthreads();
-          if (vres < 0) { ph_stage(a.V0, BS, D, DP, LD); vres = BS; }
-          res_in(vres, oY, sTh, sP, t.th + e0, t.pm + e0, a.mu, D, DP, LD);
-          res_in(vres, oY, sThc, sPc, t.thc + e0, t.pmc + e0, a.mu, D, DP, LD);
-        }
-        if (j == 1) {                                                                              // phi_C  S:447-450 (element-wise: any orthonormal basis)
-          __syncthreads();
-          const int i = opaque_tid();
-          if (i < D) phi_c_elem<float>(lds0[sTh + i], lds0[sP + i], lds0[sThc + i], lds0[sPc + i], t.c, t.s);
-        }
-        if (op == nops - 1) {                                      // back: theta = mu + V0 theta' (and the final momentum, as the other form leaves it)
-          __syncthreads();
-          ph_res_out(vres, sTh, sP, t.th + e0, t.pm + e0, a.mu, D, DP, LD);
-        }
-        continue;
-      }
-      metric_warm_system(o, DP, LD, b, vres, second, tiles);
-      if (op == 1 || j == 1) {
+      const bool step = j >= 0;
+      const int rx = (step && !fa) ? sThc : sTh, rm = (step && fa) ? sPc : sP;
+      const int upd = step ? (((fa ? sThc : sTh) >> 2) | (((fa ? sP : sPc) >> 2) << 16)) : 0;
+      if (!metric_fast_solve(o, DP, LD, b, vres, (second & 2) != 0, tiles, (rx >> 2) | ((rm >> 2) << 16), upd))
+        vres = traj_general_eval(ka, DP, LD, b, vres, op, second | 8, tiles, 1);                   // (rare: a first pass above kSecondE, a non-finite state)
+      if (j == 1) {                                                                            // phi_C  S:447-450 (element-wise: any orthonormal basis)
         __syncthreads();
         const int i = opaque_tid();
-        if (i < D) {
-          const int64_t e = b * D + i;
-          if (op == 1) {                                                                           // S:425-426
-            const float x = t.cur[e];
-            t.th[e] = x; t.thc[e] = x; t.pmc[e] = t.pm[e];
-          } else {
-            phi_c_elem<float>(t.th[e], t.pm[e], t.thc[e], t.pmc[e], t.c, t.s);                     // phi_C  S:447-450
-          }
-        }
+        if (i < D) phi_c_elem<float>(lds0[sTh + i], lds0[sP + i], lds0[sThc + i], lds0[sPc + i], t.c, t.s);
       }
     }
+    // back: theta = mu + V0 theta' (and the final momentum, as the other form leaves it)
+    __syncthreads();
+    ph_res_out(vres, sTh, sP, t.th + e0, t.pm + e0, a.mu, D, DP, LD);
   }
 }
 

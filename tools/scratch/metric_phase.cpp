@@ -34,15 +34,23 @@ int main(int argc, char** argv) {
   a.B = B; a.D = D; a.metric = 1; a.Hs = dP; a.hs_stride = 0; a.alpha = 1e6; a.has_jitter = jitter > 0; a.jitter = jitter; a.seed = 5; a.draw = 1; a.sub = 2;
   a.Pm = dP; a.mu = dmu; a.V0 = dV0; a.lam0 = dl;
   if (gibbs) a.p_out = dp; else { a.X = dX; a.m = dm; a.upd_x = dx; a.cx = 0.05; a.upd_g = dg; a.cg = -0.05; a.H_out = dH; }
+  // argv[6] = L > 0: the TRAJECTORY kernel instead (round 6: momentum draw, H_old, 4 L half steps, H_new in one launch; the stamps that remain
+  // are the last evaluation's, slot 31 = the gap between the previous evaluation's last stamp and this one's first)
+  const int trajL = argc > 6 ? atoi(argv[6]) : 0;
+  hta::g_metric_resident = argc > 7 ? atoi(argv[7]) : 1;
+  float *dth, *dthc, *dpmc, *dH1, *dlp;
+  hipMalloc(&dth, B * D * 4); hipMalloc(&dthc, B * D * 4); hipMalloc(&dpmc, B * D * 4); hipMalloc(&dH1, B * 4); hipMalloc(&dlp, B * 4);
+  hta::MetricTrajArgs ta{dX, dth, dp, dthc, dpmc, dH, dH1, dlp, trajL, 0.05, cosf(2.f), sinf(2.f)};
+  if (trajL > 0) { a.X = nullptr; a.m = nullptr; a.upd_x = nullptr; a.upd_g = nullptr; a.H_out = nullptr; a.p_out = nullptr; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0, 0);
-    for (int k = 0; k < 10; ++k) { int rc = hta::metric_warm_mfma(a, 0); if (rc) { printf("error %s\n", hta_last_error()); return 1; } }
+    for (int k = 0; k < 10; ++k) { int rc = trajL > 0 ? hta::metric_traj_mfma(a, ta, 0) : hta::metric_warm_mfma(a, 0); if (rc) { printf("error %s\n", hta_last_error()); return 1; } }
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("D=%d B=%d gibbs=%d jitter=%g second=%d: %.1f us per launch\n", D, B, gibbs, jitter, hta::g_metric_second, ms * 100);
   }
-  long long t[32] = {0}; { hipError_t e = hipMemcpyFromSymbol(t, HIP_SYMBOL(hta::hta_metric_dbg), sizeof(t)); if (e != hipSuccess) printf("hipMemcpyFromSymbol: %s\n", hipGetErrorString(e)); }
+  long long t[32] = {0}; (void)dx; { hipError_t e = hipMemcpyFromSymbol(t, HIP_SYMBOL(hta::hta_metric_dbg), sizeof(t)); if (e != hipSuccess) printf("hipMemcpyFromSymbol: %s\n", hipGetErrorString(e)); }
   const char* names[32] = {"start", "operands+V0 stage", "logp + V0^T m", "formation", "it0 begin", "it0 gemms", "it0 E", "it0 X", "it1 begin", "it1 products (F E1 | T,S,Gm)", "it1 E", "it1 X update",
                            "it2 begin", "it2 gemms", "it2 E", "it2 X", "it3 begin", "it3 gemms", "it3 E", "it3 X", "refine end", "softabs+solve", "G assembly", "cholesky", "end"};
   long long prev = t[0];
@@ -51,6 +59,7 @@ int main(int argc, char** argv) {
     if (t[k] > prev) { printf("  %-22s %8lld cycles\n", names[k], t[k] - prev); prev = t[k]; }
   }
   printf("  total %lld cycles\n", prev - t[0]);
+  if (trajL > 0) printf("  trajectory kernel, L = %d, resident = %d: gap before this evaluation %lld cycles; per evaluation (launch time / (4 L + 3)) see above\n", trajL, hta::g_metric_resident, t[31]);
   printf("  formation product, wave 0 (cycles since the phase began): entry %lld | k loop begins %lld | k loop ends %lld | returned %lld | after the barrier %lld | diagonal added %lld | phase ends %lld\n",
          t[25] - t[2], t[26] - t[2], t[27] - t[2], t[28] - t[2], t[29] - t[2], t[30] - t[2], t[3] - t[2]);
   if (!gibbs)
