@@ -70,10 +70,13 @@ def test_spill_budget_of_the_hot_kernels(kernels):
         assert kernels[k]["spill"] <= 8 and kernels[k]["scratch"] <= 48, (k, kernels[k])
     # round 4: the trajectory kernel of the eigendecomposition route (the same evaluation body inside a loop over the trajectory's
     # 4 L + 3 evaluations): nothing of the loop's state lives in scratch
+    # (round 6: the kernel's own body parks nothing; the 128 bytes are the stack frame of traj_general_eval, the out-of-line general
+    # evaluations - momentum draw, the rare way out of the resident loop -, which the resident loop never touches:
+    # test_fast_solve_phase_functions_stay_inside_the_caller_saved_registers checks the body's instructions)
     hits = _find(kernels, "metric_traj_mfma_kernel")
     assert hits
     for k in hits:
-        assert kernels[k]["spill"] <= 2 and kernels[k]["scratch"] <= 32, (k, kernels[k])
+        assert kernels[k]["spill"] == 0 and kernels[k]["scratch"] <= 128, (k, kernels[k])
     # the notebook-model kernel (round 3): its loads / stores / momentum draws run out of line and the momentum's W2 share lives
     # in a workspace, so the code object's scratch is a stack for those calls (three 160-byte state vectors and change), not a
     # home for the gradient pass's values: < 1 KB per lane (the first version: 2.4 KB and six serial reloads in every kick)
@@ -199,7 +202,8 @@ def test_fast_solve_phase_functions_stay_inside_the_caller_saved_registers():
     obj = os.path.join(ROOT, "hamiltorch_amd", "csrc", "build", "rmhmc_metric_mfma.o")
     if not os.path.exists(obj):
         pytest.skip("needs the object file of rmhmc_metric_mfma.hip")
-    for pat in ["ph_fast_vt", "ph_fast_formILi116E", "ph_fast_secondILi116ELb1E", "ph_fast_secondILi116ELb0E", "ph_fast_chain"]:
+    for pat in ["ph_fast_vt", "ph_fast_formILi116ELb1E", "ph_fast_formILi116ELb0E", "ph_fast_secondILi116ELb1E", "ph_fast_secondILi116ELb0E", "ph_fast_chain",
+                "metric_traj_mfma_kernel"]:
         name, lines = isa_of.kernel_lines(obj, pat)
         assert not any(i.startswith("scratch_") for _, i in lines), name
     # the bfloat16 instance really is one: three v_mfma_f32_16x16x32_bf16 per tile and 32 indices in the four macro-tile shapes (12 + 6 + 6 + 3 static instructions), none of the fp32 form
