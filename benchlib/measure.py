@@ -92,6 +92,10 @@ def result_of(w, W, dt, call_ms, prof_ms, prof_n, steps, warmup, world):
         dom = phys["kernels"][phys["dominant_kernel"]]
         chain_steps = w.C * (phys.get("trajectories_per_step") or w.T) * W.L
         issued = phys["mfma_tflops_issued"] * 1e12 * dom["ms_per_step"] * 1e-3 / chain_steps
+        if phys.get("mfma_bf16_tflops_issued"):      # round 6 (cfg3-eig): a product run as THREE bfloat16 products counts as one fp32 product's flops
+            bf = phys["mfma_bf16_tflops_issued"] * 1e12 * dom["ms_per_step"] * 1e-3 / chain_steps
+            roof["issued_bf16_flops_per_chain_step"] = bf
+            issued += bf / 3.0
         roof["issued_flops_per_chain_step"] = issued
         roof["padding"] = issued / roof["useful_flops_per_chain_step"]
         roof["mfma_issued_over_useful"] = roof["padding"]

@@ -108,6 +108,18 @@ def rmhmc_eig_useful_flops(D, L):
     return ((4 * L + 3) * 3 + 3 + 1.0 / 3) * D ** 3 / float(L)
 
 
+BF16_OVER_FP32_MATRIX_PEAK = 16.0       # MI355X_MICROARCH.md: dense bf16 2.5 PFLOP/s = 16 x the fp32 matrix peak
+
+
+def rmhmc_eig_pipe_time_flops(D, L, bx3=True):
+    """The same work priced in fp32-MATRIX-PIPE TIME (round 6): in a solve evaluation the second pass's product F E1 (2 D^3) runs as three
+    bfloat16 products of split operands ("metric_bx3") - 3 x 2 D^3 bfloat16 flops at 16 x the fp32 rate = 0.375 D^3 fp32-pipe equivalents -
+    beside the formation's D^3 in fp32; the momentum draw's evaluation (general sequence) stays fp32: 6.33 D^3.  useful / fp32 peak no
+    longer bounds by the pipe-busy share; this figure / fp32 peak does."""
+    second = 2.0 * (3.0 / BF16_OVER_FP32_MATRIX_PEAK if bx3 else 1.0)
+    return ((4 * L + 2) * (1.0 + second) + 6.0 + 1.0 / 3) * D ** 3 / float(L)
+
+
 # ---------------------------------------------------------------------------------------------------
 # Bayesian MLPs (cfg4, nbmlp)
 # ---------------------------------------------------------------------------------------------------

@@ -158,7 +158,8 @@ class Cfg3:
     def roof_kernel(self):      # the trajectory kernel the library picks at this chain count (csrc/rmhmc_fused.hip dispatch)
         if self.jacobi:
             return ("metric_traj_mfma_kernel (one launch per trajectory: a chain's workgroup runs its 4 L + 3 metric evaluations - "
-                    "eigenvector refinement on v_mfma_f32_16x16x4_f32 - back to back) + mh_select_kernel")
+                    "eigenvector refinement: formation on v_mfma_f32_16x16x4_f32, second-order product on 3 x v_mfma_f32_16x16x32_bf16, "
+                    "state resident in LDS in eigen-coordinates - back to back) + mh_select_kernel")
         if self.C <= 256:
             return ("rmhmc_uvc_kernel (one chain per workgroup: state set and copy as columns of v_mfma_f32_4x4x1_16b, one value per "
                     "lane, three product phases per step)")
@@ -209,9 +210,15 @@ class Cfg3:
         useful = self.useful_flops_per_unit()
         tf = useful * units / sec / 1e12
         tf_survey = models.rmhmc_survey_flops_per_chain_step(self.D) * units / sec / 1e12
+        extra = {}
+        if self.jacobi:      # round 6: F E1 runs as three bfloat16 products - the fp32-equivalent fraction is not a pipe utilisation any more
+            pt = models.rmhmc_eig_pipe_time_flops(self.D, self.L) * units / sec / 1e12
+            extra = {"pipe_time_frac": pt / FP32_PEAK_TFLOPS,
+                     "pipe_time_note": "useful work priced in fp32-matrix-pipe time (formation D^3 in fp32 + F E1 as 3 x 2 D^3 bfloat16 flops at "
+                                       "16 x the rate): the figure the pipe-busy counter bounds; `frac` prices every useful flop at the fp32 peak"}
         return {"bound": "mfma", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
                 "traffic": None, "kernel": self.roof_kernel, "kernel_ms_per_step": kernel_ms, "call_ms": call_ms,
-                "launches_per_step": prof_n / max(1, steps),
+                "launches_per_step": prof_n / max(1, steps), **extra,
                 "useful_flops_per_chain_step": useful, "issued_model_flops_per_chain_step": self.issued_model_flops_per_unit(),
                 "survey_8d": {"flops_per_chain_step": models.rmhmc_survey_flops_per_chain_step(self.D), "achieved": tf_survey,
                               "ratio_to_peak": tf_survey / FP32_PEAK_TFLOPS,

@@ -6,7 +6,7 @@ Each <dir> holds, for ONE bench.py command line, the csv files of three separate
   stats/   --kernel-trace --stats                      -> *kernel_trace.csv (durations, grid, workgroup size)
   pmc_rd/  --pmc FETCH_SIZE                            -> *counter_collection.csv
   pmc_wr/  --pmc WRITE_SIZE
-  pmc_sq/  --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES GRBM_GUI_ACTIVE
+  pmc_sq/  --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVES GRBM_GUI_ACTIVE
 Counters are per launch, summed over the chip.  FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 tallies 128-byte read
 requests at 64 bytes); WRITE_SIZE is taken as reported.  Both are KiB."""
 import collections
@@ -70,6 +70,8 @@ def main():
                 simd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * N_SIMDS           # the counter sums the 8 XCDs
                 rec["mfma_busy_frac_of_all_simd_cycles"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / simd_cycles
                 rec["mfma_tflops_issued"] = c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512.0 / (rec["ms_per_launch"] * 1e-3) / 1e12
+                if c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) > 0:      # round 6: the metric kernel's second-order product
+                    rec["mfma_bf16_tflops_issued"] = c["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512.0 / (rec["ms_per_launch"] * 1e-3) / 1e12
             if "SQ_INSTS_VALU" in c and c.get("SQ_WAVE_CYCLES", 0) > 0:      # the VALU kernels (compiled callbacks): optional fourth pass
                 rec["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / max(1.0, c.get("SQ_WAVES", waves))
                 rec["valu_active_frac_of_wave_cycles"] = c.get("SQ_ACTIVE_INST_VALU", 0.0) / c["SQ_WAVE_CYCLES"]
@@ -83,6 +85,7 @@ def main():
                     "simds_occupied_frac": kernels[dom]["simds_occupied_frac"],
                     "mfma_busy_frac": kernels[dom].get("mfma_busy_frac_of_all_simd_cycles"),
                     "mfma_tflops_issued": kernels[dom].get("mfma_tflops_issued"),
+                    "mfma_bf16_tflops_issued": kernels[dom].get("mfma_bf16_tflops_issued"),
                     "valu_active_frac": kernels[dom].get("valu_active_frac_of_wave_cycles"),
                     "valu_insts_per_wave": kernels[dom].get("valu_insts_per_wave"),
                     "kernels": kernels, "source": meta.get("source", "tools/physical.sh")}

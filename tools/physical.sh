@@ -23,7 +23,7 @@ one() {  # key steps warmup traj env -- bench args
   env $envs timeout 120 rocprofv3 --kernel-trace --stats -f csv -d $d/stats -o s -- $cmd > $d/bench.json 2> /dev/null
   env $envs timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $d/pmc_rd -o r -- $cmd > /dev/null 2>&1
   env $envs timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $d/pmc_wr -o w -- $cmd > /dev/null 2>&1
-  env $envs timeout 120 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES GRBM_GUI_ACTIVE -f csv -d $d/pmc_sq -o q -- $cmd > /dev/null 2>&1
+  env $envs timeout 120 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVES GRBM_GUI_ACTIVE -f csv -d $d/pmc_sq -o q -- $cmd > /dev/null 2>&1
   case $key in funnel*)      # the compiled-callback kernels are VALU code: instruction count and VALU-active share of the waves' cycles
     env $envs timeout 120 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES -f csv -d $d/pmc_valu -o v -- $cmd > /dev/null 2>&1;;
   esac
