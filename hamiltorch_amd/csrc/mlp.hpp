@@ -37,6 +37,28 @@ __device__ __forceinline__ void split_stage(int integ, int M, int L, int st, T e
   if (integ == HTA_SPLIT_KMID) dr = (s2 == M - 1) ? eps : (T)0;
   else dr = (s2 == M - 1 || s2 == 2 * M - 1) ? (T)0 : eps / (T)((M - 1) * 2);
 }
+// The same table without the per-stage integer modulo and floating-point divisions (round 6: on BASELINE config 4 a gradient pass is 9.5 k
+// cycles and the stage bookkeeping between two passes - `st % (2 M)` and `eps / (2 (M - 1))` expand to ~60 vector instructions that all 14
+// waves of the CU execute - was a fifth of the kernel's time, profiles/r06l_cfg4_ticks.txt): the plan holds the quotients, computed once with
+// the same fp32 operations (bit-identical stages), and the caller carries s2 = st mod 2 M along (split_next_s2).
+template <typename T> struct SplitPlan { int integ, M, L, M2; T eps, heps, epsM, epsS; bool plain; };
+template <typename T> __device__ __forceinline__ SplitPlan<T> split_plan(int integ, int M, int L, T eps) {
+  SplitPlan<T> p;
+  p.integ = integ; p.M = M; p.L = L; p.M2 = 2 * M; p.eps = eps; p.heps = (T)0.5 * eps;
+  p.epsM = eps / (T)M; p.epsS = M > 1 ? eps / (T)((M - 1) * 2) : (T)0;
+  p.plain = integ == HTA_SPLIT_SYMMETRIC && M == 1;
+  return p;
+}
+__device__ __forceinline__ int split_next_s2(int s2, int M2) { return s2 + 1 == M2 ? 0 : s2 + 1; }
+template <typename T>
+__device__ __forceinline__ void split_stage_at(const SplitPlan<T>& p, int st, int s2, const int* perm, int& m, T& kick, T& dr) {
+  if (p.plain) { m = 0; kick = (st == 0) ? p.heps : p.eps; dr = (st < p.L) ? p.eps : (T)0; return; }
+  kick = p.heps;
+  if (p.integ == HTA_SPLIT_RAND) { m = perm[s2 >> 1]; dr = (s2 & 1) ? (T)0 : p.epsM; return; }
+  m = (s2 < p.M) ? s2 : p.M2 - 1 - s2;
+  if (p.integ == HTA_SPLIT_KMID) dr = (s2 == p.M - 1) ? p.eps : (T)0;
+  else dr = (s2 == p.M - 1 || s2 == p.M2 - 1) ? (T)0 : p.epsS;
+}
 // Gradient reuse between stages (round 3).  A stage that kicks WITHOUT a drift is followed, in the reference's loops, by a stage
 // that evaluates the SAME subset at the SAME parameters: the turning point of the symmetric scheme (m = M-1 closes the forward
 // sweep, S:501-517, and opens the backward one, S:519-535) and its step boundary (m = 0 closes a step and opens the next);

@@ -416,6 +416,7 @@ __global__ __launch_bounds__(NTMAX, NC == 1 ? 4 : 2) void mlp_mfma_kernel(MlpArg
     for (int k = 0; k < NC; ++k) rejected[k] = 0;
     const float eps = a.eps, heps = 0.5f * a.eps;
     const int M = a.M;
+    const SplitPlan<float> plan = split_plan<float>(a.integ, M, a.L, eps);
     for (int tr = 0; tr < a.n_traj; ++tr) {
       const int n = a.traj_offset + tr;
       // ---- gibbs (S:185-186 / S:200-201); copies of a parameter draw the same Philox element
@@ -444,9 +445,9 @@ __global__ __launch_bounds__(NTMAX, NC == 1 ? 4 : 2) void mlp_mfma_kernel(MlpArg
         __syncthreads();
       }
       int prev_m = -1; float prev_dr = 1.0f;
-      for (int st = 0; st < nstage; ++st) {
+      for (int st = 0, s2 = 0; st < nstage; ++st, s2 = split_next_s2(s2, plan.M2)) {
         int m; float kick, dr;
-        split_stage<float>(a.integ, M, a.L, st, eps, perm, m, kick, dr);
+        split_stage_at<float>(plan, st, s2, perm, m, kick, dr);
         const int lo = m * a.Nb;
         // the same subset at the same parameters as the stage before (no drift since): its gradient is still in `gr` (mlp.hpp)
         if (!split_stage_reuses<float>(prev_m, prev_dr, m)) ch.grad_range(q, lo, lo + a.Nb, gr);
