@@ -100,12 +100,13 @@ def rmhmc_closed_form_issued_flops(D, L, K, chains_per_group, deferred=False):
     return 4 * (per_step + per_traj / float(L)) * MFMA_4X4X1_FLOPS / chains_per_group
 
 
-def rmhmc_eig_useful_flops(D, L):
+def rmhmc_eig_useful_flops(D, L, sqrtdraw=True):
     """The eigendecomposition route as it runs since round 4 (csrc/rmhmc_metric_mfma.hip: refinement of a shared eigenbasis): per
     solve evaluation the formation A = V0^T diag(e) V0 (symmetric: D^3) and the closed-form second pass F E1 (2 D^3); 4 L + 3
-    evaluations per trajectory, one of which (the momentum draw) adds Q = V0 X (2 D^3), G = Q diag Q^T (symmetric: D^3) and a
-    Cholesky (D^3 / 3).  The vector phases (matrix-vector products, soft-abs, solves: O(D^2)) are not counted."""
-    return ((4 * L + 3) * 3 + 3 + 1.0 / 3) * D ** 3 / float(L)
+    evaluations per trajectory.  Round 6: the momentum draw is solve-shaped as well (p = G^(1/2) z, "metric_sqrtdraw"); with
+    sqrtdraw=False it adds Q = V0 X (2 D^3), G = Q diag Q^T (symmetric: D^3) and a Cholesky (D^3 / 3), as rounds 4-5 ran it.
+    The vector phases (matrix-vector products, soft-abs, solves: O(D^2)) are not counted."""
+    return ((4 * L + 3) * 3 + (0.0 if sqrtdraw else 3 + 1.0 / 3)) * D ** 3 / float(L)
 
 
 BF16_OVER_FP32_MATRIX_PEAK = 16.0       # MI355X_MICROARCH.md: dense bf16 2.5 PFLOP/s = 16 x the fp32 matrix peak
@@ -114,10 +115,10 @@ BF16_OVER_FP32_MATRIX_PEAK = 16.0       # MI355X_MICROARCH.md: dense bf16 2.5 PF
 def rmhmc_eig_pipe_time_flops(D, L, bx3=True):
     """The same work priced in fp32-MATRIX-PIPE TIME (round 6): in a solve evaluation the second pass's product F E1 (2 D^3) runs as three
     bfloat16 products of split operands ("metric_bx3") - 3 x 2 D^3 bfloat16 flops at 16 x the fp32 rate = 0.375 D^3 fp32-pipe equivalents -
-    beside the formation's D^3 in fp32; the momentum draw's evaluation (general sequence) stays fp32: 6.33 D^3.  useful / fp32 peak no
+    beside the formation's D^3 in fp32; all 4 L + 3 evaluations of a trajectory are solve-shaped (the draw: "metric_sqrtdraw").  useful / fp32 peak no
     longer bounds by the pipe-busy share; this figure / fp32 peak does."""
     second = 2.0 * (3.0 / BF16_OVER_FP32_MATRIX_PEAK if bx3 else 1.0)
-    return ((4 * L + 2) * (1.0 + second) + 6.0 + 1.0 / 3) * D ** 3 / float(L)
+    return (4 * L + 3) * (1.0 + second) * D ** 3 / float(L)
 
 
 # ---------------------------------------------------------------------------------------------------

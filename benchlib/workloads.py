@@ -226,7 +226,7 @@ class Cfg3:
                                       "route does not do that work (closed form for constant curvature / refinement of a shared basis)"},
                 "note": "frac = useful flops (%s) / kernel time / fp32 peak 157.3 TF; kernel time = every profiled launch of a step; "
                         "issued (PMC) and padding = issued / useful are added from profiles/physical.json" % (
-                            "refinement route: (4 L + 3) x 3 D^3 + 3.33 D^3 per trajectory" if self.jacobi else
+                            "refinement route: (4 L + 3) x 3 D^3 per trajectory" if self.jacobi else
                             "(4 K + 4 + (2 K + 5) / L) x 2 D^2 per step, K = 2")}
 
     def burn_in_states(self, k):

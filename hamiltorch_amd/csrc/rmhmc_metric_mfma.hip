@@ -46,6 +46,8 @@ namespace hta {
 int g_metric_mfma = 1;   // tuning key "metric_mfma": 1 = warm fp32 evaluations run here, 0 = always the Jacobi kernel
 int g_metric_second = 1;    // tuning key "metric_second": 1 = the refinement's second pass in closed form (one product: ph_refine_E2) where the first pass's update is small, 0 = always the full pass (three products)
 int g_metric_bx3 = 1;       // tuning key "metric_bx3": 1 = the fast solve's second-pass product F E1 as three bfloat16 products (operands split hi + lo), 0 = exact fp32 products
+int g_metric_sqrtdraw = 1;  // tuning key "metric_sqrtdraw": 1 = the momentum draw of soft-abs evaluations on a shared basis is p = G^(1/2) z (the symmetric square root: a SOLVE-shaped
+                            // evaluation - same law as S:183-184's chol(G) z, no assembly of G, no Cholesky), 0 = the reference's map chol(G) z
 int g_metric_general = 1;   // tuning key "metric_general": 1 = evaluations with per-system curvature AND per-system bases run here too
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -1334,14 +1336,15 @@ __device__ HTA_PH_ATTR float ph_fast_second(int offF, int offE, int offLam, int 
 // the two row updates; the block sums (log-det, y^T w, sum lam0 d'^2) as wave partials at oS (waves 0 .. 9, stride 4: the caller adds them).
 // Waves 0 .. 7 carry the products (mv4: a row's value stays in its four lanes from one stage to the next), waves 8 .. 9 the soft-abs
 // map under the second product; five barriers.  Vector block at oVec: e | lam | lam0 -> lam~ | m' | y | x | d' -> lam0 d' | cs, then 16 floats, then oS.
-// flags: 1 = no second pass (E2 = 0), 2 = log p / P d wanted, 4 = RESIDENT: the state lives in LDS in eigen-coordinates (the trajectory
+// flags: 8 = the DRAW p = G^(1/2) z: w = y sqrt(lam~) instead of y / lam~; 16 (with 4) = x' REPLACES the LDS vector at 4 (resoff & 0xffff), no second update;
+// 1 = no second pass (E2 = 0), 2 = log p / P d wanted, 4 = RESIDENT: the state lives in LDS in eigen-coordinates (the trajectory
 // kernel) - the updates are theta~'[row] += cx x'[row] and p'[row] += cg lam0 d'[row] on the LDS vectors at 4 (resoff & 0xffff) / 4 (resoff >> 16)
 // (0: none), the last product and its barrier do not exist.
 __device__ HTA_PH_ATTR void ph_fast_chain(int offV, int offE1, int offE2, int oVec, int D, int DP, int LD, int flags, float alpha,
                                           float* lam_out, float* lamraw_out, float* x_out, float* upd_x, float cx, float* upd_g, float cg, int resoff) {
   HTA_LDS_BASE();
   D = HTA_U(D); DP = HTA_U(DP); LD = HTA_U(LD); flags = HTA_U(flags); oVec = HTA_U(oVec); resoff = HTA_U(resoff);
-  const bool skip2 = flags & 1, has_x = flags & 2, resident = flags & 4;
+  const bool skip2 = flags & 1, has_x = flags & 2, resident = flags & 4, sdraw = flags & 8, assign = flags & 16;
   const float* V = lds + HTA_U(offV); const float* E1 = lds + HTA_U(offE1); const float* E2 = lds + HTA_U(offE2);
   float* vlam = lds + oVec + DP; float* vlt = vlam + DP; float* vm = vlt + DP; float* vy = vm + DP; float* vx = vy + DP; float* vd = vx + DP;
   float* red3 = vd + 2 * DP + MT / 64;
@@ -1396,7 +1399,7 @@ __device__ HTA_PH_ATTR void ph_fast_chain(int offV, int offE1, int offE2, int oV
   __syncthreads();                                               // 2: lam~, lam0 d'
   HTA_WSTAMP(14);
   float w = 0.f, qd = 0.f;
-  if (row < D) { w = y / vlt[row]; if (c == 0) qd = y * w; }
+  if (row < D) { w = sdraw ? y * sqrtf(vlt[row]) : y / vlt[row]; if (c == 0) qd = y * w; }
   if (c == 0 && row < DP) vx[row] = w;
   {
     const float s1 = wave_sum_dpp(qd);
@@ -1416,8 +1419,8 @@ __device__ HTA_PH_ATTR void ph_fast_chain(int offV, int offE1, int offE2, int oV
   if (resident) {
     if (wr && resoff) {
       float* sx = lds + 4 * (resoff & 0xffff); float* sg = lds + 4 * (resoff >> 16);
-      sx[row] += cx * xp;
-      sg[row] += cg * vd[row];
+      if (assign) sx[row] = xp;
+      else { sx[row] += cx * xp; sg[row] += cg * vd[row]; }
     }
     HTA_WSTAMP(18);
     return;
@@ -1450,8 +1453,11 @@ __device__ __forceinline__ int opaque_tid() {
 // the fast solve evaluation of system b (see the block comment above ph_fast_vt); false: nothing written, run the general sequence
 // res_xm >= 0: RESIDENT operands - d' at LDS offset 4 (res_xm & 0xffff), m' at 4 (res_xm >> 16) (offsets are multiples of 4: 14 bits each) (eigen-coordinates: no V0 product), the updates
 // go to the LDS vectors of res_upd (see ph_fast_chain; 0: none)
+// sdraw: the evaluation is the momentum DRAW p = G^(1/2) z - the solve's sequence with m = z (Philox normals of the draw's stream, S:183-184's z)
+// and w = y sqrt(lam~); the result goes to a.p_out (resident: it REPLACES the vector of res_upd & 0xffff; res_xm then names theta' and the
+// place V0^T z is taken from / put to)
 __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, int DP, int LD, int64_t b, int& vres, bool bx3, int tiles,
-                                                  int res_xm = -1, int res_upd = 0) {
+                                                  int res_xm = -1, int res_upd = 0, bool sdraw = false) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = a.D, tid = threadIdx.x;
   const int nt = DP / 16, k4 = (D + 3) / 4;
@@ -1474,7 +1480,7 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
       lds0[oM + i] = lds0[4 * (res_xm >> 16) + i];
       lds0[oD + i] = lds0[4 * (res_xm & 0xffff) + i];
     } else {
-      lds0[oY + 2 * i] = in ? a.m[b * D + i] : 0.f;
+      lds0[oY + 2 * i] = in ? (sdraw ? normal_elem<float>(a.seed, chain, a.draw, 0, i) : a.m[b * D + i]) : 0.f;
       lds0[oY + 2 * i + 1] = (in && a.X) ? a.X[b * D + i] - a.mu[i] : 0.f;
     }
     lds0[oLt + i] = in ? a.lam0[i] : 0.f;                            // lam0 (the soft-abs map overwrites it element by element at the end)
@@ -1504,10 +1510,12 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
   }
   HTA_STAMP(9);
   if (res_xm >= 0)
-    ph_fast_chain(bx, bz, by, oJit, D, DP, LD, (skip2 ? 1 : 0) | 2 | 4, (float)a.alpha, nullptr, nullptr, nullptr, nullptr, (float)a.cx, nullptr, (float)a.cg, res_upd);
+    ph_fast_chain(bx, bz, by, oJit, D, DP, LD, (skip2 ? 1 : 0) | 2 | 4 | (sdraw ? 8 | 16 : 0), (float)a.alpha, nullptr, nullptr, nullptr, nullptr, (float)a.cx, nullptr,
+                  (float)a.cg, res_upd);
   else
-    ph_fast_chain(bx, bz, by, oJit, D, DP, LD, (skip2 ? 1 : 0) | (a.X ? 2 : 0), (float)a.alpha,
-                  a.lam_out ? a.lam_out + b * D : nullptr, a.lamraw_out ? a.lamraw_out + b * D : nullptr, a.x_out ? a.x_out + b * D : nullptr,
+    ph_fast_chain(bx, bz, by, oJit, D, DP, LD, (skip2 ? 1 : 0) | (a.X ? 2 : 0) | (sdraw ? 8 : 0), (float)a.alpha,
+                  a.lam_out ? a.lam_out + b * D : nullptr, a.lamraw_out ? a.lamraw_out + b * D : nullptr,
+                  sdraw ? a.p_out + b * D : (a.x_out ? a.x_out + b * D : nullptr),
                   a.upd_x ? a.upd_x + b * D : nullptr, (float)a.cx, a.upd_g ? a.upd_g + b * D : nullptr, (float)a.cg, 0);
   HTA_STAMP(21);
   if (tid == 0) {
@@ -1586,8 +1594,11 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
   // test passes, the in-launch Jacobi (on the nearly diagonal A: few sweeps) where it does not; V_out = V0_b X is the
   // basis for the caller's next call.  lam0 is not used.
   const bool general = softabs && a.hs_stride != 0;
-  if ((second & 1) && softabs && !general && a.m && !(a.G_out || a.p_out || a.V_out || a.dmetric_out) && (!a.X || a.Pm == a.Hs)) {
-    if (metric_fast_solve(a, DP, LD, b, vres, (second & 2) != 0, tiles)) return;
+  // the momentum draw as a solve-shaped evaluation (tuning key "metric_sqrtdraw"): p = G^(1/2) z = Q diag(sqrt lam~) Q^T z - same law as chol(G) z
+  const bool sdraw = (second & 16) && a.p_out && softabs && !general && !a.m && !a.G_out && !a.V_out && !a.dmetric_out;
+  const bool has_m = a.m || sdraw;
+  if ((second & 1) && softabs && !general && has_m && !(a.G_out || (a.p_out && !sdraw) || a.V_out || a.dmetric_out) && (!a.X || a.Pm == a.Hs)) {
+    if (metric_fast_solve(a, DP, LD, b, vres, (second & 2) != 0, tiles, -1, 0, sdraw)) return;
   }
 
   {
@@ -1599,7 +1610,7 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
     if (tid < DP) {
       const int i = opaque_tid();
       vjit[i] = (i < D && a.has_jitter) ? (float)a.jitter * uniform_elem<float>(a.seed, chain, a.draw, PURPOSE_JITTER, a.sub, i) : 0.f;
-      vm[i] = (i < D && a.m) ? a.m[b * D + i] : 0.f;
+      vm[i] = (i < D && has_m) ? (sdraw ? normal_elem<float>(a.seed, a.chain_offset + (uint64_t)b, a.draw, 0, i) : a.m[b * D + i]) : 0.f;
       vd[i] = (i < D && a.X) ? a.X[b * D + i] - a.mu[i] : 0.f;
     }
     // buffer roles: bx = V0 (then X), by = A / S / E, bz = scratch
@@ -1614,7 +1625,7 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
     float logp = 0.f;
     if (a.X) logp = (float)a.log_norm - 0.5f * ph_logp(a.Pm, oD, D, bz, oRed, a.upd_g ? a.upd_g + b * D : nullptr, (float)a.cg);
     // ---- m' = V0^T m
-    if (a.m && softabs) {
+    if (has_m && softabs) {
       const float v = ph_mv8(1, bx, LD, oM, D);
       __syncthreads();
       if ((tid & 7) == 0 && (tid >> 3) < DP) vm[tid >> 3] = ((tid >> 3) < D) ? v : 0.f;
@@ -1644,7 +1655,7 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
     bool implicit_e = false;          // the last update X (I + E) is applied to the vectors of the solve instead of being formed
     bool x_antisym = false;           // X = I + E1 straight from the first pass: X + X^T = 2 I exactly (the pairs), so X^T v = 2 v - X v
     bool et_in_bz = false;            // the closed-form second pass left E2^T in bz (next to E2 in by)
-    const bool want_matrix = a.G_out || a.p_out || a.V_out || a.dmetric_out;
+    const bool want_matrix = a.G_out || (a.p_out && !sdraw) || a.V_out || a.dmetric_out;
     if (softabs) {
       for (int it = 0; it < 4 && !converged && !fallback; ++it) {
         if (it >= 2 && general) { fallback = true; break; }          // (forming A again needs all three buffers: the Jacobi path does it)
@@ -1750,7 +1761,7 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
       logdet = block_sum_dpp(ld, red);
       HTA_STAMP(12);                                            // (12 .. 18: the solve's sub-phases; the passes it = 2, 3 reuse the slots when they run)
       // ---- 4. x = V0 X (X^T m' / lam~)
-      if (a.m) {
+      if (has_m) {
         // y = X^T m': row-wise products only where the structure allows it (mv8: a third of the column-wise product's time)
         float y;
         const int row = opaque_tid() >> 3;
@@ -1768,7 +1779,7 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
         float qd = 0.f;
         float wreg = 0.f;
         if ((tid & 7) == 0 && row < DP) {
-          const float w = (row < D) ? y / vlt[row] : 0.f;
+          const float w = (row < D) ? (sdraw ? y * sqrtf(vlt[row]) : y / vlt[row]) : 0.f;
           wreg = w;
           (implicit_e ? vx : vy)[row] = w;
           qd = (row < D) ? y * w : 0.f;
@@ -1794,6 +1805,7 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
         const float x = ph_mv8(0, by, LD, oX, D);
         const int orow = opaque_tid() >> 3;
         if ((tid & 7) == 0 && orow < D) {
+          if (sdraw) a.p_out[b * D + orow] = x;
           if (a.x_out) a.x_out[b * D + orow] = x;
           if (a.upd_x) a.upd_x[b * D + orow] += (float)a.cx * x;
         }
@@ -1804,7 +1816,7 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
     if (softabs && (a.V_out || a.dmetric_out)) {
       vres = -1;
       __syncthreads();
-      if (!a.m && tid < DP) vy[tid] = 0.f;                            // u = Q^T m / lam~ (vy holds it after the solve)
+      if (!has_m && tid < DP) vy[tid] = 0.f;                            // u = Q^T m / lam~ (vy holds it after the solve)
       ph_stage(V0b, by, D, DP, LD);
       __syncthreads();
       lds_gemm<false, false, false, false>(by, bx, bz, -1, -1, nt, k4, LD);             // Q = V0 X
@@ -1834,7 +1846,7 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
     }
     HTA_STAMP(21);
     // ---- 5. G = Q diag(lam~) Q^T, Q = V0 X  (S:121) for fisher() / the momentum draw; Metric.HESSIAN: G = Hs itself
-    if (a.G_out || a.p_out || !softabs) {
+    if (a.G_out || (a.p_out && !sdraw) || !softabs) {
       vres = -1;
       __syncthreads();
       int g = bz;
@@ -2019,12 +2031,32 @@ __global__ __launch_bounds__(MT) void metric_traj_mfma_kernel(MetricArgsT<float>
       continue;
     }
     const int64_t e0 = b * D;
-    vres = traj_general_eval(ka, DP, LD, b, vres, 0, second, tiles, 0);                        // the momentum draw
-    // into the eigenbasis: (theta', p') = V0^T (cur - mu, pm); theta~' = theta', p~' = p'
+    bool drawn = false;
+    if (second & 16) {
+      // the momentum draw p = G^(1/2) z in eigen-coordinates: (theta', z') = V0^T (cur - mu, z) in one pass, then the solve's sequence with
+      // m' = z' and w = y sqrt(lam~); its x' IS p' = V0^T p (no way back through V0)
+      __syncthreads();
+      ph_stage(a.V0, BS, D, DP, LD); vres = BS;
+      if ((int)threadIdx.x < DP) {
+        const int i = opaque_tid();
+        lds0[oY + 2 * i] = i < D ? normal_elem<float>(a.seed, a.chain_offset + (uint64_t)b, a.draw, 0, i) : 0.f;
+        lds0[oY + 2 * i + 1] = i < D ? t.cur[e0 + i] - a.mu[i] : 0.f;
+      }
+      __syncthreads();
+      ph_fast_vt(vres, oY, sP, sTh, DP, LD);
+      MetricArgsT<float> o = a;
+      o.sub = 0; o.X = nullptr; o.m = nullptr; o.p_out = t.pm;
+      drawn = metric_fast_solve(o, DP, LD, b, vres, (second & 2) != 0, tiles, (sTh >> 2) | ((sP >> 2) << 16), sP >> 2, true);
+    }
+    if (!drawn) {
+      vres = traj_general_eval(ka, DP, LD, b, vres, 0, second, tiles, 0);                      // the draw on the general sequence (p in t.pm)
+      // into the eigenbasis: (theta', p') = V0^T (cur - mu, pm)
+      __syncthreads();
+      if (vres < 0) { ph_stage(a.V0, BS, D, DP, LD); vres = BS; }
+      res_in(vres, oY, sTh, sP, t.cur + e0, t.pm + e0, a.mu, D, DP, LD);
+    }
     __syncthreads();
-    if (vres < 0) { ph_stage(a.V0, BS, D, DP, LD); vres = BS; }
-    res_in(vres, oY, sTh, sP, t.cur + e0, t.pm + e0, a.mu, D, DP, LD);
-    if ((int)threadIdx.x < DP) { const int i = opaque_tid(); lds0[sThc + i] = lds0[sTh + i]; lds0[sPc + i] = lds0[sP + i]; }
+    if ((int)threadIdx.x < DP) { const int i = opaque_tid(); lds0[sThc + i] = lds0[sTh + i]; lds0[sPc + i] = lds0[sP + i]; }   // theta~' = theta', p~' = p'
     __syncthreads();
     for (int op = 1; op < nops; ++op) {
       // the fields the fast solve reads (everything else of `a` is dead here)
@@ -2081,7 +2113,7 @@ int metric_traj_mfma(const MetricArgsT<float>& a, const MetricTrajArgs& t, hipSt
   const int grid = (int)(a.B < 65536 ? a.B : 65536);
   profile_begin(s);
   note_route("metric_traj_mfma_kernel");
-  metric_traj_mfma_kernel<<<grid, MT, lds, s>>>(k, t, DP, LD, (g_metric_second ? 1 : 0) | (g_metric_bx3 ? 2 : 0) | (g_metric_resident ? 4 : 0));
+  metric_traj_mfma_kernel<<<grid, MT, lds, s>>>(k, t, DP, LD, (g_metric_second ? 1 : 0) | (g_metric_bx3 ? 2 : 0) | (g_metric_resident ? 4 : 0) | (g_metric_sqrtdraw ? 16 : 0));
   profile_end(s);
   HTA_CHECK_LAUNCH("hta_rmhmc_gaussian_sample (trajectory kernel)");
   return HTA_OK;
@@ -2114,7 +2146,7 @@ int metric_warm_mfma(const MetricArgsT<float>& a, hipStream_t s) {
   const int grid = (int)(a.B < 65536 ? a.B : 65536);
   profile_begin(s);
   note_route("metric_warm_mfma_kernel");
-  metric_warm_mfma_kernel<<<grid, MT, lds, s>>>(k, DP, LD, (g_metric_second ? 1 : 0) | (g_metric_bx3 ? 2 : 0));
+  metric_warm_mfma_kernel<<<grid, MT, lds, s>>>(k, DP, LD, (g_metric_second ? 1 : 0) | (g_metric_bx3 ? 2 : 0) | (g_metric_sqrtdraw ? 16 : 0));
   profile_end(s);
   HTA_CHECK_LAUNCH("hta_metric_eval (mfma)");
   return HTA_OK;

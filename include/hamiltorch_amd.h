@@ -494,6 +494,11 @@ int hta_jit_rmhmc_sample(void* module, const HtaCbRmhmcArgs* args, int D, int it
  * more than 8e-3, the second pass is second-order perturbation theory in closed form - ONE product F E1 instead of A X, X^T A X and
  * X^T X; truncation error |F| d^2 < 1e-8 in ||A X - X Lam||, below fp32 rounding; 0 = always the three-product pass: the parity
  * partner, equal results to rounding),
+ * "metric_sqrtdraw" (round 6; 1 default: the momentum draw of a soft-abs evaluation on a shared basis - HtaMetricArgs::p_out without G_out /
+ * V_out / dmetric_out, V0 / lam0 given, v0_stride 0; the draw of hta_rmhmc_gaussian_sample's eigendecomposition route - is p = G^(1/2) z
+ * with the SYMMETRIC square root Q diag(sqrt lam~) Q^T: a solve-shaped evaluation (no assembly of G, no Cholesky: 30 k cycles instead of
+ * 350 k at D = 100).  The same law N(0, G(theta)) as samplers.py:183-184's chol(G) z from the same z, a different map (as "rmhmc_momsplit"
+ * on the fused routes); 0 = chol(G) z),
  * "metric_resident" (round 6; 1 default: that trajectory kernel takes the chain's four state vectors into the eigenbasis once after the
  * momentum draw - theta' = V0^T (theta - mu), p' = V0^T p - and keeps them in LDS: a solve evaluation has no V0 product and no global
  * traffic but its scalars, theta = mu + V0 theta' at the end; agreement with the launch sequence to fp32 rounding; 0 = the state in the

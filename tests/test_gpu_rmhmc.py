@@ -29,12 +29,16 @@ def tt(a, dtype):
     return None if a is None else torch.tensor(np.asarray(a), dtype=dtype, device=dev())
 
 
-def oracle_momentum(jitter):
+def oracle_momentum(jitter, metric="softabs"):
     """Which momentum draw the oracle must replay for the sample call that just returned: the fused Gaussian routes
     (kernel names rmhmc_*) draw p = chol(P) z1 + sqrt(jitter u) . z2 when jitter is on (tuning key "rmhmc_momsplit",
-    default 1; oracle: rm_gibbs_split, same law as chol(G) z); every other route and jitter-free runs draw chol(G) z."""
+    default 1; oracle: rm_gibbs_split, same law as chol(G) z); the eigendecomposition route on the matrix cores draws p = G^(1/2) z
+    (tuning key "metric_sqrtdraw", default 1; oracle: rm_gibbs_sqrt, same law); every other route and jitter-free fused runs draw chol(G) z."""
     from hamiltorch_amd import _abi
-    fused = _abi.last_route().startswith("rmhmc_")
+    route = _abi.last_route()
+    fused = route.startswith("rmhmc_")
+    if route in ("metric_traj_mfma_kernel", "metric_warm_mfma_kernel") and _abi.get_tuning("metric_sqrtdraw") and metric == "softabs":
+        return "sqrt"        # round 6: the matrix-core metric kernel draws p = G^(1/2) z for a Gaussian target's soft-abs metric (oracle: rm_gibbs_sqrt)
     return "split" if (jitter is not None and fused and _abi.get_tuning("rmhmc_momsplit")) else "chol"
 
 
@@ -186,7 +190,7 @@ def test_sample_rmhmc_vs_oracle(ht, dtype, tol, D, jitter, metric, burn, split):
                          softabs_const=alpha, explicit_binding_const=omega, sampler=ht.Sampler.RMHMC,
                          integrator=ht.Integrator.EXPLICIT, metric=M, debug=2, verbose=False, seed=seed, chain_offset=off)
     ref, info = O.sample_rmhmc_explicit(o, th0, N, L, eps, omega, alpha, burn, jitter, O.PhiloxDraws(seed, off + np.arange(C), NP[dtype]), metric,
-                                        momentum=oracle_momentum(jitter))
+                                        momentum=oracle_momentum(jitter, metric))
     got = np.stack([x.cpu().numpy() for x in out]); want = np.stack(ref)
     assert got.shape == want.shape
     bad = np.abs(got - want).max(axis=(0, 2)) > tol
@@ -389,7 +393,8 @@ def test_fused_path_equals_jacobi_path(ht, dtype, tol, D, jitter, metric):
               explicit_binding_const=omega, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT, metric=M, debug=2,
               verbose=False, seed=seed)
     outs = []
-    _abi.set_tuning("rmhmc_momsplit", 0)          # chol(G) z on both routes (the Jacobi route has no split draw)
+    _abi.set_tuning("rmhmc_momsplit", 0)          # chol(G) z on both routes (the Jacobi route has no split draw,
+    _abi.set_tuning("metric_sqrtdraw", 0)         # and its own default since round 6 is the symmetric square root)
     for fused in (1, 0):
         _abi.set_tuning("rmhmc_fused", fused)
         try:
@@ -959,6 +964,55 @@ def test_second_pass_in_closed_form_equals_the_three_product_pass(ht, D, alpha, 
     assert np.abs(np.sort(a["lam"], axis=1) - np.sort(lam, axis=1)).max() <= 8e-6 * np.abs(lam).max()
 
 
+@pytest.mark.parametrize("D,kind,alpha,jitter", [(100, "spd", 1e6, 1e-3), (100, "spd", 1.3, 1e-3), (100, "spd", 1e6, None), (64, "indef", 2.0, 1e-2), (37, "spd", 1e6, 5e-2),
+                                                 (48, "degenerate", 1e6, 1e-3), (3, "spd", 1e6, 1e-3), (112, "spd", 1e6, 1e-3)])
+def test_symmetric_square_root_draw_vs_oracle(ht, D, kind, alpha, jitter):
+    """Round 6 ("metric_sqrtdraw"): the momentum draw of a soft-abs evaluation on a shared basis is p = G^(1/2) z with the symmetric square
+    root Q diag(sqrt lam~) Q^T - a SOLVE-shaped evaluation (formation, refinement, five matrix-vector products) instead of assembling G and
+    factorising it; same law N(0, G) as S:183-184's chol(G) z, from the same z.  hta_metric_eval with p_out alone against the oracle's
+    rm_gibbs_sqrt map in float64 (every system its own jitter draw), the fast sequence (well separated spectrum), the general sequence
+    (jitter 5e-2: the refinement's first pass is above the bound) and the in-launch Jacobi fallback (degenerate spectrum); with the
+    tuning key off, or with G_out beside p_out, the draw is chol(G) z as before."""
+    from hamiltorch_amd import _abi
+    if kind == "spd" and D == 100:
+        P = cfg3_target(ht, 100, torch.float32)[1].P.astype(np.float64)
+    elif kind == "spd":
+        P = cfg3_target(ht, D, torch.float32, seed=7)[1].P.astype(np.float64)
+    else:
+        P = sym_batch(1, D, kind, D + 1)[0]
+    B, seed = 33, 71
+    Pd = tt(P, torch.float32)
+    V0 = torch.empty(D, D, device=dev()); lam0 = torch.empty(D, device=dev())
+    outs = {}
+    try:
+        _abi.set_tuning("metric_mfma", 0)
+        _abi.metric_eval(Pd, 1, D, _abi.METRIC_SOFTABS, Pd, 0, alpha, V_out=V0, lamraw_out=lam0)
+        _abi.set_tuning("metric_mfma", 1)
+        for key in (1, 0):
+            _abi.set_tuning("metric_sqrtdraw", key)
+            p = torch.empty(B, D, device=dev())
+            _abi.metric_eval(Pd, B, D, _abi.METRIC_SOFTABS, Pd, 0, alpha, jitter, seed, 3, 7, 0, p_out=p, V0=V0, lam0=lam0)
+            assert _abi.last_route() == "metric_warm_mfma_kernel"
+            outs[key] = p.cpu().numpy()
+    finally:
+        _abi.set_tuning("metric_sqrtdraw", 1)
+        _abi.set_tuning("metric_mfma", 1)
+    Hs = np.broadcast_to(P, (B, D, D)).astype(np.float64).copy()
+    ju = None if jitter is None else O.philox_uniforms(seed, 3 + np.arange(B), 7, D, O.PURPOSE_JITTER, 0, dtype=np.float64)
+    G, lam, Q = O.softabs_metric(Hs, alpha, jitter, ju)
+    z = O.philox_normals(seed, 3 + np.arange(B), 7, D, dtype=np.float64)
+    want_sqrt = np.einsum("bij,bj->bi", Q, np.sqrt(lam) * np.einsum("bji,bj->bi", Q, z))
+    want_chol = np.einsum("bij,bj->bi", np.linalg.cholesky(G), z)
+    cond = np.abs(lam).max() / np.abs(lam).min()
+    tol = 4e-4
+    np.testing.assert_allclose(outs[1], want_sqrt, rtol=tol * cond, atol=tol * cond * np.abs(want_sqrt).max())
+    np.testing.assert_allclose(outs[0], want_chol, rtol=tol * cond, atol=tol * cond * np.abs(want_chol).max())
+    # the two maps are different square roots of G; the symmetric one has |p|^2 = z^T G z
+    assert np.abs(outs[1] - outs[0]).max() > 1e-3 * np.abs(want_chol).max() or D <= 3
+    zGz = np.einsum("bi,bij,bj->b", z, G, z)
+    np.testing.assert_allclose((outs[1].astype(np.float64) ** 2).sum(1), zGz, rtol=2e-3 * cond)
+
+
 @pytest.mark.parametrize("D,alpha,jitter", [(100, 1e6, 1e-3), (100, 1.3, 1e-3), (100, 1e6, None), (64, 2.0, 5e-4), (37, 1e6, 1e-3), (112, 1e6, 1e-3), (3, 1e6, 1e-3)])
 def test_fast_solve_with_bfloat16_products_equals_exact_products(ht, D, alpha, jitter):
     """Round 6 ("metric_bx3"): the solve evaluations of a Gaussian target on the shared basis run a reorganised sequence (V0 resident,
@@ -1012,11 +1066,12 @@ def test_metric_mfma_kernel_issues_matrix_instructions_on_cfg3(ht):
     outs = []
     try:
         _abi.set_tuning("rmhmc_fused", 0)
+        _abi.set_tuning("metric_sqrtdraw", 0)      # chol(G) z on both (the Jacobi kernel has no other draw; the matrix-core kernel's default is G^(1/2) z)
         for mode in (1, 0):
             _abi.set_tuning("metric_mfma", mode)
             outs.append(torch.stack(ht.sample(t, th0, **kw)).cpu().numpy())
     finally:
-        _abi.set_tuning("rmhmc_fused", 1); _abi.set_tuning("metric_mfma", 1)
+        _abi.set_tuning("rmhmc_fused", 1); _abi.set_tuning("metric_mfma", 1); _abi.set_tuning("metric_sqrtdraw", 1)
     err = np.abs(outs[0] - outs[1]).max(axis=(0, 2))
     assert (err > 3e-4).sum() <= 1, err.max()
 
