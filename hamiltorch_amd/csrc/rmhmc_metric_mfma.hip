@@ -1215,29 +1215,37 @@ __device__ HTA_PH_ATTR float ph_fast_form(int offV, int offF, int offE, int offJ
 // on the accumulators): lam_i' = lam_i + M_ii from the diagonal tiles, E2_ij = M_ij / (lam_j' - lam_i'), E2_ii = -1/2 sum_k E1_ik^2
 // (row sums taken before the product), E2 stored over F once every wave has left its k loop.  Returns max |E2_ij|.
 template <int LDC, bool BX3>
-__device__ HTA_PH_ATTR float ph_fast_second(int offF, int offE, int offLam, int offCs, int offRed, int nt, int tile, int k4, int D, int LDr) {
+// Round 6, later: the vectors' first two products ride along.  The pass over E1 that takes the row sums also takes E1 m' - y0 = m' - E1 m'
+// is published before the product - and the epilogue, which holds E2 in registers, accumulates y0^T E2 per column (a DPP row sum over the 16
+// rows of a tile, one 16-byte store of four columns per tile and lane group) into one partial vector per macro-tile row (offP0 .. offP3:
+// idle vectors); the chain starts from y = y0 + the sum of those partials instead of two matrix-vector products and a barrier.
+__device__ HTA_PH_ATTR float ph_fast_second(int offF, int offE, int oVec, int offRed, int nt, int tile, int k4, int D, int LDr) {
   HTA_LDS_BASE();
-  nt = HTA_U(nt); k4 = HTA_U(k4); D = HTA_U(D);
+  nt = HTA_U(nt); k4 = HTA_U(k4); D = HTA_U(D); oVec = HTA_U(oVec);
   const int LD = LDC ? LDC : HTA_U(LDr);
+  const int DPv = 16 * nt;
   float* F = lds + HTA_U(offF); const float* E = lds + HTA_U(offE);
-  float* vlam = lds + HTA_U(offLam); float* vcs = lds + HTA_U(offCs); float* red = lds + HTA_U(offRed);
+  float* vlam = lds + oVec + DPv; const float* vm = lds + oVec + 3 * DPv; float* vy = lds + oVec + 4 * DPv; float* vcs = lds + oVec + 7 * DPv;
+  float* red = lds + HTA_U(offRed);
   const int lane = threadIdx.x & 63;
   const int li = lane & 15, lk = lane >> 4;
   {
     const int row = threadIdx.x >> 3, seg = threadIdx.x & 7;
-    float c0 = 0.f, c1 = 0.f;
+    float c0 = 0.f, c1 = 0.f, u0 = 0.f, u1 = 0.f;
     if (row < 16 * nt) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int q = seg + 8 * u;
         if (q < 4 * nt) {
           const f4 v = *reinterpret_cast<const f4*>(E + row * LD + 4 * q);
+          const f4 mq = *reinterpret_cast<const f4*>(vm + 4 * q);
           c0 = fmaf(v[0], v[0], c0); c1 = fmaf(v[1], v[1], c1); c0 = fmaf(v[2], v[2], c0); c1 = fmaf(v[3], v[3], c1);
+          u0 = fmaf(v[0], mq[0], u0); u1 = fmaf(v[1], mq[1], u1); u0 = fmaf(v[2], mq[2], u0); u1 = fmaf(v[3], mq[3], u1);
         }
       }
     }
-    const float cs = sum8_dpp(c0 + c1);
-    if (seg == 0 && row < 16 * nt) vcs[row] = cs;
+    const float cs = sum8_dpp(c0 + c1), e1m = sum8_dpp(u0 + u1);
+    if (seg == 0 && row < 16 * nt) { vcs[row] = cs; vy[row] = (row < D) ? vm[row] - e1m : 0.f; }
   }
   HTA_WVSTAMP(10);
   tile = HTA_U(tile) >> 16;                                        // fast_tiles(): this wave's 2 x 2 macro tile of the full product
@@ -1288,12 +1296,13 @@ __device__ HTA_PH_ATTR float ph_fast_second(int offF, int offE, int offLam, int 
   sc = wave_max_dpp(sc);
   const float tiny = 8.f * Eps<float>::v * sc * kSecondE;
   unsigned ebits = 0u;                                             // max |E2_ij| as a bit pattern: inf and NaN order above every finite value
+  f4 pacc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};   // y0^T E2 over this wave's rows, per column tile
   if (active) {
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
       if (y == 1 && !r2) continue;
       const int I = I0 + y, i = 16 * I + li;
-      const float lamI = vlam[i];
+      const float lamI = vlam[i], y0i = vy[i];
       const f2v lamI2 = {lamI, lamI};
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
@@ -1322,7 +1331,19 @@ __device__ HTA_PH_ATTR float ph_fast_second(int offF, int offE, int offLam, int 
           for (int t = 0; t < 4; ++t) ebits = max(ebits, __float_as_uint(e[t]) & 0x7fffffffu);
         }
         *reinterpret_cast<f4*>(F + i * LD + 16 * J + 4 * lk) = e;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) pacc[x][t] = fmaf(e[t], y0i, pacc[x][t]);
       }
+    }
+    // one partial vector per macro-tile row: vectors that are idle here (e | m' | x | the Cholesky's panel scratch)
+    float* part = lds + (I0 == 0 ? oVec : I0 == 2 ? oVec + 3 * DPv : I0 == 4 ? oVec + 5 * DPv : oVec + 8 * DPv + MT / 64 + 64);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      if (x == 1 && !c2) continue;
+      f4 sum;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) sum[t] = sum16_dpp(pacc[x][t]);
+      if (li == 0) *reinterpret_cast<f4*>(part + 16 * (J0 + x) + 4 * lk) = sum;
     }
   }
   float emax = (ebits > __float_as_uint(kFallbackE)) ? 1.f : __uint_as_float(ebits);      // NaN / inf / too large
@@ -1351,22 +1372,28 @@ __device__ HTA_PH_ATTR void ph_fast_chain(int offV, int offE1, int offE2, int oV
   typedef __attribute__((address_space(1))) float* gf;
   const int tid = threadIdx.x, wave = HTA_U(tid >> 6);
   const int nq = DP >> 2;
-  if (wave >= 10) {                                              // nothing to compute: the five (resident: four) barriers of the chain
-    __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
-    if (!resident) __syncthreads();
+  // !skip2: y0 = m' - E1 m' and the partials of E2^T y0 are in LDS already (ph_fast_second): ONE barrier (the soft-abs map) before w.
+  // skip2 (no second pass: E2 = 0): y0 is computed here, under the map.
+  const int nbar = (skip2 ? 4 : 3) + (resident ? 0 : 1);         // barriers of this call
+  if (wave >= 10) {                                              // nothing to compute
+    for (int k = 0; k < nbar; ++k) __syncthreads();
     return;
   }
-  if (wave >= 8) {                                               // soft-abs map (S:120), log-determinant (S:726), d^T P d, lam0 d': one wave's 1.5 k-cycle
-    const int i = tid - 512;                                     // instruction sequence (tanhf, a division, logf) - the map under the product E1 m' of
-    float ld = 0.f, lq = 0.f, lt = 1.f, l0 = 0.f;                // waves 0 .. 7, the logarithm and the sums under their product E2^T y0
+  if (wave >= 8) {                                               // soft-abs map (S:120), log-determinant (S:726), d^T P d, lam0 d'
+    const int i = tid - 512;
+    float ld = 0.f, lq = 0.f, lt = 1.f, l0 = 0.f;
     if (i < D) {
-      const float lam = vlam[i];
-      lt = (1.f / tanhf(alpha * lam)) * lam;
+      const float lam = vlam[i], x = alpha * lam;
+      // |alpha lam| >= 10: tanh is 1 - 4e-9, i.e. tanhf returns +-1 exactly, lam / tanh = |lam| bit for bit - the whole wave skips the function's body when
+      // every eigenvalue is there (the identity soft-abs map of BASELINE config 3: alpha = 1e6)
+      const bool sat = fabsf(x) >= 10.f;
+      if (__builtin_amdgcn_ballot_w64(!sat) == 0) lt = fabsf(lam);
+      else lt = (1.f / tanhf(x)) * lam;
       l0 = vlt[i];                                               // (lam0 is parked where lam~ goes)
       if (lamraw_out) ((gf)lamraw_out)[i] = lam;
     }
     if (i < DP) vlt[i] = lt;
-    __syncthreads();                                             // 1
+    if (skip2) __syncthreads();                                  // (the first of the four: y0)
     if (i < D) {
       ld = logf(lt);
       if (lam_out) ((gf)lam_out)[i] = lt;
@@ -1374,8 +1401,7 @@ __device__ HTA_PH_ATTR void ph_fast_chain(int offV, int offE1, int offE2, int oV
     }
     const float s0 = wave_sum_dpp(ld), s2 = wave_sum_dpp(lq);
     if ((tid & 63) == 0) { float* r = red3 + 4 * wave; r[0] = s0; r[1] = 0.f; r[2] = s2; }
-    __syncthreads(); __syncthreads(); __syncthreads();
-    if (!resident) __syncthreads();
+    for (int k = skip2 ? 1 : 0; k < nbar; ++k) __syncthreads();
     return;
   }
   const int row = tid >> 2, c = tid & 3;
@@ -1386,17 +1412,22 @@ __device__ HTA_PH_ATTR void ph_fast_chain(int offV, int offE1, int offE2, int oV
     if (wr && upd_g) ug = ((gf)upd_g)[row];
   }
   HTA_WSTAMP(12);
-  // y0 = m' - E1 m'
   float y = 0.f;
-  {
+  if (skip2) {                                                   // y0 = m' - E1 m'
     const float e1m = mv4(E1, LD, vm, nq, DP);
     if (row < D) y = vm[row] - e1m;
+    if (c == 0 && row < DP) vy[row] = y;
+    __syncthreads();                                             // 1: y0
+    HTA_WSTAMP(13);
+  } else if (row < DP) {                                         // y = y0 + E2^T y0 from the second product's partials (one per macro-tile row)
+    const float* p0 = lds + oVec; const float* p1 = lds + oVec + 3 * DP; const float* p2 = lds + oVec + 5 * DP; const float* p3 = lds + oVec + 8 * DP + MT / 64 + 64;
+    y = vy[row] + p0[row];
+    if (DP > 32) y += p1[row];
+    if (DP > 64) y += p2[row];
+    if (DP > 96) y += p3[row];
+    if (row >= D) y = 0.f;
   }
-  if (c == 0 && row < DP) vy[row] = y;
-  __syncthreads();                                               // 1: y0
-  HTA_WSTAMP(13);
-  if (!skip2) y += mv4t(E2, LD, vy, DP);                         // y += E2^T y0
-  __syncthreads();                                               // 2: lam~, lam0 d'
+  __syncthreads();                                               // lam~, lam0 d' (and, after it, x may be overwritten: its partial has been read)
   HTA_WSTAMP(14);
   float w = 0.f, qd = 0.f;
   if (row < D) { w = sdraw ? y * sqrtf(vlt[row]) : y / vlt[row]; if (c == 0) qd = y * w; }
@@ -1503,9 +1534,9 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
     float e2;
     // (the bfloat16 form only where the leading dimension is a compile-time constant: the run-time instance needs four registers beyond
     // the caller-saved set, i.e. a save / restore through scratch memory per call that costs more than the product saves)
-    if (planes) e2 = ph_fast_second<kLdCfg3, true>(by, bz, oLam, oD + DP, oRed, nt, tiles, k4, D, LD);
-    else e2 = LD == kLdCfg3 ? ph_fast_second<kLdCfg3, false>(by, bz, oLam, oD + DP, oRed, nt, tiles, k4, D, LD)
-                            : ph_fast_second<0, false>(by, bz, oLam, oD + DP, oRed, nt, tiles, k4, D, LD);
+    if (planes) e2 = ph_fast_second<kLdCfg3, true>(by, bz, oJit, oRed, nt, tiles, k4, D, LD);
+    else e2 = LD == kLdCfg3 ? ph_fast_second<kLdCfg3, false>(by, bz, oJit, oRed, nt, tiles, k4, D, LD)
+                            : ph_fast_second<0, false>(by, bz, oJit, oRed, nt, tiles, k4, D, LD);
     if (!(e2 <= kConvE)) return false;
   }
   HTA_STAMP(9);
