@@ -426,10 +426,16 @@ template <typename T> int metric_eval(const MetricArgsT<T>& a, hipStream_t s) {
     return HTA_OK;
   };
   static DevOnce done_small, done_big, done_vg, done_ag, done_dyn;   // per T instantiation
-  const int rc = g.dyn ? launch(&metric_eval_kernel<T, 0, 0, true, true>, done_dyn)
-               : g.aglobal ? launch(&metric_eval_kernel<T, 8, 8, true, true>, done_ag)
-               : g.vglobal ? launch(&metric_eval_kernel<T, 4, 3, true>, done_vg)
-                           : (g.small ? launch(&metric_eval_kernel<T, 2, 2>, done_small) : launch(&metric_eval_kernel<T, 4, 3>, done_big));
+  // (the float64 instance of the VT-only-in-global kernel is not even BUILT since round 6 - metric_geometry never selects it, and a kernel
+  // whose correctness depended on the spelling of an address expression has no business in the code object)
+  int rc;
+  if (g.dyn) rc = launch(&metric_eval_kernel<T, 0, 0, true, true>, done_dyn);
+  else if (g.aglobal) rc = launch(&metric_eval_kernel<T, 8, 8, true, true>, done_ag);
+  else if (g.vglobal) {
+    if constexpr (sizeof(T) == 4) rc = launch(&metric_eval_kernel<float, 4, 3, true>, done_vg);
+    else { set_error("hta_metric_eval: internal error: the float64 vglobal instance was retired (metric_geometry)"); rc = HTA_ERR_INVALID; }
+  }
+  else rc = g.small ? launch(&metric_eval_kernel<T, 2, 2>, done_small) : launch(&metric_eval_kernel<T, 4, 3>, done_big);
   if (rc) return rc;
   HTA_CHECK_LAUNCH("hta_metric_eval");
   return HTA_OK;

@@ -1628,7 +1628,8 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
   // the momentum draw as a solve-shaped evaluation (tuning key "metric_sqrtdraw"): p = G^(1/2) z = Q diag(sqrt lam~) Q^T z - same law as chol(G) z
   const bool sdraw = (second & 16) && a.p_out && softabs && !general && !a.m && !a.G_out && !a.V_out && !a.dmetric_out;
   const bool has_m = a.m || sdraw;
-  if ((second & 1) && softabs && !general && has_m && !(a.G_out || (a.p_out && !sdraw) || a.V_out || a.dmetric_out) && (!a.X || a.Pm == a.Hs)) {
+  // (second & 32: the caller has tried the fast solve itself - metric_warm_mfma_kernel - and it declined)
+  if (!(second & 32) && (second & 1) && softabs && !general && has_m && !(a.G_out || (a.p_out && !sdraw) || a.V_out || a.dmetric_out) && (!a.X || a.Pm == a.Hs)) {
     if (metric_fast_solve(a, DP, LD, b, vres, (second & 2) != 0, tiles, -1, 0, sdraw)) return;
   }
 
@@ -1944,19 +1945,26 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
   }
 }
 
+// one evaluation on the general sequence, out of line, its arguments read again from the kernel-argument segment (see traj_general_eval):
+// the kernel's own body keeps only what the fast solve reads.  Defined behind load_kernarg, below.
+__device__ __attribute__((noinline)) void warm_general_eval(const __attribute__((address_space(4))) char* ka, int DP, int LD, int64_t b, int vres, int second, int tiles);
+
 __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float> a, int DP, int LD, int second) {
   const int tiles = fast_tiles(DP / 16);
-  for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) { int vres = -1; metric_warm_system(a, DP, LD, b, vres, second, tiles); }
+  const __attribute__((address_space(4))) char* ka = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+  // what metric_warm_system's own hook tests, evaluated once per launch: the fast solve covers solves and solve-shaped draws of a soft-abs
+  // metric on a shared basis
+  const bool softabs = a.metric == 1, general = softabs && a.hs_stride != 0;
+  const bool sdraw = (second & 16) && a.p_out && softabs && !general && !a.m && !a.G_out && !a.V_out && !a.dmetric_out;
+  const bool fast = (second & 1) && softabs && !general && (a.m || sdraw) && !(a.G_out || (a.p_out && !sdraw) || a.V_out || a.dmetric_out) &&
+                    (!a.X || a.Pm == a.Hs);
+  for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+    int vres = -1;
+    if (fast && metric_fast_solve(a, DP, LD, b, vres, (second & 2) != 0, tiles, -1, 0, sdraw)) continue;
+    warm_general_eval(ka, DP, LD, b, vres, second | 32, tiles);
+  }
 }
 
-// One explicit-RMHMC trajectory of chain b in ONE launch (S:969-989 with S:425-461 inside): the 4 L + 3 metric evaluations of
-// rmhmc_explicit.hip's launch sequence - momentum draw (sub-stream 0), H_old (1), per step the four half steps (2 + 8 l + {1, 2,
-// 4, 7}) with the binding rotation between the second and the third, H_new (2 + 8 L) - run back to back by the chain's
-// workgroup.  A chain's evaluations depend on nothing but that chain's own rows of th / pm / thc / pmc: the sequence needs no
-// grid-wide step, only the workgroup barrier between an evaluation's row updates and the next evaluation's reads.  Same
-// evaluation code as metric_warm_mfma_kernel (metric_warm_system), same arithmetic: bit-identical to the launch sequence
-// (tests/test_gpu_rmhmc.py::test_trajectory_kernel_equals_the_launch_sequence); what goes away is 57 launches per trajectory
-// with their ramps and the gaps between them (profiles/r04q: 12 % of the step).
 // The evaluations of a trajectory that are NOT the fast solve - the momentum draw, every evaluation of the form that keeps the state in the
 // caller's coordinates, the resident form's rare way out - run out of line and read the kernel's arguments again from the kernel-argument
 // segment: inlined into the kernel they kept all ~90 argument dwords live across the resident loop (404 scalar registers parked in vector
@@ -1981,6 +1989,17 @@ template <typename S> __device__ __forceinline__ S load_kernarg(kernarg_ptr ka, 
   return v;
 }
 static_assert(alignof(MetricTrajArgs) == 8 && alignof(MetricArgsT<float>) == 8, "kernel-argument layout of metric_traj_mfma_kernel");
+__device__ __attribute__((noinline)) void warm_general_eval(kernarg_ptr ka, int DP, int LD, int64_t b, int vres, int second, int tiles) {
+  {
+    const uint64_t u = (uint64_t)ka;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    ka = (kernarg_ptr)(((uint64_t)hi << 32) | lo);
+  }
+  const MetricArgsT<float> a = load_kernarg<MetricArgsT<float>>(ka, 0);
+  DP = HTA_U(DP); LD = HTA_U(LD); vres = HTA_U(vres); second = HTA_U(second);
+  metric_warm_system(a, DP, LD, b, vres, second, tiles);
+}
+
 __device__ __attribute__((noinline)) int traj_general_eval(kernarg_ptr ka, int DP, int LD, int64_t b, int vres, int op, int second, int tiles, int mode) {
   {                                                                 // (uniform: an argument arrives in vector registers)
     const uint64_t u = (uint64_t)ka;
