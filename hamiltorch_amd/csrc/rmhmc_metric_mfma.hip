@@ -1549,7 +1549,7 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
                   sdraw ? a.p_out + b * D : (a.x_out ? a.x_out + b * D : nullptr),
                   a.upd_x ? a.upd_x + b * D : nullptr, (float)a.cx, a.upd_g ? a.upd_g + b * D : nullptr, (float)a.cg, 0);
   HTA_STAMP(21);
-  if (tid == 0) {
+  if (tid == 0 && (a.logdet_out || a.quad_out || a.logp_out || a.H_out)) {      // (the half steps of a trajectory want none of the scalars)
     const float* r = lds0 + oS;
     float logdet = 0.f, quad = 0.f, dpd = 0.f;
 #pragma unroll
