@@ -711,6 +711,39 @@ def test_split_momentum_draw_has_the_reference_covariance():
     assert (np.abs(emp - G[0]) < 4.5 * se).all()
 
 
+def test_square_root_momentum_draw_has_the_reference_covariance():
+    """oracle rm_gibbs_sqrt (the product's default draw on the eigendecomposition route of a Gaussian target's soft-abs metric, round 6):
+    p = S z with the SYMMETRIC square root S = Q diag(sqrt lam~) Q^T of G - S S^T = S^2 = G, the covariance of the reference's chol(G) z
+    (S:113-122, S:183-184); unlike an eigen-factor Q diag(sqrt lam~) the map does not depend on the eigenvectors' signs or order; an
+    indefinite curvature with a finite alpha (the soft-abs map is what makes G positive definite) and jitter."""
+    rng = np.random.default_rng(9)
+    D = 11
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    lam = np.linspace(0.4, 2.0, D) * np.where(np.arange(D) % 3 == 0, -1.0, 1.0)
+    P = (Q * lam) @ Q.T; P = 0.5 * (P + P.T)
+    tgt = O.GaussianTarget(np.zeros(D), P, 0.0)
+    th = rng.standard_normal((1, D)); u = rng.uniform(size=(1, D)); jit, alpha = 1e-2, 1.3
+    G, lam_t, Qg = O.softabs_metric(tgt.neg_hessian(th), alpha, jit, u, "softabs")
+    S = np.stack([O.rm_gibbs_sqrt(th, np.eye(D)[k:k + 1], tgt, alpha, jit, u)[0] for k in range(D)], axis=1)
+    np.testing.assert_allclose(S, S.T, rtol=0, atol=1e-12)                       # symmetric
+    np.testing.assert_allclose(S @ S, G[0], rtol=1e-10, atol=1e-12)              # a square root of G
+    assert np.linalg.eigvalsh(S).min() > 0                                       # THE positive definite one
+    # the eigenvectors' signs and order do not enter: the same map from a flipped, permuted basis
+    perm = rng.permutation(D); sg = rng.choice([-1.0, 1.0], D)
+    Q2 = Qg[0][:, perm] * sg
+    S2 = (Q2 * np.sqrt(lam_t[0][perm])) @ Q2.T
+    np.testing.assert_allclose(S2, S, rtol=1e-10, atol=1e-12)
+    # and it is not the reference's map (a different square root: chol(G) is triangular), only its law
+    Lc = np.linalg.cholesky(G[0])
+    assert np.abs(S - Lc).max() > 1e-2
+    np.testing.assert_allclose(Lc @ Lc.T, S @ S.T, rtol=1e-10, atol=1e-12)
+    n = 40000
+    p = O.rm_gibbs_sqrt(np.repeat(th, n, 0), rng.standard_normal((n, D)), tgt, alpha, jit, np.repeat(u, n, 0))
+    emp = p.T @ p / n
+    se = np.sqrt((np.outer(np.diag(G[0]), np.diag(G[0])) + G[0] ** 2) / n)
+    assert (np.abs(emp - G[0]) < 4.5 * se).all()
+
+
 def test_torch_port_funnel_hmc_matches_reference_run(golden):
     """bench.py's funnel-hmc / funnel-rmhmc cpu_baseline legs (oracle/cpu_baseline.py, `kind: "port"` on a box without the
     reference): the port on the notebook's verbatim funnel_ll closure reproduces the unmodified reference's runs
