@@ -27,6 +27,13 @@
 // (formation, F E1); hta_set_tuning("metric_second", 0) keeps the three-product pass.  And a TRAJECTORY of the Gaussian-target
 // sampler is one launch (metric_traj_mfma_kernel below): the chain's workgroup runs its 4 L + 3 evaluations back to back.
 //
+// Round 6: the SOLVE evaluations of a Gaussian target on the shared basis - 4 L + 2 of a trajectory's 4 L + 3 - and, by default, its momentum
+// draw (p = G^(1/2) z, solve-shaped) run a reorganised sequence of the same mathematics (metric_fast_solve and the ph_fast_* phases below: V0
+// resident, the element-wise passes in the products' epilogues, the second-order product as three bfloat16 products on pre-split operands,
+// vector phases on 8 waves, the trajectory's state resident in LDS in eigen-coordinates): 35 k cycles per evaluation instead of 71 k.  What
+// follows in this header describes the GENERAL sequence (metric_warm_system), which still serves everything else: per-system curvature and
+// bases, outputs that need G or Q, Metric.HESSIAN, and whatever the fast sequence declines.
+//
 // The momentum draw / fisher() outputs add Q = V0 X, G = Q diag(lam~) Q^T (two more GEMMs) and a right-looking Cholesky in
 // 16-column panels whose triangular solve and trailing update are MFMA tiles as well.
 // Matrix-vector products (V0^T m, X^T m', X w, V0 x', P d) use all 1024 threads: 8 lanes per row, DPP-free shuffles.
