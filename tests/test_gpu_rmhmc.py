@@ -1013,7 +1013,8 @@ def test_symmetric_square_root_draw_vs_oracle(ht, D, kind, alpha, jitter):
     np.testing.assert_allclose((outs[1].astype(np.float64) ** 2).sum(1), zGz, rtol=2e-3 * cond)
 
 
-@pytest.mark.parametrize("D,alpha,jitter", [(100, 1e6, 1e-3), (100, 1.3, 1e-3), (100, 1e6, None), (64, 2.0, 5e-4), (37, 1e6, 1e-3), (112, 1e6, 1e-3), (3, 1e6, 1e-3)])
+@pytest.mark.parametrize("D,alpha,jitter", [(100, 1e6, 1e-3), (100, 1.3, 1e-3), (100, 1e6, None), (64, 2.0, 5e-4), (37, 1e6, 1e-3), (112, 1e6, 1e-3), (3, 1e6, 1e-3),
+                                            (17, 1e6, 1e-3), (70, 1e6, 1e-3), (90, 2.0, 1e-3)])      # (every tile count 1 ... 7: 2, 5 and 6 tiles here)
 def test_fast_solve_with_bfloat16_products_equals_exact_products(ht, D, alpha, jitter):
     """Round 6 ("metric_bx3"): the solve evaluations of a Gaussian target on the shared basis run a reorganised sequence (V0 resident,
     the element-wise passes in the products' epilogues, log p and P d from the eigenbasis) whose second-pass product F E1 is taken
