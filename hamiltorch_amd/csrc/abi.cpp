@@ -103,7 +103,7 @@ const TuneKey kTune[] = {
     {"rmhmc_pair", &hta::g_rmhmc_pair, 1}, {"rmhmc_wide", &hta::g_rmhmc_wide, 1}, {"rmhmc_overlap", &hta::g_rmhmc_overlap, 0},
     {"rmhmc_momsplit", &hta::g_rmhmc_momsplit, 1},
     {"rmhmc_batch", &hta::g_rmhmc_batch, 1}, {"quad_max_chains", &hta::g_quad_max_chains, 65536}, {"fill_blocks", &hta::g_fill_blocks, 4096},
-    {"mlp_valu", &hta::g_mlp_valu, 0}, {"metric_mfma", &hta::g_metric_mfma, 1}, {"metric_general", &hta::g_metric_general, 1}, {"metric_traj", &hta::g_metric_traj, 1}, {"metric_second", &hta::g_metric_second, 1}, {"metric_bx3", &hta::g_metric_bx3, 1}, {"metric_resident", &hta::g_metric_resident, 1}, {"metric_sqrtdraw", &hta::g_metric_sqrtdraw, 1}, {"rmhmc_fused", &hta::g_rmhmc_fused, 1},
+    {"mlp_valu", &hta::g_mlp_valu, 0}, {"metric_mfma", &hta::g_metric_mfma, 1}, {"metric_general", &hta::g_metric_general, 1}, {"metric_traj", &hta::g_metric_traj, 1}, {"metric_second", &hta::g_metric_second, 1}, {"metric_bx3", &hta::g_metric_bx3, 2}, {"metric_resident", &hta::g_metric_resident, 1}, {"metric_sqrtdraw", &hta::g_metric_sqrtdraw, 1}, {"rmhmc_fused", &hta::g_rmhmc_fused, 1},
     {"mlp3_route", &hta::g_mlp3_route, 1}, {"quad_variant", &hta::g_quad_variant, 7}, {"rmhmc_lean", &hta::g_rmhmc_lean, 1},
     {"rmhmc_uv_co", &hta::g_rmhmc_uv_co, 1}, {"rmhmc_uv_acc", &hta::g_rmhmc_uv_acc, 2}, {"rmhmc_uv_g", &hta::g_rmhmc_uv_g, 0}, {"rmhmc_uvc", &hta::g_rmhmc_uvc, 1}, {"quad_fused", &hta::g_quad_fused, 1}, {"quad_producers", &hta::g_quad_producers, 64}, {"quad_chunks", &hta::g_quad_chunks, 8}, {"quad_starve", &hta::g_quad_starve, 0},
 };

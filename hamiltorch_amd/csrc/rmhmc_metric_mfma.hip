@@ -52,7 +52,7 @@ namespace hta {
 
 int g_metric_mfma = 1;   // tuning key "metric_mfma": 1 = warm fp32 evaluations run here, 0 = always the Jacobi kernel
 int g_metric_second = 1;    // tuning key "metric_second": 1 = the refinement's second pass in closed form (one product: ph_refine_E2) where the first pass's update is small, 0 = always the full pass (three products)
-int g_metric_bx3 = 1;       // tuning key "metric_bx3": 1 = the fast solve's second-pass product F E1 as three bfloat16 products (operands split hi + lo), 0 = exact fp32 products
+int g_metric_bx3 = 2;       // tuning key "metric_bx3": 2 = the fast solve's formation AND its second-pass product F E1 as three bfloat16 products of operands split hi + lo, 1 = F E1 only (the formation in exact fp32), 0 = exact fp32 products
 int g_metric_sqrtdraw = 1;  // tuning key "metric_sqrtdraw": 1 = the momentum draw of soft-abs evaluations on a shared basis is p = G^(1/2) z (the symmetric square root: a SOLVE-shaped
                             // evaluation - same law as S:183-184's chol(G) z, no assembly of G, no Cholesky), 0 = the reference's map chol(G) z
 int g_metric_general = 1;   // tuning key "metric_general": 1 = evaluations with per-system curvature AND per-system bases run here too
@@ -329,6 +329,50 @@ __device__ __forceinline__ void gemm_macro_bx3(const float* pa0, const unsigned 
         acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, ah[x]), __builtin_bit_cast(s4v, tl[y]), acc[x][y], 0, 0, 0);
         acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, al[x]), __builtin_bit_cast(s4v, th[y]), acc[x][y], 0, 0, 0);
       }
+    }
+  }
+}
+
+// Both operands pre-split (the formation F = W W^T on the planes of W^T = (diag(sqrt e) V0)^T, round 6): a row tile against one or two
+// row tiles, three products per tile and 32 indices, no vector instruction in the loop.  pa / pb: row starts of the hi plane.
+template <bool C2>
+__device__ __forceinline__ void gemm_macro_pp(const unsigned short* pa0, const unsigned short* pb0, int nt, f4 (&acc)[2][2]) {
+  const int kg = (threadIdx.x & 63) >> 4;
+  const int DPh = 16 * nt, plane = DPh * DPh;
+  const unsigned short* pa = pa0 + 8 * kg;
+  const unsigned short* pb[2] = {pb0 + 8 * kg, pb0 + 16 * DPh + 8 * kg};
+  const int nfull = nt >> 1;
+  i4v ah, al, bh[2], bl[2];
+#define HTA_PP_LOAD(s)                                                                                   \
+  do {                                                                                                   \
+    ah = *reinterpret_cast<const i4v*>(pa + 32 * (s)); al = *reinterpret_cast<const i4v*>(pa + plane + 32 * (s)); \
+    bh[0] = *reinterpret_cast<const i4v*>(pb[0] + 32 * (s)); bl[0] = *reinterpret_cast<const i4v*>(pb[0] + plane + 32 * (s)); \
+    if (C2) { bh[1] = *reinterpret_cast<const i4v*>(pb[1] + 32 * (s)); bl[1] = *reinterpret_cast<const i4v*>(pb[1] + plane + 32 * (s)); } \
+  } while (0)
+  if (nfull > 0) HTA_PP_LOAD(0);
+  for (int s = 0; s < nfull; ++s) {
+    const i4v cah = ah, cal = al, cbh0 = bh[0], cbl0 = bl[0], cbh1 = bh[1], cbl1 = bl[1];
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 < nfull) HTA_PP_LOAD(s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, cah), __builtin_bit_cast(bf8v, cbh0), acc[0][0], 0, 0, 0);
+    if (C2) acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, cah), __builtin_bit_cast(bf8v, cbh1), acc[0][1], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, cah), __builtin_bit_cast(bf8v, cbl0), acc[0][0], 0, 0, 0);
+    if (C2) acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, cah), __builtin_bit_cast(bf8v, cbl1), acc[0][1], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, cal), __builtin_bit_cast(bf8v, cbh0), acc[0][0], 0, 0, 0);
+    if (C2) acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, cal), __builtin_bit_cast(bf8v, cbh1), acc[0][1], 0, 0, 0);
+  }
+#undef HTA_PP_LOAD
+  if (nt & 1) {                                                          // the last 16 indices
+    const int k0 = 16 * (nt - 1) + 4 * kg - 8 * kg;
+    const i2v th = *reinterpret_cast<const i2v*>(pa + k0), tl = *reinterpret_cast<const i2v*>(pa + plane + k0);
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      if (y == 1 && !C2) continue;
+      const i2v uh = *reinterpret_cast<const i2v*>(pb[y] + k0), ul = *reinterpret_cast<const i2v*>(pb[y] + plane + k0);
+      acc[0][y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, th), __builtin_bit_cast(s4v, uh), acc[0][y], 0, 0, 0);
+      acc[0][y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, th), __builtin_bit_cast(s4v, ul), acc[0][y], 0, 0, 0);
+      acc[0][y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, tl), __builtin_bit_cast(s4v, uh), acc[0][y], 0, 0, 0);
     }
   }
 }
@@ -1100,7 +1144,14 @@ __device__ __forceinline__ void plane_store_row(unsigned short* ph, unsigned sho
 // publish lam_i = lam0_i + F_ii, then every tile turns its accumulators into E1_ij = F_ij / (lam_j - lam_i) (ph_refine_E's
 // arithmetic with X = I: the same quotients, the same threshold) and stores F (zero diagonal) and E1 (antisymmetric, zero
 // diagonal) with their mirror images as 16-byte rows.  Returns max |E1_ij| (1 for NaN / inf / > kFallbackE).
-template <int LDC, bool PL>
+// WB (round 6, "metric_bx3" = 2): the formation itself on bfloat16.  W^T = (diag(sqrt e) V0)^T is written once per evaluation as two bfloat16
+// planes (hi, lo) into E1's buffer - idle until the epilogue - by a pass that reads V0 column-wise (4-byte reads, consecutive lanes on
+// consecutive columns) and stores 16-byte groups of eight contraction indices; F = W^T W is then three products per tile and 32 indices
+// with NO vector instruction in the loop (gemm_macro_pp): 1.2 k cycles of the matrix pipe per SIMD instead of 5.6 k.  Each term of F carries a
+// relative error 2^-16; emulated in float64 around it (tools/scratch/bf16_formation_err.py), max |x - x64| / max |x64| of a solve moves from
+// 7.4e-8 to 7.8e-8 at BASELINE config 3's jitter (1.5e-7 to 1.9e-7 at three times the jitter) - the closed-form second pass's own truncation
+// is that size, the kernel's fp32 vector arithmetic (3.6e-6) is fifty times it.
+template <int LDC, bool PL, bool WB = false>
 __device__ HTA_PH_ATTR float ph_fast_form(int offV, int offF, int offE, int offJit, int offLam0, int offLam, int offRed, int tile, int k4, int D, int LDr, int nt) {
   HTA_LDS_BASE();
   k4 = HTA_U(k4); D = HTA_U(D); nt = HTA_U(nt);
@@ -1121,11 +1172,42 @@ __device__ HTA_PH_ATTR float ph_fast_form(int offV, int offF, int offE, int offJ
   for (int x = 0; x < 2; ++x)
 #pragma unroll
     for (int y = 0; y < 2; ++y) acc[x][y] = f4{0.f, 0.f, 0.f, 0.f};
+  if (WB) {
+    // W^T planes: thread (column i = tid & 127 of V0, octet o = tid >> 7 [+ 8]) scales V0[8 o .. 8 o + 7][i] by sqrt(e) and splits
+    unsigned short* Wh = reinterpret_cast<unsigned short*>(E);
+    const int DPh = 16 * nt, plane = DPh * DPh;
+    const int i = threadIdx.x & 127, o0 = HTA_U(threadIdx.x >> 7);
+    if (i < DPh) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int o = o0 + 8 * u;
+        if (8 * o < DPh) {
+          float w[8];
+          const f4 s0 = *reinterpret_cast<const f4*>(kscale + 8 * o), s1 = *reinterpret_cast<const f4*>(kscale + 8 * o + 4);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) w[r] = V[(8 * o + r) * LD + i] * (r < 4 ? s0[r] : s1[r - 4]);      // (the scale vector holds sqrt(e) here: metric_fast_solve)
+          int h[4], l[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) split_pair(w[2 * r], w[2 * r + 1], h[r], l[r]);
+          *reinterpret_cast<i4v*>(Wh + i * DPh + 8 * o) = i4v{h[0], h[1], h[2], h[3]};
+          *reinterpret_cast<i4v*>(Wh + plane + i * DPh + 8 * o) = i4v{l[0], l[1], l[2], l[3]};
+        }
+      }
+    }
+    __syncthreads();
+  }
   if (active) {
-    const float* pa0 = V + lk * LD + 16 * I0 + li;
-    const float* pb0 = V + lk * LD + 16 * J0 + li;
-    if (c2) gemm_macro<true, false, true, false, true>(pa0, pb0, kscale, k4, LD, lk, acc);
-    else gemm_macro<true, false, true, false, false>(pa0, pb0, kscale, k4, LD, lk, acc);
+    if (WB) {
+      const unsigned short* Wh = reinterpret_cast<const unsigned short*>(E);
+      const unsigned short* pa0 = Wh + (16 * I0 + li) * (16 * nt);
+      const unsigned short* pb0 = Wh + (16 * J0 + li) * (16 * nt);
+      if (c2) gemm_macro_pp<true>(pa0, pb0, nt, acc); else gemm_macro_pp<false>(pa0, pb0, nt, acc);
+    } else {
+      const float* pa0 = V + lk * LD + 16 * I0 + li;
+      const float* pb0 = V + lk * LD + 16 * J0 + li;
+      if (c2) gemm_macro<true, false, true, false, true>(pa0, pb0, kscale, k4, LD, lk, acc);
+      else gemm_macro<true, false, true, false, false>(pa0, pb0, kscale, k4, LD, lk, acc);
+    }
     HTA_WVSTAMP(5);
     if (I0 == J0) {
 #pragma unroll
@@ -1495,7 +1577,7 @@ __device__ __forceinline__ int opaque_tid() {
 // and w = y sqrt(lam~); the result goes to a.p_out (resident: it REPLACES the vector of res_upd & 0xffff; res_xm then names theta' and the
 // place V0^T z is taken from / put to)
 __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, int DP, int LD, int64_t b, int& vres, bool bx3, int tiles,
-                                                  int res_xm = -1, int res_upd = 0, bool sdraw = false) {
+                                                  int res_xm = -1, int res_upd = 0, bool sdraw = false, bool wb = false) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = a.D, tid = threadIdx.x;
   const int nt = DP / 16, k4 = (D + 3) / 4;
@@ -1513,7 +1595,10 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
   if (tid < DP) {
     const int i = opaque_tid();
     const bool in = i < D;
-    lds0[oJit + i] = (in && a.has_jitter) ? (float)a.jitter * uniform_elem<float>(a.seed, chain, a.draw, PURPOSE_JITTER, a.sub, i) : 0.f;
+    {
+      const float ej = (in && a.has_jitter) ? (float)a.jitter * uniform_elem<float>(a.seed, chain, a.draw, PURPOSE_JITTER, a.sub, i) : 0.f;
+      lds0[oJit + i] = (wb && bx3 && LD == kLdCfg3) ? sqrtf(ej) : ej;      // (the bfloat16 formation scales BOTH operands: sqrt(e))
+    }
     if (res_xm >= 0) {
       lds0[oM + i] = lds0[4 * (res_xm >> 16) + i];
       lds0[oD + i] = lds0[4 * (res_xm & 0xffff) + i];
@@ -1531,7 +1616,8 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
   if (res_xm < 0) ph_fast_vt(bx, oY, oM, oD, DP, LD);
   HTA_STAMP(2);
   const bool planes = bx3 && LD == kLdCfg3;                          // F as bfloat16 planes for the bfloat16 form of the second product
-  const float e1 = planes ? ph_fast_form<kLdCfg3, true>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD, nt)
+  const float e1 = (planes && wb) ? ph_fast_form<kLdCfg3, true, true>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD, nt)
+                   : planes ? ph_fast_form<kLdCfg3, true>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD, nt)
                    : LD == kLdCfg3 ? ph_fast_form<kLdCfg3, false>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD, nt)
                                    : ph_fast_form<0, false>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD, nt);
   HTA_STAMP(3);
@@ -1637,7 +1723,7 @@ __device__ __forceinline__ void metric_warm_system(const MetricArgsT<float>& a, 
   const bool has_m = a.m || sdraw;
   // (second & 32: the caller has tried the fast solve itself - metric_warm_mfma_kernel - and it declined)
   if (!(second & 32) && (second & 1) && softabs && !general && has_m && !(a.G_out || (a.p_out && !sdraw) || a.V_out || a.dmetric_out) && (!a.X || a.Pm == a.Hs)) {
-    if (metric_fast_solve(a, DP, LD, b, vres, (second & 2) != 0, tiles, -1, 0, sdraw)) return;
+    if (metric_fast_solve(a, DP, LD, b, vres, (second & 2) != 0, tiles, -1, 0, sdraw, (second & 64) != 0)) return;
   }
 
   {
@@ -1967,7 +2053,7 @@ __global__ __launch_bounds__(MT) void metric_warm_mfma_kernel(MetricArgsT<float>
                     (!a.X || a.Pm == a.Hs);
   for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
     int vres = -1;
-    if (fast && metric_fast_solve(a, DP, LD, b, vres, (second & 2) != 0, tiles, -1, 0, sdraw)) continue;
+    if (fast && metric_fast_solve(a, DP, LD, b, vres, (second & 2) != 0, tiles, -1, 0, sdraw, (second & 64) != 0)) continue;
     warm_general_eval(ka, DP, LD, b, vres, second | 32, tiles);
   }
 }
@@ -2103,7 +2189,7 @@ __global__ __launch_bounds__(MT) void metric_traj_mfma_kernel(MetricArgsT<float>
       ph_fast_vt(vres, oY, sP, sTh, DP, LD);
       MetricArgsT<float> o = a;
       o.sub = 0; o.X = nullptr; o.m = nullptr; o.p_out = t.pm;
-      drawn = metric_fast_solve(o, DP, LD, b, vres, (second & 2) != 0, tiles, (sTh >> 2) | ((sP >> 2) << 16), sP >> 2, true);
+      drawn = metric_fast_solve(o, DP, LD, b, vres, (second & 2) != 0, tiles, (sTh >> 2) | ((sP >> 2) << 16), sP >> 2, true, (second & 64) != 0);
     }
     if (!drawn) {
       vres = traj_general_eval(ka, DP, LD, b, vres, 0, second, tiles, 0);                      // the draw on the general sequence (p in t.pm)
@@ -2133,7 +2219,7 @@ __global__ __launch_bounds__(MT) void metric_traj_mfma_kernel(MetricArgsT<float>
       const bool step = j >= 0;
       const int rx = (step && !fa) ? sThc : sTh, rm = (step && fa) ? sPc : sP;
       const int upd = step ? (((fa ? sThc : sTh) >> 2) | (((fa ? sP : sPc) >> 2) << 16)) : 0;
-      if (!metric_fast_solve(o, DP, LD, b, vres, (second & 2) != 0, tiles, (rx >> 2) | ((rm >> 2) << 16), upd))
+      if (!metric_fast_solve(o, DP, LD, b, vres, (second & 2) != 0, tiles, (rx >> 2) | ((rm >> 2) << 16), upd, false, (second & 64) != 0))
         vres = traj_general_eval(ka, DP, LD, b, vres, op, second | 8, tiles, 1);                   // (rare: a first pass above kSecondE, a non-finite state)
       if (j == 1) {                                                                            // phi_C  S:447-450 (element-wise: any orthonormal basis)
         __syncthreads();
@@ -2170,7 +2256,7 @@ int metric_traj_mfma(const MetricArgsT<float>& a, const MetricTrajArgs& t, hipSt
   const int grid = (int)(a.B < 65536 ? a.B : 65536);
   profile_begin(s);
   note_route("metric_traj_mfma_kernel");
-  metric_traj_mfma_kernel<<<grid, MT, lds, s>>>(k, t, DP, LD, (g_metric_second ? 1 : 0) | (g_metric_bx3 ? 2 : 0) | (g_metric_resident ? 4 : 0) | (g_metric_sqrtdraw ? 16 : 0));
+  metric_traj_mfma_kernel<<<grid, MT, lds, s>>>(k, t, DP, LD, (g_metric_second ? 1 : 0) | (g_metric_bx3 ? 2 : 0) | (g_metric_resident ? 4 : 0) | (g_metric_sqrtdraw ? 16 : 0) | (g_metric_bx3 >= 2 ? 64 : 0));
   profile_end(s);
   HTA_CHECK_LAUNCH("hta_rmhmc_gaussian_sample (trajectory kernel)");
   return HTA_OK;
@@ -2203,7 +2289,7 @@ int metric_warm_mfma(const MetricArgsT<float>& a, hipStream_t s) {
   const int grid = (int)(a.B < 65536 ? a.B : 65536);
   profile_begin(s);
   note_route("metric_warm_mfma_kernel");
-  metric_warm_mfma_kernel<<<grid, MT, lds, s>>>(k, DP, LD, (g_metric_second ? 1 : 0) | (g_metric_bx3 ? 2 : 0) | (g_metric_sqrtdraw ? 16 : 0));
+  metric_warm_mfma_kernel<<<grid, MT, lds, s>>>(k, DP, LD, (g_metric_second ? 1 : 0) | (g_metric_bx3 ? 2 : 0) | (g_metric_sqrtdraw ? 16 : 0) | (g_metric_bx3 >= 2 ? 64 : 0));
   profile_end(s);
   HTA_CHECK_LAUNCH("hta_metric_eval (mfma)");
   return HTA_OK;

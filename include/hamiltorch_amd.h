@@ -503,11 +503,13 @@ int hta_jit_rmhmc_sample(void* module, const HtaCbRmhmcArgs* args, int D, int it
  * momentum draw - theta' = V0^T (theta - mu), p' = V0^T p - and keeps them in LDS: a solve evaluation has no V0 product and no global
  * traffic but its scalars, theta = mu + V0 theta' at the end; agreement with the launch sequence to fp32 rounding; 0 = the state in the
  * caller's coordinates in global memory: bit-identical to the launch sequence),
- * "metric_bx3" (round 6; 1 default: in the SOLVE evaluations of a Gaussian target on the shared basis - the fast sequence of
+ * "metric_bx3" (round 6; 2 default: in the SOLVE evaluations of a Gaussian target on the shared basis - the fast sequence of
  * csrc/rmhmc_metric_mfma.hip: V0 resident, the element-wise passes in the products' epilogues, log p and P d from the eigenbasis -
- * the closed-form second pass takes its product F E1 as three bfloat16 products, the operands split hi + lo on the fly: relative
- * error 2^-16 of a correction that is itself below 1e-4, i.e. under fp32 rounding of the first-order terms, which stay exact fp32
- * products; 0 = that product in exact fp32 as well: the parity partner),
+ * both D^3 products run as three bfloat16 products of operands split hi + lo: the closed-form second pass's F E1 (a correction that is
+ * itself below 1e-4: its 2^-16 relative error is under fp32 rounding of the first-order terms) and the formation F = W^T W on the planes
+ * of W = diag(sqrt e) V0 (a term of F with relative error 2^-16 moves a solve by 4e-9 of its size in a float64 emulation - less than the
+ * closed-form pass's own truncation; tools/scratch/bf16_formation_err.py); 1 = F E1 only, the formation in exact fp32; 0 = both in exact
+ * fp32: the parity partner),
  * "mlp3_route" (1 default: Bayesian MLPs with two wide hidden layers run on csrc/mlp3_mfma.hip; 0 = callback path),
  * "quad_variant" (7 default: the quad kernel with wave-uniform base addresses + 32-bit lane offsets, without the NaN guard of
  * the accept compare, and with the row element and the energy butterfly in one interleaved block; 3 = without that block;

@@ -1017,10 +1017,11 @@ def test_symmetric_square_root_draw_vs_oracle(ht, D, kind, alpha, jitter):
                                             (17, 1e6, 1e-3), (70, 1e6, 1e-3), (90, 2.0, 1e-3)])      # (every tile count 1 ... 7: 2, 5 and 6 tiles here)
 def test_fast_solve_with_bfloat16_products_equals_exact_products(ht, D, alpha, jitter):
     """Round 6 ("metric_bx3"): the solve evaluations of a Gaussian target on the shared basis run a reorganised sequence (V0 resident,
-    the element-wise passes in the products' epilogues, log p and P d from the eigenbasis) whose second-pass product F E1 is taken
-    as three bfloat16 products of operands split hi + lo (1) or in exact fp32 (0).  F E1 is a second-order correction: its 2^-16
-    relative error must not be visible - the two agree an order tighter than either agrees with float64, and (1) is as close to the
-    float64 oracle as (0).  Every output of the solve: x through upd_x, P d through upd_g, log|G|, the quadratic form, H, log p, the
+    the element-wise passes in the products' epilogues, log p and P d from the eigenbasis) whose second-pass product F E1 (1), and
+    whose formation F = V0^T diag(e) V0 as well (2, the default), are taken as three bfloat16 products of operands split hi + lo, or
+    in exact fp32 (0).  F E1 is a second-order correction, and a term of F with relative error 2^-16 moves the solve by less than the
+    closed-form second pass's own truncation (tools/scratch/bf16_formation_err.py): neither may be visible - (2) and (1) agree with (0)
+    an order tighter than any of them agrees with float64, and (2) is as close to the float64 oracle as (0).  Every output of the solve: x through upd_x, P d through upd_g, log|G|, the quadratic form, H, log p, the
     soft-abs spectrum; no jitter (F = 0: the second pass is skipped), the smallest and the largest tile counts."""
     from hamiltorch_amd import _abi
     rng = np.random.default_rng(D + 5)
@@ -1030,12 +1031,14 @@ def test_fast_solve_with_bfloat16_products_equals_exact_products(ht, D, alpha, j
     m = rng.standard_normal((B, D)).astype(np.float32)
     outs = []
     try:
-        for bx3 in (1, 0):
+        for bx3 in (2, 1, 0):      # 2 (default): formation and F E1 on bfloat16; 1: F E1 only; 0: exact fp32 products
             _abi.set_tuning("metric_bx3", bx3)
             outs.append(_warm_eval(ht, P, X, m, alpha, jitter, seed, 1, want_g=False))
     finally:
-        _abi.set_tuning("metric_bx3", 1)
-    a, f = outs
+        _abi.set_tuning("metric_bx3", 2)
+    a, a1, f = outs
+    np.testing.assert_allclose(a1["x"], f["x"], rtol=0, atol=2e-6 * np.abs(f["x"]).max())
+    np.testing.assert_allclose(a1["lam"], f["lam"], rtol=0, atol=1e-6 * np.abs(f["lam"]).max())
     Hs = np.broadcast_to(P, (B, D, D)).astype(np.float64).copy()
     ju = None if jitter is None else O.philox_uniforms(seed, 3 + np.arange(B), 7, D, O.PURPOSE_JITTER, 2, dtype=np.float64)
     G, lam, _ = O.softabs_metric(Hs, alpha, jitter, ju)
