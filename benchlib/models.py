@@ -112,13 +112,16 @@ def rmhmc_eig_useful_flops(D, L, sqrtdraw=True):
 BF16_OVER_FP32_MATRIX_PEAK = 16.0       # MI355X_MICROARCH.md: dense bf16 2.5 PFLOP/s = 16 x the fp32 matrix peak
 
 
-def rmhmc_eig_pipe_time_flops(D, L, bx3=True):
-    """The same work priced in fp32-MATRIX-PIPE TIME (round 6): in a solve evaluation the second pass's product F E1 (2 D^3) runs as three
-    bfloat16 products of split operands ("metric_bx3") - 3 x 2 D^3 bfloat16 flops at 16 x the fp32 rate = 0.375 D^3 fp32-pipe equivalents -
-    beside the formation's D^3 in fp32; all 4 L + 3 evaluations of a trajectory are solve-shaped (the draw: "metric_sqrtdraw").  useful / fp32 peak no
-    longer bounds by the pipe-busy share; this figure / fp32 peak does."""
-    second = 2.0 * (3.0 / BF16_OVER_FP32_MATRIX_PEAK if bx3 else 1.0)
-    return (4 * L + 3) * (1.0 + second) * D ** 3 / float(L)
+def rmhmc_eig_pipe_time_flops(D, L, bx3=2):
+    """The same work priced in fp32-MATRIX-PIPE TIME (round 6): products that run as three bfloat16 products of split operands take
+    3 / 16 of their fp32 time (bf16 at 16 x the fp32 matrix rate) - "metric_bx3" = 1: the second pass's F E1 (2 D^3 -> 0.375 D^3 fp32-pipe
+    equivalents) beside the formation's D^3 in fp32; 2 (default): the formation as well (D^3 -> 0.1875 D^3); 0 / False: everything in
+    fp32 (= the useful flops).  All 4 L + 3 evaluations of a trajectory are solve-shaped (the draw: "metric_sqrtdraw").  useful / fp32
+    peak no longer bounds by the pipe-busy share; this figure / fp32 peak does."""
+    r = 3.0 / BF16_OVER_FP32_MATRIX_PEAK
+    form = r if int(bx3) >= 2 else 1.0
+    second = 2.0 * (r if int(bx3) >= 1 else 1.0)
+    return (4 * L + 3) * (form + second) * D ** 3 / float(L)
 
 
 # ---------------------------------------------------------------------------------------------------

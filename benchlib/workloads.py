@@ -158,7 +158,7 @@ class Cfg3:
     def roof_kernel(self):      # the trajectory kernel the library picks at this chain count (csrc/rmhmc_fused.hip dispatch)
         if self.jacobi:
             return ("metric_traj_mfma_kernel (one launch per trajectory: a chain's workgroup runs its 4 L + 3 metric evaluations - "
-                    "eigenvector refinement: formation on v_mfma_f32_16x16x4_f32, second-order product on 3 x v_mfma_f32_16x16x32_bf16, "
+                    "eigenvector refinement: formation and second-order product on 3 x v_mfma_f32_16x16x32_bf16 of split operands, "
                     "state resident in LDS in eigen-coordinates - back to back) + mh_select_kernel")
         if self.C <= 256:
             return ("rmhmc_uvc_kernel (one chain per workgroup: state set and copy as columns of v_mfma_f32_4x4x1_16b, one value per "
@@ -214,7 +214,7 @@ class Cfg3:
         if self.jacobi:      # round 6: F E1 runs as three bfloat16 products - the fp32-equivalent fraction is not a pipe utilisation any more
             pt = models.rmhmc_eig_pipe_time_flops(self.D, self.L) * units / sec / 1e12
             extra = {"pipe_time_frac": pt / FP32_PEAK_TFLOPS,
-                     "pipe_time_note": "useful work priced in fp32-matrix-pipe time (formation D^3 in fp32 + F E1 as 3 x 2 D^3 bfloat16 flops at "
+                     "pipe_time_note": "useful work priced in fp32-matrix-pipe time (both D^3 products of an evaluation run as 3 x their flops in bfloat16 at "
                                        "16 x the rate): the figure the pipe-busy counter bounds; `frac` prices every useful flop at the fp32 peak"}
         return {"bound": "mfma", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
                 "traffic": None, "kernel": self.roof_kernel, "kernel_ms_per_step": kernel_ms, "call_ms": call_ms,

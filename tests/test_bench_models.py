@@ -77,7 +77,7 @@ def test_useful_flops_do_not_exceed_the_counted_ones(key, chain_steps, useful):
         assert useful <= issued, (key, useful, issued)
         pipe = M.rmhmc_eig_pipe_time_flops(100, 10) * chain_steps / (d["ms_per_step"] * 1e-3) / 1e12 / M.FP32_PEAK_TFLOPS
         assert 0 < pipe <= PHYS[key]["mfma_busy_frac"] * 1.02 + 1e-9, (key, pipe, PHYS[key]["mfma_busy_frac"])
-        assert M.rmhmc_eig_pipe_time_flops(100, 10) < useful and M.rmhmc_eig_pipe_time_flops(100, 10, bx3=False) == pytest.approx(useful)
+        assert M.rmhmc_eig_pipe_time_flops(100, 10) < M.rmhmc_eig_pipe_time_flops(100, 10, bx3=1) < useful and M.rmhmc_eig_pipe_time_flops(100, 10, bx3=0) == pytest.approx(useful)
         return
     assert useful <= issued, (key, useful, issued)
     # and the fraction that follows from the counters' own kernel time is physical
