@@ -246,89 +246,78 @@ __device__ __forceinline__ void split_pair(float x0, float x1, int& hi, int& lo)
   const f2v r = x - h;
   lo = (int)__builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302);
 }
-// The B operand (F) arrives already split: the formation's epilogue stores it as two bfloat16 planes [DP][DP] (hi, then lo; rows 2 DP bytes
-// apart - with an odd tile count the 16 lanes of a ds_read_b128 group fall on 16 different quads of the bank row) in the buffer fp32 F
-// would take.  Measured (HTA_GEMM_ABLATE builds): the k loop's time is the SUM of its matrix instructions' time and its other
-// instructions' time, not the larger - every split saved is time saved.
-template <bool R2, bool C2>
-__device__ __forceinline__ void gemm_macro_bx3(const float* pa0, const unsigned short* pb0, int nt, int LD, f4 (&acc)[2][2]) {
-  // pa0 = E1 + (16 J0 + li) LD (row start, fp32), pb0 = Fhi + (16 I0 + li) DP (row start of the hi plane); the lane's k offset is added here
+// (F arrives already split: the formation's epilogue stores it as two bfloat16 planes [DP][DP] (hi, then lo; rows 2 DP bytes apart - with an odd
+// tile count the 16 lanes of a ds_read_b128 group fall on 16 different quads of the bank row) in the buffer fp32 F would take.  Measured
+// (HTA_GEMM_ABLATE builds): a k loop's time is the SUM of its matrix instructions' time and its other instructions' time, not the larger -
+// every split saved is time saved.)
+// A 1 x NB strip of the second product: ONE tile of E1 rows (operand A, fp32, split on the fly ONCE per 32 indices) against NB <= 4 tiles
+// of F's planes (operand B) - the 2 x 2 macro tile split its two A tiles for two B tiles each, and the split is what that loop's time is
+// made of.  acc[y] = sum_k E1[j][k] F[i_y][k] = -M[i_y][j].
+template <int NB>
+__device__ __forceinline__ void gemm_strip_bx3(const float* pa0, const unsigned short* pb0, int nt, f4 (&acc)[4]) {
   const int kg = (threadIdx.x & 63) >> 4;
   const int DPh = 16 * nt, plane = DPh * DPh;
-  const float* pa[2] = {pa0 + 8 * kg, pa0 + 16 * LD + 8 * kg};
-  const unsigned short* pb[2] = {pb0 + 8 * kg, pb0 + 16 * DPh + 8 * kg};
+  const float* pa = pa0 + 8 * kg;
+  const unsigned short* pb = pb0 + 8 * kg;
   const int nfull = nt >> 1;
-  // Register budget: a phase function that needs more than the 80 caller-saved VGPRs saves and restores the rest through scratch memory
-  // in its prologue / epilogue - measured at 4-7 k cycles per call (16 waves x 15 dwords, a round trip beyond the L2 each).  So: the B
-  // tiles
-  // of the next step are requested as soon as this step's are taken, the A tiles are split one at a time, each requested while the previous
-  // one's products run.
-  i4v bh[2], bl[2];                                                      // the B tiles: the next step's are requested into the same registers right behind
-#define HTA_BX_LOAD_B(s)                                                 /* this step's last products (the A split of the next step covers the latency) */ \
-  do {                                                                                                   \
-    bh[0] = *reinterpret_cast<const i4v*>(pb[0] + 32 * (s)); bl[0] = *reinterpret_cast<const i4v*>(pb[0] + plane + 32 * (s)); \
-    if (C2) { bh[1] = *reinterpret_cast<const i4v*>(pb[1] + 32 * (s)); bl[1] = *reinterpret_cast<const i4v*>(pb[1] + plane + 32 * (s)); } \
-  } while (0)
-  f4 ra0, ra1;                                                           // the A tile in flight (the next one is requested as soon as this one is split)
-  if (nfull > 0) {
-    HTA_BX_LOAD_B(0);
-    ra0 = *reinterpret_cast<const f4*>(pa[0]); ra1 = *reinterpret_cast<const f4*>(pa[0] + 4);
-  }
+  f4 ra0, ra1;
+  if (nfull > 0) { ra0 = *reinterpret_cast<const f4*>(pa); ra1 = *reinterpret_cast<const f4*>(pa + 4); }
   for (int s = 0; s < nfull; ++s) {
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-      if (x == 1 && !R2) continue;
-      i4v ah, al;
-      {
-        int h, l;
-        split_pair(ra0[0], ra0[1], h, l); ah[0] = h; al[0] = l;
-        split_pair(ra0[2], ra0[3], h, l); ah[1] = h; al[1] = l;
-        split_pair(ra1[0], ra1[1], h, l); ah[2] = h; al[2] = l;
-        split_pair(ra1[2], ra1[3], h, l); ah[3] = h; al[3] = l;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (R2 && x == 0) { ra0 = *reinterpret_cast<const f4*>(pa[1] + 32 * s); ra1 = *reinterpret_cast<const f4*>(pa[1] + 32 * s + 4); }
-      else if (s + 1 < nfull) { ra0 = *reinterpret_cast<const f4*>(pa[0] + 32 * (s + 1)); ra1 = *reinterpret_cast<const f4*>(pa[0] + 32 * (s + 1) + 4); }
-      __builtin_amdgcn_sched_barrier(0);
-      acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, ah), __builtin_bit_cast(bf8v, bh[0]), acc[x][0], 0, 0, 0);
-      if (C2) acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, ah), __builtin_bit_cast(bf8v, bh[1]), acc[x][1], 0, 0, 0);
-      acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, ah), __builtin_bit_cast(bf8v, bl[0]), acc[x][0], 0, 0, 0);
-      if (C2) acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, ah), __builtin_bit_cast(bf8v, bl[1]), acc[x][1], 0, 0, 0);
-      acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, al), __builtin_bit_cast(bf8v, bh[0]), acc[x][0], 0, 0, 0);
-      if (C2) acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, al), __builtin_bit_cast(bf8v, bh[1]), acc[x][1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (s + 1 < nfull) HTA_BX_LOAD_B(s + 1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#undef HTA_BX_LOAD_B
-  if (nt & 1) {                                                          // the last 16 indices
-    const int k0 = 16 * (nt - 1) + 4 * kg - 8 * kg;                      // (pa / pb carry 8 kg)
-    i2v ah[2], al[2], th[2], tl[2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-      if (x == 1 && !R2) continue;
-      const f4 v = *reinterpret_cast<const f4*>(pa[x] + k0);
-      int h, l;
-      split_pair(v[0], v[1], h, l); ah[x][0] = h; al[x][0] = l;
-      split_pair(v[2], v[3], h, l); ah[x][1] = h; al[x][1] = l;
-    }
+    // (B tiles two at a time: all four at once put the function beyond the caller-saved registers)
+    i4v bh[2], bl[2];
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
-      if (y == 1 && !C2) continue;
-      th[y] = *reinterpret_cast<const i2v*>(pb[y] + k0);
-      tl[y] = *reinterpret_cast<const i2v*>(pb[y] + plane + k0);
+      if (y >= NB) continue;
+      bh[y] = *reinterpret_cast<const i4v*>(pb + y * 16 * DPh + 32 * s);
+      bl[y] = *reinterpret_cast<const i4v*>(pb + y * 16 * DPh + plane + 32 * s);
     }
+    i4v ah, al;
+    {
+      int h, l;
+      split_pair(ra0[0], ra0[1], h, l); ah[0] = h; al[0] = l;
+      split_pair(ra0[2], ra0[3], h, l); ah[1] = h; al[1] = l;
+      split_pair(ra1[0], ra1[1], h, l); ah[2] = h; al[2] = l;
+      split_pair(ra1[2], ra1[3], h, l); ah[3] = h; al[3] = l;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 < nfull) { ra0 = *reinterpret_cast<const f4*>(pa + 32 * (s + 1)); ra1 = *reinterpret_cast<const f4*>(pa + 32 * (s + 1) + 4); }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
-      if (x == 1 && !R2) continue;
+    for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
       for (int y = 0; y < 2; ++y) {
-        if (y == 1 && !C2) continue;
-        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, ah[x]), __builtin_bit_cast(s4v, th[y]), acc[x][y], 0, 0, 0);
-        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, ah[x]), __builtin_bit_cast(s4v, tl[y]), acc[x][y], 0, 0, 0);
-        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, al[x]), __builtin_bit_cast(s4v, th[y]), acc[x][y], 0, 0, 0);
+        if (y >= NB) continue;
+        acc[y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, pr == 2 ? al : ah), __builtin_bit_cast(bf8v, pr == 1 ? bl[y] : bh[y]), acc[y], 0, 0, 0);
       }
+    __builtin_amdgcn_sched_barrier(0);
+    if (NB > 2) {
+#pragma unroll
+      for (int y = 2; y < 4; ++y) {
+        if (y >= NB) continue;
+        bh[y - 2] = *reinterpret_cast<const i4v*>(pb + y * 16 * DPh + 32 * s);
+        bl[y - 2] = *reinterpret_cast<const i4v*>(pb + y * 16 * DPh + plane + 32 * s);
+      }
+#pragma unroll
+      for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+        for (int y = 2; y < 4; ++y) {
+          if (y >= NB) continue;
+          acc[y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, pr == 2 ? al : ah), __builtin_bit_cast(bf8v, pr == 1 ? bl[y - 2] : bh[y - 2]), acc[y], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (nt & 1) {
+    const int k0 = 16 * (nt - 1) + 4 * kg - 8 * kg;
+    const f4 v = *reinterpret_cast<const f4*>(pa + k0);
+    i2v th, tl;
+    { int h, l; split_pair(v[0], v[1], h, l); th[0] = h; tl[0] = l; split_pair(v[2], v[3], h, l); th[1] = h; tl[1] = l; }
+#pragma unroll
+    for (int y = 0; y < NB; ++y) {
+      const i2v uh = *reinterpret_cast<const i2v*>(pb + y * 16 * DPh + k0), ul = *reinterpret_cast<const i2v*>(pb + y * 16 * DPh + plane + k0);
+      acc[y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, th), __builtin_bit_cast(s4v, uh), acc[y], 0, 0, 0);
+      acc[y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, th), __builtin_bit_cast(s4v, ul), acc[y], 0, 0, 0);
+      acc[y] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, tl), __builtin_bit_cast(s4v, uh), acc[y], 0, 0, 0);
     }
   }
 }
@@ -1119,7 +1108,16 @@ __device__ __forceinline__ int fast_tiles(int nt) {
     const int I0 = 2 * r, J0 = 2 * c;
     hi = I0 | (J0 << 4) | ((I0 + 1 < nt ? 1 : 0) << 8) | ((J0 + 1 < nt ? 1 : 0) << 9) | (active << 10);
   }
-  return lo | (hi << 16);
+  // bits 27 .. 30 / 31: the wave's STRIP of the second product's bfloat16 form (ph_fast_second_strip) and whether it has one.  Strip s < nt:
+  // column tile J = s against row tiles 0 .. 3; strip nt + J: against row tiles 4 .. nt - 1.  nt = 7 (BASELINE config 3): 7 strips of four
+  // tiles and 7 of three dealt so that the four SIMDs (wave & 3) carry 13 / 12 / 12 / 12 tiles.
+  int sid = wave, sact = wave < nt * ((nt + 3) >> 2) ? 1 : 0;
+  if (nt == 7) {
+    const int big[7] = {0, 1, 5, 9, 2, 6, 10}, small[7] = {4, 8, 12, 3, 7, 11, 15};
+    sact = 0;
+    for (int k = 0; k < 7; ++k) { if (wave == big[k]) { sid = k; sact = 1; } if (wave == small[k]) { sid = 7 + k; sact = 1; } }
+  }
+  return (int)((unsigned)(lo | (hi << 16)) | ((unsigned)(sid & 15) << 27) | ((unsigned)sact << 31));
 }
 
 // F as two bfloat16 planes (PL: what the bfloat16 form of the second product reads): hi = the upper half of the fp32 word, lo = the upper
@@ -1303,7 +1301,7 @@ __device__ HTA_PH_ATTR float ph_fast_form(int offV, int offF, int offE, int offJ
 // M = F E1 (as lds_gemm_ld<false, false, false, false>) with the closed-form second pass in the epilogue (ph_refine_E2's arithmetic
 // on the accumulators): lam_i' = lam_i + M_ii from the diagonal tiles, E2_ij = M_ij / (lam_j' - lam_i'), E2_ii = -1/2 sum_k E1_ik^2
 // (row sums taken before the product), E2 stored over F once every wave has left its k loop.  Returns max |E2_ij|.
-template <int LDC, bool BX3>
+template <int LDC>
 // Round 6, later: the vectors' first two products ride along.  The pass over E1 that takes the row sums also takes E1 m' - y0 = m' - E1 m'
 // is published before the product - and the epilogue, which holds E2 in registers, accumulates y0^T E2 per column (a DPP row sum over the 16
 // rows of a tile, one 16-byte store of four columns per tile and lane group) into one partial vector per macro-tile row (offP0 .. offP3:
@@ -1350,14 +1348,8 @@ __device__ HTA_PH_ATTR float ph_fast_second(int offF, int offE, int oVec, int of
 #pragma unroll
     for (int y = 0; y < 2; ++y) acc[x][y] = f4{0.f, 0.f, 0.f, 0.f};
   if (active) {
-    if (BX3) {
-      const float* pa0 = E + (16 * J0 + li) * LD;
-      const unsigned short* pb0 = reinterpret_cast<const unsigned short*>(F) + (16 * I0 + li) * (16 * nt);      // F as bfloat16 planes (ph_fast_form<.., true>)
-      if (r2 && c2) gemm_macro_bx3<true, true>(pa0, pb0, nt, LD, acc);
-      else if (c2) gemm_macro_bx3<true, false>(pa0, pb0, nt, LD, acc);
-      else if (r2) gemm_macro_bx3<false, true>(pa0, pb0, nt, LD, acc);
-      else gemm_macro_bx3<false, false>(pa0, pb0, nt, LD, acc);
-    } else {
+    // (exact fp32 products; the bfloat16 form runs on strips: ph_fast_second_strip)
+    {
       const float* pa0 = E + (16 * J0 + li) * LD + lk;
       const float* pb0 = F + lk * LD + 16 * I0 + li;
       if (r2 && c2) gemm_macro<false, false, false, true, true>(pa0, pb0, nullptr, k4, LD, lk, acc);
@@ -1442,6 +1434,119 @@ __device__ HTA_PH_ATTR float ph_fast_second(int offF, int offE, int oVec, int of
   return emax;
 }
 
+// The bfloat16 form of the second product on 1 x 4 / 1 x 3 STRIPS (fast_tiles bits 27 .. 31): the same pre-pass, barrier and element-wise step
+// as ph_fast_second<.., true>, one E1 tile per wave split once per 32 indices for up to four tiles of F's planes; the partial vectors of
+// E2^T y0 are two (row tiles 0 .. 3 -> the slot of I0 = 0, row tiles 4 .. -> the slot of I0 = 4: ph_fast_chain flag 32).
+template <int LDC>
+__device__ HTA_PH_ATTR float ph_fast_second_strip(int offF, int offE, int oVec, int offRed, int nt, int tile, int D) {
+  HTA_LDS_BASE();
+  nt = HTA_U(nt); D = HTA_U(D); oVec = HTA_U(oVec);
+  constexpr int LD = LDC;
+  const int DPv = 16 * nt;
+  float* F = lds + HTA_U(offF); const float* E = lds + HTA_U(offE);
+  float* vlam = lds + oVec + DPv; const float* vm = lds + oVec + 3 * DPv; float* vy = lds + oVec + 4 * DPv; float* vcs = lds + oVec + 7 * DPv;
+  float* red = lds + HTA_U(offRed);
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  {
+    const int row = threadIdx.x >> 3, seg = threadIdx.x & 7;
+    float c0 = 0.f, c1 = 0.f, u0 = 0.f, u1 = 0.f;
+    if (row < 16 * nt) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = seg + 8 * u;
+        if (q < 4 * nt) {
+          const f4 v = *reinterpret_cast<const f4*>(E + row * LD + 4 * q);
+          const f4 mq = *reinterpret_cast<const f4*>(vm + 4 * q);
+          c0 = fmaf(v[0], v[0], c0); c1 = fmaf(v[1], v[1], c1); c0 = fmaf(v[2], v[2], c0); c1 = fmaf(v[3], v[3], c1);
+          u0 = fmaf(v[0], mq[0], u0); u1 = fmaf(v[1], mq[1], u1); u0 = fmaf(v[2], mq[2], u0); u1 = fmaf(v[3], mq[3], u1);
+        }
+      }
+    }
+    const float cs = sum8_dpp(c0 + c1), e1m = sum8_dpp(u0 + u1);
+    if (seg == 0 && row < 16 * nt) { vcs[row] = cs; vy[row] = (row < D) ? vm[row] - e1m : 0.f; }
+  }
+  HTA_WVSTAMP(10);
+  const unsigned tl = (unsigned)HTA_U(tile);
+  const int sid = (tl >> 27) & 15;
+  const bool active = (tl >> 31) != 0;
+  const int part = sid >= nt ? 1 : 0, J = sid - part * nt, I0 = 4 * part;
+  const int cnt = part ? nt - 4 : (nt < 4 ? nt : 4);
+  f4 acc[4];
+#pragma unroll
+  for (int y = 0; y < 4; ++y) acc[y] = f4{0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const float* pa0 = E + (16 * J + li) * LD;
+    const unsigned short* pb0 = reinterpret_cast<const unsigned short*>(F) + (16 * I0 + li) * (16 * nt);
+    if (cnt == 4) gemm_strip_bx3<4>(pa0, pb0, nt, acc);
+    else if (cnt == 3) gemm_strip_bx3<3>(pa0, pb0, nt, acc);
+    else if (cnt == 2) gemm_strip_bx3<2>(pa0, pb0, nt, acc);
+    else gemm_strip_bx3<1>(pa0, pb0, nt, acc);
+    HTA_WVSTAMP(11);
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+      if (y < cnt && I0 + y == J) {                                // lam_i' = lam_i + M_ii
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (4 * lk + t == li) { const int i = 16 * J + li; if (i < D) vlam[i] = vlam[i] - acc[y][t]; }
+      }
+  }
+  HTA_WVSTAMP(12);
+  __syncthreads();
+  HTA_WVSTAMP(13);
+  float sc = 0.f;
+  if (lane < D) sc = fabsf(vlam[lane]);
+  if (lane + 64 < D) sc = fmaxf(sc, fabsf(vlam[lane + 64]));
+  sc = wave_max_dpp(sc);
+  const float tiny = 8.f * Eps<float>::v * sc * kSecondE;
+  unsigned ebits = 0u;
+  if (active) {
+    const f4 lamJ = *reinterpret_cast<const f4*>(vlam + 16 * J + 4 * lk);
+    f4 pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      if (y >= cnt) continue;
+      const int I = I0 + y, i = 16 * I + li;
+      const float lamI = vlam[i], y0i = vy[i];
+      const f2v lamI2 = {lamI, lamI};
+      const f4 a = acc[y];
+      const f2v d01 = lamI2 - f2v{lamJ[0], lamJ[1]}, d23 = lamI2 - f2v{lamJ[2], lamJ[3]};
+      const f2v r01 = {__builtin_amdgcn_rcpf(d01[0]), __builtin_amdgcn_rcpf(d01[1])}, r23 = {__builtin_amdgcn_rcpf(d23[0]), __builtin_amdgcn_rcpf(d23[1])};
+      const f2v q01 = f2v{a[0], a[1]} * r01, q23 = f2v{a[2], a[3]} * r23;
+      f4 e;
+      e[0] = (fabsf(a[0]) <= tiny) ? 0.f : q01[0];
+      e[1] = (fabsf(a[1]) <= tiny) ? 0.f : q01[1];
+      e[2] = (fabsf(a[2]) <= tiny) ? 0.f : q23[0];
+      e[3] = (fabsf(a[3]) <= tiny) ? 0.f : q23[1];
+      if (I == J) {
+        const float dg = -0.5f * vcs[i];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) if (4 * lk + t == li) e[t] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ebits = max(ebits, __float_as_uint(e[t]) & 0x7fffffffu);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) if (4 * lk + t == li) e[t] = dg;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ebits = max(ebits, __float_as_uint(e[t]) & 0x7fffffffu);
+      }
+      *reinterpret_cast<f4*>(F + i * LD + 16 * J + 4 * lk) = e;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) pacc[t] = fmaf(e[t], y0i, pacc[t]);
+    }
+    float* pv = lds + (part ? oVec + 5 * DPv : oVec);
+    f4 sum;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sum[t] = sum16_dpp(pacc[t]);
+    if (li == 0) *reinterpret_cast<f4*>(pv + 16 * J + 4 * lk) = sum;
+  }
+  float emax = (ebits > __float_as_uint(kFallbackE)) ? 1.f : __uint_as_float(ebits);
+  HTA_WVSTAMP(14);
+  emax = block_max1(emax, red);
+  HTA_WVSTAMP(15);
+  return emax;
+}
+
 // The vectors of the solve: soft-abs map, y = (I + E2^T)(I - E1) m', w = y / lam~, x' = (I + E1)(I + E2) w, x = V0 x', P d = V0 (lam0 d'),
 // the two row updates; the block sums (log-det, y^T w, sum lam0 d'^2) as wave partials at oS (waves 0 .. 9, stride 4: the caller adds them).
 // Waves 0 .. 7 carry the products (mv4: a row's value stays in its four lanes from one stage to the next), waves 8 .. 9 the soft-abs
@@ -1454,7 +1559,7 @@ __device__ HTA_PH_ATTR void ph_fast_chain(int offV, int offE1, int offE2, int oV
                                           float* lam_out, float* lamraw_out, float* x_out, float* upd_x, float cx, float* upd_g, float cg, int resoff) {
   HTA_LDS_BASE();
   D = HTA_U(D); DP = HTA_U(DP); LD = HTA_U(LD); flags = HTA_U(flags); oVec = HTA_U(oVec); resoff = HTA_U(resoff);
-  const bool skip2 = flags & 1, has_x = flags & 2, resident = flags & 4, sdraw = flags & 8, assign = flags & 16;
+  const bool skip2 = flags & 1, has_x = flags & 2, resident = flags & 4, sdraw = flags & 8, assign = flags & 16, strips = flags & 32;
   const float* V = lds + HTA_U(offV); const float* E1 = lds + HTA_U(offE1); const float* E2 = lds + HTA_U(offE2);
   float* vlam = lds + oVec + DP; float* vlt = vlam + DP; float* vm = vlt + DP; float* vy = vm + DP; float* vx = vy + DP; float* vd = vx + DP;
   float* red3 = vd + 2 * DP + MT / 64;
@@ -1511,9 +1616,12 @@ __device__ HTA_PH_ATTR void ph_fast_chain(int offV, int offE1, int offE2, int oV
   } else if (row < DP) {                                         // y = y0 + E2^T y0 from the second product's partials (one per macro-tile row)
     const float* p0 = lds + oVec; const float* p1 = lds + oVec + 3 * DP; const float* p2 = lds + oVec + 5 * DP; const float* p3 = lds + oVec + 8 * DP + MT / 64 + 64;
     y = vy[row] + p0[row];
-    if (DP > 32) y += p1[row];
-    if (DP > 64) y += p2[row];
-    if (DP > 96) y += p3[row];
+    if (strips) { if (DP > 64) y += p2[row]; }                   // (ph_fast_second_strip: row tiles 0 .. 3 | 4 ..)
+    else {
+      if (DP > 32) y += p1[row];
+      if (DP > 64) y += p2[row];
+      if (DP > 96) y += p3[row];
+    }
     if (row >= D) y = 0.f;
   }
   __syncthreads();                                               // lam~, lam0 d' (and, after it, x may be overwritten: its partial has been read)
@@ -1627,17 +1735,17 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
     float e2;
     // (the bfloat16 form only where the leading dimension is a compile-time constant: the run-time instance needs four registers beyond
     // the caller-saved set, i.e. a save / restore through scratch memory per call that costs more than the product saves)
-    if (planes) e2 = ph_fast_second<kLdCfg3, true>(by, bz, oJit, oRed, nt, tiles, k4, D, LD);
-    else e2 = LD == kLdCfg3 ? ph_fast_second<kLdCfg3, false>(by, bz, oJit, oRed, nt, tiles, k4, D, LD)
-                            : ph_fast_second<0, false>(by, bz, oJit, oRed, nt, tiles, k4, D, LD);
+    if (planes) e2 = ph_fast_second_strip<kLdCfg3>(by, bz, oJit, oRed, nt, tiles, D);
+    else e2 = LD == kLdCfg3 ? ph_fast_second<kLdCfg3>(by, bz, oJit, oRed, nt, tiles, k4, D, LD)
+                            : ph_fast_second<0>(by, bz, oJit, oRed, nt, tiles, k4, D, LD);
     if (!(e2 <= kConvE)) return false;
   }
   HTA_STAMP(9);
   if (res_xm >= 0)
-    ph_fast_chain(bx, bz, by, oJit, D, DP, LD, (skip2 ? 1 : 0) | 2 | 4 | (sdraw ? 8 | 16 : 0), (float)a.alpha, nullptr, nullptr, nullptr, nullptr, (float)a.cx, nullptr,
+    ph_fast_chain(bx, bz, by, oJit, D, DP, LD, (skip2 ? 1 : 0) | 2 | 4 | (sdraw ? 8 | 16 : 0) | (planes ? 32 : 0), (float)a.alpha, nullptr, nullptr, nullptr, nullptr, (float)a.cx, nullptr,
                   (float)a.cg, res_upd);
   else
-    ph_fast_chain(bx, bz, by, oJit, D, DP, LD, (skip2 ? 1 : 0) | (a.X ? 2 : 0) | (sdraw ? 8 : 0), (float)a.alpha,
+    ph_fast_chain(bx, bz, by, oJit, D, DP, LD, (skip2 ? 1 : 0) | (a.X ? 2 : 0) | (sdraw ? 8 : 0) | (planes ? 32 : 0), (float)a.alpha,
                   a.lam_out ? a.lam_out + b * D : nullptr, a.lamraw_out ? a.lamraw_out + b * D : nullptr,
                   sdraw ? a.p_out + b * D : (a.x_out ? a.x_out + b * D : nullptr),
                   a.upd_x ? a.upd_x + b * D : nullptr, (float)a.cx, a.upd_g ? a.upd_g + b * D : nullptr, (float)a.cg, 0);

@@ -202,12 +202,12 @@ def test_fast_solve_phase_functions_stay_inside_the_caller_saved_registers():
     obj = os.path.join(ROOT, "hamiltorch_amd", "csrc", "build", "rmhmc_metric_mfma.o")
     if not os.path.exists(obj):
         pytest.skip("needs the object file of rmhmc_metric_mfma.hip")
-    for pat in ["ph_fast_vt", "ph_fast_formILi116ELb1ELb1E", "ph_fast_formILi116ELb1ELb0E", "ph_fast_formILi116ELb0ELb0E", "ph_fast_secondILi116ELb1E", "ph_fast_secondILi116ELb0E", "ph_fast_chain",
+    for pat in ["ph_fast_vt", "ph_fast_formILi116ELb1ELb1E", "ph_fast_formILi116ELb1ELb0E", "ph_fast_formILi116ELb0ELb0E", "ph_fast_secondILi116EE", "ph_fast_second_stripILi116E", "ph_fast_chain",
                 "metric_traj_mfma_kernel"]:
         name, lines = isa_of.kernel_lines(obj, pat)
         assert not any(i.startswith("scratch_") for _, i in lines), name
     # the bfloat16 instance really is one: three v_mfma_f32_16x16x32_bf16 per tile and 32 indices in the four macro-tile shapes (12 + 6 + 6 + 3 static instructions), none of the fp32 form
-    _, lines = isa_of.kernel_lines(obj, "ph_fast_secondILi116ELb1E")
+    _, lines = isa_of.kernel_lines(obj, "ph_fast_second_stripILi116E")
     ops = [i.split()[0] for _, i in lines]
     assert ops.count("v_mfma_f32_16x16x32_bf16") >= 27 and ops.count("v_mfma_f32_16x16x4_f32") == 0
     # and so is the formation of "metric_bx3" = 2: planes against planes, no fp32 matrix instruction
