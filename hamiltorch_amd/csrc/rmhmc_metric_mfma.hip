@@ -253,15 +253,20 @@ __device__ __forceinline__ void split_pair(float x0, float x1, int& hi, int& lo)
 // A 1 x NB strip of the second product: ONE tile of E1 rows (operand A, fp32, split on the fly ONCE per 32 indices) against NB <= 4 tiles
 // of F's planes (operand B) - the 2 x 2 macro tile split its two A tiles for two B tiles each, and the split is what that loop's time is
 // made of.  acc[y] = sum_k E1[j][k] F[i_y][k] = -M[i_y][j].
-template <int NB>
-__device__ __forceinline__ void gemm_strip_bx3(const float* pa0, const unsigned short* pb0, int nt, f4 (&acc)[4]) {
+// NT: the tile count as a compile-time constant (the planes exist only where the leading dimension is kLdCfg3, i.e. 7 tiles): the k loop
+// unrolls completely - every operand read is an immediate offset of ONE address register per operand and the next step's A tile lands in
+// fresh registers (the rolled loop spent 18 address additions and 4 register-pair copies per step next to its 12 matrix instructions).
+template <int NB, int NT>
+__device__ __forceinline__ void gemm_strip_bx3(const float* pa0, const unsigned short* pb0, f4 (&acc)[4]) {
+  constexpr int nt = NT;
   const int kg = (threadIdx.x & 63) >> 4;
-  const int DPh = 16 * nt, plane = DPh * DPh;
+  constexpr int DPh = 16 * nt, plane = DPh * DPh;
   const float* pa = pa0 + 8 * kg;
   const unsigned short* pb = pb0 + 8 * kg;
-  const int nfull = nt >> 1;
+  constexpr int nfull = nt >> 1;
   f4 ra0, ra1;
   if (nfull > 0) { ra0 = *reinterpret_cast<const f4*>(pa); ra1 = *reinterpret_cast<const f4*>(pa + 4); }
+#pragma unroll
   for (int s = 0; s < nfull; ++s) {
     // (B tiles two at a time: all four at once put the function beyond the caller-saved registers)
     i4v bh[2], bl[2];
@@ -324,13 +329,14 @@ __device__ __forceinline__ void gemm_strip_bx3(const float* pa0, const unsigned 
 
 // Both operands pre-split (the formation F = W W^T on the planes of W^T = (diag(sqrt e) V0)^T, round 6): a row tile against one or two
 // row tiles, three products per tile and 32 indices, no vector instruction in the loop.  pa / pb: row starts of the hi plane.
-template <bool C2>
-__device__ __forceinline__ void gemm_macro_pp(const unsigned short* pa0, const unsigned short* pb0, int nt, f4 (&acc)[2][2]) {
+template <bool C2, int NT>
+__device__ __forceinline__ void gemm_macro_pp(const unsigned short* pa0, const unsigned short* pb0, f4 (&acc)[2][2]) {
+  constexpr int nt = NT;                                                  // (compile-time tile count: see gemm_strip_bx3)
   const int kg = (threadIdx.x & 63) >> 4;
-  const int DPh = 16 * nt, plane = DPh * DPh;
+  constexpr int DPh = 16 * nt, plane = DPh * DPh;
   const unsigned short* pa = pa0 + 8 * kg;
   const unsigned short* pb[2] = {pb0 + 8 * kg, pb0 + 16 * DPh + 8 * kg};
-  const int nfull = nt >> 1;
+  constexpr int nfull = nt >> 1;
   i4v ah, al, bh[2], bl[2];
 #define HTA_PP_LOAD(s)                                                                                   \
   do {                                                                                                   \
@@ -339,6 +345,7 @@ __device__ __forceinline__ void gemm_macro_pp(const unsigned short* pa0, const u
     if (C2) { bh[1] = *reinterpret_cast<const i4v*>(pb[1] + 32 * (s)); bl[1] = *reinterpret_cast<const i4v*>(pb[1] + plane + 32 * (s)); } \
   } while (0)
   if (nfull > 0) HTA_PP_LOAD(0);
+#pragma unroll
   for (int s = 0; s < nfull; ++s) {
     const i4v cah = ah, cal = al, cbh0 = bh[0], cbl0 = bl[0], cbh1 = bh[1], cbl1 = bl[1];
     __builtin_amdgcn_sched_barrier(0);
@@ -456,6 +463,7 @@ __device__ HTA_PH_ATTR void lds_gemm_ld(int offA, int offB, int offC, int offCin
 }
 
 constexpr int kLdCfg3 = 116;             // LD of 97 <= D <= 112 (BASELINE config 3's D = 100)
+constexpr int kNtCfg3 = (kLdCfg3 - 4) / 16;      // its tile count: 7
 template <bool TA, bool TB, bool SYM, bool SCALE>
 __device__ __forceinline__ void lds_gemm(int offA, int offB, int offC, int offCinit, int offScale, int nt, int k4, int LD) {
   if (LD == kLdCfg3) lds_gemm_ld<TA, TB, SYM, SCALE, kLdCfg3>(offA, offB, offC, offCinit, offScale, nt, k4, LD);
@@ -1152,7 +1160,7 @@ __device__ __forceinline__ void plane_store_row(unsigned short* ph, unsigned sho
 template <int LDC, bool PL, bool WB = false>
 __device__ HTA_PH_ATTR float ph_fast_form(int offV, int offF, int offE, int offJit, int offLam0, int offLam, int offRed, int tile, int k4, int D, int LDr, int nt) {
   HTA_LDS_BASE();
-  k4 = HTA_U(k4); D = HTA_U(D); nt = HTA_U(nt);
+  k4 = HTA_U(k4); D = HTA_U(D); nt = LDC == kLdCfg3 ? kNtCfg3 : HTA_U(nt);
   const int LD = LDC ? LDC : HTA_U(LDr);
   const float* V = lds + HTA_U(offV);
   float* F = lds + HTA_U(offF); float* E = lds + HTA_U(offE);
@@ -1199,7 +1207,7 @@ __device__ HTA_PH_ATTR float ph_fast_form(int offV, int offF, int offE, int offJ
       const unsigned short* Wh = reinterpret_cast<const unsigned short*>(E);
       const unsigned short* pa0 = Wh + (16 * I0 + li) * (16 * nt);
       const unsigned short* pb0 = Wh + (16 * J0 + li) * (16 * nt);
-      if (c2) gemm_macro_pp<true>(pa0, pb0, nt, acc); else gemm_macro_pp<false>(pa0, pb0, nt, acc);
+      if (c2) gemm_macro_pp<true, kNtCfg3>(pa0, pb0, acc); else gemm_macro_pp<false, kNtCfg3>(pa0, pb0, acc);
     } else {
       const float* pa0 = V + lk * LD + 16 * I0 + li;
       const float* pb0 = V + lk * LD + 16 * J0 + li;
@@ -1440,7 +1448,8 @@ __device__ HTA_PH_ATTR float ph_fast_second(int offF, int offE, int oVec, int of
 template <int LDC>
 __device__ HTA_PH_ATTR float ph_fast_second_strip(int offF, int offE, int oVec, int offRed, int nt, int tile, int D) {
   HTA_LDS_BASE();
-  nt = HTA_U(nt); D = HTA_U(D); oVec = HTA_U(oVec);
+  static_assert(LDC == kLdCfg3, "the planes exist at this leading dimension only");
+  nt = kNtCfg3; D = HTA_U(D); oVec = HTA_U(oVec);
   constexpr int LD = LDC;
   const int DPv = 16 * nt;
   float* F = lds + HTA_U(offF); const float* E = lds + HTA_U(offE);
@@ -1478,10 +1487,8 @@ __device__ HTA_PH_ATTR float ph_fast_second_strip(int offF, int offE, int oVec, 
   if (active) {
     const float* pa0 = E + (16 * J + li) * LD;
     const unsigned short* pb0 = reinterpret_cast<const unsigned short*>(F) + (16 * I0 + li) * (16 * nt);
-    if (cnt == 4) gemm_strip_bx3<4>(pa0, pb0, nt, acc);
-    else if (cnt == 3) gemm_strip_bx3<3>(pa0, pb0, nt, acc);
-    else if (cnt == 2) gemm_strip_bx3<2>(pa0, pb0, nt, acc);
-    else gemm_strip_bx3<1>(pa0, pb0, nt, acc);
+    if (cnt == 4) gemm_strip_bx3<4, kNtCfg3>(pa0, pb0, acc);      // (7 tiles: strips of 4 and 3)
+    else gemm_strip_bx3<3, kNtCfg3>(pa0, pb0, acc);
     HTA_WVSTAMP(11);
 #pragma unroll
     for (int y = 0; y < 4; ++y)
