@@ -1442,11 +1442,40 @@ __device__ HTA_PH_ATTR float ph_fast_second(int offF, int offE, int oVec, int of
   return emax;
 }
 
+// The soft-abs map of rows i (one wave: 64 consecutive rows) - lam~ over lam0 at vlt, lam0 d' over d' at vd, the wave's partials of the
+// log-determinant and of sum lam0 d'^2 into slot `wslot` of the block-sum table.  Runs on waves 8 .. 9 of ph_fast_chain, or (round 6, later)
+// on the two waves ph_fast_second_strip leaves without a strip, under that phase's element-wise step.
+__device__ __forceinline__ void fast_softabs_rows(int i, int wslot, int D, int DP, float alpha, const float* vlam, float* vlt, float* vd, float* red3,
+                                                  float* lam_out, float* lamraw_out, bool has_x, bool sync_after_map) {
+  typedef __attribute__((address_space(1))) float* gf;
+  float ld = 0.f, lq = 0.f, lt = 1.f, l0 = 0.f;
+  if (i < D) {
+    const float lam = vlam[i], x = alpha * lam;
+    // |alpha lam| >= 10: tanh is 1 - 4e-9, i.e. tanhf returns +-1 exactly, lam / tanh = |lam| bit for bit - the whole wave skips the function's body when
+    // every eigenvalue is there (the identity soft-abs map of BASELINE config 3: alpha = 1e6)
+    const bool sat = fabsf(x) >= 10.f;
+    if (__builtin_amdgcn_ballot_w64(!sat) == 0) lt = fabsf(lam);
+    else lt = (1.f / tanhf(x)) * lam;
+    l0 = vlt[i];                                               // (lam0 is parked where lam~ goes)
+    if (lamraw_out) ((gf)lamraw_out)[i] = lam;
+  }
+  if (i < DP) vlt[i] = lt;
+  if (sync_after_map) __syncthreads();                         // (ph_fast_chain without a second pass: the first of its four barriers - y0)
+  if (i < D) {
+    ld = logf(lt);
+    if (lam_out) ((gf)lam_out)[i] = lt;
+    if (has_x) { const float dp = vd[i]; lq = l0 * dp * dp; vd[i] = l0 * dp; }
+  }
+  const float s0 = wave_sum_dpp(ld), s2 = wave_sum_dpp(lq);
+  if ((threadIdx.x & 63) == 0) { float* r = red3 + 4 * wslot; r[0] = s0; r[1] = 0.f; r[2] = s2; }
+}
+
 // The bfloat16 form of the second product on 1 x 4 / 1 x 3 STRIPS (fast_tiles bits 27 .. 31): the same pre-pass, barrier and element-wise step
 // as ph_fast_second<.., true>, one E1 tile per wave split once per 32 indices for up to four tiles of F's planes; the partial vectors of
 // E2^T y0 are two (row tiles 0 .. 3 -> the slot of I0 = 0, row tiles 4 .. -> the slot of I0 = 4: ph_fast_chain flag 32).
 template <int LDC>
-__device__ HTA_PH_ATTR float ph_fast_second_strip(int offF, int offE, int oVec, int offRed, int nt, int tile, int D) {
+__device__ HTA_PH_ATTR float ph_fast_second_strip(int offF, int offE, int oVec, int offRed, int nt, int tile, int D, float alpha, int has_x,
+                                                  float* lam_out, float* lamraw_out) {
   HTA_LDS_BASE();
   static_assert(LDC == kLdCfg3, "the planes exist at this leading dimension only");
   nt = kNtCfg3; D = HTA_U(D); oVec = HTA_U(oVec);
@@ -1507,6 +1536,14 @@ __device__ HTA_PH_ATTR float ph_fast_second_strip(int offF, int offE, int oVec, 
   sc = wave_max_dpp(sc);
   const float tiny = 8.f * Eps<float>::v * sc * kSecondE;
   unsigned ebits = 0u;
+  {
+    // the two waves without a strip (fast_tiles: 13 and 14 at 7 tiles) take the soft-abs map of the corrected eigenvalues, which ph_fast_chain
+    // would otherwise wait for behind a barrier of its own (flag 64 there)
+    const int wv = HTA_U(threadIdx.x >> 6);
+    if (wv == 13 || wv == 14)
+      fast_softabs_rows((int)threadIdx.x - 13 * 64, 8 + wv - 13, D, DPv, alpha, vlam, lds + oVec + 2 * DPv, lds + oVec + 6 * DPv, lds + oVec + 8 * DPv + MT / 64,
+                        lam_out, lamraw_out, HTA_U(has_x) != 0, false);
+  }
   if (active) {
     const f4 lamJ = *reinterpret_cast<const f4*>(vlam + 16 * J + 4 * lk);
     f4 pacc = {0.f, 0.f, 0.f, 0.f};
@@ -1559,6 +1596,7 @@ __device__ HTA_PH_ATTR float ph_fast_second_strip(int offF, int offE, int oVec, 
 // Waves 0 .. 7 carry the products (mv4: a row's value stays in its four lanes from one stage to the next), waves 8 .. 9 the soft-abs
 // map under the second product; five barriers.  Vector block at oVec: e | lam | lam0 -> lam~ | m' | y | x | d' -> lam0 d' | cs, then 16 floats, then oS.
 // flags: 8 = the DRAW p = G^(1/2) z: w = y sqrt(lam~) instead of y / lam~; 16 (with 4) = x' REPLACES the LDS vector at 4 (resoff & 0xffff), no second update;
+// 32 = the second product ran on strips (two partial vectors), 64 = it also took the soft-abs map (no first barrier here);
 // 1 = no second pass (E2 = 0), 2 = log p / P d wanted, 4 = RESIDENT: the state lives in LDS in eigen-coordinates (the trajectory
 // kernel) - the updates are theta~'[row] += cx x'[row] and p'[row] += cg lam0 d'[row] on the LDS vectors at 4 (resoff & 0xffff) / 4 (resoff >> 16)
 // (0: none), the last product and its barrier do not exist.
@@ -1567,6 +1605,7 @@ __device__ HTA_PH_ATTR void ph_fast_chain(int offV, int offE1, int offE2, int oV
   HTA_LDS_BASE();
   D = HTA_U(D); DP = HTA_U(DP); LD = HTA_U(LD); flags = HTA_U(flags); oVec = HTA_U(oVec); resoff = HTA_U(resoff);
   const bool skip2 = flags & 1, has_x = flags & 2, resident = flags & 4, sdraw = flags & 8, assign = flags & 16, strips = flags & 32;
+  const bool mapped = !skip2 && (flags & 64);                    // lam~, lam0 d' and their block sums are in LDS already (ph_fast_second_strip)
   const float* V = lds + HTA_U(offV); const float* E1 = lds + HTA_U(offE1); const float* E2 = lds + HTA_U(offE2);
   float* vlam = lds + oVec + DP; float* vlt = vlam + DP; float* vm = vlt + DP; float* vy = vm + DP; float* vx = vy + DP; float* vd = vx + DP;
   float* red3 = vd + 2 * DP + MT / 64;
@@ -1575,33 +1614,17 @@ __device__ HTA_PH_ATTR void ph_fast_chain(int offV, int offE1, int offE2, int oV
   const int nq = DP >> 2;
   // !skip2: y0 = m' - E1 m' and the partials of E2^T y0 are in LDS already (ph_fast_second): ONE barrier (the soft-abs map) before w.
   // skip2 (no second pass: E2 = 0): y0 is computed here, under the map.
-  const int nbar = (skip2 ? 4 : 3) + (resident ? 0 : 1);         // barriers of this call
+  const int nbar = (skip2 ? 4 : 3) + (resident ? 0 : 1) - (mapped ? 1 : 0);      // barriers of this call
   if (wave >= 10) {                                              // nothing to compute
     for (int k = 0; k < nbar; ++k) __syncthreads();
     return;
   }
   if (wave >= 8) {                                               // soft-abs map (S:120), log-determinant (S:726), d^T P d, lam0 d'
-    const int i = tid - 512;
-    float ld = 0.f, lq = 0.f, lt = 1.f, l0 = 0.f;
-    if (i < D) {
-      const float lam = vlam[i], x = alpha * lam;
-      // |alpha lam| >= 10: tanh is 1 - 4e-9, i.e. tanhf returns +-1 exactly, lam / tanh = |lam| bit for bit - the whole wave skips the function's body when
-      // every eigenvalue is there (the identity soft-abs map of BASELINE config 3: alpha = 1e6)
-      const bool sat = fabsf(x) >= 10.f;
-      if (__builtin_amdgcn_ballot_w64(!sat) == 0) lt = fabsf(lam);
-      else lt = (1.f / tanhf(x)) * lam;
-      l0 = vlt[i];                                               // (lam0 is parked where lam~ goes)
-      if (lamraw_out) ((gf)lamraw_out)[i] = lam;
+    if (mapped) {                                                // (done by ph_fast_second_strip's idle waves, under its element-wise step)
+      for (int k = 0; k < nbar; ++k) __syncthreads();
+      return;
     }
-    if (i < DP) vlt[i] = lt;
-    if (skip2) __syncthreads();                                  // (the first of the four: y0)
-    if (i < D) {
-      ld = logf(lt);
-      if (lam_out) ((gf)lam_out)[i] = lt;
-      if (has_x) { const float dp = vd[i]; lq = l0 * dp * dp; vd[i] = l0 * dp; }
-    }
-    const float s0 = wave_sum_dpp(ld), s2 = wave_sum_dpp(lq);
-    if ((tid & 63) == 0) { float* r = red3 + 4 * wave; r[0] = s0; r[1] = 0.f; r[2] = s2; }
+    fast_softabs_rows(tid - 512, wave, D, DP, alpha, vlam, vlt, vd, red3, lam_out, lamraw_out, has_x, skip2);
     for (int k = skip2 ? 1 : 0; k < nbar; ++k) __syncthreads();
     return;
   }
@@ -1631,7 +1654,7 @@ __device__ HTA_PH_ATTR void ph_fast_chain(int offV, int offE1, int offE2, int oV
     }
     if (row >= D) y = 0.f;
   }
-  __syncthreads();                                               // lam~, lam0 d' (and, after it, x may be overwritten: its partial has been read)
+  if (!mapped) __syncthreads();                                  // lam~, lam0 d' (x may now be overwritten: a row's partial is read by the quad that writes the row)
   HTA_WSTAMP(14);
   float w = 0.f, qd = 0.f;
   if (row < D) { w = sdraw ? y * sqrtf(vlt[row]) : y / vlt[row]; if (c == 0) qd = y * w; }
@@ -1742,17 +1765,19 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
     float e2;
     // (the bfloat16 form only where the leading dimension is a compile-time constant: the run-time instance needs four registers beyond
     // the caller-saved set, i.e. a save / restore through scratch memory per call that costs more than the product saves)
-    if (planes) e2 = ph_fast_second_strip<kLdCfg3>(by, bz, oJit, oRed, nt, tiles, D);
+    if (planes)
+      e2 = ph_fast_second_strip<kLdCfg3>(by, bz, oJit, oRed, nt, tiles, D, (float)a.alpha, (res_xm >= 0 || a.X) ? 1 : 0,
+                                         (res_xm < 0 && a.lam_out) ? a.lam_out + b * D : nullptr, (res_xm < 0 && a.lamraw_out) ? a.lamraw_out + b * D : nullptr);
     else e2 = LD == kLdCfg3 ? ph_fast_second<kLdCfg3>(by, bz, oJit, oRed, nt, tiles, k4, D, LD)
                             : ph_fast_second<0>(by, bz, oJit, oRed, nt, tiles, k4, D, LD);
     if (!(e2 <= kConvE)) return false;
   }
   HTA_STAMP(9);
   if (res_xm >= 0)
-    ph_fast_chain(bx, bz, by, oJit, D, DP, LD, (skip2 ? 1 : 0) | 2 | 4 | (sdraw ? 8 | 16 : 0) | (planes ? 32 : 0), (float)a.alpha, nullptr, nullptr, nullptr, nullptr, (float)a.cx, nullptr,
+    ph_fast_chain(bx, bz, by, oJit, D, DP, LD, (skip2 ? 1 : 0) | 2 | 4 | (sdraw ? 8 | 16 : 0) | (planes ? 32 | 64 : 0), (float)a.alpha, nullptr, nullptr, nullptr, nullptr, (float)a.cx, nullptr,
                   (float)a.cg, res_upd);
   else
-    ph_fast_chain(bx, bz, by, oJit, D, DP, LD, (skip2 ? 1 : 0) | (a.X ? 2 : 0) | (sdraw ? 8 : 0) | (planes ? 32 : 0), (float)a.alpha,
+    ph_fast_chain(bx, bz, by, oJit, D, DP, LD, (skip2 ? 1 : 0) | (a.X ? 2 : 0) | (sdraw ? 8 : 0) | (planes ? 32 | 64 : 0), (float)a.alpha,
                   a.lam_out ? a.lam_out + b * D : nullptr, a.lamraw_out ? a.lamraw_out + b * D : nullptr,
                   sdraw ? a.p_out + b * D : (a.x_out ? a.x_out + b * D : nullptr),
                   a.upd_x ? a.upd_x + b * D : nullptr, (float)a.cx, a.upd_g ? a.upd_g + b * D : nullptr, (float)a.cg, 0);
