@@ -1158,7 +1158,7 @@ __device__ __forceinline__ void plane_store_row(unsigned short* ph, unsigned sho
 // 7.4e-8 to 7.8e-8 at BASELINE config 3's jitter (1.5e-7 to 1.9e-7 at three times the jitter) - the closed-form second pass's own truncation
 // is that size, the kernel's fp32 vector arithmetic (3.6e-6) is fifty times it.
 template <int LDC, bool PL, bool WB = false>
-__device__ HTA_PH_ATTR float ph_fast_form(int offV, int offF, int offE, int offJit, int offLam0, int offLam, int offRed, int tile, int k4, int D, int LDr, int nt) {
+__device__ __forceinline__ float fast_form_body(int offV, int offF, int offE, int offJit, int offLam0, int offLam, int offRed, int tile, int k4, int D, int LDr, int nt) {
   HTA_LDS_BASE();
   k4 = HTA_U(k4); D = HTA_U(D); nt = LDC == kLdCfg3 ? kNtCfg3 : HTA_U(nt);
   const int LD = LDC ? LDC : HTA_U(LDr);
@@ -1304,6 +1304,29 @@ __device__ HTA_PH_ATTR float ph_fast_form(int offV, int offF, int offE, int offJ
   emax = block_max1(emax, red);         // (`red` was last read before this function's barrier above)
   HTA_WVSTAMP(9);
   return emax;
+}
+template <int LDC, bool PL, bool WB = false>
+__device__ HTA_PH_ATTR float ph_fast_form(int offV, int offF, int offE, int offJit, int offLam0, int offLam, int offRed, int tile, int k4, int D, int LDr, int nt) {
+  return fast_form_body<LDC, PL, WB>(offV, offF, offE, offJit, offLam0, offLam, offRed, tile, k4, D, LDr, nt);
+}
+// The RESIDENT evaluations of the trajectory kernel at kLdCfg3 (ph_fast_form_r / ph_fast_second_strip_r / ph_fast_chain_r): every LDS offset
+// is a compile-time function of the buffer V0 sits in, so a call passes ONE packed word (bits 0 .. 1: V0's buffer, 2 .. 9: D, 10 ..: the
+// chain's flags) instead of 12 ... 21 registers - an argument costs the caller a move (often a read of a parked scalar as well) and the
+// callee a readfirstlane, per wave, and with 16 waves on the CU every one of those is ~16 cycles: ~1 k cycles per call.
+struct ResLayout {
+  int bx, by, bz, oJit, oLam, oLt, oRed, D;
+  __device__ __forceinline__ explicit ResLayout(int code) {
+    constexpr int DP = 16 * kNtCfg3, BS = DP * kLdCfg3;
+    code = HTA_U(code);
+    const int vb = code & 3;
+    bx = vb * BS; by = vb == 0 ? BS : 0; bz = vb == 2 ? BS : 2 * BS;
+    oJit = 3 * BS; oLam = oJit + DP; oLt = oLam + DP; oRed = oJit + 8 * DP;
+    D = (code >> 2) & 255;
+  }
+};
+__device__ HTA_PH_ATTR float ph_fast_form_r(int code, int tile) {
+  const ResLayout r(code);
+  return fast_form_body<kLdCfg3, true, true>(r.bx, r.by, r.bz, r.oJit, r.oLt, r.oLam, r.oRed, tile, (r.D + 3) >> 2, r.D, kLdCfg3, kNtCfg3);
 }
 
 // M = F E1 (as lds_gemm_ld<false, false, false, false>) with the closed-form second pass in the epilogue (ph_refine_E2's arithmetic
@@ -1474,8 +1497,8 @@ __device__ __forceinline__ void fast_softabs_rows(int i, int wslot, int D, int D
 // as ph_fast_second<.., true>, one E1 tile per wave split once per 32 indices for up to four tiles of F's planes; the partial vectors of
 // E2^T y0 are two (row tiles 0 .. 3 -> the slot of I0 = 0, row tiles 4 .. -> the slot of I0 = 4: ph_fast_chain flag 32).
 template <int LDC>
-__device__ HTA_PH_ATTR float ph_fast_second_strip(int offF, int offE, int oVec, int offRed, int nt, int tile, int D, float alpha, int has_x,
-                                                  float* lam_out, float* lamraw_out) {
+__device__ __forceinline__ float fast_second_strip_body(int offF, int offE, int oVec, int offRed, int nt, int tile, int D, float alpha, int has_x,
+                                                        float* lam_out, float* lamraw_out) {
   HTA_LDS_BASE();
   static_assert(LDC == kLdCfg3, "the planes exist at this leading dimension only");
   nt = kNtCfg3; D = HTA_U(D); oVec = HTA_U(oVec);
@@ -1590,6 +1613,15 @@ __device__ HTA_PH_ATTR float ph_fast_second_strip(int offF, int offE, int oVec, 
   HTA_WVSTAMP(15);
   return emax;
 }
+template <int LDC>
+__device__ HTA_PH_ATTR float ph_fast_second_strip(int offF, int offE, int oVec, int offRed, int nt, int tile, int D, float alpha, int has_x,
+                                                  float* lam_out, float* lamraw_out) {
+  return fast_second_strip_body<LDC>(offF, offE, oVec, offRed, nt, tile, D, alpha, has_x, lam_out, lamraw_out);
+}
+__device__ HTA_PH_ATTR float ph_fast_second_strip_r(int code, int tile, float alpha) {
+  const ResLayout r(code);
+  return fast_second_strip_body<kLdCfg3>(r.by, r.bz, r.oJit, r.oRed, kNtCfg3, tile, r.D, alpha, 1, nullptr, nullptr);
+}
 
 // The vectors of the solve: soft-abs map, y = (I + E2^T)(I - E1) m', w = y / lam~, x' = (I + E1)(I + E2) w, x = V0 x', P d = V0 (lam0 d'),
 // the two row updates; the block sums (log-det, y^T w, sum lam0 d'^2) as wave partials at oS (waves 0 .. 9, stride 4: the caller adds them).
@@ -1600,8 +1632,8 @@ __device__ HTA_PH_ATTR float ph_fast_second_strip(int offF, int offE, int oVec, 
 // 1 = no second pass (E2 = 0), 2 = log p / P d wanted, 4 = RESIDENT: the state lives in LDS in eigen-coordinates (the trajectory
 // kernel) - the updates are theta~'[row] += cx x'[row] and p'[row] += cg lam0 d'[row] on the LDS vectors at 4 (resoff & 0xffff) / 4 (resoff >> 16)
 // (0: none), the last product and its barrier do not exist.
-__device__ HTA_PH_ATTR void ph_fast_chain(int offV, int offE1, int offE2, int oVec, int D, int DP, int LD, int flags, float alpha,
-                                          float* lam_out, float* lamraw_out, float* x_out, float* upd_x, float cx, float* upd_g, float cg, int resoff) {
+__device__ __forceinline__ void fast_chain_body(int offV, int offE1, int offE2, int oVec, int D, int DP, int LD, int flags, float alpha,
+                                                float* lam_out, float* lamraw_out, float* x_out, float* upd_x, float cx, float* upd_g, float cg, int resoff) {
   HTA_LDS_BASE();
   D = HTA_U(D); DP = HTA_U(DP); LD = HTA_U(LD); flags = HTA_U(flags); oVec = HTA_U(oVec); resoff = HTA_U(resoff);
   const bool skip2 = flags & 1, has_x = flags & 2, resident = flags & 4, sdraw = flags & 8, assign = flags & 16, strips = flags & 32;
@@ -1696,6 +1728,14 @@ __device__ HTA_PH_ATTR void ph_fast_chain(int offV, int offE1, int offE2, int oV
   }
   HTA_WSTAMP(18);
 }
+__device__ HTA_PH_ATTR void ph_fast_chain(int offV, int offE1, int offE2, int oVec, int D, int DP, int LD, int flags, float alpha,
+                                          float* lam_out, float* lamraw_out, float* x_out, float* upd_x, float cx, float* upd_g, float cg, int resoff) {
+  fast_chain_body(offV, offE1, offE2, oVec, D, DP, LD, flags, alpha, lam_out, lamraw_out, x_out, upd_x, cx, upd_g, cg, resoff);
+}
+__device__ HTA_PH_ATTR void ph_fast_chain_r(int code, float alpha, float cx, float cg, int resoff) {      // (ResLayout; the flags from bit 10, RESIDENT among them)
+  const ResLayout r(code);
+  fast_chain_body(r.bx, r.bz, r.by, r.oJit, r.D, 16 * kNtCfg3, kLdCfg3, (HTA_U(code) >> 10) | 4, alpha, nullptr, nullptr, nullptr, nullptr, cx, nullptr, cg, resoff);
+}
 
 // The thread index, opaque to the optimiser.  Per-lane global addresses (a.m + b D + i, a.upd_x + b D + row, ...) derived from
 // the plain index were computed at the top of the kernel and kept across its 30 out-of-line phase calls - i.e. spilled to
@@ -1754,7 +1794,9 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
   if (res_xm < 0) ph_fast_vt(bx, oY, oM, oD, DP, LD);
   HTA_STAMP(2);
   const bool planes = bx3 && LD == kLdCfg3;                          // F as bfloat16 planes for the bfloat16 form of the second product
-  const float e1 = (planes && wb) ? ph_fast_form<kLdCfg3, true, true>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD, nt)
+  const bool packed = planes && wb && res_xm >= 0;                   // the resident evaluations at kLdCfg3: one packed argument (ResLayout)
+  const int rcode = (bx == 0 ? 0 : bx == BS ? 1 : 2) | (D << 2);
+  const float e1 = packed ? ph_fast_form_r(rcode, tiles) : (planes && wb) ? ph_fast_form<kLdCfg3, true, true>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD, nt)
                    : planes ? ph_fast_form<kLdCfg3, true>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD, nt)
                    : LD == kLdCfg3 ? ph_fast_form<kLdCfg3, false>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD, nt)
                                    : ph_fast_form<0, false>(bx, by, bz, oJit, oLt, oLam, oRed, tiles, k4, D, LD, nt);
@@ -1765,7 +1807,8 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
     float e2;
     // (the bfloat16 form only where the leading dimension is a compile-time constant: the run-time instance needs four registers beyond
     // the caller-saved set, i.e. a save / restore through scratch memory per call that costs more than the product saves)
-    if (planes)
+    if (packed) e2 = ph_fast_second_strip_r(rcode, tiles, (float)a.alpha);
+    else if (planes)
       e2 = ph_fast_second_strip<kLdCfg3>(by, bz, oJit, oRed, nt, tiles, D, (float)a.alpha, (res_xm >= 0 || a.X) ? 1 : 0,
                                          (res_xm < 0 && a.lam_out) ? a.lam_out + b * D : nullptr, (res_xm < 0 && a.lamraw_out) ? a.lamraw_out + b * D : nullptr);
     else e2 = LD == kLdCfg3 ? ph_fast_second<kLdCfg3>(by, bz, oJit, oRed, nt, tiles, k4, D, LD)
@@ -1773,7 +1816,9 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
     if (!(e2 <= kConvE)) return false;
   }
   HTA_STAMP(9);
-  if (res_xm >= 0)
+  if (packed)
+    ph_fast_chain_r(rcode | (((skip2 ? 1 : 0) | 2 | 4 | (sdraw ? 8 | 16 : 0) | 32 | 64) << 10), (float)a.alpha, (float)a.cx, (float)a.cg, res_upd);
+  else if (res_xm >= 0)
     ph_fast_chain(bx, bz, by, oJit, D, DP, LD, (skip2 ? 1 : 0) | 2 | 4 | (sdraw ? 8 | 16 : 0) | (planes ? 32 | 64 : 0), (float)a.alpha, nullptr, nullptr, nullptr, nullptr, (float)a.cx, nullptr,
                   (float)a.cg, res_upd);
   else

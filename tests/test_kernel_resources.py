@@ -202,8 +202,8 @@ def test_fast_solve_phase_functions_stay_inside_the_caller_saved_registers():
     obj = os.path.join(ROOT, "hamiltorch_amd", "csrc", "build", "rmhmc_metric_mfma.o")
     if not os.path.exists(obj):
         pytest.skip("needs the object file of rmhmc_metric_mfma.hip")
-    for pat in ["ph_fast_vt", "ph_fast_formILi116ELb1ELb1E", "ph_fast_formILi116ELb1ELb0E", "ph_fast_formILi116ELb0ELb0E", "ph_fast_secondILi116EE", "ph_fast_second_stripILi116E", "ph_fast_chain",
-                "metric_traj_mfma_kernel"]:
+    for pat in ["ph_fast_vt", "ph_fast_formILi116ELb1ELb1E", "ph_fast_formILi116ELb1ELb0E", "ph_fast_formILi116ELb0ELb0E", "ph_fast_secondILi116EE", "ph_fast_second_stripILi116E", "ph_fast_chainE",
+                "ph_fast_form_r", "ph_fast_second_strip_r", "ph_fast_chain_r", "metric_traj_mfma_kernel"]:      # (_r: the packed-argument entries of the resident evaluations)
         name, lines = isa_of.kernel_lines(obj, pat)
         assert not any(i.startswith("scratch_") for _, i in lines), name
     # the bfloat16 instance really is one: three v_mfma_f32_16x16x32_bf16 per tile and 32 indices in the four macro-tile shapes (12 + 6 + 6 + 3 static instructions), none of the fp32 form
