@@ -1773,6 +1773,7 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
   if (tid < DP) {
     const int i = opaque_tid();
     const bool in = i < D;
+    const float l0 = in ? a.lam0[i] : 0.f;                           // (requested first: the read's latency runs under the jitter's Philox rounds)
     {
       const float ej = (in && a.has_jitter) ? (float)a.jitter * uniform_elem<float>(a.seed, chain, a.draw, PURPOSE_JITTER, a.sub, i) : 0.f;
       lds0[oJit + i] = (wb && bx3 && LD == kLdCfg3) ? sqrtf(ej) : ej;      // (the bfloat16 formation scales BOTH operands: sqrt(e))
@@ -1784,7 +1785,7 @@ __device__ __forceinline__ bool metric_fast_solve(const MetricArgsT<float>& a, i
       lds0[oY + 2 * i] = in ? (sdraw ? normal_elem<float>(a.seed, chain, a.draw, 0, i) : a.m[b * D + i]) : 0.f;
       lds0[oY + 2 * i + 1] = (in && a.X) ? a.X[b * D + i] - a.mu[i] : 0.f;
     }
-    lds0[oLt + i] = in ? a.lam0[i] : 0.f;                            // lam0 (the soft-abs map overwrites it element by element at the end)
+    lds0[oLt + i] = l0;                                              // lam0 (the soft-abs map overwrites it element by element at the end)
     lds0[oLam + i] = 0.f;
   }
   if (vres < 0) ph_stage(a.V0, bx, D, DP, LD);
