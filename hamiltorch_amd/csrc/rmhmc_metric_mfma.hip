@@ -514,12 +514,30 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return max16_dpp(red[threadIdx.x & 15]);
 }
 
-// the same with ONE barrier, for call sites whose previous use of `red` is already fenced by a barrier every wave has passed
+// Maxima of NON-NEGATIVE values (|x|, or 0) as unsigned maxima of their bit patterns: the DPP operand folds into v_max_u32 - one instruction per
+// butterfly step where fmaxf takes three (a v_mov_dpp and a canonicalising v_max of each operand); a NaN orders above every number and survives.
+template <int CTRL> __device__ __forceinline__ unsigned dpp_u(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ unsigned max16_u(unsigned v) {
+  v = max(v, dpp_u<0xB1>(v)); v = max(v, dpp_u<0x4E>(v)); v = max(v, dpp_u<0x141>(v)); v = max(v, dpp_u<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ float wave_max_nn(float x) {
+  const unsigned v = max16_u(__float_as_uint(x));
+  return __uint_as_float(max(max((unsigned)__builtin_amdgcn_readlane((int)v, 0), (unsigned)__builtin_amdgcn_readlane((int)v, 16)),
+                             max((unsigned)__builtin_amdgcn_readlane((int)v, 32), (unsigned)__builtin_amdgcn_readlane((int)v, 48))));
+}
+// max |v_i| over a vector of n <= 128 LDS floats whose padding entries are zero (no predicate: the index is clamped)
+__device__ __forceinline__ float wave_max_abs(const float* v, int n) {
+  const int lane = threadIdx.x & 63;
+  const unsigned a = __float_as_uint(v[min(lane, n - 1)]) & 0x7fffffffu, b = __float_as_uint(v[min(lane + 64, n - 1)]) & 0x7fffffffu;
+  return wave_max_nn(__uint_as_float(max(a, b)));
+}
+// a block maximum (non-negative values) with ONE barrier, for call sites whose previous use of `red` is already fenced by a barrier every wave has passed
 __device__ __forceinline__ float block_max1(float v, float* red) {
-  v = wave_max_dpp(v);
+  v = wave_max_nn(v);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return max16_dpp(red[threadIdx.x & 15]);
+  return __uint_as_float(max16_u(__float_as_uint(red[threadIdx.x & 15])));
 }
 
 // out[row] = sum_k M(row, k) v[k] with 8 lanes per row (rows 0 .. 127 of the workgroup's 1024 threads); M(row, k) =
@@ -1224,10 +1242,7 @@ __device__ __forceinline__ float fast_form_body(int offV, int offF, int offE, in
   HTA_WVSTAMP(6);
   __syncthreads();
   HTA_WVSTAMP(7);
-  float sc = 0.f;
-  if (lane < D) sc = fabsf(vlam[lane]);
-  if (lane + 64 < D) sc = fmaxf(sc, fabsf(vlam[lane + 64]));
-  sc = wave_max_dpp(sc);
+  const float sc = wave_max_abs(vlam, 16 * nt);                     // (entries D .. DP - 1 of lam are zero)
   const float tiny = 8.f * Eps<float>::v * sc;
   unsigned ebits = 0u;                                             // max |E1_ij| as a bit pattern: inf and NaN order above every finite value
   if (active) {
@@ -1357,8 +1372,10 @@ __device__ HTA_PH_ATTR float ph_fast_second(int offF, int offE, int oVec, int of
         if (q < 4 * nt) {
           const f4 v = *reinterpret_cast<const f4*>(E + row * LD + 4 * q);
           const f4 mq = *reinterpret_cast<const f4*>(vm + 4 * q);
-          c0 = fmaf(v[0], v[0], c0); c1 = fmaf(v[1], v[1], c1); c0 = fmaf(v[2], v[2], c0); c1 = fmaf(v[3], v[3], c1);
-          u0 = fmaf(v[0], mq[0], u0); u1 = fmaf(v[1], mq[1], u1); u0 = fmaf(v[2], mq[2], u0); u1 = fmaf(v[3], mq[3], u1);
+          // (packed: the same sums in the same order, half the instructions)
+          const f2v v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
+          f2v cc = pk_fma(v01, v01, f2v{c0, c1}); cc = pk_fma(v23, v23, cc); c0 = cc[0]; c1 = cc[1];
+          f2v uu = pk_fma(v01, f2v{mq[0], mq[1]}, f2v{u0, u1}); uu = pk_fma(v23, f2v{mq[2], mq[3]}, uu); u0 = uu[0]; u1 = uu[1];
         }
       }
     }
@@ -1402,10 +1419,7 @@ __device__ HTA_PH_ATTR float ph_fast_second(int offF, int offE, int oVec, int of
   HTA_WVSTAMP(12);
   __syncthreads();
   HTA_WVSTAMP(13);
-  float sc = 0.f;
-  if (lane < D) sc = fabsf(vlam[lane]);
-  if (lane + 64 < D) sc = fmaxf(sc, fabsf(vlam[lane + 64]));
-  sc = wave_max_dpp(sc);
+  const float sc = wave_max_abs(vlam, 16 * nt);                     // (entries D .. DP - 1 of lam are zero)
   const float tiny = 8.f * Eps<float>::v * sc * kSecondE;
   unsigned ebits = 0u;                                             // max |E2_ij| as a bit pattern: inf and NaN order above every finite value
   f4 pacc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};   // y0^T E2 over this wave's rows, per column tile
@@ -1519,8 +1533,10 @@ __device__ __forceinline__ float fast_second_strip_body(int offF, int offE, int 
         if (q < 4 * nt) {
           const f4 v = *reinterpret_cast<const f4*>(E + row * LD + 4 * q);
           const f4 mq = *reinterpret_cast<const f4*>(vm + 4 * q);
-          c0 = fmaf(v[0], v[0], c0); c1 = fmaf(v[1], v[1], c1); c0 = fmaf(v[2], v[2], c0); c1 = fmaf(v[3], v[3], c1);
-          u0 = fmaf(v[0], mq[0], u0); u1 = fmaf(v[1], mq[1], u1); u0 = fmaf(v[2], mq[2], u0); u1 = fmaf(v[3], mq[3], u1);
+          // (packed: the same sums in the same order, half the instructions)
+          const f2v v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
+          f2v cc = pk_fma(v01, v01, f2v{c0, c1}); cc = pk_fma(v23, v23, cc); c0 = cc[0]; c1 = cc[1];
+          f2v uu = pk_fma(v01, f2v{mq[0], mq[1]}, f2v{u0, u1}); uu = pk_fma(v23, f2v{mq[2], mq[3]}, uu); u0 = uu[0]; u1 = uu[1];
         }
       }
     }
@@ -1553,10 +1569,7 @@ __device__ __forceinline__ float fast_second_strip_body(int offF, int offE, int 
   HTA_WVSTAMP(12);
   __syncthreads();
   HTA_WVSTAMP(13);
-  float sc = 0.f;
-  if (lane < D) sc = fabsf(vlam[lane]);
-  if (lane + 64 < D) sc = fmaxf(sc, fabsf(vlam[lane + 64]));
-  sc = wave_max_dpp(sc);
+  const float sc = wave_max_abs(vlam, 16 * nt);                     // (entries D .. DP - 1 of lam are zero)
   const float tiny = 8.f * Eps<float>::v * sc * kSecondE;
   unsigned ebits = 0u;
   {
