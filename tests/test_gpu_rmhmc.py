@@ -449,7 +449,8 @@ def test_trajectory_kernel_equals_the_launch_sequence(ht, D, jitter, metric, alp
 
 
 @pytest.mark.parametrize("D,jitter,alpha,C,L", [(100, 1e-3, 1e6, 300, 3), (100, 1e-3, 1.3, 9, 3), (100, 3e-3, 0.7, 40, 2), (37, 5e-2, 1e6, 17, 3),
-                                                (20, None, 2.0, 5, 3), (112, 1e-3, 1e6, 4, 3), (3, 1e-3, 1e6, 7, 4)])
+                                                (20, None, 2.0, 5, 3), (112, 1e-3, 1e6, 4, 3), (3, 1e-3, 1e6, 7, 4),
+                                                (97, 1e-3, 1e6, 5, 3), (105, 2e-3, 1.3, 6, 2)])      # (97, 105: ragged last tile on the packed-argument entries of 7 tiles)
 def test_resident_trajectory_state_equals_the_callers_coordinates(ht, D, jitter, alpha, C, L):
     """Round 6 ("metric_resident"): the trajectory kernel takes the chain's state into the eigenbasis once - theta' = V0^T (theta - mu),
     p' = V0^T p - keeps it in LDS for the trajectory (no V0 product, no global traffic in a solve evaluation; the binding rotation is
@@ -965,7 +966,8 @@ def test_second_pass_in_closed_form_equals_the_three_product_pass(ht, D, alpha, 
 
 
 @pytest.mark.parametrize("D,kind,alpha,jitter", [(100, "spd", 1e6, 1e-3), (100, "spd", 1.3, 1e-3), (100, "spd", 1e6, None), (64, "indef", 2.0, 1e-2), (37, "spd", 1e6, 5e-2),
-                                                 (48, "degenerate", 1e6, 1e-3), (3, "spd", 1e6, 1e-3), (112, "spd", 1e6, 1e-3)])
+                                                 (48, "degenerate", 1e6, 1e-3), (3, "spd", 1e6, 1e-3), (112, "spd", 1e6, 1e-3), (97, "spd", 1e6, 1e-3),
+                                                 (105, "spd", 1.3, 2e-3)])
 def test_symmetric_square_root_draw_vs_oracle(ht, D, kind, alpha, jitter):
     """Round 6 ("metric_sqrtdraw"): the momentum draw of a soft-abs evaluation on a shared basis is p = G^(1/2) z with the symmetric square
     root Q diag(sqrt lam~) Q^T - a SOLVE-shaped evaluation (formation, refinement, five matrix-vector products) instead of assembling G and
@@ -1014,7 +1016,8 @@ def test_symmetric_square_root_draw_vs_oracle(ht, D, kind, alpha, jitter):
 
 
 @pytest.mark.parametrize("D,alpha,jitter", [(100, 1e6, 1e-3), (100, 1.3, 1e-3), (100, 1e6, None), (64, 2.0, 5e-4), (37, 1e6, 1e-3), (112, 1e6, 1e-3), (3, 1e6, 1e-3),
-                                            (17, 1e6, 1e-3), (70, 1e6, 1e-3), (90, 2.0, 1e-3)])      # (every tile count 1 ... 7: 2, 5 and 6 tiles here)
+                                            (17, 1e6, 1e-3), (70, 1e6, 1e-3), (90, 2.0, 1e-3),      # (every tile count 1 ... 7: 2, 5 and 6 tiles here)
+                                            (97, 1e6, 1e-3), (105, 1.3, 2e-3)])                     # (7 tiles with a ragged last tile: strips, planes)
 def test_fast_solve_with_bfloat16_products_equals_exact_products(ht, D, alpha, jitter):
     """Round 6 ("metric_bx3"): the solve evaluations of a Gaussian target on the shared basis run a reorganised sequence (V0 resident,
     the element-wise passes in the products' epilogues, log p and P d from the eigenbasis) whose second-pass product F E1 (1), and
