@@ -159,7 +159,7 @@ class Cfg3:
         if self.jacobi:
             return ("metric_traj_mfma_kernel (one launch per trajectory: a chain's workgroup runs its 4 L + 3 metric evaluations - "
                     "eigenvector refinement: formation and second-order product on 3 x v_mfma_f32_16x16x32_bf16 of split operands, "
-                    "state resident in LDS in eigen-coordinates - back to back) + mh_select_kernel")
+                    "state resident in LDS in eigen-coordinates - back to back, then its Metropolis selection)")
         if self.C <= 256:
             return ("rmhmc_uvc_kernel (one chain per workgroup: state set and copy as columns of v_mfma_f32_4x4x1_16b, one value per "
                     "lane, three product phases per step)")

@@ -38,7 +38,7 @@ int g_fill_blocks = 4096;        // grid cap of the pre-draw pass (256-thread bl
 int g_quad_max_chains = 65536;   // up to here a chain takes a DPP quad (one eigen-coordinate per lane), beyond a lane
 int g_quad_variant = 7;          // instance of the quad kernel (hmc_gaussian.hip: VAR); 0 = the round-1 instance, 3 = uniform-base addressing + no NaN guard, 7 = + fused row / butterfly block
 int g_rmhmc_fused = 1;           // 0 = per-evaluation Jacobi path, 3 = fused with two chains per workgroup (parity tests)
-extern int g_metric_mfma, g_metric_general, g_metric_traj, g_metric_second, g_metric_bx3, g_metric_resident, g_metric_sqrtdraw, g_rmhmc_wide, g_rmhmc_uv_co, g_rmhmc_uv_acc, g_rmhmc_uv_g, g_rmhmc_uvc, g_quad_fused, g_quad_producers, g_quad_chunks, g_quad_starve;         // rmhmc_metric_mfma.hip, rmhmc_fused.hip
+extern int g_metric_mfma, g_metric_general, g_metric_traj, g_metric_second, g_metric_bx3, g_metric_resident, g_metric_select, g_metric_sqrtdraw, g_rmhmc_wide, g_rmhmc_uv_co, g_rmhmc_uv_acc, g_rmhmc_uv_g, g_rmhmc_uvc, g_quad_fused, g_quad_producers, g_quad_chunks, g_quad_starve;         // rmhmc_metric_mfma.hip, rmhmc_fused.hip
 int g_mlp_valu = 0;               // 1 = keep the Bayesian-MLP sampler on the VALU kernel (parity tests of both)
 int g_mlp3_route = 1;             // csrc/mlp3_mfma.hip (two wide hidden layers on the matrix cores); 0 = such models stay on the callback path
 
@@ -103,7 +103,7 @@ const TuneKey kTune[] = {
     {"rmhmc_pair", &hta::g_rmhmc_pair, 1}, {"rmhmc_wide", &hta::g_rmhmc_wide, 1}, {"rmhmc_overlap", &hta::g_rmhmc_overlap, 0},
     {"rmhmc_momsplit", &hta::g_rmhmc_momsplit, 1},
     {"rmhmc_batch", &hta::g_rmhmc_batch, 1}, {"quad_max_chains", &hta::g_quad_max_chains, 65536}, {"fill_blocks", &hta::g_fill_blocks, 4096},
-    {"mlp_valu", &hta::g_mlp_valu, 0}, {"metric_mfma", &hta::g_metric_mfma, 1}, {"metric_general", &hta::g_metric_general, 1}, {"metric_traj", &hta::g_metric_traj, 1}, {"metric_second", &hta::g_metric_second, 1}, {"metric_bx3", &hta::g_metric_bx3, 2}, {"metric_resident", &hta::g_metric_resident, 1}, {"metric_sqrtdraw", &hta::g_metric_sqrtdraw, 1}, {"rmhmc_fused", &hta::g_rmhmc_fused, 1},
+    {"mlp_valu", &hta::g_mlp_valu, 0}, {"metric_mfma", &hta::g_metric_mfma, 1}, {"metric_general", &hta::g_metric_general, 1}, {"metric_traj", &hta::g_metric_traj, 1}, {"metric_second", &hta::g_metric_second, 1}, {"metric_bx3", &hta::g_metric_bx3, 2}, {"metric_resident", &hta::g_metric_resident, 1}, {"metric_select", &hta::g_metric_select, 1}, {"metric_sqrtdraw", &hta::g_metric_sqrtdraw, 1}, {"rmhmc_fused", &hta::g_rmhmc_fused, 1},
     {"mlp3_route", &hta::g_mlp3_route, 1}, {"quad_variant", &hta::g_quad_variant, 7}, {"rmhmc_lean", &hta::g_rmhmc_lean, 1},
     {"rmhmc_uv_co", &hta::g_rmhmc_uv_co, 1}, {"rmhmc_uv_acc", &hta::g_rmhmc_uv_acc, 2}, {"rmhmc_uv_g", &hta::g_rmhmc_uv_g, 0}, {"rmhmc_uvc", &hta::g_rmhmc_uvc, 1}, {"quad_fused", &hta::g_quad_fused, 1}, {"quad_producers", &hta::g_quad_producers, 64}, {"quad_chunks", &hta::g_quad_chunks, 8}, {"quad_starve", &hta::g_quad_starve, 0},
 };

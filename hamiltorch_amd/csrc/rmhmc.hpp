@@ -38,9 +38,14 @@ template <typename T> __device__ __forceinline__ void phi_c_elem(T& a, T& b, T& 
 }
 
 // rmhmc_metric_mfma.hip: one launch per trajectory of the eigendecomposition route (fp32, D <= 112)
-struct MetricTrajArgs { float* cur; float* th; float* pm; float* thc; float* pmc; float* H0; float* H1; float* lp1; int L; double eh; float c, s; };
+struct MetricTrajArgs {
+  float* cur; float* th; float* pm; float* thc; float* pmc; float* H0; float* H1; float* lp1; int L; double eh; float c, s;
+  // the Metropolis selection of the trajectory inside the launch (round 6; `select` = 0: the caller launches mh_select): mh_select_kernel's arguments
+  const float* init; float* row; int32_t* rej; uint8_t* acc; int32_t n, burn, select, pad_;
+};
 extern int g_metric_traj;                                   // tuning key "metric_traj" (default 1)
 extern int g_metric_resident;                               // tuning key "metric_resident" (default 1)
+extern int g_metric_select;                                 // tuning key "metric_select" (default 1): the trajectory kernel ends with the chain's Metropolis selection
 bool metric_traj_mfma_eligible(const MetricArgsT<float>& a);
 int metric_traj_mfma(const MetricArgsT<float>& a, const MetricTrajArgs& t, hipStream_t s);
 

@@ -267,13 +267,17 @@ int rmhmc_sample(T* cur, const T* theta_init, const T* P, const T* mu, double lo
   for (int t = 0; t < n_traj; ++t) {
     const int n = traj_offset + t;
     int rc;
+    bool selected = false;
     if constexpr (sizeof(T) == 4) {
       if (traj_kernel) {       // one launch: draw, H_old, L steps, H_new (rmhmc_metric_mfma.hip: metric_traj_mfma_kernel)
         const MetricArgsT<T> a = base_args(m, (uint32_t)n, 0);
         const float ang = (float)(2.0 * omega * eps);        // S:435-436
+        float* rowf = (samples && n > burn) ? (float*)samples + (int64_t)(n - burn) * total : nullptr;
         const MetricTrajArgs ta{(float*)cur, (float*)th, (float*)pm, (float*)thc, (float*)pmc, (float*)H0, (float*)H1, (float*)lp1, L, 0.5 * eps,
-                                cosf(ang), sinf(ang)};
+                                cosf(ang), sinf(ang), (const float*)theta_init, rowf, reject_count, accept_out ? accept_out + (int64_t)t * C : nullptr,
+                                n, burn, g_metric_select ? 1 : 0, 0};
         if ((rc = metric_traj_mfma(reinterpret_cast<const MetricArgsT<float>&>(a), ta, s))) return rc;
+        selected = g_metric_select != 0;                   // (the kernel ended with the chain's Metropolis selection)
       }
     }
     if (!traj_kernel) {
@@ -298,8 +302,8 @@ int rmhmc_sample(T* cur, const T* theta_init, const T* P, const T* mu, double lo
     }
     }
     T* row = (samples && n > burn) ? samples + (int64_t)(n - burn) * total : nullptr;
-    if ((rc = mh_select<T>(cur, th, theta_init, H0, H1, lp1, row, reject_count,
-                           accept_out ? accept_out + (int64_t)t * C : nullptr, C, D, n, burn, seed, chain_offset, s)))
+    if (!selected && (rc = mh_select<T>(cur, th, theta_init, H0, H1, lp1, row, reject_count,
+                                        accept_out ? accept_out + (int64_t)t * C : nullptr, C, D, n, burn, seed, chain_offset, s)))
       return rc;
     if (H_old_out) (void)hipMemcpyAsync(H_old_out + (int64_t)t * C, H0, C * sizeof(T), hipMemcpyDeviceToDevice, s);
     if (H_new_out) (void)hipMemcpyAsync(H_new_out + (int64_t)t * C, H1, C * sizeof(T), hipMemcpyDeviceToDevice, s);

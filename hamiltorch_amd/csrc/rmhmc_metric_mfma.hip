@@ -2349,6 +2349,27 @@ __device__ __attribute__((noinline)) int traj_general_eval(kernarg_ptr ka, int D
   return vres;
 }
 
+// The chain's Metropolis selection at the end of its trajectory (mh_select_kernel's rule, uniform and writes - hmc_pieces.hip - by the chain's own
+// workgroup: the proposal t.th and the three scalars were written by this workgroup, visible after the barrier)
+__device__ __forceinline__ void traj_select(const MetricArgsT<float>& a, const MetricTrajArgs& t, int64_t b) {
+  __syncthreads();
+  const int D = a.D, j = opaque_tid();
+  const uint64_t chain = a.chain_offset + (uint64_t)b;
+  const float u = u23<float>(philox_block(a.seed, chain, (uint32_t)t.n, PURPOSE_MH, 0, 0).x);
+  const bool acc = mh_accept<float>(t.H0[b], t.H1[b], t.lp1[b], u);
+  const bool reset = (!acc) && (t.n == t.burn + 1);                  // SURVEY Q2 (samplers.py:1018)
+  const int64_t e = b * D + j;
+  if (j < D) {
+    const float v = acc ? t.th[e] : (reset ? t.init[e] : t.cur[e]);
+    t.cur[e] = v;
+    if (t.row && t.n > t.burn) t.row[e] = v;
+  }
+  if (j == 0) {
+    if (!acc) t.rej[b] += 1;
+    if (t.acc) t.acc[b] = acc ? 1 : 0;
+  }
+}
+
 __global__ __launch_bounds__(MT) void metric_traj_mfma_kernel(MetricArgsT<float> a, MetricTrajArgs t, int DP, int LD, int second) {
   const int D = a.D;
   const int nops = 4 * t.L + 3;
@@ -2370,6 +2391,7 @@ __global__ __launch_bounds__(MT) void metric_traj_mfma_kernel(MetricArgsT<float>
     int vres = -1;                       // the buffer a solve left the staged V0 in: the next evaluation starts from it
     if (!resident) {
       for (int op = 0; op < nops; ++op) vres = traj_general_eval(ka, DP, LD, b, vres, op, second, tiles, 0);
+      if (t.select) traj_select(a, t, b);
       continue;
     }
     const int64_t e0 = b * D;
@@ -2429,9 +2451,11 @@ __global__ __launch_bounds__(MT) void metric_traj_mfma_kernel(MetricArgsT<float>
     // back: theta = mu + V0 theta' (and the final momentum, as the other form leaves it)
     __syncthreads();
     ph_res_out(vres, sTh, sP, t.th + e0, t.pm + e0, a.mu, D, DP, LD);
+    if (t.select) traj_select(a, t, b);
   }
 }
 
+int g_metric_select = 1;     // tuning key "metric_select": 1 = the trajectory kernel ends with the chain's Metropolis selection (one launch per trajectory), 0 = mh_select is a second launch
 int g_metric_resident = 1;   // tuning key "metric_resident": 1 = the trajectory kernel keeps the chain's state in LDS in eigen-coordinates, 0 = in the caller's (bit-identical to the launch sequence)
 int g_metric_traj = 1;   // tuning key "metric_traj": 1 = a trajectory of the eigendecomposition route is one launch, 0 = one launch per evaluation
 

@@ -499,6 +499,8 @@ int hta_jit_rmhmc_sample(void* module, const HtaCbRmhmcArgs* args, int D, int it
  * with the SYMMETRIC square root Q diag(sqrt lam~) Q^T: a solve-shaped evaluation (no assembly of G, no Cholesky: 30 k cycles instead of
  * 350 k at D = 100).  The same law N(0, G(theta)) as samplers.py:183-184's chol(G) z from the same z, a different map (as "rmhmc_momsplit"
  * on the fused routes); 0 = chol(G) z),
+ * "metric_select" (round 6; 1 default: that trajectory kernel ends with the chain's Metropolis selection - hta_mh_select's rule, uniform and
+ * writes, by the chain's own workgroup: ONE launch per trajectory; 0 = the selection is a second launch; bit-identical either way),
  * "metric_resident" (round 6; 1 default: that trajectory kernel takes the chain's four state vectors into the eigenbasis once after the
  * momentum draw - theta' = V0^T (theta - mu), p' = V0^T p - and keeps them in LDS: a solve evaluation has no V0 product and no global
  * traffic but its scalars, theta = mu + V0 theta' at the end; agreement with the launch sequence to fp32 rounding; 0 = the state in the

@@ -485,6 +485,39 @@ def test_resident_trajectory_state_equals_the_callers_coordinates(ht, D, jitter,
     assert same.mean() >= 0.95, same.mean()
 
 
+@pytest.mark.parametrize("D,jitter,eps,burn,resident", [(100, 1e-3, 0.1, 0, 1), (100, 1e-3, 1.9, 1, 1), (37, 2e-3, 2.0, 2, 1), (100, 1e-3, 2.05, 1, 0), (3, 1e-3, 1.95, 1, 1)])
+def test_selection_inside_the_trajectory_launch_equals_the_separate_launch(ht, D, jitter, eps, burn, resident):
+    """Round 6 ("metric_select"): the trajectory kernel ends with its chain's Metropolis selection (hta_mh_select's rule,
+    uniform and writes - S:1000-1018 with the burn-in reset of SURVEY Q2 - by the chain's own workgroup): one launch per trajectory.
+    Bit-identical to the two-launch form: samples, accept flags, the states after burn-in resets; steps at the integrator's stability limit so that
+    rejections occur (a small step: every proposal accepted)."""
+    from hamiltorch_amd import _abi
+    t, _ = cfg3_target(ht, D, torch.float32, seed=5)
+    C, N, L, seed = 70, 5, 2, 13
+    th0 = (0.3 * O.philox_normals(seed, np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32)
+    kw = dict(num_samples=N, num_steps_per_sample=L, step_size=eps, burn=burn, jitter=jitter, softabs_const=1e6,
+              explicit_binding_const=10.0, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT, metric=ht.Metric.SOFTABS, debug=2,
+              verbose=False, seed=seed)
+    outs, routes = [], []
+    _abi.set_tuning("rmhmc_fused", 0)
+    _abi.set_tuning("metric_resident", resident)
+    try:
+        for sel in (1, 0):
+            _abi.set_tuning("metric_select", sel)
+            out, acc = ht.sample(t, tt(th0, torch.float32), **kw)
+            routes.append(_abi.last_route())
+            outs.append((np.stack([x.cpu().numpy() for x in out]), acc.cpu().numpy()))
+    finally:
+        _abi.set_tuning("metric_select", 1)
+        _abi.set_tuning("metric_resident", 1)
+        _abi.set_tuning("rmhmc_fused", 1)
+    assert "metric_traj_mfma_kernel" in routes[0] and "metric_traj_mfma_kernel" in routes[1], routes
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    rate = outs[0][1].mean()
+    assert (rate == 1.0) if eps < 0.5 else (rate < 1.0), rate       # steps at the integrator's stability limit: rejections (and the burn-in reset) happen
+
+
 @pytest.mark.parametrize("D,jitter", [(100, 1e-3), (20, None), (37, 2e-3)])
 def test_fused_pair_kernel_equals_single_chain_kernel(ht, D, jitter):
     """The fused kernel can carry two chains per workgroup (tuning value 3; an odd chain count leaves the last pair half
