@@ -209,6 +209,37 @@ def test_cfg3_bench_instances_vs_oracle_L10(ht, C, N, nsel, route):
     assert np.abs(got[-1] - got[0]).mean() > 1e-2           # the chains moved
 
 
+def test_cfg3_eigendecomposition_route_bench_instance_vs_oracle_L10(ht):
+    """The instance bench.py times as cfg3-eig - BASELINE config 3 (256 chains, D = 100, L = 10, jitter 1e-3) WITH an eigendecomposition per
+    metric evaluation ("rmhmc_fused" = 0: metric_traj_mfma_kernel, one launch per trajectory - resident state, bfloat16 split products, the
+    draw p = G^(1/2) z, the Metropolis selection inside the launch) - against the oracle's eigh per evaluation (S:108-122) on the same Philox
+    streams: 24 chains spread over the batch, samples and acceptance."""
+    from hamiltorch_amd import _abi
+    D, C, N, L, eps, omega, alpha, jitter, seed, off = 100, 256, 3, 10, 0.1, 10.0, 1e6, 1e-3, 2026, 7
+    t, o = _cfg3(ht)
+    th0 = (0.1 * O.philox_normals(seed, off + np.arange(C), 0, D, O.PURPOSE_INIT, dtype=np.float64)).astype(np.float32)
+    _abi.set_tuning("rmhmc_fused", 0)
+    try:
+        out, acc = ht.sample(t, tt(th0), num_samples=N, num_steps_per_sample=L, step_size=eps, jitter=jitter, softabs_const=alpha,
+                             explicit_binding_const=omega, sampler=ht.Sampler.RMHMC, integrator=ht.Integrator.EXPLICIT,
+                             metric=ht.Metric.SOFTABS, debug=2, verbose=False, seed=seed, chain_offset=off)
+        route = _abi.last_route()
+        sqrtdraw = _abi.get_tuning("metric_sqrtdraw")
+    finally:
+        _abi.set_tuning("rmhmc_fused", 1)
+    assert route == "metric_traj_mfma_kernel", route
+    got = torch.stack(out).cpu().numpy()
+    assert got.shape == (N, C, D) and np.isfinite(got).all()
+    sel = np.unique(np.r_[0:4, np.linspace(4, C - 5, 16).astype(int), C - 4:C])
+    ref, info = O.sample_rmhmc_explicit(o, th0[sel], N, L, eps, omega, alpha, 0, jitter,
+                                        O.PhiloxDraws(seed, off + sel, np.float32), "softabs", momentum="sqrt" if sqrtdraw else "chol")
+    err = _chain_err(got[:, sel], np.stack(ref))
+    bad = err > 5e-4
+    assert bad.sum() <= 1, "%d of %d chains differ (max %.3g)" % (bad.sum(), len(sel), err.max())
+    np.testing.assert_allclose(acc.cpu().numpy()[sel][~bad], info["acc_rate"][~bad], atol=1e-12)
+    assert np.abs(got[-1] - got[0]).mean() > 1e-2
+
+
 def test_cfg3_reference_fixture_through_c_abi(ht, golden):
     """tests/golden/cfg3.npz (the unmodified reference at D = 100, fp32): soft-abs spectrum, diag G, G^-1 p, the Riemannian
     Hamiltonian and every step of its 3-step explicit path through the C ABI (fisher / cholesky_inverse / rm_hamiltonian /
