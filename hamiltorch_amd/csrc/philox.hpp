@@ -22,8 +22,18 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
                                             uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
+#if defined(HTA_PHILOX_MAD64)
+    // One 32 x 32 -> 64 product per multiplier (v_mad_u64_u32) instead of a v_mul_hi_u32 and a v_mul_lo_u32: integer multiplies run at a
+    // quarter of the VALU rate and are most of a Philox round.  Per translation unit (defined ahead of the first include): the 64-bit
+    // register pairs cost the 1-chain fused kernel 18 more spills, so the sources whose kernels have the registers opt in
+    // (rmhmc_uvc.hip: BASELINE config 3 + 1.4 ... 2 %, profiles/r06zd; rmhmc_metric_mfma.hip).  Same bit stream.
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+#else
     const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
     const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+#endif
     const uint32_t n0 = hi1 ^ c1 ^ k0;
     const uint32_t n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;

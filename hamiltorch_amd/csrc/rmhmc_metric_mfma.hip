@@ -1,3 +1,4 @@
+#define HTA_PHILOX_MAD64 1      // philox.hpp: 64-bit products (this file's kernels have the registers for them)
 // Riemannian-metric evaluation on the matrix cores (fp32, D <= 112): the evaluations of a constant-curvature target, which
 // all start from ONE shared eigenbasis.
 //

@@ -1,3 +1,4 @@
+#define HTA_PHILOX_MAD64 1      // philox.hpp: 64-bit products (this file's kernels have the registers for them)
 // Explicit RMHMC for a Gaussian target on the identity-soft-abs path (rmhmc_fused.hip: why that path exists; the integrator is
 // hamiltorch/samplers.py:425-461 inside the sampler loop S:969-1026), ONE chain per four-wave workgroup: the kernel of BASELINE
 // config 3 (256 chains on 256 CUs).  Round 4: the third generation of rmhmc_uv_kernel<1>, built from what the ablation builds of
