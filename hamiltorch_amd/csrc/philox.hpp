@@ -26,7 +26,8 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
     // One 32 x 32 -> 64 product per multiplier (v_mad_u64_u32) instead of a v_mul_hi_u32 and a v_mul_lo_u32: integer multiplies run at a
     // quarter of the VALU rate and are most of a Philox round.  Per translation unit (defined ahead of the first include): the 64-bit
     // register pairs cost the 1-chain fused kernel 18 more spills, so the sources whose kernels have the registers opt in
-    // (rmhmc_uvc.hip: BASELINE config 3 + 1.4 ... 2 %, profiles/r06zd; rmhmc_metric_mfma.hip).  Same bit stream.
+    // (rmhmc_uvc.hip: BASELINE config 3 + 1.3 ... 1.7 %; rmhmc_metric_mfma.hip).  Tried and not kept: mlp_mfma.hip / mlp3_mfma.hip (their kernels
+    // spill: the resource tests' budgets), hmc_gaussian.hip (BASELINE config 2 is bound by its consumer waves: 1.68e11 either way).  Same bit stream.
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
     const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
